@@ -1,0 +1,283 @@
+/*
+ * vlr.h — C ABI of the MI355X-native per-locus Bayesian likelihood engine
+ * (drop-in for the model-evaluation path of `varlociraptor call variants`).
+ *
+ * The reference (Rust, /root/reference = varlociraptor v8.9.3) has no FFI boundary;
+ * the path sits behind the in-process trait boundary
+ *     bio::stats::bayesian::model::Model::compute(events, &Data) -> ModelInstance
+ * invoked once per record at src/calling/variants/calling.rs:760 (inside
+ * Caller::call_record, calling.rs:720-842) and consumed by calling.rs:762-813 and
+ * sample_infos (calling.rs:844-937).  This header is what a Rust `extern "C"` block
+ * in calling.rs would bind instead: one *plan* per
+ * (scenario, contig) replaces configure_model (calling.rs:632-718) and one
+ * *batch run* replaces the per-record call_record loop for many records at once.
+ *
+ * Conventions
+ *   - all functions return 0 (VLR_OK) or a negative vlr_status error code;
+ *     vlr_last_error() gives a thread-local human readable message.
+ *   - numeric invariants the reference enforces with assert!/panic!
+ *     (likelihood.rs:113,150,191,217; modes/generic.rs:228) are surfaced per locus
+ *     in vlr_results.status instead of aborting.
+ *   - no torch / C++ types; plain pointers and sizes only.  Pointers inside
+ *     vlr_batch / vlr_results are DEVICE pointers for vlr_batch_run and HOST
+ *     pointers for vlr_batch_run_host.
+ *   - results are in input order; loci are independent.
+ *   - thread-safe across plans; a plan may be used from one thread at a time.
+ */
+#ifndef VLR_H
+#define VLR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VLR_ABI_VERSION 1
+#define VLR_MAX_SAMPLES 8      /* samples per scenario supported by the device path   */
+#define VLR_N_BIAS      6      /* strand, orientation, position, softclip, homopolymer, alt-locus */
+
+/* ---------------------------------------------------------------- status codes */
+typedef enum {
+    VLR_OK                    = 0,
+    VLR_ERR_INVALID_ARGUMENT  = -1,
+    VLR_ERR_UNSUPPORTED       = -2,  /* scenario feature outside the device path */
+    VLR_ERR_NO_DEVICE         = -3,  /* HIP runtime/device missing: the product path never falls back to CPU */
+    VLR_ERR_HIP               = -4,
+    VLR_ERR_INVALID_PRIOR     = -5,  /* prior.rs:788-825 CheckablePrior::check */
+    VLR_ERR_OUT_OF_MEMORY     = -6
+} vlr_status;
+
+/* per-locus status bits (vlr_results.status) */
+#define VLR_LOCUS_OK            0u
+#define VLR_LOCUS_NAN           (1u << 0)  /* a density/likelihood became NaN (reference: panic)        */
+#define VLR_LOCUS_UNDERFLOW     (1u << 1)  /* a per-observation likelihood left the f64 linear range    */
+#define VLR_LOCUS_TABLE_FULL    (1u << 2)  /* visited-point table of a range chain overflowed           */
+#define VLR_LOCUS_TOO_DEEP      (1u << 3)  /* pileup larger than the plan's LDS budget                  */
+#define VLR_LOCUS_MISSING_DATA  (1u << 4)  /* all pileups empty (calling/variants/mod.rs:423-430)       */
+#define VLR_LOCUS_SINGLETON_ADJ (1u << 5)  /* Hint::AdjustedSingletonEvidence (calling.rs:613-617)      */
+#define VLR_LOCUS_FILTERED_ALN  (1u << 6)  /* Hint::FilteredNonStandardAlignments (calling.rs:618-622)  */
+
+/* ---------------------------------------------------------------- scenario description
+ * Flattened form of grammar::Scenario after normalisation for ONE contig
+ * (grammar/mod.rs:129-279, grammar/vaftree.rs:168-305).  Samples are indexed in
+ * BTreeMap key order (grammar/mod.rs:178-190).                                         */
+
+typedef enum { VLR_SPECTRUM_SET = 0, VLR_SPECTRUM_RANGE = 1 } vlr_spectrum_kind;
+
+/* grammar/formula.rs:1018-1047 VAFSpectrum, 1049-1056 VAFRange */
+typedef struct {
+    int32_t kind;            /* vlr_spectrum_kind */
+    int32_t set_offset;      /* SET: first member in vlr_scenario_desc.vafs (ascending)  */
+    int32_t set_len;         /* SET: number of members                                  */
+    int32_t left_exclusive;  /* RANGE */
+    int32_t right_exclusive; /* RANGE */
+    int32_t _pad;
+    double  start, end;      /* RANGE */
+} vlr_spectrum;
+
+/* utils/comparison.rs:4-12 */
+typedef enum {
+    VLR_CMP_EQUAL = 0, VLR_CMP_GREATER = 1, VLR_CMP_GREATER_EQUAL = 2,
+    VLR_CMP_LESS = 3, VLR_CMP_LESS_EQUAL = 4, VLR_CMP_NOT_EQUAL = 5
+} vlr_cmp;
+
+/* grammar/vaftree.rs:63-81 NodeKind */
+typedef enum {
+    VLR_NODE_SAMPLE = 0, VLR_NODE_LFC = 1, VLR_NODE_VARIANT = 2,
+    VLR_NODE_TRUE = 3, VLR_NODE_FALSE = 4
+} vlr_node_kind;
+
+typedef struct {
+    int32_t kind;          /* vlr_node_kind                                              */
+    int32_t sample;        /* SAMPLE: sample index; LFC: sample_a                        */
+    int32_t sample_b;      /* LFC                                                        */
+    int32_t cmp;           /* LFC: vlr_cmp (utils/log2_fold_change.rs:28-31)             */
+    double  lfc_value;     /* LFC                                                        */
+    vlr_spectrum vafs;     /* SAMPLE                                                     */
+    int32_t positive;      /* VARIANT                                                    */
+    uint8_t refbase;       /* VARIANT: IUPAC code (grammar/formula.rs:20-43)             */
+    uint8_t altbase;
+    uint8_t _pad[2];
+    int32_t child_offset;  /* children = child_index[child_offset .. +n_children]        */
+    int32_t n_children;
+} vlr_node;
+
+/* variants/model/prior.rs:41-46 */
+typedef enum {
+    VLR_INHERIT_NONE = 0, VLR_INHERIT_MENDELIAN = 1, VLR_INHERIT_CLONAL = 2, VLR_INHERIT_SUBCLONAL = 3
+} vlr_inheritance_kind;
+
+typedef struct {
+    int32_t kind;      /* vlr_inheritance_kind */
+    int32_t from0;     /* parent sample index  */
+    int32_t from1;     /* second parent (mendelian) */
+    int32_t somatic;   /* clonal: somatic flag */
+} vlr_inheritance;
+
+/* variants/model/mod.rs:139-160 VariantType, collapsed to what the path distinguishes
+ * (grammar/mod.rs:420-431 VariantTypeFraction::get, calling.rs:517-534 is_snv_or_mnv) */
+typedef enum {
+    VLR_VT_SNV = 0, VLR_VT_MNV = 1, VLR_VT_INDEL = 2 /* INS|DEL|REP */, VLR_VT_SV = 3 /* INV|BND|DUP */,
+    VLR_VT_OTHER = 4 /* METH, REF */, VLR_N_VARIANT_TYPES = 5
+} vlr_variant_type;
+
+typedef struct {
+    int32_t n_samples;
+    /* per sample [n_samples] */
+    const double*  resolution;             /* grammar/mod.rs:445-447 (default 0.01)                    */
+    const int32_t* contaminated_by;        /* -1: SampleModel::Normal; else Contaminated{by} (modes/generic.rs:464-470) */
+    const double*  contamination_fraction; /* purity = 1 - fraction (modes/generic.rs:482-484)         */
+    const int32_t* universe_offset;        /* [n_samples+1] into universe[]; Sample::contig_universe (grammar/mod.rs:503-579) */
+    const vlr_spectrum* universe;
+    /* prior (variants/model/prior.rs:61-80; calling.rs:1072-1087) */
+    const uint8_t* uniform_prior;          /* sample declares `universe`                               */
+    const int32_t* ploidy;                 /* -1 = None                                                */
+    const double*  germline_mutation_rate;            /* NaN = None */
+    const double*  somatic_effective_mutation_rate;   /* NaN = None */
+    const vlr_inheritance* inheritance;
+    double  heterozygosity;                /* species heterozygosity as plain probability; NaN = None  */
+    double  fraction_indel, fraction_mnv, fraction_sv;  /* VariantTypeFraction (defaults 0.0125/0.001/0.01) */
+    int32_t is_absent_only;                /* !--full-prior (calling.rs:1086)                          */
+    /* event universe of the scenario, WITHOUT `absent` and without artifact twins
+     * (both are added by the engine exactly like calling.rs:654-687); events must be given
+     * in ascending name order (BTreeMap order of grammar/mod.rs:137).                                 */
+    int32_t n_events;
+    const char* const* event_names;
+    const int32_t* event_root_offset;      /* [n_events+1] into root_index[]                           */
+    const int32_t* root_index;             /* node ids of the VAFTree roots of each event              */
+    int32_t n_nodes;
+    const vlr_node* nodes;
+    const int32_t* child_index;
+    const double*  vafs;                   /* pool for SET spectra                                     */
+} vlr_scenario_desc;
+
+/* ---------------------------------------------------------------- observations (SoA)
+ * One entry per ReadObservation (variants/evidence/observations/read_observation.rs:219-278)
+ * as decoded from observation-format v15 (calling/variants/preprocessing/mod.rs:818-919).
+ * All log-probabilities are MiniLogProb f16/f32 in the wire format (utils/mod.rs:449-474), so
+ * f32 columns are lossless.  prob_mismapping / prob_single_overlap are derived
+ * (read_observation.rs:283-292).                                                                     */
+
+/* packed per-observation flags */
+#define VLR_F_STRAND_SHIFT   0   /* 2 bits: 0 Forward 1 Reverse 2 Both 3 None (read_observation.rs:51-57)         */
+#define VLR_F_ORIENT_SHIFT   2   /* 2 bits: 0 F1R2 1 F2R1 2 None 3 other/non-standard (bio_types SequenceReadPairOrientation) */
+#define VLR_F_READPOS_MAJOR  (1u << 4)   /* ReadPosition::Major (read_observation.rs:125-129)                     */
+#define VLR_F_SOFTCLIPPED    (1u << 5)
+#define VLR_F_PAIRED         (1u << 6)
+#define VLR_F_MAX_MAPQ       (1u << 7)
+#define VLR_F_ALTLOCUS_SHIFT 8   /* 2 bits: 0 Major 1 Some 2 None (read_observation.rs:213-217)                   */
+#define VLR_F_HP_LEN_VALID   (1u << 10)  /* homopolymer_indel_len is Some                                         */
+#define VLR_F_HP_LEN_SHIFT   16  /* 8 bits: homopolymer_indel_len as int8                                         */
+
+#define VLR_STRAND_FORWARD 0
+#define VLR_STRAND_REVERSE 1
+#define VLR_STRAND_BOTH    2
+#define VLR_STRAND_NONE    3
+#define VLR_ORIENT_F1R2    0
+#define VLR_ORIENT_F2R1    1
+#define VLR_ORIENT_NONE    2
+#define VLR_ORIENT_OTHER   3
+#define VLR_ALTLOCUS_MAJOR 0
+#define VLR_ALTLOCUS_SOME  1
+#define VLR_ALTLOCUS_NONE  2
+
+/* bias-enable mask per locus = WorkItem.check_* (calling.rs:557-567) */
+#define VLR_BIAS_STRAND      (1u << 0)
+#define VLR_BIAS_ORIENTATION (1u << 1)
+#define VLR_BIAS_POSITION    (1u << 2)
+#define VLR_BIAS_SOFTCLIP    (1u << 3)
+#define VLR_BIAS_HOMOPOLYMER (1u << 4)
+#define VLR_BIAS_ALTLOCUS    (1u << 5)
+/* locus flag: Pileup::remove_nonstandard_alignments applies (is_snv_or_mnv && !omit_read_orientation_bias;
+ * calling.rs:590-598, pileup.rs:26-43) */
+#define VLR_LOCUS_REMOVE_NONSTANDARD (1u << 6)
+/* locus flag: record is an SNV (ref/alt single base) so Data.snv is Some (calling.rs:517-524) */
+#define VLR_LOCUS_HAS_SNV    (1u << 7)
+
+typedef struct {
+    int64_t n_loci;
+    int32_t n_samples;
+    int32_t _pad;
+    int64_t n_obs;                    /* total observations = obs_offset[n_loci*n_samples]               */
+    /* pileup p = locus*n_samples + sample covers observations [obs_offset[p], obs_offset[p+1])           */
+    const uint32_t* obs_offset;       /* [n_loci*n_samples + 1]                                           */
+    const float* prob_mapping;        /* ln P(correctly mapped), already MAPQ-adjusted (preprocessing/mod.rs:951) */
+    const float* prob_alt;
+    const float* prob_ref;
+    const float* prob_missed_allele;
+    const float* prob_sample_alt;
+    const float* prob_double_overlap;
+    const float* prob_hit_base;
+    const float* prob_hp_artifact;    /* prob_observable_at_homopolymer_artifact; NaN = None; column may be NULL */
+    const float* prob_hp_variant;     /* prob_observable_at_homopolymer_variant;  NaN = None; column may be NULL */
+    const uint32_t* flags;            /* VLR_F_*                                                          */
+    /* per locus */
+    const uint8_t* locus_flags;       /* VLR_BIAS_* | VLR_LOCUS_REMOVE_NONSTANDARD | VLR_LOCUS_HAS_SNV     */
+    const uint8_t* variant_type;      /* vlr_variant_type (prior's variant_type_fraction)                 */
+    const uint8_t* ref_base;          /* SNV only (modes/generic.rs:18-22)                                */
+    const uint8_t* alt_base;
+} vlr_batch;
+
+/* ---------------------------------------------------------------- results
+ * What calling.rs:762-813 + sample_infos (844-937) extract from the ModelInstance.                     */
+typedef struct {
+    int64_t n_loci;
+    int32_t n_out;          /* = n_events + 2                                                             */
+    int32_t n_samples;
+    /* ln posterior probabilities [n_loci * n_out]: column 0 = `absent`, 1..n_events = scenario events
+     * (clean twins, in the order of vlr_scenario_desc), n_events+1 = `artifact`
+     * (ln-sum over artifact twins; calling.rs:785-799).  PROB_* in the BCF = -10/ln10 * value.           */
+    double*  ln_posterior;
+    double*  ln_marginal;   /* [n_loci] ln marginal of Model::compute (may be NULL)                       */
+    double*  map_vaf;       /* [n_loci * n_samples] FORMAT/AF: MAP allele frequency; 0 if MAP is an artifact (calling.rs:875-887); NaN if no MAP */
+    /* [n_loci * VLR_N_BIAS] bias state of the MAP estimate, identical for all samples of a locus
+     * (modes/generic.rs:248-257): 0 = none, else strand 1 '+',2 '-'; orientation 1 '>',2 '<'; others 1.  */
+    uint8_t* map_bias;
+    int32_t* best_event;    /* [n_loci] index into the engine's event universe: 0 absent, 1+2*e clean e, 2+2*e artifact twin (may be NULL) */
+    uint32_t* status;       /* [n_loci] VLR_LOCUS_* bits                                                   */
+    /* optional AFD (calling.rs:889-928; FORMAT/AFD): for locus l and sample s the entries
+     * afd_vaf/afd_lnprob[afd_offset[l*S+s] .. +afd_count[l*S+s]]; capacity afd_capacity per (locus,sample);
+     * all NULL to skip.                                                                                  */
+    int32_t  afd_capacity;
+    int32_t  _pad;
+    int32_t* afd_count;     /* [n_loci * n_samples]                                                        */
+    float*   afd_vaf;       /* [n_loci * n_samples * afd_capacity]                                         */
+    double*  afd_lnprob;    /* [n_loci * n_samples * afd_capacity]                                         */
+} vlr_results;
+
+/* ---------------------------------------------------------------- entry points */
+typedef struct vlr_plan vlr_plan;
+
+/* ABI version of the loaded library. */
+int  vlr_abi_version(void);
+/* Thread-local message of the last error. */
+const char* vlr_last_error(void);
+
+/* Compile a scenario (one contig) into a device plan: flattened VAFTrees, event universe incl.
+ * `absent` and artifact twins, prior table, contamination wiring.  Replaces
+ * Caller::configure_model (calling.rs:632-718) + GenericModelBuilder::build (modes/generic.rs:93-105). */
+int  vlr_plan_create(const vlr_scenario_desc* scenario, int device, vlr_plan** out);
+void vlr_plan_destroy(vlr_plan* plan);
+/* Number of result columns (n_events + 2) and of engine events (1 + 2*n_events). */
+int  vlr_plan_n_out(const vlr_plan* plan);
+int  vlr_plan_n_samples(const vlr_plan* plan);
+
+/* Evaluate a batch of loci on the plan's device.  All pointers in `in` / `out` are device pointers.
+ * `stream` is a hipStream_t (NULL = default stream); the call is stream-ordered and does not synchronise.
+ * Replaces the per-record Caller::call_record (calling.rs:720-842) for n_loci records.                  */
+int  vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* stream);
+
+/* Same, but `in` / `out` hold host pointers: stages through device buffers owned by the plan,
+ * synchronises before returning.  Still requires the GPU (no CPU fallback).                             */
+int  vlr_batch_run_host(vlr_plan* plan, const vlr_batch* in, vlr_results* out);
+
+/* Duration in milliseconds of the most recent kernel launch sequence of vlr_batch_run on this plan,
+ * measured with HIP events on the launch stream (synchronises on the stop event).  For bench.py.       */
+int  vlr_plan_last_kernel_ms(vlr_plan* plan, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLR_H */

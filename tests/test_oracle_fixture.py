@@ -1,0 +1,70 @@
+"""Pin the CPU oracle against the reference's only numeric known-answer fixture
+(tests/resources/flamegraph_profiling/{normal.vcf -> calls.vcf})."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from varlociraptor_amd import abi, obsfmt
+from varlociraptor_amd.scenario import Sample, Scenario
+
+
+def parse_calls(path):
+    out = []
+    with open(path) as fh:
+        for line in fh:
+            if line.startswith("#"):
+                continue
+            f = line.rstrip("\n").split("\t")
+            info = dict(kv.split("=", 1) for kv in f[7].split(";") if "=" in kv)
+            fmt = dict(zip(f[8].split(":"), f[9].split(":")))
+            afd = [tuple(x.split("=")) for x in fmt["AFD"].split(",")]
+            out.append({
+                "pos": int(f[1]),
+                "PROB_PRESENT": float(info["PROB_PRESENT"]),
+                "PROB_ABSENT": float(info["PROB_ABSENT"]),
+                "PROB_ARTIFACT": float(info["PROB_ARTIFACT"]),
+                "AF": float(fmt["AF"]),
+                "AFD": afd,
+            })
+    return out
+
+
+@pytest.fixture(scope="module")
+def fixture(golden_dir):
+    d = os.path.join(golden_dir, "flamegraph_profiling")
+    batch, sites = obsfmt.read_observation_vcf([os.path.join(d, "normal.vcf")], omit_bias_mask=abi.BIAS_ALL)
+    sc = Scenario({"normal": Sample(resolution=0.1, universe="[0.0,1.0]")}, {"present": "normal:]0.0,1.0]"})
+    return batch, sites, sc, parse_calls(os.path.join(d, "calls.vcf"))
+
+
+def test_decode_shapes(fixture):
+    batch, sites, sc, calls = fixture
+    assert batch.n_loci == 11 and batch.n_samples == 1
+    assert list(batch.depth().ravel()) == [85, 86, 98, 107, 110, 104, 116, 106, 115, 117, 109]
+    assert [s[1] for s in sites] == [c["pos"] for c in calls]
+    # worked example of SURVEY App. A: first PROB_MAPPING element is f32 0xbf25abe5
+    assert batch.columns["prob_mapping"][0] == np.frombuffer(bytes.fromhex("e5ab25bf"), "<f4")[0]
+    assert np.isneginf(batch.columns["prob_double_overlap"][0])
+
+
+def test_oracle_reproduces_reference_calls(fixture, oracle):
+    batch, sites, sc, calls = fixture
+    res = oracle.call(sc, batch, afd_capacity=64)
+    phred = res.phred()
+    names = sc.out_names()
+    assert names == ["absent", "present", "artifact"]
+    for l, c in enumerate(calls):
+        # PHRED f32 values are printed with 6 significant digits in the VCF
+        assert phred[l, 0] == pytest.approx(c["PROB_ABSENT"], rel=2e-6)
+        assert phred[l, 1] == pytest.approx(c["PROB_PRESENT"], abs=1e-6)
+        assert np.isinf(phred[l, 2]) and np.isinf(c["PROB_ARTIFACT"])
+        assert res.map_vaf[l, 0] == pytest.approx(c["AF"])
+        n = res.afd_count[l, 0]
+        got = [("%.3f" % res.afd_vaf[l, 0, i], "%.2f" % (-10.0 / np.log(10.0) * res.afd_lnprob[l, 0, i])) for i in range(n)]
+        # exact visited-point list and densities to the printed precision (allow +-0.01 PHRED rounding)
+        assert [g[0] for g in got] == [e[0] for e in c["AFD"]]
+        for g, e in zip(got, c["AFD"]):
+            assert abs(float(g[1]) - float(e[1])) <= 0.011
+    assert not res.status.any()

@@ -1,0 +1,136 @@
+"""PileupBatch: host-side SoA container for vlr_batch (numpy), plus result buffers.
+
+Layout = include/vlr.h `vlr_batch`: pileup p = locus*S + sample covers observation rows
+[obs_offset[p], obs_offset[p+1]) of every column (the AoS Vec<ReadObservation> per sample of
+variants/evidence/observations/pileup.rs:5-11 turned into columns for coalesced device loads).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import abi
+
+
+class PileupBatch:
+    def __init__(self, n_samples: int, obs_offset: np.ndarray, columns: Dict[str, np.ndarray],
+                 locus: Dict[str, np.ndarray]):
+        self.n_samples = int(n_samples)
+        self.obs_offset = np.ascontiguousarray(obs_offset, dtype=np.uint32)
+        assert (len(self.obs_offset) - 1) % self.n_samples == 0
+        self.n_loci = (len(self.obs_offset) - 1) // self.n_samples
+        self.n_obs = int(self.obs_offset[-1])
+        self.columns = {}
+        for name, dt in abi.OBS_COLUMNS:
+            a = columns.get(name)
+            if a is None:
+                if name in ("prob_hp_artifact", "prob_hp_variant"):
+                    a = np.full(self.n_obs, np.nan, dtype=np.float32)
+                else:
+                    raise KeyError(name)
+            a = np.ascontiguousarray(a, dtype=dt)
+            assert a.shape == (self.n_obs,), (name, a.shape, self.n_obs)
+            self.columns[name] = a
+        self.locus = {}
+        defaults = {"locus_flags": abi.BIAS_ALL, "variant_type": abi.VT_SNV, "ref_base": ord("A"), "alt_base": ord("C")}
+        for name, dt in abi.LOCUS_COLUMNS:
+            a = locus.get(name)
+            if a is None:
+                a = np.full(self.n_loci, defaults[name], dtype=dt)
+            a = np.ascontiguousarray(a, dtype=dt)
+            assert a.shape == (self.n_loci,)
+            self.locus[name] = a
+
+    # ---- views
+    def pileup_slice(self, locus: int, sample: int) -> slice:
+        p = locus * self.n_samples + sample
+        return slice(int(self.obs_offset[p]), int(self.obs_offset[p + 1]))
+
+    def depth(self) -> np.ndarray:
+        return np.diff(self.obs_offset.astype(np.int64)).reshape(self.n_loci, self.n_samples)
+
+    def select(self, loci: Sequence[int]) -> "PileupBatch":
+        """Sub-batch with the given loci (copy)."""
+        loci = np.asarray(loci, dtype=np.int64)
+        S = self.n_samples
+        off = self.obs_offset.astype(np.int64)
+        starts = off[loci * S]
+        ends = off[loci * S + S]
+        idx = np.concatenate([np.arange(s, e) for s, e in zip(starts, ends)]) if len(loci) else np.zeros(0, np.int64)
+        new_off = [0]
+        for l in loci:
+            for s in range(S):
+                new_off.append(new_off[-1] + int(off[l * S + s + 1] - off[l * S + s]))
+        cols = {k: v[idx] for k, v in self.columns.items()}
+        loc = {k: v[loci] for k, v in self.locus.items()}
+        return PileupBatch(S, np.asarray(new_off, np.uint32), cols, loc)
+
+    @staticmethod
+    def concat(batches: List["PileupBatch"]) -> "PileupBatch":
+        S = batches[0].n_samples
+        offs = [np.zeros(1, np.int64)]
+        base = 0
+        for b in batches:
+            offs.append(b.obs_offset[1:].astype(np.int64) + base)
+            base += b.n_obs
+        cols = {k: np.concatenate([b.columns[k] for b in batches]) for k, _ in abi.OBS_COLUMNS}
+        loc = {k: np.concatenate([b.locus[k] for b in batches]) for k, _ in abi.LOCUS_COLUMNS}
+        return PileupBatch(S, np.concatenate(offs).astype(np.uint32), cols, loc)
+
+    # ---- C struct with HOST pointers (for vlr_batch_run_host and the oracle)
+    def as_struct(self) -> abi.Batch:
+        b = abi.Batch()
+        b.n_loci, b.n_samples, b.n_obs = self.n_loci, self.n_samples, self.n_obs
+        b.obs_offset = self.obs_offset.ctypes.data
+        for name, _ in abi.OBS_COLUMNS:
+            setattr(b, name, self.columns[name].ctypes.data)
+        for name, _ in abi.LOCUS_COLUMNS:
+            setattr(b, name, self.locus[name].ctypes.data)
+        return b
+
+    def algorithmic_bytes(self) -> int:
+        """Bytes one pass must read: all observation columns + offsets + per-locus columns."""
+        per_obs = sum(np.dtype(dt).itemsize for _, dt in abi.OBS_COLUMNS)
+        return self.n_obs * per_obs + self.obs_offset.nbytes + sum(v.nbytes for v in self.locus.values())
+
+
+class CallResults:
+    """Host result buffers of include/vlr.h `vlr_results`."""
+
+    def __init__(self, n_loci: int, n_out: int, n_samples: int, afd_capacity: int = 0):
+        self.n_loci, self.n_out, self.n_samples, self.afd_capacity = n_loci, n_out, n_samples, afd_capacity
+        self.ln_posterior = np.full((n_loci, n_out), np.nan)
+        self.ln_marginal = np.full(n_loci, np.nan)
+        self.map_vaf = np.full((n_loci, n_samples), np.nan)
+        self.map_bias = np.zeros((n_loci, abi.N_BIAS), np.uint8)
+        self.best_event = np.full(n_loci, -1, np.int32)
+        self.status = np.zeros(n_loci, np.uint32)
+        if afd_capacity > 0:
+            self.afd_count = np.zeros((n_loci, n_samples), np.int32)
+            self.afd_vaf = np.zeros((n_loci, n_samples, afd_capacity), np.float32)
+            self.afd_lnprob = np.zeros((n_loci, n_samples, afd_capacity), np.float64)
+        else:
+            self.afd_count = self.afd_vaf = self.afd_lnprob = None
+
+    def as_struct(self) -> abi.Results:
+        r = abi.Results()
+        r.n_loci, r.n_out, r.n_samples = self.n_loci, self.n_out, self.n_samples
+        r.ln_posterior = self.ln_posterior.ctypes.data
+        r.ln_marginal = self.ln_marginal.ctypes.data
+        r.map_vaf = self.map_vaf.ctypes.data
+        r.map_bias = self.map_bias.ctypes.data
+        r.best_event = self.best_event.ctypes.data
+        r.status = self.status.ctypes.data
+        r.afd_capacity = self.afd_capacity
+        if self.afd_capacity > 0:
+            r.afd_count = self.afd_count.ctypes.data
+            r.afd_vaf = self.afd_vaf.ctypes.data
+            r.afd_lnprob = self.afd_lnprob.ctypes.data
+        return r
+
+    def phred(self) -> np.ndarray:
+        """PROB_* as written to the BCF: PHREDProb::from(prob).abs() as f32 (calling/variants/mod.rs:463-466)."""
+        with np.errstate(invalid="ignore"):
+            return np.abs(-10.0 / np.log(10.0) * self.ln_posterior).astype(np.float32)

@@ -1,0 +1,515 @@
+"""Host-side scenario model: samples, universes, events -> flattened VAF trees (vlr_scenario_desc).
+
+Mirrors the reference's grammar front-end for the part the hot path consumes:
+  * grammar::Scenario / Sample (src/grammar/mod.rs:129-144, 471-496), sample index = sorted name
+    order (mod.rs:178-190), default resolution 0.01 (mod.rs:445-447);
+  * VAFSpectrum / VAFRange syntax of formula.pest:1-4 (`[0.0,0.5[ | 0.5 | 1.0`, `{0.0,0.5}`);
+  * VAFTree::new from a *normalized* formula (src/grammar/vaftree.rs:168-305) incl.
+    add_missing_samples and the operand ordering of Formula::sort (formula.rs:455-471).
+The formula parser here handles atoms, `&`, `|`, parentheses, `true`/`false`, IUPAC variants and
+l2fc() terms; negation / $expressions / BDD simplification (formula.rs:473-866) belong to the
+"next" row of SURVEY §8(f) and raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import re
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import abi
+
+
+# ----------------------------------------------------------------------------- spectra
+@dataclass(frozen=True)
+class VAFRange:
+    start: float
+    end: float
+    left_exclusive: bool
+    right_exclusive: bool
+
+    def is_complete(self) -> bool:  # formula.rs:1082-1084
+        return self.start == 0.0 and self.end == 1.0 and not self.left_exclusive and not self.right_exclusive
+
+
+@dataclass(frozen=True)
+class VAFSet:
+    vafs: Tuple[float, ...]  # ascending (BTreeSet)
+
+
+Spectrum = Union[VAFRange, VAFSet]
+
+_VAF_RE = r"(?:0\.\d+|1\.0)"  # formula.pest: vaf
+
+
+def parse_vafdef(text: str) -> Spectrum:
+    """Parse one `vafdef` of formula.pest (vaf | vafrange | vafset)."""
+    t = text.strip().replace(" ", "")
+    m = re.fullmatch(r"([\[\]])(%s),(%s)([\[\]])" % (_VAF_RE, _VAF_RE), t)
+    if m:
+        return VAFRange(float(m.group(2)), float(m.group(3)), m.group(1) == "]", m.group(4) == "[")
+    m = re.fullmatch(r"\{(%s(?:,%s)+)\}" % (_VAF_RE, _VAF_RE), t)
+    if m:
+        return VAFSet(tuple(sorted(set(float(v) for v in m.group(1).split(",")))))
+    if re.fullmatch(_VAF_RE, t):
+        return VAFSet((float(t),))
+    raise ValueError("invalid VAF definition: %r" % text)
+
+
+def parse_universe(text: str) -> List[Spectrum]:
+    """formula.pest `universe` rule; VAFUniverse is a BTreeSet of spectra (Sets sort before Ranges,
+    formula.rs:1018-1022), iteration order matters for add_missing_samples child order."""
+    specs = [parse_vafdef(p) for p in text.split("|")]
+    uniq = list(dict.fromkeys(specs))
+
+    def key(s):
+        if isinstance(s, VAFSet):
+            return (0, s.vafs)
+        return (1, (s.start, s.end, s.left_exclusive, s.right_exclusive))
+
+    return sorted(uniq, key=key)
+
+
+# ----------------------------------------------------------------------------- normalized formula AST
+@dataclass
+class Atom:
+    sample: str
+    vafs: Spectrum
+
+
+@dataclass
+class Variant:
+    refbase: str
+    altbase: str
+    positive: bool = True
+
+
+@dataclass
+class Lfc:
+    sample_a: str
+    sample_b: str
+    cmp: int
+    value: float
+
+
+@dataclass
+class Conj:
+    operands: list
+
+
+@dataclass
+class Disj:
+    operands: list
+
+
+@dataclass
+class Const:
+    value: bool
+
+
+_CMP = {"==": abi.CMP_EQUAL, ">": abi.CMP_GREATER, ">=": abi.CMP_GREATER_EQUAL, "<": abi.CMP_LESS,
+        "<=": abi.CMP_LESS_EQUAL, "!=": abi.CMP_NOT_EQUAL}
+
+
+class _Parser:
+    """Recursive-descent parser for the negation-free subset of formula.pest."""
+
+    def __init__(self, text: str):
+        self.s = text.replace(" ", "")
+        self.i = 0
+
+    def peek(self, n=1):
+        return self.s[self.i:self.i + n]
+
+    def parse(self):
+        f = self.expr()
+        if self.i != len(self.s):
+            raise ValueError("trailing input in formula at %d: %r" % (self.i, self.s))
+        return f
+
+    def expr(self):
+        first = self.sub()
+        if self.peek() == "&":
+            ops = [first]
+            while self.peek() == "&":
+                self.i += 1
+                ops.append(self.sub())
+            return Conj(ops)
+        if self.peek() == "|":
+            ops = [first]
+            while self.peek() == "|":
+                self.i += 1
+                ops.append(self.sub())
+            return Disj(ops)
+        return first
+
+    def sub(self):
+        if self.peek() == "(":
+            self.i += 1
+            f = self.expr()
+            if self.peek() != ")":
+                raise ValueError("missing ) in formula")
+            self.i += 1
+            return f
+        if self.peek() in "!$":
+            raise NotImplementedError("negation / $expression need the full grammar front-end (SURVEY §8f #3)")
+        if self.s.startswith("l2fc(", self.i):
+            m = re.match(r"l2fc\(([\w.\-]+),([\w.\-]+)\)(<=|<|>=|>|!=|==)(-?\d+(?:\.\d*)?(?:[eE][+-]?\d+)?)", self.s[self.i:])
+            if not m:
+                raise ValueError("invalid l2fc term")
+            self.i += m.end()
+            return Lfc(m.group(1), m.group(2), _CMP[m.group(3)], float(m.group(4)))
+        if self.s.startswith("true", self.i):
+            self.i += 4
+            return Const(True)
+        if self.s.startswith("false", self.i):
+            self.i += 5
+            return Const(False)
+        m = re.match(r"([ACGTRYSWKMBDHVN])>([ACGTRYSWKMBDHVN])(?![\w:])", self.s[self.i:])
+        if m:
+            self.i += m.end()
+            return Variant(m.group(1), m.group(2), True)
+        m = re.match(r"([\w.\-]+):", self.s[self.i:])
+        if not m:
+            raise ValueError("cannot parse formula at %r" % self.s[self.i:])
+        name = m.group(1)
+        self.i += m.end()
+        m = re.match(r"[\[\]]%s,%s[\[\]]|\{[^}]*\}|%s" % (_VAF_RE, _VAF_RE, _VAF_RE), self.s[self.i:])
+        if not m:
+            raise ValueError("invalid VAF definition at %r" % self.s[self.i:])
+        self.i += m.end()
+        return Atom(name, parse_vafdef(m.group(0)))
+
+
+def parse_formula(text: str):
+    return _Parser(text).parse()
+
+
+# ----------------------------------------------------------------------------- scenario
+@dataclass
+class Contamination:
+    by: str
+    fraction: float
+
+
+@dataclass
+class Inheritance:
+    kind: int  # abi.INHERIT_*
+    parents: Tuple[str, ...] = ()
+    somatic: bool = False
+
+
+@dataclass
+class Sample:
+    resolution: float = 0.01  # grammar/mod.rs:445-447
+    universe: Optional[str] = None
+    contamination: Optional[Contamination] = None
+    ploidy: Optional[int] = None
+    somatic_effective_mutation_rate: Optional[float] = None
+    germline_mutation_rate: Optional[float] = None
+    inheritance: Optional[Inheritance] = None
+
+
+@dataclass
+class Species:
+    heterozygosity: Optional[float] = None
+    germline_mutation_rate: Optional[float] = None
+    somatic_effective_mutation_rate: Optional[float] = None
+    ploidy: Optional[int] = None
+    fraction_indel: float = 0.0125  # grammar/mod.rs:386-396
+    fraction_mnv: float = 0.001
+    fraction_sv: float = 0.01
+
+
+@dataclass
+class _TNode:
+    kind: int
+    sample: int = 0
+    sample_b: int = 0
+    cmp: int = 0
+    lfc_value: float = 0.0
+    vafs: Optional[Spectrum] = None
+    positive: bool = False
+    refbase: str = "N"
+    altbase: str = "N"
+    children: List["_TNode"] = field(default_factory=list)
+
+    def clone(self):
+        return _TNode(self.kind, self.sample, self.sample_b, self.cmp, self.lfc_value, self.vafs, self.positive,
+                      self.refbase, self.altbase, [c.clone() for c in self.children])
+
+    def leafs(self):
+        if not self.children:
+            return [self]
+        out = []
+        for c in self.children:
+            out.extend(c.leafs())
+        return out
+
+
+class Scenario:
+    """grammar::Scenario for one contig.  `events` maps name -> formula string or normalized AST."""
+
+    def __init__(self, samples: Dict[str, Sample], events: Dict[str, object], species: Optional[Species] = None,
+                 full_prior: bool = False):
+        self.samples = dict(sorted(samples.items()))  # BTreeMap order
+        self.sample_names = list(self.samples.keys())
+        self.idx = {n: i for i, n in enumerate(self.sample_names)}
+        if len(self.sample_names) > abi.MAX_SAMPLES:
+            raise ValueError("at most %d samples supported" % abi.MAX_SAMPLES)
+        self.species = species
+        self.full_prior = full_prior
+        self.events = dict(sorted(events.items()))  # BTreeMap order (grammar/mod.rs:137)
+        self.event_names = list(self.events.keys())
+        self._keep = []
+
+    # Sample::contig_ploidy (grammar/mod.rs:581-593)
+    def ploidy(self, name: str) -> Optional[int]:
+        s = self.samples[name]
+        if s.ploidy is not None:
+            return s.ploidy
+        if self.species is not None:
+            return self.species.ploidy
+        return None
+
+    def somatic_rate(self, name):  # grammar/mod.rs:606-616
+        s = self.samples[name]
+        if s.somatic_effective_mutation_rate is not None:
+            return s.somatic_effective_mutation_rate
+        return self.species.somatic_effective_mutation_rate if self.species else None
+
+    def germline_rate(self, name):  # grammar/mod.rs:594-604
+        s = self.samples[name]
+        if s.germline_mutation_rate is not None:
+            return s.germline_mutation_rate
+        return self.species.germline_mutation_rate if self.species else None
+
+    # Sample::contig_universe (grammar/mod.rs:503-579)
+    def universe(self, name: str) -> List[Spectrum]:
+        s = self.samples[name]
+        if s.universe is not None:
+            return parse_universe(s.universe)
+        ploidy = self.ploidy(name)
+        has_somatic = s.somatic_effective_mutation_rate is not None  # NB: sample-level only (mod.rs:535)
+        if ploidy is not None:
+            pts = tuple(sorted(set((n / ploidy if ploidy > 0 else 0.0) for n in range(ploidy + 1))))
+            if not has_somatic:
+                return [VAFSet(pts)]
+            specs: List[Spectrum] = [VAFSet(pts)]
+            for a, b in zip(pts[:-1], pts[1:]):
+                specs.append(VAFRange(a, b, True, True))
+            return specs  # Sets sort before Ranges in the BTreeSet
+        if has_somatic:
+            return [VAFRange(0.0, 1.0, False, False)]
+        raise ValueError("sample needs to define either universe, ploidy or somatic_mutation_rate")
+
+    # ---- VAFTree::new (grammar/vaftree.rs:168-305)
+    def _sorted_operands(self, ops):
+        # Formula::sort (formula.rs:455-471): derive(Ord) => Conjunction < Disjunction < Terminal;
+        # atoms by (sample, vafs); then LFC terms first (stable).
+        def rank(o):
+            if isinstance(o, Conj):
+                return (0, "")
+            if isinstance(o, Disj):
+                return (1, "")
+            if isinstance(o, Atom):
+                return (2, o.sample)
+            if isinstance(o, Variant):
+                return (3, "")
+            if isinstance(o, Lfc):
+                return (4, "")
+            return (5, "")  # False < True (formula.rs:103-124 FormulaTerminal order)
+        s = sorted(ops, key=rank)
+        return sorted(s, key=lambda o: 0 if isinstance(o, Lfc) else 1)
+
+    def _from(self, f) -> List[_TNode]:
+        if isinstance(f, Atom):
+            if f.sample not in self.idx:
+                raise ValueError("invalid sample name %r" % f.sample)
+            return [_TNode(abi.NODE_SAMPLE, sample=self.idx[f.sample], vafs=f.vafs)]
+        if isinstance(f, Disj):
+            out = []
+            for o in self._sorted_operands(f.operands):
+                out.extend(self._from(o))
+            return out
+        if isinstance(f, Conj):
+            ops = self._sorted_operands(f.operands)
+            ops = sorted(ops, key=lambda o: 1 if isinstance(o, Disj) else 0)  # disjunctions to the end (vaftree.rs:199-206)
+            roots = self._from(ops[0])
+            for o in ops[1:]:
+                subtrees = self._from(o)
+                for r in roots:
+                    for leaf in r.leafs():
+                        leaf.children = [t.clone() for t in subtrees]
+            return roots
+        if isinstance(f, Variant):
+            return [_TNode(abi.NODE_VARIANT, positive=f.positive, refbase=f.refbase, altbase=f.altbase)]
+        if isinstance(f, Const):
+            return [_TNode(abi.NODE_TRUE if f.value else abi.NODE_FALSE)]
+        if isinstance(f, Lfc):
+            return [_TNode(abi.NODE_LFC, sample=self.idx[f.sample_a], sample_b=self.idx[f.sample_b], cmp=f.cmp,
+                           lfc_value=f.value)]
+        raise TypeError(f)
+
+    def _add_missing(self, node: _TNode, seen: set):
+        if node.kind == abi.NODE_FALSE:
+            return
+        if node.kind == abi.NODE_SAMPLE:
+            seen.add(node.sample)
+        if not node.children:
+            for name in self.sample_names:
+                i = self.idx[name]
+                if i not in seen:
+                    seen.add(i)
+                    node.children = [_TNode(abi.NODE_SAMPLE, sample=i, vafs=sp) for sp in self.universe(name)]
+                    self._add_missing(node, seen)
+                    break
+        else:
+            if len(node.children) > 1:
+                for ch in node.children[1:]:
+                    self._add_missing(ch, set(seen))
+            self._add_missing(node.children[0], seen)
+
+    def vaftree(self, event: str) -> List[_TNode]:
+        f = self.events[event]
+        if isinstance(f, str):
+            f = parse_formula(f)
+        roots = self._from(f)
+        for r in roots:
+            self._add_missing(r, set())
+        return roots
+
+    # ---- flatten to vlr_scenario_desc
+    def desc(self) -> abi.ScenarioDesc:
+        S = len(self.sample_names)
+        vafs_pool: List[float] = []
+
+        def spec_struct(sp: Spectrum) -> abi.Spectrum:
+            st = abi.Spectrum()
+            if isinstance(sp, VAFSet):
+                st.kind = abi.SPECTRUM_SET
+                st.set_offset = len(vafs_pool)
+                st.set_len = len(sp.vafs)
+                vafs_pool.extend(sp.vafs)
+            else:
+                st.kind = abi.SPECTRUM_RANGE
+                st.start, st.end = sp.start, sp.end
+                st.left_exclusive, st.right_exclusive = int(sp.left_exclusive), int(sp.right_exclusive)
+            return st
+
+        nodes: List[abi.Node] = []
+        child_index: List[int] = []
+        root_index: List[int] = []
+        root_offset = [0]
+
+        def emit(n: _TNode) -> int:
+            my = len(nodes)
+            st = abi.Node()
+            nodes.append(st)
+            st.kind, st.sample, st.sample_b, st.cmp, st.lfc_value = n.kind, n.sample, n.sample_b, n.cmp, n.lfc_value
+            if n.kind == abi.NODE_SAMPLE:
+                st.vafs = spec_struct(n.vafs)
+            st.positive = int(n.positive)
+            st.refbase, st.altbase = ord(n.refbase), ord(n.altbase)
+            ids = [emit(c) for c in n.children]
+            st.child_offset = len(child_index)
+            st.n_children = len(ids)
+            child_index.extend(ids)
+            return my
+
+        for ev in self.event_names:
+            for r in self.vaftree(ev):
+                root_index.append(emit(r))
+            root_offset.append(len(root_index))
+
+        uni_off = [0]
+        uni: List[abi.Spectrum] = []
+        for name in self.sample_names:
+            for sp in self.universe(name):
+                uni.append(spec_struct(sp))
+            uni_off.append(len(uni))
+
+        d = abi.ScenarioDesc()
+        keep = self._keep = []
+
+        def arr(ctype, values):
+            a = (ctype * max(1, len(values)))(*values)
+            keep.append(a)
+            return a
+
+        d.n_samples = S
+        d.resolution = arr(C.c_double, [self.samples[n].resolution for n in self.sample_names])
+        cont_by, cont_fr = [], []
+        for n in self.sample_names:
+            c = self.samples[n].contamination
+            cont_by.append(self.idx[c.by] if c else -1)
+            cont_fr.append(c.fraction if c else 0.0)
+        d.contaminated_by = arr(C.c_int32, cont_by)
+        d.contamination_fraction = arr(C.c_double, cont_fr)
+        d.universe_offset = arr(C.c_int32, uni_off)
+        d.universe = arr(abi.Spectrum, uni)
+        d.uniform_prior = arr(C.c_uint8, [1 if self.samples[n].universe is not None else 0 for n in self.sample_names])
+        d.ploidy = arr(C.c_int32, [(-1 if self.ploidy(n) is None else self.ploidy(n)) for n in self.sample_names])
+        nan = float("nan")
+        d.germline_mutation_rate = arr(C.c_double, [nan if self.germline_rate(n) is None else self.germline_rate(n) for n in self.sample_names])
+        d.somatic_effective_mutation_rate = arr(C.c_double, [nan if self.somatic_rate(n) is None else self.somatic_rate(n) for n in self.sample_names])
+        inh = []
+        for n in self.sample_names:
+            st = abi.Inheritance()
+            i = self.samples[n].inheritance
+            if i is None:
+                st.kind, st.from0, st.from1, st.somatic = abi.INHERIT_NONE, -1, -1, 0
+            else:
+                st.kind = i.kind
+                st.from0 = self.idx[i.parents[0]]
+                st.from1 = self.idx[i.parents[1]] if len(i.parents) > 1 else -1
+                st.somatic = int(i.somatic)
+            inh.append(st)
+        d.inheritance = arr(abi.Inheritance, inh)
+        sp = self.species
+        d.heterozygosity = nan if (sp is None or sp.heterozygosity is None) else sp.heterozygosity
+        d.fraction_indel = sp.fraction_indel if sp else 0.0125
+        d.fraction_mnv = sp.fraction_mnv if sp else 0.001
+        d.fraction_sv = sp.fraction_sv if sp else 0.01
+        d.is_absent_only = int(not self.full_prior)
+        d.n_events = len(self.event_names)
+        d.event_names = arr(C.c_char_p, [e.encode() for e in self.event_names])
+        d.event_root_offset = arr(C.c_int32, root_offset)
+        d.root_index = arr(C.c_int32, root_index)
+        d.n_nodes = len(nodes)
+        d.nodes = arr(abi.Node, nodes)
+        d.child_index = arr(C.c_int32, child_index)
+        d.vafs = arr(C.c_double, vafs_pool)
+        return d
+
+    @property
+    def n_out(self) -> int:
+        return len(self.event_names) + 2
+
+    def out_names(self) -> List[str]:
+        return ["absent"] + self.event_names + ["artifact"]
+
+
+# ----------------------------------------------------------------------------- canned scenarios
+def tumor_normal(purity: float = 0.75) -> Scenario:
+    """The embedded scenario of `call variants tumor-normal` (src/cli.rs:1151-1172)."""
+    samples = {
+        "tumor": Sample(resolution=0.01, universe="[0.0,1.0]", contamination=Contamination("normal", 1.0 - purity)),
+        "normal": Sample(resolution=0.1, universe="[0.0,0.5[ | 0.5 | 1.0"),
+    }
+    events = {
+        "somatic_tumor": "tumor:]0.0,1.0] & normal:0.0",
+        "somatic_normal": "tumor:]0.0,1.0] & normal:]0.0,0.5[",
+        "germline_het": "tumor:]0.0,1.0] & normal:0.5",
+        "germline_hom": "tumor:]0.0,1.0] & normal:1.0",
+    }
+    return Scenario(samples, events)
+
+
+def single_sample(resolution: float = 0.01, name: str = "s", event: str = "present") -> Scenario:
+    """BASELINE config 2 / the flamegraph_profiling fixture shape: one sample, universe [0,1],
+    event `present: s:]0.0,1.0]` (tests/resources/flamegraph_profiling/scenario.yaml)."""
+    return Scenario({name: Sample(resolution=resolution, universe="[0.0,1.0]")}, {event: "%s:]0.0,1.0]" % name})
