@@ -264,6 +264,11 @@ void vlr_plan_destroy(vlr_plan* plan);
 int  vlr_plan_n_out(const vlr_plan* plan);
 int  vlr_plan_n_samples(const vlr_plan* plan);
 
+/* LDS budget knob: maximum pileup depth per sample the kernel reserves coefficient space for
+ * (default 200 = the reference's max_depth default, src/variants/sample.rs:236).  Loci whose kept
+ * observations exceed n_samples * depth are reported with VLR_LOCUS_TOO_DEEP.                           */
+int  vlr_plan_set_max_depth(vlr_plan* plan, int per_sample_depth);
+
 /* Evaluate a batch of loci on the plan's device.  All pointers in `in` / `out` are device pointers.
  * `stream` is a hipStream_t (NULL = default stream); the call is stream-ordered and does not synchronise.
  * Replaces the per-record Caller::call_record (calling.rs:720-842) for n_loci records.                  */
@@ -276,6 +281,10 @@ int  vlr_batch_run_host(vlr_plan* plan, const vlr_batch* in, vlr_results* out);
 /* Duration in milliseconds of the most recent kernel launch sequence of vlr_batch_run on this plan,
  * measured with HIP events on the launch stream (synchronises on the stop event).  For bench.py.       */
 int  vlr_plan_last_kernel_ms(vlr_plan* plan, float* ms);
+
+/* Profiling aid: cumulative {pileup-likelihood evaluations, observation terms} executed by the kernels of this
+ * plan since creation (or the last reset); synchronises the device.                                     */
+int  vlr_plan_work_counters(vlr_plan* plan, unsigned long long* out2, int reset);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,696 @@
+// vlr_host.cpp — host side of the engine above the C ABI (include/vlr.h): plan compiler, prior
+// tabulation, batch launch.  Compiled with hipcc into libvlr.so together with vlr_kernels.hip.
+//
+// Replaces, for the hot path only, Caller::configure_model (reference src/calling/variants/calling.rs:632-718),
+// GenericModelBuilder::build (src/variants/model/modes/generic.rs:93-105) and the per-record
+// Caller::call_record (calling.rs:720-842).  There is NO CPU fallback: without a HIP device every
+// entry point that needs one fails with VLR_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/vlr.h"
+#include "vlr_plan.h"
+
+extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_dev, const vlr::DevBatch* batch, const vlr::DevResults* out,
+                                      int n_univ, int n_samples, int max_obs, int range_depth, void* stream);
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(x)                                                                                  \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess) return fail(VLR_ERR_HIP, "%s failed: %s", #x, hipGetErrorString(e_)); \
+    } while (0)
+
+const double NEG_INF = -std::numeric_limits<double>::infinity();
+
+// ---------------------------------------------------------------------------------------------
+// Prior (reference src/variants/model/prior.rs), host restatement used ONLY to tabulate the prior over
+// per-sample VAF classes (see build_prior_table).  bio LogProb helpers restated from the crate docs.
+double ln_one_minus_exp(double p) { return p < -0.693 ? std::log1p(-std::exp(p)) : std::log(-std::expm1(p)); }
+double ln_sum_exp(const std::vector<double>& v) {
+    if (v.empty()) return NEG_INF;
+    size_t im = 0;
+    for (size_t i = 1; i < v.size(); ++i)
+        if (v[i] > v[im]) im = i;
+    if (v[im] == NEG_INF) return NEG_INF;
+    double s = 0;
+    for (size_t i = 0; i < v.size(); ++i)
+        if (i != im && v[i] != NEG_INF) s += std::exp(v[i] - v[im]);
+    return v[im] + std::log1p(s);
+}
+bool relative_eq(double a, double b) {
+    if (a == b) return true;
+    if (std::isinf(a) || std::isinf(b)) return false;
+    double d = std::fabs(a - b), eps = std::numeric_limits<double>::epsilon();
+    return d <= eps || d <= std::max(std::fabs(a), std::fabs(b)) * eps;
+}
+
+struct HostSpectrum {
+    bool is_set;
+    std::vector<double> set;
+    double start, end;
+    bool lex, rex;
+    bool contains(double v) const {
+        if (is_set) return std::find(set.begin(), set.end(), v) != set.end();
+        bool lo = lex ? start < v : start <= v, hi = rex ? end > v : end >= v;
+        return lo && hi;
+    }
+};
+
+struct HostPrior {
+    int S = 0;
+    std::vector<uint8_t> uniform;
+    std::vector<int> ploidy;
+    std::vector<std::vector<HostSpectrum>> universe;
+    std::vector<double> germline_rate, somatic_rate;
+    std::vector<vlr_inheritance> inh;
+    double het_ln = NAN;
+    double f_indel, f_mnv, f_sv;
+    bool absent_only = true;
+    int vt = VLR_VT_SNV;
+
+    bool all_uniform() const { return std::all_of(uniform.begin(), uniform.end(), [](uint8_t u) { return u != 0; }); }  // prior.rs:111-113
+    double vt_fraction() const {  // grammar/mod.rs:420-431
+        return vt == VLR_VT_INDEL ? f_indel : vt == VLR_VT_MNV ? f_mnv : vt == VLR_VT_SV ? f_sv : 1.0;
+    }
+    bool som_ln(int s, double* o) const {  // prior.rs:250-257
+        if (std::isnan(somatic_rate[s])) return false;
+        *o = std::log(somatic_rate[s] * vt_fraction());
+        return true;
+    }
+    bool het(double* o) const {  // prior.rs:263-270
+        if (std::isnan(het_ln)) return false;
+        *o = std::log(std::exp(het_ln) * vt_fraction());
+        return true;
+    }
+    static double p_somatic(double rate, double v) { return relative_eq(v, 0.0) ? ln_one_minus_exp(rate) : rate; }  // 440-456
+    using V = std::vector<double>;
+    double clonal(int s, int par, const V& ev, const V& g, bool somatic) const {  // 458-512
+        if (!relative_eq(g[s], g[par])) return NEG_INF;
+        double r;
+        bool has = som_ln(s, &r);
+        if (somatic && has) return (ev[par] - g[par] != 0.0) ? 0.0 : p_somatic(r, ev[s] - g[s]);
+        if (somatic) return relative_eq(ev[s] - g[s], ev[par] - g[par]) ? 0.0 : NEG_INF;
+        if (has) return p_somatic(r, ev[s] - g[s]);
+        return 0.0;
+    }
+    double subclonal(int s, int par, const V& ev, const V& g) const {  // 514-552
+        if (!relative_eq(g[s], g[par])) return NEG_INF;
+        double r;
+        if (som_ln(s, &r)) return (ev[par] == 0.0 && g[s] == 0.0) ? p_somatic(r, ev[s]) : 0.0;
+        return relative_eq(ev[s] - g[s], ev[par] - g[par]) ? 0.0 : NEG_INF;
+    }
+    double population(const std::vector<int>& pop, const V& g, double h) const {  // 554-582
+        unsigned m = 0, n = 0;
+        for (int s : pop) { m += (unsigned)std::llround(ploidy[s] * g[s]); n += (unsigned)ploidy[s]; }
+        if (m > 0) return h - std::log((double)m);
+        V v;
+        for (unsigned i = 1; i <= n; ++i) v.push_back(h - std::log((double)i));
+        return ln_one_minus_exp(ln_sum_exp(v));
+    }
+    static double binom(unsigned n, unsigned k) {
+        if (k > n) return 0;
+        double r = 1;
+        for (unsigned i = 1; i <= k; ++i) r = r * (n - k + i) / i;
+        return std::floor(0.5 + r);
+    }
+    static double hyper_ln(unsigned N, unsigned K, unsigned n, unsigned x) {  // 584-598 (statrs Hypergeometric::pmf)
+        unsigned lo = n + K > N ? n + K - N : 0, hi = std::min(K, n);
+        if (x < lo || x > hi) return NEG_INF;
+        return std::log(binom(K, x) * binom(N - K, n - x) / binom(N, n));
+    }
+    bool mendel_counts(unsigned sp0, unsigned sp1, unsigned tp, unsigned sa0, unsigned sa1, unsigned ta, double gr, double* out) const {  // 600-678
+        auto cases = [](unsigned p) {
+            std::vector<unsigned> v;
+            if (p % 2 == 0) v.push_back(p / 2);
+            else { v.push_back(p / 2); v.push_back(p / 2 + 1); }
+            return v;
+        };
+        bool valid = false;
+        V probs;
+        for (unsigned p1 : cases(sp0))
+            for (unsigned p2 : cases(sp1)) {
+                if (p1 + p2 != tp) continue;
+                valid = true;
+                for (unsigned a1 = 0; a1 <= std::min(sa0, p1); ++a1)
+                    for (unsigned a2 = 0; a2 <= std::min(sa1, p2); ++a2) {
+                        if (a1 + a2 > ta) continue;
+                        double pr = hyper_ln(sp0, sa0, p1, a1) + hyper_ln(sp1, sa1, p2, a2);
+                        probs.push_back(pr + std::log(gr) * (double)((int)ta - (int)(a1 + a2)));
+                    }
+            }
+        if (!valid) return false;
+        *out = ln_sum_exp(probs);
+        return true;
+    }
+    bool mendelian(int c, int p0, int p1, const V& ev, const V& g, double* out) const {  // 680-712
+        auto na = [&](int s) { return (unsigned)std::llround(g[s] * ploidy[s]); };
+        double prob;
+        if (!mendel_counts(ploidy[p0], ploidy[p1], ploidy[c], na(p0), na(p1), na(c), germline_rate[c] * vt_fraction(), &prob)) return false;
+        double r;
+        if (som_ln(c, &r)) prob += p_somatic(r, ev[c] - g[c]);
+        *out = prob;
+        return true;
+    }
+    // 298-438; `ok` is cleared when the reference would panic (ploidy mismatch)
+    double calc(const V& ev, V g, bool* ok) const {
+        if ((int)g.size() == S) {
+            double prob = 0, h;
+            if (het(&h)) {
+                std::vector<int> pop;
+                for (int s = 0; s < S; ++s)
+                    if (inh[s].kind == VLR_INHERIT_NONE && ploidy[s] >= 0 && !uniform[s]) pop.push_back(s);
+                prob = population(pop, g, h);
+            }
+            for (int s = 0; s < S; ++s) {
+                if (uniform[s]) continue;
+                double t = 0;
+                switch (inh[s].kind) {
+                    case VLR_INHERIT_MENDELIAN:
+                        if (!mendelian(s, inh[s].from0, inh[s].from1, ev, g, &t)) { *ok = false; return NEG_INF; }
+                        break;
+                    case VLR_INHERIT_CLONAL: t = clonal(s, inh[s].from0, ev, g, inh[s].somatic != 0); break;
+                    case VLR_INHERIT_SUBCLONAL: t = subclonal(s, inh[s].from0, ev, g); break;
+                    default: {
+                        double r;
+                        if (som_ln(s, &r)) t = p_somatic(r, ev[s] - g[s]);
+                    }
+                }
+                prob += t;
+            }
+            return prob;
+        }
+        int s = (int)g.size();
+        auto push = [&](double x) { V g2 = g; g2.push_back(x); return g2; };
+        if (ploidy[s] == 0 && ev[s] != 0.0) return NEG_INF;
+        if (uniform[s]) {
+            for (auto& sp : universe[s])
+                if (sp.contains(ev[s])) return calc(ev, push(0.0), ok);
+            return NEG_INF;
+        }
+        if (!std::isnan(somatic_rate[s])) {
+            V probs;
+            for (int n = 0; n <= ploidy[s]; ++n) probs.push_back(calc(ev, push(ploidy[s] > 0 ? (double)n / ploidy[s] : 0.0), ok));
+            return ln_sum_exp(probs);
+        }
+        if (ploidy[s] >= 0 && !std::isnan(het_ln)) {
+            double n_alt = ploidy[s] * ev[s];
+            if (relative_eq(n_alt, std::round(n_alt))) return calc(ev, push(ev[s]), ok);
+            return NEG_INF;
+        }
+        *ok = false;  // "bug: not enough info for prior but no universe specified"
+        return NEG_INF;
+    }
+    double compute(const V& ev, bool* ok) const {  // 715-762
+        bool absent = std::all_of(ev.begin(), ev.end(), [](double v) { return v == 0.0; });
+        if (absent_only && !all_uniform()) {
+            if (!absent) {
+                double full = calc(ev, {}, ok);
+                if (full == NEG_INF) return full;
+                return ln_one_minus_exp(calc(V(S, 0.0), {}, ok));
+            }
+            return calc(ev, {}, ok);
+        }
+        return calc(ev, {}, ok);
+    }
+};
+
+}  // namespace
+
+struct vlr_plan {
+    int device = 0;
+    vlr::DevPlan host{};       // host copy (device pointers inside)
+    vlr::DevPlan* dev = nullptr;
+    void* blob = nullptr;      // device arrays
+    int max_depth_per_sample = 200;  // reference default max_depth (src/variants/sample.rs:236)
+    int n_events = 0;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+    // staging for vlr_batch_run_host
+    void* stage = nullptr;
+    size_t stage_bytes = 0;
+    unsigned long long* work_dev = nullptr;
+};
+
+namespace {
+
+HostSpectrum host_spectrum(const vlr_spectrum& s, const double* pool) {
+    HostSpectrum h;
+    h.is_set = s.kind == VLR_SPECTRUM_SET;
+    if (h.is_set) h.set.assign(pool + s.set_offset, pool + s.set_offset + s.set_len);
+    h.start = s.start; h.end = s.end; h.lex = s.left_exclusive != 0; h.rex = s.right_exclusive != 0;
+    return h;
+}
+
+// Tabulate Prior::compute over per-sample VAF classes:
+//   uniform sample      : {in universe & 0, in universe & != 0, outside}
+//   ploidy-based sample : {k/ploidy for k = 0..ploidy, any other value}
+int build_prior_table(const vlr_scenario_desc* d, vlr::DevPlan& P, std::vector<double>& table) {
+    const int S = d->n_samples;
+    HostPrior pr;
+    pr.S = S;
+    pr.uniform.assign(d->uniform_prior, d->uniform_prior + S);
+    pr.ploidy.assign(d->ploidy, d->ploidy + S);
+    pr.germline_rate.assign(d->germline_mutation_rate, d->germline_mutation_rate + S);
+    pr.somatic_rate.assign(d->somatic_effective_mutation_rate, d->somatic_effective_mutation_rate + S);
+    pr.inh.assign(d->inheritance, d->inheritance + S);
+    pr.het_ln = std::isnan(d->heterozygosity) ? NAN : std::log(d->heterozygosity);
+    pr.f_indel = d->fraction_indel; pr.f_mnv = d->fraction_mnv; pr.f_sv = d->fraction_sv;
+    pr.absent_only = d->is_absent_only != 0;
+    pr.universe.resize(S);
+    for (int s = 0; s < S; ++s)
+        for (int i = d->universe_offset[s]; i < d->universe_offset[s + 1]; ++i) pr.universe[s].push_back(host_spectrum(d->universe[i], d->vafs));
+
+    // CheckablePrior::check (prior.rs:788-825)
+    for (int s = 0; s < S; ++s) {
+        const vlr_inheritance& in = d->inheritance[s];
+        if (in.kind == VLR_INHERIT_NONE) continue;
+        auto has_ploidy = [&](int x) { return x >= 0 && x < S && d->ploidy[x] >= 0; };
+        if (in.kind == VLR_INHERIT_MENDELIAN && (!has_ploidy(in.from0) || !has_ploidy(in.from1)))
+            return fail(VLR_ERR_INVALID_PRIOR, "inheritance defined but parental samples do not have a ploidy");
+        if (in.kind != VLR_INHERIT_MENDELIAN && !has_ploidy(in.from0))
+            return fail(VLR_ERR_INVALID_PRIOR, "inheritance defined but parental samples do not have a ploidy");
+        if (in.kind == VLR_INHERIT_MENDELIAN && std::isnan(d->germline_mutation_rate[s]))
+            return fail(VLR_ERR_INVALID_PRIOR, "mendelian inheritance but no germline mutation rate defined");
+        if (in.kind == VLR_INHERIT_SUBCLONAL && std::isnan(d->somatic_effective_mutation_rate[s]))
+            return fail(VLR_ERR_INVALID_PRIOR, "subclonal inheritance defined but no somatic mutation");
+        if (!d->uniform_prior[s] && in.kind == VLR_INHERIT_CLONAL && in.somatic && std::isnan(d->somatic_effective_mutation_rate[s]))
+            return fail(VLR_ERR_UNSUPPORTED, "clonal inheritance with inherited somatic VAF but no somatic rate compares continuous VAFs "
+                                             "across samples (prior.rs:489-499): not representable in the tabulated device prior");
+    }
+
+    std::vector<std::vector<double>> reps(S);  // representative VAF per class; NaN = class is impossible (-inf)
+    size_t size = 1;
+    for (int s = 0; s < S; ++s) {
+        if (d->uniform_prior[s]) {
+            P.prior_kind[s] = vlr::PK_UNIFORM;
+            double nonzero = NAN;
+            for (auto& sp : pr.universe[s]) {
+                if (!std::isnan(nonzero)) break;
+                if (sp.is_set) {
+                    for (double v : sp.set)
+                        if (v != 0.0) { nonzero = v; break; }
+                } else {
+                    for (double v : {(sp.start + sp.end) / 2.0, sp.end, sp.start})
+                        if (v != 0.0 && sp.contains(v)) { nonzero = v; break; }
+                }
+            }
+            bool zero_in = false;
+            for (auto& sp : pr.universe[s]) zero_in = zero_in || sp.contains(0.0);
+            reps[s] = {zero_in ? 0.0 : NAN, nonzero, NAN};
+        } else {
+            int pl = d->ploidy[s];
+            bool somatic = !std::isnan(d->somatic_effective_mutation_rate[s]);
+            if (pl < 0) return fail(VLR_ERR_INVALID_PRIOR, "sample %d has neither universe nor ploidy (grammar/mod.rs:569-574)", s);
+            if (!somatic && std::isnan(d->heterozygosity))
+                return fail(VLR_ERR_INVALID_PRIOR, "bug: not enough info for prior but no universe specified (prior.rs:433)");
+            P.prior_kind[s] = somatic ? vlr::PK_SOMATIC : vlr::PK_GERMLINE;
+            for (int k = 0; k <= pl; ++k) reps[s].push_back(pl > 0 ? (double)k / pl : 0.0);
+            reps[s].push_back(pl > 0 ? 0.37 / pl : 0.37);  // "other": between 0 and 1/ploidy, never k/ploidy
+        }
+        P.ploidy[s] = d->ploidy[s];
+        P.n_class[s] = (int)reps[s].size();
+        P.class_stride[s] = (int)size;
+        size *= reps[s].size();
+        if (size > (1u << 20)) return fail(VLR_ERR_UNSUPPORTED, "prior table too large");
+    }
+    P.table_size = (int)size;
+    table.assign((size_t)vlr::kNVariantTypes * size, NEG_INF);
+    for (int vt = 0; vt < vlr::kNVariantTypes; ++vt) {
+        pr.vt = vt;
+        for (size_t idx = 0; idx < size; ++idx) {
+            std::vector<double> ev(S);
+            bool possible = true;
+            size_t rem = idx;
+            for (int s = 0; s < S; ++s) {
+                int cls = (int)(rem % reps[s].size());
+                rem /= reps[s].size();
+                ev[s] = reps[s][cls];
+                if (std::isnan(ev[s])) possible = false;
+            }
+            if (!possible) continue;
+            bool ok = true;
+            double v = pr.compute(ev, &ok);
+            if (!ok) return fail(VLR_ERR_INVALID_PRIOR, "prior cannot be evaluated (ploidies of child and parents do not match, or missing rates)");
+            table[(size_t)vt * size + idx] = v;
+        }
+    }
+    return VLR_OK;
+}
+
+int check_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(VLR_ERR_NO_DEVICE, "no HIP device available (%s); the engine has no CPU fallback", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(VLR_ERR_INVALID_ARGUMENT, "device %d out of range (%d devices)", device, n);
+    return VLR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vlr_abi_version(void) { return VLR_ABI_VERSION; }
+const char* vlr_last_error(void) { return g_err.c_str(); }
+
+int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
+    using namespace vlr;
+    if (!d || !out) return fail(VLR_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    const int S = d->n_samples;
+    if (S < 1 || S > kMaxSamples) return fail(VLR_ERR_INVALID_ARGUMENT, "n_samples %d outside 1..%d", S, kMaxSamples);
+    if (d->n_events < 0 || d->n_events > kMaxNamedEvents) return fail(VLR_ERR_UNSUPPORTED, "n_events %d outside 0..%d", d->n_events, kMaxNamedEvents);
+    for (int s = 0; s < S; ++s) {
+        if (!(d->resolution[s] > 0.0 && d->resolution[s] < 1.0)) return fail(VLR_ERR_INVALID_ARGUMENT, "resolution must be in (0,1) (grammar/mod.rs:477-481)");
+        int by = d->contaminated_by[s];
+        if (by >= S || by == s) return fail(VLR_ERR_INVALID_ARGUMENT, "invalid contamination sample (errors::Error::InvalidContaminationSampleName)");
+        if (by >= 0) {
+            double purity = 1.0 - d->contamination_fraction[s];
+            if (!(purity > 0.0 && purity <= 1.0)) return fail(VLR_ERR_INVALID_ARGUMENT, "purity must be in (0,1] (likelihood.rs:78)");
+        }
+    }
+    DevPlan P{};
+    P.S = S;
+    P.n_named = d->n_events;
+    P.n_univ = 1 + 2 * d->n_events;
+    for (int s = 0; s < kMaxSamples; ++s) { P.by[s] = -1; P.rho[s] = 1.0; P.irho[s] = 0.0; P.resolution[s] = 0.01; }
+    for (int s = 0; s < S; ++s) {
+        P.resolution[s] = d->resolution[s];
+        P.by[s] = d->contaminated_by[s];
+        if (P.by[s] >= 0) { P.rho[s] = 1.0 - d->contamination_fraction[s]; P.irho[s] = 1.0 - P.rho[s]; }
+        P.uni_off[s] = d->universe_offset[s];
+    }
+    P.uni_off[S] = d->universe_offset[S];
+
+    // ---- nodes (+ VAFTree::absent chain, grammar/vaftree.rs:18-40)
+    std::vector<DevNode> nodes(d->n_nodes + S);
+    std::vector<int32_t> child;
+    auto conv_spec = [&](const vlr_spectrum& s) {
+        DevSpectrum o{};
+        o.kind = s.kind; o.set_off = s.set_offset; o.set_len = s.set_len;
+        o.lex = s.left_exclusive; o.rex = s.right_exclusive; o.start = s.start; o.end = s.end;
+        return o;
+    };
+    for (int i = 0; i < d->n_nodes; ++i) {
+        const vlr_node& n = d->nodes[i];
+        DevNode& o = nodes[i];
+        o = DevNode{};
+        o.kind = n.kind; o.sample = n.sample; o.sample_b = n.sample_b; o.cmp = n.cmp; o.lfc_value = n.lfc_value;
+        o.vafs = conv_spec(n.vafs);
+        o.positive = n.positive; o.refbase = n.refbase; o.altbase = n.altbase;
+        o.child_off = (int)child.size(); o.n_children = n.n_children;
+        for (int c = 0; c < n.n_children; ++c) {
+            int ci = d->child_index[n.child_offset + c];
+            if (ci < 0 || ci >= d->n_nodes) return fail(VLR_ERR_INVALID_ARGUMENT, "child index out of range");
+            child.push_back(ci);
+        }
+        if (n.kind == VLR_NODE_SAMPLE) {
+            if (n.sample < 0 || n.sample >= S) return fail(VLR_ERR_INVALID_ARGUMENT, "invalid sample index in VAF tree (errors::Error::InvalidSampleName)");
+            if (n.vafs.kind == VLR_SPECTRUM_SET && n.vafs.set_len > kMaxSet) return fail(VLR_ERR_UNSUPPORTED, "VAF set larger than %d", kMaxSet);
+        }
+        if (n.kind == VLR_NODE_LFC && (n.sample < 0 || n.sample >= S || n.sample_b < 0 || n.sample_b >= S))
+            return fail(VLR_ERR_INVALID_ARGUMENT, "invalid sample index in l2fc term");
+    }
+    // vafs pool: copy + one 0.0 for the absent chain
+    int pool_len = 0;
+    for (int i = 0; i < d->n_nodes; ++i)
+        if (d->nodes[i].kind == VLR_NODE_SAMPLE && d->nodes[i].vafs.kind == VLR_SPECTRUM_SET)
+            pool_len = std::max(pool_len, d->nodes[i].vafs.set_offset + d->nodes[i].vafs.set_len);
+    for (int i = 0; i < d->universe_offset[S]; ++i)
+        if (d->universe[i].kind == VLR_SPECTRUM_SET) pool_len = std::max(pool_len, d->universe[i].set_offset + d->universe[i].set_len);
+    std::vector<double> pool(d->vafs, d->vafs + pool_len);
+    pool.push_back(0.0);
+    for (int s = 0; s < S; ++s) {
+        DevNode& o = nodes[d->n_nodes + s];
+        o = DevNode{};
+        o.kind = VLR_NODE_SAMPLE; o.sample = s;
+        o.vafs.kind = VLR_SPECTRUM_SET; o.vafs.set_off = pool_len; o.vafs.set_len = 1;
+        o.child_off = (int)child.size();
+        o.n_children = (s + 1 < S) ? 1 : 0;
+        if (s + 1 < S) child.push_back(d->n_nodes + s + 1);
+    }
+    P.absent_root = d->n_nodes;
+    P.n_nodes = (int)nodes.size();
+    std::vector<int32_t> roots(d->root_index, d->root_index + d->event_root_offset[d->n_events]);
+    std::vector<int32_t> root_off(d->event_root_offset, d->event_root_offset + d->n_events + 1);
+    for (int r : roots)
+        if (r < 0 || r >= d->n_nodes) return fail(VLR_ERR_INVALID_ARGUMENT, "root index out of range");
+
+    // ---- static limits of the device walk: range nesting, LFC terms and frames per path
+    int max_range = 0, max_lfc = 0, max_frames = 0;
+    {
+        struct It { int node, ranges, lfcs, frames; };
+        std::vector<It> st;
+        for (int r : roots) st.push_back({r, 0, 0, 0});
+        size_t guard = 0;
+        while (!st.empty()) {
+            It it = st.back();
+            st.pop_back();
+            if (++guard > 10000000) return fail(VLR_ERR_INVALID_ARGUMENT, "VAF tree too large or cyclic");
+            const DevNode& n = nodes[it.node];
+            if (n.kind == VLR_NODE_SAMPLE) {
+                it.frames++;
+                if (n.vafs.kind == VLR_SPECTRUM_RANGE && !(n.vafs.start == n.vafs.end)) it.ranges++;
+            }
+            if (n.kind == VLR_NODE_LFC) it.lfcs++;
+            if (n.n_children > 1) it.frames++;
+            max_range = std::max(max_range, it.ranges);
+            max_lfc = std::max(max_lfc, it.lfcs);
+            max_frames = std::max(max_frames, it.frames);
+            for (int c = 0; c < n.n_children; ++c) st.push_back({child[n.child_off + c], it.ranges, it.lfcs, it.frames});
+        }
+    }
+    if (max_range > kMaxRangeDepth) return fail(VLR_ERR_UNSUPPORTED, "more than %d nested VAF ranges on one path", kMaxRangeDepth);
+    if (max_lfc > kMaxLfc) return fail(VLR_ERR_UNSUPPORTED, "more than %d l2fc terms on one path", kMaxLfc);
+    if (max_frames > kMaxFrames) return fail(VLR_ERR_UNSUPPORTED, "VAF tree deeper than %d frames", kMaxFrames);
+    P.max_range_depth = std::max(1, max_range);
+
+    std::vector<DevSpectrum> uni;
+    for (int i = 0; i < d->universe_offset[S]; ++i) uni.push_back(conv_spec(d->universe[i]));
+    std::vector<double> table;
+    int rc = build_prior_table(d, P, table);
+    if (rc != VLR_OK) return rc;
+
+    rc = check_device(device);
+    if (rc != VLR_OK) return rc;
+    HIP_TRY(hipSetDevice(device));
+
+    // ---- upload
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t o_nodes = 0, o_child = o_nodes + al(nodes.size() * sizeof(DevNode)), o_pool = o_child + al(std::max<size_t>(1, child.size()) * 4),
+           o_roots = o_pool + al(pool.size() * 8), o_roff = o_roots + al(std::max<size_t>(1, roots.size()) * 4),
+           o_uni = o_roff + al(root_off.size() * 4), o_tab = o_uni + al(std::max<size_t>(1, uni.size()) * sizeof(DevSpectrum)),
+           total = o_tab + al(table.size() * 8);
+    std::vector<char> hostblob(total, 0);
+    memcpy(&hostblob[o_nodes], nodes.data(), nodes.size() * sizeof(DevNode));
+    if (!child.empty()) memcpy(&hostblob[o_child], child.data(), child.size() * 4);
+    memcpy(&hostblob[o_pool], pool.data(), pool.size() * 8);
+    if (!roots.empty()) memcpy(&hostblob[o_roots], roots.data(), roots.size() * 4);
+    memcpy(&hostblob[o_roff], root_off.data(), root_off.size() * 4);
+    if (!uni.empty()) memcpy(&hostblob[o_uni], uni.data(), uni.size() * sizeof(DevSpectrum));
+    memcpy(&hostblob[o_tab], table.data(), table.size() * 8);
+
+    vlr_plan* plan = new vlr_plan();
+    plan->device = device;
+    plan->n_events = d->n_events;
+    if (hipMalloc(&plan->blob, total) != hipSuccess) { delete plan; return fail(VLR_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed", total); }
+    char* base = (char*)plan->blob;
+    P.nodes = (const DevNode*)(base + o_nodes);
+    P.child_index = (const int32_t*)(base + o_child);
+    P.vafs = (const double*)(base + o_pool);
+    P.roots = (const int32_t*)(base + o_roots);
+    P.root_off = (const int32_t*)(base + o_roff);
+    P.universe = (const DevSpectrum*)(base + o_uni);
+    P.prior_table = (const double*)(base + o_tab);
+    plan->host = P;
+    hipError_t e = hipMemcpy(plan->blob, hostblob.data(), total, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&plan->dev, sizeof(DevPlan));
+    if (e == hipSuccess) e = hipMemcpy(plan->dev, &P, sizeof(DevPlan), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipEventCreate(&plan->ev_start);
+    if (e == hipSuccess) e = hipEventCreate(&plan->ev_stop);
+    if (e == hipSuccess) e = hipMalloc((void**)&plan->work_dev, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(plan->work_dev, 0, 2 * sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        vlr_plan_destroy(plan);
+        return fail(VLR_ERR_HIP, "plan upload failed: %s", hipGetErrorString(e));
+    }
+    *out = plan;
+    return VLR_OK;
+}
+
+void vlr_plan_destroy(vlr_plan* plan) {
+    if (!plan) return;
+    if (plan->blob) (void)hipFree(plan->blob);
+    if (plan->dev) (void)hipFree(plan->dev);
+    if (plan->stage) (void)hipFree(plan->stage);
+    if (plan->work_dev) (void)hipFree(plan->work_dev);
+    if (plan->ev_start) (void)hipEventDestroy(plan->ev_start);
+    if (plan->ev_stop) (void)hipEventDestroy(plan->ev_stop);
+    delete plan;
+}
+
+int vlr_plan_n_out(const vlr_plan* plan) { return plan ? plan->n_events + 2 : VLR_ERR_INVALID_ARGUMENT; }
+int vlr_plan_n_samples(const vlr_plan* plan) { return plan ? plan->host.S : VLR_ERR_INVALID_ARGUMENT; }
+
+// LDS budget knob: maximum pileup depth per sample the kernel reserves coefficient space for
+// (reference default max_depth = 200, src/variants/sample.rs:236).  Loci above it get VLR_LOCUS_TOO_DEEP.
+int vlr_plan_set_max_depth(vlr_plan* plan, int per_sample_depth) {
+    if (!plan || per_sample_depth < 1) return fail(VLR_ERR_INVALID_ARGUMENT, "invalid max depth");
+    size_t lds = (size_t)3 * per_sample_depth * plan->host.S * 8;
+    if (lds > 120 * 1024) return fail(VLR_ERR_UNSUPPORTED, "max depth %d x %d samples exceeds the LDS budget", per_sample_depth, plan->host.S);
+    plan->max_depth_per_sample = per_sample_depth;
+    return VLR_OK;
+}
+
+int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* stream) {
+    using namespace vlr;
+    if (!plan || !in || !out) return fail(VLR_ERR_INVALID_ARGUMENT, "null argument");
+    if (in->n_samples != plan->host.S) return fail(VLR_ERR_INVALID_ARGUMENT, "batch has %d samples, plan %d", in->n_samples, plan->host.S);
+    if (out->n_out != plan->n_events + 2 || out->n_samples != plan->host.S || out->n_loci < in->n_loci)
+        return fail(VLR_ERR_INVALID_ARGUMENT, "result buffers do not match plan/batch");
+    if (out->afd_count || out->afd_vaf || out->afd_lnprob)
+        return fail(VLR_ERR_UNSUPPORTED, "AFD output is not produced by the device path yet (DESIGN.md: out of scope this round)");
+    if (!in->obs_offset || !in->prob_mapping || !in->prob_alt || !in->prob_ref || !in->prob_missed_allele || !in->prob_sample_alt ||
+        !in->prob_double_overlap || !in->prob_hit_base || !in->flags || !in->locus_flags || !out->ln_posterior || !out->map_vaf || !out->status)
+        return fail(VLR_ERR_INVALID_ARGUMENT, "missing required column");
+    if (in->n_loci == 0) return VLR_OK;
+    if (in->n_loci > 0x7fffffffLL) return fail(VLR_ERR_INVALID_ARGUMENT, "at most 2^31-1 loci per batch");
+    HIP_TRY(hipSetDevice(plan->device));
+    DevBatch b{};
+    b.n_loci = in->n_loci;
+    b.obs_offset = in->obs_offset;
+    b.pm = in->prob_mapping; b.pa = in->prob_alt; b.pr = in->prob_ref; b.miss = in->prob_missed_allele;
+    b.psa = in->prob_sample_alt; b.pdo = in->prob_double_overlap; b.phb = in->prob_hit_base;
+    b.hpa = in->prob_hp_artifact; b.hpv = in->prob_hp_variant;
+    b.flags = in->flags;
+    b.locus_flags = in->locus_flags; b.variant_type = in->variant_type; b.ref_base = in->ref_base; b.alt_base = in->alt_base;
+    DevResults r{};
+    r.ln_posterior = out->ln_posterior; r.ln_marginal = out->ln_marginal; r.map_vaf = out->map_vaf;
+    r.map_bias = out->map_bias; r.best_event = out->best_event; r.status = out->status;
+    r.work = plan->work_dev;
+    int max_obs = plan->max_depth_per_sample * plan->host.S;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipEventRecord(plan->ev_start, st));
+    int rc = vlr_launch_call_kernel(plan->dev, &b, &r, plan->host.n_univ, plan->host.S, max_obs, plan->host.max_range_depth, stream);
+    if (rc != 0) return fail(VLR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIP_TRY(hipEventRecord(plan->ev_stop, st));
+    plan->timed = true;
+    return VLR_OK;
+}
+
+int vlr_plan_last_kernel_ms(vlr_plan* plan, float* ms) {
+    if (!plan || !ms) return fail(VLR_ERR_INVALID_ARGUMENT, "null argument");
+    if (!plan->timed) return fail(VLR_ERR_INVALID_ARGUMENT, "no batch has been run on this plan");
+    HIP_TRY(hipEventSynchronize(plan->ev_stop));
+    HIP_TRY(hipEventElapsedTime(ms, plan->ev_start, plan->ev_stop));
+    return VLR_OK;
+}
+
+// profiling aid: cumulative {pileup evaluations, observation terms} since plan creation (synchronises)
+int vlr_plan_work_counters(vlr_plan* plan, unsigned long long* out2, int reset) {
+    if (!plan || !out2) return fail(VLR_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(plan->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out2, plan->work_dev, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(plan->work_dev, 0, 2 * sizeof(unsigned long long)));
+    return VLR_OK;
+}
+
+int vlr_batch_run_host(vlr_plan* plan, const vlr_batch* in, vlr_results* out) {
+    if (!plan || !in || !out) return fail(VLR_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(plan->device));
+    const int S = plan->host.S;
+    const int64_t L = in->n_loci, N = in->n_obs;
+    const int n_out = plan->n_events + 2;
+    if (L == 0) return VLR_OK;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    struct Col { const void* src; size_t bytes; size_t off; };
+    std::vector<Col> cols;
+    size_t off = 0;
+    auto add = [&](const void* p, size_t bytes) {
+        cols.push_back({p, bytes, off});
+        size_t o = off;
+        off += al(std::max<size_t>(bytes, 1));
+        return o;
+    };
+    size_t o_off = add(in->obs_offset, (size_t)(L * S + 1) * 4);
+    size_t o_pm = add(in->prob_mapping, N * 4), o_pa = add(in->prob_alt, N * 4), o_pr = add(in->prob_ref, N * 4);
+    size_t o_ms = add(in->prob_missed_allele, N * 4), o_psa = add(in->prob_sample_alt, N * 4), o_pdo = add(in->prob_double_overlap, N * 4);
+    size_t o_phb = add(in->prob_hit_base, N * 4);
+    size_t o_hpa = add(in->prob_hp_artifact, in->prob_hp_artifact ? N * 4 : 0), o_hpv = add(in->prob_hp_variant, in->prob_hp_variant ? N * 4 : 0);
+    size_t o_fl = add(in->flags, N * 4);
+    size_t o_lf = add(in->locus_flags, L), o_vt = add(in->variant_type, in->variant_type ? L : 0);
+    size_t o_rb = add(in->ref_base, in->ref_base ? L : 0), o_ab = add(in->alt_base, in->alt_base ? L : 0);
+    size_t in_end = off;
+    size_t r_post = off; off += al((size_t)L * n_out * 8);
+    size_t r_marg = off; off += al((size_t)L * 8);
+    size_t r_map = off; off += al((size_t)L * S * 8);
+    size_t r_bias = off; off += al((size_t)L * VLR_N_BIAS);
+    size_t r_best = off; off += al((size_t)L * 4);
+    size_t r_stat = off; off += al((size_t)L * 4);
+    (void)in_end;
+    if (off > plan->stage_bytes) {
+        if (plan->stage) (void)hipFree(plan->stage);
+        plan->stage = nullptr;
+        plan->stage_bytes = 0;
+        if (hipMalloc(&plan->stage, off) != hipSuccess) return fail(VLR_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed", off);
+        plan->stage_bytes = off;
+    }
+    char* base = (char*)plan->stage;
+    for (auto& c : cols)
+        if (c.src && c.bytes) HIP_TRY(hipMemcpy(base + c.off, c.src, c.bytes, hipMemcpyHostToDevice));
+    vlr_batch db = *in;
+    db.obs_offset = (const uint32_t*)(base + o_off);
+    db.prob_mapping = (const float*)(base + o_pm); db.prob_alt = (const float*)(base + o_pa); db.prob_ref = (const float*)(base + o_pr);
+    db.prob_missed_allele = (const float*)(base + o_ms); db.prob_sample_alt = (const float*)(base + o_psa);
+    db.prob_double_overlap = (const float*)(base + o_pdo); db.prob_hit_base = (const float*)(base + o_phb);
+    db.prob_hp_artifact = in->prob_hp_artifact ? (const float*)(base + o_hpa) : nullptr;
+    db.prob_hp_variant = in->prob_hp_variant ? (const float*)(base + o_hpv) : nullptr;
+    db.flags = (const uint32_t*)(base + o_fl);
+    db.locus_flags = (const uint8_t*)(base + o_lf);
+    db.variant_type = in->variant_type ? (const uint8_t*)(base + o_vt) : nullptr;
+    db.ref_base = in->ref_base ? (const uint8_t*)(base + o_rb) : nullptr;
+    db.alt_base = in->alt_base ? (const uint8_t*)(base + o_ab) : nullptr;
+    vlr_results dr = *out;
+    dr.ln_posterior = (double*)(base + r_post);
+    dr.ln_marginal = (double*)(base + r_marg);
+    dr.map_vaf = (double*)(base + r_map);
+    dr.map_bias = (uint8_t*)(base + r_bias);
+    dr.best_event = (int32_t*)(base + r_best);
+    dr.status = (uint32_t*)(base + r_stat);
+    dr.afd_count = nullptr; dr.afd_vaf = nullptr; dr.afd_lnprob = nullptr;
+    if (out->afd_count || out->afd_vaf || out->afd_lnprob)
+        return fail(VLR_ERR_UNSUPPORTED, "AFD output is not produced by the device path yet (DESIGN.md: out of scope this round)");
+    int rc = vlr_batch_run(plan, &db, &dr, nullptr);
+    if (rc != VLR_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out->ln_posterior, dr.ln_posterior, (size_t)L * n_out * 8, hipMemcpyDeviceToHost));
+    if (out->ln_marginal) HIP_TRY(hipMemcpy(out->ln_marginal, dr.ln_marginal, (size_t)L * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out->map_vaf, dr.map_vaf, (size_t)L * S * 8, hipMemcpyDeviceToHost));
+    if (out->map_bias) HIP_TRY(hipMemcpy(out->map_bias, dr.map_bias, (size_t)L * VLR_N_BIAS, hipMemcpyDeviceToHost));
+    if (out->best_event) HIP_TRY(hipMemcpy(out->best_event, dr.best_event, (size_t)L * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out->status, dr.status, (size_t)L * 4, hipMemcpyDeviceToHost));
+    return VLR_OK;
+}
+
+}  // extern "C"

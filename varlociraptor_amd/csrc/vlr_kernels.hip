@@ -1,0 +1,1307 @@
+// vlr_kernels.hip — gfx950 (MI355X, CDNA4) kernel of the per-locus Bayesian likelihood engine.
+//
+// One wavefront (64 lanes, one workgroup) evaluates one candidate locus end to end:
+//   phase A  pileup statistics for bias gating (wave ballots / reductions over the SoA columns)
+//   phase B  for every surviving bias hypothesis: per-observation affine coefficients -> LDS, then the
+//            VAF-tree walk of every event with the reference's adaptive integration; pileup
+//            likelihoods are evaluated as products prod_i (c_i + q_i*alpha + e_i*beta) with the lanes
+//            split into (point, observation-slice) groups
+//   phase C  posterior normalisation, artifact aggregation, MAP selection
+//
+// What is computed follows the reference (varlociraptor v8.9.3) function by function; citations are
+// file:line under /root/reference/src.  HOW it is computed is not a translation: the reference
+// evaluates ~8 log-space transcendentals per (observation, VAF point) through LRU caches; here the
+// observation likelihood is affine in the VAF, so coefficients are built once per
+// (locus, hypothesis) and a VAF point costs 2 FMAs + a mantissa/exponent product per observation.
+//
+// No MFMA: this is f64 VALU + LDS work (north star); the HBM traffic is one pass over the columns.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vlr.h"
+#include "vlr_plan.h"
+
+#pragma clang fp contract(off)
+
+namespace vlr {
+
+#define VLR_NEG_INF (-__builtin_huge_val())
+__device__ constexpr double kLn05 = -0.6931471805599453;    // ln 0.5   (utils/mod.rs:45 PROB_05)
+__device__ constexpr double kLn095 = -0.05129329438755058;  // ln 0.95  (utils/mod.rs:48 PROB_095)
+__device__ constexpr double kLn2 = 0.6931471805599453;
+__device__ constexpr double kEps = 2.220446049250313e-16;
+
+enum FrameKind { FK_BRANCH = 0, FK_SET = 1, FK_RANGE = 2 };
+enum RangePhase { RP_INIT = 0, RP_ROUND = 1, RP_TAIL = 2, RP_SIMPSON = 3 };
+
+struct Frame {
+    int kind, node, iter, n;
+    double accM, accS;  // streaming ln-sum-exp
+    int sv_present, sv_disc, sv_nlfc, sv_contained;
+    int slot, pad;      // RANGE: index into rs[] / the visited-point tables
+};
+
+struct RangeSt {
+    double lo, hi, res, L, R, vL, vR, mid, first_mid;
+    double ostart, oend;  // node spectrum, for the `contains` check of MAP candidates
+    double pend[11];
+    int have_first, phase, npend, simpson_n, tn, sample, olex, orex, leaf, have_mid;
+};
+
+struct WaveSt {
+    double ops_vaf[kMaxSamples];
+    double lfc_val[kMaxLfc];
+    int lfc_a[kMaxLfc], lfc_b[kMaxLfc], lfc_cmp[kMaxLfc];
+    int nkeep[kMaxSamples], soff[kMaxSamples];
+    int all_ref[kMaxSamples], all_posref[kMaxSamples], strong_all[kMaxSamples];
+    int strong_bias[kMaxSamples][kNHyp];
+    int any_strong_alt[kMaxSamples], has_ins[kMaxSamples], has_del[kMaxSamples];
+    double pos_all[kMaxSamples], pos_major[kMaxSamples], pos_rate[kMaxSamples];
+    double cacheA[kMaxSamples][kCacheWays], cacheB[kMaxSamples][kCacheWays], cacheV[kMaxSamples][kCacheWays];
+    int cacheN[kMaxSamples];
+    Frame frames[kMaxFrames];
+    RangeSt rs[kMaxRangeDepth];
+    double setv[kMaxSamples][kMaxSet];
+    double ptA[kMaxBatchPoints], ptB[kMaxBatchPoints], res[kMaxBatchPoints];
+    double ptJ[kMaxBatchPoints];
+    double fixedLik[kMaxSamples];
+    double curMapVaf[kMaxSamples];
+};
+
+// ------------------------------------------------------------------------------------------------
+// wave helpers (wave64; one wave per workgroup so __syncthreads() is a wave-level LDS fence)
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ inline double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ inline int popc64(unsigned long long m) { return __popcll(m); }
+
+// approx::relative_eq!(a, b) defaults (epsilon = max_relative = f64::EPSILON)
+__device__ inline bool relative_eq(double a, double b) {
+    if (a == b) return true;
+    if (isinf(a) || isinf(b)) return false;
+    double d = fabs(a - b);
+    if (d <= kEps) return true;
+    return d <= fmax(fabs(a), fabs(b)) * kEps;
+}
+// bio LogProb::ln_add_exp
+__device__ inline double ln_add_exp(double a, double b) {
+    double p0 = fmax(a, b), p1 = fmin(a, b);
+    if (p0 == VLR_NEG_INF) return VLR_NEG_INF;
+    return p0 + log1p(exp(p1 - p0));
+}
+// streaming ln-sum-exp accumulator: value = M + ln(S), S counts the max term as 1
+__device__ inline void lse_add(double& M, double& S, double v) {
+    if (v != v) { M = v; S = 1.0; return; }  // NaN poisons
+    if (v == VLR_NEG_INF) return;
+    if (M != M) return;
+    if (M == VLR_NEG_INF) { M = v; S = 1.0; return; }
+    if (v > M) { S = S * exp(M - v) + 1.0; M = v; }
+    else S += exp(v - M);
+}
+__device__ inline double lse_value(double M, double S) {
+    if (M == VLR_NEG_INF) return VLR_NEG_INF;
+    return M + log(S);
+}
+
+// ------------------------------------------------------------------------------------------------
+// spectra (grammar/formula.rs:1057-1262)
+struct RangeV { double start, end; int lex, rex; };
+__device__ inline bool range_is_empty(const RangeV& r) { return r.start == r.end && (r.lex || r.rex); }       // 1078-1080
+__device__ inline bool range_is_singleton(const RangeV& r) { return r.start == r.end && !(r.lex || r.rex); }  // 1086-1088
+__device__ inline bool range_contains(const RangeV& r, double v) {                                            // 1090-1097
+    bool lo = r.lex ? (r.start < v) : (r.start <= v);
+    bool hi = r.rex ? (r.end > v) : (r.end >= v);
+    return lo && hi;
+}
+__device__ inline RangeV range_empty() { return RangeV{0.0, 0.0, 1, 1}; }
+__device__ inline RangeV range_intersect(const RangeV& a, const RangeV& o) {  // 1131-1168, 1226-1254
+    bool eq = a.start == o.start && a.end == o.end && a.lex == o.lex && a.rex == o.rex;
+    bool none = !eq && ((a.end < o.start || a.start > o.end) || (a.end <= o.start && (a.rex || o.lex)) ||
+                        (a.start >= o.end && (a.lex || o.rex)));
+    if (none) return range_empty();
+    RangeV r;
+    r.start = fmax(a.start, o.start);
+    r.end = fmin(a.end, o.end);
+    r.lex = (a.start > o.start) ? a.lex : (a.start < o.start) ? o.lex : (a.lex || o.lex);
+    r.rex = (a.end < o.end) ? a.rex : (a.end > o.end) ? o.rex : (a.rex || o.rex);
+    return r;
+}
+__device__ inline double observable_max(const RangeV& r, int n) {  // 1198-1216
+    double dn = (double)n;
+    if (n < 10 || !(dn * (r.end - r.start) > 1.0)) return r.end;
+    double c = dn * r.end;
+    if (r.rex && fmod(c, 1.0) == 0.0) c -= 1.0;
+    c = floor(c);
+    if (c == 0.0) return r.end;
+    return floor(c) / dn;
+}
+__device__ inline double observable_min(const RangeV& r, int n) {  // 1170-1196
+    double dn = (double)n;
+    double min_vaf;
+    if (n < 10 || !(dn * (r.end - r.start) > 1.0)) {
+        min_vaf = r.start;
+    } else {
+        double c = dn * r.start;
+        if (r.lex && fmod(c, 1.0) == 0.0) {
+            double adjusted_end = observable_max(r, n);
+            double s1 = ceil(c + 1.0) / dn;
+            if (s1 <= 1.0 && s1 <= adjusted_end) return s1;
+            double s0 = ceil(c) / dn;
+            if (s0 <= 1.0 && s0 <= adjusted_end) return s0;
+        }
+        min_vaf = ceil(c) / dn;
+    }
+    if (min_vaf >= observable_max(r, n)) return r.start;
+    return min_vaf;
+}
+__device__ inline bool spectrum_contains(const DevSpectrum& sp, const double* pool, double v) {  // 1035-1040
+    if (sp.kind == 0) {
+        for (int i = 0; i < sp.set_len; ++i)
+            if (pool[sp.set_off + i] == v) return true;
+        return false;
+    }
+    RangeV r{sp.start, sp.end, sp.lex, sp.rex};
+    return range_contains(r, v);
+}
+
+// LFC predicates (utils/log2_fold_change.rs)
+__device__ inline bool lfc_is_true(int cmp, double value, double a, double b) {  // 17-26, 41-52
+    double lfc = (a == 0.0 && b == 0.0) ? 0.0 : log2(a) - log2(b);
+    switch (cmp) {
+        case VLR_CMP_EQUAL: return relative_eq(lfc, value);
+        case VLR_CMP_GREATER: return lfc > value;
+        case VLR_CMP_GREATER_EQUAL: return lfc >= value;
+        case VLR_CMP_LESS: return lfc < value;
+        case VLR_CMP_LESS_EQUAL: return lfc <= value;
+        default: return !relative_eq(lfc, value);
+    }
+}
+__device__ inline RangeV lfc_bounds_of(int cmp, double value, double vaf) {  // 56-93
+    double proj = vaf / exp2(value);
+    if (proj < 0.0 || proj > 1.0) return range_empty();
+    switch (cmp) {
+        case VLR_CMP_EQUAL: return RangeV{proj, proj, 0, 0};
+        case VLR_CMP_GREATER: return RangeV{0.0, proj, 0, 1};
+        case VLR_CMP_GREATER_EQUAL: return RangeV{0.0, proj, 0, 0};
+        case VLR_CMP_LESS: return RangeV{proj, 1.0, 1, 0};
+        case VLR_CMP_LESS_EQUAL: return RangeV{proj, 1.0, 0, 0};
+        default: return RangeV{0.0, 1.0, 0, 0};
+    }
+}
+__device__ inline void lfc_invert(int& cmp, double& value) {  // 95-122
+    switch (cmp) {
+        case VLR_CMP_GREATER: cmp = VLR_CMP_LESS_EQUAL; value = -value; break;
+        case VLR_CMP_GREATER_EQUAL: cmp = VLR_CMP_LESS; value = -value; break;
+        case VLR_CMP_LESS: cmp = VLR_CMP_GREATER_EQUAL; value = -value; break;
+        case VLR_CMP_LESS_EQUAL: cmp = VLR_CMP_GREATER; value = -value; break;
+        default: break;
+    }
+}
+__device__ inline bool iupac_contains(int code, int base) {  // grammar/formula.rs:23-43
+    if (base == code) return true;
+    switch (code) {
+        case 'R': return base == 'A' || base == 'G';
+        case 'Y': return base == 'C' || base == 'T';
+        case 'S': return base == 'G' || base == 'C';
+        case 'W': return base == 'A' || base == 'T';
+        case 'K': return base == 'G' || base == 'T';
+        case 'M': return base == 'A' || base == 'C';
+        case 'B': return base == 'C' || base == 'G' || base == 'T';
+        case 'D': return base == 'A' || base == 'G' || base == 'T';
+        case 'H': return base == 'A' || base == 'C' || base == 'T';
+        case 'V': return base == 'A' || base == 'C' || base == 'G';
+        case 'N': return true;
+        default: return false;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// observation features
+struct ObsF {
+    double pm, pa, pr;
+    uint32_t f;
+    bool valid;
+};
+__device__ inline int f_strand(uint32_t f) { return (f >> VLR_F_STRAND_SHIFT) & 3; }
+__device__ inline int f_orient(uint32_t f) { return (f >> VLR_F_ORIENT_SHIFT) & 3; }
+__device__ inline int f_altlocus(uint32_t f) { return (f >> VLR_F_ALTLOCUS_SHIFT) & 3; }
+__device__ inline int f_hplen(uint32_t f) { return (f & VLR_F_HP_LEN_VALID) ? (int)(int8_t)((f >> VLR_F_HP_LEN_SHIFT) & 0xff) : 0; }
+
+// is_bias_evidence == prob_alt(obs) != ln 0 for the artifact component of hypothesis h
+// (bias/mod.rs:52-54; strand_bias.rs:30-54; read_orientation_bias.rs:18-32; read_position_bias.rs:18-25;
+//  softclip_bias.rs:15-25; alt_locus_bias.rs:63-84)
+__device__ inline bool bias_evidence(int h, uint32_t f, bool has_alt_loci) {
+    switch (h) {
+        case H_ALB: return has_alt_loci ? (f_altlocus(f) == VLR_ALTLOCUS_MAJOR) : !(f & VLR_F_MAX_MAPQ);
+        case H_HE: return f_hplen(f) != 0;  // homopolymer_error.rs:82-84
+        case H_SCB: return (f & VLR_F_SOFTCLIPPED) != 0;
+        case H_RPB: return (f & VLR_F_READPOS_MAJOR) != 0;
+        case H_F1R2: return f_orient(f) != VLR_ORIENT_F2R1;
+        case H_F2R1: return f_orient(f) != VLR_ORIENT_F1R2;
+        case H_SBF: return f_strand(f) == VLR_STRAND_FORWARD || f_strand(f) == VLR_STRAND_NONE;
+        case H_SBR: return f_strand(f) == VLR_STRAND_REVERSE || f_strand(f) == VLR_STRAND_NONE;
+        default: return true;
+    }
+}
+
+// exp(ln_sum_exp(v_i)) over a wave-distributed set, mirroring bio's LogProb::ln_sum_exp formula
+// m + ln1p(sum_{i != imax} exp(v_i - m)) (used by strand_bias.rs:80-109, read_position_bias.rs:68-113)
+struct LseAcc {
+    double m, s;  // running max, sum of exp(v - m) incl. the max term
+};
+__device__ inline void lseacc_chunk(LseAcc& a, double v, bool on) {
+    double x = on ? v : VLR_NEG_INF;
+    double cm = wave_max(x);
+    if (cm == VLR_NEG_INF) return;
+    double nm = fmax(a.m, cm);
+    double cs = wave_sum(on && x != VLR_NEG_INF ? exp(x - nm) : 0.0);
+    double olds = (a.m == VLR_NEG_INF) ? 0.0 : a.s * exp(a.m - nm);
+    a.m = nm;
+    a.s = olds + cs;
+}
+__device__ inline double lseacc_exp(const LseAcc& a) {
+    if (a.m == VLR_NEG_INF) return 0.0;
+    return exp(a.m + log1p(a.s - 1.0));
+}
+
+// ------------------------------------------------------------------------------------------------
+// pileup likelihood: ln prod_i (c_i + q_i*alpha + e_i*beta) at np points, lanes = (point, slice)
+__device__ inline void eval_pileup(const double* __restrict__ cc, const double* __restrict__ cq,
+                                   const double* __restrict__ ce, int D, int np, const double* ptA, const double* ptB,
+                                   double* res, int lane) {
+    int lg = np <= 1 ? 0 : np <= 2 ? 1 : np <= 4 ? 2 : np <= 8 ? 3 : 4;  // G = 2^lg point groups
+    int LP = 64 >> lg;
+    int j = lane >> (6 - lg);
+    int k = lane & (LP - 1);
+    int jj = j < np ? j : np - 1;
+    double a = ptA[jj], b = ptB[jj];
+    double P = 1.0;
+    int E = 0;
+    for (int i = k; i < D; i += LP) {
+        double L = __builtin_fma(cq[i], a, cc[i]);
+        L = __builtin_fma(ce[i], b, L);
+        L = L < 0.0 ? 0.0 : L;  // rounding guard; NaN passes through
+        int ex;
+        double m = __builtin_frexp(L, &ex);
+        P *= m;  // mantissas in [0.5,1): no underflow below ~1000 terms per lane (max_obs/4 < 1000 by the LDS cap)
+        E += ex;
+    }
+    for (int o = 1; o < LP; o <<= 1) {
+        double Po = __shfl_xor(P, o);
+        int Eo = __shfl_xor(E, o);
+        int e2;
+        P = __builtin_frexp(P * Po, &e2);
+        E += Eo + e2;
+    }
+    double r = log(P) + (double)E * kLn2;
+    if (k == 0 && j < np) res[j] = r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sort the visited points of one chain by x (rank sort in LDS) and integrate:
+// LogProb::ln_trapezoidal_integrate_grid_exp over the sorted grid (utils/adaptive_integration.rs:133-140).
+// Duplicate x (HashMap key collisions in the reference) give zero-width segments = ln 0 terms.
+__device__ inline double integrate_table(const double* tx, const double* tv, int n, double* sx, double* sv, int lane) {
+    for (int i = lane; i < n; i += 64) {
+        double x = tx[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            double y = tx[j];
+            rank += (y < x) || (y == x && j < i);
+        }
+        sx[rank] = x;
+        sv[rank] = tv[i];
+    }
+    __syncthreads();
+    double M = VLR_NEG_INF;
+    double t0 = VLR_NEG_INF, t1 = VLR_NEG_INF;
+    {
+        int k = lane;
+        if (k + 1 < n) {
+            double w = (sx[k + 1] - sx[k]) / 2.0;
+            t0 = ln_add_exp(sv[k], sv[k + 1]) + log(w);
+        }
+        k = lane + 64;
+        if (k + 1 < n) {
+            double w = (sx[k + 1] - sx[k]) / 2.0;
+            t1 = ln_add_exp(sv[k], sv[k + 1]) + log(w);
+        }
+    }
+    bool nan = (t0 != t0) || (t1 != t1);
+    unsigned long long anynan = __ballot(nan);
+    M = wave_max(fmax(t0 == t0 ? t0 : VLR_NEG_INF, t1 == t1 ? t1 : VLR_NEG_INF));
+    double r;
+    if (anynan) r = __builtin_nan("");
+    else if (M == VLR_NEG_INF) r = VLR_NEG_INF;
+    else {
+        double s = (t0 == VLR_NEG_INF ? 0.0 : exp(t0 - M)) + (t1 == VLR_NEG_INF ? 0.0 : exp(t1 - M));
+        s = wave_sum(s);
+        r = M + log(s);
+    }
+    __syncthreads();
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct Ctx {
+    const DevPlan* __restrict__ plan;
+    WaveSt* w;
+    double *cc, *cq, *ce;            // coefficient arrays (LDS)
+    double *tabX, *tabV, *sx, *sv;   // visited tables [depth][kTableCap], sort scratch
+    int lane;
+    int S;
+    int vt;                          // variant type of the locus
+    int has_snv, refbase, altbase;
+    // operands state (modes/generic.rs:116-121), wave-uniform
+    int present, disc, nlfc, contained;
+    int hyp;
+    // MAP candidate of the current (event, hypothesis class)
+    double curJ;
+    int curHyp;
+    unsigned status;
+    unsigned long long n_eval, n_terms;
+};
+
+// Prior::compute via the host-built class table (prior.rs:715-762; see vlr_host.cpp build_prior_table)
+__device__ inline double prior_of(const Ctx& c, int inner, double x) {
+    const DevPlan& p = *c.plan;
+    int idx = 0;
+    for (int s = 0; s < c.S; ++s) {
+        double v = (s == inner) ? x : c.w->ops_vaf[s];
+        int cls;
+        if (p.prior_kind[s] == PK_UNIFORM) {
+            bool in = false;
+            for (int u = p.uni_off[s]; u < p.uni_off[s + 1]; ++u) in = in || spectrum_contains(p.universe[u], p.vafs, v);
+            cls = in ? (v == 0.0 ? 0 : 1) : 2;
+        } else {
+            int pl = p.ploidy[s];
+            double dp = (double)pl;
+            double k = rint(dp * v);
+            bool match;
+            if (p.prior_kind[s] == PK_GERMLINE) match = relative_eq(dp * v, k);  // prior.rs:236-240
+            else match = pl > 0 ? relative_eq(v - k / dp, 0.0) : (v == 0.0);    // prior.rs:440-456 on vaf - n/ploidy
+            cls = (match && k >= 0.0 && k <= dp) ? (int)k : pl + 1;
+        }
+        idx += cls * p.class_stride[s];
+    }
+    return p.prior_table[c.vt * p.table_size + idx];
+}
+
+// alpha/beta of sample s given its own VAF a and its contaminant's VAF b:
+// L_i = c_i + q_i*(rho*a + (1-rho)*b) + e_i*(rho*[a==1] + (1-rho)*[b==1])   (likelihood.rs:43-53,86-115,171-220)
+__device__ inline void alpha_beta(const DevPlan& p, int s, double a, double b, double& al, double& be) {
+    if (p.by[s] >= 0) {
+        al = p.rho[s] * a + p.irho[s] * b;
+        be = p.rho[s] * (a == 1.0 ? 1.0 : 0.0) + p.irho[s] * (b == 1.0 ? 1.0 : 0.0);
+    } else {
+        al = a;
+        be = (a == 1.0) ? 1.0 : 0.0;
+    }
+}
+
+// cached single-point pileup likelihood of sample s (stands in for the per-sample LRU caches of
+// modes/generic.rs:38-53: the normal sample's likelihood is reused across all tumor VAFs)
+__device__ inline double sample_lik(Ctx& c, int s, double a, double b) {
+    WaveSt* w = c.w;
+    int n = w->cacheN[s];
+    int lim = n < kCacheWays ? n : kCacheWays;
+    for (int i = 0; i < lim; ++i)
+        if (w->cacheA[s][i] == a && w->cacheB[s][i] == b) return w->cacheV[s][i];
+    double al, be;
+    alpha_beta(*c.plan, s, a, b, al, be);
+    __syncthreads();
+    if (c.lane == 0) { w->ptA[0] = al; w->ptB[0] = be; }
+    __syncthreads();
+    int off = w->soff[s], D = w->nkeep[s];
+    eval_pileup(c.cc + off, c.cq + off, c.ce + off, D, 1, w->ptA, w->ptB, w->res, c.lane);
+    __syncthreads();
+    double r = w->res[0];
+    c.n_eval += 1;
+    c.n_terms += (unsigned long long)D;
+    int slot = n % kCacheWays;
+    __syncthreads();
+    if (c.lane == 0) {
+        w->cacheA[s][slot] = a;
+        w->cacheB[s][slot] = b;
+        w->cacheV[s][slot] = r;
+        w->cacheN[s] = n + 1;
+    }
+    __syncthreads();
+    return r;
+}
+
+// MAP ordering (oracle map_before): higher joint first; ties: lower hypothesis id, then smaller VAF tuple
+__device__ inline void map_consider(Ctx& c, double joint, int inner, double x) {
+    if (!(joint == joint)) return;
+    bool better = joint > c.curJ;
+    if (!better && joint == c.curJ && c.curHyp >= 0) {
+        if (c.hyp != c.curHyp) better = c.hyp < c.curHyp;
+        else {
+            for (int s = 0; s < c.S; ++s) {
+                double v = (s == inner) ? x : c.w->ops_vaf[s];
+                double o = c.w->curMapVaf[s];
+                if (v != o) { better = v < o; break; }
+            }
+        }
+    }
+    if (c.curHyp < 0) better = true;
+    if (better) {
+        c.curJ = joint;
+        c.curHyp = c.hyp;
+        __syncthreads();
+        if (c.lane < c.S) c.w->curMapVaf[c.lane] = (c.lane == inner) ? x : c.w->ops_vaf[c.lane];
+        __syncthreads();
+    }
+}
+
+// GenericLikelihood::compute step 1 (modes/generic.rs:503-509) for a leaf operand set
+__device__ inline bool lfcs_ok(const Ctx& c, int inner, double x) {
+    for (int i = 0; i < c.nlfc; ++i) {
+        int sa = c.w->lfc_a[i], sb = c.w->lfc_b[i];
+        double va = (sa == inner) ? x : c.w->ops_vaf[sa];
+        double vb = (sb == inner) ? x : c.w->ops_vaf[sb];
+        if (!lfc_is_true(c.w->lfc_cmp[i], c.w->lfc_val[i], va, vb)) return false;
+    }
+    return true;
+}
+
+// joint probability of the current operands at a leaf (bio Model::compute closure:
+// Prior::compute + GenericLikelihood::compute), single point
+__device__ inline double leaf_joint(Ctx& c) {
+    double joint;
+    if (!lfcs_ok(c, -1, 0.0)) {
+        joint = VLR_NEG_INF;
+    } else {
+        double lik = 0.0;
+        for (int s = 0; s < c.S; ++s) {
+            int by = c.plan->by[s];
+            double a = c.w->ops_vaf[s];
+            double b = by >= 0 ? c.w->ops_vaf[by] : 0.0;
+            lik += sample_lik(c, s, a, b);
+        }
+        joint = prior_of(c, -1, 0.0) + lik;
+    }
+    if (joint != joint) c.status |= VLR_LOCUS_NAN;
+    if (c.contained) map_consider(c, joint, -1, 0.0);
+    return joint;
+}
+
+// batched leaf evaluation of the pending points of a Range chain whose node is a leaf:
+// all points share the operands of the outer samples and differ in sample `inner`.
+__device__ inline void leaf_joint_batch(Ctx& c, RangeSt& r, double* tx, double* tv) {
+    WaveSt* w = c.w;
+    const DevPlan& p = *c.plan;
+    int np = r.npend, inner = r.sample;
+    // likelihood of samples that do not depend on `inner`
+    double fixed = 0.0;
+    for (int s = 0; s < c.S; ++s) {
+        int by = p.by[s];
+        if (s == inner || by == inner) continue;
+        fixed += sample_lik(c, s, w->ops_vaf[s], by >= 0 ? w->ops_vaf[by] : 0.0);
+    }
+    __syncthreads();
+    if (c.lane < np) w->ptJ[c.lane] = fixed;
+    __syncthreads();
+    for (int s = 0; s < c.S; ++s) {
+        int by = p.by[s];
+        if (!(s == inner || by == inner)) continue;
+        if (c.lane < np) {
+            double x = r.pend[c.lane];
+            double a = (s == inner) ? x : w->ops_vaf[s];
+            double b = by >= 0 ? ((by == inner) ? x : w->ops_vaf[by]) : 0.0;
+            double al, be;
+            alpha_beta(p, s, a, b, al, be);
+            w->ptA[c.lane] = al;
+            w->ptB[c.lane] = be;
+        }
+        __syncthreads();
+        int off = w->soff[s], D = w->nkeep[s];
+        eval_pileup(c.cc + off, c.cq + off, c.ce + off, D, np, w->ptA, w->ptB, w->res, c.lane);
+        __syncthreads();
+        if (c.lane < np) w->ptJ[c.lane] += w->res[c.lane];
+        c.n_eval += (unsigned long long)np;
+        c.n_terms += (unsigned long long)np * (unsigned long long)D;
+        __syncthreads();
+    }
+    bool nan = false;
+    if (c.lane < np) {
+        double x = r.pend[c.lane];
+        double joint = lfcs_ok(c, inner, x) ? prior_of(c, inner, x) + w->ptJ[c.lane] : VLR_NEG_INF;
+        nan = joint != joint;
+        w->ptJ[c.lane] = joint;
+        tx[r.tn + c.lane] = x;
+        tv[r.tn + c.lane] = joint;
+    }
+    if (__ballot(nan)) c.status |= VLR_LOCUS_NAN;
+    __syncthreads();
+    RangeV orig{r.ostart, r.oend, r.olex, r.orex};
+    for (int j = 0; j < np; ++j) {
+        double x = r.pend[j];
+        if (c.contained && range_contains(orig, x)) map_consider(c, w->ptJ[j], inner, x);
+    }
+    r.tn += np;
+}
+
+// ---- adaptive integration state machine (utils/adaptive_integration.rs:25-141)
+// after the values of r.pend[] are in the table: advance; returns true when the chain is finished
+__device__ inline bool range_advance(Ctx& c, RangeSt& r, const double* tx, const double* tv) {
+    if (r.phase == RP_SIMPSON) return true;
+    if (r.phase == RP_TAIL) return true;
+    if (r.phase == RP_INIT) {
+        r.L = r.lo;
+        r.R = r.hi;
+        r.vL = tv[0];
+        r.vR = tv[1];
+        r.have_mid = 0;
+    } else {  // RP_ROUND: argmax over {left, middle1, middle2, right} (61-94); lowest index wins ties.
+        // The round's points were appended as (mid, middle1, middle2), so their values are the last two
+        // table entries; left/right values are carried along (the reference looks them up in its HashMap).
+        double xs[4] = {r.L, r.pend[1], r.pend[2], r.R};
+        double vs[4] = {r.vL, tv[r.tn - 2], tv[r.tn - 1], r.vR};
+        int k = 0;
+        for (int i = 1; i < 4; ++i)
+            if (vs[i] > vs[k]) k = i;
+        double nl = (k > 0) ? xs[k - 1] : xs[k], vl = (k > 0) ? vs[k - 1] : vs[k];
+        double nr = (k < 3) ? xs[k + 1] : xs[k], vr = (k < 3) ? vs[k + 1] : vs[k];
+        r.L = nl; r.vL = vl;
+        r.R = nr; r.vR = vr;
+    }
+    if ((((r.R - r.L) >= r.res) && r.L < r.R) || !r.have_mid) {
+        double mid = (r.R + r.L) / 2.0;
+        r.mid = mid;
+        r.have_mid = 1;
+        if (!r.have_first) { r.first_mid = mid; r.have_first = 1; }
+        r.pend[0] = mid;
+        r.pend[1] = (mid + r.L) / 2.0;
+        r.pend[2] = (r.R + mid) / 2.0;
+        r.npend = 3;
+        r.phase = RP_ROUND;
+        return false;
+    }
+    // tail: abandoned arm (95-106) + small interval around the optimum (107-131)
+    double arm = (r.mid < r.first_mid) ? (r.hi + r.first_mid) / 2.0 : (r.first_mid + r.lo) / 2.0;
+    double lo3 = fmax(r.mid - r.res * 3.0, r.lo);
+    double hi3 = fmin(r.mid + r.res * 3.0, r.hi);
+    double sa = (r.mid - lo3) / 3.0, sb = (hi3 - r.mid) / 3.0;  // itertools_num::linspace step, n = 4
+    r.pend[0] = arm;
+    r.pend[1] = lo3 + sa * 0.0;
+    r.pend[2] = lo3 + sa * 1.0;
+    r.pend[3] = lo3 + sa * 2.0;
+    r.pend[4] = r.mid + sb * 1.0;
+    r.pend[5] = r.mid + sb * 2.0;
+    r.pend[6] = r.mid + sb * 3.0;
+    r.npend = 7;
+    r.phase = RP_TAIL;
+    return false;
+}
+
+// final value of a finished chain
+__device__ inline double range_finish(Ctx& c, RangeSt& r, const double* tx, const double* tv) {
+    if (r.phase == RP_SIMPSON) {  // bio LogProb::ln_simpsons_integrate_exp (modes/generic.rs:367-385)
+        int n = r.simpson_n;
+        double M = VLR_NEG_INF, S = 0.0;
+        for (int i = 1; i < n - 1; ++i) lse_add(M, S, tv[i] + log((double)(2 + (i % 2) * 2)));
+        lse_add(M, S, tv[0]);
+        lse_add(M, S, tv[n - 1]);
+        return lse_value(M, S) + log(r.hi - r.lo) - log((double)(n - 1)) - log(3.0);
+    }
+    return integrate_table(tx, tv, r.tn, c.sx, c.sv, c.lane);
+}
+
+// LikelihoodOperands::lfc_bounds (modes/generic.rs:148-174)
+__device__ inline bool ops_lfc_bounds(const Ctx& c, int sample, RangeV& out) {
+    bool have = false;
+    RangeV acc = range_empty();
+    for (int i = 0; i < c.nlfc; ++i) {
+        int sa = c.w->lfc_a[i], sb = c.w->lfc_b[i];
+        int cmp = c.w->lfc_cmp[i];
+        double val = c.w->lfc_val[i];
+        bool got = false;
+        RangeV b = range_empty();
+        if (sa == sample) {
+            if (c.present & (1 << sb)) { lfc_invert(cmp, val); b = lfc_bounds_of(cmp, val, c.w->ops_vaf[sb]); got = true; }
+        } else if (sb == sample) {
+            if (c.present & (1 << sa)) { b = lfc_bounds_of(cmp, val, c.w->ops_vaf[sa]); got = true; }
+        }
+        if (got) {
+            acc = have ? range_intersect(acc, b) : b;
+            have = true;
+        }
+    }
+    out = acc;
+    return have;
+}
+
+// GenericPosterior::density (modes/generic.rs:190-423) for one (hypothesis, root): explicit-stack walk.
+__device__ __forceinline__ double walk_root(Ctx& c, int root) {
+    const DevPlan& p = *c.plan;
+    WaveSt* w = c.w;
+    c.present = 0; c.disc = 0; c.nlfc = 0; c.contained = 1;
+    int sp = 0, node = root, nrange = 0;
+    enum { PC_DESCEND, PC_SUB, PC_RETURN, PC_RANGE_ISSUE } pc = PC_DESCEND;
+    double rv = VLR_NEG_INF;
+    for (;;) {
+        if (pc == PC_DESCEND) {
+            const DevNode& nd = p.nodes[node];
+            if (nd.kind == VLR_NODE_LFC) {  // 233-244
+                if (c.nlfc < kMaxLfc) {
+                    __syncthreads();
+                    if (c.lane == 0) {
+                        w->lfc_a[c.nlfc] = nd.sample; w->lfc_b[c.nlfc] = nd.sample_b;
+                        w->lfc_cmp[c.nlfc] = nd.cmp; w->lfc_val[c.nlfc] = nd.lfc_value;
+                    }
+                    __syncthreads();
+                    c.nlfc++;
+                }
+                pc = PC_SUB;
+            } else if (nd.kind == VLR_NODE_FALSE) { rv = VLR_NEG_INF; pc = PC_RETURN; }
+            else if (nd.kind == VLR_NODE_TRUE) { rv = 0.0; pc = PC_RETURN; }
+            else if (nd.kind == VLR_NODE_VARIANT) {  // 398-420
+                bool go;
+                if (c.has_snv) {
+                    bool contains = iupac_contains(nd.refbase, c.refbase) && iupac_contains(nd.altbase, c.altbase);
+                    go = !((nd.positive && !contains) || (!nd.positive && contains));
+                } else go = !nd.positive;
+                if (go) pc = PC_SUB; else { rv = VLR_NEG_INF; pc = PC_RETURN; }
+            } else {  // Sample (247-397)
+                int s = nd.sample;
+                RangeV bounds;
+                bool have_bounds = ops_lfc_bounds(c, s, bounds);
+                int n_obs = w->nkeep[s];
+                bool clear_ref = n_obs > 10 && w->all_posref[s];  // 270-291
+                bool is_set = nd.vafs.kind == 0;
+                RangeV vr{nd.vafs.start, nd.vafs.end, nd.vafs.lex, nd.vafs.rex};
+                bool dead = have_bounds && range_is_empty(bounds);  // 262-268
+                int ncand = 0;
+                bool as_set = false;
+                if (!dead) {
+                    if (is_set) {  // 294-330
+                        bool all_pos = true;
+                        for (int i = 0; i < nd.vafs.set_len; ++i) all_pos = all_pos && (p.vafs[nd.vafs.set_off + i] > 0.0);
+                        if (clear_ref && all_pos) dead = true;
+                        else {
+                            __syncthreads();
+                            for (int i = 0; i < nd.vafs.set_len && ncand < kMaxSet; ++i) {
+                                double v = p.vafs[nd.vafs.set_off + i];
+                                if (!have_bounds || range_contains(bounds, v)) {
+                                    if (c.lane == 0) w->setv[s][ncand] = v;
+                                    ncand++;
+                                }
+                            }
+                            __syncthreads();
+                            as_set = true;
+                            if (ncand == 0) dead = true;  // ln_sum_exp of nothing
+                        }
+                    } else {  // 331-395
+                        if (have_bounds) vr = range_intersect(vr, bounds);
+                        if (range_is_empty(vr)) dead = true;
+                        else if (clear_ref && vr.start > 0.0) dead = true;
+                        else if (range_is_singleton(vr)) {
+                            __syncthreads();
+                            if (c.lane == 0) w->setv[s][0] = vr.start;
+                            __syncthreads();
+                            ncand = 1;
+                            as_set = true;
+                        }
+                    }
+                }
+                if (dead) { rv = VLR_NEG_INF; pc = PC_RETURN; }
+                else if (sp >= kMaxFrames) { c.status |= VLR_LOCUS_TABLE_FULL; rv = __builtin_nan(""); pc = PC_RETURN; }
+                else {
+                    __syncthreads();
+                    Frame& f = w->frames[sp];
+                    if (c.lane == 0) {
+                        f.node = node; f.iter = 0; f.accM = VLR_NEG_INF; f.accS = 0.0;
+                        f.sv_present = c.present; f.sv_disc = c.disc; f.sv_nlfc = c.nlfc; f.sv_contained = c.contained;
+                    }
+                    if (as_set) {
+                        if (c.lane == 0) { f.kind = FK_SET; f.n = ncand; w->ops_vaf[s] = w->setv[s][0]; }
+                        __syncthreads();
+                        sp++;
+                        c.present |= (1 << s);
+                        c.disc |= (1 << s);
+                        c.contained = f.sv_contained && spectrum_contains(nd.vafs, p.vafs, w->ops_vaf[s]);
+                        pc = PC_SUB;
+                    } else if (nrange >= p.max_range_depth || nrange >= kMaxRangeDepth) {
+                        c.status |= VLR_LOCUS_TABLE_FULL; rv = __builtin_nan(""); pc = PC_RETURN;
+                    } else {
+                        RangeSt& r = w->rs[nrange];
+                        double res = p.resolution[s];
+                        double min_vaf = observable_min(vr, n_obs);
+                        double max_vaf = observable_max(vr, n_obs);
+                        if (c.lane == 0) {
+                            f.kind = FK_RANGE; f.slot = nrange; f.n = 0;
+                            r.lo = min_vaf; r.hi = max_vaf; r.res = res;
+                            r.ostart = nd.vafs.start; r.oend = nd.vafs.end; r.olex = nd.vafs.lex; r.orex = nd.vafs.rex;
+                            r.have_first = 0; r.have_mid = 0; r.tn = 0; r.sample = s; r.leaf = (nd.n_children == 0);
+                            int simpson = ((max_vaf - min_vaf) < res) ? 3 : (n_obs < 5 ? 11 : 0);  // 367-394
+                            r.simpson_n = simpson;
+                            if (simpson) {
+                                // density is evaluated for interior points first, then a, b (bio); table order = grid order
+                                double step = (max_vaf - min_vaf) / (double)(simpson - 1);
+                                for (int i = 0; i < simpson; ++i) r.pend[i] = min_vaf + step * (double)i;
+                                r.pend[0] = min_vaf; r.pend[simpson - 1] = max_vaf;
+                                r.npend = simpson; r.phase = RP_SIMPSON;
+                            } else {
+                                r.pend[0] = min_vaf; r.pend[1] = max_vaf; r.npend = 2; r.phase = RP_INIT;
+                            }
+                        }
+                        __syncthreads();
+                        sp++;
+                        nrange++;
+                        c.present |= (1 << s);
+                        c.disc &= ~(1 << s);
+                        pc = PC_RANGE_ISSUE;
+                    }
+                }
+            }
+        } else if (pc == PC_SUB) {  // subdensity (199-230)
+            const DevNode& nd = p.nodes[node];
+            if (nd.n_children == 0) { rv = leaf_joint(c); pc = PC_RETURN; }
+            else if (nd.n_children == 1) { node = p.child_index[nd.child_off]; pc = PC_DESCEND; }
+            else if (sp >= kMaxFrames) { c.status |= VLR_LOCUS_TABLE_FULL; rv = __builtin_nan(""); pc = PC_RETURN; }
+            else {
+                __syncthreads();
+                Frame& f = w->frames[sp];
+                if (c.lane == 0) {
+                    f.kind = FK_BRANCH; f.node = node; f.iter = 0; f.n = nd.n_children; f.accM = VLR_NEG_INF; f.accS = 0.0;
+                    f.sv_present = c.present; f.sv_disc = c.disc; f.sv_nlfc = c.nlfc; f.sv_contained = c.contained;
+                }
+                __syncthreads();
+                sp++;
+                node = p.child_index[nd.child_off];
+                pc = PC_DESCEND;
+            }
+        } else if (pc == PC_RANGE_ISSUE) {
+            Frame& f = w->frames[sp - 1];
+            RangeSt& r = w->rs[f.slot];
+            double* tx = c.tabX + f.slot * kTableCap;
+            double* tv = c.tabV + f.slot * kTableCap;
+            if (r.tn + r.npend > kTableCap) {
+                c.status |= VLR_LOCUS_TABLE_FULL;
+                rv = __builtin_nan("");
+                c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained;
+                sp--; nrange--;
+                pc = PC_RETURN;
+            } else if (r.leaf) {
+                // innermost chain: evaluate all pending points at once, loop the state machine here
+                c.present = f.sv_present | (1 << r.sample);
+                c.nlfc = f.sv_nlfc;
+                c.contained = f.sv_contained;
+                for (;;) {
+                    leaf_joint_batch(c, r, tx, tv);
+                    __syncthreads();
+                    bool done = range_advance(c, r, tx, tv);
+                    __syncthreads();
+                    if (done) break;
+                    if (r.tn + r.npend > kTableCap) { c.status |= VLR_LOCUS_TABLE_FULL; break; }
+                }
+                rv = (c.status & VLR_LOCUS_TABLE_FULL) ? __builtin_nan("") : range_finish(c, r, tx, tv);
+                c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained;
+                sp--; nrange--;
+                pc = PC_RETURN;
+            } else {
+                // outer chain: one point at a time through the subtree
+                int it = f.iter;
+                double x = r.pend[it];
+                c.present = f.sv_present | (1 << r.sample);
+                c.disc = f.sv_disc & ~(1 << r.sample);
+                c.nlfc = f.sv_nlfc;
+                RangeV orig{r.ostart, r.oend, r.olex, r.orex};
+                c.contained = f.sv_contained && range_contains(orig, x);
+                __syncthreads();
+                if (c.lane == 0) w->ops_vaf[r.sample] = x;
+                __syncthreads();
+                node = f.node;
+                pc = PC_SUB;
+            }
+        } else {  // PC_RETURN: hand rv to the enclosing frame
+            if (sp == 0) return rv;
+            Frame& f = w->frames[sp - 1];
+            if (f.kind == FK_RANGE) {
+                RangeSt& r = w->rs[f.slot];
+                double* tx = c.tabX + f.slot * kTableCap;
+                double* tv = c.tabV + f.slot * kTableCap;
+                __syncthreads();
+                if (c.lane == 0) { tx[r.tn] = r.pend[f.iter]; tv[r.tn] = rv; r.tn = r.tn + 1; f.iter = f.iter + 1; }
+                __syncthreads();
+                if (f.iter < r.npend) { pc = PC_RANGE_ISSUE; }
+                else {
+                    bool done = range_advance(c, r, tx, tv);
+                    __syncthreads();
+                    if (c.lane == 0) f.iter = 0;
+                    __syncthreads();
+                    if (!done) { pc = PC_RANGE_ISSUE; }
+                    else {
+                        rv = range_finish(c, r, tx, tv);
+                        c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained;
+                        sp--; nrange--;
+                        pc = PC_RETURN;
+                    }
+                }
+            } else {  // SET or BRANCH: ln_sum_exp over members / children (203-217, 319-328)
+                double M = f.accM, S = f.accS;
+                lse_add(M, S, rv);
+                int it = f.iter + 1;
+                __syncthreads();
+                if (c.lane == 0) { f.accM = M; f.accS = S; f.iter = it; }
+                __syncthreads();
+                c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained;
+                if (it < f.n) {
+                    const DevNode& nd = p.nodes[f.node];
+                    if (f.kind == FK_SET) {
+                        int s = nd.sample;
+                        __syncthreads();
+                        if (c.lane == 0) w->ops_vaf[s] = w->setv[s][it];
+                        __syncthreads();
+                        c.present |= (1 << s);
+                        c.disc |= (1 << s);
+                        c.contained = f.sv_contained && spectrum_contains(nd.vafs, p.vafs, w->ops_vaf[s]);
+                        node = f.node;
+                        pc = PC_SUB;
+                    } else {
+                        node = p.child_index[nd.child_off + it];
+                        pc = PC_DESCEND;
+                    }
+                } else {
+                    rv = (M != M) ? M : lse_value(M, S);
+                    sp--;
+                    pc = PC_RETURN;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) vlr_call_kernel(const DevPlan* __restrict__ planp, DevBatch batch, DevResults out,
+                                                       int max_obs, int range_depth) {
+    extern __shared__ double dyn[];
+    __shared__ WaveSt wst;
+    const DevPlan& p = *planp;
+    const int lane = threadIdx.x;
+    const int64_t locus = blockIdx.x;
+    if (locus >= batch.n_loci) return;
+    const int S = p.S;
+    WaveSt* w = &wst;
+
+    Ctx c;
+    c.plan = planp; c.w = w; c.lane = lane; c.S = S;
+    c.cc = dyn; c.cq = dyn + max_obs; c.ce = dyn + 2 * max_obs;
+    c.tabX = dyn + 3 * max_obs;
+    c.tabV = c.tabX + range_depth * kTableCap;
+    c.sx = c.tabV + range_depth * kTableCap;
+    c.sv = c.sx + kTableCap;
+    double* evM = c.sv + kTableCap;
+    double* evS = evM + p.n_univ;
+    double* mapJ = evS + p.n_univ;          // [n_univ]
+    double* mapVaf = mapJ + p.n_univ;       // [n_univ][S]
+    int* mapHyp = (int*)(mapVaf + p.n_univ * S);  // [n_univ]
+    c.status = 0; c.n_eval = 0; c.n_terms = 0;
+
+    const unsigned lf = batch.locus_flags[locus];
+    c.vt = batch.variant_type ? batch.variant_type[locus] : 0;
+    if (c.vt >= kNVariantTypes) c.vt = VLR_VT_OTHER;
+    c.has_snv = (lf & VLR_LOCUS_HAS_SNV) != 0;
+    c.refbase = batch.ref_base ? batch.ref_base[locus] : 0;
+    c.altbase = batch.alt_base ? batch.alt_base[locus] : 0;
+    const bool remove_nonstd = (lf & VLR_LOCUS_REMOVE_NONSTANDARD) != 0;
+    const unsigned bias_mask = lf & 0x3f;
+
+    // ============================ phase A: pileup statistics ============================
+    // (preprocess_record's pileup edits calling.rs:581-625; gating inputs bias/*.rs; all predicates use
+    //  the ORIGINAL prob_alt/prob_ref, read_observation.rs:425-452)
+    int n_alt_like = 0, total_kept = 0, filtered = 0;
+    int n_uncertain = 0, strong_ref_std = 0, strong_ref_f1r2 = 0;        // read_orientation_bias.rs:38-97
+    int n_alt_s = 0, nm_alt = 0, n_ref_s = 0, nm_ref = 0;                 // alt_locus_bias.rs:124-144
+    bool any_altloci = false, any_softclip = false;
+    unsigned possible = 0;                                                 // bit h: some obs is bias evidence under h
+    unsigned possible_alb_noloci = 0;
+    LseAcc sb_all{VLR_NEG_INF, 0.0}, sb_fwd{VLR_NEG_INF, 0.0};            // strand_bias.rs:79-123
+    int offset_acc = 0;
+    bool too_deep = false;
+    for (int s = 0; s < S; ++s) {
+        const int64_t pidx = locus * S + s;
+        const uint32_t o0 = batch.obs_offset[pidx], o1 = batch.obs_offset[pidx + 1];
+        int nk = 0, allref = 1, allpos = 1, sall = 0, anysa = 0, ins = 0, del = 0;
+        int sbias[kNHyp];
+        int sbias_alb_noloci = 0;
+        for (int h = 0; h < kNHyp; ++h) sbias[h] = 0;
+        LseAcc pa_all{VLR_NEG_INF, 0.0}, pa_major{VLR_NEG_INF, 0.0}, pa_rate{VLR_NEG_INF, 0.0};
+        for (uint32_t base = o0; base < o1; base += 64) {
+            uint32_t i = base + lane;
+            bool valid = i < o1;
+            double pm = 0, pa = 0, pr = 0, phb = 0;
+            uint32_t f = 0;
+            if (valid) {
+                pm = batch.pm[i]; pa = batch.pa[i]; pr = batch.pr[i]; phb = batch.phb[i];
+                f = batch.flags[i];
+            }
+            bool keep = valid && !(remove_nonstd && f_orient(f) == VLR_ORIENT_OTHER);  // pileup.rs:26-43
+            filtered += popc64(__ballot(valid && !keep));
+            double bf_ref = exp(pr - pa), bf_alt = exp(pa - pr);
+            bool strong_ref = keep && bf_ref > 20.0;       // read_observation.rs:434-437 (KassRaftery >= Strong)
+            bool strong_alt = keep && bf_alt > 20.0;       // 429-432
+            bool pos_ref = bf_ref > 3.0;                   // 443-446
+            bool ref_sup = pr > pa;                        // 439-441
+            bool uniq = pm >= kLn095;                      // 425-427
+            nk += popc64(__ballot(keep));
+            n_alt_like += popc64(__ballot(keep && pa > pr));
+            if (__ballot(keep && !ref_sup)) allref = 0;
+            if (__ballot(keep && !pos_ref)) allpos = 0;
+            bool sa_u = strong_alt && uniq;
+            sall += popc64(__ballot(sa_u));
+            if (__ballot(strong_alt)) anysa = 1;
+            int hl = f_hplen(f);
+            if (__ballot(keep && hl > 0)) ins = 1;
+            if (__ballot(keep && hl < 0)) del = 1;
+            int orient = f_orient(f), strand = f_strand(f);
+            bool std_or = orient == VLR_ORIENT_F1R2 || orient == VLR_ORIENT_F2R1;
+            n_uncertain += popc64(__ballot(keep && !std_or));
+            strong_ref_std += popc64(__ballot(strong_ref && std_or));
+            strong_ref_f1r2 += popc64(__ballot(strong_ref && orient == VLR_ORIENT_F1R2));
+            bool maxq = (f & VLR_F_MAX_MAPQ) != 0;
+            n_alt_s += popc64(__ballot(strong_alt));
+            nm_alt += popc64(__ballot(strong_alt && !maxq));
+            n_ref_s += popc64(__ballot(strong_ref));
+            nm_ref += popc64(__ballot(strong_ref && !maxq));
+            if (__ballot(keep && f_altlocus(f) != VLR_ALTLOCUS_NONE)) any_altloci = true;
+            if (__ballot(keep && (f & VLR_F_SOFTCLIPPED))) any_softclip = true;
+            for (int h = 1; h < kNHyp; ++h) {
+                if (h == H_HE) continue;
+                bool ev = bias_evidence(h, f, true);
+                if (__ballot(keep && ev)) possible |= (1u << h);
+                sbias[h] += popc64(__ballot(sa_u && ev));
+            }
+            {
+                bool ev = bias_evidence(H_ALB, f, false);
+                if (__ballot(keep && ev)) possible_alb_noloci = 1;
+                sbias_alb_noloci += popc64(__ballot(sa_u && ev));
+            }
+            lseacc_chunk(sb_all, pm, strong_ref && strand != VLR_STRAND_BOTH);
+            lseacc_chunk(sb_fwd, pm, strong_ref && strand == VLR_STRAND_FORWARD);
+            lseacc_chunk(pa_all, pm, strong_ref);
+            lseacc_chunk(pa_major, pm, strong_ref && (f & VLR_F_READPOS_MAJOR));
+            lseacc_chunk(pa_rate, pm + phb, strong_ref);
+        }
+        if (lane == 0) {
+            w->nkeep[s] = nk; w->soff[s] = offset_acc;
+            w->all_ref[s] = allref; w->all_posref[s] = allpos; w->strong_all[s] = sall;
+            w->any_strong_alt[s] = anysa; w->has_ins[s] = ins; w->has_del[s] = del;
+            for (int h = 0; h < kNHyp; ++h) w->strong_bias[s][h] = sbias[h];
+            w->strong_bias[s][0] = sbias_alb_noloci;  // slot 0 reused: alt-locus evidence without alt loci
+            w->pos_all[s] = lseacc_exp(pa_all); w->pos_major[s] = lseacc_exp(pa_major); w->pos_rate[s] = lseacc_exp(pa_rate);
+        }
+        offset_acc += nk;
+        total_kept += nk;
+    }
+    if (offset_acc > max_obs) too_deep = true;
+    __syncthreads();
+    if (filtered > 0) c.status |= VLR_LOCUS_FILTERED_ALN;
+    if (total_kept == 0) c.status |= VLR_LOCUS_MISSING_DATA;
+    const bool singleton = (n_alt_like == 1);  // adjust_singleton_evidence (read_observation.rs:548-562)
+    if (singleton) c.status |= VLR_LOCUS_SINGLETON_ADJ;
+
+    // ---- learn_parameters (bias/mod.rs:295-300)
+    double forward_rate = 0.5;
+    bool sb_informative = false;
+    {
+        double strong_all_f = lseacc_exp(sb_all), strong_fwd_f = lseacc_exp(sb_fwd);
+        if (strong_all_f > 2.0) {
+            double ff = strong_fwd_f / strong_all_f;
+            if (strong_all_f > 100.0 && ff > 0.0 && ff < 1.0) { forward_rate = ff; sb_informative = true; }
+            else if (ff >= 0.4 && ff <= 0.6) { forward_rate = 0.5; sb_informative = true; }
+        }
+    }
+    const bool has_alt_loci = any_altloci;
+
+    // ---- gating (modes/generic.rs:443-448; bias/mod.rs:232-257)
+    unsigned enabled = 0;  // hypotheses in the event's bias list (bias/mod.rs:131-218)
+    if (bias_mask & VLR_BIAS_ALTLOCUS) enabled |= 1u << H_ALB;
+    if (bias_mask & VLR_BIAS_HOMOPOLYMER) enabled |= 1u << H_HE;
+    if (bias_mask & VLR_BIAS_SOFTCLIP) enabled |= 1u << H_SCB;
+    if (bias_mask & VLR_BIAS_POSITION) enabled |= 1u << H_RPB;
+    if (bias_mask & VLR_BIAS_ORIENTATION) enabled |= (1u << H_F1R2) | (1u << H_F2R1);
+    if (bias_mask & VLR_BIAS_STRAND) enabled |= (1u << H_SBF) | (1u << H_SBR);
+    const int n_biases = __popc(enabled);
+    unsigned surviving = 0;
+    if (!too_deep) {
+        bool he_inf = true;  // homopolymer_error.rs:46-72
+        for (int s = 0; s < S; ++s) he_inf = he_inf && (!w->any_strong_alt[s] || (w->has_ins[s] && w->has_del[s]));
+        bool rob_inf;
+        {
+            bool enough = (double)n_uncertain < ((double)total_kept / 2.0);
+            bool uniform = false;
+            if (strong_ref_std > 2) {
+                double fr = (double)strong_ref_f1r2 / (double)strong_ref_std;
+                uniform = fr >= 0.3 && fr <= 0.7;
+            }
+            rob_inf = enough && uniform;
+        }
+        bool rpb_inf = false;  // read_position_bias.rs:63-122
+        for (int s = 0; s < S; ++s) {
+            double ea = w->pos_all[s];
+            if (ea > 10.0) {
+                double em = w->pos_major[s], er = w->pos_rate[s];
+                double major_rate = em / ea;
+                if (em > 0.0 && fabs(major_rate - er) < 0.05) rpb_inf = true;
+            }
+        }
+        bool alb_inf;
+        {
+            bool enough_alt = n_alt_s > 0 && (double)nm_alt > ((double)n_alt_s * 0.1) && (n_alt_s - nm_alt) < 10;
+            bool enough_ref = n_ref_s > 0 && ((double)nm_ref < ((double)n_ref_s * 0.9));
+            alb_inf = enough_alt && (has_alt_loci || enough_ref);
+        }
+        for (int h = 1; h < kNHyp; ++h) {
+            if (!(enabled & (1u << h))) continue;
+            bool ok;
+            if (h == H_HE) ok = he_inf;  // is_possible = is_likely = is_informative (homopolymer_error.rs:74-80)
+            else {
+                bool poss = (h == H_ALB && !has_alt_loci) ? (possible_alb_noloci != 0) : ((possible >> h) & 1u);
+                bool inf = (h == H_ALB) ? alb_inf : (h == H_SCB) ? any_softclip : (h == H_RPB) ? rpb_inf
+                           : (h == H_F1R2 || h == H_F2R1) ? rob_inf : sb_informative;
+                bool likely = false;  // bias/mod.rs:60-104
+                for (int s = 0; s < S; ++s) {
+                    int sa = w->strong_all[s];
+                    int sbv = (h == H_ALB && !has_alt_loci) ? w->strong_bias[s][0] : w->strong_bias[s][h];
+                    bool r;
+                    if (sa >= 10) r = ((double)sbv / (double)sa) >= 0.66666;
+                    else if (w->all_ref[s]) r = false;
+                    else if (w->nkeep[s] == 0) r = false;
+                    else r = true;
+                    likely = likely || r;
+                }
+                ok = poss && inf && likely;
+            }
+            if (ok) surviving |= (1u << h);
+        }
+    }
+
+    // ============================ phase B: hypotheses x events ============================
+    for (int u = lane; u < p.n_univ; u += 64) { evM[u] = VLR_NEG_INF; evS[u] = 0.0; mapJ[u] = VLR_NEG_INF; mapHyp[u] = -1; }
+    __syncthreads();
+
+    if (too_deep) c.status |= VLR_LOCUS_TOO_DEEP;
+    const unsigned hyps = too_deep ? 0u : (1u | surviving);
+    for (int h = 0; h < kNHyp; ++h) {
+        if (!((hyps >> h) & 1u)) continue;
+        c.hyp = h;
+        // ---- per-observation affine coefficients for this hypothesis -> LDS
+        // L_i(alpha, beta) = c_i + q_i*alpha + e_i*beta with
+        //   w = e^pm, u = (1-w) * e^(missed + b_any), A = e^(pa + b_alt), R = e^(pr + b_ref), s = e^prob_sample_alt
+        //   c = w*R + u, q = w*s*(A-R), e = w*(1-s)*(A-R)
+        // (likelihood.rs:43-53,86-115,171-220; bias factors bias/mod.rs:259-284)
+        for (int s = 0; s < S; ++s) {
+            const int64_t pidx = locus * S + s;
+            const uint32_t o0 = batch.obs_offset[pidx], o1 = batch.obs_offset[pidx + 1];
+            int wr = w->soff[s];
+            for (uint32_t base = o0; base < o1; base += 64) {
+                uint32_t i = base + lane;
+                bool valid = i < o1;
+                uint32_t f = valid ? batch.flags[i] : 0u;
+                bool keep = valid && !(remove_nonstd && f_orient(f) == VLR_ORIENT_OTHER);
+                unsigned long long km = __ballot(keep);
+                int pos = wr + popc64(km & ((1ull << lane) - 1ull));
+                if (keep) {
+                    double pm = batch.pm[i], pa = batch.pa[i], pr = batch.pr[i], miss = batch.miss[i];
+                    double psa = batch.psa[i], pdo = batch.pdo[i], phb = batch.phb[i];
+                    double hpa = batch.hpa ? (double)batch.hpa[i] : __builtin_nan("");
+                    double hpv = batch.hpv ? (double)batch.hpv[i] : __builtin_nan("");
+                    if (singleton && pa > pr) { pa = kLn05; pr = kLn05; }  // prob_alt_adj / prob_ref_adj
+                    int strand = f_strand(f), orient = f_orient(f);
+                    bool major = (f & VLR_F_READPOS_MAJOR) != 0;
+                    // read position: prob_any (read_position_bias.rs:27-37,51-62)
+                    double one_minus_hit = (phb != 0.0) ? -expm1(phb) : 1.0;
+                    double rp_any = major ? exp(phb) : one_minus_hit;
+                    // linear-space bias factors for alt / ref / any
+                    double fa, fr, fany;
+                    // strand (strand_bias.rs:30-58)
+                    double sb_alt;
+                    if (h == H_SBF) sb_alt = (strand == VLR_STRAND_FORWARD || strand == VLR_STRAND_NONE) ? 1.0 : 0.0;
+                    else if (h == H_SBR) sb_alt = (strand == VLR_STRAND_REVERSE || strand == VLR_STRAND_NONE) ? 1.0 : 0.0;
+                    else if (strand == VLR_STRAND_BOTH) sb_alt = exp(pdo);
+                    else if (strand == VLR_STRAND_NONE) sb_alt = 1.0;
+                    else {
+                        double rate = (strand == VLR_STRAND_FORWARD) ? forward_rate : 1.0 - forward_rate;
+                        sb_alt = rate * (-expm1(pdo));  // ln(rate) + prob_single_overlap
+                    }
+                    // orientation (read_orientation_bias.rs:18-36)
+                    double ro_alt = 0.5;
+                    if (h == H_F1R2) ro_alt = (orient == VLR_ORIENT_F1R2) ? 1.0 : (orient == VLR_ORIENT_F2R1) ? 0.0 : 0.5;
+                    else if (h == H_F2R1) ro_alt = (orient == VLR_ORIENT_F2R1) ? 1.0 : (orient == VLR_ORIENT_F1R2) ? 0.0 : 0.5;
+                    // position (read_position_bias.rs:18-25)
+                    double rp_alt = (h == H_RPB) ? (major ? 1.0 : 0.0) : rp_any;
+                    // softclip (softclip_bias.rs:15-29)
+                    double sc_alt = (h == H_SCB) ? ((f & VLR_F_SOFTCLIPPED) ? 1.0 : 0.0) : 1.0;
+                    // homopolymer (homopolymer_error.rs:23-44): prob_ref = prob_alt, prob_any = 1
+                    double he_lp = (h == H_HE) ? hpa : hpv;
+                    double he_alt = (he_lp == he_lp) ? exp(he_lp) : 1.0;
+                    // alt locus (alt_locus_bias.rs:63-113)
+                    double al_alt = 0.5, al_ref = 0.5;
+                    if (h == H_ALB) {
+                        if (has_alt_loci) {
+                            bool mj = f_altlocus(f) == VLR_ALTLOCUS_MAJOR;
+                            al_alt = mj ? 1.0 : 0.0;
+                            al_ref = mj ? 0.0 : 1.0;
+                        } else {
+                            al_alt = (f & VLR_F_MAX_MAPQ) ? 0.0 : 1.0;
+                            al_ref = 0.5;
+                        }
+                    }
+                    fa = sb_alt * ro_alt * rp_alt * sc_alt * he_alt * al_alt;
+                    fr = 0.5 * 0.5 * rp_any * 1.0 * he_alt * al_ref;
+                    fany = 0.5 * 0.5 * rp_any * 0.5;
+                    double wv = exp(pm);
+                    double mis = -expm1(pm);  // prob_mismapping = ln_one_minus_exp(pm) (read_observation.rs:283-286)
+                    double A = exp(pa) * fa, R = exp(pr) * fr;
+                    double uu = mis * exp(miss) * fany;
+                    double sv = exp(psa);
+                    if ((A == 0.0 && fa != 0.0 && pa > VLR_NEG_INF) || (R == 0.0 && fr != 0.0 && pr > VLR_NEG_INF))
+                        c.status |= VLR_LOCUS_UNDERFLOW;
+                    double d = A - R;
+                    if (pos < max_obs) {
+                        c.cc[pos] = wv * R + uu;
+                        c.cq[pos] = wv * sv * d;
+                        c.ce[pos] = wv * (1.0 - sv) * d;
+                    }
+                }
+                wr += popc64(km);
+            }
+        }
+        if (lane < S) w->cacheN[lane] = 0;
+        __syncthreads();
+        if (__ballot((c.status & VLR_LOCUS_UNDERFLOW) != 0)) c.status |= VLR_LOCUS_UNDERFLOW;
+
+        // ---- events (calling.rs:654-687): absent + clean events under h = none, artifact twins otherwise
+        const double bias_prior = (h == 0) ? kLn05 : kLn05 + log(1.0 / (double)n_biases);  // modes/generic.rs:437-441
+        const int first_ev = (h == 0) ? -1 : 0;
+        for (int e = first_ev; e < p.n_named; ++e) {
+            int u = (e < 0) ? 0 : (1 + 2 * e + (h == 0 ? 0 : 1));
+            int r0 = (e < 0) ? 0 : p.root_off[e], r1 = (e < 0) ? 1 : p.root_off[e + 1];
+            c.curJ = mapJ[u];
+            c.curHyp = mapHyp[u];
+            __syncthreads();
+            if (lane < S) w->curMapVaf[lane] = mapVaf[u * S + lane];
+            __syncthreads();
+            double M = evM[u], Sx = evS[u];
+            for (int ri = r0; ri < r1; ++ri) {
+                int root = (e < 0) ? p.absent_root : p.roots[ri];
+                double dens = walk_root(c, root);
+                if (dens != dens) c.status |= VLR_LOCUS_NAN;
+                lse_add(M, Sx, bias_prior + dens);
+            }
+            __syncthreads();
+            if (lane == 0) { evM[u] = M; evS[u] = Sx; mapJ[u] = c.curJ; mapHyp[u] = c.curHyp; }
+            if (lane < S) mapVaf[u * S + lane] = w->curMapVaf[lane];
+            __syncthreads();
+        }
+    }
+
+    // ============================ phase C: posteriors + MAP ============================
+    // bio Model::compute: marginal = ln_sum_exp(event values); posterior = value - marginal
+    const int n_out = p.n_named + 2;
+    double mM = VLR_NEG_INF, mS = 0.0;
+    for (int u = 0; u < p.n_univ; ++u) {
+        double v = (evM[u] != evM[u]) ? evM[u] : lse_value(evM[u], evS[u]);
+        lse_add(mM, mS, v);
+    }
+    double marginal = (mM != mM) ? mM : lse_value(mM, mS);
+    if (marginal != marginal) c.status |= VLR_LOCUS_NAN;
+    // call_record (calling.rs:762-803)
+    int best = 0;
+    double best_post = VLR_NEG_INF;
+    double aM = VLR_NEG_INF, aS = 0.0;
+    bool have_twins = n_biases > 0;
+    for (int u = 0; u < p.n_univ; ++u) {
+        bool twin = (u > 0) && ((u & 1) == 0);
+        if (twin && !have_twins) continue;
+        double v = lse_value(evM[u], evS[u]);
+        double post = v - marginal;
+        if (u == 0 || !(post < best_post)) { best = u; best_post = post; }  // last maximum wins (itertools minmax)
+        if (twin) lse_add(aM, aS, post);
+    }
+    double prob_artifact = lse_value(aM, aS);
+    bool is_artifact = true;
+    for (int u = 0; u < p.n_univ; ++u) {
+        bool twin = (u > 0) && ((u & 1) == 0);
+        if (twin) continue;
+        double post = lse_value(evM[u], evS[u]) - marginal;
+        if (!(post < prob_artifact)) is_artifact = false;
+    }
+    double* lp = out.ln_posterior + locus * n_out;
+    if (lane == 0) {
+        lp[0] = lse_value(evM[0], evS[0]) - marginal;
+        for (int e = 0; e < p.n_named; ++e) lp[1 + e] = lse_value(evM[1 + 2 * e], evS[1 + 2 * e]) - marginal;
+        lp[n_out - 1] = prob_artifact;
+        if (out.ln_marginal) out.ln_marginal[locus] = marginal;
+        if (out.best_event) out.best_event[locus] = best;
+    }
+    // sample_infos (calling.rs:844-937): MAP among operands of the best event's tree (clean + twin share it)
+    {
+        int uc = (best == 0) ? 0 : (((best - 1) / 2) * 2 + 1);
+        int ua = (best == 0) ? -1 : uc + 1;
+        int pick = -1;
+        if (mapHyp[uc] >= 0) pick = uc;
+        if (ua >= 0 && is_artifact && have_twins && mapHyp[ua] >= 0) {
+            if (pick < 0) pick = ua;
+            else {
+                // same comparator as map_consider: prob desc, then lower hypothesis id (clean = 0 wins ties)
+                if (mapJ[ua] > mapJ[uc]) pick = ua;
+            }
+        }
+        if (lane < S) {
+            double v = __builtin_nan("");
+            if (pick >= 0) v = (mapHyp[pick] > 0) ? 0.0 : mapVaf[pick * S + lane];
+            out.map_vaf[locus * S + lane] = v;
+        }
+        if (out.map_bias && lane == 0) {
+            uint8_t* mb = out.map_bias + locus * VLR_N_BIAS;
+            for (int i = 0; i < VLR_N_BIAS; ++i) mb[i] = 0;
+            int hh = pick >= 0 ? mapHyp[pick] : 0;
+            switch (hh) {
+                case H_SBF: mb[0] = 1; break;
+                case H_SBR: mb[0] = 2; break;
+                case H_F1R2: mb[1] = 1; break;
+                case H_F2R1: mb[1] = 2; break;
+                case H_RPB: mb[2] = 1; break;
+                case H_SCB: mb[3] = 1; break;
+                case H_HE: mb[4] = 1; break;
+                case H_ALB: mb[5] = 1; break;
+                default: break;
+            }
+        }
+    }
+    if (lane == 0) {
+        out.status[locus] = c.status;
+        if (out.work) {
+            atomicAdd(&out.work[0], c.n_eval);
+            atomicAdd(&out.work[1], c.n_terms);
+        }
+    }
+}
+
+}  // namespace vlr
+
+// host-callable launcher (used by vlr_host.cpp)
+extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_dev, const vlr::DevBatch* batch, const vlr::DevResults* out,
+                                      int n_univ, int n_samples, int max_obs, int range_depth, void* stream) {
+    using namespace vlr;
+    if (batch->n_loci <= 0) return 0;
+    if (range_depth < 1) range_depth = 1;
+    size_t dbl = (size_t)3 * max_obs + (size_t)2 * range_depth * kTableCap + 2 * kTableCap + (size_t)3 * n_univ +
+                 (size_t)n_univ * n_samples + (size_t)(n_univ + 1) / 2 + 2;
+    size_t bytes = dbl * sizeof(double);
+    hipError_t e = hipFuncSetAttribute((const void*)vlr_call_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+    dim3 grid((unsigned)batch->n_loci), block(64);
+    hipLaunchKernelGGL(vlr_call_kernel, grid, block, bytes, (hipStream_t)stream, plan_dev, *batch, *out, max_obs, range_depth);
+    return (int)hipGetLastError();
+}

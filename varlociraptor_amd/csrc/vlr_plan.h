@@ -1,0 +1,87 @@
+// vlr_plan.h — device-visible plan layout shared by the host plan compiler (vlr_host.cpp) and the
+// gfx950 kernels (vlr_kernels.hip).  Not part of the public ABI (that is include/vlr.h).
+#pragma once
+#include <stdint.h>
+
+namespace vlr {
+
+constexpr int kMaxSamples = 8;        // == VLR_MAX_SAMPLES
+constexpr int kMaxLfc = 4;            // LFC terms on one root->leaf path
+constexpr int kMaxFrames = 24;        // explicit recursion stack of the VAF-tree walk
+constexpr int kTableCap = 128;        // visited points of one range chain (57 at resolution 0.01)
+constexpr int kMaxRangeDepth = 4;     // nested Range levels on one path
+constexpr int kMaxSet = 16;           // members of one Set spectrum
+constexpr int kMaxNamedEvents = 31;   // scenario events (engine universe = 1 + 2*named)
+constexpr int kNHyp = 9;              // 0 = Artifacts::none(), 1..8 single-artifact combinations
+constexpr int kCacheWays = 4;         // per-sample pileup-likelihood cache entries
+constexpr int kMaxBatchPoints = 16;   // points evaluated by one eval_pileup call
+constexpr int kNVariantTypes = 5;
+
+// hypothesis slots, in the cartesian order of Artifacts::all_artifact_combinations
+// (reference src/variants/model/bias/mod.rs:131-218; alt-locus varies fastest)
+enum Hyp { H_NONE = 0, H_ALB = 1, H_HE = 2, H_SCB = 3, H_RPB = 4, H_F1R2 = 5, H_F2R1 = 6, H_SBF = 7, H_SBR = 8 };
+
+struct DevSpectrum {
+    int32_t kind;  // 0 set, 1 range
+    int32_t set_off, set_len;
+    int32_t lex, rex;
+    int32_t pad;
+    double start, end;
+};
+
+struct DevNode {
+    int32_t kind, sample, sample_b, cmp;
+    double lfc_value;
+    DevSpectrum vafs;
+    int32_t positive;
+    int32_t refbase, altbase;
+    int32_t child_off, n_children;
+    int32_t pad;
+};
+
+// prior "class" per sample: the reference's Prior::compute
+// (src/variants/model/prior.rs:298-438,715-762) depends on a VAF only through equality tests with
+// k/ploidy and universe membership, so it is tabulated on the host over per-sample classes.
+enum PriorKind { PK_UNIFORM = 0, PK_GERMLINE = 1, PK_SOMATIC = 2 };
+
+struct DevPlan {
+    int32_t S, n_named, n_univ, absent_root;
+    int32_t n_nodes, max_range_depth, table_size, pad0;
+    double resolution[kMaxSamples];
+    double rho[kMaxSamples];   // purity (1 - contamination fraction); 1 for uncontaminated samples
+    double irho[kMaxSamples];  // 1 - purity
+    int32_t by[kMaxSamples];   // contaminant sample or -1
+    int32_t uni_off[kMaxSamples + 1];
+    int32_t prior_kind[kMaxSamples];
+    int32_t ploidy[kMaxSamples];
+    int32_t n_class[kMaxSamples];
+    int32_t class_stride[kMaxSamples];
+    const DevNode* nodes;
+    const int32_t* child_index;
+    const double* vafs;
+    const int32_t* roots;       // root node ids, absent root NOT included
+    const int32_t* root_off;    // [n_named + 1]
+    const DevSpectrum* universe;
+    const double* prior_table;  // [kNVariantTypes][table_size]
+};
+
+// SoA observation columns + per-locus columns (device pointers), mirrors vlr_batch
+struct DevBatch {
+    int64_t n_loci;
+    const uint32_t* obs_offset;
+    const float *pm, *pa, *pr, *miss, *psa, *pdo, *phb, *hpa, *hpv;
+    const uint32_t* flags;
+    const uint8_t *locus_flags, *variant_type, *ref_base, *alt_base;
+};
+
+struct DevResults {
+    double* ln_posterior;  // [n_loci * (n_named + 2)]
+    double* ln_marginal;   // nullable
+    double* map_vaf;       // [n_loci * S]
+    uint8_t* map_bias;     // [n_loci * 6] nullable
+    int32_t* best_event;   // nullable
+    uint32_t* status;
+    unsigned long long* work;  // nullable: [0] pileup evaluations, [1] observation terms (profiling aid)
+};
+
+}  // namespace vlr

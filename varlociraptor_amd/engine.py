@@ -1,0 +1,193 @@
+"""ctypes binding of the engine's C ABI (varlociraptor_amd/libvlr.so, include/vlr.h).
+
+Host-side mirror of the reference interface for the hot path: a `Caller` is configured with a
+scenario (like CallerBuilder, src/calling/variants/calling.rs:52-81) and `call()` evaluates a batch
+of records (Caller::call_record, calling.rs:720-842).  The library must be built (`build()`); there
+is no Python/CPU fallback — importing works without a GPU, creating a plan does not.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import numpy as np
+
+from . import abi
+from .batch import CallResults, PileupBatch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvlr.so")
+_LIB = None
+
+EXPORTS = [
+    "vlr_abi_version", "vlr_last_error", "vlr_plan_create", "vlr_plan_destroy", "vlr_plan_n_out",
+    "vlr_plan_n_samples", "vlr_plan_set_max_depth", "vlr_batch_run", "vlr_batch_run_host",
+    "vlr_plan_last_kernel_ms", "vlr_plan_work_counters",
+]
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("vlr error %d: %s" % (code, msg))
+        self.code = code
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(src_dir, f) for f in ("vlr_kernels.hip", "vlr_host.cpp", "vlr_plan.h")] + [os.path.join(_HERE, "..", "include", "vlr.h")]
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["make", "-C", src_dir, "-B"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(abi.ERR_NO_DEVICE, "libvlr.so is not built (run varlociraptor_amd.engine.build()); no fallback path exists")
+        L = C.CDLL(LIB_PATH)
+        L.vlr_abi_version.restype = C.c_int
+        L.vlr_last_error.restype = C.c_char_p
+        L.vlr_plan_create.restype = C.c_int
+        L.vlr_plan_create.argtypes = [C.POINTER(abi.ScenarioDesc), C.c_int, C.POINTER(C.c_void_p)]
+        L.vlr_plan_destroy.restype = None
+        L.vlr_plan_destroy.argtypes = [C.c_void_p]
+        L.vlr_plan_n_out.restype = C.c_int
+        L.vlr_plan_n_out.argtypes = [C.c_void_p]
+        L.vlr_plan_n_samples.restype = C.c_int
+        L.vlr_plan_n_samples.argtypes = [C.c_void_p]
+        L.vlr_plan_set_max_depth.restype = C.c_int
+        L.vlr_plan_set_max_depth.argtypes = [C.c_void_p, C.c_int]
+        L.vlr_batch_run.restype = C.c_int
+        L.vlr_batch_run.argtypes = [C.c_void_p, C.POINTER(abi.Batch), C.POINTER(abi.Results), C.c_void_p]
+        L.vlr_batch_run_host.restype = C.c_int
+        L.vlr_batch_run_host.argtypes = [C.c_void_p, C.POINTER(abi.Batch), C.POINTER(abi.Results)]
+        L.vlr_plan_last_kernel_ms.restype = C.c_int
+        L.vlr_plan_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.vlr_plan_work_counters.restype = C.c_int
+        L.vlr_plan_work_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
+        if L.vlr_abi_version() != abi.ABI_VERSION:
+            raise EngineError(abi.ERR_INVALID_ARGUMENT, "ABI version mismatch")
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise EngineError(rc, lib().vlr_last_error().decode())
+
+
+class Plan:
+    """vlr_plan: a scenario compiled for one contig on one device."""
+
+    def __init__(self, scenario, device: int = 0, max_depth: Optional[int] = None):
+        self.scenario = scenario
+        self.device = device
+        self._h = C.c_void_p()
+        desc = scenario.desc()
+        _check(lib().vlr_plan_create(C.byref(desc), device, C.byref(self._h)))
+        self.n_out = lib().vlr_plan_n_out(self._h)
+        self.n_samples = lib().vlr_plan_n_samples(self._h)
+        if max_depth is not None:
+            self.set_max_depth(max_depth)
+
+    def set_max_depth(self, depth: int):
+        _check(lib().vlr_plan_set_max_depth(self._h, int(depth)))
+
+    def close(self):
+        if self._h:
+            lib().vlr_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host buffers in, host buffers out (stages through the device; synchronous)
+    def call_host(self, batch: PileupBatch) -> CallResults:
+        res = CallResults(batch.n_loci, self.n_out, self.n_samples)
+        bs, rs = batch.as_struct(), res.as_struct()
+        _check(lib().vlr_batch_run_host(self._h, C.byref(bs), C.byref(rs)))
+        return res
+
+    # ---- device pointers (torch tensors) in/out, stream-ordered
+    def call_device(self, dbatch: "DeviceBatch", out: "DeviceResults", stream=None):
+        bs, rs = dbatch.as_struct(), out.as_struct()
+        _check(lib().vlr_batch_run(self._h, C.byref(bs), C.byref(rs), C.c_void_p(stream) if stream else None))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        _check(lib().vlr_plan_last_kernel_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def work_counters(self, reset: bool = False):
+        out = (C.c_ulonglong * 2)()
+        _check(lib().vlr_plan_work_counters(self._h, out, int(reset)))
+        return int(out[0]), int(out[1])
+
+
+class DeviceBatch:
+    """vlr_batch whose columns are torch tensors resident in HBM (plumbing only)."""
+
+    def __init__(self, batch: PileupBatch, device="cuda:0"):
+        import torch
+        self.n_loci, self.n_samples, self.n_obs = batch.n_loci, batch.n_samples, batch.n_obs
+        self.t = {}
+        self.t["obs_offset"] = torch.from_numpy(batch.obs_offset.view(np.int32)).to(device)
+        for name, _ in abi.OBS_COLUMNS:
+            a = batch.columns[name]
+            self.t[name] = torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).to(device)
+        for name, _ in abi.LOCUS_COLUMNS:
+            self.t[name] = torch.from_numpy(batch.locus[name]).to(device)
+        self._algorithmic_bytes = batch.algorithmic_bytes()
+
+    def algorithmic_bytes(self):
+        return self._algorithmic_bytes
+
+    def as_struct(self) -> abi.Batch:
+        b = abi.Batch()
+        b.n_loci, b.n_samples, b.n_obs = self.n_loci, self.n_samples, self.n_obs
+        b.obs_offset = self.t["obs_offset"].data_ptr()
+        for name, _ in abi.OBS_COLUMNS:
+            setattr(b, name, self.t[name].data_ptr())
+        for name, _ in abi.LOCUS_COLUMNS:
+            setattr(b, name, self.t[name].data_ptr())
+        return b
+
+
+class DeviceResults:
+    def __init__(self, n_loci, n_out, n_samples, device="cuda:0"):
+        import torch
+        self.n_loci, self.n_out, self.n_samples = n_loci, n_out, n_samples
+        self.ln_posterior = torch.empty((n_loci, n_out), dtype=torch.float64, device=device)
+        self.ln_marginal = torch.empty(n_loci, dtype=torch.float64, device=device)
+        self.map_vaf = torch.empty((n_loci, n_samples), dtype=torch.float64, device=device)
+        self.map_bias = torch.empty((n_loci, abi.N_BIAS), dtype=torch.uint8, device=device)
+        self.best_event = torch.empty(n_loci, dtype=torch.int32, device=device)
+        self.status = torch.empty(n_loci, dtype=torch.int32, device=device)
+
+    def as_struct(self) -> abi.Results:
+        r = abi.Results()
+        r.n_loci, r.n_out, r.n_samples = self.n_loci, self.n_out, self.n_samples
+        r.ln_posterior = self.ln_posterior.data_ptr()
+        r.ln_marginal = self.ln_marginal.data_ptr()
+        r.map_vaf = self.map_vaf.data_ptr()
+        r.map_bias = self.map_bias.data_ptr()
+        r.best_event = self.best_event.data_ptr()
+        r.status = self.status.data_ptr()
+        return r
+
+    def to_host(self) -> CallResults:
+        res = CallResults(self.n_loci, self.n_out, self.n_samples)
+        res.ln_posterior[:] = self.ln_posterior.cpu().numpy()
+        res.ln_marginal[:] = self.ln_marginal.cpu().numpy()
+        res.map_vaf[:] = self.map_vaf.cpu().numpy()
+        res.map_bias[:] = self.map_bias.cpu().numpy()
+        res.best_event[:] = self.best_event.cpu().numpy()
+        res.status[:] = self.status.cpu().numpy().view(np.uint32)
+        return res
