@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""bench.py — throughput of the per-locus likelihood engine on synthetic pileups (BASELINE.json metric).
+
+One "step" = one pass of the hot path (vlr_batch_run) over the rank's resident batch of candidate
+loci + the all-gather of result records when N > 1.  Workload at N=1: BASELINE configs[2]
+(tumor-normal with contamination, SNV+indel, 100x, 1M loci); weak scaling: every rank gets its own
+1M-locus shard.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F64_VALU_PEAK_TFLOPS = 78.6  # half of the 157.3 TF f32 vector peak (SURVEY.md §8d secondary figure)
+
+
+def _gen_chunk(args):
+    name, n, chunk = args
+    from varlociraptor_amd import synth
+    cfg = synth.CONFIGS[name]()
+    return synth.generate(cfg, n, chunk=chunk)
+
+
+def generate(name, n_loci, rank, chunk_loci=50000, workers=None):
+    from varlociraptor_amd.batch import PileupBatch
+    chunks = []
+    left, k = n_loci, 0
+    while left > 0:
+        m = min(left, chunk_loci)
+        chunks.append((name, m, rank * 100000 + k))
+        left -= m
+        k += 1
+    if len(chunks) == 1:
+        return _gen_chunk(chunks[0])
+    workers = workers or min(len(chunks), max(1, (os.cpu_count() or 8) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+    with ProcessPoolExecutor(max_workers=workers) as ex:
+        parts = list(ex.map(_gen_chunk, chunks))
+    return PileupBatch.concat(parts)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="config3", choices=["config2", "config3", "config4"])
+    ap.add_argument("--loci", type=int, default=None, help="loci per GPU (default: the config's size)")
+    ap.add_argument("--cpu-loci", type=int, default=None, help="loci of the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from varlociraptor_amd import engine, synth
+    from varlociraptor_amd.dist import all_gather_records, pack_records
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+
+    default_loci = {"config2": 100_000, "config3": 1_000_000, "config4": 1_250_000}[args.workload]
+    n_loci = args.loci or default_loci
+    cfg = synth.CONFIGS[args.workload]()
+    t0 = time.time()
+    batch = generate(args.workload, n_loci, rank)
+    t_gen = time.time() - t0
+    dbatch = engine.DeviceBatch(batch, dev)
+    plan = engine.Plan(cfg.scenario, device=local_rank)
+    out = engine.DeviceResults(batch.n_loci, plan.n_out, plan.n_samples, dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    n_total = n_loci * world
+
+    def step():
+        plan.call_device(dbatch, out, stream)
+        if world > 1:
+            rec = pack_records(out.ln_posterior, out.map_vaf, out.status)
+            return all_gather_records(rec, n_total, world)
+        return None
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    plan.work_counters(reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(None)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    # per-launch kernel duration from HIP events recorded on the launch stream inside vlr_batch_run
+    # (the last launch's events; all launches process the same batch)
+    last_ms = plan.last_kernel_ms()
+    n_eval, n_terms = plan.work_counters()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    res = out.to_host()
+    line = None
+    if rank == 0:
+        alg_bytes = dbatch.algorithmic_bytes() + res.ln_posterior.nbytes + res.map_vaf.nbytes + res.status.nbytes
+        achieved = alg_bytes / (last_ms * 1e-3) / 1e9
+        # ---- parity + CPU baseline on a bounded sample of the same workload (rank 0, N = 1 only)
+        parity = None
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle
+            from parity import compare
+            cores = os.cpu_count() or 1
+            per_core = 40 if args.workload != "config2" else 2500
+            n_cpu = args.cpu_loci or min(batch.n_loci, per_core * cores)
+            sub = batch.select(np.arange(n_cpu))
+            bounds = np.linspace(0, n_cpu, cores + 1).astype(int)
+            oracle.lib()
+            sc = cfg.scenario
+            tc = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=cores) as ex:
+                parts = list(ex.map(lambda i: oracle.call(sc, sub, begin=int(bounds[i]), end=int(bounds[i + 1])), range(cores)))
+            t_cpu = time.perf_counter() - tc
+            from varlociraptor_amd.batch import CallResults
+            ref = CallResults(n_cpu, plan.n_out, plan.n_samples)
+            for i, p in enumerate(parts):
+                lo, hi = int(bounds[i]), int(bounds[i + 1])
+                for f in ("ln_posterior", "map_vaf", "map_bias", "best_event", "status"):
+                    getattr(ref, f)[lo:hi] = getattr(p, f)[lo:hi]
+            got = CallResults(n_cpu, plan.n_out, plan.n_samples)
+            for f in ("ln_posterior", "map_vaf", "map_bias", "best_event", "status"):
+                getattr(got, f)[:] = getattr(res, f)[:n_cpu]
+            m = compare(got, ref)
+            parity = {"n_checked": int(n_cpu), "max_abs_dposterior": m["max_dpost"], "max_abs_dmap_vaf": m["max_dvaf"],
+                      "frac_within_1e-6": m["frac_within"], "vs": "CPU restatement of the reference (oracle/)"}
+            cpu = {"value": n_cpu / t_cpu, "unit": "loci/s", "cores": cores, "kind": "port",
+                   "sample": "first %d loci of the same batch, %d threads x contiguous shards, %.1f s" % (n_cpu, cores, t_cpu)}
+        # posteriors must be normalised at full size (size-independent property)
+        ps = np.exp(res.ln_posterior)
+        ok = (res.status & 0xF) == 0
+        norm_err = float(np.abs(ps[ok].sum(axis=1) - 1.0).max()) if ok.any() else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            if tj.get("n_loci") == n_loci:
+                traffic = tj.get("hbm_bytes_per_launch")
+        line = {
+            "metric": "candidate loci/sec (whole node)", "value": n_total * args.steps / elapsed, "unit": "loci/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %s, %d loci/GPU, mean depth %.0fx/sample" % (args.workload, cfg.name, n_loci, cfg.depth),
+                       "scenario_events": cfg.scenario.event_names, "parallelism": "loci sharded x%d, all-gather of result records" % world,
+                       "gen_seconds": round(t_gen, 1)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": last_ms,
+                         "note": "path is f64-VALU/latency bound, not bandwidth bound (SURVEY §8d); see valu"},
+            "valu": {"pileup_evals_per_launch": n_eval // max(1, args.steps), "obs_terms_per_launch": n_terms // max(1, args.steps),
+                     "obs_terms_per_s": (n_terms / max(1, args.steps)) / (last_ms * 1e-3),
+                     "f64_valu_peak_tflops": F64_VALU_PEAK_TFLOPS},
+            "cpu_baseline": cpu, "parity": parity, "posterior_normalisation_max_err": norm_err,
+            "status_counts": {str(k): int(v) for k, v in zip(*np.unique(res.status, return_counts=True))},
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
