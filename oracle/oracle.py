@@ -55,6 +55,10 @@ def lib():
         L.vlro_lik_obs_single.argtypes = [C.POINTER(abi.Batch), C.c_int64, C.c_double]
         L.vlro_lik_obs_contaminated.restype = C.c_double
         L.vlro_lik_obs_contaminated.argtypes = [C.POINTER(abi.Batch), C.c_int64, C.c_double, C.c_double, C.c_double]
+        L.vlro_pileup_lik_single.restype = C.c_double
+        L.vlro_pileup_lik_single.argtypes = [C.POINTER(abi.Batch), C.c_int64, C.c_int64, C.c_double]
+        L.vlro_pileup_lik_contaminated.restype = C.c_double
+        L.vlro_pileup_lik_contaminated.argtypes = [C.POINTER(abi.Batch), C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double]
         L.vlro_bias_prob_ref_none.restype = C.c_double
         L.vlro_bias_prob_ref_none.argtypes = [C.POINTER(abi.Batch), C.c_int64]
         _LIB = L

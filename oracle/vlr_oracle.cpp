@@ -1321,7 +1321,7 @@ int vlro_call_batch(const vlr_scenario_desc* desc, const vlr_batch* in, vlr_resu
         c.has_snv = (lf & VLR_LOCUS_HAS_SNV) != 0;
         c.refbase = in->ref_base ? in->ref_base[l] : 0;
         c.altbase = in->alt_base ? in->alt_base[l] : 0;
-        sc.prior.variant_type = in->variant_type ? in->variant_type[l] : VLR_VT_SNV;
+        sc.prior.variant_type = in->variant_type ? (int)in->variant_type[l] : (int)VLR_VT_SNV;
         uint32_t status = 0;
 
         // ---- preprocess_record (calling.rs:581-625)
@@ -1543,6 +1543,19 @@ double vlro_lik_obs_contaminated(const vlr_batch* b, int64_t i, double purity, d
     Artifacts a;
     double lp = std::log(purity);
     return lik_obs_contaminated(lp, ln_one_minus_exp(lp), std::log(af_p), std::log(af_s), a, a, o);
+}
+// pileup likelihood probes (likelihood.rs:122-157, 227-249) over observations [i0, i1) with Artifacts::none()
+double vlro_pileup_lik_single(const vlr_batch* b, int64_t i0, int64_t i1, double af) {
+    Artifacts a;
+    double lh = 0.0, la = std::log(af);
+    for (int64_t i = i0; i < i1; ++i) lh += lik_obs_single(la, a, make_obs(b, i));
+    return lh;
+}
+double vlro_pileup_lik_contaminated(const vlr_batch* b, int64_t i0, int64_t i1, double purity, double af_p, double af_s) {
+    Artifacts a;
+    double lp = std::log(purity), li = ln_one_minus_exp(lp), la = std::log(af_p), lb = std::log(af_s), lh = 0.0;
+    for (int64_t i = i0; i < i1; ++i) lh += lik_obs_contaminated(lp, li, la, lb, a, a, make_obs(b, i));
+    return lh;
 }
 double vlro_bias_prob_ref_none(const vlr_batch* b, int64_t i) {
     Obs o = make_obs(b, i);

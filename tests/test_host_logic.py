@@ -1,0 +1,151 @@
+"""CPU tests of the host side: scenario/VAF-tree builder, codecs, synthetic generator, C-ABI library
+loading (no compute calls without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from varlociraptor_amd import abi, engine, synth
+from varlociraptor_amd.batch import PileupBatch
+from varlociraptor_amd.dist import shard_range
+from varlociraptor_amd.scenario import (Sample, Scenario, VAFRange, VAFSet, parse_formula, parse_universe, single_sample,
+                                        tumor_normal)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_parse_universe():
+    u = parse_universe("[0.0,0.5[ | 0.5 | 1.0")
+    assert u == [VAFSet((0.5,)), VAFSet((1.0,)), VAFRange(0.0, 0.5, False, True)]  # Sets sort before Ranges
+    assert parse_universe("[0.0,1.0]") == [VAFRange(0.0, 1.0, False, False)]
+    assert parse_universe("{0.0,0.5,1.0}") == [VAFSet((0.0, 0.5, 1.0))]
+    with pytest.raises(ValueError):
+        parse_universe("[0,1]")  # formula.pest: vaf needs a decimal point
+
+
+def test_tumor_normal_trees():
+    """normal = 0, tumor = 1; every event's root is the normal atom, child the tumor range."""
+    sc = tumor_normal(0.75)
+    assert sc.sample_names == ["normal", "tumor"]
+    assert sc.event_names == ["germline_het", "germline_hom", "somatic_normal", "somatic_tumor"]
+    d = sc.desc()
+    assert d.n_events == 4 and d.n_nodes == 8
+    for e in range(4):
+        assert d.event_root_offset[e + 1] - d.event_root_offset[e] == 1
+        root = d.nodes[d.root_index[d.event_root_offset[e]]]
+        assert root.kind == abi.NODE_SAMPLE and root.sample == 0 and root.n_children == 1
+        child = d.nodes[d.child_index[root.child_offset]]
+        assert child.sample == 1 and child.vafs.kind == abi.SPECTRUM_RANGE and child.n_children == 0
+        assert (child.vafs.start, child.vafs.end, child.vafs.left_exclusive, child.vafs.right_exclusive) == (0.0, 1.0, 1, 0)
+    assert d.contaminated_by[1] == 0 and d.contaminated_by[0] == -1
+    assert d.contamination_fraction[1] == pytest.approx(0.25)
+    assert (d.resolution[0], d.resolution[1]) == (0.1, 0.01)
+
+
+def test_missing_samples_are_added_from_the_universe():
+    """grammar/vaftree.rs:246-295 add_missing_samples: one child per universe spectrum."""
+    sc = Scenario({"a": Sample(universe="[0.0,1.0]"), "b": Sample(universe="[0.0,0.5[ | 0.5 | 1.0")}, {"ev": "a:0.5"})
+    roots = sc.vaftree("ev")
+    assert len(roots) == 1 and roots[0].sample == 0
+    assert [type(c.vafs) for c in roots[0].children] == [VAFSet, VAFSet, VAFRange]
+    assert all(c.sample == 1 for c in roots[0].children)
+
+
+def test_formula_parser():
+    f = parse_formula("(tumor:]0.0,1.0] & normal:0.0) | l2fc(tumor,normal) >= 1.5")
+    assert type(f).__name__ == "Disj" and len(f.operands) == 2
+    assert parse_formula("A>T").refbase == "A"
+    with pytest.raises(NotImplementedError):
+        parse_formula("!tumor:0.5")
+
+
+def test_synth_is_deterministic_and_well_formed():
+    cfg = synth.config3()
+    a = synth.generate(cfg, 50, chunk=3)
+    b = synth.generate(cfg, 50, chunk=3)
+    for k in a.columns:
+        assert np.array_equal(a.columns[k], b.columns[k], equal_nan=True)
+    assert a.n_samples == 2 and a.n_loci == 50
+    # realigned observations are normalised, SNV ones come from the base-quality table
+    pa, pr = a.columns["prob_alt"].astype(np.float64), a.columns["prob_ref"].astype(np.float64)
+    assert np.all(pa <= 0) and np.all(pr <= 0)
+    # prob_mapping constant within a pileup (pileup-mean adjustment)
+    for l in range(5):
+        for s in range(2):
+            sl = a.pileup_slice(l, s)
+            assert np.unique(a.columns["prob_mapping"][sl]).size <= 1
+    c = synth.generate(cfg, 50, chunk=4)
+    assert not np.array_equal(a.columns["prob_alt"][:100], c.columns["prob_alt"][:100])
+
+
+def test_minilogprob_round():
+    x = np.array([-0.5, -10.5, -11.0, -1000.0, -np.inf, 0.0])
+    r = synth.minilogprob_round(x)
+    assert r[0] == np.float32(-0.5) and r[5] == 0.0 and np.isneginf(r[4])
+    assert r[2] == -11.0 and r[3] == -1000.0  # exactly representable in f16
+    assert r[1] == np.float32(np.float16(-10.5))
+
+
+def test_batch_select_concat_roundtrip():
+    cfg = synth.config2()
+    a = synth.generate(cfg, 30)
+    parts = [a.select(range(0, 10)), a.select(range(10, 30))]
+    b = PileupBatch.concat(parts)
+    assert np.array_equal(a.obs_offset, b.obs_offset)
+    for k in a.columns:
+        assert np.array_equal(a.columns[k], b.columns[k], equal_nan=True)
+    e = a.select([])
+    assert e.n_loci == 0 and e.n_obs == 0
+
+
+def test_shard_range_covers_everything():
+    for n in (0, 1, 7, 8, 1000003):
+        for w in (1, 2, 4, 8):
+            r = [shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+
+
+# ---- C ABI: library loads, exports every symbol include/vlr.h declares, fails loudly without a GPU
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "vlr.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vlr_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_all_declared_symbols():
+    engine.build()
+    L = engine.lib()
+    names = declared_functions()
+    assert "vlr_plan_create" in names and "vlr_batch_run" in names and len(names) >= 10
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(engine.EXPORTS) == names
+    assert L.vlr_abi_version() == abi.ABI_VERSION
+
+
+def test_plan_create_validates_before_touching_the_device():
+    L = engine.lib()
+    sc = single_sample(0.01)
+    d = sc.desc()
+    d.resolution[0] = 1.5
+    h = C.c_void_p()
+    assert L.vlr_plan_create(C.byref(d), 0, C.byref(h)) == abi.ERR_INVALID_ARGUMENT
+    assert b"resolution" in L.vlr_last_error()
+    # invalid prior configuration: mendelian inheritance without germline mutation rate (prior.rs:812-816)
+    from varlociraptor_amd.scenario import Inheritance, Species
+    sc = Scenario({"c": Sample(inheritance=Inheritance(abi.INHERIT_MENDELIAN, ("m", "f"))), "m": Sample(), "f": Sample()},
+                  {"e": "c:0.5"}, species=Species(heterozygosity=0.001, ploidy=2))
+    d = sc.desc()
+    assert L.vlr_plan_create(C.byref(d), 0, C.byref(h)) == abi.ERR_INVALID_PRIOR
+
+
+def test_no_device_is_an_error_not_a_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(engine.EngineError) as ei:
+        engine.Plan(single_sample(0.01))
+    assert ei.value.code == abi.ERR_NO_DEVICE
