@@ -138,20 +138,22 @@ def main():
             sc = cfg.scenario
             tc = time.perf_counter()
             with ThreadPoolExecutor(max_workers=cores) as ex:
-                parts = list(ex.map(lambda i: oracle.call(sc, sub, begin=int(bounds[i]), end=int(bounds[i + 1])), range(cores)))
+                parts = list(ex.map(lambda i: oracle.call(sc, sub, begin=int(bounds[i]), end=int(bounds[i + 1]), want_events=True), range(cores)))
             t_cpu = time.perf_counter() - tc
             from varlociraptor_amd.batch import CallResults
             ref = CallResults(n_cpu, plan.n_out, plan.n_samples)
+            ref.event_ln_posterior = np.full((n_cpu, 1 + 2 * len(sc.event_names)), np.nan)
             for i, p in enumerate(parts):
                 lo, hi = int(bounds[i]), int(bounds[i + 1])
                 for f in ("ln_posterior", "map_vaf", "map_bias", "best_event", "status"):
                     getattr(ref, f)[lo:hi] = getattr(p, f)[lo:hi]
+                ref.event_ln_posterior[lo:hi] = p.event_ln_posterior
             got = CallResults(n_cpu, plan.n_out, plan.n_samples)
             for f in ("ln_posterior", "map_vaf", "map_bias", "best_event", "status"):
                 getattr(got, f)[:] = getattr(res, f)[:n_cpu]
             m = compare(got, ref)
             parity = {"n_checked": int(n_cpu), "max_abs_dposterior": m["max_dpost"], "max_abs_dmap_vaf": m["max_dvaf"],
-                      "frac_within_1e-6": m["frac_within"], "vs": "CPU restatement of the reference (oracle/)"}
+                      "frac_within_1e-6": m["frac_within"], "exact_event_ties": m["n_ties"], "vs": "CPU restatement of the reference (oracle/)"}
             cpu = {"value": n_cpu / t_cpu, "unit": "loci/s", "cores": cores, "kind": "port",
                    "sample": "first %d loci of the same batch, %d threads x contiguous shards, %.1f s" % (n_cpu, cores, t_cpu)}
         # posteriors must be normalised at full size (size-independent property)

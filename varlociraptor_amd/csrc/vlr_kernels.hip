@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include "../../include/vlr.h"
+#include "../../include/vlr_detmath.h"
 #include "vlr_plan.h"
 
 #pragma clang fp contract(off)
@@ -38,7 +39,7 @@ struct Frame {
     int kind, node, iter, n;
     double accM, accS;  // streaming ln-sum-exp
     int sv_present, sv_disc, sv_nlfc, sv_contained;
-    int slot, pad;      // RANGE: index into rs[] / the visited-point tables
+    int slot, sv_alive;  // RANGE: index into rs[] / the visited-point tables; saved cross-event candidate mask
 };
 
 struct RangeSt {
@@ -66,6 +67,7 @@ struct WaveSt {
     double ptJ[kMaxBatchPoints];
     double fixedLik[kMaxSamples];
     double curMapVaf[kMaxSamples];
+    int cs_node[kContainStack], cs_mask[kContainStack];
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -261,14 +263,16 @@ __device__ inline void lseacc_chunk(LseAcc& a, double v, bool on) {
     double cm = wave_max(x);
     if (cm == VLR_NEG_INF) return;
     double nm = fmax(a.m, cm);
-    double cs = wave_sum(on && x != VLR_NEG_INF ? exp(x - nm) : 0.0);
-    double olds = (a.m == VLR_NEG_INF) ? 0.0 : a.s * exp(a.m - nm);
+    double cs = wave_sum(on && x != VLR_NEG_INF ? vlr_det::det_exp(x - nm) : 0.0);
+    double olds = (a.m == VLR_NEG_INF) ? 0.0 : a.s * vlr_det::det_exp(a.m - nm);
     a.m = nm;
     a.s = olds + cs;
 }
+// deterministic exp/log1p (include/vlr_detmath.h): these sums decide threshold tests that sit exactly on
+// k/n boundaries when prob_mapping is constant within the pileup
 __device__ inline double lseacc_exp(const LseAcc& a) {
     if (a.m == VLR_NEG_INF) return 0.0;
-    return exp(a.m + log1p(a.s - 1.0));
+    return vlr_det::det_exp(a.m + vlr_det::det_log1p_pos(a.s - 1.0));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -361,6 +365,10 @@ struct Ctx {
     int has_snv, refbase, altbase;
     // operands state (modes/generic.rs:116-121), wave-uniform
     int present, disc, nlfc, contained;
+    int alive;   // event groups (other than the current one) whose tree may still contain the current operands
+    int group;   // group of the event being evaluated (0 absent, 1 + e)
+    int n_slots;
+    double* mapJ; double* mapVaf; int* mapHyp;  // best MAP candidate per slot (LDS)
     int hyp;
     // MAP candidate of the current (event, hypothesis class)
     double curJ;
@@ -461,6 +469,106 @@ __device__ inline void map_consider(Ctx& c, double joint, int inner, double x) {
     }
 }
 
+// ---- cross-event MAP candidates -------------------------------------------------------------------
+// sample_infos (calling.rs:851-864) takes the MAP from ALL visited operands that the best event's tree
+// `contains` (vaftree.rs:42-51) — including operands visited while evaluating a different event (e.g. the
+// excluded range start 0.0, visited when n_obs < 10, belongs to `absent`).  `alive` tracks, per pushed VAF,
+// which other groups can still contain the operands (necessary condition on the union of their spectra);
+// at a leaf the survivors get the full contains walk.
+__device__ inline int slot_clean(int g) { return g == 0 ? 0 : 1 + 2 * (g - 1); }
+__device__ inline int slot_art(const Ctx& c, int g) { return g == 0 ? c.plan->n_univ : 2 + 2 * (g - 1); }
+
+__device__ inline bool group_may_contain(const DevPlan& p, int g, int s, double v) {
+    int o0 = p.grp_spec_off[g * p.S + s], o1 = p.grp_spec_off[g * p.S + s + 1];
+    for (int i = o0; i < o1; ++i)
+        if (spectrum_contains(p.grp_spec[i], p.vafs, v)) return true;
+    return false;
+}
+__device__ inline int alive_update(const Ctx& c, int alive, int s, double v) {
+    int m = alive;
+    while (m) {
+        int g = __builtin_ctz(m);
+        m &= m - 1;
+        if (!group_may_contain(*c.plan, g, s, v)) alive &= ~(1 << g);
+    }
+    return alive;
+}
+// VAFTree::contains (vaftree.rs:42-51,116-164) of group g for the current operands (sample `inner` at x)
+__device__ inline bool group_contains(Ctx& c, int g, int inner, double x) {
+    const DevPlan& p = *c.plan;
+    WaveSt* w = c.w;
+    int r0 = (g == 0) ? 0 : p.root_off[g - 1], r1 = (g == 0) ? 1 : p.root_off[g];
+    int full = (1 << c.nlfc) - 1;
+    bool result = false;
+    for (int ri = r0; ri < r1 && !result; ++ri) {
+        int sp = 0;
+        w->cs_node[0] = (g == 0) ? p.absent_root : p.roots[ri];
+        w->cs_mask[0] = full;
+        sp = 1;
+        while (sp > 0 && !result) {
+            sp--;
+            int node = w->cs_node[sp], mask = w->cs_mask[sp];
+            const DevNode& nd = p.nodes[node];
+            bool contained;
+            if (nd.kind == VLR_NODE_SAMPLE) {
+                double v = (nd.sample == inner) ? x : w->ops_vaf[nd.sample];
+                contained = spectrum_contains(nd.vafs, p.vafs, v);
+            } else if (nd.kind == VLR_NODE_LFC) {
+                bool found = false;
+                for (int i = 0; i < c.nlfc; ++i)
+                    if ((mask >> i) & 1)
+                        if (w->lfc_a[i] == nd.sample && w->lfc_b[i] == nd.sample_b && w->lfc_cmp[i] == nd.cmp && w->lfc_val[i] == nd.lfc_value) {
+                            found = true;
+                            mask &= ~(1 << i);
+                        }
+                contained = found;
+            } else contained = (nd.kind != VLR_NODE_FALSE);
+            if (!contained) continue;
+            if (nd.n_children == 0) { if (mask == 0) result = true; continue; }
+            for (int ch = nd.n_children - 1; ch >= 0; --ch) {
+                if (sp >= kContainStack) { c.status |= VLR_LOCUS_TABLE_FULL; break; }
+                w->cs_node[sp] = p.child_index[nd.child_off + ch];
+                w->cs_mask[sp] = mask;
+                sp++;
+            }
+        }
+    }
+    return result;
+}
+// candidate for another group's slot; same ordering as map_consider
+__device__ inline void cross_consider(Ctx& c, int g, double joint, int inner, double x) {
+    if (!(joint == joint)) return;
+    int slot = (c.hyp == 0) ? slot_clean(g) : slot_art(c, g);
+    double curJ = c.mapJ[slot];
+    int curHyp = c.mapHyp[slot];
+    bool better = curHyp < 0 || joint > curJ;
+    if (!better && joint == curJ) {
+        if (c.hyp != curHyp) better = c.hyp < curHyp;
+        else
+            for (int s = 0; s < c.S; ++s) {
+                double v = (s == inner) ? x : c.w->ops_vaf[s];
+                double o = c.mapVaf[slot * c.S + s];
+                if (v != o) { better = v < o; break; }
+            }
+    }
+    if (better) {
+        __syncthreads();
+        if (c.lane == 0) { c.mapJ[slot] = joint; c.mapHyp[slot] = c.hyp; }
+        if (c.lane < c.S) c.mapVaf[slot * c.S + c.lane] = (c.lane == inner) ? x : c.w->ops_vaf[c.lane];
+        __syncthreads();
+    }
+}
+// all MAP bookkeeping for one evaluated operand set
+__device__ inline void map_all(Ctx& c, double joint, int inner, double x, bool own_path_contained, int alive) {
+    if (own_path_contained) map_consider(c, joint, inner, x);
+    else if (group_contains(c, c.group, inner, x)) map_consider(c, joint, inner, x);  // contained via another path
+    while (alive) {
+        int g = __builtin_ctz(alive);
+        alive &= alive - 1;
+        if (group_contains(c, g, inner, x)) cross_consider(c, g, joint, inner, x);
+    }
+}
+
 // GenericLikelihood::compute step 1 (modes/generic.rs:503-509) for a leaf operand set
 __device__ inline bool lfcs_ok(const Ctx& c, int inner, double x) {
     for (int i = 0; i < c.nlfc; ++i) {
@@ -489,7 +597,7 @@ __device__ inline double leaf_joint(Ctx& c) {
         joint = prior_of(c, -1, 0.0) + lik;
     }
     if (joint != joint) c.status |= VLR_LOCUS_NAN;
-    if (c.contained) map_consider(c, joint, -1, 0.0);
+    map_all(c, joint, -1, 0.0, c.contained != 0, c.alive);
     return joint;
 }
 
@@ -542,9 +650,23 @@ __device__ inline void leaf_joint_batch(Ctx& c, RangeSt& r, double* tx, double* 
     if (__ballot(nan)) c.status |= VLR_LOCUS_NAN;
     __syncthreads();
     RangeV orig{r.ostart, r.oend, r.olex, r.orex};
+    // which points need more than the own-path candidate? (lane-parallel necessary conditions)
+    int need = 0;
+    {
+        bool own_in = false;
+        int al = 0;
+        if (c.lane < np) {
+            double x = r.pend[c.lane];
+            own_in = c.contained && range_contains(orig, x);
+            al = alive_update(c, c.alive, inner, x);
+        }
+        need = __ballot(c.lane < np && (!own_in || al != 0)) != 0ull;
+    }
     for (int j = 0; j < np; ++j) {
         double x = r.pend[j];
-        if (c.contained && range_contains(orig, x)) map_consider(c, w->ptJ[j], inner, x);
+        bool own_in = c.contained && range_contains(orig, x);
+        if (!need) { if (own_in) map_consider(c, w->ptJ[j], inner, x); }
+        else map_all(c, w->ptJ[j], inner, x, own_in, alive_update(c, c.alive, inner, x));
     }
     r.tn += np;
 }
@@ -644,6 +766,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
     const DevPlan& p = *c.plan;
     WaveSt* w = c.w;
     c.present = 0; c.disc = 0; c.nlfc = 0; c.contained = 1;
+    c.alive = ((1 << (p.n_named + 1)) - 1) & ~(1 << c.group);
     int sp = 0, node = root, nrange = 0;
     enum { PC_DESCEND, PC_SUB, PC_RETURN, PC_RANGE_ISSUE } pc = PC_DESCEND;
     double rv = VLR_NEG_INF;
@@ -720,6 +843,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                     if (c.lane == 0) {
                         f.node = node; f.iter = 0; f.accM = VLR_NEG_INF; f.accS = 0.0;
                         f.sv_present = c.present; f.sv_disc = c.disc; f.sv_nlfc = c.nlfc; f.sv_contained = c.contained;
+                        f.sv_alive = c.alive;
                     }
                     if (as_set) {
                         if (c.lane == 0) { f.kind = FK_SET; f.n = ncand; w->ops_vaf[s] = w->setv[s][0]; }
@@ -728,6 +852,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                         c.present |= (1 << s);
                         c.disc |= (1 << s);
                         c.contained = f.sv_contained && spectrum_contains(nd.vafs, p.vafs, w->ops_vaf[s]);
+                        c.alive = alive_update(c, f.sv_alive, s, w->ops_vaf[s]);
                         pc = PC_SUB;
                     } else if (nrange >= p.max_range_depth || nrange >= kMaxRangeDepth) {
                         c.status |= VLR_LOCUS_TABLE_FULL; rv = __builtin_nan(""); pc = PC_RETURN;
@@ -773,6 +898,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                 if (c.lane == 0) {
                     f.kind = FK_BRANCH; f.node = node; f.iter = 0; f.n = nd.n_children; f.accM = VLR_NEG_INF; f.accS = 0.0;
                     f.sv_present = c.present; f.sv_disc = c.disc; f.sv_nlfc = c.nlfc; f.sv_contained = c.contained;
+                    f.sv_alive = c.alive;
                 }
                 __syncthreads();
                 sp++;
@@ -787,7 +913,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
             if (r.tn + r.npend > kTableCap) {
                 c.status |= VLR_LOCUS_TABLE_FULL;
                 rv = __builtin_nan("");
-                c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained;
+                c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained; c.alive = f.sv_alive;
                 sp--; nrange--;
                 pc = PC_RETURN;
             } else if (r.leaf) {
@@ -795,6 +921,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                 c.present = f.sv_present | (1 << r.sample);
                 c.nlfc = f.sv_nlfc;
                 c.contained = f.sv_contained;
+                c.alive = f.sv_alive;
                 for (;;) {
                     leaf_joint_batch(c, r, tx, tv);
                     __syncthreads();
@@ -804,7 +931,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                     if (r.tn + r.npend > kTableCap) { c.status |= VLR_LOCUS_TABLE_FULL; break; }
                 }
                 rv = (c.status & VLR_LOCUS_TABLE_FULL) ? __builtin_nan("") : range_finish(c, r, tx, tv);
-                c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained;
+                c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained; c.alive = f.sv_alive;
                 sp--; nrange--;
                 pc = PC_RETURN;
             } else {
@@ -816,6 +943,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                 c.nlfc = f.sv_nlfc;
                 RangeV orig{r.ostart, r.oend, r.olex, r.orex};
                 c.contained = f.sv_contained && range_contains(orig, x);
+                c.alive = alive_update(c, f.sv_alive, r.sample, x);
                 __syncthreads();
                 if (c.lane == 0) w->ops_vaf[r.sample] = x;
                 __syncthreads();
@@ -841,7 +969,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                     if (!done) { pc = PC_RANGE_ISSUE; }
                     else {
                         rv = range_finish(c, r, tx, tv);
-                        c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained;
+                        c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained; c.alive = f.sv_alive;
                         sp--; nrange--;
                         pc = PC_RETURN;
                     }
@@ -853,7 +981,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                 __syncthreads();
                 if (c.lane == 0) { f.accM = M; f.accS = S; f.iter = it; }
                 __syncthreads();
-                c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained;
+                c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained; c.alive = f.sv_alive;
                 if (it < f.n) {
                     const DevNode& nd = p.nodes[f.node];
                     if (f.kind == FK_SET) {
@@ -864,6 +992,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                         c.present |= (1 << s);
                         c.disc |= (1 << s);
                         c.contained = f.sv_contained && spectrum_contains(nd.vafs, p.vafs, w->ops_vaf[s]);
+                        c.alive = alive_update(c, f.sv_alive, s, w->ops_vaf[s]);
                         node = f.node;
                         pc = PC_SUB;
                     } else {
@@ -901,9 +1030,11 @@ __global__ void __launch_bounds__(64) vlr_call_kernel(const DevPlan* __restrict_
     c.sv = c.sx + kTableCap;
     double* evM = c.sv + kTableCap;
     double* evS = evM + p.n_univ;
-    double* mapJ = evS + p.n_univ;          // [n_univ]
-    double* mapVaf = mapJ + p.n_univ;       // [n_univ][S]
-    int* mapHyp = (int*)(mapVaf + p.n_univ * S);  // [n_univ]
+    const int n_slots = p.n_univ + 1;       // + virtual artifact slot of the `absent` group
+    double* mapJ = evS + p.n_univ;          // [n_slots]
+    double* mapVaf = mapJ + n_slots;        // [n_slots][S]
+    int* mapHyp = (int*)(mapVaf + n_slots * S);  // [n_slots]
+    c.mapJ = mapJ; c.mapVaf = mapVaf; c.mapHyp = mapHyp; c.n_slots = n_slots;
     c.status = 0; c.n_eval = 0; c.n_terms = 0;
 
     const unsigned lf = batch.locus_flags[locus];
@@ -1086,7 +1217,8 @@ __global__ void __launch_bounds__(64) vlr_call_kernel(const DevPlan* __restrict_
     }
 
     // ============================ phase B: hypotheses x events ============================
-    for (int u = lane; u < p.n_univ; u += 64) { evM[u] = VLR_NEG_INF; evS[u] = 0.0; mapJ[u] = VLR_NEG_INF; mapHyp[u] = -1; }
+    for (int u = lane; u < p.n_univ; u += 64) { evM[u] = VLR_NEG_INF; evS[u] = 0.0; }
+    for (int u = lane; u < n_slots; u += 64) { mapJ[u] = VLR_NEG_INF; mapHyp[u] = -1; }
     __syncthreads();
 
     if (too_deep) c.status |= VLR_LOCUS_TOO_DEEP;
@@ -1186,6 +1318,8 @@ __global__ void __launch_bounds__(64) vlr_call_kernel(const DevPlan* __restrict_
         for (int e = first_ev; e < p.n_named; ++e) {
             int u = (e < 0) ? 0 : (1 + 2 * e + (h == 0 ? 0 : 1));
             int r0 = (e < 0) ? 0 : p.root_off[e], r1 = (e < 0) ? 1 : p.root_off[e + 1];
+            c.group = e + 1;
+            __syncthreads();
             c.curJ = mapJ[u];
             c.curHyp = mapHyp[u];
             __syncthreads();
@@ -1246,11 +1380,12 @@ __global__ void __launch_bounds__(64) vlr_call_kernel(const DevPlan* __restrict_
     }
     // sample_infos (calling.rs:844-937): MAP among operands of the best event's tree (clean + twin share it)
     {
+        __syncthreads();
         int uc = (best == 0) ? 0 : (((best - 1) / 2) * 2 + 1);
-        int ua = (best == 0) ? -1 : uc + 1;
+        int ua = (best == 0) ? p.n_univ : uc + 1;
         int pick = -1;
         if (mapHyp[uc] >= 0) pick = uc;
-        if (ua >= 0 && is_artifact && have_twins && mapHyp[ua] >= 0) {
+        if (is_artifact && have_twins && mapHyp[ua] >= 0) {
             if (pick < 0) pick = ua;
             else {
                 // same comparator as map_consider: prob desc, then lower hypothesis id (clean = 0 wins ties)
@@ -1296,8 +1431,9 @@ extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_dev, const vlr::D
     using namespace vlr;
     if (batch->n_loci <= 0) return 0;
     if (range_depth < 1) range_depth = 1;
-    size_t dbl = (size_t)3 * max_obs + (size_t)2 * range_depth * kTableCap + 2 * kTableCap + (size_t)3 * n_univ +
-                 (size_t)n_univ * n_samples + (size_t)(n_univ + 1) / 2 + 2;
+    size_t n_slots = (size_t)n_univ + 1;
+    size_t dbl = (size_t)3 * max_obs + (size_t)2 * range_depth * kTableCap + 2 * kTableCap + (size_t)2 * n_univ + n_slots +
+                 n_slots * n_samples + (n_slots + 1) / 2 + 2;
     size_t bytes = dbl * sizeof(double);
     hipError_t e = hipFuncSetAttribute((const void*)vlr_call_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;

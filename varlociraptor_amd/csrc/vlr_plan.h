@@ -15,6 +15,7 @@ constexpr int kMaxNamedEvents = 31;   // scenario events (engine universe = 1 + 
 constexpr int kNHyp = 9;              // 0 = Artifacts::none(), 1..8 single-artifact combinations
 constexpr int kCacheWays = 4;         // per-sample pileup-likelihood cache entries
 constexpr int kMaxBatchPoints = 16;   // points evaluated by one eval_pileup call
+constexpr int kContainStack = 48;     // explicit stack of the VAFTree::contains walk
 constexpr int kNVariantTypes = 5;
 
 // hypothesis slots, in the cartesian order of Artifacts::all_artifact_combinations
@@ -63,6 +64,11 @@ struct DevPlan {
     const int32_t* root_off;    // [n_named + 1]
     const DevSpectrum* universe;
     const double* prior_table;  // [kNVariantTypes][table_size]
+    // event groups (0 = absent, 1 + e = scenario event e; an event and its artifact twin share a VAF tree):
+    // union of the spectra of all Sample nodes of sample s in the trees of group g, used as a cheap
+    // necessary condition before the full VAFTree::contains walk for cross-event MAP candidates
+    const int32_t* grp_spec_off;    // [(n_named + 1) * S + 1]
+    const DevSpectrum* grp_spec;
 };
 
 // SoA observation columns + per-locus columns (device pointers), mirrors vlr_batch

@@ -7,8 +7,8 @@ Mirrors the reference's grammar front-end for the part the hot path consumes:
   * VAFTree::new from a *normalized* formula (src/grammar/vaftree.rs:168-305) incl.
     add_missing_samples and the operand ordering of Formula::sort (formula.rs:455-471).
 The formula parser here handles atoms, `&`, `|`, parentheses, `true`/`false`, IUPAC variants and
-l2fc() terms; negation / $expressions / BDD simplification (formula.rs:473-866) belong to the
-"next" row of SURVEY §8(f) and raise NotImplementedError.
+l2fc() terms and negation pushed down to the atoms (formula.rs:717-905); $expressions and the BDD
+simplification (formula.rs:473-530) belong to the "next" row of SURVEY §8(f).
 """
 from __future__ import annotations
 
@@ -110,6 +110,11 @@ class Const:
     value: bool
 
 
+@dataclass
+class Neg:
+    operand: object
+
+
 _CMP = {"==": abi.CMP_EQUAL, ">": abi.CMP_GREATER, ">=": abi.CMP_GREATER_EQUAL, "<": abi.CMP_LESS,
         "<=": abi.CMP_LESS_EQUAL, "!=": abi.CMP_NOT_EQUAL}
 
@@ -154,8 +159,11 @@ class _Parser:
                 raise ValueError("missing ) in formula")
             self.i += 1
             return f
-        if self.peek() in "!$":
-            raise NotImplementedError("negation / $expression need the full grammar front-end (SURVEY §8f #3)")
+        if self.peek() == "!":
+            self.i += 1
+            return Neg(self.sub())
+        if self.peek() == "$":
+            raise NotImplementedError("$expression needs the full grammar front-end (SURVEY §8f #3)")
         if self.s.startswith("l2fc(", self.i):
             m = re.match(r"l2fc\(([\w.\-]+),([\w.\-]+)\)(<=|<|>=|>|!=|==)(-?\d+(?:\.\d*)?(?:[eE][+-]?\d+)?)", self.s[self.i:])
             if not m:
@@ -373,10 +381,128 @@ class Scenario:
                     self._add_missing(ch, set(seen))
             self._add_missing(node.children[0], seen)
 
+    # ---- Formula::negate / apply_negations (grammar/formula.rs:717-905), without the BDD simplification
+    def _split_at(self, r: VAFRange, vaf: float):
+        """VAFRange::split_at (formula.rs:1099-1129)."""
+        def to_spec(start, end, lex, rex):
+            if start == end:
+                if not (lex and r.right_exclusive):
+                    return VAFSet((start,))
+                return None
+            return VAFRange(start, end, lex, rex)
+        return to_spec(r.start, vaf, r.left_exclusive, True), to_spec(vaf, r.end, True, r.right_exclusive)
+
+    @staticmethod
+    def _overlap(a: VAFRange, b: VAFRange) -> str:
+        """VAFRange::overlap (formula.rs:1131-1168) of a relative to b."""
+        if a == b:
+            return "Equal"
+        start_right = (a.start >= b.start) if (a.left_exclusive and not b.left_exclusive) else (a.start > b.start)
+        end_left = (a.end <= b.end) if (a.right_exclusive and not b.right_exclusive) else (a.end < b.end)
+        if (a.end < b.start or a.start > b.end) or (a.end <= b.start and (a.right_exclusive or b.left_exclusive)) or \
+                (a.start >= b.end and (a.left_exclusive or b.right_exclusive)):
+            return "None"
+        return {(True, True): "Contained", (True, False): "Start", (False, True): "End", (False, False): "Contains"}[(start_right, end_left)]
+
+    @staticmethod
+    def _contains(r: VAFRange, v: float) -> bool:
+        lo = r.start < v if r.left_exclusive else r.start <= v
+        hi = r.end > v if r.right_exclusive else r.end >= v
+        return lo and hi
+
+    def _negate(self, f):
+        if isinstance(f, Const):
+            return Const(not f.value)
+        if isinstance(f, Conj):
+            return Disj([self._negate(o) for o in f.operands])
+        if isinstance(f, Disj):
+            return Conj([self._negate(o) for o in f.operands])
+        if isinstance(f, Neg):
+            return self._apply_negations(f.operand)
+        if isinstance(f, Variant):
+            return Variant(f.refbase, f.altbase, not f.positive)
+        if isinstance(f, Lfc):
+            inv = {abi.CMP_EQUAL: abi.CMP_NOT_EQUAL, abi.CMP_GREATER: abi.CMP_LESS_EQUAL, abi.CMP_GREATER_EQUAL: abi.CMP_LESS,
+                   abi.CMP_LESS: abi.CMP_GREATER_EQUAL, abi.CMP_LESS_EQUAL: abi.CMP_GREATER, abi.CMP_NOT_EQUAL: abi.CMP_EQUAL}
+            return Lfc(f.sample_a, f.sample_b, inv[f.cmp], f.value)  # utils/comparison.rs:28-41
+        assert isinstance(f, Atom)
+        universe = self.universe(f.sample)
+        out: List[Spectrum] = []
+        if isinstance(f.vafs, VAFSet):
+            stack = list(universe)
+            while stack:
+                u = stack.pop(0)
+                if isinstance(u, VAFSet):
+                    diff = tuple(v for v in u.vafs if v not in f.vafs.vafs)
+                    if diff:
+                        out.append(VAFSet(diff))
+                else:
+                    for vaf in f.vafs.vafs:
+                        if self._contains(u, vaf):
+                            left, right = self._split_at(u, vaf)
+                            if right is not None:
+                                stack.append(right)
+                            if left is not None:
+                                out.append(left)
+                        else:
+                            out.append(u)
+        else:
+            rng = f.vafs
+            for u in universe:
+                if isinstance(u, VAFSet):
+                    keep = tuple(v for v in u.vafs if not self._contains(rng, v))
+                    if keep:
+                        out.append(VAFSet(keep))
+                else:
+                    ov = self._overlap(rng, u)
+                    if ov == "Contained":
+                        l = self._split_at(u, rng.start)[0]
+                        r = self._split_at(u, rng.end)[1]
+                        out.extend(x for x in (l, r) if x is not None)
+                    elif ov == "End":
+                        r = self._split_at(u, rng.end)[1]
+                        if r is not None:
+                            out.append(r)
+                    elif ov == "Start":
+                        l = self._split_at(u, rng.start)[0]
+                        if l is not None:
+                            out.append(l)
+                    elif ov == "None":
+                        out.append(u)
+        if not out:
+            return Atom(f.sample, VAFSet(()))
+        return Disj([Atom(f.sample, sp) for sp in out])
+
+    def _apply_negations(self, f):
+        if isinstance(f, Neg):
+            return self._negate(self._apply_negations(f.operand)) if isinstance(f.operand, Neg) else self._negate(f.operand)
+        if isinstance(f, Conj):
+            return Conj([self._apply_negations(o) for o in f.operands])
+        if isinstance(f, Disj):
+            return Disj([self._apply_negations(o) for o in f.operands])
+        return f
+
+    @staticmethod
+    def _flatten(f):
+        """Minimal stand-in for Formula::simplify: merge nested conjunctions/disjunctions, unwrap singletons."""
+        if isinstance(f, (Conj, Disj)):
+            ops = []
+            for o in f.operands:
+                o = Scenario._flatten(o)
+                if type(o) is type(f):
+                    ops.extend(o.operands)
+                else:
+                    ops.append(o)
+            if len(ops) == 1:
+                return ops[0]
+            return type(f)(ops)
+        return f
+
     def vaftree(self, event: str) -> List[_TNode]:
         f = self.events[event]
         if isinstance(f, str):
             f = parse_formula(f)
+        f = self._flatten(self._apply_negations(f))
         roots = self._from(f)
         for r in roots:
             self._add_missing(r, set())

@@ -98,7 +98,35 @@ def config4() -> SynthConfig:
     return c
 
 
-CONFIGS = {"config2": config2, "config3": config3, "config4": config4}
+def pedigree_scenario() -> Scenario:
+    """tests/resources/prior/scenarios/pedigree.scenario.yaml on an autosome (ploidy 2 for every sample):
+    ploidy-derived universes {0, 0.5, 1}, Mendelian inheritance of child and sibling from mother and father."""
+    from .scenario import Inheritance, Sample, Species
+    species = Species(heterozygosity=0.001, germline_mutation_rate=1e-3, ploidy=2)
+    mend = Inheritance(abi.INHERIT_MENDELIAN, ("mother", "father"))
+    samples = {"mother": Sample(), "father": Sample(), "child": Sample(inheritance=mend), "sibling": Sample(inheritance=mend)}
+    events = {
+        "denovo_child": "(child:0.5 | child:1.0) & mother:0.0 & father:0.0",
+        "denovo_sibling": "(sibling:0.5 | sibling:1.0) & mother:0.0 & father:0.0",
+        "inherited": "!mother:0.0 | !father:0.0",
+    }
+    return Scenario(samples, events, species=species)
+
+
+def config5() -> SynthConfig:
+    """8 GPU, 4-sample pedigree, 60x, incl. SV/breakend loci (BASELINE configs[4]).
+    Sample order (BTreeMap): child 0, father 1, mother 2, sibling 3."""
+    h = (0.5, 0.5)
+    z = (0.0, 0.0)
+    return SynthConfig(
+        name="pedigree-60x", config_id=5, scenario=pedigree_scenario(), depth=60.0,
+        type_mix={abi.VT_SNV: 0.65, abi.VT_INDEL: 0.25, abi.VT_SV: 0.10},
+        classes=[("absent", 0.55, (z, z, z, z)), ("inherited_father", 0.15, (h, h, z, z)), ("inherited_mother", 0.10, (z, z, h, h)),
+                 ("inherited_both", 0.08, ((1.0, 1.0), h, h, h)), ("denovo_child", 0.07, (h, z, z, z)), ("denovo_sibling", 0.05, (z, z, z, h))],
+    )
+
+
+CONFIGS = {"config2": config2, "config3": config3, "config4": config4, "config5": config5}
 
 
 def generate(cfg: SynthConfig, n_loci: int, seed: Optional[int] = None, chunk: int = 0,
@@ -236,6 +264,8 @@ def generate(cfg: SynthConfig, n_loci: int, seed: Optional[int] = None, chunk: i
     lf |= np.where(is_snv_or_mnv, abi.BIAS_ORIENTATION | abi.BIAS_POSITION | abi.BIAS_SOFTCLIP, 0).astype(np.uint8)
     lf |= np.uint8(abi.BIAS_STRAND | abi.BIAS_ALTLOCUS)
     lf |= np.where(has_hp, abi.BIAS_HOMOPOLYMER, 0).astype(np.uint8)
+    is_sv = vt == abi.VT_SV  # imprecise SV/breakend records: only the alt-locus bias is checked (calling.rs:553-567)
+    lf = np.where(is_sv, np.uint8(abi.BIAS_ALTLOCUS), lf).astype(np.uint8)
     lf &= np.uint8(bias_mask | 0xC0)
     if bias_mask & abi.BIAS_ORIENTATION:
         lf |= np.where(is_snv_or_mnv, abi.LOCUS_REMOVE_NONSTANDARD, 0).astype(np.uint8)
