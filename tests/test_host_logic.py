@@ -57,8 +57,23 @@ def test_formula_parser():
     f = parse_formula("(tumor:]0.0,1.0] & normal:0.0) | l2fc(tumor,normal) >= 1.5")
     assert type(f).__name__ == "Disj" and len(f.operands) == 2
     assert parse_formula("A>T").refbase == "A"
+    assert type(parse_formula("!tumor:0.5")).__name__ == "Neg"
     with pytest.raises(NotImplementedError):
-        parse_formula("!tumor:0.5")
+        parse_formula("$expr & tumor:0.5")
+
+
+def test_negation_uses_the_universe():
+    """Formula::negate on atoms (formula.rs:757-858): complement within the sample's universe."""
+    sc = Scenario({"m": Sample(ploidy=2, germline_mutation_rate=1e-3), "t": Sample(universe="[0.0,1.0]")},
+                  {"a": "!m:0.0 & t:0.5", "b": "!t:[0.2,0.5[ & m:0.0"},
+                  species=__import__("varlociraptor_amd.scenario", fromlist=["Species"]).Species(heterozygosity=1e-3))
+    roots = sc.vaftree("a")
+    assert len(roots) == 1 and roots[0].sample == 0 and roots[0].vafs == VAFSet((0.5, 1.0))
+    roots = sc.vaftree("b")
+    assert roots[0].sample == 0
+    kids = roots[0].children
+    # VAFRange::split_at always makes the right part left-exclusive (formula.rs:1099-1129), so 0.5 itself is dropped
+    assert [k.vafs for k in kids] == [VAFRange(0.0, 0.2, False, True), VAFRange(0.5, 1.0, True, False)]
 
 
 def test_synth_is_deterministic_and_well_formed():
