@@ -626,7 +626,7 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
     int max_obs = plan->max_depth_per_sample * plan->host.S;
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipEventRecord(plan->ev_start, st));
-    int rc = vlr_launch_call_kernel(plan->dev, &b, &r, plan->host.n_univ, plan->host.S, max_obs, plan->host.max_range_depth, stream);
+    int rc = vlr_launch_call_kernel(&plan->host, &b, &r, plan->host.n_univ, plan->host.S, max_obs, plan->host.max_range_depth, stream);
     if (rc != 0) return fail(VLR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipEventRecord(plan->ev_stop, st));
     plan->timed = true;

@@ -68,6 +68,7 @@ struct WaveSt {
     double fixedLik[kMaxSamples];
     double curMapVaf[kMaxSamples];
     int cs_node[kContainStack], cs_mask[kContainStack];
+    int fastok;  // bit s: all terms of sample s stay >= 2^-200 under the current hypothesis (4-term renormalisation is safe)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -276,34 +277,90 @@ __device__ inline double lseacc_exp(const LseAcc& a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// pileup likelihood: ln prod_i (c_i + q_i*alpha + e_i*beta) at np points, lanes = (point, slice)
-__device__ inline void eval_pileup(const double* __restrict__ cc, const double* __restrict__ cq,
-                                   const double* __restrict__ ce, int D, int np, const double* ptA, const double* ptB,
+// pileup likelihood: ln prod_i (c_i + q_i*alpha + e_i*beta) at np points, lanes = (point, slice).
+// Coefficients are AoS triples {c,q,e} (24 B per observation) so one address serves all three reads;
+// consecutive slices read consecutive triples: bank = 6k mod 64, conflict free per 32-lane half.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+
+// product (mantissa P in [0.5,1) x 2^E) over the LP = 64 >> lg lanes of each point group; every lane of the
+// group ends with the result.  DPP quad/row permutes inside a 16-lane row, bpermute across rows.
+__device__ __forceinline__ void group_product(double& P, int& E, int lg) {
+    if (lg <= 5) { P *= dpp_f64<0xB1>(P); E += dpp_i32<0xB1>(E); }      // quad_perm [1,0,3,2]
+    if (lg <= 4) { P *= dpp_f64<0x4E>(P); E += dpp_i32<0x4E>(E); }      // quad_perm [2,3,0,1]
+    if (lg <= 3) { P *= dpp_f64<0x141>(P); E += dpp_i32<0x141>(E); }    // row_half_mirror
+    if (lg <= 2) { P *= dpp_f64<0x140>(P); E += dpp_i32<0x140>(E); }    // row_mirror
+    if (lg <= 1) { P *= __shfl_xor(P, 16); E += __shfl_xor(E, 16); }
+    if (lg == 0) { P *= __shfl_xor(P, 32); E += __shfl_xor(E, 32); }
+    int e2;
+    P = __builtin_frexp(P, &e2);  // group product of <= 64 mantissas >= 2^-64: one renormalisation suffices
+    E += e2;
+}
+
+// this lane's slice k of the product; `fast`: every term of this pileup is >= 2^-200 at every VAF (checked when
+// the coefficients were built), so four terms are multiplied before one renormalisation
+__device__ __forceinline__ void pileup_partial(const double* __restrict__ coef, int D, int LP, int k, double al, double be,
+                                               bool fast, double& P, int& E) {
+    P = 1.0;
+    E = 0;
+    int i = k;
+    const int st = 3 * LP;
+    if (fast) {
+        for (; i + 3 * LP < D; i += 4 * LP) {
+            const double* a0 = coef + 3 * i;
+            const double* a1 = a0 + st;
+            const double* a2 = a1 + st;
+            const double* a3 = a2 + st;
+            double L0 = __builtin_fma(a0[2], be, __builtin_fma(a0[1], al, a0[0]));
+            double L1 = __builtin_fma(a1[2], be, __builtin_fma(a1[1], al, a1[0]));
+            double L2 = __builtin_fma(a2[2], be, __builtin_fma(a2[1], al, a2[0]));
+            double L3 = __builtin_fma(a3[2], be, __builtin_fma(a3[1], al, a3[0]));
+            L0 = fmax(L0, 0.0); L1 = fmax(L1, 0.0); L2 = fmax(L2, 0.0); L3 = fmax(L3, 0.0);
+            int e;
+            P = __builtin_frexp(P * ((L0 * L1) * (L2 * L3)), &e);
+            E += e;
+        }
+        for (; i < D; i += LP) {
+            const double* a0 = coef + 3 * i;
+            double L0 = fmax(__builtin_fma(a0[2], be, __builtin_fma(a0[1], al, a0[0])), 0.0);
+            int e;
+            P = __builtin_frexp(P * L0, &e);
+            E += e;
+        }
+    } else {
+        for (; i < D; i += LP) {  // robust path: per-term mantissa/exponent split (terms may be denormal or zero)
+            const double* a0 = coef + 3 * i;
+            double L0 = __builtin_fma(a0[2], be, __builtin_fma(a0[1], al, a0[0]));
+            L0 = L0 < 0.0 ? 0.0 : L0;
+            int e;
+            double m = __builtin_frexp(L0, &e);
+            P *= m;  // mantissas in [0.5,1): no underflow below ~1000 terms per lane (max_obs/4 < 1000 by the LDS cap)
+            E += e;
+        }
+        int e;
+        P = __builtin_frexp(P, &e);
+        E += e;
+    }
+}
+
+__device__ inline void eval_pileup(const double* __restrict__ coef, int D, bool fast, int np, const double* ptA, const double* ptB,
                                    double* res, int lane) {
     int lg = np <= 1 ? 0 : np <= 2 ? 1 : np <= 4 ? 2 : np <= 8 ? 3 : 4;  // G = 2^lg point groups
     int LP = 64 >> lg;
     int j = lane >> (6 - lg);
     int k = lane & (LP - 1);
     int jj = j < np ? j : np - 1;
-    double a = ptA[jj], b = ptB[jj];
-    double P = 1.0;
-    int E = 0;
-    for (int i = k; i < D; i += LP) {
-        double L = __builtin_fma(cq[i], a, cc[i]);
-        L = __builtin_fma(ce[i], b, L);
-        L = L < 0.0 ? 0.0 : L;  // rounding guard; NaN passes through
-        int ex;
-        double m = __builtin_frexp(L, &ex);
-        P *= m;  // mantissas in [0.5,1): no underflow below ~1000 terms per lane (max_obs/4 < 1000 by the LDS cap)
-        E += ex;
-    }
-    for (int o = 1; o < LP; o <<= 1) {
-        double Po = __shfl_xor(P, o);
-        int Eo = __shfl_xor(E, o);
-        int e2;
-        P = __builtin_frexp(P * Po, &e2);
-        E += Eo + e2;
-    }
+    double P;
+    int E;
+    pileup_partial(coef, D, LP, k, ptA[jj], ptB[jj], fast, P, E);
+    group_product(P, E, lg);
     double r = log(P) + (double)E * kLn2;
     if (k == 0 && j < np) res[j] = r;
 }
@@ -357,7 +414,7 @@ __device__ inline double integrate_table(const double* tx, const double* tv, int
 struct Ctx {
     const DevPlan* __restrict__ plan;
     WaveSt* w;
-    double *cc, *cq, *ce;            // coefficient arrays (LDS)
+    double* coef;                    // AoS coefficient triples {c,q,e} (LDS)
     double *tabX, *tabV, *sx, *sv;   // visited tables [depth][kTableCap], sort scratch
     int lane;
     int S;
@@ -378,27 +435,24 @@ struct Ctx {
 };
 
 // Prior::compute via the host-built class table (prior.rs:715-762; see vlr_host.cpp build_prior_table)
+__device__ inline int prior_class(const DevPlan& p, int s, double v) {
+    if (p.prior_kind[s] == PK_UNIFORM) {
+        bool in = false;
+        for (int u = p.uni_off[s]; u < p.uni_off[s + 1]; ++u) in = in || spectrum_contains(p.universe[u], p.vafs, v);
+        return in ? (v == 0.0 ? 0 : 1) : 2;
+    }
+    int pl = p.ploidy[s];
+    double dp = (double)pl;
+    double k = rint(dp * v);
+    bool match;
+    if (p.prior_kind[s] == PK_GERMLINE) match = relative_eq(dp * v, k);  // prior.rs:236-240
+    else match = pl > 0 ? relative_eq(v - k / dp, 0.0) : (v == 0.0);    // prior.rs:440-456 on vaf - n/ploidy
+    return (match && k >= 0.0 && k <= dp) ? (int)k : pl + 1;
+}
 __device__ inline double prior_of(const Ctx& c, int inner, double x) {
     const DevPlan& p = *c.plan;
     int idx = 0;
-    for (int s = 0; s < c.S; ++s) {
-        double v = (s == inner) ? x : c.w->ops_vaf[s];
-        int cls;
-        if (p.prior_kind[s] == PK_UNIFORM) {
-            bool in = false;
-            for (int u = p.uni_off[s]; u < p.uni_off[s + 1]; ++u) in = in || spectrum_contains(p.universe[u], p.vafs, v);
-            cls = in ? (v == 0.0 ? 0 : 1) : 2;
-        } else {
-            int pl = p.ploidy[s];
-            double dp = (double)pl;
-            double k = rint(dp * v);
-            bool match;
-            if (p.prior_kind[s] == PK_GERMLINE) match = relative_eq(dp * v, k);  // prior.rs:236-240
-            else match = pl > 0 ? relative_eq(v - k / dp, 0.0) : (v == 0.0);    // prior.rs:440-456 on vaf - n/ploidy
-            cls = (match && k >= 0.0 && k <= dp) ? (int)k : pl + 1;
-        }
-        idx += cls * p.class_stride[s];
-    }
+    for (int s = 0; s < c.S; ++s) idx += prior_class(p, s, (s == inner) ? x : c.w->ops_vaf[s]) * p.class_stride[s];
     return p.prior_table[c.vt * p.table_size + idx];
 }
 
@@ -428,7 +482,7 @@ __device__ inline double sample_lik(Ctx& c, int s, double a, double b) {
     if (c.lane == 0) { w->ptA[0] = al; w->ptB[0] = be; }
     __syncthreads();
     int off = w->soff[s], D = w->nkeep[s];
-    eval_pileup(c.cc + off, c.cq + off, c.ce + off, D, 1, w->ptA, w->ptB, w->res, c.lane);
+    eval_pileup(c.coef + 3 * off, D, (w->fastok >> s) & 1, 1, w->ptA, w->ptB, w->res, c.lane);
     __syncthreads();
     double r = w->res[0];
     c.n_eval += 1;
@@ -601,76 +655,6 @@ __device__ inline double leaf_joint(Ctx& c) {
     return joint;
 }
 
-// batched leaf evaluation of the pending points of a Range chain whose node is a leaf:
-// all points share the operands of the outer samples and differ in sample `inner`.
-__device__ inline void leaf_joint_batch(Ctx& c, RangeSt& r, double* tx, double* tv) {
-    WaveSt* w = c.w;
-    const DevPlan& p = *c.plan;
-    int np = r.npend, inner = r.sample;
-    // likelihood of samples that do not depend on `inner`
-    double fixed = 0.0;
-    for (int s = 0; s < c.S; ++s) {
-        int by = p.by[s];
-        if (s == inner || by == inner) continue;
-        fixed += sample_lik(c, s, w->ops_vaf[s], by >= 0 ? w->ops_vaf[by] : 0.0);
-    }
-    __syncthreads();
-    if (c.lane < np) w->ptJ[c.lane] = fixed;
-    __syncthreads();
-    for (int s = 0; s < c.S; ++s) {
-        int by = p.by[s];
-        if (!(s == inner || by == inner)) continue;
-        if (c.lane < np) {
-            double x = r.pend[c.lane];
-            double a = (s == inner) ? x : w->ops_vaf[s];
-            double b = by >= 0 ? ((by == inner) ? x : w->ops_vaf[by]) : 0.0;
-            double al, be;
-            alpha_beta(p, s, a, b, al, be);
-            w->ptA[c.lane] = al;
-            w->ptB[c.lane] = be;
-        }
-        __syncthreads();
-        int off = w->soff[s], D = w->nkeep[s];
-        eval_pileup(c.cc + off, c.cq + off, c.ce + off, D, np, w->ptA, w->ptB, w->res, c.lane);
-        __syncthreads();
-        if (c.lane < np) w->ptJ[c.lane] += w->res[c.lane];
-        c.n_eval += (unsigned long long)np;
-        c.n_terms += (unsigned long long)np * (unsigned long long)D;
-        __syncthreads();
-    }
-    bool nan = false;
-    if (c.lane < np) {
-        double x = r.pend[c.lane];
-        double joint = lfcs_ok(c, inner, x) ? prior_of(c, inner, x) + w->ptJ[c.lane] : VLR_NEG_INF;
-        nan = joint != joint;
-        w->ptJ[c.lane] = joint;
-        tx[r.tn + c.lane] = x;
-        tv[r.tn + c.lane] = joint;
-    }
-    if (__ballot(nan)) c.status |= VLR_LOCUS_NAN;
-    __syncthreads();
-    RangeV orig{r.ostart, r.oend, r.olex, r.orex};
-    // which points need more than the own-path candidate? (lane-parallel necessary conditions)
-    int need = 0;
-    {
-        bool own_in = false;
-        int al = 0;
-        if (c.lane < np) {
-            double x = r.pend[c.lane];
-            own_in = c.contained && range_contains(orig, x);
-            al = alive_update(c, c.alive, inner, x);
-        }
-        need = __ballot(c.lane < np && (!own_in || al != 0)) != 0ull;
-    }
-    for (int j = 0; j < np; ++j) {
-        double x = r.pend[j];
-        bool own_in = c.contained && range_contains(orig, x);
-        if (!need) { if (own_in) map_consider(c, w->ptJ[j], inner, x); }
-        else map_all(c, w->ptJ[j], inner, x, own_in, alive_update(c, c.alive, inner, x));
-    }
-    r.tn += np;
-}
-
 // ---- adaptive integration state machine (utils/adaptive_integration.rs:25-141)
 // after the values of r.pend[] are in the table: advance; returns true when the chain is finished
 __device__ inline bool range_advance(Ctx& c, RangeSt& r, const double* tx, const double* tv) {
@@ -735,6 +719,169 @@ __device__ inline double range_finish(Ctx& c, RangeSt& r, const double* tx, cons
         return lse_value(M, S) + log(r.hi - r.lo) - log((double)(n - 1)) - log(3.0);
     }
     return integrate_table(tx, tv, r.tn, c.sx, c.sv, c.lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Innermost Range chain at a leaf node: the hot loop of the whole engine (>95 % of all pileup evaluations).
+// Same algorithm as leaf_joint_batch + range_advance, but the chain state lives in registers, the
+// likelihood of samples that do not depend on the integrated VAF and the prior index of the outer samples
+// are hoisted out of the rounds, each lane selects its point from uniform registers, and results come
+// back through lane broadcasts — no barriers, no LDS traffic besides coefficient reads and table appends.
+__device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx, double* tv) {
+    const DevPlan& p = *c.plan;
+    WaveSt* w = c.w;
+    const int lane = c.lane;
+    const int inner = rl.sample;
+    const double lo = rl.lo, hi = rl.hi, res = rl.res;
+    const RangeV orig{rl.ostart, rl.oend, rl.olex, rl.orex};
+    const int simpson_n = rl.simpson_n;
+
+    double fixed = 0.0;
+    int dep = 0, pidx = 0;
+    for (int s = 0; s < c.S; ++s) {
+        int by = p.by[s];
+        if (s == inner || by == inner) dep |= 1 << s;
+        else fixed += sample_lik(c, s, w->ops_vaf[s], by >= 0 ? w->ops_vaf[by] : 0.0);
+        if (s != inner) pidx += prior_class(p, s, w->ops_vaf[s]) * p.class_stride[s];
+    }
+    const double* ptab = p.prior_table + c.vt * p.table_size;
+    const int istride = p.class_stride[inner];
+
+    // pending points and their joint values live in two tiny LDS arrays (same-wave LDS ops execute in order;
+    // wave_barrier() only stops the compiler from reordering them)
+    double* pend = w->ptA;  // reuse: ptA = pending x, ptJ = joint values
+    double* vals = w->ptJ;
+    int np, phase, tn = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (simpson_n) {
+        double step = (hi - lo) / (double)(simpson_n - 1);
+        if (lane < simpson_n) pend[lane] = (lane == 0) ? lo : (lane == simpson_n - 1) ? hi : lo + step * (double)lane;
+        np = simpson_n;
+        phase = RP_SIMPSON;
+    } else {
+        if (lane < 2) pend[lane] = lane ? hi : lo;
+        np = 2;
+        phase = RP_INIT;
+    }
+    __builtin_amdgcn_wave_barrier();
+    double L = lo, R = hi, vL = VLR_NEG_INF, vR = VLR_NEG_INF, mid = lo, first_mid = lo;
+    bool have_first = false, have_mid = false, failed = false;
+    double bestJ = VLR_NEG_INF, bestX = 0.0;
+    bool haveBest = false;
+    unsigned long long evals = 0, terms = 0;
+
+    for (;;) {
+        if (tn + np > kTableCap) { c.status |= VLR_LOCUS_TABLE_FULL; failed = true; break; }
+        const int lg = np <= 1 ? 0 : np <= 2 ? 1 : np <= 4 ? 2 : np <= 8 ? 3 : 4;
+        const int LP = 64 >> lg;
+        const int j = lane >> (6 - lg);
+        const int k = lane & (LP - 1);
+        const int jj = j < np ? j : np - 1;
+        const double x = pend[jj];
+
+        double lik = fixed;
+        int dm = dep;
+        while (dm) {
+            int s = __builtin_ctz(dm);
+            dm &= dm - 1;
+            int by = p.by[s];
+            double a = (s == inner) ? x : w->ops_vaf[s];
+            double b = by >= 0 ? ((by == inner) ? x : w->ops_vaf[by]) : 0.0;
+            double al, be;
+            alpha_beta(p, s, a, b, al, be);
+            const int off = w->soff[s], D = w->nkeep[s];
+            double P;
+            int E;
+            pileup_partial(c.coef + 3 * off, D, LP, k, al, be, (w->fastok >> s) & 1, P, E);
+            group_product(P, E, lg);
+            lik += log(P) + (double)E * kLn2;
+            evals += (unsigned long long)np;
+            terms += (unsigned long long)np * (unsigned long long)D;
+        }
+        double joint;
+        if (c.nlfc > 0 && !lfcs_ok(c, inner, x)) joint = VLR_NEG_INF;
+        else joint = ptab[pidx + prior_class(p, inner, x) * istride] + lik;
+        if (__ballot(joint != joint)) c.status |= VLR_LOCUS_NAN;
+        if (k == 0 && j < np) { tx[tn + j] = x; tv[tn + j] = joint; }
+
+        // MAP candidates (calling.rs:851-864)
+        const bool own_in = c.contained && range_contains(orig, x);
+        const int al2 = c.alive ? alive_update(c, c.alive, inner, x) : 0;
+        const bool slow = __ballot(j < np && (!own_in || al2 != 0)) != 0ull;
+        __builtin_amdgcn_wave_barrier();
+        if (k == 0 && j < np) vals[j] = joint;
+        __builtin_amdgcn_wave_barrier();
+        if (!slow) {
+            for (int i = 0; i < np; ++i) {
+                double v = vals[i], xi = pend[i];
+                if (v == v && (!haveBest || v > bestJ || (v == bestJ && xi < bestX))) { bestJ = v; bestX = xi; haveBest = true; }
+            }
+        } else {
+            for (int i = 0; i < np; ++i) {
+                double xi = pend[i];
+                map_all(c, vals[i], inner, xi, c.contained && range_contains(orig, xi), c.alive ? alive_update(c, c.alive, inner, xi) : 0);
+            }
+        }
+        tn += np;
+
+        // ---- advance the chain (utils/adaptive_integration.rs:54-131)
+        if (phase == RP_SIMPSON || phase == RP_TAIL) break;
+        if (phase == RP_INIT) {
+            L = lo; R = hi; vL = vals[0]; vR = vals[1];
+        } else {  // argmax over {left, middle1, middle2, right}; lowest index wins ties
+            double xs0 = L, xs1 = pend[1], xs2 = pend[2], xs3 = R;
+            double v0 = vL, v1 = vals[1], v2 = vals[2], v3 = vR;
+            __builtin_amdgcn_wave_barrier();
+            int kk = 0;
+            double vb = v0;
+            if (v1 > vb) { kk = 1; vb = v1; }
+            if (v2 > vb) { kk = 2; vb = v2; }
+            if (v3 > vb) { kk = 3; vb = v3; }
+            if (kk == 0) { R = xs1; vR = v1; }                              // [L, m1]
+            else if (kk == 1) { R = xs2; vR = v2; }                         // [L, m2]
+            else if (kk == 2) { L = xs1; vL = v1; }                         // [m1, R]
+            else { L = xs2; vL = v2; }                                      // [m2, R]
+            (void)xs0; (void)xs3;
+        }
+        if ((((R - L) >= res) && L < R) || !have_mid) {
+            mid = (R + L) / 2.0;
+            have_mid = true;
+            if (!have_first) { first_mid = mid; have_first = true; }
+            double m1 = (mid + L) / 2.0, m2 = (R + mid) / 2.0;
+            if (lane < 3) pend[lane] = (lane == 0) ? mid : (lane == 1) ? m1 : m2;
+            np = 3;
+            phase = RP_ROUND;
+        } else {
+            double arm = (mid < first_mid) ? (hi + first_mid) / 2.0 : (first_mid + lo) / 2.0;
+            double lo3 = fmax(mid - res * 3.0, lo);
+            double hi3 = fmin(mid + res * 3.0, hi);
+            double sa = (mid - lo3) / 3.0, sb = (hi3 - mid) / 3.0;  // itertools_num::linspace step, n = 4
+            if (lane < 7) {
+                double v;
+                if (lane == 0) v = arm;
+                else if (lane <= 3) v = lo3 + sa * (double)(lane - 1);
+                else v = mid + sb * (double)(lane - 3);
+                pend[lane] = v;
+            }
+            np = 7;
+            phase = RP_TAIL;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    c.n_eval += evals;
+    c.n_terms += terms;
+    if (haveBest) map_consider(c, bestJ, inner, bestX);
+    if (failed) return __builtin_nan("");
+    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    if (phase == RP_SIMPSON) {  // bio LogProb::ln_simpsons_integrate_exp (modes/generic.rs:367-385)
+        double M = VLR_NEG_INF, S = 0.0;
+        for (int i = 1; i < simpson_n - 1; ++i) lse_add(M, S, tv[i] + log((double)(2 + (i % 2) * 2)));
+        lse_add(M, S, tv[0]);
+        lse_add(M, S, tv[simpson_n - 1]);
+        return lse_value(M, S) + log(hi - lo) - log((double)(simpson_n - 1)) - log(3.0);
+    }
+    return integrate_table(tx, tv, tn, c.sx, c.sv, lane);
 }
 
 // LikelihoodOperands::lfc_bounds (modes/generic.rs:148-174)
@@ -922,15 +1069,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                 c.nlfc = f.sv_nlfc;
                 c.contained = f.sv_contained;
                 c.alive = f.sv_alive;
-                for (;;) {
-                    leaf_joint_batch(c, r, tx, tv);
-                    __syncthreads();
-                    bool done = range_advance(c, r, tx, tv);
-                    __syncthreads();
-                    if (done) break;
-                    if (r.tn + r.npend > kTableCap) { c.status |= VLR_LOCUS_TABLE_FULL; break; }
-                }
-                rv = (c.status & VLR_LOCUS_TABLE_FULL) ? __builtin_nan("") : range_finish(c, r, tx, tv);
+                rv = run_leaf_chain(c, r, tx, tv);
                 c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained; c.alive = f.sv_alive;
                 sp--; nrange--;
                 pc = PC_RETURN;
@@ -1010,11 +1149,14 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) vlr_call_kernel(const DevPlan* __restrict__ planp, DevBatch batch, DevResults out,
+#ifndef VLR_WAVES_PER_EU
+#define VLR_WAVES_PER_EU 1
+#endif
+__global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const DevPlan plan_arg, DevBatch batch, DevResults out,
                                                        int max_obs, int range_depth) {
     extern __shared__ double dyn[];
     __shared__ WaveSt wst;
-    const DevPlan& p = *planp;
+    const DevPlan& p = plan_arg;
     const int lane = threadIdx.x;
     const int64_t locus = blockIdx.x;
     if (locus >= batch.n_loci) return;
@@ -1022,8 +1164,8 @@ __global__ void __launch_bounds__(64) vlr_call_kernel(const DevPlan* __restrict_
     WaveSt* w = &wst;
 
     Ctx c;
-    c.plan = planp; c.w = w; c.lane = lane; c.S = S;
-    c.cc = dyn; c.cq = dyn + max_obs; c.ce = dyn + 2 * max_obs;
+    c.plan = &plan_arg; c.w = w; c.lane = lane; c.S = S;
+    c.coef = dyn;
     c.tabX = dyn + 3 * max_obs;
     c.tabV = c.tabX + range_depth * kTableCap;
     c.sx = c.tabV + range_depth * kTableCap;
@@ -1231,13 +1373,16 @@ __global__ void __launch_bounds__(64) vlr_call_kernel(const DevPlan* __restrict_
         //   w = e^pm, u = (1-w) * e^(missed + b_any), A = e^(pa + b_alt), R = e^(pr + b_ref), s = e^prob_sample_alt
         //   c = w*R + u, q = w*s*(A-R), e = w*(1-s)*(A-R)
         // (likelihood.rs:43-53,86-115,171-220; bias factors bias/mod.rs:259-284)
+        int fastmask = 0;
         for (int s = 0; s < S; ++s) {
             const int64_t pidx = locus * S + s;
             const uint32_t o0 = batch.obs_offset[pidx], o1 = batch.obs_offset[pidx + 1];
             int wr = w->soff[s];
+            int fast_s = 1;
             for (uint32_t base = o0; base < o1; base += 64) {
                 uint32_t i = base + lane;
                 bool valid = i < o1;
+                bool tiny = false;
                 uint32_t f = valid ? batch.flags[i] : 0u;
                 bool keep = valid && !(remove_nonstd && f_orient(f) == VLR_ORIENT_OTHER);
                 unsigned long long km = __ballot(keep);
@@ -1299,15 +1444,22 @@ __global__ void __launch_bounds__(64) vlr_call_kernel(const DevPlan* __restrict_
                     if ((A == 0.0 && fa != 0.0 && pa > VLR_NEG_INF) || (R == 0.0 && fr != 0.0 && pr > VLR_NEG_INF))
                         c.status |= VLR_LOCUS_UNDERFLOW;
                     double d = A - R;
+                    double cc_ = wv * R + uu, cq_ = wv * sv * d, ce_ = wv * (1.0 - sv) * d;
                     if (pos < max_obs) {
-                        c.cc[pos] = wv * R + uu;
-                        c.cq[pos] = wv * sv * d;
-                        c.ce[pos] = wv * (1.0 - sv) * d;
+                        c.coef[3 * pos + 0] = cc_;
+                        c.coef[3 * pos + 1] = cq_;
+                        c.coef[3 * pos + 2] = ce_;
                     }
+                    // smallest value the term can take over alpha in [0,1], beta in [0,1] (linear => at a corner)
+                    double mn = fmin(fmin(cc_, cc_ + cq_), fmin(cc_ + ce_, cc_ + cq_ + ce_));
+                    tiny = !(mn >= 0x1p-200);  // also catches NaN
                 }
+                if (__ballot(tiny)) fast_s = 0;
                 wr += popc64(km);
             }
+            if (fast_s) fastmask |= 1 << s;
         }
+        if (lane == 0) w->fastok = fastmask;
         if (lane < S) w->cacheN[lane] = 0;
         __syncthreads();
         if (__ballot((c.status & VLR_LOCUS_UNDERFLOW) != 0)) c.status |= VLR_LOCUS_UNDERFLOW;
@@ -1426,7 +1578,7 @@ __global__ void __launch_bounds__(64) vlr_call_kernel(const DevPlan* __restrict_
 }  // namespace vlr
 
 // host-callable launcher (used by vlr_host.cpp)
-extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_dev, const vlr::DevBatch* batch, const vlr::DevResults* out,
+extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out,
                                       int n_univ, int n_samples, int max_obs, int range_depth, void* stream) {
     using namespace vlr;
     if (batch->n_loci <= 0) return 0;
@@ -1438,6 +1590,6 @@ extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_dev, const vlr::D
     hipError_t e = hipFuncSetAttribute((const void*)vlr_call_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;
     dim3 grid((unsigned)batch->n_loci), block(64);
-    hipLaunchKernelGGL(vlr_call_kernel, grid, block, bytes, (hipStream_t)stream, plan_dev, *batch, *out, max_obs, range_depth);
+    hipLaunchKernelGGL(vlr_call_kernel, grid, block, bytes, (hipStream_t)stream, *plan_host, *batch, *out, max_obs, range_depth);
     return (int)hipGetLastError();
 }

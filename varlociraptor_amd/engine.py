@@ -18,7 +18,7 @@ from . import abi
 from .batch import CallResults, PileupBatch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvlr.so")
+LIB_PATH = os.environ.get("VLR_LIB", os.path.join(_HERE, "libvlr.so"))  # VLR_LIB: tuning variants only
 _LIB = None
 
 EXPORTS = [
