@@ -269,6 +269,11 @@ int  vlr_plan_n_samples(const vlr_plan* plan);
  * observations exceed n_samples * depth are reported with VLR_LOCUS_TOO_DEEP.                           */
 int  vlr_plan_set_max_depth(vlr_plan* plan, int per_sample_depth);
 
+/* Finer form of the same knob: maximum number of kept observations of ONE locus summed over its samples.  A
+ * caller that knows its batch (it decoded the pileups) sets this to the batch maximum: less LDS per
+ * workgroup = more resident waves.  vlr_batch_run_host does this automatically.                          */
+int  vlr_plan_set_max_obs(vlr_plan* plan, int max_obs_per_locus);
+
 /* Evaluate a batch of loci on the plan's device.  All pointers in `in` / `out` are device pointers.
  * `stream` is a hipStream_t (NULL = default stream); the call is stream-ordered and does not synchronise.
  * Replaces the per-record Caller::call_record (calling.rs:720-842) for n_loci records.                  */

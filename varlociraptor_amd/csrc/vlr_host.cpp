@@ -242,6 +242,7 @@ struct vlr_plan {
     vlr::DevPlan* dev = nullptr;
     void* blob = nullptr;      // device arrays
     int max_depth_per_sample = 200;  // reference default max_depth (src/variants/sample.rs:236)
+    int max_obs = 0;                 // 0: max_depth_per_sample * S
     int n_events = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
@@ -484,6 +485,18 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
     if (max_lfc > kMaxLfc) return fail(VLR_ERR_UNSUPPORTED, "more than %d l2fc terms on one path", kMaxLfc);
     if (max_frames > kMaxFrames) return fail(VLR_ERR_UNSUPPORTED, "VAF tree deeper than %d frames", kMaxFrames);
     P.max_range_depth = std::max(1, max_range);
+    {
+        // capacity of a visited-point table: 2 endpoints + 3 per bisection round + 7 tail points, with at most
+        // ceil(ln(1/res) / ln(4/3)) + 1 rounds (the bracket shrinks to at most 3/4 per round,
+        // utils/adaptive_integration.rs:61-94); at least the 11 Simpson points
+        int cap = 16;
+        for (int s = 0; s < S; ++s) {
+            int rounds = (int)std::ceil(std::log(1.0 / d->resolution[s]) / std::log(4.0 / 3.0)) + 1;
+            cap = std::max(cap, 2 + 3 * rounds + 7);
+        }
+        cap = std::min((cap + 3) & ~3, (int)kTableCap);
+        P.table_cap = cap;
+    }
 
     std::vector<DevSpectrum> uni;
     for (int i = 0; i < d->universe_offset[S]; ++i) uni.push_back(conv_spec(d->universe[i]));
@@ -594,6 +607,15 @@ int vlr_plan_set_max_depth(vlr_plan* plan, int per_sample_depth) {
     size_t lds = (size_t)3 * per_sample_depth * plan->host.S * 8;
     if (lds > 120 * 1024) return fail(VLR_ERR_UNSUPPORTED, "max depth %d x %d samples exceeds the LDS budget", per_sample_depth, plan->host.S);
     plan->max_depth_per_sample = per_sample_depth;
+    plan->max_obs = 0;
+    return VLR_OK;
+}
+
+// finer LDS knob: maximum number of kept observations of one locus over all samples
+int vlr_plan_set_max_obs(vlr_plan* plan, int max_obs_per_locus) {
+    if (!plan || max_obs_per_locus < 1) return fail(VLR_ERR_INVALID_ARGUMENT, "invalid max obs");
+    if ((size_t)3 * max_obs_per_locus * 8 > 120 * 1024) return fail(VLR_ERR_UNSUPPORTED, "max obs %d exceeds the LDS budget", max_obs_per_locus);
+    plan->max_obs = max_obs_per_locus;
     return VLR_OK;
 }
 
@@ -623,7 +645,8 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
     r.ln_posterior = out->ln_posterior; r.ln_marginal = out->ln_marginal; r.map_vaf = out->map_vaf;
     r.map_bias = out->map_bias; r.best_event = out->best_event; r.status = out->status;
     r.work = plan->work_dev;
-    int max_obs = plan->max_depth_per_sample * plan->host.S;
+    int max_obs = plan->max_obs > 0 ? plan->max_obs : plan->max_depth_per_sample * plan->host.S;
+    max_obs = (max_obs + 3) & ~3;
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipEventRecord(plan->ev_start, st));
     int rc = vlr_launch_call_kernel(&plan->host, &b, &r, plan->host.n_univ, plan->host.S, max_obs, plan->host.max_range_depth, stream);
@@ -716,7 +739,16 @@ int vlr_batch_run_host(vlr_plan* plan, const vlr_batch* in, vlr_results* out) {
     dr.afd_count = nullptr; dr.afd_vaf = nullptr; dr.afd_lnprob = nullptr;
     if (out->afd_count || out->afd_vaf || out->afd_lnprob)
         return fail(VLR_ERR_UNSUPPORTED, "AFD output is not produced by the device path yet (DESIGN.md: out of scope this round)");
+    // size the LDS coefficient area to this batch (never above the configured budget)
+    int saved_max_obs = plan->max_obs;
+    {
+        int budget = plan->max_obs > 0 ? plan->max_obs : plan->max_depth_per_sample * S;
+        uint32_t mx = 1;
+        for (int64_t l = 0; l < L; ++l) mx = std::max(mx, in->obs_offset[(l + 1) * S] - in->obs_offset[l * S]);
+        plan->max_obs = std::min<int>(budget, (int)mx);
+    }
     int rc = vlr_batch_run(plan, &db, &dr, nullptr);
+    plan->max_obs = saved_max_obs;
     if (rc != VLR_OK) return rc;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out->ln_posterior, dr.ln_posterior, (size_t)L * n_out * 8, hipMemcpyDeviceToHost));

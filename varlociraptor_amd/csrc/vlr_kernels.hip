@@ -58,11 +58,9 @@ struct WaveSt {
     int strong_bias[kMaxSamples][kNHyp];
     int any_strong_alt[kMaxSamples], has_ins[kMaxSamples], has_del[kMaxSamples];
     double pos_all[kMaxSamples], pos_major[kMaxSamples], pos_rate[kMaxSamples];
-    double cacheA[kMaxSamples][kCacheWays], cacheB[kMaxSamples][kCacheWays], cacheV[kMaxSamples][kCacheWays];
     int cacheN[kMaxSamples];
     Frame frames[kMaxFrames];
     RangeSt rs[kMaxRangeDepth];
-    double setv[kMaxSamples][kMaxSet];
     double ptA[kMaxBatchPoints], ptB[kMaxBatchPoints], res[kMaxBatchPoints];
     double ptJ[kMaxBatchPoints];
     double fixedLik[kMaxSamples];
@@ -415,6 +413,9 @@ struct Ctx {
     const DevPlan* __restrict__ plan;
     WaveSt* w;
     double* coef;                    // AoS coefficient triples {c,q,e} (LDS)
+    double* setv;                    // [S][kMaxSet] Set candidates per sample (LDS)
+    double *cacheA, *cacheB, *cacheV;  // [S][kCacheWays] per-sample likelihood cache (LDS)
+    int cap;                         // capacity of one visited-point table
     double *tabX, *tabV, *sx, *sv;   // visited tables [depth][kTableCap], sort scratch
     int lane;
     int S;
@@ -475,7 +476,7 @@ __device__ inline double sample_lik(Ctx& c, int s, double a, double b) {
     int n = w->cacheN[s];
     int lim = n < kCacheWays ? n : kCacheWays;
     for (int i = 0; i < lim; ++i)
-        if (w->cacheA[s][i] == a && w->cacheB[s][i] == b) return w->cacheV[s][i];
+        if (c.cacheA[s * kCacheWays + i] == a && c.cacheB[s * kCacheWays + i] == b) return c.cacheV[s * kCacheWays + i];
     double al, be;
     alpha_beta(*c.plan, s, a, b, al, be);
     __syncthreads();
@@ -490,9 +491,9 @@ __device__ inline double sample_lik(Ctx& c, int s, double a, double b) {
     int slot = n % kCacheWays;
     __syncthreads();
     if (c.lane == 0) {
-        w->cacheA[s][slot] = a;
-        w->cacheB[s][slot] = b;
-        w->cacheV[s][slot] = r;
+        c.cacheA[s * kCacheWays + slot] = a;
+        c.cacheB[s * kCacheWays + slot] = b;
+        c.cacheV[s * kCacheWays + slot] = r;
         w->cacheN[s] = n + 1;
     }
     __syncthreads();
@@ -771,7 +772,7 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
     unsigned long long evals = 0, terms = 0;
 
     for (;;) {
-        if (tn + np > kTableCap) { c.status |= VLR_LOCUS_TABLE_FULL; failed = true; break; }
+        if (tn + np > c.cap) { c.status |= VLR_LOCUS_TABLE_FULL; failed = true; break; }
         const int lg = np <= 1 ? 0 : np <= 2 ? 1 : np <= 4 ? 2 : np <= 8 ? 3 : 4;
         const int LP = 64 >> lg;
         const int j = lane >> (6 - lg);
@@ -961,7 +962,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                             for (int i = 0; i < nd.vafs.set_len && ncand < kMaxSet; ++i) {
                                 double v = p.vafs[nd.vafs.set_off + i];
                                 if (!have_bounds || range_contains(bounds, v)) {
-                                    if (c.lane == 0) w->setv[s][ncand] = v;
+                                    if (c.lane == 0) c.setv[s * kMaxSet + ncand] = v;
                                     ncand++;
                                 }
                             }
@@ -975,7 +976,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                         else if (clear_ref && vr.start > 0.0) dead = true;
                         else if (range_is_singleton(vr)) {
                             __syncthreads();
-                            if (c.lane == 0) w->setv[s][0] = vr.start;
+                            if (c.lane == 0) c.setv[s * kMaxSet] = vr.start;
                             __syncthreads();
                             ncand = 1;
                             as_set = true;
@@ -993,7 +994,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                         f.sv_alive = c.alive;
                     }
                     if (as_set) {
-                        if (c.lane == 0) { f.kind = FK_SET; f.n = ncand; w->ops_vaf[s] = w->setv[s][0]; }
+                        if (c.lane == 0) { f.kind = FK_SET; f.n = ncand; w->ops_vaf[s] = c.setv[s * kMaxSet]; }
                         __syncthreads();
                         sp++;
                         c.present |= (1 << s);
@@ -1055,9 +1056,9 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
         } else if (pc == PC_RANGE_ISSUE) {
             Frame& f = w->frames[sp - 1];
             RangeSt& r = w->rs[f.slot];
-            double* tx = c.tabX + f.slot * kTableCap;
-            double* tv = c.tabV + f.slot * kTableCap;
-            if (r.tn + r.npend > kTableCap) {
+            double* tx = c.tabX + f.slot * c.cap;
+            double* tv = c.tabV + f.slot * c.cap;
+            if (r.tn + r.npend > c.cap) {
                 c.status |= VLR_LOCUS_TABLE_FULL;
                 rv = __builtin_nan("");
                 c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained; c.alive = f.sv_alive;
@@ -1094,8 +1095,8 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
             Frame& f = w->frames[sp - 1];
             if (f.kind == FK_RANGE) {
                 RangeSt& r = w->rs[f.slot];
-                double* tx = c.tabX + f.slot * kTableCap;
-                double* tv = c.tabV + f.slot * kTableCap;
+                double* tx = c.tabX + f.slot * c.cap;
+                double* tv = c.tabV + f.slot * c.cap;
                 __syncthreads();
                 if (c.lane == 0) { tx[r.tn] = r.pend[f.iter]; tv[r.tn] = rv; r.tn = r.tn + 1; f.iter = f.iter + 1; }
                 __syncthreads();
@@ -1126,7 +1127,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                     if (f.kind == FK_SET) {
                         int s = nd.sample;
                         __syncthreads();
-                        if (c.lane == 0) w->ops_vaf[s] = w->setv[s][it];
+                        if (c.lane == 0) w->ops_vaf[s] = c.setv[s * kMaxSet + it];
                         __syncthreads();
                         c.present |= (1 << s);
                         c.disc |= (1 << s);
@@ -1150,7 +1151,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
 
 // ------------------------------------------------------------------------------------------------
 #ifndef VLR_WAVES_PER_EU
-#define VLR_WAVES_PER_EU 1
+#define VLR_WAVES_PER_EU 3
 #endif
 __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const DevPlan plan_arg, DevBatch batch, DevResults out,
                                                        int max_obs, int range_depth) {
@@ -1165,17 +1166,23 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
 
     Ctx c;
     c.plan = &plan_arg; c.w = w; c.lane = lane; c.S = S;
+    const int cap = p.table_cap;
+    c.cap = cap;
     c.coef = dyn;
     c.tabX = dyn + 3 * max_obs;
-    c.tabV = c.tabX + range_depth * kTableCap;
-    c.sx = c.tabV + range_depth * kTableCap;
-    c.sv = c.sx + kTableCap;
-    double* evM = c.sv + kTableCap;
+    c.tabV = c.tabX + range_depth * cap;
+    c.sx = c.tabV + range_depth * cap;
+    c.sv = c.sx + cap;
+    double* evM = c.sv + cap;
     double* evS = evM + p.n_univ;
     const int n_slots = p.n_univ + 1;       // + virtual artifact slot of the `absent` group
     double* mapJ = evS + p.n_univ;          // [n_slots]
     double* mapVaf = mapJ + n_slots;        // [n_slots][S]
-    int* mapHyp = (int*)(mapVaf + n_slots * S);  // [n_slots]
+    c.setv = mapVaf + n_slots * S;          // [S][kMaxSet]
+    c.cacheA = c.setv + S * kMaxSet;        // [S][kCacheWays] x 3
+    c.cacheB = c.cacheA + S * kCacheWays;
+    c.cacheV = c.cacheB + S * kCacheWays;
+    int* mapHyp = (int*)(c.cacheV + S * kCacheWays);  // [n_slots]
     c.mapJ = mapJ; c.mapVaf = mapVaf; c.mapHyp = mapHyp; c.n_slots = n_slots;
     c.status = 0; c.n_eval = 0; c.n_terms = 0;
 
@@ -1584,8 +1591,9 @@ extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_host, const vlr::
     if (batch->n_loci <= 0) return 0;
     if (range_depth < 1) range_depth = 1;
     size_t n_slots = (size_t)n_univ + 1;
-    size_t dbl = (size_t)3 * max_obs + (size_t)2 * range_depth * kTableCap + 2 * kTableCap + (size_t)2 * n_univ + n_slots +
-                 n_slots * n_samples + (n_slots + 1) / 2 + 2;
+    size_t cap = (size_t)plan_host->table_cap;
+    size_t dbl = (size_t)3 * max_obs + (size_t)2 * range_depth * cap + 2 * cap + (size_t)2 * n_univ + n_slots + n_slots * n_samples +
+                 (size_t)n_samples * kMaxSet + (size_t)3 * n_samples * kCacheWays + (n_slots + 1) / 2 + 2;
     size_t bytes = dbl * sizeof(double);
     hipError_t e = hipFuncSetAttribute((const void*)vlr_call_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;

@@ -7,15 +7,16 @@ namespace vlr {
 
 constexpr int kMaxSamples = 8;        // == VLR_MAX_SAMPLES
 constexpr int kMaxLfc = 4;            // LFC terms on one root->leaf path
-constexpr int kMaxFrames = 24;        // explicit recursion stack of the VAF-tree walk
-constexpr int kTableCap = 128;        // visited points of one range chain (57 at resolution 0.01)
+constexpr int kMaxFrames = 16;        // explicit recursion stack of the VAF-tree walk
+constexpr int kTableCap = 128;        // upper limit of visited points of one range chain (57 at resolution 0.01);
+                                      // the per-plan capacity is derived from the finest resolution
 constexpr int kMaxRangeDepth = 4;     // nested Range levels on one path
 constexpr int kMaxSet = 16;           // members of one Set spectrum
 constexpr int kMaxNamedEvents = 31;   // scenario events (engine universe = 1 + 2*named)
 constexpr int kNHyp = 9;              // 0 = Artifacts::none(), 1..8 single-artifact combinations
 constexpr int kCacheWays = 4;         // per-sample pileup-likelihood cache entries
 constexpr int kMaxBatchPoints = 16;   // points evaluated by one eval_pileup call
-constexpr int kContainStack = 48;     // explicit stack of the VAFTree::contains walk
+constexpr int kContainStack = 24;     // explicit stack of the VAFTree::contains walk
 constexpr int kNVariantTypes = 5;
 
 // hypothesis slots, in the cartesian order of Artifacts::all_artifact_combinations
@@ -47,7 +48,7 @@ enum PriorKind { PK_UNIFORM = 0, PK_GERMLINE = 1, PK_SOMATIC = 2 };
 
 struct DevPlan {
     int32_t S, n_named, n_univ, absent_root;
-    int32_t n_nodes, max_range_depth, table_size, pad0;
+    int32_t n_nodes, max_range_depth, table_size, table_cap;
     double resolution[kMaxSamples];
     double rho[kMaxSamples];   // purity (1 - contamination fraction); 1 for uncontaminated samples
     double irho[kMaxSamples];  // 1 - purity

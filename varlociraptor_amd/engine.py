@@ -23,7 +23,7 @@ _LIB = None
 
 EXPORTS = [
     "vlr_abi_version", "vlr_last_error", "vlr_plan_create", "vlr_plan_destroy", "vlr_plan_n_out",
-    "vlr_plan_n_samples", "vlr_plan_set_max_depth", "vlr_batch_run", "vlr_batch_run_host",
+    "vlr_plan_n_samples", "vlr_plan_set_max_depth", "vlr_plan_set_max_obs", "vlr_batch_run", "vlr_batch_run_host",
     "vlr_plan_last_kernel_ms", "vlr_plan_work_counters",
 ]
 
@@ -61,6 +61,8 @@ def lib():
         L.vlr_plan_n_samples.argtypes = [C.c_void_p]
         L.vlr_plan_set_max_depth.restype = C.c_int
         L.vlr_plan_set_max_depth.argtypes = [C.c_void_p, C.c_int]
+        L.vlr_plan_set_max_obs.restype = C.c_int
+        L.vlr_plan_set_max_obs.argtypes = [C.c_void_p, C.c_int]
         L.vlr_batch_run.restype = C.c_int
         L.vlr_batch_run.argtypes = [C.c_void_p, C.POINTER(abi.Batch), C.POINTER(abi.Results), C.c_void_p]
         L.vlr_batch_run_host.restype = C.c_int
@@ -96,6 +98,9 @@ class Plan:
 
     def set_max_depth(self, depth: int):
         _check(lib().vlr_plan_set_max_depth(self._h, int(depth)))
+
+    def set_max_obs(self, n: int):
+        _check(lib().vlr_plan_set_max_obs(self._h, int(n)))
 
     def close(self):
         if self._h:
