@@ -49,6 +49,14 @@ struct RangeSt {
     int have_first, phase, npend, simpson_n, tn, sample, olex, orex, leaf, have_mid;
 };
 
+constexpr int kRows = 4;        // concurrent chains per wave: one per 16-lane DPP row
+constexpr int kRowPts = 12;     // pending points of one chain round (<= 11)
+
+struct ChainTask {              // one innermost Range chain (see run_chain_batch)
+    double lo, hi, res, ostart, oend, fixed, result, bestJ, bestX;
+    int olex, orex, simpson_n, pidx, contained, alive, haveBest, n;
+};
+
 struct WaveSt {
     double ops_vaf[kMaxSamples];
     double lfc_val[kMaxLfc];
@@ -66,6 +74,8 @@ struct WaveSt {
     double fixedLik[kMaxSamples];
     double curMapVaf[kMaxSamples];
     int cs_node[kContainStack], cs_mask[kContainStack];
+    ChainTask task[kRows];
+    double bpend[kRows][kRowPts], bvals[kRows][kRowPts];
     int fastok;  // bit s: all terms of sample s stay >= 2^-200 under the current hypothesis (4-term renormalisation is safe)
 };
 
@@ -416,6 +426,8 @@ struct Ctx {
     double* setv;                    // [S][kMaxSet] Set candidates per sample (LDS)
     double *cacheA, *cacheB, *cacheV;  // [S][kCacheWays] per-sample likelihood cache (LDS)
     int cap;                         // capacity of one visited-point table
+    double *rowX, *rowV;             // [kRows][cap] visited-point tables of the row-parallel innermost chains
+    double* tvaf;                    // [kRows][S] outer operands of the chain tasks
     double *tabX, *tabV, *sx, *sv;   // visited tables [depth][kTableCap], sort scratch
     int lane;
     int S;
@@ -885,6 +897,238 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
     return integrate_table(tx, tv, tn, c.sx, c.sv, lane);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Row-parallel innermost chains: up to kRows sibling chains (same integrated sample, different outer operands)
+// run concurrently, one per 16-lane DPP row.  Every "uniform" control instruction of the adaptive integrator now
+// serves four chains; the row's 16 lanes are split into (point, slice) groups for the pileup products and the
+// partial products are combined with in-row DPP permutes (a 16-lane row is exactly one DPP row).
+__device__ __forceinline__ void row_product(double& P, int& E, int lgp) {
+    if (lgp >= 1) { P *= dpp_f64<0xB1>(P); E += dpp_i32<0xB1>(E); }
+    if (lgp >= 2) { P *= dpp_f64<0x4E>(P); E += dpp_i32<0x4E>(E); }
+    if (lgp >= 3) { P *= dpp_f64<0x141>(P); E += dpp_i32<0x141>(E); }
+    if (lgp >= 4) { P *= dpp_f64<0x140>(P); E += dpp_i32<0x140>(E); }
+    int e2;
+    P = __builtin_frexp(P, &e2);
+    E += e2;
+}
+__device__ __forceinline__ double row_max(double v) {
+    v = fmax(v, dpp_f64<0xB1>(v)); v = fmax(v, dpp_f64<0x4E>(v)); v = fmax(v, dpp_f64<0x141>(v)); v = fmax(v, dpp_f64<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ double row_sum(double v) {
+    v += dpp_f64<0xB1>(v); v += dpp_f64<0x4E>(v); v += dpp_f64<0x141>(v); v += dpp_f64<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ int row_or(int v) {
+    v |= dpp_i32<0xB1>(v); v |= dpp_i32<0x4E>(v); v |= dpp_i32<0x141>(v); v |= dpp_i32<0x140>(v);
+    return v;
+}
+
+__device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
+    const DevPlan& p = *c.plan;
+    WaveSt* w = c.w;
+    const int lane = c.lane, row = lane >> 4, rl = lane & 15;
+    const bool rowon = row < nt;
+    const int cap = c.cap;
+    __builtin_amdgcn_wave_barrier();
+    const ChainTask& T = w->task[rowon ? row : 0];
+    const double lo = T.lo, hi = T.hi, res = T.res, fixed = T.fixed;
+    const RangeV orig{T.ostart, T.oend, T.olex, T.orex};
+    const int simpson_n = T.simpson_n, pidx = T.pidx, contained = T.contained;
+    const double* tvr = c.tvaf + (rowon ? row : 0) * c.S;
+    double* tx = c.rowX + row * cap;
+    double* tv = c.rowV + row * cap;
+    double* pend = w->bpend[row];
+    double* vals = w->bvals[row];
+    int dep = 0;
+    for (int s = 0; s < c.S; ++s)
+        if (s == inner || p.by[s] == inner) dep |= 1 << s;
+    const double* ptab = p.prior_table + c.vt * p.table_size;
+    const int istride = p.class_stride[inner];
+    // prior class of the integrated sample: if one Range spectrum of a uniform-prior universe covers [lo, hi],
+    // every point of the chain is inside the universe (class 1, or 0 at exactly 0) — no per-point spectrum walk
+    bool cls_fast = false;
+    if (p.prior_kind[inner] == PK_UNIFORM)
+        for (int u = p.uni_off[inner]; u < p.uni_off[inner + 1]; ++u) {
+            const DevSpectrum& sp = p.universe[u];
+            if (sp.kind == 1) {
+                RangeV ur{sp.start, sp.end, sp.lex, sp.rex};
+                cls_fast = cls_fast || (range_contains(ur, lo) && range_contains(ur, hi));
+            }
+        }
+
+    int np, phase, tn = 0;
+    bool done = !rowon;
+    if (simpson_n) {
+        double step = (hi - lo) / (double)(simpson_n - 1);
+        if (rl < simpson_n) pend[rl] = (rl == 0) ? lo : (rl == simpson_n - 1) ? hi : lo + step * (double)rl;
+        np = simpson_n;
+        phase = RP_SIMPSON;
+    } else {
+        if (rl < 2) pend[rl] = rl ? hi : lo;
+        np = 2;
+        phase = RP_INIT;
+    }
+    double L = lo, R = hi, vL = VLR_NEG_INF, vR = VLR_NEG_INF, mid = lo, first_mid = lo;
+    bool have_first = false, have_mid = false, failed = false, sawnan = false;
+    unsigned evals = 0, terms = 0;
+    __builtin_amdgcn_wave_barrier();
+
+    while (__ballot(!done)) {
+        const bool act = !done;
+        if (act && tn + np > cap) { failed = true; done = true; }
+        const bool go = act && !failed;
+        const int lgp = np <= 1 ? 4 : np <= 2 ? 3 : np <= 4 ? 2 : np <= 8 ? 1 : 0;  // lanes per point = 2^lgp
+        const int LPr = 1 << lgp;
+        const int j = rl >> lgp, k = rl & (LPr - 1);
+        const int jj = j < np ? j : np - 1;
+        const double x = pend[jj];
+        double lik = fixed;
+        int dm = dep;
+        while (dm) {
+            int s = __builtin_ctz(dm);
+            dm &= dm - 1;
+            int by = p.by[s];
+            double a = (s == inner) ? x : tvr[s];
+            double b = by >= 0 ? ((by == inner) ? x : tvr[by]) : 0.0;
+            double al, be;
+            alpha_beta(p, s, a, b, al, be);
+            const int off = w->soff[s], D = go ? w->nkeep[s] : 0;
+            double P;
+            int E;
+            pileup_partial(c.coef + 3 * off, D, LPr, k, al, be, (w->fastok >> s) & 1, P, E);
+            row_product(P, E, lgp);
+            lik += log(P) + (double)E * kLn2;
+            if (go && rl == 0) { evals += (unsigned)np; terms += (unsigned)np * (unsigned)w->nkeep[s]; }
+        }
+        double joint;
+        if (c.nlfc > 0 && !lfcs_ok(c, inner, x)) joint = VLR_NEG_INF;
+        else {
+            int cls = cls_fast ? (x == 0.0 ? 0 : 1) : prior_class(p, inner, x);
+            joint = ptab[pidx + cls * istride] + lik;
+        }
+        if (go && j < np && joint != joint) sawnan = true;
+        if (go && k == 0 && j < np) { tx[tn + j] = x; tv[tn + j] = joint; vals[j] = joint; }
+        __builtin_amdgcn_wave_barrier();
+        if (go) {
+            tn += np;
+            if (phase == RP_SIMPSON || phase == RP_TAIL) done = true;
+            else {
+                if (phase == RP_INIT) { L = lo; R = hi; vL = vals[0]; vR = vals[1]; }
+                else {  // argmax over {left, middle1, middle2, right}; lowest index wins ties
+                    double xs1 = pend[1], xs2 = pend[2];
+                    double v1 = vals[1], v2 = vals[2];
+                    int kk = 0;
+                    double vb = vL;
+                    if (v1 > vb) { kk = 1; vb = v1; }
+                    if (v2 > vb) { kk = 2; vb = v2; }
+                    if (vR > vb) { kk = 3; }
+                    if (kk == 0) { R = xs1; vR = v1; }
+                    else if (kk == 1) { R = xs2; vR = v2; }
+                    else if (kk == 2) { L = xs1; vL = v1; }
+                    else { L = xs2; vL = v2; }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if ((((R - L) >= res) && L < R) || !have_mid) {
+                    mid = (R + L) / 2.0;
+                    have_mid = true;
+                    if (!have_first) { first_mid = mid; have_first = true; }
+                    double m1 = (mid + L) / 2.0, m2 = (R + mid) / 2.0;
+                    if (rl < 3) pend[rl] = (rl == 0) ? mid : (rl == 1) ? m1 : m2;
+                    np = 3;
+                    phase = RP_ROUND;
+                } else {
+                    double arm = (mid < first_mid) ? (hi + first_mid) / 2.0 : (first_mid + lo) / 2.0;
+                    double lo3 = fmax(mid - res * 3.0, lo);
+                    double hi3 = fmin(mid + res * 3.0, hi);
+                    double sa = (mid - lo3) / 3.0, sb = (hi3 - mid) / 3.0;
+                    if (rl < 7) {
+                        double v;
+                        if (rl == 0) v = arm;
+                        else if (rl <= 3) v = lo3 + sa * (double)(rl - 1);
+                        else v = mid + sb * (double)(rl - 3);
+                        pend[rl] = v;
+                    }
+                    np = 7;
+                    phase = RP_TAIL;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (__ballot(failed)) c.status |= VLR_LOCUS_TABLE_FULL;
+    if (__ballot(sawnan)) c.status |= VLR_LOCUS_NAN;
+    {   // work counters: row leaders hold their row's counts
+        unsigned e2 = evals, t2 = terms;
+        e2 += __shfl_xor(e2, 16); e2 += __shfl_xor(e2, 32);
+        t2 += __shfl_xor(t2, 16); t2 += __shfl_xor(t2, 32);
+        c.n_eval += (unsigned long long)__shfl(e2, 0);
+        c.n_terms += (unsigned long long)__shfl(t2, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- epilogue, row-parallel: MAP candidate of the chain and the integral over the visited points
+    const int n = (rowon && !failed) ? tn : 0;
+    double bJ = VLR_NEG_INF, bX = 0.0;
+    int bHave = 0;
+    double tval[4];
+    bool anynan = false;
+    for (int t = 0; t < 4; ++t) {
+        int i = rl + 16 * t;
+        tval[t] = VLR_NEG_INF;
+        if (i < n) {
+            double xi = tx[i], vi = tv[i];
+            if (contained && range_contains(orig, xi) && vi == vi && (!bHave || vi > bJ || (vi == bJ && xi < bX))) { bJ = vi; bX = xi; bHave = 1; }
+            if (phase == RP_SIMPSON) {  // bio LogProb::ln_simpsons_integrate_exp weights
+                double wgt = (i == 0 || i == n - 1) ? 0.0 : log((double)(2 + (i % 2) * 2));
+                tval[t] = vi + wgt;
+            } else {
+                // successor in (x, index) order = next grid point of the sorted, de-duplicated table
+                double sx = __builtin_huge_val(), sv = VLR_NEG_INF;
+                int sj = -1;
+                for (int q = 0; q < n; ++q) {
+                    double xq = tx[q];
+                    bool gt = (xq > xi) || (xq == xi && q > i);
+                    bool better = gt && (sj < 0 || xq < sx || (xq == sx && q < sj));
+                    if (better) { sx = xq; sv = tv[q]; sj = q; }
+                }
+                if (sj >= 0) tval[t] = ln_add_exp(vi, sv) + log((sx - xi) / 2.0);
+            }
+            if (tval[t] != tval[t]) anynan = true;
+        }
+    }
+    // row arg-best of (bJ desc, bX asc)
+    for (int st = 0; st < 4; ++st) {
+        double oJ, oX;
+        int oH;
+        if (st == 0) { oJ = dpp_f64<0xB1>(bJ); oX = dpp_f64<0xB1>(bX); oH = dpp_i32<0xB1>(bHave); }
+        else if (st == 1) { oJ = dpp_f64<0x4E>(bJ); oX = dpp_f64<0x4E>(bX); oH = dpp_i32<0x4E>(bHave); }
+        else if (st == 2) { oJ = dpp_f64<0x141>(bJ); oX = dpp_f64<0x141>(bX); oH = dpp_i32<0x141>(bHave); }
+        else { oJ = dpp_f64<0x140>(bJ); oX = dpp_f64<0x140>(bX); oH = dpp_i32<0x140>(bHave); }
+        bool take = oH && (!bHave || oJ > bJ || (oJ == bJ && oX < bX));
+        if (take) { bJ = oJ; bX = oX; bHave = 1; }
+    }
+    double m4 = fmax(fmax(tval[0], tval[1]), fmax(tval[2], tval[3]));
+    int nanrow = row_or(anynan ? 1 : 0);
+    double M = row_max(m4 == m4 ? m4 : VLR_NEG_INF);
+    double r;
+    if (M == VLR_NEG_INF) r = VLR_NEG_INF;
+    else {
+        double ssum = 0.0;
+        for (int t = 0; t < 4; ++t) ssum += (tval[t] == VLR_NEG_INF || tval[t] != tval[t]) ? 0.0 : exp(tval[t] - M);
+        ssum = row_sum(ssum);
+        r = M + log(ssum);
+    }
+    if (phase == RP_SIMPSON) r = r + log(hi - lo) - log((double)(simpson_n - 1)) - log(3.0);
+    if (nanrow || failed) r = __builtin_nan("");
+    if (rowon && rl == 0) {
+        ChainTask& To = w->task[row];
+        To.result = r; To.bestJ = bJ; To.bestX = bX; To.haveBest = bHave; To.n = n;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+}
+
 // LikelihoodOperands::lfc_bounds (modes/generic.rs:148-174)
 __device__ inline bool ops_lfc_bounds(const Ctx& c, int sample, RangeV& out) {
     bool have = false;
@@ -909,6 +1153,104 @@ __device__ inline bool ops_lfc_bounds(const Ctx& c, int sample, RangeV& out) {
     return have;
 }
 
+// Outer Range frame whose single child is a leaf Range node (the nested `somatic_normal` shape): evaluate the
+// inner chains of ALL pending outer points together, kRows at a time (run_chain_batch), instead of descending
+// once per point.  Semantics identical to the sequential walk (modes/generic.rs:331-395 for the child node).
+__device__ __forceinline__ void batch_outer_points(Ctx& c, const Frame& f, RangeSt& r, int chn, double* txo, double* tvo) {
+    const DevPlan& p = *c.plan;
+    WaveSt* w = c.w;
+    const DevNode& ch = p.nodes[chn];
+    const int s_in = ch.sample, s_out = r.sample, S = c.S, lane = c.lane;
+    const int n_obs = w->nkeep[s_in];
+    const bool clear_ref = n_obs > 10 && w->all_posref[s_in];
+    const RangeV vr{ch.vafs.start, ch.vafs.end, ch.vafs.lex, ch.vafs.rex};
+    const bool dead = clear_ref && vr.start > 0.0;  // generic.rs:342-347
+    const double res = p.resolution[s_in];
+    const double lo = observable_min(vr, n_obs), hi = observable_max(vr, n_obs);
+    const int simpson = ((hi - lo) < res) ? 3 : (n_obs < 5 ? 11 : 0);
+    const RangeV oorig{r.ostart, r.oend, r.olex, r.orex};
+    const int np = r.npend;
+    // samples whose likelihood is fixed during an inner chain: constant over the outer points, or varying with them
+    double fixed_const = 0.0;
+    int vary = 0;
+    for (int s = 0; s < S; ++s) {
+        int by = p.by[s];
+        if (s == s_in || by == s_in) continue;
+        if (s == s_out || by == s_out) vary |= 1 << s;
+        else fixed_const += sample_lik(c, s, w->ops_vaf[s], by >= 0 ? w->ops_vaf[by] : 0.0);
+    }
+    for (int c0 = 0; c0 < np; c0 += kRows) {
+        const int nt = (np - c0) < kRows ? (np - c0) : kRows;
+        __syncthreads();
+        if (lane < nt) {
+            const double x = r.pend[c0 + lane];
+            ChainTask& T = w->task[lane];
+            T.lo = lo; T.hi = hi; T.res = res;
+            T.ostart = ch.vafs.start; T.oend = ch.vafs.end; T.olex = ch.vafs.lex; T.orex = ch.vafs.rex;
+            T.simpson_n = simpson;
+            T.contained = f.sv_contained && range_contains(oorig, x);
+            T.alive = alive_update(c, f.sv_alive, s_out, x);
+            int pidx = 0;
+            for (int s = 0; s < S; ++s) {
+                double v = (s == s_out) ? x : w->ops_vaf[s];
+                c.tvaf[lane * S + s] = v;
+                if (s != s_in) pidx += prior_class(p, s, v) * p.class_stride[s];
+            }
+            T.pidx = pidx;
+            T.fixed = fixed_const;
+            T.result = VLR_NEG_INF; T.haveBest = 0; T.n = 0; T.bestJ = VLR_NEG_INF; T.bestX = 0.0;
+        }
+        __syncthreads();
+        int vm = vary;
+        while (vm && !dead) {
+            int s = __builtin_ctz(vm);
+            vm &= vm - 1;
+            int by = p.by[s];
+            if (lane < nt) {
+                double a = c.tvaf[lane * S + s];
+                double b = by >= 0 ? c.tvaf[lane * S + by] : 0.0;
+                double al, be;
+                alpha_beta(p, s, a, b, al, be);
+                w->ptA[lane] = al;
+                w->ptB[lane] = be;
+            }
+            __syncthreads();
+            int off = w->soff[s], D = w->nkeep[s];
+            eval_pileup(c.coef + 3 * off, D, (w->fastok >> s) & 1, nt, w->ptA, w->ptB, w->res, lane);
+            __syncthreads();
+            if (lane < nt) w->task[lane].fixed += w->res[lane];
+            c.n_eval += (unsigned long long)nt;
+            c.n_terms += (unsigned long long)nt * (unsigned long long)D;
+            __syncthreads();
+        }
+        if (!dead) run_chain_batch(c, nt, s_in);
+        __syncthreads();
+        for (int i = 0; i < nt; ++i) {
+            const ChainTask& T = w->task[i];
+            const double x = r.pend[c0 + i];
+            __syncthreads();
+            if (lane == 0) { txo[r.tn + c0 + i] = x; tvo[r.tn + c0 + i] = dead ? VLR_NEG_INF : T.result; w->ops_vaf[s_out] = x; }
+            __syncthreads();
+            if (dead) continue;
+            if (T.haveBest) map_consider(c, T.bestJ, s_in, T.bestX);
+            if (T.alive != 0 || !T.contained) {  // rare: candidates for other groups / containment via another path
+                const RangeV io{T.ostart, T.oend, T.olex, T.orex};
+                const double* rx = c.rowX + i * c.cap;
+                const double* rvv = c.rowV + i * c.cap;
+                for (int q = 0; q < T.n; ++q) {
+                    double xq = rx[q];
+                    bool own = T.contained && range_contains(io, xq);
+                    int al = T.alive ? alive_update(c, T.alive, s_in, xq) : 0;
+                    if (!own || al) map_all(c, rvv[q], s_in, xq, false, al);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (lane == 0) r.tn = r.tn + np;
+    __syncthreads();
+}
+
 // GenericPosterior::density (modes/generic.rs:190-423) for one (hypothesis, root): explicit-stack walk.
 __device__ __forceinline__ double walk_root(Ctx& c, int root) {
     const DevPlan& p = *c.plan;
@@ -918,6 +1260,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
     int sp = 0, node = root, nrange = 0;
     enum { PC_DESCEND, PC_SUB, PC_RETURN, PC_RANGE_ISSUE } pc = PC_DESCEND;
     double rv = VLR_NEG_INF;
+    bool skip_record = false;
     for (;;) {
         if (pc == PC_DESCEND) {
             const DevNode& nd = p.nodes[node];
@@ -1070,9 +1413,24 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                 c.nlfc = f.sv_nlfc;
                 c.contained = f.sv_contained;
                 c.alive = f.sv_alive;
-                rv = run_leaf_chain(c, r, tx, tv);
+                rv = run_leaf_chain(c, r, c.rowX, c.rowV);
                 c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained; c.alive = f.sv_alive;
                 sp--; nrange--;
+                pc = PC_RETURN;
+            } else if (f.iter == 0 && f.sv_nlfc == 0 && p.nodes[f.node].n_children == 1 &&
+                       p.nodes[p.child_index[p.nodes[f.node].child_off]].kind == VLR_NODE_SAMPLE &&
+                       p.nodes[p.child_index[p.nodes[f.node].child_off]].vafs.kind == 1 &&
+                       p.nodes[p.child_index[p.nodes[f.node].child_off]].n_children == 0 &&
+                       p.nodes[p.child_index[p.nodes[f.node].child_off]].vafs.start != p.nodes[p.child_index[p.nodes[f.node].child_off]].vafs.end) {
+                // outer chain over a leaf Range child: all pending points at once, kRows inner chains per pass
+                c.present = f.sv_present | (1 << r.sample);
+                c.disc = f.sv_disc & ~(1 << r.sample);
+                c.nlfc = f.sv_nlfc;
+                batch_outer_points(c, f, r, p.child_index[p.nodes[f.node].child_off], tx, tv);
+                __syncthreads();
+                if (c.lane == 0) f.iter = r.npend;
+                __syncthreads();
+                skip_record = true;
                 pc = PC_RETURN;
             } else {
                 // outer chain: one point at a time through the subtree
@@ -1098,7 +1456,8 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                 double* tx = c.tabX + f.slot * c.cap;
                 double* tv = c.tabV + f.slot * c.cap;
                 __syncthreads();
-                if (c.lane == 0) { tx[r.tn] = r.pend[f.iter]; tv[r.tn] = rv; r.tn = r.tn + 1; f.iter = f.iter + 1; }
+                if (c.lane == 0 && !skip_record) { tx[r.tn] = r.pend[f.iter]; tv[r.tn] = rv; r.tn = r.tn + 1; f.iter = f.iter + 1; }
+                skip_record = false;
                 __syncthreads();
                 if (f.iter < r.npend) { pc = PC_RANGE_ISSUE; }
                 else {
@@ -1171,9 +1530,14 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
     c.coef = dyn;
     c.tabX = dyn + 3 * max_obs;
     c.tabV = c.tabX + range_depth * cap;
-    c.sx = c.tabV + range_depth * cap;
-    c.sv = c.sx + cap;
-    double* evM = c.sv + cap;
+    c.rowX = c.tabV + range_depth * cap;
+    c.rowV = c.rowX + kRows * cap;
+    // sort scratch of integrate_table aliases row 1: it is only used by outer chains (whose inner chains are
+    // finished) and by the single-chain fallback (which owns row 0)
+    c.sx = c.rowX + cap;
+    c.sv = c.rowV + cap;
+    c.tvaf = c.rowV + kRows * cap;
+    double* evM = c.tvaf + kRows * S;
     double* evS = evM + p.n_univ;
     const int n_slots = p.n_univ + 1;       // + virtual artifact slot of the `absent` group
     double* mapJ = evS + p.n_univ;          // [n_slots]
@@ -1592,8 +1956,9 @@ extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_host, const vlr::
     if (range_depth < 1) range_depth = 1;
     size_t n_slots = (size_t)n_univ + 1;
     size_t cap = (size_t)plan_host->table_cap;
-    size_t dbl = (size_t)3 * max_obs + (size_t)2 * range_depth * cap + 2 * cap + (size_t)2 * n_univ + n_slots + n_slots * n_samples +
-                 (size_t)n_samples * kMaxSet + (size_t)3 * n_samples * kCacheWays + (n_slots + 1) / 2 + 2;
+    size_t dbl = (size_t)3 * max_obs + (size_t)2 * range_depth * cap + (size_t)2 * kRows * cap + (size_t)kRows * n_samples +
+                 (size_t)2 * n_univ + n_slots + n_slots * n_samples + (size_t)n_samples * kMaxSet + (size_t)3 * n_samples * kCacheWays +
+                 (n_slots + 1) / 2 + 2;
     size_t bytes = dbl * sizeof(double);
     hipError_t e = hipFuncSetAttribute((const void*)vlr_call_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;
