@@ -1510,7 +1510,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
 
 // ------------------------------------------------------------------------------------------------
 #ifndef VLR_WAVES_PER_EU
-#define VLR_WAVES_PER_EU 3
+#define VLR_WAVES_PER_EU 2
 #endif
 __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const DevPlan plan_arg, DevBatch batch, DevResults out,
                                                        int max_obs, int range_depth) {
