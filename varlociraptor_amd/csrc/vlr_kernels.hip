@@ -26,6 +26,17 @@
 
 namespace vlr {
 
+// optional per-phase cycle accounting (build with -DVLR_PROFILE): wall cycles of the wave spent per phase
+#ifdef VLR_PROFILE
+#define PROF_DECL unsigned long long prof[12]; unsigned long long prof_t;
+#define PROF_START(c) (c).prof_t = __builtin_amdgcn_s_memtime()
+#define PROF_ADD(c, i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); (c).prof[i] += t_ - (c).prof_t; (c).prof_t = t_; } while (0)
+#else
+#define PROF_DECL
+#define PROF_START(c)
+#define PROF_ADD(c, i)
+#endif
+
 #define VLR_NEG_INF (-__builtin_huge_val())
 __device__ constexpr double kLn05 = -0.6931471805599453;    // ln 0.5   (utils/mod.rs:45 PROB_05)
 __device__ constexpr double kLn095 = -0.05129329438755058;  // ln 0.95  (utils/mod.rs:48 PROB_095)
@@ -80,6 +91,13 @@ struct WaveSt {
 };
 
 // ------------------------------------------------------------------------------------------------
+// values that are wave-uniform by construction but live in VGPRs/LDS: moving them to SGPRs lets the compiler
+// use scalar branches and scalar (cached) loads of plan data instead of vector loads
+#define UNI(x) __builtin_amdgcn_readfirstlane(x)
+__device__ __forceinline__ double uni_d(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
 // wave helpers (wave64; one wave per workgroup so __syncthreads() is a wave-level LDS fence)
 __device__ inline double wave_sum(double v) {
 #pragma unroll
@@ -445,6 +463,7 @@ struct Ctx {
     int curHyp;
     unsigned status;
     unsigned long long n_eval, n_terms;
+    PROF_DECL
 };
 
 // Prior::compute via the host-built class table (prior.rs:715-762; see vlr_host.cpp build_prior_table)
@@ -741,6 +760,10 @@ __device__ inline double range_finish(Ctx& c, RangeSt& r, const double* tx, cons
 // are hoisted out of the rounds, each lane selects its point from uniform registers, and results come
 // back through lane broadcasts — no barriers, no LDS traffic besides coefficient reads and table appends.
 __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx, double* tv) {
+    PROF_ADD(c, 3);
+#ifdef VLR_PROFILE
+    c.prof[11] += 1;
+#endif
     const DevPlan& p = *c.plan;
     WaveSt* w = c.w;
     const int lane = c.lane;
@@ -759,6 +782,8 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
     }
     const double* ptab = p.prior_table + c.vt * p.table_size;
     const int istride = p.class_stride[inner];
+    const int ncls = p.n_class[inner];
+    const double pr0 = ptab[pidx], pr1 = ncls > 1 ? ptab[pidx + istride] : VLR_NEG_INF, pr2 = ncls > 2 ? ptab[pidx + 2 * istride] : VLR_NEG_INF;
 
     // pending points and their joint values live in two tiny LDS arrays (same-wave LDS ops execute in order;
     // wave_barrier() only stops the compiler from reordering them)
@@ -813,7 +838,10 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
         }
         double joint;
         if (c.nlfc > 0 && !lfcs_ok(c, inner, x)) joint = VLR_NEG_INF;
-        else joint = ptab[pidx + prior_class(p, inner, x) * istride] + lik;
+        else {
+            int cls = prior_class(p, inner, x);
+            joint = (cls == 0 ? pr0 : cls == 1 ? pr1 : cls == 2 ? pr2 : ptab[pidx + cls * istride]) + lik;
+        }
         if (__ballot(joint != joint)) c.status |= VLR_LOCUS_NAN;
         if (k == 0 && j < np) { tx[tn + j] = x; tv[tn + j] = joint; }
 
@@ -883,6 +911,7 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
     }
     c.n_eval += evals;
     c.n_terms += terms;
+    PROF_ADD(c, 4);  // single-chain rounds
     if (haveBest) map_consider(c, bestJ, inner, bestX);
     if (failed) return __builtin_nan("");
     __builtin_amdgcn_wave_barrier();
@@ -894,7 +923,9 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
         lse_add(M, S, tv[simpson_n - 1]);
         return lse_value(M, S) + log(hi - lo) - log((double)(simpson_n - 1)) - log(3.0);
     }
-    return integrate_table(tx, tv, tn, c.sx, c.sv, lane);
+    double rr_ = integrate_table(tx, tv, tn, c.sx, c.sv, lane);
+    PROF_ADD(c, 5);  // single-chain integrate
+    return rr_;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -925,6 +956,10 @@ __device__ __forceinline__ int row_or(int v) {
 }
 
 __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
+    PROF_ADD(c, 6);  // batch preparation (task setup, fixed-sample likelihoods)
+#ifdef VLR_PROFILE
+    c.prof[10] += 1;
+#endif
     const DevPlan& p = *c.plan;
     WaveSt* w = c.w;
     const int lane = c.lane, row = lane >> 4, rl = lane & 15;
@@ -943,8 +978,22 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
     int dep = 0;
     for (int s = 0; s < c.S; ++s)
         if (s == inner || p.by[s] == inner) dep |= 1 << s;
+    // the first dependent sample (there is always one: `inner` itself or the sample it contaminates)
+    const int d0 = __builtin_ctz(dep);
+    const int dep_rest = dep & (dep - 1);
+    const int d0_byi = p.by[d0];
+    const bool d0_cont = d0_byi >= 0, d0_is_inner = (d0 == inner), d0_by_inner = (d0_byi == inner);
+    const double d0_rho = p.rho[d0], d0_irho = p.irho[d0];
+    const double d0_a = tvr[d0], d0_b = d0_cont ? tvr[d0_byi] : 0.0;
+    const double* d0_coef = c.coef + 3 * w->soff[d0];
+    const int d0_D = w->nkeep[d0];
+    const bool d0_fast = (w->fastok >> d0) & 1;
     const double* ptab = p.prior_table + c.vt * p.table_size;
     const int istride = p.class_stride[inner];
+    // prior values of the first classes of the integrated sample, loaded once (a global load per round would sit
+    // on the critical path of every round)
+    const int ncls = p.n_class[inner];
+    const double pr0 = ptab[pidx], pr1 = ncls > 1 ? ptab[pidx + istride] : VLR_NEG_INF, pr2 = ncls > 2 ? ptab[pidx + 2 * istride] : VLR_NEG_INF;
     // prior class of the integrated sample: if one Range spectrum of a uniform-prior universe covers [lo, hi],
     // every point of the chain is inside the universe (class 1, or 0 at exactly 0) — no per-point spectrum walk
     bool cls_fast = false;
@@ -984,7 +1033,20 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
         const int jj = j < np ? j : np - 1;
         const double x = pend[jj];
         double lik = fixed;
-        int dm = dep;
+        {   // first dependent sample: everything but x hoisted out of the rounds
+            double a = d0_is_inner ? x : d0_a;
+            double b = d0_by_inner ? x : d0_b;
+            double al, be;
+            if (d0_cont) { al = d0_rho * a + d0_irho * b; be = d0_rho * (a == 1.0 ? 1.0 : 0.0) + d0_irho * (b == 1.0 ? 1.0 : 0.0); }
+            else { al = a; be = (a == 1.0) ? 1.0 : 0.0; }
+            double P;
+            int E;
+            pileup_partial(d0_coef, go ? d0_D : 0, LPr, k, al, be, d0_fast, P, E);
+            row_product(P, E, lgp);
+            lik += log(P) + (double)E * kLn2;
+            if (go && rl == 0) { evals += (unsigned)np; terms += (unsigned)np * (unsigned)d0_D; }
+        }
+        int dm = dep_rest;
         while (dm) {
             int s = __builtin_ctz(dm);
             dm &= dm - 1;
@@ -1005,7 +1067,8 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
         if (c.nlfc > 0 && !lfcs_ok(c, inner, x)) joint = VLR_NEG_INF;
         else {
             int cls = cls_fast ? (x == 0.0 ? 0 : 1) : prior_class(p, inner, x);
-            joint = ptab[pidx + cls * istride] + lik;
+            double pv = cls == 0 ? pr0 : cls == 1 ? pr1 : cls == 2 ? pr2 : ptab[pidx + cls * istride];
+            joint = pv + lik;
         }
         if (go && j < np && joint != joint) sawnan = true;
         if (go && k == 0 && j < np) { tx[tn + j] = x; tv[tn + j] = joint; vals[j] = joint; }
@@ -1056,6 +1119,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
         }
         __builtin_amdgcn_wave_barrier();
     }
+    PROF_ADD(c, 7);  // batch rounds
     if (__ballot(failed)) c.status |= VLR_LOCUS_TABLE_FULL;
     if (__ballot(sawnan)) c.status |= VLR_LOCUS_NAN;
     {   // work counters: row leaders hold their row's counts
@@ -1071,54 +1135,85 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
     const int n = (rowon && !failed) ? tn : 0;
     double bJ = VLR_NEG_INF, bX = 0.0;
     int bHave = 0;
-    double tval[4];
     bool anynan = false;
-    for (int t = 0; t < 4; ++t) {
-        int i = rl + 16 * t;
-        tval[t] = VLR_NEG_INF;
-        if (i < n) {
-            double xi = tx[i], vi = tv[i];
-            if (contained && range_contains(orig, xi) && vi == vi && (!bHave || vi > bJ || (vi == bJ && xi < bX))) { bJ = vi; bX = xi; bHave = 1; }
-            if (phase == RP_SIMPSON) {  // bio LogProb::ln_simpsons_integrate_exp weights
-                double wgt = (i == 0 || i == n - 1) ? 0.0 : log((double)(2 + (i % 2) * 2));
-                tval[t] = vi + wgt;
-            } else {
-                // successor in (x, index) order = next grid point of the sorted, de-duplicated table
-                double sx = __builtin_huge_val(), sv = VLR_NEG_INF;
-                int sj = -1;
-                for (int q = 0; q < n; ++q) {
-                    double xq = tx[q];
-                    bool gt = (xq > xi) || (xq == xi && q > i);
-                    bool better = gt && (sj < 0 || xq < sx || (xq == sx && q < sj));
-                    if (better) { sx = xq; sv = tv[q]; sj = q; }
-                }
-                if (sj >= 0) tval[t] = ln_add_exp(vi, sv) + log((sx - xi) / 2.0);
+    double rint_ = VLR_NEG_INF;
+    {
+        // this lane's (up to) four entries; successor of each in (x, index) order = next grid point of the
+        // sorted, de-duplicated table.  One pass over the table serves all four (one LDS read per q).
+        double xi[4], vi[4], sx[4];
+        int sj[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            int i = rl + 16 * t;
+            bool on = i < n;
+            xi[t] = on ? tx[i] : __builtin_huge_val();
+            vi[t] = on ? tv[i] : VLR_NEG_INF;
+            sx[t] = __builtin_huge_val();
+            sj[t] = -1;
+            if (on && contained && range_contains(orig, xi[t]) && vi[t] == vi[t] && (!bHave || vi[t] > bJ || (vi[t] == bJ && xi[t] < bX))) {
+                bJ = vi[t]; bX = xi[t]; bHave = 1;
             }
-            if (tval[t] != tval[t]) anynan = true;
         }
-    }
-    // row arg-best of (bJ desc, bX asc)
-    for (int st = 0; st < 4; ++st) {
-        double oJ, oX;
-        int oH;
-        if (st == 0) { oJ = dpp_f64<0xB1>(bJ); oX = dpp_f64<0xB1>(bX); oH = dpp_i32<0xB1>(bHave); }
-        else if (st == 1) { oJ = dpp_f64<0x4E>(bJ); oX = dpp_f64<0x4E>(bX); oH = dpp_i32<0x4E>(bHave); }
-        else if (st == 2) { oJ = dpp_f64<0x141>(bJ); oX = dpp_f64<0x141>(bX); oH = dpp_i32<0x141>(bHave); }
-        else { oJ = dpp_f64<0x140>(bJ); oX = dpp_f64<0x140>(bX); oH = dpp_i32<0x140>(bHave); }
-        bool take = oH && (!bHave || oJ > bJ || (oJ == bJ && oX < bX));
-        if (take) { bJ = oJ; bX = oX; bHave = 1; }
-    }
-    double m4 = fmax(fmax(tval[0], tval[1]), fmax(tval[2], tval[3]));
-    int nanrow = row_or(anynan ? 1 : 0);
-    double M = row_max(m4 == m4 ? m4 : VLR_NEG_INF);
-    double r;
-    if (M == VLR_NEG_INF) r = VLR_NEG_INF;
-    else {
+        if (phase != RP_SIMPSON) {
+            const int nmax = __builtin_amdgcn_readfirstlane(max(max(__shfl(n, 0), __shfl(n, 16)), max(__shfl(n, 32), __shfl(n, 48))));
+            for (int q = 0; q < nmax; ++q) {
+                double xq = (q < n) ? tx[q] : -__builtin_huge_val();
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    int i = rl + 16 * t;
+                    bool gt = (xq > xi[t]) || (xq == xi[t] && q > i);
+                    bool better = gt && (xq < sx[t] || (xq == sx[t] && q < sj[t]) || sj[t] < 0);
+                    if (better && q < n && i < n) { sx[t] = xq; sj[t] = q; }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (vi[t] != vi[t]) anynan = true;
+        // ---- row arg-best of (bJ desc, bX asc) for the MAP candidate
+        for (int st = 0; st < 4; ++st) {
+            double oJ, oX;
+            int oH;
+            if (st == 0) { oJ = dpp_f64<0xB1>(bJ); oX = dpp_f64<0xB1>(bX); oH = dpp_i32<0xB1>(bHave); }
+            else if (st == 1) { oJ = dpp_f64<0x4E>(bJ); oX = dpp_f64<0x4E>(bX); oH = dpp_i32<0x4E>(bHave); }
+            else if (st == 2) { oJ = dpp_f64<0x141>(bJ); oX = dpp_f64<0x141>(bX); oH = dpp_i32<0x141>(bHave); }
+            else { oJ = dpp_f64<0x140>(bJ); oX = dpp_f64<0x140>(bX); oH = dpp_i32<0x140>(bHave); }
+            bool take = oH && (!bHave || oJ > bJ || (oJ == bJ && oX < bX));
+            if (take) { bJ = oJ; bX = oX; bHave = 1; }
+        }
+        // ---- integral in the linear domain relative to the row maximum M:
+        //   trapezoid  ln sum_seg (e^{v_i} + e^{v_succ}) (x_succ - x_i)/2 = M + ln sum_seg (e_i + e_succ) w_seg / 2
+        //   (== LogProb::ln_trapezoidal_integrate_grid_exp, utils/adaptive_integration.rs:133-140);
+        //   Simpson: sum of weighted e_i.  One exp per entry, one log per chain.
+        double m4 = VLR_NEG_INF;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) m4 = fmax(m4, (vi[t] == vi[t]) ? vi[t] : VLR_NEG_INF);
+        const double M = row_max(m4);
+        double ev[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) ev[t] = (vi[t] == VLR_NEG_INF || M == VLR_NEG_INF || vi[t] != vi[t]) ? 0.0 : exp(vi[t] - M);
         double ssum = 0.0;
-        for (int t = 0; t < 4; ++t) ssum += (tval[t] == VLR_NEG_INF || tval[t] != tval[t]) ? 0.0 : exp(tval[t] - M);
+        if (phase == RP_SIMPSON) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                int i = rl + 16 * t;
+                if (i < n) ssum += ev[t] * ((i == 0 || i == n - 1) ? 1.0 : (double)(2 + (i % 2) * 2));
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (sj[t] >= 0) {
+                    double vs = tv[sj[t]];
+                    double es = (vs == VLR_NEG_INF || vs != vs) ? 0.0 : exp(vs - M);
+                    if (vs != vs) anynan = true;
+                    ssum += (ev[t] + es) * ((sx[t] - xi[t]) / 2.0);
+                }
+        }
         ssum = row_sum(ssum);
-        r = M + log(ssum);
+        rint_ = (M == VLR_NEG_INF) ? VLR_NEG_INF : M + log(ssum);
     }
+    int nanrow = row_or(anynan ? 1 : 0);
+    double r = rint_;
     if (phase == RP_SIMPSON) r = r + log(hi - lo) - log((double)(simpson_n - 1)) - log(3.0);
     if (nanrow || failed) r = __builtin_nan("");
     if (rowon && rl == 0) {
@@ -1127,6 +1222,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
     }
     __builtin_amdgcn_wave_barrier();
     __syncthreads();
+    PROF_ADD(c, 8);  // batch epilogue (MAP scan + integrate)
 }
 
 // LikelihoodOperands::lfc_bounds (modes/generic.rs:148-174)
@@ -1157,11 +1253,12 @@ __device__ inline bool ops_lfc_bounds(const Ctx& c, int sample, RangeV& out) {
 // inner chains of ALL pending outer points together, kRows at a time (run_chain_batch), instead of descending
 // once per point.  Semantics identical to the sequential walk (modes/generic.rs:331-395 for the child node).
 __device__ __forceinline__ void batch_outer_points(Ctx& c, const Frame& f, RangeSt& r, int chn, double* txo, double* tvo) {
+    PROF_ADD(c, 3);
     const DevPlan& p = *c.plan;
     WaveSt* w = c.w;
     const DevNode& ch = p.nodes[chn];
-    const int s_in = ch.sample, s_out = r.sample, S = c.S, lane = c.lane;
-    const int n_obs = w->nkeep[s_in];
+    const int s_in = ch.sample, s_out = UNI(r.sample), S = c.S, lane = c.lane;
+    const int n_obs = UNI(w->nkeep[s_in]);
     const bool clear_ref = n_obs > 10 && w->all_posref[s_in];
     const RangeV vr{ch.vafs.start, ch.vafs.end, ch.vafs.lex, ch.vafs.rex};
     const bool dead = clear_ref && vr.start > 0.0;  // generic.rs:342-347
@@ -1169,7 +1266,7 @@ __device__ __forceinline__ void batch_outer_points(Ctx& c, const Frame& f, Range
     const double lo = observable_min(vr, n_obs), hi = observable_max(vr, n_obs);
     const int simpson = ((hi - lo) < res) ? 3 : (n_obs < 5 ? 11 : 0);
     const RangeV oorig{r.ostart, r.oend, r.olex, r.orex};
-    const int np = r.npend;
+    const int np = UNI(r.npend);
     // samples whose likelihood is fixed during an inner chain: constant over the outer points, or varying with them
     double fixed_const = 0.0;
     int vary = 0;
@@ -1227,13 +1324,13 @@ __device__ __forceinline__ void batch_outer_points(Ctx& c, const Frame& f, Range
         __syncthreads();
         for (int i = 0; i < nt; ++i) {
             const ChainTask& T = w->task[i];
-            const double x = r.pend[c0 + i];
+            const double x = uni_d(r.pend[c0 + i]);
             __syncthreads();
             if (lane == 0) { txo[r.tn + c0 + i] = x; tvo[r.tn + c0 + i] = dead ? VLR_NEG_INF : T.result; w->ops_vaf[s_out] = x; }
             __syncthreads();
             if (dead) continue;
-            if (T.haveBest) map_consider(c, T.bestJ, s_in, T.bestX);
-            if (T.alive != 0 || !T.contained) {  // rare: candidates for other groups / containment via another path
+            if (UNI(T.haveBest)) map_consider(c, uni_d(T.bestJ), s_in, uni_d(T.bestX));
+            if (UNI(T.alive) != 0 || !UNI(T.contained)) {  // rare: candidates for other groups / containment via another path
                 const RangeV io{T.ostart, T.oend, T.olex, T.orex};
                 const double* rx = c.rowX + i * c.cap;
                 const double* rvv = c.rowV + i * c.cap;
@@ -1257,7 +1354,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
     WaveSt* w = c.w;
     c.present = 0; c.disc = 0; c.nlfc = 0; c.contained = 1;
     c.alive = ((1 << (p.n_named + 1)) - 1) & ~(1 << c.group);
-    int sp = 0, node = root, nrange = 0;
+    int sp = 0, node = UNI(root), nrange = 0;
     enum { PC_DESCEND, PC_SUB, PC_RETURN, PC_RANGE_ISSUE } pc = PC_DESCEND;
     double rv = VLR_NEG_INF;
     bool skip_record = false;
@@ -1381,7 +1478,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
         } else if (pc == PC_SUB) {  // subdensity (199-230)
             const DevNode& nd = p.nodes[node];
             if (nd.n_children == 0) { rv = leaf_joint(c); pc = PC_RETURN; }
-            else if (nd.n_children == 1) { node = p.child_index[nd.child_off]; pc = PC_DESCEND; }
+            else if (nd.n_children == 1) { node = UNI(p.child_index[nd.child_off]); pc = PC_DESCEND; }
             else if (sp >= kMaxFrames) { c.status |= VLR_LOCUS_TABLE_FULL; rv = __builtin_nan(""); pc = PC_RETURN; }
             else {
                 __syncthreads();
@@ -1393,21 +1490,22 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                 }
                 __syncthreads();
                 sp++;
-                node = p.child_index[nd.child_off];
+                node = UNI(p.child_index[nd.child_off]);
                 pc = PC_DESCEND;
             }
         } else if (pc == PC_RANGE_ISSUE) {
             Frame& f = w->frames[sp - 1];
-            RangeSt& r = w->rs[f.slot];
-            double* tx = c.tabX + f.slot * c.cap;
-            double* tv = c.tabV + f.slot * c.cap;
-            if (r.tn + r.npend > c.cap) {
+            const int fslot = UNI(f.slot), fnode = UNI(f.node);
+            RangeSt& r = w->rs[fslot];
+            double* tx = c.tabX + fslot * c.cap;
+            double* tv = c.tabV + fslot * c.cap;
+            if (UNI(r.tn) + UNI(r.npend) > c.cap) {
                 c.status |= VLR_LOCUS_TABLE_FULL;
                 rv = __builtin_nan("");
                 c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained; c.alive = f.sv_alive;
                 sp--; nrange--;
                 pc = PC_RETURN;
-            } else if (r.leaf) {
+            } else if (UNI(r.leaf)) {
                 // innermost chain: evaluate all pending points at once, loop the state machine here
                 c.present = f.sv_present | (1 << r.sample);
                 c.nlfc = f.sv_nlfc;
@@ -1417,16 +1515,16 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                 c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained; c.alive = f.sv_alive;
                 sp--; nrange--;
                 pc = PC_RETURN;
-            } else if (f.iter == 0 && f.sv_nlfc == 0 && p.nodes[f.node].n_children == 1 &&
-                       p.nodes[p.child_index[p.nodes[f.node].child_off]].kind == VLR_NODE_SAMPLE &&
-                       p.nodes[p.child_index[p.nodes[f.node].child_off]].vafs.kind == 1 &&
-                       p.nodes[p.child_index[p.nodes[f.node].child_off]].n_children == 0 &&
-                       p.nodes[p.child_index[p.nodes[f.node].child_off]].vafs.start != p.nodes[p.child_index[p.nodes[f.node].child_off]].vafs.end) {
+            } else if (UNI(f.iter) == 0 && UNI(f.sv_nlfc) == 0 && p.nodes[fnode].n_children == 1 &&
+                       p.nodes[UNI(p.child_index[p.nodes[fnode].child_off])].kind == VLR_NODE_SAMPLE &&
+                       p.nodes[UNI(p.child_index[p.nodes[fnode].child_off])].vafs.kind == 1 &&
+                       p.nodes[UNI(p.child_index[p.nodes[fnode].child_off])].n_children == 0 &&
+                       p.nodes[UNI(p.child_index[p.nodes[fnode].child_off])].vafs.start != p.nodes[UNI(p.child_index[p.nodes[fnode].child_off])].vafs.end) {
                 // outer chain over a leaf Range child: all pending points at once, kRows inner chains per pass
                 c.present = f.sv_present | (1 << r.sample);
                 c.disc = f.sv_disc & ~(1 << r.sample);
                 c.nlfc = f.sv_nlfc;
-                batch_outer_points(c, f, r, p.child_index[p.nodes[f.node].child_off], tx, tv);
+                batch_outer_points(c, f, r, UNI(p.child_index[p.nodes[fnode].child_off]), tx, tv);
                 __syncthreads();
                 if (c.lane == 0) f.iter = r.npend;
                 __syncthreads();
@@ -1434,8 +1532,8 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                 pc = PC_RETURN;
             } else {
                 // outer chain: one point at a time through the subtree
-                int it = f.iter;
-                double x = r.pend[it];
+                int it = UNI(f.iter);
+                double x = uni_d(r.pend[it]);
                 c.present = f.sv_present | (1 << r.sample);
                 c.disc = f.sv_disc & ~(1 << r.sample);
                 c.nlfc = f.sv_nlfc;
@@ -1445,21 +1543,22 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                 __syncthreads();
                 if (c.lane == 0) w->ops_vaf[r.sample] = x;
                 __syncthreads();
-                node = f.node;
+                node = fnode;
                 pc = PC_SUB;
             }
         } else {  // PC_RETURN: hand rv to the enclosing frame
             if (sp == 0) return rv;
             Frame& f = w->frames[sp - 1];
-            if (f.kind == FK_RANGE) {
-                RangeSt& r = w->rs[f.slot];
-                double* tx = c.tabX + f.slot * c.cap;
-                double* tv = c.tabV + f.slot * c.cap;
+            if (UNI(f.kind) == FK_RANGE) {
+                const int fslot = UNI(f.slot);
+                RangeSt& r = w->rs[fslot];
+                double* tx = c.tabX + fslot * c.cap;
+                double* tv = c.tabV + fslot * c.cap;
                 __syncthreads();
                 if (c.lane == 0 && !skip_record) { tx[r.tn] = r.pend[f.iter]; tv[r.tn] = rv; r.tn = r.tn + 1; f.iter = f.iter + 1; }
                 skip_record = false;
                 __syncthreads();
-                if (f.iter < r.npend) { pc = PC_RANGE_ISSUE; }
+                if (UNI(f.iter) < UNI(r.npend)) { pc = PC_RANGE_ISSUE; }
                 else {
                     bool done = range_advance(c, r, tx, tv);
                     __syncthreads();
@@ -1476,14 +1575,15 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
             } else {  // SET or BRANCH: ln_sum_exp over members / children (203-217, 319-328)
                 double M = f.accM, S = f.accS;
                 lse_add(M, S, rv);
-                int it = f.iter + 1;
+                int it = UNI(f.iter) + 1;
                 __syncthreads();
                 if (c.lane == 0) { f.accM = M; f.accS = S; f.iter = it; }
                 __syncthreads();
                 c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained; c.alive = f.sv_alive;
-                if (it < f.n) {
-                    const DevNode& nd = p.nodes[f.node];
-                    if (f.kind == FK_SET) {
+                if (it < UNI(f.n)) {
+                    const int fnode = UNI(f.node);
+                    const DevNode& nd = p.nodes[fnode];
+                    if (UNI(f.kind) == FK_SET) {
                         int s = nd.sample;
                         __syncthreads();
                         if (c.lane == 0) w->ops_vaf[s] = c.setv[s * kMaxSet + it];
@@ -1492,10 +1592,10 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                         c.disc |= (1 << s);
                         c.contained = f.sv_contained && spectrum_contains(nd.vafs, p.vafs, w->ops_vaf[s]);
                         c.alive = alive_update(c, f.sv_alive, s, w->ops_vaf[s]);
-                        node = f.node;
+                        node = fnode;
                         pc = PC_SUB;
                     } else {
-                        node = p.child_index[nd.child_off + it];
+                        node = UNI(p.child_index[nd.child_off + it]);
                         pc = PC_DESCEND;
                     }
                 } else {
@@ -1549,6 +1649,10 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
     int* mapHyp = (int*)(c.cacheV + S * kCacheWays);  // [n_slots]
     c.mapJ = mapJ; c.mapVaf = mapVaf; c.mapHyp = mapHyp; c.n_slots = n_slots;
     c.status = 0; c.n_eval = 0; c.n_terms = 0;
+#ifdef VLR_PROFILE
+    for (int i = 0; i < 12; ++i) c.prof[i] = 0;
+#endif
+    PROF_START(c);
 
     const unsigned lf = batch.locus_flags[locus];
     c.vt = batch.variant_type ? batch.variant_type[locus] : 0;
@@ -1653,6 +1757,7 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
     const bool singleton = (n_alt_like == 1);  // adjust_singleton_evidence (read_observation.rs:548-562)
     if (singleton) c.status |= VLR_LOCUS_SINGLETON_ADJ;
 
+    PROF_ADD(c, 0);  // phase A statistics
     // ---- learn_parameters (bias/mod.rs:295-300)
     double forward_rate = 0.5;
     bool sb_informative = false;
@@ -1729,6 +1834,7 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
         }
     }
 
+    PROF_ADD(c, 1);  // gating
     // ============================ phase B: hypotheses x events ============================
     for (int u = lane; u < p.n_univ; u += 64) { evM[u] = VLR_NEG_INF; evS[u] = 0.0; }
     for (int u = lane; u < n_slots; u += 64) { mapJ[u] = VLR_NEG_INF; mapHyp[u] = -1; }
@@ -1835,6 +1941,7 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
         __syncthreads();
         if (__ballot((c.status & VLR_LOCUS_UNDERFLOW) != 0)) c.status |= VLR_LOCUS_UNDERFLOW;
 
+        PROF_ADD(c, 2);  // coefficient pass
         // ---- events (calling.rs:654-687): absent + clean events under h = none, artifact twins otherwise
         const double bias_prior = (h == 0) ? kLn05 : kLn05 + log(1.0 / (double)n_biases);  // modes/generic.rs:437-441
         const int first_ev = (h == 0) ? -1 : 0;
@@ -1862,6 +1969,7 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
         }
     }
 
+    PROF_ADD(c, 3);  // walk remainder (everything in the event loop not attributed below)
     // ============================ phase C: posteriors + MAP ============================
     // bio Model::compute: marginal = ln_sum_exp(event values); posterior = value - marginal
     const int n_out = p.n_named + 2;
@@ -1942,6 +2050,10 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
         if (out.work) {
             atomicAdd(&out.work[0], c.n_eval);
             atomicAdd(&out.work[1], c.n_terms);
+#ifdef VLR_PROFILE
+            PROF_ADD(c, 9);  // phase C
+            for (int i = 0; i < 12; ++i) atomicAdd(&out.work[2 + i], c.prof[i]);
+#endif
         }
     }
 }
