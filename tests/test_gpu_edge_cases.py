@@ -214,3 +214,63 @@ def test_device_pointer_entry_point(oracle):
     assert np.array_equal(dev.map_vaf, host.map_vaf, equal_nan=True)
     assert plan.last_kernel_ms() > 0
     plan.close()
+
+
+def afd_lists(res, l, s):
+    n = int(res.afd_count[l, s])
+    assert n <= res.afd_capacity, "raise afd_capacity in the test"
+    v = res.afd_vaf[l, s, :n].astype(np.float64)
+    p = res.afd_lnprob[l, s, :n]
+    order = np.lexsort((p, v))
+    return v[order], p[order]
+
+
+@pytest.mark.parametrize("cfg_name,n", [("config2", 300), ("config3", 120), ("config5", 200)])
+def test_afd_matches_oracle(oracle, cfg_name, n):
+    """FORMAT/AFD (calling.rs:889-928): visited VAFs of each sample at the MAP of the others, with densities."""
+    cfg = synth.CONFIGS[cfg_name]()
+    batch = synth.generate(cfg, n, seed=31)
+    plan = engine.Plan(cfg.scenario)
+    got = plan.call_host(batch, afd_capacity=256)
+    plan.close()
+    ref = oracle.call(cfg.scenario, batch, afd_capacity=256, want_events=True)
+    m = compare(got, ref, label="afd " + cfg_name)
+    assert m["frac_within"] == 1.0
+    ties = got.best_event != ref.best_event
+    n_entries = 0
+    for l in range(n):
+        if ties[l]:
+            continue
+        for s in range(batch.n_samples):
+            assert got.afd_count[l, s] == ref.afd_count[l, s], (l, s, got.afd_count[l, s], ref.afd_count[l, s])
+            gv, gp = afd_lists(got, l, s)
+            rv, rp = afd_lists(ref, l, s)
+            assert np.array_equal(gv, rv), (l, s)
+            with np.errstate(invalid="ignore"):
+                d = np.abs(np.exp(gp) - np.exp(rp))
+            assert np.all((d <= 1e-9 * np.maximum(1.0, np.exp(rp))) | (np.isneginf(gp) & np.isneginf(rp))), (l, s)
+            n_entries += len(gv)
+    assert n_entries > n  # lists are non-trivial
+
+
+def test_afd_fixture_matches_reference_file(oracle, golden_dir):
+    """The reference's own AFD strings of tests/resources/flamegraph_profiling/calls.vcf."""
+    from varlociraptor_amd import obsfmt
+    d = os.path.join(golden_dir, "flamegraph_profiling")
+    batch, _ = obsfmt.read_observation_vcf([os.path.join(d, "normal.vcf")], omit_bias_mask=abi.BIAS_ALL)
+    sc = Scenario({"normal": Sample(resolution=0.1, universe="[0.0,1.0]")}, {"present": "normal:]0.0,1.0]"})
+    plan = engine.Plan(sc)
+    got = plan.call_host(batch, afd_capacity=64)
+    plan.close()
+    expected = []
+    with open(os.path.join(d, "calls.vcf")) as fh:
+        for line in fh:
+            if not line.startswith("#"):
+                f = line.rstrip("\n").split("\t")
+                fmt = dict(zip(f[8].split(":"), f[9].split(":")))
+                expected.append([tuple(x.split("=")) for x in fmt["AFD"].split(",")])
+    for l, exp in enumerate(expected):
+        v, p = afd_lists(got, l, 0)
+        assert ["%.3f" % x for x in v] == [e[0] for e in exp]
+        for pi, e in zip(p, exp):
+            assert abs(-10.0 / np.log(10.0) * pi - float(e[1])) <= 0.011

@@ -250,6 +250,9 @@ struct vlr_plan {
     void* stage = nullptr;
     size_t stage_bytes = 0;
     unsigned long long* work_dev = nullptr;
+    // AFD replay scratch (device): is_discrete mask of the MAP, and marginal/best_event when the caller passes NULL
+    void* afd_scratch = nullptr;
+    size_t afd_scratch_bytes = 0;
 };
 
 namespace {
@@ -592,6 +595,7 @@ void vlr_plan_destroy(vlr_plan* plan) {
     if (plan->dev) (void)hipFree(plan->dev);
     if (plan->stage) (void)hipFree(plan->stage);
     if (plan->work_dev) (void)hipFree(plan->work_dev);
+    if (plan->afd_scratch) (void)hipFree(plan->afd_scratch);
     if (plan->ev_start) (void)hipEventDestroy(plan->ev_start);
     if (plan->ev_stop) (void)hipEventDestroy(plan->ev_stop);
     delete plan;
@@ -625,8 +629,9 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
     if (in->n_samples != plan->host.S) return fail(VLR_ERR_INVALID_ARGUMENT, "batch has %d samples, plan %d", in->n_samples, plan->host.S);
     if (out->n_out != plan->n_events + 2 || out->n_samples != plan->host.S || out->n_loci < in->n_loci)
         return fail(VLR_ERR_INVALID_ARGUMENT, "result buffers do not match plan/batch");
-    if (out->afd_count || out->afd_vaf || out->afd_lnprob)
-        return fail(VLR_ERR_UNSUPPORTED, "AFD output is not produced by the device path yet (DESIGN.md: out of scope this round)");
+    const bool want_afd = out->afd_count || out->afd_vaf || out->afd_lnprob;
+    if (want_afd && (!out->afd_count || !out->afd_vaf || !out->afd_lnprob || out->afd_capacity < 1))
+        return fail(VLR_ERR_INVALID_ARGUMENT, "AFD needs afd_count, afd_vaf, afd_lnprob and afd_capacity >= 1");
     if (!in->obs_offset || !in->prob_mapping || !in->prob_alt || !in->prob_ref || !in->prob_missed_allele || !in->prob_sample_alt ||
         !in->prob_double_overlap || !in->prob_hit_base || !in->flags || !in->locus_flags || !out->ln_posterior || !out->map_vaf || !out->status)
         return fail(VLR_ERR_INVALID_ARGUMENT, "missing required column");
@@ -645,6 +650,23 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
     r.ln_posterior = out->ln_posterior; r.ln_marginal = out->ln_marginal; r.map_vaf = out->map_vaf;
     r.map_bias = out->map_bias; r.best_event = out->best_event; r.status = out->status;
     r.work = plan->work_dev;
+    if (want_afd) {
+        // the replay pass needs MAP is_discrete flags, marginal and best event of the first pass
+        size_t L = (size_t)in->n_loci, need = L + 8 * L + 4 * L + 64;
+        if (need > plan->afd_scratch_bytes) {
+            if (plan->afd_scratch) (void)hipFree(plan->afd_scratch);
+            plan->afd_scratch = nullptr;
+            plan->afd_scratch_bytes = 0;
+            if (hipMalloc(&plan->afd_scratch, need) != hipSuccess) return fail(VLR_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed", need);
+            plan->afd_scratch_bytes = need;
+        }
+        char* sc = (char*)plan->afd_scratch;
+        if (!r.ln_marginal) r.ln_marginal = (double*)sc;
+        if (!r.best_event) r.best_event = (int32_t*)(sc + 8 * L);
+        r.map_disc = (uint8_t*)(sc + 12 * L);
+        if (!r.map_bias) return fail(VLR_ERR_INVALID_ARGUMENT, "AFD needs map_bias");
+        r.afd_count = out->afd_count; r.afd_vaf = out->afd_vaf; r.afd_lnprob = out->afd_lnprob; r.afd_capacity = out->afd_capacity;
+    }
     int max_obs = plan->max_obs > 0 ? plan->max_obs : plan->max_depth_per_sample * plan->host.S;
     max_obs = (max_obs + 3) & ~3;
     hipStream_t st = (hipStream_t)stream;
@@ -652,6 +674,12 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
     int rc = vlr_launch_call_kernel(&plan->host, &b, &r, plan->host.n_univ, plan->host.S, max_obs, plan->host.max_range_depth, stream);
     if (rc != 0) return fail(VLR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipEventRecord(plan->ev_stop, st));
+    if (want_afd) {  // second launch: AFD replay over the clean events (calling.rs:889-928)
+        HIP_TRY(hipMemsetAsync(out->afd_count, 0, (size_t)in->n_loci * plan->host.S * sizeof(int32_t), st));
+        r.replay = 1;
+        rc = vlr_launch_call_kernel(&plan->host, &b, &r, plan->host.n_univ, plan->host.S, max_obs, plan->host.max_range_depth, stream);
+        if (rc != 0) return fail(VLR_ERR_HIP, "AFD kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    }
     plan->timed = true;
     return VLR_OK;
 }
@@ -715,6 +743,11 @@ int vlr_batch_run_host(vlr_plan* plan, const vlr_batch* in, vlr_results* out) {
     size_t r_bias = off; off += al((size_t)L * VLR_N_BIAS);
     size_t r_best = off; off += al((size_t)L * 4);
     size_t r_stat = off; off += al((size_t)L * 4);
+    const bool want_afd = out->afd_count || out->afd_vaf || out->afd_lnprob;
+    const size_t cap = want_afd ? (size_t)out->afd_capacity : 0;
+    size_t r_ac = off; off += al(want_afd ? (size_t)L * S * 4 : 0);
+    size_t r_av = off; off += al((size_t)L * S * cap * 4);
+    size_t r_al = off; off += al((size_t)L * S * cap * 8);
     (void)in_end;
     if (off > plan->stage_bytes) {
         if (plan->stage) (void)hipFree(plan->stage);
@@ -745,9 +778,11 @@ int vlr_batch_run_host(vlr_plan* plan, const vlr_batch* in, vlr_results* out) {
     dr.map_bias = (uint8_t*)(base + r_bias);
     dr.best_event = (int32_t*)(base + r_best);
     dr.status = (uint32_t*)(base + r_stat);
-    dr.afd_count = nullptr; dr.afd_vaf = nullptr; dr.afd_lnprob = nullptr;
-    if (out->afd_count || out->afd_vaf || out->afd_lnprob)
-        return fail(VLR_ERR_UNSUPPORTED, "AFD output is not produced by the device path yet (DESIGN.md: out of scope this round)");
+    dr.afd_count = want_afd ? (int32_t*)(base + r_ac) : nullptr;
+    dr.afd_vaf = want_afd ? (float*)(base + r_av) : nullptr;
+    dr.afd_lnprob = want_afd ? (double*)(base + r_al) : nullptr;
+    if (want_afd && (!out->afd_count || !out->afd_vaf || !out->afd_lnprob || out->afd_capacity < 1))
+        return fail(VLR_ERR_INVALID_ARGUMENT, "AFD needs afd_count, afd_vaf, afd_lnprob and afd_capacity >= 1");
     // size the LDS coefficient area to this batch (never above the configured budget)
     int saved_max_obs = plan->max_obs;
     {
@@ -766,6 +801,11 @@ int vlr_batch_run_host(vlr_plan* plan, const vlr_batch* in, vlr_results* out) {
     if (out->map_bias) HIP_TRY(hipMemcpy(out->map_bias, dr.map_bias, (size_t)L * VLR_N_BIAS, hipMemcpyDeviceToHost));
     if (out->best_event) HIP_TRY(hipMemcpy(out->best_event, dr.best_event, (size_t)L * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(out->status, dr.status, (size_t)L * 4, hipMemcpyDeviceToHost));
+    if (want_afd) {
+        HIP_TRY(hipMemcpy(out->afd_count, dr.afd_count, (size_t)L * S * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out->afd_vaf, dr.afd_vaf, (size_t)L * S * cap * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out->afd_lnprob, dr.afd_lnprob, (size_t)L * S * cap * 8, hipMemcpyDeviceToHost));
+    }
     return VLR_OK;
 }
 

@@ -51,6 +51,7 @@ struct Frame {
     double accM, accS;  // streaming ln-sum-exp
     int sv_present, sv_disc, sv_nlfc, sv_contained;
     int slot, sv_alive;  // RANGE: index into rs[] / the visited-point tables; saved cross-event candidate mask
+    int sv_mute, pad2;
 };
 
 struct RangeSt {
@@ -84,6 +85,9 @@ struct WaveSt {
     double ptJ[kMaxBatchPoints];
     double fixedLik[kMaxSamples];
     double curMapVaf[kMaxSamples];
+    double mapv[kMaxSamples];  // replay: MAP VAF per sample
+    int afd_nseen[kMaxSamples]; // replay: discrete VAFs of sample s already recorded (overlapping roots/branches
+                                // visit the same operands; the reference's joint_probs map keeps one entry)
     int cs_node[kContainStack], cs_mask[kContainStack];
     ChainTask task[kRows];
     double bpend[kRows][kRowPts], bvals[kRows][kRowPts];
@@ -445,6 +449,7 @@ struct Ctx {
     double *cacheA, *cacheB, *cacheV;  // [S][kCacheWays] per-sample likelihood cache (LDS)
     int cap;                         // capacity of one visited-point table
     double *rowX, *rowV;             // [kRows][cap] visited-point tables of the row-parallel innermost chains
+    double* afd_seen;                // replay: [S][kMaxSet] recorded discrete VAFs (aliases setv-sized scratch)
     double* tvaf;                    // [kRows][S] outer operands of the chain tasks
     double *tabX, *tabV, *sx, *sv;   // visited tables [depth][kTableCap], sort scratch
     int lane;
@@ -458,6 +463,12 @@ struct Ctx {
     int n_slots;
     double* mapJ; double* mapVaf; int* mapHyp;  // best MAP candidate per slot (LDS)
     int hyp;
+    // AFD replay pass (calling.rs:889-928): MAP operands of the first pass, recorded per matching operand
+    int replay, mapGroup, mapDisc;
+    int afd_mute;  // replay: the current path repeats an outer VAF already visited by its chain (duplicate map key)
+    double marginal;
+    int64_t locus;
+    const DevResults* outp;
     // MAP candidate of the current (event, hypothesis class)
     double curJ;
     int curHyp;
@@ -536,7 +547,7 @@ __device__ inline void map_consider(Ctx& c, double joint, int inner, double x) {
     if (!(joint == joint)) return;
     bool better = joint > c.curJ;
     if (!better && joint == c.curJ && c.curHyp >= 0) {
-        if (c.hyp != c.curHyp) better = c.hyp < c.curHyp;
+        if (c.hyp != (c.curHyp & 15)) better = c.hyp < (c.curHyp & 15);
         else {
             for (int s = 0; s < c.S; ++s) {
                 double v = (s == inner) ? x : c.w->ops_vaf[s];
@@ -548,7 +559,7 @@ __device__ inline void map_consider(Ctx& c, double joint, int inner, double x) {
     if (c.curHyp < 0) better = true;
     if (better) {
         c.curJ = joint;
-        c.curHyp = c.hyp;
+        c.curHyp = c.hyp | (((inner >= 0) ? (c.disc & ~(1 << inner)) : c.disc) << 4);  // hypothesis | is_discrete mask
         __syncthreads();
         if (c.lane < c.S) c.w->curMapVaf[c.lane] = (c.lane == inner) ? x : c.w->ops_vaf[c.lane];
         __syncthreads();
@@ -580,7 +591,7 @@ __device__ inline int alive_update(const Ctx& c, int alive, int s, double v) {
     return alive;
 }
 // VAFTree::contains (vaftree.rs:42-51,116-164) of group g for the current operands (sample `inner` at x)
-__device__ inline bool group_contains(Ctx& c, int g, int inner, double x) {
+__device__ inline bool group_contains(Ctx& c, int g, int inner, double x, int excl = -1) {
     const DevPlan& p = *c.plan;
     WaveSt* w = c.w;
     int r0 = (g == 0) ? 0 : p.root_off[g - 1], r1 = (g == 0) ? 1 : p.root_off[g];
@@ -597,6 +608,7 @@ __device__ inline bool group_contains(Ctx& c, int g, int inner, double x) {
             const DevNode& nd = p.nodes[node];
             bool contained;
             if (nd.kind == VLR_NODE_SAMPLE) {
+                if (nd.sample == excl) { result = true; continue; }  // vaftree.rs:124-128: excluded sample => true
                 double v = (nd.sample == inner) ? x : w->ops_vaf[nd.sample];
                 contained = spectrum_contains(nd.vafs, p.vafs, v);
             } else if (nd.kind == VLR_NODE_LFC) {
@@ -629,7 +641,7 @@ __device__ inline void cross_consider(Ctx& c, int g, double joint, int inner, do
     int curHyp = c.mapHyp[slot];
     bool better = curHyp < 0 || joint > curJ;
     if (!better && joint == curJ) {
-        if (c.hyp != curHyp) better = c.hyp < curHyp;
+        if (c.hyp != (curHyp & 15)) better = c.hyp < (curHyp & 15);
         else
             for (int s = 0; s < c.S; ++s) {
                 double v = (s == inner) ? x : c.w->ops_vaf[s];
@@ -639,11 +651,57 @@ __device__ inline void cross_consider(Ctx& c, int g, double joint, int inner, do
     }
     if (better) {
         __syncthreads();
-        if (c.lane == 0) { c.mapJ[slot] = joint; c.mapHyp[slot] = c.hyp; }
+        if (c.lane == 0) { c.mapJ[slot] = joint; c.mapHyp[slot] = c.hyp | (((inner >= 0) ? (c.disc & ~(1 << inner)) : c.disc) << 4); }
         if (c.lane < c.S) c.mapVaf[slot * c.S + c.lane] = (c.lane == inner) ? x : c.w->ops_vaf[c.lane];
         __syncthreads();
     }
 }
+// AFD replay (calling.rs:889-928): record (VAF of sample s, posterior density) of every clean operand set that
+// equals the MAP on all other samples (allele_freq, artifacts, is_discrete) and is contained in the best event
+// with sample s excluded.
+__device__ inline void afd_consider(Ctx& c, double joint, int inner, double x) {
+    if (c.hyp != 0 || c.afd_mute) return;
+    int mism = 0, ms = -1;
+    const int disc = (inner >= 0) ? (c.disc & ~(1 << inner)) : c.disc;
+    for (int s = 0; s < c.S; ++s) {
+        double v = (s == inner) ? x : c.w->ops_vaf[s];
+        bool eq = v == c.w->mapv[s] && (((disc >> s) & 1) == ((c.mapDisc >> s) & 1));
+        if (!eq) { mism++; ms = s; }
+    }
+    if (mism >= 2) return;
+    for (int s = 0; s < c.S; ++s) {
+        if (mism == 1 && s != ms) continue;
+        if (!group_contains(c, c.mapGroup, inner, x, s)) continue;
+        const double vs = (s == inner) ? x : c.w->ops_vaf[s];
+        if ((disc >> s) & 1) {  // discrete operand for s: the whole operand set is a repeat if this VAF was recorded before
+            int ns = c.w->afd_nseen[s];
+            bool seen = false;
+            for (int i = 0; i < ns; ++i) seen = seen || (c.afd_seen[s * kMaxSet + i] == vs);
+            if (seen) continue;
+            __syncthreads();
+            if (c.lane == 0 && ns < kMaxSet) { c.afd_seen[s * kMaxSet + ns] = vs; c.w->afd_nseen[s] = ns + 1; }
+            __syncthreads();
+        }
+        if (c.lane == 0) {
+            const DevResults& o = *c.outp;
+            int64_t slot = c.locus * c.S + s;
+            int idx = atomicAdd(&o.afd_count[slot], 1);
+            if (idx < o.afd_capacity) {
+                double v = (s == inner) ? x : c.w->ops_vaf[s];
+                o.afd_vaf[slot * o.afd_capacity + idx] = (float)v;
+                o.afd_lnprob[slot * o.afd_capacity + idx] = joint - c.marginal;
+            }
+        }
+    }
+}
+
+// the reference's joint_probs is a map keyed by the operands: a VAF visited twice by one chain (tail points that
+// coincide with end points, the abandoned-arm point) is one entry.  True if x already occurs in tx[0..n).
+__device__ inline bool table_has(const double* tx, int n, double x, int lane) {
+    bool hit = (lane < n && tx[lane] == x) || (lane + 64 < n && tx[lane + 64] == x);
+    return __ballot(hit) != 0ull;
+}
+
 // all MAP bookkeeping for one evaluated operand set
 __device__ inline void map_all(Ctx& c, double joint, int inner, double x, bool own_path_contained, int alive) {
     if (own_path_contained) map_consider(c, joint, inner, x);
@@ -683,7 +741,8 @@ __device__ inline double leaf_joint(Ctx& c) {
         joint = prior_of(c, -1, 0.0) + lik;
     }
     if (joint != joint) c.status |= VLR_LOCUS_NAN;
-    map_all(c, joint, -1, 0.0, c.contained != 0, c.alive);
+    if (c.replay) afd_consider(c, joint, -1, 0.0);
+    else map_all(c, joint, -1, 0.0, c.contained != 0, c.alive);
     return joint;
 }
 
@@ -852,7 +911,12 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
         __builtin_amdgcn_wave_barrier();
         if (k == 0 && j < np) vals[j] = joint;
         __builtin_amdgcn_wave_barrier();
-        if (!slow) {
+        if (c.replay) {
+            for (int i = 0; i < np; ++i) {
+                double xi = uni_d(pend[i]);
+                if (!table_has(tx, tn + i, xi, lane)) afd_consider(c, uni_d(vals[i]), inner, xi);
+            }
+        } else if (!slow) {
             for (int i = 0; i < np; ++i) {
                 double v = vals[i], xi = pend[i];
                 if (v == v && (!haveBest || v > bestJ || (v == bestJ && xi < bestX))) { bestJ = v; bestX = xi; haveBest = true; }
@@ -1329,6 +1393,24 @@ __device__ __forceinline__ void batch_outer_points(Ctx& c, const Frame& f, Range
             if (lane == 0) { txo[r.tn + c0 + i] = x; tvo[r.tn + c0 + i] = dead ? VLR_NEG_INF : T.result; w->ops_vaf[s_out] = x; }
             __syncthreads();
             if (dead) continue;
+            if (c.replay) {
+                if (UNI(f.sv_mute) || table_has(txo, UNI(r.tn) + c0 + i, x, lane)) continue;  // repeated outer VAF: same map keys
+                const double* rx = c.rowX + i * c.cap;
+                const double* rvv = c.rowV + i * c.cap;
+                int mism = 0;
+                for (int s = 0; s < S; ++s)
+                    if (s != s_in && !(w->ops_vaf[s] == w->mapv[s] && (((c.disc >> s) & 1) == ((c.mapDisc >> s) & 1)))) mism++;
+                const int nq = UNI(T.n);
+                if (mism == 0) {
+                    for (int q = 0; q < nq; ++q) { double xq = uni_d(rx[q]); if (!table_has(rx, q, xq, lane)) afd_consider(c, uni_d(rvv[q]), s_in, xq); }
+                } else if (mism == 1) {
+                    for (int q = 0; q < nq; ++q) {
+                        double xq = uni_d(rx[q]);
+                        if (xq == w->mapv[s_in] && !table_has(rx, q, xq, lane)) afd_consider(c, uni_d(rvv[q]), s_in, xq);
+                    }
+                }
+                continue;
+            }
             if (UNI(T.haveBest)) map_consider(c, uni_d(T.bestJ), s_in, uni_d(T.bestX));
             if (UNI(T.alive) != 0 || !UNI(T.contained)) {  // rare: candidates for other groups / containment via another path
                 const RangeV io{T.ostart, T.oend, T.olex, T.orex};
@@ -1352,7 +1434,7 @@ __device__ __forceinline__ void batch_outer_points(Ctx& c, const Frame& f, Range
 __device__ __forceinline__ double walk_root(Ctx& c, int root) {
     const DevPlan& p = *c.plan;
     WaveSt* w = c.w;
-    c.present = 0; c.disc = 0; c.nlfc = 0; c.contained = 1;
+    c.present = 0; c.disc = 0; c.nlfc = 0; c.contained = 1; c.afd_mute = 0;
     c.alive = ((1 << (p.n_named + 1)) - 1) & ~(1 << c.group);
     int sp = 0, node = UNI(root), nrange = 0;
     enum { PC_DESCEND, PC_SUB, PC_RETURN, PC_RANGE_ISSUE } pc = PC_DESCEND;
@@ -1431,7 +1513,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                     if (c.lane == 0) {
                         f.node = node; f.iter = 0; f.accM = VLR_NEG_INF; f.accS = 0.0;
                         f.sv_present = c.present; f.sv_disc = c.disc; f.sv_nlfc = c.nlfc; f.sv_contained = c.contained;
-                        f.sv_alive = c.alive;
+                        f.sv_alive = c.alive; f.sv_mute = c.afd_mute;
                     }
                     if (as_set) {
                         if (c.lane == 0) { f.kind = FK_SET; f.n = ncand; w->ops_vaf[s] = c.setv[s * kMaxSet]; }
@@ -1486,7 +1568,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                 if (c.lane == 0) {
                     f.kind = FK_BRANCH; f.node = node; f.iter = 0; f.n = nd.n_children; f.accM = VLR_NEG_INF; f.accS = 0.0;
                     f.sv_present = c.present; f.sv_disc = c.disc; f.sv_nlfc = c.nlfc; f.sv_contained = c.contained;
-                    f.sv_alive = c.alive;
+                    f.sv_alive = c.alive; f.sv_mute = c.afd_mute;
                 }
                 __syncthreads();
                 sp++;
@@ -1502,7 +1584,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
             if (UNI(r.tn) + UNI(r.npend) > c.cap) {
                 c.status |= VLR_LOCUS_TABLE_FULL;
                 rv = __builtin_nan("");
-                c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained; c.alive = f.sv_alive;
+                c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained; c.alive = f.sv_alive; c.afd_mute = f.sv_mute;
                 sp--; nrange--;
                 pc = PC_RETURN;
             } else if (UNI(r.leaf)) {
@@ -1512,7 +1594,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                 c.contained = f.sv_contained;
                 c.alive = f.sv_alive;
                 rv = run_leaf_chain(c, r, c.rowX, c.rowV);
-                c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained; c.alive = f.sv_alive;
+                c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained; c.alive = f.sv_alive; c.afd_mute = f.sv_mute;
                 sp--; nrange--;
                 pc = PC_RETURN;
             } else if (UNI(f.iter) == 0 && UNI(f.sv_nlfc) == 0 && p.nodes[fnode].n_children == 1 &&
@@ -1540,6 +1622,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                 RangeV orig{r.ostart, r.oend, r.olex, r.orex};
                 c.contained = f.sv_contained && range_contains(orig, x);
                 c.alive = alive_update(c, f.sv_alive, r.sample, x);
+                if (c.replay) c.afd_mute = UNI(f.sv_mute) || table_has(tx, UNI(r.tn), x, c.lane);
                 __syncthreads();
                 if (c.lane == 0) w->ops_vaf[r.sample] = x;
                 __syncthreads();
@@ -1567,7 +1650,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                     if (!done) { pc = PC_RANGE_ISSUE; }
                     else {
                         rv = range_finish(c, r, tx, tv);
-                        c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained; c.alive = f.sv_alive;
+                        c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained; c.alive = f.sv_alive; c.afd_mute = f.sv_mute;
                         sp--; nrange--;
                         pc = PC_RETURN;
                     }
@@ -1579,7 +1662,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                 __syncthreads();
                 if (c.lane == 0) { f.accM = M; f.accS = S; f.iter = it; }
                 __syncthreads();
-                c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained; c.alive = f.sv_alive;
+                c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained; c.alive = f.sv_alive; c.afd_mute = f.sv_mute;
                 if (it < UNI(f.n)) {
                     const int fnode = UNI(f.node);
                     const DevNode& nd = p.nodes[fnode];
@@ -1646,9 +1729,11 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
     c.cacheA = c.setv + S * kMaxSet;        // [S][kCacheWays] x 3
     c.cacheB = c.cacheA + S * kCacheWays;
     c.cacheV = c.cacheB + S * kCacheWays;
-    int* mapHyp = (int*)(c.cacheV + S * kCacheWays);  // [n_slots]
+    c.afd_seen = c.cacheV + S * kCacheWays;  // [S][kMaxSet]
+    int* mapHyp = (int*)(c.afd_seen + S * kMaxSet);  // [n_slots]
     c.mapJ = mapJ; c.mapVaf = mapVaf; c.mapHyp = mapHyp; c.n_slots = n_slots;
     c.status = 0; c.n_eval = 0; c.n_terms = 0;
+    c.replay = out.replay; c.locus = locus; c.outp = &out; c.mapGroup = 0; c.mapDisc = 0; c.marginal = 0.0;
 #ifdef VLR_PROFILE
     for (int i = 0; i < 12; ++i) c.prof[i] = 0;
 #endif
@@ -1841,7 +1926,24 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
     __syncthreads();
 
     if (too_deep) c.status |= VLR_LOCUS_TOO_DEEP;
-    const unsigned hyps = too_deep ? 0u : (1u | surviving);
+    unsigned hyps = too_deep ? 0u : (1u | surviving);
+    if (c.replay) {
+        // AFD only exists for a non-artifact MAP (calling.rs:889): MAP operands, best event group and marginal come
+        // from the first pass; only the clean events are re-evaluated
+        bool have = true;
+        for (int s = 0; s < S; ++s) { double v = out.map_vaf[locus * S + s]; if (v != v) have = false; }
+        bool art = false;
+        if (out.map_bias) for (int i = 0; i < VLR_N_BIAS; ++i) art = art || out.map_bias[locus * VLR_N_BIAS + i] != 0;
+        if (!have || art || too_deep) return;
+        __syncthreads();
+        if (lane < S) { w->mapv[lane] = out.map_vaf[locus * S + lane]; w->afd_nseen[lane] = 0; }
+        __syncthreads();
+        int be = out.best_event[locus];
+        c.mapGroup = (be == 0) ? 0 : ((be - 1) / 2 + 1);
+        c.mapDisc = out.map_disc[locus];
+        c.marginal = out.ln_marginal[locus];
+        hyps = 1u;
+    }
     for (int h = 0; h < kNHyp; ++h) {
         if (!((hyps >> h) & 1u)) continue;
         c.hyp = h;
@@ -1970,6 +2072,7 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
     }
 
     PROF_ADD(c, 3);  // walk remainder (everything in the event loop not attributed below)
+    if (c.replay) return;
     // ============================ phase C: posteriors + MAP ============================
     // bio Model::compute: marginal = ln_sum_exp(event values); posterior = value - marginal
     const int n_out = p.n_named + 2;
@@ -2025,13 +2128,14 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
         }
         if (lane < S) {
             double v = __builtin_nan("");
-            if (pick >= 0) v = (mapHyp[pick] > 0) ? 0.0 : mapVaf[pick * S + lane];
+            if (pick >= 0) v = ((mapHyp[pick] & 15) > 0) ? 0.0 : mapVaf[pick * S + lane];
             out.map_vaf[locus * S + lane] = v;
         }
         if (out.map_bias && lane == 0) {
             uint8_t* mb = out.map_bias + locus * VLR_N_BIAS;
             for (int i = 0; i < VLR_N_BIAS; ++i) mb[i] = 0;
-            int hh = pick >= 0 ? mapHyp[pick] : 0;
+            int hh = pick >= 0 ? (mapHyp[pick] & 15) : 0;
+            if (out.map_disc) out.map_disc[locus] = (uint8_t)(pick >= 0 ? (mapHyp[pick] >> 4) : 0);
             switch (hh) {
                 case H_SBF: mb[0] = 1; break;
                 case H_SBR: mb[0] = 2; break;
@@ -2069,7 +2173,7 @@ extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_host, const vlr::
     size_t n_slots = (size_t)n_univ + 1;
     size_t cap = (size_t)plan_host->table_cap;
     size_t dbl = (size_t)3 * max_obs + (size_t)2 * range_depth * cap + (size_t)2 * kRows * cap + (size_t)kRows * n_samples +
-                 (size_t)2 * n_univ + n_slots + n_slots * n_samples + (size_t)n_samples * kMaxSet + (size_t)3 * n_samples * kCacheWays +
+                 (size_t)2 * n_univ + n_slots + n_slots * n_samples + (size_t)2 * n_samples * kMaxSet + (size_t)3 * n_samples * kCacheWays +
                  (n_slots + 1) / 2 + 2;
     size_t bytes = dbl * sizeof(double);
     hipError_t e = hipFuncSetAttribute((const void*)vlr_call_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);

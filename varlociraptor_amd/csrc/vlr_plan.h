@@ -89,6 +89,14 @@ struct DevResults {
     int32_t* best_event;   // nullable
     uint32_t* status;
     unsigned long long* work;  // nullable: [0] pileup evaluations, [1] observation terms (profiling aid)
+    // AFD (optional second "replay" launch): is_discrete flags of the MAP operands (internal, written by the first
+    // launch), and the caller's AFD buffers
+    uint8_t* map_disc;      // [n_loci]
+    int32_t* afd_count;     // [n_loci * S]
+    float* afd_vaf;         // [n_loci * S * afd_capacity]
+    double* afd_lnprob;     // [n_loci * S * afd_capacity]
+    int32_t afd_capacity;
+    int32_t replay;         // 0: call pass, 1: AFD replay pass
 };
 
 }  // namespace vlr

@@ -114,8 +114,8 @@ class Plan:
             pass
 
     # ---- host buffers in, host buffers out (stages through the device; synchronous)
-    def call_host(self, batch: PileupBatch) -> CallResults:
-        res = CallResults(batch.n_loci, self.n_out, self.n_samples)
+    def call_host(self, batch: PileupBatch, afd_capacity: int = 0) -> CallResults:
+        res = CallResults(batch.n_loci, self.n_out, self.n_samples, afd_capacity)
         bs, rs = batch.as_struct(), res.as_struct()
         _check(lib().vlr_batch_run_host(self._h, C.byref(bs), C.byref(rs)))
         return res
