@@ -67,6 +67,7 @@ constexpr int kRowPts = 12;     // pending points of one chain round (<= 11)
 struct ChainTask {              // one innermost Range chain (see run_chain_batch)
     double lo, hi, res, ostart, oend, fixed, result, bestJ, bestX;
     int olex, orex, simpson_n, pidx, contained, alive, haveBest, n;
+    int u, group, disc, inner;  // deferred event-level chains: destination slot, event group, is_discrete mask, sample
 };
 
 struct WaveSt {
@@ -465,6 +466,7 @@ struct Ctx {
     int hyp;
     // AFD replay pass (calling.rs:889-928): MAP operands of the first pass, recorded per matching operand
     int replay, mapGroup, mapDisc;
+    int defer_ok, deferred, ndef, defer_slot;  // event-level deferral of simple chains into a row-parallel batch
     int afd_mute;  // replay: the current path repeats an outer VAF already visited by its chain (duplicate map key)
     double marginal;
     int64_t locus;
@@ -1313,6 +1315,24 @@ __device__ inline bool ops_lfc_bounds(const Ctx& c, int sample, RangeV& out) {
     return have;
 }
 
+// replay: record the operands of one finished row-parallel chain (row i); ops_vaf must hold the chain's outer operands
+__device__ inline void afd_emit_row(Ctx& c, int i, int s_in, int nq) {
+    WaveSt* w = c.w;
+    const double* rx = c.rowX + i * c.cap;
+    const double* rvv = c.rowV + i * c.cap;
+    int mism = 0;
+    for (int s = 0; s < c.S; ++s)
+        if (s != s_in && !(w->ops_vaf[s] == w->mapv[s] && (((c.disc >> s) & 1) == ((c.mapDisc >> s) & 1)))) mism++;
+    if (mism == 0) {
+        for (int q = 0; q < nq; ++q) { double xq = uni_d(rx[q]); if (!table_has(rx, q, xq, c.lane)) afd_consider(c, uni_d(rvv[q]), s_in, xq); }
+    } else if (mism == 1) {
+        for (int q = 0; q < nq; ++q) {
+            double xq = uni_d(rx[q]);
+            if (xq == w->mapv[s_in] && !table_has(rx, q, xq, c.lane)) afd_consider(c, uni_d(rvv[q]), s_in, xq);
+        }
+    }
+}
+
 // Outer Range frame whose single child is a leaf Range node (the nested `somatic_normal` shape): evaluate the
 // inner chains of ALL pending outer points together, kRows at a time (run_chain_batch), instead of descending
 // once per point.  Semantics identical to the sequential walk (modes/generic.rs:331-395 for the child node).
@@ -1395,20 +1415,7 @@ __device__ __forceinline__ void batch_outer_points(Ctx& c, const Frame& f, Range
             if (dead) continue;
             if (c.replay) {
                 if (UNI(f.sv_mute) || table_has(txo, UNI(r.tn) + c0 + i, x, lane)) continue;  // repeated outer VAF: same map keys
-                const double* rx = c.rowX + i * c.cap;
-                const double* rvv = c.rowV + i * c.cap;
-                int mism = 0;
-                for (int s = 0; s < S; ++s)
-                    if (s != s_in && !(w->ops_vaf[s] == w->mapv[s] && (((c.disc >> s) & 1) == ((c.mapDisc >> s) & 1)))) mism++;
-                const int nq = UNI(T.n);
-                if (mism == 0) {
-                    for (int q = 0; q < nq; ++q) { double xq = uni_d(rx[q]); if (!table_has(rx, q, xq, lane)) afd_consider(c, uni_d(rvv[q]), s_in, xq); }
-                } else if (mism == 1) {
-                    for (int q = 0; q < nq; ++q) {
-                        double xq = uni_d(rx[q]);
-                        if (xq == w->mapv[s_in] && !table_has(rx, q, xq, lane)) afd_consider(c, uni_d(rvv[q]), s_in, xq);
-                    }
-                }
+                afd_emit_row(c, i, s_in, UNI(T.n));
                 continue;
             }
             if (UNI(T.haveBest)) map_consider(c, uni_d(T.bestJ), s_in, uni_d(T.bestX));
@@ -1428,6 +1435,80 @@ __device__ __forceinline__ void batch_outer_points(Ctx& c, const Frame& f, Range
     __syncthreads();
     if (lane == 0) r.tn = r.tn + np;
     __syncthreads();
+}
+
+// Event-level deferral: an event root whose path is a chain of single-valued Sample nodes ending in a leaf Range
+// (tumor-normal: somatic_tumor, germline_het, germline_hom) contributes exactly one innermost chain.  Such chains of
+// different events are collected and run together, one per DPP row (run_chain_batch); flush_deferred delivers the
+// integrals to the event accumulators and the MAP candidates to the event slots.
+__device__ __forceinline__ void flush_deferred(Ctx& c, double* evM, double* evS, double bias_prior) {
+    WaveSt* w = c.w;
+    const int nt = c.ndef;
+    if (nt == 0) return;
+    const int s_in = UNI(w->task[0].inner);
+    __syncthreads();
+    if (nt == 1) {
+        // a lone chain is cheaper on all 64 lanes (7 terms per lane instead of 25): rebuild its frame context
+        const ChainTask& T = w->task[0];
+        const int u = UNI(T.u);
+        RangeSt& r = w->rs[kMaxRangeDepth - 1];
+        if (c.lane == 0) {
+            r.lo = T.lo; r.hi = T.hi; r.res = T.res; r.ostart = T.ostart; r.oend = T.oend; r.olex = T.olex; r.orex = T.orex;
+            r.simpson_n = T.simpson_n; r.sample = s_in; r.leaf = 1; r.tn = 0;
+        }
+        if (c.lane < c.S) { w->ops_vaf[c.lane] = c.tvaf[c.lane]; w->curMapVaf[c.lane] = c.mapVaf[u * c.S + c.lane]; }
+        __syncthreads();
+        c.group = UNI(T.group); c.disc = UNI(T.disc); c.contained = UNI(T.contained); c.alive = UNI(T.alive); c.nlfc = 0;
+        c.present = (1 << c.S) - 1; c.afd_mute = 0;
+        c.curJ = uni_d(c.mapJ[u]); c.curHyp = UNI(c.mapHyp[u]);
+        const double dens = run_leaf_chain(c, r, c.rowX, c.rowV);
+        if (dens != dens) c.status |= VLR_LOCUS_NAN;
+        double M = uni_d(evM[u]), Sx = uni_d(evS[u]);
+        lse_add(M, Sx, bias_prior + dens);
+        __syncthreads();
+        if (c.lane == 0) { evM[u] = M; evS[u] = Sx; c.mapJ[u] = c.curJ; c.mapHyp[u] = c.curHyp; }
+        if (c.lane < c.S) c.mapVaf[u * c.S + c.lane] = w->curMapVaf[c.lane];
+        __syncthreads();
+        c.ndef = 0;
+        return;
+    }
+    run_chain_batch(c, nt, s_in);
+    __syncthreads();
+    for (int i = 0; i < nt; ++i) {
+        const ChainTask& T = w->task[i];
+        const int u = UNI(T.u);
+        // restore the context of the deferred leaf: operands, event group, flags, and the slot's MAP candidate
+        __syncthreads();
+        if (c.lane < c.S) { w->ops_vaf[c.lane] = c.tvaf[i * c.S + c.lane]; w->curMapVaf[c.lane] = c.mapVaf[u * c.S + c.lane]; }
+        __syncthreads();
+        c.group = UNI(T.group); c.disc = UNI(T.disc); c.contained = UNI(T.contained); c.alive = UNI(T.alive); c.nlfc = 0;
+        c.curJ = uni_d(c.mapJ[u]); c.curHyp = UNI(c.mapHyp[u]);
+        const double dens = uni_d(T.result);
+        if (dens != dens) c.status |= VLR_LOCUS_NAN;
+        const int nq = UNI(T.n);
+        if (c.replay) afd_emit_row(c, i, s_in, nq);
+        else {
+            if (UNI(T.haveBest)) map_consider(c, uni_d(T.bestJ), s_in, uni_d(T.bestX));
+            if (c.alive != 0 || !c.contained) {
+                const RangeV io{T.ostart, T.oend, T.olex, T.orex};
+                const double* rx = c.rowX + i * c.cap;
+                const double* rvv = c.rowV + i * c.cap;
+                for (int q = 0; q < nq; ++q) {
+                    double xq = uni_d(rx[q]);
+                    bool own = c.contained && range_contains(io, xq);
+                    int al = c.alive ? alive_update(c, c.alive, s_in, xq) : 0;
+                    if (!own || al) map_all(c, uni_d(rvv[q]), s_in, xq, false, al);
+                }
+            }
+        }
+        double M = uni_d(evM[u]), Sx = uni_d(evS[u]);
+        lse_add(M, Sx, bias_prior + dens);
+        __syncthreads();
+        if (c.lane == 0) { evM[u] = M; evS[u] = Sx; c.mapJ[u] = c.curJ; c.mapHyp[u] = c.curHyp; }
+        if (c.lane < c.S) c.mapVaf[u * c.S + c.lane] = w->curMapVaf[c.lane];
+        __syncthreads();
+    }
+    c.ndef = 0;
 }
 
 // GenericPosterior::density (modes/generic.rs:190-423) for one (hypothesis, root): explicit-stack walk.
@@ -1515,6 +1596,10 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                         f.sv_present = c.present; f.sv_disc = c.disc; f.sv_nlfc = c.nlfc; f.sv_contained = c.contained;
                         f.sv_alive = c.alive; f.sv_mute = c.afd_mute;
                     }
+                    if (c.defer_ok && (as_set ? (ncand > 1) : (nd.n_children != 0))) {
+                        c.deferred = 2;  // probe pass: not a single-chain root, evaluate in the second pass
+                        return 0.0;
+                    }
                     if (as_set) {
                         if (c.lane == 0) { f.kind = FK_SET; f.n = ncand; w->ops_vaf[s] = c.setv[s * kMaxSet]; }
                         __syncthreads();
@@ -1562,6 +1647,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
             if (nd.n_children == 0) { rv = leaf_joint(c); pc = PC_RETURN; }
             else if (nd.n_children == 1) { node = UNI(p.child_index[nd.child_off]); pc = PC_DESCEND; }
             else if (sp >= kMaxFrames) { c.status |= VLR_LOCUS_TABLE_FULL; rv = __builtin_nan(""); pc = PC_RETURN; }
+            else if (c.defer_ok) { c.deferred = 2; return 0.0; }  // probe pass: branching root is not a single chain
             else {
                 __syncthreads();
                 Frame& f = w->frames[sp];
@@ -1593,11 +1679,39 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                 c.nlfc = f.sv_nlfc;
                 c.contained = f.sv_contained;
                 c.alive = f.sv_alive;
+                if (c.defer_ok && (c.cap > 64 || c.nlfc != 0 || (c.ndef > 0 && UNI(w->task[0].inner) != UNI(r.sample)))) {
+                    c.deferred = 2;
+                    return 0.0;
+                }
+                if (c.defer_ok) {
+                    // defer: this root is exactly one innermost chain (all enclosing frames are single-valued)
+                    const int inner = UNI(r.sample), S = c.S, row = c.ndef;
+                    double fixed = 0.0;
+                    int pidx = 0;
+                    for (int s2 = 0; s2 < S; ++s2) {
+                        int by = p.by[s2];
+                        if (!(s2 == inner || by == inner)) fixed += sample_lik(c, s2, w->ops_vaf[s2], by >= 0 ? w->ops_vaf[by] : 0.0);
+                        if (s2 != inner) pidx += prior_class(p, s2, w->ops_vaf[s2]) * p.class_stride[s2];
+                    }
+                    __syncthreads();
+                    if (c.lane == 0) {
+                        ChainTask& T = w->task[row];
+                        T.lo = r.lo; T.hi = r.hi; T.res = r.res; T.ostart = r.ostart; T.oend = r.oend; T.olex = r.olex; T.orex = r.orex;
+                        T.simpson_n = r.simpson_n; T.fixed = fixed; T.pidx = pidx; T.contained = c.contained; T.alive = c.alive;
+                        T.result = VLR_NEG_INF; T.haveBest = 0; T.n = 0; T.bestJ = VLR_NEG_INF; T.bestX = 0.0;
+                        T.group = c.group; T.disc = c.disc; T.inner = inner; T.u = c.defer_slot;
+                    }
+                    if (c.lane < S) c.tvaf[row * S + c.lane] = w->ops_vaf[c.lane];
+                    __syncthreads();
+                    c.ndef = row + 1;
+                    c.deferred = 1;
+                    return 0.0;
+                }
                 rv = run_leaf_chain(c, r, c.rowX, c.rowV);
                 c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained; c.alive = f.sv_alive; c.afd_mute = f.sv_mute;
                 sp--; nrange--;
                 pc = PC_RETURN;
-            } else if (UNI(f.iter) == 0 && UNI(f.sv_nlfc) == 0 && p.nodes[fnode].n_children == 1 &&
+            } else if (c.cap <= 64 && UNI(f.iter) == 0 && UNI(f.sv_nlfc) == 0 && p.nodes[fnode].n_children == 1 &&
                        p.nodes[UNI(p.child_index[p.nodes[fnode].child_off])].kind == VLR_NODE_SAMPLE &&
                        p.nodes[UNI(p.child_index[p.nodes[fnode].child_off])].vafs.kind == 1 &&
                        p.nodes[UNI(p.child_index[p.nodes[fnode].child_off])].n_children == 0 &&
@@ -2047,30 +2161,45 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
         // ---- events (calling.rs:654-687): absent + clean events under h = none, artifact twins otherwise
         const double bias_prior = (h == 0) ? kLn05 : kLn05 + log(1.0 / (double)n_biases);  // modes/generic.rs:437-441
         const int first_ev = (h == 0) ? -1 : 0;
-        for (int e = first_ev; e < p.n_named; ++e) {
-            int u = (e < 0) ? 0 : (1 + 2 * e + (h == 0 ? 0 : 1));
-            int r0 = (e < 0) ? 0 : p.root_off[e], r1 = (e < 0) ? 1 : p.root_off[e + 1];
-            c.group = e + 1;
-            __syncthreads();
-            c.curJ = mapJ[u];
-            c.curHyp = mapHyp[u];
-            __syncthreads();
-            if (lane < S) w->curMapVaf[lane] = mapVaf[u * S + lane];
-            __syncthreads();
-            double M = evM[u], Sx = evS[u];
-            for (int ri = r0; ri < r1; ++ri) {
-                int root = (e < 0) ? p.absent_root : p.roots[ri];
-                double dens = walk_root(c, root);
-                if (dens != dens) c.status |= VLR_LOCUS_NAN;
-                lse_add(M, Sx, bias_prior + dens);
+        // pass 0 (probe): roots that are a single innermost chain are deferred and run together, one per DPP row;
+        // pass 1: the remaining (nested / branching / set-valued) roots through the general walk
+        c.ndef = 0;
+        c.deferred = 0;
+        unsigned long long todo = 0ull;  // roots left for pass 1 (bit = running root counter, first 64 roots)
+        for (int pass = 0; pass < 2; ++pass) {
+            int rc_ = 0;
+            for (int e = first_ev; e < p.n_named; ++e) {
+                int u = (e < 0) ? 0 : (1 + 2 * e + (h == 0 ? 0 : 1));
+                int r0 = (e < 0) ? 0 : p.root_off[e], r1 = (e < 0) ? 1 : p.root_off[e + 1];
+                for (int ri = r0; ri < r1; ++ri, ++rc_) {
+                    const bool probe = (pass == 0) && rc_ < 64;
+                    if (pass == 0 && !probe) continue;
+                    if (pass == 1 && rc_ < 64 && !((todo >> rc_) & 1ull)) continue;
+                    if (c.ndef == kRows) flush_deferred(c, evM, evS, bias_prior);
+                    c.group = e + 1;
+                    c.defer_ok = probe ? 1 : 0;
+                    c.defer_slot = u;
+                    __syncthreads();
+                    c.curJ = uni_d(mapJ[u]);
+                    c.curHyp = UNI(mapHyp[u]);
+                    if (lane < S) w->curMapVaf[lane] = mapVaf[u * S + lane];
+                    __syncthreads();
+                    int root = (e < 0) ? p.absent_root : p.roots[ri];
+                    double dens = walk_root(c, root);
+                    if (c.deferred == 1) { c.deferred = 0; continue; }                      // delivered by flush_deferred
+                    if (c.deferred == 2) { c.deferred = 0; todo |= 1ull << rc_; continue; } // second pass
+                    if (dens != dens) c.status |= VLR_LOCUS_NAN;
+                    double M = uni_d(evM[u]), Sx = uni_d(evS[u]);
+                    lse_add(M, Sx, bias_prior + dens);
+                    __syncthreads();
+                    if (lane == 0) { evM[u] = M; evS[u] = Sx; mapJ[u] = c.curJ; mapHyp[u] = c.curHyp; }
+                    if (lane < S) mapVaf[u * S + lane] = w->curMapVaf[lane];
+                    __syncthreads();
+                }
             }
-            __syncthreads();
-            if (lane == 0) { evM[u] = M; evS[u] = Sx; mapJ[u] = c.curJ; mapHyp[u] = c.curHyp; }
-            if (lane < S) mapVaf[u * S + lane] = w->curMapVaf[lane];
-            __syncthreads();
+            if (pass == 0) flush_deferred(c, evM, evS, bias_prior);  // rows are free again for the nested events
         }
     }
-
     PROF_ADD(c, 3);  // walk remainder (everything in the event loop not attributed below)
     if (c.replay) return;
     // ============================ phase C: posteriors + MAP ============================
