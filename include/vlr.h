@@ -238,12 +238,12 @@ typedef struct {
     int32_t* best_event;    /* [n_loci] index into the engine's event universe: 0 absent, 1+2*e clean e, 2+2*e artifact twin (may be NULL) */
     uint32_t* status;       /* [n_loci] VLR_LOCUS_* bits                                                   */
     /* optional AFD (calling.rs:889-928; FORMAT/AFD): for locus l and sample s the entries
-     * afd_vaf/afd_lnprob[afd_offset[l*S+s] .. +afd_count[l*S+s]]; capacity afd_capacity per (locus,sample);
+     * afd_vaf/afd_lnprob[(l*S+s)*afd_capacity .. + min(afd_count[l*S+s], afd_capacity)]; unordered;
      * all NULL to skip.                                                                                  */
     int32_t  afd_capacity;
     int32_t  _pad;
     int32_t* afd_count;     /* [n_loci * n_samples]                                                        */
-    float*   afd_vaf;       /* [n_loci * n_samples * afd_capacity]                                         */
+    double*  afd_vaf;       /* [n_loci * n_samples * afd_capacity] (f64: the BCF prints it with 3 decimals)      */
     double*  afd_lnprob;    /* [n_loci * n_samples * afd_capacity]                                         */
 } vlr_results;
 

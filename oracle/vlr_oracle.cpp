@@ -1511,7 +1511,7 @@ int vlro_call_batch(const vlr_scenario_desc* desc, const vlr_batch* in, vlr_resu
                     int n = (int)std::min<size_t>(dist.size(), (size_t)out->afd_capacity);
                     out->afd_count[l * S + s] = (int)dist.size();
                     for (int i = 0; i < n; ++i) {
-                        out->afd_vaf[(l * S + s) * out->afd_capacity + i] = (float)dist[i].first;
+                        out->afd_vaf[(l * S + s) * out->afd_capacity + i] = dist[i].first;
                         out->afd_lnprob[(l * S + s) * out->afd_capacity + i] = dist[i].second;
                     }
                 }

@@ -1,0 +1,53 @@
+"""End to end at the process boundary: observation VCF (format v15) + scenario YAML in, calls VCF out, compared
+record by record with the reference's own output file tests/resources/flamegraph_profiling/calls.vcf."""
+import io
+import os
+import re
+
+import pytest
+
+from varlociraptor_amd import abi, cli
+
+pytestmark = pytest.mark.gpu
+
+
+def tokens(obs: str):
+    return sorted(re.findall(r"\d+[^\d]+", obs))
+
+
+def test_cli_reproduces_reference_calls_file(golden_dir):
+    d = os.path.join(golden_dir, "flamegraph_profiling")
+    sc = cli.scenario_from_yaml(os.path.join(d, "scenario.yaml"))
+    buf = io.StringIO()
+    # the reference file was produced without artifact events (PROB_ARTIFACT=inf): all six biases omitted
+    cli.call_variants(sc, {"normal": os.path.join(d, "normal.vcf")}, omit_mask=abi.BIAS_ALL, out=buf)
+    got = [l for l in buf.getvalue().splitlines() if not l.startswith("#")]
+    exp = [l.rstrip("\n") for l in open(os.path.join(d, "calls.vcf")) if not l.startswith("#")]
+    assert len(got) == len(exp) == 11
+    n_identical = 0
+    for g, e in zip(got, exp):
+        gf, ef = g.split("\t"), e.split("\t")
+        assert gf[:7] == ef[:7]
+        # PROB_* INFO: same tags in the same (descending probability) order; values agree to the 6 printed digits
+        # up to one unit in the last place (calls.vcf comes from an older build of the reference)
+        gi, ei = [kv.split("=") for kv in gf[7].split(";")], [kv.split("=") for kv in ef[7].split(";")]
+        assert [k for k, _ in gi] == [k for k, _ in ei]
+        for (_, a), (_, b) in zip(gi, ei):
+            assert float(a) == pytest.approx(float(b), rel=3e-6)
+        assert gf[8] == ef[8]
+        gs, es = gf[9].split(":"), ef[9].split(":")
+        keys = gf[8].split(":")
+        same = gf[7] == ef[7]
+        for k, a, b in zip(keys, gs, es):
+            if k in ("SAOBS", "SROBS", "OBS"):
+                assert tokens(a) == tokens(b), (k, a, b)  # Counter::most_common leaves ties unordered
+            elif k == "AFD":
+                ga, ea = [x.split("=") for x in a.split(",")], [x.split("=") for x in b.split(",")]
+                assert [x for x, _ in ga] == [x for x, _ in ea]           # exact visited-point list
+                for (_, u), (_, v) in zip(ga, ea):
+                    assert abs(float(u) - float(v)) <= 0.011            # 2 printed decimals
+                same = same and a == b
+            else:
+                assert a == b, (k, a, b)
+        n_identical += same
+    assert n_identical >= 5  # most records are character-identical

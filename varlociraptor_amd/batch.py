@@ -109,7 +109,7 @@ class CallResults:
         self.status = np.zeros(n_loci, np.uint32)
         if afd_capacity > 0:
             self.afd_count = np.zeros((n_loci, n_samples), np.int32)
-            self.afd_vaf = np.zeros((n_loci, n_samples, afd_capacity), np.float32)
+            self.afd_vaf = np.zeros((n_loci, n_samples, afd_capacity), np.float64)
             self.afd_lnprob = np.zeros((n_loci, n_samples, afd_capacity), np.float64)
         else:
             self.afd_count = self.afd_vaf = self.afd_lnprob = None

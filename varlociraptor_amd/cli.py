@@ -1,0 +1,111 @@
+"""`python -m varlociraptor_amd call variants generic --scenario S.yaml --obs name=path.vcf ... [> calls.vcf]`
+
+Mirror of the reference's `call variants` surface (src/cli.rs:684-735) for text observation VCFs (format v15):
+`generic` with a scenario YAML (grammar/mod.rs:129-144) and `tumor-normal --tumor --normal --purity`
+(src/cli.rs:1151-1172).  Model evaluation runs on the GPU engine; there is no CPU path.
+"""
+from __future__ import annotations
+
+import argparse
+import sys
+from typing import Dict, List
+
+from . import abi, callsfmt, engine, obsfmt
+from .scenario import Contamination, Inheritance, Sample, Scenario, Species, tumor_normal
+
+
+def scenario_from_yaml(path: str) -> Scenario:
+    import yaml
+    with open(path) as fh:
+        y = yaml.safe_load(fh)
+    if "expressions" in y and y["expressions"]:
+        raise NotImplementedError("scenario expressions need the full grammar front-end (SURVEY §8f #3)")
+    species = None
+    if y.get("species"):
+        sp = y["species"]
+        ploidy = sp.get("ploidy")
+        if isinstance(ploidy, dict):
+            raise NotImplementedError("sex/contig specific ploidy maps: pass a per-contig scenario")
+        vf = sp.get("variant-fractions", {}) or {}
+        species = Species(heterozygosity=sp.get("heterozygosity"), germline_mutation_rate=sp.get("germline-mutation-rate"),
+                          somatic_effective_mutation_rate=sp.get("somatic-effective-mutation-rate"), ploidy=ploidy,
+                          fraction_indel=vf.get("indel", 0.0125), fraction_mnv=vf.get("mnv", 0.001), fraction_sv=vf.get("sv", 0.01))
+    samples: Dict[str, Sample] = {}
+    for name, sd in y["samples"].items():
+        sd = sd or {}
+        cont = sd.get("contamination")
+        inh = sd.get("inheritance")
+        inheritance = None
+        if inh:
+            if "mendelian" in inh:
+                inheritance = Inheritance(abi.INHERIT_MENDELIAN, tuple(inh["mendelian"]["from"]))
+            elif "clonal" in inh:
+                inheritance = Inheritance(abi.INHERIT_CLONAL, (inh["clonal"]["from"],), bool(inh["clonal"]["somatic"]))
+            elif "subclonal" in inh:
+                inheritance = Inheritance(abi.INHERIT_SUBCLONAL, (inh["subclonal"]["from"],))
+        universe = sd.get("universe")
+        if isinstance(universe, dict):
+            raise NotImplementedError("contig specific universes: pass a per-contig scenario")
+        samples[name] = Sample(
+            resolution=float(sd.get("resolution", 0.01)), universe=universe,
+            contamination=Contamination(cont["by"], float(cont["fraction"])) if cont else None, ploidy=sd.get("ploidy"),
+            somatic_effective_mutation_rate=sd.get("somatic-effective-mutation-rate"),
+            germline_mutation_rate=sd.get("germline-mutation-rate"), inheritance=inheritance)
+    return Scenario(samples, dict(y["events"]), species=species)
+
+
+def call_variants(scenario: Scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_capacity: int = 128, out=sys.stdout,
+                  device: int = 0):
+    paths = []
+    for name in scenario.sample_names:
+        if name not in obs_paths:
+            raise SystemExit("no observations given for sample %r" % name)
+        paths.append(obs_paths[name])
+    for name in obs_paths:
+        if name not in scenario.sample_names:
+            raise SystemExit("invalid observation sample name %r" % name)  # errors::Error::InvalidObservationSampleName
+    batch, sites = obsfmt.read_observation_vcf(paths, omit_bias_mask=omit_mask)
+    plan = engine.Plan(scenario, device=device)
+    res = plan.call_host(batch, afd_capacity=afd_capacity)
+    plan.close()
+    names = scenario.out_names()
+    print(callsfmt.header(names, scenario.sample_names, sorted(set(s[0] for s in sites))), file=out)
+    for l, site in enumerate(sites):
+        print(callsfmt.format_record(site, batch, res, l, names, scenario.sample_names), file=out)
+    return res
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="varlociraptor_amd")
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    call = sub.add_parser("call").add_subparsers(dest="what", required=True)
+    variants = call.add_parser("variants")
+    for flag, bit in (("--omit-strand-bias", abi.BIAS_STRAND), ("--omit-read-orientation-bias", abi.BIAS_ORIENTATION),
+                      ("--omit-read-position-bias", abi.BIAS_POSITION), ("--omit-softclip-bias", abi.BIAS_SOFTCLIP),
+                      ("--omit-homopolymer-artifact-detection", abi.BIAS_HOMOPOLYMER), ("--omit-alt-locus-bias", abi.BIAS_ALTLOCUS)):
+        variants.add_argument(flag, action="store_const", const=bit, default=0)
+    variants.add_argument("--full-prior", action="store_true")
+    variants.add_argument("--device", type=int, default=0)
+    mode = variants.add_subparsers(dest="mode", required=True)
+    g = mode.add_parser("generic")
+    g.add_argument("--scenario", required=True)
+    g.add_argument("--obs", nargs="+", required=True, metavar="NAME=PATH")
+    t = mode.add_parser("tumor-normal")
+    t.add_argument("--tumor", required=True)
+    t.add_argument("--normal", required=True)
+    t.add_argument("--purity", type=float, required=True)
+    a = ap.parse_args(argv)
+    omit = (a.omit_strand_bias | a.omit_read_orientation_bias | a.omit_read_position_bias | a.omit_softclip_bias |
+            a.omit_homopolymer_artifact_detection | a.omit_alt_locus_bias)
+    if a.mode == "generic":
+        sc = scenario_from_yaml(a.scenario)
+        obs = dict(kv.split("=", 1) for kv in a.obs)
+    else:
+        sc = tumor_normal(a.purity)
+        obs = {"tumor": a.tumor, "normal": a.normal}
+    sc.full_prior = a.full_prior
+    call_variants(sc, obs, omit_mask=omit, device=a.device)
+
+
+if __name__ == "__main__":
+    main()

@@ -746,7 +746,7 @@ int vlr_batch_run_host(vlr_plan* plan, const vlr_batch* in, vlr_results* out) {
     const bool want_afd = out->afd_count || out->afd_vaf || out->afd_lnprob;
     const size_t cap = want_afd ? (size_t)out->afd_capacity : 0;
     size_t r_ac = off; off += al(want_afd ? (size_t)L * S * 4 : 0);
-    size_t r_av = off; off += al((size_t)L * S * cap * 4);
+    size_t r_av = off; off += al((size_t)L * S * cap * 8);
     size_t r_al = off; off += al((size_t)L * S * cap * 8);
     (void)in_end;
     if (off > plan->stage_bytes) {
@@ -779,7 +779,7 @@ int vlr_batch_run_host(vlr_plan* plan, const vlr_batch* in, vlr_results* out) {
     dr.best_event = (int32_t*)(base + r_best);
     dr.status = (uint32_t*)(base + r_stat);
     dr.afd_count = want_afd ? (int32_t*)(base + r_ac) : nullptr;
-    dr.afd_vaf = want_afd ? (float*)(base + r_av) : nullptr;
+    dr.afd_vaf = want_afd ? (double*)(base + r_av) : nullptr;
     dr.afd_lnprob = want_afd ? (double*)(base + r_al) : nullptr;
     if (want_afd && (!out->afd_count || !out->afd_vaf || !out->afd_lnprob || out->afd_capacity < 1))
         return fail(VLR_ERR_INVALID_ARGUMENT, "AFD needs afd_count, afd_vaf, afd_lnprob and afd_capacity >= 1");
@@ -803,7 +803,7 @@ int vlr_batch_run_host(vlr_plan* plan, const vlr_batch* in, vlr_results* out) {
     HIP_TRY(hipMemcpy(out->status, dr.status, (size_t)L * 4, hipMemcpyDeviceToHost));
     if (want_afd) {
         HIP_TRY(hipMemcpy(out->afd_count, dr.afd_count, (size_t)L * S * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(out->afd_vaf, dr.afd_vaf, (size_t)L * S * cap * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out->afd_vaf, dr.afd_vaf, (size_t)L * S * cap * 8, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(out->afd_lnprob, dr.afd_lnprob, (size_t)L * S * cap * 8, hipMemcpyDeviceToHost));
     }
     return VLR_OK;

@@ -690,7 +690,7 @@ __device__ inline void afd_consider(Ctx& c, double joint, int inner, double x) {
             int idx = atomicAdd(&o.afd_count[slot], 1);
             if (idx < o.afd_capacity) {
                 double v = (s == inner) ? x : c.w->ops_vaf[s];
-                o.afd_vaf[slot * o.afd_capacity + idx] = (float)v;
+                o.afd_vaf[slot * o.afd_capacity + idx] = v;
                 o.afd_lnprob[slot * o.afd_capacity + idx] = joint - c.marginal;
             }
         }

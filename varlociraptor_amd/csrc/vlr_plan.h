@@ -93,7 +93,7 @@ struct DevResults {
     // launch), and the caller's AFD buffers
     uint8_t* map_disc;      // [n_loci]
     int32_t* afd_count;     // [n_loci * S]
-    float* afd_vaf;         // [n_loci * S * afd_capacity]
+    double* afd_vaf;        // [n_loci * S * afd_capacity]
     double* afd_lnprob;     // [n_loci * S * afd_capacity]
     int32_t afd_capacity;
     int32_t replay;         // 0: call pass, 1: AFD replay pass

@@ -92,6 +92,16 @@ def _vec_opt_i8(buf: bytes) -> np.ndarray:
     return out
 
 
+def _vec_opt_u32(buf: bytes) -> np.ndarray:
+    r = _Reader(buf)
+    n = r.u64()
+    out = np.full(n, -1, dtype=np.int64)  # -1 = None
+    for i in range(n):
+        if r.u8():
+            out[i] = r.u32()
+    return out
+
+
 def _bitvec(buf: bytes) -> np.ndarray:
     r = _Reader(buf)
     if not r.u8():
@@ -147,6 +157,8 @@ def decode_record_info(info: Dict[str, str]) -> Dict[str, np.ndarray]:
         assert len(a) == n
     cols["flags"] = abi.pack_flags(strand, orient, readpos == 0, softclipped, paired, max_mapq, alt_locus, hp_len)
     cols["_is_homopolymer_indel"] = np.array([is_hp])
+    # output-only feature (OBS string of the calls record, calling/variants/mod.rs:283-287)
+    cols["_third_allele_evidence"] = _vec_opt_u32(g("THIRD_ALLELE_EVIDENCE")) if "THIRD_ALLELE_EVIDENCE" in info else np.full(n, -1, np.int64)
     return cols
 
 
@@ -201,6 +213,7 @@ def read_observation_vcf(paths: List[str], omit_bias_mask: int = 0) -> Tuple[Pil
     S = len(paths)
     offsets = [0]
     cols: Dict[str, List[np.ndarray]] = {k: [] for k, _ in abi.OBS_COLUMNS}
+    third: List[np.ndarray] = []
     locus_flags, vtypes, refb, altb, sites = [], [], [], [], []
     for i in range(n):
         chrom, pos, ref, alt, _ = per_sample[0][i]
@@ -213,6 +226,7 @@ def read_observation_vcf(paths: List[str], omit_bias_mask: int = 0) -> Tuple[Pil
         for s in range(S):
             c = decode_record_info(per_sample[s][i][4])
             any_hp |= bool(c.pop("_is_homopolymer_indel")[0])
+            third.append(c.pop("_third_allele_evidence"))
             for k, _ in abi.OBS_COLUMNS:
                 cols[k].append(c[k])
             offsets.append(offsets[-1] + len(c["prob_mapping"]))
@@ -241,4 +255,6 @@ def read_observation_vcf(paths: List[str], omit_bias_mask: int = 0) -> Tuple[Pil
     columns = {k: (np.concatenate(v) if v else np.zeros(0, dt)) for (k, dt), v in zip(abi.OBS_COLUMNS, cols.values())}
     locus = {"locus_flags": np.array(locus_flags, np.uint8), "variant_type": np.array(vtypes, np.uint8),
              "ref_base": np.array(refb, np.uint8), "alt_base": np.array(altb, np.uint8)}
-    return PileupBatch(S, np.array(offsets, np.uint32), columns, locus), sites
+    batch = PileupBatch(S, np.array(offsets, np.uint32), columns, locus)
+    batch.extra = {"third_allele_evidence": np.concatenate(third) if third else np.zeros(0, np.int64)}
+    return batch, sites
