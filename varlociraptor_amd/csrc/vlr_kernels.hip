@@ -1871,7 +1871,6 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
     bool any_altloci = false, any_softclip = false;
     unsigned possible = 0;                                                 // bit h: some obs is bias evidence under h
     unsigned possible_alb_noloci = 0;
-    LseAcc sb_all{VLR_NEG_INF, 0.0}, sb_fwd{VLR_NEG_INF, 0.0};            // strand_bias.rs:79-123
     int offset_acc = 0;
     bool too_deep = false;
     for (int s = 0; s < S; ++s) {
@@ -1881,14 +1880,13 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
         int sbias[kNHyp];
         int sbias_alb_noloci = 0;
         for (int h = 0; h < kNHyp; ++h) sbias[h] = 0;
-        LseAcc pa_all{VLR_NEG_INF, 0.0}, pa_major{VLR_NEG_INF, 0.0}, pa_rate{VLR_NEG_INF, 0.0};
         for (uint32_t base = o0; base < o1; base += 64) {
             uint32_t i = base + lane;
             bool valid = i < o1;
-            double pm = 0, pa = 0, pr = 0, phb = 0;
+            double pm = 0, pa = 0, pr = 0;
             uint32_t f = 0;
             if (valid) {
-                pm = batch.pm[i]; pa = batch.pa[i]; pr = batch.pr[i]; phb = batch.phb[i];
+                pm = batch.pm[i]; pa = batch.pa[i]; pr = batch.pr[i];
                 f = batch.flags[i];
             }
             bool keep = valid && !(remove_nonstd && f_orient(f) == VLR_ORIENT_OTHER);  // pileup.rs:26-43
@@ -1909,7 +1907,7 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
             int hl = f_hplen(f);
             if (__ballot(keep && hl > 0)) ins = 1;
             if (__ballot(keep && hl < 0)) del = 1;
-            int orient = f_orient(f), strand = f_strand(f);
+            int orient = f_orient(f);
             bool std_or = orient == VLR_ORIENT_F1R2 || orient == VLR_ORIENT_F2R1;
             n_uncertain += popc64(__ballot(keep && !std_or));
             strong_ref_std += popc64(__ballot(strong_ref && std_or));
@@ -1932,11 +1930,6 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
                 if (__ballot(keep && ev)) possible_alb_noloci = 1;
                 sbias_alb_noloci += popc64(__ballot(sa_u && ev));
             }
-            lseacc_chunk(sb_all, pm, strong_ref && strand != VLR_STRAND_BOTH);
-            lseacc_chunk(sb_fwd, pm, strong_ref && strand == VLR_STRAND_FORWARD);
-            lseacc_chunk(pa_all, pm, strong_ref);
-            lseacc_chunk(pa_major, pm, strong_ref && (f & VLR_F_READPOS_MAJOR));
-            lseacc_chunk(pa_rate, pm + phb, strong_ref);
         }
         if (lane == 0) {
             w->nkeep[s] = nk; w->soff[s] = offset_acc;
@@ -1944,10 +1937,33 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
             w->any_strong_alt[s] = anysa; w->has_ins[s] = ins; w->has_del[s] = del;
             for (int h = 0; h < kNHyp; ++h) w->strong_bias[s][h] = sbias[h];
             w->strong_bias[s][0] = sbias_alb_noloci;  // slot 0 reused: alt-locus evidence without alt loci
-            w->pos_all[s] = lseacc_exp(pa_all); w->pos_major[s] = lseacc_exp(pa_major); w->pos_rate[s] = lseacc_exp(pa_rate);
         }
         offset_acc += nk;
         total_kept += nk;
+    }
+    // second pass (rows are L2-hot): the exp(ln_sum_exp(prob_mapping)) sums of strand_bias.rs:79-123 and
+    // read_position_bias.rs:63-122, kept apart from the counters above to bound register pressure
+    LseAcc sb_all{VLR_NEG_INF, 0.0}, sb_fwd{VLR_NEG_INF, 0.0};
+    for (int s = 0; s < S; ++s) {
+        const int64_t pidx = locus * S + s;
+        const uint32_t o0 = batch.obs_offset[pidx], o1 = batch.obs_offset[pidx + 1];
+        LseAcc pa_all{VLR_NEG_INF, 0.0}, pa_major{VLR_NEG_INF, 0.0}, pa_rate{VLR_NEG_INF, 0.0};
+        for (uint32_t base = o0; base < o1; base += 64) {
+            uint32_t i = base + lane;
+            bool valid = i < o1;
+            double pm = 0, pa = 0, pr = 0, phb = 0;
+            uint32_t f = 0;
+            if (valid) { pm = batch.pm[i]; pa = batch.pa[i]; pr = batch.pr[i]; phb = batch.phb[i]; f = batch.flags[i]; }
+            bool keep = valid && !(remove_nonstd && f_orient(f) == VLR_ORIENT_OTHER);
+            bool strong_ref = keep && exp(pr - pa) > 20.0;
+            int strand = f_strand(f);
+            lseacc_chunk(sb_all, pm, strong_ref && strand != VLR_STRAND_BOTH);
+            lseacc_chunk(sb_fwd, pm, strong_ref && strand == VLR_STRAND_FORWARD);
+            lseacc_chunk(pa_all, pm, strong_ref);
+            lseacc_chunk(pa_major, pm, strong_ref && (f & VLR_F_READPOS_MAJOR));
+            lseacc_chunk(pa_rate, pm + phb, strong_ref);
+        }
+        if (lane == 0) { w->pos_all[s] = lseacc_exp(pa_all); w->pos_major[s] = lseacc_exp(pa_major); w->pos_rate[s] = lseacc_exp(pa_rate); }
     }
     if (offset_acc > max_obs) too_deep = true;
     __syncthreads();
