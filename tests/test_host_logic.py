@@ -164,3 +164,27 @@ def test_no_device_is_an_error_not_a_fallback():
     with pytest.raises(engine.EngineError) as ei:
         engine.Plan(single_sample(0.01))
     assert ei.value.code == abi.ERR_NO_DEVICE
+
+
+def test_bcf_reader_agrees_with_the_text_vcf(golden_dir):
+    """The binary observation BCF of the reference's fixture decodes to exactly the batch of its text twin."""
+    from varlociraptor_amd import obsfmt
+    d = os.path.join(golden_dir, "flamegraph_profiling")
+    a, sa = obsfmt.read_observation_vcf([os.path.join(d, "normal.vcf")])
+    b, sb = obsfmt.read_observation_vcf([os.path.join(d, "normal.bcf")])
+    assert sa == sb
+    assert np.array_equal(a.obs_offset, b.obs_offset)
+    for k in a.columns:
+        assert np.array_equal(a.columns[k], b.columns[k], equal_nan=True), k
+    for k in a.locus:
+        assert np.array_equal(a.locus[k], b.locus[k]), k
+    assert np.array_equal(a.extra["third_allele_evidence"], b.extra["third_allele_evidence"])
+
+
+def test_bcf_reader_reads_the_reference_calls_file(golden_dir):
+    from varlociraptor_amd.bcfio import BcfReader
+    d = os.path.join(golden_dir, "flamegraph_profiling")
+    recs = list(BcfReader(os.path.join(d, "calls.bcf")))
+    assert len(recs) == 11 and recs[0]["pos"] == 10469 and recs[0]["alt"] == "<METH>"
+    assert recs[0]["info"]["PROB_ABSENT"][0] == pytest.approx(285.541, rel=1e-6)
+    assert recs[0]["info"]["PROB_PRESENT"][0] == 0.0

@@ -6,8 +6,8 @@ into LE u16 words, each stored as one i32 of an INFO integer vector (odd byte co
 mod.rs:985-988).  T = MiniLogProb{F16(f16) | F32(f32)} (src/utils/mod.rs:449-474), Option<…>,
 C-like enums, bv::BitVec<u8> = {Option tag, u64 nblocks, blocks, u64 nbits}.
 
-This module handles uncompressed `.vcf` text only (no htslib in this image); the BCF container and
-the calls writer are the "next" row §8(f)#2 of SURVEY.md.
+Text `.vcf` and binary `.bcf` (via the htslib-free reader in bcfio.py) are accepted; the calls formatter is
+callsfmt.py ("next" row §8(f)#2 of SURVEY.md).
 """
 from __future__ import annotations
 
@@ -188,6 +188,14 @@ def read_observation_vcf(paths: List[str], omit_bias_mask: int = 0) -> Tuple[Pil
     for path in paths:
         recs = []
         version_ok = False
+        if path.endswith(".bcf"):
+            from .bcfio import bcf_to_vcf_info_records
+            hdr, recs = bcf_to_vcf_info_records(path)
+            version_ok = any(l.strip() == "##varlociraptor_observation_format_version=" + OBSERVATION_FORMAT_VERSION for l in hdr)
+            if not version_ok:
+                raise ValueError("invalid observation format (calling.rs:324-339)")
+            per_sample.append(recs)
+            continue
         with open(path) as fh:
             for line in fh:
                 if line.startswith("##varlociraptor_observation_format_version="):
