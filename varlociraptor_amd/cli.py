@@ -94,7 +94,35 @@ def main(argv=None):
     t.add_argument("--tumor", required=True)
     t.add_argument("--normal", required=True)
     t.add_argument("--purity", type=float, required=True)
+    fc = sub.add_parser("filter-calls").add_subparsers(dest="what", required=True)
+    cf = fc.add_parser("control-fdr")  # cli.rs FilterMethod::ControlFDR
+    cf.add_argument("calls")
+    cf.add_argument("--events", nargs="+", required=True)
+    cf.add_argument("--fdr", type=float, required=True)
+    cf.add_argument("--mode", choices=["local-smart", "local-strict", "global-smart", "global-strict"], default="local-smart")
+    cf.add_argument("--smart-retain-artifacts", action="store_true")
+    cf.add_argument("--var", choices=["SNV", "MNV", "INS", "DEL", "BND", "INV", "DUP", "REP"])
+    cf.add_argument("--minlen", type=int)
+    cf.add_argument("--maxlen", type=int)
+    cf.add_argument("--device", default="cpu")
     a = ap.parse_args(argv)
+    if a.cmd == "filter-calls":
+        from . import fdr
+        from .bcfio import BcfReader
+        r = BcfReader(a.calls)
+        recs = list(r)
+        tags = [l.split("ID=")[1].split(",")[0] for l in r.header_lines if l.startswith("##INFO") and "ID=PROB_" in l]
+        vartype = None
+        if a.var:
+            rng = (a.minlen or 0, a.maxlen if a.maxlen is not None else 1 << 62) if (a.minlen is not None or a.maxlen is not None) else None
+            vartype = (a.var, rng)
+        kept = fdr.control_fdr(recs, a.events, a.fdr, vartype=vartype, local=a.mode.startswith("local"), smart=a.mode.endswith("smart"),
+                               smart_retain_artifacts=a.smart_retain_artifacts, header_tags=tags, device=a.device)
+        print("#CHROM\tPOS\tID\tREF\tALT")
+        for rec in kept:
+            print("\t".join(str(rec[k]) for k in ("chrom", "pos", "id", "ref", "alt")))
+        print(f"{len(kept)} of {len(recs)} records kept", file=sys.stderr)
+        return
     omit = (a.omit_strand_bias | a.omit_read_orientation_bias | a.omit_read_position_bias | a.omit_softclip_bias |
             a.omit_homopolymer_artifact_detection | a.omit_alt_locus_bias)
     if a.mode == "generic":
