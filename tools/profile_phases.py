@@ -10,11 +10,12 @@ b = synth.generate(cfg, n)
 plan = engine.Plan(cfg.scenario)
 plan.call_host(b)
 L = engine.lib()
-out = (C.c_ulonglong * 12)()
+out = (C.c_ulonglong * 24)()
 L.vlr_plan_profile_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 assert L.vlr_plan_profile_counters(plan._h, out) == 0
-names = ["A stats", "gating", "coefficients", "walk/other", "single rounds", "single integrate", "batch prep", "batch rounds", "batch epilogue", "phase C", "#batch runs", "#single chains"]
-tot = sum(out)
+names = ["A stats", "gating", "coefficients", "walk/other", "single rounds", "single integrate", "batch prep", "batch rounds", "batch epilogue", "phase C", "#batch runs", "#single chains", "round: products", "round: reduce", "round: log+prior", "round: advance"] + ["-"] * 8
+cnt = {10, 11}
+tot = sum(v for i, v in enumerate(out) if i not in cnt)
 for nm, v in zip(names, out):
     print("%-18s %14d  %5.1f%%  per locus %9.0f" % (nm, v, 100.0 * v / max(tot, 1), v / n))
 print("evals, terms", plan.work_counters())

@@ -28,7 +28,7 @@ namespace vlr {
 
 // optional per-phase cycle accounting (build with -DVLR_PROFILE): wall cycles of the wave spent per phase
 #ifdef VLR_PROFILE
-#define PROF_DECL unsigned long long prof[12]; unsigned long long prof_t;
+#define PROF_DECL unsigned long long prof[24]; unsigned long long prof_t;
 #define PROF_START(c) (c).prof_t = __builtin_amdgcn_s_memtime()
 #define PROF_ADD(c, i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); (c).prof[i] += t_ - (c).prof_t; (c).prof_t = t_; } while (0)
 #else
@@ -92,6 +92,7 @@ struct WaveSt {
     int cs_node[kContainStack], cs_mask[kContainStack];
     ChainTask task[kRows];
     double bpend[kRows][kRowPts], bvals[kRows][kRowPts];
+    unsigned long long work[2];  // [0] pileup evaluations, [1] observation terms (lane 0 adds; profiling aid)
     int fastok;  // bit s: all terms of sample s stay >= 2^-200 under the current hypothesis (4-term renormalisation is safe)
 };
 
@@ -150,9 +151,9 @@ struct RangeV { double start, end; int lex, rex; };
 __device__ inline bool range_is_empty(const RangeV& r) { return r.start == r.end && (r.lex || r.rex); }       // 1078-1080
 __device__ inline bool range_is_singleton(const RangeV& r) { return r.start == r.end && !(r.lex || r.rex); }  // 1086-1088
 __device__ inline bool range_contains(const RangeV& r, double v) {                                            // 1090-1097
-    bool lo = r.lex ? (r.start < v) : (r.start <= v);
-    bool hi = r.rex ? (r.end > v) : (r.end >= v);
-    return lo && hi;
+    const bool lo = (r.start < v) | ((r.lex == 0) & (r.start == v));
+    const bool hi = (r.end > v) | ((r.rex == 0) & (r.end == v));
+    return lo & hi;
 }
 __device__ inline RangeV range_empty() { return RangeV{0.0, 0.0, 1, 1}; }
 __device__ inline RangeV range_intersect(const RangeV& a, const RangeV& o) {  // 1131-1168, 1226-1254
@@ -321,79 +322,129 @@ __device__ __forceinline__ double dpp_f64(double v) {
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
 
-// product (mantissa P in [0.5,1) x 2^E) over the LP = 64 >> lg lanes of each point group; every lane of the
-// group ends with the result.  DPP quad/row permutes inside a 16-lane row, bpermute across rows.
-__device__ __forceinline__ void group_product(double& P, int& E, int lg) {
-    if (lg <= 5) { P *= dpp_f64<0xB1>(P); E += dpp_i32<0xB1>(E); }      // quad_perm [1,0,3,2]
-    if (lg <= 4) { P *= dpp_f64<0x4E>(P); E += dpp_i32<0x4E>(E); }      // quad_perm [2,3,0,1]
-    if (lg <= 3) { P *= dpp_f64<0x141>(P); E += dpp_i32<0x141>(E); }    // row_half_mirror
-    if (lg <= 2) { P *= dpp_f64<0x140>(P); E += dpp_i32<0x140>(E); }    // row_mirror
-    if (lg <= 1) { P *= __shfl_xor(P, 16); E += __shfl_xor(E, 16); }
-    if (lg == 0) { P *= __shfl_xor(P, 32); E += __shfl_xor(E, 32); }
-    int e2;
-    P = __builtin_frexp(P, &e2);  // group product of <= 64 mantissas >= 2^-64: one renormalisation suffices
-    E += e2;
+// mantissa/exponent renormalisation of a POSITIVE NORMAL double with integer ops on the high word (the
+// fast path guarantees every partial product stays far above 2^-1022)
+__device__ __forceinline__ void renorm_pos(double& P, int& E) {
+    const int hi = __double2hiint(P);
+    E += (int)(((unsigned)hi >> 20) & 0x7ffu) - 1022;
+    P = __hiloint2double((hi & 0x800fffff) | 0x3fe00000, __double2loint(P));
 }
 
-// this lane's slice k of the product; `fast`: every term of this pileup is >= 2^-200 at every VAF (checked when
-// the coefficients were built), so four terms are multiplied before one renormalisation
-__device__ __forceinline__ void pileup_partial(const double* __restrict__ coef, int D, int LP, int k, double al, double be,
-                                               bool fast, double& P, int& E) {
-    P = 1.0;
-    E = 0;
-    int i = k;
-    const int st = 3 * LP;
+// Partial products of NP points over this lane's observation slice: lane k of a W-lane group (W = 16: one DPP
+// row = one chain; W = 64: the whole wave) takes terms k, k+W, k+2W, ...  Every coefficient triple is loaded
+// once and used for all NP points (the LDS return path, not the VALU, limited the previous (point, slice)
+// lane split).  `fast`: every term of this pileup is >= 2^-200 at every VAF (checked when the coefficients were
+// built), so four terms are multiplied before one renormalisation and no clamping at zero is needed.
+template <int NP, int W>
+__device__ __forceinline__ void accum_terms(const double* __restrict__ coef, int D, int k, bool fast, const double* al, const double* be,
+                                            double* P, int* E) {
+    constexpr int ST = 3 * W;
+    const double* a = coef + 3 * k;
+    int base = 0;
     if (fast) {
-        for (; i + 3 * LP < D; i += 4 * LP) {
-            const double* a0 = coef + 3 * i;
-            const double* a1 = a0 + st;
-            const double* a2 = a1 + st;
-            const double* a3 = a2 + st;
-            double L0 = __builtin_fma(a0[2], be, __builtin_fma(a0[1], al, a0[0]));
-            double L1 = __builtin_fma(a1[2], be, __builtin_fma(a1[1], al, a1[0]));
-            double L2 = __builtin_fma(a2[2], be, __builtin_fma(a2[1], al, a2[0]));
-            double L3 = __builtin_fma(a3[2], be, __builtin_fma(a3[1], al, a3[0]));
-            L0 = fmax(L0, 0.0); L1 = fmax(L1, 0.0); L2 = fmax(L2, 0.0); L3 = fmax(L3, 0.0);
-            int e;
-            P = __builtin_frexp(P * ((L0 * L1) * (L2 * L3)), &e);
-            E += e;
+        for (; base + 4 * W <= D; base += 4 * W, a += 4 * ST) {
+            const double c0 = a[0], q0 = a[1], e0 = a[2];
+            const double c1 = a[ST], q1 = a[ST + 1], e1 = a[ST + 2];
+            const double c2 = a[2 * ST], q2 = a[2 * ST + 1], e2 = a[2 * ST + 2];
+            const double c3 = a[3 * ST], q3 = a[3 * ST + 1], e3 = a[3 * ST + 2];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const double L0 = __builtin_fma(e0, be[j], __builtin_fma(q0, al[j], c0));
+                const double L1 = __builtin_fma(e1, be[j], __builtin_fma(q1, al[j], c1));
+                const double L2 = __builtin_fma(e2, be[j], __builtin_fma(q2, al[j], c2));
+                const double L3 = __builtin_fma(e3, be[j], __builtin_fma(q3, al[j], c3));
+                P[j] *= (L0 * L1) * (L2 * L3);
+                renorm_pos(P[j], E[j]);
+            }
         }
-        for (; i < D; i += LP) {
-            const double* a0 = coef + 3 * i;
-            double L0 = fmax(__builtin_fma(a0[2], be, __builtin_fma(a0[1], al, a0[0])), 0.0);
-            int e;
-            P = __builtin_frexp(P * L0, &e);
-            E += e;
+        if (base < D) {  // <= 3 remaining slots, the last one partially filled
+            double acc[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) acc[j] = 1.0;
+            for (; base < D; base += W, a += ST) {
+                const bool v = base + k < D;
+                const double* aa = v ? a : coef;
+                double c0 = aa[0], q0 = aa[1], e0 = aa[2];
+                c0 = v ? c0 : 1.0; q0 = v ? q0 : 0.0; e0 = v ? e0 : 0.0;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) acc[j] *= __builtin_fma(e0, be[j], __builtin_fma(q0, al[j], c0));
+            }
+#pragma unroll
+            for (int j = 0; j < NP; ++j) { P[j] *= acc[j]; renorm_pos(P[j], E[j]); }
         }
     } else {
-        for (; i < D; i += LP) {  // robust path: per-term mantissa/exponent split (terms may be denormal or zero)
-            const double* a0 = coef + 3 * i;
-            double L0 = __builtin_fma(a0[2], be, __builtin_fma(a0[1], al, a0[0]));
-            L0 = L0 < 0.0 ? 0.0 : L0;
-            int e;
-            double m = __builtin_frexp(L0, &e);
-            P *= m;  // mantissas in [0.5,1): no underflow below ~1000 terms per lane (max_obs/4 < 1000 by the LDS cap)
-            E += e;
+        for (; base < D; base += W, a += ST) {  // robust path: per-term mantissa/exponent split (terms may be denormal or zero)
+            const bool v = base + k < D;
+            const double* aa = v ? a : coef;
+            double c0 = aa[0], q0 = aa[1], e0 = aa[2];
+            c0 = v ? c0 : 1.0; q0 = v ? q0 : 0.0; e0 = v ? e0 : 0.0;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                double L0 = __builtin_fma(e0, be[j], __builtin_fma(q0, al[j], c0));
+                L0 = L0 < 0.0 ? 0.0 : L0;
+                int e;
+                const double m = __builtin_frexp(L0, &e);
+                P[j] *= m;  // mantissas in [0.5,1): no underflow below ~1000 terms per lane
+                E[j] += e;
+            }
         }
-        int e;
-        P = __builtin_frexp(P, &e);
-        E += e;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { int e; P[j] = __builtin_frexp(P[j], &e); E[j] += e; }
+    }
+}
+// product over the W lanes of the group; every lane ends with the result (mantissa in [0.5,1) or 0, exponent)
+template <int NP, int W>
+__device__ __forceinline__ void reduce_terms(double* P, int* E) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        P[j] *= dpp_f64<0xB1>(P[j]); E[j] += dpp_i32<0xB1>(E[j]);      // quad_perm [1,0,3,2]
+        P[j] *= dpp_f64<0x4E>(P[j]); E[j] += dpp_i32<0x4E>(E[j]);      // quad_perm [2,3,0,1]
+        P[j] *= dpp_f64<0x141>(P[j]); E[j] += dpp_i32<0x141>(E[j]);    // row_half_mirror
+        P[j] *= dpp_f64<0x140>(P[j]); E[j] += dpp_i32<0x140>(E[j]);    // row_mirror
+        if (W == 64) {
+            P[j] *= __shfl_xor(P[j], 16); E[j] += __shfl_xor(E[j], 16);
+            P[j] *= __shfl_xor(P[j], 32); E[j] += __shfl_xor(E[j], 32);
+        }
+        int e2;
+        P[j] = __builtin_frexp(P[j], &e2);  // product of <= 64 mantissas >= 2^-64: one renormalisation suffices
+        E[j] += e2;
+    }
+}
+template <int W>
+__device__ __forceinline__ void accum_terms_n(int cnt, const double* __restrict__ coef, int D, int k, bool fast, const double* al,
+                                              const double* be, double* P, int* E) {
+    switch (cnt) {
+        case 1: accum_terms<1, W>(coef, D, k, fast, al, be, P, E); break;
+        case 2: accum_terms<2, W>(coef, D, k, fast, al, be, P, E); break;
+        case 3: accum_terms<3, W>(coef, D, k, fast, al, be, P, E); break;
+        default: accum_terms<4, W>(coef, D, k, fast, al, be, P, E); break;
+    }
+}
+template <int W>
+__device__ __forceinline__ void reduce_terms_n(int cnt, double* P, int* E) {
+    switch (cnt) {
+        case 1: reduce_terms<1, W>(P, E); break;
+        case 2: reduce_terms<2, W>(P, E); break;
+        case 3: reduce_terms<3, W>(P, E); break;
+        default: reduce_terms<4, W>(P, E); break;
     }
 }
 
+// ln pileup likelihood at np <= 4 points (alpha, beta) on all 64 lanes; lane j < np writes res[j]
 __device__ inline void eval_pileup(const double* __restrict__ coef, int D, bool fast, int np, const double* ptA, const double* ptB,
                                    double* res, int lane) {
-    int lg = np <= 1 ? 0 : np <= 2 ? 1 : np <= 4 ? 2 : np <= 8 ? 3 : 4;  // G = 2^lg point groups
-    int LP = 64 >> lg;
-    int j = lane >> (6 - lg);
-    int k = lane & (LP - 1);
-    int jj = j < np ? j : np - 1;
-    double P;
-    int E;
-    pileup_partial(coef, D, LP, k, ptA[jj], ptB[jj], fast, P, E);
-    group_product(P, E, lg);
-    double r = log(P) + (double)E * kLn2;
-    if (k == 0 && j < np) res[j] = r;
+    double al[4], be[4], P[4];
+    int E[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int jj = j < np ? j : np - 1;
+        al[j] = ptA[jj]; be[j] = ptB[jj]; P[j] = 1.0; E[j] = 0;
+    }
+    accum_terms_n<64>(np, coef, D, lane, fast, al, be, P, E);
+    reduce_terms_n<64>(np, P, E);
+    const double Pm = lane == 1 ? P[1] : lane == 2 ? P[2] : lane == 3 ? P[3] : P[0];
+    const int Em = lane == 1 ? E[1] : lane == 2 ? E[2] : lane == 3 ? E[3] : E[0];
+    if (lane < np) res[lane] = log(Pm) + (double)Em * kLn2;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -475,7 +526,6 @@ struct Ctx {
     double curJ;
     int curHyp;
     unsigned status;
-    unsigned long long n_eval, n_terms;
     PROF_DECL
 };
 
@@ -520,7 +570,7 @@ __device__ inline double sample_lik(Ctx& c, int s, double a, double b) {
     int n = w->cacheN[s];
     int lim = n < kCacheWays ? n : kCacheWays;
     for (int i = 0; i < lim; ++i)
-        if (c.cacheA[s * kCacheWays + i] == a && c.cacheB[s * kCacheWays + i] == b) return c.cacheV[s * kCacheWays + i];
+        if (c.cacheA[s * kCacheWays + i] == a && c.cacheB[s * kCacheWays + i] == b) return uni_d(c.cacheV[s * kCacheWays + i]);
     double al, be;
     alpha_beta(*c.plan, s, a, b, al, be);
     __syncthreads();
@@ -529,9 +579,8 @@ __device__ inline double sample_lik(Ctx& c, int s, double a, double b) {
     int off = w->soff[s], D = w->nkeep[s];
     eval_pileup(c.coef + 3 * off, D, (w->fastok >> s) & 1, 1, w->ptA, w->ptB, w->res, c.lane);
     __syncthreads();
-    double r = w->res[0];
-    c.n_eval += 1;
-    c.n_terms += (unsigned long long)D;
+    double r = uni_d(w->res[0]);
+    if (c.lane == 0) { w->work[0] += 1; w->work[1] += (unsigned long long)D; }
     int slot = n % kCacheWays;
     __syncthreads();
     if (c.lane == 0) {
@@ -546,6 +595,7 @@ __device__ inline double sample_lik(Ctx& c, int s, double a, double b) {
 
 // MAP ordering (oracle map_before): higher joint first; ties: lower hypothesis id, then smaller VAF tuple
 __device__ inline void map_consider(Ctx& c, double joint, int inner, double x) {
+    joint = uni_d(joint); x = uni_d(x); inner = UNI(inner);
     if (!(joint == joint)) return;
     bool better = joint > c.curJ;
     if (!better && joint == c.curJ && c.curHyp >= 0) {
@@ -583,17 +633,22 @@ __device__ inline bool group_may_contain(const DevPlan& p, int g, int s, double 
         if (spectrum_contains(p.grp_spec[i], p.vafs, v)) return true;
     return false;
 }
+// `alive` and s are wave-uniform (scalar loop over groups, scalar loads of the group spectra); v may differ per lane
 __device__ inline int alive_update(const Ctx& c, int alive, int s, double v) {
-    int m = alive;
+    int m = UNI(alive);
+    s = UNI(s);
+    int res = m;
     while (m) {
         int g = __builtin_ctz(m);
         m &= m - 1;
-        if (!group_may_contain(*c.plan, g, s, v)) alive &= ~(1 << g);
+        const bool may = group_may_contain(*c.plan, g, s, v);
+        res = may ? res : (res & ~(1 << g));
     }
-    return alive;
+    return res;
 }
 // VAFTree::contains (vaftree.rs:42-51,116-164) of group g for the current operands (sample `inner` at x)
 __device__ inline bool group_contains(Ctx& c, int g, int inner, double x, int excl = -1) {
+    g = UNI(g); inner = UNI(inner); x = uni_d(x);
     const DevPlan& p = *c.plan;
     WaveSt* w = c.w;
     int r0 = (g == 0) ? 0 : p.root_off[g - 1], r1 = (g == 0) ? 1 : p.root_off[g];
@@ -606,7 +661,7 @@ __device__ inline bool group_contains(Ctx& c, int g, int inner, double x, int ex
         sp = 1;
         while (sp > 0 && !result) {
             sp--;
-            int node = w->cs_node[sp], mask = w->cs_mask[sp];
+            int node = UNI(w->cs_node[sp]), mask = UNI(w->cs_mask[sp]);
             const DevNode& nd = p.nodes[node];
             bool contained;
             if (nd.kind == VLR_NODE_SAMPLE) {
@@ -637,10 +692,11 @@ __device__ inline bool group_contains(Ctx& c, int g, int inner, double x, int ex
 }
 // candidate for another group's slot; same ordering as map_consider
 __device__ inline void cross_consider(Ctx& c, int g, double joint, int inner, double x) {
+    joint = uni_d(joint); x = uni_d(x); inner = UNI(inner);
     if (!(joint == joint)) return;
     int slot = (c.hyp == 0) ? slot_clean(g) : slot_art(c, g);
-    double curJ = c.mapJ[slot];
-    int curHyp = c.mapHyp[slot];
+    double curJ = uni_d(c.mapJ[slot]);
+    int curHyp = UNI(c.mapHyp[slot]);
     bool better = curHyp < 0 || joint > curJ;
     if (!better && joint == curJ) {
         if (c.hyp != (curHyp & 15)) better = c.hyp < (curHyp & 15);
@@ -706,6 +762,7 @@ __device__ inline bool table_has(const double* tx, int n, double x, int lane) {
 
 // all MAP bookkeeping for one evaluated operand set
 __device__ inline void map_all(Ctx& c, double joint, int inner, double x, bool own_path_contained, int alive) {
+    alive = UNI(alive);
     if (own_path_contained) map_consider(c, joint, inner, x);
     else if (group_contains(c, c.group, inner, x)) map_consider(c, joint, inner, x);  // contained via another path
     while (alive) {
@@ -742,6 +799,7 @@ __device__ inline double leaf_joint(Ctx& c) {
         }
         joint = prior_of(c, -1, 0.0) + lik;
     }
+    joint = uni_d(joint);
     if (joint != joint) c.status |= VLR_LOCUS_NAN;
     if (c.replay) afd_consider(c, joint, -1, 0.0);
     else map_all(c, joint, -1, 0.0, c.contained != 0, c.alive);
@@ -762,13 +820,15 @@ __device__ inline bool range_advance(Ctx& c, RangeSt& r, const double* tx, const
     } else {  // RP_ROUND: argmax over {left, middle1, middle2, right} (61-94); lowest index wins ties.
         // The round's points were appended as (mid, middle1, middle2), so their values are the last two
         // table entries; left/right values are carried along (the reference looks them up in its HashMap).
-        double xs[4] = {r.L, r.pend[1], r.pend[2], r.R};
-        double vs[4] = {r.vL, tv[r.tn - 2], tv[r.tn - 1], r.vR};
+        const double x0 = uni_d(r.L), x1 = uni_d(r.pend[1]), x2 = uni_d(r.pend[2]), x3 = uni_d(r.R);
+        const double v0 = uni_d(r.vL), v1 = uni_d(tv[r.tn - 2]), v2 = uni_d(tv[r.tn - 1]), v3 = uni_d(r.vR);
         int k = 0;
-        for (int i = 1; i < 4; ++i)
-            if (vs[i] > vs[k]) k = i;
-        double nl = (k > 0) ? xs[k - 1] : xs[k], vl = (k > 0) ? vs[k - 1] : vs[k];
-        double nr = (k < 3) ? xs[k + 1] : xs[k], vr = (k < 3) ? vs[k + 1] : vs[k];
+        double vb = v0;
+        if (v1 > vb) { k = 1; vb = v1; }
+        if (v2 > vb) { k = 2; vb = v2; }
+        if (v3 > vb) { k = 3; }
+        const double nl = (k <= 1) ? x0 : (k == 2) ? x1 : x2, vl = (k <= 1) ? v0 : (k == 2) ? v1 : v2;
+        const double nr = (k == 0) ? x1 : (k == 1) ? x2 : x3, vr = (k == 0) ? v1 : (k == 1) ? v2 : v3;
         r.L = nl; r.vL = vl;
         r.R = nr; r.vR = vr;
     }
@@ -828,10 +888,10 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
     const DevPlan& p = *c.plan;
     WaveSt* w = c.w;
     const int lane = c.lane;
-    const int inner = rl.sample;
-    const double lo = rl.lo, hi = rl.hi, res = rl.res;
-    const RangeV orig{rl.ostart, rl.oend, rl.olex, rl.orex};
-    const int simpson_n = rl.simpson_n;
+    const int inner = UNI(rl.sample);
+    const double lo = uni_d(rl.lo), hi = uni_d(rl.hi), res = uni_d(rl.res);
+    const RangeV orig{uni_d(rl.ostart), uni_d(rl.oend), UNI(rl.olex), UNI(rl.orex)};
+    const int simpson_n = UNI(rl.simpson_n);
 
     double fixed = 0.0;
     int dep = 0, pidx = 0;
@@ -841,10 +901,12 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
         else fixed += sample_lik(c, s, w->ops_vaf[s], by >= 0 ? w->ops_vaf[by] : 0.0);
         if (s != inner) pidx += prior_class(p, s, w->ops_vaf[s]) * p.class_stride[s];
     }
+    fixed = uni_d(fixed);
+    pidx = UNI(pidx);
     const double* ptab = p.prior_table + c.vt * p.table_size;
     const int istride = p.class_stride[inner];
     const int ncls = p.n_class[inner];
-    const double pr0 = ptab[pidx], pr1 = ncls > 1 ? ptab[pidx + istride] : VLR_NEG_INF, pr2 = ncls > 2 ? ptab[pidx + 2 * istride] : VLR_NEG_INF;
+    const double pr0 = uni_d(ptab[pidx]), pr1 = ncls > 1 ? uni_d(ptab[pidx + istride]) : VLR_NEG_INF, pr2 = ncls > 2 ? uni_d(ptab[pidx + 2 * istride]) : VLR_NEG_INF;
 
     // pending points and their joint values live in two tiny LDS arrays (same-wave LDS ops execute in order;
     // wave_barrier() only stops the compiler from reordering them)
@@ -867,51 +929,63 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
     bool have_first = false, have_mid = false, failed = false;
     double bestJ = VLR_NEG_INF, bestX = 0.0;
     bool haveBest = false;
-    unsigned long long evals = 0, terms = 0;
+    int ndep = 0;
+    unsigned dep_terms = 0;
 
     for (;;) {
         if (tn + np > c.cap) { c.status |= VLR_LOCUS_TABLE_FULL; failed = true; break; }
-        const int lg = np <= 1 ? 0 : np <= 2 ? 1 : np <= 4 ? 2 : np <= 8 ? 3 : 4;
-        const int LP = 64 >> lg;
-        const int j = lane >> (6 - lg);
-        const int k = lane & (LP - 1);
-        const int jj = j < np ? j : np - 1;
-        const double x = pend[jj];
-
-        double lik = fixed;
-        int dm = dep;
-        while (dm) {
-            int s = __builtin_ctz(dm);
-            dm &= dm - 1;
-            int by = p.by[s];
-            double a = (s == inner) ? x : w->ops_vaf[s];
-            double b = by >= 0 ? ((by == inner) ? x : w->ops_vaf[by]) : 0.0;
-            double al, be;
-            alpha_beta(p, s, a, b, al, be);
-            const int off = w->soff[s], D = w->nkeep[s];
-            double P;
-            int E;
-            pileup_partial(c.coef + 3 * off, D, LP, k, al, be, (w->fastok >> s) & 1, P, E);
-            group_product(P, E, lg);
-            lik += log(P) + (double)E * kLn2;
-            evals += (unsigned long long)np;
-            terms += (unsigned long long)np * (unsigned long long)D;
+        // lane j < np owns point j; every lane multiplies its observation slice (terms lane, lane+64, ...) for up to
+        // four points per pass
+        const int jown = lane < np ? lane : np - 1;
+        const double x = pend[jown];
+        double Psel = 1.0;
+        int Esel = 0;
+        for (int p0 = 0; p0 < np; p0 += 4) {
+            const int cnt = (np - p0) < 4 ? (np - p0) : 4;
+            double xs[4], P[4];
+            int E[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { xs[j] = pend[(p0 + j) < np ? (p0 + j) : np - 1]; P[j] = 1.0; E[j] = 0; }
+            int dm = dep;
+            while (dm) {
+                int s = __builtin_ctz(dm);
+                dm &= dm - 1;
+                int by = p.by[s];
+                double al[4], be[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    double a = (s == inner) ? xs[j] : w->ops_vaf[s];
+                    double b = by >= 0 ? ((by == inner) ? xs[j] : w->ops_vaf[by]) : 0.0;
+                    alpha_beta(p, s, a, b, al[j], be[j]);
+                }
+                const int off = w->soff[s], D = w->nkeep[s];
+                accum_terms_n<64>(cnt, c.coef + 3 * off, D, lane, (w->fastok >> s) & 1, al, be, P, E);
+            }
+            reduce_terms_n<64>(cnt, P, E);
+            const int jr = lane - p0;
+            const double Pm = jr == 1 ? P[1] : jr == 2 ? P[2] : jr == 3 ? P[3] : P[0];
+            const int Em = jr == 1 ? E[1] : jr == 2 ? E[2] : jr == 3 ? E[3] : E[0];
+            const bool mine = jr >= 0 && jr < 4;
+            Psel = mine ? Pm : Psel;
+            Esel = mine ? Em : Esel;
         }
+        const double lik = fixed + (log(Psel) + (double)Esel * kLn2);
         double joint;
         if (c.nlfc > 0 && !lfcs_ok(c, inner, x)) joint = VLR_NEG_INF;
         else {
             int cls = prior_class(p, inner, x);
             joint = (cls == 0 ? pr0 : cls == 1 ? pr1 : cls == 2 ? pr2 : ptab[pidx + cls * istride]) + lik;
         }
-        if (__ballot(joint != joint)) c.status |= VLR_LOCUS_NAN;
-        if (k == 0 && j < np) { tx[tn + j] = x; tv[tn + j] = joint; }
+        const bool owner = lane < np;
+        if (__ballot(owner && joint != joint)) c.status |= VLR_LOCUS_NAN;
+        if (owner) { tx[tn + lane] = x; tv[tn + lane] = joint; }
 
         // MAP candidates (calling.rs:851-864)
         const bool own_in = c.contained && range_contains(orig, x);
         const int al2 = c.alive ? alive_update(c, c.alive, inner, x) : 0;
-        const bool slow = __ballot(j < np && (!own_in || al2 != 0)) != 0ull;
+        const bool slow = __ballot(owner && (!own_in || al2 != 0)) != 0ull;
         __builtin_amdgcn_wave_barrier();
-        if (k == 0 && j < np) vals[j] = joint;
+        if (owner) vals[lane] = joint;
         __builtin_amdgcn_wave_barrier();
         if (c.replay) {
             for (int i = 0; i < np; ++i) {
@@ -920,7 +994,7 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
             }
         } else if (!slow) {
             for (int i = 0; i < np; ++i) {
-                double v = vals[i], xi = pend[i];
+                double v = uni_d(vals[i]), xi = uni_d(pend[i]);
                 if (v == v && (!haveBest || v > bestJ || (v == bestJ && xi < bestX))) { bestJ = v; bestX = xi; haveBest = true; }
             }
         } else {
@@ -934,10 +1008,10 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
         // ---- advance the chain (utils/adaptive_integration.rs:54-131)
         if (phase == RP_SIMPSON || phase == RP_TAIL) break;
         if (phase == RP_INIT) {
-            L = lo; R = hi; vL = vals[0]; vR = vals[1];
+            L = lo; R = hi; vL = uni_d(vals[0]); vR = uni_d(vals[1]);
         } else {  // argmax over {left, middle1, middle2, right}; lowest index wins ties
-            double xs0 = L, xs1 = pend[1], xs2 = pend[2], xs3 = R;
-            double v0 = vL, v1 = vals[1], v2 = vals[2], v3 = vR;
+            double xs0 = L, xs1 = uni_d(pend[1]), xs2 = uni_d(pend[2]), xs3 = R;
+            double v0 = vL, v1 = uni_d(vals[1]), v2 = uni_d(vals[2]), v3 = vR;
             __builtin_amdgcn_wave_barrier();
             int kk = 0;
             double vb = v0;
@@ -951,7 +1025,7 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
             (void)xs0; (void)xs3;
         }
         if ((((R - L) >= res) && L < R) || !have_mid) {
-            mid = (R + L) / 2.0;
+            mid = uni_d((R + L) / 2.0);
             have_mid = true;
             if (!have_first) { first_mid = mid; have_first = true; }
             double m1 = (mid + L) / 2.0, m2 = (R + mid) / 2.0;
@@ -975,8 +1049,9 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
         }
         __builtin_amdgcn_wave_barrier();
     }
-    c.n_eval += evals;
-    c.n_terms += terms;
+    for (int s = 0; s < c.S; ++s)
+        if ((dep >> s) & 1) { ndep++; dep_terms += (unsigned)w->nkeep[s]; }
+    if (lane == 0) { w->work[0] += (unsigned long long)(tn * ndep); w->work[1] += (unsigned long long)tn * dep_terms; }
     PROF_ADD(c, 4);  // single-chain rounds
     if (haveBest) map_consider(c, bestJ, inner, bestX);
     if (failed) return __builtin_nan("");
@@ -999,15 +1074,6 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
 // run concurrently, one per 16-lane DPP row.  Every "uniform" control instruction of the adaptive integrator now
 // serves four chains; the row's 16 lanes are split into (point, slice) groups for the pileup products and the
 // partial products are combined with in-row DPP permutes (a 16-lane row is exactly one DPP row).
-__device__ __forceinline__ void row_product(double& P, int& E, int lgp) {
-    if (lgp >= 1) { P *= dpp_f64<0xB1>(P); E += dpp_i32<0xB1>(E); }
-    if (lgp >= 2) { P *= dpp_f64<0x4E>(P); E += dpp_i32<0x4E>(E); }
-    if (lgp >= 3) { P *= dpp_f64<0x141>(P); E += dpp_i32<0x141>(E); }
-    if (lgp >= 4) { P *= dpp_f64<0x140>(P); E += dpp_i32<0x140>(E); }
-    int e2;
-    P = __builtin_frexp(P, &e2);
-    E += e2;
-}
 __device__ __forceinline__ double row_max(double v) {
     v = fmax(v, dpp_f64<0xB1>(v)); v = fmax(v, dpp_f64<0x4E>(v)); v = fmax(v, dpp_f64<0x141>(v)); v = fmax(v, dpp_f64<0x140>(v));
     return v;
@@ -1054,6 +1120,9 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
     const double* d0_coef = c.coef + 3 * w->soff[d0];
     const int d0_D = w->nkeep[d0];
     const bool d0_fast = (w->fastok >> d0) & 1;
+    unsigned dep_terms = 0;  // observation terms per point
+    for (int s = 0; s < c.S; ++s)
+        if ((dep >> s) & 1) dep_terms += (unsigned)w->nkeep[s];
     const double* ptab = p.prior_table + c.vt * p.table_size;
     const int istride = p.class_stride[inner];
     // prior values of the first classes of the integrated sample, loaded once (a global load per round would sit
@@ -1086,49 +1155,64 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
     }
     double L = lo, R = hi, vL = VLR_NEG_INF, vR = VLR_NEG_INF, mid = lo, first_mid = lo;
     bool have_first = false, have_mid = false, failed = false, sawnan = false;
-    unsigned evals = 0, terms = 0;
     __builtin_amdgcn_wave_barrier();
 
     while (__ballot(!done)) {
         const bool act = !done;
         if (act && tn + np > cap) { failed = true; done = true; }
         const bool go = act && !failed;
-        const int lgp = np <= 1 ? 4 : np <= 2 ? 3 : np <= 4 ? 2 : np <= 8 ? 1 : 0;  // lanes per point = 2^lgp
-        const int LPr = 1 << lgp;
-        const int j = rl >> lgp, k = rl & (LPr - 1);
-        const int jj = j < np ? j : np - 1;
-        const double x = pend[jj];
-        double lik = fixed;
-        {   // first dependent sample: everything but x hoisted out of the rounds
-            double a = d0_is_inner ? x : d0_a;
-            double b = d0_by_inner ? x : d0_b;
-            double al, be;
-            if (d0_cont) { al = d0_rho * a + d0_irho * b; be = d0_rho * (a == 1.0 ? 1.0 : 0.0) + d0_irho * (b == 1.0 ? 1.0 : 0.0); }
-            else { al = a; be = (a == 1.0) ? 1.0 : 0.0; }
-            double P;
-            int E;
-            pileup_partial(d0_coef, go ? d0_D : 0, LPr, k, al, be, d0_fast, P, E);
-            row_product(P, E, lgp);
-            lik += log(P) + (double)E * kLn2;
-            if (go && rl == 0) { evals += (unsigned)np; terms += (unsigned)np * (unsigned)d0_D; }
+        // row lane j < np owns point j of its chain; every lane multiplies its observation slice (terms rl, rl+16,
+        // ...) for up to four points per pass.  Rows in different phases have different np: the pass loop runs to
+        // the largest, rows without points left compute on repeated points and discard the result.
+        PROF_ADD(c, 15);  // round: advance + loop control (previous iteration)
+        const int npg = go ? np : 0;
+        const int npmax = max(max(__builtin_amdgcn_readlane(npg, 0), __builtin_amdgcn_readlane(npg, 16)),
+                              max(__builtin_amdgcn_readlane(npg, 32), __builtin_amdgcn_readlane(npg, 48)));
+        const double x = pend[rl < np ? rl : np - 1];
+        double Psel = 1.0;
+        int Esel = 0;
+        for (int p0 = 0; p0 < npmax; p0 += 4) {
+            const int cnt = (npmax - p0) < 4 ? (npmax - p0) : 4;
+            double xs[4], P[4];
+            int E[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { xs[j] = pend[(p0 + j) < np ? (p0 + j) : np - 1]; P[j] = 1.0; E[j] = 0; }
+            {   // first dependent sample: everything but x hoisted out of the rounds
+                double al[4], be[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double a = d0_is_inner ? xs[j] : d0_a;
+                    const double b = d0_by_inner ? xs[j] : d0_b;
+                    if (d0_cont) { al[j] = d0_rho * a + d0_irho * b; be[j] = d0_rho * (a == 1.0 ? 1.0 : 0.0) + d0_irho * (b == 1.0 ? 1.0 : 0.0); }
+                    else { al[j] = a; be[j] = (a == 1.0) ? 1.0 : 0.0; }
+                }
+                accum_terms_n<16>(cnt, d0_coef, d0_D, rl, d0_fast, al, be, P, E);
+            }
+            int dm = dep_rest;
+            while (dm) {
+                int s = __builtin_ctz(dm);
+                dm &= dm - 1;
+                int by = p.by[s];
+                double al[4], be[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    double a = (s == inner) ? xs[j] : tvr[s];
+                    double b = by >= 0 ? ((by == inner) ? xs[j] : tvr[by]) : 0.0;
+                    alpha_beta(p, s, a, b, al[j], be[j]);
+                }
+                accum_terms_n<16>(cnt, c.coef + 3 * w->soff[s], w->nkeep[s], rl, (w->fastok >> s) & 1, al, be, P, E);
+            }
+            PROF_ADD(c, 12);  // round: term products
+            reduce_terms_n<16>(cnt, P, E);
+            const int jr = rl - p0;
+            const double Pm = jr == 1 ? P[1] : jr == 2 ? P[2] : jr == 3 ? P[3] : P[0];
+            const int Em = jr == 1 ? E[1] : jr == 2 ? E[2] : jr == 3 ? E[3] : E[0];
+            const bool mine = jr >= 0 && jr < 4;
+            Psel = mine ? Pm : Psel;
+            Esel = mine ? Em : Esel;
         }
-        int dm = dep_rest;
-        while (dm) {
-            int s = __builtin_ctz(dm);
-            dm &= dm - 1;
-            int by = p.by[s];
-            double a = (s == inner) ? x : tvr[s];
-            double b = by >= 0 ? ((by == inner) ? x : tvr[by]) : 0.0;
-            double al, be;
-            alpha_beta(p, s, a, b, al, be);
-            const int off = w->soff[s], D = go ? w->nkeep[s] : 0;
-            double P;
-            int E;
-            pileup_partial(c.coef + 3 * off, D, LPr, k, al, be, (w->fastok >> s) & 1, P, E);
-            row_product(P, E, lgp);
-            lik += log(P) + (double)E * kLn2;
-            if (go && rl == 0) { evals += (unsigned)np; terms += (unsigned)np * (unsigned)w->nkeep[s]; }
-        }
+        PROF_ADD(c, 13);  // round: reduction
+        const double lik = fixed + (log(Psel) + (double)Esel * kLn2);
         double joint;
         if (c.nlfc > 0 && !lfcs_ok(c, inner, x)) joint = VLR_NEG_INF;
         else {
@@ -1136,8 +1220,10 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
             double pv = cls == 0 ? pr0 : cls == 1 ? pr1 : cls == 2 ? pr2 : ptab[pidx + cls * istride];
             joint = pv + lik;
         }
-        if (go && j < np && joint != joint) sawnan = true;
-        if (go && k == 0 && j < np) { tx[tn + j] = x; tv[tn + j] = joint; vals[j] = joint; }
+        const bool owner = go && rl < np;
+        if (owner && joint != joint) sawnan = true;
+        if (owner) { tx[tn + rl] = x; tv[tn + rl] = joint; vals[rl] = joint; }
+        PROF_ADD(c, 14);  // round: log + prior + store
         __builtin_amdgcn_wave_barrier();
         if (go) {
             tn += np;
@@ -1185,57 +1271,72 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
         }
         __builtin_amdgcn_wave_barrier();
     }
-    PROF_ADD(c, 7);  // batch rounds
+    PROF_ADD(c, 15);
     if (__ballot(failed)) c.status |= VLR_LOCUS_TABLE_FULL;
     if (__ballot(sawnan)) c.status |= VLR_LOCUS_NAN;
-    {   // work counters: row leaders hold their row's counts
-        unsigned e2 = evals, t2 = terms;
-        e2 += __shfl_xor(e2, 16); e2 += __shfl_xor(e2, 32);
-        t2 += __shfl_xor(t2, 16); t2 += __shfl_xor(t2, 32);
-        c.n_eval += (unsigned long long)__shfl(e2, 0);
-        c.n_terms += (unsigned long long)__shfl(t2, 0);
+    if (rowon && rl == 0) {  // work counters
+        atomicAdd(&w->work[0], (unsigned long long)tn);
+        atomicAdd(&w->work[1], (unsigned long long)tn * dep_terms);
     }
     __builtin_amdgcn_wave_barrier();
 
-    // ---- epilogue, row-parallel: MAP candidate of the chain and the integral over the visited points
+    // ---- epilogue, row-parallel: MAP candidate of the chain and the integral over the visited points.
+    // Trapezoid over the sorted grid (LogProb::ln_trapezoidal_integrate_grid_exp, utils/adaptive_integration.rs:133-140)
+    // in the linear domain relative to the row maximum M, regrouped per grid point:
+    //   sum_seg (e_k + e_{k+1}) (x_{k+1} - x_k)/2  =  sum_k e_k (x_{k+1} - x_{k-1})/2   (one-sided at the ends),
+    // so every entry only needs the x of its predecessor and successor in (x, index) order — no sort, no gather.
+    // Duplicate x (HashMap key collisions in the reference) are neighbours at distance zero.  All predicates are
+    // evaluated branch-free (bitwise), the table scan is uniform.
     const int n = (rowon && !failed) ? tn : 0;
+    const int nmax = max(max(__builtin_amdgcn_readlane(n, 0), __builtin_amdgcn_readlane(n, 16)),
+                         max(__builtin_amdgcn_readlane(n, 32), __builtin_amdgcn_readlane(n, 48)));
+    const int TT = (nmax + 15) >> 4;  // entries per lane (uniform), <= 4 because the row path requires cap <= 64
     double bJ = VLR_NEG_INF, bX = 0.0;
     int bHave = 0;
     bool anynan = false;
     double rint_ = VLR_NEG_INF;
     {
-        // this lane's (up to) four entries; successor of each in (x, index) order = next grid point of the
-        // sorted, de-duplicated table.  One pass over the table serves all four (one LDS read per q).
-        double xi[4], vi[4], sx[4];
-        int sj[4];
+        double xi[4], vi[4], px[4], sx[4];
+        int dlo[4], dhi[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            int i = rl + 16 * t;
-            bool on = i < n;
-            xi[t] = on ? tx[i] : __builtin_huge_val();
-            vi[t] = on ? tv[i] : VLR_NEG_INF;
-            sx[t] = __builtin_huge_val();
-            sj[t] = -1;
-            if (on && contained && range_contains(orig, xi[t]) && vi[t] == vi[t] && (!bHave || vi[t] > bJ || (vi[t] == bJ && xi[t] < bX))) {
-                bJ = vi[t]; bX = xi[t]; bHave = 1;
+            xi[t] = __builtin_huge_val(); vi[t] = VLR_NEG_INF;
+            px[t] = -__builtin_huge_val(); sx[t] = __builtin_huge_val();
+            dlo[t] = 0; dhi[t] = 0;
+            if (t < TT) {
+                const int i = rl + 16 * t;
+                const bool on = i < n;
+                const int ic = on ? i : 0;
+                const double xr = tx[ic], vr = tv[ic];
+                xi[t] = on ? xr : __builtin_huge_val();
+                vi[t] = on ? vr : VLR_NEG_INF;
+                const bool inlo = (orig.start < xi[t]) | ((orig.lex == 0) & (orig.start == xi[t]));
+                const bool inhi = (orig.end > xi[t]) | ((orig.rex == 0) & (orig.end == xi[t]));
+                const bool cand = on & (contained != 0) & inlo & inhi & (vi[t] == vi[t]);
+                const bool take = cand & ((bHave == 0) | (vi[t] > bJ) | ((vi[t] == bJ) & (xi[t] < bX)));
+                bJ = take ? vi[t] : bJ; bX = take ? xi[t] : bX; bHave = take ? 1 : bHave;
+                anynan = anynan | (vi[t] != vi[t]);
             }
         }
         if (phase != RP_SIMPSON) {
-            const int nmax = __builtin_amdgcn_readfirstlane(max(max(__shfl(n, 0), __shfl(n, 16)), max(__shfl(n, 32), __shfl(n, 48))));
-            for (int q = 0; q < nmax; ++q) {
-                double xq = (q < n) ? tx[q] : -__builtin_huge_val();
+            for (int q = 0; q < nmax; q += 2) {
+                const double r0 = tx[q], r1 = tx[q + 1 < cap ? q + 1 : q];
+                const double xq0 = (q < n) ? r0 : __builtin_nan("");
+                const double xq1 = (q + 1 < n) ? r1 : __builtin_nan("");
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    int i = rl + 16 * t;
-                    bool gt = (xq > xi[t]) || (xq == xi[t] && q > i);
-                    bool better = gt && (xq < sx[t] || (xq == sx[t] && q < sj[t]) || sj[t] < 0);
-                    if (better && q < n && i < n) { sx[t] = xq; sj[t] = q; }
+                    if (t < TT) {
+                        const int i = rl + 16 * t;
+                        const bool lt0 = xq0 < xi[t], gt0 = xq0 > xi[t], eq0 = xq0 == xi[t];
+                        const bool lt1 = xq1 < xi[t], gt1 = xq1 > xi[t], eq1 = xq1 == xi[t];
+                        px[t] = fmax(px[t], fmax(lt0 ? xq0 : -__builtin_huge_val(), lt1 ? xq1 : -__builtin_huge_val()));
+                        sx[t] = fmin(sx[t], fmin(gt0 ? xq0 : __builtin_huge_val(), gt1 ? xq1 : __builtin_huge_val()));
+                        dlo[t] |= (int)(eq0 & (q < i)) | (int)(eq1 & (q + 1 < i));
+                        dhi[t] |= (int)(eq0 & (q > i)) | (int)(eq1 & (q + 1 > i));
+                    }
                 }
             }
         }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-            if (vi[t] != vi[t]) anynan = true;
         // ---- row arg-best of (bJ desc, bX asc) for the MAP candidate
         for (int st = 0; st < 4; ++st) {
             double oJ, oX;
@@ -1244,36 +1345,31 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
             else if (st == 1) { oJ = dpp_f64<0x4E>(bJ); oX = dpp_f64<0x4E>(bX); oH = dpp_i32<0x4E>(bHave); }
             else if (st == 2) { oJ = dpp_f64<0x141>(bJ); oX = dpp_f64<0x141>(bX); oH = dpp_i32<0x141>(bHave); }
             else { oJ = dpp_f64<0x140>(bJ); oX = dpp_f64<0x140>(bX); oH = dpp_i32<0x140>(bHave); }
-            bool take = oH && (!bHave || oJ > bJ || (oJ == bJ && oX < bX));
-            if (take) { bJ = oJ; bX = oX; bHave = 1; }
+            const bool take = (oH != 0) & ((bHave == 0) | (oJ > bJ) | ((oJ == bJ) & (oX < bX)));
+            bJ = take ? oJ : bJ; bX = take ? oX : bX; bHave = take ? 1 : bHave;
         }
-        // ---- integral in the linear domain relative to the row maximum M:
-        //   trapezoid  ln sum_seg (e^{v_i} + e^{v_succ}) (x_succ - x_i)/2 = M + ln sum_seg (e_i + e_succ) w_seg / 2
-        //   (== LogProb::ln_trapezoidal_integrate_grid_exp, utils/adaptive_integration.rs:133-140);
-        //   Simpson: sum of weighted e_i.  One exp per entry, one log per chain.
         double m4 = VLR_NEG_INF;
 #pragma unroll
         for (int t = 0; t < 4; ++t) m4 = fmax(m4, (vi[t] == vi[t]) ? vi[t] : VLR_NEG_INF);
         const double M = row_max(m4);
-        double ev[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) ev[t] = (vi[t] == VLR_NEG_INF || M == VLR_NEG_INF || vi[t] != vi[t]) ? 0.0 : exp(vi[t] - M);
         double ssum = 0.0;
-        if (phase == RP_SIMPSON) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                int i = rl + 16 * t;
-                if (i < n) ssum += ev[t] * ((i == 0 || i == n - 1) ? 1.0 : (double)(2 + (i % 2) * 2));
-            }
-        } else {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                if (sj[t] >= 0) {
-                    double vs = tv[sj[t]];
-                    double es = (vs == VLR_NEG_INF || vs != vs) ? 0.0 : exp(vs - M);
-                    if (vs != vs) anynan = true;
-                    ssum += (ev[t] + es) * ((sx[t] - xi[t]) / 2.0);
+        for (int t = 0; t < 4; ++t) {
+            if (t < TT) {
+                const int i = rl + 16 * t;
+                const bool on = i < n;
+                const bool zero = (vi[t] == VLR_NEG_INF) | (M == VLR_NEG_INF) | (vi[t] != vi[t]);
+                const double ev = zero ? 0.0 : exp(vi[t] - M);
+                double wgt;
+                if (phase == RP_SIMPSON) wgt = (i == 0 || i == n - 1) ? 1.0 : (double)(2 + (i % 2) * 2);
+                else {
+                    const double pred = dlo[t] ? xi[t] : px[t], succ = dhi[t] ? xi[t] : sx[t];
+                    const double lo2 = (pred == -__builtin_huge_val()) ? xi[t] : pred;
+                    const double hi2 = (succ == __builtin_huge_val()) ? xi[t] : succ;
+                    wgt = (hi2 - lo2) / 2.0;
                 }
+                ssum += on ? ev * wgt : 0.0;
+            }
         }
         ssum = row_sum(ssum);
         rint_ = (M == VLR_NEG_INF) ? VLR_NEG_INF : M + log(ssum);
@@ -1289,6 +1385,27 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
     __builtin_amdgcn_wave_barrier();
     __syncthreads();
     PROF_ADD(c, 8);  // batch epilogue (MAP scan + integrate)
+}
+
+// MAP candidates of one finished row-parallel chain for OTHER groups / containment via another path (rare): the lanes
+// test all visited points at once; only points that need the full contains walk are visited one by one, in table order
+__device__ inline void scan_chain_candidates(Ctx& c, const double* rx, const double* rvv, int nq, const RangeV& io, int contained, int alive,
+                                             int s_in) {
+    for (int q0 = 0; q0 < nq; q0 += 64) {
+        const int q = q0 + c.lane;
+        const bool on = q < nq;
+        const double xq = rx[on ? q : 0];
+        const bool own = (contained != 0) & range_contains(io, xq);
+        const int al = alive ? alive_update(c, alive, s_in, xq) : 0;
+        unsigned long long need = __ballot(on & (!own | (al != 0)));
+        while (need) {
+            const int qq = q0 + __builtin_ctzll(need);
+            need &= need - 1;
+            const double xqq = uni_d(rx[qq]);
+            const int alq = alive ? UNI(alive_update(c, alive, s_in, xqq)) : 0;
+            map_all(c, uni_d(rvv[qq]), s_in, xqq, false, alq);
+        }
+    }
 }
 
 // LikelihoodOperands::lfc_bounds (modes/generic.rs:148-174)
@@ -1347,9 +1464,9 @@ __device__ __forceinline__ void batch_outer_points(Ctx& c, const Frame& f, Range
     const RangeV vr{ch.vafs.start, ch.vafs.end, ch.vafs.lex, ch.vafs.rex};
     const bool dead = clear_ref && vr.start > 0.0;  // generic.rs:342-347
     const double res = p.resolution[s_in];
-    const double lo = observable_min(vr, n_obs), hi = observable_max(vr, n_obs);
+    const double lo = uni_d(observable_min(vr, n_obs)), hi = uni_d(observable_max(vr, n_obs));
     const int simpson = ((hi - lo) < res) ? 3 : (n_obs < 5 ? 11 : 0);
-    const RangeV oorig{r.ostart, r.oend, r.olex, r.orex};
+    const RangeV oorig{uni_d(r.ostart), uni_d(r.oend), UNI(r.olex), UNI(r.orex)};
     const int np = UNI(r.npend);
     // samples whose likelihood is fixed during an inner chain: constant over the outer points, or varying with them
     double fixed_const = 0.0;
@@ -1360,6 +1477,7 @@ __device__ __forceinline__ void batch_outer_points(Ctx& c, const Frame& f, Range
         if (s == s_out || by == s_out) vary |= 1 << s;
         else fixed_const += sample_lik(c, s, w->ops_vaf[s], by >= 0 ? w->ops_vaf[by] : 0.0);
     }
+    fixed_const = uni_d(fixed_const);
     for (int c0 = 0; c0 < np; c0 += kRows) {
         const int nt = (np - c0) < kRows ? (np - c0) : kRows;
         __syncthreads();
@@ -1369,8 +1487,8 @@ __device__ __forceinline__ void batch_outer_points(Ctx& c, const Frame& f, Range
             T.lo = lo; T.hi = hi; T.res = res;
             T.ostart = ch.vafs.start; T.oend = ch.vafs.end; T.olex = ch.vafs.lex; T.orex = ch.vafs.rex;
             T.simpson_n = simpson;
-            T.contained = f.sv_contained && range_contains(oorig, x);
-            T.alive = alive_update(c, f.sv_alive, s_out, x);
+            T.contained = UNI(f.sv_contained) && range_contains(oorig, x);
+            T.alive = alive_update(c, UNI(f.sv_alive), s_out, x);
             int pidx = 0;
             for (int s = 0; s < S; ++s) {
                 double v = (s == s_out) ? x : w->ops_vaf[s];
@@ -1400,8 +1518,7 @@ __device__ __forceinline__ void batch_outer_points(Ctx& c, const Frame& f, Range
             eval_pileup(c.coef + 3 * off, D, (w->fastok >> s) & 1, nt, w->ptA, w->ptB, w->res, lane);
             __syncthreads();
             if (lane < nt) w->task[lane].fixed += w->res[lane];
-            c.n_eval += (unsigned long long)nt;
-            c.n_terms += (unsigned long long)nt * (unsigned long long)D;
+            if (lane == 0) { w->work[0] += (unsigned long long)nt; w->work[1] += (unsigned long long)nt * (unsigned long long)D; }
             __syncthreads();
         }
         if (!dead) run_chain_batch(c, nt, s_in);
@@ -1420,15 +1537,8 @@ __device__ __forceinline__ void batch_outer_points(Ctx& c, const Frame& f, Range
             }
             if (UNI(T.haveBest)) map_consider(c, uni_d(T.bestJ), s_in, uni_d(T.bestX));
             if (UNI(T.alive) != 0 || !UNI(T.contained)) {  // rare: candidates for other groups / containment via another path
-                const RangeV io{T.ostart, T.oend, T.olex, T.orex};
-                const double* rx = c.rowX + i * c.cap;
-                const double* rvv = c.rowV + i * c.cap;
-                for (int q = 0; q < T.n; ++q) {
-                    double xq = rx[q];
-                    bool own = T.contained && range_contains(io, xq);
-                    int al = T.alive ? alive_update(c, T.alive, s_in, xq) : 0;
-                    if (!own || al) map_all(c, rvv[q], s_in, xq, false, al);
-                }
+                const RangeV io{uni_d(T.ostart), uni_d(T.oend), UNI(T.olex), UNI(T.orex)};
+                scan_chain_candidates(c, c.rowX + i * c.cap, c.rowV + i * c.cap, UNI(T.n), io, UNI(T.contained), UNI(T.alive), s_in);
             }
         }
     }
@@ -1490,15 +1600,8 @@ __device__ __forceinline__ void flush_deferred(Ctx& c, double* evM, double* evS,
         else {
             if (UNI(T.haveBest)) map_consider(c, uni_d(T.bestJ), s_in, uni_d(T.bestX));
             if (c.alive != 0 || !c.contained) {
-                const RangeV io{T.ostart, T.oend, T.olex, T.orex};
-                const double* rx = c.rowX + i * c.cap;
-                const double* rvv = c.rowV + i * c.cap;
-                for (int q = 0; q < nq; ++q) {
-                    double xq = uni_d(rx[q]);
-                    bool own = c.contained && range_contains(io, xq);
-                    int al = c.alive ? alive_update(c, c.alive, s_in, xq) : 0;
-                    if (!own || al) map_all(c, uni_d(rvv[q]), s_in, xq, false, al);
-                }
+                const RangeV io{uni_d(T.ostart), uni_d(T.oend), UNI(T.olex), UNI(T.orex)};
+                scan_chain_candidates(c, c.rowX + i * c.cap, c.rowV + i * c.cap, nq, io, c.contained, c.alive, s_in);
             }
         }
         double M = uni_d(evM[u]), Sx = uni_d(evS[u]);
@@ -1606,8 +1709,8 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                         sp++;
                         c.present |= (1 << s);
                         c.disc |= (1 << s);
-                        c.contained = f.sv_contained && spectrum_contains(nd.vafs, p.vafs, w->ops_vaf[s]);
-                        c.alive = alive_update(c, f.sv_alive, s, w->ops_vaf[s]);
+                        c.contained = UNI(f.sv_contained) && spectrum_contains(nd.vafs, p.vafs, w->ops_vaf[s]);
+                        c.alive = alive_update(c, UNI(f.sv_alive), s, w->ops_vaf[s]);
                         pc = PC_SUB;
                     } else if (nrange >= p.max_range_depth || nrange >= kMaxRangeDepth) {
                         c.status |= VLR_LOCUS_TABLE_FULL; rv = __builtin_nan(""); pc = PC_RETURN;
@@ -1670,15 +1773,15 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
             if (UNI(r.tn) + UNI(r.npend) > c.cap) {
                 c.status |= VLR_LOCUS_TABLE_FULL;
                 rv = __builtin_nan("");
-                c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained; c.alive = f.sv_alive; c.afd_mute = f.sv_mute;
+                c.present = UNI(f.sv_present); c.disc = UNI(f.sv_disc); c.nlfc = UNI(f.sv_nlfc); c.contained = UNI(f.sv_contained); c.alive = UNI(f.sv_alive); c.afd_mute = UNI(f.sv_mute);
                 sp--; nrange--;
                 pc = PC_RETURN;
             } else if (UNI(r.leaf)) {
                 // innermost chain: evaluate all pending points at once, loop the state machine here
-                c.present = f.sv_present | (1 << r.sample);
-                c.nlfc = f.sv_nlfc;
-                c.contained = f.sv_contained;
-                c.alive = f.sv_alive;
+                c.present = UNI(f.sv_present) | (1 << UNI(r.sample));
+                c.nlfc = UNI(f.sv_nlfc);
+                c.contained = UNI(f.sv_contained);
+                c.alive = UNI(f.sv_alive);
                 if (c.defer_ok && (c.cap > 64 || c.nlfc != 0 || (c.ndef > 0 && UNI(w->task[0].inner) != UNI(r.sample)))) {
                     c.deferred = 2;
                     return 0.0;
@@ -1708,7 +1811,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                     return 0.0;
                 }
                 rv = run_leaf_chain(c, r, c.rowX, c.rowV);
-                c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained; c.alive = f.sv_alive; c.afd_mute = f.sv_mute;
+                c.present = UNI(f.sv_present); c.disc = UNI(f.sv_disc); c.nlfc = UNI(f.sv_nlfc); c.contained = UNI(f.sv_contained); c.alive = UNI(f.sv_alive); c.afd_mute = UNI(f.sv_mute);
                 sp--; nrange--;
                 pc = PC_RETURN;
             } else if (c.cap <= 64 && UNI(f.iter) == 0 && UNI(f.sv_nlfc) == 0 && p.nodes[fnode].n_children == 1 &&
@@ -1717,9 +1820,9 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                        p.nodes[UNI(p.child_index[p.nodes[fnode].child_off])].n_children == 0 &&
                        p.nodes[UNI(p.child_index[p.nodes[fnode].child_off])].vafs.start != p.nodes[UNI(p.child_index[p.nodes[fnode].child_off])].vafs.end) {
                 // outer chain over a leaf Range child: all pending points at once, kRows inner chains per pass
-                c.present = f.sv_present | (1 << r.sample);
-                c.disc = f.sv_disc & ~(1 << r.sample);
-                c.nlfc = f.sv_nlfc;
+                c.present = UNI(f.sv_present) | (1 << UNI(r.sample));
+                c.disc = UNI(f.sv_disc) & ~(1 << UNI(r.sample));
+                c.nlfc = UNI(f.sv_nlfc);
                 batch_outer_points(c, f, r, UNI(p.child_index[p.nodes[fnode].child_off]), tx, tv);
                 __syncthreads();
                 if (c.lane == 0) f.iter = r.npend;
@@ -1730,20 +1833,21 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                 // outer chain: one point at a time through the subtree
                 int it = UNI(f.iter);
                 double x = uni_d(r.pend[it]);
-                c.present = f.sv_present | (1 << r.sample);
-                c.disc = f.sv_disc & ~(1 << r.sample);
-                c.nlfc = f.sv_nlfc;
+                c.present = UNI(f.sv_present) | (1 << UNI(r.sample));
+                c.disc = UNI(f.sv_disc) & ~(1 << UNI(r.sample));
+                c.nlfc = UNI(f.sv_nlfc);
                 RangeV orig{r.ostart, r.oend, r.olex, r.orex};
-                c.contained = f.sv_contained && range_contains(orig, x);
-                c.alive = alive_update(c, f.sv_alive, r.sample, x);
+                c.contained = UNI(f.sv_contained) && range_contains(orig, x);
+                c.alive = alive_update(c, UNI(f.sv_alive), UNI(r.sample), x);
                 if (c.replay) c.afd_mute = UNI(f.sv_mute) || table_has(tx, UNI(r.tn), x, c.lane);
                 __syncthreads();
-                if (c.lane == 0) w->ops_vaf[r.sample] = x;
+                if (c.lane == 0) w->ops_vaf[UNI(r.sample)] = x;
                 __syncthreads();
                 node = fnode;
                 pc = PC_SUB;
             }
         } else {  // PC_RETURN: hand rv to the enclosing frame
+            rv = uni_d(rv);
             if (sp == 0) return rv;
             Frame& f = w->frames[sp - 1];
             if (UNI(f.kind) == FK_RANGE) {
@@ -1764,7 +1868,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                     if (!done) { pc = PC_RANGE_ISSUE; }
                     else {
                         rv = range_finish(c, r, tx, tv);
-                        c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained; c.alive = f.sv_alive; c.afd_mute = f.sv_mute;
+                        c.present = UNI(f.sv_present); c.disc = UNI(f.sv_disc); c.nlfc = UNI(f.sv_nlfc); c.contained = UNI(f.sv_contained); c.alive = UNI(f.sv_alive); c.afd_mute = UNI(f.sv_mute);
                         sp--; nrange--;
                         pc = PC_RETURN;
                     }
@@ -1776,7 +1880,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                 __syncthreads();
                 if (c.lane == 0) { f.accM = M; f.accS = S; f.iter = it; }
                 __syncthreads();
-                c.present = f.sv_present; c.disc = f.sv_disc; c.nlfc = f.sv_nlfc; c.contained = f.sv_contained; c.alive = f.sv_alive; c.afd_mute = f.sv_mute;
+                c.present = UNI(f.sv_present); c.disc = UNI(f.sv_disc); c.nlfc = UNI(f.sv_nlfc); c.contained = UNI(f.sv_contained); c.alive = UNI(f.sv_alive); c.afd_mute = UNI(f.sv_mute);
                 if (it < UNI(f.n)) {
                     const int fnode = UNI(f.node);
                     const DevNode& nd = p.nodes[fnode];
@@ -1787,8 +1891,8 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                         __syncthreads();
                         c.present |= (1 << s);
                         c.disc |= (1 << s);
-                        c.contained = f.sv_contained && spectrum_contains(nd.vafs, p.vafs, w->ops_vaf[s]);
-                        c.alive = alive_update(c, f.sv_alive, s, w->ops_vaf[s]);
+                        c.contained = UNI(f.sv_contained) && spectrum_contains(nd.vafs, p.vafs, w->ops_vaf[s]);
+                        c.alive = alive_update(c, UNI(f.sv_alive), s, w->ops_vaf[s]);
                         node = fnode;
                         pc = PC_SUB;
                     } else {
@@ -1846,10 +1950,11 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
     c.afd_seen = c.cacheV + S * kCacheWays;  // [S][kMaxSet]
     int* mapHyp = (int*)(c.afd_seen + S * kMaxSet);  // [n_slots]
     c.mapJ = mapJ; c.mapVaf = mapVaf; c.mapHyp = mapHyp; c.n_slots = n_slots;
-    c.status = 0; c.n_eval = 0; c.n_terms = 0;
+    c.status = 0;
+    if (lane == 0) { w->work[0] = 0; w->work[1] = 0; }
     c.replay = out.replay; c.locus = locus; c.outp = &out; c.mapGroup = 0; c.mapDisc = 0; c.marginal = 0.0;
 #ifdef VLR_PROFILE
-    for (int i = 0; i < 12; ++i) c.prof[i] = 0;
+    for (int i = 0; i < 24; ++i) c.prof[i] = 0;
 #endif
     PROF_START(c);
 
@@ -1984,6 +2089,7 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
             else if (ff >= 0.4 && ff <= 0.6) { forward_rate = 0.5; sb_informative = true; }
         }
     }
+    forward_rate = uni_d(forward_rate);
     const bool has_alt_loci = any_altloci;
 
     // ---- gating (modes/generic.rs:443-448; bias/mod.rs:232-257)
@@ -2068,10 +2174,10 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
         __syncthreads();
         if (lane < S) { w->mapv[lane] = out.map_vaf[locus * S + lane]; w->afd_nseen[lane] = 0; }
         __syncthreads();
-        int be = out.best_event[locus];
+        int be = UNI(out.best_event[locus]);
         c.mapGroup = (be == 0) ? 0 : ((be - 1) / 2 + 1);
-        c.mapDisc = out.map_disc[locus];
-        c.marginal = out.ln_marginal[locus];
+        c.mapDisc = UNI((int)out.map_disc[locus]);
+        c.marginal = uni_d(out.ln_marginal[locus]);
         hyps = 1u;
     }
     for (int h = 0; h < kNHyp; ++h) {
@@ -2175,7 +2281,7 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
 
         PROF_ADD(c, 2);  // coefficient pass
         // ---- events (calling.rs:654-687): absent + clean events under h = none, artifact twins otherwise
-        const double bias_prior = (h == 0) ? kLn05 : kLn05 + log(1.0 / (double)n_biases);  // modes/generic.rs:437-441
+        const double bias_prior = uni_d((h == 0) ? kLn05 : kLn05 + log(1.0 / (double)n_biases));  // modes/generic.rs:437-441
         const int first_ev = (h == 0) ? -1 : 0;
         // pass 0 (probe): roots that are a single innermost chain are deferred and run together, one per DPP row;
         // pass 1: the remaining (nested / branching / set-valued) roots through the general walk
@@ -2201,7 +2307,7 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
                     if (lane < S) w->curMapVaf[lane] = mapVaf[u * S + lane];
                     __syncthreads();
                     int root = (e < 0) ? p.absent_root : p.roots[ri];
-                    double dens = walk_root(c, root);
+                    double dens = uni_d(walk_root(c, root));
                     if (c.deferred == 1) { c.deferred = 0; continue; }                      // delivered by flush_deferred
                     if (c.deferred == 2) { c.deferred = 0; todo |= 1ull << rc_; continue; } // second pass
                     if (dens != dens) c.status |= VLR_LOCUS_NAN;
@@ -2297,11 +2403,11 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
     if (lane == 0) {
         out.status[locus] = c.status;
         if (out.work) {
-            atomicAdd(&out.work[0], c.n_eval);
-            atomicAdd(&out.work[1], c.n_terms);
+            atomicAdd(&out.work[0], w->work[0]);
+            atomicAdd(&out.work[1], w->work[1]);
 #ifdef VLR_PROFILE
             PROF_ADD(c, 9);  // phase C
-            for (int i = 0; i < 12; ++i) atomicAdd(&out.work[2 + i], c.prof[i]);
+            for (int i = 0; i < 24; ++i) atomicAdd(&out.work[2 + i], c.prof[i]);
 #endif
         }
     }
