@@ -70,6 +70,15 @@ struct ChainTask {              // one innermost Range chain (see run_chain_batc
     int u, group, disc, inner;  // deferred event-level chains: destination slot, event group, is_discrete mask, sample
 };
 
+struct BatchOuter {              // outer Range frame whose pending points are evaluated as row-parallel inner chains
+    double lo, hi, res, fixed_const;
+    int simpson, dead, vary, np, c0, nt, chn, s_in, s_out, pad;
+};
+struct WalkSave {                // walk_root state while the kernel's event loop runs a chain batch on its behalf
+    double rv;
+    int sp, node, nrange, skip_record;
+};
+
 struct WaveSt {
     double ops_vaf[kMaxSamples];
     double lfc_val[kMaxLfc];
@@ -91,6 +100,8 @@ struct WaveSt {
                                 // visit the same operands; the reference's joint_probs map keeps one entry)
     int cs_node[kContainStack], cs_mask[kContainStack];
     ChainTask task[kRows];
+    BatchOuter bo;
+    WalkSave wk;
     double bpend[kRows][kRowPts], bvals[kRows][kRowPts];
     unsigned long long work[2];  // [0] pileup evaluations, [1] observation terms (lane 0 adds; profiling aid)
     int fastok;  // bit s: all terms of sample s stay >= 2^-200 under the current hypothesis (4-term renormalisation is safe)
@@ -143,6 +154,35 @@ __device__ inline void lse_add(double& M, double& S, double v) {
 __device__ inline double lse_value(double M, double S) {
     if (M == VLR_NEG_INF) return VLR_NEG_INF;
     return M + log(S);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Plan arrays (nodes, spectra, VAF pool, roots) are read-only device memory addressed with wave-uniform indices.
+// Reading them through the constant address space makes the loads scalar (s_load into SGPRs, scalar data cache)
+// instead of per-lane vector loads that every lane has to wait for.
+#define VLR_K4 __attribute__((address_space(4)))
+#ifdef VLR_NO_K4
+template <class T>
+__device__ __forceinline__ T ldc(const T* ptr) { return *ptr; }
+#else
+template <class T>
+__device__ __forceinline__ T ldc(const T* ptr) { return *(const VLR_K4 T*)(uintptr_t)ptr; }
+#endif
+__device__ __forceinline__ DevSpectrum ld_spec(const DevSpectrum* g) {
+    DevSpectrum s;
+    s.kind = ldc(&g->kind); s.set_off = ldc(&g->set_off); s.set_len = ldc(&g->set_len);
+    s.lex = ldc(&g->lex); s.rex = ldc(&g->rex); s.pad = 0;
+    s.start = ldc(&g->start); s.end = ldc(&g->end);
+    return s;
+}
+__device__ __forceinline__ DevNode ld_node(const DevNode* g) {
+    DevNode n;
+    n.kind = ldc(&g->kind); n.sample = ldc(&g->sample); n.sample_b = ldc(&g->sample_b); n.cmp = ldc(&g->cmp);
+    n.lfc_value = ldc(&g->lfc_value);
+    n.vafs = ld_spec(&g->vafs);
+    n.positive = ldc(&g->positive); n.refbase = ldc(&g->refbase); n.altbase = ldc(&g->altbase);
+    n.child_off = ldc(&g->child_off); n.n_children = ldc(&g->n_children); n.pad = 0;
+    return n;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -199,7 +239,7 @@ __device__ inline double observable_min(const RangeV& r, int n) {  // 1170-1196
 __device__ inline bool spectrum_contains(const DevSpectrum& sp, const double* pool, double v) {  // 1035-1040
     if (sp.kind == 0) {
         for (int i = 0; i < sp.set_len; ++i)
-            if (pool[sp.set_off + i] == v) return true;
+            if (ldc(pool + sp.set_off + i) == v) return true;
         return false;
     }
     RangeV r{sp.start, sp.end, sp.lex, sp.rex};
@@ -518,6 +558,7 @@ struct Ctx {
     // AFD replay pass (calling.rs:889-928): MAP operands of the first pass, recorded per matching operand
     int replay, mapGroup, mapDisc;
     int defer_ok, deferred, ndef, defer_slot;  // event-level deferral of simple chains into a row-parallel batch
+    int need_batch, bt_nt, bt_inner;           // walk_root asks the event loop to run run_chain_batch (single inline site, few live registers)
     int afd_mute;  // replay: the current path repeats an outer VAF already visited by its chain (duplicate map key)
     double marginal;
     int64_t locus;
@@ -533,7 +574,7 @@ struct Ctx {
 __device__ inline int prior_class(const DevPlan& p, int s, double v) {
     if (p.prior_kind[s] == PK_UNIFORM) {
         bool in = false;
-        for (int u = p.uni_off[s]; u < p.uni_off[s + 1]; ++u) in = in || spectrum_contains(p.universe[u], p.vafs, v);
+        for (int u = p.uni_off[s]; u < p.uni_off[s + 1]; ++u) in = in || spectrum_contains(ld_spec(p.universe + u), p.vafs, v);
         return in ? (v == 0.0 ? 0 : 1) : 2;
     }
     int pl = p.ploidy[s];
@@ -567,19 +608,25 @@ __device__ inline void alpha_beta(const DevPlan& p, int s, double a, double b, d
 // modes/generic.rs:38-53: the normal sample's likelihood is reused across all tumor VAFs)
 __device__ inline double sample_lik(Ctx& c, int s, double a, double b) {
     WaveSt* w = c.w;
-    int n = w->cacheN[s];
-    int lim = n < kCacheWays ? n : kCacheWays;
-    for (int i = 0; i < lim; ++i)
-        if (c.cacheA[s * kCacheWays + i] == a && c.cacheB[s * kCacheWays + i] == b) return uni_d(c.cacheV[s * kCacheWays + i]);
+    const int n = UNI(w->cacheN[s]);
+    const int lim = n < kCacheWays ? n : kCacheWays;
+    {   // all ways probed at once (lane i looks at way i)
+        const int wi = c.lane < kCacheWays ? c.lane : 0;
+        const bool hit = (c.lane < lim) & (c.cacheA[s * kCacheWays + wi] == a) & (c.cacheB[s * kCacheWays + wi] == b);
+        const unsigned long long hm = __ballot(hit);
+        if (hm) return uni_d(c.cacheV[s * kCacheWays + __builtin_ctzll(hm)]);
+    }
     double al, be;
     alpha_beta(*c.plan, s, a, b, al, be);
-    __syncthreads();
-    if (c.lane == 0) { w->ptA[0] = al; w->ptB[0] = be; }
-    __syncthreads();
-    int off = w->soff[s], D = w->nkeep[s];
-    eval_pileup(c.coef + 3 * off, D, (w->fastok >> s) & 1, 1, w->ptA, w->ptB, w->res, c.lane);
-    __syncthreads();
-    double r = uni_d(w->res[0]);
+    int off = UNI(w->soff[s]), D = UNI(w->nkeep[s]);
+    double r;
+    {   // one point on all 64 lanes
+        double P1[1] = {1.0};
+        int E1[1] = {0};
+        accum_terms<1, 64>(c.coef + 3 * off, D, c.lane, (w->fastok >> s) & 1, &al, &be, P1, E1);
+        reduce_terms<1, 64>(P1, E1);
+        r = uni_d(log(P1[0]) + (double)E1[0] * kLn2);
+    }
     if (c.lane == 0) { w->work[0] += 1; w->work[1] += (unsigned long long)D; }
     int slot = n % kCacheWays;
     __syncthreads();
@@ -628,9 +675,9 @@ __device__ inline int slot_clean(int g) { return g == 0 ? 0 : 1 + 2 * (g - 1); }
 __device__ inline int slot_art(const Ctx& c, int g) { return g == 0 ? c.plan->n_univ : 2 + 2 * (g - 1); }
 
 __device__ inline bool group_may_contain(const DevPlan& p, int g, int s, double v) {
-    int o0 = p.grp_spec_off[g * p.S + s], o1 = p.grp_spec_off[g * p.S + s + 1];
+    int o0 = ldc(p.grp_spec_off + g * p.S + s), o1 = ldc(p.grp_spec_off + g * p.S + s + 1);
     for (int i = o0; i < o1; ++i)
-        if (spectrum_contains(p.grp_spec[i], p.vafs, v)) return true;
+        if (spectrum_contains(ld_spec(p.grp_spec + i), p.vafs, v)) return true;
     return false;
 }
 // `alive` and s are wave-uniform (scalar loop over groups, scalar loads of the group spectra); v may differ per lane
@@ -651,18 +698,18 @@ __device__ inline bool group_contains(Ctx& c, int g, int inner, double x, int ex
     g = UNI(g); inner = UNI(inner); x = uni_d(x);
     const DevPlan& p = *c.plan;
     WaveSt* w = c.w;
-    int r0 = (g == 0) ? 0 : p.root_off[g - 1], r1 = (g == 0) ? 1 : p.root_off[g];
+    int r0 = (g == 0) ? 0 : ldc(p.root_off + g - 1), r1 = (g == 0) ? 1 : ldc(p.root_off + g);
     int full = (1 << c.nlfc) - 1;
     bool result = false;
     for (int ri = r0; ri < r1 && !result; ++ri) {
         int sp = 0;
-        w->cs_node[0] = (g == 0) ? p.absent_root : p.roots[ri];
+        w->cs_node[0] = (g == 0) ? p.absent_root : ldc(p.roots + ri);
         w->cs_mask[0] = full;
         sp = 1;
         while (sp > 0 && !result) {
             sp--;
             int node = UNI(w->cs_node[sp]), mask = UNI(w->cs_mask[sp]);
-            const DevNode& nd = p.nodes[node];
+            const DevNode nd = ld_node(p.nodes + node);
             bool contained;
             if (nd.kind == VLR_NODE_SAMPLE) {
                 if (nd.sample == excl) { result = true; continue; }  // vaftree.rs:124-128: excluded sample => true
@@ -682,7 +729,7 @@ __device__ inline bool group_contains(Ctx& c, int g, int inner, double x, int ex
             if (nd.n_children == 0) { if (mask == 0) result = true; continue; }
             for (int ch = nd.n_children - 1; ch >= 0; --ch) {
                 if (sp >= kContainStack) { c.status |= VLR_LOCUS_TABLE_FULL; break; }
-                w->cs_node[sp] = p.child_index[nd.child_off + ch];
+                w->cs_node[sp] = ldc(p.child_index + nd.child_off + ch);
                 w->cs_mask[sp] = mask;
                 sp++;
             }
@@ -934,59 +981,51 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
 
     for (;;) {
         if (tn + np > c.cap) { c.status |= VLR_LOCUS_TABLE_FULL; failed = true; break; }
-        // lane j < np owns point j; every lane multiplies its observation slice (terms lane, lane+64, ...) for up to
-        // four points per pass
-        const int jown = lane < np ? lane : np - 1;
-        const double x = pend[jown];
-        double Psel = 1.0;
-        int Esel = 0;
+        // one point per 16-lane DPP row (four points per pass); the row's lanes split the observations and the
+        // row leader stores the joint value.  (Cheaper than a 64-lane product for a single chain: the reduction
+        // stays inside a row.)
+        const int row = lane >> 4, rlane = lane & 15;
+        bool nan_seen = false;
         for (int p0 = 0; p0 < np; p0 += 4) {
-            const int cnt = (np - p0) < 4 ? (np - p0) : 4;
-            double xs[4], P[4];
-            int E[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { xs[j] = pend[(p0 + j) < np ? (p0 + j) : np - 1]; P[j] = 1.0; E[j] = 0; }
+            const int jp = (p0 + row) < np ? (p0 + row) : np - 1;
+            const double xr = pend[jp];
+            double P1[1] = {1.0};
+            int E1[1] = {0};
             int dm = dep;
             while (dm) {
                 int s = __builtin_ctz(dm);
                 dm &= dm - 1;
                 int by = p.by[s];
-                double al[4], be[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    double a = (s == inner) ? xs[j] : w->ops_vaf[s];
-                    double b = by >= 0 ? ((by == inner) ? xs[j] : w->ops_vaf[by]) : 0.0;
-                    alpha_beta(p, s, a, b, al[j], be[j]);
-                }
-                const int off = w->soff[s], D = w->nkeep[s];
-                accum_terms_n<64>(cnt, c.coef + 3 * off, D, lane, (w->fastok >> s) & 1, al, be, P, E);
+                double a = (s == inner) ? xr : w->ops_vaf[s];
+                double b = by >= 0 ? ((by == inner) ? xr : w->ops_vaf[by]) : 0.0;
+                double al, be;
+                alpha_beta(p, s, a, b, al, be);
+                accum_terms<1, 16>(c.coef + 3 * UNI(w->soff[s]), UNI(w->nkeep[s]), rlane, (w->fastok >> s) & 1, &al, &be, P1, E1);
             }
-            reduce_terms_n<64>(cnt, P, E);
-            const int jr = lane - p0;
-            const double Pm = jr == 1 ? P[1] : jr == 2 ? P[2] : jr == 3 ? P[3] : P[0];
-            const int Em = jr == 1 ? E[1] : jr == 2 ? E[2] : jr == 3 ? E[3] : E[0];
-            const bool mine = jr >= 0 && jr < 4;
-            Psel = mine ? Pm : Psel;
-            Esel = mine ? Em : Esel;
+            reduce_terms<1, 16>(P1, E1);
+            const double lik = fixed + (log(P1[0]) + (double)E1[0] * kLn2);
+            double jv;
+            if (c.nlfc > 0 && !lfcs_ok(c, inner, xr)) jv = VLR_NEG_INF;
+            else {
+                int cls = prior_class(p, inner, xr);
+                jv = (cls == 0 ? pr0 : cls == 1 ? pr1 : cls == 2 ? pr2 : ptab[pidx + cls * istride]) + lik;
+            }
+            const bool lead = rlane == 0 && (p0 + row) < np;
+            nan_seen = nan_seen | (lead && jv != jv);
+            if (lead) { tx[tn + p0 + row] = xr; tv[tn + p0 + row] = jv; vals[p0 + row] = jv; }
         }
-        const double lik = fixed + (log(Psel) + (double)Esel * kLn2);
-        double joint;
-        if (c.nlfc > 0 && !lfcs_ok(c, inner, x)) joint = VLR_NEG_INF;
-        else {
-            int cls = prior_class(p, inner, x);
-            joint = (cls == 0 ? pr0 : cls == 1 ? pr1 : cls == 2 ? pr2 : ptab[pidx + cls * istride]) + lik;
-        }
+        if (__ballot(nan_seen)) c.status |= VLR_LOCUS_NAN;
+        __builtin_amdgcn_wave_barrier();
+        // lane j < np looks at point j for the MAP bookkeeping
         const bool owner = lane < np;
-        if (__ballot(owner && joint != joint)) c.status |= VLR_LOCUS_NAN;
-        if (owner) { tx[tn + lane] = x; tv[tn + lane] = joint; }
+        const double x = pend[owner ? lane : np - 1];
+        const double joint = vals[owner ? lane : np - 1];
 
         // MAP candidates (calling.rs:851-864)
         const bool own_in = c.contained && range_contains(orig, x);
         const int al2 = c.alive ? alive_update(c, c.alive, inner, x) : 0;
         const bool slow = __ballot(owner && (!own_in || al2 != 0)) != 0ull;
-        __builtin_amdgcn_wave_barrier();
-        if (owner) vals[lane] = joint;
-        __builtin_amdgcn_wave_barrier();
+        (void)joint;
         if (c.replay) {
             for (int i = 0; i < np; ++i) {
                 double xi = uni_d(pend[i]);
@@ -1134,7 +1173,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
     bool cls_fast = false;
     if (p.prior_kind[inner] == PK_UNIFORM)
         for (int u = p.uni_off[inner]; u < p.uni_off[inner + 1]; ++u) {
-            const DevSpectrum& sp = p.universe[u];
+            const DevSpectrum sp = ld_spec(p.universe + u);
             if (sp.kind == 1) {
                 RangeV ur{sp.start, sp.end, sp.lex, sp.rex};
                 cls_fast = cls_fast || (range_contains(ur, lo) && range_contains(ur, hi));
@@ -1453,21 +1492,22 @@ __device__ inline void afd_emit_row(Ctx& c, int i, int s_in, int nq) {
 // Outer Range frame whose single child is a leaf Range node (the nested `somatic_normal` shape): evaluate the
 // inner chains of ALL pending outer points together, kRows at a time (run_chain_batch), instead of descending
 // once per point.  Semantics identical to the sequential walk (modes/generic.rs:331-395 for the child node).
-__device__ __forceinline__ void batch_outer_points(Ctx& c, const Frame& f, RangeSt& r, int chn, double* txo, double* tvo) {
+// The work is split in three steps around run_chain_batch, which the kernel's event loop runs on behalf of the
+// walk (bo_begin -> [bo_setup -> run_chain_batch -> bo_deliver]*): inlining the batch runner inside the walk kept
+// ~100 more VGPRs alive across it and made the compiler spill in its rounds.
+__device__ __forceinline__ void bo_begin(Ctx& c, RangeSt& r, int chn) {
     PROF_ADD(c, 3);
     const DevPlan& p = *c.plan;
     WaveSt* w = c.w;
-    const DevNode& ch = p.nodes[chn];
-    const int s_in = ch.sample, s_out = UNI(r.sample), S = c.S, lane = c.lane;
+    const DevNode ch = ld_node(p.nodes + chn);
+    const int s_in = ch.sample, s_out = UNI(r.sample), S = c.S;
     const int n_obs = UNI(w->nkeep[s_in]);
-    const bool clear_ref = n_obs > 10 && w->all_posref[s_in];
+    const bool clear_ref = n_obs > 10 && UNI(w->all_posref[s_in]);
     const RangeV vr{ch.vafs.start, ch.vafs.end, ch.vafs.lex, ch.vafs.rex};
     const bool dead = clear_ref && vr.start > 0.0;  // generic.rs:342-347
     const double res = p.resolution[s_in];
     const double lo = uni_d(observable_min(vr, n_obs)), hi = uni_d(observable_max(vr, n_obs));
     const int simpson = ((hi - lo) < res) ? 3 : (n_obs < 5 ? 11 : 0);
-    const RangeV oorig{uni_d(r.ostart), uni_d(r.oend), UNI(r.olex), UNI(r.orex)};
-    const int np = UNI(r.npend);
     // samples whose likelihood is fixed during an inner chain: constant over the outer points, or varying with them
     double fixed_const = 0.0;
     int vary = 0;
@@ -1478,73 +1518,112 @@ __device__ __forceinline__ void batch_outer_points(Ctx& c, const Frame& f, Range
         else fixed_const += sample_lik(c, s, w->ops_vaf[s], by >= 0 ? w->ops_vaf[by] : 0.0);
     }
     fixed_const = uni_d(fixed_const);
-    for (int c0 = 0; c0 < np; c0 += kRows) {
-        const int nt = (np - c0) < kRows ? (np - c0) : kRows;
-        __syncthreads();
-        if (lane < nt) {
-            const double x = r.pend[c0 + lane];
-            ChainTask& T = w->task[lane];
-            T.lo = lo; T.hi = hi; T.res = res;
-            T.ostart = ch.vafs.start; T.oend = ch.vafs.end; T.olex = ch.vafs.lex; T.orex = ch.vafs.rex;
-            T.simpson_n = simpson;
-            T.contained = UNI(f.sv_contained) && range_contains(oorig, x);
-            T.alive = alive_update(c, UNI(f.sv_alive), s_out, x);
-            int pidx = 0;
-            for (int s = 0; s < S; ++s) {
-                double v = (s == s_out) ? x : w->ops_vaf[s];
-                c.tvaf[lane * S + s] = v;
-                if (s != s_in) pidx += prior_class(p, s, v) * p.class_stride[s];
-            }
-            T.pidx = pidx;
-            T.fixed = fixed_const;
-            T.result = VLR_NEG_INF; T.haveBest = 0; T.n = 0; T.bestJ = VLR_NEG_INF; T.bestX = 0.0;
-        }
-        __syncthreads();
-        int vm = vary;
-        while (vm && !dead) {
-            int s = __builtin_ctz(vm);
-            vm &= vm - 1;
-            int by = p.by[s];
-            if (lane < nt) {
-                double a = c.tvaf[lane * S + s];
-                double b = by >= 0 ? c.tvaf[lane * S + by] : 0.0;
-                double al, be;
-                alpha_beta(p, s, a, b, al, be);
-                w->ptA[lane] = al;
-                w->ptB[lane] = be;
-            }
-            __syncthreads();
-            int off = w->soff[s], D = w->nkeep[s];
-            eval_pileup(c.coef + 3 * off, D, (w->fastok >> s) & 1, nt, w->ptA, w->ptB, w->res, lane);
-            __syncthreads();
-            if (lane < nt) w->task[lane].fixed += w->res[lane];
-            if (lane == 0) { w->work[0] += (unsigned long long)nt; w->work[1] += (unsigned long long)nt * (unsigned long long)D; }
-            __syncthreads();
-        }
-        if (!dead) run_chain_batch(c, nt, s_in);
-        __syncthreads();
-        for (int i = 0; i < nt; ++i) {
-            const ChainTask& T = w->task[i];
-            const double x = uni_d(r.pend[c0 + i]);
-            __syncthreads();
-            if (lane == 0) { txo[r.tn + c0 + i] = x; tvo[r.tn + c0 + i] = dead ? VLR_NEG_INF : T.result; w->ops_vaf[s_out] = x; }
-            __syncthreads();
-            if (dead) continue;
-            if (c.replay) {
-                if (UNI(f.sv_mute) || table_has(txo, UNI(r.tn) + c0 + i, x, lane)) continue;  // repeated outer VAF: same map keys
-                afd_emit_row(c, i, s_in, UNI(T.n));
-                continue;
-            }
-            if (UNI(T.haveBest)) map_consider(c, uni_d(T.bestJ), s_in, uni_d(T.bestX));
-            if (UNI(T.alive) != 0 || !UNI(T.contained)) {  // rare: candidates for other groups / containment via another path
-                const RangeV io{uni_d(T.ostart), uni_d(T.oend), UNI(T.olex), UNI(T.orex)};
-                scan_chain_candidates(c, c.rowX + i * c.cap, c.rowV + i * c.cap, UNI(T.n), io, UNI(T.contained), UNI(T.alive), s_in);
-            }
-        }
+    __syncthreads();
+    if (c.lane == 0) {
+        BatchOuter& B = w->bo;
+        B.lo = lo; B.hi = hi; B.res = res; B.fixed_const = fixed_const;
+        B.simpson = simpson; B.dead = dead ? 1 : 0; B.vary = vary; B.np = UNI(r.npend); B.c0 = 0; B.nt = 0;
+        B.chn = chn; B.s_in = s_in; B.s_out = s_out;
     }
     __syncthreads();
+}
+// tasks of the pending outer points [c0, c0 + kRows); returns false if the inner range is dead (no chains to run)
+__device__ __forceinline__ bool bo_setup(Ctx& c, const Frame& f, RangeSt& r) {
+    const DevPlan& p = *c.plan;
+    WaveSt* w = c.w;
+    const BatchOuter& B = w->bo;
+    const int lane = c.lane, S = c.S;
+    const int np = UNI(B.np), c0 = UNI(B.c0), s_in = UNI(B.s_in), s_out = UNI(B.s_out), chn = UNI(B.chn);
+    const bool dead = UNI(B.dead) != 0;
+    const int nt = (np - c0) < kRows ? (np - c0) : kRows;
+    PROF_ADD(c, 18);  // outer batch: entry (fixed samples) / delivery of the previous pass
+    __syncthreads();
+    if (lane == 0) w->bo.nt = nt;
+    if (lane < nt) {
+        const DevNode ch = ld_node(p.nodes + chn);
+        const RangeV oorig{r.ostart, r.oend, r.olex, r.orex};
+        const double x = r.pend[c0 + lane];
+        ChainTask& T = w->task[lane];
+        T.lo = B.lo; T.hi = B.hi; T.res = B.res;
+        T.ostart = ch.vafs.start; T.oend = ch.vafs.end; T.olex = ch.vafs.lex; T.orex = ch.vafs.rex;
+        T.simpson_n = B.simpson;
+        T.contained = UNI(f.sv_contained) && range_contains(oorig, x);
+        T.alive = alive_update(c, UNI(f.sv_alive), s_out, x);
+        int pidx = 0;
+        for (int s = 0; s < S; ++s) {
+            double v = (s == s_out) ? x : w->ops_vaf[s];
+            c.tvaf[lane * S + s] = v;
+            if (s != s_in) pidx += prior_class(p, s, v) * p.class_stride[s];
+        }
+        T.pidx = pidx;
+        T.fixed = B.fixed_const;
+        T.result = VLR_NEG_INF; T.haveBest = 0; T.n = 0; T.bestJ = VLR_NEG_INF; T.bestX = 0.0;
+    }
+    __syncthreads();
+    PROF_ADD(c, 16);  // outer batch: task setup
+    int vm = UNI(B.vary);
+    while (vm && !dead) {
+        int s = __builtin_ctz(vm);
+        vm &= vm - 1;
+        int by = p.by[s];
+        if (lane < nt) {
+            double a = c.tvaf[lane * S + s];
+            double b = by >= 0 ? c.tvaf[lane * S + by] : 0.0;
+            double al, be;
+            alpha_beta(p, s, a, b, al, be);
+            w->ptA[lane] = al;
+            w->ptB[lane] = be;
+        }
+        __syncthreads();
+        int off = UNI(w->soff[s]), D = UNI(w->nkeep[s]);
+        eval_pileup(c.coef + 3 * off, D, (w->fastok >> s) & 1, nt, w->ptA, w->ptB, w->res, lane);
+        __syncthreads();
+        if (lane < nt) w->task[lane].fixed += w->res[lane];
+        if (lane == 0) { w->work[0] += (unsigned long long)nt; w->work[1] += (unsigned long long)nt * (unsigned long long)D; }
+        __syncthreads();
+    }
+    PROF_ADD(c, 17);  // outer batch: likelihoods of the samples that vary with the outer point
+    c.bt_nt = nt;
+    c.bt_inner = s_in;
+    return !dead;
+}
+// hand the finished chains [c0, c0 + nt) to the outer frame; returns true while outer points are left
+__device__ __forceinline__ bool bo_deliver(Ctx& c, const Frame& f, RangeSt& r, double* txo, double* tvo) {
+    WaveSt* w = c.w;
+    const BatchOuter& B = w->bo;
+    const int lane = c.lane;
+    const int np = UNI(B.np), c0 = UNI(B.c0), nt = UNI(B.nt), s_in = UNI(B.s_in), s_out = UNI(B.s_out);
+    const bool dead = UNI(B.dead) != 0;
+    __syncthreads();
+    for (int i = 0; i < nt; ++i) {
+        const ChainTask& T = w->task[i];
+        const double x = uni_d(r.pend[c0 + i]);
+        __syncthreads();
+        if (lane == 0) { txo[r.tn + c0 + i] = x; tvo[r.tn + c0 + i] = dead ? VLR_NEG_INF : T.result; w->ops_vaf[s_out] = x; }
+        __syncthreads();
+        if (dead) continue;
+        if (c.replay) {
+            if (UNI(f.sv_mute) || table_has(txo, UNI(r.tn) + c0 + i, x, lane)) continue;  // repeated outer VAF: same map keys
+            afd_emit_row(c, i, s_in, UNI(T.n));
+            continue;
+        }
+        if (UNI(T.haveBest)) map_consider(c, uni_d(T.bestJ), s_in, uni_d(T.bestX));
+        if (UNI(T.alive) != 0 || !UNI(T.contained)) {  // rare: candidates for other groups / containment via another path
+            const RangeV io{uni_d(T.ostart), uni_d(T.oend), UNI(T.olex), UNI(T.orex)};
+            scan_chain_candidates(c, c.rowX + i * c.cap, c.rowV + i * c.cap, UNI(T.n), io, UNI(T.contained), UNI(T.alive), s_in);
+        }
+    }
+    const int c1 = c0 + kRows;
+    __syncthreads();
+    if (c1 < np) {
+        if (lane == 0) w->bo.c0 = c1;
+        __syncthreads();
+        return true;
+    }
+    PROF_ADD(c, 18);
     if (lane == 0) r.tn = r.tn + np;
     __syncthreads();
+    return false;
 }
 
 // Event-level deferral: an event root whose path is a chain of single-valued Sample nodes ending in a leaf Range
@@ -1614,19 +1693,36 @@ __device__ __forceinline__ void flush_deferred(Ctx& c, double* evM, double* evS,
     c.ndef = 0;
 }
 
+// node id of the single child of `fnode` if that child is a leaf Sample node with a proper Range spectrum, else -1
+__device__ __forceinline__ int leaf_range_child(const DevPlan& p, int fnode) {
+    const DevNode* f = p.nodes + fnode;
+    if (ldc(&f->n_children) != 1) return -1;
+    const int chn = ldc(p.child_index + ldc(&f->child_off));
+    const DevNode* ch = p.nodes + chn;
+    const bool ok = ldc(&ch->kind) == VLR_NODE_SAMPLE && ldc(&ch->vafs.kind) == 1 && ldc(&ch->n_children) == 0 &&
+                    ldc(&ch->vafs.start) != ldc(&ch->vafs.end);
+    return ok ? chn : -1;
+}
+
 // GenericPosterior::density (modes/generic.rs:190-423) for one (hypothesis, root): explicit-stack walk.
-__device__ __forceinline__ double walk_root(Ctx& c, int root) {
+__device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
     const DevPlan& p = *c.plan;
     WaveSt* w = c.w;
-    c.present = 0; c.disc = 0; c.nlfc = 0; c.contained = 1; c.afd_mute = 0;
-    c.alive = ((1 << (p.n_named + 1)) - 1) & ~(1 << c.group);
     int sp = 0, node = UNI(root), nrange = 0;
-    enum { PC_DESCEND, PC_SUB, PC_RETURN, PC_RANGE_ISSUE } pc = PC_DESCEND;
+    enum { PC_DESCEND, PC_SUB, PC_RETURN, PC_RANGE_ISSUE, PC_BO_PRE, PC_BO_POST } pc = PC_DESCEND;
     double rv = VLR_NEG_INF;
     bool skip_record = false;
+    if (resume) {  // the event loop ran the chain batch this walk asked for
+        const WalkSave& k = w->wk;
+        sp = UNI(k.sp); node = UNI(k.node); nrange = UNI(k.nrange); skip_record = UNI(k.skip_record) != 0; rv = uni_d(k.rv);
+        pc = PC_BO_POST;
+    } else {
+        c.present = 0; c.disc = 0; c.nlfc = 0; c.contained = 1; c.afd_mute = 0;
+        c.alive = ((1 << (p.n_named + 1)) - 1) & ~(1 << c.group);
+    }
     for (;;) {
         if (pc == PC_DESCEND) {
-            const DevNode& nd = p.nodes[node];
+            const DevNode nd = ld_node(p.nodes + node);
             if (nd.kind == VLR_NODE_LFC) {  // 233-244
                 if (c.nlfc < kMaxLfc) {
                     __syncthreads();
@@ -1661,12 +1757,12 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                 if (!dead) {
                     if (is_set) {  // 294-330
                         bool all_pos = true;
-                        for (int i = 0; i < nd.vafs.set_len; ++i) all_pos = all_pos && (p.vafs[nd.vafs.set_off + i] > 0.0);
+                        for (int i = 0; i < nd.vafs.set_len; ++i) all_pos = all_pos && (ldc(p.vafs + nd.vafs.set_off + i) > 0.0);
                         if (clear_ref && all_pos) dead = true;
                         else {
                             __syncthreads();
                             for (int i = 0; i < nd.vafs.set_len && ncand < kMaxSet; ++i) {
-                                double v = p.vafs[nd.vafs.set_off + i];
+                                double v = ldc(p.vafs + nd.vafs.set_off + i);
                                 if (!have_bounds || range_contains(bounds, v)) {
                                     if (c.lane == 0) c.setv[s * kMaxSet + ncand] = v;
                                     ncand++;
@@ -1746,9 +1842,9 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                 }
             }
         } else if (pc == PC_SUB) {  // subdensity (199-230)
-            const DevNode& nd = p.nodes[node];
+            const DevNode nd = ld_node(p.nodes + node);
             if (nd.n_children == 0) { rv = leaf_joint(c); pc = PC_RETURN; }
-            else if (nd.n_children == 1) { node = UNI(p.child_index[nd.child_off]); pc = PC_DESCEND; }
+            else if (nd.n_children == 1) { node = ldc(p.child_index + nd.child_off); pc = PC_DESCEND; }
             else if (sp >= kMaxFrames) { c.status |= VLR_LOCUS_TABLE_FULL; rv = __builtin_nan(""); pc = PC_RETURN; }
             else if (c.defer_ok) { c.deferred = 2; return 0.0; }  // probe pass: branching root is not a single chain
             else {
@@ -1761,7 +1857,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                 }
                 __syncthreads();
                 sp++;
-                node = UNI(p.child_index[nd.child_off]);
+                node = ldc(p.child_index + nd.child_off);
                 pc = PC_DESCEND;
             }
         } else if (pc == PC_RANGE_ISSUE) {
@@ -1814,21 +1910,13 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                 c.present = UNI(f.sv_present); c.disc = UNI(f.sv_disc); c.nlfc = UNI(f.sv_nlfc); c.contained = UNI(f.sv_contained); c.alive = UNI(f.sv_alive); c.afd_mute = UNI(f.sv_mute);
                 sp--; nrange--;
                 pc = PC_RETURN;
-            } else if (c.cap <= 64 && UNI(f.iter) == 0 && UNI(f.sv_nlfc) == 0 && p.nodes[fnode].n_children == 1 &&
-                       p.nodes[UNI(p.child_index[p.nodes[fnode].child_off])].kind == VLR_NODE_SAMPLE &&
-                       p.nodes[UNI(p.child_index[p.nodes[fnode].child_off])].vafs.kind == 1 &&
-                       p.nodes[UNI(p.child_index[p.nodes[fnode].child_off])].n_children == 0 &&
-                       p.nodes[UNI(p.child_index[p.nodes[fnode].child_off])].vafs.start != p.nodes[UNI(p.child_index[p.nodes[fnode].child_off])].vafs.end) {
+            } else if (c.cap <= 64 && UNI(f.iter) == 0 && UNI(f.sv_nlfc) == 0 && leaf_range_child(p, fnode) >= 0) {
                 // outer chain over a leaf Range child: all pending points at once, kRows inner chains per pass
                 c.present = UNI(f.sv_present) | (1 << UNI(r.sample));
                 c.disc = UNI(f.sv_disc) & ~(1 << UNI(r.sample));
                 c.nlfc = UNI(f.sv_nlfc);
-                batch_outer_points(c, f, r, UNI(p.child_index[p.nodes[fnode].child_off]), tx, tv);
-                __syncthreads();
-                if (c.lane == 0) f.iter = r.npend;
-                __syncthreads();
-                skip_record = true;
-                pc = PC_RETURN;
+                bo_begin(c, r, leaf_range_child(p, fnode));
+                pc = PC_BO_PRE;
             } else {
                 // outer chain: one point at a time through the subtree
                 int it = UNI(f.iter);
@@ -1845,6 +1933,29 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                 __syncthreads();
                 node = fnode;
                 pc = PC_SUB;
+            }
+        } else if (pc == PC_BO_PRE) {
+            Frame& f = w->frames[sp - 1];
+            RangeSt& r = w->rs[UNI(f.slot)];
+            if (bo_setup(c, f, r)) {
+                __syncthreads();
+                if (c.lane == 0) { WalkSave& k = w->wk; k.sp = sp; k.node = node; k.nrange = nrange; k.skip_record = skip_record ? 1 : 0; k.rv = rv; }
+                __syncthreads();
+                c.need_batch = 1;
+                return 0.0;
+            }
+            pc = PC_BO_POST;
+        } else if (pc == PC_BO_POST) {
+            Frame& f = w->frames[sp - 1];
+            const int fslot = UNI(f.slot);
+            RangeSt& r = w->rs[fslot];
+            if (bo_deliver(c, f, r, c.tabX + fslot * c.cap, c.tabV + fslot * c.cap)) pc = PC_BO_PRE;
+            else {
+                __syncthreads();
+                if (c.lane == 0) f.iter = r.npend;
+                __syncthreads();
+                skip_record = true;
+                pc = PC_RETURN;
             }
         } else {  // PC_RETURN: hand rv to the enclosing frame
             rv = uni_d(rv);
@@ -1883,7 +1994,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                 c.present = UNI(f.sv_present); c.disc = UNI(f.sv_disc); c.nlfc = UNI(f.sv_nlfc); c.contained = UNI(f.sv_contained); c.alive = UNI(f.sv_alive); c.afd_mute = UNI(f.sv_mute);
                 if (it < UNI(f.n)) {
                     const int fnode = UNI(f.node);
-                    const DevNode& nd = p.nodes[fnode];
+                    const DevNode nd = ld_node(p.nodes + fnode);
                     if (UNI(f.kind) == FK_SET) {
                         int s = nd.sample;
                         __syncthreads();
@@ -1896,7 +2007,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root) {
                         node = fnode;
                         pc = PC_SUB;
                     } else {
-                        node = UNI(p.child_index[nd.child_off + it]);
+                        node = ldc(p.child_index + nd.child_off + it);
                         pc = PC_DESCEND;
                     }
                 } else {
@@ -1952,6 +2063,7 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
     c.mapJ = mapJ; c.mapVaf = mapVaf; c.mapHyp = mapHyp; c.n_slots = n_slots;
     c.status = 0;
     if (lane == 0) { w->work[0] = 0; w->work[1] = 0; }
+    c.need_batch = 0; c.bt_nt = 0; c.bt_inner = 0;
     c.replay = out.replay; c.locus = locus; c.outp = &out; c.mapGroup = 0; c.mapDisc = 0; c.marginal = 0.0;
 #ifdef VLR_PROFILE
     for (int i = 0; i < 24; ++i) c.prof[i] = 0;
@@ -2292,7 +2404,7 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
             int rc_ = 0;
             for (int e = first_ev; e < p.n_named; ++e) {
                 int u = (e < 0) ? 0 : (1 + 2 * e + (h == 0 ? 0 : 1));
-                int r0 = (e < 0) ? 0 : p.root_off[e], r1 = (e < 0) ? 1 : p.root_off[e + 1];
+                int r0 = (e < 0) ? 0 : ldc(p.root_off + e), r1 = (e < 0) ? 1 : ldc(p.root_off + e + 1);
                 for (int ri = r0; ri < r1; ++ri, ++rc_) {
                     const bool probe = (pass == 0) && rc_ < 64;
                     if (pass == 0 && !probe) continue;
@@ -2306,8 +2418,15 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
                     c.curHyp = UNI(mapHyp[u]);
                     if (lane < S) w->curMapVaf[lane] = mapVaf[u * S + lane];
                     __syncthreads();
-                    int root = (e < 0) ? p.absent_root : p.roots[ri];
-                    double dens = uni_d(walk_root(c, root));
+                    int root = (e < 0) ? p.absent_root : ldc(p.roots + ri);
+                    double dens;
+                    for (int resume = 0;; resume = 1) {
+                        dens = uni_d(walk_root(c, root, resume));
+                        if (!c.need_batch) break;
+                        c.need_batch = 0;
+                        run_chain_batch(c, c.bt_nt, c.bt_inner);
+                        __syncthreads();
+                    }
                     if (c.deferred == 1) { c.deferred = 0; continue; }                      // delivered by flush_deferred
                     if (c.deferred == 2) { c.deferred = 0; todo |= 1ull << rc_; continue; } // second pass
                     if (dens != dens) c.status |= VLR_LOCUS_NAN;
