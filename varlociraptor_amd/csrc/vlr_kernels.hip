@@ -63,6 +63,7 @@ struct RangeSt {
 
 constexpr int kRows = 4;        // concurrent chains per wave: one per 16-lane DPP row
 constexpr int kRowPts = 12;     // pending points of one chain round (<= 11)
+constexpr int kPass = 3;        // points one lane carries through a pass over its observation slice
 
 struct ChainTask {              // one innermost Range chain (see run_chain_batch)
     double lo, hi, res, ostart, oend, fixed, result, bestJ, bestX;
@@ -1149,16 +1150,6 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
     int dep = 0;
     for (int s = 0; s < c.S; ++s)
         if (s == inner || p.by[s] == inner) dep |= 1 << s;
-    // the first dependent sample (there is always one: `inner` itself or the sample it contaminates)
-    const int d0 = __builtin_ctz(dep);
-    const int dep_rest = dep & (dep - 1);
-    const int d0_byi = p.by[d0];
-    const bool d0_cont = d0_byi >= 0, d0_is_inner = (d0 == inner), d0_by_inner = (d0_byi == inner);
-    const double d0_rho = p.rho[d0], d0_irho = p.irho[d0];
-    const double d0_a = tvr[d0], d0_b = d0_cont ? tvr[d0_byi] : 0.0;
-    const double* d0_coef = c.coef + 3 * w->soff[d0];
-    const int d0_D = w->nkeep[d0];
-    const bool d0_fast = (w->fastok >> d0) & 1;
     unsigned dep_terms = 0;  // observation terms per point
     for (int s = 0; s < c.S; ++s)
         if ((dep >> s) & 1) dep_terms += (unsigned)w->nkeep[s];
@@ -1210,43 +1201,35 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
         const double x = pend[rl < np ? rl : np - 1];
         double Psel = 1.0;
         int Esel = 0;
-        for (int p0 = 0; p0 < npmax; p0 += 4) {
-            const int cnt = (npmax - p0) < 4 ? (npmax - p0) : 4;
-            double xs[4], P[4];
-            int E[4];
+        for (int p0 = 0; p0 < npmax; p0 += kPass) {
+            const int cnt = (npmax - p0) < kPass ? (npmax - p0) : kPass;
+            double xs[kPass], P[kPass];
+            int E[kPass];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { xs[j] = pend[(p0 + j) < np ? (p0 + j) : np - 1]; P[j] = 1.0; E[j] = 0; }
-            {   // first dependent sample: everything but x hoisted out of the rounds
-                double al[4], be[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const double a = d0_is_inner ? xs[j] : d0_a;
-                    const double b = d0_by_inner ? xs[j] : d0_b;
-                    if (d0_cont) { al[j] = d0_rho * a + d0_irho * b; be[j] = d0_rho * (a == 1.0 ? 1.0 : 0.0) + d0_irho * (b == 1.0 ? 1.0 : 0.0); }
-                    else { al[j] = a; be[j] = (a == 1.0) ? 1.0 : 0.0; }
-                }
-                accum_terms_n<16>(cnt, d0_coef, d0_D, rl, d0_fast, al, be, P, E);
-            }
-            int dm = dep_rest;
+            for (int j = 0; j < kPass; ++j) { xs[j] = pend[(p0 + j) < np ? (p0 + j) : np - 1]; P[j] = 1.0; E[j] = 0; }
+            int dm = dep;
             while (dm) {
-                int s = __builtin_ctz(dm);
+                const int s = __builtin_ctz(dm);
                 dm &= dm - 1;
-                int by = p.by[s];
-                double al[4], be[4];
+                const int by = p.by[s];
+                const double va = tvr[s], vb = by >= 0 ? tvr[by] : 0.0;
+                double al[kPass], be[kPass];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    double a = (s == inner) ? xs[j] : tvr[s];
-                    double b = by >= 0 ? ((by == inner) ? xs[j] : tvr[by]) : 0.0;
+                for (int j = 0; j < kPass; ++j) {
+                    const double a = (s == inner) ? xs[j] : va;
+                    const double b = by >= 0 ? ((by == inner) ? xs[j] : vb) : 0.0;
                     alpha_beta(p, s, a, b, al[j], be[j]);
                 }
-                accum_terms_n<16>(cnt, c.coef + 3 * w->soff[s], w->nkeep[s], rl, (w->fastok >> s) & 1, al, be, P, E);
+                accum_terms_n<16>(cnt, c.coef + 3 * UNI(w->soff[s]), UNI(w->nkeep[s]), rl, (UNI(w->fastok) >> s) & 1, al, be, P, E);
             }
             PROF_ADD(c, 12);  // round: term products
             reduce_terms_n<16>(cnt, P, E);
             const int jr = rl - p0;
-            const double Pm = jr == 1 ? P[1] : jr == 2 ? P[2] : jr == 3 ? P[3] : P[0];
-            const int Em = jr == 1 ? E[1] : jr == 2 ? E[2] : jr == 3 ? E[3] : E[0];
-            const bool mine = jr >= 0 && jr < 4;
+            double Pm = P[0];
+            int Em = E[0];
+#pragma unroll
+            for (int j = 1; j < kPass; ++j) { Pm = (jr == j) ? P[j] : Pm; Em = (jr == j) ? E[j] : Em; }
+            const bool mine = jr >= 0 && jr < kPass;
             Psel = mine ? Pm : Psel;
             Esel = mine ? Em : Esel;
         }
