@@ -167,7 +167,13 @@ template <class T>
 __device__ __forceinline__ T ldc(const T* ptr) { return *ptr; }
 #else
 template <class T>
-__device__ __forceinline__ T ldc(const T* ptr) { return *(const VLR_K4 T*)(uintptr_t)ptr; }
+__device__ __forceinline__ T ldc(const T* ptr) {
+    // the address is wave-uniform by construction; say so even where the compiler's divergence analysis cannot see it
+    const unsigned long long a = (unsigned long long)(uintptr_t)ptr;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    return *(const VLR_K4 T*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+}
 #endif
 __device__ __forceinline__ DevSpectrum ld_spec(const DevSpectrum* g) {
     DevSpectrum s;
@@ -1128,6 +1134,7 @@ __device__ __forceinline__ int row_or(int v) {
 }
 
 __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
+    nt = UNI(nt); inner = UNI(inner);
     PROF_ADD(c, 6);  // batch preparation (task setup, fixed-sample likelihoods)
 #ifdef VLR_PROFILE
     c.prof[10] += 1;
