@@ -51,3 +51,25 @@ def test_cli_reproduces_reference_calls_file(golden_dir):
                 assert a == b, (k, a, b)
         n_identical += same
     assert n_identical >= 5  # most records are character-identical
+
+
+def test_cli_writes_bcf_calls_readable_back(golden_dir, tmp_path):
+    """--output calls.bcf: the binary file decodes to the same records as the text output, and field by field to the
+    reference's own calls.bcf (PROB_* within f32 text rounding)."""
+    from varlociraptor_amd.bcfio import BcfReader
+    d = os.path.join(golden_dir, "flamegraph_profiling")
+    sc = cli.scenario_from_yaml(os.path.join(d, "scenario.yaml"))
+    out = str(tmp_path / "calls.bcf")
+    cli.call_variants(sc, {"normal": os.path.join(d, "normal.bcf")}, omit_mask=abi.BIAS_ALL, output=out)
+    got = list(BcfReader(out))
+    ref = list(BcfReader(os.path.join(d, "calls.bcf")))
+    assert len(got) == len(ref) == 11
+    for g, r in zip(got, ref):
+        assert (g["chrom"], g["pos"], g["ref"], g["alt"]) == (r["chrom"], r["pos"], r["ref"], r["alt"])
+        assert list(g["info"]) == list(r["info"])
+        for k in r["info"]:
+            for a, b in zip(g["info"][k], r["info"][k]):
+                assert a == b or abs(a - b) <= 3e-6 * max(1.0, abs(b))
+        assert g["format"]["DP"] == r["format"]["DP"] and g["format"]["AF"] == r["format"]["AF"]
+        assert g["format"]["OOBS"] == r["format"]["OOBS"]
+        assert tokens(g["format"]["OBS"][0]) == tokens(r["format"]["OBS"][0])

@@ -188,3 +188,38 @@ def test_bcf_reader_reads_the_reference_calls_file(golden_dir):
     assert len(recs) == 11 and recs[0]["pos"] == 10469 and recs[0]["alt"] == "<METH>"
     assert recs[0]["info"]["PROB_ABSENT"][0] == pytest.approx(285.541, rel=1e-6)
     assert recs[0]["info"]["PROB_PRESENT"][0] == 0.0
+
+
+def test_bcf_writer_matches_reference_encoding(tmp_path):
+    """Re-encoding the reference's calls.vcf text with the reference calls.bcf header gives records of identical
+    layout (descriptor bytes, integer widths, string padding, dictionary indices); only f32 payload bytes may differ
+    because the text carries 6 significant digits."""
+    import struct
+    from varlociraptor_amd.bcfio import BcfReader, BcfWriter
+    g = os.path.join(os.path.dirname(__file__), "golden", "flamegraph_profiling")
+    recs = [l for l in open(os.path.join(g, "calls.vcf")).read().split("\n") if l and not l.startswith("#")]
+    ref = BcfReader(os.path.join(g, "calls.bcf"))
+    path = str(tmp_path / "re.bcf")
+    with BcfWriter(path, ref.header_text) as w:
+        for r in recs:
+            w.write_line(r)
+    mine = BcfReader(path)
+
+    def raw(r):
+        p, out = r.pos, []
+        while p + 8 <= len(r.buf):
+            a, b = struct.unpack_from("<II", r.buf, p)
+            out.append(r.buf[p:p + 8 + a + b])
+            p += 8 + a + b
+        return out
+    A, B = raw(ref), raw(mine)
+    assert len(A) == len(B) == 11
+    for x, y in zip(A, B):
+        assert len(x) == len(y)
+        assert sum(1 for i in range(len(x)) if x[i] != y[i]) <= 6  # low bytes of the PROB_* floats
+    a, b = list(ref), list(mine)
+    for ra, rb in zip(a, b):
+        assert ra["format"] == rb["format"] and ra["pos"] == rb["pos"] and ra["alt"] == rb["alt"]
+        for k in ra["info"]:
+            va, vb = ra["info"][k], rb["info"][k]
+            assert all((x == y) or abs(x - y) <= 1e-3 * max(1.0, abs(x)) for x, y in zip(va, vb))

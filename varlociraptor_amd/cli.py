@@ -55,7 +55,7 @@ def scenario_from_yaml(path: str) -> Scenario:
 
 
 def call_variants(scenario: Scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_capacity: int = 128, out=sys.stdout,
-                  device: int = 0):
+                  device: int = 0, output: str = None):
     paths = []
     for name in scenario.sample_names:
         if name not in obs_paths:
@@ -69,9 +69,20 @@ def call_variants(scenario: Scenario, obs_paths: Dict[str, str], omit_mask: int 
     res = plan.call_host(batch, afd_capacity=afd_capacity)
     plan.close()
     names = scenario.out_names()
-    print(callsfmt.header(names, scenario.sample_names, sorted(set(s[0] for s in sites))), file=out)
+    header = callsfmt.header(names, scenario.sample_names, sorted(set(s[0] for s in sites)))
+    if output and output.endswith(".bcf"):  # binary calls file (reference: bcf::Writer, calling.rs:296-304)
+        from .bcfio import BcfWriter
+        with BcfWriter(output, header) as wr:
+            for l, site in enumerate(sites):
+                wr.write_line(callsfmt.format_record(site, batch, res, l, names, scenario.sample_names))
+        return res
+    if output:
+        out = open(output, "w")
+    print(header, file=out)
     for l, site in enumerate(sites):
         print(callsfmt.format_record(site, batch, res, l, names, scenario.sample_names), file=out)
+    if output:
+        out.close()
     return res
 
 
@@ -86,6 +97,7 @@ def main(argv=None):
         variants.add_argument(flag, action="store_const", const=bit, default=0)
     variants.add_argument("--full-prior", action="store_true")
     variants.add_argument("--device", type=int, default=0)
+    variants.add_argument("--output", help="calls file (.bcf = BCF2, anything else text VCF; default stdout)")
     mode = variants.add_subparsers(dest="mode", required=True)
     g = mode.add_parser("generic")
     g.add_argument("--scenario", required=True)
@@ -132,7 +144,7 @@ def main(argv=None):
         sc = tumor_normal(a.purity)
         obs = {"tumor": a.tumor, "normal": a.normal}
     sc.full_prior = a.full_prior
-    call_variants(sc, obs, omit_mask=omit, device=a.device)
+    call_variants(sc, obs, omit_mask=omit, device=a.device, output=a.output)
 
 
 if __name__ == "__main__":
