@@ -58,8 +58,9 @@ def test_formula_parser():
     assert type(f).__name__ == "Disj" and len(f.operands) == 2
     assert parse_formula("A>T").refbase == "A"
     assert type(parse_formula("!tumor:0.5")).__name__ == "Neg"
-    with pytest.raises(NotImplementedError):
-        parse_formula("$expr & tumor:0.5")
+    assert type(parse_formula("$loh & tumor:0.5").operands[0]).__name__ == "ExprRef"
+    with pytest.raises(ValueError):
+        parse_formula("$ & tumor:0.5")
 
 
 def test_negation_uses_the_universe():
@@ -70,10 +71,11 @@ def test_negation_uses_the_universe():
     roots = sc.vaftree("a")
     assert len(roots) == 1 and roots[0].sample == 0 and roots[0].vafs == VAFSet((0.5, 1.0))
     roots = sc.vaftree("b")
-    assert roots[0].sample == 0
-    kids = roots[0].children
+    # the normal form is a disjunction of conjunctions: one root per complement piece, each m:0.0 -> t:<piece>
+    assert [r.sample for r in roots] == [0, 0]
+    kids = [r.children[0] for r in roots]
     # VAFRange::split_at always makes the right part left-exclusive (formula.rs:1099-1129), so 0.5 itself is dropped
-    assert [k.vafs for k in kids] == [VAFRange(0.0, 0.2, False, True), VAFRange(0.5, 1.0, True, False)]
+    assert sorted((k.vafs for k in kids), key=lambda v: v.start) == [VAFRange(0.0, 0.2, False, True), VAFRange(0.5, 1.0, True, False)]
 
 
 def test_synth_is_deterministic_and_well_formed():
@@ -223,3 +225,42 @@ def test_bcf_writer_matches_reference_encoding(tmp_path):
         for k in ra["info"]:
             va, vb = ra["info"][k], rb["info"][k]
             assert all((x == y) or abs(x - y) <= 1e-3 * max(1.0, abs(x)) for x, y in zip(va, vb))
+
+
+# ---- Formula::normalize: the reference's own unit tests (grammar/formula.rs:1601-1735) -----------------------------
+def test_formula_range_conjunction():
+    from varlociraptor_amd.scenario import Conj, Sample, Scenario, parse_formula
+    sc = Scenario({"normal": Sample(resolution=0.01, universe="[0.0,1.0]")}, {"full": "normal:[0.0,1.0]"})
+    conj = Conj([parse_formula("normal:[0.0,0.7]"), parse_formula("normal:[0.3,1.0]")])
+    assert sc.canonical(conj) == sc.canonical("normal:[0.3,0.7]")
+    assert sc.canonical(conj) != sc.canonical("normal:[0.0,1.0]")
+
+
+def test_formula_nested_range_disjunction():
+    from varlociraptor_amd.scenario import Sample, Scenario
+    sc = Scenario({"normal": Sample(resolution=0.01, universe="[0.0,1.0]")}, {"full": "normal:[0.0,1.0]"})
+    full = "(normal:[0.0, 0.25] | normal:[0.5,0.75]) | (normal:[0.25,0.5] | normal:[0.75,1.0]) | normal:[0.1,0.4] | normal:0.1"
+    assert sc.canonical(full) == sc.canonical("normal:[0.0,1.0]")
+
+
+def test_formula_two_separate_range_disjunctions():
+    from varlociraptor_amd.scenario import Sample, Scenario
+    sc = Scenario({"normal": Sample(resolution=0.01, universe="[0.0,1.0]")}, {"full": "normal:[0.0,1.0]"})
+    full = "(normal:[0.0, 0.25] | normal:[0.5,0.6]) | ((normal:[0.25,0.5] | normal:[0.7,0.9]) | normal:[0.9,1.0]) | normal:]0.8,0.9[ | normal:0.75"
+    assert sc.canonical(full) == sc.canonical("normal:[0.0,0.6] | normal:[0.7,1.0]")
+
+
+def test_formula_merge_atoms_with_expressions_and_negation():
+    from varlociraptor_amd import abi
+    from varlociraptor_amd.scenario import Contamination, Inheritance, Sample, Scenario, Species
+    sp = Species(heterozygosity=0.001, germline_mutation_rate=1e-3, somatic_effective_mutation_rate=None, ploidy=2)
+    sc = Scenario(
+        {"tumor": Sample(resolution=0.01, somatic_effective_mutation_rate=1e-6, inheritance=Inheritance(abi.INHERIT_CLONAL, ("normal",), False),
+                         contamination=Contamination("normal", 0.11)),
+         "normal": Sample(resolution=0.01, somatic_effective_mutation_rate=1e-10)},
+        {"germline": "(normal:0.5 | normal:1.0) & !($loh | $loh_or_amplification)",
+         "expected": "(normal:0.5 & tumor:{0.0, 0.5}) | (normal:0.5 & tumor:]0.0,0.5[) | (normal:0.5 & tumor:]0.5,0.9[) | normal:1.0"},
+        species=sp, expressions={"loh": "normal:0.5 & tumor:1.0", "loh_or_amplification": "normal:0.5 & tumor:[0.9,1.0["})
+    assert sc.canonical(sc.events["germline"]) == sc.canonical(sc.events["expected"])
+    with pytest.raises(ValueError):
+        sc.canonical("$undefined & normal:0.5")

@@ -18,8 +18,6 @@ def scenario_from_yaml(path: str) -> Scenario:
     import yaml
     with open(path) as fh:
         y = yaml.safe_load(fh)
-    if "expressions" in y and y["expressions"]:
-        raise NotImplementedError("scenario expressions need the full grammar front-end (SURVEY §8f #3)")
     species = None
     if y.get("species"):
         sp = y["species"]
@@ -51,7 +49,7 @@ def scenario_from_yaml(path: str) -> Scenario:
             contamination=Contamination(cont["by"], float(cont["fraction"])) if cont else None, ploidy=sd.get("ploidy"),
             somatic_effective_mutation_rate=sd.get("somatic-effective-mutation-rate"),
             germline_mutation_rate=sd.get("germline-mutation-rate"), inheritance=inheritance)
-    return Scenario(samples, dict(y["events"]), species=species)
+    return Scenario(samples, dict(y["events"]), species=species, expressions=dict(y.get("expressions") or {}))
 
 
 def call_variants(scenario: Scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_capacity: int = 128, out=sys.stdout,

@@ -119,8 +119,14 @@ _CMP = {"==": abi.CMP_EQUAL, ">": abi.CMP_GREATER, ">=": abi.CMP_GREATER_EQUAL, 
         "<=": abi.CMP_LESS_EQUAL, "!=": abi.CMP_NOT_EQUAL}
 
 
+@dataclass(frozen=True)
+class ExprRef:
+    """`$identifier` (formula.pest: expression); expanded from Scenario.expressions before normalisation."""
+    identifier: str
+
+
 class _Parser:
-    """Recursive-descent parser for the negation-free subset of formula.pest."""
+    """Recursive-descent parser for formula.pest."""
 
     def __init__(self, text: str):
         self.s = text.replace(" ", "")
@@ -163,7 +169,11 @@ class _Parser:
             self.i += 1
             return Neg(self.sub())
         if self.peek() == "$":
-            raise NotImplementedError("$expression needs the full grammar front-end (SURVEY §8f #3)")
+            m = re.match(r"\$([\w.\-]+)", self.s[self.i:])
+            if not m:
+                raise ValueError("invalid expression reference at %r" % self.s[self.i:])
+            self.i += m.end()
+            return ExprRef(m.group(1))
         if self.s.startswith("l2fc(", self.i):
             m = re.match(r"l2fc\(([\w.\-]+),([\w.\-]+)\)(<=|<|>=|>|!=|==)(-?\d+(?:\.\d*)?(?:[eE][+-]?\d+)?)", self.s[self.i:])
             if not m:
@@ -262,7 +272,7 @@ class Scenario:
     """grammar::Scenario for one contig.  `events` maps name -> formula string or normalized AST."""
 
     def __init__(self, samples: Dict[str, Sample], events: Dict[str, object], species: Optional[Species] = None,
-                 full_prior: bool = False):
+                 full_prior: bool = False, expressions: Optional[Dict[str, object]] = None):
         self.samples = dict(sorted(samples.items()))  # BTreeMap order
         self.sample_names = list(self.samples.keys())
         self.idx = {n: i for i, n in enumerate(self.sample_names)}
@@ -272,6 +282,7 @@ class Scenario:
         self.full_prior = full_prior
         self.events = dict(sorted(events.items()))  # BTreeMap order (grammar/mod.rs:137)
         self.event_names = list(self.events.keys())
+        self.expressions = dict(expressions or {})
         self._keep = []
 
     # Sample::contig_ploidy (grammar/mod.rs:581-593)
@@ -498,12 +509,218 @@ class Scenario:
             return type(f)(ops)
         return f
 
-    def vaftree(self, event: str) -> List[_TNode]:
-        f = self.events[event]
+    # ---- Formula::normalize (grammar/formula.rs:473-485): expand expressions, push negations into the atoms, simplify,
+    # merge the atoms of one sample, simplify again, strip false, sort.  `simplify` stands in for the reference's
+    # BDD round trip (boolean_expression::Expr::simplify_via_bdd, third-party): after apply_negations every formula is
+    # monotone in its terminals, and the minimal cover of a monotone function is its set of prime implicants, i.e.
+    # distribution into a disjunction of conjunctions plus absorption.
+    def _expand(self, f, depth=0):
+        if depth > 64:
+            raise ValueError("cyclic scenario expressions")
+        if isinstance(f, ExprRef):
+            if f.identifier not in self.expressions:
+                raise ValueError("undefined expression %r" % f.identifier)  # errors::Error::UndefinedExpression
+            e = self.expressions[f.identifier]
+            if isinstance(e, str):
+                e = parse_formula(e)
+            return self._expand(e, depth + 1)
+        if isinstance(f, Conj):
+            return Conj([self._expand(o, depth) for o in f.operands])
+        if isinstance(f, Disj):
+            return Disj([self._expand(o, depth) for o in f.operands])
+        if isinstance(f, Neg):
+            return Neg(self._expand(f.operand, depth))
+        return f
+
+    @staticmethod
+    def _lit_key(o):
+        if isinstance(o, Atom):
+            v = o.vafs
+            return ("atom", o.sample, ("set",) + tuple(v.vafs) if isinstance(v, VAFSet) else ("range", v.start, v.end, v.left_exclusive, v.right_exclusive))
+        if isinstance(o, Variant):
+            return ("variant", o.positive, o.refbase, o.altbase)
+        if isinstance(o, Lfc):
+            return ("lfc", o.sample_a, o.sample_b, o.cmp, o.value)
+        raise TypeError(o)
+
+    @classmethod
+    def _cubes(cls, f) -> List[List[object]]:
+        """Disjunction of conjunctions of terminals: [] = false, [[]] = true."""
+        if isinstance(f, Const):
+            return [[]] if f.value else []
+        if isinstance(f, Disj):
+            out = []
+            for o in f.operands:
+                out.extend(cls._cubes(o))
+            return out
+        if isinstance(f, Conj):
+            acc = [[]]
+            for o in f.operands:
+                nxt = []
+                for a in acc:
+                    for b in cls._cubes(o):
+                        cube, seen = [], set()
+                        for lit in a + b:
+                            k = cls._lit_key(lit)
+                            if k not in seen:
+                                seen.add(k)
+                                cube.append(lit)
+                        nxt.append(cube)
+                acc = nxt
+            return acc
+        return [[f]]
+
+    @classmethod
+    def _simplify(cls, f):
+        cubes = cls._cubes(f)
+        keyed = [(frozenset(cls._lit_key(l) for l in c), c) for c in cubes]
+        out = []
+        for i, (ki, ci) in enumerate(keyed):
+            absorbed = False
+            for j, (kj, _) in enumerate(keyed):
+                if i != j and (kj < ki or (kj == ki and j < i)):  # a proper sub-cube (or an earlier duplicate) covers this one
+                    absorbed = True
+                    break
+            if not absorbed:
+                out.append(ci)
+        if not out:
+            return Const(False)
+        if any(len(c) == 0 for c in out):
+            return Const(True)
+        terms = [c[0] if len(c) == 1 else Conj(list(c)) for c in out]
+        return terms[0] if len(terms) == 1 else Disj(terms)
+
+    @classmethod
+    def _range_and(cls, a: VAFRange, b: VAFRange) -> VAFRange:  # `&` (formula.rs:1268-1286)
+        ov = cls._overlap(a, b)
+        if ov in ("Contained", "Equal"):
+            return a
+        if ov == "Contains":
+            return b
+        if ov == "Start":
+            return VAFRange(a.start, b.end, a.left_exclusive, b.right_exclusive)
+        if ov == "End":
+            return VAFRange(b.start, a.end, b.left_exclusive, a.right_exclusive)
+        return VAFRange(0.0, 0.0, True, True)
+
+    @classmethod
+    def _range_or(cls, a: VAFRange, b: VAFRange) -> VAFRange:  # `|` (formula.rs:1288-1306), overlapping operands only
+        ov = cls._overlap(a, b)
+        if ov == "Contained":
+            return b
+        if ov in ("Contains", "Equal"):
+            return a
+        if ov == "Start":
+            return VAFRange(b.start, a.end, b.left_exclusive, a.right_exclusive)
+        return VAFRange(a.start, b.end, a.left_exclusive, b.right_exclusive)  # End
+
+    @staticmethod
+    def _spec_empty(v: Spectrum) -> bool:
+        if isinstance(v, VAFSet):
+            return len(v.vafs) == 0
+        return v.start == v.end and (v.left_exclusive or v.right_exclusive)
+
+    @classmethod
+    def _merge_conj(cls, a: Spectrum, b: Spectrum) -> Spectrum:  # FormulaTerminal::merge_conjunctions (127-168)
+        if isinstance(a, VAFRange) and isinstance(b, VAFRange):
+            r = cls._range_and(a, b)
+            if r.start == r.end and not (r.left_exclusive or r.right_exclusive):
+                return VAFSet((a.start,))
+            return r
+        if isinstance(a, VAFRange):
+            return VAFSet(tuple(v for v in b.vafs if cls._contains(a, v)))
+        if isinstance(b, VAFRange):
+            return VAFSet(tuple(v for v in a.vafs if cls._contains(b, v)))
+        return VAFSet(tuple(v for v in a.vafs if v in b.vafs))
+
+    @classmethod
+    def _try_merge_disj(cls, a: Spectrum, b: Spectrum) -> Optional[Spectrum]:  # try_merge_disjunction (170-210)
+        if isinstance(a, VAFRange) and isinstance(b, VAFRange):
+            return None if cls._overlap(a, b) == "None" else cls._range_or(a, b)
+        if isinstance(a, VAFRange):
+            return a if all(cls._contains(a, v) for v in b.vafs) else None
+        if isinstance(b, VAFRange):
+            return b if all(cls._contains(b, v) for v in a.vafs) else None
+        return VAFSet(tuple(sorted(set(a.vafs) | set(b.vafs))))
+
+    @classmethod
+    def _merge_atoms(cls, f):  # formula.rs:575-689
+        if isinstance(f, Conj):
+            groups: Dict[Optional[str], list] = {}
+            for o in f.operands:
+                groups.setdefault(o.sample if isinstance(o, Atom) else None, []).append(o)
+            ops = []
+            for sample, stmts in groups.items():
+                if sample is None:
+                    ops.extend(cls._merge_atoms(o) for o in stmts)
+                    continue
+                merged = stmts[-1].vafs
+                for o in stmts[:-1]:
+                    merged = cls._merge_conj(merged, o.vafs)
+                if cls._spec_empty(merged):
+                    return Const(False)
+                ops.append(Atom(sample, merged))
+            return Conj(ops)
+        if isinstance(f, Disj):
+            groups = {}
+            for o in f.operands:
+                groups.setdefault(o.sample if isinstance(o, Atom) else None, []).append(o)
+            ops = []
+            for sample, stmts in groups.items():
+                if sample is None:
+                    ops.extend(cls._merge_atoms(o) for o in stmts)
+                    continue
+                stmts = sorted(stmts, key=lambda a: min(a.vafs.vafs) if isinstance(a.vafs, VAFSet) and a.vafs.vafs else (a.vafs.start if isinstance(a.vafs, VAFRange) else -1.0))
+                cur = stmts[0].vafs
+                for o in stmts[1:]:
+                    m = cls._try_merge_disj(cur, o.vafs)
+                    if m is not None:
+                        cur = m
+                    else:
+                        ops.append(Atom(sample, cur))
+                        cur = o.vafs
+                ops.append(Atom(sample, cur))
+            return Disj(ops)
+        if isinstance(f, Neg):
+            return Neg(cls._merge_atoms(f.operand))
+        return f
+
+    @staticmethod
+    def _strip_false(f):  # formula.rs:691-707
+        if isinstance(f, Disj):
+            keep = []
+            for o in f.operands:
+                if isinstance(o, Const) and not o.value:
+                    continue
+                if isinstance(o, Conj) and any(isinstance(x, Const) and not x.value for x in o.operands):
+                    continue
+                keep.append(o)
+            return Disj(keep)
+        return f
+
+    def normalize(self, f):
         if isinstance(f, str):
             f = parse_formula(f)
-        f = self._flatten(self._apply_negations(f))
-        roots = self._from(f)
+        f = self._apply_negations(self._expand(f))
+        f = self._simplify(self._merge_atoms(self._simplify(f)))
+        return self._strip_false(f)
+
+    def canonical(self, f) -> tuple:
+        """Order-independent rendering of a normalised formula (what Formula::sort + derive(Eq) compare)."""
+        f = self.normalize(f)
+
+        def canon(o):
+            if isinstance(o, Conj):
+                return ("and", tuple(sorted(canon(x) for x in o.operands)))
+            if isinstance(o, Disj):
+                return ("or", tuple(sorted(canon(x) for x in o.operands)))
+            if isinstance(o, Const):
+                return ("const", o.value)
+            return self._lit_key(o)
+        return canon(f)
+
+    def vaftree(self, event: str) -> List[_TNode]:
+        roots = self._from(self.normalize(self.events[event]))
         for r in roots:
             self._add_missing(r, set())
         return roots
