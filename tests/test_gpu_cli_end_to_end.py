@@ -73,3 +73,39 @@ def test_cli_writes_bcf_calls_readable_back(golden_dir, tmp_path):
         assert g["format"]["DP"] == r["format"]["DP"] and g["format"]["AF"] == r["format"]["AF"]
         assert g["format"]["OOBS"] == r["format"]["OOBS"]
         assert tokens(g["format"]["OBS"][0]) == tokens(r["format"]["OBS"][0])
+
+
+def test_cli_contig_specific_scenario_uses_one_plan_per_resolution(golden_dir, tmp_path):
+    """Records on two contigs with different universes: every record is evaluated under its contig's scenario and the
+    results come back in input order."""
+    import numpy as np
+    d = os.path.join(golden_dir, "flamegraph_profiling")
+    lines = open(os.path.join(d, "normal.vcf")).read().split("\n")
+    out, k = [], 0
+    for l in lines:
+        if l and not l.startswith("#"):
+            f = l.split("\t")
+            if k % 2:
+                f[0] = "X"
+            k += 1
+            l = "\t".join(f)
+        out.append(l)
+        if l.startswith("##contig=<ID=1"):
+            out.append(l.replace("ID=1", "ID=X"))
+    obs = tmp_path / "two_contigs.vcf"
+    obs.write_text("\n".join(out))
+    y = tmp_path / "s.yaml"
+    y.write_text('samples:\n  normal:\n    resolution: 0.1\n    universe: {all: "[0.0,1.0]", X: "{0.0,1.0}"}\nevents:\n  present: "normal:]0.0,1.0]"\n')
+    ya = tmp_path / "a.yaml"
+    ya.write_text('samples:\n  normal:\n    resolution: 0.1\n    universe: "[0.0,1.0]"\nevents:\n  present: "normal:]0.0,1.0]"\n')
+    yx = tmp_path / "x.yaml"
+    yx.write_text('samples:\n  normal:\n    resolution: 0.1\n    universe: "{0.0,1.0}"\nevents:\n  present: "normal:]0.0,1.0]"\n')
+    mixed = cli.call_variants(lambda c: cli.scenario_from_yaml(str(y), c), {"normal": str(obs)}, out=io.StringIO())
+    plain_a = cli.call_variants(cli.scenario_from_yaml(str(ya)), {"normal": str(obs)}, out=io.StringIO())
+    plain_x = cli.call_variants(cli.scenario_from_yaml(str(yx)), {"normal": str(obs)}, out=io.StringIO())
+    assert k == 11
+    for l in range(k):
+        want = plain_x if l % 2 else plain_a
+        assert np.array_equal(mixed.ln_posterior[l], want.ln_posterior[l], equal_nan=True)
+        assert np.array_equal(mixed.map_vaf[l], want.map_vaf[l], equal_nan=True)
+    assert not np.array_equal(plain_a.ln_posterior, plain_x.ln_posterior)

@@ -264,3 +264,37 @@ def test_formula_merge_atoms_with_expressions_and_negation():
     assert sc.canonical(sc.events["germline"]) == sc.canonical(sc.events["expected"])
     with pytest.raises(ValueError):
         sc.canonical("$undefined & normal:0.5")
+
+
+def test_scenario_yaml_contig_and_sex_specific_definitions(tmp_path):
+    """UniverseDefinition / PloidyDefinition maps and SexPloidyDefinition (grammar/mod.rs:280-345, 503-593)."""
+    from varlociraptor_amd import cli
+    y = tmp_path / "s.yaml"
+    y.write_text("""
+species:
+  heterozygosity: 0.001
+  ploidy:
+    male: {all: 2, X: 1, Y: 1}
+    female: {all: 2, X: 2, Y: 0}
+samples:
+  father: {sex: male}
+  mother: {sex: female, ploidy: {all: 2, MT: 1}}
+  tumor:
+    sex: female
+    resolution: 0.05
+    universe: {all: "[0.0,1.0]", X: "{0.0,1.0}"}
+events:
+  e: "father:0.5"
+""")
+    sc = cli.scenario_from_yaml(str(y), "1")
+    assert (sc.samples["father"].ploidy, sc.samples["mother"].ploidy, sc.samples["tumor"].universe) == (2, 2, "[0.0,1.0]")
+    sc = cli.scenario_from_yaml(str(y), "X")
+    assert (sc.samples["father"].ploidy, sc.samples["mother"].ploidy, sc.samples["tumor"].universe) == (1, 2, "{0.0,1.0}")
+    assert cli.scenario_from_yaml(str(y), "Y").samples["father"].ploidy == 1
+    assert cli.scenario_from_yaml(str(y), "MT").samples["mother"].ploidy == 1
+    y.write_text("species: {ploidy: {male: 2, female: 2}}\nsamples: {a: {}}\nevents: {e: 'a:0.5'}\n")
+    with pytest.raises(ValueError):
+        cli.scenario_from_yaml(str(y), "1")  # sex specific ploidy but no sex in the sample
+    y.write_text("samples: {a: {universe: {X: '[0.0,1.0]'}}}\nevents: {e: 'a:0.5'}\n")
+    with pytest.raises(ValueError):
+        cli.scenario_from_yaml(str(y), "1")  # UniverseContigNotFound

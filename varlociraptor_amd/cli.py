@@ -14,19 +14,29 @@ from . import abi, callsfmt, engine, obsfmt
 from .scenario import Contamination, Inheritance, Sample, Scenario, Species, tumor_normal
 
 
-def scenario_from_yaml(path: str) -> Scenario:
+def _contig_value(defn, contig: str, what: str):
+    """PloidyDefinition / UniverseDefinition (grammar/mod.rs:280-312, 503-523): a plain value or a contig map with `all`."""
+    if isinstance(defn, dict):
+        if contig in defn:
+            return defn[contig]
+        if "all" in defn:
+            return defn["all"]
+        raise ValueError("%s for contig %r not found and no 'all' entry" % (what, contig))  # Ploidy/UniverseContigNotFound
+    return defn
+
+
+def scenario_from_yaml(path: str, contig: str = "all") -> Scenario:
+    """Scenario as `Caller::configure_model` sees it on `contig` (calling.rs:632-718): contig maps of universes and
+    ploidies and sex-specific species ploidies (grammar/mod.rs:314-345) are resolved here."""
     import yaml
     with open(path) as fh:
         y = yaml.safe_load(fh)
     species = None
-    if y.get("species"):
-        sp = y["species"]
-        ploidy = sp.get("ploidy")
-        if isinstance(ploidy, dict):
-            raise NotImplementedError("sex/contig specific ploidy maps: pass a per-contig scenario")
+    sp = y.get("species") or None
+    if sp:
         vf = sp.get("variant-fractions", {}) or {}
         species = Species(heterozygosity=sp.get("heterozygosity"), germline_mutation_rate=sp.get("germline-mutation-rate"),
-                          somatic_effective_mutation_rate=sp.get("somatic-effective-mutation-rate"), ploidy=ploidy,
+                          somatic_effective_mutation_rate=sp.get("somatic-effective-mutation-rate"), ploidy=None,
                           fraction_indel=vf.get("indel", 0.0125), fraction_mnv=vf.get("mnv", 0.001), fraction_sv=vf.get("sv", 0.01))
     samples: Dict[str, Sample] = {}
     for name, sd in y["samples"].items():
@@ -42,43 +52,99 @@ def scenario_from_yaml(path: str) -> Scenario:
             elif "subclonal" in inh:
                 inheritance = Inheritance(abi.INHERIT_SUBCLONAL, (inh["subclonal"]["from"],))
         universe = sd.get("universe")
-        if isinstance(universe, dict):
-            raise NotImplementedError("contig specific universes: pass a per-contig scenario")
+        if universe is not None:
+            universe = _contig_value(universe, contig, "universe")
+        # Sample::contig_ploidy (grammar/mod.rs:581-593): the sample's own definition wins over the species'
+        ploidy = sd.get("ploidy")
+        if ploidy is not None:
+            ploidy = int(_contig_value(ploidy, contig, "ploidy"))
+        elif sp and sp.get("ploidy") is not None:
+            pd = sp["ploidy"]
+            if isinstance(pd, dict) and set(pd) <= {"male", "female"}:  # SexPloidyDefinition::Specific
+                sex = sd.get("sex")
+                if sex is None:
+                    raise ValueError("sex specific ploidy definition found but no sex specified in sample %r" % name)
+                if sex not in pd:
+                    raise ValueError("ploidy definition for %s not found" % sex)
+                pd = pd[sex]
+            ploidy = int(_contig_value(pd, contig, "ploidy"))
         samples[name] = Sample(
             resolution=float(sd.get("resolution", 0.01)), universe=universe,
-            contamination=Contamination(cont["by"], float(cont["fraction"])) if cont else None, ploidy=sd.get("ploidy"),
+            contamination=Contamination(cont["by"], float(cont["fraction"])) if cont else None, ploidy=ploidy,
             somatic_effective_mutation_rate=sd.get("somatic-effective-mutation-rate"),
             germline_mutation_rate=sd.get("germline-mutation-rate"), inheritance=inheritance)
     return Scenario(samples, dict(y["events"]), species=species, expressions=dict(y.get("expressions") or {}))
 
 
-def call_variants(scenario: Scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_capacity: int = 128, out=sys.stdout,
+def _scenario_signature(sc: Scenario):
+    return tuple((n, s.universe, s.ploidy) for n, s in sc.samples.items())
+
+
+def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_capacity: int = 128, out=sys.stdout,
                   device: int = 0, output: str = None):
-    paths = []
-    for name in scenario.sample_names:
-        if name not in obs_paths:
-            raise SystemExit("no observations given for sample %r" % name)
-        paths.append(obs_paths[name])
-    for name in obs_paths:
-        if name not in scenario.sample_names:
-            raise SystemExit("invalid observation sample name %r" % name)  # errors::Error::InvalidObservationSampleName
+    """`scenario`: a Scenario, or a callable contig -> Scenario (contig-specific universes / ploidies: one plan per
+    distinct resolution, as the reference re-configures its model on contig change, calling.rs:343-356)."""
+    per_contig = scenario if callable(scenario) else (lambda contig: scenario)
+    scen: Dict[str, Scenario] = {}
+
+    def resolve(contig):
+        if contig not in scen:
+            sc = per_contig(contig)
+            for name in sc.sample_names:
+                if name not in obs_paths:
+                    raise SystemExit("no observations given for sample %r" % name)
+            for name in obs_paths:
+                if name not in sc.sample_names:
+                    raise SystemExit("invalid observation sample name %r" % name)  # errors::Error::InvalidObservationSampleName
+            scen[contig] = sc
+        return scen[contig]
+
+    # samples are ordered by name (BTreeMap, grammar/mod.rs:137), independent of the contig
+    sample_order = scenario.sample_names if not callable(scenario) else sorted(obs_paths)
+    paths = [obs_paths[name] for name in sample_order if name in obs_paths]
+    if not callable(scenario):
+        resolve("all")
+        scen.clear()
     batch, sites = obsfmt.read_observation_vcf(paths, omit_bias_mask=omit_mask)
-    plan = engine.Plan(scenario, device=device)
-    res = plan.call_host(batch, afd_capacity=afd_capacity)
-    plan.close()
-    names = scenario.out_names()
-    header = callsfmt.header(names, scenario.sample_names, sorted(set(s[0] for s in sites)))
+    from .batch import CallResults
+    import numpy as np
+    groups: Dict[tuple, List[int]] = {}
+    for l, site in enumerate(sites):
+        sc = resolve(site[0])
+        groups.setdefault(_scenario_signature(sc), []).append(l)
+    res = None
+    names = None
+    for sig, loci in groups.items():
+        sc = resolve(sites[loci[0]][0])
+        plan = engine.Plan(sc, device=device)
+        sub = batch if len(loci) == batch.n_loci else batch.select(loci)
+        r = plan.call_host(sub, afd_capacity=afd_capacity)
+        plan.close()
+        if names is None:
+            names = sc.out_names()
+        if len(loci) == batch.n_loci:
+            res = r
+            break
+        if res is None:
+            res = CallResults(batch.n_loci, r.n_out, r.n_samples, afd_capacity)
+        idx = np.asarray(loci)
+        for f in ("ln_posterior", "ln_marginal", "map_vaf", "map_bias", "best_event", "status", "afd_count", "afd_vaf", "afd_lnprob"):
+            a = getattr(res, f)
+            if a is not None:
+                a[idx] = getattr(r, f)
+    scenario0 = resolve(sites[0][0] if sites else "all")
+    header = callsfmt.header(names or scenario0.out_names(), scenario0.sample_names, sorted(set(s[0] for s in sites)))
     if output and output.endswith(".bcf"):  # binary calls file (reference: bcf::Writer, calling.rs:296-304)
         from .bcfio import BcfWriter
         with BcfWriter(output, header) as wr:
             for l, site in enumerate(sites):
-                wr.write_line(callsfmt.format_record(site, batch, res, l, names, scenario.sample_names))
+                wr.write_line(callsfmt.format_record(site, batch, res, l, names, scenario0.sample_names))
         return res
     if output:
         out = open(output, "w")
     print(header, file=out)
     for l, site in enumerate(sites):
-        print(callsfmt.format_record(site, batch, res, l, names, scenario.sample_names), file=out)
+        print(callsfmt.format_record(site, batch, res, l, names, scenario0.sample_names), file=out)
     if output:
         out.close()
     return res
@@ -136,12 +202,18 @@ def main(argv=None):
     omit = (a.omit_strand_bias | a.omit_read_orientation_bias | a.omit_read_position_bias | a.omit_softclip_bias |
             a.omit_homopolymer_artifact_detection | a.omit_alt_locus_bias)
     if a.mode == "generic":
-        sc = scenario_from_yaml(a.scenario)
+        full_prior = a.full_prior
+
+        def sc(contig, _path=a.scenario):
+            r = scenario_from_yaml(_path, contig)
+            r.full_prior = full_prior
+            return r
         obs = dict(kv.split("=", 1) for kv in a.obs)
     else:
         sc = tumor_normal(a.purity)
         obs = {"tumor": a.tumor, "normal": a.normal}
-    sc.full_prior = a.full_prior
+    if not callable(sc):
+        sc.full_prior = a.full_prior
     call_variants(sc, obs, omit_mask=omit, device=a.device, output=a.output)
 
 
