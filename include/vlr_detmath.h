@@ -1,5 +1,5 @@
 /*
- * vlr_detmath.h — platform-independent exp / log1p for the *decision* arithmetic of the bias gating.
+ * vlr_detmath.h — platform-independent exp / log1p / log2-ratio for the *decision* arithmetic (bias gating, l2fc predicates).
  *
  * Why: StrandBias::estimate_forward_rate (reference src/variants/model/bias/strand_bias.rs:79-123) and
  * ReadPositionBias::has_valid_major_rate (read_position_bias.rs:63-122) compare ratios of
@@ -19,6 +19,12 @@
 #define VLR_HD __host__ __device__
 #else
 #define VLR_HD
+#endif
+
+/* no fused contraction of a*b+c beyond the explicit fma()s below: results must not depend on whether the target has FMA
+ * (gfx950 does, the oracle's x86-64-v2 build does not).  GCC: build with -ffp-contract=off (oracle/Makefile). */
+#if defined(__clang__)
+#pragma clang fp contract(off)
 #endif
 
 namespace vlr_det {
@@ -82,6 +88,54 @@ VLR_HD inline double det_log1p_pos(double s) {
     const double ln2_lo = 0x1.a39ef35793c76p-33;
     double de = (double)e;
     return __builtin_fma(de, ln2_hi, __builtin_fma(de, ln2_lo, lnm));
+}
+
+/* log2(a) - log2(b) for a, b > 0 (utils/log2_fold_change.rs:17-26).  The l2fc predicates compare this value with literal
+ * thresholds, and the VAF bounds inferred from one sample (vaf / 2^value, log2_fold_change.rs:56-93) put the first
+ * integration point of the other sample EXACTLY on the threshold whenever 2^value is a power of two: libm's log2 then
+ * decides by its last-bit rounding whether that end point counts.  Here the binary exponents are subtracted as
+ * integers and only the mantissa parts go through the (deterministic) logarithm, so a ratio of exactly 2^k gives
+ * exactly k on every platform. */
+VLR_HD inline void det_log2_parts(double x, int* e_out, double* frac_out) {
+    int e;
+    double m = __builtin_frexp(x, &e);
+    if (m < 0x1.6a09e667f3bcdp-1) { m = m * 2.0; e -= 1; }
+    double z = (m - 1.0) / (m + 1.0);
+    double w = z * z;
+    double t = 1.0 / 27.0;
+    t = __builtin_fma(t, w, 1.0 / 25.0);
+    t = __builtin_fma(t, w, 1.0 / 23.0);
+    t = __builtin_fma(t, w, 1.0 / 21.0);
+    t = __builtin_fma(t, w, 1.0 / 19.0);
+    t = __builtin_fma(t, w, 1.0 / 17.0);
+    t = __builtin_fma(t, w, 1.0 / 15.0);
+    t = __builtin_fma(t, w, 1.0 / 13.0);
+    t = __builtin_fma(t, w, 1.0 / 11.0);
+    t = __builtin_fma(t, w, 1.0 / 9.0);
+    t = __builtin_fma(t, w, 1.0 / 7.0);
+    t = __builtin_fma(t, w, 1.0 / 5.0);
+    t = __builtin_fma(t, w, 1.0 / 3.0);
+    t = __builtin_fma(t, w, 1.0);
+    const double inv_ln2 = 0x1.71547652b82fep+0;
+    *e_out = e;
+    *frac_out = (2.0 * z * t) * inv_ln2;
+}
+/* 2^v: exact for integral v, otherwise the deterministic exp of v ln 2 (projection of a VAF through an l2fc
+ * predicate, log2_fold_change.rs:58) */
+VLR_HD inline double det_exp2(double v) {
+    if (v == __builtin_rint(v) && v > -1000.0 && v < 1000.0) return __builtin_ldexp(1.0, (int)v);
+    return det_exp(v * 0x1.62e42fefa39efp-1);
+}
+VLR_HD inline double det_log2_ratio(double a, double b) {
+    if (a != a || b != b) return a + b;
+    if (a == 0.0 && b == 0.0) return 0.0;
+    if (a == 0.0) return -__builtin_huge_val();
+    if (b == 0.0) return __builtin_huge_val();
+    int ea, eb;
+    double fa, fb;
+    det_log2_parts(a, &ea, &fa);
+    det_log2_parts(b, &eb, &fb);
+    return (double)(ea - eb) + (fa - fb);
 }
 
 }  /* namespace vlr_det */

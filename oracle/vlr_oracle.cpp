@@ -536,7 +536,7 @@ struct LfcPred {
     double value;
     bool operator==(const LfcPred& o) const { return cmp == o.cmp && value == o.value; }
     bool is_true(double vaf_a, double vaf_b) const {  // 17-26, 41-52
-        double lfc = (vaf_a == 0.0 && vaf_b == 0.0) ? 0.0 : std::log2(vaf_a) - std::log2(vaf_b);
+        double lfc = vlr_det::det_log2_ratio(vaf_a, vaf_b);  // see include/vlr_detmath.h: platform-independent at exact 2^k ratios
         switch (cmp) {
             case VLR_CMP_EQUAL: return relative_eq(lfc, value);
             case VLR_CMP_GREATER: return lfc > value;
@@ -547,7 +547,7 @@ struct LfcPred {
         }
     }
     Range infer_vaf_bounds(double vaf) const {  // 56-93
-        double proj = vaf / std::exp2(value);
+        double proj = vaf / vlr_det::det_exp2(value);  // platform-independent, exact for integral values
         if (proj < 0.0 || proj > 1.0) return Range::empty();
         switch (cmp) {
             case VLR_CMP_EQUAL: return {proj, proj, false, false};

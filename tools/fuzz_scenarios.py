@@ -1,0 +1,111 @@
+"""Randomised scenario fuzzing: GPU engine vs oracle on random event formulas (sets, ranges, negation, disjunctions,
+l2fc terms, contamination) over small random pileups.  usage: python tools/fuzz_scenarios.py [n_scenarios] [seed]"""
+import os
+import sys
+import traceback
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+
+from oracle import oracle
+from parity import compare, describe
+from varlociraptor_amd import abi, engine, synth
+from varlociraptor_amd.scenario import Contamination, Sample, Scenario
+
+SPECTRA = ["0.0", "0.5", "1.0", "{0.0,0.5}", "{0.5,1.0}", "]0.0,1.0]", "]0.0,0.5[", "[0.5,1.0]", "]0.5,1.0[", "[0.0,1.0]", "]0.0,0.25]", "[0.1,0.4]", "]0.2,0.8["]
+
+
+def random_scenario(rng):
+    S = int(rng.choice([1, 2, 2, 3]))
+    names = ["a", "b", "c"][:S]
+    samples = {}
+    for i, n in enumerate(names):
+        cont = None
+        if S > 1 and i == 0 and rng.random() < 0.4:
+            cont = Contamination(names[1], float(rng.choice([0.1, 0.25, 0.5])))
+        samples[n] = Sample(resolution=float(rng.choice([0.1, 0.05, 0.02] if S < 3 else [0.1, 0.2])), universe="[0.0,1.0]", contamination=cont)
+
+    def atom():
+        n = names[int(rng.integers(S))]
+        f = "%s:%s" % (n, SPECTRA[int(rng.integers(len(SPECTRA)))])
+        return "!" + f if rng.random() < 0.15 else f
+
+    def conj():
+        k = int(rng.integers(1, S + 1))
+        used, parts = set(), []
+        for _ in range(k):
+            a = atom()
+            n = a.lstrip("!").split(":")[0]
+            if n in used:
+                continue
+            used.add(n)
+            parts.append(a)
+        if S >= 2 and rng.random() < 0.2:
+            x, y = rng.choice(S, 2, replace=False)
+            parts.append("l2fc(%s,%s) %s %s" % (names[x], names[y], rng.choice([">", ">=", "<", "<="]), rng.choice(["0.5", "1.0", "-1.0"])))
+        return " & ".join(parts)
+
+    events = {}
+    for e in range(int(rng.integers(2, 5))):
+        f = conj()
+        if rng.random() < 0.3:
+            f = "(%s) | (%s)" % (f, conj())
+        events["ev%d" % e] = f
+    return Scenario(samples, events), names
+
+
+def main():
+    n_sc = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    only = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+    rng = np.random.default_rng(seed)
+    bad = 0
+    done = 0
+    for it in range(n_sc):
+        try:
+            sc, names = random_scenario(rng)
+            sc.desc()
+        except Exception as ex:  # invalid formula for the front-end (e.g. empty spectrum): not a kernel case
+            continue
+        S = len(names)
+        classes = []
+        for _ in range(4):
+            classes.append(("c", 0.25, tuple((float(v), float(v + w)) for v, w in zip(rng.choice([0.0, 0.1, 0.5, 1.0], S), rng.choice([0.0, 0.0, 0.2], S)))))
+        classes = [(l, f, tuple((lo, min(hi, 1.0)) for lo, hi in spec)) for l, f, spec in classes]
+        cfg = synth.SynthConfig(name="fuzz", config_id=50, scenario=sc, depth=float(rng.choice([4.0, 12.0, 30.0])), type_mix={abi.VT_SNV: 0.7, abi.VT_INDEL: 0.3},
+                                classes=classes, purity=None)
+        b = synth.generate(cfg, 24, seed=int(rng.integers(1 << 30)))
+        if only >= 0 and it != only:
+            continue
+        if only >= 0 and os.environ.get("FUZZ_EVENTS"):
+            sc = Scenario(sc.samples, eval(os.environ["FUZZ_EVENTS"]))
+        try:
+            plan = engine.Plan(sc)
+        except Exception as ex:
+            print("plan rejected:", ex, sc.events)
+            continue
+        got = plan.call_host(b)
+        plan.close()
+        ref = oracle.call(sc, b, want_events=True)
+        m = compare(got, ref, label="fuzz %d" % it)
+        done += 1
+        ok = m["frac_within"] == 1.0 and m["bias_equal"] and m["status_equal"]
+        if not ok:
+            bad += 1
+            print("MISMATCH", it, {k: (v.universe, v.resolution, v.contamination) for k, v in sc.samples.items()}, sc.events)
+            print(describe(m))
+            if only >= 0:
+                np.set_printoptions(precision=6, linewidth=200)
+                print("out names", sc.out_names(), "univ events", sc.event_names)
+                for l in m["bad"][:4]:
+                    print(" locus", l, "depth", b.depth()[l], "status got %x ref %x" % (got.status[l], ref.status[l]))
+                    print("  got post", got.ln_posterior[l], "map", got.map_vaf[l], "bias", got.map_bias[l], "best", got.best_event[l])
+                    print("  ref post", ref.ln_posterior[l], "map", ref.map_vaf[l], "bias", ref.map_bias[l], "best", ref.best_event[l])
+                    print("  ref events", ref.event_ln_posterior[l])
+    print("scenarios run %d, mismatching %d" % (done, bad))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

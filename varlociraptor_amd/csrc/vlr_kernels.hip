@@ -129,6 +129,10 @@ __device__ inline double wave_max(double v) {
 }
 __device__ inline int popc64(unsigned long long m) { return __popcll(m); }
 
+// start + step * i of itertools_num::linspace with two roundings (never contracted to an fma: the grid points must be
+// bit-identical to the CPU's, a tail point may sit within one ulp of an l2fc boundary)
+__device__ __forceinline__ double lin_pt(double start, double step, double i) { return __dadd_rn(start, __dmul_rn(step, i)); }
+
 // approx::relative_eq!(a, b) defaults (epsilon = max_relative = f64::EPSILON)
 __device__ inline bool relative_eq(double a, double b) {
     if (a == b) return true;
@@ -255,7 +259,7 @@ __device__ inline bool spectrum_contains(const DevSpectrum& sp, const double* po
 
 // LFC predicates (utils/log2_fold_change.rs)
 __device__ inline bool lfc_is_true(int cmp, double value, double a, double b) {  // 17-26, 41-52
-    double lfc = (a == 0.0 && b == 0.0) ? 0.0 : log2(a) - log2(b);
+    double lfc = vlr_det::det_log2_ratio(a, b);  // exact on power-of-two ratios (include/vlr_detmath.h)
     switch (cmp) {
         case VLR_CMP_EQUAL: return relative_eq(lfc, value);
         case VLR_CMP_GREATER: return lfc > value;
@@ -266,7 +270,7 @@ __device__ inline bool lfc_is_true(int cmp, double value, double a, double b) { 
     }
 }
 __device__ inline RangeV lfc_bounds_of(int cmp, double value, double vaf) {  // 56-93
-    double proj = vaf / exp2(value);
+    double proj = vaf / vlr_det::det_exp2(value);
     if (proj < 0.0 || proj > 1.0) return range_empty();
     switch (cmp) {
         case VLR_CMP_EQUAL: return RangeV{proj, proj, 0, 0};
@@ -904,12 +908,12 @@ __device__ inline bool range_advance(Ctx& c, RangeSt& r, const double* tx, const
     double hi3 = fmin(r.mid + r.res * 3.0, r.hi);
     double sa = (r.mid - lo3) / 3.0, sb = (hi3 - r.mid) / 3.0;  // itertools_num::linspace step, n = 4
     r.pend[0] = arm;
-    r.pend[1] = lo3 + sa * 0.0;
-    r.pend[2] = lo3 + sa * 1.0;
-    r.pend[3] = lo3 + sa * 2.0;
-    r.pend[4] = r.mid + sb * 1.0;
-    r.pend[5] = r.mid + sb * 2.0;
-    r.pend[6] = r.mid + sb * 3.0;
+    r.pend[1] = lin_pt(lo3, sa, 0.0);
+    r.pend[2] = lin_pt(lo3, sa, 1.0);
+    r.pend[3] = lin_pt(lo3, sa, 2.0);
+    r.pend[4] = lin_pt(r.mid, sb, 1.0);
+    r.pend[5] = lin_pt(r.mid, sb, 2.0);
+    r.pend[6] = lin_pt(r.mid, sb, 3.0);
     r.npend = 7;
     r.phase = RP_TAIL;
     return false;
@@ -970,7 +974,7 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
     __builtin_amdgcn_wave_barrier();
     if (simpson_n) {
         double step = (hi - lo) / (double)(simpson_n - 1);
-        if (lane < simpson_n) pend[lane] = (lane == 0) ? lo : (lane == simpson_n - 1) ? hi : lo + step * (double)lane;
+        if (lane < simpson_n) pend[lane] = (lane == 0) ? lo : (lane == simpson_n - 1) ? hi : lin_pt(lo, step, (double)lane);
         np = simpson_n;
         phase = RP_SIMPSON;
     } else {
@@ -1086,8 +1090,8 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
             if (lane < 7) {
                 double v;
                 if (lane == 0) v = arm;
-                else if (lane <= 3) v = lo3 + sa * (double)(lane - 1);
-                else v = mid + sb * (double)(lane - 3);
+                else if (lane <= 3) v = lin_pt(lo3, sa, (double)(lane - 1));
+                else v = lin_pt(mid, sb, (double)(lane - 3));
                 pend[lane] = v;
             }
             np = 7;
@@ -1182,7 +1186,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
     bool done = !rowon;
     if (simpson_n) {
         double step = (hi - lo) / (double)(simpson_n - 1);
-        if (rl < simpson_n) pend[rl] = (rl == 0) ? lo : (rl == simpson_n - 1) ? hi : lo + step * (double)rl;
+        if (rl < simpson_n) pend[rl] = (rl == 0) ? lo : (rl == simpson_n - 1) ? hi : lin_pt(lo, step, (double)rl);
         np = simpson_n;
         phase = RP_SIMPSON;
     } else {
@@ -1289,8 +1293,8 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
                     if (rl < 7) {
                         double v;
                         if (rl == 0) v = arm;
-                        else if (rl <= 3) v = lo3 + sa * (double)(rl - 1);
-                        else v = mid + sb * (double)(rl - 3);
+                        else if (rl <= 3) v = lin_pt(lo3, sa, (double)(rl - 1));
+                        else v = lin_pt(mid, sb, (double)(rl - 3));
                         pend[rl] = v;
                     }
                     np = 7;
@@ -1815,7 +1819,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                             if (simpson) {
                                 // density is evaluated for interior points first, then a, b (bio); table order = grid order
                                 double step = (max_vaf - min_vaf) / (double)(simpson - 1);
-                                for (int i = 0; i < simpson; ++i) r.pend[i] = min_vaf + step * (double)i;
+                                for (int i = 0; i < simpson; ++i) r.pend[i] = lin_pt(min_vaf, step, (double)i);
                                 r.pend[0] = min_vaf; r.pend[simpson - 1] = max_vaf;
                                 r.npend = simpson; r.phase = RP_SIMPSON;
                             } else {
@@ -1856,7 +1860,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
             RangeSt& r = w->rs[fslot];
             double* tx = c.tabX + fslot * c.cap;
             double* tv = c.tabV + fslot * c.cap;
-            if (UNI(r.tn) + UNI(r.npend) > c.cap) {
+            if (UNI(r.tn) + (UNI(r.npend) - UNI(f.iter)) > c.cap) {  // room for the points of this round still to be recorded
                 c.status |= VLR_LOCUS_TABLE_FULL;
                 rv = __builtin_nan("");
                 c.present = UNI(f.sv_present); c.disc = UNI(f.sv_disc); c.nlfc = UNI(f.sv_nlfc); c.contained = UNI(f.sv_contained); c.alive = UNI(f.sv_alive); c.afd_mute = UNI(f.sv_mute);
