@@ -79,7 +79,9 @@ def main():
         if only >= 0 and it != only:
             continue
         if only >= 0 and os.environ.get("FUZZ_EVENTS"):
-            sc = Scenario(sc.samples, eval(os.environ["FUZZ_EVENTS"]))
+            from varlociraptor_amd.scenario import Conj, Atom, Lfc, VAFSet, VAFRange, parse_formula
+            env = dict(Conj=Conj, Atom=Atom, Lfc=Lfc, VAFSet=VAFSet, VAFRange=VAFRange, parse_formula=parse_formula, abi=abi)
+            sc = Scenario(sc.samples, eval(os.environ["FUZZ_EVENTS"], env))
         try:
             plan = engine.Plan(sc)
         except Exception as ex:
@@ -90,7 +92,13 @@ def main():
         ref = oracle.call(sc, b, want_events=True)
         m = compare(got, ref, label="fuzz %d" % it)
         done += 1
-        ok = m["frac_within"] == 1.0 and m["bias_equal"] and m["status_equal"]
+        # flat-likelihood loci (one observation in total, singleton-adjusted to pa = pr = ln 0.5): every operand has the
+        # same joint up to rounding noise, the MAP among them is arbitrary in the reference too (HashMap order)
+        flat = ((got.status & abi.LOCUS_SINGLETON_ADJ) != 0) & (b.depth().sum(axis=1) <= 2)
+        pg, pr_ = np.exp(got.ln_posterior), np.exp(ref.ln_posterior)
+        post_ok = np.nan_to_num(np.abs(pg - pr_), nan=0.0).max(axis=1) <= 1e-6
+        real_bad = [l for l in m["bad"] if not (flat[l] and post_ok[l])]
+        ok = len(real_bad) == 0 and m["bias_equal"] and m["status_equal"]
         if not ok:
             bad += 1
             print("MISMATCH", it, {k: (v.universe, v.resolution, v.contamination) for k, v in sc.samples.items()}, sc.events)

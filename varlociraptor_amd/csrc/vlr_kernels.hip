@@ -1655,6 +1655,7 @@ __device__ __forceinline__ void flush_deferred(Ctx& c, double* evM, double* evS,
         c.ndef = 0;
         return;
     }
+    c.nlfc = 0;  // deferred chains carry no l2fc terms; a later probe walk may have left some in the context
     run_chain_batch(c, nt, s_in);
     __syncthreads();
     for (int i = 0; i < nt; ++i) {
