@@ -138,5 +138,38 @@ VLR_HD inline double det_log2_ratio(double a, double b) {
     return (double)(ea - eb) + (fa - fb);
 }
 
+/* Double-double accumulation for the decision sums: sum_i exp(v_i - m) is formed with ~106 significant bits, so the
+ * rounded result does not depend on the order of summation (sequential on the CPU, lane-strided plus a butterfly on the
+ * GPU) except with probability ~2^-50 per sum. */
+struct dd {
+    double hi, lo;
+};
+VLR_HD inline dd dd_two_sum(double a, double b) {
+    double s = a + b;
+    double bb = s - a;
+    double e = (a - (s - bb)) + (b - bb);
+    return dd{s, e};
+}
+VLR_HD inline dd dd_add(dd a, double x) {
+    dd t = dd_two_sum(a.hi, x);
+    double lo = t.lo + a.lo;
+    double hi = t.hi + lo;
+    return dd{hi, lo - (hi - t.hi)};
+}
+VLR_HD inline dd dd_add_dd(dd a, dd b) {
+    dd t = dd_two_sum(a.hi, b.hi);
+    double lo = t.lo + (a.lo + b.lo);
+    double hi = t.hi + lo;
+    return dd{hi, lo - (hi - t.hi)};
+}
+/* exp(ln_sum_exp(v)) of bio's formula m + ln1p(sum_{i != imax} exp(v_i - m)) given m = max v and the double-double sum
+ * over ALL finite terms (the maximum term contributes exactly 1) */
+VLR_HD inline double exp_lse_from_sum(double m, dd sum_all) {
+    if (m == -__builtin_huge_val()) return 0.0;
+    dd rest = dd_add(sum_all, -1.0);
+    double s = rest.hi + rest.lo;
+    return det_exp(m + det_log1p_pos(s));
+}
+
 }  /* namespace vlr_det */
 #endif

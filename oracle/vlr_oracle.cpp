@@ -247,16 +247,13 @@ bool comp_is_artifact(int comp, const Artifacts& a) {
 // see that header for why these decision sums must not depend on libm's last bit.
 double exp_lse_det(const std::vector<double>& v) {
     if (v.empty()) return 0.0;
-    size_t imax = 0;
-    for (size_t i = 1; i < v.size(); ++i)
-        if (v[i] > v[imax]) imax = i;
-    if (v[imax] == NEG_INF) return 0.0;
-    double s = 0.0;
-    for (size_t i = 0; i < v.size(); ++i) {
-        if (i == imax || v[i] == NEG_INF) continue;
-        s += vlr_det::det_exp(v[i] - v[imax]);
-    }
-    return vlr_det::det_exp(v[imax] + vlr_det::det_log1p_pos(s));
+    double m = NEG_INF;
+    for (double x : v) m = std::max(m, x);
+    if (m == NEG_INF) return 0.0;
+    vlr_det::dd s{0.0, 0.0};  // order-independent (double-double) sum, see include/vlr_detmath.h
+    for (double x : v)
+        if (x != NEG_INF) s = vlr_det::dd_add(s, vlr_det::det_exp(x - m));
+    return vlr_det::exp_lse_from_sum(m, s);
 }
 
 // strand_bias.rs:79-123

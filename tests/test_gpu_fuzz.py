@@ -1,0 +1,19 @@
+"""Randomised scenarios (tools/fuzz_scenarios.py): sets, ranges, negation, disjunctions, l2fc terms, contamination,
+1-3 samples over small pileups — GPU engine vs oracle.  The fuzzer found, among others, the l2fc end-point boundary
+(include/vlr_detmath.h det_log2_ratio), a false TABLE_FULL on triple-nested ranges and a stale l2fc context in deferred
+batches; this seeded run keeps them fixed."""
+import importlib.util
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [1, 5])
+def test_random_scenarios_match_oracle(seed):
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_scenarios.py")
+    spec = importlib.util.spec_from_file_location("fuzz_scenarios", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(["fuzz", "60", str(seed)]) == 0

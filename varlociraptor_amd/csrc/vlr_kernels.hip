@@ -339,24 +339,26 @@ __device__ inline bool bias_evidence(int h, uint32_t f, bool has_alt_loci) {
 
 // exp(ln_sum_exp(v_i)) over a wave-distributed set, mirroring bio's LogProb::ln_sum_exp formula
 // m + ln1p(sum_{i != imax} exp(v_i - m)) (used by strand_bias.rs:80-109, read_position_bias.rs:68-113)
-struct LseAcc {
-    double m, s;  // running max, sum of exp(v - m) incl. the max term
+// exp(ln_sum_exp(v_i)) over a wave-distributed set (strand_bias.rs:80-109, read_position_bias.rs:68-113): the maximum is
+// found first (pass 1), then every lane accumulates its exp(v - m) terms in double-double and the lane sums are
+// combined by a butterfly — the rounded sum does not depend on the order (include/vlr_detmath.h), so the thresholds
+// that sit exactly on k/n boundaries (prob_mapping is constant within a pileup) are decided as on the CPU.
+struct DdAcc {
+    vlr_det::dd s;
 };
-__device__ inline void lseacc_chunk(LseAcc& a, double v, bool on) {
-    double x = on ? v : VLR_NEG_INF;
-    double cm = wave_max(x);
-    if (cm == VLR_NEG_INF) return;
-    double nm = fmax(a.m, cm);
-    double cs = wave_sum(on && x != VLR_NEG_INF ? vlr_det::det_exp(x - nm) : 0.0);
-    double olds = (a.m == VLR_NEG_INF) ? 0.0 : a.s * vlr_det::det_exp(a.m - nm);
-    a.m = nm;
-    a.s = olds + cs;
+__device__ __forceinline__ void ddacc_add(DdAcc& a, double v, double m, bool on) {
+    if (on && v != VLR_NEG_INF) a.s = vlr_det::dd_add(a.s, vlr_det::det_exp(v - m));
 }
-// deterministic exp/log1p (include/vlr_detmath.h): these sums decide threshold tests that sit exactly on
-// k/n boundaries when prob_mapping is constant within the pileup
-__device__ inline double lseacc_exp(const LseAcc& a) {
-    if (a.m == VLR_NEG_INF) return 0.0;
-    return vlr_det::det_exp(a.m + vlr_det::det_log1p_pos(a.s - 1.0));
+__device__ inline double ddacc_exp(const DdAcc& a, double m) {
+    vlr_det::dd t = a.s;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        vlr_det::dd u{__shfl_xor(t.hi, o), __shfl_xor(t.lo, o)};
+        t = vlr_det::dd_add_dd(t, u);
+    }
+    // every lane holds a sum of all 64 lane sums (a tree, not the same tree on every lane): take lane 0's
+    t.hi = uni_d(t.hi); t.lo = uni_d(t.lo);
+    return vlr_det::exp_lse_from_sum(m, t);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2085,12 +2087,14 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
     unsigned possible_alb_noloci = 0;
     int offset_acc = 0;
     bool too_deep = false;
+    double mx_sb_all = VLR_NEG_INF, mx_sb_fwd = VLR_NEG_INF;
     for (int s = 0; s < S; ++s) {
         const int64_t pidx = locus * S + s;
         const uint32_t o0 = batch.obs_offset[pidx], o1 = batch.obs_offset[pidx + 1];
         int nk = 0, allref = 1, allpos = 1, sall = 0, anysa = 0, ins = 0, del = 0;
         int sbias[kNHyp];
         int sbias_alb_noloci = 0;
+        double mx_all = VLR_NEG_INF, mx_major = VLR_NEG_INF, mx_rate = VLR_NEG_INF;
         for (int h = 0; h < kNHyp; ++h) sbias[h] = 0;
         for (uint32_t base = o0; base < o1; base += 64) {
             uint32_t i = base + lane;
@@ -2131,6 +2135,15 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
             nm_ref += popc64(__ballot(strong_ref && !maxq));
             if (__ballot(keep && f_altlocus(f) != VLR_ALTLOCUS_NONE)) any_altloci = true;
             if (__ballot(keep && (f & VLR_F_SOFTCLIPPED))) any_softclip = true;
+            {   // maxima of the decision sums (second pass below)
+                const double phb1 = valid ? (double)batch.phb[i] : 0.0;
+                const int st1 = f_strand(f);
+                mx_sb_all = fmax(mx_sb_all, (strong_ref && st1 != VLR_STRAND_BOTH) ? pm : VLR_NEG_INF);
+                mx_sb_fwd = fmax(mx_sb_fwd, (strong_ref && st1 == VLR_STRAND_FORWARD) ? pm : VLR_NEG_INF);
+                mx_all = fmax(mx_all, strong_ref ? pm : VLR_NEG_INF);
+                mx_major = fmax(mx_major, (strong_ref && (f & VLR_F_READPOS_MAJOR)) ? pm : VLR_NEG_INF);
+                mx_rate = fmax(mx_rate, strong_ref ? pm + phb1 : VLR_NEG_INF);
+            }
             for (int h = 1; h < kNHyp; ++h) {
                 if (h == H_HE) continue;
                 bool ev = bias_evidence(h, f, true);
@@ -2150,16 +2163,23 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
             for (int h = 0; h < kNHyp; ++h) w->strong_bias[s][h] = sbias[h];
             w->strong_bias[s][0] = sbias_alb_noloci;  // slot 0 reused: alt-locus evidence without alt loci
         }
+        {
+            const double a0 = wave_max(mx_all), a1 = wave_max(mx_major), a2 = wave_max(mx_rate);
+            if (lane == 0) { w->pos_all[s] = a0; w->pos_major[s] = a1; w->pos_rate[s] = a2; }  // maxima; replaced by the sums below
+        }
         offset_acc += nk;
         total_kept += nk;
     }
     // second pass (rows are L2-hot): the exp(ln_sum_exp(prob_mapping)) sums of strand_bias.rs:79-123 and
     // read_position_bias.rs:63-122, kept apart from the counters above to bound register pressure
-    LseAcc sb_all{VLR_NEG_INF, 0.0}, sb_fwd{VLR_NEG_INF, 0.0};
+    const double m_sb_all = uni_d(wave_max(mx_sb_all)), m_sb_fwd = uni_d(wave_max(mx_sb_fwd));
+    DdAcc sb_all{{0.0, 0.0}}, sb_fwd{{0.0, 0.0}};
+    __syncthreads();
     for (int s = 0; s < S; ++s) {
         const int64_t pidx = locus * S + s;
         const uint32_t o0 = batch.obs_offset[pidx], o1 = batch.obs_offset[pidx + 1];
-        LseAcc pa_all{VLR_NEG_INF, 0.0}, pa_major{VLR_NEG_INF, 0.0}, pa_rate{VLR_NEG_INF, 0.0};
+        const double m_all = uni_d(w->pos_all[s]), m_major = uni_d(w->pos_major[s]), m_rate = uni_d(w->pos_rate[s]);
+        DdAcc pa_all{{0.0, 0.0}}, pa_major{{0.0, 0.0}}, pa_rate{{0.0, 0.0}};
         for (uint32_t base = o0; base < o1; base += 64) {
             uint32_t i = base + lane;
             bool valid = i < o1;
@@ -2169,13 +2189,15 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
             bool keep = valid && !(remove_nonstd && f_orient(f) == VLR_ORIENT_OTHER);
             bool strong_ref = keep && exp(pr - pa) > 20.0;
             int strand = f_strand(f);
-            lseacc_chunk(sb_all, pm, strong_ref && strand != VLR_STRAND_BOTH);
-            lseacc_chunk(sb_fwd, pm, strong_ref && strand == VLR_STRAND_FORWARD);
-            lseacc_chunk(pa_all, pm, strong_ref);
-            lseacc_chunk(pa_major, pm, strong_ref && (f & VLR_F_READPOS_MAJOR));
-            lseacc_chunk(pa_rate, pm + phb, strong_ref);
+            ddacc_add(sb_all, pm, m_sb_all, strong_ref && strand != VLR_STRAND_BOTH);
+            ddacc_add(sb_fwd, pm, m_sb_fwd, strong_ref && strand == VLR_STRAND_FORWARD);
+            ddacc_add(pa_all, pm, m_all, strong_ref);
+            ddacc_add(pa_major, pm, m_major, strong_ref && (f & VLR_F_READPOS_MAJOR));
+            ddacc_add(pa_rate, pm + phb, m_rate, strong_ref);
         }
-        if (lane == 0) { w->pos_all[s] = lseacc_exp(pa_all); w->pos_major[s] = lseacc_exp(pa_major); w->pos_rate[s] = lseacc_exp(pa_rate); }
+        const double e_all = ddacc_exp(pa_all, m_all), e_major = ddacc_exp(pa_major, m_major), e_rate = ddacc_exp(pa_rate, m_rate);
+        __syncthreads();
+        if (lane == 0) { w->pos_all[s] = e_all; w->pos_major[s] = e_major; w->pos_rate[s] = e_rate; }
     }
     if (offset_acc > max_obs) too_deep = true;
     __syncthreads();
@@ -2189,7 +2211,7 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
     double forward_rate = 0.5;
     bool sb_informative = false;
     {
-        double strong_all_f = lseacc_exp(sb_all), strong_fwd_f = lseacc_exp(sb_fwd);
+        double strong_all_f = ddacc_exp(sb_all, m_sb_all), strong_fwd_f = ddacc_exp(sb_fwd, m_sb_fwd);
         if (strong_all_f > 2.0) {
             double ff = strong_fwd_f / strong_all_f;
             if (strong_all_f > 100.0 && ff > 0.0 && ff < 1.0) { forward_rate = ff; sb_informative = true; }
