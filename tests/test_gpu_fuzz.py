@@ -17,3 +17,13 @@ def test_random_scenarios_match_oracle(seed):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.main(["fuzz", "60", str(seed)]) == 0
+
+
+def test_random_prior_scenarios_match_oracle(monkeypatch):
+    """Ploidy-derived universes with germline / somatic / Mendelian / clonal / subclonal priors, default and --full-prior."""
+    monkeypatch.setenv("FUZZ_PRIOR", "1")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_scenarios.py")
+    spec = importlib.util.spec_from_file_location("fuzz_scenarios_prior", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(["fuzz", "40", "3"]) == 0

@@ -55,26 +55,66 @@ def random_scenario(rng):
     return Scenario(samples, events), names
 
 
+def random_scenario_prior(rng):
+    """Ploidy-derived universes with germline / somatic / Mendelian / clonal priors (prior.rs), variant nodes, one fine
+    resolution; mirrors the shapes of tests/resources/prior/scenarios."""
+    from varlociraptor_amd.scenario import Inheritance, Species
+    kind = int(rng.integers(4))
+    species = Species(heterozygosity=float(rng.choice([0.001, 0.01])), germline_mutation_rate=1e-3, ploidy=2,
+                      somatic_effective_mutation_rate=(1e-6 if rng.random() < 0.5 else None))
+    if kind == 0:   # trio
+        mend = Inheritance(abi.INHERIT_MENDELIAN, ("m", "f"))
+        samples = {"m": Sample(), "f": Sample(), "k": Sample(inheritance=mend)}
+        events = {"denovo": "(k:0.5 | k:1.0) & m:0.0 & f:0.0", "inherited": "!m:0.0 | !f:0.0", "het_all": "k:0.5 & m:0.5 & f:0.5"}
+        names = ["f", "k", "m"]
+    elif kind == 1:  # tumor/normal with somatic rates and clonal inheritance
+        samples = {"n": Sample(somatic_effective_mutation_rate=1e-10, resolution=float(rng.choice([0.1, 0.05]))),
+                   "t": Sample(somatic_effective_mutation_rate=1e-6, resolution=float(rng.choice([0.05, 0.02])),
+                               inheritance=Inheritance(abi.INHERIT_CLONAL, ("n",), bool(rng.random() < 0.5)),
+                               contamination=Contamination("n", float(rng.choice([0.1, 0.3]))) if rng.random() < 0.6 else None)}
+        events = {"germline": "n:0.5 | n:1.0", "somatic_t": "n:0.0 & t:]0.0,1.0]", "somatic_n": "n:]0.0,0.5[", "loh": "n:0.5 & t:1.0"}
+        if rng.random() < 0.5:
+            del events["loh"]
+        names = ["n", "t"]
+    elif kind == 2:  # single sample, germline + somatic, fine resolution, variant nodes
+        samples = {"s": Sample(somatic_effective_mutation_rate=1e-6, resolution=float(rng.choice([0.01, 0.02, 0.005])))}
+        events = {"het": "s:0.5", "hom": "s:1.0", "low": "s:]0.0,0.5[", "high": "s:]0.5,1.0["}
+        if rng.random() < 0.5:
+            events = {"ct_het": "C>T & s:0.5", "other_het": "!C>T & s:0.5", "hom": "s:1.0", "sub": "s:]0.0,0.5[ | s:]0.5,1.0["}
+        names = ["s"]
+    else:           # subclonal relapse
+        samples = {"n": Sample(somatic_effective_mutation_rate=1e-10, resolution=0.1),
+                   "p": Sample(somatic_effective_mutation_rate=1e-6, resolution=0.05, inheritance=Inheritance(abi.INHERIT_CLONAL, ("n",), True)),
+                   "r": Sample(somatic_effective_mutation_rate=1e-6, resolution=0.05, inheritance=Inheritance(abi.INHERIT_SUBCLONAL, ("p",)))}
+        events = {"germline": "n:0.5 | n:1.0", "primary_only": "n:0.0 & p:]0.0,1.0] & r:0.0", "relapse": "n:0.0 & r:]0.0,1.0]"}
+        names = ["n", "p", "r"]
+    sc = Scenario(samples, events, species=species, full_prior=bool(rng.random() < 0.5))
+    return sc, names
+
+
 def main(argv=None):
     argv = sys.argv if argv is None else argv
     n_sc = int(argv[1]) if len(argv) > 1 else 50
     seed = int(argv[2]) if len(argv) > 2 else 1
     only = int(argv[3]) if len(argv) > 3 else -1
+    prior_mode = os.environ.get("FUZZ_PRIOR") == "1"
     rng = np.random.default_rng(seed)
     bad = 0
     done = 0
     for it in range(n_sc):
         try:
-            sc, names = random_scenario(rng)
+            sc, names = (random_scenario_prior(rng) if prior_mode else random_scenario(rng))
             sc.desc()
         except Exception as ex:  # invalid formula for the front-end (e.g. empty spectrum): not a kernel case
+            if prior_mode:
+                print("scenario rejected:", ex)
             continue
         S = len(names)
         classes = []
         for _ in range(4):
             classes.append(("c", 0.25, tuple((float(v), float(v + w)) for v, w in zip(rng.choice([0.0, 0.1, 0.5, 1.0], S), rng.choice([0.0, 0.0, 0.2], S)))))
         classes = [(l, f, tuple((lo, min(hi, 1.0)) for lo, hi in spec)) for l, f, spec in classes]
-        cfg = synth.SynthConfig(name="fuzz", config_id=50, scenario=sc, depth=float(rng.choice([4.0, 12.0, 30.0])), type_mix={abi.VT_SNV: 0.7, abi.VT_INDEL: 0.3},
+        cfg = synth.SynthConfig(name="fuzz", config_id=50, scenario=sc, depth=float(rng.choice([4.0, 12.0, 30.0] if not prior_mode else [8.0, 25.0, 60.0])), type_mix={abi.VT_SNV: 0.7, abi.VT_INDEL: 0.3},
                                 classes=classes, purity=None)
         b = synth.generate(cfg, 24, seed=int(rng.integers(1 << 30)))
         if only >= 0 and it != only:
