@@ -41,7 +41,7 @@ def random_scenario(rng):
                 continue
             used.add(n)
             parts.append(a)
-        if S >= 2 and rng.random() < 0.2:
+        if S >= 2 and rng.random() < 0.2 and os.environ.get("FUZZ_NO_LFC") != "1":
             x, y = rng.choice(S, 2, replace=False)
             parts.append("l2fc(%s,%s) %s %s" % (names[x], names[y], rng.choice([">", ">=", "<", "<="]), rng.choice(["0.5", "1.0", "-1.0"])))
         return " & ".join(parts)
@@ -128,9 +128,10 @@ def main(argv=None):
         except Exception as ex:
             print("plan rejected:", ex, sc.events)
             continue
-        got = plan.call_host(b)
+        afd_cap = 256 if os.environ.get("FUZZ_AFD") == "1" else 0
+        got = plan.call_host(b, afd_capacity=afd_cap)
         plan.close()
-        ref = oracle.call(sc, b, want_events=True)
+        ref = oracle.call(sc, b, afd_capacity=afd_cap, want_events=True)
         m = compare(got, ref, label="fuzz %d" % it)
         done += 1
         # flat-likelihood samples (at most three observations, typically neutralised by the singleton adjustment): every
@@ -143,6 +144,37 @@ def main(argv=None):
         flat = post_ok & np.all((dv <= 1e-6) | shallow, axis=1) & (got.best_event == ref.best_event)
         real_bad = [l for l in m["bad"] if not flat[l]]
         ok = len(real_bad) == 0 and m["bias_equal"] and m["status_equal"]
+        if ok and afd_cap:
+            n_afd_bad = 0
+            for l in range(b.n_loci):
+                if flat[l] and l in m["bad"]:
+                    continue
+                for si in range(S):
+                    ng, nr = int(got.afd_count[l, si]), int(ref.afd_count[l, si])
+                    if ng != nr or ng > afd_cap:
+                        n_afd_bad += 1
+                        if n_afd_bad <= 3:
+                            print("  AFD count differs: locus %d sample %d gpu %d ref %d" % (l, si, ng, nr))
+                        continue
+                    og, orr = np.argsort(got.afd_vaf[l, si, :ng], kind="stable"), np.argsort(ref.afd_vaf[l, si, :nr], kind="stable")
+                    if not (np.array_equal(got.afd_vaf[l, si, :ng][og], ref.afd_vaf[l, si, :nr][orr]) and
+                            np.allclose(np.sort(got.afd_lnprob[l, si, :ng]), np.sort(ref.afd_lnprob[l, si, :nr]), atol=1e-6, equal_nan=True)):
+                        n_afd_bad += 1
+                        if n_afd_bad <= 3:
+                            print("  AFD list differs: locus %d sample %d" % (l, si))
+            if n_afd_bad:
+                ok = False
+                print("  AFD mismatches:", n_afd_bad)
+                if only >= 0:
+                    np.set_printoptions(precision=5, linewidth=220)
+                    for l in range(b.n_loci):
+                        if any(int(got.afd_count[l, si]) != int(ref.afd_count[l, si]) for si in range(S)):
+                            print(" locus", l, "depth", b.depth()[l], "best", got.best_event[l], ref.best_event[l], "map", got.map_vaf[l], ref.map_vaf[l], "post", ref.ln_posterior[l])
+                            for si in range(S):
+                                ng, nr = int(got.afd_count[l, si]), int(ref.afd_count[l, si])
+                                print("   s%d gpu" % si, np.sort(got.afd_vaf[l, si, :ng]))
+                                print("   s%d ref" % si, np.sort(ref.afd_vaf[l, si, :nr]))
+                            break
         if not ok:
             bad += 1
             print("MISMATCH", it, {k: (v.universe, v.resolution, v.contamination) for k, v in sc.samples.items()}, sc.events)

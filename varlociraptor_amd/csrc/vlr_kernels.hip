@@ -806,10 +806,56 @@ __device__ inline void afd_consider(Ctx& c, double joint, int inner, double x) {
             int idx = atomicAdd(&o.afd_count[slot], 1);
             if (idx < o.afd_capacity) {
                 double v = (s == inner) ? x : c.w->ops_vaf[s];
+                // the sign bit marks a discrete operand until afd_finish() has removed repeated keys
+                if ((disc >> s) & 1) v = __hiloint2double(__double2hiint(v) | (int)0x80000000, __double2loint(v));
                 o.afd_vaf[slot * o.afd_capacity + idx] = v;
                 o.afd_lnprob[slot * o.afd_capacity + idx] = joint - c.marginal;
             }
         }
+    }
+}
+
+// End of the replay pass: the reference's joint_probs is ONE map per record keyed by the operands, so an operand set
+// visited from several events / roots (overlapping events, the same Range point reached along two branches) has a
+// single AFD entry.  Entries of sample s are keyed by (VAF, is_discrete) — the other samples equal the MAP by
+// construction; the first occurrence is kept.
+__device__ inline void afd_finish(Ctx& c) {
+    const DevResults& o = *c.outp;
+    __threadfence();
+    for (int s = 0; s < c.S; ++s) {
+        const int64_t slot = c.locus * c.S + s;
+        int cnt = 0;
+        if (c.lane == 0) cnt = atomicAdd(&o.afd_count[slot], 0);
+        cnt = UNI(cnt);
+        if (cnt <= 0) continue;
+        double* vv = o.afd_vaf + slot * o.afd_capacity;
+        double* pp = o.afd_lnprob + slot * o.afd_capacity;
+        if (cnt <= o.afd_capacity) {
+            int kept = 0;
+            for (int base = 0; base < cnt; base += 64) {
+                const int i = base + c.lane;
+                const bool on = i < cnt;
+                const double v = on ? vv[i] : 0.0, pr = on ? pp[i] : 0.0;
+                const long long key = __double_as_longlong(v);
+                bool dup = false;
+                for (int j = 0; j < kept; ++j) dup = dup | (__double_as_longlong(vv[j]) == key);  // compacted prefix (earlier chunks)
+                for (int j = base; j < base + 64 && j < cnt; ++j) {                                  // earlier entries of this chunk
+                    const long long kj = __shfl(key, j - base);
+                    dup = dup | ((j < i) & (kj == key));
+                }
+                const unsigned long long keep = __ballot(on & !dup);
+                const int pos = kept + __popcll(keep & ((1ull << c.lane) - 1ull));
+                __threadfence();
+                if (on & !dup) { vv[pos] = v; pp[pos] = pr; }
+                __threadfence();
+                kept += __popcll(keep);
+            }
+            if (c.lane == 0) o.afd_count[slot] = kept;
+            cnt = kept;
+        }
+        const int lim = cnt < o.afd_capacity ? cnt : o.afd_capacity;
+        __threadfence();
+        for (int i = c.lane; i < lim; i += 64) vv[i] = fabs(vv[i]);
     }
 }
 
@@ -2459,7 +2505,7 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
         }
     }
     PROF_ADD(c, 3);  // walk remainder (everything in the event loop not attributed below)
-    if (c.replay) return;
+    if (c.replay) { afd_finish(c); return; }
     // ============================ phase C: posteriors + MAP ============================
     // bio Model::compute: marginal = ln_sum_exp(event values); posterior = value - marginal
     const int n_out = p.n_named + 2;
