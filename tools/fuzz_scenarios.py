@@ -114,9 +114,14 @@ def main(argv=None):
         for _ in range(4):
             classes.append(("c", 0.25, tuple((float(v), float(v + w)) for v, w in zip(rng.choice([0.0, 0.1, 0.5, 1.0], S), rng.choice([0.0, 0.0, 0.2], S)))))
         classes = [(l, f, tuple((lo, min(hi, 1.0)) for lo, hi in spec)) for l, f, spec in classes]
-        cfg = synth.SynthConfig(name="fuzz", config_id=50, scenario=sc, depth=float(rng.choice([4.0, 12.0, 30.0] if not prior_mode else [8.0, 25.0, 60.0])), type_mix={abi.VT_SNV: 0.7, abi.VT_INDEL: 0.3},
+        if os.environ.get("FUZZ_TYPES") == "1":
+            type_mix = {abi.VT_SNV: 0.4, abi.VT_MNV: 0.15, abi.VT_INDEL: 0.3, abi.VT_SV: 0.15}
+            bias_mask = int(rng.choice([abi.BIAS_ALL, abi.BIAS_ALL, abi.BIAS_STRAND | abi.BIAS_ORIENTATION, abi.BIAS_POSITION | abi.BIAS_SOFTCLIP | abi.BIAS_HOMOPOLYMER, abi.BIAS_ALTLOCUS, 0]))
+        else:
+            type_mix, bias_mask = {abi.VT_SNV: 0.7, abi.VT_INDEL: 0.3}, abi.BIAS_ALL
+        cfg = synth.SynthConfig(name="fuzz", config_id=50, scenario=sc, depth=float(rng.choice([4.0, 12.0, 30.0] if not prior_mode else [8.0, 25.0, 60.0])), type_mix=type_mix,
                                 classes=classes, purity=None)
-        b = synth.generate(cfg, 24, seed=int(rng.integers(1 << 30)))
+        b = synth.generate(cfg, 24, seed=int(rng.integers(1 << 30)), bias_mask=bias_mask)
         if only >= 0 and it != only:
             continue
         if only >= 0 and os.environ.get("FUZZ_EVENTS"):
