@@ -109,3 +109,39 @@ def test_cli_contig_specific_scenario_uses_one_plan_per_resolution(golden_dir, t
         assert np.array_equal(mixed.ln_posterior[l], want.ln_posterior[l], equal_nan=True)
         assert np.array_equal(mixed.map_vaf[l], want.map_vaf[l], equal_nan=True)
     assert not np.array_equal(plain_a.ln_posterior, plain_x.ln_posterior)
+
+
+def test_cli_breakend_groups_are_evaluated_once_and_fanned_out(golden_dir, tmp_path, monkeypatch):
+    """Records carrying the same INFO EVENT share one evaluation; every record of the group gets its result."""
+    import numpy as np
+    from varlociraptor_amd import engine
+    d = os.path.join(golden_dir, "flamegraph_profiling")
+    out = []
+    k = 0
+    for l in open(os.path.join(d, "normal.vcf")).read().split("\n"):
+        if l and not l.startswith("#"):
+            f = l.split("\t")
+            if k in (2, 5, 6):   # records 2, 5 and 6 become members of one event; they keep their own (different) pileups,
+                f[7] = "EVENT=grp1;" + f[7]   # so the fan-out is visible: all three must carry record 2's result
+            k += 1
+            l = "\t".join(f)
+        out.append(l)
+        if l.startswith("##INFO=<ID=SVLEN"):
+            pass
+    obs = tmp_path / "grouped.vcf"
+    obs.write_text("\n".join(out))
+    sc = cli.scenario_from_yaml(os.path.join(d, "scenario.yaml"))
+    seen = []
+    orig = engine.Plan.call_host
+
+    def spy(self, batch, afd_capacity=0):
+        seen.append(batch.n_loci)
+        return orig(self, batch, afd_capacity=afd_capacity)
+    monkeypatch.setattr(engine.Plan, "call_host", spy)
+    grouped = cli.call_variants(sc, {"normal": str(obs)}, omit_mask=abi.BIAS_ALL, out=io.StringIO())
+    plain = cli.call_variants(sc, {"normal": os.path.join(d, "normal.vcf")}, omit_mask=abi.BIAS_ALL, out=io.StringIO())
+    assert seen == [9, 11]  # 11 records, one group of three -> nine evaluations
+    for l in range(11):
+        want = 2 if l in (2, 5, 6) else l
+        assert np.array_equal(grouped.ln_posterior[l], plain.ln_posterior[want], equal_nan=True)
+        assert np.array_equal(grouped.map_vaf[l], plain.map_vaf[want], equal_nan=True)

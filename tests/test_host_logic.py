@@ -298,3 +298,15 @@ events:
     y.write_text("samples: {a: {universe: {X: '[0.0,1.0]'}}}\nevents: {e: 'a:0.5'}\n")
     with pytest.raises(ValueError):
         cli.scenario_from_yaml(str(y), "1")  # UniverseContigNotFound
+
+
+def test_haplotype_identifier_and_groups():
+    """HaplotypeIdentifier::from (variants/model/mod.rs:87-133) and the breakend-group fan-out (calling.rs:569-580)."""
+    from varlociraptor_amd.obsfmt import haplotype_groups, haplotype_identifier
+    assert haplotype_identifier({"EVENT": "ev7", "MATEID": "b"}) == "ev7"
+    assert haplotype_identifier({"MATEID": "bnd_U", "__ID": "bnd_W"}) == "bnd_U-bnd_W"
+    assert haplotype_identifier({"SVTYPE": "BND"}) is None
+    with pytest.raises(ValueError):
+        haplotype_identifier({"MATEID": "x", "__ID": "."})
+    reps, source = haplotype_groups([None, "e1", None, "e1", "e2", "e1", "e2"])
+    assert reps == [0, 1, 2, 4] and source == [0, 1, 2, 1, 3, 1, 3]

@@ -141,6 +141,7 @@ def bcf_to_vcf_info_records(path: str) -> Tuple[List[str], List[Tuple[str, int, 
                 info[k] = ",".join("." if x is None else ("%d" % x if isinstance(x, int) else repr(x)) for x in v)
             else:
                 info[k] = ""
+        info["__ID"] = rec["id"]
         recs.append((rec["chrom"], rec["pos"], rec["ref"], rec["alt"], info))
     return r.header_lines, recs
 

@@ -108,9 +108,12 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
     batch, sites = obsfmt.read_observation_vcf(paths, omit_bias_mask=omit_mask)
     from .batch import CallResults
     import numpy as np
+    # breakends of one event share a pileup and a result: evaluate the first record of every event only and copy its
+    # event probabilities / sample info to the others (calling.rs:569-580, 726-741, 820-839)
+    reps, source = obsfmt.haplotype_groups(batch.extra.get("haplotype") or [None] * batch.n_loci)
     groups: Dict[tuple, List[int]] = {}
-    for l, site in enumerate(sites):
-        sc = resolve(site[0])
+    for l in reps:
+        sc = resolve(sites[l][0])
         groups.setdefault(_scenario_signature(sc), []).append(l)
     res = None
     names = None
@@ -132,6 +135,12 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
             a = getattr(res, f)
             if a is not None:
                 a[idx] = getattr(r, f)
+    if res is not None and len(reps) < batch.n_loci:  # fan the group results out to every record of the group
+        src = np.asarray([reps[i] for i in source])
+        for f in ("ln_posterior", "ln_marginal", "map_vaf", "map_bias", "best_event", "status", "afd_count", "afd_vaf", "afd_lnprob"):
+            a = getattr(res, f)
+            if a is not None:
+                a[:] = a[src]
     scenario0 = resolve(sites[0][0] if sites else "all")
     header = callsfmt.header(names or scenario0.out_names(), scenario0.sample_names, sorted(set(s[0] for s in sites)))
     if output and output.endswith(".bcf"):  # binary calls file (reference: bcf::Writer, calling.rs:296-304)

@@ -178,6 +178,37 @@ def _variant_class(ref: str, alt: str) -> Tuple[int, bool, bool]:
     return abi.VT_INDEL, False, False
 
 
+def haplotype_identifier(info: Dict[str, str]) -> Optional[str]:
+    """HaplotypeIdentifier::from (variants/model/mod.rs:87-133): INFO EVENT, else the sorted pair (record ID, MATEID)."""
+    ev = info.get("EVENT")
+    if ev:
+        return ev.split(",")[0]
+    mate = info.get("MATEID")
+    if mate:
+        rid = info.get("__ID", ".")
+        if rid in (".", ""):
+            raise ValueError("breakend with MATEID but without record ID")  # errors::Error::BreakendMateidWithoutRecid
+        return "-".join(sorted([rid, mate.split(",")[0]]))
+    return None
+
+
+def haplotype_groups(haplotypes: List[Optional[str]]) -> Tuple[List[int], List[int]]:
+    """Breakends of one event share a pileup and a result (calling.rs:569-580, 726-741, 820-839): returns
+    (representatives, source) where `representatives` are the loci to evaluate and source[l] indexes into them."""
+    reps: List[int] = []
+    first: Dict[str, int] = {}
+    source: List[int] = []
+    for l, h in enumerate(haplotypes):
+        if h is not None and h in first:
+            source.append(first[h])
+            continue
+        if h is not None:
+            first[h] = len(reps)
+        source.append(len(reps))
+        reps.append(l)
+    return reps, source
+
+
 def read_observation_vcf(paths: List[str], omit_bias_mask: int = 0) -> Tuple[PileupBatch, List[Tuple[str, int, str, str]]]:
     """Read one observation VCF per sample (in sample-index order) into a PileupBatch.
 
@@ -210,6 +241,7 @@ def read_observation_vcf(paths: List[str], omit_bias_mask: int = 0) -> Tuple[Pil
                         info[k] = v
                     else:
                         info[kv] = ""
+                info["__ID"] = f[2]
                 recs.append((f[0], int(f[1]), f[3], f[4], info))
         if not version_ok:
             raise ValueError("invalid observation format (calling.rs:324-339)")  # errors::Error::InvalidObservationFormat
@@ -222,7 +254,7 @@ def read_observation_vcf(paths: List[str], omit_bias_mask: int = 0) -> Tuple[Pil
     offsets = [0]
     cols: Dict[str, List[np.ndarray]] = {k: [] for k, _ in abi.OBS_COLUMNS}
     third: List[np.ndarray] = []
-    locus_flags, vtypes, refb, altb, sites = [], [], [], [], []
+    locus_flags, vtypes, refb, altb, sites, haplotypes = [], [], [], [], [], []
     for i in range(n):
         chrom, pos, ref, alt, _ = per_sample[0][i]
         for recs in per_sample[1:]:
@@ -260,9 +292,10 @@ def read_observation_vcf(paths: List[str], omit_bias_mask: int = 0) -> Tuple[Pil
         refb.append(ord(ref[0]) if has_snv else 0)
         altb.append(ord(alt[0]) if has_snv else 0)
         sites.append((chrom, pos, ref, alt))
+        haplotypes.append(haplotype_identifier(per_sample[0][i][4]))
     columns = {k: (np.concatenate(v) if v else np.zeros(0, dt)) for (k, dt), v in zip(abi.OBS_COLUMNS, cols.values())}
     locus = {"locus_flags": np.array(locus_flags, np.uint8), "variant_type": np.array(vtypes, np.uint8),
              "ref_base": np.array(refb, np.uint8), "alt_base": np.array(altb, np.uint8)}
     batch = PileupBatch(S, np.array(offsets, np.uint32), columns, locus)
-    batch.extra = {"third_allele_evidence": np.concatenate(third) if third else np.zeros(0, np.int64)}
+    batch.extra = {"third_allele_evidence": np.concatenate(third) if third else np.zeros(0, np.int64), "haplotype": haplotypes}
     return batch, sites
