@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define VLR_ABI_VERSION 1
+#define VLR_ABI_VERSION 2
 #define VLR_MAX_SAMPLES 8      /* samples per scenario supported by the device path   */
 #define VLR_N_BIAS      6      /* strand, orientation, position, softclip, homopolymer, alt-locus */
 
@@ -151,6 +151,12 @@ typedef struct {
     const vlr_node* nodes;
     const int32_t* child_index;
     const double*  vafs;                   /* pool for SET spectra                                     */
+    /* per-variant prior overrides from the candidate record's INFO HETEROZYGOSITY / SOMATIC_EFFECTIVE_MUTATION_RATE
+     * (PHRED in the file, calling.rs:470-494), as LogProb; NaN = None.  The reference installs them together with the
+     * contig's universe (calling.rs:704-713), i.e. they are plan data: when present they replace the (variant-type
+     * scaled) species heterozygosity / the per-sample somatic rates (prior.rs:250-270).                          */
+    double  variant_heterozygosity_ln;
+    double  variant_somatic_effective_mutation_rate_ln;
 } vlr_scenario_desc;
 
 /* ---------------------------------------------------------------- observations (SoA)

@@ -634,6 +634,7 @@ struct Prior {
     std::vector<double> germline_rate, somatic_rate;  // NaN none
     std::vector<vlr_inheritance> inheritance;
     double heterozygosity_ln = NAN;  // LogProb; NaN none
+    double variant_heterozygosity_ln = NAN, variant_somatic_rate_ln = NAN;  // per-variant overrides (calling.rs:470-494)
     double frac_indel = 0.0125, frac_mnv = 0.001, frac_sv = 0.01;
     bool is_absent_only = true;
     int variant_type = VLR_VT_SNV;
@@ -651,12 +652,14 @@ struct Prior {
             default: return 1.0;
         }
     }
-    bool somatic_rate_ln(int s, double* out) const {  // 250-257 (no per-variant override in the batch ABI)
+    bool somatic_rate_ln(int s, double* out) const {  // 250-257
+        if (!std::isnan(variant_somatic_rate_ln)) { *out = variant_somatic_rate_ln; return true; }
         if (std::isnan(somatic_rate[s])) return false;
         *out = std::log(somatic_rate[s] * variant_type_fraction());
         return true;
     }
     bool heterozygosity(double* out) const {  // 263-270
+        if (!std::isnan(variant_heterozygosity_ln)) { *out = variant_heterozygosity_ln; return true; }
         if (std::isnan(heterozygosity_ln)) return false;
         *out = std::log(std::exp(heterozygosity_ln) * variant_type_fraction());
         return true;
@@ -1254,6 +1257,8 @@ void build_scenario(const vlr_scenario_desc* d, Scenario& sc) {
     p.somatic_rate.assign(d->somatic_effective_mutation_rate, d->somatic_effective_mutation_rate + S);
     p.inheritance.assign(d->inheritance, d->inheritance + S);
     p.heterozygosity_ln = std::isnan(d->heterozygosity) ? NAN : std::log(d->heterozygosity);  // calling.rs:1079-1084
+    p.variant_heterozygosity_ln = d->variant_heterozygosity_ln;
+    p.variant_somatic_rate_ln = d->variant_somatic_effective_mutation_rate_ln;
     p.frac_indel = d->fraction_indel;
     p.frac_mnv = d->fraction_mnv;
     p.frac_sv = d->fraction_sv;

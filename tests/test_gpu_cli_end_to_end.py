@@ -145,3 +145,28 @@ def test_cli_breakend_groups_are_evaluated_once_and_fanned_out(golden_dir, tmp_p
         want = 2 if l in (2, 5, 6) else l
         assert np.array_equal(grouped.ln_posterior[l], plain.ln_posterior[want], equal_nan=True)
         assert np.array_equal(grouped.map_vaf[l], plain.map_vaf[want], equal_nan=True)
+
+
+def test_cli_reads_variant_specific_priors_from_the_first_record_of_a_contig(golden_dir, tmp_path):
+    import numpy as np
+    d = os.path.join(golden_dir, "flamegraph_profiling")
+    out, k = [], 0
+    for l in open(os.path.join(d, "normal.vcf")).read().split("\n"):
+        if l and not l.startswith("#"):
+            f = l.split("\t")
+            if k == 0:
+                f[7] = "HETEROZYGOSITY=13.0103;" + f[7]  # PHRED(0.05)
+            k += 1
+            l = "\t".join(f)
+        out.append(l)
+    obs = tmp_path / "het.vcf"
+    obs.write_text("\n".join(out))
+    y = tmp_path / "s.yaml"
+    y.write_text("species:\n  heterozygosity: 0.001\n  ploidy: 2\nsamples:\n  normal:\n    resolution: 0.1\nevents:\n  het: 'normal:0.5'\n  hom: 'normal:1.0'\n")
+    with_info = cli.call_variants(cli.scenario_from_yaml(str(y)), {"normal": str(obs)}, out=io.StringIO())
+    plain = cli.call_variants(cli.scenario_from_yaml(str(y)), {"normal": os.path.join(d, "normal.vcf")}, out=io.StringIO())
+    sc = cli.scenario_from_yaml(str(y))
+    sc.variant_heterozygosity_ln = -13.0103 * np.log(10.0) / 10.0
+    forced = cli.call_variants(sc, {"normal": os.path.join(d, "normal.vcf")}, out=io.StringIO())
+    assert np.array_equal(with_info.ln_posterior, forced.ln_posterior, equal_nan=True)
+    assert not np.allclose(with_info.ln_posterior, plain.ln_posterior, equal_nan=True)

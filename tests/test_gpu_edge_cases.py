@@ -274,3 +274,27 @@ def test_afd_fixture_matches_reference_file(oracle, golden_dir):
         assert ["%.3f" % x for x in v] == [e[0] for e in exp]
         for pi, e in zip(p, exp):
             assert abs(-10.0 / np.log(10.0) * pi - float(e[1])) <= 0.011
+
+
+def test_variant_specific_prior_overrides(oracle):
+    """INFO HETEROZYGOSITY / SOMATIC_EFFECTIVE_MUTATION_RATE of the candidate record replace the species heterozygosity and
+    the per-sample somatic rates (prior.rs:250-270, calling.rs:470-494, 704-713)."""
+    cfg = synth.config5()
+    b = synth.generate(cfg, 200, seed=31)
+    base, _ = check(oracle, cfg.scenario, b, "pedigree, scenario priors")
+    sc = synth.pedigree_scenario()
+    sc.variant_heterozygosity_ln = float(np.log(0.05))
+    got, _ = check(oracle, sc, b, "pedigree, variant heterozygosity 0.05")
+    assert np.nanmax(np.abs(np.exp(got.ln_posterior) - np.exp(base.ln_posterior))) > 1e-3
+    from varlociraptor_amd.scenario import Inheritance, Species
+    species = Species(heterozygosity=0.001, germline_mutation_rate=1e-3, ploidy=2)
+    tn = Scenario({"n": Sample(somatic_effective_mutation_rate=1e-10, resolution=0.1),
+                   "t": Sample(somatic_effective_mutation_rate=1e-6, resolution=0.05, inheritance=Inheritance(abi.INHERIT_CLONAL, ("n",), True))},
+                  {"germline": "n:0.5 | n:1.0", "somatic_t": "n:0.0 & t:]0.0,1.0]", "somatic_n": "n:]0.0,0.5["}, species=species)
+    cfg3 = synth.config3()
+    cfg3.scenario = tn
+    b3 = synth.generate(cfg3, 150, seed=32)
+    base3, _ = check(oracle, tn, b3, "tumor-normal, scenario rates")
+    tn.variant_somatic_effective_mutation_rate_ln = float(np.log(1e-3))
+    got3, _ = check(oracle, tn, b3, "tumor-normal, variant somatic rate 1e-3")
+    assert np.nanmax(np.abs(np.exp(got3.ln_posterior) - np.exp(base3.ln_posterior))) > 1e-3

@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_SAMPLES = 8
 N_BIAS = 6
 
@@ -84,6 +84,8 @@ class ScenarioDesc(C.Structure):
         ("nodes", C.POINTER(Node)),
         ("child_index", C.POINTER(C.c_int32)),
         ("vafs", C.POINTER(C.c_double)),
+        ("variant_heterozygosity_ln", C.c_double),
+        ("variant_somatic_effective_mutation_rate_ln", C.c_double),
     ]
 
 

@@ -77,7 +77,7 @@ def scenario_from_yaml(path: str, contig: str = "all") -> Scenario:
 
 
 def _scenario_signature(sc: Scenario):
-    return tuple((n, s.universe, s.ploidy) for n, s in sc.samples.items())
+    return tuple((n, s.universe, s.ploidy) for n, s in sc.samples.items()) + (sc.variant_heterozygosity_ln, sc.variant_somatic_effective_mutation_rate_ln)
 
 
 def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_capacity: int = 128, out=sys.stdout,
@@ -87,9 +87,20 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
     per_contig = scenario if callable(scenario) else (lambda contig: scenario)
     scen: Dict[str, Scenario] = {}
 
+    first_of_contig: Dict[str, tuple] = {}
+
     def resolve(contig):
         if contig not in scen:
             sc = per_contig(contig)
+            if callable(scenario) or contig in first_of_contig:
+                import copy
+                sc = copy.copy(sc)
+            # variant-specific priors are installed with the contig's model, from its first record (calling.rs:643-713)
+            het, som = first_of_contig.get(contig, (None, None))
+            if het is not None:
+                sc.variant_heterozygosity_ln = het
+            if som is not None:
+                sc.variant_somatic_effective_mutation_rate_ln = som
             for name in sc.sample_names:
                 if name not in obs_paths:
                     raise SystemExit("no observations given for sample %r" % name)
@@ -110,6 +121,8 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
     import numpy as np
     # breakends of one event share a pileup and a result: evaluate the first record of every event only and copy its
     # event probabilities / sample info to the others (calling.rs:569-580, 726-741, 820-839)
+    for site, pri in zip(sites, batch.extra.get("prior_overrides") or []):
+        first_of_contig.setdefault(site[0], pri)
     reps, source = obsfmt.haplotype_groups(batch.extra.get("haplotype") or [None] * batch.n_loci)
     groups: Dict[tuple, List[int]] = {}
     for l in reps:

@@ -84,6 +84,7 @@ struct HostPrior {
     std::vector<double> germline_rate, somatic_rate;
     std::vector<vlr_inheritance> inh;
     double het_ln = NAN;
+    double var_het_ln = NAN, var_som_ln = NAN;  // per-variant overrides (prior.rs:250-270)
     double f_indel, f_mnv, f_sv;
     bool absent_only = true;
     int vt = VLR_VT_SNV;
@@ -93,11 +94,13 @@ struct HostPrior {
         return vt == VLR_VT_INDEL ? f_indel : vt == VLR_VT_MNV ? f_mnv : vt == VLR_VT_SV ? f_sv : 1.0;
     }
     bool som_ln(int s, double* o) const {  // prior.rs:250-257
+        if (!std::isnan(var_som_ln)) { *o = var_som_ln; return true; }
         if (std::isnan(somatic_rate[s])) return false;
         *o = std::log(somatic_rate[s] * vt_fraction());
         return true;
     }
     bool het(double* o) const {  // prior.rs:263-270
+        if (!std::isnan(var_het_ln)) { *o = var_het_ln; return true; }
         if (std::isnan(het_ln)) return false;
         *o = std::log(std::exp(het_ln) * vt_fraction());
         return true;
@@ -278,6 +281,8 @@ int build_prior_table(const vlr_scenario_desc* d, vlr::DevPlan& P, std::vector<d
     pr.somatic_rate.assign(d->somatic_effective_mutation_rate, d->somatic_effective_mutation_rate + S);
     pr.inh.assign(d->inheritance, d->inheritance + S);
     pr.het_ln = std::isnan(d->heterozygosity) ? NAN : std::log(d->heterozygosity);
+    pr.var_het_ln = d->variant_heterozygosity_ln;
+    pr.var_som_ln = d->variant_somatic_effective_mutation_rate_ln;
     pr.f_indel = d->fraction_indel; pr.f_mnv = d->fraction_mnv; pr.f_sv = d->fraction_sv;
     pr.absent_only = d->is_absent_only != 0;
     pr.universe.resize(S);

@@ -48,6 +48,15 @@ def lib():
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             raise EngineError(abi.ERR_NO_DEVICE, "libvlr.so is not built (run varlociraptor_amd.engine.build()); no fallback path exists")
+        # One process, one HIP runtime: torch ships its own libamdhip64, libvlr.so is linked against /opt/rocm's.  If the
+        # engine initialises HIP first, a later torch.cuda initialisation finds no devices; loading torch's runtime first
+        # lets the dynamic loader resolve libvlr.so's dependency to the copy that is already mapped.
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.vlr_abi_version.restype = C.c_int
         L.vlr_last_error.restype = C.c_char_p

@@ -178,6 +178,17 @@ def _variant_class(ref: str, alt: str) -> Tuple[int, bool, bool]:
     return abi.VT_INDEL, False, False
 
 
+def _phred_info(info: Dict[str, str], key: str) -> Optional[float]:
+    """Variant-specific prior from the candidate record (calling.rs:470-494): PHRED float -> LogProb; None if absent/missing."""
+    v = info.get(key)
+    if v is None or v in ("", "."):
+        return None
+    x = float(v.split(",")[0])
+    if x != x:
+        return None
+    return -x * np.log(10.0) / 10.0
+
+
 def haplotype_identifier(info: Dict[str, str]) -> Optional[str]:
     """HaplotypeIdentifier::from (variants/model/mod.rs:87-133): INFO EVENT, else the sorted pair (record ID, MATEID)."""
     ev = info.get("EVENT")
@@ -254,7 +265,7 @@ def read_observation_vcf(paths: List[str], omit_bias_mask: int = 0) -> Tuple[Pil
     offsets = [0]
     cols: Dict[str, List[np.ndarray]] = {k: [] for k, _ in abi.OBS_COLUMNS}
     third: List[np.ndarray] = []
-    locus_flags, vtypes, refb, altb, sites, haplotypes = [], [], [], [], [], []
+    locus_flags, vtypes, refb, altb, sites, haplotypes, priors = [], [], [], [], [], [], []
     for i in range(n):
         chrom, pos, ref, alt, _ = per_sample[0][i]
         for recs in per_sample[1:]:
@@ -293,9 +304,11 @@ def read_observation_vcf(paths: List[str], omit_bias_mask: int = 0) -> Tuple[Pil
         altb.append(ord(alt[0]) if has_snv else 0)
         sites.append((chrom, pos, ref, alt))
         haplotypes.append(haplotype_identifier(per_sample[0][i][4]))
+        priors.append(tuple(_phred_info(per_sample[0][i][4], k) for k in ("HETEROZYGOSITY", "SOMATIC_EFFECTIVE_MUTATION_RATE")))
     columns = {k: (np.concatenate(v) if v else np.zeros(0, dt)) for (k, dt), v in zip(abi.OBS_COLUMNS, cols.values())}
     locus = {"locus_flags": np.array(locus_flags, np.uint8), "variant_type": np.array(vtypes, np.uint8),
              "ref_base": np.array(refb, np.uint8), "alt_base": np.array(altb, np.uint8)}
     batch = PileupBatch(S, np.array(offsets, np.uint32), columns, locus)
-    batch.extra = {"third_allele_evidence": np.concatenate(third) if third else np.zeros(0, np.int64), "haplotype": haplotypes}
+    batch.extra = {"third_allele_evidence": np.concatenate(third) if third else np.zeros(0, np.int64), "haplotype": haplotypes,
+                   "prior_overrides": priors}
     return batch, sites

@@ -283,6 +283,9 @@ class Scenario:
         self.events = dict(sorted(events.items()))  # BTreeMap order (grammar/mod.rs:137)
         self.event_names = list(self.events.keys())
         self.expressions = dict(expressions or {})
+        # per-variant prior overrides (LogProb) taken from the first candidate record of a contig (calling.rs:470-494, 704-713)
+        self.variant_heterozygosity_ln = None
+        self.variant_somatic_effective_mutation_rate_ln = None
         self._keep = []
 
     # Sample::contig_ploidy (grammar/mod.rs:581-593)
@@ -814,6 +817,9 @@ class Scenario:
         d.inheritance = arr(abi.Inheritance, inh)
         sp = self.species
         d.heterozygosity = nan if (sp is None or sp.heterozygosity is None) else sp.heterozygosity
+        d.variant_heterozygosity_ln = nan if self.variant_heterozygosity_ln is None else float(self.variant_heterozygosity_ln)
+        d.variant_somatic_effective_mutation_rate_ln = (nan if self.variant_somatic_effective_mutation_rate_ln is None
+                                                        else float(self.variant_somatic_effective_mutation_rate_ln))
         d.fraction_indel = sp.fraction_indel if sp else 0.0125
         d.fraction_mnv = sp.fraction_mnv if sp else 0.001
         d.fraction_sv = sp.fraction_sv if sp else 0.01
