@@ -249,13 +249,16 @@ struct vlr_plan {
     int n_events = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
-    // staging for vlr_batch_run_host
-    void* stage = nullptr;
-    size_t stage_bytes = 0;
+    // staging for vlr_batch_run_host: two slots (buffer + stream) so that the copies of one chunk of loci overlap the
+    // kernel of the previous one
+    void* stage[2] = {nullptr, nullptr};
+    size_t stage_bytes[2] = {0, 0};
+    hipStream_t stage_stream[2] = {nullptr, nullptr};
     unsigned long long* work_dev = nullptr;
-    // AFD replay scratch (device): is_discrete mask of the MAP, and marginal/best_event when the caller passes NULL
-    void* afd_scratch = nullptr;
-    size_t afd_scratch_bytes = 0;
+    // AFD replay scratch (device), one per slot: is_discrete mask of the MAP, and marginal/best_event when the caller passes NULL
+    void* afd_scratch[2] = {nullptr, nullptr};
+    size_t afd_scratch_bytes[2] = {0, 0};
+    int slot = 0;  // slot used by the next vlr_batch_run (set by vlr_batch_run_host)
 };
 
 namespace {
@@ -598,9 +601,12 @@ void vlr_plan_destroy(vlr_plan* plan) {
     if (!plan) return;
     if (plan->blob) (void)hipFree(plan->blob);
     if (plan->dev) (void)hipFree(plan->dev);
-    if (plan->stage) (void)hipFree(plan->stage);
+    for (int k = 0; k < 2; ++k) {
+        if (plan->stage[k]) (void)hipFree(plan->stage[k]);
+        if (plan->afd_scratch[k]) (void)hipFree(plan->afd_scratch[k]);
+        if (plan->stage_stream[k]) (void)hipStreamDestroy(plan->stage_stream[k]);
+    }
     if (plan->work_dev) (void)hipFree(plan->work_dev);
-    if (plan->afd_scratch) (void)hipFree(plan->afd_scratch);
     if (plan->ev_start) (void)hipEventDestroy(plan->ev_start);
     if (plan->ev_stop) (void)hipEventDestroy(plan->ev_stop);
     delete plan;
@@ -658,14 +664,15 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
     if (want_afd) {
         // the replay pass needs MAP is_discrete flags, marginal and best event of the first pass
         size_t L = (size_t)in->n_loci, need = L + 8 * L + 4 * L + 64;
-        if (need > plan->afd_scratch_bytes) {
-            if (plan->afd_scratch) (void)hipFree(plan->afd_scratch);
-            plan->afd_scratch = nullptr;
-            plan->afd_scratch_bytes = 0;
-            if (hipMalloc(&plan->afd_scratch, need) != hipSuccess) return fail(VLR_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed", need);
-            plan->afd_scratch_bytes = need;
+        const int k = plan->slot & 1;
+        if (need > plan->afd_scratch_bytes[k]) {
+            if (plan->afd_scratch[k]) (void)hipFree(plan->afd_scratch[k]);
+            plan->afd_scratch[k] = nullptr;
+            plan->afd_scratch_bytes[k] = 0;
+            if (hipMalloc(&plan->afd_scratch[k], need) != hipSuccess) return fail(VLR_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed", need);
+            plan->afd_scratch_bytes[k] = need;
         }
-        char* sc = (char*)plan->afd_scratch;
+        char* sc = (char*)plan->afd_scratch[k];
         if (!r.ln_marginal) r.ln_marginal = (double*)sc;
         if (!r.best_event) r.best_event = (int32_t*)(sc + 8 * L);
         r.map_disc = (uint8_t*)(sc + 12 * L);
@@ -716,13 +723,23 @@ extern "C" int vlr_plan_profile_counters(vlr_plan* plan, unsigned long long* out
     return VLR_OK;
 }
 
-int vlr_batch_run_host(vlr_plan* plan, const vlr_batch* in, vlr_results* out) {
-    if (!plan || !in || !out) return fail(VLR_ERR_INVALID_ARGUMENT, "null argument");
-    HIP_TRY(hipSetDevice(plan->device));
+// One chunk of loci [l0, l1) of a host batch: stage the inputs in slot k, launch on the slot's stream.  The result
+// copies are issued later by host_chunk_finish so that they do not stall the staging of the next chunk.
+struct HostChunk {
+    int64_t l0 = 0, l1 = 0;
+    int k = 0;
+    vlr_results dr{};
+    bool want_afd = false;
+    bool active = false;
+};
+
+static int host_chunk_start(vlr_plan* plan, const vlr_batch* in, vlr_results* out, int64_t l0, int64_t l1, int k, HostChunk* hc) {
     const int S = plan->host.S;
-    const int64_t L = in->n_loci, N = in->n_obs;
+    const int64_t L = l1 - l0;
     const int n_out = plan->n_events + 2;
-    if (L == 0) return VLR_OK;
+    const uint32_t ob = in->obs_offset[l0 * S], oe = in->obs_offset[l1 * S];
+    const size_t N = (size_t)(oe - ob);
+    hipStream_t st = plan->stage_stream[k];
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     struct Col { const void* src; size_t bytes; size_t off; };
     std::vector<Col> cols;
@@ -733,15 +750,15 @@ int vlr_batch_run_host(vlr_plan* plan, const vlr_batch* in, vlr_results* out) {
         off += al(std::max<size_t>(bytes, 1));
         return o;
     };
-    size_t o_off = add(in->obs_offset, (size_t)(L * S + 1) * 4);
-    size_t o_pm = add(in->prob_mapping, N * 4), o_pa = add(in->prob_alt, N * 4), o_pr = add(in->prob_ref, N * 4);
-    size_t o_ms = add(in->prob_missed_allele, N * 4), o_psa = add(in->prob_sample_alt, N * 4), o_pdo = add(in->prob_double_overlap, N * 4);
-    size_t o_phb = add(in->prob_hit_base, N * 4);
-    size_t o_hpa = add(in->prob_hp_artifact, in->prob_hp_artifact ? N * 4 : 0), o_hpv = add(in->prob_hp_variant, in->prob_hp_variant ? N * 4 : 0);
-    size_t o_fl = add(in->flags, N * 4);
-    size_t o_lf = add(in->locus_flags, L), o_vt = add(in->variant_type, in->variant_type ? L : 0);
-    size_t o_rb = add(in->ref_base, in->ref_base ? L : 0), o_ab = add(in->alt_base, in->alt_base ? L : 0);
-    size_t in_end = off;
+    auto obs = [&](const float* p) { return p ? (const void*)(p + ob) : nullptr; };
+    size_t o_off = add(in->obs_offset + l0 * S, (size_t)(L * S + 1) * 4);
+    size_t o_pm = add(obs(in->prob_mapping), N * 4), o_pa = add(obs(in->prob_alt), N * 4), o_pr = add(obs(in->prob_ref), N * 4);
+    size_t o_ms = add(obs(in->prob_missed_allele), N * 4), o_psa = add(obs(in->prob_sample_alt), N * 4), o_pdo = add(obs(in->prob_double_overlap), N * 4);
+    size_t o_phb = add(obs(in->prob_hit_base), N * 4);
+    size_t o_hpa = add(obs(in->prob_hp_artifact), in->prob_hp_artifact ? N * 4 : 0), o_hpv = add(obs(in->prob_hp_variant), in->prob_hp_variant ? N * 4 : 0);
+    size_t o_fl = add(in->flags + ob, N * 4);
+    size_t o_lf = add(in->locus_flags + l0, L), o_vt = add(in->variant_type ? in->variant_type + l0 : nullptr, in->variant_type ? L : 0);
+    size_t o_rb = add(in->ref_base ? in->ref_base + l0 : nullptr, in->ref_base ? L : 0), o_ab = add(in->alt_base ? in->alt_base + l0 : nullptr, in->alt_base ? L : 0);
     size_t r_post = off; off += al((size_t)L * n_out * 8);
     size_t r_marg = off; off += al((size_t)L * 8);
     size_t r_map = off; off += al((size_t)L * S * 8);
@@ -753,30 +770,36 @@ int vlr_batch_run_host(vlr_plan* plan, const vlr_batch* in, vlr_results* out) {
     size_t r_ac = off; off += al(want_afd ? (size_t)L * S * 4 : 0);
     size_t r_av = off; off += al((size_t)L * S * cap * 8);
     size_t r_al = off; off += al((size_t)L * S * cap * 8);
-    (void)in_end;
-    if (off > plan->stage_bytes) {
-        if (plan->stage) (void)hipFree(plan->stage);
-        plan->stage = nullptr;
-        plan->stage_bytes = 0;
-        if (hipMalloc(&plan->stage, off) != hipSuccess) return fail(VLR_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed", off);
-        plan->stage_bytes = off;
+    if (off > plan->stage_bytes[k]) {
+        if (plan->stage[k]) (void)hipFree(plan->stage[k]);
+        plan->stage[k] = nullptr;
+        plan->stage_bytes[k] = 0;
+        if (hipMalloc(&plan->stage[k], off) != hipSuccess) return fail(VLR_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed", off);
+        plan->stage_bytes[k] = off;
     }
-    char* base = (char*)plan->stage;
+    char* base = (char*)plan->stage[k];
+    // (A pinned bounce buffer filled by CPU threads was measured slower than the runtime's own pageable path on the
+    //  test box, 15 vs 14 GB/s with more CPU; callers that can hand over pinned arrays get true async DMA here.)
     for (auto& c : cols)
-        if (c.src && c.bytes) HIP_TRY(hipMemcpy(base + c.off, c.src, c.bytes, hipMemcpyHostToDevice));
+        if (c.src && c.bytes) HIP_TRY(hipMemcpyAsync(base + c.off, c.src, c.bytes, hipMemcpyHostToDevice, st));
+    // the kernel indexes the observation columns with the absolute row numbers of obs_offset: bias the column pointers
     vlr_batch db = *in;
+    db.n_loci = L;
+    db.n_obs = (int64_t)N;
     db.obs_offset = (const uint32_t*)(base + o_off);
-    db.prob_mapping = (const float*)(base + o_pm); db.prob_alt = (const float*)(base + o_pa); db.prob_ref = (const float*)(base + o_pr);
-    db.prob_missed_allele = (const float*)(base + o_ms); db.prob_sample_alt = (const float*)(base + o_psa);
-    db.prob_double_overlap = (const float*)(base + o_pdo); db.prob_hit_base = (const float*)(base + o_phb);
-    db.prob_hp_artifact = in->prob_hp_artifact ? (const float*)(base + o_hpa) : nullptr;
-    db.prob_hp_variant = in->prob_hp_variant ? (const float*)(base + o_hpv) : nullptr;
-    db.flags = (const uint32_t*)(base + o_fl);
+    auto colp = [&](size_t o) { return (const float*)(base + o) - ob; };
+    db.prob_mapping = colp(o_pm); db.prob_alt = colp(o_pa); db.prob_ref = colp(o_pr);
+    db.prob_missed_allele = colp(o_ms); db.prob_sample_alt = colp(o_psa);
+    db.prob_double_overlap = colp(o_pdo); db.prob_hit_base = colp(o_phb);
+    db.prob_hp_artifact = in->prob_hp_artifact ? colp(o_hpa) : nullptr;
+    db.prob_hp_variant = in->prob_hp_variant ? colp(o_hpv) : nullptr;
+    db.flags = (const uint32_t*)(base + o_fl) - ob;
     db.locus_flags = (const uint8_t*)(base + o_lf);
     db.variant_type = in->variant_type ? (const uint8_t*)(base + o_vt) : nullptr;
     db.ref_base = in->ref_base ? (const uint8_t*)(base + o_rb) : nullptr;
     db.alt_base = in->alt_base ? (const uint8_t*)(base + o_ab) : nullptr;
     vlr_results dr = *out;
+    dr.n_loci = L;
     dr.ln_posterior = (double*)(base + r_post);
     dr.ln_marginal = (double*)(base + r_marg);
     dr.map_vaf = (double*)(base + r_map);
@@ -786,32 +809,80 @@ int vlr_batch_run_host(vlr_plan* plan, const vlr_batch* in, vlr_results* out) {
     dr.afd_count = want_afd ? (int32_t*)(base + r_ac) : nullptr;
     dr.afd_vaf = want_afd ? (double*)(base + r_av) : nullptr;
     dr.afd_lnprob = want_afd ? (double*)(base + r_al) : nullptr;
-    if (want_afd && (!out->afd_count || !out->afd_vaf || !out->afd_lnprob || out->afd_capacity < 1))
-        return fail(VLR_ERR_INVALID_ARGUMENT, "AFD needs afd_count, afd_vaf, afd_lnprob and afd_capacity >= 1");
-    // size the LDS coefficient area to this batch (never above the configured budget)
+    // size the LDS coefficient area to this chunk (never above the configured budget)
     int saved_max_obs = plan->max_obs;
     {
         int budget = plan->max_obs > 0 ? plan->max_obs : plan->max_depth_per_sample * S;
         uint32_t mx = 1;
-        for (int64_t l = 0; l < L; ++l) mx = std::max(mx, in->obs_offset[(l + 1) * S] - in->obs_offset[l * S]);
+        for (int64_t l = l0; l < l1; ++l) mx = std::max(mx, in->obs_offset[(l + 1) * S] - in->obs_offset[l * S]);
         plan->max_obs = std::min<int>(budget, (int)mx);
     }
-    int rc = vlr_batch_run(plan, &db, &dr, nullptr);
+    plan->slot = k;
+    int rc = vlr_batch_run(plan, &db, &dr, (void*)st);
     plan->max_obs = saved_max_obs;
     if (rc != VLR_OK) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out->ln_posterior, dr.ln_posterior, (size_t)L * n_out * 8, hipMemcpyDeviceToHost));
-    if (out->ln_marginal) HIP_TRY(hipMemcpy(out->ln_marginal, dr.ln_marginal, (size_t)L * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(out->map_vaf, dr.map_vaf, (size_t)L * S * 8, hipMemcpyDeviceToHost));
-    if (out->map_bias) HIP_TRY(hipMemcpy(out->map_bias, dr.map_bias, (size_t)L * VLR_N_BIAS, hipMemcpyDeviceToHost));
-    if (out->best_event) HIP_TRY(hipMemcpy(out->best_event, dr.best_event, (size_t)L * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(out->status, dr.status, (size_t)L * 4, hipMemcpyDeviceToHost));
-    if (want_afd) {
-        HIP_TRY(hipMemcpy(out->afd_count, dr.afd_count, (size_t)L * S * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(out->afd_vaf, dr.afd_vaf, (size_t)L * S * cap * 8, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(out->afd_lnprob, dr.afd_lnprob, (size_t)L * S * cap * 8, hipMemcpyDeviceToHost));
-    }
+    hc->l0 = l0; hc->l1 = l1; hc->k = k; hc->dr = dr; hc->want_afd = want_afd; hc->active = true;
     return VLR_OK;
+}
+
+static int host_chunk_finish(vlr_plan* plan, vlr_results* out, HostChunk* hc) {
+    if (!hc->active) return VLR_OK;
+    const int S = plan->host.S;
+    const int n_out = plan->n_events + 2;
+    const int64_t l0 = hc->l0, L = hc->l1 - hc->l0;
+    const size_t cap = hc->want_afd ? (size_t)out->afd_capacity : 0;
+    hipStream_t st = plan->stage_stream[hc->k];
+    const vlr_results& dr = hc->dr;
+    HIP_TRY(hipMemcpyAsync(out->ln_posterior + l0 * n_out, dr.ln_posterior, (size_t)L * n_out * 8, hipMemcpyDeviceToHost, st));
+    if (out->ln_marginal) HIP_TRY(hipMemcpyAsync(out->ln_marginal + l0, dr.ln_marginal, (size_t)L * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out->map_vaf + l0 * S, dr.map_vaf, (size_t)L * S * 8, hipMemcpyDeviceToHost, st));
+    if (out->map_bias) HIP_TRY(hipMemcpyAsync(out->map_bias + l0 * VLR_N_BIAS, dr.map_bias, (size_t)L * VLR_N_BIAS, hipMemcpyDeviceToHost, st));
+    if (out->best_event) HIP_TRY(hipMemcpyAsync(out->best_event + l0, dr.best_event, (size_t)L * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out->status + l0, dr.status, (size_t)L * 4, hipMemcpyDeviceToHost, st));
+    if (hc->want_afd) {
+        HIP_TRY(hipMemcpyAsync(out->afd_count + l0 * S, dr.afd_count, (size_t)L * S * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(out->afd_vaf + l0 * S * cap, dr.afd_vaf, (size_t)L * S * cap * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(out->afd_lnprob + l0 * S * cap, dr.afd_lnprob, (size_t)L * S * cap * 8, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    hc->active = false;
+    return VLR_OK;
+}
+
+// Host buffers in, host buffers out.  The loci are cut into chunks of ~64 MB of observation data; chunk c+1 is staged
+// (H2D) while the kernel of chunk c runs on the other slot's stream, and the results of chunk c are fetched after the
+// launch of chunk c+1 — the PCIe transfers disappear behind the kernels.
+int vlr_batch_run_host(vlr_plan* plan, const vlr_batch* in, vlr_results* out) {
+    if (!plan || !in || !out) return fail(VLR_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(plan->device));
+    const int S = plan->host.S;
+    const int64_t L = in->n_loci;
+    if (L == 0) return VLR_OK;
+    if (in->n_samples != S) return fail(VLR_ERR_INVALID_ARGUMENT, "batch has %d samples, plan %d", in->n_samples, S);
+    if (!in->obs_offset || !in->flags || !in->locus_flags) return fail(VLR_ERR_INVALID_ARGUMENT, "missing required column");
+    const bool want_afd = out->afd_count || out->afd_vaf || out->afd_lnprob;
+    if (want_afd && (!out->afd_count || !out->afd_vaf || !out->afd_lnprob || out->afd_capacity < 1))
+        return fail(VLR_ERR_INVALID_ARGUMENT, "AFD needs afd_count, afd_vaf, afd_lnprob and afd_capacity >= 1");
+    for (int k = 0; k < 2; ++k)
+        if (!plan->stage_stream[k]) HIP_TRY(hipStreamCreateWithFlags(&plan->stage_stream[k], hipStreamNonBlocking));
+    // chunk boundaries: ~64 MB of observation columns (40 B per observation) and at least 8192 loci per chunk
+    const size_t bytes_total = (size_t)in->n_obs * 40 + (size_t)L * (S + 1) * 4;
+    int64_t n_chunks = (int64_t)std::max<size_t>(1, bytes_total / ((size_t)64 << 20));
+    n_chunks = std::min<int64_t>(n_chunks, std::max<int64_t>(1, L / 8192));
+    HostChunk hc[2];
+    int rc = VLR_OK;
+    for (int64_t c = 0; c < n_chunks && rc == VLR_OK; ++c) {
+        const int k = (int)(c & 1);
+        const int64_t l0 = L * c / n_chunks, l1 = L * (c + 1) / n_chunks;
+        rc = host_chunk_start(plan, in, out, l0, l1, k, &hc[k]);
+        if (rc == VLR_OK) rc = host_chunk_finish(plan, out, &hc[k ^ 1]);  // previous chunk: overlaps the kernel just launched
+    }
+    for (int k = 0; k < 2; ++k) {
+        int r2 = host_chunk_finish(plan, out, &hc[k]);
+        if (rc == VLR_OK) rc = r2;
+    }
+    if (rc != VLR_OK) (void)hipDeviceSynchronize();
+    return rc;
 }
 
 }  // extern "C"
