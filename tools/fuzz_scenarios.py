@@ -119,7 +119,7 @@ def main(argv=None):
             bias_mask = int(rng.choice([abi.BIAS_ALL, abi.BIAS_ALL, abi.BIAS_STRAND | abi.BIAS_ORIENTATION, abi.BIAS_POSITION | abi.BIAS_SOFTCLIP | abi.BIAS_HOMOPOLYMER, abi.BIAS_ALTLOCUS, 0]))
         else:
             type_mix, bias_mask = {abi.VT_SNV: 0.7, abi.VT_INDEL: 0.3}, abi.BIAS_ALL
-        cfg = synth.SynthConfig(name="fuzz", config_id=50, scenario=sc, depth=float(rng.choice([4.0, 12.0, 30.0] if not prior_mode else [8.0, 25.0, 60.0])), type_mix=type_mix,
+        cfg = synth.SynthConfig(name="fuzz", config_id=50, scenario=sc, depth=float(os.environ.get("FUZZ_DEPTH") or rng.choice([4.0, 12.0, 30.0] if not prior_mode else [8.0, 25.0, 60.0])), type_mix=type_mix,
                                 classes=classes, purity=None)
         b = synth.generate(cfg, 24, seed=int(rng.integers(1 << 30)), bias_mask=bias_mask)
         if only >= 0 and it != only:
