@@ -170,3 +170,13 @@ def test_cli_reads_variant_specific_priors_from_the_first_record_of_a_contig(gol
     forced = cli.call_variants(sc, {"normal": os.path.join(d, "normal.vcf")}, out=io.StringIO())
     assert np.array_equal(with_info.ln_posterior, forced.ln_posterior, equal_nan=True)
     assert not np.allclose(with_info.ln_posterior, plain.ln_posterior, equal_nan=True)
+
+
+@pytest.mark.parametrize("name,sample,lo,hi", [("test_moelder_floatisnan", "tumor", -1e-12, 1e-12), ("test_mapq_meth", "normal", 0.71, 0.72)])
+def test_cli_reference_testcases_expected_allele_frequencies(golden_dir, name, sample, lo, hi):
+    """The reference's testcase.yaml `expected: allelefreqs` conditions on the recorded v15 observations (see
+    tests/test_oracle_fixture.py); the 1009-observation pileup also exercises the LDS budget sizing of the CLI."""
+    d = os.path.join(golden_dir, "testcases", name)
+    res = cli.call_variants(cli.scenario_from_yaml(os.path.join(d, "scenario.yaml")), {sample: os.path.join(d, "observations.vcf")}, out=io.StringIO())
+    assert lo < res.map_vaf[0, 0] < hi
+    assert (res.status[0] & 0xF) == 0

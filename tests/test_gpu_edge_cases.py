@@ -298,3 +298,20 @@ def test_variant_specific_prior_overrides(oracle):
     tn.variant_somatic_effective_mutation_rate_ln = float(np.log(1e-3))
     got3, _ = check(oracle, tn, b3, "tumor-normal, variant somatic rate 1e-3")
     assert np.nanmax(np.abs(np.exp(got3.ln_posterior) - np.exp(base3.ln_posterior))) > 1e-3
+
+
+@pytest.mark.parametrize("name", ["test_moelder_floatisnan", "test_mapq_meth"])
+def test_reference_testcase_fixtures_parity(oracle, golden_dir, name):
+    """The recorded v15 observations of two reference testcases (1009 and 14 observations, SNV and <METH>): GPU == oracle."""
+    from varlociraptor_amd import cli, obsfmt
+    d = os.path.join(golden_dir, "testcases", name)
+    sc = cli.scenario_from_yaml(os.path.join(d, "scenario.yaml"))
+    batch, _ = obsfmt.read_observation_vcf([os.path.join(d, "observations.vcf")])
+    plan = engine.Plan(sc)
+    plan.set_max_obs(int(batch.depth().sum(axis=1).max()))
+    got = plan.call_host(batch)
+    plan.close()
+    ref = oracle.call(sc, batch, want_events=True)
+    m = compare(got, ref, label=name)
+    print(describe(m))
+    assert m["frac_within"] == 1.0 and m["bias_equal"] and m["status_equal"], describe(m)

@@ -134,6 +134,9 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
         sc = resolve(sites[loci[0]][0])
         plan = engine.Plan(sc, device=device)
         sub = batch if len(loci) == batch.n_loci else batch.select(loci)
+        # observation files are already capped by preprocess's --max-depth: size the LDS budget to the deepest record
+        deepest = int(sub.depth().sum(axis=1).max()) if sub.n_loci else 1
+        plan.set_max_obs(max(deepest, 1))
         r = plan.call_host(sub, afd_capacity=afd_capacity)
         plan.close()
         if names is None:
