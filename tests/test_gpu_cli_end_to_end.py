@@ -172,7 +172,10 @@ def test_cli_reads_variant_specific_priors_from_the_first_record_of_a_contig(gol
     assert not np.allclose(with_info.ln_posterior, plain.ln_posterior, equal_nan=True)
 
 
-@pytest.mark.parametrize("name,sample,lo,hi", [("test_moelder_floatisnan", "tumor", -1e-12, 1e-12), ("test_mapq_meth", "normal", 0.71, 0.72)])
+@pytest.mark.parametrize("name,sample,lo,hi", [("test_moelder_floatisnan", "tumor", -1e-12, 1e-12), ("test_mapq_meth", "normal", 0.71, 0.72),
+                                               ("test_hiv_vaf_higher_than_expected", "sample", 0.05, 0.3), ("test_prinz_af_scan", "normal", 0.0, 1.0),
+                                               ("test_prinz_call_meth_1", "normal", 0.97, 1.0 + 1e-12), ("test_prinz_call_meth_2", "normal", -1e-12, 1e-12),
+                                               ("test_uzuner_only_N", "sample", -1e-12, 1e-12)])
 def test_cli_reference_testcases_expected_allele_frequencies(golden_dir, name, sample, lo, hi):
     """The reference's testcase.yaml `expected: allelefreqs` conditions on the recorded v15 observations (see
     tests/test_oracle_fixture.py); the 1009-observation pileup also exercises the LDS budget sizing of the CLI."""

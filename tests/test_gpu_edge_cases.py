@@ -300,9 +300,11 @@ def test_variant_specific_prior_overrides(oracle):
     assert np.nanmax(np.abs(np.exp(got3.ln_posterior) - np.exp(base3.ln_posterior))) > 1e-3
 
 
-@pytest.mark.parametrize("name", ["test_moelder_floatisnan", "test_mapq_meth"])
+@pytest.mark.parametrize("name", ["test_moelder_floatisnan", "test_mapq_meth", "test_hiv_vaf_higher_than_expected", "test_prinz_af_scan",
+                                  "test_prinz_call_meth_1", "test_prinz_call_meth_2", "test_prinz_pacbio_zero", "test_uzuner_only_N"])
 def test_reference_testcase_fixtures_parity(oracle, golden_dir, name):
-    """The recorded v15 observations of two reference testcases (1009 and 14 observations, SNV and <METH>): GPU == oracle."""
+    """The recorded v15 observations of eight reference testcases (up to 2991 observations in one pileup = 72 kB of
+    coefficients in LDS; SNV and <METH> records): GPU == oracle."""
     from varlociraptor_amd import cli, obsfmt
     d = os.path.join(golden_dir, "testcases", name)
     sc = cli.scenario_from_yaml(os.path.join(d, "scenario.yaml"))
