@@ -1014,6 +1014,17 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
     const int ncls = p.n_class[inner];
     const double pr0 = uni_d(ptab[pidx]), pr1 = ncls > 1 ? uni_d(ptab[pidx + istride]) : VLR_NEG_INF, pr2 = ncls > 2 ? uni_d(ptab[pidx + 2 * istride]) : VLR_NEG_INF;
 
+    // prior class of the integrated sample: if one Range spectrum of a uniform-prior universe covers [lo, hi], every
+    // point of the chain is inside the universe (class 1, or 0 at exactly 0) — no per-point spectrum walk
+    bool cls_fast = false;
+    if (p.prior_kind[inner] == PK_UNIFORM)
+        for (int u = p.uni_off[inner]; u < p.uni_off[inner + 1]; ++u) {
+            const DevSpectrum sp = ld_spec(p.universe + u);
+            if (sp.kind == 1) {
+                RangeV ur{sp.start, sp.end, sp.lex, sp.rex};
+                cls_fast = cls_fast || (range_contains(ur, lo) && range_contains(ur, hi));
+            }
+        }
     // pending points and their joint values live in two tiny LDS arrays (same-wave LDS ops execute in order;
     // wave_barrier() only stops the compiler from reordering them)
     double* pend = w->ptA;  // reuse: ptA = pending x, ptJ = joint values
@@ -1066,7 +1077,7 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
             double jv;
             if (c.nlfc > 0 && !lfcs_ok(c, inner, xr)) jv = VLR_NEG_INF;
             else {
-                int cls = prior_class(p, inner, xr);
+                int cls = cls_fast ? (xr == 0.0 ? 0 : 1) : prior_class(p, inner, xr);
                 jv = (cls == 0 ? pr0 : cls == 1 ? pr1 : cls == 2 ? pr2 : ptab[pidx + cls * istride]) + lik;
             }
             const bool lead = rlane == 0 && (p0 + row) < np;
