@@ -706,6 +706,33 @@ __device__ inline int alive_update(const Ctx& c, int alive, int s, double v) {
     }
     return res;
 }
+// groups among `alive` whose spectra for sample s can contain ANY point of [lo, hi] (closed, slightly widened: a tail
+// point of a chain may exceed the bracket by an ulp): a chain whose interval misses all spectra of the other groups
+// needs no per-point alive_update
+__device__ inline int alive_restrict(const Ctx& c, int alive, int s, double lo, double hi) {
+    const DevPlan& p = *c.plan;
+    int m = UNI(alive);
+    s = UNI(s);
+    const double a = lo - 1e-9, b = hi + 1e-9;
+    int res = 0;
+    while (m) {
+        const int g = __builtin_ctz(m);
+        m &= m - 1;
+        const int o0 = ldc(p.grp_spec_off + g * p.S + s), o1 = ldc(p.grp_spec_off + g * p.S + s + 1);
+        bool hit = false;
+        for (int i = o0; i < o1 && !hit; ++i) {
+            const DevSpectrum sp = ld_spec(p.grp_spec + i);
+            if (sp.kind == 0) {
+                for (int k = 0; k < sp.set_len; ++k) {
+                    const double v = ldc(p.vafs + sp.set_off + k);
+                    hit = hit || (v >= a && v <= b);
+                }
+            } else hit = sp.start <= b && sp.end >= a;
+        }
+        if (hit) res |= 1 << g;
+    }
+    return res;
+}
 // VAFTree::contains (vaftree.rs:42-51,116-164) of group g for the current operands (sample `inner` at x)
 __device__ inline bool group_contains(Ctx& c, int g, int inner, double x, int excl = -1) {
     g = UNI(g); inner = UNI(inner); x = uni_d(x);
@@ -1014,6 +1041,7 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
     const int ncls = p.n_class[inner];
     const double pr0 = uni_d(ptab[pidx]), pr1 = ncls > 1 ? uni_d(ptab[pidx + istride]) : VLR_NEG_INF, pr2 = ncls > 2 ? uni_d(ptab[pidx + 2 * istride]) : VLR_NEG_INF;
 
+    const int alive_c = c.alive ? alive_restrict(c, c.alive, inner, lo, hi) : 0;  // other groups that can contain a point of this chain
     // prior class of the integrated sample: if one Range spectrum of a uniform-prior universe covers [lo, hi], every
     // point of the chain is inside the universe (class 1, or 0 at exactly 0) — no per-point spectrum walk
     bool cls_fast = false;
@@ -1093,7 +1121,7 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
 
         // MAP candidates (calling.rs:851-864)
         const bool own_in = c.contained && range_contains(orig, x);
-        const int al2 = c.alive ? alive_update(c, c.alive, inner, x) : 0;
+        const int al2 = alive_c ? alive_update(c, alive_c, inner, x) : 0;
         const bool slow = __ballot(owner && (!own_in || al2 != 0)) != 0ull;
         (void)joint;
         if (c.replay) {
@@ -1109,7 +1137,7 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
         } else {
             for (int i = 0; i < np; ++i) {
                 double xi = pend[i];
-                map_all(c, vals[i], inner, xi, c.contained && range_contains(orig, xi), c.alive ? alive_update(c, c.alive, inner, xi) : 0);
+                map_all(c, vals[i], inner, xi, c.contained && range_contains(orig, xi), alive_c ? alive_update(c, alive_c, inner, xi) : 0);
             }
         }
         tn += np;
