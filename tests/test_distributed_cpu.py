@@ -58,3 +58,49 @@ def test_two_rank_gather_matches_single_process(n_loci):
     assert np.array_equal(full[:, :n_out], ref.ln_posterior)
     assert np.array_equal(full[:, n_out:n_out + 1], ref.map_vaf, equal_nan=True)
     assert np.array_equal(full[:, -1].astype(np.uint32), ref.status)
+
+
+def _worker_full(rank, world, port, n_loci, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle
+    from varlociraptor_amd import synth
+    from varlociraptor_amd.batch import CallResults
+    from varlociraptor_amd.dist import gather_call_results, shard_range
+    cfg = synth.config2()
+    batch = synth.generate(cfg, n_loci)
+    lo, hi = shard_range(n_loci, rank, world)
+    res = oracle.call(cfg.scenario, batch.select(range(lo, hi)), afd_capacity=96) if hi > lo else CallResults(0, cfg.scenario.n_out, 1, 96)
+    full = gather_call_results(res, lo, hi, n_loci, cfg.scenario.n_out, 1, afd_capacity=96)
+    if rank == 1:  # every rank holds the full result
+        q.put({k: getattr(full, k) for k in ("ln_posterior", "ln_marginal", "map_vaf", "map_bias", "best_event", "status", "afd_count", "afd_vaf", "afd_lnprob")})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_loci,world", [(41, 2), (5, 3)])
+def test_gather_call_results_including_afd_lists(n_loci, world):
+    """Fixed-size fields in one all-gather, the ragged AFD lists as counts + packed pairs in a second one; ranks with an
+    empty shard take part (5 loci on 3 ranks)."""
+    sys.path.insert(0, ROOT)
+    from oracle import oracle
+    from varlociraptor_amd import synth
+    oracle.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29100 + (os.getpid() % 500) + n_loci
+    procs = [ctx.Process(target=_worker_full, args=(r, world, port, n_loci, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cfg = synth.config2()
+    ref = oracle.call(cfg.scenario, synth.generate(cfg, n_loci), afd_capacity=96)
+    for k in ("ln_posterior", "ln_marginal", "map_vaf", "map_bias", "best_event", "status", "afd_count"):
+        assert np.array_equal(full[k], getattr(ref, k), equal_nan=True), k
+    m = np.arange(96)[None, None, :] < ref.afd_count[:, :, None]
+    assert np.array_equal(full["afd_vaf"][m], ref.afd_vaf[m]) and np.array_equal(full["afd_lnprob"][m], ref.afd_lnprob[m])

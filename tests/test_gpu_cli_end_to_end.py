@@ -183,3 +183,23 @@ def test_cli_reference_testcases_expected_allele_frequencies(golden_dir, name, s
     res = cli.call_variants(cli.scenario_from_yaml(os.path.join(d, "scenario.yaml")), {sample: os.path.join(d, "observations.vcf")}, out=io.StringIO())
     assert lo < res.map_vaf[0, 0] < hi
     assert (res.status[0] & 0xF) == 0
+
+
+def test_cli_two_ranks_shard_and_reassemble(golden_dir, tmp_path):
+    """`call variants` under torchrun with two ranks (both on the one GPU of the test box, gloo for the exchange): loci
+    are sharded, results all-gathered, rank 0 writes the same file as a single process."""
+    import subprocess
+    import sys
+    d = os.path.join(golden_dir, "flamegraph_profiling")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    one = tmp_path / "one.vcf"
+    two = tmp_path / "two.vcf"
+    base = ["-m", "varlociraptor_amd", "call", "variants", "--omit-strand-bias", "--omit-read-orientation-bias", "--omit-read-position-bias",
+            "--omit-softclip-bias", "--omit-homopolymer-artifact-detection", "--omit-alt-locus-bias"]
+    tail = ["generic", "--scenario", os.path.join(d, "scenario.yaml"), "--obs", "normal=" + os.path.join(d, "normal.vcf")]
+    env = dict(os.environ, PYTHONPATH=root, VLR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    subprocess.run([sys.executable] + base + ["--output", str(one)] + tail, check=True, cwd=root, env=env, timeout=600)
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", "29541"] + base + ["--output", str(two)] + tail, check=True, cwd=root, env=env, timeout=900)
+    a, b = one.read_text(), two.read_text()
+    assert a == b and a.count("\n") > 11

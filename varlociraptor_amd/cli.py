@@ -123,6 +123,13 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
     # event probabilities / sample info to the others (calling.rs:569-580, 726-741, 820-839)
     for site, pri in zip(sites, batch.extra.get("prior_overrides") or []):
         first_of_contig.setdefault(site[0], pri)
+    world, rank = 1, 0
+    try:
+        import torch.distributed as tdist
+        if tdist.is_available() and tdist.is_initialized():
+            world, rank = tdist.get_world_size(), tdist.get_rank()
+    except ImportError:
+        pass
     reps, source = obsfmt.haplotype_groups(batch.extra.get("haplotype") or [None] * batch.n_loci)
     groups: Dict[tuple, List[int]] = {}
     for l in reps:
@@ -132,13 +139,30 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
     names = None
     for sig, loci in groups.items():
         sc = resolve(sites[loci[0]][0])
-        plan = engine.Plan(sc, device=device)
-        sub = batch if len(loci) == batch.n_loci else batch.select(loci)
-        # observation files are already capped by preprocess's --max-depth: size the LDS budget to the deepest record
-        deepest = int(sub.depth().sum(axis=1).max()) if sub.n_loci else 1
-        plan.set_max_obs(max(deepest, 1))
-        r = plan.call_host(sub, afd_capacity=afd_capacity)
-        plan.close()
+        if world > 1:
+            # loci shard across the ranks (one process per GPU); the results are reassembled by one all-gather of
+            # fixed-size records (+ one for the AFD lists), every rank ends up with the full result
+            from . import dist as vdist
+            lo, hi = vdist.shard_range(len(loci), rank, world)
+            mine = loci[lo:hi]
+            n_out_, S_ = sc.n_out, len(sc.sample_names)
+            if mine:
+                plan = engine.Plan(sc, device=device)
+                sub = batch.select(mine)
+                plan.set_max_obs(max(int(sub.depth().sum(axis=1).max()), 1))
+                rl = plan.call_host(sub, afd_capacity=afd_capacity)
+                plan.close()
+            else:
+                rl = CallResults(0, n_out_, S_, afd_capacity)
+            r = vdist.gather_call_results(rl, lo, hi, len(loci), n_out_, S_, afd_capacity)
+        else:
+            plan = engine.Plan(sc, device=device)
+            sub = batch if len(loci) == batch.n_loci else batch.select(loci)
+            # observation files are already capped by preprocess's --max-depth: size the LDS budget to the deepest record
+            deepest = int(sub.depth().sum(axis=1).max()) if sub.n_loci else 1
+            plan.set_max_obs(max(deepest, 1))
+            r = plan.call_host(sub, afd_capacity=afd_capacity)
+            plan.close()
         if names is None:
             names = sc.out_names()
         if len(loci) == batch.n_loci:
@@ -159,6 +183,8 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                 a[:] = a[src]
     scenario0 = resolve(sites[0][0] if sites else "all")
     header = callsfmt.header(names or scenario0.out_names(), scenario0.sample_names, sorted(set(s[0] for s in sites)))
+    if rank != 0:
+        return res
     if output and output.endswith(".bcf"):  # binary calls file (reference: bcf::Writer, calling.rs:296-304)
         from .bcfio import BcfWriter
         with BcfWriter(output, header) as wr:
@@ -207,6 +233,16 @@ def main(argv=None):
     cf.add_argument("--maxlen", type=int)
     cf.add_argument("--device", default="cpu")
     a = ap.parse_args(argv)
+    import os
+    if a.cmd == "call" and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # one process per GPU (torchrun): `nccl` is RCCL on ROCm; VLR_DIST_BACKEND=gloo for hosts with fewer GPUs than ranks
+        import torch
+        import torch.distributed as tdist
+        backend = os.environ.get("VLR_DIST_BACKEND", "nccl")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        a.device = local % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(a.device)
+        tdist.init_process_group(backend, **({"device_id": torch.device("cuda", a.device)} if backend == "nccl" else {}))
     if a.cmd == "filter-calls":
         from . import fdr
         from .bcfio import BcfReader
