@@ -99,6 +99,17 @@ def test_set_and_range_spectra_mixed(oracle):
     check(oracle, sc, synth.generate(cfg, 200, seed=14), "set+range")
 
 
+def test_map_via_another_branch_at_excluded_range_end(oracle):
+    """With fewer than 10 observations the excluded end of `!b:1.0` (= b:[0,1[) is still visited (formula.rs:1170-1216);
+    that operand set belongs to the same event through its other branch `b:1.0` and can be its MAP (calling.rs:851-864)."""
+    samples = {"a": Sample(resolution=0.1, universe="[0.0,1.0]"), "b": Sample(resolution=0.05, universe="[0.0,1.0]")}
+    events = {"ev0": "(b:1.0) | (!b:1.0 & !a:[0.5,1.0])", "ev1": "!a:[0.1,0.4]", "ev2": "a:[0.5,1.0]", "ev3": "a:1.0 & b:[0.5,1.0]"}
+    sc = Scenario(samples, events)
+    cfg = synth.SynthConfig(name="excl", config_id=9, scenario=sc, depth=5.0, type_mix={abi.VT_SNV: 0.7, abi.VT_INDEL: 0.3},
+                            classes=[("hom_b", 0.7, ((0.1, 0.3), (1.0, 1.0))), ("other", 0.3, ((0.0, 0.5), (0.5, 1.0)))], purity=None)
+    check(oracle, sc, synth.generate(cfg, 300, seed=40), "excluded-end MAP")
+
+
 def test_log2_fold_change_events(oracle):
     """LFC nodes: bounds inference for the second sample (modes/generic.rs:148-174) and the predicate check at
     the leaf (generic.rs:503-509)."""

@@ -26,11 +26,19 @@ if events: sc = Scenario(sc.samples, events)
 sub = b.select([locus])
 np.set_printoptions(precision=6, linewidth=220)
 print(sc.events, "variant type", sub.locus["variant_type"], "flags", bin(int(sub.locus["locus_flags"][0])))
+if os.environ.get("AFD"):
+    plan=engine.Plan(sc); g=plan.call_host(sub, afd_capacity=128); plan.close()
+    r=oracle.call(sc,sub,afd_capacity=128)
+    for si in range(sub.n_samples):
+        ng, nr = int(g.afd_count[0, si]), int(r.afd_count[0, si])
+        print("AFD s%d gpu" % si, ng, list(zip(g.afd_vaf[0, si, :min(ng,128)].round(5), g.afd_lnprob[0, si, :min(ng,128)].round(6))))
+        print("AFD s%d ref" % si, nr, list(zip(r.afd_vaf[0, si, :min(nr,128)].round(5), r.afd_lnprob[0, si, :min(nr,128)].round(6))))
 for mask in [abi.BIAS_ALL, abi.BIAS_STRAND, abi.BIAS_ORIENTATION, abi.BIAS_POSITION, abi.BIAS_SOFTCLIP, abi.BIAS_HOMOPOLYMER, abi.BIAS_ALTLOCUS]:
     sub.locus["locus_flags"][:] = (sub.locus["locus_flags"] & ~np.uint8(0x3f)) | np.uint8(mask)
     plan=engine.Plan(sc); g=plan.call_host(sub); plan.close()
     r=oracle.call(sc,sub,want_events=True)
     print("mask %02x gpu" % mask, g.ln_posterior[0], "| ref", r.ln_posterior[0], "| ref events", r.event_ln_posterior[0])
+    print("   map gpu", g.map_vaf[0], "best", g.best_event[0], "bias", g.map_bias[0], "| ref", r.map_vaf[0], "best", r.best_event[0], "bias", r.map_bias[0])
 if os.environ.get("DUMP"):
     for s in range(sub.n_samples):
         sl = sub.pileup_slice(0, s)

@@ -1413,7 +1413,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
     const int TT = (nmax + 15) >> 4;  // entries per lane (uniform), <= 4 because the row path requires cap <= 64
     double bJ = VLR_NEG_INF, bX = 0.0;
     int bHave = 0;
-    bool anynan = false;
+    bool anynan = false, anyout = false;  // anyout: a visited point lies outside the leaf's own range (excluded range end)
     double rint_ = VLR_NEG_INF;
     {
         double xi[4], vi[4], px[4], sx[4];
@@ -1435,6 +1435,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
                 const bool cand = on & (contained != 0) & inlo & inhi & (vi[t] == vi[t]);
                 const bool take = cand & ((bHave == 0) | (vi[t] > bJ) | ((vi[t] == bJ) & (xi[t] < bX)));
                 bJ = take ? vi[t] : bJ; bX = take ? xi[t] : bX; bHave = take ? 1 : bHave;
+                anyout = anyout | (on & !(inlo & inhi));
                 anynan = anynan | (vi[t] != vi[t]);
             }
         }
@@ -1495,12 +1496,13 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
         rint_ = (M == VLR_NEG_INF) ? VLR_NEG_INF : M + log(ssum);
     }
     int nanrow = row_or(anynan ? 1 : 0);
+    const int rowout = row_or(anyout ? 1 : 0);
     double r = rint_;
     if (phase == RP_SIMPSON) r = r + log(hi - lo) - log((double)(simpson_n - 1)) - log(3.0);
     if (nanrow || failed) r = __builtin_nan("");
     if (rowon && rl == 0) {
         ChainTask& To = w->task[row];
-        To.result = r; To.bestJ = bJ; To.bestX = bX; To.haveBest = bHave; To.n = n;
+        To.result = r; To.bestJ = bJ; To.bestX = bX; To.haveBest = bHave | (rowout ? 2 : 0); To.n = n;
     }
     __builtin_amdgcn_wave_barrier();
     __syncthreads();
@@ -1688,8 +1690,9 @@ __device__ __forceinline__ bool bo_deliver(Ctx& c, const Frame& f, RangeSt& r, d
             afd_emit_row(c, i, s_in, UNI(T.n));
             continue;
         }
-        if (UNI(T.haveBest)) map_consider(c, uni_d(T.bestJ), s_in, uni_d(T.bestX));
-        if (UNI(T.alive) != 0 || !UNI(T.contained)) {  // rare: candidates for other groups / containment via another path
+        if (UNI(T.haveBest) & 1) map_consider(c, uni_d(T.bestJ), s_in, uni_d(T.bestX));
+        // rare: candidates for other groups / containment via another path (also of a visited excluded range end)
+        if (UNI(T.alive) != 0 || !UNI(T.contained) || (UNI(T.haveBest) & 2)) {
             const RangeV io{uni_d(T.ostart), uni_d(T.oend), UNI(T.olex), UNI(T.orex)};
             scan_chain_candidates(c, c.rowX + i * c.cap, c.rowV + i * c.cap, UNI(T.n), io, UNI(T.contained), UNI(T.alive), s_in);
         }
@@ -1759,8 +1762,8 @@ __device__ __forceinline__ void flush_deferred(Ctx& c, double* evM, double* evS,
         const int nq = UNI(T.n);
         if (c.replay) afd_emit_row(c, i, s_in, nq);
         else {
-            if (UNI(T.haveBest)) map_consider(c, uni_d(T.bestJ), s_in, uni_d(T.bestX));
-            if (c.alive != 0 || !c.contained) {
+            if (UNI(T.haveBest) & 1) map_consider(c, uni_d(T.bestJ), s_in, uni_d(T.bestX));
+            if (c.alive != 0 || !c.contained || (UNI(T.haveBest) & 2)) {
                 const RangeV io{uni_d(T.ostart), uni_d(T.oend), UNI(T.olex), UNI(T.orex)};
                 scan_chain_candidates(c, c.rowX + i * c.cap, c.rowV + i * c.cap, nq, io, c.contained, c.alive, s_in);
             }
