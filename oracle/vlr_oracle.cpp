@@ -1298,7 +1298,8 @@ Obs make_obs(const vlr_batch* b, int64_t i) {
 
 // MAP ordering: reference sorts joint_probs by posterior descending with unspecified tie order
 // (bio ModelInstance::event_posteriors over a HashMap).  Deterministic rule: higher prob first;
-// ties: non-artifact first, then lower hypothesis id, then lexicographically smaller VAF tuple.
+// ties: non-artifact first, then lower hypothesis id, then lexicographically smaller VAF tuple, then the operand
+// set whose first differing is_discrete flag is set.
 bool map_before(const JointEntry& a, const JointEntry& b) {
     if (a.prob != b.prob) return a.prob > b.prob;
     int aa = 0, ab = 0;
@@ -1307,6 +1308,8 @@ bool map_before(const JointEntry& a, const JointEntry& b) {
     if (aa != ab) return aa < ab;
     for (size_t s = 0; s < a.ops.events.size(); ++s)
         if (a.ops.events[s].af != b.ops.events[s].af) return a.ops.events[s].af < b.ops.events[s].af;
+    for (size_t s = 0; s < a.ops.events.size(); ++s)
+        if (a.ops.events[s].discrete != b.ops.events[s].discrete) return a.ops.events[s].discrete;
     return false;
 }
 

@@ -653,7 +653,12 @@ __device__ inline double sample_lik(Ctx& c, int s, double a, double b) {
     return r;
 }
 
-// MAP ordering (oracle map_before): higher joint first; ties: lower hypothesis id, then smaller VAF tuple
+// MAP ordering (oracle map_before): higher joint first; ties: lower hypothesis id, then smaller VAF tuple, then the
+// operand set whose first differing is_discrete flag is set
+__device__ inline bool disc_before(int nd, int od) {
+    const int diff = nd ^ od;
+    return diff != 0 && (nd & diff & -diff) != 0;
+}
 __device__ inline void map_consider(Ctx& c, double joint, int inner, double x) {
     joint = uni_d(joint); x = uni_d(x); inner = UNI(inner);
     if (!(joint == joint)) return;
@@ -661,11 +666,13 @@ __device__ inline void map_consider(Ctx& c, double joint, int inner, double x) {
     if (!better && joint == c.curJ && c.curHyp >= 0) {
         if (c.hyp != (c.curHyp & 15)) better = c.hyp < (c.curHyp & 15);
         else {
+            bool same = true;
             for (int s = 0; s < c.S; ++s) {
                 double v = (s == inner) ? x : c.w->ops_vaf[s];
                 double o = c.w->curMapVaf[s];
-                if (v != o) { better = v < o; break; }
+                if (v != o) { better = v < o; same = false; break; }
             }
+            if (same) better = disc_before((inner >= 0) ? (c.disc & ~(1 << inner)) : c.disc, c.curHyp >> 4);
         }
     }
     if (c.curHyp < 0) better = true;
@@ -787,12 +794,15 @@ __device__ inline void cross_consider(Ctx& c, int g, double joint, int inner, do
     bool better = curHyp < 0 || joint > curJ;
     if (!better && joint == curJ) {
         if (c.hyp != (curHyp & 15)) better = c.hyp < (curHyp & 15);
-        else
+        else {
+            bool same = true;
             for (int s = 0; s < c.S; ++s) {
                 double v = (s == inner) ? x : c.w->ops_vaf[s];
                 double o = c.mapVaf[slot * c.S + s];
-                if (v != o) { better = v < o; break; }
+                if (v != o) { better = v < o; same = false; break; }
             }
+            if (same) better = disc_before((inner >= 0) ? (c.disc & ~(1 << inner)) : c.disc, curHyp >> 4);
+        }
     }
     if (better) {
         __syncthreads();
