@@ -289,6 +289,14 @@ int  vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* 
  * synchronises before returning.  Still requires the GPU (no CPU fallback).                             */
 int  vlr_batch_run_host(vlr_plan* plan, const vlr_batch* in, vlr_results* out);
 
+/* Page-locked host memory for the arrays handed to vlr_batch_run_host (columns in, results out).  The staging
+ * copies of vlr_batch_run_host are asynchronous; from pageable memory the runtime bounces them through its own
+ * pinned buffer (about 14 GB/s here), from memory obtained here they are direct DMA and overlap the kernel of the
+ * previous chunk.  The reference-side binding decodes the observation records (calling.rs:720-760) straight into
+ * such arrays.  vlr_host_alloc returns NULL on failure (see vlr_last_error); vlr_host_free(NULL) is a no-op. */
+void* vlr_host_alloc(size_t bytes);
+void  vlr_host_free(void* p);
+
 /* Duration in milliseconds of the most recent kernel launch sequence of vlr_batch_run on this plan,
  * measured with HIP events on the launch stream (synchronises on the stop event).  For bench.py.       */
 int  vlr_plan_last_kernel_ms(vlr_plan* plan, float* ms);

@@ -24,7 +24,7 @@ _LIB = None
 EXPORTS = [
     "vlr_abi_version", "vlr_last_error", "vlr_plan_create", "vlr_plan_destroy", "vlr_plan_n_out",
     "vlr_plan_n_samples", "vlr_plan_set_max_depth", "vlr_plan_set_max_obs", "vlr_batch_run", "vlr_batch_run_host",
-    "vlr_plan_last_kernel_ms", "vlr_plan_work_counters",
+    "vlr_plan_last_kernel_ms", "vlr_plan_work_counters", "vlr_host_alloc", "vlr_host_free",
 ]
 
 
@@ -78,6 +78,10 @@ def lib():
         L.vlr_batch_run_host.argtypes = [C.c_void_p, C.POINTER(abi.Batch), C.POINTER(abi.Results)]
         L.vlr_plan_last_kernel_ms.restype = C.c_int
         L.vlr_plan_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.vlr_host_alloc.restype = C.c_void_p
+        L.vlr_host_alloc.argtypes = [C.c_size_t]
+        L.vlr_host_free.restype = None
+        L.vlr_host_free.argtypes = [C.c_void_p]
         L.vlr_plan_work_counters.restype = C.c_int
         L.vlr_plan_work_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
         if L.vlr_abi_version() != abi.ABI_VERSION:
@@ -89,6 +93,40 @@ def lib():
 def _check(rc):
     if rc != 0:
         raise EngineError(rc, lib().vlr_last_error().decode())
+
+
+class _HostBlock:
+    """Page-locked host memory from vlr_host_alloc, exposed to numpy through the array interface."""
+
+    def __init__(self, nbytes: int):
+        self.ptr = lib().vlr_host_alloc(max(1, int(nbytes)))
+        if not self.ptr:
+            raise EngineError(abi.ERR_OOM, lib().vlr_last_error().decode())
+        self.__array_interface__ = {"shape": (max(1, int(nbytes)),), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
+
+    def __del__(self):
+        if getattr(self, "ptr", None) and _LIB is not None:
+            _LIB.vlr_host_free(self.ptr)
+            self.ptr = None
+
+
+def host_array(shape, dtype) -> np.ndarray:
+    """Uninitialised page-locked numpy array (include/vlr.h vlr_host_alloc); freed with its last view."""
+    dtype = np.dtype(dtype)
+    shape = (int(shape),) if np.isscalar(shape) else tuple(int(x) for x in shape)
+    n = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    flat = np.asarray(_HostBlock(n))[:n]
+    return flat.view(dtype).reshape(shape)
+
+
+def pin_batch(batch: PileupBatch) -> PileupBatch:
+    """Copy of `batch` whose arrays live in page-locked memory, so that call_host stages them by direct DMA."""
+    def pin(a):
+        out = host_array(a.shape, a.dtype)
+        out[...] = a
+        return out
+    return PileupBatch(batch.n_samples, pin(batch.obs_offset), {k: pin(v) for k, v in batch.columns.items()},
+                       {k: pin(v) for k, v in batch.locus.items()})
 
 
 class Plan:
