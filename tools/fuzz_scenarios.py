@@ -17,8 +17,8 @@ SPECTRA = ["0.0", "0.5", "1.0", "{0.0,0.5}", "{0.5,1.0}", "]0.0,1.0]", "]0.0,0.5
 
 
 def random_scenario(rng):
-    S = int(rng.choice([1, 2, 2, 3]))
-    names = ["a", "b", "c"][:S]
+    S = int(os.environ.get("FUZZ_S") or rng.choice([1, 2, 2, 3]))
+    names = ["a", "b", "c", "d", "e", "f"][:S]
     samples = {}
     for i, n in enumerate(names):
         cont = None

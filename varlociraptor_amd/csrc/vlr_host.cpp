@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <string>
 #include <vector>
@@ -546,6 +547,138 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
     int rc = build_prior_table(d, P, table);
     if (rc != VLR_OK) return rc;
 
+    // ---- all-discrete roots, flattened for the lane-parallel leaf evaluation (vlr_kernels.hip eval_discrete_root)
+    std::vector<DevDLeaf> dleaf;
+    std::vector<DevDKey> dkey;
+    std::vector<int32_t> droot(2 * (1 + roots.size()), -1);
+    {
+        auto node_values = [&](const DevNode& n, std::vector<double>& vals) {
+            vals.clear();
+            if (n.kind != VLR_NODE_SAMPLE) return false;
+            if (n.vafs.kind == VLR_SPECTRUM_SET) vals.assign(pool.begin() + n.vafs.set_off, pool.begin() + n.vafs.set_off + n.vafs.set_len);
+            else if (n.vafs.start == n.vafs.end && !n.vafs.lex && !n.vafs.rex) vals.push_back(n.vafs.start);
+            return !vals.empty();
+        };
+        auto spec_contains = [&](const DevSpectrum& sp, double v) {
+            if (sp.kind == VLR_SPECTRUM_SET) {
+                for (int i = 0; i < sp.set_len; ++i) if (pool[sp.set_off + i] == v) return true;
+                return false;
+            }
+            bool lo = sp.lex ? sp.start < v : sp.start <= v, hi = sp.rex ? sp.end > v : sp.end >= v;
+            return lo && hi;
+        };
+        auto rel_eq = [](double a, double b) {
+            const double eps = 2.220446049250313e-16;
+            if (a == b) return true;
+            if (std::isinf(a) || std::isinf(b)) return false;
+            double df = std::fabs(a - b);
+            if (df <= eps) return true;
+            return df <= std::max(std::fabs(a), std::fabs(b)) * eps;
+        };
+        auto prior_class = [&](int s2, double v) {  // same classes as the device's prior_class()
+            if (P.prior_kind[s2] == PK_UNIFORM) {
+                bool in = false;
+                for (int u = P.uni_off[s2]; u < P.uni_off[s2 + 1]; ++u) in = in || spec_contains(uni[u], v);
+                return in ? (v == 0.0 ? 0 : 1) : 2;
+            }
+            int pl = P.ploidy[s2];
+            double dp = (double)pl, k = std::rint(dp * v);
+            bool match;
+            if (P.prior_kind[s2] == PK_GERMLINE) match = rel_eq(dp * v, k);
+            else match = pl > 0 ? rel_eq(v - k / dp, 0.0) : (v == 0.0);
+            return (match && k >= 0.0 && k <= dp) ? (int)k : pl + 1;
+        };
+        // VAFTree::contains (vaftree.rs:42-51,116-164) for operands without l2fc terms
+        std::function<bool(int, const double*)> contains = [&](int node, const double* v) -> bool {
+            const DevNode& n = nodes[node];
+            bool in;
+            if (n.kind == VLR_NODE_SAMPLE) in = spec_contains(n.vafs, v[n.sample]);
+            else if (n.kind == VLR_NODE_LFC) in = false;
+            else in = n.kind != VLR_NODE_FALSE;
+            if (!in) return false;
+            if (n.n_children == 0) return true;
+            for (int ci = 0; ci < n.n_children; ++ci)
+                if (contains(child[n.child_off + ci], v)) return true;
+            return false;
+        };
+        auto group_contains = [&](int g, const double* v) {
+            if (g == 0) return contains(P.absent_root, v);
+            for (int ri = root_off[g - 1]; ri < root_off[g]; ++ri)
+                if (contains(roots[ri], v)) return true;
+            return false;
+        };
+        struct Path { double vaf[kMaxSamples]; uint32_t have, posmask; };
+        const uint32_t full = (1u << S) - 1u;
+        std::vector<Path> paths;
+        std::function<bool(int, Path)> flatten = [&](int node, Path cur) -> bool {
+            const DevNode& n = nodes[node];
+            std::vector<double> vals;
+            if (!node_values(n, vals)) return false;
+            const int s2 = n.sample;
+            if (cur.have & (1u << s2)) return false;
+            bool allpos = true;
+            for (double v : vals) allpos = allpos && v > 0.0;
+            for (double v : vals) {
+                Path q = cur;
+                q.vaf[s2] = v; q.have |= 1u << s2;
+                if (allpos) q.posmask |= 1u << s2;
+                if (n.n_children == 0) {
+                    if (q.have != full || paths.size() >= (size_t)kMaxDLeaf) return false;
+                    paths.push_back(q);
+                } else {
+                    for (int ci = 0; ci < n.n_children; ++ci)
+                        if (!flatten(child[n.child_off + ci], q)) return false;
+                }
+            }
+            return true;
+        };
+        bool keys_ok = true;
+        for (size_t i = 0; i < 1 + roots.size() && keys_ok; ++i) {
+            const int root = i == 0 ? P.absent_root : roots[i - 1];
+            int own = 0;
+            if (i > 0) for (int e = 0; e < d->n_events; ++e) if ((int)(i - 1) >= root_off[e] && (int)(i - 1) < root_off[e + 1]) own = e + 1;
+            paths.clear();
+            Path start{};
+            if (!flatten(root, start) || paths.empty()) continue;
+            const size_t first = dleaf.size();
+            for (const Path& q : paths) {
+                DevDLeaf L{};
+                int idx = 0;
+                for (int s2 = 0; s2 < S; ++s2) {
+                    L.vaf[s2] = q.vaf[s2];
+                    idx += prior_class(s2, q.vaf[s2]) * P.class_stride[s2];
+                    const double a = q.vaf[s2], bq = P.by[s2] >= 0 ? q.vaf[P.by[s2]] : 0.0;
+                    int k = -1;
+                    for (size_t j = 0; j < dkey.size(); ++j)
+                        if (dkey[j].sample == s2 && dkey[j].a == a && dkey[j].b == bq) k = (int)j;
+                    if (k < 0) {
+                        if (dkey.size() >= (size_t)kMaxDKeys) { keys_ok = false; break; }
+                        DevDKey nk{};
+                        nk.sample = s2; nk.a = a; nk.b = bq;
+                        k = (int)dkey.size();
+                        dkey.push_back(nk);
+                    }
+                    L.key[s2] = (uint8_t)k;
+                }
+                if (!keys_ok) break;
+                L.prior_idx = idx;
+                L.posmask = q.posmask;
+                for (int g = 0; g <= d->n_events; ++g)
+                    if (g != own && group_contains(g, q.vaf)) L.cmask |= 1u << g;
+                dleaf.push_back(L);
+            }
+            if (!keys_ok) break;
+            droot[2 * i] = (int32_t)first;
+            droot[2 * i + 1] = (int32_t)dleaf.size();
+        }
+        if (!keys_ok || getenv("VLR_NO_DISCRETE_ROOTS")) {  // too many distinct likelihoods (or switched off for A/B runs): general walk
+            dleaf.clear(); dkey.clear();
+            std::fill(droot.begin(), droot.end(), -1);
+        }
+        P.n_dkey = (int32_t)dkey.size();
+        P.n_dleaf = (int32_t)dleaf.size();
+    }
+
     rc = check_device(device);
     if (rc != VLR_OK) return rc;
     HIP_TRY(hipSetDevice(device));
@@ -556,7 +689,10 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
            o_roots = o_pool + al(pool.size() * 8), o_roff = o_roots + al(std::max<size_t>(1, roots.size()) * 4),
            o_uni = o_roff + al(root_off.size() * 4), o_tab = o_uni + al(std::max<size_t>(1, uni.size()) * sizeof(DevSpectrum)),
            o_gso = o_tab + al(table.size() * 8), o_gs = o_gso + al(gs_off.size() * 4),
-           total = o_gs + al(std::max<size_t>(1, gs.size()) * sizeof(DevSpectrum));
+           o_dl = o_gs + al(std::max<size_t>(1, gs.size()) * sizeof(DevSpectrum)),
+           o_dk = o_dl + al(std::max<size_t>(1, dleaf.size()) * sizeof(DevDLeaf)),
+           o_dr = o_dk + al(std::max<size_t>(1, dkey.size()) * sizeof(DevDKey)),
+           total = o_dr + al(droot.size() * 4);
     std::vector<char> hostblob(total, 0);
     memcpy(&hostblob[o_nodes], nodes.data(), nodes.size() * sizeof(DevNode));
     if (!child.empty()) memcpy(&hostblob[o_child], child.data(), child.size() * 4);
@@ -567,6 +703,9 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
     memcpy(&hostblob[o_tab], table.data(), table.size() * 8);
     memcpy(&hostblob[o_gso], gs_off.data(), gs_off.size() * 4);
     if (!gs.empty()) memcpy(&hostblob[o_gs], gs.data(), gs.size() * sizeof(DevSpectrum));
+    if (!dleaf.empty()) memcpy(&hostblob[o_dl], dleaf.data(), dleaf.size() * sizeof(DevDLeaf));
+    if (!dkey.empty()) memcpy(&hostblob[o_dk], dkey.data(), dkey.size() * sizeof(DevDKey));
+    memcpy(&hostblob[o_dr], droot.data(), droot.size() * 4);
 
     vlr_plan* plan = new vlr_plan();
     plan->device = device;
@@ -582,6 +721,9 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
     P.prior_table = (const double*)(base + o_tab);
     P.grp_spec_off = (const int32_t*)(base + o_gso);
     P.grp_spec = (const DevSpectrum*)(base + o_gs);
+    P.dleaf = (const DevDLeaf*)(base + o_dl);
+    P.dkey = (const DevDKey*)(base + o_dk);
+    P.droot = (const int32_t*)(base + o_dr);
     plan->host = P;
     hipError_t e = hipMemcpy(plan->blob, hostblob.data(), total, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&plan->dev, sizeof(DevPlan));

@@ -552,6 +552,7 @@ struct Ctx {
     double* coef;                    // AoS coefficient triples {c,q,e} (LDS)
     double* setv;                    // [S][kMaxSet] Set candidates per sample (LDS)
     double *cacheA, *cacheB, *cacheV;  // [S][kCacheWays] per-sample likelihood cache (LDS)
+    double* dkeyV;                     // [n_dkey] pileup likelihoods of the flattened discrete roots, per hypothesis (LDS)
     int cap;                         // capacity of one visited-point table
     double *rowX, *rowV;             // [kRows][cap] visited-point tables of the row-parallel innermost chains
     double* afd_seen;                // replay: [S][kMaxSet] recorded discrete VAFs (aliases setv-sized scratch)
@@ -619,6 +620,18 @@ __device__ inline void alpha_beta(const DevPlan& p, int s, double a, double b, d
 
 // cached single-point pileup likelihood of sample s (stands in for the per-sample LRU caches of
 // modes/generic.rs:38-53: the normal sample's likelihood is reused across all tumor VAFs)
+__device__ inline double sample_lik_point(Ctx& c, int s, double a, double b) {  // uncached single point on all 64 lanes
+    WaveSt* w = c.w;
+    double al, be;
+    alpha_beta(*c.plan, s, a, b, al, be);
+    const int off = UNI(w->soff[s]), D = UNI(w->nkeep[s]);
+    double P1[1] = {1.0};
+    int E1[1] = {0};
+    accum_terms<1, 64>(c.coef + 3 * off, D, c.lane, (w->fastok >> s) & 1, &al, &be, P1, E1);
+    reduce_terms<1, 64>(P1, E1);
+    if (c.lane == 0) { w->work[0] += 1; w->work[1] += (unsigned long long)D; }
+    return uni_d(log(P1[0]) + (double)E1[0] * kLn2);
+}
 __device__ inline double sample_lik(Ctx& c, int s, double a, double b) {
     WaveSt* w = c.w;
     const int n = UNI(w->cacheN[s]);
@@ -629,18 +642,7 @@ __device__ inline double sample_lik(Ctx& c, int s, double a, double b) {
         const unsigned long long hm = __ballot(hit);
         if (hm) return uni_d(c.cacheV[s * kCacheWays + __builtin_ctzll(hm)]);
     }
-    double al, be;
-    alpha_beta(*c.plan, s, a, b, al, be);
-    int off = UNI(w->soff[s]), D = UNI(w->nkeep[s]);
-    double r;
-    {   // one point on all 64 lanes
-        double P1[1] = {1.0};
-        int E1[1] = {0};
-        accum_terms<1, 64>(c.coef + 3 * off, D, c.lane, (w->fastok >> s) & 1, &al, &be, P1, E1);
-        reduce_terms<1, 64>(P1, E1);
-        r = uni_d(log(P1[0]) + (double)E1[0] * kLn2);
-    }
-    if (c.lane == 0) { w->work[0] += 1; w->work[1] += (unsigned long long)D; }
+    const double r = sample_lik_point(c, s, a, b);
     int slot = n % kCacheWays;
     __syncthreads();
     if (c.lane == 0) {
@@ -811,6 +813,122 @@ __device__ inline void cross_consider(Ctx& c, int g, double joint, int inner, do
         __syncthreads();
     }
 }
+// ---- all-discrete roots (DevDLeaf): every leaf of the root on its own lane --------------------------------------
+// GenericPosterior::density of a root whose nodes are all Set / single-valued Sample nodes (modes/generic.rs:294-330):
+// ln_sum_exp over the leaves of prior + likelihood; a leaf below a node that is dead under clear_ref (270-291) is not
+// visited.  The MAP candidates of the root's own slot and of the other groups containing a leaf (static, DevDLeaf::cmask)
+// are the arg-best leaves under the map_consider ordering.  Values of the likelihood terms come from c.dkeyV.
+__device__ inline bool dleaf_tuple_before(const DevDLeaf* leaves, int la, int lb, int S) {
+    for (int s = 0; s < S; ++s) {
+        const double va = leaves[la].vaf[s], vb = leaves[lb].vaf[s];
+        if (va != vb) return va < vb;
+    }
+    return false;
+}
+// wave arg-best of per-lane candidates (J desc, then VAF tuple asc); returns the leaf index (uniform) or -1
+__device__ inline int dleaf_wave_best(const DevDLeaf* leaves, double bJ, int bL, int S, double& Jout) {
+    const double Jm = wave_max(bL >= 0 ? bJ : VLR_NEG_INF);
+    unsigned long long tie = __ballot(bL >= 0 && bJ == Jm);
+    int best = -1;
+    while (tie) {
+        const int ln = __builtin_ctzll(tie);
+        tie &= tie - 1;
+        const int l = __builtin_amdgcn_readlane(bL, ln);
+        if (best < 0 || dleaf_tuple_before(leaves, l, best, S)) best = l;
+    }
+    Jout = Jm;
+    return best;
+}
+__device__ inline double eval_discrete_root(Ctx& c, int l0, int l1) {
+    const DevPlan& p = *c.plan;
+    WaveSt* w = c.w;
+    const int lane = c.lane, S = c.S;
+    const DevDLeaf* leaves = p.dleaf;
+    unsigned cr = 0;
+    for (int s = 0; s < S; ++s)
+        if (UNI(w->nkeep[s]) > 10 && UNI(w->all_posref[s])) cr |= 1u << s;
+    const double* ptab = p.prior_table + (size_t)c.vt * p.table_size;
+    constexpr int T = kMaxDLeaf / 64;
+    double jv[T];
+    unsigned cm[T];
+    bool ok[T];
+    bool sawnan = false;
+    unsigned gm = 0;
+    double bJ = VLR_NEG_INF;
+    int bL = -1;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int l = l0 + lane + 64 * t;
+        jv[t] = VLR_NEG_INF; cm[t] = 0; ok[t] = false;
+        if (l < l1) {
+            const DevDLeaf& L = leaves[l];
+            if ((L.posmask & cr) == 0) {
+                double lik = 0.0;
+                for (int s = 0; s < S; ++s) lik += c.dkeyV[L.key[s]];
+                const double joint = ptab[L.prior_idx] + lik;
+                if (joint != joint) sawnan = true;
+                else {
+                    jv[t] = joint; cm[t] = L.cmask; ok[t] = true;
+                    gm |= L.cmask;
+                    if (bL < 0 || joint > bJ || (joint == bJ && dleaf_tuple_before(leaves, l, bL, S))) { bJ = joint; bL = l; }
+                }
+            }
+        }
+    }
+    if (__ballot(sawnan)) { c.status |= VLR_LOCUS_NAN; return __builtin_nan(""); }
+    // density
+    double m = VLR_NEG_INF;
+#pragma unroll
+    for (int t = 0; t < T; ++t) m = fmax(m, jv[t]);
+    const double M = wave_max(m);
+    double dens = VLR_NEG_INF;
+    if (M != VLR_NEG_INF) {
+        double ssum = 0.0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) ssum += ok[t] ? exp(jv[t] - M) : 0.0;
+        dens = uni_d(M + log(wave_sum(ssum)));
+    }
+    // MAP candidates: all operands are discrete
+    const int saved_disc = c.disc;
+    c.disc = (1 << S) - 1;
+    {
+        double J;
+        const int best = dleaf_wave_best(leaves, bJ, bL, S, J);
+        if (best >= 0) {
+            __syncthreads();
+            if (lane < S) w->ops_vaf[lane] = leaves[best].vaf[lane];
+            __syncthreads();
+            map_consider(c, J, -1, 0.0);
+        }
+    }
+    // other groups
+    for (int o = 32; o > 0; o >>= 1) gm |= (unsigned)__shfl_xor((int)gm, o);
+    gm = (unsigned)UNI((int)gm);
+    while (gm) {
+        const int g = __builtin_ctz(gm);
+        gm &= gm - 1;
+        double gJ = VLR_NEG_INF;
+        int gL = -1;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int l = l0 + lane + 64 * t;
+            if (ok[t] && ((cm[t] >> g) & 1u)) {
+                if (gL < 0 || jv[t] > gJ || (jv[t] == gJ && dleaf_tuple_before(leaves, l, gL, S))) { gJ = jv[t]; gL = l; }
+            }
+        }
+        double J;
+        const int best = dleaf_wave_best(leaves, gJ, gL, S, J);
+        if (best >= 0) {
+            __syncthreads();
+            if (lane < S) w->ops_vaf[lane] = leaves[best].vaf[lane];
+            __syncthreads();
+            cross_consider(c, g, J, -1, 0.0);
+        }
+    }
+    c.disc = saved_disc;
+    return dens;
+}
+
 // AFD replay (calling.rs:889-928): record (VAF of sample s, posterior density) of every clean operand set that
 // equals the MAP on all other samples (allele_freq, artifacts, is_discrete) and is contained in the best event
 // with sample s excluded.
@@ -930,6 +1048,7 @@ __device__ inline bool lfcs_ok(const Ctx& c, int inner, double x) {
 // Prior::compute + GenericLikelihood::compute), single point
 __device__ inline double leaf_joint(Ctx& c) {
     double joint;
+    PROF_ADD(c, 19);  // walk: descent to a discrete leaf
     if (!lfcs_ok(c, -1, 0.0)) {
         joint = VLR_NEG_INF;
     } else {
@@ -940,12 +1059,15 @@ __device__ inline double leaf_joint(Ctx& c) {
             double b = by >= 0 ? c.w->ops_vaf[by] : 0.0;
             lik += sample_lik(c, s, a, b);
         }
+        PROF_ADD(c, 20);  // leaf: likelihoods
         joint = prior_of(c, -1, 0.0) + lik;
+        PROF_ADD(c, 21);  // leaf: prior
     }
     joint = uni_d(joint);
     if (joint != joint) c.status |= VLR_LOCUS_NAN;
     if (c.replay) afd_consider(c, joint, -1, 0.0);
     else map_all(c, joint, -1, 0.0, c.contained != 0, c.alive);
+    PROF_ADD(c, 22);  // leaf: MAP candidates
     return joint;
 }
 
@@ -2155,6 +2277,7 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
     c.cacheV = c.cacheB + S * kCacheWays;
     c.afd_seen = c.cacheV + S * kCacheWays;  // [S][kMaxSet]
     int* mapHyp = (int*)(c.afd_seen + S * kMaxSet);  // [n_slots]
+    c.dkeyV = c.afd_seen + S * kMaxSet + (n_slots + 1) / 2 + 2;  // [n_dkey]
     c.mapJ = mapJ; c.mapVaf = mapVaf; c.mapHyp = mapHyp; c.n_slots = n_slots;
     c.status = 0;
     if (lane == 0) { w->work[0] = 0; w->work[1] = 0; }
@@ -2505,6 +2628,13 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
         if (lane < S) w->cacheN[lane] = 0;
         __syncthreads();
         if (__ballot((c.status & VLR_LOCUS_UNDERFLOW) != 0)) c.status |= VLR_LOCUS_UNDERFLOW;
+        if (p.n_dkey > 0 && !c.replay) {  // pileup likelihoods of the flattened discrete roots under this hypothesis
+            for (int k = 0; k < p.n_dkey; ++k) {
+                const double r = sample_lik_point(c, ldc(&p.dkey[k].sample), ldc(&p.dkey[k].a), ldc(&p.dkey[k].b));
+                if (lane == 0) c.dkeyV[k] = r;
+            }
+            __syncthreads();
+        }
 
         PROF_ADD(c, 2);  // coefficient pass
         // ---- events (calling.rs:654-687): absent + clean events under h = none, artifact twins otherwise
@@ -2535,15 +2665,22 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
                     __syncthreads();
                     int root = (e < 0) ? p.absent_root : ldc(p.roots + ri);
                     double dens;
-                    for (int resume = 0;; resume = 1) {
-                        dens = uni_d(walk_root(c, root, resume));
-                        if (!c.need_batch) break;
-                        c.need_batch = 0;
-                        run_chain_batch(c, c.bt_nt, c.bt_inner);
-                        __syncthreads();
+                    const int di = (e < 0) ? 0 : 1 + ri;
+                    const int dl0 = (c.replay || p.n_dkey == 0) ? -1 : ldc(p.droot + 2 * di);
+                    if (dl0 >= 0) {  // all-discrete root: its leaves side by side on the lanes
+                        dens = eval_discrete_root(c, dl0, ldc(p.droot + 2 * di + 1));
+                        PROF_ADD(c, 23);
+                    } else {
+                        for (int resume = 0;; resume = 1) {
+                            dens = uni_d(walk_root(c, root, resume));
+                            if (!c.need_batch) break;
+                            c.need_batch = 0;
+                            run_chain_batch(c, c.bt_nt, c.bt_inner);
+                            __syncthreads();
+                        }
+                        if (c.deferred == 1) { c.deferred = 0; continue; }                      // delivered by flush_deferred
+                        if (c.deferred == 2) { c.deferred = 0; todo |= 1ull << rc_; continue; } // second pass
                     }
-                    if (c.deferred == 1) { c.deferred = 0; continue; }                      // delivered by flush_deferred
-                    if (c.deferred == 2) { c.deferred = 0; todo |= 1ull << rc_; continue; } // second pass
                     if (dens != dens) c.status |= VLR_LOCUS_NAN;
                     double M = uni_d(evM[u]), Sx = uni_d(evS[u]);
                     lse_add(M, Sx, bias_prior + dens);
@@ -2555,6 +2692,7 @@ __global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const De
             }
             if (pass == 0) flush_deferred(c, evM, evS, bias_prior);  // rows are free again for the nested events
         }
+        PROF_ADD(c, 3);
     }
     PROF_ADD(c, 3);  // walk remainder (everything in the event loop not attributed below)
     if (c.replay) { afd_finish(c); return; }
@@ -2659,7 +2797,7 @@ extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_host, const vlr::
     size_t cap = (size_t)plan_host->table_cap;
     size_t dbl = (size_t)3 * max_obs + (size_t)2 * range_depth * cap + (size_t)2 * kRows * cap + (size_t)kRows * n_samples +
                  (size_t)2 * n_univ + n_slots + n_slots * n_samples + (size_t)2 * n_samples * kMaxSet + (size_t)3 * n_samples * kCacheWays +
-                 (n_slots + 1) / 2 + 2;
+                 (n_slots + 1) / 2 + 2 + (size_t)plan_host->n_dkey;
     size_t bytes = dbl * sizeof(double);
     hipError_t e = hipFuncSetAttribute((const void*)vlr_call_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;

@@ -18,6 +18,8 @@ constexpr int kCacheWays = 4;         // per-sample pileup-likelihood cache entr
 constexpr int kMaxBatchPoints = 16;   // points evaluated by one eval_pileup call
 constexpr int kContainStack = 24;     // explicit stack of the VAFTree::contains walk
 constexpr int kNVariantTypes = 5;
+constexpr int kMaxDLeaf = 256;        // leaves of one all-discrete root evaluated across the lanes (4 per lane)
+constexpr int kMaxDKeys = 64;         // distinct (sample, VAF, contaminant VAF) pileup likelihoods of the discrete roots
 
 // hypothesis slots, in the cartesian order of Artifacts::all_artifact_combinations
 // (reference src/variants/model/bias/mod.rs:131-218; alt-locus varies fastest)
@@ -40,6 +42,18 @@ struct DevNode {
     int32_t child_off, n_children;
     int32_t pad;
 };
+
+// All-discrete roots (every node a Sample node with a Set or single-valued spectrum, e.g. the pedigree scenarios and
+// the `absent` chain) are flattened on the host: one record per root-to-leaf path, in walk order.
+struct DevDLeaf {
+    double vaf[kMaxSamples];
+    int32_t prior_idx;          // index into one variant type's prior table
+    uint32_t posmask;           // samples whose node on this path holds only VAFs > 0 (dead under clear_ref, generic.rs:270-291)
+    uint32_t cmask;             // other event groups whose VAF tree contains these operands (vaftree.rs:42-51)
+    uint8_t key[kMaxSamples];   // per sample: index of its (VAF, contaminant VAF) pair in DevPlan::dkey
+    int32_t pad;
+};
+struct DevDKey { int32_t sample, pad; double a, b; };
 
 // prior "class" per sample: the reference's Prior::compute
 // (src/variants/model/prior.rs:298-438,715-762) depends on a VAF only through equality tests with
@@ -70,6 +84,12 @@ struct DevPlan {
     // necessary condition before the full VAFTree::contains walk for cross-event MAP candidates
     const int32_t* grp_spec_off;    // [(n_named + 1) * S + 1]
     const DevSpectrum* grp_spec;
+    // flattened all-discrete roots: droot[2 * i], droot[2 * i + 1] = leaf range of root i (0 = absent, 1 + k = roots[k]);
+    // a start of -1 sends the root through the general walk
+    int32_t n_dkey, n_dleaf;
+    const DevDLeaf* dleaf;
+    const DevDKey* dkey;
+    const int32_t* droot;
 };
 
 // SoA observation columns + per-locus columns (device pointers), mirrors vlr_batch
