@@ -849,6 +849,7 @@ __device__ inline double eval_discrete_root(Ctx& c, int l0, int l1) {
         if (UNI(w->nkeep[s]) > 10 && UNI(w->all_posref[s])) cr |= 1u << s;
     const double* ptab = p.prior_table + (size_t)c.vt * p.table_size;
     constexpr int T = kMaxDLeaf / 64;
+    const int TT = (l1 - l0 + 63) >> 6;  // leaves per lane (uniform)
     double jv[T];
     unsigned cm[T];
     bool ok[T];
@@ -860,7 +861,7 @@ __device__ inline double eval_discrete_root(Ctx& c, int l0, int l1) {
     for (int t = 0; t < T; ++t) {
         const int l = l0 + lane + 64 * t;
         jv[t] = VLR_NEG_INF; cm[t] = 0; ok[t] = false;
-        if (l < l1) {
+        if (t < TT && l < l1) {
             const DevDLeaf& L = leaves[l];
             if ((L.posmask & cr) == 0) {
                 double lik = 0.0;
@@ -885,7 +886,8 @@ __device__ inline double eval_discrete_root(Ctx& c, int l0, int l1) {
     if (M != VLR_NEG_INF) {
         double ssum = 0.0;
 #pragma unroll
-        for (int t = 0; t < T; ++t) ssum += ok[t] ? exp(jv[t] - M) : 0.0;
+        for (int t = 0; t < T; ++t)
+            if (t < TT) ssum += ok[t] ? exp(jv[t] - M) : 0.0;
         dens = uni_d(M + log(wave_sum(ssum)));
     }
     // MAP candidates: all operands are discrete
@@ -912,7 +914,7 @@ __device__ inline double eval_discrete_root(Ctx& c, int l0, int l1) {
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int l = l0 + lane + 64 * t;
-            if (ok[t] && ((cm[t] >> g) & 1u)) {
+            if (t < TT && ok[t] && ((cm[t] >> g) & 1u)) {
                 if (gL < 0 || jv[t] > gJ || (jv[t] == gJ && dleaf_tuple_before(leaves, l, gL, S))) { gJ = jv[t]; gL = l; }
             }
         }
