@@ -116,6 +116,13 @@ __device__ __forceinline__ double uni_d(double v) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
+// The lane id as a value the optimiser cannot hoist: without it every lane-derived constant of the chain runners
+// ((double)(lane - 1), row masks, ...) is computed once before the hypothesis loop and then SPILLED across it.
+__device__ __forceinline__ int fresh_lane(int lane) {
+    asm volatile("" : "+v"(lane));
+    return lane;
+}
+
 // wave helpers (wave64; one wave per workgroup so __syncthreads() is a wave-level LDS fence)
 __device__ inline double wave_sum(double v) {
 #pragma unroll
@@ -842,7 +849,7 @@ __device__ inline int dleaf_wave_best(const DevDLeaf* leaves, double bJ, int bL,
 __device__ inline double eval_discrete_root(Ctx& c, int l0, int l1) {
     const DevPlan& p = *c.plan;
     WaveSt* w = c.w;
-    const int lane = c.lane, S = c.S;
+    const int lane = fresh_lane(c.lane), S = c.S;
     const DevDLeaf* leaves = p.dleaf;
     unsigned cr = 0;
     for (int s = 0; s < S; ++s)
@@ -1154,7 +1161,7 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
 #endif
     const DevPlan& p = *c.plan;
     WaveSt* w = c.w;
-    const int lane = c.lane;
+    const int lane = fresh_lane(c.lane);
     const int inner = UNI(rl.sample);
     const double lo = uni_d(rl.lo), hi = uni_d(rl.hi), res = uni_d(rl.res);
     const RangeV orig{uni_d(rl.ostart), uni_d(rl.oend), UNI(rl.olex), UNI(rl.orex)};
@@ -1366,7 +1373,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
 #endif
     const DevPlan& p = *c.plan;
     WaveSt* w = c.w;
-    const int lane = c.lane, row = lane >> 4, rl = lane & 15;
+    const int lane = fresh_lane(c.lane), row = lane >> 4, rl = lane & 15;
     const bool rowon = row < nt;
     const int cap = c.cap;
     __builtin_amdgcn_wave_barrier();
@@ -1749,7 +1756,7 @@ __device__ __forceinline__ bool bo_setup(Ctx& c, const Frame& f, RangeSt& r) {
     const DevPlan& p = *c.plan;
     WaveSt* w = c.w;
     const BatchOuter& B = w->bo;
-    const int lane = c.lane, S = c.S;
+    const int lane = fresh_lane(c.lane), S = c.S;
     const int np = UNI(B.np), c0 = UNI(B.c0), s_in = UNI(B.s_in), s_out = UNI(B.s_out), chn = UNI(B.chn);
     const bool dead = UNI(B.dead) != 0;
     const int nt = (np - c0) < kRows ? (np - c0) : kRows;
@@ -1808,7 +1815,7 @@ __device__ __forceinline__ bool bo_setup(Ctx& c, const Frame& f, RangeSt& r) {
 __device__ __forceinline__ bool bo_deliver(Ctx& c, const Frame& f, RangeSt& r, double* txo, double* tvo) {
     WaveSt* w = c.w;
     const BatchOuter& B = w->bo;
-    const int lane = c.lane;
+    const int lane = fresh_lane(c.lane);
     const int np = UNI(B.np), c0 = UNI(B.c0), nt = UNI(B.nt), s_in = UNI(B.s_in), s_out = UNI(B.s_out);
     const bool dead = UNI(B.dead) != 0;
     __syncthreads();
