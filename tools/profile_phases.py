@@ -18,4 +18,5 @@ cnt = {10, 11}
 tot = sum(v for i, v in enumerate(out) if i not in cnt)
 for nm, v in zip(names, out):
     print("%-18s %14d  %5.1f%%  per locus %9.0f" % (nm, v, 100.0 * v / max(tot, 1), v / n))
+print("batch runs %.1f, single chains %.1f, batch rounds %.1f, active rows per round %.2f" % ((out[10] & 0xffffffff) / n, (out[11] & 0xffffffff) / n, (out[10] >> 32) / n, (out[11] >> 32) / max(out[10] >> 32, 1)))
 print("evals, terms", plan.work_counters())

@@ -1428,6 +1428,10 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
 
     while (__ballot(!done)) {
         const bool act = !done;
+#ifdef VLR_PROFILE
+        c.prof[10] += 1ull << 32;                                                     // rounds (high word)
+        c.prof[11] += (unsigned long long)(popc64(__ballot(!done && rl == 0))) << 32;  // active rows (high word)
+#endif
         if (act && tn + np > cap) { failed = true; done = true; }
         const bool go = act && !failed;
         // row lane j < np owns point j of its chain; every lane multiplies its observation slice (terms rl, rl+16,
