@@ -2251,11 +2251,12 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
 }
 
 // ------------------------------------------------------------------------------------------------
-#ifndef VLR_WAVES_PER_EU
-#define VLR_WAVES_PER_EU 2
-#endif
-__global__ void __launch_bounds__(64, VLR_WAVES_PER_EU) vlr_call_kernel(const DevPlan plan_arg, DevBatch batch, DevResults out,
-                                                       int max_obs, int range_depth) {
+// Two builds of the same kernel: WPE = 2 waves per SIMD (256 VGPRs, no spills) for workgroups whose LDS footprint allows
+// only 8 of them per CU anyway (tumor-normal 100x: 18.9 kB), WPE = 3 (168 VGPRs, 32 of them spilled) where 12 fit
+// (single-sample 30x: +33 % from the third wave).  The launcher picks by LDS bytes.
+template <int WPE>
+__global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_arg, DevBatch batch, DevResults out,
+                                                           int max_obs, int range_depth) {
     extern __shared__ double dyn[];
     __shared__ WaveSt wst;
     const DevPlan& p = plan_arg;
@@ -2812,9 +2813,21 @@ extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_host, const vlr::
                  (size_t)2 * n_univ + n_slots + n_slots * n_samples + (size_t)2 * n_samples * kMaxSet + (size_t)3 * n_samples * kCacheWays +
                  (n_slots + 1) / 2 + 2 + (size_t)plan_host->n_dkey;
     size_t bytes = dbl * sizeof(double);
-    hipError_t e = hipFuncSetAttribute((const void*)vlr_call_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    static size_t static_lds = 0;
+    if (!static_lds) {
+        hipFuncAttributes fa{};
+        hipError_t ea = hipFuncGetAttributes(&fa, (const void*)vlr_call_kernel<2>);
+        if (ea != hipSuccess) return (int)ea;
+        static_lds = fa.sharedSizeBytes ? fa.sharedSizeBytes : 1;
+    }
+    // 160 kB of LDS per CU: twelve workgroups (three waves per SIMD) need <= 13 312 B each (512 B granules)
+    int wpe = (static_lds + bytes <= 13312) ? 3 : 2;
+    if (const char* ev = getenv("VLR_WAVES_PER_SIMD")) wpe = atoi(ev) == 3 ? 3 : 2;  // tuning knob
+    const void* fn = wpe == 3 ? (const void*)vlr_call_kernel<3> : (const void*)vlr_call_kernel<2>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;
     dim3 grid((unsigned)batch->n_loci), block(64);
-    hipLaunchKernelGGL(vlr_call_kernel, grid, block, bytes, (hipStream_t)stream, *plan_host, *batch, *out, max_obs, range_depth);
+    if (wpe == 3) hipLaunchKernelGGL(vlr_call_kernel<3>, grid, block, bytes, (hipStream_t)stream, *plan_host, *batch, *out, max_obs, range_depth);
+    else hipLaunchKernelGGL(vlr_call_kernel<2>, grid, block, bytes, (hipStream_t)stream, *plan_host, *batch, *out, max_obs, range_depth);
     return (int)hipGetLastError();
 }
