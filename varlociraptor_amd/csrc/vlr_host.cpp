@@ -498,6 +498,7 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
     if (max_lfc > kMaxLfc) return fail(VLR_ERR_UNSUPPORTED, "more than %d l2fc terms on one path", kMaxLfc);
     if (max_frames > kMaxFrames) return fail(VLR_ERR_UNSUPPORTED, "VAF tree deeper than %d frames", kMaxFrames);
     P.max_range_depth = std::max(1, max_range);
+    P.max_frames = std::max(S, max_frames);  // the absent chain pushes one frame per sample
     {
         // capacity of a visited-point table: 2 endpoints + 3 per bisection round + 7 tail points, with at most
         // ceil(ln(1/res) / ln(4/3)) + 1 rounds (the bracket shrinks to at most 3/4 per round,

@@ -85,13 +85,19 @@ struct WaveSt {
     double lfc_val[kMaxLfc];
     int lfc_a[kMaxLfc], lfc_b[kMaxLfc], lfc_cmp[kMaxLfc];
     int nkeep[kMaxSamples], soff[kMaxSamples];
-    int all_ref[kMaxSamples], all_posref[kMaxSamples], strong_all[kMaxSamples];
-    int strong_bias[kMaxSamples][kNHyp];
-    int any_strong_alt[kMaxSamples], has_ins[kMaxSamples], has_del[kMaxSamples];
-    double pos_all[kMaxSamples], pos_major[kMaxSamples], pos_rate[kMaxSamples];
+    int all_posref[kMaxSamples];
+    union {
+        struct {  // phase A statistics: dead once the hypotheses are gated (before phase B starts)
+            double pos_all[kMaxSamples], pos_major[kMaxSamples], pos_rate[kMaxSamples];
+            int all_ref[kMaxSamples], strong_all[kMaxSamples];
+            int strong_bias[kMaxSamples][kNHyp];
+            int any_strong_alt[kMaxSamples], has_ins[kMaxSamples], has_del[kMaxSamples];
+        };
+        struct {  // phase B: pending points / values of the row-parallel chains
+            double bpend[kRows][kRowPts], bvals[kRows][kRowPts];
+        };
+    };
     int cacheN[kMaxSamples];
-    Frame frames[kMaxFrames];
-    RangeSt rs[kMaxRangeDepth];
     double ptA[kMaxBatchPoints], ptB[kMaxBatchPoints], res[kMaxBatchPoints];
     double ptJ[kMaxBatchPoints];
     double fixedLik[kMaxSamples];
@@ -103,7 +109,6 @@ struct WaveSt {
     ChainTask task[kRows];
     BatchOuter bo;
     WalkSave wk;
-    double bpend[kRows][kRowPts], bvals[kRows][kRowPts];
     unsigned long long work[2];  // [0] pileup evaluations, [1] observation terms (lane 0 adds; profiling aid)
     int fastok;  // bit s: all terms of sample s stay >= 2^-200 under the current hypothesis (4-term renormalisation is safe)
 };
@@ -560,6 +565,9 @@ struct Ctx {
     double* setv;                    // [S][kMaxSet] Set candidates per sample (LDS)
     double *cacheA, *cacheB, *cacheV;  // [S][kCacheWays] per-sample likelihood cache (LDS)
     double* dkeyV;                     // [n_dkey] pileup likelihoods of the flattened discrete roots, per hypothesis (LDS)
+    Frame* frames;                     // [nframes] explicit recursion stack of walk_root (LDS, sized by the plan's deepest path)
+    RangeSt* rs;                       // [nrs] adaptive-integration state per nested Range level (LDS)
+    int nframes, nrs;
     int cap;                         // capacity of one visited-point table
     double *rowX, *rowV;             // [kRows][cap] visited-point tables of the row-parallel innermost chains
     double* afd_seen;                // replay: [S][kMaxSet] recorded discrete VAFs (aliases setv-sized scratch)
@@ -1869,7 +1877,7 @@ __device__ __forceinline__ void flush_deferred(Ctx& c, double* evM, double* evS,
         // a lone chain is cheaper on all 64 lanes (7 terms per lane instead of 25): rebuild its frame context
         const ChainTask& T = w->task[0];
         const int u = UNI(T.u);
-        RangeSt& r = w->rs[kMaxRangeDepth - 1];
+        RangeSt& r = c.rs[c.nrs - 1];
         if (c.lane == 0) {
             r.lo = T.lo; r.hi = T.hi; r.res = T.res; r.ostart = T.ostart; r.oend = T.oend; r.olex = T.olex; r.orex = T.orex;
             r.simpson_n = T.simpson_n; r.sample = s_in; r.leaf = 1; r.tn = 0;
@@ -2016,10 +2024,10 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                     }
                 }
                 if (dead) { rv = VLR_NEG_INF; pc = PC_RETURN; }
-                else if (sp >= kMaxFrames) { c.status |= VLR_LOCUS_TABLE_FULL; rv = __builtin_nan(""); pc = PC_RETURN; }
+                else if (sp >= c.nframes) { c.status |= VLR_LOCUS_TABLE_FULL; rv = __builtin_nan(""); pc = PC_RETURN; }
                 else {
                     __syncthreads();
-                    Frame& f = w->frames[sp];
+                    Frame& f = c.frames[sp];
                     if (c.lane == 0) {
                         f.node = node; f.iter = 0; f.accM = VLR_NEG_INF; f.accS = 0.0;
                         f.sv_present = c.present; f.sv_disc = c.disc; f.sv_nlfc = c.nlfc; f.sv_contained = c.contained;
@@ -2041,7 +2049,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                     } else if (nrange >= p.max_range_depth || nrange >= kMaxRangeDepth) {
                         c.status |= VLR_LOCUS_TABLE_FULL; rv = __builtin_nan(""); pc = PC_RETURN;
                     } else {
-                        RangeSt& r = w->rs[nrange];
+                        RangeSt& r = c.rs[nrange];
                         double res = p.resolution[s];
                         double min_vaf = observable_min(vr, n_obs);
                         double max_vaf = observable_max(vr, n_obs);
@@ -2075,11 +2083,11 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
             const DevNode nd = ld_node(p.nodes + node);
             if (nd.n_children == 0) { rv = leaf_joint(c); pc = PC_RETURN; }
             else if (nd.n_children == 1) { node = ldc(p.child_index + nd.child_off); pc = PC_DESCEND; }
-            else if (sp >= kMaxFrames) { c.status |= VLR_LOCUS_TABLE_FULL; rv = __builtin_nan(""); pc = PC_RETURN; }
+            else if (sp >= c.nframes) { c.status |= VLR_LOCUS_TABLE_FULL; rv = __builtin_nan(""); pc = PC_RETURN; }
             else if (c.defer_ok) { c.deferred = 2; return 0.0; }  // probe pass: branching root is not a single chain
             else {
                 __syncthreads();
-                Frame& f = w->frames[sp];
+                Frame& f = c.frames[sp];
                 if (c.lane == 0) {
                     f.kind = FK_BRANCH; f.node = node; f.iter = 0; f.n = nd.n_children; f.accM = VLR_NEG_INF; f.accS = 0.0;
                     f.sv_present = c.present; f.sv_disc = c.disc; f.sv_nlfc = c.nlfc; f.sv_contained = c.contained;
@@ -2091,9 +2099,9 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                 pc = PC_DESCEND;
             }
         } else if (pc == PC_RANGE_ISSUE) {
-            Frame& f = w->frames[sp - 1];
+            Frame& f = c.frames[sp - 1];
             const int fslot = UNI(f.slot), fnode = UNI(f.node);
-            RangeSt& r = w->rs[fslot];
+            RangeSt& r = c.rs[fslot];
             double* tx = c.tabX + fslot * c.cap;
             double* tv = c.tabV + fslot * c.cap;
             if (UNI(r.tn) + (UNI(r.npend) - UNI(f.iter)) > c.cap) {  // room for the points of this round still to be recorded
@@ -2165,8 +2173,8 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                 pc = PC_SUB;
             }
         } else if (pc == PC_BO_PRE) {
-            Frame& f = w->frames[sp - 1];
-            RangeSt& r = w->rs[UNI(f.slot)];
+            Frame& f = c.frames[sp - 1];
+            RangeSt& r = c.rs[UNI(f.slot)];
             if (bo_setup(c, f, r)) {
                 __syncthreads();
                 if (c.lane == 0) { WalkSave& k = w->wk; k.sp = sp; k.node = node; k.nrange = nrange; k.skip_record = skip_record ? 1 : 0; k.rv = rv; }
@@ -2176,9 +2184,9 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
             }
             pc = PC_BO_POST;
         } else if (pc == PC_BO_POST) {
-            Frame& f = w->frames[sp - 1];
+            Frame& f = c.frames[sp - 1];
             const int fslot = UNI(f.slot);
-            RangeSt& r = w->rs[fslot];
+            RangeSt& r = c.rs[fslot];
             if (bo_deliver(c, f, r, c.tabX + fslot * c.cap, c.tabV + fslot * c.cap)) pc = PC_BO_PRE;
             else {
                 __syncthreads();
@@ -2190,10 +2198,10 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
         } else {  // PC_RETURN: hand rv to the enclosing frame
             rv = uni_d(rv);
             if (sp == 0) return rv;
-            Frame& f = w->frames[sp - 1];
+            Frame& f = c.frames[sp - 1];
             if (UNI(f.kind) == FK_RANGE) {
                 const int fslot = UNI(f.slot);
-                RangeSt& r = w->rs[fslot];
+                RangeSt& r = c.rs[fslot];
                 double* tx = c.tabX + fslot * c.cap;
                 double* tv = c.tabV + fslot * c.cap;
                 __syncthreads();
@@ -2251,9 +2259,9 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Two builds of the same kernel: WPE = 2 waves per SIMD (256 VGPRs, no spills) for workgroups whose LDS footprint allows
-// only 8 of them per CU anyway (tumor-normal 100x: 18.9 kB), WPE = 3 (168 VGPRs, 32 of them spilled) where 12 fit
-// (single-sample 30x: +33 % from the third wave).  The launcher picks by LDS bytes.
+// Two builds of the same kernel: WPE = 2 waves per SIMD (no spills) for workgroups whose LDS footprint allows only 8 of
+// them per CU anyway, WPE = 3 (168 VGPRs, 32 of them spilled) where 9 or more fit (single-sample 30x: 12 workgroups,
+// +33 %).  The launcher picks by LDS bytes.
 template <int WPE>
 __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_arg, DevBatch batch, DevResults out,
                                                            int max_obs, int range_depth) {
@@ -2292,6 +2300,9 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
     c.afd_seen = c.cacheV + S * kCacheWays;  // [S][kMaxSet]
     int* mapHyp = (int*)(c.afd_seen + S * kMaxSet);  // [n_slots]
     c.dkeyV = c.afd_seen + S * kMaxSet + (n_slots + 1) / 2 + 2;  // [n_dkey]
+    c.nframes = p.max_frames + 1; c.nrs = range_depth;
+    c.frames = (Frame*)(c.dkeyV + p.n_dkey);
+    c.rs = (RangeSt*)(c.frames + c.nframes);
     c.mapJ = mapJ; c.mapVaf = mapVaf; c.mapHyp = mapHyp; c.n_slots = n_slots;
     c.status = 0;
     if (lane == 0) { w->work[0] = 0; w->work[1] = 0; }
@@ -2811,7 +2822,8 @@ extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_host, const vlr::
     size_t cap = (size_t)plan_host->table_cap;
     size_t dbl = (size_t)3 * max_obs + (size_t)2 * range_depth * cap + (size_t)2 * kRows * cap + (size_t)kRows * n_samples +
                  (size_t)2 * n_univ + n_slots + n_slots * n_samples + (size_t)2 * n_samples * kMaxSet + (size_t)3 * n_samples * kCacheWays +
-                 (n_slots + 1) / 2 + 2 + (size_t)plan_host->n_dkey;
+                 (n_slots + 1) / 2 + 2 + (size_t)plan_host->n_dkey +
+                 ((size_t)(plan_host->max_frames + 1) * sizeof(Frame) + (size_t)range_depth * sizeof(RangeSt) + 7) / 8;
     size_t bytes = dbl * sizeof(double);
     static size_t static_lds = 0;
     if (!static_lds) {
@@ -2820,8 +2832,10 @@ extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_host, const vlr::
         if (ea != hipSuccess) return (int)ea;
         static_lds = fa.sharedSizeBytes ? fa.sharedSizeBytes : 1;
     }
-    // 160 kB of LDS per CU: twelve workgroups (three waves per SIMD) need <= 13 312 B each (512 B granules)
-    int wpe = (static_lds + bytes <= 13312) ? 3 : 2;
+    // 160 kB of LDS per CU: the 2-wave build tops out at 8 workgroups per CU; from 9 on the 3-wave build wins although it
+    // spills (tools/occupancy_probe.py: +5 % at 9-10 workgroups, +15..33 % at 10-12, -4 % at 8)
+    const size_t lds_wg = (static_lds + bytes + 511) & ~(size_t)511;
+    int wpe = (163840 / lds_wg >= 9) ? 3 : 2;
     if (const char* ev = getenv("VLR_WAVES_PER_SIMD")) wpe = atoi(ev) == 3 ? 3 : 2;  // tuning knob
     const void* fn = wpe == 3 ? (const void*)vlr_call_kernel<3> : (const void*)vlr_call_kernel<2>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
