@@ -471,7 +471,7 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
         if (r < 0 || r >= d->n_nodes) return fail(VLR_ERR_INVALID_ARGUMENT, "root index out of range");
 
     // ---- static limits of the device walk: range nesting, LFC terms and frames per path
-    int max_range = 0, max_lfc = 0, max_frames = 0;
+    int max_range = 0, max_lfc = 0, max_frames = 0, max_tab = 0;
     {
         struct It { int node, ranges, lfcs, frames; };
         std::vector<It> st;
@@ -484,7 +484,10 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
             const DevNode& n = nodes[it.node];
             if (n.kind == VLR_NODE_SAMPLE) {
                 it.frames++;
-                if (n.vafs.kind == VLR_SPECTRUM_RANGE && !(n.vafs.start == n.vafs.end)) it.ranges++;
+                if (n.vafs.kind == VLR_SPECTRUM_RANGE && !(n.vafs.start == n.vafs.end)) {
+                    if (n.n_children > 0) max_tab = std::max(max_tab, it.ranges + 1);
+                    it.ranges++;
+                }
             }
             if (n.kind == VLR_NODE_LFC) it.lfcs++;
             if (n.n_children > 1) it.frames++;
@@ -498,6 +501,7 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
     if (max_lfc > kMaxLfc) return fail(VLR_ERR_UNSUPPORTED, "more than %d l2fc terms on one path", kMaxLfc);
     if (max_frames > kMaxFrames) return fail(VLR_ERR_UNSUPPORTED, "VAF tree deeper than %d frames", kMaxFrames);
     P.max_range_depth = std::max(1, max_range);
+    P.max_tab_depth = max_tab;
     P.max_frames = std::max(S, max_frames);  // the absent chain pushes one frame per sample
     {
         // capacity of a visited-point table: 2 endpoints + 3 per bisection round + 7 tail points, with at most

@@ -62,7 +62,7 @@ struct RangeSt {
 };
 
 constexpr int kRows = 4;        // concurrent chains per wave: one per 16-lane DPP row
-constexpr int kRowPts = 12;     // pending points of one chain round (<= 11)
+constexpr int kRowPts = 11;     // pending points of one chain round (Simpson fall-back: 11)
 constexpr int kPass = 3;        // points one lane carries through a pass over its observation slice
 
 struct ChainTask {              // one innermost Range chain (see run_chain_batch)
@@ -98,9 +98,6 @@ struct WaveSt {
         };
     };
     int cacheN[kMaxSamples];
-    double ptA[kMaxBatchPoints], ptB[kMaxBatchPoints], res[kMaxBatchPoints];
-    double ptJ[kMaxBatchPoints];
-    double fixedLik[kMaxSamples];
     double curMapVaf[kMaxSamples];
     double mapv[kMaxSamples];  // replay: MAP VAF per sample
     int afd_nseen[kMaxSamples]; // replay: discrete VAFs of sample s already recorded (overlapping roots/branches
@@ -1204,8 +1201,8 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
         }
     // pending points and their joint values live in two tiny LDS arrays (same-wave LDS ops execute in order;
     // wave_barrier() only stops the compiler from reordering them)
-    double* pend = w->ptA;  // reuse: ptA = pending x, ptJ = joint values
-    double* vals = w->ptJ;
+    double* pend = w->bpend[0];  // the row buffers are idle while a single chain runs
+    double* vals = w->bvals[0];
     int np, phase, tn = 0;
     __builtin_amdgcn_wave_barrier();
     if (simpson_n) {
@@ -1807,14 +1804,14 @@ __device__ __forceinline__ bool bo_setup(Ctx& c, const Frame& f, RangeSt& r) {
             double b = by >= 0 ? c.tvaf[lane * S + by] : 0.0;
             double al, be;
             alpha_beta(p, s, a, b, al, be);
-            w->ptA[lane] = al;
-            w->ptB[lane] = be;
+            w->bpend[1][lane] = al;  // scratch: the row buffers are rewritten by the chain batch that follows
+            w->bpend[2][lane] = be;
         }
         __syncthreads();
         int off = UNI(w->soff[s]), D = UNI(w->nkeep[s]);
-        eval_pileup(c.coef + 3 * off, D, (w->fastok >> s) & 1, nt, w->ptA, w->ptB, w->res, lane);
+        eval_pileup(c.coef + 3 * off, D, (w->fastok >> s) & 1, nt, w->bpend[1], w->bpend[2], w->bpend[3], lane);
         __syncthreads();
-        if (lane < nt) w->task[lane].fixed += w->res[lane];
+        if (lane < nt) w->task[lane].fixed += w->bpend[3][lane];
         if (lane == 0) { w->work[0] += (unsigned long long)nt; w->work[1] += (unsigned long long)nt * (unsigned long long)D; }
         __syncthreads();
     }
@@ -2280,8 +2277,8 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
     c.cap = cap;
     c.coef = dyn;
     c.tabX = dyn + 3 * max_obs;
-    c.tabV = c.tabX + range_depth * cap;
-    c.rowX = c.tabV + range_depth * cap;
+    c.tabV = c.tabX + p.max_tab_depth * cap;
+    c.rowX = c.tabV + p.max_tab_depth * cap;
     c.rowV = c.rowX + kRows * cap;
     // sort scratch of integrate_table aliases row 1: it is only used by outer chains (whose inner chains are
     // finished) and by the single-chain fallback (which owns row 0)
@@ -2298,9 +2295,10 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
     c.cacheB = c.cacheA + S * kCacheWays;
     c.cacheV = c.cacheB + S * kCacheWays;
     c.afd_seen = c.cacheV + S * kCacheWays;  // [S][kMaxSet]
-    int* mapHyp = (int*)(c.afd_seen + S * kMaxSet);  // [n_slots]
-    c.dkeyV = c.afd_seen + S * kMaxSet + (n_slots + 1) / 2 + 2;  // [n_dkey]
-    c.nframes = p.max_frames + 1; c.nrs = range_depth;
+    const int n_seen = out.replay ? S * kMaxSet : 0;  // only the AFD replay pass records discrete VAFs
+    int* mapHyp = (int*)(c.afd_seen + n_seen);  // [n_slots]
+    c.dkeyV = c.afd_seen + n_seen + (n_slots + 1) / 2 + 2;  // [n_dkey]
+    c.nframes = p.max_frames; c.nrs = range_depth;
     c.frames = (Frame*)(c.dkeyV + p.n_dkey);
     c.rs = (RangeSt*)(c.frames + c.nframes);
     c.mapJ = mapJ; c.mapVaf = mapVaf; c.mapHyp = mapHyp; c.n_slots = n_slots;
@@ -2820,10 +2818,10 @@ extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_host, const vlr::
     if (range_depth < 1) range_depth = 1;
     size_t n_slots = (size_t)n_univ + 1;
     size_t cap = (size_t)plan_host->table_cap;
-    size_t dbl = (size_t)3 * max_obs + (size_t)2 * range_depth * cap + (size_t)2 * kRows * cap + (size_t)kRows * n_samples +
-                 (size_t)2 * n_univ + n_slots + n_slots * n_samples + (size_t)2 * n_samples * kMaxSet + (size_t)3 * n_samples * kCacheWays +
+    size_t dbl = (size_t)3 * max_obs + (size_t)2 * plan_host->max_tab_depth * cap + (size_t)2 * kRows * cap + (size_t)kRows * n_samples +
+                 (size_t)2 * n_univ + n_slots + n_slots * n_samples + (size_t)(out->replay ? 2 : 1) * n_samples * kMaxSet + (size_t)3 * n_samples * kCacheWays +
                  (n_slots + 1) / 2 + 2 + (size_t)plan_host->n_dkey +
-                 ((size_t)(plan_host->max_frames + 1) * sizeof(Frame) + (size_t)range_depth * sizeof(RangeSt) + 7) / 8;
+                 ((size_t)plan_host->max_frames * sizeof(Frame) + (size_t)range_depth * sizeof(RangeSt) + 7) / 8;
     size_t bytes = dbl * sizeof(double);
     static size_t static_lds = 0;
     if (!static_lds) {

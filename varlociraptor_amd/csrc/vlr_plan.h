@@ -87,7 +87,8 @@ struct DevPlan {
     // flattened all-discrete roots: droot[2 * i], droot[2 * i + 1] = leaf range of root i (0 = absent, 1 + k = roots[k]);
     // a start of -1 sends the root through the general walk
     int32_t n_dkey, n_dleaf;
-    int32_t max_frames, pad0;   // deepest explicit-stack depth of the walk over this plan's trees
+    int32_t max_frames;         // deepest explicit-stack depth of the walk over this plan's trees
+    int32_t max_tab_depth;      // visited-point tables needed by NON-leaf Range frames (leaf chains use the row tables)
     const DevDLeaf* dleaf;
     const DevDKey* dkey;
     const int32_t* droot;
