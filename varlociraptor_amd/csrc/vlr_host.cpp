@@ -260,6 +260,9 @@ struct vlr_plan {
     // AFD replay scratch (device), one per slot: is_discrete mask of the MAP, and marginal/best_event when the caller passes NULL
     void* afd_scratch[2] = {nullptr, nullptr};
     size_t afd_scratch_bytes[2] = {0, 0};
+    // kernel scratch, one per slot: the third likelihood coefficient of every kept observation (8 B x max_obs per locus)
+    void* escratch[2] = {nullptr, nullptr};
+    size_t escratch_bytes[2] = {0, 0};
     int slot = 0;  // slot used by the next vlr_batch_run (set by vlr_batch_run_host)
 };
 
@@ -752,6 +755,7 @@ void vlr_plan_destroy(vlr_plan* plan) {
     for (int k = 0; k < 2; ++k) {
         if (plan->stage[k]) (void)hipFree(plan->stage[k]);
         if (plan->afd_scratch[k]) (void)hipFree(plan->afd_scratch[k]);
+        if (plan->escratch[k]) (void)hipFree(plan->escratch[k]);
         if (plan->stage_stream[k]) (void)hipStreamDestroy(plan->stage_stream[k]);
     }
     if (plan->work_dev) (void)hipFree(plan->work_dev);
@@ -767,7 +771,7 @@ int vlr_plan_n_samples(const vlr_plan* plan) { return plan ? plan->host.S : VLR_
 // (reference default max_depth = 200, src/variants/sample.rs:236).  Loci above it get VLR_LOCUS_TOO_DEEP.
 int vlr_plan_set_max_depth(vlr_plan* plan, int per_sample_depth) {
     if (!plan || per_sample_depth < 1) return fail(VLR_ERR_INVALID_ARGUMENT, "invalid max depth");
-    size_t lds = (size_t)3 * per_sample_depth * plan->host.S * 8;
+    size_t lds = (size_t)2 * per_sample_depth * plan->host.S * 8;
     if (lds > 120 * 1024) return fail(VLR_ERR_UNSUPPORTED, "max depth %d x %d samples exceeds the LDS budget", per_sample_depth, plan->host.S);
     plan->max_depth_per_sample = per_sample_depth;
     plan->max_obs = 0;
@@ -777,7 +781,7 @@ int vlr_plan_set_max_depth(vlr_plan* plan, int per_sample_depth) {
 // finer LDS knob: maximum number of kept observations of one locus over all samples
 int vlr_plan_set_max_obs(vlr_plan* plan, int max_obs_per_locus) {
     if (!plan || max_obs_per_locus < 1) return fail(VLR_ERR_INVALID_ARGUMENT, "invalid max obs");
-    if ((size_t)3 * max_obs_per_locus * 8 > 120 * 1024) return fail(VLR_ERR_UNSUPPORTED, "max obs %d exceeds the LDS budget", max_obs_per_locus);
+    if ((size_t)2 * max_obs_per_locus * 8 > 120 * 1024) return fail(VLR_ERR_UNSUPPORTED, "max obs %d exceeds the LDS budget", max_obs_per_locus);
     plan->max_obs = max_obs_per_locus;
     return VLR_OK;
 }
@@ -829,6 +833,18 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
     }
     int max_obs = plan->max_obs > 0 ? plan->max_obs : plan->max_depth_per_sample * plan->host.S;
     max_obs = (max_obs + 3) & ~3;
+    {
+        const int k = plan->slot & 1;
+        const size_t need = (size_t)in->n_loci * (size_t)max_obs * sizeof(double);
+        if (need > plan->escratch_bytes[k]) {
+            if (plan->escratch[k]) (void)hipFree(plan->escratch[k]);
+            plan->escratch[k] = nullptr;
+            plan->escratch_bytes[k] = 0;
+            if (hipMalloc(&plan->escratch[k], need) != hipSuccess) return fail(VLR_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed", need);
+            plan->escratch_bytes[k] = need;
+        }
+        r.escratch = (double*)plan->escratch[k];
+    }
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipEventRecord(plan->ev_start, st));
     int rc = vlr_launch_call_kernel(&plan->host, &b, &r, plan->host.n_univ, plan->host.S, max_obs, plan->host.max_range_depth, stream);

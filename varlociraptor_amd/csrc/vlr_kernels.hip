@@ -393,28 +393,38 @@ __device__ __forceinline__ void renorm_pos(double& P, int& E) {
 }
 
 // Partial products of NP points over this lane's observation slice: lane k of a W-lane group (W = 16: one DPP
-// row = one chain; W = 64: the whole wave) takes terms k, k+W, k+2W, ...  Every coefficient triple is loaded
-// once and used for all NP points (the LDS return path, not the VALU, limited the previous (point, slice)
-// lane split).  `fast`: every term of this pileup is >= 2^-200 at every VAF (checked when the coefficients were
-// built), so four terms are multiplied before one renormalisation and no clamping at zero is needed.
-template <int NP, int W>
-__device__ __forceinline__ void accum_terms(const double* __restrict__ coef, int D, int k, bool fast, const double* al, const double* be,
-                                            double* P, int* E) {
-    constexpr int ST = 3 * W;
-    const double* a = coef + 3 * k;
+// row = one chain; W = 64: the whole wave) takes terms k, k+W, k+2W, ...  Every coefficient pair {c, q} is loaded from
+// LDS once and used for all NP points.  The third coefficient e only matters where beta != 0 (a VAF of exactly 1 in the
+// sample or its contaminant): it lives in a per-locus HBM scratch row (`ecoef`, 8 B per observation, read back by the
+// same wave) so that the LDS footprint of a workgroup stays at 16 B per observation (occupancy: see tools/lds_sweep.py);
+// USE_E is wave-uniform.  `fast`: every term of this pileup is >= 2^-200 at every VAF (checked when the coefficients
+// were built), so four terms are multiplied before one renormalisation and no clamping at zero is needed.
+// (written and read by the same wave: workgroup-scope coherence through the CU's vector L1 is enough, the barrier after
+// the coefficient pass orders the stores before the loads)
+__device__ __forceinline__ double ld_e(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+template <int NP, int W, bool USE_E>
+__device__ __forceinline__ void accum_terms_e(const double* __restrict__ coef, const double* __restrict__ ecoef, int D, int k, bool fast,
+                                              const double* al, const double* be, double* P, int* E) {
+    constexpr int ST = 2 * W;
+    const double* a = coef + 2 * k;
+    const double* g = ecoef + k;
     int base = 0;
     if (fast) {
-        for (; base + 4 * W <= D; base += 4 * W, a += 4 * ST) {
-            const double c0 = a[0], q0 = a[1], e0 = a[2];
-            const double c1 = a[ST], q1 = a[ST + 1], e1 = a[ST + 2];
-            const double c2 = a[2 * ST], q2 = a[2 * ST + 1], e2 = a[2 * ST + 2];
-            const double c3 = a[3 * ST], q3 = a[3 * ST + 1], e3 = a[3 * ST + 2];
+        for (; base + 4 * W <= D; base += 4 * W, a += 4 * ST, g += 4 * W) {
+            const double c0 = a[0], q0 = a[1];
+            const double c1 = a[ST], q1 = a[ST + 1];
+            const double c2 = a[2 * ST], q2 = a[2 * ST + 1];
+            const double c3 = a[3 * ST], q3 = a[3 * ST + 1];
+            double e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0;
+            if (USE_E) { e0 = ld_e(g); e1 = ld_e(g + W); e2 = ld_e(g + 2 * W); e3 = ld_e(g + 3 * W); }
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
-                const double L0 = __builtin_fma(e0, be[j], __builtin_fma(q0, al[j], c0));
-                const double L1 = __builtin_fma(e1, be[j], __builtin_fma(q1, al[j], c1));
-                const double L2 = __builtin_fma(e2, be[j], __builtin_fma(q2, al[j], c2));
-                const double L3 = __builtin_fma(e3, be[j], __builtin_fma(q3, al[j], c3));
+                double L0 = __builtin_fma(q0, al[j], c0), L1 = __builtin_fma(q1, al[j], c1);
+                double L2 = __builtin_fma(q2, al[j], c2), L3 = __builtin_fma(q3, al[j], c3);
+                if (USE_E) {  // same operation order as e*beta + (q*alpha + c)
+                    L0 = __builtin_fma(e0, be[j], L0); L1 = __builtin_fma(e1, be[j], L1);
+                    L2 = __builtin_fma(e2, be[j], L2); L3 = __builtin_fma(e3, be[j], L3);
+                }
                 P[j] *= (L0 * L1) * (L2 * L3);
                 renorm_pos(P[j], E[j]);
             }
@@ -423,26 +433,35 @@ __device__ __forceinline__ void accum_terms(const double* __restrict__ coef, int
             double acc[NP];
 #pragma unroll
             for (int j = 0; j < NP; ++j) acc[j] = 1.0;
-            for (; base < D; base += W, a += ST) {
+            for (; base < D; base += W, a += ST, g += W) {
                 const bool v = base + k < D;
                 const double* aa = v ? a : coef;
-                double c0 = aa[0], q0 = aa[1], e0 = aa[2];
-                c0 = v ? c0 : 1.0; q0 = v ? q0 : 0.0; e0 = v ? e0 : 0.0;
+                double c0 = aa[0], q0 = aa[1];
+                double e0 = 0.0;
+                if (USE_E) { e0 = ld_e(v ? g : ecoef); e0 = v ? e0 : 0.0; }
+                c0 = v ? c0 : 1.0; q0 = v ? q0 : 0.0;
 #pragma unroll
-                for (int j = 0; j < NP; ++j) acc[j] *= __builtin_fma(e0, be[j], __builtin_fma(q0, al[j], c0));
+                for (int j = 0; j < NP; ++j) {
+                    double L0 = __builtin_fma(q0, al[j], c0);
+                    if (USE_E) L0 = __builtin_fma(e0, be[j], L0);
+                    acc[j] *= L0;
+                }
             }
 #pragma unroll
             for (int j = 0; j < NP; ++j) { P[j] *= acc[j]; renorm_pos(P[j], E[j]); }
         }
     } else {
-        for (; base < D; base += W, a += ST) {  // robust path: per-term mantissa/exponent split (terms may be denormal or zero)
+        for (; base < D; base += W, a += ST, g += W) {  // robust path: per-term mantissa/exponent split (terms may be denormal or zero)
             const bool v = base + k < D;
             const double* aa = v ? a : coef;
-            double c0 = aa[0], q0 = aa[1], e0 = aa[2];
-            c0 = v ? c0 : 1.0; q0 = v ? q0 : 0.0; e0 = v ? e0 : 0.0;
+            double c0 = aa[0], q0 = aa[1];
+            double e0 = 0.0;
+            if (USE_E) { e0 = ld_e(v ? g : ecoef); e0 = v ? e0 : 0.0; }
+            c0 = v ? c0 : 1.0; q0 = v ? q0 : 0.0;
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
-                double L0 = __builtin_fma(e0, be[j], __builtin_fma(q0, al[j], c0));
+                double L0 = __builtin_fma(q0, al[j], c0);
+                if (USE_E) L0 = __builtin_fma(e0, be[j], L0);
                 L0 = L0 < 0.0 ? 0.0 : L0;
                 int e;
                 const double m = __builtin_frexp(L0, &e);
@@ -453,6 +472,15 @@ __device__ __forceinline__ void accum_terms(const double* __restrict__ coef, int
 #pragma unroll
         for (int j = 0; j < NP; ++j) { int e; P[j] = __builtin_frexp(P[j], &e); E[j] += e; }
     }
+}
+template <int NP, int W>
+__device__ __forceinline__ void accum_terms(const double* __restrict__ coef, const double* __restrict__ ecoef, int D, int k, bool fast,
+                                            const double* al, const double* be, double* P, int* E) {
+    bool nz = false;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) nz = nz || (be[j] != 0.0);
+    if (__ballot(nz)) accum_terms_e<NP, W, true>(coef, ecoef, D, k, fast, al, be, P, E);
+    else accum_terms_e<NP, W, false>(coef, ecoef, D, k, fast, al, be, P, E);
 }
 // product over the W lanes of the group; every lane ends with the result (mantissa in [0.5,1) or 0, exponent)
 template <int NP, int W>
@@ -473,13 +501,13 @@ __device__ __forceinline__ void reduce_terms(double* P, int* E) {
     }
 }
 template <int W>
-__device__ __forceinline__ void accum_terms_n(int cnt, const double* __restrict__ coef, int D, int k, bool fast, const double* al,
-                                              const double* be, double* P, int* E) {
+__device__ __forceinline__ void accum_terms_n(int cnt, const double* __restrict__ coef, const double* __restrict__ ecoef, int D, int k, bool fast,
+                                              const double* al, const double* be, double* P, int* E) {
     switch (cnt) {
-        case 1: accum_terms<1, W>(coef, D, k, fast, al, be, P, E); break;
-        case 2: accum_terms<2, W>(coef, D, k, fast, al, be, P, E); break;
-        case 3: accum_terms<3, W>(coef, D, k, fast, al, be, P, E); break;
-        default: accum_terms<4, W>(coef, D, k, fast, al, be, P, E); break;
+        case 1: accum_terms<1, W>(coef, ecoef, D, k, fast, al, be, P, E); break;
+        case 2: accum_terms<2, W>(coef, ecoef, D, k, fast, al, be, P, E); break;
+        case 3: accum_terms<3, W>(coef, ecoef, D, k, fast, al, be, P, E); break;
+        default: accum_terms<4, W>(coef, ecoef, D, k, fast, al, be, P, E); break;
     }
 }
 template <int W>
@@ -493,8 +521,8 @@ __device__ __forceinline__ void reduce_terms_n(int cnt, double* P, int* E) {
 }
 
 // ln pileup likelihood at np <= 4 points (alpha, beta) on all 64 lanes; lane j < np writes res[j]
-__device__ inline void eval_pileup(const double* __restrict__ coef, int D, bool fast, int np, const double* ptA, const double* ptB,
-                                   double* res, int lane) {
+__device__ inline void eval_pileup(const double* __restrict__ coef, const double* __restrict__ ecoef, int D, bool fast, int np, const double* ptA,
+                                   const double* ptB, double* res, int lane) {
     double al[4], be[4], P[4];
     int E[4];
 #pragma unroll
@@ -502,7 +530,7 @@ __device__ inline void eval_pileup(const double* __restrict__ coef, int D, bool 
         const int jj = j < np ? j : np - 1;
         al[j] = ptA[jj]; be[j] = ptB[jj]; P[j] = 1.0; E[j] = 0;
     }
-    accum_terms_n<64>(np, coef, D, lane, fast, al, be, P, E);
+    accum_terms_n<64>(np, coef, ecoef, D, lane, fast, al, be, P, E);
     reduce_terms_n<64>(np, P, E);
     const double Pm = lane == 1 ? P[1] : lane == 2 ? P[2] : lane == 3 ? P[3] : P[0];
     const int Em = lane == 1 ? E[1] : lane == 2 ? E[2] : lane == 3 ? E[3] : E[0];
@@ -560,6 +588,7 @@ struct Ctx {
     WaveSt* w;
     double* coef;                    // AoS coefficient triples {c,q,e} (LDS)
     double* setv;                    // [S][kMaxSet] Set candidates per sample (LDS)
+    const double* ecoef;               // third coefficient of every kept observation of this locus (HBM scratch row)
     double *cacheA, *cacheB, *cacheV;  // [S][kCacheWays] per-sample likelihood cache (LDS)
     double* dkeyV;                     // [n_dkey] pileup likelihoods of the flattened discrete roots, per hypothesis (LDS)
     Frame* frames;                     // [nframes] explicit recursion stack of walk_root (LDS, sized by the plan's deepest path)
@@ -639,7 +668,7 @@ __device__ inline double sample_lik_point(Ctx& c, int s, double a, double b) {  
     const int off = UNI(w->soff[s]), D = UNI(w->nkeep[s]);
     double P1[1] = {1.0};
     int E1[1] = {0};
-    accum_terms<1, 64>(c.coef + 3 * off, D, c.lane, (w->fastok >> s) & 1, &al, &be, P1, E1);
+    accum_terms<1, 64>(c.coef + 2 * off, c.ecoef + off, D, c.lane, (w->fastok >> s) & 1, &al, &be, P1, E1);
     reduce_terms<1, 64>(P1, E1);
     if (c.lane == 0) { w->work[0] += 1; w->work[1] += (unsigned long long)D; }
     return uni_d(log(P1[0]) + (double)E1[0] * kLn2);
@@ -1244,7 +1273,7 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
                 double b = by >= 0 ? ((by == inner) ? xr : w->ops_vaf[by]) : 0.0;
                 double al, be;
                 alpha_beta(p, s, a, b, al, be);
-                accum_terms<1, 16>(c.coef + 3 * UNI(w->soff[s]), UNI(w->nkeep[s]), rlane, (w->fastok >> s) & 1, &al, &be, P1, E1);
+                accum_terms<1, 16>(c.coef + 2 * UNI(w->soff[s]), c.ecoef + UNI(w->soff[s]), UNI(w->nkeep[s]), rlane, (w->fastok >> s) & 1, &al, &be, P1, E1);
             }
             reduce_terms<1, 16>(P1, E1);
             const double lik = fixed + (log(P1[0]) + (double)E1[0] * kLn2);
@@ -1468,7 +1497,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
                     const double b = by >= 0 ? ((by == inner) ? xs[j] : vb) : 0.0;
                     alpha_beta(p, s, a, b, al[j], be[j]);
                 }
-                accum_terms_n<16>(cnt, c.coef + 3 * UNI(w->soff[s]), UNI(w->nkeep[s]), rl, (UNI(w->fastok) >> s) & 1, al, be, P, E);
+                accum_terms_n<16>(cnt, c.coef + 2 * UNI(w->soff[s]), c.ecoef + UNI(w->soff[s]), UNI(w->nkeep[s]), rl, (UNI(w->fastok) >> s) & 1, al, be, P, E);
             }
             PROF_ADD(c, 12);  // round: term products
             reduce_terms_n<16>(cnt, P, E);
@@ -1809,7 +1838,7 @@ __device__ __forceinline__ bool bo_setup(Ctx& c, const Frame& f, RangeSt& r) {
         }
         __syncthreads();
         int off = UNI(w->soff[s]), D = UNI(w->nkeep[s]);
-        eval_pileup(c.coef + 3 * off, D, (w->fastok >> s) & 1, nt, w->bpend[1], w->bpend[2], w->bpend[3], lane);
+        eval_pileup(c.coef + 2 * off, c.ecoef + off, D, (w->fastok >> s) & 1, nt, w->bpend[1], w->bpend[2], w->bpend[3], lane);
         __syncthreads();
         if (lane < nt) w->task[lane].fixed += w->bpend[3][lane];
         if (lane == 0) { w->work[0] += (unsigned long long)nt; w->work[1] += (unsigned long long)nt * (unsigned long long)D; }
@@ -2276,7 +2305,8 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
     const int cap = p.table_cap;
     c.cap = cap;
     c.coef = dyn;
-    c.tabX = dyn + 3 * max_obs;
+    c.ecoef = out.escratch + (size_t)blockIdx.x * (size_t)max_obs;
+    c.tabX = dyn + 2 * max_obs;
     c.tabV = c.tabX + p.max_tab_depth * cap;
     c.rowX = c.tabV + p.max_tab_depth * cap;
     c.rowV = c.rowX + kRows * cap;
@@ -2634,9 +2664,9 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                     double d = A - R;
                     double cc_ = wv * R + uu, cq_ = wv * sv * d, ce_ = wv * (1.0 - sv) * d;
                     if (pos < max_obs) {
-                        c.coef[3 * pos + 0] = cc_;
-                        c.coef[3 * pos + 1] = cq_;
-                        c.coef[3 * pos + 2] = ce_;
+                        c.coef[2 * pos + 0] = cc_;
+                        c.coef[2 * pos + 1] = cq_;
+                        __hip_atomic_store(out.escratch + (size_t)blockIdx.x * (size_t)max_obs + pos, ce_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                     // smallest value the term can take over alpha in [0,1], beta in [0,1] (linear => at a corner)
                     double mn = fmin(fmin(cc_, cc_ + cq_), fmin(cc_ + ce_, cc_ + cq_ + ce_));
@@ -2649,7 +2679,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
         }
         if (lane == 0) w->fastok = fastmask;
         if (lane < S) w->cacheN[lane] = 0;
-        __syncthreads();
+        __syncthreads();  // also orders the e coefficients (HBM scratch row, written by other lanes than the ones that read them)
         if (__ballot((c.status & VLR_LOCUS_UNDERFLOW) != 0)) c.status |= VLR_LOCUS_UNDERFLOW;
         if (p.n_dkey > 0 && !c.replay) {  // pileup likelihoods of the flattened discrete roots under this hypothesis
             for (int k = 0; k < p.n_dkey; ++k) {
@@ -2818,7 +2848,7 @@ extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_host, const vlr::
     if (range_depth < 1) range_depth = 1;
     size_t n_slots = (size_t)n_univ + 1;
     size_t cap = (size_t)plan_host->table_cap;
-    size_t dbl = (size_t)3 * max_obs + (size_t)2 * plan_host->max_tab_depth * cap + (size_t)2 * kRows * cap + (size_t)kRows * n_samples +
+    size_t dbl = (size_t)2 * max_obs + (size_t)2 * plan_host->max_tab_depth * cap + (size_t)2 * kRows * cap + (size_t)kRows * n_samples +
                  (size_t)2 * n_univ + n_slots + n_slots * n_samples + (size_t)(out->replay ? 2 : 1) * n_samples * kMaxSet + (size_t)3 * n_samples * kCacheWays +
                  (n_slots + 1) / 2 + 2 + (size_t)plan_host->n_dkey +
                  ((size_t)plan_host->max_frames * sizeof(Frame) + (size_t)range_depth * sizeof(RangeSt) + 7) / 8;

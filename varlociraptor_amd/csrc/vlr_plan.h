@@ -119,6 +119,7 @@ struct DevResults {
     double* afd_lnprob;     // [n_loci * S * afd_capacity]
     int32_t afd_capacity;
     int32_t replay;         // 0: call pass, 1: AFD replay pass
+    double* escratch;       // [n_loci * max_obs] third likelihood coefficient per kept observation (kernel scratch, plan-owned)
 };
 
 }  // namespace vlr
