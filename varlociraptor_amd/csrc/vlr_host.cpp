@@ -505,6 +505,9 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
     if (max_frames > kMaxFrames) return fail(VLR_ERR_UNSUPPORTED, "VAF tree deeper than %d frames", kMaxFrames);
     P.max_range_depth = std::max(1, max_range);
     P.max_tab_depth = max_tab;
+    P.max_set = 1;
+    for (const DevNode& n : nodes)
+        if (n.kind == VLR_NODE_SAMPLE && n.vafs.kind == VLR_SPECTRUM_SET) P.max_set = std::max(P.max_set, n.vafs.set_len);
     P.max_frames = std::max(S, max_frames);  // the absent chain pushes one frame per sample
     {
         // capacity of a visited-point table: 2 endpoints + 3 per bisection round + 7 tail points, with at most

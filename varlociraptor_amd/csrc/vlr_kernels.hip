@@ -2025,10 +2025,10 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                         if (clear_ref && all_pos) dead = true;
                         else {
                             __syncthreads();
-                            for (int i = 0; i < nd.vafs.set_len && ncand < kMaxSet; ++i) {
+                            for (int i = 0; i < nd.vafs.set_len && ncand < p.max_set; ++i) {
                                 double v = ldc(p.vafs + nd.vafs.set_off + i);
                                 if (!have_bounds || range_contains(bounds, v)) {
-                                    if (c.lane == 0) c.setv[s * kMaxSet + ncand] = v;
+                                    if (c.lane == 0) c.setv[s * p.max_set + ncand] = v;
                                     ncand++;
                                 }
                             }
@@ -2042,7 +2042,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                         else if (clear_ref && vr.start > 0.0) dead = true;
                         else if (range_is_singleton(vr)) {
                             __syncthreads();
-                            if (c.lane == 0) c.setv[s * kMaxSet] = vr.start;
+                            if (c.lane == 0) c.setv[s * p.max_set] = vr.start;
                             __syncthreads();
                             ncand = 1;
                             as_set = true;
@@ -2064,7 +2064,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                         return 0.0;
                     }
                     if (as_set) {
-                        if (c.lane == 0) { f.kind = FK_SET; f.n = ncand; w->ops_vaf[s] = c.setv[s * kMaxSet]; }
+                        if (c.lane == 0) { f.kind = FK_SET; f.n = ncand; w->ops_vaf[s] = c.setv[s * p.max_set]; }
                         __syncthreads();
                         sp++;
                         c.present |= (1 << s);
@@ -2262,7 +2262,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                     if (UNI(f.kind) == FK_SET) {
                         int s = nd.sample;
                         __syncthreads();
-                        if (c.lane == 0) w->ops_vaf[s] = c.setv[s * kMaxSet + it];
+                        if (c.lane == 0) w->ops_vaf[s] = c.setv[s * p.max_set + it];
                         __syncthreads();
                         c.present |= (1 << s);
                         c.disc |= (1 << s);
@@ -2321,7 +2321,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
     double* mapJ = evS + p.n_univ;          // [n_slots]
     double* mapVaf = mapJ + n_slots;        // [n_slots][S]
     c.setv = mapVaf + n_slots * S;          // [S][kMaxSet]
-    c.cacheA = c.setv + S * kMaxSet;        // [S][kCacheWays] x 3
+    c.cacheA = c.setv + S * p.max_set;      // [S][kCacheWays] x 3   (setv: [S][max_set], the plan's largest Set spectrum)
     c.cacheB = c.cacheA + S * kCacheWays;
     c.cacheV = c.cacheB + S * kCacheWays;
     c.afd_seen = c.cacheV + S * kCacheWays;  // [S][kMaxSet]
@@ -2849,7 +2849,7 @@ extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_host, const vlr::
     size_t n_slots = (size_t)n_univ + 1;
     size_t cap = (size_t)plan_host->table_cap;
     size_t dbl = (size_t)2 * max_obs + (size_t)2 * plan_host->max_tab_depth * cap + (size_t)2 * kRows * cap + (size_t)kRows * n_samples +
-                 (size_t)2 * n_univ + n_slots + n_slots * n_samples + (size_t)(out->replay ? 2 : 1) * n_samples * kMaxSet + (size_t)3 * n_samples * kCacheWays +
+                 (size_t)2 * n_univ + n_slots + n_slots * n_samples + (size_t)n_samples * plan_host->max_set + (size_t)(out->replay ? n_samples * kMaxSet : 0) + (size_t)3 * n_samples * kCacheWays +
                  (n_slots + 1) / 2 + 2 + (size_t)plan_host->n_dkey +
                  ((size_t)plan_host->max_frames * sizeof(Frame) + (size_t)range_depth * sizeof(RangeSt) + 7) / 8;
     size_t bytes = dbl * sizeof(double);

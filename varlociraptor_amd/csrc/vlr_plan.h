@@ -89,6 +89,7 @@ struct DevPlan {
     int32_t n_dkey, n_dleaf;
     int32_t max_frames;         // deepest explicit-stack depth of the walk over this plan's trees
     int32_t max_tab_depth;      // visited-point tables needed by NON-leaf Range frames (leaf chains use the row tables)
+    int32_t max_set, pad1;      // members of the largest Set spectrum of a Sample node (>= 1)
     const DevDLeaf* dleaf;
     const DevDKey* dkey;
     const int32_t* droot;
