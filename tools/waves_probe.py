@@ -1,0 +1,19 @@
+import sys, os
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from varlociraptor_amd import engine, synth
+from bench import generate
+n=200000
+for name in ["config2", "config5"]:
+    cfg = synth.CONFIGS[name]()
+    batch = generate(name, n, 0)
+    dbatch = engine.DeviceBatch(batch, "cuda:0")
+    for wpe in ("2","3","4"):
+        os.environ["VLR_WAVES_PER_SIMD"]=wpe
+        plan = engine.Plan(cfg.scenario); plan.set_max_obs(int(batch.depth().sum(axis=1).max()))
+        out = engine.DeviceResults(batch.n_loci, plan.n_out, plan.n_samples, "cuda:0")
+        st = torch.cuda.current_stream().cuda_stream
+        ms=[]
+        for i in range(4):
+            plan.call_device(dbatch, out, st); torch.cuda.synchronize(); ms.append(plan.last_kernel_ms())
+        print(name, "waves", wpe, "%.2f ms" % min(ms[1:]), flush=True); plan.close()
