@@ -99,9 +99,6 @@ struct WaveSt {
     };
     int cacheN[kMaxSamples];
     double curMapVaf[kMaxSamples];
-    double mapv[kMaxSamples];  // replay: MAP VAF per sample
-    int afd_nseen[kMaxSamples]; // replay: discrete VAFs of sample s already recorded (overlapping roots/branches
-                                // visit the same operands; the reference's joint_probs map keeps one entry)
     int cs_node[kContainStack], cs_mask[kContainStack];
     ChainTask task[kRows];
     BatchOuter bo;
@@ -596,7 +593,10 @@ struct Ctx {
     int nframes, nrs;
     int cap;                         // capacity of one visited-point table
     double *rowX, *rowV;             // [kRows][cap] visited-point tables of the row-parallel innermost chains
-    double* afd_seen;                // replay: [S][kMaxSet] recorded discrete VAFs (aliases setv-sized scratch)
+    double* afd_seen;                // replay: [S][kMaxSet] recorded discrete VAFs
+    double* mapv;                    // replay: [S] MAP VAF per sample
+    int* afd_nseen;                  // replay: [S] discrete VAFs of sample s already recorded (overlapping roots/branches
+                                     // visit the same operands; the reference's joint_probs map keeps one entry)
     double* tvaf;                    // [kRows][S] outer operands of the chain tasks
     double *tabX, *tabV, *sx, *sv;   // visited tables [depth][kTableCap], sort scratch
     int lane;
@@ -981,7 +981,7 @@ __device__ inline void afd_consider(Ctx& c, double joint, int inner, double x) {
     const int disc = (inner >= 0) ? (c.disc & ~(1 << inner)) : c.disc;
     for (int s = 0; s < c.S; ++s) {
         double v = (s == inner) ? x : c.w->ops_vaf[s];
-        bool eq = v == c.w->mapv[s] && (((disc >> s) & 1) == ((c.mapDisc >> s) & 1));
+        bool eq = v == c.mapv[s] && (((disc >> s) & 1) == ((c.mapDisc >> s) & 1));
         if (!eq) { mism++; ms = s; }
     }
     if (mism >= 2) return;
@@ -990,12 +990,12 @@ __device__ inline void afd_consider(Ctx& c, double joint, int inner, double x) {
         if (!group_contains(c, c.mapGroup, inner, x, s)) continue;
         const double vs = (s == inner) ? x : c.w->ops_vaf[s];
         if ((disc >> s) & 1) {  // discrete operand for s: the whole operand set is a repeat if this VAF was recorded before
-            int ns = c.w->afd_nseen[s];
+            int ns = c.afd_nseen[s];
             bool seen = false;
             for (int i = 0; i < ns; ++i) seen = seen || (c.afd_seen[s * kMaxSet + i] == vs);
             if (seen) continue;
             __syncthreads();
-            if (c.lane == 0 && ns < kMaxSet) { c.afd_seen[s * kMaxSet + ns] = vs; c.w->afd_nseen[s] = ns + 1; }
+            if (c.lane == 0 && ns < kMaxSet) { c.afd_seen[s * kMaxSet + ns] = vs; c.afd_nseen[s] = ns + 1; }
             __syncthreads();
         }
         if (c.lane == 0) {
@@ -1740,13 +1740,13 @@ __device__ inline void afd_emit_row(Ctx& c, int i, int s_in, int nq) {
     const double* rvv = c.rowV + i * c.cap;
     int mism = 0;
     for (int s = 0; s < c.S; ++s)
-        if (s != s_in && !(w->ops_vaf[s] == w->mapv[s] && (((c.disc >> s) & 1) == ((c.mapDisc >> s) & 1)))) mism++;
+        if (s != s_in && !(w->ops_vaf[s] == c.mapv[s] && (((c.disc >> s) & 1) == ((c.mapDisc >> s) & 1)))) mism++;
     if (mism == 0) {
         for (int q = 0; q < nq; ++q) { double xq = uni_d(rx[q]); if (!table_has(rx, q, xq, c.lane)) afd_consider(c, uni_d(rvv[q]), s_in, xq); }
     } else if (mism == 1) {
         for (int q = 0; q < nq; ++q) {
             double xq = uni_d(rx[q]);
-            if (xq == w->mapv[s_in] && !table_has(rx, q, xq, c.lane)) afd_consider(c, uni_d(rvv[q]), s_in, xq);
+            if (xq == c.mapv[s_in] && !table_has(rx, q, xq, c.lane)) afd_consider(c, uni_d(rvv[q]), s_in, xq);
         }
     }
 }
@@ -2325,7 +2325,9 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
     c.cacheB = c.cacheA + S * kCacheWays;
     c.cacheV = c.cacheB + S * kCacheWays;
     c.afd_seen = c.cacheV + S * kCacheWays;  // [S][kMaxSet]
-    const int n_seen = out.replay ? S * kMaxSet : 0;  // only the AFD replay pass records discrete VAFs
+    const int n_seen = out.replay ? S * kMaxSet + 2 * S : 0;  // only the AFD replay pass records discrete VAFs
+    c.mapv = c.afd_seen + S * kMaxSet;
+    c.afd_nseen = (int*)(c.mapv + S);
     int* mapHyp = (int*)(c.afd_seen + n_seen);  // [n_slots]
     c.dkeyV = c.afd_seen + n_seen + (n_slots + 1) / 2 + 2;  // [n_dkey]
     c.nframes = p.max_frames; c.nrs = range_depth;
@@ -2575,7 +2577,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
         if (out.map_bias) for (int i = 0; i < VLR_N_BIAS; ++i) art = art || out.map_bias[locus * VLR_N_BIAS + i] != 0;
         if (!have || art || too_deep) return;
         __syncthreads();
-        if (lane < S) { w->mapv[lane] = out.map_vaf[locus * S + lane]; w->afd_nseen[lane] = 0; }
+        if (lane < S) { c.mapv[lane] = out.map_vaf[locus * S + lane]; c.afd_nseen[lane] = 0; }
         __syncthreads();
         int be = UNI(out.best_event[locus]);
         c.mapGroup = (be == 0) ? 0 : ((be - 1) / 2 + 1);
@@ -2849,7 +2851,7 @@ extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_host, const vlr::
     size_t n_slots = (size_t)n_univ + 1;
     size_t cap = (size_t)plan_host->table_cap;
     size_t dbl = (size_t)2 * max_obs + (size_t)2 * plan_host->max_tab_depth * cap + (size_t)2 * kRows * cap + (size_t)kRows * n_samples +
-                 (size_t)2 * n_univ + n_slots + n_slots * n_samples + (size_t)n_samples * plan_host->max_set + (size_t)(out->replay ? n_samples * kMaxSet : 0) + (size_t)3 * n_samples * kCacheWays +
+                 (size_t)2 * n_univ + n_slots + n_slots * n_samples + (size_t)n_samples * plan_host->max_set + (size_t)(out->replay ? n_samples * kMaxSet + 2 * n_samples : 0) + (size_t)3 * n_samples * kCacheWays +
                  (n_slots + 1) / 2 + 2 + (size_t)plan_host->n_dkey +
                  ((size_t)plan_host->max_frames * sizeof(Frame) + (size_t)range_depth * sizeof(RangeSt) + 7) / 8;
     size_t bytes = dbl * sizeof(double);
