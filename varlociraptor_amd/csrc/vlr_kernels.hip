@@ -407,6 +407,21 @@ __device__ __forceinline__ void accum_terms_e(const double* __restrict__ coef, c
     const double* g = ecoef + k;
     int base = 0;
     if (fast) {
+        if (NP >= 3) {  // three or four points per lane: groups of two terms keep the register footprint of the hot loop down
+            for (; base + 2 * W <= D; base += 2 * W, a += 2 * ST, g += 2 * W) {
+                const double c0 = a[0], q0 = a[1];
+                const double c1 = a[ST], q1 = a[ST + 1];
+                double e0 = 0.0, e1 = 0.0;
+                if (USE_E) { e0 = ld_e(g); e1 = ld_e(g + W); }
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    double L0 = __builtin_fma(q0, al[j], c0), L1 = __builtin_fma(q1, al[j], c1);
+                    if (USE_E) { L0 = __builtin_fma(e0, be[j], L0); L1 = __builtin_fma(e1, be[j], L1); }
+                    P[j] *= L0 * L1;
+                    renorm_pos(P[j], E[j]);
+                }
+            }
+        } else
         for (; base + 4 * W <= D; base += 4 * W, a += 4 * ST, g += 4 * W) {
             const double c0 = a[0], q0 = a[1];
             const double c1 = a[ST], q1 = a[ST + 1];
