@@ -207,6 +207,19 @@ def test_larger_random_sample_config3(oracle):
     check(oracle, cfg.scenario, synth.generate(cfg, 1500, seed=22), "config3 x1500")
 
 
+def test_page_locked_input_arrays_give_identical_results():
+    """vlr_host_alloc (include/vlr.h): arrays handed to vlr_batch_run_host may live in page-locked memory."""
+    cfg = synth.config3()
+    b = synth.generate(cfg, 3000, seed=21)
+    plan = engine.Plan(cfg.scenario)
+    ref = plan.call_host(b)
+    got = plan.call_host(engine.pin_batch(b))
+    plan.close()
+    assert np.array_equal(ref.ln_posterior, got.ln_posterior, equal_nan=True)
+    assert np.array_equal(ref.map_vaf, got.map_vaf, equal_nan=True)
+    assert np.array_equal(ref.status, got.status)
+
+
 def test_device_pointer_entry_point(oracle):
     """vlr_batch_run with device-resident columns (torch owns the memory) equals the host-staged path."""
     import torch
