@@ -15,7 +15,7 @@
 #ifndef VLR_DETMATH_H
 #define VLR_DETMATH_H
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define VLR_HD __host__ __device__
 #else
 #define VLR_HD

@@ -1,0 +1,60 @@
+"""Static checks of the shipped kernel build (no GPU): compiler-configuration hazards found in rounds 1-2.
+
+`-mllvm -disable-machine-cse` (tried as a tuning flag in round 1) produced a kernel that flagged every locus with
+VLR_LOCUS_UNDERFLOW.  Root cause (round 2, tools/repro/nocse_exp.hip): without MachineCSE this compiler materialises
+64-bit floating-point constants as `s_mov_b64 sN, <64-bit literal>`; gfx950 cannot encode 64-bit literals, the object
+keeps the low 32 bits (+inf becomes 0, the range thresholds of exp() become denormals).  The textual ISA shows the full
+literal, so the pattern can be searched for: the shipped flags must not produce it."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+BAD = re.compile(r"^\s*s_\w+_b64\s+[^;\n]*\b0x[0-9a-fA-F]{9,16}\b", re.M)
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+
+
+def _asm(src, flags, tmp_path, name):
+    out = str(tmp_path / name)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "--cuda-device-only", "-S", src, "-o", out] + flags, stderr=subprocess.DEVNULL)
+    with open(out) as fh:
+        return fh.read()
+
+
+def _makefile_flags():
+    with open(os.path.join(ROOT, "varlociraptor_amd", "csrc", "Makefile")) as fh:
+        for line in fh:
+            if line.startswith("CXXFLAGS"):
+                return [f for f in line.split("=", 1)[1].split() if f not in ("-fPIC", "-Wall")]
+    raise AssertionError("CXXFLAGS not found")
+
+
+def test_shipped_flags_do_not_use_disable_machine_cse():
+    assert "-disable-machine-cse" not in _makefile_flags()
+
+
+def test_shipped_isa_has_no_truncated_64bit_scalar_literals(tmp_path):
+    text = _asm(os.path.join(ROOT, "varlociraptor_amd", "csrc", "vlr_kernels.hip"), _makefile_flags(), tmp_path, "vlr.s")
+    assert "vlr_call_kernel" in text
+    hits = BAD.findall(text)
+    assert not hits, hits[:5]
+
+
+def test_disable_machine_cse_reproducer_shows_the_compiler_defect(tmp_path):
+    src = os.path.join(ROOT, "tools", "repro", "nocse_exp.hip")
+    good = _asm(src, ["-O3"], tmp_path, "ok.s")
+    bad = _asm(src, ["-O3", "-mllvm", "-disable-machine-cse"], tmp_path, "nocse.s")
+    assert not BAD.findall(good)
+    if not BAD.findall(bad):
+        pytest.skip("this compiler no longer emits 64-bit scalar literals without MachineCSE")
+    # the compiler's own assembler refuses what its code generator printed
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    if os.path.exists(clang):
+        r = subprocess.run([clang, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", str(tmp_path / "nocse.s"), "-o", str(tmp_path / "nocse.o")],
+                           capture_output=True, text=True)
+        assert r.returncode != 0 and "invalid operand" in r.stderr

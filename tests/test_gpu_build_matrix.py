@@ -1,0 +1,51 @@
+"""Build matrix: the engine's results must not depend on the register allocator.
+
+The same kernel source is run under register budgets of 2, 3, 4, 6 and 8 waves per SIMD (256 ... 64 VGPRs; the last two
+spill hundreds of registers), under -O1, and with workgroup barriers in place of the wave-level LDS fences
+(varlociraptor_amd/csrc/Makefile `matrix`).  Every (build, budget) evaluates the same seeded workloads in its own process
+(tools/matrix_run.py: edge-case pileups, BASELINE configs 2-5 incl. AFD lists, 24 fuzzer scenarios) and every output
+array — ln posteriors, marginals, MAP VAFs, bias codes, best events, status words, AFD lists — must be bit-identical
+to the shipped build's.  History: round 1 saw a 4-wave build fail (bisected in round 2 to the code generation of the
+4-term product loop that commit 6517fc7 replaced) — this test keeps every budget honest."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MATRIX = [  # (library, waves per SIMD)
+    (None, "2"), (None, "3"), (None, "4"),
+    ("stress", "6"), ("stress", "8"),
+    ("O1", "3"), ("O1", "4"),
+    ("sync", "3"),
+]
+
+
+def _run(out, lib, budget, mode="quick"):
+    env = dict(os.environ)
+    env.pop("VLR_LIB", None)
+    env.pop("VLR_WAVES_PER_SIMD", None)
+    if lib is not None:
+        path = os.path.join(ROOT, "varlociraptor_amd", "matrix", "libvlr_%s.so" % lib)
+        assert os.path.exists(path), "%s is not built (varlociraptor_amd.engine.build_matrix())" % path
+        env["VLR_LIB"] = path
+    if budget is not None:
+        env["VLR_WAVES_PER_SIMD"] = budget
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "matrix_run.py"), out, mode], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_results_do_not_depend_on_register_budget_or_build(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import matrix_run
+    base = str(tmp_path / "base.npz")
+    _run(base, None, None)
+    dumps = []
+    for lib, budget in MATRIX:
+        out = str(tmp_path / ("%s_%s.npz" % (lib or "default", budget)))
+        _run(out, lib, budget)
+        dumps.append(out)
+    assert matrix_run.compare([base] + dumps) == 0

@@ -110,10 +110,26 @@ struct WaveSt {
 // ------------------------------------------------------------------------------------------------
 // values that are wave-uniform by construction but live in VGPRs/LDS: moving them to SGPRs lets the compiler
 // use scalar branches and scalar (cached) loads of plan data instead of vector loads
+#ifdef VLR_NO_UNI  // diagnosis builds: leave uniformity to the compiler's own analysis
+#define UNI(x) (x)
+__device__ __forceinline__ double uni_d(double v) { return v; }
+#else
 #define UNI(x) __builtin_amdgcn_readfirstlane(x)
 __device__ __forceinline__ double uni_d(double v) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
+#endif
+
+// Ordering of LDS traffic between the lanes of ONE wave (the workgroup is a single wave64): same-wave LDS operations
+// execute in program order, so all that is needed is that the COMPILER keeps the stores of some lanes ahead of the loads
+// of others.  Variants for the build matrix (tests/test_gpu_build_matrix.py).
+#if defined(VLR_WB_SYNC)
+#define VLR_WAVE_FENCE() __syncthreads()
+#elif defined(VLR_WB_PLAIN)
+#define VLR_WAVE_FENCE() __builtin_amdgcn_wave_barrier()
+#else
+#define VLR_WAVE_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#endif
 
 // The lane id as a value the optimiser cannot hoist: without it every lane-derived constant of the chain runners
 // ((double)(lane - 1), row masks, ...) is computed once before the hypothesis loop and then SPILLED across it.
@@ -1248,7 +1264,7 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
     double* pend = w->bpend[0];  // the row buffers are idle while a single chain runs
     double* vals = w->bvals[0];
     int np, phase, tn = 0;
-    __builtin_amdgcn_wave_barrier();
+    VLR_WAVE_FENCE();
     if (simpson_n) {
         double step = (hi - lo) / (double)(simpson_n - 1);
         if (lane < simpson_n) pend[lane] = (lane == 0) ? lo : (lane == simpson_n - 1) ? hi : lin_pt(lo, step, (double)lane);
@@ -1259,7 +1275,7 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
         np = 2;
         phase = RP_INIT;
     }
-    __builtin_amdgcn_wave_barrier();
+    VLR_WAVE_FENCE();
     double L = lo, R = hi, vL = VLR_NEG_INF, vR = VLR_NEG_INF, mid = lo, first_mid = lo;
     bool have_first = false, have_mid = false, failed = false;
     double bestJ = VLR_NEG_INF, bestX = 0.0;
@@ -1303,7 +1319,7 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
             if (lead) { tx[tn + p0 + row] = xr; tv[tn + p0 + row] = jv; vals[p0 + row] = jv; }
         }
         if (__ballot(nan_seen)) c.status |= VLR_LOCUS_NAN;
-        __builtin_amdgcn_wave_barrier();
+        VLR_WAVE_FENCE();
         // lane j < np looks at point j for the MAP bookkeeping
         const bool owner = lane < np;
         const double x = pend[owner ? lane : np - 1];
@@ -1339,7 +1355,7 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
         } else {  // argmax over {left, middle1, middle2, right}; lowest index wins ties
             double xs0 = L, xs1 = uni_d(pend[1]), xs2 = uni_d(pend[2]), xs3 = R;
             double v0 = vL, v1 = uni_d(vals[1]), v2 = uni_d(vals[2]), v3 = vR;
-            __builtin_amdgcn_wave_barrier();
+            VLR_WAVE_FENCE();
             int kk = 0;
             double vb = v0;
             if (v1 > vb) { kk = 1; vb = v1; }
@@ -1374,7 +1390,7 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
             np = 7;
             phase = RP_TAIL;
         }
-        __builtin_amdgcn_wave_barrier();
+        VLR_WAVE_FENCE();
     }
     for (int s = 0; s < c.S; ++s)
         if ((dep >> s) & 1) { ndep++; dep_terms += (unsigned)w->nkeep[s]; }
@@ -1382,7 +1398,7 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
     PROF_ADD(c, 4);  // single-chain rounds
     if (haveBest) map_consider(c, bestJ, inner, bestX);
     if (failed) return __builtin_nan("");
-    __builtin_amdgcn_wave_barrier();
+    VLR_WAVE_FENCE();
     __syncthreads();
     if (phase == RP_SIMPSON) {  // bio LogProb::ln_simpsons_integrate_exp (modes/generic.rs:367-385)
         double M = VLR_NEG_INF, S = 0.0;
@@ -1425,7 +1441,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
     const int lane = fresh_lane(c.lane), row = lane >> 4, rl = lane & 15;
     const bool rowon = row < nt;
     const int cap = c.cap;
-    __builtin_amdgcn_wave_barrier();
+    VLR_WAVE_FENCE();
     const ChainTask& T = w->task[rowon ? row : 0];
     const double lo = T.lo, hi = T.hi, res = T.res, fixed = T.fixed;
     const RangeV orig{T.ostart, T.oend, T.olex, T.orex};
@@ -1473,7 +1489,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
     }
     double L = lo, R = hi, vL = VLR_NEG_INF, vR = VLR_NEG_INF, mid = lo, first_mid = lo;
     bool have_first = false, have_mid = false, failed = false, sawnan = false;
-    __builtin_amdgcn_wave_barrier();
+    VLR_WAVE_FENCE();
 
     while (__ballot(!done)) {
         const bool act = !done;
@@ -1538,7 +1554,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
         if (owner && joint != joint) sawnan = true;
         if (owner) { tx[tn + rl] = x; tv[tn + rl] = joint; vals[rl] = joint; }
         PROF_ADD(c, 14);  // round: log + prior + store
-        __builtin_amdgcn_wave_barrier();
+        VLR_WAVE_FENCE();
         if (go) {
             tn += np;
             if (phase == RP_SIMPSON || phase == RP_TAIL) done = true;
@@ -1557,7 +1573,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
                     else if (kk == 2) { L = xs1; vL = v1; }
                     else { L = xs2; vL = v2; }
                 }
-                __builtin_amdgcn_wave_barrier();
+                VLR_WAVE_FENCE();
                 if ((((R - L) >= res) && L < R) || !have_mid) {
                     mid = (R + L) / 2.0;
                     have_mid = true;
@@ -1583,7 +1599,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        VLR_WAVE_FENCE();
     }
     PROF_ADD(c, 15);
     if (__ballot(failed)) c.status |= VLR_LOCUS_TABLE_FULL;
@@ -1592,7 +1608,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
         atomicAdd(&w->work[0], (unsigned long long)tn);
         atomicAdd(&w->work[1], (unsigned long long)tn * dep_terms);
     }
-    __builtin_amdgcn_wave_barrier();
+    VLR_WAVE_FENCE();
 
     // ---- epilogue, row-parallel: MAP candidate of the chain and the integral over the visited points.
     // Trapezoid over the sorted grid (LogProb::ln_trapezoidal_integrate_grid_exp, utils/adaptive_integration.rs:133-140)
@@ -1698,7 +1714,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
         ChainTask& To = w->task[row];
         To.result = r; To.bestJ = bJ; To.bestX = bX; To.haveBest = bHave | (rowout ? 2 : 0); To.n = n;
     }
-    __builtin_amdgcn_wave_barrier();
+    VLR_WAVE_FENCE();
     __syncthreads();
     PROF_ADD(c, 8);  // batch epilogue (MAP scan + integrate)
 }
@@ -2881,12 +2897,25 @@ extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_host, const vlr::
     // spills (tools/occupancy_probe.py: +5 % at 9-10 workgroups, +15..33 % at 10-12, -4 % at 8)
     const size_t lds_wg = (static_lds + bytes + 511) & ~(size_t)511;
     int wpe = (163840 / lds_wg >= 9) ? 3 : 2;
-    if (const char* ev = getenv("VLR_WAVES_PER_SIMD")) wpe = atoi(ev) == 3 ? 3 : 2;  // tuning knob
-    const void* fn = wpe == 3 ? (const void*)vlr_call_kernel<3> : (const void*)vlr_call_kernel<2>;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return (int)e;
+    if (const char* ev = getenv("VLR_WAVES_PER_SIMD")) wpe = atoi(ev);  // tuning / build-matrix knob (tests/test_gpu_build_matrix.py)
     dim3 grid((unsigned)batch->n_loci), block(64);
-    if (wpe == 3) hipLaunchKernelGGL(vlr_call_kernel<3>, grid, block, bytes, (hipStream_t)stream, *plan_host, *batch, *out, max_obs, range_depth);
-    else hipLaunchKernelGGL(vlr_call_kernel<2>, grid, block, bytes, (hipStream_t)stream, *plan_host, *batch, *out, max_obs, range_depth);
+#define VLR_LAUNCH(W)                                                                                                        \
+    case W: {                                                                                                                \
+        hipError_t e = hipFuncSetAttribute((const void*)vlr_call_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
+        if (e != hipSuccess) return (int)e;                                                                                  \
+        hipLaunchKernelGGL(vlr_call_kernel<W>, grid, block, bytes, (hipStream_t)stream, *plan_host, *batch, *out, max_obs, range_depth); \
+        break;                                                                                                               \
+    }
+    switch (wpe) {
+        VLR_LAUNCH(4)
+        VLR_LAUNCH(3)
+#ifdef VLR_STRESS_BUDGETS  // register budgets far below anything shipped: 80 and 64 VGPRs, hundreds of spills
+        VLR_LAUNCH(6)
+        VLR_LAUNCH(8)
+#endif
+        default:
+        VLR_LAUNCH(2)
+    }
+#undef VLR_LAUNCH
     return (int)hipGetLastError();
 }

@@ -43,6 +43,18 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
+MATRIX_DIR = os.path.join(_HERE, "matrix")
+MATRIX_LIBS = ("stress", "O1", "sync")
+
+
+def build_matrix(force: bool = False) -> str:
+    """Compile the build-matrix variants of the engine (csrc/Makefile `matrix`; tests/test_gpu_build_matrix.py)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-C", src_dir, "-j", "3", "matrix"] + (["-B"] if force else [])
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return MATRIX_DIR
+
+
 def lib():
     global _LIB
     if _LIB is None:
