@@ -115,7 +115,45 @@ def compare(paths):
     return total
 
 
+def compare_tol(paths, tol=1e-9):
+    """Tolerance comparison (probability space) of dumps against the first one: for changes of the arithmetic order."""
+    base = np.load(paths[0])
+    worst = 0
+    for p in paths[1:]:
+        other = np.load(p)
+        nbad = 0
+        for k in base.files:
+            if k.endswith("/rejected") or k not in other.files or "/afd_" in k:
+                continue
+            a, b = base[k], other[k]
+            name = k.split("/")[1]
+            if name in ("ln_posterior",):
+                with np.errstate(invalid="ignore", over="ignore"):
+                    d = np.abs(np.exp(a) - np.exp(b))
+                d = np.where(np.isnan(a) & np.isnan(b), 0.0, d)
+                m = float(np.nan_to_num(d, nan=np.inf).max()) if d.size else 0.0
+                rows = np.nonzero(np.nan_to_num(d, nan=np.inf).reshape(len(a), -1).max(axis=1) > tol)[0]
+                if len(rows):
+                    nbad += 1
+                    print("    %s: max |dP| %.3g, rows %s" % (k, m, rows[:8].tolist()))
+            elif name in ("map_vaf",):
+                d = np.where(np.isnan(a) & np.isnan(b), 0.0, np.abs(a - b))
+                rows = np.nonzero(np.nan_to_num(d, nan=np.inf).reshape(len(a), -1).max(axis=1) > 0)[0]
+                if len(rows):
+                    nbad += 1
+                    print("    %s: %d rows with another MAP VAF %s" % (k, len(rows), rows[:8].tolist()))
+            elif name in ("map_bias", "best_event", "status"):
+                if not np.array_equal(a, b):
+                    nbad += 1
+                    print("    %s: %d elements differ" % (k, int((a != b).sum())))
+        print("%s vs %s (tol %g): %d arrays outside" % (os.path.basename(p), os.path.basename(paths[0]), tol, nbad))
+        worst += nbad
+    return worst
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "compare":
         sys.exit(1 if compare(sys.argv[2:]) else 0)
+    if sys.argv[1] == "compare-tol":
+        sys.exit(1 if compare_tol(sys.argv[2:]) else 0)
     main()

@@ -105,6 +105,9 @@ struct WaveSt {
     WalkSave wk;
     unsigned long long work[2];  // [0] pileup evaluations, [1] observation terms (lane 0 adds; profiling aid)
     int fastok;  // bit s: all terms of sample s stay >= 2^-200 under the current hypothesis (4-term renormalisation is safe)
+    int vfast;   // bit s: all terms of sample s stay >= 2^-70: 13 of them multiply without any renormalisation (register-resident runner)
+    int ehas;    // bit s: some kept observation of sample s has prob_sample_alt != 0, i.e. a non-zero third coefficient e
+                 // (phase A); otherwise e == 0 exactly for the whole pileup and the HBM scratch row is neither written nor read
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -390,12 +393,14 @@ __device__ inline double ddacc_exp(const DdAcc& a, double m) {
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    // every lane has a valid source under these permutations: bound_ctrl with an undefined `old` lets the compiler write the
+    // destination directly instead of copying the source first (three instructions per f64 permute otherwise)
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 template <int CTRL>
-__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
 
 // mantissa/exponent renormalisation of a POSITIVE NORMAL double with integer ops on the high word (the
 // fast path guarantees every partial product stays far above 2^-1022)
@@ -507,7 +512,7 @@ __device__ __forceinline__ void accum_terms(const double* __restrict__ coef, con
     bool nz = false;
 #pragma unroll
     for (int j = 0; j < NP; ++j) nz = nz || (be[j] != 0.0);
-    if (__ballot(nz)) accum_terms_e<NP, W, true>(coef, ecoef, D, k, fast, al, be, P, E);
+    if (ecoef != nullptr && __ballot(nz)) accum_terms_e<NP, W, true>(coef, ecoef, D, k, fast, al, be, P, E);
     else accum_terms_e<NP, W, false>(coef, ecoef, D, k, fast, al, be, P, E);
 }
 // product over the W lanes of the group; every lane ends with the result (mantissa in [0.5,1) or 0, exponent)
@@ -646,6 +651,7 @@ struct Ctx {
     int defer_ok, deferred, ndef, defer_slot;  // event-level deferral of simple chains into a row-parallel batch
     int need_batch, bt_nt, bt_inner;           // walk_root asks the event loop to run run_chain_batch (single inline site, few live registers)
     int afd_mute;  // replay: the current path repeats an outer VAF already visited by its chain (duplicate map key)
+    int ehas;      // bit s: sample s has non-zero third coefficients (constant per locus, see WaveSt::ehas)
     double marginal;
     int64_t locus;
     const DevResults* outp;
@@ -690,6 +696,11 @@ __device__ inline void alpha_beta(const DevPlan& p, int s, double a, double b, d
     }
 }
 
+// scratch row of the third coefficients of sample s, or nullptr when they are all zero (WaveSt::ehas)
+__device__ __forceinline__ const double* ecoef_of(const Ctx& c, int s, int off) {
+    return ((c.ehas >> s) & 1) ? c.ecoef + off : nullptr;
+}
+
 // cached single-point pileup likelihood of sample s (stands in for the per-sample LRU caches of
 // modes/generic.rs:38-53: the normal sample's likelihood is reused across all tumor VAFs)
 __device__ inline double sample_lik_point(Ctx& c, int s, double a, double b) {  // uncached single point on all 64 lanes
@@ -699,7 +710,7 @@ __device__ inline double sample_lik_point(Ctx& c, int s, double a, double b) {  
     const int off = UNI(w->soff[s]), D = UNI(w->nkeep[s]);
     double P1[1] = {1.0};
     int E1[1] = {0};
-    accum_terms<1, 64>(c.coef + 2 * off, c.ecoef + off, D, c.lane, (w->fastok >> s) & 1, &al, &be, P1, E1);
+    accum_terms<1, 64>(c.coef + 2 * off, ecoef_of(c, s, off), D, c.lane, (w->fastok >> s) & 1, &al, &be, P1, E1);
     reduce_terms<1, 64>(P1, E1);
     if (c.lane == 0) { w->work[0] += 1; w->work[1] += (unsigned long long)D; }
     return uni_d(log(P1[0]) + (double)E1[0] * kLn2);
@@ -1304,7 +1315,7 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
                 double b = by >= 0 ? ((by == inner) ? xr : w->ops_vaf[by]) : 0.0;
                 double al, be;
                 alpha_beta(p, s, a, b, al, be);
-                accum_terms<1, 16>(c.coef + 2 * UNI(w->soff[s]), c.ecoef + UNI(w->soff[s]), UNI(w->nkeep[s]), rlane, (w->fastok >> s) & 1, &al, &be, P1, E1);
+                accum_terms<1, 16>(c.coef + 2 * UNI(w->soff[s]), ecoef_of(c, s, UNI(w->soff[s])), UNI(w->nkeep[s]), rlane, (w->fastok >> s) & 1, &al, &be, P1, E1);
             }
             reduce_terms<1, 16>(P1, E1);
             const double lik = fixed + (log(P1[0]) + (double)E1[0] * kLn2);
@@ -1430,6 +1441,212 @@ __device__ __forceinline__ int row_or(int v) {
     return v;
 }
 
+// ln(m) for a mantissa m in [0.5, 1) (what reduce_terms leaves): the classic argument reduction to f in [sqrt(1/2) - 1,
+// sqrt(2) - 1], s = f / (2 + f), ln(1 + f) = f - (f^2/2 - s (f^2/2 + R(s^2))) with the degree-14 odd minimax polynomial of
+// fdlibm's e_log.c (< 1 ulp); no special cases (zero, negative, infinite, subnormal arguments cannot occur), about half the
+// instructions of the general log().  Returns ln(m) as hi part; the caller adds E * ln 2.
+__device__ __forceinline__ double ln_mantissa(double m) {
+    const bool small = m < 0.70710678118654752440;
+    const double mm = small ? m * 2.0 : m;       // [sqrt(1/2), sqrt(2))
+    const double kk = small ? -1.0 : 0.0;
+    const double f = mm - 1.0;
+    const double d = 2.0 + f;
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    double sq = f * r;
+    sq = __builtin_fma(__builtin_fma(-d, sq, f), r, sq);  // s = f / (2 + f), correctly rounded to within an ulp
+    const double z = sq * sq, w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    // k * ln2 split as in fdlibm (k in {-1, 0})
+    return __builtin_fma(kk, 6.93147180369123816490e-01, f - ((hfsq - __builtin_fma(sq, hfsq + R, kk * 1.90821492927058770002e-10))));
+}
+
+// value of row lane N on every lane of its 16-lane DPP row (row_newbcast: no LDS round trip)
+template <int N>
+__device__ __forceinline__ double row_bcast(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + N, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + N, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+// Products of three points over a lane's observation slice with the coefficient pairs held in REGISTERS (loaded once per
+// chain batch: only alpha changes between the rounds of a chain).  Slot j of row lane k is observation k + 16 j; empty slots
+// hold {c, q} = {1, 0}, so their term is exactly 1.  Same association as accum_terms_e's two-term groups (mantissas are
+// bit-identical); no renormalisation: every term is in [2^-70, 2] (WaveSt::vfast), 13 of them stay normal.
+constexpr int kRegSlots = 13;  // 16 * 13 = 208 observations of the integrated sample
+template <int NS, bool USE_E>
+__device__ __forceinline__ void reg_products(const double* cc, const double* cq, const double* ecoef, int rl, int D, const double* al, const double* be, double* P) {
+    double ce[NS];
+    if (USE_E) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int i = rl + 16 * j;
+            const double e = ld_e(ecoef + (i < D ? i : 0));
+            ce[j] = i < D ? e : 0.0;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) P[t] = 1.0;
+#pragma unroll
+    for (int j = 0; j < NS; j += 2) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            double L0 = __builtin_fma(cq[j], al[t], cc[j]);
+            if (USE_E) L0 = __builtin_fma(ce[j], be[t], L0);
+            if (j + 1 < NS) {
+                double L1 = __builtin_fma(cq[j + 1], al[t], cc[j + 1]);
+                if (USE_E) L1 = __builtin_fma(ce[j + 1], be[t], L1);
+                P[t] *= L0 * L1;
+            } else P[t] *= L0;
+        }
+    }
+}
+
+// ---- pass-based chain machine (utils/adaptive_integration.rs:54-131), one chain per 16-lane DPP row, for chains whose
+// integrated sample is the only one that moves with the chain.  A pass evaluates up to three points of every row:
+// INIT = {lo, hi}; ROUND = {mid, middle1, middle2}; TAIL = 7 points in three passes; Simpson fall-backs = grid points three at
+// a time.  The chain state is replicated in the registers of the row's lanes, every lane derives the points itself, joint
+// values travel by row broadcasts: the only LDS traffic of a pass is the append to the visited-point table.  The state
+// update is written with selects (rows are in different phases; divergent branches cost more than the few dead operations).
+struct RegChain {
+    double lo, hi, res, fixed, pr0, pr1, pr2, rho, al_fix, be_fix;
+    double *tx, *tv;
+    const double *ptab, *ecoef;
+    int pidx, istride, simpson_n, cap, inner, rl, off, D;
+    bool cls_fast, rowon, has_by;
+    int tn;
+    bool failed, sawnan;
+};
+template <int NS>
+__device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
+    const DevPlan& p = *c.plan;
+    const int rl = q.rl, D = q.D, simpson_n = q.simpson_n;
+    const double lo = q.lo, hi = q.hi, res = q.res;
+    double cc[NS], cq[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int i = rl + 16 * j;
+        const double* a = c.coef + 2 * (q.off + (i < D ? i : 0));
+        const double c0 = a[0], q0 = a[1];
+        cc[j] = i < D ? c0 : 1.0; cq[j] = i < D ? q0 : 0.0;
+    }
+    const double sstep = simpson_n ? (hi - lo) / (double)(simpson_n - 1) : 0.0;
+    double px0 = lo, px1 = simpson_n ? lin_pt(lo, sstep, 1.0) : hi, px2 = simpson_n == 3 ? hi : simpson_n ? lin_pt(lo, sstep, 2.0) : hi;
+    int npp = simpson_n ? 3 : 2, k = 0, tn = 0;
+    int phase = simpson_n ? RP_SIMPSON : RP_INIT;
+    bool done = !q.rowon, failed = false, sawnan = false, have_first = false;
+    double L = lo, R = hi, vL = VLR_NEG_INF, vR = VLR_NEG_INF, mid = lo, first_mid = lo;
+    PROF_ADD(c, 7);  // batch prologue (task fields, coefficient registers)
+    while (__ballot(!done)) {
+        PROF_ADD(c, 15);
+        const bool over = !done && (tn + npp > q.cap);
+        failed = failed || over;
+        done = done || over;
+        const bool go = !done;
+        double al[3], be[3], P[3];
+        int E[3];
+        {
+            const double xs[3] = {px0, px1, px2};
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                al[t] = q.has_by ? q.rho * xs[t] + q.al_fix : xs[t];
+                be[t] = 0.0;
+            }
+            if (q.ecoef != nullptr) {  // beta only matters where the third coefficients are not all zero
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const double ind = xs[t] == 1.0 ? 1.0 : 0.0;
+                    be[t] = q.has_by ? q.rho * ind + q.be_fix : ind;
+                }
+            }
+        }
+        if (q.ecoef != nullptr && __ballot(go && (be[0] != 0.0 || be[1] != 0.0 || be[2] != 0.0)) != 0ull)
+            reg_products<NS, true>(cc, cq, q.ecoef, rl, D, al, be, P);
+        else
+            reg_products<NS, false>(cc, cq, q.ecoef, rl, D, al, be, P);
+        PROF_ADD(c, 12);  // pass: term products
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { int e; P[t] = __builtin_frexp(P[t], &e); E[t] = e; }
+        reduce_terms<3, 16>(P, E);
+        PROF_ADD(c, 13);  // pass: reduction
+        const double Psel = rl == 1 ? P[1] : rl == 2 ? P[2] : P[0];
+        const int Esel = rl == 1 ? E[1] : rl == 2 ? E[2] : E[0];
+        const double x = rl == 0 ? px0 : rl == 1 ? px1 : px2;
+        const double lik = q.fixed + (ln_mantissa(Psel) + (double)Esel * kLn2);
+        double joint;
+        if (c.nlfc > 0 && !lfcs_ok(c, q.inner, x)) joint = VLR_NEG_INF;
+        else {
+            const int cls = q.cls_fast ? (x == 0.0 ? 0 : 1) : prior_class(p, q.inner, x);
+            const double pv = cls == 0 ? q.pr0 : cls == 1 ? q.pr1 : cls == 2 ? q.pr2 : q.ptab[q.pidx + cls * q.istride];
+            joint = pv + lik;
+        }
+        const bool owner = go && rl < npp;
+        sawnan = sawnan || (owner && joint != joint);
+        if (owner) { q.tx[tn + rl] = x; q.tv[tn + rl] = joint; }
+        PROF_ADD(c, 14);  // pass: log + prior + store
+        const double j0 = row_bcast<0>(joint), j1 = row_bcast<1>(joint), j2 = row_bcast<2>(joint);
+        // ---- state update, select form
+        const bool isI = phase == RP_INIT, isR = phase == RP_ROUND, isTS = phase == RP_TAIL || phase == RP_SIMPSON;
+        const bool srch = go && (isI || isR);
+        tn = go ? tn + npp : tn;
+        int kk = 0;  // argmax over {left, middle1, middle2, right}; lowest index wins ties
+        double vb = vL;
+        kk = j1 > vb ? 1 : kk; vb = j1 > vb ? j1 : vb;
+        kk = j2 > vb ? 2 : kk; vb = j2 > vb ? j2 : vb;
+        kk = vR > vb ? 3 : kk;
+        const double nL = isI ? lo : kk == 2 ? px1 : kk == 3 ? px2 : L;
+        const double nvL = isI ? j0 : kk == 2 ? j1 : kk == 3 ? j2 : vL;
+        const double nR = isI ? hi : kk == 0 ? px1 : kk == 1 ? px2 : R;
+        const double nvR = isI ? j1 : kk == 0 ? j1 : kk == 1 ? j2 : vR;
+        L = srch ? nL : L; vL = srch ? nvL : vL; R = srch ? nR : R; vR = srch ? nvR : vR;
+        const bool more = (((R - L) >= res) && L < R) || isI;  // the first round always happens (mid is None)
+        const bool toRound = srch && more, toTail = srch && !more;
+        const double nmid = (R + L) / 2.0;
+        first_mid = (toRound && !have_first) ? nmid : first_mid;
+        have_first = have_first || toRound;
+        mid = toRound ? nmid : mid;
+        px0 = toRound ? nmid : px0;
+        px1 = toRound ? (nmid + L) / 2.0 : px1;
+        px2 = toRound ? (R + nmid) / 2.0 : px2;
+        npp = toRound ? 3 : npp;
+        k = (go && isTS) ? k + 3 : toTail ? 0 : k;
+        phase = toRound ? RP_ROUND : toTail ? RP_TAIL : phase;
+        const bool nowTS = phase == RP_TAIL || phase == RP_SIMPSON;
+        done = done || (go && nowTS && k >= (phase == RP_TAIL ? 7 : simpson_n));
+        if (__ballot(!done && nowTS)) {  // next points of the rows in the tail / on a Simpson grid
+            // tail: abandoned arm (95-106) + small interval around the optimum (107-131)
+            const double arm = (mid < first_mid) ? (hi + first_mid) / 2.0 : (first_mid + lo) / 2.0;
+            const double lo3 = fmax(mid - res * 3.0, lo);
+            const double hi3 = fmin(mid + res * 3.0, hi);
+            const double sa = (mid - lo3) / 3.0, sb = (hi3 - mid) / 3.0;  // itertools_num::linspace step, n = 4
+            const double t0 = k == 0 ? arm : k == 3 ? lin_pt(lo3, sa, 2.0) : lin_pt(mid, sb, 3.0);
+            const double t1 = k == 0 ? lin_pt(lo3, sa, 0.0) : lin_pt(mid, sb, 1.0);
+            const double t2 = k == 0 ? lin_pt(lo3, sa, 1.0) : lin_pt(mid, sb, 2.0);
+            // Simpson grid (modes/generic.rs:367-385): points k, k+1, k+2 of linspace(lo, hi, n) with exact end points
+            const int left = simpson_n - k;
+            const double s0 = lin_pt(lo, sstep, (double)k);
+            const double s1 = (k + 1 == simpson_n - 1) ? hi : lin_pt(lo, sstep, (double)(k + 1));
+            const double s2 = (k + 2 == simpson_n - 1) ? hi : lin_pt(lo, sstep, (double)(k + 2));
+            const bool isT = phase == RP_TAIL;
+            const int nn = isT ? (k == 6 ? 1 : 3) : (left < 3 ? left : 3);
+            const double n0 = isT ? t0 : s0;
+            double n1 = isT ? t1 : s1, n2 = isT ? t2 : s2;
+            n2 = nn < 3 ? n1 : n2;
+            n1 = nn < 2 ? n0 : n1;
+            n2 = nn < 2 ? n0 : n2;
+            const bool upd = !done && nowTS;
+            px0 = upd ? n0 : px0; px1 = upd ? n1 : px1; px2 = upd ? n2 : px2; npp = upd ? nn : npp;
+        }
+    }
+    PROF_ADD(c, 15);  // pass: state update (+ loop control)
+    q.tn = tn; q.failed = failed; q.sawnan = sawnan;
+}
+
 __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
     nt = UNI(nt); inner = UNI(inner);
     PROF_ADD(c, 6);  // batch preparation (task setup, fixed-sample likelihoods)
@@ -1477,6 +1694,31 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
 
     int np, phase, tn = 0;
     bool done = !rowon;
+    double L = lo, R = hi, vL = VLR_NEG_INF, vR = VLR_NEG_INF, mid = lo, first_mid = lo;
+    bool have_first = false, have_mid = false, failed = false, sawnan = false;
+    const int D_in = UNI(w->nkeep[inner]);
+    // register-resident runner: the integrated sample is the only one whose likelihood moves with the chain (no sample is
+    // contaminated by it), its pileup fits the register slots and its terms need no renormalisation
+    const bool regrun = dep == (1 << inner) && D_in <= 16 * kRegSlots && ((UNI(w->vfast) >> inner) & 1);
+    if (regrun) {
+        RegChain rc;
+        rc.lo = lo; rc.hi = hi; rc.res = res; rc.fixed = fixed; rc.pr0 = pr0; rc.pr1 = pr1; rc.pr2 = pr2;
+        rc.tx = tx; rc.tv = tv; rc.ptab = ptab; rc.pidx = pidx; rc.istride = istride; rc.simpson_n = simpson_n;
+        rc.cap = cap; rc.cls_fast = cls_fast; rc.rowon = rowon; rc.inner = inner; rc.rl = rl;
+        rc.off = UNI(w->soff[inner]); rc.D = D_in;
+        const int byi = p.by[inner];
+        rc.has_by = byi >= 0;
+        rc.rho = p.rho[inner];
+        const double bvaf = byi >= 0 ? tvr[byi] : 0.0;  // contaminant VAF: fixed along the chain
+        rc.al_fix = p.irho[inner] * bvaf; rc.be_fix = p.irho[inner] * (bvaf == 1.0 ? 1.0 : 0.0);
+        rc.ecoef = ecoef_of(c, inner, rc.off);
+        if (D_in <= 64) reg_chain_loop<4>(c, rc);
+        else if (D_in <= 128) reg_chain_loop<8>(c, rc);
+        else reg_chain_loop<kRegSlots>(c, rc);
+        tn = rc.tn; failed = rc.failed; sawnan = rc.sawnan;
+        phase = simpson_n ? RP_SIMPSON : RP_TAIL;
+        np = 0;
+    } else {
     if (simpson_n) {
         double step = (hi - lo) / (double)(simpson_n - 1);
         if (rl < simpson_n) pend[rl] = (rl == 0) ? lo : (rl == simpson_n - 1) ? hi : lin_pt(lo, step, (double)rl);
@@ -1487,8 +1729,6 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
         np = 2;
         phase = RP_INIT;
     }
-    double L = lo, R = hi, vL = VLR_NEG_INF, vR = VLR_NEG_INF, mid = lo, first_mid = lo;
-    bool have_first = false, have_mid = false, failed = false, sawnan = false;
     VLR_WAVE_FENCE();
 
     while (__ballot(!done)) {
@@ -1528,7 +1768,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
                     const double b = by >= 0 ? ((by == inner) ? xs[j] : vb) : 0.0;
                     alpha_beta(p, s, a, b, al[j], be[j]);
                 }
-                accum_terms_n<16>(cnt, c.coef + 2 * UNI(w->soff[s]), c.ecoef + UNI(w->soff[s]), UNI(w->nkeep[s]), rl, (UNI(w->fastok) >> s) & 1, al, be, P, E);
+                accum_terms_n<16>(cnt, c.coef + 2 * UNI(w->soff[s]), ecoef_of(c, s, UNI(w->soff[s])), UNI(w->nkeep[s]), rl, (UNI(w->fastok) >> s) & 1, al, be, P, E);
             }
             PROF_ADD(c, 12);  // round: term products
             reduce_terms_n<16>(cnt, P, E);
@@ -1601,6 +1841,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
         }
         VLR_WAVE_FENCE();
     }
+    }  // !regrun
     PROF_ADD(c, 15);
     if (__ballot(failed)) c.status |= VLR_LOCUS_TABLE_FULL;
     if (__ballot(sawnan)) c.status |= VLR_LOCUS_NAN;
@@ -1614,9 +1855,10 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
     // Trapezoid over the sorted grid (LogProb::ln_trapezoidal_integrate_grid_exp, utils/adaptive_integration.rs:133-140)
     // in the linear domain relative to the row maximum M, regrouped per grid point:
     //   sum_seg (e_k + e_{k+1}) (x_{k+1} - x_k)/2  =  sum_k e_k (x_{k+1} - x_{k-1})/2   (one-sided at the ends),
-    // so every entry only needs the x of its predecessor and successor in (x, index) order — no sort, no gather.
-    // Duplicate x (HashMap key collisions in the reference) are neighbours at distance zero.  All predicates are
-    // evaluated branch-free (bitwise), the table scan is uniform.
+    // so every entry only needs the x of its predecessor and successor in (x, index) order: every lane ranks its (up to
+    // four) entries against the row's table — one 64-bit compare and one add-with-carry per pair —, the table is rewritten
+    // in rank order in place and the neighbours are read back.  Duplicate x (HashMap key collisions in the reference) are
+    // neighbours at distance zero.
     const int n = (rowon && !failed) ? tn : 0;
     const int nmax = max(max(__builtin_amdgcn_readlane(n, 0), __builtin_amdgcn_readlane(n, 16)),
                          max(__builtin_amdgcn_readlane(n, 32), __builtin_amdgcn_readlane(n, 48)));
@@ -1626,13 +1868,14 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
     bool anynan = false, anyout = false;  // anyout: a visited point lies outside the leaf's own range (excluded range end)
     double rint_ = VLR_NEG_INF;
     {
-        double xi[4], vi[4], px[4], sx[4];
-        int dlo[4], dhi[4];
+        double xi[4], vi[4];
+        unsigned long long key[4];
+        int rank[4];
+        const bool srt = phase != RP_SIMPSON;  // per row: trapezoid over the sorted visited points (Simpson grids are in order)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             xi[t] = __builtin_huge_val(); vi[t] = VLR_NEG_INF;
-            px[t] = -__builtin_huge_val(); sx[t] = __builtin_huge_val();
-            dlo[t] = 0; dhi[t] = 0;
+            key[t] = ~0ull; rank[t] = 0;
             if (t < TT) {
                 const int i = rl + 16 * t;
                 const bool on = i < n;
@@ -1640,6 +1883,10 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
                 const double xr = tx[ic], vr = tv[ic];
                 xi[t] = on ? xr : __builtin_huge_val();
                 vi[t] = on ? vr : VLR_NEG_INF;
+                // sort key: the bit pattern of a non-negative double orders like the number; the low six bits carry the
+                // table index so that revisited points (equal x: HashMap key collisions in the reference) get distinct,
+                // adjacent ranks.  (Distinct points closer than 64 ulp may swap: a segment of width ~1e-16 changes sign.)
+                key[t] = on ? ((((unsigned long long)__double_as_longlong(xr)) & ~63ull) | (unsigned long long)i) : ~0ull;
                 const bool inlo = (orig.start < xi[t]) | ((orig.lex == 0) & (orig.start == xi[t]));
                 const bool inhi = (orig.end > xi[t]) | ((orig.rex == 0) & (orig.end == xi[t]));
                 const bool cand = on & (contained != 0) & inlo & inhi & (vi[t] == vi[t]);
@@ -1649,24 +1896,32 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
                 anynan = anynan | (vi[t] != vi[t]);
             }
         }
-        if (phase != RP_SIMPSON) {
-            for (int q = 0; q < nmax; q += 2) {
-                const double r0 = tx[q], r1 = tx[q + 1 < cap ? q + 1 : q];
-                const double xq0 = (q < n) ? r0 : __builtin_nan("");
-                const double xq1 = (q + 1 < n) ? r1 : __builtin_nan("");
+        // rank of every entry among its row's entries: one compare + one add-with-carry per (entry, q)
+        if (__ballot(srt && n > 0)) {
+            for (int q0 = 0; q0 < nmax; q0 += 4) {  // four table reads in flight
+                unsigned long long kq[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (t < TT) {
-                        const int i = rl + 16 * t;
-                        const bool lt0 = xq0 < xi[t], gt0 = xq0 > xi[t], eq0 = xq0 == xi[t];
-                        const bool lt1 = xq1 < xi[t], gt1 = xq1 > xi[t], eq1 = xq1 == xi[t];
-                        px[t] = fmax(px[t], fmax(lt0 ? xq0 : -__builtin_huge_val(), lt1 ? xq1 : -__builtin_huge_val()));
-                        sx[t] = fmin(sx[t], fmin(gt0 ? xq0 : __builtin_huge_val(), gt1 ? xq1 : __builtin_huge_val()));
-                        dlo[t] |= (int)(eq0 & (q < i)) | (int)(eq1 & (q + 1 < i));
-                        dhi[t] |= (int)(eq0 & (q > i)) | (int)(eq1 & (q + 1 > i));
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    const int q = q0 + j;
+                    const double r0 = tx[q < cap ? q : 0];
+                    kq[j] = (q < n) ? ((((unsigned long long)__double_as_longlong(r0)) & ~63ull) | (unsigned long long)q) : ~0ull;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (t < TT) rank[t] += (kq[j] < key[t]) ? 1 : 0;
+            }
+            VLR_WAVE_FENCE();
+            // scatter into sorted order, in place (every entry is in registers by now)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < TT) {
+                    const int i = rl + 16 * t;
+                    if (srt && i < n) { tx[rank[t]] = xi[t]; tv[rank[t]] = vi[t]; }
                 }
             }
+            VLR_WAVE_FENCE();
         }
         // ---- row arg-best of (bJ desc, bX asc) for the MAP candidate
         for (int st = 0; st < 4; ++st) {
@@ -1692,11 +1947,13 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
                 const bool zero = (vi[t] == VLR_NEG_INF) | (M == VLR_NEG_INF) | (vi[t] != vi[t]);
                 const double ev = zero ? 0.0 : exp(vi[t] - M);
                 double wgt;
-                if (phase == RP_SIMPSON) wgt = (i == 0 || i == n - 1) ? 1.0 : (double)(2 + (i % 2) * 2);
+                if (!srt) wgt = (i == 0 || i == n - 1) ? 1.0 : (double)(2 + (i % 2) * 2);
                 else {
-                    const double pred = dlo[t] ? xi[t] : px[t], succ = dhi[t] ? xi[t] : sx[t];
-                    const double lo2 = (pred == -__builtin_huge_val()) ? xi[t] : pred;
-                    const double hi2 = (succ == __builtin_huge_val()) ? xi[t] : succ;
+                    // sum_seg (e_k + e_{k+1}) (x_{k+1} - x_k)/2 = sum_k e_k (x_{k+1} - x_{k-1})/2, one-sided at the ends
+                    const int rk = on ? rank[t] : 0;
+                    const double pred = tx[rk > 0 ? rk - 1 : 0], succ = tx[(rk + 1 < n) ? rk + 1 : rk];
+                    const double lo2 = (rk > 0) ? pred : xi[t];
+                    const double hi2 = (rk + 1 < n) ? succ : xi[t];
                     wgt = (hi2 - lo2) / 2.0;
                 }
                 ssum += on ? ev * wgt : 0.0;
@@ -1869,7 +2126,7 @@ __device__ __forceinline__ bool bo_setup(Ctx& c, const Frame& f, RangeSt& r) {
         }
         __syncthreads();
         int off = UNI(w->soff[s]), D = UNI(w->nkeep[s]);
-        eval_pileup(c.coef + 2 * off, c.ecoef + off, D, (w->fastok >> s) & 1, nt, w->bpend[1], w->bpend[2], w->bpend[3], lane);
+        eval_pileup(c.coef + 2 * off, ecoef_of(c, s, off), D, (w->fastok >> s) & 1, nt, w->bpend[1], w->bpend[2], w->bpend[3], lane);
         __syncthreads();
         if (lane < nt) w->task[lane].fixed += w->bpend[3][lane];
         if (lane == 0) { w->work[0] += (unsigned long long)nt; w->work[1] += (unsigned long long)nt * (unsigned long long)D; }
@@ -1922,41 +2179,13 @@ __device__ __forceinline__ bool bo_deliver(Ctx& c, const Frame& f, RangeSt& r, d
 
 // Event-level deferral: an event root whose path is a chain of single-valued Sample nodes ending in a leaf Range
 // (tumor-normal: somatic_tumor, germline_het, germline_hom) contributes exactly one innermost chain.  Such chains of
-// different events are collected and run together, one per DPP row (run_chain_batch); flush_deferred delivers the
+// different events are collected and run together, one per DPP row (run_chain_batch); flush_deliver hands the
 // integrals to the event accumulators and the MAP candidates to the event slots.
-__device__ __forceinline__ void flush_deferred(Ctx& c, double* evM, double* evS, double bias_prior) {
+__device__ __forceinline__ void flush_deliver(Ctx& c, double* evM, double* evS, double bias_prior) {
+    // (the chains were run by the event loop's single run_chain_batch site; a lone deferred chain takes the same path)
     WaveSt* w = c.w;
     const int nt = c.ndef;
-    if (nt == 0) return;
     const int s_in = UNI(w->task[0].inner);
-    __syncthreads();
-    if (nt == 1) {
-        // a lone chain is cheaper on all 64 lanes (7 terms per lane instead of 25): rebuild its frame context
-        const ChainTask& T = w->task[0];
-        const int u = UNI(T.u);
-        RangeSt& r = c.rs[c.nrs - 1];
-        if (c.lane == 0) {
-            r.lo = T.lo; r.hi = T.hi; r.res = T.res; r.ostart = T.ostart; r.oend = T.oend; r.olex = T.olex; r.orex = T.orex;
-            r.simpson_n = T.simpson_n; r.sample = s_in; r.leaf = 1; r.tn = 0;
-        }
-        if (c.lane < c.S) { w->ops_vaf[c.lane] = c.tvaf[c.lane]; w->curMapVaf[c.lane] = c.mapVaf[u * c.S + c.lane]; }
-        __syncthreads();
-        c.group = UNI(T.group); c.disc = UNI(T.disc); c.contained = UNI(T.contained); c.alive = UNI(T.alive); c.nlfc = 0;
-        c.present = (1 << c.S) - 1; c.afd_mute = 0;
-        c.curJ = uni_d(c.mapJ[u]); c.curHyp = UNI(c.mapHyp[u]);
-        const double dens = run_leaf_chain(c, r, c.rowX, c.rowV);
-        if (dens != dens) c.status |= VLR_LOCUS_NAN;
-        double M = uni_d(evM[u]), Sx = uni_d(evS[u]);
-        lse_add(M, Sx, bias_prior + dens);
-        __syncthreads();
-        if (c.lane == 0) { evM[u] = M; evS[u] = Sx; c.mapJ[u] = c.curJ; c.mapHyp[u] = c.curHyp; }
-        if (c.lane < c.S) c.mapVaf[u * c.S + c.lane] = w->curMapVaf[c.lane];
-        __syncthreads();
-        c.ndef = 0;
-        return;
-    }
-    c.nlfc = 0;  // deferred chains carry no l2fc terms; a later probe walk may have left some in the context
-    run_chain_batch(c, nt, s_in);
     __syncthreads();
     for (int i = 0; i < nt; ++i) {
         const ChainTask& T = w->task[i];
@@ -2395,6 +2624,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
     int offset_acc = 0;
     bool too_deep = false;
     double mx_sb_all = VLR_NEG_INF, mx_sb_fwd = VLR_NEG_INF;
+    int ehas_mask = 0;
     for (int s = 0; s < S; ++s) {
         const int64_t pidx = locus * S + s;
         const uint32_t o0 = batch.obs_offset[pidx], o1 = batch.obs_offset[pidx + 1];
@@ -2414,6 +2644,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
             }
             bool keep = valid && !(remove_nonstd && f_orient(f) == VLR_ORIENT_OTHER);  // pileup.rs:26-43
             filtered += popc64(__ballot(valid && !keep));
+            if (__ballot(keep && batch.psa[i] != 0.0f)) ehas_mask |= 1 << s;  // s = e^psa != 1: third coefficient e != 0
             double bf_ref = exp(pr - pa), bf_alt = exp(pa - pr);
             bool strong_ref = keep && bf_ref > 20.0;       // read_observation.rs:434-437 (KassRaftery >= Strong)
             bool strong_alt = keep && bf_alt > 20.0;       // 429-432
@@ -2507,6 +2738,8 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
         if (lane == 0) { w->pos_all[s] = e_all; w->pos_major[s] = e_major; w->pos_rate[s] = e_rate; }
     }
     if (offset_acc > max_obs) too_deep = true;
+    if (lane == 0) w->ehas = ehas_mask;
+    c.ehas = ehas_mask;
     __syncthreads();
     if (filtered > 0) c.status |= VLR_LOCUS_FILTERED_ALN;
     if (total_kept == 0) c.status |= VLR_LOCUS_MISSING_DATA;
@@ -2624,16 +2857,17 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
         //   w = e^pm, u = (1-w) * e^(missed + b_any), A = e^(pa + b_alt), R = e^(pr + b_ref), s = e^prob_sample_alt
         //   c = w*R + u, q = w*s*(A-R), e = w*(1-s)*(A-R)
         // (likelihood.rs:43-53,86-115,171-220; bias factors bias/mod.rs:259-284)
-        int fastmask = 0;
+        int fastmask = 0, vfastmask = 0;
         for (int s = 0; s < S; ++s) {
             const int64_t pidx = locus * S + s;
             const uint32_t o0 = batch.obs_offset[pidx], o1 = batch.obs_offset[pidx + 1];
             int wr = w->soff[s];
-            int fast_s = 1;
+            int fast_s = 1, vfast_s = 1;
+            const bool ehas_s = (ehas_mask >> s) & 1;
             for (uint32_t base = o0; base < o1; base += 64) {
                 uint32_t i = base + lane;
                 bool valid = i < o1;
-                bool tiny = false;
+                bool tiny = false, small = false;
                 uint32_t f = valid ? batch.flags[i] : 0u;
                 bool keep = valid && !(remove_nonstd && f_orient(f) == VLR_ORIENT_OTHER);
                 unsigned long long km = __ballot(keep);
@@ -2699,18 +2933,21 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                     if (pos < max_obs) {
                         c.coef[2 * pos + 0] = cc_;
                         c.coef[2 * pos + 1] = cq_;
-                        __hip_atomic_store(out.escratch + (size_t)blockIdx.x * (size_t)max_obs + pos, ce_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (ehas_s) __hip_atomic_store(out.escratch + (size_t)blockIdx.x * (size_t)max_obs + pos, ce_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                     // smallest value the term can take over alpha in [0,1], beta in [0,1] (linear => at a corner)
                     double mn = fmin(fmin(cc_, cc_ + cq_), fmin(cc_ + ce_, cc_ + cq_ + ce_));
                     tiny = !(mn >= 0x1p-200);  // also catches NaN
+                    small = !(mn >= 0x1p-70 && fmax(fmax(cc_, cc_ + cq_), fmax(cc_ + ce_, cc_ + cq_ + ce_)) <= 2.0);
                 }
                 if (__ballot(tiny)) fast_s = 0;
+                if (__ballot(small)) vfast_s = 0;
                 wr += popc64(km);
             }
             if (fast_s) fastmask |= 1 << s;
+            if (vfast_s) vfastmask |= 1 << s;
         }
-        if (lane == 0) w->fastok = fastmask;
+        if (lane == 0) { w->fastok = fastmask; w->vfast = vfastmask; }
         if (lane < S) w->cacheN[lane] = 0;
         __syncthreads();  // also orders the e coefficients (HBM scratch row, written by other lanes than the ones that read them)
         if (__ballot((c.status & VLR_LOCUS_UNDERFLOW) != 0)) c.status |= VLR_LOCUS_UNDERFLOW;
@@ -2731,52 +2968,103 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
         c.ndef = 0;
         c.deferred = 0;
         unsigned long long todo = 0ull;  // roots left for pass 1 (bit = running root counter, first 64 roots)
-        for (int pass = 0; pass < 2; ++pass) {
-            int rc_ = 0;
-            for (int e = first_ev; e < p.n_named; ++e) {
-                int u = (e < 0) ? 0 : (1 + 2 * e + (h == 0 ? 0 : 1));
-                int r0 = (e < 0) ? 0 : ldc(p.root_off + e), r1 = (e < 0) ? 1 : ldc(p.root_off + e + 1);
-                for (int ri = r0; ri < r1; ++ri, ++rc_) {
-                    const bool probe = (pass == 0) && rc_ < 64;
-                    if (pass == 0 && !probe) continue;
-                    if (pass == 1 && rc_ < 64 && !((todo >> rc_) & 1ull)) continue;
-                    if (c.ndef == kRows) flush_deferred(c, evM, evS, bias_prior);
+        // The two passes over (event, root) are an explicit iterator so that the chain batches — asked for by a resumable
+        // walk (outer Range over a leaf Range) or by a full / final set of deferred event-level chains — all run at ONE
+        // inlined run_chain_batch site (three copies of that loop cost code size, registers and instruction-cache hits).
+        {
+            enum { IT_NEXT, IT_ROOT, IT_WALK, IT_DONE };
+            int pass = 0, e = first_ev, rc_ = 0, st = IT_NEXT;
+            int ri = (e < 0) ? 0 : ldc(p.root_off + e);
+            int r1 = (e < 0) ? 1 : ldc(p.root_off + e + 1);
+            int u = 0, root = 0, resume = 0;
+            bool fresh = true;  // (e, ri) not yet considered
+            for (;;) {
+                int run_nt = 0, run_inner = 0, run_kind = 0;  // 1: batch of the walk, 2: deferred chains, then same root, 3: deferred chains at the end of pass 0
+                if (st == IT_NEXT) {
+                    // advance to the next root this pass has to look at
+                    bool found = false;
+                    for (;;) {
+                        if (!fresh) { ++ri; ++rc_; }
+                        fresh = false;
+                        while (ri >= r1) {
+                            ++e;
+                            if (e >= p.n_named) break;
+                            ri = ldc(p.root_off + e);
+                            r1 = ldc(p.root_off + e + 1);
+                        }
+                        if (e >= p.n_named) break;
+                        const bool probe = (pass == 0) && rc_ < 64;
+                        if (pass == 0 && !probe) continue;
+                        if (pass == 1 && rc_ < 64 && !((todo >> rc_) & 1ull)) continue;
+                        found = true;
+                        break;
+                    }
+                    if (!found) {
+                        if (pass == 0) {  // end of the probe pass: run what was deferred, then the general pass
+                            pass = 1; e = first_ev; rc_ = 0; fresh = true;
+                            ri = (e < 0) ? 0 : ldc(p.root_off + e);
+                            r1 = (e < 0) ? 1 : ldc(p.root_off + e + 1);
+                            if (c.ndef > 0) { run_kind = 3; run_nt = c.ndef; run_inner = UNI(w->task[0].inner); }
+                        } else st = IT_DONE;
+                    } else if (c.ndef == kRows) { run_kind = 2; run_nt = c.ndef; run_inner = UNI(w->task[0].inner); }
+                    else st = IT_ROOT;
+                }
+                if (st == IT_DONE) break;
+                if (st == IT_ROOT) {
+                    u = (e < 0) ? 0 : (1 + 2 * e + (h == 0 ? 0 : 1));
                     c.group = e + 1;
-                    c.defer_ok = probe ? 1 : 0;
+                    c.defer_ok = ((pass == 0) && rc_ < 64) ? 1 : 0;
                     c.defer_slot = u;
                     __syncthreads();
                     c.curJ = uni_d(mapJ[u]);
                     c.curHyp = UNI(mapHyp[u]);
                     if (lane < S) w->curMapVaf[lane] = mapVaf[u * S + lane];
                     __syncthreads();
-                    int root = (e < 0) ? p.absent_root : ldc(p.roots + ri);
-                    double dens;
+                    root = (e < 0) ? p.absent_root : ldc(p.roots + ri);
                     const int di = (e < 0) ? 0 : 1 + ri;
                     const int dl0 = (c.replay || p.n_dkey == 0) ? -1 : ldc(p.droot + 2 * di);
                     if (dl0 >= 0) {  // all-discrete root: its leaves side by side on the lanes
-                        dens = eval_discrete_root(c, dl0, ldc(p.droot + 2 * di + 1));
+                        const double dens = eval_discrete_root(c, dl0, ldc(p.droot + 2 * di + 1));
                         PROF_ADD(c, 23);
-                    } else {
-                        for (int resume = 0;; resume = 1) {
-                            dens = uni_d(walk_root(c, root, resume));
-                            if (!c.need_batch) break;
-                            c.need_batch = 0;
-                            run_chain_batch(c, c.bt_nt, c.bt_inner);
+                        if (dens != dens) c.status |= VLR_LOCUS_NAN;
+                        double M = uni_d(evM[u]), Sx = uni_d(evS[u]);
+                        lse_add(M, Sx, bias_prior + dens);
+                        __syncthreads();
+                        if (lane == 0) { evM[u] = M; evS[u] = Sx; mapJ[u] = c.curJ; mapHyp[u] = c.curHyp; }
+                        if (lane < S) mapVaf[u * S + lane] = w->curMapVaf[lane];
+                        __syncthreads();
+                        st = IT_NEXT;
+                    } else { resume = 0; st = IT_WALK; }
+                }
+                if (st == IT_WALK) {
+                    const double dens = uni_d(walk_root(c, root, resume));
+                    if (c.need_batch) { c.need_batch = 0; run_kind = 1; run_nt = c.bt_nt; run_inner = c.bt_inner; }
+                    else {
+                        if (c.deferred == 1) c.deferred = 0;                                 // delivered by flush_deliver
+                        else if (c.deferred == 2) { c.deferred = 0; todo |= 1ull << rc_; }  // second pass
+                        else {
+                            if (dens != dens) c.status |= VLR_LOCUS_NAN;
+                            double M = uni_d(evM[u]), Sx = uni_d(evS[u]);
+                            lse_add(M, Sx, bias_prior + dens);
+                            __syncthreads();
+                            if (lane == 0) { evM[u] = M; evS[u] = Sx; mapJ[u] = c.curJ; mapHyp[u] = c.curHyp; }
+                            if (lane < S) mapVaf[u * S + lane] = w->curMapVaf[lane];
                             __syncthreads();
                         }
-                        if (c.deferred == 1) { c.deferred = 0; continue; }                      // delivered by flush_deferred
-                        if (c.deferred == 2) { c.deferred = 0; todo |= 1ull << rc_; continue; } // second pass
+                        st = IT_NEXT;
                     }
-                    if (dens != dens) c.status |= VLR_LOCUS_NAN;
-                    double M = uni_d(evM[u]), Sx = uni_d(evS[u]);
-                    lse_add(M, Sx, bias_prior + dens);
+                }
+                if (run_kind) {
+                    if (run_kind != 1) c.nlfc = 0;  // deferred chains carry no l2fc terms; a later probe walk may have left some in the context
+                    run_chain_batch(c, run_nt, run_inner);
                     __syncthreads();
-                    if (lane == 0) { evM[u] = M; evS[u] = Sx; mapJ[u] = c.curJ; mapHyp[u] = c.curHyp; }
-                    if (lane < S) mapVaf[u * S + lane] = w->curMapVaf[lane];
-                    __syncthreads();
+                    if (run_kind == 1) { resume = 1; st = IT_WALK; }
+                    else {
+                        flush_deliver(c, evM, evS, bias_prior);
+                        st = (run_kind == 2) ? IT_ROOT : IT_NEXT;
+                    }
                 }
             }
-            if (pass == 0) flush_deferred(c, evM, evS, bias_prior);  // rows are free again for the nested events
         }
         PROF_ADD(c, 3);
     }
