@@ -258,6 +258,9 @@ typedef struct vlr_plan vlr_plan;
 
 /* ABI version of the loaded library. */
 int  vlr_abi_version(void);
+/* Identity of the build: "<sha1 of the engine sources and the Makefile>" (measurement files under profiles/ carry the id of
+ * the build they were taken from; the build-matrix test refuses variants built from other sources). */
+const char* vlr_build_id(void);
 /* Thread-local message of the last error. */
 const char* vlr_last_error(void);
 

@@ -58,3 +58,18 @@ def test_disable_machine_cse_reproducer_shows_the_compiler_defect(tmp_path):
         r = subprocess.run([clang, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", str(tmp_path / "nocse.s"), "-o", str(tmp_path / "nocse.o")],
                            capture_output=True, text=True)
         assert r.returncode != 0 and "invalid operand" in r.stderr
+
+
+def test_built_libraries_carry_the_id_of_the_current_sources():
+    """libvlr.so and the build-matrix variants must come from the sources in the tree (vlr_build_id): a stale variant would
+    make tests/test_gpu_build_matrix.py compare two different kernels."""
+    import ctypes
+    from varlociraptor_amd import engine
+    engine.build()
+    engine.build_matrix()
+    want = engine.source_id()
+    paths = [engine.LIB_PATH] + [os.path.join(engine.MATRIX_DIR, "libvlr_%s.so" % n) for n in engine.MATRIX_LIBS]
+    for path in paths:
+        L = ctypes.CDLL(path)
+        L.vlr_build_id.restype = ctypes.c_char_p
+        assert L.vlr_build_id().decode() == want, path

@@ -83,6 +83,7 @@ def main():
             mask = np.arange(afd)[None, None, :] < cnt[:, :, None]
             res[name + "/afd_vaf"] = np.where(mask, np.asarray(got.afd_vaf), 0.0)
             res[name + "/afd_lnprob"] = np.where(mask, np.asarray(got.afd_lnprob), 0.0)
+    res["build_id"] = np.array([engine.build_id()])
     np.savez(outp, **res)
     print("matrix_run: %d arrays -> %s (lib %s, waves/SIMD %s)" % (len(res), outp, os.environ.get("VLR_LIB", "default"), os.environ.get("VLR_WAVES_PER_SIMD", "auto")))
 
@@ -94,6 +95,11 @@ def compare(paths):
     for p in paths[1:]:
         other = np.load(p)
         bad = []
+        if "build_id" in base.files and str(base["build_id"][0]) != str(other["build_id"][0]):
+            print("%s was built from other sources (%s) than %s (%s): rebuild with varlociraptor_amd.engine.build_matrix()" %
+                  (os.path.basename(p), other["build_id"][0], os.path.basename(paths[0]), base["build_id"][0]))
+            total += 1
+            continue
         for k in base.files:
             if k not in other.files:
                 bad.append((k, "missing"))
@@ -123,6 +129,8 @@ def compare_tol(paths, tol=1e-9):
         other = np.load(p)
         nbad = 0
         for k in base.files:
+            if k == "build_id":
+                continue
             if k.endswith("/rejected") or k not in other.files or "/afd_" in k:
                 continue
             a, b = base[k], other[k]

@@ -388,6 +388,10 @@ int check_device(int device) {
 extern "C" {
 
 int vlr_abi_version(void) { return VLR_ABI_VERSION; }
+#ifndef VLR_SRC_ID
+#define VLR_SRC_ID "unknown"
+#endif
+const char* vlr_build_id(void) { return VLR_SRC_ID; }
 const char* vlr_last_error(void) { return g_err.c_str(); }
 
 int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {

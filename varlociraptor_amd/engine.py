@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("VLR_LIB", os.path.join(_HERE, "libvlr.so"))  # VLR_LI
 _LIB = None
 
 EXPORTS = [
-    "vlr_abi_version", "vlr_last_error", "vlr_plan_create", "vlr_plan_destroy", "vlr_plan_n_out",
+    "vlr_abi_version", "vlr_build_id", "vlr_last_error", "vlr_plan_create", "vlr_plan_destroy", "vlr_plan_n_out",
     "vlr_plan_n_samples", "vlr_plan_set_max_depth", "vlr_plan_set_max_obs", "vlr_batch_run", "vlr_batch_run_host",
     "vlr_plan_last_kernel_ms", "vlr_plan_work_counters", "vlr_host_alloc", "vlr_host_free",
 ]
@@ -41,6 +41,21 @@ def build(force: bool = False) -> str:
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", src_dir, "-B"], stdout=subprocess.DEVNULL)
     return LIB_PATH
+
+
+def build_id() -> str:
+    """Source identity of the loaded library (vlr_build_id)."""
+    return lib().vlr_build_id().decode()
+
+
+def source_id() -> str:
+    """The id a build of the current sources would carry (same recipe as csrc/Makefile)."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("csrc/vlr_kernels.hip", "csrc/vlr_host.cpp", "csrc/vlr_plan.h", "../include/vlr.h", "../include/vlr_detmath.h"):
+        with open(os.path.join(_HERE, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 MATRIX_DIR = os.path.join(_HERE, "matrix")
@@ -72,6 +87,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.vlr_abi_version.restype = C.c_int
         L.vlr_last_error.restype = C.c_char_p
+        L.vlr_build_id.restype = C.c_char_p
         L.vlr_plan_create.restype = C.c_int
         L.vlr_plan_create.argtypes = [C.POINTER(abi.ScenarioDesc), C.c_int, C.POINTER(C.c_void_p)]
         L.vlr_plan_destroy.restype = None
