@@ -308,6 +308,38 @@ int  vlr_plan_last_kernel_ms(vlr_plan* plan, float* ms);
  * plan since creation (or the last reset); synchronises the device.                                     */
 int  vlr_plan_work_counters(vlr_plan* plan, unsigned long long* out2, int reset);
 
+/* ------------------------------------------------------------------------------------------------
+ * Read-vs-allele pair HMM: ln P(read window | allele) for a batch of pairs.
+ * Replaces, batched, PairHMMRealigner::calculate_prob_allele -> bio PairHMM::prob_related
+ * (/root/reference/src/variants/evidence/realignment/mod.rs:519-537) with the emission model of
+ * realignment/pairhmm.rs:296-455 (match: 1 - P(miscall), mismatch: P(miscall) * 0.3333, insertion: P(miscall),
+ * P(miscall) = 10^(-qual/10)), semiglobal in the allele (free start and end gaps, pairhmm.rs:186-205).
+ * The caller (Realigner::allele_support, mod.rs:161-424) keeps the edit-distance pre-filter, builds the allele
+ * windows (shrink_to_hit, pairhmm.rs:66-72) and normalises ref against alt.
+ *
+ * Pair p: allele bases x_bases[x_offset[p] .. x_offset[p+1]) (ASCII, case-insensitive), read window
+ * y_bases / y_quals [y_offset[p] .. y_offset[p+1]) (ASCII bases, PHRED qualities without offset), at most 128 read bases
+ * (EditDistanceCalculation::max_pattern_len, edit_distance.rs:145-147).  max_edit_dist[p] >= 0 restricts the matrix
+ * to cells reachable with at most that many edits (band = hit distance + 4, pairhmm.rs:20); < 0 or a NULL array:
+ * full matrix.  gap[] = ln { P(gap in x) = prob_insertion_artifact, P(gap in y) = prob_deletion_artifact,
+ * P(extend gap in x), P(extend gap in y) } (pairhmm.rs:119-180; -inf = no extension, the default).
+ * ln_prob[p] <- result, -inf for an empty sequence, NaN for a read window above 128 bases.            */
+typedef struct vlr_realign_batch_desc {
+    int64_t n_pairs;
+    const uint32_t* x_offset;       /* [n_pairs + 1] */
+    const uint8_t*  x_bases;
+    const uint32_t* y_offset;       /* [n_pairs + 1] */
+    const uint8_t*  y_bases;
+    const uint8_t*  y_quals;
+    const int32_t*  max_edit_dist;  /* [n_pairs] or NULL */
+    double gap[4];
+} vlr_realign_batch_desc;
+
+/* Device pointers, stream-ordered, no synchronisation. */
+int vlr_realign_batch(int device, const vlr_realign_batch_desc* pairs, double* ln_prob, void* hip_stream);
+/* Host pointers: stages the sequences, runs the kernel, returns when ln_prob is filled. */
+int vlr_realign_batch_host(int device, const vlr_realign_batch_desc* pairs, double* ln_prob);
+
 #ifdef __cplusplus
 }
 #endif

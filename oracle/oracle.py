@@ -21,8 +21,9 @@ class Stats(C.Structure):
 def build(force=False):
     so = os.path.join(_HERE, "libvlr_oracle.so")
     src = os.path.join(_HERE, "vlr_oracle.cpp")
+    src2 = os.path.join(_HERE, "vlr_realign_oracle.cpp")
     hdr = os.path.join(_HERE, "..", "include", "vlr.h")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(src2), os.path.getmtime(hdr)):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libvlr_oracle.so"], stdout=subprocess.DEVNULL)
     return so
 
@@ -61,8 +62,40 @@ def lib():
         L.vlro_pileup_lik_contaminated.argtypes = [C.POINTER(abi.Batch), C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double]
         L.vlro_bias_prob_ref_none.restype = C.c_double
         L.vlro_bias_prob_ref_none.argtypes = [C.POINTER(abi.Batch), C.c_int64]
+        L.vlro_pairhmm_prob_related.restype = C.c_double
+        L.vlro_pairhmm_prob_related.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int]
+        L.vlro_normalize_support.restype = None
+        L.vlro_normalize_support.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _LIB = L
     return _LIB
+
+
+def pairhmm_prob_related(allele: bytes, read: bytes, qual, gap, max_edit_dist: int = -1) -> float:
+    """Restated bio PairHMM::prob_related over the reference's emission model (oracle/vlr_realign_oracle.cpp)."""
+    L = lib()
+    x = np.frombuffer(bytes(allele) or b"\0", np.uint8)
+    y = np.frombuffer(bytes(read) or b"\0", np.uint8)
+    q = np.asarray(bytearray(qual) or b"\0", np.uint8)
+    g = (C.c_double * 4)(*gap)
+    return float(L.vlro_pairhmm_prob_related(x.ctypes.data, len(allele), y.ctypes.data, q.ctypes.data, len(read), g, int(max_edit_dist)))
+
+
+def pairhmm_batch(batch, gap, threads=1):
+    """All pairs of a varlociraptor_amd.realign.PairBatch through the oracle."""
+    g = [gap.prob_insertion_artifact, gap.prob_deletion_artifact, gap.prob_insertion_extend_artifact, gap.prob_deletion_extend_artifact]
+    idx = range(len(batch))
+    f = lambda k: pairhmm_prob_related(batch.x[k], batch.y[k], batch.q[k], g, batch.band[k])
+    if threads > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            return np.array(list(ex.map(f, idx)))
+    return np.array([f(k) for k in idx])
+
+
+def normalize_support(prob_ref: float, prob_alt: float):
+    r, a = C.c_double(prob_ref), C.c_double(prob_alt)
+    lib().vlro_normalize_support(C.byref(r), C.byref(a))
+    return r.value, a.value
 
 
 def call(scenario, batch: PileupBatch, afd_capacity: int = 0, begin: int = 0, end: int = None, want_events=False):

@@ -1,0 +1,149 @@
+// vlr_realign_oracle.cpp — CPU restatement (f64, log space) of the read-vs-allele pair HMM behind
+// `varlociraptor preprocess variants`: the producer of prob_alt / prob_ref.
+//
+// THIS IS TEST INFRASTRUCTURE (parity oracle of vlr_realign_batch and CPU baseline of bench.py --workload realign).
+// Nothing in the product may include, link or call it.
+//
+// What is restated, and from where:
+//   * emission and gap parameters, window shrinking and the ref/alt normalisation are the reference's own code:
+//       ReadEmission::{new, prob_match_mismatch, prob_insertion}     realignment/pairhmm.rs:392-455
+//       prob_read_base_miscall                                       evidence/bases.rs:30-41
+//       ReadVsAlleleEmission (EmissionParameters impl)               realignment/pairhmm.rs:340-368
+//       GapParams (defaults, GapParameters / StartEndGapParameters)  realignment/pairhmm.rs:119-205
+//       PairHMMRealigner::calculate_prob_allele (band = dist + 4)    realignment/mod.rs:519-537, pairhmm.rs:20
+//       ref/alt normalisation of Realigner::allele_support           realignment/mod.rs:359-385
+//   * the forward recursion itself lives in the THIRD-PARTY crate bio (Cargo.toml:29, `bio = "2.0.0"`,
+//     bio::stats::pairhmm::PairHMM::prob_related) whose source is NOT under /root/reference.  It is restated here from
+//     the crate's published algorithm: three-state (match / gap-in-y / gap-in-x) forward algorithm over two rolling
+//     columns, semiglobal in x (free start and end gaps), each column's last-row states collected and summed at the end,
+//     result capped at probability one, optional band: a cell is skipped when the minimum edit distance of its three
+//     predecessors exceeds `max_edit_dist` (an integer DP that runs along).
+//
+// PARITY UNPINNED for the recursion: the reference tree holds no numeric vector for it (pairhmm.rs has no tests; the
+// recorded prob_alt/prob_ref of tests/resources/testcases could anchor it only through the whole BAM-side pipeline).
+// Known behaviours of the crate that are NOT reproduced because they cannot be verified here:
+//   (1) its `ln_sum3_exp_approx` drops addends more than e^-10 below the largest (relative effect <= ~1e-4 per cell);
+//       this restatement sums exactly;
+//   (2) skipped band cells: this restatement treats them as probability zero with infinite edit distance; the crate only
+//       resets the match column between iterations;
+//   (3) the start mass of the first column (the crate adds the free-start mass to an initial mass of one).
+// The GPU path is compared against THIS function (tests/test_gpu_realign.py); against the real crate the three items
+// above bound the deviation.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <vector>
+
+namespace {
+const double NEG_INF = -std::numeric_limits<double>::infinity();
+const double LN10 = 2.302585092994046;
+
+inline double ln_add_exp(double a, double b) {  // bio LogProb::ln_add_exp
+    double p0 = a, p1 = b;
+    if (p1 > p0) std::swap(p0, p1);
+    if (p0 == NEG_INF) return NEG_INF;
+    return p0 + std::log1p(std::exp(p1 - p0));
+}
+inline double ln_one_minus_exp(double p) {  // bio LogProb::ln_one_minus_exp
+    if (p < -0.693) return std::log1p(-std::exp(p));
+    return std::log(-std::expm1(p));
+}
+inline double ln_sum_exp(const std::vector<double>& v) {  // bio LogProb::ln_sum_exp
+    if (v.empty()) return NEG_INF;
+    size_t im = 0;
+    for (size_t i = 1; i < v.size(); ++i)
+        if (v[i] > v[im]) im = i;
+    if (v[im] == NEG_INF) return NEG_INF;
+    double s = 0.0;
+    for (size_t i = 0; i < v.size(); ++i)
+        if (i != im && v[i] != NEG_INF) s += std::exp(v[i] - v[im]);
+    return v[im] + std::log1p(s);
+}
+inline int upper(int b) { return (b >= 'a' && b <= 'z') ? b - 32 : b; }
+}  // namespace
+
+extern "C" {
+
+// ln P(read window | allele) — PairHMM::prob_related over ReadVsAlleleEmission.
+//   x[0..len_x)  allele bases (reference coordinates of the shrunken window), y/qual[0..len_y) read window
+//   gap[4] = {ln prob_gap_x (insertion artifact), ln prob_gap_y (deletion artifact), ln x-extend, ln y-extend}
+//   max_edit_dist < 0: no band
+double vlro_pairhmm_prob_related(const uint8_t* x, int len_x, const uint8_t* y, const uint8_t* qual, int len_y, const double* gap,
+                                 int max_edit_dist) {
+    const double PROB_CONFUSION = std::log(0.3333);  // pairhmm.rs:22-24
+    const double prob_gap_x = gap[0], prob_gap_y = gap[1], prob_gap_x_extend = gap[2], prob_gap_y_extend = gap[3];
+    // GapParamCache (bio): P(no gap) = 1 - (P(gap x) + P(gap y)); leaving a gap: 1 - P(extend)
+    const double prob_no_gap = ln_one_minus_exp(ln_add_exp(prob_gap_x, prob_gap_y));
+    const double prob_no_gap_x_extend = ln_one_minus_exp(prob_gap_x_extend);
+    const double prob_no_gap_y_extend = ln_one_minus_exp(prob_gap_y_extend);
+    const bool do_gap_x_extend = prob_gap_x_extend != NEG_INF, do_gap_y_extend = prob_gap_y_extend != NEG_INF;
+    // ReadEmission::new (pairhmm.rs:406-428)
+    std::vector<double> any_miscall(len_y), no_miscall(len_y);
+    for (int j = 0; j < len_y; ++j) {
+        any_miscall[j] = -(double)qual[j] * LN10 / 10.0;  // LogProb::from(PHREDProb(q))
+        no_miscall[j] = ln_one_minus_exp(any_miscall[j]);
+    }
+    const unsigned BIG = std::numeric_limits<unsigned>::max();
+    std::vector<double> fm[2], fx[2], fy[2];
+    std::vector<unsigned> med[2];
+    for (int k = 0; k < 2; ++k) {
+        fm[k].assign(len_y + 1, NEG_INF); fx[k].assign(len_y + 1, NEG_INF); fy[k].assign(len_y + 1, NEG_INF);
+        med[k].assign(len_y + 1, BIG);
+    }
+    std::vector<double> prob_cols;
+    prob_cols.reserve((size_t)len_x * 3);
+    int prev = 0, curr = 1;
+    for (int i = 0; i < len_x; ++i) {
+        // semiglobal: an alignment may start at any column of x with mass one (StartEndGapParameters, pairhmm.rs:186-205)
+        fm[prev][0] = 0.0;
+        med[prev][0] = 0;
+        fx[prev][0] = NEG_INF; fy[prev][0] = NEG_INF;
+        const double prob_emit_x = 0.0;  // pairhmm.rs:350-352
+        const int xb = upper(x[i]);
+        for (int j = 0; j < len_y; ++j) {
+            const int j_ = j + 1, jm = j;
+            const unsigned e_tl = med[prev][jm], e_top = med[curr][jm], e_left = med[prev][j_];
+            // a fresh column: everything outside the band is probability zero / unreachable
+            fm[curr][j_] = NEG_INF; fx[curr][j_] = NEG_INF; fy[curr][j_] = NEG_INF; med[curr][j_] = BIG;
+            if (max_edit_dist >= 0 && std::min(e_tl, std::min(e_top, e_left)) > (unsigned)max_edit_dist) continue;
+            // match or mismatch (ReadEmission::prob_match_mismatch, pairhmm.rs:434-445)
+            const bool is_match = upper(y[j]) == xb;
+            const double emit_xy = is_match ? no_miscall[j] : any_miscall[j] + PROB_CONFUSION;
+            std::vector<double> in3 = {prob_no_gap + fm[prev][jm], prob_no_gap_y_extend + fx[prev][jm], prob_no_gap_x_extend + fy[prev][jm]};
+            fm[curr][j_] = emit_xy + ln_sum_exp(in3);
+            // gap in y: x_i is emitted alone (a deletion in the read)
+            double g = prob_gap_y + fm[prev][j_];
+            if (do_gap_y_extend) g = ln_add_exp(g, prob_gap_y_extend + fx[prev][j_]);
+            fx[curr][j_] = prob_emit_x + g;
+            // gap in x: y_j is emitted alone (an insertion in the read), prob_emit_y = any_miscall (pairhmm.rs:354-357,447-449)
+            double h = prob_gap_x + fm[curr][jm];
+            if (do_gap_x_extend) h = ln_add_exp(h, prob_gap_x_extend + fy[curr][jm]);
+            fy[curr][j_] = any_miscall[j] + h;
+            if (max_edit_dist >= 0) {
+                auto inc = [BIG](unsigned v) { return v == BIG ? BIG : v + 1; };
+                med[curr][j_] = std::min(is_match ? e_tl : inc(e_tl), std::min(inc(e_top), inc(e_left)));
+            }
+        }
+        // free end gap in x: every column may end the alignment
+        prob_cols.push_back(fm[curr][len_y]); prob_cols.push_back(fx[curr][len_y]); prob_cols.push_back(fy[curr][len_y]);
+        std::swap(curr, prev);
+        fm[curr][0] = NEG_INF; fx[curr][0] = NEG_INF; fy[curr][0] = NEG_INF; med[curr][0] = BIG;
+    }
+    const double p = ln_sum_exp(prob_cols);
+    return p > 0.0 ? 0.0 : p;  // "sum of paths can exceed probability 1.0 especially in case of repeats"
+}
+
+// The ref/alt normalisation of Realigner::allele_support (realignment/mod.rs:359-385): both non-zero -> divide by the sum;
+// both zero -> 0.5 / 0.5.
+void vlro_normalize_support(double* prob_ref, double* prob_alt) {
+    double r = *prob_ref, a = *prob_alt;
+    if (r != NEG_INF && a != NEG_INF) {
+        const double t = ln_add_exp(a, r);
+        r -= t; a -= t;
+    }
+    if (r == NEG_INF && a == NEG_INF) r = a = std::log(0.5);
+    *prob_ref = r; *prob_alt = a;
+}
+
+}  // extern "C"

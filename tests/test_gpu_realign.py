@@ -1,0 +1,95 @@
+"""GPU parity of the pair-HMM kernel (vlr_realign_batch, varlociraptor_amd/csrc/vlr_realign.hip) against the CPU restatement
+(oracle/vlr_realign_oracle.cpp) through the C ABI: random read/allele windows of every variant kind, banded and unbanded,
+with and without gap extension, edge shapes (one base, 128-base reads, long alleles, lower case, empty, oversize), the
+underflow guard, and the size-independent property that ref/alt supports normalise to one.  Tolerance: 1e-9 absolute on
+ln P (the kernel multiplies in linear space, the oracle adds logarithms); BASELINE's 1e-6 bar applies to the normalised
+probabilities, checked as well."""
+import math
+
+import numpy as np
+import pytest
+
+from varlociraptor_amd import realign, realign_synth
+from varlociraptor_amd.realign import GapParams, PairBatch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+def check(oracle, pb, gap=None, tol=TOL):
+    gap = gap or GapParams()
+    got = realign.prob_related(pb, gap)
+    ref = oracle.pairhmm_batch(pb, gap, threads=8)
+    both_inf = np.isneginf(got) & np.isneginf(ref)
+    d = np.where(both_inf, 0.0, np.abs(got - ref))
+    assert np.all(d <= tol * np.maximum(1.0, np.abs(ref) * 1e-3)), (float(np.nanmax(d)), int(np.nanargmax(d)))
+    return got, ref
+
+
+@pytest.mark.parametrize("banded", [True, False])
+def test_random_windows_match_oracle(oracle, banded):
+    pb, truth = realign_synth.generate(300, seed=11, banded=banded)
+    got, ref = check(oracle, pb)
+    # normalised supports (what the observation records carry) within BASELINE's 1e-6
+    for k in range(len(truth)):
+        g = realign.normalize_support(got[2 * k], got[2 * k + 1])
+        r = oracle.normalize_support(ref[2 * k], ref[2 * k + 1])
+        assert abs(math.exp(g[0]) - math.exp(r[0])) <= 1e-6 and abs(math.exp(g[1]) - math.exp(r[1])) <= 1e-6
+        assert abs(math.exp(g[0]) + math.exp(g[1]) - 1.0) < 1e-9
+    # reads drawn from the alt allele support it
+    sup = np.array([got[2 * k + 1] > got[2 * k] for k in range(len(truth))])
+    assert (sup == truth).mean() > 0.9
+
+
+def test_gap_extension(oracle):
+    pb, _ = realign_synth.generate(120, seed=12)
+    check(oracle, pb, GapParams(math.log(1e-4), math.log(2e-4), math.log(0.2), math.log(0.3)))
+
+
+def test_edge_shapes(oracle):
+    rng = np.random.default_rng(5)
+    B = np.frombuffer(b"ACGT", np.uint8)
+    pb = PairBatch()
+    pb.add(b"A", b"A", [30])
+    pb.add(b"C", b"A", [30])
+    pb.add(b"ACGT", b"A", [40])
+    pb.add(b"AAAA", b"A", [40])                       # capped at ln 1
+    x = B[rng.integers(0, 4, 300)].tobytes()
+    pb.add(x, x[100:228], [37] * 128)                 # the longest read window
+    pb.add(x.lower(), x[100:228], [37] * 128)         # lower-case reference
+    pb.add(x[:3], x[:64], [20] * 64)                  # read much longer than the allele
+    pb.add(B[rng.integers(0, 4, 2000)].tobytes(), x[10:90], [30] * 80)   # long allele window
+    y = B[rng.integers(0, 4, 128)].tobytes()
+    pb.add(x[:200], y, [40] * 128)                    # unrelated read at Q40: ~1e-400, exercises the rescaling
+    pb.add(x[:200], y, [93] * 128)                    # and at Q93
+    pb.add(x[:200], x[20:120], [30] * 100, max_edit_dist=0)   # tightest band
+    pb.add(x[:200], y[:100], [30] * 100, max_edit_dist=3)     # band that excludes every path
+    got, ref = check(oracle, pb)
+    assert got[3] == 0.0
+    assert got[8] < -700 and got[9] < -1300   # far below the f64 range in linear space
+    assert np.isneginf(got[11]) and np.isneginf(ref[11])
+
+
+def test_empty_and_oversize_inputs():
+    pb = PairBatch()
+    assert len(realign.prob_related(pb)) == 0
+    pb.add(b"ACGT", b"", [])
+    pb.add(b"", b"ACGT", [30] * 4)
+    pb.add(b"A" * 300, b"A" * 129, [30] * 129)
+    got = realign.prob_related(pb)
+    assert np.isneginf(got[0]) and np.isneginf(got[1]) and np.isnan(got[2])
+
+
+def test_allele_support_pipeline(oracle):
+    """allele_support(): pre-filter + banded kernel + normalisation for a deletion, checked against the oracle path."""
+    rng = np.random.default_rng(9)
+    locus = realign_synth.make_locus(rng, kind="del")
+    reads = [realign_synth.make_read(rng, locus, from_alt=bool(k % 2)) for k in range(40)]
+    sup = realign.allele_support(reads, locus["ref_allele"], locus["alt_allele"])
+    for k, (seq, q) in enumerate(reads):
+        pr = oracle.pairhmm_prob_related(locus["ref_allele"], seq, q, [math.log(2.8e-6), math.log(5.1e-6), -math.inf, -math.inf],
+                                         realign.best_hit(seq, locus["ref_allele"])[0] + realign.EDIT_BAND)
+        pa = oracle.pairhmm_prob_related(locus["alt_allele"], seq, q, [math.log(2.8e-6), math.log(5.1e-6), -math.inf, -math.inf],
+                                         realign.best_hit(seq, locus["alt_allele"])[0] + realign.EDIT_BAND)
+        r, a = oracle.normalize_support(pr, pa)
+        assert abs(math.exp(sup[k, 0]) - math.exp(r)) <= 1e-6 and abs(math.exp(sup[k, 1]) - math.exp(a)) <= 1e-6

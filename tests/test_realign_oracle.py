@@ -1,0 +1,109 @@
+"""CPU checks of the pair-HMM restatement (oracle/vlr_realign_oracle.cpp): closed forms for tiny cases, the emission and
+gap conventions of realignment/pairhmm.rs, the normalisation of realignment/mod.rs:359-385, and the host-side
+allele windows / edit-distance pre-filter of varlociraptor_amd/realign.py.  (The recursion itself lives in the bio crate,
+absent from the reference tree: see the oracle's header — parity unpinned.)"""
+import math
+
+import numpy as np
+import pytest
+
+from varlociraptor_amd import realign
+
+GAP = [math.log(2.8e-6), math.log(5.1e-6), -math.inf, -math.inf]
+
+
+def test_single_cell_closed_form(oracle):
+    """x = 'A', y = 'A' q30: paths = match from the start row: P = P(no gap) * (1 - 10^-3)."""
+    p = oracle.pairhmm_prob_related(b"A", b"A", [30], GAP)
+    want = math.log1p(-(2.8e-6 + 5.1e-6)) + math.log1p(-1e-3)
+    assert abs(p - want) < 1e-12
+    # mismatch: P(miscall) * 0.3333 (pairhmm.rs:22-24, 430-445)
+    p = oracle.pairhmm_prob_related(b"C", b"A", [30], GAP)
+    assert abs(p - (math.log1p(-(2.8e-6 + 5.1e-6)) + math.log(1e-3) + math.log(0.3333))) < 1e-12
+
+
+def test_semiglobal_free_ends_sum_over_placements(oracle):
+    """A read of one base against 'ACGT': one matching and three mismatching placements (gap paths add terms of order 1e-6);
+    against 'AAAA' the four matching placements exceed one and the result is capped at ln 1."""
+    pn = math.log1p(-(2.8e-6 + 5.1e-6))
+    p4 = oracle.pairhmm_prob_related(b"ACGT", b"A", [40], GAP)
+    want = pn + math.log((1 - 1e-4) + 3 * 1e-4 * 0.3333)
+    assert abs(p4 - want) < 1e-5
+    assert oracle.pairhmm_prob_related(b"AAAA", b"A", [40], GAP) == 0.0
+    assert oracle.pairhmm_prob_related(b"A" * 50, b"A", [2], GAP) <= 0.0
+
+
+def test_case_insensitive_and_band_wide_enough_changes_nothing(oracle):
+    x, y, q = b"ACGTTGCAAGGCTTAACG", b"GTTGCTAGGC", [30] * 10
+    a = oracle.pairhmm_prob_related(x, y, q, GAP)
+    assert oracle.pairhmm_prob_related(x.lower(), y, q, GAP) == a
+    # a band wider than the read admits every cell a path can reach; narrower bands only remove mass
+    assert abs(oracle.pairhmm_prob_related(x, y, q, GAP, max_edit_dist=50) - a) < 1e-12
+    assert oracle.pairhmm_prob_related(x, y, q, GAP, max_edit_dist=1) <= a + 1e-15
+    hit = realign.best_hit(y, x)
+    assert hit[0] == 1
+    tight = oracle.pairhmm_prob_related(x, y, q, GAP, max_edit_dist=hit[0] + realign.EDIT_BAND)
+    assert abs(tight - a) < 1e-9  # what the band drops is negligible
+
+
+def test_gap_extension_parameters(oracle):
+    """Without extension a two-base deletion needs mismatches; with it the gap path dominates."""
+    x, y, q = b"ACGTACGTTTGGCCAATT", b"ACGTACGGGCCAATT"[:], [40] * 15
+    no_ext = oracle.pairhmm_prob_related(x, y, q, GAP)
+    ext = oracle.pairhmm_prob_related(x, y, q, [GAP[0], GAP[1], math.log(0.1), math.log(0.1)])
+    assert ext > no_ext + 5.0
+
+
+def test_normalize_support(oracle):
+    r, a = oracle.normalize_support(math.log(1e-10), math.log(3e-10))
+    assert abs(math.exp(r) + math.exp(a) - 1.0) < 1e-12 and abs(math.exp(a) - 0.75) < 1e-12
+    assert oracle.normalize_support(-math.inf, -math.inf) == (math.log(0.5), math.log(0.5))
+    assert oracle.normalize_support(-math.inf, -3.0) == (-math.inf, -3.0)  # no magnification against a zero (mod.rs:365-373)
+    for pair in [(-5.0, -7.0), (-math.inf, -math.inf), (-math.inf, -1.0)]:
+        assert realign.normalize_support(*pair) == pytest.approx(oracle.normalize_support(*pair), abs=1e-15)
+
+
+def test_allele_windows_follow_the_emission_types():
+    ref = b"AAAACCCCGGGGTTTTACGT"
+    assert realign.ref_allele(ref, 2, 10) == b"AACCCCGG"
+    assert realign.snv_allele(ref, 2, 10, 4, ord("T")) == b"AATCCCGG"
+    assert realign.mnv_allele(ref, 2, 10, 4, b"TG") == b"AATGCCGG"
+    # deletion of CCCC after position 3 (types/deletion.rs:316-323): window keeps its length, later bases shift in
+    assert realign.deletion_allele(ref, 2, 10, 3, 4) == b"AAGGGGTT"
+    # insertion of TT after position 3 (types/insertion.rs:252-274): window grows by the insertion
+    assert realign.insertion_allele(ref, 2, 10, 3, b"TT") == b"AATTCCCCGG"
+
+
+def test_best_hit_is_the_semiglobal_edit_distance():
+    rng = np.random.default_rng(3)
+    for _ in range(12):
+        x = rng.choice(np.frombuffer(b"ACGT", np.uint8), 24).tobytes()
+        y = rng.choice(np.frombuffer(b"ACGT", np.uint8), 8).tobytes()
+        d, end = realign.best_hit(y, x)
+        # brute force: minimum over substrings via plain DP
+        best = min(_edit(y, x[s:e]) for s in range(len(x)) for e in range(s, min(len(x), s + 2 * len(y)) + 1))
+        assert d == best
+    assert realign.best_hit(b"ACGT", b"TTACGTTT") == (0, 6)
+
+
+def _edit(a, b):
+    D = list(range(len(b) + 1))
+    for i in range(1, len(a) + 1):
+        prev, D[0] = D[0], i
+        for j in range(1, len(b) + 1):
+            cur = min(prev + (a[i - 1] != b[j - 1]), D[j] + 1, D[j - 1] + 1)
+            prev, D[j] = D[j], cur
+    return D[len(b)]
+
+
+def test_reads_support_their_allele_of_origin(oracle):
+    """End to end on the CPU oracle: reads drawn from the alt allele prefer it after normalisation, reference reads do not."""
+    from varlociraptor_amd import realign_synth
+    from varlociraptor_amd.realign import GapParams
+    pb, truth = realign_synth.generate(40, seed=5, reads_per_locus=20)
+    p = oracle.pairhmm_batch(pb, GapParams())
+    agree = 0
+    for k, from_alt in enumerate(truth):
+        r, a = oracle.normalize_support(p[2 * k], p[2 * k + 1])
+        agree += (a > r) == from_alt or abs(a - r) < 1e-3
+    assert agree >= 38

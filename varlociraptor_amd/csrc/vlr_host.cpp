@@ -1075,4 +1075,65 @@ void vlr_host_free(void* p) {
     if (p) (void)hipHostFree(p);
 }
 
+// ---- read-vs-allele pair HMM (vlr_realign.hip)
+extern "C" int vlr_launch_realign_kernel(const vlr_realign_batch_desc* b, double* ln_prob, void* stream);
+
+static int check_realign(const vlr_realign_batch_desc* b, const double* ln_prob) {
+    if (!b || (b->n_pairs > 0 && (!b->x_offset || !b->x_bases || !b->y_offset || !b->y_bases || !b->y_quals || !ln_prob)))
+        return fail(VLR_ERR_INVALID_ARGUMENT, "null argument");
+    if (b->n_pairs < 0) return fail(VLR_ERR_INVALID_ARGUMENT, "negative pair count");
+    for (int k = 0; k < 4; ++k)
+        if (b->gap[k] != b->gap[k] || b->gap[k] > 0.0) return fail(VLR_ERR_INVALID_ARGUMENT, "gap[%d] is not a log probability", k);
+    return VLR_OK;
+}
+
+int vlr_realign_batch(int device, const vlr_realign_batch_desc* b, double* ln_prob, void* hip_stream) {
+    int rc = check_realign(b, ln_prob);
+    if (rc != VLR_OK) return rc;
+    if (b->n_pairs == 0) return VLR_OK;
+    HIP_TRY(hipSetDevice(device));
+    hipError_t e = (hipError_t)vlr_launch_realign_kernel(b, ln_prob, hip_stream);
+    if (e != hipSuccess) return fail(VLR_ERR_HIP, "realign kernel launch: %s", hipGetErrorString(e));
+    return VLR_OK;
+}
+
+int vlr_realign_batch_host(int device, const vlr_realign_batch_desc* b, double* ln_prob) {
+    int rc = check_realign(b, ln_prob);
+    if (rc != VLR_OK) return rc;
+    const int64_t n = b->n_pairs;
+    if (n == 0) return VLR_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) return fail(VLR_ERR_NO_DEVICE, "no HIP device %d (the engine has no CPU path)", device);
+    HIP_TRY(hipSetDevice(device));
+    const size_t nx = b->x_offset[n], ny = b->y_offset[n];
+    // one staging buffer: offsets, bases, qualities, band, results
+    const size_t o_xoff = 0, o_yoff = o_xoff + (n + 1) * 4, o_band = o_yoff + (n + 1) * 4, o_out = (o_band + n * 4 + 7) & ~(size_t)7;
+    const size_t o_x = o_out + n * 8, o_y = o_x + ((nx + 7) & ~(size_t)7), o_q = o_y + ((ny + 7) & ~(size_t)7), total = o_q + ny + 8;
+    char* d = nullptr;
+    if (hipMalloc((void**)&d, total) != hipSuccess) { (void)hipGetLastError(); return fail(VLR_ERR_OUT_OF_MEMORY, "hipMalloc(%zu)", total); }
+    hipStream_t st = nullptr;
+    rc = VLR_OK;
+    do {
+        if (hipMemcpyAsync(d + o_xoff, b->x_offset, (n + 1) * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(d + o_yoff, b->y_offset, (n + 1) * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(d + o_x, b->x_bases, nx, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(d + o_y, b->y_bases, ny, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(d + o_q, b->y_quals, ny, hipMemcpyHostToDevice, st) != hipSuccess ||
+            (b->max_edit_dist && hipMemcpyAsync(d + o_band, b->max_edit_dist, n * 4, hipMemcpyHostToDevice, st) != hipSuccess)) {
+            rc = fail(VLR_ERR_HIP, "staging copy failed"); break;
+        }
+        vlr_realign_batch_desc db = *b;
+        db.x_offset = (const uint32_t*)(d + o_xoff); db.y_offset = (const uint32_t*)(d + o_yoff);
+        db.x_bases = (const uint8_t*)(d + o_x); db.y_bases = (const uint8_t*)(d + o_y); db.y_quals = (const uint8_t*)(d + o_q);
+        db.max_edit_dist = b->max_edit_dist ? (const int32_t*)(d + o_band) : nullptr;
+        hipError_t e = (hipError_t)vlr_launch_realign_kernel(&db, (double*)(d + o_out), st);
+        if (e != hipSuccess) { rc = fail(VLR_ERR_HIP, "realign kernel launch: %s", hipGetErrorString(e)); break; }
+        if (hipMemcpyAsync(ln_prob, d + o_out, n * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            rc = fail(VLR_ERR_HIP, "result copy failed"); break;
+        }
+    } while (0);
+    (void)hipFree(d);
+    return rc;
+}
+
 }  // extern "C"

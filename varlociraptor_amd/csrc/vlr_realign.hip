@@ -1,0 +1,189 @@
+// vlr_realign.hip — gfx950 kernel of the read-vs-allele pair HMM ("next" row #1): the producer of
+// prob_alt / prob_ref in `varlociraptor preprocess variants`.
+//
+// What is computed: bio::stats::pairhmm::PairHMM::prob_related (third-party crate, restated in
+// oracle/vlr_realign_oracle.cpp — see its header for what is and is not pinned) over the reference's emission model
+//   ReadVsAlleleEmission / ReadEmission        /root/reference/src/variants/evidence/realignment/pairhmm.rs:296-455
+//   GapParams, semiglobal start/end            pairhmm.rs:119-205
+//   band = edit distance of the hit + EDIT_BAND realignment/mod.rs:519-537, pairhmm.rs:20
+// for a batch of (allele window x, read window y) pairs.
+//
+// How: one wave64 per pair, anti-diagonal wavefront.  Lane l owns read rows 2l and 2l+1 (the reference limits a read window
+// to 128 bases, EditDistanceCalculation::max_pattern_len, edit_distance.rs:145-147); at step d a row j works on column
+// i = d - j.  The three forward states and the running minimum edit distance of a cell live in registers; a row needs the
+// previous step's cell of the row above (wave_shr:1 DPP shift, or its own lane's other register), which one step later is
+// its top-left neighbour — no LDS, no barriers.  Arithmetic is linear-space f64 (the reference works in log space): a cell
+// costs 3 multiplies + 4 FMAs instead of ~5 exp/log1p; every lane keeps a power-of-two scale for its two rows (rows deep in
+// an unrelated read are hundreds of orders of magnitude below the first ones) that is aligned when neighbours exchange cells.
+// No MFMA (a recurrence, not a contraction); HBM traffic is the two sequences and the qualities, a few hundred bytes per pair.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vlr.h"
+
+namespace vlr {
+
+struct RealignArgs {
+    int64_t n_pairs;
+    const uint32_t* x_offset;
+    const uint8_t* x_bases;
+    const uint32_t* y_offset;
+    const uint8_t* y_bases;
+    const uint8_t* y_quals;
+    const int32_t* max_edit_dist;
+    double pn, pnx, pny, pgx, pgy, pgxe, pgye;  // linear: P(no gap), P(leave x-gap), P(leave y-gap), gap opens, extends
+    double* ln_prob;
+};
+
+__device__ __forceinline__ int up(int b) { return (b >= 'a' && b <= 'z') ? b - 32 : b; }
+
+// value of lane l-1 (lane 0: `edge`)
+__device__ __forceinline__ double shr1(double v, double edge) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(edge), lo, 0x138, 0xF, 0xF, false);  // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), hi, 0x138, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ unsigned shr1(unsigned v, unsigned edge) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xF, 0xF, false);
+}
+
+constexpr unsigned kBig = 0x3fffffffu;  // "unreachable" edit distance (adding one cannot wrap)
+
+__global__ void __launch_bounds__(64) vlr_realign_kernel(RealignArgs a) {
+    const int64_t pair = blockIdx.x;
+    if (pair >= a.n_pairs) return;
+    const int lane = threadIdx.x;
+    const uint32_t x0 = a.x_offset[pair], y0 = a.y_offset[pair];
+    const int len_x = (int)(a.x_offset[pair + 1] - x0), len_y = (int)(a.y_offset[pair + 1] - y0);
+    const int med_max = a.max_edit_dist ? a.max_edit_dist[pair] : -1;
+    const bool banded = med_max >= 0;
+    if (len_y > 128 || len_y <= 0 || len_x <= 0) {
+        if (lane == 0) a.ln_prob[pair] = (len_x <= 0 || len_y <= 0) ? -__builtin_huge_val() : __builtin_nan("");
+        return;
+    }
+    // per-row emission constants (ReadEmission::new, pairhmm.rs:406-428; PROB_CONFUSION pairhmm.rs:22-24)
+    int yb[2];
+    double e_match[2], e_mis[2], e_ins[2];
+    bool rowon[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int j = 2 * lane + r;
+        rowon[r] = j < len_y;
+        const int q = rowon[r] ? a.y_quals[y0 + j] : 0;
+        yb[r] = rowon[r] ? up(a.y_bases[y0 + j]) : 0;
+        const double mis = exp(-(double)q * 2.302585092994046 / 10.0);  // P(miscall) = 10^(-q/10)
+        e_match[r] = 1.0 - mis;
+        e_mis[r] = mis * 0.3333;
+        e_ins[r] = mis;
+    }
+    // state of the cell each row computed at the previous step (its "left" neighbour now) ...
+    double M1[2] = {0.0, 0.0}, X1[2] = {0.0, 0.0}, Y1[2] = {0.0, 0.0};
+    unsigned E1[2] = {kBig, kBig};
+    // ... and of the row above one step earlier (the "top-left" neighbour now)
+    double Mt[2] = {0.0, 0.0}, Xt[2] = {0.0, 0.0}, Yt[2] = {0.0, 0.0};
+    unsigned Et[2] = {kBig, kBig};
+    double total = 0.0;  // sum over columns of the last row's three states (free end gap in x)
+    int scale = 0;       // this lane's states and total carry a factor 2^scale
+    const int last_row = len_y - 1;
+    const int nsteps = len_x + len_y - 1;
+    // x bases: lane-strided prefetch is not worth it for a few hundred bytes; every row reads its column's base (L1/L2 hits)
+    for (int d = 0; d < nsteps; ++d) {
+        // top neighbour = previous step's cell of row j-1.  Row -1 is the virtual start row: as "top" (same column) it is
+        // empty, as "top-left" (previous column) it carries the free start mass one with edit distance zero.
+        double Mu[2], Xu[2], Yu[2];
+        unsigned Eu[2];
+        {
+            // the lane above stores its states with its own power-of-two scale: bring them to this lane's.  A lane that holds
+            // nothing yet (rows not reached, or everything outside the band) simply adopts the scale of the lane above.
+            const int nb = (int)shr1((unsigned)scale, (unsigned)scale);
+            const double mass = ((M1[0] + M1[1]) + (X1[0] + X1[1])) + ((Y1[0] + Y1[1]) + (Mt[0] + Mt[1])) + ((Xt[0] + Xt[1]) + (Yt[0] + Yt[1])) + total;
+            if (mass == 0.0) scale = nb;
+            int dsc = scale - nb;
+            dsc = dsc > 1000 ? 1000 : dsc < -1000 ? -1000 : dsc;
+            const double f = __builtin_ldexp(1.0, dsc);
+            Mu[0] = shr1(M1[1], 0.0) * f; Xu[0] = shr1(X1[1], 0.0) * f; Yu[0] = shr1(Y1[1], 0.0) * f; Eu[0] = shr1(E1[1], kBig);
+        }
+        Mu[1] = M1[0]; Xu[1] = X1[0]; Yu[1] = Y1[0]; Eu[1] = E1[0];
+        double Mn[2], Xn[2], Yn[2];
+        unsigned En[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int j = 2 * lane + r;
+            const int i = d - j;
+            const bool on = rowon[r] && i >= 0 && i < len_x;
+            // top-left: virtual start row for j == 0 (mass one in every column), virtual empty column for i == 0
+            double mtl = Mt[r], xtl = Xt[r], ytl = Yt[r];
+            unsigned etl = Et[r];
+            if (j == 0) { mtl = __builtin_ldexp(1.0, scale); xtl = 0.0; ytl = 0.0; etl = 0u; }
+            else if (i == 0) { mtl = 0.0; xtl = 0.0; ytl = 0.0; etl = kBig; }
+            // left: previous column of the same row; empty for the first column
+            const double ml = (i == 0) ? 0.0 : M1[r], xl = (i == 0) ? 0.0 : X1[r];
+            const unsigned el = (i == 0) ? kBig : E1[r];
+            // top: same column, row above (already computed: it is one anti-diagonal behind)
+            const double mu = Mu[r], yu = Yu[r];
+            const unsigned eu = Eu[r];
+            const int xb = on ? up(a.x_bases[x0 + i]) : 0;
+            const bool is_match = xb == yb[r];
+            const unsigned emin = min(etl, min(eu, el));
+            const bool skip = banded && emin > (unsigned)med_max;
+            const bool live = on && !skip;
+            const double emit = is_match ? e_match[r] : e_mis[r];
+            const double m = emit * (a.pn * mtl + a.pny * xtl + a.pnx * ytl);
+            const double x = a.pgy * ml + a.pgye * xl;                 // gap in y: x_i alone (prob_emit_x = 1)
+            const double y = e_ins[r] * (a.pgx * mu + a.pgxe * yu);    // gap in x: y_j alone
+            const unsigned e = min(is_match ? etl : etl + 1u, min(eu + 1u, el + 1u));
+            Mn[r] = live ? m : 0.0; Xn[r] = live ? x : 0.0; Yn[r] = live ? y : 0.0;
+            En[r] = (live && banded) ? min(e, kBig) : kBig;
+            if (on && j == last_row) total += Mn[r] + Xn[r] + Yn[r];
+            // a row that is not inside the matrix this step keeps nothing
+            if (!on) { Mn[r] = 0.0; Xn[r] = 0.0; Yn[r] = 0.0; En[r] = kBig; }
+        }
+        // this step's "top" of a row is its "top-left" at the next step
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { Mt[r] = Mu[r]; Xt[r] = Xu[r]; Yt[r] = Yu[r]; Et[r] = Eu[r]; M1[r] = Mn[r]; X1[r] = Xn[r]; Y1[r] = Yn[r]; E1[r] = En[r]; }
+        // underflow guard, every 8 steps (a Q93 mismatch shrinks a state by 1e-10: 1e-80 between two checks).  Rows deep in
+        // the read carry far smaller numbers than the first rows, so every LANE keeps its own power-of-two scale: when its
+        // largest state has dropped below 2^-200 it is brought back to ~1 (exact), unless what the lane has collected for
+        // the result already outweighs anything its states can still add.
+        if ((d & 7) == 7) {
+            double mx = fmax(fmax(fmax(M1[0], X1[0]), fmax(Y1[0], M1[1])), fmax(X1[1], Y1[1]));
+            mx = fmax(mx, fmax(fmax(Mt[0], Xt[0]), fmax(fmax(Yt[0], Mt[1]), fmax(Xt[1], Yt[1]))));
+            int ex = 0;
+            (void)__builtin_frexp(mx, &ex);
+            // (scaled DOWN as well: the mass of a lane grows again when the wavefront reaches the columns the read aligns to)
+            if (mx > 0.0 && (ex > 200 || (ex < -200 && !(total > mx * 0x1p60)))) {
+                const int sh = -ex > 1000 ? 1000 : -ex < -1000 ? -1000 : -ex;
+                const double f1 = __builtin_ldexp(1.0, sh);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) { M1[r] *= f1; X1[r] *= f1; Y1[r] *= f1; Mt[r] *= f1; Xt[r] *= f1; Yt[r] *= f1; }
+                total *= f1;
+                scale += sh;
+            }
+        }
+    }
+    // the lane that owns the last row holds the sum
+    const int owner = last_row >> 1;
+    total = __shfl(total, owner);
+    scale = __shfl(scale, owner);
+    if (lane == 0) {
+        double p = (total > 0.0) ? log(total) - (double)scale * 0.6931471805599453 : -__builtin_huge_val();
+        a.ln_prob[pair] = p > 0.0 ? 0.0 : p;  // "sum of paths can exceed probability 1.0"
+    }
+}
+
+}  // namespace vlr
+
+extern "C" int vlr_launch_realign_kernel(const vlr_realign_batch_desc* b, double* ln_prob, void* stream) {
+    using namespace vlr;
+    if (b->n_pairs <= 0) return 0;
+    RealignArgs a;
+    a.n_pairs = b->n_pairs; a.x_offset = b->x_offset; a.x_bases = b->x_bases; a.y_offset = b->y_offset; a.y_bases = b->y_bases;
+    a.y_quals = b->y_quals; a.max_edit_dist = b->max_edit_dist; a.ln_prob = ln_prob;
+    // GapParamCache of the pair HMM: P(no gap) = 1 - (P(gap x) + P(gap y)); leaving a gap state: 1 - P(extend)
+    const double gx = exp(b->gap[0]), gy = exp(b->gap[1]), gxe = exp(b->gap[2]), gye = exp(b->gap[3]);
+    a.pgx = gx; a.pgy = gy; a.pgxe = gxe; a.pgye = gye;
+    a.pn = 1.0 - (gx + gy); a.pnx = 1.0 - gxe; a.pny = 1.0 - gye;
+    hipLaunchKernelGGL(vlr_realign_kernel, dim3((unsigned)b->n_pairs), dim3(64), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
