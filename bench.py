@@ -2,9 +2,15 @@
 """bench.py — throughput of the per-locus likelihood engine on synthetic pileups (BASELINE.json metric).
 
 One "step" = one pass of the hot path (vlr_batch_run) over the rank's resident batch of candidate
-loci + the all-gather of result records when N > 1.  Workload at N=1: BASELINE configs[2]
+loci + the all-gather of the full result records when N > 1.  Workload at N=1: BASELINE configs[2]
 (tumor-normal with contamination, SNV+indel, 100x, 1M loci); weak scaling: every rank gets its own
-1M-locus shard.  Prints ONE JSON line on rank 0.
+shard of that size.  Prints ONE JSON line on rank 0.
+
+  --workload config2|config3|config4|config5   BASELINE configs[1..4] (locus counts of the config, or --loci)
+  --workload realign                          second hot path: read-vs-allele pair HMM, pairs/s
+  --afd                                       additionally time the step WITH the AFD replay launch (the reference always
+                                              computes AFD, calling.rs:889-928) and report it as `with_afd`; `value` stays the
+                                              BASELINE metric
 """
 import argparse
 import json
@@ -21,6 +27,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F64_VALU_PEAK_TFLOPS = 78.6  # half of the 157.3 TF f32 vector peak (SURVEY.md §8d secondary figure)
+FLOP_PER_TERM = 3  # one observation term of one VAF point: fma(q, alpha, c) and the running product
+FLOP_PER_CELL = 13  # pair-HMM cell in linear space: 5 multiplies + 4 fused multiply-adds
+DEFAULT_LOCI = {"config2": 100_000, "config3": 1_000_000, "config4": 1_250_000, "config5": 625_000}  # configs 4/5: 10 M / 5 M over 8 GPUs
 
 
 def _gen_chunk(args):
@@ -47,13 +56,110 @@ def generate(name, n_loci, rank, chunk_loci=50000, workers=None):
     return PileupBatch.concat(parts)
 
 
+def _gen_pairs(args):
+    n_reads, seed = args
+    from varlociraptor_amd import realign_synth
+    pb, _ = realign_synth.generate(n_reads, seed=seed)
+    return pb.x, pb.y, pb.q, pb.band
+
+
+def traffic_for(workload, n_units, build_id):
+    """HBM bytes per launch from the PMC passes kept under profiles/ — only if they were taken from THIS build and size."""
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
+    if not os.path.exists(tpath):
+        return None
+    with open(tpath) as fh:
+        tj = json.load(fh)
+    if tj.get("n_units", tj.get("n_loci")) != n_units or tj.get("build_id") != build_id:
+        return None
+    return tj.get("hbm_bytes_per_launch")
+
+
+def bench_realign(args, rank, world, local_rank, dev):
+    import torch
+    import torch.distributed as dist
+    from varlociraptor_amd import engine, realign
+    n_reads = 4000 if args.loci is None else max(50, args.loci // 2)
+    jobs = [(250, 1000 * rank + k) for k in range(max(1, n_reads // 250))]
+    with ProcessPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 8)) as ex:
+        parts = list(ex.map(_gen_pairs, jobs))
+    base = realign.PairBatch()
+    for x, y, q, band in parts:
+        base.x += x; base.y += y; base.q += q; base.band += band
+    tile = 64 if args.loci is None else 1  # the same pairs many times over: the kernel's work per pair does not depend on its neighbours
+    pb = realign.PairBatch()
+    pb.x, pb.y, pb.q, pb.band = base.x * tile, base.y * tile, base.q * tile, base.band * tile
+    dp = realign.DevicePairs(pb, dev)
+    gap = realign.GapParams()
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(args.warmup):
+        dp.run(gap, local_rank, stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)  # same stream as the launches
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        dp.run(gap, local_rank, stream)
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return None
+    got = dp.out.cpu().numpy()
+    n_pairs = len(pb)
+    parity = cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle
+        cores = os.cpu_count() or 1
+        n_cpu = min(len(base), args.cpu_loci or 40 * cores)
+        sub = realign.PairBatch()
+        sub.x, sub.y, sub.q, sub.band = base.x[:n_cpu], base.y[:n_cpu], base.q[:n_cpu], base.band[:n_cpu]
+        oracle.lib()
+        tc = time.perf_counter()
+        ref = oracle.pairhmm_batch(sub, gap, threads=cores)
+        t_cpu = time.perf_counter() - tc
+        d = np.abs(got[:n_cpu] - ref)
+        parity = {"n_checked": int(n_cpu), "max_abs_dlnprob": float(np.nanmax(d)), "vs": "CPU restatement (oracle/vlr_realign_oracle.cpp), parity unpinned for the third-party recursion"}
+        cpu = {"value": n_cpu / t_cpu, "unit": "pairs/s", "cores": cores, "kind": "port",
+               "sample": "first %d pairs of the same batch, %d threads, %.1f s" % (n_cpu, cores, t_cpu)}
+    achieved = dp.bytes / (kernel_ms * 1e-3) / 1e9
+    cells = dp.cells
+    return {
+        "metric": "read-allele pairs/sec (pair HMM, whole node)", "value": n_pairs * world * args.steps / elapsed, "unit": "pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "realign: %d read-allele pairs/GPU (%d distinct, SNV/MNV/insertion/deletion loci, read windows <= 128 bases, reference windows 192 bases, banded)" % (n_pairs, len(base)),
+                   "parallelism": "pairs sharded x%d, no collective" % world},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic_for("realign", n_pairs, engine.build_id()), "algorithmic_bytes_per_launch": int(dp.bytes), "kernel_ms": kernel_ms,
+                     "note": "recurrence, f64 VALU bound: see valu",
+                     "valu": {"cells_per_s": cells / (kernel_ms * 1e-3), "flop_per_cell": FLOP_PER_CELL,
+                              "achieved_tflops": cells * FLOP_PER_CELL / (kernel_ms * 1e-3) / 1e12, "peak_tflops": F64_VALU_PEAK_TFLOPS,
+                              "frac": cells * FLOP_PER_CELL / (kernel_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TFLOPS}},
+        "cpu_baseline": cpu, "parity": parity, "build_id": engine.build_id(),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="config3", choices=["config2", "config3", "config4"])
-    ap.add_argument("--loci", type=int, default=None, help="loci per GPU (default: the config's size)")
+    ap.add_argument("--workload", default="config3", choices=["config2", "config3", "config4", "config5", "realign"])
+    ap.add_argument("--loci", type=int, default=None, help="loci per GPU (default: the config's size); realign: pairs per GPU")
+    ap.add_argument("--afd", action="store_true", help="also time the step with the AFD replay launch")
+    ap.add_argument("--afd-capacity", type=int, default=96)
     ap.add_argument("--cpu-loci", type=int, default=None, help="loci of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -61,7 +167,7 @@ def main():
     import torch
     import torch.distributed as dist
     from varlociraptor_amd import engine, synth
-    from varlociraptor_amd.dist import all_gather_records, pack_records
+    from varlociraptor_amd.dist import all_gather_records, pack_full_records
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -73,8 +179,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
 
-    default_loci = {"config2": 100_000, "config3": 1_000_000, "config4": 1_250_000}[args.workload]
-    n_loci = args.loci or default_loci
+    if args.workload == "realign":
+        line = bench_realign(args, rank, world, local_rank, dev)
+        if rank == 0:
+            print(json.dumps(line))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    n_loci = args.loci or DEFAULT_LOCI[args.workload]
     cfg = synth.CONFIGS[args.workload]()
     t0 = time.time()
     batch = generate(args.workload, n_loci, rank)
@@ -87,38 +200,54 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     n_total = n_loci * world
 
-    def step():
-        plan.call_device(dbatch, out, stream)
+    def step(o=out):
+        plan.call_device(dbatch, o, stream)
         if world > 1:
-            rec = pack_records(out.ln_posterior, out.map_vaf, out.status)
-            return all_gather_records(rec, n_total, world)
+            # the FULL fixed-size record travels: posteriors, marginal, MAP VAFs, bias codes, best event, status
+            return all_gather_records(pack_full_records(o), n_total, world)
         return None
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     plan.work_counters(reset=True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    kernel_ms = []
-    for _ in range(args.steps):
-        step()
-        kernel_ms.append(None)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed(step)
     # per-launch kernel duration from HIP events recorded on the launch stream inside vlr_batch_run
     # (the last launch's events; all launches process the same batch)
     last_ms = plan.last_kernel_ms()
     n_eval, n_terms = plan.work_counters()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    with_afd = None
+    if args.afd:
+        out_afd = engine.DeviceResults(batch.n_loci, plan.n_out, plan.n_samples, dev, afd_capacity=args.afd_capacity)
+        step(out_afd)
+        el_afd = timed(lambda: step(out_afd))
+        cnt = out_afd.afd_count.cpu().numpy()
+        with_afd = {"value": n_total * args.steps / el_afd, "unit": "loci/s", "ms_per_step": el_afd / args.steps * 1e3,
+                    "kernel_ms_both_launches": plan.last_kernel_ms(), "afd_capacity": args.afd_capacity,
+                    "mean_afd_points_per_sample": float(np.minimum(cnt, args.afd_capacity).mean()),
+                    "truncated_lists": int((cnt > args.afd_capacity).sum()),
+                    "ratio_to_plain": (n_total * args.steps / el_afd) / (n_total * args.steps / elapsed)}
+        del out_afd
 
     res = out.to_host()
     line = None
@@ -132,7 +261,7 @@ def main():
             from oracle import oracle
             from parity import compare
             cores = os.cpu_count() or 1
-            per_core = 40 if args.workload != "config2" else 2500
+            per_core = {"config2": 2500, "config5": 400}.get(args.workload, 40)
             n_cpu = args.cpu_loci or min(batch.n_loci, per_core * cores)
             sub = batch.select(np.arange(n_cpu))
             bounds = np.linspace(0, n_cpu, cores + 1).astype(int)
@@ -157,33 +286,33 @@ def main():
             parity = {"n_checked": int(n_cpu), "max_abs_dposterior": m["max_dpost"], "max_abs_dmap_vaf": m["max_dvaf"],
                       "frac_within_1e-6": m["frac_within"], "exact_event_ties": m["n_ties"], "vs": "CPU restatement of the reference (oracle/)"}
             cpu = {"value": n_cpu / t_cpu, "unit": "loci/s", "cores": cores, "kind": "port",
-                   "sample": "first %d loci of the same batch, %d threads x contiguous shards, %.1f s" % (n_cpu, cores, t_cpu)}
+                   "sample": "first %d loci of the same batch, %d threads x contiguous shards, %.1f s" % (n_cpu, cores, t_cpu),
+                   "note": "fidelity oracle (reference operation order, log-space transcendentals, caches), not a tuned CPU implementation"}
         # posteriors must be normalised at full size (size-independent property)
         ps = np.exp(res.ln_posterior)
         ok = (res.status & 0xF) == 0
         norm_err = float(np.abs(ps[ok].sum(axis=1) - 1.0).max()) if ok.any() else None
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-        if os.path.exists(tpath):
-            with open(tpath) as fh:
-                tj = json.load(fh)
-            if tj.get("n_loci") == n_loci:
-                traffic = tj.get("hbm_bytes_per_launch")
+        terms_per_launch = n_terms / max(1, args.steps)
+        tflops = terms_per_launch * FLOP_PER_TERM / (last_ms * 1e-3) / 1e12
         line = {
             "metric": "candidate loci/sec (whole node)", "value": n_total * args.steps / elapsed, "unit": "loci/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %s, %d loci/GPU, mean depth %.0fx/sample" % (args.workload, cfg.name, n_loci, cfg.depth),
-                       "scenario_events": cfg.scenario.event_names, "parallelism": "loci sharded x%d, all-gather of result records" % world,
+                       "scenario_events": cfg.scenario.event_names,
+                       "parallelism": "loci sharded x%d, all-gather of the full result records (posteriors, marginal, MAP VAFs, bias codes, best event, status)" % world,
                        "gen_seconds": round(t_gen, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": last_ms,
-                         "note": "path is f64-VALU/latency bound, not bandwidth bound (SURVEY §8d); see valu"},
-            "valu": {"pileup_evals_per_launch": n_eval // max(1, args.steps), "obs_terms_per_launch": n_terms // max(1, args.steps),
-                     "obs_terms_per_s": (n_terms / max(1, args.steps)) / (last_ms * 1e-3),
-                     "f64_valu_peak_tflops": F64_VALU_PEAK_TFLOPS},
+                         "traffic": traffic_for(args.workload, n_loci, engine.build_id()),
+                         "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": last_ms,
+                         "note": "path is f64-VALU bound, not bandwidth bound (SURVEY §8d): see valu",
+                         "valu": {"pileup_evals_per_launch": n_eval // max(1, args.steps), "obs_terms_per_launch": int(terms_per_launch),
+                                  "terms_per_s": terms_per_launch / (last_ms * 1e-3), "flop_per_term": FLOP_PER_TERM,
+                                  "achieved_tflops": tflops, "peak_tflops": F64_VALU_PEAK_TFLOPS, "frac": tflops / F64_VALU_PEAK_TFLOPS}},
+            "with_afd": with_afd,
             "cpu_baseline": cpu, "parity": parity, "posterior_normalisation_max_err": norm_err,
             "status_counts": {str(k): int(v) for k, v in zip(*np.unique(res.status, return_counts=True))},
+            "build_id": engine.build_id(),
         }
         print(json.dumps(line))
     if world > 1:

@@ -20,14 +20,17 @@ def _worker(rank, world, port, n_loci, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle
     from varlociraptor_amd import synth
-    from varlociraptor_amd.dist import all_gather_records, pack_records, shard_range
+    from types import SimpleNamespace
+    from varlociraptor_amd.dist import all_gather_records, pack_full_records, shard_range
     cfg = synth.config2()
     batch = synth.generate(cfg, n_loci)
     lo, hi = shard_range(n_loci, rank, world)
     res = oracle.call(cfg.scenario, batch, begin=lo, end=hi)
-    rec = pack_records(torch.from_numpy(res.ln_posterior[lo:hi]), torch.from_numpy(res.map_vaf[lo:hi]),
-                       torch.from_numpy(res.status[lo:hi].astype(np.int64)))
-    full = all_gather_records(rec, n_loci, world)
+    # the record bench.py and the CLI send: every fixed-size field of the result (stand-in for engine.DeviceResults)
+    shard = SimpleNamespace(ln_posterior=torch.from_numpy(res.ln_posterior[lo:hi]), ln_marginal=torch.from_numpy(res.ln_marginal[lo:hi]),
+                            map_vaf=torch.from_numpy(res.map_vaf[lo:hi]), map_bias=torch.from_numpy(res.map_bias[lo:hi]),
+                            best_event=torch.from_numpy(res.best_event[lo:hi]), status=torch.from_numpy(res.status[lo:hi].astype(np.int64)))
+    full = all_gather_records(pack_full_records(shard), n_loci, world)
     if rank == 0:
         q.put(full.numpy())
     dist.barrier()
@@ -54,10 +57,15 @@ def test_two_rank_gather_matches_single_process(n_loci):
     batch = synth.generate(cfg, n_loci)
     ref = oracle.call(cfg.scenario, batch)
     n_out = cfg.scenario.n_out
-    assert full.shape == (n_loci, n_out + 1 + 1)
-    assert np.array_equal(full[:, :n_out], ref.ln_posterior)
-    assert np.array_equal(full[:, n_out:n_out + 1], ref.map_vaf, equal_nan=True)
-    assert np.array_equal(full[:, -1].astype(np.uint32), ref.status)
+    from varlociraptor_amd.dist import unpack_full_records
+    assert full.shape == (n_loci, n_out + 1 + 1 + 6 + 2)
+    got = unpack_full_records(full, n_out, 1)
+    assert np.array_equal(got["ln_posterior"], ref.ln_posterior)
+    assert np.array_equal(got["ln_marginal"], ref.ln_marginal, equal_nan=True)
+    assert np.array_equal(got["map_vaf"], ref.map_vaf, equal_nan=True)
+    assert np.array_equal(got["map_bias"], ref.map_bias)
+    assert np.array_equal(got["best_event"], ref.best_event)
+    assert np.array_equal(got["status"], ref.status)
 
 
 def _worker_full(rank, world, port, n_loci, q):

@@ -119,3 +119,24 @@ def test_config2_full_size_parity(oracle):
     # probabilities then differ only by rounding and the reported bias symbol is arbitrary (AF = 0 either way)
     n_label = int((got.map_bias != ref.map_bias).any(axis=1).sum())
     assert n_label <= 5, n_label
+
+
+def test_breakend_mates_sharing_a_pileup_get_identical_results():
+    """config5 carries SV/breakend loci whose mate record shares the pileup (calling.rs:569-580: the reference evaluates
+    one of them and reuses the result, 726-741, 820-839); evaluated twice by the engine they must agree bit for bit, and
+    observations without strand information (Strand::None) are part of those pileups."""
+    import numpy as np
+    from varlociraptor_amd import abi, engine, synth
+    cfg = synth.config5()
+    b = synth.generate(cfg, 3000, seed=77)
+    g = b.truth["group"]
+    mates = np.nonzero(g != np.arange(b.n_loci))[0]
+    assert len(mates) > 20
+    strand = (b.columns["flags"] >> abi.F_STRAND_SHIFT) & 3
+    assert (strand == abi.STRAND_NONE).sum() > 100
+    plan = engine.Plan(cfg.scenario)
+    got = plan.call_host(b)
+    plan.close()
+    for f in ("ln_posterior", "map_vaf", "map_bias", "best_event", "status"):
+        a = getattr(got, f)
+        assert np.array_equal(a[mates], a[g[mates]], equal_nan=True), f

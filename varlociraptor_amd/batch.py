@@ -57,12 +57,12 @@ class PileupBatch:
         S = self.n_samples
         off = self.obs_offset.astype(np.int64)
         starts = off[loci * S]
-        ends = off[loci * S + S]
-        idx = np.concatenate([np.arange(s, e) for s, e in zip(starts, ends)]) if len(loci) else np.zeros(0, np.int64)
-        new_off = [0]
-        for l in loci:
-            for s in range(S):
-                new_off.append(new_off[-1] + int(off[l * S + s + 1] - off[l * S + s]))
+        totals = off[loci * S + S] - starts
+        # rows of a locus are contiguous: one arange over the total, shifted per locus (no Python loop over loci)
+        first = np.concatenate(([0], np.cumsum(totals)))[:-1]
+        idx = np.repeat(starts - first, totals) + np.arange(int(totals.sum()), dtype=np.int64)
+        lens = np.diff(off).reshape(self.n_loci, S)[loci]
+        new_off = np.concatenate(([0], np.cumsum(lens.ravel())))
         cols = {k: v[idx] for k, v in self.columns.items()}
         loc = {k: v[loci] for k, v in self.locus.items()}
         return PileupBatch(S, np.asarray(new_off, np.uint32), cols, loc)

@@ -26,6 +26,29 @@ def pack_records(ln_posterior, map_vaf, status):
     return torch.cat([ln_posterior, map_vaf, status.to(torch.float64).unsqueeze(1)], dim=1).contiguous()
 
 
+def pack_full_records(out):
+    """[n, n_out + 1 + S + 6 + 2] float64 record per locus from an engine.DeviceResults: ln posteriors, ln marginal, MAP
+    VAFs, the six bias codes, best event and status (small integers travel bit-exactly as float64) — everything the calls
+    writer needs besides the ragged AFD lists."""
+    import torch
+    f = torch.float64
+    return torch.cat([out.ln_posterior, out.ln_marginal.unsqueeze(1), out.map_vaf, out.map_bias.to(f),
+                      out.best_event.to(f).unsqueeze(1), out.status.to(f).unsqueeze(1)], dim=1).contiguous()
+
+
+def unpack_full_records(rec, n_out: int, n_samples: int):
+    """Inverse of pack_full_records on a host array: dict of numpy arrays."""
+    rec = np.asarray(rec)
+    o = 0
+    res = {"ln_posterior": rec[:, o:o + n_out]}; o += n_out
+    res["ln_marginal"] = rec[:, o]; o += 1
+    res["map_vaf"] = rec[:, o:o + n_samples]; o += n_samples
+    res["map_bias"] = rec[:, o:o + 6].astype(np.uint8); o += 6
+    res["best_event"] = rec[:, o].astype(np.int32); o += 1
+    res["status"] = rec[:, o].astype(np.int64).astype(np.uint32)
+    return res
+
+
 def all_gather_records(records, n_total: int, world: int):
     """All-gather equally sized per-rank record blocks (padded to ceil(n/world) rows) and trim to n_total rows."""
     import torch

@@ -242,9 +242,14 @@ class DeviceBatch:
 
 
 class DeviceResults:
-    def __init__(self, n_loci, n_out, n_samples, device="cuda:0"):
+    def __init__(self, n_loci, n_out, n_samples, device="cuda:0", afd_capacity=0):
         import torch
         self.n_loci, self.n_out, self.n_samples = n_loci, n_out, n_samples
+        self.afd_capacity = afd_capacity
+        if afd_capacity:
+            self.afd_count = torch.zeros((n_loci, n_samples), dtype=torch.int32, device=device)
+            self.afd_vaf = torch.empty((n_loci, n_samples, afd_capacity), dtype=torch.float64, device=device)
+            self.afd_lnprob = torch.empty((n_loci, n_samples, afd_capacity), dtype=torch.float64, device=device)
         self.ln_posterior = torch.empty((n_loci, n_out), dtype=torch.float64, device=device)
         self.ln_marginal = torch.empty(n_loci, dtype=torch.float64, device=device)
         self.map_vaf = torch.empty((n_loci, n_samples), dtype=torch.float64, device=device)
@@ -261,6 +266,11 @@ class DeviceResults:
         r.map_bias = self.map_bias.data_ptr()
         r.best_event = self.best_event.data_ptr()
         r.status = self.status.data_ptr()
+        if self.afd_capacity:
+            r.afd_capacity = self.afd_capacity
+            r.afd_count = self.afd_count.data_ptr()
+            r.afd_vaf = self.afd_vaf.data_ptr()
+            r.afd_lnprob = self.afd_lnprob.data_ptr()
         return r
 
     def to_host(self) -> CallResults:

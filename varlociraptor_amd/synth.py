@@ -63,6 +63,10 @@ class SynthConfig:
     softclip: float = 0.03
     alt_locus_fraction: float = 0.02
     empty_fraction: float = 0.0      # loci with an empty pileup in one sample (edge case)
+    strand_none_fraction: float = 0.0    # observations of SV/breakend loci without strand information (Strand::None:
+                                         # realignment/mod.rs:237,387-396 keeps the strand of informative reads only)
+    breakend_pair_fraction: float = 0.0  # SV loci followed by a mate record that shares their pileup (breakend groups,
+                                         # calling.rs:569-580,726-741): truth["group"] gives the shared id
 
 
 def config2() -> SynthConfig:
@@ -121,6 +125,7 @@ def config5() -> SynthConfig:
     return SynthConfig(
         name="pedigree-60x", config_id=5, scenario=pedigree_scenario(), depth=60.0,
         type_mix={abi.VT_SNV: 0.65, abi.VT_INDEL: 0.25, abi.VT_SV: 0.10},
+        strand_none_fraction=0.15, breakend_pair_fraction=0.5,
         classes=[("absent", 0.55, (z, z, z, z)), ("inherited_father", 0.15, (h, h, z, z)), ("inherited_mother", 0.10, (z, z, h, h)),
                  ("inherited_both", 0.08, ((1.0, 1.0), h, h, h)), ("denovo_child", 0.07, (h, z, z, z)), ("denovo_sibling", 0.05, (z, z, z, h))],
     )
@@ -231,6 +236,11 @@ def generate(cfg: SynthConfig, n_loci: int, seed: Optional[int] = None, chunk: i
     position = np.where((ak == 4) & alt_like, major_pos[pile], position)
     readpos_major = position == major_pos[pile]
     # SNV reads whose evidence is uninformative lose strand info (snv.rs:118-124): not generated here
+    rng2 = np.random.Generator(np.random.PCG64([seed, chunk, 7]))  # features added later draw from their own stream
+    if cfg.strand_none_fraction > 0:
+        none = (vt[loc] == abi.VT_SV) & (rng2.random(N) < cfg.strand_none_fraction)
+        strand = np.where(none, abi.STRAND_NONE, strand)
+        pdo = np.where(none, -np.inf, pdo)
     altloc = np.full(N, abi.ALTLOCUS_NONE, np.uint32)
     al = has_altloc[loc]
     r = rng.random(N)
@@ -276,5 +286,14 @@ def generate(cfg: SynthConfig, n_loci: int, seed: Optional[int] = None, chunk: i
     locus = {"locus_flags": lf, "variant_type": vt.astype(np.uint8),
              "ref_base": np.where(is_snv, refb, 0).astype(np.uint8), "alt_base": np.where(is_snv, altb, 0).astype(np.uint8)}
     b = PileupBatch(S, obs_offset.astype(np.uint32), cols, locus)
-    b.truth = {"class": cls, "vaf": vaf, "class_names": [c[0] for c in cfg.classes]}
+    group = np.arange(L)
+    if cfg.breakend_pair_fraction > 0 and L > 1:
+        # the mate record of a breakend shares the pileup of its partner: locus k + 1 becomes a copy of locus k
+        first = np.nonzero((vt[:-1] == abi.VT_SV) & (rng2.random(L - 1) < cfg.breakend_pair_fraction))[0]
+        first = first[np.concatenate(([True], np.diff(first) > 1))] if len(first) else first  # no chains
+        src = np.arange(L)
+        src[first + 1] = first
+        b = b.select(src)
+        cls, vaf, group = cls[src], vaf[src], src
+    b.truth = {"class": cls, "vaf": vaf, "class_names": [c[0] for c in cfg.classes], "group": group}
     return b
