@@ -340,6 +340,11 @@ int vlr_realign_batch(int device, const vlr_realign_batch_desc* pairs, double* l
 /* Host pointers: stages the sequences, runs the kernel, returns when ln_prob is filled. */
 int vlr_realign_batch_host(int device, const vlr_realign_batch_desc* pairs, double* ln_prob);
 
+/* Diagnostics: the DEVICE build of the platform-independent decision arithmetic (include/vlr_detmath.h; which = 0 det_exp,
+ * 1 det_log1p_pos, 2 det_log2_ratio(a, b), 3 det_exp2) and of the kernel's mantissa logarithm (4), element-wise on host
+ * arrays.  tests/test_gpu_math.py requires 0-3 to be bit-identical to the host build of the same header. */
+int vlr_selftest_math(int device, int which, const double* a, const double* b, double* out, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,8 +123,11 @@ VLR_HD inline void det_log2_parts(double x, int* e_out, double* frac_out) {
 /* 2^v: exact for integral v, otherwise the deterministic exp of v ln 2 (projection of a VAF through an l2fc
  * predicate, log2_fold_change.rs:58) */
 VLR_HD inline double det_exp2(double v) {
-    if (v == __builtin_rint(v) && v > -1000.0 && v < 1000.0) return __builtin_ldexp(1.0, (int)v);
-    return det_exp(v * 0x1.62e42fefa39efp-1);
+    if (!(v > -1000.0 && v < 1000.0)) return det_exp(v * 0x1.62e42fefa39efp-1);
+    /* 2^v = 2^k 2^f with k = rint(v), |f| <= 1/2: the rounding of f ln 2 costs half an ulp instead of |v| ulps */
+    const double k = __builtin_rint(v), f = v - k;
+    if (f == 0.0) return __builtin_ldexp(1.0, (int)k);
+    return __builtin_ldexp(det_exp(f * 0x1.62e42fefa39efp-1), (int)k);
 }
 VLR_HD inline double det_log2_ratio(double a, double b) {
     if (a != a || b != b) return a + b;

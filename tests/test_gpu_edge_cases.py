@@ -332,14 +332,18 @@ def test_variant_specific_prior_overrides(oracle):
 
 
 @pytest.mark.parametrize("name", ["test_moelder_floatisnan", "test_mapq_meth", "test_hiv_vaf_higher_than_expected", "test_prinz_af_scan",
-                                  "test_prinz_call_meth_1", "test_prinz_call_meth_2", "test_prinz_pacbio_zero", "test_uzuner_only_N"])
+                                  "test_prinz_call_meth_1", "test_prinz_call_meth_2", "test_prinz_pacbio_zero", "test_uzuner_only_N",
+                                  "test_false_negative_indel_call", "test_uzuner_clonal_1", "test_uzuner_clonal_2", "test_uzuner_clonal_3",
+                                  "test_uzuner_fp_snv_on_ins", "test_alt_locus_mapq_only"])
 def test_reference_testcase_fixtures_parity(oracle, golden_dir, name):
-    """The recorded v15 observations of eight reference testcases (up to 2991 observations in one pileup = 72 kB of
-    coefficients in LDS; SNV and <METH> records): GPU == oracle."""
+    """The recorded v15 observations of all fourteen format-v15 reference testcases (up to 2991 observations in one pileup =
+    72 kB of coefficients in LDS; SNV, MNV, deletion and <METH> records): GPU == oracle.  `test_alt_locus_mapq_only` is a
+    three-sample scenario (contamination, l2fc events, sex-specific ploidies) whose testcase bundles the record of one
+    sample: it is used for all three."""
     from varlociraptor_amd import cli, obsfmt
     d = os.path.join(golden_dir, "testcases", name)
-    sc = cli.scenario_from_yaml(os.path.join(d, "scenario.yaml"))
-    batch, _ = obsfmt.read_observation_vcf([os.path.join(d, "observations.vcf")])
+    sc = cli.scenario_from_yaml(os.path.join(d, "scenario.yaml"), contig="19" if name == "test_alt_locus_mapq_only" else "all")
+    batch, _ = obsfmt.read_observation_vcf([os.path.join(d, "observations.vcf")] * len(sc.sample_names))
     plan = engine.Plan(sc)
     plan.set_max_obs(int(batch.depth().sum(axis=1).max()))
     got = plan.call_host(batch)

@@ -117,3 +117,48 @@ def test_reference_testcases_expected_allele_frequency(oracle, golden_dir, name,
     res = oracle.call(sc, batch)
     assert cond(float(res.map_vaf[0, 0])), res.map_vaf[0]
     assert (res.status[0] & 0xF) == 0
+
+
+# The remaining six format-v15 testcases of the reference.  Five of them document preprocessing (BAM-side)
+# bugs: their candidates.vcf carries the observations recorded BEFORE the fix, the `expected` condition of testcase.yaml
+# describes the call AFTER it — on the recorded observations the condition is false by construction (that is what the
+# testcase was filed for).  They still are real pileups (MNV, deletion, SNV-on-insertion) and pin the oracle's numbers:
+# a change of the restatement shows up here.  PROB_* conditions are PHRED-scaled (runner/common/mod.rs:332-393).
+PRE_FIX_TESTCASES = [
+    # name, n_obs, P(absent), P(present), MAP VAF, condition of testcase.yaml evaluated on (vaf, phred_present)
+    ("test_false_negative_indel_call", 170, 0.534801, 0.465199, 0.0, lambda v, q: v > 0.0 and q <= 0.05),
+    ("test_uzuner_clonal_1", 102, 0.0, 1.0, 0.9416731659542111, lambda v, q: v == 1.0),
+    ("test_uzuner_clonal_2", 96, 0.993248, 0.003952, 0.0, lambda v, q: v == 1.0),
+    ("test_uzuner_clonal_3", 110, 0.996672, 0.003328, 0.0, lambda v, q: v == 1.0),
+    ("test_uzuner_fp_snv_on_ins", 59, 0.0, 1.0, 1.0, lambda v, q: v == 0.0),
+]
+
+
+@pytest.mark.parametrize("name,n_obs,p_absent,p_present,vaf,cond", PRE_FIX_TESTCASES, ids=[t[0] for t in PRE_FIX_TESTCASES])
+def test_reference_testcases_recorded_before_their_fix(oracle, golden_dir, name, n_obs, p_absent, p_present, vaf, cond):
+    sc, batch, sites = _testcase(name, golden_dir)
+    assert batch.depth().tolist() == [[n_obs]]
+    res = oracle.call(sc, batch)
+    assert (res.status[0] & 0xF) == 0
+    p = np.exp(res.ln_posterior[0])
+    assert p[0] == pytest.approx(p_absent, abs=2e-6) and p[1] == pytest.approx(p_present, abs=2e-6)
+    assert res.map_vaf[0, 0] == pytest.approx(vaf, abs=1e-12)
+    phred_present = -10.0 * res.ln_posterior[0, 1] / np.log(10.0)
+    assert not cond(float(res.map_vaf[0, 0]), float(phred_present))  # the pre-fix observations still show the reported defect
+
+
+def test_reference_testcase_alt_locus_mapq_only_scenario(oracle, golden_dir):
+    """Three samples (normal, tumor_pre, tumor_post; contamination, l2fc events, sex-specific species ploidies, rates written
+    as `1e-3`), but the testcase bundles the observation record of ONE sample (174 observations): its `PROB_ARTIFACT < 0.5`
+    expectation needs all three and cannot be evaluated.  What it does anchor: the scenario front-end accepts the
+    reference's YAML and the oracle evaluates the three-sample tree (same record for every sample) without error."""
+    from varlociraptor_amd import cli, obsfmt
+    d = os.path.join(golden_dir, "testcases", "test_alt_locus_mapq_only")
+    sc = cli.scenario_from_yaml(os.path.join(d, "scenario.yaml"), contig="19")
+    assert sc.sample_names == ["normal", "tumor_post", "tumor_pre"]
+    assert sc.event_names == ["germline", "somatic_normal", "somatic_tumor_equal", "somatic_tumor_post_decreased", "somatic_tumor_post_increased"]
+    batch, _ = obsfmt.read_observation_vcf([os.path.join(d, "observations.vcf")] * 3)
+    assert batch.depth().tolist() == [[174, 174, 174]]
+    res = oracle.call(sc, batch)
+    assert (res.status[0] & 0xF) == 0
+    assert abs(np.exp(res.ln_posterior[0]).sum() - 1.0) < 1e-9  # clean events + the artifact column

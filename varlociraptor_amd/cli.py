@@ -25,6 +25,11 @@ def _contig_value(defn, contig: str, what: str):
     return defn
 
 
+def _num(v):
+    """YAML 1.1 (PyYAML) reads `1e-3` as a string, serde_yaml (the reference) as a float: accept both."""
+    return None if v is None else float(v)
+
+
 def scenario_from_yaml(path: str, contig: str = "all") -> Scenario:
     """Scenario as `Caller::configure_model` sees it on `contig` (calling.rs:632-718): contig maps of universes and
     ploidies and sex-specific species ploidies (grammar/mod.rs:314-345) are resolved here."""
@@ -35,8 +40,8 @@ def scenario_from_yaml(path: str, contig: str = "all") -> Scenario:
     sp = y.get("species") or None
     if sp:
         vf = sp.get("variant-fractions", {}) or {}
-        species = Species(heterozygosity=sp.get("heterozygosity"), germline_mutation_rate=sp.get("germline-mutation-rate"),
-                          somatic_effective_mutation_rate=sp.get("somatic-effective-mutation-rate"), ploidy=None,
+        species = Species(heterozygosity=_num(sp.get("heterozygosity")), germline_mutation_rate=_num(sp.get("germline-mutation-rate")),
+                          somatic_effective_mutation_rate=_num(sp.get("somatic-effective-mutation-rate")), ploidy=None,
                           fraction_indel=vf.get("indel", 0.0125), fraction_mnv=vf.get("mnv", 0.001), fraction_sv=vf.get("sv", 0.01))
     samples: Dict[str, Sample] = {}
     for name, sd in y["samples"].items():
@@ -71,8 +76,8 @@ def scenario_from_yaml(path: str, contig: str = "all") -> Scenario:
         samples[name] = Sample(
             resolution=float(sd.get("resolution", 0.01)), universe=universe,
             contamination=Contamination(cont["by"], float(cont["fraction"])) if cont else None, ploidy=ploidy,
-            somatic_effective_mutation_rate=sd.get("somatic-effective-mutation-rate"),
-            germline_mutation_rate=sd.get("germline-mutation-rate"), inheritance=inheritance)
+            somatic_effective_mutation_rate=_num(sd.get("somatic-effective-mutation-rate")),
+            germline_mutation_rate=_num(sd.get("germline-mutation-rate")), inheritance=inheritance)
     return Scenario(samples, dict(y["events"]), species=species, expressions=dict(y.get("expressions") or {}))
 
 

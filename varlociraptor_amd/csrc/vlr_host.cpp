@@ -1136,4 +1136,23 @@ int vlr_realign_batch_host(int device, const vlr_realign_batch_desc* b, double* 
     return rc;
 }
 
+// ---- diagnostics (tests/test_gpu_math.py)
+extern "C" int vlr_launch_selftest_math(int which, const double* a, const double* b, double* out, long long n, void* stream);
+int vlr_selftest_math(int device, int which, const double* a, const double* b, double* out, int64_t n) {
+    if (n < 0 || (n > 0 && (!a || !out)) || which < 0 || which > 4) return fail(VLR_ERR_INVALID_ARGUMENT, "bad argument");
+    if (n == 0) return VLR_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) return fail(VLR_ERR_NO_DEVICE, "no HIP device %d", device);
+    HIP_TRY(hipSetDevice(device));
+    double* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, (size_t)n * 24));
+    int rc = VLR_OK;
+    if (hipMemcpy(d, a, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d + n, b ? b : a, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess) rc = fail(VLR_ERR_HIP, "copy failed");
+    if (rc == VLR_OK && vlr_launch_selftest_math(which, d, d + n, d + 2 * n, (long long)n, nullptr) != 0) rc = fail(VLR_ERR_HIP, "launch failed");
+    if (rc == VLR_OK && hipMemcpy(out, d + 2 * n, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(VLR_ERR_HIP, "copy back failed");
+    (void)hipFree(d);
+    return rc;
+}
+
 }  // extern "C"

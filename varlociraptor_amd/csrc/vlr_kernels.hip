@@ -3161,6 +3161,28 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
 
 }  // namespace vlr
 
+// ---- diagnostics: the device build of the decision arithmetic (include/vlr_detmath.h) and of ln_mantissa, element-wise
+namespace vlr {
+__global__ void vlr_selftest_math_kernel(int which, const double* a, const double* b, double* out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double r;
+    switch (which) {
+        case 0: r = vlr_det::det_exp(a[i]); break;
+        case 1: r = vlr_det::det_log1p_pos(a[i]); break;
+        case 2: r = vlr_det::det_log2_ratio(a[i], b[i]); break;
+        case 3: r = vlr_det::det_exp2(a[i]); break;
+        default: r = ln_mantissa(a[i]); break;
+    }
+    out[i] = r;
+}
+}  // namespace vlr
+extern "C" int vlr_launch_selftest_math(int which, const double* a, const double* b, double* out, long long n, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(vlr::vlr_selftest_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, which, a, b, out, n);
+    return (int)hipGetLastError();
+}
+
 // host-callable launcher (used by vlr_host.cpp)
 extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out,
                                       int n_univ, int n_samples, int max_obs, int range_depth, void* stream) {
