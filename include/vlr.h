@@ -340,6 +340,18 @@ int vlr_realign_batch(int device, const vlr_realign_batch_desc* pairs, double* l
 /* Host pointers: stages the sequences, runs the kernel, returns when ln_prob is filled. */
 int vlr_realign_batch_host(int device, const vlr_realign_batch_desc* pairs, double* ln_prob);
 
+/* ------------------------------------------------------------------------------------------------
+ * Bayesian FDR control: the threshold search of `filter-calls control-fdr`
+ * (/root/reference/src/filtration/fdr.rs:107-141): sort the posterior (ln) probabilities of the chosen events in
+ * descending order, PEP = 1 - p (with smart != 0 the probabilities are first converted to 1 - p: they are PROB_ABSENT
+ * [+ PROB_ARTIFACT] sums, fdr.rs:96-114), expected FDR = running mean of the PEPs (bio expected_fdr), threshold = probability of
+ * the last entry whose expected FDR is <= alpha and whose PEP differs from its predecessor's.  ln_prob: host array of n
+ * values (utils::collect_prob_dist, utils/mod.rs:236-270, any order).  *status: VLR_FDR_EMPTY (no values: the reference's
+ * None), VLR_FDR_VALUE (*threshold set), VLR_FDR_LN_ONE (already the best entry exceeds alpha: threshold = ln 1),
+ * VLR_FDR_NONE (no admissible entry: None).  The filtering pass (utils/mod.rs:288-374) stays with the caller. */
+enum { VLR_FDR_EMPTY = 0, VLR_FDR_VALUE = 1, VLR_FDR_LN_ONE = 2, VLR_FDR_NONE = 3 };
+int vlr_fdr_threshold(int device, const double* ln_prob, int64_t n, int smart, double alpha_ln, double* threshold, int* status);
+
 /* Diagnostics: the DEVICE build of the platform-independent decision arithmetic (include/vlr_detmath.h; which = 0 det_exp,
  * 1 det_log1p_pos, 2 det_log2_ratio(a, b), 3 det_exp2) and of the kernel's mantissa logarithm (4), element-wise on host
  * arrays.  tests/test_gpu_math.py requires 0-3 to be bit-identical to the host build of the same header. */

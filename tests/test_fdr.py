@@ -44,8 +44,46 @@ def test_unknown_events_rejected():
 
 
 @pytest.mark.gpu
-def test_threshold_on_device_matches_cpu():
+@pytest.mark.parametrize("fixture,events,alpha,local,smart,retain,vartype,expected", CASES)
+def test_reference_fdr_counts_on_device(fixture, events, alpha, local, smart, retain, vartype, expected):
+    """The eight reference count cases with the threshold search on the GPU (vlr_fdr_threshold)."""
+    r = BcfReader(os.path.join(RES, fixture.replace("test_fdr_", "") + ".bcf"))
+    recs = list(r)
+    tags = [l.split("ID=")[1].split(",")[0] for l in r.header_lines if "ID=PROB_" in l]
+    kept = fdr.control_fdr(recs, events, alpha, vartype=vartype, local=local, smart=smart, smart_retain_artifacts=retain, header_tags=tags, device="cuda")
+    host = fdr.control_fdr(recs, events, alpha, vartype=vartype, local=local, smart=smart, smart_retain_artifacts=retain, header_tags=tags)
+    assert [id(k) for k in kept] == [id(k) for k in host]
+    if expected > 50:
+        assert abs(len(kept) - expected) <= 1
+    else:
+        assert len(kept) == expected
+
+
+@pytest.mark.gpu
+def test_device_threshold_matches_host_restatement():
+    """vlr_fdr_threshold vs the host restatement on the reference's ev_2 distribution and on random distributions of many
+    sizes (bitonic padding, LDS / HBM merge phases, ties, smart conversion, all four status codes)."""
     import math
+    import numpy as np
     r = BcfReader(os.path.join(RES, "ev_2.bcf"))
-    desc = fdr.collect_prob_dist(list(r), ["PROB_SOMATIC"], DEL_1_30)[::-1]
-    assert fdr.fdr_threshold(desc, math.log(0.05), device="cuda") == pytest.approx(fdr.fdr_threshold(desc, math.log(0.05)), abs=1e-12)
+    asc = fdr.collect_prob_dist(list(r), ["PROB_SOMATIC"], DEL_1_30)
+    for alpha in (0.05, 0.2, 0.001):
+        assert fdr.fdr_threshold_device(asc, math.log(alpha)) == pytest.approx(fdr.fdr_threshold(asc[::-1], math.log(alpha)), abs=1e-12)
+    rng = np.random.default_rng(4)
+    for n in (1, 2, 3, 100, 2047, 2048, 2049, 5000, 70000, 300001):
+        p = np.log(rng.beta(6.0, 1.0, n))
+        p[rng.random(n) < 0.05] = 0.0                                   # certain calls
+        p = np.round(p, 2) if n % 2 else p                              # ties
+        desc = np.sort(p)[::-1]
+        for smart in (False, True):
+            d = desc
+            if smart:
+                with np.errstate(divide="ignore"):
+                    d = np.where(desc < -0.693, np.log1p(-np.exp(desc)), np.log(-np.expm1(desc)))
+            for alpha in (0.3, 0.05, 1e-6):
+                want = fdr.fdr_threshold(list(d), math.log(alpha))
+                got = fdr.fdr_threshold_device(rng.permutation(p), math.log(alpha), smart=smart)
+                assert (got is None) == (want is None), (n, smart, alpha, got, want)
+                if want is not None:
+                    assert got == pytest.approx(want, abs=1e-12), (n, smart, alpha)
+    assert fdr.fdr_threshold_device([], math.log(0.05)) is None

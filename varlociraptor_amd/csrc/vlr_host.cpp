@@ -1136,6 +1136,55 @@ int vlr_realign_batch_host(int device, const vlr_realign_batch_desc* b, double* 
     return rc;
 }
 
+// ---- Bayesian FDR threshold (vlr_fdr.hip)
+extern "C" int vlr_launch_fdr(double* keys, long long n, long long npad, int smart, double alpha_ln, double* work, long long* best, double* fdr0, void* stream);
+
+int vlr_fdr_threshold(int device, const double* ln_prob, int64_t n, int smart, double alpha_ln, double* threshold, int* status) {
+    if (n < 0 || (n > 0 && !ln_prob) || !threshold || !status) return fail(VLR_ERR_INVALID_ARGUMENT, "null argument");
+    *threshold = 0.0;
+    *status = VLR_FDR_EMPTY;
+    if (n == 0) return VLR_OK;
+    for (int64_t i = 0; i < n; ++i)
+        if (ln_prob[i] != ln_prob[i] || ln_prob[i] > 0.0) return fail(VLR_ERR_INVALID_ARGUMENT, "ln_prob[%lld] is not a log probability", (long long)i);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) return fail(VLR_ERR_NO_DEVICE, "no HIP device %d (the engine has no CPU path)", device);
+    HIP_TRY(hipSetDevice(device));
+    long long npad = 2048;
+    while (npad < n) npad <<= 1;
+    const long long nb = (n + 1023) / 1024;
+    const size_t words = (size_t)npad + 3 * (size_t)n + (size_t)nb + 4;
+    double* d = nullptr;
+    if (hipMalloc((void**)&d, words * 8) != hipSuccess) { (void)hipGetLastError(); return fail(VLR_ERR_OUT_OF_MEMORY, "hipMalloc(%zu)", words * 8); }
+    int rc = VLR_OK;
+    do {
+        std::vector<double> pad((size_t)(npad - n), -std::numeric_limits<double>::infinity());
+        double* keys = d;
+        double* work = d + npad;
+        long long* best = (long long*)(work + 3 * (size_t)n + nb);
+        double* fdr0 = (double*)(best + 1);
+        long long zero = 0;
+        if (hipMemcpy(keys, ln_prob, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess ||
+            (npad > n && hipMemcpy(keys + n, pad.data(), pad.size() * 8, hipMemcpyHostToDevice) != hipSuccess) ||
+            hipMemcpy(best, &zero, 8, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(VLR_ERR_HIP, "staging copy failed"); break; }
+        hipError_t e = (hipError_t)vlr_launch_fdr(keys, (long long)n, npad, smart ? 1 : 0, alpha_ln, work, best, fdr0, nullptr);
+        if (e != hipSuccess) { rc = fail(VLR_ERR_HIP, "fdr kernels: %s", hipGetErrorString(e)); break; }
+        long long b = 0;
+        double f0 = 0.0;
+        if (hipMemcpy(&b, best, 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&f0, fdr0, 8, hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = fail(VLR_ERR_HIP, "result copy failed"); break;
+        }
+        if (f0 > alpha_ln) { *status = VLR_FDR_LN_ONE; *threshold = 0.0; }       // fdr.rs:127-128
+        else if (b == 0) { *status = VLR_FDR_NONE; }
+        else {
+            double pv = 0.0;
+            if (hipMemcpy(&pv, work + (b - 1), 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(VLR_ERR_HIP, "result copy failed"); break; }
+            *status = VLR_FDR_VALUE; *threshold = pv;
+        }
+    } while (0);
+    (void)hipFree(d);
+    return rc;
+}
+
 // ---- diagnostics (tests/test_gpu_math.py)
 extern "C" int vlr_launch_selftest_math(int which, const double* a, const double* b, double* out, long long n, void* stream);
 int vlr_selftest_math(int device, int which, const double* a, const double* b, double* out, int64_t n) {

@@ -2,9 +2,9 @@
 
 Mirrors `filter-calls control-fdr` (reference src/filtration/fdr.rs:36-158, src/utils/mod.rs:169-374; Müller,
 Parmigiani & Rice 2006): collect the posterior of the chosen events per variant, sort, expected FDR = running mean of
-the posterior error probabilities, threshold at alpha, then filter.  The O(n log n) part (sort + log-cumsum) runs as
-torch ops on the given device (the GPU when the calls came from the engine); record typing follows
-utils/collect_variants.rs:44-304.
+the posterior error probabilities, threshold at alpha, then filter.  The O(n log n) part — sort, PEP prefix sums and the
+boundary search — has a HIP implementation behind the C ABI (`vlr_fdr_threshold`, csrc/vlr_fdr.hip; `device="cuda"`) next
+to the host restatement used by the CPU suite; record typing follows utils/collect_variants.rs:44-304.
 """
 from __future__ import annotations
 
@@ -128,9 +128,28 @@ def collect_prob_dist(records: Iterable[dict], tags: Sequence[str], vartype) -> 
     return dist
 
 
+def fdr_threshold_device(prob_dist: Sequence[float], alpha_ln: float, smart: bool = False, device: int = 0) -> Optional[float]:
+    """The threshold search on the GPU (vlr_fdr_threshold, include/vlr.h; kernels in csrc/vlr_fdr.hip): sort, PEP prefix
+    sums, boundary search.  `prob_dist`: the collected ln probabilities in ANY order, before the `smart` conversion."""
+    import ctypes as C
+    from . import engine
+    L = engine.lib()
+    L.vlr_fdr_threshold.restype = C.c_int
+    L.vlr_fdr_threshold.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    a = np.ascontiguousarray(prob_dist, dtype=np.float64)
+    thr, st = C.c_double(), C.c_int()
+    rc = L.vlr_fdr_threshold(device, a.ctypes.data, len(a), int(smart), float(alpha_ln), C.byref(thr), C.byref(st))
+    if rc != 0:
+        raise engine.EngineError(rc, (L.vlr_last_error() or b"").decode())
+    return {0: None, 1: thr.value, 2: 0.0, 3: None}[st.value]
+
+
 def fdr_threshold(prob_dist_desc: Sequence[float], alpha_ln: float, device: str = "cpu") -> Optional[float]:
     """fdr.rs:118-141 + bio::stats::bayesian::expected_fdr: threshold = probability of the last entry whose
-    expected FDR (running mean of 1 - p over the descending list) is <= alpha."""
+    expected FDR (running mean of 1 - p over the descending list) is <= alpha.  Host restatement (numpy/torch on the CPU);
+    `device="cuda"` routes to the HIP kernels behind vlr_fdr_threshold."""
+    if str(device).startswith("cuda"):
+        return fdr_threshold_device(prob_dist_desc, alpha_ln, smart=False, device=int(str(device).split(":")[1]) if ":" in str(device) else 0)
     import torch
     if len(prob_dist_desc) == 0:
         return None
@@ -178,10 +197,13 @@ def control_fdr(records: List[dict], events: Sequence[str], alpha: float, vartyp
         else:
             dist_tags = tags
         asc = collect_prob_dist(records, dist_tags, vartype)
-        desc = asc[::-1]
-        if smart:
-            desc = [(math.log1p(-math.exp(p)) if p < -0.693 else math.log(-math.expm1(p))) if p < 0 else -math.inf for p in desc]
-        threshold = fdr_threshold(desc, alpha_ln, device=device)
+        if str(device).startswith("cuda"):
+            threshold = fdr_threshold_device(asc, alpha_ln, smart=smart, device=int(str(device).split(":")[1]) if ":" in str(device) else 0)
+        else:
+            desc = asc[::-1]
+            if smart:
+                desc = [(math.log1p(-math.exp(p)) if p < -0.693 else math.log(-math.expm1(p))) if p < 0 else -math.inf for p in desc]
+            threshold = fdr_threshold(desc, alpha_ln, device=device)
     # filter_by_threshold (utils/mod.rs:288-374)
     ftags = list(tags)
     absent_tags = ["PROB_ABSENT"]
