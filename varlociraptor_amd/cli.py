@@ -78,7 +78,9 @@ def scenario_from_yaml(path: str, contig: str = "all") -> Scenario:
             contamination=Contamination(cont["by"], float(cont["fraction"])) if cont else None, ploidy=ploidy,
             somatic_effective_mutation_rate=_num(sd.get("somatic-effective-mutation-rate")),
             germline_mutation_rate=_num(sd.get("germline-mutation-rate")), inheritance=inheritance)
-    return Scenario(samples, dict(y["events"]), species=species, expressions=dict(y.get("expressions") or {}))
+    sc = Scenario(samples, dict(y["events"]), species=species, expressions=dict(y.get("expressions") or {}))
+    sc.validate()  # Scenario::vaftrees -> validate (grammar/mod.rs:206-279): OverlappingEvents
+    return sc
 
 
 def _scenario_signature(sc: Scenario):

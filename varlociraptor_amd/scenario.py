@@ -129,6 +129,7 @@ class _Parser:
     """Recursive-descent parser for formula.pest."""
 
     def __init__(self, text: str):
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)  # COMMENT = "/*" ... "*/" (formula.pest)
         self.s = text.replace(" ", "")
         self.i = 0
 
@@ -190,6 +191,11 @@ class _Parser:
         if m:
             self.i += m.end()
             return Variant(m.group(1), m.group(2), True)
+        # cmp = identifier cmp_ops identifier: a log2 fold change predicate with value 0 (formula.rs:1532-1545)
+        m = re.match(r"([\w.\-]+?)(<=|<|>=|>|!=|==)([\w.\-]+)", self.s[self.i:])
+        if m and not re.match(r"[\w.\-]+:", self.s[self.i:]):
+            self.i += m.end()
+            return Lfc(m.group(1), m.group(3), _CMP[m.group(2)], 0.0)
         m = re.match(r"([\w.\-]+):", self.s[self.i:])
         if not m:
             raise ValueError("cannot parse formula at %r" % self.s[self.i:])
@@ -283,6 +289,12 @@ class Scenario:
         self.events = dict(sorted(events.items()))  # BTreeMap order (grammar/mod.rs:137)
         self.event_names = list(self.events.keys())
         self.expressions = dict(expressions or {})
+        # Scenario::from_path (grammar/mod.rs:147-168): every event is also a reusable expression, and `$absent` is the
+        # conjunction of sample:0.0 over all samples (Formula::absent, formula.rs:440-453) unless the user defines one
+        for name, formula in self.events.items():
+            self.expressions.setdefault(name, formula)
+        self.expressions.setdefault("absent", Conj([Atom(n, VAFSet((0.0,))) for n in self.samples]) if len(self.samples) > 1
+                                    else Atom(next(iter(self.samples)), VAFSet((0.0,))))
         # per-variant prior overrides (LogProb) taken from the first candidate record of a contig (calling.rs:470-494, 704-713)
         self.variant_heterozygosity_ln = None
         self.variant_somatic_effective_mutation_rate_ln = None
@@ -673,7 +685,15 @@ class Scenario:
                 if sample is None:
                     ops.extend(cls._merge_atoms(o) for o in stmts)
                     continue
-                stmts = sorted(stmts, key=lambda a: min(a.vafs.vafs) if isinstance(a.vafs, VAFSet) and a.vafs.vafs else (a.vafs.start if isinstance(a.vafs, VAFRange) else -1.0))
+                # the reference sorts by start only, with an UNSTABLE sort (formula.rs:636-648): the order among equal starts
+                # is unspecified there and decides how far the greedy merge gets.  Ties are broken here so that the result
+                # does not depend on the operand order: ranges before sets, inclusive before exclusive starts, longer first.
+                def merge_key(a):
+                    v = a.vafs
+                    if isinstance(v, VAFSet):
+                        return (min(v.vafs) if v.vafs else -1.0, 1, 0, 0.0)
+                    return (v.start, 0, int(v.left_exclusive), -v.end)
+                stmts = sorted(stmts, key=merge_key)
                 cur = stmts[0].vafs
                 for o in stmts[1:]:
                     m = cls._try_merge_disj(cur, o.vafs)
@@ -721,6 +741,29 @@ class Scenario:
                 return ("const", o.value)
             return self._lit_key(o)
         return canon(f)
+
+    def validate(self):
+        """Scenario::validate (grammar/mod.rs:223-279): two events whose disjunction is itself one of the events overlap
+        (errors::Error::OverlappingEvents).  The reference runs this from `vaftrees()` for every contig."""
+        names = {}
+        for name, formula in self.events.items():
+            if name == "absent":
+                continue
+            names.setdefault(self.canonical(formula), []).append(name)
+        keys = sorted(names, key=repr)
+        overlapping = []
+        for i, e1 in enumerate(keys):
+            for e2 in keys[i + 1:]:
+                if e1 == ("const", False) or e2 == ("const", False):
+                    continue
+                f1, f2 = self.events[names[e1][0]], self.events[names[e2][0]]
+                f1 = parse_formula(f1) if isinstance(f1, str) else f1
+                f2 = parse_formula(f2) if isinstance(f2, str) else f2
+                d = self.canonical(Disj([f1, f2]))
+                if d in names:
+                    overlapping.append("(%r | %r) = %r" % (names[e1], names[e2], names[d]))
+        if overlapping:
+            raise ValueError("overlapping events: " + ", ".join(overlapping))
 
     def vaftree(self, event: str) -> List[_TNode]:
         roots = self._from(self.normalize(self.events[event]))
