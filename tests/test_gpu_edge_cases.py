@@ -352,3 +352,36 @@ def test_reference_testcase_fixtures_parity(oracle, golden_dir, name):
     m = compare(got, ref, label=name)
     print(describe(m))
     assert m["frac_within"] == 1.0 and m["bias_equal"] and m["status_equal"], describe(m)
+
+
+def test_clonal_somatic_inheritance_without_own_rate(oracle):
+    """Round 1 refused this prior with VLR_ERR_UNSUPPORTED (prior.rs:489-499); it is exactly tabulable (see
+    vlr_host.cpp build_prior_table): engine == oracle on a primary/relapse pair."""
+    from varlociraptor_amd.scenario import Inheritance, Species
+    species = Species(heterozygosity=0.001, germline_mutation_rate=1e-3, ploidy=2, somatic_effective_mutation_rate=None)
+    for full in (False, True):
+        sc = Scenario({"p": Sample(somatic_effective_mutation_rate=1e-6, resolution=0.05),
+                       "r": Sample(resolution=0.1, inheritance=Inheritance(abi.INHERIT_CLONAL, ("p",), True))},
+                      {"het": "p:0.5 & r:0.5", "hom": "p:1.0 & r:1.0", "primary_sub": "p:]0.0,0.5[ | p:]0.5,1.0[", "lost": "(p:0.5 & r:0.0) | (p:1.0 & r:0.0) | (p:1.0 & r:0.5)"},
+                      species=species, full_prior=full)
+        cfg = synth.SynthConfig(name="clonal", config_id=11, scenario=sc, depth=25.0, type_mix={abi.VT_SNV: 0.7, abi.VT_INDEL: 0.3},
+                                classes=[("absent", 0.4, ((0.0, 0.0), (0.0, 0.0))), ("het", 0.3, ((0.5, 0.5), (0.5, 0.5))),
+                                         ("sub", 0.2, ((0.1, 0.4), (0.0, 0.0))), ("hom", 0.1, ((1.0, 1.0), (1.0, 1.0)))], purity=None)
+        check(oracle, sc, synth.generate(cfg, 200, seed=51), "clonal somatic inheritance without own rate, full_prior=%s" % full)
+
+
+def test_log_probabilities_below_the_f64_exponent_range(oracle):
+    """prob_alt / prob_ref far below ln(2^-1074) (MiniLogProb keeps them as f16, utils/mod.rs:449-474): e^x is zero in
+    linear space.  As long as the observation's likelihood term itself is representable — always the case for records the
+    reference writes: realigned supports are normalised (realignment/mod.rs:359-374), SNV supports have one side near
+    ln 1 — the engine must agree with the log-space oracle and must NOT flag the locus."""
+    cfg = with_depth(synth.config3(), 40.0)
+    b = synth.generate(cfg, 200, seed=52)
+    pa, pr = b.columns["prob_alt"], b.columns["prob_ref"]
+    rng = np.random.default_rng(3)
+    hit = rng.random(b.n_obs) < 0.3
+    alt_like = pa > pr
+    pa[hit & ~alt_like] = np.float32(-1200.0)   # the weaker side drops out of the f64 range
+    pr[hit & alt_like] = np.float32(-2000.0)
+    got, ref = check(oracle, cfg.scenario, b, "supports below the f64 range")
+    assert not (got.status & abi.LOCUS_UNDERFLOW).any()

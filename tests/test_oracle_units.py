@@ -175,3 +175,26 @@ def test_mendelian_prior(oracle):
     # de novo in the child only: no alt in founders -> 1 - sum_m het/m ; child needs one germline mutation (rate 1e-3)
     p0 = math.log(1.0 - sum(0.001 / m for m in range(1, 5)))
     assert fprior(0.5, 0.0, 0.0, 0.0) == pytest.approx(p0 + math.log(1e-3), rel=1e-9)
+
+
+def test_clonal_inheritance_of_somatic_vaf_without_own_rate(oracle):
+    """prior.rs:489-499 (`(true, None)` arm of prob_clonal_inheritance): a sample that inherits clonally, somatic VAF
+    included, and has no somatic rate of its own must carry exactly the parent's VAF, which then has to be one of the
+    germline levels (the sample has no somatic variation, calc_prob pins its germline VAF to its VAF, prior.rs:417-427)."""
+    import ctypes as C
+    from varlociraptor_amd.scenario import Inheritance, Sample, Scenario, Species
+    species = Species(heterozygosity=0.001, germline_mutation_rate=1e-3, ploidy=2, somatic_effective_mutation_rate=None)
+    sc = Scenario({"p": Sample(somatic_effective_mutation_rate=1e-6, resolution=0.1),
+                   "r": Sample(resolution=0.1, inheritance=Inheritance(abi.INHERIT_CLONAL, ("p",), True))},
+                  {"het": "p:0.5 & r:0.5", "hom": "p:1.0 & r:1.0", "sub": "p:]0.0,0.5["}, species=species, full_prior=True)
+    d = sc.desc()
+    L = oracle.lib()
+
+    def prior(p, r):
+        return L.vlro_prior(C.byref(d), (C.c_double * 2)(p, r), abi.VT_SNV)
+
+    assert prior(0.5, 0.5) > NEG_INF and prior(1.0, 1.0) > NEG_INF and prior(0.0, 0.0) > NEG_INF
+    assert prior(0.5, 1.0) == NEG_INF          # germline VAFs differ
+    assert prior(0.3, 0.3) == NEG_INF          # 0.3 is not a germline level of the relapse sample
+    assert prior(0.3, 0.0) == NEG_INF          # parent carries a somatic VAF the child cannot have inherited unchanged
+    assert prior(0.3, 0.5) == NEG_INF

@@ -310,9 +310,11 @@ int build_prior_table(const vlr_scenario_desc* d, vlr::DevPlan& P, std::vector<d
             return fail(VLR_ERR_INVALID_PRIOR, "mendelian inheritance but no germline mutation rate defined");
         if (in.kind == VLR_INHERIT_SUBCLONAL && std::isnan(d->somatic_effective_mutation_rate[s]))
             return fail(VLR_ERR_INVALID_PRIOR, "subclonal inheritance defined but no somatic mutation");
-        if (!d->uniform_prior[s] && in.kind == VLR_INHERIT_CLONAL && in.somatic && std::isnan(d->somatic_effective_mutation_rate[s]))
-            return fail(VLR_ERR_UNSUPPORTED, "clonal inheritance with inherited somatic VAF but no somatic rate compares continuous VAFs "
-                                             "across samples (prior.rs:489-499): not representable in the tabulated device prior");
+        // Clonal inheritance of the somatic VAF by a sample WITHOUT own somatic rate (prior.rs:489-499) compares the
+        // effective somatic VAFs of sample and parent.  The sample has no somatic variation, so the recursion of calc_prob
+        // (prior.rs:417-427) pins its germline VAF to its VAF: its effective somatic VAF is exactly zero and the comparison
+        // reduces to "the parent's VAF is one of its germline levels" — a property of the parent's class.  The tabulated
+        // prior is therefore exact for this case too (round 1 rejected it with VLR_ERR_UNSUPPORTED).
     }
 
     std::vector<std::vector<double>> reps(S);  // representative VAF per class; NaN = class is impossible (-inf)

@@ -2926,8 +2926,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                     double A = exp(pa) * fa, R = exp(pr) * fr;
                     double uu = mis * exp(miss) * fany;
                     double sv = exp(psa);
-                    if ((A == 0.0 && fa != 0.0 && pa > VLR_NEG_INF) || (R == 0.0 && fr != 0.0 && pr > VLR_NEG_INF))
-                        c.status |= VLR_LOCUS_UNDERFLOW;
+                    const bool uflow = (A == 0.0 && fa != 0.0 && pa > VLR_NEG_INF) || (R == 0.0 && fr != 0.0 && pr > VLR_NEG_INF);
                     double d = A - R;
                     double cc_ = wv * R + uu, cq_ = wv * sv * d, ce_ = wv * (1.0 - sv) * d;
                     if (pos < max_obs) {
@@ -2938,6 +2937,10 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                     // smallest value the term can take over alpha in [0,1], beta in [0,1] (linear => at a corner)
                     double mn = fmin(fmin(cc_, cc_ + cq_), fmin(cc_ + ce_, cc_ + cq_ + ce_));
                     tiny = !(mn >= 0x1p-200);  // also catches NaN
+                    // e^x of a finite log-probability came out as zero: harmless while the term itself stays a normal number
+                    // (whatever underflowed is below 5e-324, i.e. < 2.5e-16 of any normal term: the reference's ln_add_exp
+                    // drops it too).  Only a term that is itself unrepresentable makes the locus unusable in linear space.
+                    if (uflow && !(mn >= 0x1p-1022)) c.status |= VLR_LOCUS_UNDERFLOW;
                     small = !(mn >= 0x1p-70 && fmax(fmax(cc_, cc_ + cq_), fmax(cc_ + ce_, cc_ + cq_ + ce_)) <= 2.0);
                 }
                 if (__ballot(tiny)) fast_s = 0;
