@@ -87,3 +87,21 @@ def test_device_threshold_matches_host_restatement():
                 if want is not None:
                     assert got == pytest.approx(want, abs=1e-12), (n, smart, alpha)
     assert fdr.fdr_threshold_device([], math.log(0.05)) is None
+
+
+def test_filter_calls_writes_bcf_with_the_input_header(tmp_path):
+    """`filter-calls control-fdr --output x.bcf` (filtration/fdr.rs:58-62): kept records in BCF, input header, records
+    unchanged; reading the output back gives the kept records."""
+    from varlociraptor_amd import cli
+    src = os.path.join(RES, "ev_2.bcf")
+    out = str(tmp_path / "kept.bcf")
+    cli.main(["filter-calls", "control-fdr", src, "--events", "SOMATIC", "--fdr", "0.05", "--mode", "global-strict", "--var", "DEL",
+              "--minlen", "1", "--maxlen", "30", "--output", out])
+    r_in, r_out = BcfReader(src), BcfReader(out)
+    assert [l for l in r_out.header_lines if not l.startswith("##FILTER=<ID=PASS")] == [l for l in r_in.header_lines if not l.startswith("##FILTER=<ID=PASS")]
+    kept = list(r_out)
+    assert abs(len(kept) - 985) <= 1
+    by_key = {(r["chrom"], r["pos"], r["ref"], r["alt"]): r for r in r_in}
+    for rec in kept[:50]:
+        orig = by_key[(rec["chrom"], rec["pos"], rec["ref"], rec["alt"])]
+        assert rec["info"] == orig["info"] and rec["format"] == orig["format"]

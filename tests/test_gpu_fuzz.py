@@ -17,6 +17,11 @@ def test_random_scenarios_match_oracle(seed):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.main(["fuzz", "60", str(seed)]) == 0
+    st = mod.LAST_STATS
+    # nothing is skipped or excused silently: every generated scenario compiles into a plan and runs, and the exemptions
+    # (knife-edge loci where the reference itself is chaotic; MAP among exactly flat likelihoods) stay rare
+    assert st["plans_rejected"] == 0 and st["run"] == st["generated"] >= 50, st
+    assert st["knife_edge_loci"] <= 2 and st["flat_loci"] <= 0.02 * 24 * st["run"], st
 
 
 def test_random_prior_scenarios_match_oracle(monkeypatch):
@@ -27,3 +32,5 @@ def test_random_prior_scenarios_match_oracle(monkeypatch):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.main(["fuzz", "40", "3"]) == 0
+    st = mod.LAST_STATS
+    assert st["plans_rejected"] == 0 and st["run"] == st["generated"] >= 35 and st["knife_edge_loci"] <= 2, st

@@ -92,8 +92,14 @@ def random_scenario_prior(rng):
     return sc, names
 
 
+LAST_STATS = {}  # counters of the most recent main() run, for the tests: nothing may be skipped or excused silently
+
+
 def main(argv=None):
     argv = sys.argv if argv is None else argv
+    stats = {"generated": 0, "front_end_rejected": 0, "plans_rejected": 0, "run": 0, "mismatching": 0, "knife_edge_loci": 0, "flat_loci": 0}
+    LAST_STATS.clear()
+    LAST_STATS.update(stats)
     n_sc = int(argv[1]) if len(argv) > 1 else 50
     seed = int(argv[2]) if len(argv) > 2 else 1
     only = int(argv[3]) if len(argv) > 3 else -1
@@ -108,7 +114,9 @@ def main(argv=None):
         except Exception as ex:  # invalid formula for the front-end (e.g. empty spectrum): not a kernel case
             if prior_mode:
                 print("scenario rejected:", ex)
+            LAST_STATS["front_end_rejected"] += 1
             continue
+        LAST_STATS["generated"] += 1
         S = len(names)
         classes = []
         for _ in range(4):
@@ -132,6 +140,7 @@ def main(argv=None):
             plan = engine.Plan(sc)
         except Exception as ex:
             print("plan rejected:", ex, sc.events)
+            LAST_STATS["plans_rejected"] += 1
             continue
         afd_cap = 256 if os.environ.get("FUZZ_AFD") == "1" else 0
         got = plan.call_host(b, afd_capacity=afd_cap)
@@ -148,6 +157,7 @@ def main(argv=None):
         shallow = b.depth() <= 3
         flat = post_ok & np.all((dv <= 1e-6) | shallow, axis=1) & (got.best_event == ref.best_event)
         real_bad = [l for l in m["bad"] if not flat[l]]
+        LAST_STATS["flat_loci"] += len(m["bad"]) - len(real_bad)
         # knife-edge loci: an argmax of the adaptive integrator sits on a (near-)tie, so the REFERENCE's own posterior jumps
         # between discrete levels when the inputs move by 1e-7 relative (seed 164 / scenario 31 / locus 4: levels 6e-5 and 3e-4
         # apart).  A posterior-only deviation smaller than that spread, with equal MAP and best event, is not a defect.
@@ -170,6 +180,7 @@ def main(argv=None):
         if knife:
             print("  knife-edge loci (reference chaotic under 1e-7 input perturbation):", knife)
             real_bad = [l for l in real_bad if l not in knife]
+            LAST_STATS["knife_edge_loci"] += len(knife)
         ok = len(real_bad) == 0 and m["bias_equal"] and m["status_equal"]
         if ok and afd_cap:
             n_afd_bad = 0
@@ -214,7 +225,8 @@ def main(argv=None):
                     print("  got post", got.ln_posterior[l], "map", got.map_vaf[l], "bias", got.map_bias[l], "best", got.best_event[l])
                     print("  ref post", ref.ln_posterior[l], "map", ref.map_vaf[l], "bias", ref.map_bias[l], "best", ref.best_event[l])
                     print("  ref events", ref.event_ln_posterior[l])
-    print("scenarios run %d, mismatching %d" % (done, bad))
+    LAST_STATS["run"], LAST_STATS["mismatching"] = done, bad
+    print("scenarios run %d, mismatching %d; %s" % (done, bad, LAST_STATS))
     return 1 if bad else 0
 
 

@@ -18,7 +18,10 @@ class PileupBatch:
     def __init__(self, n_samples: int, obs_offset: np.ndarray, columns: Dict[str, np.ndarray],
                  locus: Dict[str, np.ndarray]):
         self.n_samples = int(n_samples)
-        self.obs_offset = np.ascontiguousarray(obs_offset, dtype=np.uint32)
+        oo = np.asarray(obs_offset)
+        if oo.size and int(oo.max()) > 0xFFFFFFFF:
+            raise ValueError("batch of %d observations exceeds the 32-bit observation offsets of vlr_batch: split it" % int(oo.max()))
+        self.obs_offset = np.ascontiguousarray(oo, dtype=np.uint32)
         assert (len(self.obs_offset) - 1) % self.n_samples == 0
         self.n_loci = (len(self.obs_offset) - 1) // self.n_samples
         self.n_obs = int(self.obs_offset[-1])

@@ -86,6 +86,7 @@ class BcfReader:
         buf = self.buf
         while p + 8 <= len(buf):
             l_shared, l_indiv = struct.unpack_from("<II", buf, p)
+            rec_start = p
             p += 8
             end = p + l_shared + l_indiv
             chrom, pos, rlen, qual, nai, nfs = struct.unpack_from("<iiifII", buf, p)
@@ -124,7 +125,8 @@ class BcfReader:
                 fmt[self.strings[key[0]]] = per_sample
             yield {"chrom": self.contigs.get(chrom, str(chrom)), "pos": pos + 1, "id": bytes(rid).decode() if rid else ".",
                    "ref": alleles[0] if alleles else ".", "alt": ",".join(alleles[1:]) if len(alleles) > 1 else ".", "info": info,
-                   "qual": qual, "filter": [self.strings[i] for i in filt] if filt else [], "format": fmt}
+                   "qual": qual, "filter": [self.strings[i] for i in filt] if filt else [], "format": fmt,
+                   "raw": bytes(buf[rec_start:end])}  # the encoded record, for writers that pass records through unchanged
             p = end
 
 
@@ -319,6 +321,11 @@ class BcfWriter:
         fixed = struct.pack("<iiiIII", self.contigs[chrom], int(pos) - 1, rlen, qbits, (len(alleles) << 16) | len(infos),
                             (n_fmt << 24) | len(self.samples))
         self.pending += struct.pack("<II", len(fixed) + len(shared), len(indiv)) + fixed + shared + indiv
+        self._flush()
+
+    def write_raw(self, raw: bytes):
+        """A record in its BCF encoding (BcfReader's rec["raw"]), valid against the same header (dictionary indices)."""
+        self.pending += raw
         self._flush()
 
     def close(self):

@@ -94,16 +94,19 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
     per_contig = scenario if callable(scenario) else (lambda contig: scenario)
     scen: Dict[str, Scenario] = {}
 
-    first_of_contig: Dict[str, tuple] = {}
+    # The reference keeps one model (and one `last_rid`) per model mode = the tuple of check_* flags of the work item
+    # (calling.rs:414-443): each mode installs the variant-specific prior of ITS first record on a contig.
+    first_of_contig: Dict[tuple, tuple] = {}
 
-    def resolve(contig):
-        if contig not in scen:
+    def resolve(contig, mode=0):
+        key = (contig, mode)
+        if key not in scen:
             sc = per_contig(contig)
-            if callable(scenario) or contig in first_of_contig:
+            if callable(scenario) or key in first_of_contig:
                 import copy
                 sc = copy.copy(sc)
             # variant-specific priors are installed with the contig's model, from its first record (calling.rs:643-713)
-            het, som = first_of_contig.get(contig, (None, None))
+            het, som = first_of_contig.get(key, (None, None))
             if het is not None:
                 sc.variant_heterozygosity_ln = het
             if som is not None:
@@ -114,8 +117,8 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
             for name in obs_paths:
                 if name not in sc.sample_names:
                     raise SystemExit("invalid observation sample name %r" % name)  # errors::Error::InvalidObservationSampleName
-            scen[contig] = sc
-        return scen[contig]
+            scen[key] = sc
+        return scen[key]
 
     # samples are ordered by name (BTreeMap, grammar/mod.rs:137), independent of the contig
     sample_order = scenario.sample_names if not callable(scenario) else sorted(obs_paths)
@@ -128,8 +131,9 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
     import numpy as np
     # breakends of one event share a pileup and a result: evaluate the first record of every event only and copy its
     # event probabilities / sample info to the others (calling.rs:569-580, 726-741, 820-839)
-    for site, pri in zip(sites, batch.extra.get("prior_overrides") or []):
-        first_of_contig.setdefault(site[0], pri)
+    modes = (batch.locus["locus_flags"] & 0x3F).astype(int) if batch.n_loci else []
+    for l, (site, pri) in enumerate(zip(sites, batch.extra.get("prior_overrides") or [])):
+        first_of_contig.setdefault((site[0], int(modes[l])), pri)
     world, rank = 1, 0
     try:
         import torch.distributed as tdist
@@ -140,12 +144,12 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
     reps, source = obsfmt.haplotype_groups(batch.extra.get("haplotype") or [None] * batch.n_loci)
     groups: Dict[tuple, List[int]] = {}
     for l in reps:
-        sc = resolve(sites[l][0])
+        sc = resolve(sites[l][0], int(modes[l]))
         groups.setdefault(_scenario_signature(sc), []).append(l)
     res = None
     names = None
     for sig, loci in groups.items():
-        sc = resolve(sites[loci[0]][0])
+        sc = resolve(sites[loci[0]][0], int(modes[loci[0]]))
         if world > 1:
             # loci shard across the ranks (one process per GPU); the results are reassembled by one all-gather of
             # fixed-size records (+ one for the AFD lists), every rank ends up with the full result
@@ -156,7 +160,7 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
             if mine:
                 plan = engine.Plan(sc, device=device)
                 sub = batch.select(mine)
-                plan.set_max_obs(max(int(sub.depth().sum(axis=1).max()), 1))
+                plan.set_max_obs(min(max(int(sub.depth().sum(axis=1).max()), 1), engine.MAX_OBS_LDS))
                 rl = plan.call_host(sub, afd_capacity=afd_capacity)
                 plan.close()
             else:
@@ -167,7 +171,7 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
             sub = batch if len(loci) == batch.n_loci else batch.select(loci)
             # observation files are already capped by preprocess's --max-depth: size the LDS budget to the deepest record
             deepest = int(sub.depth().sum(axis=1).max()) if sub.n_loci else 1
-            plan.set_max_obs(max(deepest, 1))
+            plan.set_max_obs(min(max(deepest, 1), engine.MAX_OBS_LDS))  # deeper records come back flagged VLR_LOCUS_TOO_DEEP
             r = plan.call_host(sub, afd_capacity=afd_capacity)
             plan.close()
         if names is None:
@@ -188,6 +192,14 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
             a = getattr(res, f)
             if a is not None:
                 a[:] = a[src]
+    if res is not None and rank == 0:
+        # the reference panics on NaN (assert!(!p.is_nan())) and has no depth limit: say so instead of writing `.` silently
+        hard = res.status & (abi.LOCUS_NAN | abi.LOCUS_UNDERFLOW | abi.LOCUS_TABLE_FULL | abi.LOCUS_TOO_DEEP)
+        for bit, what in ((abi.LOCUS_NAN, "a likelihood became NaN"), (abi.LOCUS_UNDERFLOW, "an observation likelihood is outside the f64 range"),
+                          (abi.LOCUS_TABLE_FULL, "visited-point table overflow"), (abi.LOCUS_TOO_DEEP, "pileup above the LDS budget of %d observations" % engine.MAX_OBS_LDS)):
+            n_bad = int(((hard & bit) != 0).sum())
+            if n_bad:
+                print("warning: %d record(s) without a result: %s" % (n_bad, what), file=sys.stderr)
     scenario0 = resolve(sites[0][0] if sites else "all")
     header = callsfmt.header(names or scenario0.out_names(), scenario0.sample_names, sorted(set(s[0] for s in sites)))
     if rank != 0:
@@ -239,6 +251,7 @@ def main(argv=None):
     cf.add_argument("--minlen", type=int)
     cf.add_argument("--maxlen", type=int)
     cf.add_argument("--device", default="cpu")
+    cf.add_argument("--output", "-o", help="BCF file for the kept records (default: a CHROM/POS/ID/REF/ALT table on stdout)")
     a = ap.parse_args(argv)
     import os
     if a.cmd == "call" and int(os.environ.get("WORLD_SIZE", "1")) > 1:
@@ -262,9 +275,18 @@ def main(argv=None):
             vartype = (a.var, rng)
         kept = fdr.control_fdr(recs, a.events, a.fdr, vartype=vartype, local=a.mode.startswith("local"), smart=a.mode.endswith("smart"),
                                smart_retain_artifacts=a.smart_retain_artifacts, header_tags=tags, device=a.device)
-        print("#CHROM\tPOS\tID\tREF\tALT")
-        for rec in kept:
-            print("\t".join(str(rec[k]) for k in ("chrom", "pos", "id", "ref", "alt")))
+        # utils::filter_calls (filtration/fdr.rs:58-62, utils/mod.rs:288-374): the kept records go out as BCF with the input's
+        # header.  Records pass through in their original encoding (calls written by `call variants` carry one ALT per record,
+        # so there are no ALT alleles to trim; a multi-ALT record is kept whole when any of its alleles is kept).
+        if a.output:
+            from .bcfio import BcfWriter
+            with BcfWriter(a.output, r.header_text) as w:
+                for rec in kept:
+                    w.write_raw(rec["raw"])
+        else:
+            print("#CHROM\tPOS\tID\tREF\tALT")
+            for rec in kept:
+                print("\t".join(str(rec[k]) for k in ("chrom", "pos", "id", "ref", "alt")))
         print(f"{len(kept)} of {len(recs)} records kept", file=sys.stderr)
         return
     omit = (a.omit_strand_bias | a.omit_read_orientation_bias | a.omit_read_position_bias | a.omit_softclip_bias |

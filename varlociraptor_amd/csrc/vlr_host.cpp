@@ -1033,6 +1033,10 @@ int vlr_batch_run_host(vlr_plan* plan, const vlr_batch* in, vlr_results* out) {
     if (L == 0) return VLR_OK;
     if (in->n_samples != S) return fail(VLR_ERR_INVALID_ARGUMENT, "batch has %d samples, plan %d", in->n_samples, S);
     if (!in->obs_offset || !in->flags || !in->locus_flags) return fail(VLR_ERR_INVALID_ARGUMENT, "missing required column");
+    if (in->n_obs > 0 && (!in->prob_mapping || !in->prob_alt || !in->prob_ref || !in->prob_missed_allele || !in->prob_sample_alt ||
+                          !in->prob_double_overlap || !in->prob_hit_base))
+        return fail(VLR_ERR_INVALID_ARGUMENT, "missing required probability column (only the homopolymer columns are optional)");
+    if (in->n_obs < 0 || in->n_obs > 0xffffffffll) return fail(VLR_ERR_INVALID_ARGUMENT, "n_obs %lld does not fit the 32-bit observation offsets", (long long)in->n_obs);
     const bool want_afd = out->afd_count || out->afd_vaf || out->afd_lnprob;
     if (want_afd && (!out->afd_count || !out->afd_vaf || !out->afd_lnprob || out->afd_capacity < 1))
         return fail(VLR_ERR_INVALID_ARGUMENT, "AFD needs afd_count, afd_vaf, afd_lnprob and afd_capacity >= 1");

@@ -59,6 +59,8 @@ def source_id() -> str:
     return h.hexdigest()[:16]
 
 
+MAX_OBS_LDS = 7680  # kept observations of one locus whose coefficient pairs fit the 120 kB LDS budget (vlr_plan_set_max_obs)
+
 MATRIX_DIR = os.path.join(_HERE, "matrix")
 MATRIX_LIBS = ("stress", "O1", "sync")
 
