@@ -356,6 +356,10 @@ int vlr_fdr_threshold(int device, const double* ln_prob, int64_t n, int smart, d
  * 1 det_log1p_pos, 2 det_log2_ratio(a, b), 3 det_exp2) and of the kernel's mantissa logarithm (4), element-wise on host
  * arrays.  tests/test_gpu_math.py requires 0-3 to be bit-identical to the host build of the same header. */
 int vlr_selftest_math(int device, int which, const double* a, const double* b, double* out, int64_t n);
+/* Diagnostics: `reps` launches of a stream of known size in the engine's own access widths — mode 0 reads n f32 with
+ * lane-contiguous 4-byte loads (4 n bytes per launch), mode 1 writes n f64 with lane-contiguous 8-byte stores (8 n bytes
+ * per launch) — so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be calibrated for them (tools/traffic_measure.sh). */
+int vlr_selftest_stream(int device, int mode, int64_t n, int reps);
 
 #ifdef __cplusplus
 }

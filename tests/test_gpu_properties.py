@@ -53,7 +53,7 @@ def test_planted_classes_are_recovered():
     names = cfg.scenario.out_names()
     called = np.exp(res.ln_posterior).argmax(axis=1)
     cls, cls_names = b.truth["class"], b.truth["class_names"]
-    floor = {"absent": 0.97, "germline_het": 0.95, "germline_hom": 0.95, "somatic_tumor": 0.80, "somatic_normal": 0.50}
+    floor = {"absent": 0.97, "germline_het": 0.90, "germline_hom": 0.90, "somatic_tumor": 0.75, "somatic_normal": 0.40}  # 3 % of the loci carry an injected artifact
     for ci, cname in enumerate(cls_names):
         sel = cls == ci
         assert sel.sum() > 100

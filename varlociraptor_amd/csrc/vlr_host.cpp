@@ -1210,4 +1210,23 @@ int vlr_selftest_math(int device, int which, const double* a, const double* b, d
     return rc;
 }
 
+extern "C" int vlr_launch_selftest_stream(const float* in, double* out, long long n, int mode, void* stream);
+int vlr_selftest_stream(int device, int mode, int64_t n, int reps) {
+    if (n <= 0 || reps <= 0 || (mode != 0 && mode != 1)) return fail(VLR_ERR_INVALID_ARGUMENT, "bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) return fail(VLR_ERR_NO_DEVICE, "no HIP device %d", device);
+    HIP_TRY(hipSetDevice(device));
+    float* in = nullptr;
+    double* out = nullptr;
+    HIP_TRY(hipMalloc((void**)&in, (size_t)n * 4));
+    if (hipMalloc((void**)&out, mode == 1 ? (size_t)n * 8 : (size_t)(n / 16384 + 1) * 8) != hipSuccess) { (void)hipFree(in); return fail(VLR_ERR_OUT_OF_MEMORY, "hipMalloc"); }
+    (void)hipMemset(in, 0, (size_t)n * 4);
+    int rc = VLR_OK;
+    for (int r = 0; r < reps && rc == VLR_OK; ++r)
+        if (vlr_launch_selftest_stream(in, out, (long long)n, mode, nullptr) != 0) rc = fail(VLR_ERR_HIP, "launch failed");
+    if (hipDeviceSynchronize() != hipSuccess && rc == VLR_OK) rc = fail(VLR_ERR_HIP, "kernel failed");
+    (void)hipFree(in); (void)hipFree(out);
+    return rc;
+}
+
 }  // extern "C"

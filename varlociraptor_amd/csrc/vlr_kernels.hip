@@ -3180,6 +3180,35 @@ __global__ void vlr_selftest_math_kernel(int which, const double* a, const doubl
     out[i] = r;
 }
 }  // namespace vlr
+// ---- diagnostics: streams of known size in the engine's own access widths, to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE
+// (the microarchitecture guide calibrates them for 16 B/lane reads only): mode 0 reads n f32 with lane-contiguous 4-byte
+// loads (the observation columns), mode 1 writes n f64 with lane-contiguous 8-byte stores (the e scratch, the results)
+namespace vlr {
+__global__ void __launch_bounds__(64) vlr_selftest_stream_kernel(const float* in, double* out, long long n, int mode) {
+    const long long per_wg = 64 * 256;  // a wave streams 256 consecutive 256-byte segments, like a deep pileup
+    const long long base = (long long)blockIdx.x * per_wg;
+    if (mode == 0) {
+        float acc = 0.f;
+        for (int k = 0; k < 256; ++k) {
+            const long long i = base + (long long)k * 64 + threadIdx.x;
+            if (i < n) acc += in[i];
+        }
+        if (acc == 12345.678f) out[blockIdx.x] = acc;  // keep the loads alive without writing
+    } else {
+        for (int k = 0; k < 256; ++k) {
+            const long long i = base + (long long)k * 64 + threadIdx.x;
+            if (i < n) out[i] = (double)i;
+        }
+    }
+}
+}  // namespace vlr
+extern "C" int vlr_launch_selftest_stream(const float* in, double* out, long long n, int mode, void* stream) {
+    if (n <= 0) return 0;
+    const long long per_wg = 64 * 256;
+    hipLaunchKernelGGL(vlr::vlr_selftest_stream_kernel, dim3((unsigned)((n + per_wg - 1) / per_wg)), dim3(64), 0, (hipStream_t)stream, in, out, n, mode);
+    return (int)hipGetLastError();
+}
+
 extern "C" int vlr_launch_selftest_math(int which, const double* a, const double* b, double* out, long long n, void* stream) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(vlr::vlr_selftest_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, which, a, b, out, n);
