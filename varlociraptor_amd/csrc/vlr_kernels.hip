@@ -1479,30 +1479,56 @@ __device__ __forceinline__ double row_bcast(double v) {
 // hold {c, q} = {1, 0}, so their term is exactly 1.  Same association as accum_terms_e's two-term groups (mantissas are
 // bit-identical); no renormalisation: every term is in [2^-70, 2] (WaveSt::vfast), 13 of them stay normal.
 constexpr int kRegSlots = 13;  // 16 * 13 = 208 observations of the integrated sample
-template <int NS, bool USE_E>
-__device__ __forceinline__ void reg_products(const double* cc, const double* cq, const double* ecoef, int rl, int D, const double* al, const double* be, double* P) {
-    double ce[NS];
-    if (USE_E) {
+constexpr int kRegHeld = 8;    // slots whose coefficient pairs stay in registers for the whole batch; deeper slots of the 13-slot
+                               // variant are re-read from LDS every pass (five b128 reads): holding all 13 pushed the
+                               // 3-waves-per-SIMD build 20 VGPRs over its budget and the spills around the batch loop went to HBM
+template <int NS>
+__device__ __forceinline__ void reg_products(const double* cc, const double* cq, const double* lcoef, int rl, int D, const double* al, double* P) {
+    constexpr int NR = NS < kRegHeld ? NS : kRegHeld;
+    double xc[NS > NR ? NS - NR : 1], xq[NS > NR ? NS - NR : 1];
 #pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            const int i = rl + 16 * j;
-            const double e = ld_e(ecoef + (i < D ? i : 0));
-            ce[j] = i < D ? e : 0.0;
-        }
+    for (int j = NR; j < NS; ++j) {  // issued first: the LDS latency hides behind the register-held slots
+        const int i = rl + 16 * j;
+        const double* a = lcoef + 2 * (i < D ? i : 0);
+        const double c0 = a[0], q0 = a[1];
+        xc[j - NR] = i < D ? c0 : 1.0; xq[j - NR] = i < D ? q0 : 0.0;
     }
 #pragma unroll
     for (int t = 0; t < 3; ++t) P[t] = 1.0;
 #pragma unroll
     for (int j = 0; j < NS; j += 2) {
+        const double c0 = j < NR ? cc[j < NR ? j : 0] : xc[j >= NR ? j - NR : 0], q0 = j < NR ? cq[j < NR ? j : 0] : xq[j >= NR ? j - NR : 0];
+        const double c1 = (j + 1 < NR) ? cc[(j + 1 < NR) ? j + 1 : 0] : xc[(j + 1 >= NR && j + 1 < NS) ? j + 1 - NR : 0];
+        const double q1 = (j + 1 < NR) ? cq[(j + 1 < NR) ? j + 1 : 0] : xq[(j + 1 >= NR && j + 1 < NS) ? j + 1 - NR : 0];
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-            double L0 = __builtin_fma(cq[j], al[t], cc[j]);
-            if (USE_E) L0 = __builtin_fma(ce[j], be[t], L0);
+            const double L0 = __builtin_fma(q0, al[t], c0);
             if (j + 1 < NS) {
-                double L1 = __builtin_fma(cq[j + 1], al[t], cc[j + 1]);
-                if (USE_E) L1 = __builtin_fma(ce[j + 1], be[t], L1);
+                const double L1 = __builtin_fma(q1, al[t], c1);
                 P[t] *= L0 * L1;
             } else P[t] *= L0;
+        }
+    }
+}
+// The same products with the third coefficient (beta != 0: a VAF of exactly one in the sample or its contaminant — one chain
+// in ten): every slot comes from memory (c, q from LDS, e from the scratch row), a plain loop over slot pairs with the
+// association of the register variant.  Kept out of the register variant: its 13 extra values set the kernel's VGPR peak.
+__device__ __forceinline__ void lds_products_e(const double* lcoef, const double* ecoef, int rl, int D, const double* al, const double* be, double* P) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) P[t] = 1.0;
+    for (int j = 0; 16 * j < D; j += 2) {
+        const int i0 = rl + 16 * j, i1 = i0 + 16;
+        const bool v0 = i0 < D, v1 = i1 < D;
+        const double* a0 = lcoef + 2 * (v0 ? i0 : 0);
+        const double* a1 = lcoef + 2 * (v1 ? i1 : 0);
+        const double c0 = v0 ? a0[0] : 1.0, q0 = v0 ? a0[1] : 0.0, c1 = v1 ? a1[0] : 1.0, q1 = v1 ? a1[1] : 0.0;
+        const double g0 = ld_e(ecoef + (v0 ? i0 : 0)), g1 = ld_e(ecoef + (v1 ? i1 : 0));
+        const double e0 = v0 ? g0 : 0.0, e1 = v1 ? g1 : 0.0;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const double L0 = __builtin_fma(e0, be[t], __builtin_fma(q0, al[t], c0));
+            const double L1 = __builtin_fma(e1, be[t], __builtin_fma(q1, al[t], c1));
+            P[t] *= L0 * L1;
         }
     }
 }
@@ -1527,9 +1553,11 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
     const DevPlan& p = *c.plan;
     const int rl = q.rl, D = q.D, simpson_n = q.simpson_n;
     const double lo = q.lo, hi = q.hi, res = q.res;
-    double cc[NS], cq[NS];
+    constexpr int NR = NS < kRegHeld ? NS : kRegHeld;
+    const double* lcoef = c.coef + 2 * q.off;
+    double cc[NR], cq[NR];
 #pragma unroll
-    for (int j = 0; j < NS; ++j) {
+    for (int j = 0; j < NR; ++j) {
         const int i = rl + 16 * j;
         const double* a = c.coef + 2 * (q.off + (i < D ? i : 0));
         const double c0 = a[0], q0 = a[1];
@@ -1566,9 +1594,9 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
             }
         }
         if (q.ecoef != nullptr && __ballot(go && (be[0] != 0.0 || be[1] != 0.0 || be[2] != 0.0)) != 0ull)
-            reg_products<NS, true>(cc, cq, q.ecoef, rl, D, al, be, P);
+            lds_products_e(lcoef, q.ecoef, rl, D, al, be, P);
         else
-            reg_products<NS, false>(cc, cq, q.ecoef, rl, D, al, be, P);
+            reg_products<NS>(cc, cq, lcoef, rl, D, al, P);
         PROF_ADD(c, 12);  // pass: term products
 #pragma unroll
         for (int t = 0; t < 3; ++t) { int e; P[t] = __builtin_frexp(P[t], &e); E[t] = e; }
