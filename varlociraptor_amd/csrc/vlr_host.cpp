@@ -21,6 +21,7 @@
 #include "../../include/vlr.h"
 #include "vlr_plan.h"
 
+extern "C" int vlr_launch_afd_kernel(const vlr::DevPlan* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out, void* stream);
 extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_dev, const vlr::DevBatch* batch, const vlr::DevResults* out,
                                       int n_univ, int n_samples, int max_obs, int range_depth, void* stream);
 
@@ -263,6 +264,9 @@ struct vlr_plan {
     // kernel scratch, one per slot: the third likelihood coefficient of every kept observation (8 B x max_obs per locus)
     void* escratch[2] = {nullptr, nullptr};
     size_t escratch_bytes[2] = {0, 0};
+    // AFD log, one per slot (only when AFD lists are requested): afd_log_words 8-byte words per locus
+    void* afd_log[2] = {nullptr, nullptr};
+    size_t afd_log_bytes[2] = {0, 0};
     int slot = 0;  // slot used by the next vlr_batch_run (set by vlr_batch_run_host)
 };
 
@@ -765,6 +769,7 @@ void vlr_plan_destroy(vlr_plan* plan) {
         if (plan->stage[k]) (void)hipFree(plan->stage[k]);
         if (plan->afd_scratch[k]) (void)hipFree(plan->afd_scratch[k]);
         if (plan->escratch[k]) (void)hipFree(plan->escratch[k]);
+        if (plan->afd_log[k]) (void)hipFree(plan->afd_log[k]);
         if (plan->stage_stream[k]) (void)hipStreamDestroy(plan->stage_stream[k]);
     }
     if (plan->work_dev) (void)hipFree(plan->work_dev);
@@ -854,16 +859,36 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
         }
         r.escratch = (double*)plan->escratch[k];
     }
+    if (want_afd && !getenv("VLR_AFD_REPLAY")) {
+        // AFD log: room for ~36 chain tables of the plan's capacity per locus; a locus that needs more falls back to the replay
+        size_t words = 1 + (size_t)36 * (1 + plan->host.S + 2 * (size_t)plan->host.table_cap);
+        words = std::min<size_t>((words + 63) & ~(size_t)63, (size_t)1 << 15);
+        const int k = plan->slot & 1;
+        const size_t need = (size_t)in->n_loci * words * sizeof(double);
+        if (need > plan->afd_log_bytes[k]) {
+            if (plan->afd_log[k]) (void)hipFree(plan->afd_log[k]);
+            plan->afd_log[k] = nullptr;
+            plan->afd_log_bytes[k] = 0;
+            if (hipMalloc(&plan->afd_log[k], need) == hipSuccess) plan->afd_log_bytes[k] = need;
+            else (void)hipGetLastError();  // no room for the log: the replay launch alone produces the lists
+        }
+        if (plan->afd_log[k]) { r.afd_log = (double*)plan->afd_log[k]; r.afd_log_stride = (long long)words; }
+    }
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipEventRecord(plan->ev_start, st));
     int rc = vlr_launch_call_kernel(&plan->host, &b, &r, plan->host.n_univ, plan->host.S, max_obs, plan->host.max_range_depth, stream);
     if (rc != 0) return fail(VLR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-    HIP_TRY(hipEventRecord(plan->ev_stop, st));
-    if (want_afd) {  // second launch: AFD replay over the clean events (calling.rs:889-928)
+    if (!want_afd) HIP_TRY(hipEventRecord(plan->ev_stop, st));
+    if (want_afd) {  // FORMAT/AFD (calling.rs:889-928): from the log of the call pass; replay of the clean events where the log overflowed
         HIP_TRY(hipMemsetAsync(out->afd_count, 0, (size_t)in->n_loci * plan->host.S * sizeof(int32_t), st));
+        if (r.afd_log) {
+            rc = vlr_launch_afd_kernel(&plan->host, &b, &r, stream);
+            if (rc != 0) return fail(VLR_ERR_HIP, "AFD kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        }
         r.replay = 1;
         rc = vlr_launch_call_kernel(&plan->host, &b, &r, plan->host.n_univ, plan->host.S, max_obs, plan->host.max_range_depth, stream);
-        if (rc != 0) return fail(VLR_ERR_HIP, "AFD kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        if (rc != 0) return fail(VLR_ERR_HIP, "AFD replay launch failed: %s", hipGetErrorString((hipError_t)rc));
+        HIP_TRY(hipEventRecord(plan->ev_stop, st));
     }
     plan->timed = true;
     return VLR_OK;

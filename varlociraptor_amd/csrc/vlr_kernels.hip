@@ -126,6 +126,11 @@ __device__ __forceinline__ double uni_d(double v) {
 // Ordering of LDS traffic between the lanes of ONE wave (the workgroup is a single wave64): same-wave LDS operations
 // execute in program order, so all that is needed is that the COMPILER keeps the stores of some lanes ahead of the loads
 // of others.  Variants for the build matrix (tests/test_gpu_build_matrix.py).
+// The AFD buffers of a locus are written and read back by ONE wave: workgroup scope orders them (the CU's vector L1 is shared
+// by the workgroup).  __threadfence() is agent scope, which on this multi-XCD part means an L2 write-back per call — it made
+// the AFD pass as expensive as the likelihood evaluation itself.
+#define VLR_WG_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
+
 #if defined(VLR_WB_SYNC)
 #define VLR_WAVE_FENCE() __syncthreads()
 #elif defined(VLR_WB_PLAIN)
@@ -652,6 +657,9 @@ struct Ctx {
     int need_batch, bt_nt, bt_inner;           // walk_root asks the event loop to run run_chain_batch (single inline site, few live registers)
     int afd_mute;  // replay: the current path repeats an outer VAF already visited by its chain (duplicate map key)
     int ehas;      // bit s: sample s has non-zero third coefficients (constant per locus, see WaveSt::ehas)
+    double* lg;    // AFD log region of this locus (DevResults::afd_log) or nullptr
+    int lg_pos, lg_cap;  // next free word / capacity; lg_pos < 0: overflowed
+    int lg_nrec;         // records written so far (directory entries)
     double marginal;
     int64_t locus;
     const DevResults* outp;
@@ -896,6 +904,54 @@ __device__ inline void cross_consider(Ctx& c, int g, double joint, int inner, do
         __syncthreads();
     }
 }
+// ---- AFD log (DevResults::afd_log): what FORMAT/AFD needs from the call pass (calling.rs:889-928) is the joint probability of
+// every visited operand set; which of them end up in the lists is only known once the MAP is.  Re-evaluating the clean events
+// in a second launch (the replay below) costs as much as the call itself, so the call pass writes the values it has anyway:
+//   record = header word | S outer operands | nlfc x 2 words (l2fc terms on the path) | payload
+//   header: n (16 bits) | integrated sample + 1 (4) | is_discrete mask (8) | event group (8) | nlfc (4) | kind (2)
+//   kind 1: the visited-point table of a Range chain: n x values, then n joint values;  kind 2: one discrete leaf: its joint
+__device__ __forceinline__ bool log_on(const Ctx& c) { return c.lg != nullptr && c.hyp == 0 && !c.replay && c.lg_pos >= 0; }
+__device__ __forceinline__ long long log_header(int kind, int n, int s_in, int disc, int group, int nlfc) {
+    return (long long)n | ((long long)(s_in + 1) << 16) | ((long long)(disc & 0xff) << 20) | ((long long)(group & 0xff) << 28) |
+           ((long long)(nlfc & 0xf) << 36) | ((long long)kind << 40);
+}
+// Region layout: word 0 = words used (-1: overflow), word 1 = number of records, words 2 .. 2 + kLogDir = start of every
+// record (so that vlr_afd_kernel can look at all headers at once), records from word kLogFirst on.
+constexpr int kLogDir = 64;
+constexpr int kLogFirst = 2 + kLogDir;
+// reserve one record of `words` (uniform); returns its start or -1 after marking the region as overflowed
+__device__ __forceinline__ int log_reserve(Ctx& c, int words) {
+    if (c.lg_pos + words > c.lg_cap || c.lg_nrec >= kLogDir) { c.lg_pos = -1; return -1; }
+    const int at = c.lg_pos;
+    if (c.lane == 0) c.lg[2 + c.lg_nrec] = __longlong_as_double((long long)at);
+    c.lg_nrec += 1;
+    c.lg_pos += words;
+    return at;
+}
+// header + operands + l2fc terms of the CURRENT context (walk state); returns the payload position or -1
+__device__ inline int log_begin(Ctx& c, int kind, int n, int s_in, int disc, int payload_words) {
+    const int S = c.S, nl = c.nlfc;
+    const int at = log_reserve(c, 1 + S + 2 * nl + payload_words);
+    if (at < 0) return -1;
+    WaveSt* w = c.w;
+    if (c.lane == 0) c.lg[at] = __longlong_as_double(log_header(kind, n, s_in, disc, c.group, nl));
+    if (c.lane < S) c.lg[at + 1 + c.lane] = w->ops_vaf[c.lane];
+    if (c.lane < nl) {
+        c.lg[at + 1 + S + 2 * c.lane] = __longlong_as_double((long long)w->lfc_a[c.lane] | ((long long)w->lfc_b[c.lane] << 8) | ((long long)w->lfc_cmp[c.lane] << 16));
+        c.lg[at + 1 + S + 2 * c.lane + 1] = w->lfc_val[c.lane];
+    }
+    return at + 1 + S + 2 * nl;
+}
+__device__ inline void log_leaf(Ctx& c, double joint) {
+    const int at = log_begin(c, 2, 1, -1, c.disc, 1);
+    if (at >= 0 && c.lane == 0) c.lg[at] = joint;
+}
+__device__ inline void log_table(Ctx& c, int s_in, const double* tx, const double* tv, int n) {  // a single chain, all 64 lanes
+    const int at = log_begin(c, 1, n, s_in, c.disc & ~(1 << s_in), 2 * n);
+    if (at < 0) return;
+    for (int i = c.lane; i < n; i += 64) { c.lg[at + i] = tx[i]; c.lg[at + n + i] = tv[i]; }
+}
+
 // ---- all-discrete roots (DevDLeaf): every leaf of the root on its own lane --------------------------------------
 // GenericPosterior::density of a root whose nodes are all Set / single-valued Sample nodes (modes/generic.rs:294-330):
 // ln_sum_exp over the leaves of prior + likelihood; a leaf below a node that is dead under clear_ref (270-291) is not
@@ -960,6 +1016,31 @@ __device__ inline double eval_discrete_root(Ctx& c, int l0, int l1) {
         }
     }
     if (__ballot(sawnan)) { c.status |= VLR_LOCUS_NAN; return __builtin_nan(""); }
+    if (log_on(c)) {  // AFD log: every visited leaf is a complete, all-discrete operand set; one record (kind 3) for the root
+        int cnt = 0;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+            if (t < TT) cnt += __popcll(__ballot(ok[t]));
+        const int rec = S + 1;
+        const int at0 = cnt ? log_reserve(c, 1 + rec * cnt) : -1;
+        if (at0 >= 0) {
+            if (lane == 0) c.lg[at0] = __longlong_as_double(log_header(3, cnt, -1, (1 << S) - 1, c.group, 0));
+            int base = at0 + 1;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                if (t < TT) {
+                    const unsigned long long m = __ballot(ok[t]);
+                    if (ok[t]) {
+                        const int at = base + rec * __popcll(m & ((1ull << lane) - 1ull));
+                        const DevDLeaf& L = leaves[l0 + lane + 64 * t];
+                        for (int s = 0; s < S; ++s) c.lg[at + s] = L.vaf[s];
+                        c.lg[at + S] = jv[t];
+                    }
+                    base += rec * __popcll(m);
+                }
+            }
+        }
+    }
     // density
     double m = VLR_NEG_INF;
 #pragma unroll
@@ -1017,7 +1098,7 @@ __device__ inline double eval_discrete_root(Ctx& c, int l0, int l1) {
 // AFD replay (calling.rs:889-928): record (VAF of sample s, posterior density) of every clean operand set that
 // equals the MAP on all other samples (allele_freq, artifacts, is_discrete) and is contained in the best event
 // with sample s excluded.
-__device__ inline void afd_consider(Ctx& c, double joint, int inner, double x) {
+__device__ inline void afd_consider(Ctx& c, double joint, int inner, double x, int skip_sample = -1) {
     if (c.hyp != 0 || c.afd_mute) return;
     int mism = 0, ms = -1;
     const int disc = (inner >= 0) ? (c.disc & ~(1 << inner)) : c.disc;
@@ -1029,6 +1110,7 @@ __device__ inline void afd_consider(Ctx& c, double joint, int inner, double x) {
     if (mism >= 2) return;
     for (int s = 0; s < c.S; ++s) {
         if (mism == 1 && s != ms) continue;
+        if (s == skip_sample) continue;  // vlr_afd_kernel has written this sample's entries of the record in bulk
         if (!group_contains(c, c.mapGroup, inner, x, s)) continue;
         const double vs = (s == inner) ? x : c.w->ops_vaf[s];
         if ((disc >> s) & 1) {  // discrete operand for s: the whole operand set is a repeat if this VAF was recorded before
@@ -1061,7 +1143,7 @@ __device__ inline void afd_consider(Ctx& c, double joint, int inner, double x) {
 // construction; the first occurrence is kept.
 __device__ inline void afd_finish(Ctx& c) {
     const DevResults& o = *c.outp;
-    __threadfence();
+    VLR_WG_FENCE();
     for (int s = 0; s < c.S; ++s) {
         const int64_t slot = c.locus * c.S + s;
         int cnt = 0;
@@ -1085,16 +1167,16 @@ __device__ inline void afd_finish(Ctx& c) {
                 }
                 const unsigned long long keep = __ballot(on & !dup);
                 const int pos = kept + __popcll(keep & ((1ull << c.lane) - 1ull));
-                __threadfence();
+                VLR_WG_FENCE();
                 if (on & !dup) { vv[pos] = v; pp[pos] = pr; }
-                __threadfence();
+                VLR_WG_FENCE();
                 kept += __popcll(keep);
             }
             if (c.lane == 0) o.afd_count[slot] = kept;
             cnt = kept;
         }
         const int lim = cnt < o.afd_capacity ? cnt : o.afd_capacity;
-        __threadfence();
+        VLR_WG_FENCE();
         for (int i = c.lane; i < lim; i += 64) vv[i] = fabs(vv[i]);
     }
 }
@@ -1150,6 +1232,7 @@ __device__ inline double leaf_joint(Ctx& c) {
     }
     joint = uni_d(joint);
     if (joint != joint) c.status |= VLR_LOCUS_NAN;
+    if (log_on(c)) log_leaf(c, joint);
     if (c.replay) afd_consider(c, joint, -1, 0.0);
     else map_all(c, joint, -1, 0.0, c.contained != 0, c.alive);
     PROF_ADD(c, 22);  // leaf: MAP candidates
@@ -1411,6 +1494,7 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
     if (failed) return __builtin_nan("");
     VLR_WAVE_FENCE();
     __syncthreads();
+    if (log_on(c)) log_table(c, inner, tx, tv, tn);
     if (phase == RP_SIMPSON) {  // bio LogProb::ln_simpsons_integrate_exp (modes/generic.rs:367-385)
         double M = VLR_NEG_INF, S = 0.0;
         for (int i = 1; i < simpson_n - 1; ++i) lse_add(M, S, tv[i] + log((double)(2 + (i % 2) * 2)));
@@ -1924,6 +2008,30 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
                 anynan = anynan | (vi[t] != vi[t]);
             }
         }
+        // AFD log: the four row tables as they stand (any order), one record per chain (no l2fc terms on batched chains)
+        if (log_on(c)) {
+            const int hsz = 1 + c.S;
+            int at_row = -1;
+#pragma unroll
+            for (int r4 = 0; r4 < kRows; ++r4) {
+                const int nr = __builtin_amdgcn_readlane(n, 16 * r4);
+                if (nr > 0 && log_on(c)) {
+                    const int a = log_reserve(c, hsz + 2 * nr);
+                    at_row = (row == r4) ? a : at_row;
+                }
+            }
+            if (at_row >= 0 && n > 0 && c.lg_pos >= 0) {
+                const int at = at_row;
+                const ChainTask& Tl = w->task[row];
+                if (rl == 0) c.lg[at] = __longlong_as_double(log_header(1, n, inner, Tl.disc & ~(1 << inner), Tl.group, 0));
+                if (rl < c.S) c.lg[at + 1 + rl] = tvr[rl];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int i = rl + 16 * t;
+                    if (t < TT && i < n) { c.lg[at + hsz + i] = xi[t]; c.lg[at + hsz + n + i] = vi[t]; }
+                }
+            }
+        }
         // rank of every entry among its row's entries: one compare + one add-with-carry per (entry, q)
         if (__ballot(srt && n > 0)) {
             for (int q0 = 0; q0 < nmax; q0 += 4) {  // four table reads in flight
@@ -2135,6 +2243,7 @@ __device__ __forceinline__ bool bo_setup(Ctx& c, const Frame& f, RangeSt& r) {
         }
         T.pidx = pidx;
         T.fixed = B.fixed_const;
+        T.group = c.group; T.disc = c.disc & ~(1 << s_in);  // for the AFD log
         T.result = VLR_NEG_INF; T.haveBest = 0; T.n = 0; T.bestJ = VLR_NEG_INF; T.bestX = 0.0;
     }
     __syncthreads();
@@ -2573,6 +2682,163 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// FORMAT/AFD from the log of the call pass (calling.rs:889-928): one wave per locus filters the logged operand sets with the
+// rules of afd_consider — equal to the MAP on all other samples (VAF and is_discrete), contained in the best event's tree
+// with the sample excluded, one entry per operand key (afd_finish).
+//   1. all record headers at once (directory): lane r classifies record r — how many samples other than the integrated one
+//      differ from the MAP; a record whose key (sample, is_discrete flags, operands, l2fc terms) repeats an earlier one is a
+//      re-visit of the same map keys (an outer chain evaluating a VAF twice) and is dropped;
+//   2. records that agree with the MAP everywhere else (the chain the MAP sits on, typically one): one `contains` walk for the
+//      record, then its whole table goes to the list of its sample with coalesced stores; the entry at the MAP VAF itself and
+//      the matching entries of the records that differ in exactly one sample take the scalar afd_consider path;
+//   3. discrete leaves: classified one per lane, matches through afd_consider.
+__global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, DevBatch batch, DevResults out) {
+    __shared__ WaveSt wst;
+    __shared__ double sh_seen[kMaxSamples * kMaxSet];
+    __shared__ double sh_mapv[kMaxSamples];
+    __shared__ int sh_nseen[kMaxSamples];
+    const DevPlan& p = plan_arg;
+    const int lane = threadIdx.x;
+    const int64_t locus = blockIdx.x;
+    if (locus >= batch.n_loci) return;
+    const int S = p.S;
+    const double* lg = out.afd_log + (size_t)locus * (size_t)out.afd_log_stride;
+    if (__double_as_longlong(lg[0]) < 0) return;  // overflowed: the replay launch handles this locus
+    bool have = true;
+    for (int s = 0; s < S; ++s) { double v = out.map_vaf[locus * S + s]; if (v != v) have = false; }
+    bool art = false;
+    if (out.map_bias) for (int i = 0; i < VLR_N_BIAS; ++i) art = art || out.map_bias[locus * VLR_N_BIAS + i] != 0;
+    if (!have || art) return;  // AFD only exists for a non-artifact MAP
+    Ctx c;
+    c.plan = &plan_arg; c.w = &wst; c.lane = lane; c.S = S;
+    c.afd_seen = sh_seen; c.mapv = sh_mapv; c.afd_nseen = sh_nseen;
+    c.replay = 1; c.hyp = 0; c.afd_mute = 0; c.locus = locus; c.outp = &out; c.status = 0; c.lg = nullptr; c.lg_pos = -1; c.lg_cap = 0; c.lg_nrec = 0;
+    c.vt = 0; c.has_snv = 0; c.refbase = 0; c.altbase = 0;
+    if (lane < S) { sh_mapv[lane] = out.map_vaf[locus * S + lane]; sh_nseen[lane] = 0; }
+    __syncthreads();
+    const int be = UNI(out.best_event[locus]);
+    c.mapGroup = (be == 0) ? 0 : ((be - 1) / 2 + 1);
+    c.mapDisc = UNI((int)out.map_disc[locus]);
+    c.marginal = uni_d(out.ln_marginal[locus]);
+    const int nrec = (int)__double_as_longlong(lg[1]);
+    // ---- 1. classify the records, one per lane (headers, operands and three probes of the table go through LDS so that the
+    // comparison with the earlier records does not chase global memory)
+    __shared__ long long sh_hdr[kLogDir];
+    __shared__ double sh_ops[kLogDir][kMaxSamples];
+    __shared__ double sh_probe[kLogDir][3];
+    int at = 0, n = 0, s_in = -1, disc = 0, nl = 0, kind = 0, grp = 0, mism = 99;
+    long long h = 0;
+    if (lane < nrec) {
+        at = (int)__double_as_longlong(lg[2 + lane]);
+        h = __double_as_longlong(lg[at]);
+        n = (int)(h & 0xffff); s_in = (int)((h >> 16) & 0xf) - 1; disc = (int)((h >> 20) & 0xff); grp = (int)((h >> 28) & 0xff);
+        nl = (int)((h >> 36) & 0xf); kind = (int)((h >> 40) & 3);
+        sh_hdr[lane] = h;
+        if (kind != 3) {
+            for (int s = 0; s < S; ++s) sh_ops[lane][s] = lg[at + 1 + s];
+            const double* X = lg + at + 1 + S + 2 * nl;
+            // two chains with equal keys are the same chain iff they integrate the same interval: first, second and last point
+            sh_probe[lane][0] = X[0]; sh_probe[lane][1] = (kind == 1 && n > 1) ? X[1] : 0.0; sh_probe[lane][2] = (kind == 1) ? X[n - 1] : 0.0;
+        }
+    }
+    __syncthreads();
+    if (lane < nrec && kind != 3) {
+        mism = 0;
+        for (int s = 0; s < S; ++s) {
+            if (s == s_in) continue;
+            if (!(sh_ops[lane][s] == sh_mapv[s] && (((disc >> s) & 1) == ((c.mapDisc >> s) & 1)))) mism++;
+        }
+        // the same map keys as an earlier record? (an outer chain that evaluates a VAF twice runs the inner chain twice)
+        for (int r = 0; r < lane && mism <= 1; ++r) {
+            const long long h2 = sh_hdr[r];
+            if (((h ^ h2) & ~(0xffll << 28)) != 0) continue;  // sample, flags, l2fc count, kind, table length (event group aside)
+            bool same = true;
+            for (int s = 0; s < S; ++s) same = same && (s == s_in || sh_ops[lane][s] == sh_ops[r][s]);
+            if (kind == 1) same = same && sh_probe[lane][0] == sh_probe[r][0] && sh_probe[lane][1] == sh_probe[r][1] && sh_probe[lane][2] == sh_probe[r][2];
+            if (same && nl > 0) {
+                const int at2 = (int)__double_as_longlong(lg[2 + r]);
+                for (int k = 0; k < 2 * nl; ++k) same = same && (__double_as_longlong(lg[at + 1 + S + k]) == __double_as_longlong(lg[at2 + 1 + S + k]));
+            }
+            if (same) mism = 98;
+        }
+    }
+    // ---- 2./3. records in log order
+    for (int r = 0; r < nrec; ++r) {
+        const int k_r = __builtin_amdgcn_readlane(kind, r), m_r = __builtin_amdgcn_readlane(mism, r);
+        if (k_r != 3 && m_r > 1) continue;
+        const int at_r = __builtin_amdgcn_readlane(at, r), n_r = __builtin_amdgcn_readlane(n, r), sin_r = __builtin_amdgcn_readlane(s_in, r);
+        const int nl_r = __builtin_amdgcn_readlane(nl, r);
+        c.group = __builtin_amdgcn_readlane(grp, r);
+        c.disc = __builtin_amdgcn_readlane(disc, r); c.nlfc = nl_r;
+        const int pay = at_r + 1 + S + 2 * nl_r;
+        if (k_r == 3) {  // discrete leaves of one root: n_r x (S VAFs, joint)
+            const double* L = lg + at_r + 1;
+            for (int q0 = 0; q0 < n_r; q0 += 64) {
+                const int q = q0 + lane;
+                int mm = 99;
+                if (q < n_r) {
+                    mm = 0;
+                    for (int s = 0; s < S; ++s)
+                        if (!(L[q * (S + 1) + s] == sh_mapv[s] && ((c.mapDisc >> s) & 1))) mm++;
+                }
+                unsigned long long todo = __ballot(mm <= 1);
+                while (todo) {
+                    const int qq = q0 + __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    __syncthreads();
+                    if (lane < S) wst.ops_vaf[lane] = L[qq * (S + 1) + lane];
+                    __syncthreads();
+                    afd_consider(c, uni_d(L[qq * (S + 1) + S]), -1, 0.0);
+                }
+            }
+            continue;
+        }
+        __syncthreads();
+        if (lane < S) wst.ops_vaf[lane] = lg[at_r + 1 + lane];
+        if (lane < nl_r) {
+            const long long t = __double_as_longlong(lg[at_r + 1 + S + 2 * lane]);
+            wst.lfc_a[lane] = (int)(t & 0xff); wst.lfc_b[lane] = (int)((t >> 8) & 0xff); wst.lfc_cmp[lane] = (int)((t >> 16) & 0xff);
+            wst.lfc_val[lane] = lg[at_r + 1 + S + 2 * lane + 1];
+        }
+        __syncthreads();
+        if (k_r == 2) { afd_consider(c, uni_d(lg[pay]), -1, 0.0); continue; }
+        const double* X = lg + pay;
+        const double* V = X + n_r;
+        const double mx = uni_d(sh_mapv[sin_r]);
+        const bool bulk = m_r == 0 && group_contains(c, c.mapGroup, sin_r, 0.0, sin_r);  // the integrated sample is excluded: x does not matter
+        for (int q0 = 0; q0 < n_r; q0 += 64) {
+            const int q = q0 + lane;
+            const bool on = q < n_r;
+            const double xq = on ? X[q] : __builtin_nan(""), vq = on ? V[q] : 0.0;
+            // one map key per revisited point of the chain: first occurrence only
+            bool dup = false;
+            for (int j = 0; j < q0 + 64 && j < n_r; ++j) dup = dup || (j < q && X[j] == xq);
+            if (bulk) {
+                const bool emit = on && !dup;
+                const unsigned long long em = __ballot(emit);
+                const int64_t slot = locus * S + sin_r;
+                int base = 0;
+                if (lane == 0 && em) base = atomicAdd(&out.afd_count[slot], __popcll(em));
+                base = UNI(base);
+                const int idx = base + __popcll(em & ((1ull << lane) - 1ull));
+                if (emit && idx < out.afd_capacity) {
+                    out.afd_vaf[slot * out.afd_capacity + idx] = xq;  // continuous operand: no discrete marker
+                    out.afd_lnprob[slot * out.afd_capacity + idx] = vq - c.marginal;
+                }
+            }
+            // the other samples' lists: only operand sets that equal the MAP in the integrated sample as well
+            unsigned long long todo = __ballot(on && !dup && xq == mx);
+            while (todo) {
+                const int qq = q0 + __builtin_ctzll(todo);
+                todo &= todo - 1;
+                afd_consider(c, uni_d(V[qq]), sin_r, uni_d(X[qq]), bulk ? sin_r : -1);
+            }
+        }
+    }
+    afd_finish(c);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Two builds of the same kernel: WPE = 2 waves per SIMD (no spills) for workgroups whose LDS footprint allows only 8 of
 // them per CU anyway, WPE = 3 (168 VGPRs, 32 of them spilled) where 9 or more fit (single-sample 30x: 12 workgroups,
 // +33 %).  The launcher picks by LDS bytes.
@@ -2585,6 +2851,8 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
     const int lane = threadIdx.x;
     const int64_t locus = blockIdx.x;
     if (locus >= batch.n_loci) return;
+    // replay launch next to an AFD log: only the loci whose log region overflowed are re-evaluated
+    if (out.replay && out.afd_log && __double_as_longlong(out.afd_log[(size_t)locus * (size_t)out.afd_log_stride]) >= 0) return;
     const int S = p.S;
     WaveSt* w = &wst;
 
@@ -2626,6 +2894,8 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
     if (lane == 0) { w->work[0] = 0; w->work[1] = 0; }
     c.need_batch = 0; c.bt_nt = 0; c.bt_inner = 0;
     c.replay = out.replay; c.locus = locus; c.outp = &out; c.mapGroup = 0; c.mapDisc = 0; c.marginal = 0.0;
+    c.lg = (out.afd_log && !out.replay) ? out.afd_log + (size_t)locus * (size_t)out.afd_log_stride : nullptr;
+    c.lg_pos = kLogFirst; c.lg_cap = (int)out.afd_log_stride; c.lg_nrec = 0; c.hyp = 0;
 #ifdef VLR_PROFILE
     for (int i = 0; i < 24; ++i) c.prof[i] = 0;
 #endif
@@ -3177,6 +3447,10 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
             }
         }
     }
+    if (c.lg && lane == 0) {  // words used (-1: overflow, the replay launch takes over) and the record count
+        c.lg[0] = __longlong_as_double((long long)c.lg_pos);
+        c.lg[1] = __longlong_as_double((long long)c.lg_nrec);
+    }
     if (lane == 0) {
         out.status[locus] = c.status;
         if (out.work) {
@@ -3240,6 +3514,12 @@ extern "C" int vlr_launch_selftest_stream(const float* in, double* out, long lon
 extern "C" int vlr_launch_selftest_math(int which, const double* a, const double* b, double* out, long long n, void* stream) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(vlr::vlr_selftest_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, which, a, b, out, n);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vlr_launch_afd_kernel(const vlr::DevPlan* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out, void* stream) {
+    if (batch->n_loci <= 0) return 0;
+    hipLaunchKernelGGL(vlr::vlr_afd_kernel, dim3((unsigned)batch->n_loci), dim3(64), 0, (hipStream_t)stream, *plan_host, *batch, *out);
     return (int)hipGetLastError();
 }
 

@@ -121,6 +121,12 @@ struct DevResults {
     int32_t afd_capacity;
     int32_t replay;         // 0: call pass, 1: AFD replay pass
     double* escratch;       // [n_loci * max_obs] third likelihood coefficient per kept observation (kernel scratch, plan-owned)
+    // AFD log (plan-owned, only when AFD lists are requested): the call pass appends every evaluated leaf operand set of the
+    // clean events — whole visited-point tables of the Range chains, single discrete leaves — to a per-locus region of
+    // afd_log_stride 8-byte words; vlr_afd_kernel filters it once the MAP is known.  Word 0 of a region = words used, or
+    // -1 when the region overflowed (that locus falls back to the replay launch).
+    double* afd_log;
+    long long afd_log_stride;
 };
 
 }  // namespace vlr
