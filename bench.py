@@ -196,6 +196,7 @@ def main():
     plan = engine.Plan(cfg.scenario, device=local_rank)
     # the caller knows its pileups: size the kernel's LDS coefficient area to the deepest locus of the batch
     plan.set_max_obs(int(batch.depth().sum(axis=1).max()))
+    plan.reserve(batch.n_loci, with_afd=args.afd)  # vlr_batch_run then only enqueues work on the stream
     out = engine.DeviceResults(batch.n_loci, plan.n_out, plan.n_samples, dev)
     stream = torch.cuda.current_stream().cuda_stream
     n_total = n_loci * world

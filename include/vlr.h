@@ -300,6 +300,11 @@ int  vlr_batch_run_host(vlr_plan* plan, const vlr_batch* in, vlr_results* out);
 void* vlr_host_alloc(size_t bytes);
 void  vlr_host_free(void* p);
 
+/* Size the plan's own device buffers (kernel scratch; with_afd != 0: AFD scratch and log) for batches of up to n_loci loci of
+ * at most the configured observation count.  vlr_batch_run grows them on demand with hipMalloc/hipFree, which synchronise the
+ * device: after vlr_plan_reserve with the largest batch size, vlr_batch_run only enqueues work on the stream. */
+int  vlr_plan_reserve(vlr_plan* plan, int64_t n_loci, int with_afd);
+
 /* Duration in milliseconds of the most recent kernel launch sequence of vlr_batch_run on this plan,
  * measured with HIP events on the launch stream (synchronises on the stop event).  For bench.py.       */
 int  vlr_plan_last_kernel_ms(vlr_plan* plan, float* ms);

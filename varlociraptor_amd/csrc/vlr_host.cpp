@@ -267,6 +267,7 @@ struct vlr_plan {
     // AFD log, one per slot (only when AFD lists are requested): afd_log_words 8-byte words per locus
     void* afd_log[2] = {nullptr, nullptr};
     size_t afd_log_bytes[2] = {0, 0};
+    size_t afd_log_words = 0;
     int slot = 0;  // slot used by the next vlr_batch_run (set by vlr_batch_run_host)
 };
 
@@ -800,6 +801,47 @@ int vlr_plan_set_max_obs(vlr_plan* plan, int max_obs_per_locus) {
     return VLR_OK;
 }
 
+// Device buffers a batch of n_loci needs besides the caller's: kernel scratch (third coefficients), and with AFD the replay
+// scratch and the AFD log.  Grown here (hipMalloc/hipFree synchronise the device); vlr_batch_run calls this itself, callers that
+// need a strictly asynchronous vlr_batch_run size the plan once with vlr_plan_reserve.
+static int ensure_buffers(vlr_plan* plan, int64_t n_loci, int max_obs, bool want_afd, bool want_log) {
+    const int k = plan->slot & 1;
+    const size_t L = (size_t)n_loci;
+    auto grow = [&](void** buf, size_t* have, size_t need, bool optional) -> int {
+        if (need <= *have) return VLR_OK;
+        if (*buf) (void)hipFree(*buf);
+        *buf = nullptr; *have = 0;
+        if (hipMalloc(buf, need) != hipSuccess) {
+            (void)hipGetLastError();
+            *buf = nullptr;
+            return optional ? VLR_OK : fail(VLR_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed", need);
+        }
+        *have = need;
+        return VLR_OK;
+    };
+    int rc = grow(&plan->escratch[k], &plan->escratch_bytes[k], L * (size_t)max_obs * sizeof(double), false);
+    if (rc != VLR_OK) return rc;
+    if (want_afd) {
+        rc = grow(&plan->afd_scratch[k], &plan->afd_scratch_bytes[k], L + 8 * L + 4 * L + 64, false);
+        if (rc != VLR_OK) return rc;
+        if (want_log) {
+            size_t words = 1 + (size_t)36 * (1 + plan->host.S + 2 * (size_t)plan->host.table_cap);
+            words = std::min<size_t>((words + 63) & ~(size_t)63, (size_t)1 << 15);
+            plan->afd_log_words = words;
+            (void)grow(&plan->afd_log[k], &plan->afd_log_bytes[k], L * words * sizeof(double), true);  // no room: replay alone
+        }
+    }
+    return VLR_OK;
+}
+
+int vlr_plan_reserve(vlr_plan* plan, int64_t n_loci, int with_afd) {
+    if (!plan || n_loci < 0) return fail(VLR_ERR_INVALID_ARGUMENT, "bad argument");
+    HIP_TRY(hipSetDevice(plan->device));
+    int max_obs = plan->max_obs > 0 ? plan->max_obs : plan->max_depth_per_sample * plan->host.S;
+    max_obs = (max_obs + 3) & ~3;
+    return ensure_buffers(plan, n_loci, max_obs, with_afd != 0, with_afd != 0 && !getenv("VLR_AFD_REPLAY"));
+}
+
 int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* stream) {
     using namespace vlr;
     if (!plan || !in || !out) return fail(VLR_ERR_INVALID_ARGUMENT, "null argument");
@@ -827,17 +869,16 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
     r.ln_posterior = out->ln_posterior; r.ln_marginal = out->ln_marginal; r.map_vaf = out->map_vaf;
     r.map_bias = out->map_bias; r.best_event = out->best_event; r.status = out->status;
     r.work = plan->work_dev;
+    int max_obs = plan->max_obs > 0 ? plan->max_obs : plan->max_depth_per_sample * plan->host.S;
+    max_obs = (max_obs + 3) & ~3;
+    {
+        const int rc0 = ensure_buffers(plan, in->n_loci, max_obs, want_afd, want_afd && !getenv("VLR_AFD_REPLAY"));
+        if (rc0 != VLR_OK) return rc0;
+    }
     if (want_afd) {
         // the replay pass needs MAP is_discrete flags, marginal and best event of the first pass
-        size_t L = (size_t)in->n_loci, need = L + 8 * L + 4 * L + 64;
+        const size_t L = (size_t)in->n_loci;
         const int k = plan->slot & 1;
-        if (need > plan->afd_scratch_bytes[k]) {
-            if (plan->afd_scratch[k]) (void)hipFree(plan->afd_scratch[k]);
-            plan->afd_scratch[k] = nullptr;
-            plan->afd_scratch_bytes[k] = 0;
-            if (hipMalloc(&plan->afd_scratch[k], need) != hipSuccess) return fail(VLR_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed", need);
-            plan->afd_scratch_bytes[k] = need;
-        }
         char* sc = (char*)plan->afd_scratch[k];
         if (!r.ln_marginal) r.ln_marginal = (double*)sc;
         if (!r.best_event) r.best_event = (int32_t*)(sc + 8 * L);
@@ -845,34 +886,10 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
         if (!r.map_bias) return fail(VLR_ERR_INVALID_ARGUMENT, "AFD needs map_bias");
         r.afd_count = out->afd_count; r.afd_vaf = out->afd_vaf; r.afd_lnprob = out->afd_lnprob; r.afd_capacity = out->afd_capacity;
     }
-    int max_obs = plan->max_obs > 0 ? plan->max_obs : plan->max_depth_per_sample * plan->host.S;
-    max_obs = (max_obs + 3) & ~3;
-    {
-        const int k = plan->slot & 1;
-        const size_t need = (size_t)in->n_loci * (size_t)max_obs * sizeof(double);
-        if (need > plan->escratch_bytes[k]) {
-            if (plan->escratch[k]) (void)hipFree(plan->escratch[k]);
-            plan->escratch[k] = nullptr;
-            plan->escratch_bytes[k] = 0;
-            if (hipMalloc(&plan->escratch[k], need) != hipSuccess) return fail(VLR_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed", need);
-            plan->escratch_bytes[k] = need;
-        }
-        r.escratch = (double*)plan->escratch[k];
-    }
-    if (want_afd && !getenv("VLR_AFD_REPLAY")) {
-        // AFD log: room for ~36 chain tables of the plan's capacity per locus; a locus that needs more falls back to the replay
-        size_t words = 1 + (size_t)36 * (1 + plan->host.S + 2 * (size_t)plan->host.table_cap);
-        words = std::min<size_t>((words + 63) & ~(size_t)63, (size_t)1 << 15);
-        const int k = plan->slot & 1;
-        const size_t need = (size_t)in->n_loci * words * sizeof(double);
-        if (need > plan->afd_log_bytes[k]) {
-            if (plan->afd_log[k]) (void)hipFree(plan->afd_log[k]);
-            plan->afd_log[k] = nullptr;
-            plan->afd_log_bytes[k] = 0;
-            if (hipMalloc(&plan->afd_log[k], need) == hipSuccess) plan->afd_log_bytes[k] = need;
-            else (void)hipGetLastError();  // no room for the log: the replay launch alone produces the lists
-        }
-        if (plan->afd_log[k]) { r.afd_log = (double*)plan->afd_log[k]; r.afd_log_stride = (long long)words; }
+    r.escratch = (double*)plan->escratch[plan->slot & 1];
+    if (want_afd && !getenv("VLR_AFD_REPLAY") && plan->afd_log[plan->slot & 1]) {
+        r.afd_log = (double*)plan->afd_log[plan->slot & 1];
+        r.afd_log_stride = (long long)plan->afd_log_words;
     }
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipEventRecord(plan->ev_start, st));

@@ -23,7 +23,7 @@ _LIB = None
 
 EXPORTS = [
     "vlr_abi_version", "vlr_build_id", "vlr_last_error", "vlr_plan_create", "vlr_plan_destroy", "vlr_plan_n_out",
-    "vlr_plan_n_samples", "vlr_plan_set_max_depth", "vlr_plan_set_max_obs", "vlr_batch_run", "vlr_batch_run_host",
+    "vlr_plan_n_samples", "vlr_plan_set_max_depth", "vlr_plan_set_max_obs", "vlr_plan_reserve", "vlr_batch_run", "vlr_batch_run_host",
     "vlr_plan_last_kernel_ms", "vlr_plan_work_counters", "vlr_host_alloc", "vlr_host_free",
     "vlr_realign_batch", "vlr_realign_batch_host", "vlr_fdr_threshold", "vlr_selftest_math", "vlr_selftest_stream",
 ]
@@ -199,6 +199,13 @@ class Plan:
         return res
 
     # ---- device pointers (torch tensors) in/out, stream-ordered
+    def reserve(self, n_loci: int, with_afd: bool = False):
+        """Size the plan's device buffers once so that call_device never allocates (vlr_plan_reserve)."""
+        L = lib()
+        L.vlr_plan_reserve.restype = C.c_int
+        L.vlr_plan_reserve.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+        _check(L.vlr_plan_reserve(self._h, int(n_loci), int(bool(with_afd))))
+
     def call_device(self, dbatch: "DeviceBatch", out: "DeviceResults", stream=None):
         bs, rs = dbatch.as_struct(), out.as_struct()
         _check(lib().vlr_batch_run(self._h, C.byref(bs), C.byref(rs), C.c_void_p(stream) if stream else None))
