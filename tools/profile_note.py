@@ -1,0 +1,68 @@
+"""Write profiles/<tag>.md (+ the bench lines and the traffic file) from what tools/profile_round.sh left in gpurun_out/<tag>/.
+   python tools/profile_note.py <tag> ["free-text title"]"""
+import glob, json, os, shutil, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+title = sys.argv[2] if len(sys.argv) > 2 else tag
+O = os.path.join(ROOT, "gpurun_out", tag)
+P = os.path.join(ROOT, "profiles")
+def line(name):
+    path = os.path.join(O, name)
+    if not os.path.exists(path):
+        return None
+    rows = [l for l in open(path).read().splitlines() if l.startswith("{")]
+    return json.loads(rows[-1]) if rows else None
+def rocpd(d):
+    db = glob.glob(os.path.join(O, d, "**", "*.db"), recursive=True)
+    if not db:
+        return "(no trace)\n"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocpd_summary.py"), db[0]], capture_output=True, text=True).stdout
+    return "\n".join(out.splitlines()[:7]) + "\n"
+bid = open(os.path.join(O, "build_id.txt")).read().split()[-1]
+md = ["# %s" % title, "",
+      "Build id `%s` (`vlr_build_id()`).  One gpurun call on a fresh MI355X box, script `tools/profile_round.sh %s`; every rocprofv3" % (bid, tag),
+      "pass is its own run (`--kernel-trace --stats` for durations; `--pmc` passes with `--kernel-trace` only).  Tables made by",
+      "`tools/profile_note.py` from the rocpd databases and the bench lines (committed next to this note as `%s_bench_*.json`)." % tag, "",
+      "## bench.py lines (HBM-resident inputs, 3 timed launches after 1 warm-up)", "",
+      "| workload | units per launch | value | ms per step | kernel ms (HIP events) | evaluations / unit | parity vs oracle | cpu_baseline (oracle, 256 threads) |", "|---|---|---|---|---|---|---|---|"]
+for w in ("config3", "config2", "config4", "config5", "realign"):
+    j = line("bench_%s.json" % w)
+    if not j:
+        continue
+    shutil.copy(os.path.join(O, "bench_%s.json" % w), os.path.join(P, "%s_bench_%s.json" % (tag, w)))
+    rf = j["roofline"]; v = rf.get("valu", {})
+    units = int(round(j["value"] * j["ms_per_step"] / 1e3))
+    ev = v.get("pileup_evals_per_launch")
+    par = j.get("parity") or {}
+    pr = ("max |dposterior| %.1e, max |dMAP VAF| %.1e over %d loci" % (par.get("max_abs_dposterior", 0), par.get("max_abs_dmap_vaf", 0), par.get("n_checked", 0))) if "max_abs_dposterior" in par else ("max |dln p| %.1e over %d pairs" % (par.get("max_abs_dlnprob", 0), par.get("n_checked", 0)))
+    cb = j.get("cpu_baseline") or {}
+    md.append("| %s | %d | %.3f M %s | %.2f | %.2f | %s | %s | %.0f %s |" % (w, units, j["value"] / 1e6, j["unit"], j["ms_per_step"], rf["kernel_ms"],
+              ("%.0f" % (ev / units)) if ev else ("%.0f cells" % (v.get("cells_per_s", 0) * rf["kernel_ms"] / 1e3 / units)), pr, cb.get("value", 0), cb.get("unit", "")))
+j = line("bench_config3_afd.json")
+if j and j.get("with_afd"):
+    shutil.copy(os.path.join(O, "bench_config3_afd.json"), os.path.join(P, "%s_bench_config3_afd.json" % tag))
+    a = j["with_afd"]
+    md += ["", "With AFD lists (`bench.py --afd`, capacity %d): %.3f M loci/s = %.0f %% of the plain rate (%.1f ms for call pass + log filter + replay of overflowed loci), mean %.1f points per sample list, %d truncated lists."
+           % (a["afd_capacity"], a["value"] / 1e6, 100 * a["ratio_to_plain"], a["kernel_ms_both_launches"], a["mean_afd_points_per_sample"], a["truncated_lists"])]
+md += ["", "## rocprofv3 --kernel-trace --stats of `python bench.py --no-cpu-baseline` (config3, 1 M loci per launch)", "", rocpd("stats_config3"),
+       "## … of `python bench.py --afd --no-cpu-baseline`", "", rocpd("stats_config3_afd"),
+       "## … of `python bench.py --workload realign --no-cpu-baseline`", "", rocpd("stats_realign")]
+md += ["## PMC counters per locus (= per wave; config3, 50 000 loci, `tools/pmc_pass.sh`)", ""]
+for name in ("insts", "util", "f64", "icache"):
+    f = os.path.join(O, "pmc", name + ".md")
+    if os.path.exists(f):
+        md += [open(f).read().rstrip(), ""]
+tj = os.path.join(ROOT, "gpurun_out", "traffic_config3.json")
+if os.path.exists(tj):
+    t = json.load(open(tj))
+    if t.get("build_id") == bid:
+        shutil.copy(tj, os.path.join(P, "traffic_config3.json"))
+        md += ["## HBM traffic per 1 M-locus launch (`tools/traffic_measure.sh config3` -> profiles/traffic_config3.json)", "",
+               "    FETCH_SIZE %.0f KB raw x calibration %.3f (4 B/lane stream of known size) = %.2f GB read" % (t["FETCH_SIZE_KB_per_launch"], t["calibration"]["read_4B_per_lane"]["factor"], t["read_bytes_per_launch"] / 1e9),
+               "    WRITE_SIZE %.0f KB raw x calibration %.3f (8 B/lane stream of known size) = %.2f GB written" % (t["WRITE_SIZE_KB_per_launch"], t["calibration"]["write_8B_per_lane"]["factor"], t["write_bytes_per_launch"] / 1e9),
+               "    total %.2f GB vs %.2f GB algorithmic = %.2f x" % (t["hbm_bytes_per_launch"] / 1e9, t["algorithmic_bytes_per_launch"] / 1e9, t["ratio_to_algorithmic"]), ""]
+extra = os.path.join(O, "notes.md")
+if os.path.exists(extra):
+    md += [open(extra).read()]
+open(os.path.join(P, tag + ".md"), "w").write("\n".join(md) + "\n")
+print("\n".join(md))
