@@ -146,16 +146,60 @@ __device__ __forceinline__ int fresh_lane(int lane) {
     return lane;
 }
 
-// wave helpers (wave64; one wave per workgroup so __syncthreads() is a wave-level LDS fence)
-__device__ inline double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+// A wave-uniform double parked in SGPRs (park_sd, at its definition) and re-defined in SGPRs at the point of use (fresh_sd):
+// instruction selection otherwise copies an SGPR value that feeds a vector select into VGPRs where it is DEFINED (outside the
+// loops), and that copy then lives — spilled to scratch — across the kernel.
+struct SgprD { int lo, hi; };
+__device__ __forceinline__ SgprD park_sd(double v) {
+    SgprD r;
+    asm volatile("v_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3" : "=s"(r.lo), "=s"(r.hi) : "v"(__double2loint(v)), "v"(__double2hiint(v)));
+    return r;
 }
-__device__ inline double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
+__device__ __forceinline__ double fresh_sd(const SgprD& v) {
+    int lo, hi;
+    asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "s"(v.lo), "s"(v.hi));
+    return __hiloint2double(hi, lo);
+}
+
+// x / 3.0, correctly rounded, in three instructions (Markstein: with r = RN(1/3), q0 = RN(x r), the exact residual x - 3 q0 and
+// one more FMA give the IEEE quotient; checked against x / 3.0 on 4e8 random doubles).  The compiler's general division is
+// eleven instructions with its scaling steps, and the tail of every chain needs two.
+__device__ __forceinline__ double div3(double x) {
+    const double r = 0.33333333333333331483;  // RN(1/3)
+    const double q0 = x * r;
+    return __builtin_fma(__builtin_fma(-3.0, q0, x), r, q0);
+}
+
+// wave helpers (wave64; one wave per workgroup so __syncthreads() is a wave-level LDS fence).
+// Reductions over the wave: four DPP steps inside each 16-lane row (quad_perm, quad_perm, row_half_mirror, row_mirror: every
+// lane of a row ends with the row's total), then the four row totals are read into SGPRs and combined — the result is
+// wave-uniform.  (The __shfl_xor butterflies these replace go through ds_bpermute: six lane-address registers that the compiler
+// kept alive — and spilled — across the whole kernel, and six LDS round trips per reduction.)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    // every lane has a valid source under these permutations: bound_ctrl with an undefined `old` lets the compiler write the
+    // destination directly instead of copying the source first (three instructions per f64 permute otherwise)
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+__device__ __forceinline__ double lane_d(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_f64<0xB1>(v); v += dpp_f64<0x4E>(v); v += dpp_f64<0x141>(v); v += dpp_f64<0x140>(v);
+    return (lane_d(v, 0) + lane_d(v, 16)) + (lane_d(v, 32) + lane_d(v, 48));
+}
+__device__ __forceinline__ double wave_max(double v) {
+    v = fmax(v, dpp_f64<0xB1>(v)); v = fmax(v, dpp_f64<0x4E>(v)); v = fmax(v, dpp_f64<0x141>(v)); v = fmax(v, dpp_f64<0x140>(v));
+    return fmax(fmax(lane_d(v, 0), lane_d(v, 16)), fmax(lane_d(v, 32), lane_d(v, 48)));
+}
+__device__ __forceinline__ int wave_or(int v) {
+    v |= dpp_i32<0xB1>(v); v |= dpp_i32<0x4E>(v); v |= dpp_i32<0x141>(v); v |= dpp_i32<0x140>(v);
+    return (__builtin_amdgcn_readlane(v, 0) | __builtin_amdgcn_readlane(v, 16)) | (__builtin_amdgcn_readlane(v, 32) | __builtin_amdgcn_readlane(v, 48));
 }
 __device__ inline int popc64(unsigned long long m) { return __popcll(m); }
 
@@ -381,13 +425,14 @@ __device__ __forceinline__ void ddacc_add(DdAcc& a, double v, double m, bool on)
 }
 __device__ inline double ddacc_exp(const DdAcc& a, double m) {
     vlr_det::dd t = a.s;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        vlr_det::dd u{__shfl_xor(t.hi, o), __shfl_xor(t.lo, o)};
-        t = vlr_det::dd_add_dd(t, u);
-    }
-    // every lane holds a sum of all 64 lane sums (a tree, not the same tree on every lane): take lane 0's
-    t.hi = uni_d(t.hi); t.lo = uni_d(t.lo);
+    { vlr_det::dd u{dpp_f64<0xB1>(t.hi), dpp_f64<0xB1>(t.lo)}; t = vlr_det::dd_add_dd(t, u); }
+    { vlr_det::dd u{dpp_f64<0x4E>(t.hi), dpp_f64<0x4E>(t.lo)}; t = vlr_det::dd_add_dd(t, u); }
+    { vlr_det::dd u{dpp_f64<0x141>(t.hi), dpp_f64<0x141>(t.lo)}; t = vlr_det::dd_add_dd(t, u); }
+    { vlr_det::dd u{dpp_f64<0x140>(t.hi), dpp_f64<0x140>(t.lo)}; t = vlr_det::dd_add_dd(t, u); }
+    // the four row sums (wave-uniform from here on); a 106-bit sum: the order does not reach the rounded value
+    const vlr_det::dd r0{lane_d(t.hi, 0), lane_d(t.lo, 0)}, r1{lane_d(t.hi, 16), lane_d(t.lo, 16)};
+    const vlr_det::dd r2{lane_d(t.hi, 32), lane_d(t.lo, 32)}, r3{lane_d(t.hi, 48), lane_d(t.lo, 48)};
+    t = vlr_det::dd_add_dd(vlr_det::dd_add_dd(r0, r1), vlr_det::dd_add_dd(r2, r3));
     return vlr_det::exp_lse_from_sum(m, t);
 }
 
@@ -395,17 +440,6 @@ __device__ inline double ddacc_exp(const DdAcc& a, double m) {
 // pileup likelihood: ln prod_i (c_i + q_i*alpha + e_i*beta) at np points, lanes = (point, slice).
 // Coefficients are AoS triples {c,q,e} (24 B per observation) so one address serves all three reads;
 // consecutive slices read consecutive triples: bank = 6k mod 64, conflict free per 32-lane half.
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    // every lane has a valid source under these permutations: bound_ctrl with an undefined `old` lets the compiler write the
-    // destination directly instead of copying the source first (three instructions per f64 permute otherwise)
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-template <int CTRL>
-__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
 
 // mantissa/exponent renormalisation of a POSITIVE NORMAL double with integer ops on the high word (the
 // fast path guarantees every partial product stays far above 2^-1022)
@@ -529,9 +563,9 @@ __device__ __forceinline__ void reduce_terms(double* P, int* E) {
         P[j] *= dpp_f64<0x4E>(P[j]); E[j] += dpp_i32<0x4E>(E[j]);      // quad_perm [2,3,0,1]
         P[j] *= dpp_f64<0x141>(P[j]); E[j] += dpp_i32<0x141>(E[j]);    // row_half_mirror
         P[j] *= dpp_f64<0x140>(P[j]); E[j] += dpp_i32<0x140>(E[j]);    // row_mirror
-        if (W == 64) {
-            P[j] *= __shfl_xor(P[j], 16); E[j] += __shfl_xor(E[j], 16);
-            P[j] *= __shfl_xor(P[j], 32); E[j] += __shfl_xor(E[j], 32);
+        if (W == 64) {  // the four row products, combined from SGPRs (wave-uniform result)
+            P[j] = (lane_d(P[j], 0) * lane_d(P[j], 16)) * (lane_d(P[j], 32) * lane_d(P[j], 48));
+            E[j] = (__builtin_amdgcn_readlane(E[j], 0) + __builtin_amdgcn_readlane(E[j], 16)) + (__builtin_amdgcn_readlane(E[j], 32) + __builtin_amdgcn_readlane(E[j], 48));
         }
         int e2;
         P[j] = __builtin_frexp(P[j], &e2);  // product of <= 64 mantissas >= 2^-64: one renormalisation suffices
@@ -934,11 +968,12 @@ __device__ inline int log_begin(Ctx& c, int kind, int n, int s_in, int disc, int
     const int at = log_reserve(c, 1 + S + 2 * nl + payload_words);
     if (at < 0) return -1;
     WaveSt* w = c.w;
-    if (c.lane == 0) c.lg[at] = __longlong_as_double(log_header(kind, n, s_in, disc, c.group, nl));
-    if (c.lane < S) c.lg[at + 1 + c.lane] = w->ops_vaf[c.lane];
-    if (c.lane < nl) {
-        c.lg[at + 1 + S + 2 * c.lane] = __longlong_as_double((long long)w->lfc_a[c.lane] | ((long long)w->lfc_b[c.lane] << 8) | ((long long)w->lfc_cmp[c.lane] << 16));
-        c.lg[at + 1 + S + 2 * c.lane + 1] = w->lfc_val[c.lane];
+    const int lane = fresh_lane(c.lane);  // keeps the lane-derived offsets below out of registers that live across the kernel
+    if (lane == 0) c.lg[at] = __longlong_as_double(log_header(kind, n, s_in, disc, c.group, nl));
+    if (lane < S) c.lg[at + 1 + lane] = w->ops_vaf[lane];
+    if (lane < nl) {
+        c.lg[at + 1 + S + 2 * lane] = __longlong_as_double((long long)w->lfc_a[lane] | ((long long)w->lfc_b[lane] << 8) | ((long long)w->lfc_cmp[lane] << 16));
+        c.lg[at + 1 + S + 2 * lane + 1] = w->lfc_val[lane];
     }
     return at + 1 + S + 2 * nl;
 }
@@ -949,7 +984,7 @@ __device__ inline void log_leaf(Ctx& c, double joint) {
 __device__ inline void log_table(Ctx& c, int s_in, const double* tx, const double* tv, int n) {  // a single chain, all 64 lanes
     const int at = log_begin(c, 1, n, s_in, c.disc & ~(1 << s_in), 2 * n);
     if (at < 0) return;
-    for (int i = c.lane; i < n; i += 64) { c.lg[at + i] = tx[i]; c.lg[at + n + i] = tv[i]; }
+    for (int i = fresh_lane(c.lane); i < n; i += 64) { c.lg[at + i] = tx[i]; c.lg[at + n + i] = tv[i]; }
 }
 
 // ---- all-discrete roots (DevDLeaf): every leaf of the root on its own lane --------------------------------------
@@ -1068,8 +1103,7 @@ __device__ inline double eval_discrete_root(Ctx& c, int l0, int l1) {
         }
     }
     // other groups
-    for (int o = 32; o > 0; o >>= 1) gm |= (unsigned)__shfl_xor((int)gm, o);
-    gm = (unsigned)UNI((int)gm);
+    gm = (unsigned)wave_or((int)gm);
     while (gm) {
         const int g = __builtin_ctz(gm);
         gm &= gm - 1;
@@ -1281,7 +1315,7 @@ __device__ inline bool range_advance(Ctx& c, RangeSt& r, const double* tx, const
     double arm = (r.mid < r.first_mid) ? (r.hi + r.first_mid) / 2.0 : (r.first_mid + r.lo) / 2.0;
     double lo3 = fmax(r.mid - r.res * 3.0, r.lo);
     double hi3 = fmin(r.mid + r.res * 3.0, r.hi);
-    double sa = (r.mid - lo3) / 3.0, sb = (hi3 - r.mid) / 3.0;  // itertools_num::linspace step, n = 4
+    double sa = div3(r.mid - lo3), sb = div3(hi3 - r.mid);  // itertools_num::linspace step, n = 4
     r.pend[0] = arm;
     r.pend[1] = lin_pt(lo3, sa, 0.0);
     r.pend[2] = lin_pt(lo3, sa, 1.0);
@@ -1473,7 +1507,7 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
             double arm = (mid < first_mid) ? (hi + first_mid) / 2.0 : (first_mid + lo) / 2.0;
             double lo3 = fmax(mid - res * 3.0, lo);
             double hi3 = fmin(mid + res * 3.0, hi);
-            double sa = (mid - lo3) / 3.0, sb = (hi3 - mid) / 3.0;  // itertools_num::linspace step, n = 4
+            double sa = div3(mid - lo3), sb = div3(hi3 - mid);  // itertools_num::linspace step, n = 4
             if (lane < 7) {
                 double v;
                 if (lane == 0) v = arm;
@@ -1563,7 +1597,7 @@ __device__ __forceinline__ double row_bcast(double v) {
 // hold {c, q} = {1, 0}, so their term is exactly 1.  Same association as accum_terms_e's two-term groups (mantissas are
 // bit-identical); no renormalisation: every term is in [2^-70, 2] (WaveSt::vfast), 13 of them stay normal.
 constexpr int kRegSlots = 13;  // 16 * 13 = 208 observations of the integrated sample
-constexpr int kRegHeld = 8;    // slots whose coefficient pairs stay in registers for the whole batch; deeper slots of the 13-slot
+constexpr int kRegHeld = 7;    // slots whose coefficient pairs stay in registers for the whole batch; deeper slots of the 13-slot
                                // variant are re-read from LDS every pass (five b128 reads): holding all 13 pushed the
                                // 3-waves-per-SIMD build 20 VGPRs over its budget and the spills around the batch loop went to HBM
 template <int NS>
@@ -1706,16 +1740,22 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
         const bool isI = phase == RP_INIT, isR = phase == RP_ROUND, isTS = phase == RP_TAIL || phase == RP_SIMPSON;
         const bool srch = go && (isI || isR);
         tn = go ? tn + npp : tn;
-        int kk = 0;  // argmax over {left, middle1, middle2, right}; lowest index wins ties
-        double vb = vL;
-        kk = j1 > vb ? 1 : kk; vb = j1 > vb ? j1 : vb;
-        kk = j2 > vb ? 2 : kk; vb = j2 > vb ? j2 : vb;
-        kk = vR > vb ? 3 : kk;
-        const double nL = isI ? lo : kk == 2 ? px1 : kk == 3 ? px2 : L;
-        const double nvL = isI ? j0 : kk == 2 ? j1 : kk == 3 ? j2 : vL;
-        const double nR = isI ? hi : kk == 0 ? px1 : kk == 1 ? px2 : R;
-        const double nvR = isI ? j1 : kk == 0 ? j1 : kk == 1 ? j2 : vR;
-        L = srch ? nL : L; vL = srch ? nvL : vL; R = srch ? nR : R; vR = srch ? nvR : vR;
+        // argmax over {left, middle1, middle2, right}, lowest index wins ties (adaptive_integration.rs:70-82): as three
+        // compare masks.  0: [L, m1]  1: [L, m2]  2: [m1, R]  3: [m2, R] — the new bracket keeps one end and takes one of the
+        // two middles, so the update is two selects for the middle and one per bracket field (INIT only sets the values)
+        const bool c1 = j1 > vL;
+        const double vb1 = c1 ? j1 : vL;
+        const bool c2 = j2 > vb1;
+        const double vb2 = c2 ? j2 : vb1;
+        const bool c3 = vR > vb2;
+        const bool keepR = c3 || c2;                 // kk >= 2: the left end moves
+        const bool useM2 = c3 || (!c2 && c1);        // kk odd: the moving end goes to middle2
+        const double mX = useM2 ? px2 : px1, mV = useM2 ? j2 : j1;
+        const bool rnd = go && isR, ini = go && isI;
+        const bool updL = rnd && keepR, updR = rnd && !keepR;
+        L = updL ? mX : L; R = updR ? mX : R;
+        vL = ini ? j0 : (updL ? mV : vL);
+        vR = ini ? j1 : (updR ? mV : vR);
         const bool more = (((R - L) >= res) && L < R) || isI;  // the first round always happens (mid is None)
         const bool toRound = srch && more, toTail = srch && !more;
         const double nmid = (R + L) / 2.0;
@@ -1735,7 +1775,7 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
             const double arm = (mid < first_mid) ? (hi + first_mid) / 2.0 : (first_mid + lo) / 2.0;
             const double lo3 = fmax(mid - res * 3.0, lo);
             const double hi3 = fmin(mid + res * 3.0, hi);
-            const double sa = (mid - lo3) / 3.0, sb = (hi3 - mid) / 3.0;  // itertools_num::linspace step, n = 4
+            const double sa = div3(mid - lo3), sb = div3(hi3 - mid);  // itertools_num::linspace step, n = 4
             const double t0 = k == 0 ? arm : k == 3 ? lin_pt(lo3, sa, 2.0) : lin_pt(mid, sb, 3.0);
             const double t1 = k == 0 ? lin_pt(lo3, sa, 0.0) : lin_pt(mid, sb, 1.0);
             const double t2 = k == 0 ? lin_pt(lo3, sa, 1.0) : lin_pt(mid, sb, 2.0);
@@ -1938,7 +1978,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
                     double arm = (mid < first_mid) ? (hi + first_mid) / 2.0 : (first_mid + lo) / 2.0;
                     double lo3 = fmax(mid - res * 3.0, lo);
                     double hi3 = fmin(mid + res * 3.0, hi);
-                    double sa = (mid - lo3) / 3.0, sb = (hi3 - mid) / 3.0;
+                    double sa = div3(mid - lo3), sb = div3(hi3 - mid);
                     if (rl < 7) {
                         double v;
                         if (rl == 0) v = arm;
@@ -3147,6 +3187,10 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
         c.marginal = uni_d(out.ln_marginal[locus]);
         hyps = 1u;
     }
+    // wave-uniform doubles of the hypothesis loop, computed once and parked in SGPRs (left to the compiler they are hoisted
+    // into VGPRs and spilled to scratch across the loop)
+    const double ln_bias_share = uni_d(kLn05 + log(1.0 / (double)n_biases));
+    const SgprD reverse_rate = park_sd(1.0 - forward_rate);
     for (int h = 0; h < kNHyp; ++h) {
         if (!((hyps >> h) & 1u)) continue;
         c.hyp = h;
@@ -3190,7 +3234,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                     else if (strand == VLR_STRAND_BOTH) sb_alt = exp(pdo);
                     else if (strand == VLR_STRAND_NONE) sb_alt = 1.0;
                     else {
-                        double rate = (strand == VLR_STRAND_FORWARD) ? forward_rate : 1.0 - forward_rate;
+                        double rate = (strand == VLR_STRAND_FORWARD) ? forward_rate : fresh_sd(reverse_rate);
                         sb_alt = rate * (-expm1(pdo));  // ln(rate) + prob_single_overlap
                     }
                     // orientation (read_orientation_bias.rs:18-36)
@@ -3262,7 +3306,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
 
         PROF_ADD(c, 2);  // coefficient pass
         // ---- events (calling.rs:654-687): absent + clean events under h = none, artifact twins otherwise
-        const double bias_prior = uni_d((h == 0) ? kLn05 : kLn05 + log(1.0 / (double)n_biases));  // modes/generic.rs:437-441
+        const double bias_prior = (h == 0) ? kLn05 : ln_bias_share;  // modes/generic.rs:437-441
         const int first_ev = (h == 0) ? -1 : 0;
         // pass 0 (probe): roots that are a single innermost chain are deferred and run together, one per DPP row;
         // pass 1: the remaining (nested / branching / set-valued) roots through the general walk
@@ -3314,7 +3358,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                 if (st == IT_ROOT) {
                     u = (e < 0) ? 0 : (1 + 2 * e + (h == 0 ? 0 : 1));
                     c.group = e + 1;
-                    c.defer_ok = ((pass == 0) && rc_ < 64) ? 1 : 0;
+                    c.defer_ok = (1 - pass) & (int)((unsigned)(rc_ - 64) >> 31);  // pass == 0 && rc_ < 64, as integer arithmetic (stays a scalar)
                     c.defer_slot = u;
                     __syncthreads();
                     c.curJ = uni_d(mapJ[u]);
