@@ -101,6 +101,8 @@ struct WaveSt {
     double curMapVaf[kMaxSamples];
     int cs_node[kContainStack], cs_mask[kContainStack];
     ChainTask task[kRows];
+    ChainTask stash;                  // one held event-level chain that found no free row yet (see the event loop: "held chains")
+    double stash_vaf[kMaxSamples];
     BatchOuter bo;
     WalkSave wk;
     unsigned long long work[2];  // [0] pileup evaluations, [1] observation terms (lane 0 adds; profiling aid)
@@ -689,6 +691,7 @@ struct Ctx {
     int replay, mapGroup, mapDisc;
     int defer_ok, deferred, ndef, defer_slot;  // event-level deferral of simple chains into a row-parallel batch
     int need_batch, bt_nt, bt_inner;           // walk_root asks the event loop to run run_chain_batch (single inline site, few live registers)
+    int nhold, nstash, hold_inner;             // held event-level chains: nhold of them parked in the TOP rows (tasks kRows-1, ...), one more in WaveSt::stash
     int afd_mute;  // replay: the current path repeats an outer VAF already visited by its chain (duplicate map key)
     int ehas;      // bit s: sample s has non-zero third coefficients (constant per locus, see WaveSt::ehas)
     double* lg;    // AFD log region of this locus (DevResults::afd_log) or nullptr
@@ -1597,7 +1600,7 @@ __device__ __forceinline__ double row_bcast(double v) {
 // hold {c, q} = {1, 0}, so their term is exactly 1.  Same association as accum_terms_e's two-term groups (mantissas are
 // bit-identical); no renormalisation: every term is in [2^-70, 2] (WaveSt::vfast), 13 of them stay normal.
 constexpr int kRegSlots = 13;  // 16 * 13 = 208 observations of the integrated sample
-constexpr int kRegHeld = 7;    // slots whose coefficient pairs stay in registers for the whole batch; deeper slots of the 13-slot
+constexpr int kRegHeld = 8;    // slots whose coefficient pairs stay in registers for the whole batch; deeper slots of the 13-slot
                                // variant are re-read from LDS every pass (five b128 reads): holding all 13 pushed the
                                // 3-waves-per-SIMD build 20 VGPRs over its budget and the spills around the batch loop went to HBM
 template <int NS>
@@ -1669,14 +1672,14 @@ struct RegChain {
 template <int NS>
 __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
     const DevPlan& p = *c.plan;
-    const int rl = q.rl, D = q.D, simpson_n = q.simpson_n;
+    const int rl0 = q.rl, D = q.D, simpson_n = q.simpson_n;
     const double lo = q.lo, hi = q.hi, res = q.res;
     constexpr int NR = NS < kRegHeld ? NS : kRegHeld;
     const double* lcoef = c.coef + 2 * q.off;
     double cc[NR], cq[NR];
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
-        const int i = rl + 16 * j;
+        const int i = rl0 + 16 * j;
         const double* a = c.coef + 2 * (q.off + (i < D ? i : 0));
         const double c0 = a[0], q0 = a[1];
         cc[j] = i < D ? c0 : 1.0; cq[j] = i < D ? q0 : 0.0;
@@ -1690,6 +1693,7 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
     PROF_ADD(c, 7);  // batch prologue (task fields, coefficient registers)
     while (__ballot(!done)) {
         PROF_ADD(c, 15);
+        const int rl = fresh_lane(rl0);  // lane masks (rl == 1, rl < npp, ...) are recomputed: one compare each instead of two lane reads of a spilled pair
         const bool over = !done && (tn + npp > q.cap);
         failed = failed || over;
         done = done || over;
@@ -1799,8 +1803,8 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
     q.tn = tn; q.failed = failed; q.sawnan = sawnan;
 }
 
-__device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
-    nt = UNI(nt); inner = UNI(inner);
+__device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) {
+    rowmask = UNI(rowmask); inner = UNI(inner);
     PROF_ADD(c, 6);  // batch preparation (task setup, fixed-sample likelihoods)
 #ifdef VLR_PROFILE
     c.prof[10] += 1;
@@ -1808,14 +1812,14 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int nt, int inner) {
     const DevPlan& p = *c.plan;
     WaveSt* w = c.w;
     const int lane = fresh_lane(c.lane), row = lane >> 4, rl = lane & 15;
-    const bool rowon = row < nt;
+    const bool rowon = (rowmask >> row) & 1;
     const int cap = c.cap;
     VLR_WAVE_FENCE();
-    const ChainTask& T = w->task[rowon ? row : 0];
+    const ChainTask& T = w->task[rowon ? row : __builtin_ctz(rowmask)];
     const double lo = T.lo, hi = T.hi, res = T.res, fixed = T.fixed;
     const RangeV orig{T.ostart, T.oend, T.olex, T.orex};
     const int simpson_n = T.simpson_n, pidx = T.pidx, contained = T.contained;
-    const double* tvr = c.tvaf + (rowon ? row : 0) * c.S;
+    const double* tvr = c.tvaf + (rowon ? row : __builtin_ctz(rowmask)) * c.S;
     double* tx = c.rowX + row * cap;
     double* tv = c.rowV + row * cap;
     double* pend = w->bpend[row];
@@ -2261,7 +2265,8 @@ __device__ __forceinline__ bool bo_setup(Ctx& c, const Frame& f, RangeSt& r) {
     const int lane = fresh_lane(c.lane), S = c.S;
     const int np = UNI(B.np), c0 = UNI(B.c0), s_in = UNI(B.s_in), s_out = UNI(B.s_out), chn = UNI(B.chn);
     const bool dead = UNI(B.dead) != 0;
-    const int nt = (np - c0) < kRows ? (np - c0) : kRows;
+    const int free_rows = kRows - c.nhold;  // held event-level chains keep the top rows (they ride along with this batch)
+    const int nt = (np - c0) < free_rows ? (np - c0) : free_rows;
     PROF_ADD(c, 18);  // outer batch: entry (fixed samples) / delivery of the previous pass
     __syncthreads();
     if (lane == 0) w->bo.nt = nt;
@@ -2341,7 +2346,7 @@ __device__ __forceinline__ bool bo_deliver(Ctx& c, const Frame& f, RangeSt& r, d
             scan_chain_candidates(c, c.rowX + i * c.cap, c.rowV + i * c.cap, UNI(T.n), io, UNI(T.contained), UNI(T.alive), s_in);
         }
     }
-    const int c1 = c0 + kRows;
+    const int c1 = c0 + nt;
     __syncthreads();
     if (c1 < np) {
         if (lane == 0) w->bo.c0 = c1;
@@ -2358,15 +2363,16 @@ __device__ __forceinline__ bool bo_deliver(Ctx& c, const Frame& f, RangeSt& r, d
 // (tumor-normal: somatic_tumor, germline_het, germline_hom) contributes exactly one innermost chain.  Such chains of
 // different events are collected and run together, one per DPP row (run_chain_batch); flush_deliver hands the
 // integrals to the event accumulators and the MAP candidates to the event slots.
-__device__ __forceinline__ void flush_deliver(Ctx& c, double* evM, double* evS, double bias_prior) {
+__device__ __forceinline__ void flush_deliver(Ctx& c, int rowmask, double* evM, double* evS, double bias_prior) {
     // (the chains were run by the event loop's single run_chain_batch site; a lone deferred chain takes the same path)
     WaveSt* w = c.w;
-    const int nt = c.ndef;
-    const int s_in = UNI(w->task[0].inner);
+    rowmask = UNI(rowmask);
     __syncthreads();
-    for (int i = 0; i < nt; ++i) {
+    while (rowmask) {
+        const int i = __builtin_ctz(rowmask);
+        rowmask &= rowmask - 1;
         const ChainTask& T = w->task[i];
-        const int u = UNI(T.u);
+        const int u = UNI(T.u), s_in = UNI(T.inner);
         // restore the context of the deferred leaf: operands, event group, flags, and the slot's MAP candidate
         __syncthreads();
         if (c.lane < c.S) { w->ops_vaf[c.lane] = c.tvaf[i * c.S + c.lane]; w->curMapVaf[c.lane] = c.mapVaf[u * c.S + c.lane]; }
@@ -2391,7 +2397,23 @@ __device__ __forceinline__ void flush_deliver(Ctx& c, double* evM, double* evS, 
         if (c.lane < c.S) c.mapVaf[u * c.S + c.lane] = w->curMapVaf[c.lane];
         __syncthreads();
     }
-    c.ndef = 0;
+}
+// one chain task with its operands from row `from` (or the stash: from < 0) to row `to` (or the stash: to < 0)
+__device__ __forceinline__ void move_task(Ctx& c, int from, int to) {
+    WaveSt* w = c.w;
+    const int lane = fresh_lane(c.lane);
+    constexpr int NW = (int)(sizeof(ChainTask) / 8);
+    static_assert(sizeof(ChainTask) % 8 == 0, "ChainTask is copied in 8-byte words");
+    const double* src = (const double*)(from < 0 ? &w->stash : &w->task[from]);
+    double* dst = (double*)(to < 0 ? &w->stash : &w->task[to]);
+    const double* vs = from < 0 ? w->stash_vaf : c.tvaf + from * c.S;
+    double* vd = to < 0 ? w->stash_vaf : c.tvaf + to * c.S;
+    __syncthreads();
+    const double a = src[lane < NW ? lane : 0], b = vs[lane < c.S ? lane : 0];
+    __syncthreads();
+    if (lane < NW) dst[lane] = a;
+    if (lane < c.S) vd[lane] = b;
+    __syncthreads();
 }
 
 // node id of the single child of `fnode` if that child is a leaf Sample node with a proper Range spectrum, else -1
@@ -3312,6 +3334,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
         // pass 1: the remaining (nested / branching / set-valued) roots through the general walk
         c.ndef = 0;
         c.deferred = 0;
+        c.nhold = 0; c.nstash = 0; c.hold_inner = -1;
         unsigned long long todo = 0ull;  // roots left for pass 1 (bit = running root counter, first 64 roots)
         // The two passes over (event, root) are an explicit iterator so that the chain batches — asked for by a resumable
         // walk (outer Range over a leaf Range) or by a full / final set of deferred event-level chains — all run at ONE
@@ -3324,7 +3347,9 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
             int u = 0, root = 0, resume = 0;
             bool fresh = true;  // (e, ri) not yet considered
             for (;;) {
-                int run_nt = 0, run_inner = 0, run_kind = 0;  // 1: batch of the walk, 2: deferred chains, then same root, 3: deferred chains at the end of pass 0
+                // run_kind 1: batch of the walk (+ held chains riding along in its free rows), 2: a full set of deferred chains, then
+                // the same root again, 3: the held chains that found no batch to ride along with, at the end of pass 1
+                int run_mask = 0, run_inner = 0, run_kind = 0, piggy = 0;
                 if (st == IT_NEXT) {
                     // advance to the next root this pass has to look at
                     bool found = false;
@@ -3349,9 +3374,26 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                             pass = 1; e = first_ev; rc_ = 0; fresh = true;
                             ri = (e < 0) ? 0 : ldc(p.root_off + e);
                             r1 = (e < 0) ? 1 : ldc(p.root_off + e + 1);
-                            if (c.ndef > 0) { run_kind = 3; run_nt = c.ndef; run_inner = UNI(w->task[0].inner); }
+                            if (c.ndef > 0 && (c.replay || todo == 0ull)) {  // nothing left that could give them a ride
+                                run_kind = 3; run_mask = (1 << c.ndef) - 1; run_inner = UNI(w->task[0].inner); c.ndef = 0;
+                            } else if (c.ndef > 0) {
+                                // Held chains: instead of a batch of their own (three of four rows busy in the tumor-normal
+                                // scenarios) the deferred chains ride along in the free rows of the batches that the nested
+                                // roots of pass 1 ask for (2, 3, 3, ... of four rows busy).  Two are parked in the top rows,
+                                // a third in WaveSt::stash; bo_setup leaves the parked rows alone.
+                                const int nd = c.ndef;
+                                c.hold_inner = UNI(w->task[0].inner);
+                                move_task(c, nd - 1, kRows - 1);
+                                if (nd >= 2) move_task(c, nd - 2, kRows - 2);
+                                if (nd >= 3) move_task(c, nd - 3, -1);
+                                c.nhold = nd >= 2 ? 2 : 1; c.nstash = nd >= 3 ? 1 : 0; c.ndef = 0;
+                            }
+                        } else if (c.nhold + c.nstash > 0) {  // nobody gave them a ride
+                            if (c.nstash) { move_task(c, -1, kRows - 1 - c.nhold); c.nhold += 1; c.nstash = 0; }
+                            run_kind = 3; run_mask = ((1 << c.nhold) - 1) << (kRows - c.nhold); run_inner = c.hold_inner;
+                            c.nhold = 0;
                         } else st = IT_DONE;
-                    } else if (c.ndef == kRows) { run_kind = 2; run_nt = c.ndef; run_inner = UNI(w->task[0].inner); }
+                    } else if (c.ndef == kRows) { run_kind = 2; run_mask = (1 << kRows) - 1; run_inner = UNI(w->task[0].inner); c.ndef = 0; }
                     else st = IT_ROOT;
                 }
                 if (st == IT_DONE) break;
@@ -3383,7 +3425,13 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                 }
                 if (st == IT_WALK) {
                     const double dens = uni_d(walk_root(c, root, resume));
-                    if (c.need_batch) { c.need_batch = 0; run_kind = 1; run_nt = c.bt_nt; run_inner = c.bt_inner; }
+                    if (c.need_batch) {
+                        c.need_batch = 0; run_kind = 1; run_mask = (1 << c.bt_nt) - 1; run_inner = c.bt_inner;
+                        if ((c.nhold | c.nstash) && c.hold_inner == c.bt_inner) {  // (batches of the walk carry no l2fc terms)
+                            if (c.nhold == 0 && c.bt_nt < kRows) { move_task(c, -1, kRows - 1); c.nhold = 1; c.nstash = 0; }
+                            if (c.nhold) { piggy = ((1 << c.nhold) - 1) << (kRows - c.nhold); run_mask |= piggy; }
+                        }
+                    }
                     else {
                         if (c.deferred == 1) c.deferred = 0;                                 // delivered by flush_deliver
                         else if (c.deferred == 2) { c.deferred = 0; todo |= 1ull << rc_; }  // second pass
@@ -3401,11 +3449,28 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                 }
                 if (run_kind) {
                     if (run_kind != 1) c.nlfc = 0;  // deferred chains carry no l2fc terms; a later probe walk may have left some in the context
-                    run_chain_batch(c, run_nt, run_inner);
+                    run_chain_batch(c, run_mask, run_inner);
                     __syncthreads();
-                    if (run_kind == 1) { resume = 1; st = IT_WALK; }
-                    else {
-                        flush_deliver(c, evM, evS, bias_prior);
+                    if (run_kind == 1) {
+                        if (piggy) {
+                            // the walk is suspended with the MAP candidate of ITS slot and its operands in the context: park them
+                            // in the slot arrays, hand the held chains to their events, and take the context back
+                            const int sg = c.group, sd = c.disc, sc = c.contained, sa = c.alive, sn = c.nlfc;
+                            const double so = w->ops_vaf[lane < S ? lane : 0];
+                            __syncthreads();
+                            if (lane == 0) { mapJ[u] = c.curJ; mapHyp[u] = c.curHyp; }
+                            if (lane < S) mapVaf[u * S + lane] = w->curMapVaf[lane];
+                            __syncthreads();
+                            flush_deliver(c, piggy, evM, evS, bias_prior);
+                            c.curJ = uni_d(mapJ[u]); c.curHyp = UNI(mapHyp[u]);
+                            if (lane < S) { w->curMapVaf[lane] = mapVaf[u * S + lane]; w->ops_vaf[lane] = so; }
+                            __syncthreads();
+                            c.group = sg; c.disc = sd; c.contained = sc; c.alive = sa; c.nlfc = sn;
+                            c.nhold = 0;
+                        }
+                        resume = 1; st = IT_WALK;
+                    } else {
+                        flush_deliver(c, run_mask, evM, evS, bias_prior);
                         st = (run_kind == 2) ? IT_ROOT : IT_NEXT;
                     }
                 }
