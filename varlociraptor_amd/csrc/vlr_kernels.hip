@@ -85,7 +85,7 @@ struct WaveSt {
     double lfc_val[kMaxLfc];
     int lfc_a[kMaxLfc], lfc_b[kMaxLfc], lfc_cmp[kMaxLfc];
     int nkeep[kMaxSamples], soff[kMaxSamples];
-    int all_posref[kMaxSamples];
+    unsigned char all_posref[kMaxSamples];  // (bytes: the static LDS of the kernel sits 32 B under an occupancy step for 4 x 60x pileups)
     union {
         struct {  // phase A statistics: dead once the hypotheses are gated (before phase B starts)
             double pos_all[kMaxSamples], pos_major[kMaxSamples], pos_rate[kMaxSamples];
@@ -97,7 +97,7 @@ struct WaveSt {
             double bpend[kRows][kRowPts], bvals[kRows][kRowPts];
         };
     };
-    int cacheN[kMaxSamples];
+    unsigned char cacheN[kMaxSamples];
     double curMapVaf[kMaxSamples];
     int cs_node[kContainStack], cs_mask[kContainStack];
     ChainTask task[kRows];
@@ -762,7 +762,7 @@ __device__ inline double sample_lik_point(Ctx& c, int s, double a, double b) {  
 }
 __device__ inline double sample_lik(Ctx& c, int s, double a, double b) {
     WaveSt* w = c.w;
-    const int n = UNI(w->cacheN[s]);
+    const int n = UNI((int)w->cacheN[s]);
     const int lim = n < kCacheWays ? n : kCacheWays;
     {   // all ways probed at once (lane i looks at way i)
         const int wi = c.lane < kCacheWays ? c.lane : 0;
@@ -777,7 +777,7 @@ __device__ inline double sample_lik(Ctx& c, int s, double a, double b) {
         c.cacheA[s * kCacheWays + slot] = a;
         c.cacheB[s * kCacheWays + slot] = b;
         c.cacheV[s * kCacheWays + slot] = r;
-        w->cacheN[s] = n + 1;
+        w->cacheN[s] = (unsigned char)(n + 1 == 252 ? 248 : n + 1);  // a byte: wraps within the same residue mod kCacheWays
     }
     __syncthreads();
     return r;
@@ -1023,7 +1023,7 @@ __device__ inline double eval_discrete_root(Ctx& c, int l0, int l1) {
     const DevDLeaf* leaves = p.dleaf;
     unsigned cr = 0;
     for (int s = 0; s < S; ++s)
-        if (UNI(w->nkeep[s]) > 10 && UNI(w->all_posref[s])) cr |= 1u << s;
+        if (UNI(w->nkeep[s]) > 10 && UNI((int)w->all_posref[s])) cr |= 1u << s;
     const double* ptab = p.prior_table + (size_t)c.vt * p.table_size;
     constexpr int T = kMaxDLeaf / 64;
     const int TT = (l1 - l0 + 63) >> 6;  // leaves per lane (uniform)
@@ -2232,7 +2232,7 @@ __device__ __forceinline__ void bo_begin(Ctx& c, RangeSt& r, int chn) {
     const DevNode ch = ld_node(p.nodes + chn);
     const int s_in = ch.sample, s_out = UNI(r.sample), S = c.S;
     const int n_obs = UNI(w->nkeep[s_in]);
-    const bool clear_ref = n_obs > 10 && UNI(w->all_posref[s_in]);
+    const bool clear_ref = n_obs > 10 && UNI((int)w->all_posref[s_in]);
     const RangeV vr{ch.vafs.start, ch.vafs.end, ch.vafs.lex, ch.vafs.rex};
     const bool dead = clear_ref && vr.start > 0.0;  // generic.rs:342-347
     const double res = p.resolution[s_in];
@@ -3056,7 +3056,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
         }
         if (lane == 0) {
             w->nkeep[s] = nk; w->soff[s] = offset_acc;
-            w->all_ref[s] = allref; w->all_posref[s] = allpos; w->strong_all[s] = sall;
+            w->all_ref[s] = allref; w->all_posref[s] = allpos ? 1 : 0; w->strong_all[s] = sall;
             w->any_strong_alt[s] = anysa; w->has_ins[s] = ins; w->has_del[s] = del;
             for (int h = 0; h < kNHyp; ++h) w->strong_bias[s][h] = sbias[h];
             w->strong_bias[s][0] = sbias_alb_noloci;  // slot 0 reused: alt-locus evidence without alt loci
