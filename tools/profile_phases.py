@@ -13,7 +13,7 @@ L = engine.lib()
 out = (C.c_ulonglong * 24)()
 L.vlr_plan_profile_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 assert L.vlr_plan_profile_counters(plan._h, out) == 0
-names = ["A stats", "gating", "coefficients", "walk/other", "single rounds", "single integrate", "batch prep", "batch rounds", "batch epilogue", "phase C", "#batch runs", "#single chains", "round: products", "round: reduce", "round: log+prior", "round: advance", "outer: task setup", "outer: vary eval", "outer: entry/delivery", "leaf: descent", "leaf: likelihoods", "leaf: prior", "leaf: MAP", "discrete roots"]
+names = ["A stats", "gating", "coefficients", "walk/other", "deliver held/deferred", "single integrate", "batch prep", "batch rounds", "batch epilogue", "phase C", "#batch runs", "#single chains", "round: products", "round: reduce", "round: log+prior", "round: advance", "outer: task setup", "outer: vary eval", "outer: entry/delivery", "iter: next root", "iter: root entry", "walk", "iter: root exit", "discrete roots"]
 cnt = {10, 11}
 tot = sum(v for i, v in enumerate(out) if i not in cnt)
 for nm, v in zip(names, out):

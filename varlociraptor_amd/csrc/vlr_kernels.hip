@@ -1783,15 +1783,18 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
             const double t0 = k == 0 ? arm : k == 3 ? lin_pt(lo3, sa, 2.0) : lin_pt(mid, sb, 3.0);
             const double t1 = k == 0 ? lin_pt(lo3, sa, 0.0) : lin_pt(mid, sb, 1.0);
             const double t2 = k == 0 ? lin_pt(lo3, sa, 1.0) : lin_pt(mid, sb, 2.0);
-            // Simpson grid (modes/generic.rs:367-385): points k, k+1, k+2 of linspace(lo, hi, n) with exact end points
-            const int left = simpson_n - k;
-            const double s0 = lin_pt(lo, sstep, (double)k);
-            const double s1 = (k + 1 == simpson_n - 1) ? hi : lin_pt(lo, sstep, (double)(k + 1));
-            const double s2 = (k + 2 == simpson_n - 1) ? hi : lin_pt(lo, sstep, (double)(k + 2));
             const bool isT = phase == RP_TAIL;
-            const int nn = isT ? (k == 6 ? 1 : 3) : (left < 3 ? left : 3);
-            const double n0 = isT ? t0 : s0;
-            double n1 = isT ? t1 : s1, n2 = isT ? t2 : s2;
+            int nn = k == 6 ? 1 : 3;
+            double n0 = t0, n1 = t1, n2 = t2;
+            if (__ballot(!done && phase == RP_SIMPSON)) {  // rare (fewer than five observations, ranges below the resolution)
+                // Simpson grid (modes/generic.rs:367-385): points k, k+1, k+2 of linspace(lo, hi, n) with exact end points
+                const int left = simpson_n - k;
+                const double s0 = lin_pt(lo, sstep, (double)k);
+                const double s1 = (k + 1 == simpson_n - 1) ? hi : lin_pt(lo, sstep, (double)(k + 1));
+                const double s2 = (k + 2 == simpson_n - 1) ? hi : lin_pt(lo, sstep, (double)(k + 2));
+                nn = isT ? nn : (left < 3 ? left : 3);
+                n0 = isT ? t0 : s0; n1 = isT ? t1 : s1; n2 = isT ? t2 : s2;
+            }
             n2 = nn < 3 ? n1 : n2;
             n1 = nn < 2 ? n0 : n1;
             n2 = nn < 2 ? n0 : n2;
@@ -2076,29 +2079,43 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
                 }
             }
         }
-        // rank of every entry among its row's entries: one compare + one add-with-carry per (entry, q)
+        // rank of every entry among its row's entries: one compare + one add-with-carry per (entry, q).  The keys are parked in
+        // the value table meanwhile (x and value of every entry are in registers), so the loop reads finished keys
         if (__ballot(srt && n > 0)) {
-            for (int q0 = 0; q0 < nmax; q0 += 4) {  // four table reads in flight
+            unsigned long long* kv = (unsigned long long*)tv;
+            VLR_WAVE_FENCE();
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (t < TT) { const int i = rl + 16 * t; if (i < cap) kv[i] = key[t]; }  // ~0 beyond the row's entries
+            VLR_WAVE_FENCE();
+            int q0 = 0;
+            for (; q0 + 4 <= nmax; q0 += 4) {  // four table reads in flight
                 unsigned long long kq[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int q = q0 + j;
-                    const double r0 = tx[q < cap ? q : 0];
-                    kq[j] = (q < n) ? ((((unsigned long long)__double_as_longlong(r0)) & ~63ull) | (unsigned long long)q) : ~0ull;
-                }
+                for (int j = 0; j < 4; ++j) kq[j] = kv[q0 + j];
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
                         if (t < TT) rank[t] += (kq[j] < key[t]) ? 1 : 0;
             }
+            for (; q0 < nmax; ++q0) {
+                const unsigned long long kq = kv[q0];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (t < TT) rank[t] += (kq < key[t]) ? 1 : 0;
+            }
             VLR_WAVE_FENCE();
-            // scatter into sorted order, in place (every entry is in registers by now)
+            // scatter into sorted order, in place (every entry is in registers by now); rows that are not sorted (Simpson grids)
+            // get their values back
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 if (t < TT) {
                     const int i = rl + 16 * t;
-                    if (srt && i < n) { tx[rank[t]] = xi[t]; tv[rank[t]] = vi[t]; }
+                    if (i < n) {
+                        if (srt) { tx[rank[t]] = xi[t]; tv[rank[t]] = vi[t]; }
+                        else tv[i] = vi[t];
+                    }
                 }
             }
             VLR_WAVE_FENCE();
@@ -3396,6 +3413,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                     } else if (c.ndef == kRows) { run_kind = 2; run_mask = (1 << kRows) - 1; run_inner = UNI(w->task[0].inner); c.ndef = 0; }
                     else st = IT_ROOT;
                 }
+                PROF_ADD(c, 19);  // iterator: next root
                 if (st == IT_DONE) break;
                 if (st == IT_ROOT) {
                     u = (e < 0) ? 0 : (1 + 2 * e + (h == 0 ? 0 : 1));
@@ -3422,9 +3440,11 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                         __syncthreads();
                         st = IT_NEXT;
                     } else { resume = 0; st = IT_WALK; }
+                    PROF_ADD(c, 20);  // root entry (slot state, discrete roots are counted apart)
                 }
                 if (st == IT_WALK) {
                     const double dens = uni_d(walk_root(c, root, resume));
+                    PROF_ADD(c, 21);  // walk (descent, frames; the outer-batch steps are counted apart)
                     if (c.need_batch) {
                         c.need_batch = 0; run_kind = 1; run_mask = (1 << c.bt_nt) - 1; run_inner = c.bt_inner;
                         if ((c.nhold | c.nstash) && c.hold_inner == c.bt_inner) {  // (batches of the walk carry no l2fc terms)
@@ -3447,6 +3467,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                         st = IT_NEXT;
                     }
                 }
+                PROF_ADD(c, 22);  // root exit (event accumulators, slot state)
                 if (run_kind) {
                     if (run_kind != 1) c.nlfc = 0;  // deferred chains carry no l2fc terms; a later probe walk may have left some in the context
                     run_chain_batch(c, run_mask, run_inner);
@@ -3473,6 +3494,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                         flush_deliver(c, run_mask, evM, evS, bias_prior);
                         st = (run_kind == 2) ? IT_ROOT : IT_NEXT;
                     }
+                    PROF_ADD(c, 4);  // delivery of deferred / held chains
                 }
             }
         }
