@@ -13,7 +13,7 @@ def line(name):
     rows = [l for l in open(path).read().splitlines() if l.startswith("{")]
     return json.loads(rows[-1]) if rows else None
 def rocpd(d):
-    db = glob.glob(os.path.join(O, d, "**", "*.db"), recursive=True)
+    db = [os.path.join(r, f) for r, _, fs in os.walk(os.path.join(O, d)) for f in fs if f.endswith(".db")]
     if not db:
         return "(no trace)\n"
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocpd_summary.py"), db[0]], capture_output=True, text=True).stdout
