@@ -2605,7 +2605,6 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
             const int fslot = UNI(f.slot), fnode = UNI(f.node);
             RangeSt& r = c.rs[fslot];
             double* tx = c.tabX + fslot * c.cap;
-            double* tv = c.tabV + fslot * c.cap;
             if (UNI(r.tn) + (UNI(r.npend) - UNI(f.iter)) > c.cap) {  // room for the points of this round still to be recorded
                 c.status |= VLR_LOCUS_TABLE_FULL;
                 rv = __builtin_nan("");

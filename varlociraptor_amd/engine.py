@@ -59,6 +59,12 @@ def source_id() -> str:
     return h.hexdigest()[:16]
 
 
+def build_all(force: bool = False) -> None:
+    """The engine and its build-matrix variants in ONE parallel make (four hipcc jobs)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    subprocess.check_call(["make", "-C", src_dir, "-j", "4", "all", "matrix"] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
+
+
 MAX_OBS_LDS = 7680  # kept observations of one locus whose coefficient pairs fit the 120 kB LDS budget (vlr_plan_set_max_obs)
 
 MATRIX_DIR = os.path.join(_HERE, "matrix")
