@@ -8,9 +8,10 @@ shard of that size.  Prints ONE JSON line on rank 0.
 
   --workload config2|config3|config4|config5   BASELINE configs[1..4] (locus counts of the config, or --loci)
   --workload realign                          second hot path: read-vs-allele pair HMM, pairs/s
-  --afd                                       additionally time the step WITH the AFD replay launch (the reference always
-                                              computes AFD, calling.rs:889-928) and report it as `with_afd`; `value` stays the
-                                              BASELINE metric
+  --afd                                       additionally time the step WITH the AFD lists (the reference always computes AFD,
+                                              calling.rs:889-928) and report it as `with_afd` in the same line; `value` stays
+                                              the BASELINE metric.  Off by default so that a kernel trace of the default command
+                                              holds launches of one kind only (profiles/ keep the --afd line and its trace)
 """
 import argparse
 import json
@@ -158,7 +159,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="config3", choices=["config2", "config3", "config4", "config5", "realign"])
     ap.add_argument("--loci", type=int, default=None, help="loci per GPU (default: the config's size); realign: pairs per GPU")
-    ap.add_argument("--afd", action="store_true", help="also time the step with the AFD replay launch")
+    ap.add_argument("--afd", dest="afd", action="store_true", default=False, help="also time the step with the AFD lists")
+    ap.add_argument("--no-afd", dest="afd", action="store_false", help="(default) only the plain step")
     ap.add_argument("--afd-capacity", type=int, default=96)
     ap.add_argument("--cpu-loci", type=int, default=None, help="loci of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")

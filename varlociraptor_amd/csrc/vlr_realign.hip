@@ -37,13 +37,14 @@ struct RealignArgs {
 
 __device__ __forceinline__ int up(int b) { return (b >= 'a' && b <= 'z') ? b - 32 : b; }
 
-// value of lane l-1 (lane 0: `edge`)
-__device__ __forceinline__ double shr1(double v, double edge) {
+// value of lane l-1 (lane 0: zero — bound_ctrl supplies it, no copy of an edge value into the destination first)
+__device__ __forceinline__ double shr1z(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(__double2loint(edge), lo, 0x138, 0xF, 0xF, false);  // wave_shr:1
-    hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), hi, 0x138, 0xF, 0xF, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
+// value of lane l-1 (lane 0: `edge`)
 __device__ __forceinline__ unsigned shr1(unsigned v, unsigned edge) {
     return (unsigned)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xF, 0xF, false);
 }
@@ -62,20 +63,20 @@ __global__ void __launch_bounds__(64) vlr_realign_kernel(RealignArgs a) {
         if (lane == 0) a.ln_prob[pair] = (len_x <= 0 || len_y <= 0) ? -__builtin_huge_val() : __builtin_nan("");
         return;
     }
-    // per-row emission constants (ReadEmission::new, pairhmm.rs:406-428; PROB_CONFUSION pairhmm.rs:22-24)
+    // per-row emission constants (ReadEmission::new, pairhmm.rs:406-428; PROB_CONFUSION pairhmm.rs:22-24).  Rows beyond the
+    // read get zero emissions: every state of such a row stays exactly zero without a select in the loop.
     int yb[2];
     double e_match[2], e_mis[2], e_ins[2];
-    bool rowon[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int j = 2 * lane + r;
-        rowon[r] = j < len_y;
-        const int q = rowon[r] ? a.y_quals[y0 + j] : 0;
-        yb[r] = rowon[r] ? up(a.y_bases[y0 + j]) : 0;
+        const bool rowon = j < len_y;
+        const int q = rowon ? a.y_quals[y0 + j] : 0;
+        yb[r] = rowon ? up(a.y_bases[y0 + j]) : 0;
         const double mis = exp(-(double)q * 2.302585092994046 / 10.0);  // P(miscall) = 10^(-q/10)
-        e_match[r] = 1.0 - mis;
-        e_mis[r] = mis * 0.3333;
-        e_ins[r] = mis;
+        e_match[r] = rowon ? 1.0 - mis : 0.0;
+        e_mis[r] = rowon ? mis * 0.3333 : 0.0;
+        e_ins[r] = rowon ? mis : 0.0;
     }
     // state of the cell each row computed at the previous step (its "left" neighbour now) ...
     double M1[2] = {0.0, 0.0}, X1[2] = {0.0, 0.0}, Y1[2] = {0.0, 0.0};
@@ -86,58 +87,73 @@ __global__ void __launch_bounds__(64) vlr_realign_kernel(RealignArgs a) {
     double total = 0.0;  // sum over columns of the last row's three states (free end gap in x)
     int scale = 0;       // this lane's states and total carry a factor 2^scale
     const int last_row = len_y - 1;
+    const int lr = last_row & 1;             // which of its two rows the owner lane sums (uniform)
+    const bool owner_lane = lane == (last_row >> 1);
     const int nsteps = len_x + len_y - 1;
-    // x bases: lane-strided prefetch is not worth it for a few hundred bytes; every row reads its column's base (L1/L2 hits)
+    // x bases travel with the wavefront: row 2l works on column d - 2l, row 2l+1 on the column row 2l had one step earlier, and
+    // row 2l's column is the one row 2(l-1)+1 had one step earlier.  So every base is loaded once (64 at a time, lane-
+    // contiguous), enters at lane 0 and moves down the lanes by one DPP shift per step; columns outside the allele carry 0.
+    int xchunk = 0, xb0 = 0, xb1 = 0;
     for (int d = 0; d < nsteps; ++d) {
+        if ((d & 63) == 0) {
+            const int i = d + lane;
+            xchunk = (i < len_x) ? up(a.x_bases[x0 + i]) : 0;
+        }
+        const int xnew = __builtin_amdgcn_readlane(xchunk, d & 63);
+        const int prev1 = xb1;
+        xb1 = xb0;
+        xb0 = (int)shr1((unsigned)prev1 /* lane l-1's row-1 base of the previous step */, (unsigned)xnew);
         // top neighbour = previous step's cell of row j-1.  Row -1 is the virtual start row: as "top" (same column) it is
         // empty, as "top-left" (previous column) it carries the free start mass one with edit distance zero.
         double Mu[2], Xu[2], Yu[2];
         unsigned Eu[2];
+        Mu[0] = shr1z(M1[1]); Xu[0] = shr1z(X1[1]); Yu[0] = shr1z(Y1[1]); Eu[0] = shr1(E1[1], kBig);
         {
             // the lane above stores its states with its own power-of-two scale: bring them to this lane's.  A lane that holds
             // nothing yet (rows not reached, or everything outside the band) simply adopts the scale of the lane above.
+            // Skipped altogether while all lanes agree (the common case: scales only move at the checks below).
             const int nb = (int)shr1((unsigned)scale, (unsigned)scale);
-            const double mass = ((M1[0] + M1[1]) + (X1[0] + X1[1])) + ((Y1[0] + Y1[1]) + (Mt[0] + Mt[1])) + ((Xt[0] + Xt[1]) + (Yt[0] + Yt[1])) + total;
-            if (mass == 0.0) scale = nb;
-            int dsc = scale - nb;
-            dsc = dsc > 1000 ? 1000 : dsc < -1000 ? -1000 : dsc;
-            const double f = __builtin_ldexp(1.0, dsc);
-            Mu[0] = shr1(M1[1], 0.0) * f; Xu[0] = shr1(X1[1], 0.0) * f; Yu[0] = shr1(Y1[1], 0.0) * f; Eu[0] = shr1(E1[1], kBig);
+            if (__ballot(scale != nb)) {
+                const double mass = ((M1[0] + M1[1]) + (X1[0] + X1[1])) + ((Y1[0] + Y1[1]) + (Mt[0] + Mt[1])) + ((Xt[0] + Xt[1]) + (Yt[0] + Yt[1])) + total;
+                if (mass == 0.0) scale = nb;
+                int dsc = scale - nb;
+                dsc = dsc > 1000 ? 1000 : dsc < -1000 ? -1000 : dsc;
+                const double f = __builtin_ldexp(1.0, dsc);
+                Mu[0] *= f; Xu[0] *= f; Yu[0] *= f;
+            }
         }
         Mu[1] = M1[0]; Xu[1] = X1[0]; Yu[1] = Y1[0]; Eu[1] = E1[0];
+        // virtual start row: the top-left neighbour of row 0 holds mass one in every column (free start gap in x)
+        if (lane == 0) { Mt[0] = __builtin_ldexp(1.0, scale); Et[0] = 0u; }
         double Mn[2], Xn[2], Yn[2];
         unsigned En[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const int j = 2 * lane + r;
-            const int i = d - j;
-            const bool on = rowon[r] && i >= 0 && i < len_x;
-            // top-left: virtual start row for j == 0 (mass one in every column), virtual empty column for i == 0
-            double mtl = Mt[r], xtl = Xt[r], ytl = Yt[r];
-            unsigned etl = Et[r];
-            if (j == 0) { mtl = __builtin_ldexp(1.0, scale); xtl = 0.0; ytl = 0.0; etl = 0u; }
-            else if (i == 0) { mtl = 0.0; xtl = 0.0; ytl = 0.0; etl = kBig; }
-            // left: previous column of the same row; empty for the first column
-            const double ml = (i == 0) ? 0.0 : M1[r], xl = (i == 0) ? 0.0 : X1[r];
-            const unsigned el = (i == 0) ? kBig : E1[r];
-            // top: same column, row above (already computed: it is one anti-diagonal behind)
-            const double mu = Mu[r], yu = Yu[r];
-            const unsigned eu = Eu[r];
-            const int xb = on ? up(a.x_bases[x0 + i]) : 0;
+            const int i = d - (2 * lane + r);
+            const bool incol = (unsigned)i < (unsigned)len_x;
+            const int xb = r == 0 ? xb0 : xb1;
             const bool is_match = xb == yb[r];
-            const unsigned emin = min(etl, min(eu, el));
-            const bool skip = banded && emin > (unsigned)med_max;
-            const bool live = on && !skip;
+            // top-left (j-1, i-1), left (j, i-1), top (j-1, i): cells outside the matrix are exactly zero by construction (rows
+            // start from zero states, the row above is zero before its first column)
             const double emit = is_match ? e_match[r] : e_mis[r];
-            const double m = emit * (a.pn * mtl + a.pny * xtl + a.pnx * ytl);
-            const double x = a.pgy * ml + a.pgye * xl;                 // gap in y: x_i alone (prob_emit_x = 1)
-            const double y = e_ins[r] * (a.pgx * mu + a.pgxe * yu);    // gap in x: y_j alone
-            const unsigned e = min(is_match ? etl : etl + 1u, min(eu + 1u, el + 1u));
+            const double m = emit * (a.pn * Mt[r] + a.pny * Xt[r] + a.pnx * Yt[r]);
+            const double x = a.pgy * M1[r] + a.pgye * X1[r];                  // gap in y: x_i alone (prob_emit_x = 1)
+            const double y = e_ins[r] * (a.pgx * Mu[r] + a.pgxe * Yu[r]);    // gap in x: y_j alone
+            bool live = incol;
+            unsigned e = kBig;
+            if (banded) {  // (uniform per pair)
+                const unsigned etl = Et[r], eu = Eu[r], el = E1[r];
+                const unsigned emin = min(etl, min(eu, el));
+                live = incol && !(emin > (unsigned)med_max);
+                e = live ? min(min(is_match ? etl : etl + 1u, min(eu + 1u, el + 1u)), kBig) : kBig;
+            }
+            // beyond the last column (and outside the band) a row keeps nothing
             Mn[r] = live ? m : 0.0; Xn[r] = live ? x : 0.0; Yn[r] = live ? y : 0.0;
-            En[r] = (live && banded) ? min(e, kBig) : kBig;
-            if (on && j == last_row) total += Mn[r] + Xn[r] + Yn[r];
-            // a row that is not inside the matrix this step keeps nothing
-            if (!on) { Mn[r] = 0.0; Xn[r] = 0.0; Yn[r] = 0.0; En[r] = kBig; }
+            En[r] = e;
+        }
+        {
+            const double s = (Mn[lr] + Xn[lr]) + Yn[lr];
+            total += owner_lane ? s : 0.0;  // (zero outside the columns of the allele)
         }
         // this step's "top" of a row is its "top-left" at the next step
 #pragma unroll
@@ -152,8 +168,10 @@ __global__ void __launch_bounds__(64) vlr_realign_kernel(RealignArgs a) {
             int ex = 0;
             (void)__builtin_frexp(mx, &ex);
             // (scaled DOWN as well: the mass of a lane grows again when the wavefront reaches the columns the read aligns to)
-            if (mx > 0.0 && (ex > 200 || (ex < -200 && !(total > mx * 0x1p60)))) {
-                const int sh = -ex > 1000 ? 1000 : -ex < -1000 ? -1000 : -ex;
+            const bool resc = mx > 0.0 && (ex > 200 || (ex < -200 && !(total > mx * 0x1p60)));
+            if (__ballot(resc)) {
+                const int sh0 = -ex > 1000 ? 1000 : -ex < -1000 ? -1000 : -ex;
+                const int sh = resc ? sh0 : 0;
                 const double f1 = __builtin_ldexp(1.0, sh);
 #pragma unroll
                 for (int r = 0; r < 2; ++r) { M1[r] *= f1; X1[r] *= f1; Y1[r] *= f1; Mt[r] *= f1; Xt[r] *= f1; Yt[r] *= f1; }
