@@ -310,3 +310,28 @@ def test_haplotype_identifier_and_groups():
         haplotype_identifier({"MATEID": "x", "__ID": "."})
     reps, source = haplotype_groups([None, "e1", None, "e1", "e2", "e1", "e2"])
     assert reps == [0, 1, 2, 4] and source == [0, 1, 2, 1, 3, 1, 3]
+
+
+def test_minilogprob_vectors_decode_the_same_on_the_strided_and_the_element_path():
+    """obsfmt._vec_minilogprob: all-f16 and all-f32 vectors take a strided numpy view, mixed ones the element loop
+    (bincode: u64 length, then per element a u32 variant tag + f16 | f32; utils/mod.rs:449-474)."""
+    import struct
+    from varlociraptor_amd import obsfmt
+    rng = np.random.default_rng(3)
+    vals = (-rng.random(37) * 50).astype(np.float32)
+
+    def enc(tags):
+        b = struct.pack("<Q", len(vals))
+        for v, t in zip(vals, tags):
+            b += struct.pack("<I", t) + (np.float16(v).tobytes() if t == 0 else struct.pack("<f", v))
+        return b
+
+    want16 = vals.astype(np.float16).astype(np.float32)
+    assert np.array_equal(obsfmt._vec_minilogprob(enc([0] * 37)), want16)
+    assert np.array_equal(obsfmt._vec_minilogprob(enc([1] * 37)), vals)
+    tags = rng.integers(0, 2, 37)
+    tags[0], tags[1] = 0, 1
+    mixed = obsfmt._vec_minilogprob(enc(tags))
+    assert np.array_equal(mixed, np.where(tags == 0, want16, vals))
+    assert len(obsfmt._vec_minilogprob(struct.pack("<Q", 0))) == 0
+    assert np.array_equal(obsfmt._vec_enum(struct.pack("<Q", 3) + struct.pack("<III", 2, 0, 8)), np.array([2, 0, 8], dtype=np.uint32))

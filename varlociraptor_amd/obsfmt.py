@@ -63,6 +63,17 @@ class _Reader:
 def _vec_minilogprob(buf: bytes) -> np.ndarray:
     r = _Reader(buf)
     n = r.u64()
+    # every element is a u32 variant tag + an f16 (6 bytes) or an f32 (8 bytes): a vector of n elements that is 6n or 8n bytes
+    # long holds one variant only and decodes as a strided array; mixed vectors take the element loop
+    body = len(buf) - 8
+    if n and body == 6 * n:
+        a = np.frombuffer(buf, dtype=np.dtype([("tag", "<u4"), ("v", "<f2")]), count=n, offset=8)
+        if not a["tag"].any():
+            return a["v"].astype(np.float32)
+    elif n and body == 8 * n:
+        a = np.frombuffer(buf, dtype=np.dtype([("tag", "<u4"), ("v", "<f4")]), count=n, offset=8)
+        if (a["tag"] == 1).all():
+            return a["v"].astype(np.float32)
     return np.array([r.minilogprob() for _ in range(n)], dtype=np.float32)
 
 
@@ -79,7 +90,7 @@ def _vec_opt_minilogprob(buf: bytes) -> np.ndarray:
 def _vec_enum(buf: bytes) -> np.ndarray:
     r = _Reader(buf)
     n = r.u64()
-    return np.array([r.u32() for _ in range(n)], dtype=np.uint32)
+    return np.frombuffer(buf, dtype="<u4", count=n, offset=8).astype(np.uint32)
 
 
 def _vec_opt_i8(buf: bytes) -> np.ndarray:
