@@ -115,6 +115,18 @@ def bench_realign(args, rank, world, local_rank, dev):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # the edit-distance pre-filter of the same pairs (calc_best_hit): its kernel time, and that the band it yields is the one the
+    # synthetic batch carries (host routine)
+    band_host = dp.t[5].clone()
+    dp.band_from_hits(local_rank, stream)
+    ev2, ev3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev2.record()
+    for _ in range(args.steps):
+        dp.band_from_hits(local_rank, stream)
+    ev3.record()
+    torch.cuda.synchronize()
+    edit_ms = ev2.elapsed_time(ev3) / args.steps
+    bands_equal = bool(torch.equal(band_host, dp.t[5]))
     if rank != 0:
         return None
     got = dp.out.cpu().numpy()
@@ -148,6 +160,8 @@ def bench_realign(args, rank, world, local_rank, dev):
                      "valu": {"cells_per_s": cells / (kernel_ms * 1e-3), "flop_per_cell": FLOP_PER_CELL,
                               "achieved_tflops": cells * FLOP_PER_CELL / (kernel_ms * 1e-3) / 1e12, "peak_tflops": F64_VALU_PEAK_TFLOPS,
                               "frac": cells * FLOP_PER_CELL / (kernel_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TFLOPS}},
+        "edit_distance_prefilter": {"kernel_ms": edit_ms, "pairs_per_s": n_pairs / (edit_ms * 1e-3), "bands_equal_host_routine": bands_equal,
+                                    "note": "vlr_edit_distance_batch + band update on the resident pairs, not part of `value`"},
         "cpu_baseline": cpu, "parity": parity, "build_id": engine.build_id(),
     }
 

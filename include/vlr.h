@@ -345,6 +345,16 @@ int vlr_realign_batch(int device, const vlr_realign_batch_desc* pairs, double* l
 /* Host pointers: stages the sequences, runs the kernel, returns when ln_prob is filled. */
 int vlr_realign_batch_host(int device, const vlr_realign_batch_desc* pairs, double* ln_prob);
 
+/* Edit-distance pre-filter of the same pairs: replaces EditDistanceCalculation::calc_best_hit
+ * (/root/reference/src/variants/evidence/realignment/edit_distance.rs:164-260, bio Myers find_all_lazy) as far as
+ * Realigner::prob_allele and the band of the pair HMM use it.  dist[p] = smallest semiglobal edit distance of the read
+ * window against the allele window (free start and end in the allele; bases compared case-insensitively), end[p] = first
+ * allele position (exclusive, 1-based) at which an alignment with that distance ends, n_hits[p] = number of such end
+ * positions; dist = -1 for an empty sequence or a read window above 128 bases.  `end` and `n_hits` may be NULL.  y_quals,
+ * max_edit_dist and gap of `pairs` are not read.  The band of vlr_realign_batch is max_edit_dist[p] = dist[p] + 4. */
+int vlr_edit_distance_batch(int device, const vlr_realign_batch_desc* pairs, int32_t* dist, int32_t* end, int32_t* n_hits, void* hip_stream);
+int vlr_edit_distance_batch_host(int device, const vlr_realign_batch_desc* pairs, int32_t* dist, int32_t* end, int32_t* n_hits);
+
 /* ------------------------------------------------------------------------------------------------
  * Bayesian FDR control: the threshold search of `filter-calls control-fdr`
  * (/root/reference/src/filtration/fdr.rs:107-141): sort the posterior (ln) probabilities of the chosen events in

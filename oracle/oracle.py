@@ -64,6 +64,8 @@ def lib():
         L.vlro_bias_prob_ref_none.argtypes = [C.POINTER(abi.Batch), C.c_int64]
         L.vlro_pairhmm_prob_related.restype = C.c_double
         L.vlro_pairhmm_prob_related.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int]
+        L.vlro_edit_distance.restype = C.c_int
+        L.vlro_edit_distance.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.vlro_normalize_support.restype = None
         L.vlro_normalize_support.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _LIB = L
@@ -78,6 +80,16 @@ def pairhmm_prob_related(allele: bytes, read: bytes, qual, gap, max_edit_dist: i
     q = np.asarray(bytearray(qual) or b"\0", np.uint8)
     g = (C.c_double * 4)(*gap)
     return float(L.vlro_pairhmm_prob_related(x.ctypes.data, len(allele), y.ctypes.data, q.ctypes.data, len(read), g, int(max_edit_dist)))
+
+
+def edit_distance(allele: bytes, read: bytes):
+    """(dist, end, n_hits) of the semiglobal edit distance of `read` in `allele` (oracle/vlr_realign_oracle.cpp)."""
+    L = lib()
+    x = np.frombuffer(bytes(allele) or b"\0", np.uint8)
+    y = np.frombuffer(bytes(read) or b"\0", np.uint8)
+    e, n = C.c_int(), C.c_int()
+    d = L.vlro_edit_distance(x.ctypes.data, len(allele), y.ctypes.data, len(read), C.byref(e), C.byref(n))
+    return int(d), int(e.value), int(n.value)
 
 
 def pairhmm_batch(batch, gap, threads=1):

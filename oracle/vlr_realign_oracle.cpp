@@ -146,4 +146,28 @@ void vlro_normalize_support(double* prob_ref, double* prob_alt) {
     *prob_ref = r; *prob_alt = a;
 }
 
+
+// Smallest semiglobal edit distance of the read window y against the allele window x (free start and end in x), the first end
+// position (exclusive, 1-based) reaching it and the number of such end positions: what calc_best_hit
+// (edit_distance.rs:164-260) keeps of bio's Myers matches.  Plain row-by-row dynamic programme.
+int vlro_edit_distance(const uint8_t* x, int len_x, const uint8_t* y, int len_y, int* end, int* n_hits) {
+    if (len_x <= 0 || len_y <= 0 || len_y > 128) { if (end) *end = -1; if (n_hits) *n_hits = 0; return -1; }
+    std::vector<int> prev(len_x + 1, 0), cur(len_x + 1);
+    for (int j = 0; j < len_y; ++j) {
+        cur[0] = j + 1;
+        for (int i = 1; i <= len_x; ++i) {
+            const int sub = prev[i - 1] + (upper(x[i - 1]) == upper(y[j]) ? 0 : 1);
+            cur[i] = std::min(sub, std::min(prev[i] + 1, cur[i - 1] + 1));
+        }
+        std::swap(prev, cur);
+    }
+    int best = prev[1], e = 1, n = 0;
+    for (int i = 1; i <= len_x; ++i)
+        if (prev[i] < best) { best = prev[i]; e = i; }
+    for (int i = 1; i <= len_x; ++i) n += prev[i] == best;
+    if (end) *end = e;
+    if (n_hits) *n_hits = n;
+    return best;
+}
+
 }  // extern "C"

@@ -93,3 +93,48 @@ def test_allele_support_pipeline(oracle):
                                          realign.best_hit(seq, locus["alt_allele"])[0] + realign.EDIT_BAND)
         r, a = oracle.normalize_support(pr, pa)
         assert abs(math.exp(sup[k, 0]) - math.exp(r)) <= 1e-6 and abs(math.exp(sup[k, 1]) - math.exp(a)) <= 1e-6
+
+
+def test_edit_distance_kernel_is_bit_exact(oracle):
+    """vlr_edit_distance_batch (integers: bit-exact) against the CPU restatement on the synthetic realignment windows, on random
+    pairs of every shape (one base to 128-base reads, alleles shorter than the read, lower case) and on degenerate input."""
+    pb, _ = realign_synth.generate(300, seed=21, banded=False)
+    rng = np.random.default_rng(8)
+    B = np.frombuffer(b"ACGTacgtN", np.uint8)
+    for _ in range(400):
+        ly = int(rng.choice([1, 2, 3, 7, 31, 63, 64, 65, 100, 127, 128]))
+        lx = int(rng.choice([1, 2, 5, 40, 128, 129, 192, 300]))
+        x = B[rng.integers(0, len(B), lx)].tobytes()
+        if rng.random() < 0.5 and lx > ly:  # the read really comes from the allele, with a few edits
+            s = int(rng.integers(0, lx - ly + 1))
+            y = bytearray(x[s:s + ly].upper())
+            for _ in range(int(rng.integers(0, 4))):
+                y[int(rng.integers(0, ly))] = B[int(rng.integers(0, 4))]
+            y = bytes(y)
+        else:
+            y = B[rng.integers(0, 4, ly)].tobytes()
+        pb.add(x, y, [30] * ly)
+    pb.add(b"", b"A", [30])
+    pb.add(b"A", b"", [])
+    pb.add(b"ACGT" * 40, b"A" * 129, [30] * 129)
+    dist, end, hits = realign.best_hits(pb)
+    for k in range(len(pb)):
+        assert (int(dist[k]), int(end[k]), int(hits[k])) == oracle.edit_distance(pb.x[k], pb.y[k]), k
+    # the band the pipeline derives from it is the one the host routine gives
+    for k in range(0, 200, 7):
+        h = realign.best_hit(pb.y[k], pb.x[k])
+        assert h is not None and h[0] == dist[k] and h[1] == end[k]
+
+
+def test_resident_pairs_take_their_band_from_the_edit_distance_kernel(oracle):
+    import torch
+    pb, _ = realign_synth.generate(64, seed=23, banded=False)
+    dp = realign.DevicePairs(pb)
+    dist = dp.band_from_hits().cpu().numpy()
+    torch.cuda.synchronize()
+    want = np.array([oracle.edit_distance(pb.x[k], pb.y[k])[0] for k in range(len(pb))])
+    assert np.array_equal(dist, want)
+    got = dp.run().cpu().numpy()
+    pb.band = [int(d) + realign.EDIT_BAND for d in want]
+    ref = oracle.pairhmm_batch(pb, GapParams(), threads=8)
+    assert np.all(np.abs(got - ref) <= TOL * np.maximum(1.0, np.abs(ref) * 1e-3))

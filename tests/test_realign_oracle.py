@@ -107,3 +107,30 @@ def test_reads_support_their_allele_of_origin(oracle):
         r, a = oracle.normalize_support(p[2 * k], p[2 * k + 1])
         agree += (a > r) == from_alt or abs(a - r) < 1e-3
     assert agree >= 38
+
+
+def test_edit_distance_restatement_against_the_textbook_definition(oracle):
+    """vlro_edit_distance = min over all substrings of the allele of the Levenshtein distance to the read (semiglobal),
+    first end position, number of end positions: brute force on small random pairs, plus the numpy host routine."""
+    from varlociraptor_amd import realign
+
+    def lev(a, b):
+        prev = list(range(len(b) + 1))
+        for i, ca in enumerate(a, 1):
+            cur = [i]
+            for j, cb in enumerate(b, 1):
+                cur.append(min(prev[j - 1] + (ca != cb), prev[j] + 1, cur[j - 1] + 1))
+            prev = cur
+        return prev[-1]
+
+    rng = np.random.default_rng(17)
+    B = np.frombuffer(b"ACGT", np.uint8)
+    for _ in range(150):
+        x = B[rng.integers(0, 4, int(rng.integers(1, 14)))].tobytes()
+        y = B[rng.integers(0, 4, int(rng.integers(1, 9)))].tobytes()
+        by_end = [min(lev(y, x[s:e]) for s in range(e + 1)) for e in range(1, len(x) + 1)]  # best start for every end position
+        d = min(by_end)
+        assert oracle.edit_distance(x, y) == (d, by_end.index(d) + 1, by_end.count(d)), (x, y)
+        assert realign.best_hit(y, x) == (d, by_end.index(d) + 1)
+    assert oracle.edit_distance(b"acgtACGT", b"CGTa")[0] == 0          # case-insensitive
+    assert oracle.edit_distance(b"", b"A")[0] == -1 and oracle.edit_distance(b"A", b"")[0] == -1

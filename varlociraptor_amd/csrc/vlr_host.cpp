@@ -1184,6 +1184,65 @@ int vlr_realign_batch_host(int device, const vlr_realign_batch_desc* b, double* 
     return rc;
 }
 
+// ---- edit-distance pre-filter (vlr_realign.hip)
+extern "C" int vlr_launch_edit_kernel(const vlr_realign_batch_desc* b, int32_t* dist, int32_t* end, int32_t* n_hits, void* stream);
+
+static int check_edit(const vlr_realign_batch_desc* b, const int32_t* dist) {
+    if (!b || (b->n_pairs > 0 && (!b->x_offset || !b->x_bases || !b->y_offset || !b->y_bases || !dist)))
+        return fail(VLR_ERR_INVALID_ARGUMENT, "null argument");
+    if (b->n_pairs < 0) return fail(VLR_ERR_INVALID_ARGUMENT, "negative pair count");
+    return VLR_OK;
+}
+
+int vlr_edit_distance_batch(int device, const vlr_realign_batch_desc* b, int32_t* dist, int32_t* end, int32_t* n_hits, void* hip_stream) {
+    int rc = check_edit(b, dist);
+    if (rc != VLR_OK) return rc;
+    if (b->n_pairs == 0) return VLR_OK;
+    HIP_TRY(hipSetDevice(device));
+    hipError_t e = (hipError_t)vlr_launch_edit_kernel(b, dist, end, n_hits, hip_stream);
+    if (e != hipSuccess) return fail(VLR_ERR_HIP, "edit-distance kernel launch: %s", hipGetErrorString(e));
+    return VLR_OK;
+}
+
+int vlr_edit_distance_batch_host(int device, const vlr_realign_batch_desc* b, int32_t* dist, int32_t* end, int32_t* n_hits) {
+    int rc = check_edit(b, dist);
+    if (rc != VLR_OK) return rc;
+    const int64_t n = b->n_pairs;
+    if (n == 0) return VLR_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) return fail(VLR_ERR_NO_DEVICE, "no HIP device %d (the engine has no CPU path)", device);
+    HIP_TRY(hipSetDevice(device));
+    const size_t nx = b->x_offset[n], ny = b->y_offset[n];
+    const size_t o_xoff = 0, o_yoff = o_xoff + (n + 1) * 4, o_out = o_yoff + (n + 1) * 4;  // three int32 result arrays
+    const size_t o_x = (o_out + 3 * n * 4 + 7) & ~(size_t)7, o_y = o_x + ((nx + 7) & ~(size_t)7), total = o_y + ny + 8;
+    char* d = nullptr;
+    if (hipMalloc((void**)&d, total) != hipSuccess) { (void)hipGetLastError(); return fail(VLR_ERR_OUT_OF_MEMORY, "hipMalloc(%zu)", total); }
+    hipStream_t st = nullptr;
+    rc = VLR_OK;
+    do {
+        if (hipMemcpyAsync(d + o_xoff, b->x_offset, (n + 1) * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(d + o_yoff, b->y_offset, (n + 1) * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(d + o_x, b->x_bases, nx, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(d + o_y, b->y_bases, ny, hipMemcpyHostToDevice, st) != hipSuccess) {
+            rc = fail(VLR_ERR_HIP, "staging copy failed"); break;
+        }
+        vlr_realign_batch_desc db = *b;
+        db.x_offset = (const uint32_t*)(d + o_xoff); db.y_offset = (const uint32_t*)(d + o_yoff);
+        db.x_bases = (const uint8_t*)(d + o_x); db.y_bases = (const uint8_t*)(d + o_y);
+        int32_t* dd = (int32_t*)(d + o_out);
+        hipError_t e = (hipError_t)vlr_launch_edit_kernel(&db, dd, dd + n, dd + 2 * n, st);
+        if (e != hipSuccess) { rc = fail(VLR_ERR_HIP, "edit-distance kernel launch: %s", hipGetErrorString(e)); break; }
+        if (hipMemcpyAsync(dist, dd, n * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            (end && hipMemcpyAsync(end, dd + n, n * 4, hipMemcpyDeviceToHost, st) != hipSuccess) ||
+            (n_hits && hipMemcpyAsync(n_hits, dd + 2 * n, n * 4, hipMemcpyDeviceToHost, st) != hipSuccess) ||
+            hipStreamSynchronize(st) != hipSuccess) {
+            rc = fail(VLR_ERR_HIP, "result copy failed"); break;
+        }
+    } while (0);
+    (void)hipFree(d);
+    return rc;
+}
+
 // ---- Bayesian FDR threshold (vlr_fdr.hip)
 extern "C" int vlr_launch_fdr(double* keys, long long n, long long npad, int smart, double alpha_ln, double* work, long long* best, double* fdr0, void* stream);
 

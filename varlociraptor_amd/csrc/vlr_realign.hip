@@ -190,6 +190,88 @@ __global__ void __launch_bounds__(64) vlr_realign_kernel(RealignArgs a) {
     }
 }
 
+// ---- edit-distance pre-filter ----------------------------------------------------------------------------------------
+// EditDistanceCalculation::calc_best_hit (edit_distance.rs:164-260; bio Myers `find_all_lazy`): the smallest semiglobal edit
+// distance of the read window against the allele window (free start and end in the allele), the first allele position at
+// which an alignment with that distance ends, and the number of such end positions.  The pair HMM is banded to
+// distance + EDIT_BAND (realignment/mod.rs:519-537).  Same wavefront as the pair HMM, integers only: lane l owns rows 2l and
+// 2l+1, a cell is min(top-left + mismatch, top + 1, left + 1); row -1 is all zero (free start), column -1 of row j is j + 1.
+struct EditArgs {
+    int64_t n_pairs;
+    const uint32_t* x_offset;
+    const uint8_t* x_bases;
+    const uint32_t* y_offset;
+    const uint8_t* y_bases;
+    int32_t* dist;
+    int32_t* end;
+    int32_t* n_hits;
+};
+
+__global__ void __launch_bounds__(64) vlr_edit_kernel(EditArgs a) {
+    const int64_t pair = blockIdx.x;
+    if (pair >= a.n_pairs) return;
+    const int lane = threadIdx.x;
+    const uint32_t x0 = a.x_offset[pair], y0 = a.y_offset[pair];
+    const int len_x = (int)(a.x_offset[pair + 1] - x0), len_y = (int)(a.y_offset[pair + 1] - y0);
+    if (len_y > 128 || len_y <= 0 || len_x <= 0) {
+        if (lane == 0) { a.dist[pair] = -1; if (a.end) a.end[pair] = -1; if (a.n_hits) a.n_hits[pair] = 0; }
+        return;
+    }
+    int yb[2];
+    unsigned E1[2], Et[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int j = 2 * lane + r;
+        yb[r] = j < len_y ? up(a.y_bases[y0 + j]) : 0;
+        E1[r] = (unsigned)(j + 1);  // the cell left of column 0 of row j
+        Et[r] = (unsigned)j;        // (j-1, -1)
+    }
+    const int last_row = len_y - 1;
+    const int lr = last_row & 1;
+    const bool owner_lane = lane == (last_row >> 1);
+    unsigned best = kBig;
+    int best_end = 0, nbest = 0;
+    const int nsteps = len_x + len_y - 1;
+    int xchunk = 0, xb0 = 0, xb1 = 0;
+    for (int d = 0; d < nsteps; ++d) {
+        if ((d & 63) == 0) {
+            const int i = d + lane;
+            xchunk = (i < len_x) ? up(a.x_bases[x0 + i]) : 0;
+        }
+        const int xnew = __builtin_amdgcn_readlane(xchunk, d & 63);
+        const int prev1 = xb1;
+        xb1 = xb0;
+        xb0 = (int)shr1((unsigned)prev1, (unsigned)xnew);
+        unsigned Eu[2];
+        Eu[0] = shr1(E1[1], 0u);  // row -1 for lane 0: zero in every column
+        Eu[1] = E1[0];
+        if (lane == 0) Et[0] = 0u;
+        unsigned En[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int i = d - (2 * lane + r);
+            const bool incol = (unsigned)i < (unsigned)len_x;
+            const int xb = r == 0 ? xb0 : xb1;
+            const unsigned e = min(Et[r] + (xb == yb[r] ? 0u : 1u), min(Eu[r], E1[r]) + 1u);
+            En[r] = incol ? e : E1[r];  // before its first column a row keeps the value left of column 0
+        }
+        {
+            const int i = d - last_row;
+            const bool hit = owner_lane && (unsigned)i < (unsigned)len_x;
+            const unsigned e = En[lr];
+            if (hit && e < best) { best = e; best_end = i + 1; nbest = 0; }
+            if (hit && e == best) nbest += 1;
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { Et[r] = Eu[r]; E1[r] = En[r]; }
+    }
+    if (owner_lane) {
+        a.dist[pair] = (int32_t)best;
+        if (a.end) a.end[pair] = best_end;
+        if (a.n_hits) a.n_hits[pair] = nbest;
+    }
+}
+
 }  // namespace vlr
 
 extern "C" int vlr_launch_realign_kernel(const vlr_realign_batch_desc* b, double* ln_prob, void* stream) {
@@ -203,5 +285,15 @@ extern "C" int vlr_launch_realign_kernel(const vlr_realign_batch_desc* b, double
     a.pgx = gx; a.pgy = gy; a.pgxe = gxe; a.pgye = gye;
     a.pn = 1.0 - (gx + gy); a.pnx = 1.0 - gxe; a.pny = 1.0 - gye;
     hipLaunchKernelGGL(vlr_realign_kernel, dim3((unsigned)b->n_pairs), dim3(64), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vlr_launch_edit_kernel(const vlr_realign_batch_desc* b, int32_t* dist, int32_t* end, int32_t* n_hits, void* stream) {
+    using namespace vlr;
+    if (b->n_pairs <= 0) return 0;
+    EditArgs a;
+    a.n_pairs = b->n_pairs; a.x_offset = b->x_offset; a.x_bases = b->x_bases; a.y_offset = b->y_offset; a.y_bases = b->y_bases;
+    a.dist = dist; a.end = end; a.n_hits = n_hits;
+    hipLaunchKernelGGL(vlr_edit_kernel, dim3((unsigned)b->n_pairs), dim3(64), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }

@@ -25,7 +25,7 @@ EXPORTS = [
     "vlr_abi_version", "vlr_build_id", "vlr_last_error", "vlr_plan_create", "vlr_plan_destroy", "vlr_plan_n_out",
     "vlr_plan_n_samples", "vlr_plan_set_max_depth", "vlr_plan_set_max_obs", "vlr_plan_reserve", "vlr_batch_run", "vlr_batch_run_host",
     "vlr_plan_last_kernel_ms", "vlr_plan_work_counters", "vlr_host_alloc", "vlr_host_free",
-    "vlr_realign_batch", "vlr_realign_batch_host", "vlr_fdr_threshold", "vlr_selftest_math", "vlr_selftest_stream",
+    "vlr_realign_batch", "vlr_realign_batch_host", "vlr_edit_distance_batch", "vlr_edit_distance_batch_host", "vlr_fdr_threshold", "vlr_selftest_math", "vlr_selftest_stream",
 ]
 
 

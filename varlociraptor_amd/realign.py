@@ -99,7 +99,7 @@ def prob_related(batch: PairBatch, gap: Optional[GapParams] = None, device: int 
 
 
 class DevicePairs:
-    """A PairBatch resident in HBM (torch owns the buffers) for vlr_realign_batch."""
+    """A PairBatch resident in HBM (torch owns the buffers) for vlr_realign_batch / vlr_edit_distance_batch."""
 
     def __init__(self, batch: PairBatch, device="cuda:0"):
         import torch
@@ -119,6 +119,21 @@ class DevicePairs:
         if rc != 0:
             raise engine.EngineError(rc, (L.vlr_last_error() or b"").decode())
         return self.out
+
+    def band_from_hits(self, device: int = 0, stream: int = 0):
+        """Edit-distance pre-filter on the resident pairs; sets the band of the pair HMM to distance + EDIT_BAND in place."""
+        import torch
+        L = _bind()
+        L.vlr_edit_distance_batch.restype = C.c_int
+        L.vlr_edit_distance_batch.argtypes = [C.c_int, C.POINTER(RealignDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        p = [t.data_ptr() for t in self.t]
+        d = RealignDesc(self.n, p[0], p[1], p[2], p[3], p[4], None, GapParams().as_array())
+        dist = torch.empty(self.n, dtype=torch.int32, device=self.t[5].device)
+        rc = L.vlr_edit_distance_batch(device, C.byref(d), dist.data_ptr(), None, None, stream)
+        if rc != 0:
+            raise engine.EngineError(rc, (L.vlr_last_error() or b"").decode())
+        self.t[5].copy_(torch.where(dist >= 0, dist + EDIT_BAND, torch.full_like(dist, -1)))
+        return dist
 
 
 # ---- allele windows (`ref_base(i)` of the emission parameter types) -----------------------------------------------
@@ -194,6 +209,26 @@ def best_hit(read: bytes, allele: bytes) -> Optional[Tuple[int, int]]:
     return d, int(np.argmax(prev[1:] == d)) + 1
 
 
+def best_hits(batch: "PairBatch", device: int = 0) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """(dist, end, n_hits) of every pair on the GPU (vlr_edit_distance_batch_host, csrc/vlr_realign.hip): what `best_hit` computes
+    for one pair on the host, plus the number of end positions reaching the smallest distance."""
+    L = _bind()
+    L.vlr_edit_distance_batch_host.restype = C.c_int
+    L.vlr_edit_distance_batch_host.argtypes = [C.c_int, C.POINTER(RealignDesc), C.c_void_p, C.c_void_p, C.c_void_p]
+    n = len(batch)
+    dist = np.full(n, -1, np.int32)
+    end = np.full(n, -1, np.int32)
+    hits = np.zeros(n, np.int32)
+    if n == 0:
+        return dist, end, hits
+    xo, xb, yo, yb, qb, band = batch.arrays()
+    desc = RealignDesc(n, xo.ctypes.data, xb.ctypes.data, yo.ctypes.data, yb.ctypes.data, qb.ctypes.data, None, GapParams().as_array())
+    rc = L.vlr_edit_distance_batch_host(device, C.byref(desc), dist.ctypes.data, end.ctypes.data, hits.ctypes.data)
+    if rc != 0:
+        raise engine.EngineError(rc, (L.vlr_last_error() or b"").decode())
+    return dist, end, hits
+
+
 def normalize_support(prob_ref: float, prob_alt: float) -> Tuple[float, float]:
     """mod.rs:359-385."""
     if prob_ref != -math.inf and prob_alt != -math.inf:
@@ -214,8 +249,9 @@ def allele_support(reads: Sequence[Tuple[bytes, Sequence[int]]], ref_allele_seq:
     for seq, qual in reads:
         assert len(seq) <= MAX_PATTERN_LEN
         for allele in (ref_allele_seq, alt_allele_seq):
-            hit = best_hit(seq, allele)
-            pb.add(allele, seq, qual, (hit[0] + EDIT_BAND) if hit else -1)
+            pb.add(allele, seq, qual, -1)
+    dist, _, _ = best_hits(pb, device)  # edit-distance pre-filter on the GPU; the pair HMM is banded to distance + EDIT_BAND
+    pb.band = [int(d) + EDIT_BAND if d >= 0 else -1 for d in dist]
     p = prob_related(pb, gap, device)
     out = np.empty((len(reads), 2))
     for k in range(len(reads)):
