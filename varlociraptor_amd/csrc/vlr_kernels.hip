@@ -73,7 +73,7 @@ struct ChainTask {              // one innermost Range chain (see run_chain_batc
 
 struct BatchOuter {              // outer Range frame whose pending points are evaluated as row-parallel inner chains
     double lo, hi, res, fixed_const;
-    int simpson, dead, vary, np, c0, nt, chn, s_in, s_out, pad;
+    int simpson, dead, vary, np, c0, nt, chn, s_in, s_out, alive0;  // alive0: other groups that can contain ANY point of the outer range
 };
 struct WalkSave {                // walk_root state while the kernel's event loop runs a chain batch on its behalf
     double rv;
@@ -2242,7 +2242,7 @@ __device__ inline void afd_emit_row(Ctx& c, int i, int s_in, int nq) {
 // The work is split in three steps around run_chain_batch, which the kernel's event loop runs on behalf of the
 // walk (bo_begin -> [bo_setup -> run_chain_batch -> bo_deliver]*): inlining the batch runner inside the walk kept
 // ~100 more VGPRs alive across it and made the compiler spill in its rounds.
-__device__ __forceinline__ void bo_begin(Ctx& c, RangeSt& r, int chn) {
+__device__ __forceinline__ void bo_begin(Ctx& c, RangeSt& r, int chn, int alive_in) {
     PROF_ADD(c, 3);
     const DevPlan& p = *c.plan;
     WaveSt* w = c.w;
@@ -2265,9 +2265,12 @@ __device__ __forceinline__ void bo_begin(Ctx& c, RangeSt& r, int chn) {
         else fixed_const += sample_lik(c, s, w->ops_vaf[s], by >= 0 ? w->ops_vaf[by] : 0.0);
     }
     fixed_const = uni_d(fixed_const);
+    // cross-event MAP candidates: groups whose spectra for the outer sample miss the whole outer range need no per-point test
+    const int alive0 = alive_restrict(c, alive_in, s_out, uni_d(r.lo), uni_d(r.hi));
     __syncthreads();
     if (c.lane == 0) {
         BatchOuter& B = w->bo;
+        B.alive0 = alive0;
         B.lo = lo; B.hi = hi; B.res = res; B.fixed_const = fixed_const;
         B.simpson = simpson; B.dead = dead ? 1 : 0; B.vary = vary; B.np = UNI(r.npend); B.c0 = 0; B.nt = 0;
         B.chn = chn; B.s_in = s_in; B.s_out = s_out;
@@ -2296,7 +2299,7 @@ __device__ __forceinline__ bool bo_setup(Ctx& c, const Frame& f, RangeSt& r) {
         T.ostart = ch.vafs.start; T.oend = ch.vafs.end; T.olex = ch.vafs.lex; T.orex = ch.vafs.rex;
         T.simpson_n = B.simpson;
         T.contained = UNI(f.sv_contained) && range_contains(oorig, x);
-        T.alive = alive_update(c, UNI(f.sv_alive), s_out, x);
+        T.alive = alive_update(c, UNI(B.alive0), s_out, x);
         int pidx = 0;
         for (int s = 0; s < S; ++s) {
             double v = (s == s_out) ? x : w->ops_vaf[s];
@@ -2654,7 +2657,15 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                 c.present = UNI(f.sv_present) | (1 << UNI(r.sample));
                 c.disc = UNI(f.sv_disc) & ~(1 << UNI(r.sample));
                 c.nlfc = UNI(f.sv_nlfc);
-                bo_begin(c, r, leaf_range_child(p, fnode));
+                // the frame's constants (inner range, fixed likelihoods, ...) are set up in its first round only; later rounds
+                // just rewind the point counters (no other outer frame can run between the rounds of this one: its children
+                // are leaf chains)
+                if (UNI(r.tn) == 0) bo_begin(c, r, leaf_range_child(p, fnode), UNI(f.sv_alive));
+                else {
+                    __syncthreads();
+                    if (c.lane == 0) { BatchOuter& B = w->bo; B.np = r.npend; B.c0 = 0; B.nt = 0; }
+                    __syncthreads();
+                }
                 pc = PC_BO_PRE;
             } else {
                 // outer chain: one point at a time through the subtree
