@@ -565,6 +565,26 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
             gs_off.push_back((int32_t)gs.size());
         }
     }
+    // per Sample node: the groups whose spectra for its sample overlap the node's own spectrum (DevNode::alive_mask)
+    {
+        auto overlap = [&](const DevSpectrum& a, const DevSpectrum& b) {
+            const double eps = 1e-9;
+            auto lo = [&](const DevSpectrum& x, int i) { return x.kind == VLR_SPECTRUM_SET ? pool[x.set_off + i] : x.start; };
+            auto hi = [&](const DevSpectrum& x, int i) { return x.kind == VLR_SPECTRUM_SET ? pool[x.set_off + i] : x.end; };
+            const int na = a.kind == VLR_SPECTRUM_SET ? a.set_len : 1, nb = b.kind == VLR_SPECTRUM_SET ? b.set_len : 1;
+            for (int i = 0; i < na; ++i)
+                for (int j = 0; j < nb; ++j)
+                    if (lo(a, i) <= hi(b, j) + eps && lo(b, j) <= hi(a, i) + eps) return true;
+            return false;
+        };
+        for (DevNode& n : nodes) {
+            n.alive_mask = 0;
+            if (n.kind != VLR_NODE_SAMPLE) continue;
+            for (int g = 0; g <= d->n_events; ++g)
+                for (int k = gs_off[g * S + n.sample]; k < gs_off[g * S + n.sample + 1]; ++k)
+                    if (overlap(n.vafs, gs[k])) { n.alive_mask |= 1 << g; break; }
+        }
+    }
     std::vector<double> table;
     int rc = build_prior_table(d, P, table);
     if (rc != VLR_OK) return rc;

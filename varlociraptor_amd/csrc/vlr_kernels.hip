@@ -268,7 +268,7 @@ __device__ __forceinline__ DevNode ld_node(const DevNode* g) {
     n.lfc_value = ldc(&g->lfc_value);
     n.vafs = ld_spec(&g->vafs);
     n.positive = ldc(&g->positive); n.refbase = ldc(&g->refbase); n.altbase = ldc(&g->altbase);
-    n.child_off = ldc(&g->child_off); n.n_children = ldc(&g->n_children); n.pad = 0;
+    n.child_off = ldc(&g->child_off); n.n_children = ldc(&g->n_children); n.alive_mask = ldc(&g->alive_mask);
     return n;
 }
 
@@ -2299,7 +2299,7 @@ __device__ __forceinline__ bool bo_setup(Ctx& c, const Frame& f, RangeSt& r) {
         T.ostart = ch.vafs.start; T.oend = ch.vafs.end; T.olex = ch.vafs.lex; T.orex = ch.vafs.rex;
         T.simpson_n = B.simpson;
         T.contained = UNI(f.sv_contained) && range_contains(oorig, x);
-        T.alive = alive_update(c, UNI(B.alive0), s_out, x);
+        T.alive = alive_update(c, UNI(B.alive0), s_out, x) & ch.alive_mask;  // (& the groups that can contain a VAF of the inner node)
         int pidx = 0;
         for (int s = 0; s < S; ++s) {
             double v = (s == s_out) ? x : w->ops_vaf[s];
@@ -2347,23 +2347,33 @@ __device__ __forceinline__ bool bo_deliver(Ctx& c, const Frame& f, RangeSt& r, d
     const int np = UNI(B.np), c0 = UNI(B.c0), nt = UNI(B.nt), s_in = UNI(B.s_in), s_out = UNI(B.s_out);
     const bool dead = UNI(B.dead) != 0;
     __syncthreads();
+    // lane i < nt fetches the results of chain i and records its outer point in one go; the row loop below then reads lanes
+    // instead of making an LDS round trip per field and row
+    const int li = lane < nt ? lane : 0;
+    const ChainTask& Tl = w->task[li];
+    const double xl = r.pend[c0 + li], resl = Tl.result, bJl = Tl.bestJ, bXl = Tl.bestX;
+    const int hbl = Tl.haveBest, alivel = Tl.alive, contl = Tl.contained, nl = Tl.n;
+    const int tn0 = UNI(r.tn);
+    if (lane < nt) { txo[tn0 + c0 + lane] = xl; tvo[tn0 + c0 + lane] = dead ? VLR_NEG_INF : resl; }
     for (int i = 0; i < nt; ++i) {
-        const ChainTask& T = w->task[i];
-        const double x = uni_d(r.pend[c0 + i]);
+        const double x = lane_d(xl, i);
         __syncthreads();
-        if (lane == 0) { txo[r.tn + c0 + i] = x; tvo[r.tn + c0 + i] = dead ? VLR_NEG_INF : T.result; w->ops_vaf[s_out] = x; }
+        if (lane == 0) w->ops_vaf[s_out] = x;
         __syncthreads();
         if (dead) continue;
+        const int hb = __builtin_amdgcn_readlane(hbl, i), n_i = __builtin_amdgcn_readlane(nl, i);
         if (c.replay) {
-            if (UNI(f.sv_mute) || table_has(txo, UNI(r.tn) + c0 + i, x, lane)) continue;  // repeated outer VAF: same map keys
-            afd_emit_row(c, i, s_in, UNI(T.n));
+            if (UNI(f.sv_mute) || table_has(txo, tn0 + c0 + i, x, lane)) continue;  // repeated outer VAF: same map keys
+            afd_emit_row(c, i, s_in, n_i);
             continue;
         }
-        if (UNI(T.haveBest) & 1) map_consider(c, uni_d(T.bestJ), s_in, uni_d(T.bestX));
+        if (hb & 1) map_consider(c, lane_d(bJl, i), s_in, lane_d(bXl, i));
         // rare: candidates for other groups / containment via another path (also of a visited excluded range end)
-        if (UNI(T.alive) != 0 || !UNI(T.contained) || (UNI(T.haveBest) & 2)) {
+        const int al_i = __builtin_amdgcn_readlane(alivel, i), co_i = __builtin_amdgcn_readlane(contl, i);
+        if (al_i != 0 || !co_i || (hb & 2)) {
+            const ChainTask& T = w->task[i];
             const RangeV io{uni_d(T.ostart), uni_d(T.oend), UNI(T.olex), UNI(T.orex)};
-            scan_chain_candidates(c, c.rowX + i * c.cap, c.rowV + i * c.cap, UNI(T.n), io, UNI(T.contained), UNI(T.alive), s_in);
+            scan_chain_candidates(c, c.rowX + i * c.cap, c.rowV + i * c.cap, n_i, io, co_i, al_i, s_in);
         }
     }
     const int c1 = c0 + nt;
@@ -2536,7 +2546,9 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                     if (c.lane == 0) {
                         f.node = node; f.iter = 0; f.accM = VLR_NEG_INF; f.accS = 0.0;
                         f.sv_present = c.present; f.sv_disc = c.disc; f.sv_nlfc = c.nlfc; f.sv_contained = c.contained;
-                        f.sv_alive = c.alive; f.sv_mute = c.afd_mute;
+                        // every operand set below this frame takes sample s from this node: groups whose spectra for s miss the
+                        // node's spectrum altogether (static, DevNode::alive_mask) cannot contain any of them
+                        f.sv_alive = c.alive & nd.alive_mask; f.sv_mute = c.afd_mute;
                     }
                     if (c.defer_ok && (as_set ? (ncand > 1) : (nd.n_children != 0))) {
                         c.deferred = 2;  // probe pass: not a single-chain root, evaluate in the second pass
@@ -2549,7 +2561,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                         c.present |= (1 << s);
                         c.disc |= (1 << s);
                         c.contained = UNI(f.sv_contained) && spectrum_contains(nd.vafs, p.vafs, w->ops_vaf[s]);
-                        c.alive = alive_update(c, UNI(f.sv_alive), s, w->ops_vaf[s]);
+                        c.alive = alive_update(c, UNI(f.sv_alive) & nd.alive_mask, s, w->ops_vaf[s]);
                         pc = PC_SUB;
                     } else if (nrange >= p.max_range_depth || nrange >= kMaxRangeDepth) {
                         c.status |= VLR_LOCUS_TABLE_FULL; rv = __builtin_nan(""); pc = PC_RETURN;
@@ -2558,8 +2570,10 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                         double res = p.resolution[s];
                         double min_vaf = observable_min(vr, n_obs);
                         double max_vaf = observable_max(vr, n_obs);
+                        // the leaf Range child of this frame, if it has one (looked up once: every round of the frame asks)
+                        const int lchild = (nd.n_children != 0) ? leaf_range_child(p, node) : -1;
                         if (c.lane == 0) {
-                            f.kind = FK_RANGE; f.slot = nrange; f.n = 0;
+                            f.kind = FK_RANGE; f.slot = nrange; f.n = lchild;
                             r.lo = min_vaf; r.hi = max_vaf; r.res = res;
                             r.ostart = nd.vafs.start; r.oend = nd.vafs.end; r.olex = nd.vafs.lex; r.orex = nd.vafs.rex;
                             r.have_first = 0; r.have_mid = 0; r.tn = 0; r.sample = s; r.leaf = (nd.n_children == 0);
@@ -2652,7 +2666,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                 c.present = UNI(f.sv_present); c.disc = UNI(f.sv_disc); c.nlfc = UNI(f.sv_nlfc); c.contained = UNI(f.sv_contained); c.alive = UNI(f.sv_alive); c.afd_mute = UNI(f.sv_mute);
                 sp--; nrange--;
                 pc = PC_RETURN;
-            } else if (c.cap <= 64 && UNI(f.iter) == 0 && UNI(f.sv_nlfc) == 0 && leaf_range_child(p, fnode) >= 0) {
+            } else if (c.cap <= 64 && UNI(f.iter) == 0 && UNI(f.sv_nlfc) == 0 && UNI(f.n) >= 0) {
                 // outer chain over a leaf Range child: all pending points at once, kRows inner chains per pass
                 c.present = UNI(f.sv_present) | (1 << UNI(r.sample));
                 c.disc = UNI(f.sv_disc) & ~(1 << UNI(r.sample));
@@ -2660,7 +2674,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                 // the frame's constants (inner range, fixed likelihoods, ...) are set up in its first round only; later rounds
                 // just rewind the point counters (no other outer frame can run between the rounds of this one: its children
                 // are leaf chains)
-                if (UNI(r.tn) == 0) bo_begin(c, r, leaf_range_child(p, fnode), UNI(f.sv_alive));
+                if (UNI(r.tn) == 0) bo_begin(c, r, UNI(f.n), UNI(f.sv_alive));
                 else {
                     __syncthreads();
                     if (c.lane == 0) { BatchOuter& B = w->bo; B.np = r.npend; B.c0 = 0; B.nt = 0; }
@@ -2699,13 +2713,21 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
             Frame& f = c.frames[sp - 1];
             const int fslot = UNI(f.slot);
             RangeSt& r = c.rs[fslot];
-            if (bo_deliver(c, f, r, c.tabX + fslot * c.cap, c.tabV + fslot * c.cap)) pc = PC_BO_PRE;
+            double* tx = c.tabX + fslot * c.cap;
+            double* tv = c.tabV + fslot * c.cap;
+            if (bo_deliver(c, f, r, tx, tv)) pc = PC_BO_PRE;
             else {
+                // all points of the round are recorded (f.iter stays 0 in batched rounds): advance the outer chain right here
+                // (what PC_RETURN does for a frame whose points come back one by one)
+                const bool done = range_advance(c, r, tx, tv);
                 __syncthreads();
-                if (c.lane == 0) f.iter = r.npend;
-                __syncthreads();
-                skip_record = true;
-                pc = PC_RETURN;
+                if (!done) pc = PC_RANGE_ISSUE;
+                else {
+                    rv = range_finish(c, r, tx, tv);
+                    c.present = UNI(f.sv_present); c.disc = UNI(f.sv_disc); c.nlfc = UNI(f.sv_nlfc); c.contained = UNI(f.sv_contained); c.alive = UNI(f.sv_alive); c.afd_mute = UNI(f.sv_mute);
+                    sp--; nrange--;
+                    pc = PC_RETURN;
+                }
             }
         } else {  // PC_RETURN: hand rv to the enclosing frame
             rv = uni_d(rv);

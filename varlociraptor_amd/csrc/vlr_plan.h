@@ -40,7 +40,9 @@ struct DevNode {
     int32_t positive;
     int32_t refbase, altbase;
     int32_t child_off, n_children;
-    int32_t pad;
+    int32_t alive_mask;  // Sample nodes: event groups (bit 0 = absent, 1 + e = event e) with a spectrum for this sample that overlaps
+                         // this node's spectrum at all (closed intervals, 1e-9 slack) — no other group can `contain` an operand set
+                         // that takes this sample's VAF from here; lets the walk drop cross-event MAP candidates early
 };
 
 // All-discrete roots (every node a Sample node with a Set or single-valued spectrum, e.g. the pedigree scenarios and
