@@ -112,6 +112,20 @@ struct WaveSt {
                  // (phase A); otherwise e == 0 exactly for the whole pileup and the HBM scratch row is neither written nor read
 };
 
+// one observation row (all ten columns) of lane `i`; rows beyond `end` read as an empty observation
+struct ObsRow { uint32_t f; float pm, pa, pr, miss, psa, pdo, phb, hpa, hpv; };
+__device__ __forceinline__ ObsRow load_obs_row(const DevBatch& batch, uint32_t i, uint32_t end) {
+    ObsRow r{0u, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, __builtin_nanf(""), __builtin_nanf("")};
+    if (i < end) {
+        r.f = batch.flags[i];
+        r.pm = batch.pm[i]; r.pa = batch.pa[i]; r.pr = batch.pr[i]; r.miss = batch.miss[i];
+        r.psa = batch.psa[i]; r.pdo = batch.pdo[i]; r.phb = batch.phb[i];
+        if (batch.hpa) r.hpa = batch.hpa[i];
+        if (batch.hpv) r.hpv = batch.hpv[i];
+    }
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // values that are wave-uniform by construction but live in VGPRs/LDS: moving them to SGPRs lets the compiler
 // use scalar branches and scalar (cached) loads of plan data instead of vector loads
@@ -3046,14 +3060,15 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
             uint32_t i = base + lane;
             bool valid = i < o1;
             double pm = 0, pa = 0, pr = 0;
+            float psa_f = 0.0f, phb_f = 0.0f;
             uint32_t f = 0;
-            if (valid) {
+            if (valid) {  // all columns this pass needs in one round of loads (none waits for another)
                 pm = batch.pm[i]; pa = batch.pa[i]; pr = batch.pr[i];
-                f = batch.flags[i];
+                f = batch.flags[i]; psa_f = batch.psa[i]; phb_f = batch.phb[i];
             }
             bool keep = valid && !(remove_nonstd && f_orient(f) == VLR_ORIENT_OTHER);  // pileup.rs:26-43
             filtered += popc64(__ballot(valid && !keep));
-            if (__ballot(keep && batch.psa[i] != 0.0f)) ehas_mask |= 1 << s;  // s = e^psa != 1: third coefficient e != 0
+            if (__ballot(keep && psa_f != 0.0f)) ehas_mask |= 1 << s;  // s = e^psa != 1: third coefficient e != 0
             double bf_ref = exp(pr - pa), bf_alt = exp(pa - pr);
             bool strong_ref = keep && bf_ref > 20.0;       // read_observation.rs:434-437 (KassRaftery >= Strong)
             bool strong_alt = keep && bf_alt > 20.0;       // 429-432
@@ -3083,7 +3098,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
             if (__ballot(keep && f_altlocus(f) != VLR_ALTLOCUS_NONE)) any_altloci = true;
             if (__ballot(keep && (f & VLR_F_SOFTCLIPPED))) any_softclip = true;
             {   // maxima of the decision sums (second pass below)
-                const double phb1 = valid ? (double)batch.phb[i] : 0.0;
+                const double phb1 = (double)phb_f;
                 const int st1 = f_strand(f);
                 mx_sb_all = fmax(mx_sb_all, (strong_ref && st1 != VLR_STRAND_BOTH) ? pm : VLR_NEG_INF);
                 mx_sb_fwd = fmax(mx_sb_fwd, (strong_ref && st1 == VLR_STRAND_FORWARD) ? pm : VLR_NEG_INF);
@@ -3277,19 +3292,25 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
             int wr = w->soff[s];
             int fast_s = 1, vfast_s = 1;
             const bool ehas_s = (ehas_mask >> s) & 1;
+            // every column of a row in one round of loads (the few rows that are dropped below are loaded in vain), and the rows of
+            // the NEXT 64 observations are requested before this iteration's arithmetic starts
+            ObsRow nxt = load_obs_row(batch, o0 + lane, o1);
             for (uint32_t base = o0; base < o1; base += 64) {
                 uint32_t i = base + lane;
                 bool valid = i < o1;
                 bool tiny = false, small = false;
-                uint32_t f = valid ? batch.flags[i] : 0u;
+                const ObsRow cur = nxt;
+                if (base + 64 < o1) nxt = load_obs_row(batch, i + 64, o1);
+                const uint32_t f = cur.f;
+                const float pm_f = cur.pm, pa_f = cur.pa, pr_f = cur.pr, miss_f = cur.miss, psa_f = cur.psa, pdo_f = cur.pdo, phb_f = cur.phb, hpa_f = cur.hpa, hpv_f = cur.hpv;
                 bool keep = valid && !(remove_nonstd && f_orient(f) == VLR_ORIENT_OTHER);
                 unsigned long long km = __ballot(keep);
                 int pos = wr + popc64(km & ((1ull << lane) - 1ull));
                 if (keep) {
-                    double pm = batch.pm[i], pa = batch.pa[i], pr = batch.pr[i], miss = batch.miss[i];
-                    double psa = batch.psa[i], pdo = batch.pdo[i], phb = batch.phb[i];
-                    double hpa = batch.hpa ? (double)batch.hpa[i] : __builtin_nan("");
-                    double hpv = batch.hpv ? (double)batch.hpv[i] : __builtin_nan("");
+                    double pm = pm_f, pa = pa_f, pr = pr_f, miss = miss_f;
+                    double psa = psa_f, pdo = pdo_f, phb = phb_f;
+                    double hpa = hpa_f;
+                    double hpv = hpv_f;
                     if (singleton && pa > pr) { pa = kLn05; pr = kLn05; }  // prob_alt_adj / prob_ref_adj
                     int strand = f_strand(f), orient = f_orient(f);
                     bool major = (f & VLR_F_READPOS_MAJOR) != 0;
