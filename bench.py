@@ -8,10 +8,13 @@ shard of that size.  Prints ONE JSON line on rank 0.
 
   --workload config2|config3|config4|config5   BASELINE configs[1..4] (locus counts of the config, or --loci)
   --workload realign                          second hot path: read-vs-allele pair HMM, pairs/s
-  --afd                                       additionally time the step WITH the AFD lists (the reference always computes AFD,
-                                              calling.rs:889-928) and report it as `with_afd` in the same line; `value` stays
-                                              the BASELINE metric.  Off by default so that a kernel trace of the default command
-                                              holds launches of one kind only (profiles/ keep the --afd line and its trace)
+  --workload cli                              end to end through the process boundary: observation BCFs -> call variants -> calls BCF
+  --afd / --no-afd                            (default on) additionally time the step WITH the AFD lists (the reference always
+                                              computes AFD, calling.rs:889-928) and report it as `with_afd` in the same line;
+                                              `value` stays the BASELINE metric (plain step), the roofline is the plain kernel's
+  --gpus N                                    N > 1 without a torchrun environment: bench.py starts its own ranks
+                                              (python -m torch.distributed.run --nproc-per-node N on 127.0.0.1) and relays rank 0's line
+  --dry-run                                   launcher / collective check without a GPU (gloo, synthetic result records)
 """
 import argparse
 import json
@@ -166,19 +169,131 @@ def bench_realign(args, rank, world, local_rank, dev):
     }
 
 
+def self_launch(argv, n):
+    """`python bench.py --gpus N` outside torchrun: start one rank per GPU on this node and relay their output."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank, world):
+    """No GPU: the ranks rendezvous over gloo, shard a synthetic record set like the timed step does and all-gather it."""
+    import torch
+    import torch.distributed as dist
+    from varlociraptor_amd.dist import all_gather_records, shard_range
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    n_loci = args.loci or 1000
+    n_total = n_loci * world
+    width = 9
+    mine = torch.arange(rank * n_loci, (rank + 1) * n_loci, dtype=torch.float64)[:, None].repeat(1, width)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full = all_gather_records(mine, n_total, world) if world > 1 else mine
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    ok = bool(torch.equal(full[:, 0], torch.arange(n_total, dtype=torch.float64)))
+    assert shard_range(n_total, rank, world) == (rank * n_loci, (rank + 1) * n_loci)
+    if rank == 0:
+        print(json.dumps({"metric": "candidate loci/sec (whole node)", "dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "gathered_in_order": ok, "ms_per_step": el / args.steps * 1e3, "value": None}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_cli(args, rank, world, local_rank, dev):
+    """End to end through the process boundary: observation BCFs on disk -> `call variants` (native BGZF/BCF/v15
+    ingest, vlr_batch_run_host with AFD lists, native calls writer) -> calls BCF on disk.  One step = one whole run of
+    cli.call_variants over the rank's files; the synthetic observation files are written once, outside the timed region."""
+    import tempfile
+    import torch
+    import torch.distributed as dist
+    from varlociraptor_amd import cli, engine, ingest, synth
+    n_loci = args.loci or 200_000
+    cfg = synth.CONFIGS["config3"]()
+    batch = generate("config3", n_loci, rank)
+    tmp = tempfile.mkdtemp(prefix="vlr_cli_%d_" % rank, dir=os.environ.get("VLR_BENCH_TMP", None))
+    names = cfg.scenario.sample_names
+    paths = {}
+    t0 = time.perf_counter()
+    for s, name in enumerate(names):
+        paths[name] = os.path.join(tmp, "%s.bcf" % name)
+        ingest.write_observations(paths[name], batch, s)
+    t_write_obs = time.perf_counter() - t0
+    obs_bytes = sum(os.path.getsize(p) for p in paths.values())
+    out_path = os.path.join(tmp, "calls.bcf")
+    del batch
+    tm = {}
+
+    def step():
+        cli.call_variants(cfg.scenario, paths, output=out_path, device=local_rank, afd_capacity=args.afd_capacity, timings=tm)
+    for _ in range(max(1, args.warmup)):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    stages = {"read_s": 0.0, "call_s": 0.0, "write_s": 0.0}
+    for _ in range(args.steps):
+        step()
+        for k in stages:
+            stages[k] += tm[k]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    calls_bytes = os.path.getsize(out_path)
+    n_obs = tm["n_obs"]
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    if rank != 0:
+        return None
+    per = {k: v / args.steps for k, v in stages.items()}
+    return {
+        "metric": "candidate loci/sec end to end (observation BCF -> call variants -> calls BCF, whole node)", "value": n_loci * world * args.steps / elapsed,
+        "unit": "loci/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup), "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "cli: tumor-normal 100x (config3 pileups), %d records/GPU in two observation BCFs (format v15, BGZF), AFD lists of %d entries, calls written as BCF" % (n_loci, args.afd_capacity),
+                   "parallelism": "records sharded x%d, one process per GPU" % world, "host_threads": os.cpu_count()},
+        "stages_s": per,
+        "stage_rates": {"read_records_per_s": n_loci / per["read_s"], "read_uncompressed_GBps": None, "call_loci_per_s": n_loci / per["call_s"], "write_records_per_s": n_loci / per["write_s"]},
+        "files": {"observation_bcf_bytes": obs_bytes, "calls_bcf_bytes": calls_bytes, "observations": int(n_obs), "observation_write_s_untimed": t_write_obs},
+        "roofline": None, "cpu_baseline": None, "build_id": engine.build_id(),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="config3", choices=["config2", "config3", "config4", "config5", "realign"])
+    ap.add_argument("--workload", default="config3", choices=["config2", "config3", "config4", "config5", "realign", "cli"])
     ap.add_argument("--loci", type=int, default=None, help="loci per GPU (default: the config's size); realign: pairs per GPU")
-    ap.add_argument("--afd", dest="afd", action="store_true", default=False, help="also time the step with the AFD lists")
-    ap.add_argument("--no-afd", dest="afd", action="store_false", help="(default) only the plain step")
+    ap.add_argument("--afd", dest="afd", action="store_true", default=True, help="(default) also time the step with the AFD lists")
+    ap.add_argument("--no-afd", dest="afd", action="store_false", help="only the plain step")
+    ap.add_argument("--dry-run", action="store_true", help="launcher and collective check without a GPU (gloo)")
     ap.add_argument("--afd-capacity", type=int, default=96)
     ap.add_argument("--cpu-loci", type=int, default=None, help="loci of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
+    if args.dry_run:
+        assert int(os.environ.get("WORLD_SIZE", "1")) == args.gpus
+        return dry_run(args, int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
 
     import torch
     import torch.distributed as dist
@@ -191,12 +306,14 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d needs cuda:%d, %d device(s) visible (no CPU path)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
 
-    if args.workload == "realign":
-        line = bench_realign(args, rank, world, local_rank, dev)
+    if args.workload in ("realign", "cli"):
+        line = (bench_realign if args.workload == "realign" else bench_cli)(args, rank, world, local_rank, dev)
         if rank == 0:
             print(json.dumps(line))
         if world > 1:
@@ -212,7 +329,7 @@ def main():
     plan = engine.Plan(cfg.scenario, device=local_rank)
     # the caller knows its pileups: size the kernel's LDS coefficient area to the deepest locus of the batch
     plan.set_max_obs(int(batch.depth().sum(axis=1).max()))
-    plan.reserve(batch.n_loci, with_afd=args.afd)  # vlr_batch_run then only enqueues work on the stream
+    plan.reserve(batch.n_loci, with_afd=args.afd_capacity if args.afd else 0)  # vlr_batch_run then only enqueues work on the stream
     out = engine.DeviceResults(batch.n_loci, plan.n_out, plan.n_samples, dev)
     stream = torch.cuda.current_stream().cuda_stream
     n_total = n_loci * world
@@ -315,7 +432,11 @@ def main():
             "metric": "candidate loci/sec (whole node)", "value": n_total * args.steps / elapsed, "unit": "loci/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: %s, %d loci/GPU, mean depth %.0fx/sample" % (args.workload, cfg.name, n_loci, cfg.depth),
+            "config": {"workload": "%s: %s, %d loci/GPU, mean depth %.0fx/sample, %s%s; variant types %s; truth classes %s" % (
+                           args.workload, cfg.name, n_loci, cfg.depth, "%d samples" % plan.n_samples,
+                           (", purity %.2f (contamination %.2f)" % (cfg.purity, 1.0 - cfg.purity)) if cfg.purity is not None else "",
+                           "/".join("%s %.0f%%" % ({0: "SNV", 1: "MNV", 2: "indel", 3: "SV/BND", 4: "other"}.get(k, str(k)), 100 * v) for k, v in cfg.type_mix.items()),
+                           "/".join("%s %.0f%%" % (c[0], 100 * c[1]) for c in cfg.classes)),
                        "scenario_events": cfg.scenario.event_names,
                        "parallelism": "loci sharded x%d, all-gather of the full result records (posteriors, marginal, MAP VAFs, bias codes, best event, status)" % world,
                        "gen_seconds": round(t_gen, 1)},

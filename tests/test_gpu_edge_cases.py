@@ -385,3 +385,18 @@ def test_log_probabilities_below_the_f64_exponent_range(oracle):
     pr[hit & alt_like] = np.float32(-2000.0)
     got, ref = check(oracle, cfg.scenario, b, "supports below the f64 range")
     assert not (got.status & abi.LOCUS_UNDERFLOW).any()
+
+
+def test_thirty_named_events_use_every_bit_of_the_alive_masks(oracle):
+    """kMaxNamedEvents = 30 -> 31 event groups, the alive masks use bits 0..30 of an int32; a plan with 31 events
+    is rejected instead of shifting into the sign bit.  MAP candidates that belong to another event group must survive."""
+    edges = [round(k / 30.0, 6) for k in range(31)]
+    events = {"e%02d" % k: "s:]%s,%s]" % (repr(edges[k]), repr(edges[k + 1])) for k in range(30)}
+    sc = Scenario({"s": Sample(resolution=0.01, universe="[0.0,1.0]")}, events)
+    cfg = with_depth(synth.config2(), 30.0)
+    cfg.scenario = sc
+    check(oracle, sc, synth.generate(cfg, 150, seed=23), "30 events")
+    events["e30"] = "s:0.0"
+    too_many = Scenario({"s": Sample(resolution=0.01, universe="[0.0,1.0]")}, {("x%02d" % i): "s:{%r}" % (i / 40.0) for i in range(31)})
+    with pytest.raises(Exception):
+        engine.Plan(too_many)

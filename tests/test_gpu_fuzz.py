@@ -24,6 +24,21 @@ def test_random_scenarios_match_oracle(seed):
     assert st["knife_edge_loci"] <= 2 and st["flat_loci"] <= 0.02 * 24 * st["run"], st
 
 
+@pytest.mark.parametrize("seed", [1, 5])
+def test_random_scenarios_afd_lists_match_oracle(seed, monkeypatch):
+    """the AFD lists (FORMAT/AFD, calling.rs:889-928) of the same random scenarios, including those whose events
+    overlap: list membership follows the reference's map key (VAFs, is_discrete flags AND the l2fc terms on the path), and the
+    MAP among operand sets that differ only in their flags is the oracle's."""
+    monkeypatch.setenv("FUZZ_AFD", "1")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_scenarios.py")
+    spec = importlib.util.spec_from_file_location("fuzz_scenarios_afd", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(["fuzz", "60", str(seed)]) == 0
+    st = mod.LAST_STATS
+    assert st["plans_rejected"] == 0 and st["run"] == st["generated"] >= 50 and st["afd_bad_lists"] == 0 and st["afd_map_tie_loci"] <= 2, st
+
+
 def test_random_prior_scenarios_match_oracle(monkeypatch):
     """Ploidy-derived universes with germline / somatic / Mendelian / clonal / subclonal priors, default and --full-prior."""
     monkeypatch.setenv("FUZZ_PRIOR", "1")

@@ -335,3 +335,17 @@ def test_minilogprob_vectors_decode_the_same_on_the_strided_and_the_element_path
     assert np.array_equal(mixed, np.where(tags == 0, want16, vals))
     assert len(obsfmt._vec_minilogprob(struct.pack("<Q", 0))) == 0
     assert np.array_equal(obsfmt._vec_enum(struct.pack("<Q", 3) + struct.pack("<III", 2, 0, 8)), np.array([2, 0, 8], dtype=np.uint32))
+
+
+def test_model_mode_has_only_the_four_reference_flags():
+    """calling.rs:413-418: the model (and with it the variant-specific prior of a contig's first record) is keyed by the
+    orientation / position / softclip / homopolymer checks only; strand and alt-locus checks follow `is_precise` and must not
+    split a contig's records into two models."""
+    import numpy as np
+    from varlociraptor_amd import abi, cli
+    precise_indel = abi.BIAS_STRAND | abi.BIAS_HOMOPOLYMER | abi.BIAS_ALTLOCUS
+    imprecise_sv = abi.BIAS_HOMOPOLYMER | abi.BIAS_ALTLOCUS
+    snv = abi.BIAS_ALL
+    m = cli.model_modes(np.array([precise_indel, imprecise_sv, snv, imprecise_sv & ~abi.BIAS_ALTLOCUS], dtype=np.uint8))
+    assert m[0] == m[1] == m[3] and m[2] != m[0]
+    assert cli.MODEL_MODE_MASK == 0x1E

@@ -1,0 +1,170 @@
+"""Native ingest / emission (csrc/vlr_ingest.cpp behind include/vlr.h) against the Python restatement (obsfmt.py, bcfio.py,
+callsfmt.py) and the reference's own files: the v15 decoder on the reference's fourteen testcase records and the
+flamegraph_profiling fixture, the observation writer (write_observations) through both readers, the calls writer (text and BCF)
+against the Python formatter and against the reference's calls.vcf.  No GPU: results come from the oracle."""
+import glob
+import io
+import os
+
+import numpy as np
+import pytest
+
+from varlociraptor_amd import abi, callsfmt, cli, ingest, obsfmt, synth
+from varlociraptor_amd.bcfio import BcfReader
+
+
+def _same_batch(a, b):
+    assert np.array_equal(a.obs_offset, b.obs_offset)
+    for k, _ in abi.OBS_COLUMNS:
+        assert np.array_equal(a.columns[k], b.columns[k], equal_nan=True), k
+    for k, _ in abi.LOCUS_COLUMNS:
+        assert np.array_equal(a.locus[k], b.locus[k]), k
+
+
+def test_native_decoder_equals_python_decoder_on_reference_records(golden_dir):
+    files = [os.path.join(golden_dir, "flamegraph_profiling", "normal.vcf")] + sorted(glob.glob(os.path.join(golden_dir, "testcases", "*", "observations.vcf")))
+    assert len(files) == 15
+    for f in files:
+        a, sa = ingest.read_observations([f])
+        b, sb = obsfmt.read_observation_vcf([f])
+        _same_batch(a, b)
+        assert np.array_equal(a.extra["third_allele_evidence"], b.extra["third_allele_evidence"])
+        assert [sa[l] for l in range(len(sa))] == list(sb)
+        pri = b.extra["prior_overrides"]
+        for l in range(a.n_loci):
+            for got, want in ((a.extra["prior_het_ln"][l], pri[l][0]), (a.extra["prior_som_ln"][l], pri[l][1])):
+                assert (want is None and got != got) or (want is not None and abs(got - want) < 1e-12)
+
+
+def test_native_decoder_reads_the_reference_bcf(golden_dir):
+    """calls.bcf of the reference fixture is BGZF/BCF2 written by htslib: the container code (block index, parallel inflate,
+    typed values, dictionaries) is exercised on a file this repo did not write.  Its header still carries the observation format
+    version (calls headers derive from the observation header), its records hold no observation vectors: the reference's own
+    error for that (read_values, preprocessing/mod.rs:828-834)."""
+    with pytest.raises(Exception, match="No varlociraptor observations found in record"):
+        ingest.read_observations([os.path.join(golden_dir, "flamegraph_profiling", "calls.bcf")])
+
+
+@pytest.mark.parametrize("name", ["config3", "config4", "config5"])
+def test_observation_writer_round_trip(name, tmp_path):
+    cfg = synth.CONFIGS[name]()
+    b = synth.generate(cfg, 400, seed=21)
+    third = np.where(np.arange(b.n_obs) % 7 == 0, np.arange(b.n_obs) % 5, -1).astype(np.int32)
+    paths = []
+    for s in range(b.n_samples):
+        p = str(tmp_path / ("%s_%d.bcf" % (name, s)))
+        ingest.write_observations(p, b, s, third_allele_evidence=third)
+        paths.append(p)
+    r, sites = ingest.read_observations(paths)
+    _same_batch(r, b)   # incl. locus_flags: IMPRECISE is derived from the bias mask of SV records
+    assert np.array_equal(r.extra["third_allele_evidence"], third)
+    # the Python BCF reader + decoder on the natively written file
+    pb, _ = obsfmt.read_observation_vcf(paths)
+    _same_batch(pb, b)
+    # omit mask (calling.rs:63-68)
+    r2, _ = ingest.read_observations(paths, omit_bias_mask=abi.BIAS_STRAND | abi.BIAS_HOMOPOLYMER)
+    assert not (r2.locus["locus_flags"] & (abi.BIAS_STRAND | abi.BIAS_HOMOPOLYMER)).any()
+
+
+def test_inconsistent_sample_files_are_refused(tmp_path):
+    cfg = synth.config3()
+    b = synth.generate(cfg, 50, seed=2)
+    p0, p1, p2 = (str(tmp_path / n) for n in ("a.bcf", "b.bcf", "c.bcf"))
+    ingest.write_observations(p0, b, 0)
+    ingest.write_observations(p1, b, 1)
+    ingest.write_observations(p2, b.select(np.arange(40)), 1)
+    ingest.read_observations([p0, p1])
+    with pytest.raises(Exception, match="inconsistent observations"):
+        ingest.read_observations([p0, p2])
+
+
+def _oracle_results(oracle, sc, batch, afd_capacity=64):
+    return oracle.call(sc, batch, afd_capacity=afd_capacity)
+
+
+def test_native_calls_writer_equals_python_formatter(oracle, golden_dir, tmp_path):
+    """Text VCF: byte-identical lines; BCF: the same records field by field (PROB_* to f32: the native writer stores the f32 of
+    the PHRED value like the reference's push_info_float, the Python writer goes through %g text)."""
+    d = os.path.join(golden_dir, "flamegraph_profiling")
+    sc = cli.scenario_from_yaml(os.path.join(d, "scenario.yaml"))
+    batch, sites = ingest.read_observations([os.path.join(d, "normal.vcf")], omit_bias_mask=abi.BIAS_ALL)
+    res = _oracle_results(oracle, sc, batch)
+    names = sc.out_names()
+    header = callsfmt.header(names, sc.sample_names, ["J02459"] if sites.chrom(0) == "J02459" else [sites.chrom(0)])
+    table = batch.extra["native_table"]
+    txt = str(tmp_path / "calls.vcf")
+    ingest.write_calls(txt, header, table, res, names)
+    want = [callsfmt.format_record(sites[l], batch, res, l, names, sc.sample_names) for l in range(batch.n_loci)]
+    got = [l for l in open(txt).read().split("\n") if l and not l.startswith("#")]
+    assert got == want
+    bcf = str(tmp_path / "calls.bcf")
+    ingest.write_calls(bcf, header, table, res, names)
+    recs = list(BcfReader(bcf))
+    assert len(recs) == batch.n_loci
+    for l, rec in enumerate(recs):
+        f = want[l].split("\t")
+        assert (rec["chrom"], rec["pos"], rec["ref"], rec["alt"]) == (f[0], int(f[1]), f[3], f[4])
+        info = dict(kv.split("=") for kv in f[7].split(";"))
+        assert list(rec["info"]) == list(info)  # same order: descending probability
+        for k, v in info.items():
+            assert rec["info"][k][0] == pytest.approx(float(v), rel=2e-6) or (np.isinf(float(v)) and np.isinf(rec["info"][k][0]))
+        keys = f[8].split(":")
+        vals = f[9].split(":")
+        for k, v in zip(keys, vals):
+            g = rec["format"][k][0]
+            if k in ("DP", "OOBS"):
+                assert g == [int(v)]
+            elif k == "AF":
+                assert g[0] == pytest.approx(float(v), rel=2e-6)
+            else:
+                assert g == v, k
+
+
+def test_native_calls_writer_reproduces_the_reference_calls_file(oracle, golden_dir, tmp_path):
+    """The reference's calls.vcf of the fixture (PROB_*, DP, AF, SAOBS, SROBS, OBS, AFD) from the natively written text."""
+    d = os.path.join(golden_dir, "flamegraph_profiling")
+    sc = cli.scenario_from_yaml(os.path.join(d, "scenario.yaml"))
+    batch, sites = ingest.read_observations([os.path.join(d, "normal.vcf")], omit_bias_mask=abi.BIAS_ALL)
+    res = _oracle_results(oracle, sc, batch, afd_capacity=128)
+    names = sc.out_names()
+    txt = str(tmp_path / "calls.vcf")
+    ingest.write_calls(txt, callsfmt.header(names, sc.sample_names, [sites.chrom(0)]), batch.extra["native_table"], res, names)
+    got = [l.split("\t") for l in open(txt).read().split("\n") if l and not l.startswith("#")]
+    ref = [l.split("\t") for l in open(os.path.join(d, "calls.vcf")).read().split("\n") if l and not l.startswith("#")]
+    assert len(got) == len(ref) == 11
+    for g, r in zip(got, ref):
+        assert g[:2] == r[:2] and g[3:5] == r[3:5]
+        gi = dict(kv.split("=") for kv in g[7].split(";"))
+        ri = dict(kv.split("=") for kv in r[7].split(";") if "=" in kv)
+        for k in ("PROB_ABSENT", "PROB_PRESENT"):
+            assert float(gi[k]) == pytest.approx(float(ri[k]), rel=2e-5, abs=1e-4)
+        gk, rk = g[8].split(":"), r[8].split(":")
+        gv, rv = dict(zip(gk, g[9].split(":"))), dict(zip(rk, r[9].split(":")))
+        import re
+        assert gv["DP"] == rv["DP"]
+        for k in ("SAOBS", "SROBS"):  # equal counts: Counter::most_common leaves their order open (utils/mod.rs:122-156)
+            assert sorted(re.findall(r"\d+\D", gv[k])) == sorted(re.findall(r"\d+\D", rv[k])), k
+        assert float(gv["AF"]) == pytest.approx(float(rv["AF"]), abs=1e-6)
+        gp = [(float(a), float(b)) for a, b in (kv.split("=") for kv in gv["AFD"].split(","))]
+        rp = [(float(a), float(b)) for a, b in (kv.split("=") for kv in rv["AFD"].split(","))]
+        assert [a for a, _ in gp] == [a for a, _ in rp]
+        assert max(abs(x[1] - y[1]) for x, y in zip(gp, rp)) <= 0.011
+
+
+def test_ingest_throughput_is_reported(tmp_path, capsys):
+    """Not a benchmark (8 cores here): the native reader must be far above the Python decoder's ~900 records/s."""
+    import time
+    cfg = synth.config3()
+    b = synth.generate(cfg, 4000, seed=5)
+    paths = []
+    for s in range(2):
+        p = str(tmp_path / ("t%d.bcf" % s))
+        ingest.write_observations(p, b, s)
+        paths.append(p)
+    t0 = time.perf_counter()
+    r, _ = ingest.read_observations(paths)
+    dt = time.perf_counter() - t0
+    assert r.n_loci == 4000
+    rate = r.n_loci / dt
+    print("native ingest: %.0f records/s (%d threads)" % (rate, os.cpu_count()))
+    assert rate > 5000

@@ -97,7 +97,7 @@ LAST_STATS = {}  # counters of the most recent main() run, for the tests: nothin
 
 def main(argv=None):
     argv = sys.argv if argv is None else argv
-    stats = {"generated": 0, "front_end_rejected": 0, "plans_rejected": 0, "run": 0, "mismatching": 0, "knife_edge_loci": 0, "flat_loci": 0}
+    stats = {"generated": 0, "front_end_rejected": 0, "plans_rejected": 0, "run": 0, "mismatching": 0, "knife_edge_loci": 0, "flat_loci": 0, "afd_bad_lists": 0, "afd_map_tie_loci": 0}
     LAST_STATS.clear()
     LAST_STATS.update(stats)
     n_sc = int(argv[1]) if len(argv) > 1 else 50
@@ -187,6 +187,13 @@ def main(argv=None):
             for l in range(b.n_loci):
                 if flat[l] and l in m["bad"]:
                     continue
+                # MAP on a near-tie: two visited points one rounding error apart (a bisection point and a tail point of the same
+                # chain) have joints that differ in the last bits, and the engine's product-of-mantissas likelihood may order them
+                # the other way round than the oracle's sum of logarithms.  The MAP VAFs then agree to 1e-6 (the parity bar) but
+                # not bit for bit, and the lists — "operand sets EQUAL to the MAP in all other samples" — are those of another chain.
+                if not np.array_equal(got.map_vaf[l], ref.map_vaf[l], equal_nan=True) and np.all(dv[l] <= 1e-9):
+                    LAST_STATS["afd_map_tie_loci"] += 1
+                    continue
                 for si in range(S):
                     ng, nr = int(got.afd_count[l, si]), int(ref.afd_count[l, si])
                     if ng != nr or ng > afd_cap:
@@ -200,6 +207,7 @@ def main(argv=None):
                         n_afd_bad += 1
                         if n_afd_bad <= 3:
                             print("  AFD list differs: locus %d sample %d" % (l, si))
+            LAST_STATS["afd_bad_lists"] += n_afd_bad
             if n_afd_bad:
                 ok = False
                 print("  AFD mismatches:", n_afd_bad)
@@ -220,6 +228,11 @@ def main(argv=None):
             if only >= 0:
                 np.set_printoptions(precision=6, linewidth=200)
                 print("out names", sc.out_names(), "univ events", sc.event_names)
+                for l in np.nonzero((got.map_bias != ref.map_bias).any(axis=1))[0][:4]:
+                    print(" bias differs at locus", l, "depth", b.depth()[l], "got", got.map_bias[l], "ref", ref.map_bias[l], "map", got.map_vaf[l], ref.map_vaf[l],
+                          "best", got.best_event[l], ref.best_event[l])
+                    print("  got post", got.ln_posterior[l])
+                    print("  ref post", ref.ln_posterior[l], "events", ref.event_ln_posterior[l])
                 for l in m["bad"][:4]:
                     print(" locus", l, "depth", b.depth()[l], "status got %x ref %x" % (got.status[l], ref.status[l]))
                     print("  got post", got.ln_posterior[l], "map", got.map_vaf[l], "bias", got.map_bias[l], "best", got.best_event[l])

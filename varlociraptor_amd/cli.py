@@ -83,12 +83,23 @@ def scenario_from_yaml(path: str, contig: str = "all") -> Scenario:
     return sc
 
 
+# model_mode of the reference (calling.rs:413-418): (check_read_orientation_bias, check_read_position_bias, check_softclip_bias,
+# check_homopolymer_artifact_detection).  check_strand_bias and the alt-locus check are NOT part of it: a precise indel and an
+# imprecise SV of one contig share a model, its `last_rid` and therefore the variant-specific prior of the contig's first record.
+MODEL_MODE_MASK = abi.BIAS_ORIENTATION | abi.BIAS_POSITION | abi.BIAS_SOFTCLIP | abi.BIAS_HOMOPOLYMER
+
+
+def model_modes(locus_flags):
+    import numpy as np
+    return (np.asarray(locus_flags) & MODEL_MODE_MASK).astype(int)
+
+
 def _scenario_signature(sc: Scenario):
     return tuple((n, s.universe, s.ploidy) for n, s in sc.samples.items()) + (sc.variant_heterozygosity_ln, sc.variant_somatic_effective_mutation_rate_ln)
 
 
 def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_capacity: int = 128, out=sys.stdout,
-                  device: int = 0, output: str = None):
+                  device: int = 0, output: str = None, ingest: str = None, timings: dict = None):
     """`scenario`: a Scenario, or a callable contig -> Scenario (contig-specific universes / ploidies: one plan per
     distinct resolution, as the reference re-configures its model on contig change, calling.rs:343-356)."""
     per_contig = scenario if callable(scenario) else (lambda contig: scenario)
@@ -126,14 +137,38 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
     if not callable(scenario):
         resolve("all")
         scen.clear()
-    batch, sites = obsfmt.read_observation_vcf(paths, omit_bias_mask=omit_mask)
-    from .batch import CallResults
     import numpy as np
-    # breakends of one event share a pileup and a result: evaluate the first record of every event only and copy its
-    # event probabilities / sample info to the others (calling.rs:569-580, 726-741, 820-839)
-    modes = (batch.locus["locus_flags"] & 0x3F).astype(int) if batch.n_loci else []
-    for l, (site, pri) in enumerate(zip(sites, batch.extra.get("prior_overrides") or [])):
-        first_of_contig.setdefault((site[0], int(modes[l])), pri)
+    import os
+    from .batch import CallResults
+    import time
+    native = (ingest or os.environ.get("VLR_INGEST", "native")) == "native"
+    t_begin = time.perf_counter()
+    if native:
+        # product path: BGZF inflate, BCF/VCF parse and the v15 decoder in native code (csrc/vlr_ingest.cpp)
+        from . import ingest as vingest
+        batch, sites = vingest.read_observations(paths, omit_bias_mask=omit_mask)
+        contig_names = list(sites.contig_names)
+        contig_of = np.asarray(sites.contig, np.int64)
+        het, som = batch.extra["prior_het_ln"], batch.extra["prior_som_ln"]
+        group_rep = np.asarray(batch.extra["group_representative"], np.int64)
+    else:
+        # the Python restatement of the same decoder (obsfmt.py / bcfio.py); the tests compare the two
+        batch, sites = obsfmt.read_observation_vcf(paths, omit_bias_mask=omit_mask)
+        contig_names = sorted(set(s_[0] for s_ in sites))
+        cidx = {c: i for i, c in enumerate(contig_names)}
+        contig_of = np.array([cidx[s_[0]] for s_ in sites], np.int64)
+        pri = batch.extra.get("prior_overrides") or []
+        het = np.array([np.nan if p_[0] is None else p_[0] for p_ in pri], np.float64)
+        som = np.array([np.nan if p_[1] is None else p_[1] for p_ in pri], np.float64)
+        reps_, source_ = obsfmt.haplotype_groups(batch.extra.get("haplotype") or [None] * batch.n_loci)
+        group_rep = np.asarray(reps_, np.int64)[np.asarray(source_, np.int64)] if batch.n_loci else np.zeros(0, np.int64)
+    L = batch.n_loci
+    t_read = time.perf_counter()
+    modes = model_modes(batch.locus["locus_flags"]) if L else np.zeros(0, np.int64)
+    key = contig_of * 256 + modes  # (contig, model mode): one model, one `last_rid`, one variant-specific prior (calling.rs:413-443)
+    for k_, first in zip(*np.unique(key, return_index=True)):
+        first_of_contig[(contig_names[int(k_) // 256] if contig_names else "all", int(k_) % 256)] = (
+            None if het[first] != het[first] else float(het[first]), None if som[first] != som[first] else float(som[first]))
     world, rank = 1, 0
     try:
         import torch.distributed as tdist
@@ -141,15 +176,21 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
             world, rank = tdist.get_world_size(), tdist.get_rank()
     except ImportError:
         pass
-    reps, source = obsfmt.haplotype_groups(batch.extra.get("haplotype") or [None] * batch.n_loci)
-    groups: Dict[tuple, List[int]] = {}
-    for l in reps:
-        sc = resolve(sites[l][0], int(modes[l]))
-        groups.setdefault(_scenario_signature(sc), []).append(l)
+    # breakends of one event share a pileup and a result: evaluate the first record of every event only and copy its
+    # event probabilities / sample info to the others (calling.rs:569-580, 726-741, 820-839)
+    reps = np.nonzero(group_rep == np.arange(L))[0]
+    groups: Dict[tuple, List] = {}
+    sig_scenario: Dict[tuple, Scenario] = {}
+    for k_ in np.unique(key[reps]) if len(reps) else []:
+        sc = resolve(contig_names[int(k_) // 256] if contig_names else "all", int(k_) % 256)
+        sig = _scenario_signature(sc)
+        sig_scenario.setdefault(sig, sc)
+        groups.setdefault(sig, []).append(reps[key[reps] == k_])
     res = None
     names = None
-    for sig, loci in groups.items():
-        sc = resolve(sites[loci[0]][0], int(modes[loci[0]]))
+    for sig, parts in groups.items():
+        loci = np.sort(np.concatenate(parts))
+        sc = sig_scenario[sig]
         if world > 1:
             # loci shard across the ranks (one process per GPU); the results are reassembled by one all-gather of
             # fixed-size records (+ one for the AFD lists), every rank ends up with the full result
@@ -157,7 +198,7 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
             lo, hi = vdist.shard_range(len(loci), rank, world)
             mine = loci[lo:hi]
             n_out_, S_ = sc.n_out, len(sc.sample_names)
-            if mine:
+            if len(mine):
                 plan = engine.Plan(sc, device=device)
                 sub = batch.select(mine)
                 plan.set_max_obs(min(max(int(sub.depth().sum(axis=1).max()), 1), engine.MAX_OBS_LDS))
@@ -168,7 +209,7 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
             r = vdist.gather_call_results(rl, lo, hi, len(loci), n_out_, S_, afd_capacity)
         else:
             plan = engine.Plan(sc, device=device)
-            sub = batch if len(loci) == batch.n_loci else batch.select(loci)
+            sub = batch if len(loci) == L else batch.select(loci)
             # observation files are already capped by preprocess's --max-depth: size the LDS budget to the deepest record
             deepest = int(sub.depth().sum(axis=1).max()) if sub.n_loci else 1
             plan.set_max_obs(min(max(deepest, 1), engine.MAX_OBS_LDS))  # deeper records come back flagged VLR_LOCUS_TOO_DEEP
@@ -176,22 +217,20 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
             plan.close()
         if names is None:
             names = sc.out_names()
-        if len(loci) == batch.n_loci:
+        if len(loci) == L:
             res = r
             break
         if res is None:
-            res = CallResults(batch.n_loci, r.n_out, r.n_samples, afd_capacity)
-        idx = np.asarray(loci)
+            res = CallResults(L, r.n_out, r.n_samples, afd_capacity)
         for f in ("ln_posterior", "ln_marginal", "map_vaf", "map_bias", "best_event", "status", "afd_count", "afd_vaf", "afd_lnprob"):
             a = getattr(res, f)
             if a is not None:
-                a[idx] = getattr(r, f)
-    if res is not None and len(reps) < batch.n_loci:  # fan the group results out to every record of the group
-        src = np.asarray([reps[i] for i in source])
+                a[loci] = getattr(r, f)
+    if res is not None and len(reps) < L:  # fan the group results out to every record of the group
         for f in ("ln_posterior", "ln_marginal", "map_vaf", "map_bias", "best_event", "status", "afd_count", "afd_vaf", "afd_lnprob"):
             a = getattr(res, f)
             if a is not None:
-                a[:] = a[src]
+                a[:] = a[group_rep]
     if res is not None and rank == 0:
         # the reference panics on NaN (assert!(!p.is_nan())) and has no depth limit: say so instead of writing `.` silently
         hard = res.status & (abi.LOCUS_NAN | abi.LOCUS_UNDERFLOW | abi.LOCUS_TABLE_FULL | abi.LOCUS_TOO_DEEP)
@@ -200,23 +239,47 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
             n_bad = int(((hard & bit) != 0).sum())
             if n_bad:
                 print("warning: %d record(s) without a result: %s" % (n_bad, what), file=sys.stderr)
-    scenario0 = resolve(sites[0][0] if sites else "all")
-    header = callsfmt.header(names or scenario0.out_names(), scenario0.sample_names, sorted(set(s[0] for s in sites)))
+    t_call = time.perf_counter()
+
+    def _done():
+        if timings is not None:
+            t_end = time.perf_counter()
+            timings.update({"read_s": t_read - t_begin, "call_s": t_call - t_read, "write_s": t_end - t_call, "n_loci": L, "n_obs": batch.n_obs})
+    scenario0 = resolve(contig_names[int(contig_of[0])] if L else "all")
+    header = callsfmt.header(names or scenario0.out_names(), scenario0.sample_names, sorted(set(contig_names[int(c_)] for c_ in np.unique(contig_of))) if L else [])
     if rank != 0:
+        return res
+    names = names or scenario0.out_names()
+    if native and res is not None:
+        # the calls file from native code too (vlr_calls_write): BCF2 in BGZF blocks or text VCF
+        from . import ingest as vingest
+        table = batch.extra["native_table"]
+        if output:
+            vingest.write_calls(output, header, table, res, list(names))
+        else:
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                tmp = os.path.join(td, "calls.vcf")
+                vingest.write_calls(tmp, header, table, res, list(names))
+                with open(tmp) as fh:
+                    out.write(fh.read())
+        _done()
         return res
     if output and output.endswith(".bcf"):  # binary calls file (reference: bcf::Writer, calling.rs:296-304)
         from .bcfio import BcfWriter
         with BcfWriter(output, header) as wr:
-            for l, site in enumerate(sites):
-                wr.write_line(callsfmt.format_record(site, batch, res, l, names, scenario0.sample_names))
+            for l in range(L):
+                wr.write_line(callsfmt.format_record(sites[l], batch, res, l, names, scenario0.sample_names))
+        _done()
         return res
     if output:
         out = open(output, "w")
     print(header, file=out)
-    for l, site in enumerate(sites):
-        print(callsfmt.format_record(site, batch, res, l, names, scenario0.sample_names), file=out)
+    for l in range(L):
+        print(callsfmt.format_record(sites[l], batch, res, l, names, scenario0.sample_names), file=out)
     if output:
         out.close()
+    _done()
     return res
 
 

@@ -133,6 +133,10 @@ __global__ void __launch_bounds__(1024) fdr_search(const double* pep_ln, const d
     if (i == 0) *fdr0 = f;
     const bool ok = f <= alpha_ln && (i == 0 || pep_ln[i] != pep_ln[i - 1]);
     if (ok) atomicMax((unsigned long long*)best, (unsigned long long)(i + 1));  // 0 = none
+    // The prefix sums are linear here and log-space (sequential ln_add_exp) in the reference: an expected FDR within rounding
+    // of alpha could land on the other side of the comparison.  Such entries are reported; the host then repeats the search
+    // with the reference's own accumulation (vlr_fdr_threshold), so the decision never depends on the summation order.
+    if (fabs(f - alpha_ln) <= 1e-9 * fmax(1.0, fabs(alpha_ln))) best[2] = 1;
 }
 
 }  // namespace vlr

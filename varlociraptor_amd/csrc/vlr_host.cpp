@@ -257,6 +257,8 @@ struct vlr_plan {
     void* stage[2] = {nullptr, nullptr};
     size_t stage_bytes[2] = {0, 0};
     hipStream_t stage_stream[2] = {nullptr, nullptr};
+    hipStream_t afd_aux_stream = nullptr;   // second lane of the AFD sub-ranges (vlr_batch_run)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     unsigned long long* work_dev = nullptr;
     // AFD replay scratch (device), one per slot: is_discrete mask of the MAP, and marginal/best_event when the caller passes NULL
     void* afd_scratch[2] = {nullptr, nullptr};
@@ -268,6 +270,9 @@ struct vlr_plan {
     void* afd_log[2] = {nullptr, nullptr};
     size_t afd_log_bytes[2] = {0, 0};
     size_t afd_log_words = 0;
+    void* afd_keys[2] = {nullptr, nullptr};   // l2fc-list keys of the AFD entries (DevResults::afd_key), one per slot
+    size_t afd_keys_bytes[2] = {0, 0};
+    int64_t afd_log_loci[2] = {0, 0};  // loci whose log regions fit afd_log[slot] (the budget of ensure_buffers)
     int slot = 0;  // slot used by the next vlr_batch_run (set by vlr_batch_run_host)
 };
 
@@ -400,6 +405,7 @@ int vlr_abi_version(void) { return VLR_ABI_VERSION; }
 #endif
 const char* vlr_build_id(void) { return VLR_SRC_ID; }
 const char* vlr_last_error(void) { return g_err.c_str(); }
+void vlr_set_error(const char* msg) { g_err = msg ? msg : ""; }  // for the other translation units of the library (vlr_ingest.cpp)
 
 int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
     using namespace vlr;
@@ -791,9 +797,13 @@ void vlr_plan_destroy(vlr_plan* plan) {
         if (plan->afd_scratch[k]) (void)hipFree(plan->afd_scratch[k]);
         if (plan->escratch[k]) (void)hipFree(plan->escratch[k]);
         if (plan->afd_log[k]) (void)hipFree(plan->afd_log[k]);
+        if (plan->afd_keys[k]) (void)hipFree(plan->afd_keys[k]);
         if (plan->stage_stream[k]) (void)hipStreamDestroy(plan->stage_stream[k]);
     }
     if (plan->work_dev) (void)hipFree(plan->work_dev);
+    if (plan->afd_aux_stream) (void)hipStreamDestroy(plan->afd_aux_stream);
+    if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
+    if (plan->ev_join) (void)hipEventDestroy(plan->ev_join);
     if (plan->ev_start) (void)hipEventDestroy(plan->ev_start);
     if (plan->ev_stop) (void)hipEventDestroy(plan->ev_stop);
     delete plan;
@@ -824,7 +834,7 @@ int vlr_plan_set_max_obs(vlr_plan* plan, int max_obs_per_locus) {
 // Device buffers a batch of n_loci needs besides the caller's: kernel scratch (third coefficients), and with AFD the replay
 // scratch and the AFD log.  Grown here (hipMalloc/hipFree synchronise the device); vlr_batch_run calls this itself, callers that
 // need a strictly asynchronous vlr_batch_run size the plan once with vlr_plan_reserve.
-static int ensure_buffers(vlr_plan* plan, int64_t n_loci, int max_obs, bool want_afd, bool want_log) {
+static int ensure_buffers(vlr_plan* plan, int64_t n_loci, int max_obs, bool want_afd, bool want_log, int afd_capacity) {
     const int k = plan->slot & 1;
     const size_t L = (size_t)n_loci;
     auto grow = [&](void** buf, size_t* have, size_t need, bool optional) -> int {
@@ -848,8 +858,22 @@ static int ensure_buffers(vlr_plan* plan, int64_t n_loci, int max_obs, bool want
             size_t words = 1 + (size_t)36 * (1 + plan->host.S + 2 * (size_t)plan->host.table_cap);
             words = std::min<size_t>((words + 63) & ~(size_t)63, (size_t)1 << 15);
             plan->afd_log_words = words;
-            (void)grow(&plan->afd_log[k], &plan->afd_log_bytes[k], L * words * sizeof(double), true);  // no room: replay alone
+            // budget (default 4 GiB, VLR_AFD_LOG_BUDGET_MB): a 1 M-locus tumor-normal batch would otherwise ask for 38 GB of
+            // log; vlr_batch_run walks the batch in sub-ranges of afd_log_loci loci that share the buffer
+            size_t budget = (size_t)4 << 30;
+            if (const char* ev = getenv("VLR_AFD_LOG_BUDGET_MB")) budget = (size_t)std::max(1L, atol(ev)) << 20;
+            size_t loci = std::max<size_t>(std::min<size_t>(L, budget / (words * sizeof(double))), std::min<size_t>(L, 4096));
+            if (plan->afd_log_loci[k] > 0 && plan->afd_log[k] && (size_t)plan->afd_log_loci[k] * words * sizeof(double) <= plan->afd_log_bytes[k])
+                loci = std::max<size_t>(loci, std::min<size_t>(L, (size_t)plan->afd_log_loci[k]));
+            (void)grow(&plan->afd_log[k], &plan->afd_log_bytes[k], loci * words * sizeof(double), true);  // no room: replay alone
+            plan->afd_log_loci[k] = plan->afd_log[k] ? (int64_t)(plan->afd_log_bytes[k] / (words * sizeof(double))) : 0;
+        } else {
+            plan->afd_log_loci[k] = 0;
         }
+        // one 8-byte key per AFD entry of a sub-range (vlr_batch_run walks the batch in steps of afd_log_loci loci)
+        const size_t step = plan->afd_log_loci[k] > 0 ? std::min<size_t>(L, (size_t)plan->afd_log_loci[k]) : L;  // both lanes
+        rc = grow(&plan->afd_keys[k], &plan->afd_keys_bytes[k], step * (size_t)plan->host.S * (size_t)std::max(afd_capacity, 1) * sizeof(long long), false);
+        if (rc != VLR_OK) return rc;
     }
     return VLR_OK;
 }
@@ -859,7 +883,15 @@ int vlr_plan_reserve(vlr_plan* plan, int64_t n_loci, int with_afd) {
     HIP_TRY(hipSetDevice(plan->device));
     int max_obs = plan->max_obs > 0 ? plan->max_obs : plan->max_depth_per_sample * plan->host.S;
     max_obs = (max_obs + 3) & ~3;
-    return ensure_buffers(plan, n_loci, max_obs, with_afd != 0, with_afd != 0 && !getenv("VLR_AFD_REPLAY"));
+    // both staging slots (vlr_batch_run_host alternates between them)
+    const int slot0 = plan->slot;
+    int rc = VLR_OK;
+    for (int k = 0; k < 2 && rc == VLR_OK; ++k) {
+        plan->slot = slot0 ^ k;
+        rc = ensure_buffers(plan, n_loci, max_obs, with_afd != 0, with_afd != 0 && !getenv("VLR_AFD_REPLAY"), with_afd);
+    }
+    plan->slot = slot0;
+    return rc;
 }
 
 int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* stream) {
@@ -892,7 +924,7 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
     int max_obs = plan->max_obs > 0 ? plan->max_obs : plan->max_depth_per_sample * plan->host.S;
     max_obs = (max_obs + 3) & ~3;
     {
-        const int rc0 = ensure_buffers(plan, in->n_loci, max_obs, want_afd, want_afd && !getenv("VLR_AFD_REPLAY"));
+        const int rc0 = ensure_buffers(plan, in->n_loci, max_obs, want_afd, want_afd && !getenv("VLR_AFD_REPLAY"), want_afd ? out->afd_capacity : 0);
         if (rc0 != VLR_OK) return rc0;
     }
     if (want_afd) {
@@ -905,6 +937,7 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
         r.map_disc = (uint8_t*)(sc + 12 * L);
         if (!r.map_bias) return fail(VLR_ERR_INVALID_ARGUMENT, "AFD needs map_bias");
         r.afd_count = out->afd_count; r.afd_vaf = out->afd_vaf; r.afd_lnprob = out->afd_lnprob; r.afd_capacity = out->afd_capacity;
+        r.afd_key = (long long*)plan->afd_keys[k];
     }
     r.escratch = (double*)plan->escratch[plan->slot & 1];
     if (want_afd && !getenv("VLR_AFD_REPLAY") && plan->afd_log[plan->slot & 1]) {
@@ -913,18 +946,62 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
     }
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipEventRecord(plan->ev_start, st));
-    int rc = vlr_launch_call_kernel(&plan->host, &b, &r, plan->host.n_univ, plan->host.S, max_obs, plan->host.max_range_depth, stream);
-    if (rc != 0) return fail(VLR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-    if (!want_afd) HIP_TRY(hipEventRecord(plan->ev_stop, st));
-    if (want_afd) {  // FORMAT/AFD (calling.rs:889-928): from the log of the call pass; replay of the clean events where the log overflowed
+    if (!want_afd) {
+        int rc = vlr_launch_call_kernel(&plan->host, &b, &r, plan->host.n_univ, plan->host.S, max_obs, plan->host.max_range_depth, stream);
+        if (rc != 0) return fail(VLR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        HIP_TRY(hipEventRecord(plan->ev_stop, st));
+    } else {
+        // FORMAT/AFD (calling.rs:889-928): from the log of the call pass; replay of the clean events where the log overflowed.
+        // The log region of a locus is sized for the worst case (tens of kB), so the batch is walked in sub-ranges of loci whose
+        // logs fit the plan's budget (afd_log_loci, ensure_buffers) and reuse one buffer: call pass, log filter and replay of a
+        // sub-range are stream-ordered one behind the other.
         HIP_TRY(hipMemsetAsync(out->afd_count, 0, (size_t)in->n_loci * plan->host.S * sizeof(int32_t), st));
-        if (r.afd_log) {
-            rc = vlr_launch_afd_kernel(&plan->host, &b, &r, stream);
-            if (rc != 0) return fail(VLR_ERR_HIP, "AFD kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        const int S = plan->host.S, n_out = out->n_out;
+        const int64_t cap = (r.afd_log && plan->afd_log_loci[plan->slot & 1] > 0) ? plan->afd_log_loci[plan->slot & 1] : in->n_loci;
+        // one sub-range when everything fits; otherwise two lanes (the caller's stream and a plan-owned one, each with half of the
+        // log) so that the long tail of one sub-range — a few nested loci cost ten times the average — overlaps the next
+        const bool two = in->n_loci > cap && cap >= 2;
+        const int64_t step = two ? cap / 2 : std::max<int64_t>(cap, 1);
+        if (two) {
+            if (!plan->afd_aux_stream) {
+                HIP_TRY(hipStreamCreateWithFlags(&plan->afd_aux_stream, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&plan->ev_join, hipEventDisableTiming));
+            }
+            HIP_TRY(hipEventRecord(plan->ev_fork, st));
+            HIP_TRY(hipStreamWaitEvent(plan->afd_aux_stream, plan->ev_fork, 0));
         }
-        r.replay = 1;
-        rc = vlr_launch_call_kernel(&plan->host, &b, &r, plan->host.n_univ, plan->host.S, max_obs, plan->host.max_range_depth, stream);
-        if (rc != 0) return fail(VLR_ERR_HIP, "AFD replay launch failed: %s", hipGetErrorString((hipError_t)rc));
+        int64_t k = 0;
+        for (int64_t l0 = 0; l0 < in->n_loci; l0 += step, ++k) {
+            const int lane = two ? (int)(k & 1) : 0;
+            void* ss = lane ? (void*)plan->afd_aux_stream : stream;
+            DevBatch bs = b;
+            DevResults rs = r;
+            bs.n_loci = std::min<int64_t>(step, in->n_loci - l0);
+            bs.obs_offset += l0 * S;
+            bs.locus_flags += l0;
+            if (bs.variant_type) bs.variant_type += l0;
+            if (bs.ref_base) bs.ref_base += l0;
+            if (bs.alt_base) bs.alt_base += l0;
+            rs.ln_posterior += l0 * n_out; rs.ln_marginal += l0; rs.map_vaf += l0 * S; rs.map_bias += l0 * 6; rs.best_event += l0;
+            rs.status += l0; rs.map_disc += l0; rs.escratch += (size_t)l0 * max_obs;
+            rs.afd_count += l0 * S; rs.afd_vaf += (size_t)l0 * S * r.afd_capacity; rs.afd_lnprob += (size_t)l0 * S * r.afd_capacity;
+            if (rs.afd_log) rs.afd_log += (size_t)lane * (size_t)step * (size_t)r.afd_log_stride;
+            rs.afd_key += (size_t)lane * (size_t)step * (size_t)S * (size_t)r.afd_capacity;
+            int rc = vlr_launch_call_kernel(&plan->host, &bs, &rs, plan->host.n_univ, S, max_obs, plan->host.max_range_depth, ss);
+            if (rc != 0) return fail(VLR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+            if (rs.afd_log) {
+                rc = vlr_launch_afd_kernel(&plan->host, &bs, &rs, ss);
+                if (rc != 0) return fail(VLR_ERR_HIP, "AFD kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+            }
+            rs.replay = 1;
+            rc = vlr_launch_call_kernel(&plan->host, &bs, &rs, plan->host.n_univ, S, max_obs, plan->host.max_range_depth, ss);
+            if (rc != 0) return fail(VLR_ERR_HIP, "AFD replay launch failed: %s", hipGetErrorString((hipError_t)rc));
+        }
+        if (two) {
+            HIP_TRY(hipEventRecord(plan->ev_join, plan->afd_aux_stream));
+            HIP_TRY(hipStreamWaitEvent(st, plan->ev_join, 0));
+        }
         HIP_TRY(hipEventRecord(plan->ev_stop, st));
     }
     plan->timed = true;
@@ -1266,13 +1343,49 @@ int vlr_edit_distance_batch_host(int device, const vlr_realign_batch_desc* b, in
 // ---- Bayesian FDR threshold (vlr_fdr.hip)
 extern "C" int vlr_launch_fdr(double* keys, long long n, long long npad, int smart, double alpha_ln, double* work, long long* best, double* fdr0, void* stream);
 
+// The reference's accumulation (bio expected_fdr: ln_cumsum_exp = running ln_add_exp, minus ln rank, capped at ln 1) and its boundary
+// search (fdr.rs:118-141) over the device-sorted arrays; only used when an expected FDR sits within rounding of alpha.
+static void fdr_search_reference_order(const double* prob, int64_t n, double alpha_ln, double* threshold, int* status) {
+    const double ninf = -std::numeric_limits<double>::infinity();
+    // the PEPs with the host's libm as well (LogProb::ln_one_minus_exp): the device's log1p/exp may differ in the last bit
+    std::vector<double> pep_ln((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        const double q = prob[i];
+        pep_ln[(size_t)i] = q >= 0.0 ? ninf : (q < -0.693 ? std::log1p(-std::exp(q)) : std::log(-std::expm1(q)));
+    }
+    double acc = ninf;
+    int64_t best = -1;
+    double f0 = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double p = pep_ln[(size_t)i];
+        const double hi = acc > p ? acc : p, lo = acc > p ? p : acc;
+        acc = (hi == ninf) ? ninf : (lo == ninf ? hi : hi + std::log1p(std::exp(lo - hi)));   // LogProb::ln_add_exp
+        double f = acc - std::log((double)(i + 1));
+        f = f > 0.0 ? 0.0 : f;
+        if (i == 0) f0 = f;
+        if (f <= alpha_ln && (i == 0 || pep_ln[i] != pep_ln[i - 1])) best = i;
+    }
+    if (f0 > alpha_ln) { *status = VLR_FDR_LN_ONE; *threshold = 0.0; }
+    else if (best < 0) { *status = VLR_FDR_NONE; *threshold = 0.0; }
+    else { *status = VLR_FDR_VALUE; *threshold = prob[best]; }
+}
+
 int vlr_fdr_threshold(int device, const double* ln_prob, int64_t n, int smart, double alpha_ln, double* threshold, int* status) {
     if (n < 0 || (n > 0 && !ln_prob) || !threshold || !status) return fail(VLR_ERR_INVALID_ARGUMENT, "null argument");
     *threshold = 0.0;
     *status = VLR_FDR_EMPTY;
     if (n == 0) return VLR_OK;
-    for (int64_t i = 0; i < n; ++i)
-        if (ln_prob[i] != ln_prob[i] || ln_prob[i] > 0.0) return fail(VLR_ERR_INVALID_ARGUMENT, "ln_prob[%lld] is not a log probability", (long long)i);
+    // LogProb sums of PHRED-rounded probabilities overshoot ln 1 by rounding: capped like cap_numerical_overshoot(NUMERICAL_EPSILON)
+    // (utils/mod.rs:40, 207-209) instead of being refused; anything larger is not a log probability.
+    std::vector<double> capped;
+    for (int64_t i = 0; i < n; ++i) {
+        if (ln_prob[i] != ln_prob[i] || ln_prob[i] > 1e-3) return fail(VLR_ERR_INVALID_ARGUMENT, "ln_prob[%lld] is not a log probability", (long long)i);
+        if (ln_prob[i] > 0.0 && capped.empty()) capped.assign(ln_prob, ln_prob + n);
+    }
+    if (!capped.empty()) {
+        for (auto& v : capped) v = v > 0.0 ? 0.0 : v;
+        ln_prob = capped.data();
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) return fail(VLR_ERR_NO_DEVICE, "no HIP device %d (the engine has no CPU path)", device);
     HIP_TRY(hipSetDevice(device));
@@ -1287,24 +1400,30 @@ int vlr_fdr_threshold(int device, const double* ln_prob, int64_t n, int smart, d
         std::vector<double> pad((size_t)(npad - n), -std::numeric_limits<double>::infinity());
         double* keys = d;
         double* work = d + npad;
-        long long* best = (long long*)(work + 3 * (size_t)n + nb);
+        long long* best = (long long*)(work + 3 * (size_t)n + nb);   // [0] boundary index + 1, [1] expected FDR of entry 0 (double), [2] near-alpha flag
         double* fdr0 = (double*)(best + 1);
-        long long zero = 0;
+        long long zero[3] = {0, 0, 0};
         if (hipMemcpy(keys, ln_prob, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess ||
             (npad > n && hipMemcpy(keys + n, pad.data(), pad.size() * 8, hipMemcpyHostToDevice) != hipSuccess) ||
-            hipMemcpy(best, &zero, 8, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(VLR_ERR_HIP, "staging copy failed"); break; }
+            hipMemcpy(best, zero, 24, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(VLR_ERR_HIP, "staging copy failed"); break; }
         hipError_t e = (hipError_t)vlr_launch_fdr(keys, (long long)n, npad, smart ? 1 : 0, alpha_ln, work, best, fdr0, nullptr);
         if (e != hipSuccess) { rc = fail(VLR_ERR_HIP, "fdr kernels: %s", hipGetErrorString(e)); break; }
-        long long b = 0;
-        double f0 = 0.0;
-        if (hipMemcpy(&b, best, 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&f0, fdr0, 8, hipMemcpyDeviceToHost) != hipSuccess) {
-            rc = fail(VLR_ERR_HIP, "result copy failed"); break;
+        long long b[3] = {0, 0, 0};
+        if (hipMemcpy(b, best, 24, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(VLR_ERR_HIP, "result copy failed"); break; }
+        double f0;
+        std::memcpy(&f0, &b[1], 8);
+        if (b[2] != 0) {
+            // an expected FDR within rounding of alpha: decide with the reference's accumulation order (ties at alpha)
+            std::vector<double> host((size_t)n);
+            if (hipMemcpy(host.data(), work, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(VLR_ERR_HIP, "result copy failed"); break; }
+            fdr_search_reference_order(host.data(), n, alpha_ln, threshold, status);
+            break;
         }
         if (f0 > alpha_ln) { *status = VLR_FDR_LN_ONE; *threshold = 0.0; }       // fdr.rs:127-128
-        else if (b == 0) { *status = VLR_FDR_NONE; }
+        else if (b[0] == 0) { *status = VLR_FDR_NONE; }
         else {
             double pv = 0.0;
-            if (hipMemcpy(&pv, work + (b - 1), 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(VLR_ERR_HIP, "result copy failed"); break; }
+            if (hipMemcpy(&pv, work + (b[0] - 1), 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(VLR_ERR_HIP, "result copy failed"); break; }
             *status = VLR_FDR_VALUE; *threshold = pv;
         }
     } while (0);

@@ -1,0 +1,1474 @@
+// vlr_ingest.cpp — the process boundary of `call variants` in native code:
+//   observation files in  (BCF2 in BGZF blocks, or text VCF)  ->  the SoA columns of vlr_batch, page-locked
+//   calls file out        (results + observations -> BCF2 / text VCF records)
+// What it replaces in the reference (file:line under /root/reference/src):
+//   calling/variants/calling.rs:306-318, 324-339   bcf::Reader over the observation files, format-version check
+//   calling/variants/preprocessing/mod.rs:818-919  read_observations: INFO integer vectors -> bincode -> ReadObservation
+//   utils/mod.rs:449-474                           MiniLogProb {F16, F32}
+//   calling/variants/calling.rs:517-598            WorkItem.check_* flags, is_snv_or_mnv, remove_nonstandard_alignments
+//   variants/model/mod.rs:87-133                   HaplotypeIdentifier (EVENT / MATEID pairs)
+//   calling/variants/mod.rs:178-600                Call::write_final_record (PROB_*, DP, AF, SAOBS/SROBS/OBS, bias symbols, AFD)
+//   calling/variants/preprocessing/mod.rs:921-1038 write_observations (used here by the synthetic-workload writer of bench.py and
+//                                                  by the round-trip tests; the BAM side of `preprocess` is out of scope)
+// No htslib: BGZF members are located through their BSIZE fields and inflated in parallel with zlib, BCF records are decoded in
+// place, every stage runs on a pool of std::threads over contiguous record ranges.  Pure host code; the only device-related call
+// is vlr_host_alloc (page-locked result arrays so that vlr_batch_run_host copies them by direct DMA).
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <limits>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/vlr.h"
+
+extern "C" void vlr_set_error(const char* msg);  // vlr_host.cpp: the text behind vlr_last_error()
+
+namespace {
+
+int ifail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    vlr_set_error(buf);
+    return code;
+}
+
+// ------------------------------------------------------------------------------------------------ threads
+int pick_threads(int n) {
+    if (n > 0) return n;
+    unsigned h = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(h ? h : 1u, 128u));
+}
+// fn(begin, end, worker) over [0, n) in contiguous ranges
+template <typename F>
+void parallel_ranges(int64_t n, int n_threads, F&& fn) {
+    if (n <= 0) return;
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, n));
+    if (T == 1) { fn((int64_t)0, n, 0); return; }
+    std::vector<std::thread> th;
+    th.reserve(T);
+    for (int t = 0; t < T; ++t) {
+        const int64_t b = n * t / T, e = n * (t + 1) / T;
+        th.emplace_back([&fn, b, e, t] { fn(b, e, t); });
+    }
+    for (auto& x : th) x.join();
+}
+// dynamic work items (blocks of very different cost)
+template <typename F>
+void parallel_items(int64_t n, int n_threads, F&& fn) {
+    if (n <= 0) return;
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, n));
+    std::atomic<int64_t> next{0};
+    auto body = [&](int t) {
+        for (;;) {
+            const int64_t i = next.fetch_add(1);
+            if (i >= n) break;
+            fn(i, t);
+        }
+    };
+    if (T == 1) { body(0); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back(body, t);
+    for (auto& x : th) x.join();
+}
+
+// ------------------------------------------------------------------------------------------------ files, BGZF
+bool read_whole_file(const char* path, std::vector<uint8_t>& out, std::string& err) {
+    FILE* f = fopen(path, "rb");
+    if (!f) { err = std::string("cannot open ") + path; return false; }
+    fseek(f, 0, SEEK_END);
+    const long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    out.resize((size_t)std::max(0L, n));
+    const size_t got = n > 0 ? fread(out.data(), 1, (size_t)n, f) : 0;
+    fclose(f);
+    if (got != (size_t)std::max(0L, n)) { err = std::string("short read on ") + path; return false; }
+    return true;
+}
+
+struct BgzfBlock { size_t off, clen; uint32_t isize; size_t out_off; };
+
+// all gzip members carry the BGZF extra field `BC` with their total size: index them without inflating
+bool bgzf_index(const std::vector<uint8_t>& raw, std::vector<BgzfBlock>& blocks) {
+    size_t p = 0;
+    size_t total = 0;
+    while (p < raw.size()) {
+        if (p + 18 > raw.size() || raw[p] != 0x1f || raw[p + 1] != 0x8b || raw[p + 2] != 8 || !(raw[p + 3] & 4)) return false;
+        const unsigned xlen = raw[p + 10] | (raw[p + 11] << 8);
+        size_t q = p + 12;
+        const size_t xend = q + xlen;
+        if (xend > raw.size()) return false;
+        long bsize = -1;
+        while (q + 4 <= xend) {
+            const unsigned slen = raw[q + 2] | (raw[q + 3] << 8);
+            if (raw[q] == 'B' && raw[q + 1] == 'C' && slen == 2 && q + 6 <= xend) bsize = (raw[q + 4] | (raw[q + 5] << 8)) + 1;
+            q += 4 + slen;
+        }
+        if (bsize < 0 || p + (size_t)bsize > raw.size() || (size_t)bsize < xlen + 20) return false;
+        const size_t cdata = xend, cend = p + (size_t)bsize - 8;
+        const uint32_t isize = raw[cend + 4] | (raw[cend + 5] << 8) | (raw[cend + 6] << 16) | ((uint32_t)raw[cend + 7] << 24);
+        blocks.push_back({cdata, cend - cdata, isize, total});
+        total += isize;
+        p += (size_t)bsize;
+    }
+    return true;
+}
+
+bool inflate_raw(const uint8_t* src, size_t clen, uint8_t* dst, size_t dlen) {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = const_cast<Bytef*>(src); zs.avail_in = (uInt)clen;
+    zs.next_out = dst; zs.avail_out = (uInt)dlen;
+    const int rc = inflate(&zs, Z_FINISH);
+    const bool ok = (rc == Z_STREAM_END) && zs.total_out == dlen;
+    inflateEnd(&zs);
+    return ok;
+}
+
+// file contents, decompressed: BGZF (parallel), plain gzip (sequential), or as is
+bool load_inflated(const char* path, std::vector<uint8_t>& out, int n_threads, std::string& err) {
+    std::vector<uint8_t> raw;
+    if (!read_whole_file(path, raw, err)) return false;
+    if (raw.size() < 2 || raw[0] != 0x1f || raw[1] != 0x8b) { out.swap(raw); return true; }
+    std::vector<BgzfBlock> blocks;
+    if (bgzf_index(raw, blocks)) {
+        size_t total = 0;
+        for (auto& b : blocks) total += b.isize;
+        out.resize(total);
+        std::atomic<bool> bad{false};
+        parallel_items((int64_t)blocks.size(), n_threads, [&](int64_t i, int) {
+            const BgzfBlock& b = blocks[(size_t)i];
+            if (b.isize == 0) return;
+            if (!inflate_raw(raw.data() + b.off, b.clen, out.data() + b.out_off, b.isize)) bad = true;
+        });
+        if (bad) { err = std::string("corrupt BGZF block in ") + path; return false; }
+        return true;
+    }
+    // generic (multi-member) gzip
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, 15 + 32) != Z_OK) { err = "zlib init failed"; return false; }
+    zs.next_in = raw.data(); zs.avail_in = (uInt)std::min<size_t>(raw.size(), 0x7fffffff);
+    out.resize(std::max<size_t>(raw.size() * 4, 1 << 16));
+    size_t have = 0;
+    for (;;) {
+        if (have == out.size()) out.resize(out.size() * 2);
+        zs.next_out = out.data() + have; zs.avail_out = (uInt)std::min<size_t>(out.size() - have, 0x7fffffff);
+        const int rc = inflate(&zs, Z_NO_FLUSH);
+        have = (size_t)(zs.next_out - out.data());
+        if (rc == Z_STREAM_END) {
+            if (zs.avail_in == 0) break;
+            if (inflateReset(&zs) != Z_OK) { inflateEnd(&zs); err = "zlib reset failed"; return false; }
+            continue;
+        }
+        if (rc != Z_OK) { inflateEnd(&zs); err = std::string("corrupt gzip stream in ") + path; return false; }
+    }
+    inflateEnd(&zs);
+    out.resize(have);
+    return true;
+}
+
+// one BGZF member holding `n` bytes (n <= 0xff00)
+void bgzf_deflate_block(const uint8_t* data, size_t n, int level, std::vector<uint8_t>& out) {
+    uLong bound = compressBound((uLong)n) + 64;
+    const size_t at = out.size();
+    out.resize(at + 18 + bound + 8);
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+    zs.next_in = const_cast<Bytef*>(data); zs.avail_in = (uInt)n;
+    zs.next_out = out.data() + at + 18; zs.avail_out = (uInt)bound;
+    deflate(&zs, Z_FINISH);
+    const size_t clen = zs.total_out;
+    deflateEnd(&zs);
+    static const uint8_t head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+    memcpy(out.data() + at, head, 16);
+    const unsigned bsize = (unsigned)(clen + 25);
+    out[at + 16] = (uint8_t)(bsize & 0xff); out[at + 17] = (uint8_t)(bsize >> 8);
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), data, (uInt)n), isz = (uint32_t)n;
+    uint8_t* t = out.data() + at + 18 + clen;
+    for (int i = 0; i < 4; ++i) { t[i] = (uint8_t)(crc >> (8 * i)); t[4 + i] = (uint8_t)(isz >> (8 * i)); }
+    out.resize(at + 18 + clen + 8);
+}
+const uint8_t kBgzfEof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+// compress `data` into BGZF members of 0xff00 bytes in parallel and write the file
+bool write_bgzf_file(const char* path, const std::vector<const std::vector<uint8_t>*>& parts, int n_threads, int level, std::string& err) {
+    // the parts are logically concatenated; cut into blocks without copying more than one block at a time
+    size_t total = 0;
+    std::vector<size_t> start;
+    for (auto* p : parts) { start.push_back(total); total += p->size(); }
+    const size_t B = 0xff00;
+    const int64_t nb = (int64_t)((total + B - 1) / B);
+    std::vector<std::vector<uint8_t>> comp((size_t)nb);
+    parallel_items(nb, n_threads, [&](int64_t bi, int) {
+        const size_t b0 = (size_t)bi * B, b1 = std::min(total, b0 + B);
+        std::vector<uint8_t> tmp;
+        tmp.reserve(b1 - b0);
+        size_t k = (size_t)(std::upper_bound(start.begin(), start.end(), b0) - start.begin()) - 1;
+        size_t pos = b0;
+        while (pos < b1) {
+            const std::vector<uint8_t>& P = *parts[k];
+            const size_t o = pos - start[k], n = std::min(P.size() - o, b1 - pos);
+            tmp.insert(tmp.end(), P.begin() + (long)o, P.begin() + (long)(o + n));
+            pos += n;
+            ++k;
+        }
+        bgzf_deflate_block(tmp.data(), tmp.size(), level, comp[(size_t)bi]);
+    });
+    FILE* f = fopen(path, "wb");
+    if (!f) { err = std::string("cannot create ") + path; return false; }
+    bool ok = true;
+    for (auto& c : comp) ok = ok && fwrite(c.data(), 1, c.size(), f) == c.size();
+    ok = ok && fwrite(kBgzfEof, 1, 28, f) == 28;
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) err = std::string("write failed on ") + path;
+    return ok;
+}
+
+// ------------------------------------------------------------------------------------------------ f16
+float half_to_float(uint16_t h) {
+    const uint32_t s = (uint32_t)(h >> 15) << 31, e = (h >> 10) & 0x1f, m = h & 0x3ff;
+    uint32_t bits;
+    if (e == 0) {
+        if (m == 0) bits = s;
+        else {  // subnormal: normalise
+            int k = 0;
+            uint32_t mm = m;
+            while (!(mm & 0x400)) { mm <<= 1; ++k; }
+            bits = s | ((uint32_t)(127 - 15 - k + 1) << 23) | ((mm & 0x3ff) << 13);
+        }
+    } else if (e == 31) bits = s | 0x7f800000u | (m << 13);
+    else bits = s | ((e + 112) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+uint16_t float_to_half(float f) {  // round to nearest even (half::f16::from_f64 of an f32 value rounds once, as here)
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t s = (x >> 16) & 0x8000u;
+    const int32_t e = (int32_t)((x >> 23) & 0xff) - 127 + 15;
+    uint32_t m = x & 0x7fffffu;
+    if (((x >> 23) & 0xff) == 0xff) return (uint16_t)(s | 0x7c00u | (m ? 0x200u : 0));
+    if (e >= 31) return (uint16_t)(s | 0x7c00u);
+    if (e <= 0) {
+        if (e < -10) return (uint16_t)s;
+        m |= 0x800000u;
+        const int shift = 14 - e;
+        uint32_t hm = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1), halfway = 1u << (shift - 1);
+        if (rem > halfway || (rem == halfway && (hm & 1))) ++hm;
+        return (uint16_t)(s | hm);
+    }
+    uint32_t hm = m >> 13;
+    const uint32_t rem = m & 0x1fffu;
+    uint32_t out = s | ((uint32_t)e << 10) | hm;
+    if (rem > 0x1000u || (rem == 0x1000u && (hm & 1))) ++out;  // carries into the exponent correctly
+    return (uint16_t)out;
+}
+
+// ------------------------------------------------------------------------------------------------ header
+struct Header {
+    std::string text;
+    std::vector<std::string> dict;     // FILTER/INFO/FORMAT ids by dictionary index
+    std::vector<std::string> contigs;  // by index
+    bool version_ok = false;
+};
+std::string attr(const std::string& body, const char* key) {
+    const std::string k = std::string(key) + "=";
+    size_t p = 0;
+    while ((p = body.find(k, p)) != std::string::npos) {
+        if (p == 0 || body[p - 1] == ',' || body[p - 1] == '<') {
+            size_t q = p + k.size(), e = q;
+            while (e < body.size() && body[e] != ',' && body[e] != '>') ++e;
+            return body.substr(q, e - q);
+        }
+        p += k.size();
+    }
+    return "";
+}
+void parse_header(const std::string& text, Header& h) {
+    h.text = text;
+    h.dict.assign(1, "PASS");
+    std::unordered_map<std::string, int> seen{{"PASS", 0}};
+    size_t p = 0;
+    int next = 1, cnext = 0;
+    while (p < text.size()) {
+        size_t e = text.find('\n', p);
+        if (e == std::string::npos) e = text.size();
+        const std::string line = text.substr(p, e - p);
+        p = e + 1;
+        if (line.compare(0, 2, "##") != 0) continue;
+        if (line == "##varlociraptor_observation_format_version=15") h.version_ok = true;  // preprocessing/mod.rs:810, calling.rs:324-339
+        const bool dictline = line.compare(0, 9, "##FILTER=") == 0 || line.compare(0, 7, "##INFO=") == 0 || line.compare(0, 9, "##FORMAT=") == 0;
+        if (dictline) {
+            const std::string body = line.substr(line.find('<'));
+            const std::string id = attr(body, "ID"), idx = attr(body, "IDX");
+            if (id.empty() || seen.count(id)) continue;
+            const int i = idx.empty() ? next : atoi(idx.c_str());
+            seen[id] = i;
+            if ((int)h.dict.size() <= i) h.dict.resize((size_t)i + 1);
+            h.dict[(size_t)i] = id;
+            next = std::max(next, i + 1);
+        } else if (line.compare(0, 9, "##contig=") == 0) {
+            const std::string body = line.substr(line.find('<'));
+            const std::string id = attr(body, "ID"), idx = attr(body, "IDX");
+            const int i = idx.empty() ? cnext : atoi(idx.c_str());
+            if ((int)h.contigs.size() <= i) h.contigs.resize((size_t)i + 1);
+            h.contigs[(size_t)i] = id;
+            cnext = std::max(cnext, i + 1);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ observation records
+enum Field {
+    FD_PROB_MAPPING, FD_PROB_REF, FD_PROB_ALT, FD_PROB_MISSED, FD_PROB_SAMPLE_ALT, FD_PROB_DOUBLE_OVERLAP, FD_PROB_HIT_BASE,
+    FD_STRAND, FD_ORIENT, FD_READPOS, FD_ALTLOCUS, FD_SOFTCLIPPED, FD_PAIRED, FD_MAX_MAPQ, FD_HP_ART, FD_HP_VAR, FD_HP_LEN, FD_THIRD,
+    FD_N_VEC,
+    FD_IMPRECISE = FD_N_VEC, FD_EVENT, FD_MATEID, FD_HET, FD_SOM, FD_N
+};
+const char* const kFieldName[FD_N] = {
+    "PROB_MAPPING", "PROB_REF", "PROB_ALT", "PROB_MISSED_ALLELE", "PROB_SAMPLE_ALT", "PROB_DOUBLE_OVERLAP", "PROB_HIT_BASE",
+    "STRAND", "READ_ORIENTATION", "READ_POSITION", "ALT_LOCUS", "SOFTCLIPPED", "PAIRED", "IS_MAX_MAPQ",
+    "PROB_HOMOPOLYMER_ARTIFACT_OBSERVABLE", "PROB_HOMOPOLYMER_VARIANT_OBSERVABLE", "HOMOPOLYMER_INDEL_LEN", "THIRD_ALLELE_EVIDENCE",
+    "IMPRECISE", "EVENT", "MATEID", "HETEROZYGOSITY", "SOMATIC_EFFECTIVE_MUTATION_RATE"};
+
+// one decoded record of one sample file, before it is placed into the batch
+struct RecView {
+    int32_t contig = -1;          // index into the file's contig dictionary (BCF) / interned name (text)
+    int64_t pos = 0;              // 1-based
+    std::string id, ref, alt, event, mateid;
+    bool imprecise = false;
+    double het_ln = NAN, som_ln = NAN;
+    std::vector<uint8_t> vec[FD_N_VEC];  // bincode bytes of every vector field (LE u16 words of the INFO integers)
+    bool present[FD_N_VEC] = {};
+    void reset() {
+        id.clear(); ref.clear(); alt.clear(); event.clear(); mateid.clear();
+        imprecise = false; het_ln = NAN; som_ln = NAN;
+        for (int i = 0; i < FD_N_VEC; ++i) { vec[i].clear(); present[i] = false; }
+    }
+};
+
+struct Cursor {  // bincode reader (little-endian, u64 lengths, u32 enum tags, u8 Option tags)
+    const uint8_t* p; const uint8_t* e; bool bad = false;
+    bool need(size_t n) { if ((size_t)(e - p) < n) { bad = true; return false; } return true; }
+    uint8_t u8() { if (!need(1)) return 0; return *p++; }
+    uint32_t u32() { if (!need(4)) return 0; uint32_t v; memcpy(&v, p, 4); p += 4; return v; }
+    uint64_t u64() { if (!need(8)) return 0; uint64_t v; memcpy(&v, p, 8); p += 8; return v; }
+    float mini() {  // MiniLogProb (utils/mod.rs:449-474)
+        const uint32_t tag = u32();
+        if (tag == 0) { if (!need(2)) return 0; uint16_t h; memcpy(&h, p, 2); p += 2; return half_to_float(h); }
+        if (tag == 1) { if (!need(4)) return 0; float f; memcpy(&f, p, 4); p += 4; return f; }
+        bad = true; return 0;
+    }
+};
+
+// columns of one sample file for a contiguous range of its records
+struct Chunk {
+    std::vector<uint32_t> n_obs;  // per record
+    std::vector<float> col[9];
+    std::vector<uint32_t> flags;
+    std::vector<int32_t> third;
+    std::vector<uint8_t> is_hp, imprecise;
+    std::vector<int32_t> contig;
+    std::vector<int64_t> pos;
+    std::vector<double> het, som;
+    std::string pool;                       // NUL-terminated strings
+    std::vector<uint32_t> id, ref, alt, hap;  // offsets into pool (hap: 0xffffffff = none)
+    std::string error;
+};
+
+uint32_t pool_add(std::string& pool, const std::string& s) {
+    const uint32_t at = (uint32_t)pool.size();
+    pool.append(s);
+    pool.push_back('\0');
+    return at;
+}
+
+// read_observations (preprocessing/mod.rs:818-919) of one record into the chunk
+bool decode_into(const RecView& r, Chunk& c, std::string& err) {
+    static const int kMini[7] = {FD_PROB_MAPPING, FD_PROB_ALT, FD_PROB_REF, FD_PROB_MISSED, FD_PROB_SAMPLE_ALT, FD_PROB_DOUBLE_OVERLAP, FD_PROB_HIT_BASE};
+    for (int k = 0; k < 7; ++k)
+        if (!r.present[kMini[k]]) { err = std::string("No varlociraptor observations found in record (") + kFieldName[kMini[k]] + ")"; return false; }
+    for (int f : {FD_STRAND, FD_ORIENT, FD_READPOS, FD_ALTLOCUS, FD_SOFTCLIPPED, FD_PAIRED, FD_MAX_MAPQ})
+        if (!r.present[f]) { err = std::string("No varlociraptor observations found in record (") + kFieldName[f] + ")"; return false; }
+    uint64_t n = 0;
+    const size_t base = c.flags.size();
+    for (int k = 0; k < 7; ++k) {  // column order of vlr_batch: pm, pa, pr, miss, psa, pdo, phb
+        const auto& v = r.vec[kMini[k]];
+        Cursor cu{v.data(), v.data() + v.size()};
+        const uint64_t m = cu.u64();
+        if (k == 0) n = m;
+        if (m != n || m > (1u << 28)) { err = "inconsistent observation vector lengths"; return false; }
+        auto& col = c.col[k];
+        col.resize(base + n);
+        float* dst = col.data() + base;
+        for (uint64_t i = 0; i < n; ++i) dst[i] = cu.mini();
+        if (cu.bad) { err = std::string("truncated ") + kFieldName[kMini[k]]; return false; }
+    }
+    c.flags.resize(base + n);
+    uint32_t* fl = c.flags.data() + base;
+    for (uint64_t i = 0; i < n; ++i) fl[i] = 0;
+    auto enums = [&](int field, auto&& put) -> bool {
+        const auto& v = r.vec[field];
+        Cursor cu{v.data(), v.data() + v.size()};
+        if (cu.u64() != n) { err = std::string("length of ") + kFieldName[field]; return false; }
+        for (uint64_t i = 0; i < n; ++i) put(i, cu.u32());
+        if (cu.bad) { err = std::string("truncated ") + kFieldName[field]; return false; }
+        return true;
+    };
+    if (!enums(FD_STRAND, [&](uint64_t i, uint32_t v) { fl[i] |= (v & 3u) << VLR_F_STRAND_SHIFT; })) return false;
+    // bio_types SequenceReadPairOrientation: F1R2 0, F2R1 1, ..., None 8 (the reference fixture pins None = 8)
+    if (!enums(FD_ORIENT, [&](uint64_t i, uint32_t v) {
+            const uint32_t o = v == 0 ? VLR_ORIENT_F1R2 : v == 1 ? VLR_ORIENT_F2R1 : v == 8 ? VLR_ORIENT_NONE : VLR_ORIENT_OTHER;
+            fl[i] |= o << VLR_F_ORIENT_SHIFT;
+        })) return false;
+    if (!enums(FD_READPOS, [&](uint64_t i, uint32_t v) { if (v == 0) fl[i] |= VLR_F_READPOS_MAJOR; })) return false;
+    if (!enums(FD_ALTLOCUS, [&](uint64_t i, uint32_t v) { fl[i] |= (v & 3u) << VLR_F_ALTLOCUS_SHIFT; })) return false;
+    auto bits = [&](int field, uint32_t flag) -> bool {  // bv::BitVec<u8>: Option tag, u64 blocks, bytes, u64 bits
+        const auto& v = r.vec[field];
+        Cursor cu{v.data(), v.data() + v.size()};
+        if (!cu.u8()) { const uint64_t nb = cu.u64(); if (nb != n && !(nb == 0 && n == 0)) { err = std::string("length of ") + kFieldName[field]; return false; } return !cu.bad; }
+        const uint64_t nblocks = cu.u64();
+        if (!cu.need(nblocks)) { err = std::string("truncated ") + kFieldName[field]; return false; }
+        const uint8_t* blocks = cu.p;
+        cu.p += nblocks;
+        const uint64_t nbits = cu.u64();
+        if (cu.bad || nbits != n || nblocks * 8 < nbits) { err = std::string("length of ") + kFieldName[field]; return false; }
+        for (uint64_t i = 0; i < n; ++i)
+            if ((blocks[i >> 3] >> (i & 7)) & 1) fl[i] |= flag;
+        return true;
+    };
+    if (!bits(FD_SOFTCLIPPED, VLR_F_SOFTCLIPPED) || !bits(FD_PAIRED, VLR_F_PAIRED) || !bits(FD_MAX_MAPQ, VLR_F_MAX_MAPQ)) return false;
+    // homopolymer fields: present for the whole record or not at all (mod.rs:867: is_homopolymer_indel)
+    bool is_hp = false;
+    for (int k = 0; k < 2; ++k) {
+        auto& col = c.col[7 + k];
+        col.resize(base + n);
+        float* dst = col.data() + base;
+        const int field = k == 0 ? FD_HP_ART : FD_HP_VAR;
+        if (!r.present[field]) { for (uint64_t i = 0; i < n; ++i) dst[i] = NAN; continue; }
+        const auto& v = r.vec[field];
+        Cursor cu{v.data(), v.data() + v.size()};
+        const uint64_t m = cu.u64();
+        if (m != n) { err = std::string("length of ") + kFieldName[field]; return false; }
+        if (k == 0 && m > 0) is_hp = true;
+        for (uint64_t i = 0; i < n; ++i) dst[i] = cu.u8() ? cu.mini() : NAN;
+        if (cu.bad) { err = std::string("truncated ") + kFieldName[field]; return false; }
+    }
+    if (r.present[FD_HP_LEN]) {
+        const auto& v = r.vec[FD_HP_LEN];
+        Cursor cu{v.data(), v.data() + v.size()};
+        if (cu.u64() != n) { err = "length of HOMOPOLYMER_INDEL_LEN"; return false; }
+        for (uint64_t i = 0; i < n; ++i)
+            if (cu.u8()) fl[i] |= VLR_F_HP_LEN_VALID | ((uint32_t)cu.u8() << VLR_F_HP_LEN_SHIFT);
+        if (cu.bad) { err = "truncated HOMOPOLYMER_INDEL_LEN"; return false; }
+    }
+    c.third.resize(base + n);
+    int32_t* th = c.third.data() + base;
+    if (r.present[FD_THIRD]) {
+        const auto& v = r.vec[FD_THIRD];
+        Cursor cu{v.data(), v.data() + v.size()};
+        if (cu.u64() != n) { err = "length of THIRD_ALLELE_EVIDENCE"; return false; }
+        for (uint64_t i = 0; i < n; ++i) th[i] = cu.u8() ? (int32_t)cu.u32() : -1;
+        if (cu.bad) { err = "truncated THIRD_ALLELE_EVIDENCE"; return false; }
+    } else
+        for (uint64_t i = 0; i < n; ++i) th[i] = -1;
+    c.n_obs.push_back((uint32_t)n);
+    c.is_hp.push_back(is_hp ? 1 : 0);
+    c.imprecise.push_back(r.imprecise ? 1 : 0);
+    c.contig.push_back(r.contig);
+    c.pos.push_back(r.pos);
+    c.het.push_back(r.het_ln);
+    c.som.push_back(r.som_ln);
+    c.id.push_back(pool_add(c.pool, r.id.empty() ? std::string(".") : r.id));
+    c.ref.push_back(pool_add(c.pool, r.ref));
+    c.alt.push_back(pool_add(c.pool, r.alt));
+    // HaplotypeIdentifier::from (variants/model/mod.rs:87-133): EVENT, else the sorted pair (record id, MATEID)
+    if (!r.event.empty()) c.hap.push_back(pool_add(c.pool, r.event.substr(0, r.event.find(','))));
+    else if (!r.mateid.empty()) {
+        if (r.id.empty() || r.id == ".") { err = "breakend with MATEID but without record ID"; return false; }
+        std::string a = r.id, b = r.mateid.substr(0, r.mateid.find(','));
+        if (b < a) std::swap(a, b);
+        c.hap.push_back(pool_add(c.pool, a + "-" + b));
+    } else c.hap.push_back(0xffffffffu);
+    return true;
+}
+
+// ---- BCF2 typed values
+struct Typed { int type; uint32_t n; const uint8_t* data; };
+bool bcf_typed(const uint8_t*& p, const uint8_t* e, Typed& t) {
+    if (p >= e) return false;
+    const uint8_t b = *p++;
+    t.type = b & 0xf;
+    t.n = b >> 4;
+    if (t.n == 15) {
+        Typed l;
+        if (!bcf_typed(p, e, l) || l.n != 1) return false;
+        if (l.type == 1) t.n = (uint32_t)(int8_t)l.data[0];
+        else if (l.type == 2) { int16_t v; memcpy(&v, l.data, 2); t.n = (uint32_t)v; }
+        else if (l.type == 3) { int32_t v; memcpy(&v, l.data, 4); t.n = (uint32_t)v; }
+        else return false;
+    }
+    static const int size[16] = {0, 1, 2, 4, 0, 4, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0};
+    const size_t bytes = (size_t)t.n * size[t.type];
+    if ((size_t)(e - p) < bytes) return false;
+    t.data = p;
+    p += bytes;
+    return true;
+}
+int32_t typed_int(const Typed& t, uint32_t i) {
+    if (t.type == 1) return (int8_t)t.data[i];
+    if (t.type == 2) { int16_t v; memcpy(&v, t.data + 2 * i, 2); return v; }
+    int32_t v; memcpy(&v, t.data + 4 * (size_t)i, 4); return v;
+}
+double phred_to_ln(float x) { return x != x ? NAN : -(double)x * std::log(10.0) / 10.0; }  // calling.rs:470-494
+
+bool parse_bcf_record(const uint8_t* rec, const uint8_t* end, const std::vector<int8_t>& field_of_key, RecView& r, std::string& err) {
+    if (end - rec < 32) { err = "truncated BCF record"; return false; }
+    uint32_t l_shared;
+    memcpy(&l_shared, rec, 4);
+    const uint8_t* p = rec + 8;
+    const uint8_t* se = p + l_shared;
+    if (se > end) { err = "truncated BCF record"; return false; }
+    int32_t chrom, pos;
+    uint32_t nai;
+    memcpy(&chrom, p, 4); memcpy(&pos, p + 4, 4); memcpy(&nai, p + 16, 4);
+    p += 24;
+    r.contig = chrom; r.pos = (int64_t)pos + 1;
+    const uint32_t n_allele = nai >> 16, n_info = nai & 0xffff;
+    Typed t;
+    if (!bcf_typed(p, se, t)) { err = "bad ID"; return false; }
+    r.id.assign((const char*)t.data, t.type == 7 ? t.n : 0);
+    for (uint32_t a = 0; a < n_allele; ++a) {
+        if (!bcf_typed(p, se, t) || (t.type != 7 && t.n != 0)) { err = "bad allele"; return false; }
+        if (a == 0) r.ref.assign((const char*)t.data, t.n);
+        else { if (a > 1) r.alt.push_back(','); r.alt.append((const char*)t.data, t.n); }
+    }
+    if (n_allele < 2) r.alt = ".";
+    if (!bcf_typed(p, se, t)) { err = "bad FILTER"; return false; }
+    for (uint32_t k = 0; k < n_info; ++k) {
+        Typed key, val;
+        if (!bcf_typed(p, se, key) || key.n != 1 || !bcf_typed(p, se, val)) { err = "bad INFO"; return false; }
+        const int32_t ki = typed_int(key, 0);
+        const int f = (ki >= 0 && (size_t)ki < field_of_key.size()) ? field_of_key[(size_t)ki] : -1;
+        if (f < 0) continue;
+        if (f < FD_N_VEC) {
+            if (val.type < 1 || val.type > 3) continue;  // read_values: info(tag).integer()
+            auto& out = r.vec[f];
+            out.resize((size_t)val.n * 2);
+            // i32 -> u16 -> 2 bytes LE (mod.rs:836-842); vector-end padding cannot occur inside an INFO vector
+            if (val.type == 3) for (uint32_t i = 0; i < val.n; ++i) { out[2 * i] = val.data[4 * (size_t)i]; out[2 * i + 1] = val.data[4 * (size_t)i + 1]; }
+            else if (val.type == 2) memcpy(out.data(), val.data, (size_t)val.n * 2);
+            else for (uint32_t i = 0; i < val.n; ++i) { const int v = (int8_t)val.data[i]; out[2 * i] = (uint8_t)(v & 0xff); out[2 * i + 1] = (uint8_t)((v >> 8) & 0xff); }
+            r.present[f] = true;
+        } else if (f == FD_IMPRECISE) r.imprecise = true;
+        else if (f == FD_EVENT && val.type == 7) r.event.assign((const char*)val.data, val.n);
+        else if (f == FD_MATEID && val.type == 7) r.mateid.assign((const char*)val.data, val.n);
+        else if ((f == FD_HET || f == FD_SOM) && val.type == 5 && val.n >= 1) {
+            uint32_t bits;
+            memcpy(&bits, val.data, 4);
+            float x;
+            memcpy(&x, &bits, 4);
+            const bool missing = bits == 0x7F800001u || bits == 0x7F800002u;
+            (f == FD_HET ? r.het_ln : r.som_ln) = missing ? NAN : phred_to_ln(x);
+        }
+    }
+    while (!r.event.empty() && r.event.back() == '\0') r.event.pop_back();
+    while (!r.mateid.empty() && r.mateid.back() == '\0') r.mateid.pop_back();
+    return true;
+}
+
+bool parse_text_record(const char* line, const char* le, std::unordered_map<std::string, int>& contig_ids, std::mutex& contig_mu,
+                       std::vector<std::string>& contig_names, RecView& r, std::string& err) {
+    const char* f[9];
+    const char* fe[9];
+    int nf = 0;
+    const char* p = line;
+    while (nf < 9) {
+        const char* t = (const char*)memchr(p, '\t', (size_t)(le - p));
+        f[nf] = p; fe[nf] = t ? t : le;
+        ++nf;
+        if (!t) break;
+        p = t + 1;
+    }
+    if (nf < 8) { err = "VCF line with fewer than 8 columns"; return false; }
+    const std::string chrom(f[0], fe[0]);
+    {
+        std::lock_guard<std::mutex> g(contig_mu);
+        auto it = contig_ids.find(chrom);
+        if (it == contig_ids.end()) { it = contig_ids.emplace(chrom, (int)contig_names.size()).first; contig_names.push_back(chrom); }
+        r.contig = it->second;
+    }
+    r.pos = strtoll(std::string(f[1], fe[1]).c_str(), nullptr, 10);
+    r.id.assign(f[2], fe[2]); r.ref.assign(f[3], fe[3]); r.alt.assign(f[4], fe[4]);
+    const char* q = f[7];
+    const char* qe = fe[7];
+    while (q < qe) {
+        const char* semi = (const char*)memchr(q, ';', (size_t)(qe - q));
+        const char* ke = semi ? semi : qe;
+        const char* eq = (const char*)memchr(q, '=', (size_t)(ke - q));
+        const size_t klen = (size_t)((eq ? eq : ke) - q);
+        int fld = -1;
+        for (int i = 0; i < FD_N; ++i)
+            if (strlen(kFieldName[i]) == klen && memcmp(kFieldName[i], q, klen) == 0) { fld = i; break; }
+        if (fld >= 0) {
+            const char* v = eq ? eq + 1 : ke;
+            if (fld < FD_N_VEC) {
+                auto& out = r.vec[fld];
+                while (v < ke) {
+                    char* endp;
+                    const long x = strtol(v, &endp, 10);
+                    if (endp == v) break;
+                    out.push_back((uint8_t)(x & 0xff));
+                    out.push_back((uint8_t)((x >> 8) & 0xff));
+                    v = endp;
+                    if (v < ke && *v == ',') ++v;
+                }
+                r.present[fld] = true;
+            } else if (fld == FD_IMPRECISE) r.imprecise = true;
+            else if (fld == FD_EVENT) r.event.assign(v, ke);
+            else if (fld == FD_MATEID) r.mateid.assign(v, ke);
+            else {
+                const std::string s(v, ke);
+                const std::string first = s.substr(0, s.find(','));
+                if (!first.empty() && first != ".") {
+                    const float x = strtof(first.c_str(), nullptr);
+                    (fld == FD_HET ? r.het_ln : r.som_ln) = phred_to_ln(x);
+                }
+            }
+        }
+        q = semi ? semi + 1 : qe;
+    }
+    return true;
+}
+
+// all records of one observation file, decoded by `n_threads` workers into chunks of consecutive records
+struct SampleFile {
+    std::vector<Chunk> chunks;
+    std::vector<std::string> contig_names;
+    int64_t n_rec = 0;
+};
+
+bool read_sample_file(const char* path, int n_threads, SampleFile& sf, std::string& err) {
+    std::vector<uint8_t> data;
+    if (!load_inflated(path, data, n_threads, err)) return false;
+    const bool is_bcf = data.size() >= 9 && memcmp(data.data(), "BCF\2\2", 5) == 0;
+    Header h;
+    std::vector<size_t> starts;  // record starts (+ end sentinel)
+    if (is_bcf) {
+        uint32_t l_text;
+        memcpy(&l_text, data.data() + 5, 4);
+        if (9 + (size_t)l_text > data.size()) { err = std::string("truncated BCF header in ") + path; return false; }
+        std::string text((const char*)data.data() + 9, l_text);
+        while (!text.empty() && text.back() == '\0') text.pop_back();
+        parse_header(text, h);
+        size_t p = 9 + (size_t)l_text;
+        while (p + 8 <= data.size()) {
+            uint32_t ls, li;
+            memcpy(&ls, data.data() + p, 4); memcpy(&li, data.data() + p + 4, 4);
+            starts.push_back(p);
+            p += 8 + (size_t)ls + li;
+        }
+        if (p != data.size()) { err = std::string("truncated BCF record in ") + path; return false; }
+        starts.push_back(p);
+        sf.contig_names = h.contigs;
+    } else {
+        size_t p = 0;
+        std::string text;
+        while (p < data.size()) {
+            const uint8_t* nl = (const uint8_t*)memchr(data.data() + p, '\n', data.size() - p);
+            const size_t e = nl ? (size_t)(nl - data.data()) : data.size();
+            if (e > p && data[p] == '#') text.append((const char*)data.data() + p, e - p + 1);
+            else if (e > p) starts.push_back(p);
+            p = e + 1;
+        }
+        starts.push_back(data.size() + 1);
+        parse_header(text, h);
+    }
+    if (!h.version_ok) { err = std::string("invalid observation format in ") + path + " (calling.rs:324-339: varlociraptor_observation_format_version=15 expected)"; return false; }
+    std::vector<int8_t> field_of_key(h.dict.size(), -1);
+    for (size_t i = 0; i < h.dict.size(); ++i)
+        for (int f = 0; f < FD_N; ++f)
+            if (h.dict[i] == kFieldName[f]) field_of_key[i] = (int8_t)f;
+    const int64_t n = (int64_t)starts.size() - 1;
+    sf.n_rec = n;
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(pick_threads(n_threads), (n + 255) / 256));
+    sf.chunks.assign((size_t)T, Chunk());
+    std::unordered_map<std::string, int> contig_ids;
+    std::mutex contig_mu;
+    parallel_ranges(n, T, [&](int64_t b, int64_t e, int t) {
+        Chunk& c = sf.chunks[(size_t)t];
+        RecView r;
+        for (int64_t i = b; i < e && c.error.empty(); ++i) {
+            r.reset();
+            std::string er;
+            bool ok;
+            if (is_bcf) ok = parse_bcf_record(data.data() + starts[(size_t)i], data.data() + starts[(size_t)i + 1], field_of_key, r, er);
+            else {
+                const char* ls = (const char*)data.data() + starts[(size_t)i];
+                const char* le = (const char*)memchr(ls, '\n', data.size() - starts[(size_t)i]);
+                if (!le) le = (const char*)data.data() + data.size();
+                if (le > ls && le[-1] == '\r') --le;
+                ok = parse_text_record(ls, le, contig_ids, contig_mu, sf.contig_names, r, er);
+            }
+            ok = ok && decode_into(r, c, er);
+            if (!ok) c.error = er + " (record " + std::to_string(i + 1) + " of " + path + ")";
+        }
+    });
+    for (auto& c : sf.chunks)
+        if (!c.error.empty()) { err = c.error; return false; }
+    return true;
+}
+
+// _variant_class of obsfmt.py / calling.rs:517-534: (vlr_variant_type, is_snv_or_mnv, has_snv)
+void variant_class(const char* ref, const char* alt, int& vt, bool& snv_or_mnv, bool& has_snv) {
+    const size_t lr = strlen(ref), la = strlen(alt);
+    has_snv = false;
+    if (alt[0] == '<') {
+        std::string t(alt);
+        while (!t.empty() && (t.front() == '<')) t.erase(t.begin());
+        while (!t.empty() && (t.back() == '>')) t.pop_back();
+        vt = (t == "DEL" || t == "INS") ? VLR_VT_INDEL : (t == "INV" || t == "DUP" || t == "BND") ? VLR_VT_SV : VLR_VT_OTHER;
+        snv_or_mnv = lr == la;  // calling.rs compares allele byte lengths
+        return;
+    }
+    if (strchr(alt, '[') || strchr(alt, ']')) { vt = VLR_VT_SV; snv_or_mnv = lr == la; return; }
+    if (lr == 1 && la == 1) { vt = VLR_VT_SNV; snv_or_mnv = true; has_snv = true; return; }
+    if (lr == la) { vt = VLR_VT_MNV; snv_or_mnv = true; return; }
+    vt = VLR_VT_INDEL; snv_or_mnv = false;
+}
+
+void* table_alloc(size_t bytes, bool& pinned) {
+    if (bytes == 0) bytes = 8;
+    void* p = vlr_host_alloc(bytes);
+    pinned = p != nullptr;
+    if (!p) p = aligned_alloc(64, (bytes + 63) & ~(size_t)63);
+    return p;
+}
+
+}  // namespace
+
+// ================================================================================================ the observation table
+struct vlr_obs_table {
+    int32_t n_samples = 0;
+    int64_t n_loci = 0, n_obs = 0;
+    struct Arr { void* p = nullptr; bool pinned = false; };
+    Arr a_off, a_col[9], a_flags, a_lflags, a_vt, a_ref, a_alt, a_third;
+    uint32_t* obs_offset = nullptr;
+    float* col[9] = {};
+    uint32_t* flags = nullptr;
+    int32_t* third = nullptr;
+    uint8_t *locus_flags = nullptr, *variant_type = nullptr, *ref_base = nullptr, *alt_base = nullptr;
+    std::vector<int32_t> contig;
+    std::vector<int64_t> pos, hap_rep;
+    std::vector<double> het, som;
+    std::vector<uint8_t> imprecise;
+    std::vector<std::string> contig_names;
+    std::vector<const char*> contig_ptrs;
+    std::string pool;
+    std::vector<uint64_t> id_off, ref_off, alt_off;
+    ~vlr_obs_table() {
+        Arr* all[] = {&a_off, &a_col[0], &a_col[1], &a_col[2], &a_col[3], &a_col[4], &a_col[5], &a_col[6], &a_col[7], &a_col[8],
+                      &a_flags, &a_lflags, &a_vt, &a_ref, &a_alt, &a_third};
+        for (Arr* a : all)
+            if (a->p) { if (a->pinned) vlr_host_free(a->p); else free(a->p); }
+    }
+    template <typename T>
+    T* make(Arr& a, size_t n) { a.p = table_alloc(n * sizeof(T), a.pinned); return (T*)a.p; }
+};
+
+extern "C" {
+
+int vlr_obs_read(int n_samples, const char* const* paths, uint32_t omit_bias_mask, int n_threads, vlr_obs_table** out) {
+    if (!out || !paths || n_samples < 1 || n_samples > VLR_MAX_SAMPLES) return ifail(VLR_ERR_INVALID_ARGUMENT, "vlr_obs_read: bad argument");
+    *out = nullptr;
+    n_threads = pick_threads(n_threads);
+    std::vector<SampleFile> files((size_t)n_samples);
+    for (int s = 0; s < n_samples; ++s) {
+        std::string err;
+        if (!read_sample_file(paths[s], n_threads, files[(size_t)s], err)) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s", err.c_str());
+        if (files[(size_t)s].n_rec != files[0].n_rec) return ifail(VLR_ERR_INVALID_ARGUMENT, "inconsistent observations: %s holds %lld records, %s %lld (calling.rs:369-371)",
+                                                                    paths[s], (long long)files[(size_t)s].n_rec, paths[0], (long long)files[0].n_rec);
+    }
+    const int S = n_samples;
+    const int64_t L = files[0].n_rec;
+    std::unique_ptr<vlr_obs_table> t(new vlr_obs_table());
+    t->n_samples = S; t->n_loci = L;
+    // where record l of sample s lives: (chunk, index in chunk, observation base in chunk)
+    struct Loc { const Chunk* c; uint32_t i; uint64_t base; };
+    std::vector<Loc> loc((size_t)(L * S));
+    for (int s = 0; s < S; ++s) {
+        int64_t l = 0;
+        for (const Chunk& c : files[(size_t)s].chunks) {
+            uint64_t base = 0;
+            for (uint32_t i = 0; i < c.n_obs.size(); ++i) { loc[(size_t)(l * S + s)] = {&c, i, base}; base += c.n_obs[i]; ++l; }
+        }
+    }
+    t->obs_offset = t->make<uint32_t>(t->a_off, (size_t)(L * S + 1));
+    uint64_t total = 0;
+    for (int64_t p = 0; p < L * S; ++p) { t->obs_offset[p] = (uint32_t)total; total += loc[(size_t)p].c->n_obs[loc[(size_t)p].i]; }
+    if (total > 0xffffffffull) return ifail(VLR_ERR_INVALID_ARGUMENT, "more than 2^32 observations in one table");
+    t->obs_offset[L * S] = (uint32_t)total;
+    t->n_obs = (int64_t)total;
+    for (int k = 0; k < 9; ++k) t->col[k] = t->make<float>(t->a_col[k], (size_t)total);
+    t->flags = t->make<uint32_t>(t->a_flags, (size_t)total);
+    t->third = t->make<int32_t>(t->a_third, (size_t)total);
+    t->locus_flags = t->make<uint8_t>(t->a_lflags, (size_t)L);
+    t->variant_type = t->make<uint8_t>(t->a_vt, (size_t)L);
+    t->ref_base = t->make<uint8_t>(t->a_ref, (size_t)L);
+    t->alt_base = t->make<uint8_t>(t->a_alt, (size_t)L);
+    t->contig.resize((size_t)L); t->pos.resize((size_t)L); t->het.resize((size_t)L); t->som.resize((size_t)L); t->imprecise.resize((size_t)L);
+    t->id_off.resize((size_t)L); t->ref_off.resize((size_t)L); t->alt_off.resize((size_t)L); t->hap_rep.resize((size_t)L);
+    // contigs: names of sample 0's file; the other files must name the same contig at every record
+    t->contig_names = files[0].contig_names;
+    std::atomic<int64_t> bad_rec{-1};
+    parallel_ranges(L, n_threads, [&](int64_t b, int64_t e, int) {
+        for (int64_t l = b; l < e; ++l) {
+            const Loc& a = loc[(size_t)(l * S)];
+            const char* ref0 = a.c->pool.c_str() + a.c->ref[a.i];
+            const char* alt0 = a.c->pool.c_str() + a.c->alt[a.i];
+            bool any_hp = false;
+            for (int s = 0; s < S; ++s) {
+                const Loc& x = loc[(size_t)(l * S + s)];
+                const uint32_t n = x.c->n_obs[x.i];
+                const uint32_t dst = t->obs_offset[l * S + s];
+                for (int k = 0; k < 9; ++k) memcpy(t->col[k] + dst, x.c->col[k].data() + x.base, (size_t)n * 4);
+                memcpy(t->flags + dst, x.c->flags.data() + x.base, (size_t)n * 4);
+                memcpy(t->third + dst, x.c->third.data() + x.base, (size_t)n * 4);
+                any_hp = any_hp || x.c->is_hp[x.i];
+                if (s > 0) {  // calling.rs:379-390: same site in every sample
+                    const std::string& n0 = files[0].contig_names.size() > (size_t)a.c->contig[a.i] && a.c->contig[a.i] >= 0 ? files[0].contig_names[(size_t)a.c->contig[a.i]] : std::string();
+                    const auto& cn = files[(size_t)s].contig_names;
+                    const std::string& ns = cn.size() > (size_t)x.c->contig[x.i] && x.c->contig[x.i] >= 0 ? cn[(size_t)x.c->contig[x.i]] : std::string();
+                    if (n0 != ns || x.c->pos[x.i] != a.c->pos[a.i] || strcmp(x.c->pool.c_str() + x.c->ref[x.i], ref0) != 0 ||
+                        strcmp(x.c->pool.c_str() + x.c->alt[x.i], alt0) != 0) {
+                        int64_t exp = -1;
+                        bad_rec.compare_exchange_strong(exp, l);
+                    }
+                }
+            }
+            int vt;
+            bool snv_or_mnv, has_snv;
+            variant_class(ref0, alt0, vt, snv_or_mnv, has_snv);
+            const bool precise = !a.c->imprecise[a.i];
+            // WorkItem.check_* (calling.rs:557-567), remove_nonstandard_alignments (590-598)
+            unsigned m = 0;
+            if (snv_or_mnv && precise && !(omit_bias_mask & VLR_BIAS_ORIENTATION)) m |= VLR_BIAS_ORIENTATION;
+            if (precise && !(omit_bias_mask & VLR_BIAS_STRAND)) m |= VLR_BIAS_STRAND;
+            if (snv_or_mnv && precise && !(omit_bias_mask & VLR_BIAS_POSITION)) m |= VLR_BIAS_POSITION;
+            if (snv_or_mnv && precise && !(omit_bias_mask & VLR_BIAS_SOFTCLIP)) m |= VLR_BIAS_SOFTCLIP;
+            if (any_hp && !(omit_bias_mask & VLR_BIAS_HOMOPOLYMER)) m |= VLR_BIAS_HOMOPOLYMER;
+            if (!(omit_bias_mask & VLR_BIAS_ALTLOCUS)) m |= VLR_BIAS_ALTLOCUS;
+            if (snv_or_mnv && !(omit_bias_mask & VLR_BIAS_ORIENTATION)) m |= VLR_LOCUS_REMOVE_NONSTANDARD;
+            if (has_snv) m |= VLR_LOCUS_HAS_SNV;
+            t->locus_flags[l] = (uint8_t)m;
+            t->variant_type[l] = (uint8_t)vt;
+            t->ref_base[l] = has_snv ? (uint8_t)ref0[0] : 0;
+            t->alt_base[l] = has_snv ? (uint8_t)alt0[0] : 0;
+            t->contig[(size_t)l] = a.c->contig[a.i];
+            t->pos[(size_t)l] = a.c->pos[a.i];
+            t->het[(size_t)l] = a.c->het[a.i];
+            t->som[(size_t)l] = a.c->som[a.i];
+            t->imprecise[(size_t)l] = a.c->imprecise[a.i];
+        }
+    });
+    if (bad_rec >= 0) return ifail(VLR_ERR_INVALID_ARGUMENT, "inconsistent observations: record %lld differs between the sample files (calling.rs:379-390)", (long long)bad_rec + 1);
+    // strings and breakend groups (sequential: first occurrence of a haplotype identifier is the representative)
+    std::unordered_map<std::string, int64_t> first;
+    {
+        size_t need = 0;
+        for (const Chunk& c : files[0].chunks) need += c.pool.size();
+        t->pool.reserve(need + 16);
+    }
+    for (int64_t l = 0; l < L; ++l) {
+        const Loc& a = loc[(size_t)(l * S)];
+        const char* base = a.c->pool.c_str();
+        t->id_off[(size_t)l] = t->pool.size(); t->pool.append(base + a.c->id[a.i]); t->pool.push_back('\0');
+        t->ref_off[(size_t)l] = t->pool.size(); t->pool.append(base + a.c->ref[a.i]); t->pool.push_back('\0');
+        t->alt_off[(size_t)l] = t->pool.size(); t->pool.append(base + a.c->alt[a.i]); t->pool.push_back('\0');
+        int64_t rep = l;
+        if (a.c->hap[a.i] != 0xffffffffu) {
+            auto ins = first.emplace(std::string(base + a.c->hap[a.i]), l);
+            rep = ins.first->second;
+        }
+        t->hap_rep[(size_t)l] = rep;
+    }
+    for (auto& n : t->contig_names) t->contig_ptrs.push_back(n.c_str());
+    *out = t.release();
+    return VLR_OK;
+}
+
+void vlr_obs_table_free(vlr_obs_table* t) { delete t; }
+
+int vlr_obs_table_batch(const vlr_obs_table* t, vlr_batch* b) {
+    if (!t || !b) return ifail(VLR_ERR_INVALID_ARGUMENT, "null argument");
+    memset(b, 0, sizeof *b);
+    b->n_loci = t->n_loci; b->n_samples = t->n_samples; b->n_obs = t->n_obs;
+    b->obs_offset = t->obs_offset;
+    b->prob_mapping = t->col[0]; b->prob_alt = t->col[1]; b->prob_ref = t->col[2]; b->prob_missed_allele = t->col[3];
+    b->prob_sample_alt = t->col[4]; b->prob_double_overlap = t->col[5]; b->prob_hit_base = t->col[6];
+    b->prob_hp_artifact = t->col[7]; b->prob_hp_variant = t->col[8];
+    b->flags = t->flags;
+    b->locus_flags = t->locus_flags; b->variant_type = t->variant_type; b->ref_base = t->ref_base; b->alt_base = t->alt_base;
+    return VLR_OK;
+}
+
+int vlr_obs_table_sites(const vlr_obs_table* t, vlr_obs_sites* s) {
+    if (!t || !s) return ifail(VLR_ERR_INVALID_ARGUMENT, "null argument");
+    s->n_loci = t->n_loci;
+    s->n_contigs = (int32_t)t->contig_names.size();
+    s->contig_names = t->contig_ptrs.data();
+    s->contig = t->contig.data(); s->pos = t->pos.data();
+    s->strings = t->pool.c_str();
+    s->id_offset = t->id_off.data(); s->ref_offset = t->ref_off.data(); s->alt_offset = t->alt_off.data();
+    s->group_representative = t->hap_rep.data();
+    s->heterozygosity_ln = t->het.data(); s->somatic_effective_mutation_rate_ln = t->som.data();
+    s->third_allele_evidence = t->third;
+    s->imprecise = t->imprecise.data();
+    return VLR_OK;
+}
+
+}  // extern "C"
+
+// ================================================================================================ writers
+namespace {
+
+// ---- BCF2 encoding helpers
+void put_u32(std::vector<uint8_t>& o, uint32_t v) { for (int i = 0; i < 4; ++i) o.push_back((uint8_t)(v >> (8 * i))); }
+void put_typed_int_scalar(std::vector<uint8_t>& o, int32_t v) {
+    if (v >= -120 && v <= 127) { o.push_back(0x11); o.push_back((uint8_t)(int8_t)v); }
+    else if (v >= -32760 && v <= 32767) { o.push_back(0x12); o.push_back((uint8_t)(v & 0xff)); o.push_back((uint8_t)((v >> 8) & 0xff)); }
+    else { o.push_back(0x13); put_u32(o, (uint32_t)v); }
+}
+void put_desc(std::vector<uint8_t>& o, uint32_t n, int type) {
+    if (n < 15) o.push_back((uint8_t)((n << 4) | type));
+    else { o.push_back((uint8_t)(0xF0 | type)); put_typed_int_scalar(o, (int32_t)n); }
+}
+void put_str(std::vector<uint8_t>& o, const char* s, size_t n) { put_desc(o, (uint32_t)n, 7); o.insert(o.end(), s, s + n); }
+int int_type_for(int32_t lo, int32_t hi) { return (lo >= -120 && hi <= 127) ? 1 : (lo >= -32760 && hi <= 32767) ? 2 : 3; }
+void put_int_vec(std::vector<uint8_t>& o, const int32_t* v, uint32_t n) {  // typed vector, smallest width
+    int32_t lo = 0, hi = 0;
+    for (uint32_t i = 0; i < n; ++i) { lo = std::min(lo, v[i]); hi = std::max(hi, v[i]); }
+    const int t = int_type_for(lo, hi);
+    put_desc(o, n, t);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (t == 1) o.push_back((uint8_t)(int8_t)v[i]);
+        else if (t == 2) { o.push_back((uint8_t)(v[i] & 0xff)); o.push_back((uint8_t)((v[i] >> 8) & 0xff)); }
+        else put_u32(o, (uint32_t)v[i]);
+    }
+}
+
+struct OutHeader {
+    std::string text;                              // with the PASS filter line, ends with '\n'
+    std::unordered_map<std::string, int> dict, contigs;
+};
+void build_out_header(const std::string& header_text, OutHeader& h) {
+    std::vector<std::string> meta;
+    std::string chrom_line;
+    size_t p = 0;
+    while (p < header_text.size()) {
+        size_t e = header_text.find('\n', p);
+        if (e == std::string::npos) e = header_text.size();
+        std::string line = header_text.substr(p, e - p);
+        p = e + 1;
+        if (line.empty()) continue;
+        if (line.compare(0, 2, "##") == 0) meta.push_back(line);
+        else if (line.compare(0, 6, "#CHROM") == 0) chrom_line = line;
+    }
+    bool has_pass = false;
+    for (auto& l : meta) has_pass = has_pass || l.compare(0, 17, "##FILTER=<ID=PASS") == 0;
+    if (!has_pass) meta.insert(meta.begin() + std::min<size_t>(1, meta.size()), "##FILTER=<ID=PASS,Description=\"All filters passed\">");
+    h.dict["PASS"] = 0;
+    int next = 1, cnext = 0;
+    for (auto& l : meta) {
+        const bool d = l.compare(0, 9, "##FILTER=") == 0 || l.compare(0, 7, "##INFO=") == 0 || l.compare(0, 9, "##FORMAT=") == 0;
+        if (d) {
+            const std::string body = l.substr(l.find('<'));
+            const std::string id = attr(body, "ID"), idx = attr(body, "IDX");
+            if (!h.dict.count(id)) { const int i = idx.empty() ? next : atoi(idx.c_str()); h.dict[id] = i; next = std::max(next, i + 1); }
+        } else if (l.compare(0, 9, "##contig=") == 0) {
+            const std::string body = l.substr(l.find('<'));
+            const std::string id = attr(body, "ID"), idx = attr(body, "IDX");
+            if (!h.contigs.count(id)) { const int i = idx.empty() ? cnext : atoi(idx.c_str()); h.contigs[id] = i; cnext = std::max(cnext, i + 1); }
+        }
+    }
+    for (auto& l : meta) { h.text += l; h.text.push_back('\n'); }
+    h.text += chrom_line;
+    h.text.push_back('\n');
+}
+
+// htslib's %g of an f32 (callsfmt.fmt_float)
+std::string fmt_g(float x) {
+    if (x != x) return ".";
+    if (std::isinf(x)) return x > 0 ? "inf" : "-inf";
+    char b[48];
+    snprintf(b, sizeof b, "%g", (double)x);
+    return b;
+}
+bool relative_eq(double a, double b) {
+    if (a == b) return true;
+    const double d = std::fabs(a - b), eps = std::numeric_limits<double>::epsilon();
+    return d <= eps || d <= std::max(std::fabs(a), std::fabs(b)) * eps;
+}
+char kr_letter(double bf) {  // utils/mod.rs:158-167 over bio's Kass-Raftery scale
+    if (bf <= 1.0) return relative_eq(bf, 1.0) ? 'E' : 'N';
+    if (bf <= 3.0) return 'B';
+    if (bf <= 20.0) return 'P';
+    if (bf <= 150.0) return 'S';
+    return 'V';
+}
+// utils/mod.rs:122-156 generalized_cigar, keep_order = false: counts in first-appearance order, stable by count desc, stable by aux
+template <typename Aux>
+std::string generalized_cigar(const std::vector<std::string>& items, Aux aux) {
+    std::vector<std::pair<std::string, int>> cnt;
+    std::unordered_map<std::string, size_t> at;
+    for (auto& it : items) {
+        auto f = at.find(it);
+        if (f == at.end()) { at.emplace(it, cnt.size()); cnt.emplace_back(it, 1); }
+        else cnt[f->second].second++;
+    }
+    std::stable_sort(cnt.begin(), cnt.end(), [](const auto& a, const auto& b) { return a.second > b.second; });
+    std::stable_sort(cnt.begin(), cnt.end(), [&](const auto& a, const auto& b) { return aux(a.first) < aux(b.first); });
+    std::string out;
+    for (auto& kv : cnt) { out += std::to_string(kv.second); out += kv.first; }
+    return out;
+}
+
+struct SampleFields { int32_t dp = 0, oobs = 0; float af = NAN; std::string saobs, srobs, obs, sym[6], afd; bool has_afd = false; };
+
+// Call::write_final_record, per sample (calling/variants/mod.rs:233-360, 473-559); mirrors callsfmt.sample_fields
+void sample_fields(const vlr_obs_table* t, const vlr_results* r, int64_t l, int s, SampleFields& o) {
+    const int S = t->n_samples;
+    const uint32_t b = t->obs_offset[l * S + s], e = t->obs_offset[l * S + s + 1];
+    const bool drop_nonstd = t->locus_flags[l] & VLR_LOCUS_REMOVE_NONSTANDARD;  // pileup.rs:26-43
+    std::vector<std::string> obs_items, alt_items, ref_items;
+    double depth = 0.0;
+    int kept = 0;
+    for (uint32_t i = b; i < e; ++i) {
+        const uint32_t f = t->flags[i];
+        const unsigned orient = (f >> VLR_F_ORIENT_SHIFT) & 3;
+        if (drop_nonstd && orient == VLR_ORIENT_OTHER) continue;
+        ++kept;
+        const double pa = t->col[1][i], pr = t->col[2][i], pm = t->col[0][i];
+        depth += std::exp(pm);
+        const double bf_alt = std::exp(pa - pr), bf_ref = std::exp(pr - pa);
+        const bool maxq = f & VLR_F_MAX_MAPQ;
+        std::string score;
+        if (bf_alt > bf_ref) { score = "A"; score.push_back(kr_letter(bf_alt)); }
+        else if (bf_ref > bf_alt) { score = "R"; score.push_back(kr_letter(bf_ref)); }
+        else score = "E";
+        for (auto& ch : score) ch = maxq ? (char)toupper(ch) : (char)tolower(ch);
+        const unsigned strand = (f >> VLR_F_STRAND_SHIFT) & 3, altloc = (f >> VLR_F_ALTLOCUS_SHIFT) & 3;
+        const bool hp_err = (f & VLR_F_HP_LEN_VALID) && ((f >> VLR_F_HP_LEN_SHIFT) & 0xff) != 0;
+        std::string item = score;
+        item += t->third[i] >= 0 ? std::to_string(t->third[i]) : std::string(".");
+        item.push_back((f & VLR_F_PAIRED) ? 'p' : 's');
+        item.push_back("#*."[altloc > 2 ? 2 : altloc]);
+        item.push_back("+-*."[strand]);
+        item.push_back("><*!"[orient]);
+        item.push_back((f & VLR_F_READPOS_MAJOR) ? '^' : '*');
+        item.push_back((f & VLR_F_SOFTCLIPPED) ? '$' : '.');
+        item.push_back(hp_err ? '*' : '.');
+        obs_items.push_back(item);
+        if (pa > pr) { const char c = kr_letter(bf_alt); alt_items.push_back(std::string(1, maxq ? (char)toupper(c) : (char)tolower(c))); }
+        else { const char c = kr_letter(bf_ref); ref_items.push_back(std::string(1, maxq ? (char)toupper(c) : (char)tolower(c))); }
+    }
+    o.dp = kept ? (int32_t)std::floor(depth + 0.5) : 0;  // expected_depth (read_observation.rs:43-47)
+    o.oobs = (int32_t)(e - b) - kept;
+    o.obs = generalized_cigar(obs_items, [](const std::string& k) { return k[0] == 'N' ? 2 : k[0] == 'E' ? 1 : 0; });
+    auto simple = [](const std::string& k) { return k[0] == 'R' ? 2 : (k.back() == 'E' ? 1 : 0); };
+    o.saobs = generalized_cigar(alt_items, simple);
+    o.srobs = generalized_cigar(ref_items, simple);
+    const uint8_t* mb = r->map_bias ? r->map_bias + l * VLR_N_BIAS : nullptr;
+    static const char* sy[6] = {".+-", ".><", ".^", ".$", ".*", ".*"};
+    bool any_bias = false;
+    for (int k = 0; k < 6; ++k) { const int v = mb ? mb[k] : 0; o.sym[k] = std::string(1, sy[k][v < (int)strlen(sy[k]) ? v : 0]); any_bias = any_bias || v; }
+    o.af = (float)r->map_vaf[l * S + s];
+    o.afd = ".";
+    o.has_afd = false;
+    if (r->afd_count && !any_bias) {
+        const int n = std::min(r->afd_count[l * S + s], r->afd_capacity);
+        const double* v = r->afd_vaf + (size_t)(l * S + s) * r->afd_capacity;
+        const double* p = r->afd_lnprob + (size_t)(l * S + s) * r->afd_capacity;
+        std::vector<int> order((size_t)std::max(n, 0));
+        for (int i = 0; i < n; ++i) order[(size_t)i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return v[a] < v[c]; });
+        std::string out;
+        char buf[64];
+        for (int k = 0; k < n; ++k) {
+            const int i = order[(size_t)k];
+            const double ph = -10.0 * p[i] / std::log(10.0) + 0.0;
+            snprintf(buf, sizeof buf, "%s%.3f=%.2f", k ? "," : "", v[i], ph);
+            out += buf;
+        }
+        o.afd = out;
+        o.has_afd = true;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// The calls file (calling.rs:296-304 bcf::Writer, mod.rs:178-600): one record per locus of the table.  `header_text`: the VCF
+// header (## lines and #CHROM line with the sample names); out_names[n_out]: names of the columns of ln_posterior
+// ("absent", events..., "artifact").  `path` ending in ".bcf" -> BCF2 in BGZF blocks, otherwise text VCF.
+int vlr_calls_write(const char* path, const char* header_text, const vlr_obs_table* t, const vlr_results* r, const char* const* out_names, int n_threads) {
+    if (!path || !header_text || !t || !r || !out_names) return ifail(VLR_ERR_INVALID_ARGUMENT, "null argument");
+    if (r->n_loci < t->n_loci || r->n_samples != t->n_samples || !r->ln_posterior || !r->map_vaf || !r->status)
+        return ifail(VLR_ERR_INVALID_ARGUMENT, "results do not match the table");
+    n_threads = pick_threads(n_threads);
+    const size_t plen = strlen(path);
+    const bool bcf = plen > 4 && strcmp(path + plen - 4, ".bcf") == 0;
+    const int S = t->n_samples, n_out = r->n_out;
+    const int64_t L = t->n_loci;
+    OutHeader h;
+    build_out_header(header_text, h);
+    static const char* kFmt[13] = {"DP", "AF", "SAOBS", "SROBS", "OBS", "OOBS", "SB", "ROB", "RPB", "SCB", "HE", "ALB", "AFD"};
+    std::vector<int> tag_key((size_t)n_out), fmt_key(13);
+    std::vector<std::string> tags((size_t)n_out);
+    for (int i = 0; i < n_out; ++i) {
+        std::string u = out_names[i];
+        for (auto& c : u) c = (char)toupper(c);
+        tags[(size_t)i] = "PROB_" + u;
+        auto it = h.dict.find(tags[(size_t)i]);
+        if (bcf && it == h.dict.end()) return ifail(VLR_ERR_INVALID_ARGUMENT, "INFO key %s not in the header", tags[(size_t)i].c_str());
+        tag_key[(size_t)i] = bcf ? it->second : 0;
+    }
+    for (int k = 0; k < 13; ++k) {
+        auto it = h.dict.find(kFmt[k]);
+        if (bcf && it == h.dict.end()) return ifail(VLR_ERR_INVALID_ARGUMENT, "FORMAT key %s not in the header", kFmt[k]);
+        fmt_key[(size_t)k] = bcf ? it->second : 0;
+    }
+    std::vector<int> contig_idx(t->contig_names.size(), -1);
+    for (size_t i = 0; i < t->contig_names.size(); ++i) {
+        auto it = h.contigs.find(t->contig_names[i]);
+        if (it != h.contigs.end()) contig_idx[i] = it->second;
+    }
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, (L + 63) / 64));
+    std::vector<std::vector<uint8_t>> parts((size_t)T + 1);
+    std::vector<std::string> errs((size_t)T);
+    if (bcf) {
+        auto& p0 = parts[0];
+        p0.insert(p0.end(), {'B', 'C', 'F', 2, 2});
+        put_u32(p0, (uint32_t)h.text.size() + 1);
+        p0.insert(p0.end(), h.text.begin(), h.text.end());
+        p0.push_back(0);
+    } else {
+        std::string ht;  // text output carries the caller's header verbatim (no PASS line added)
+        ht = header_text;
+        if (ht.empty() || ht.back() != '\n') ht.push_back('\n');
+        parts[0].assign(ht.begin(), ht.end());
+    }
+    const double LN10 = std::log(10.0);
+    parallel_ranges(L, T, [&](int64_t b, int64_t e, int w) {
+        std::vector<uint8_t>& out = parts[(size_t)w + 1];
+        std::vector<SampleFields> sf((size_t)S);
+        std::vector<uint8_t> shared, indiv;
+        std::vector<int> order((size_t)n_out);
+        for (int64_t l = b; l < e; ++l) {
+            const bool missing = r->status[l] & VLR_LOCUS_MISSING_DATA;
+            const double* lp = r->ln_posterior + l * n_out;
+            for (int i = 0; i < n_out; ++i) order[(size_t)i] = i;
+            // mod.rs:231: sorted by descending probability (NaN last)
+            std::stable_sort(order.begin(), order.end(), [&](int a, int c) {
+                const double ka = lp[a] == lp[a] ? -lp[a] : INFINITY, kc = lp[c] == lp[c] ? -lp[c] : INFINITY;
+                return ka < kc;
+            });
+            if (!missing) for (int s = 0; s < S; ++s) sample_fields(t, r, l, s, sf[(size_t)s]);
+            const char* cid = t->pool.c_str() + t->id_off[(size_t)l];
+            const char* ref = t->pool.c_str() + t->ref_off[(size_t)l];
+            const char* alt = t->pool.c_str() + t->alt_off[(size_t)l];
+            const int ci = t->contig[(size_t)l];
+            if (!bcf) {
+                std::string line = (ci >= 0 && (size_t)ci < t->contig_names.size()) ? t->contig_names[(size_t)ci] : std::to_string(ci);
+                line += "\t" + std::to_string(t->pos[(size_t)l]) + "\t.\t" + ref + "\t" + alt + "\t.\t.\t";
+                for (int k = 0; k < n_out; ++k) {
+                    const int i = order[(size_t)k];
+                    if (k) line.push_back(';');
+                    line += tags[(size_t)i] + "=" + (missing ? std::string(".") : fmt_g((float)std::fabs(-10.0 * lp[i] / LN10)));
+                }
+                line += "\tDP:AF:SAOBS:SROBS:OBS:OOBS:SB:ROB:RPB:SCB:HE:ALB:AFD";
+                for (int s = 0; s < S; ++s) {
+                    line.push_back('\t');
+                    if (missing) { line += "0:.:.:.:.:.:.:.:.:.:.:.:."; continue; }
+                    const SampleFields& f = sf[(size_t)s];
+                    line += std::to_string(f.dp) + ":" + fmt_g(f.af) + ":" + (f.saobs.empty() ? "." : f.saobs) + ":" + (f.srobs.empty() ? "." : f.srobs) + ":" +
+                            (f.obs.empty() ? "." : f.obs) + ":" + std::to_string(f.oobs);
+                    for (int k = 0; k < 6; ++k) line += ":" + f.sym[k];
+                    line += ":" + f.afd;
+                }
+                line.push_back('\n');
+                out.insert(out.end(), line.begin(), line.end());
+                (void)cid;
+                continue;
+            }
+            if (ci < 0 || (size_t)ci >= contig_idx.size() || contig_idx[(size_t)ci] < 0) { errs[(size_t)w] = "contig of record " + std::to_string(l + 1) + " not in the header"; return; }
+            shared.clear(); indiv.clear();
+            put_str(shared, "", 0);  // ID "."
+            put_str(shared, ref, strlen(ref));
+            uint32_t n_allele = 1;
+            if (strcmp(alt, ".") != 0) {
+                const char* a = alt;
+                while (true) {
+                    const char* comma = strchr(a, ',');
+                    put_str(shared, a, comma ? (size_t)(comma - a) : strlen(a));
+                    ++n_allele;
+                    if (!comma) break;
+                    a = comma + 1;
+                }
+            }
+            shared.push_back(0x00);  // FILTER: none
+            for (int k = 0; k < n_out; ++k) {
+                const int i = order[(size_t)k];
+                put_typed_int_scalar(shared, tag_key[(size_t)i]);
+                shared.push_back(0x15);
+                uint32_t bits = 0x7F800001u;  // missing
+                if (!missing && lp[i] == lp[i]) { const float v = (float)std::fabs(-10.0 * lp[i] / LN10); memcpy(&bits, &v, 4); }
+                put_u32(shared, bits);
+            }
+            // FORMAT
+            auto fmt_ints = [&](int key, auto get) {
+                put_typed_int_scalar(indiv, fmt_key[(size_t)key]);
+                int32_t lo = 0, hi = 0;
+                for (int s = 0; s < S; ++s) { lo = std::min(lo, get(s)); hi = std::max(hi, get(s)); }
+                const int ty = int_type_for(lo, hi);
+                put_desc(indiv, 1, ty);
+                for (int s = 0; s < S; ++s) {
+                    const int32_t v = get(s);
+                    if (ty == 1) indiv.push_back((uint8_t)(int8_t)v);
+                    else if (ty == 2) { indiv.push_back((uint8_t)(v & 0xff)); indiv.push_back((uint8_t)((v >> 8) & 0xff)); }
+                    else put_u32(indiv, (uint32_t)v);
+                }
+            };
+            auto fmt_strs = [&](int key, auto get) {
+                put_typed_int_scalar(indiv, fmt_key[(size_t)key]);
+                size_t n = 0;
+                for (int s = 0; s < S; ++s) n = std::max(n, get(s).size());
+                put_desc(indiv, (uint32_t)n, 7);
+                for (int s = 0; s < S; ++s) { const std::string v = get(s); indiv.insert(indiv.end(), v.begin(), v.end()); indiv.insert(indiv.end(), n - v.size(), (uint8_t)0); }
+            };
+            const std::string dot(".");
+            fmt_ints(0, [&](int s) { return missing ? 0 : sf[(size_t)s].dp; });
+            put_typed_int_scalar(indiv, fmt_key[1]);
+            put_desc(indiv, 1, 5);
+            for (int s = 0; s < S; ++s) {
+                uint32_t bits = 0x7F800001u;
+                if (!missing && sf[(size_t)s].af == sf[(size_t)s].af) memcpy(&bits, &sf[(size_t)s].af, 4);
+                put_u32(indiv, bits);
+            }
+            fmt_strs(2, [&](int s) { return (missing || sf[(size_t)s].saobs.empty()) ? dot : sf[(size_t)s].saobs; });
+            fmt_strs(3, [&](int s) { return (missing || sf[(size_t)s].srobs.empty()) ? dot : sf[(size_t)s].srobs; });
+            fmt_strs(4, [&](int s) { return (missing || sf[(size_t)s].obs.empty()) ? dot : sf[(size_t)s].obs; });
+            if (missing) fmt_strs(5, [&](int) { return dot; });  // "." in an Integer field: callsfmt writes the missing value
+            else fmt_ints(5, [&](int s) { return sf[(size_t)s].oobs; });
+            for (int k = 0; k < 6; ++k) fmt_strs(6 + k, [&](int s) { return missing ? dot : sf[(size_t)s].sym[k]; });
+            fmt_strs(12, [&](int s) { return missing ? dot : sf[(size_t)s].afd; });
+            const uint32_t l_shared = 24 + (uint32_t)shared.size(), l_indiv = (uint32_t)indiv.size();
+            put_u32(out, l_shared); put_u32(out, l_indiv);
+            put_u32(out, (uint32_t)contig_idx[(size_t)ci]);
+            put_u32(out, (uint32_t)(t->pos[(size_t)l] - 1));
+            put_u32(out, (uint32_t)strlen(ref));
+            put_u32(out, 0x7F800001u);  // QUAL missing
+            put_u32(out, (n_allele << 16) | (uint32_t)n_out);
+            put_u32(out, (13u << 24) | (uint32_t)S);
+            out.insert(out.end(), shared.begin(), shared.end());
+            out.insert(out.end(), indiv.begin(), indiv.end());
+        }
+    });
+    for (auto& e : errs)
+        if (!e.empty()) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s", e.c_str());
+    std::string err;
+    if (bcf) {
+        std::vector<const std::vector<uint8_t>*> ps;
+        for (auto& p : parts) ps.push_back(&p);
+        if (!write_bgzf_file(path, ps, n_threads, 6, err)) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s", err.c_str());
+        return VLR_OK;
+    }
+    FILE* f = fopen(path, "wb");
+    if (!f) return ifail(VLR_ERR_INVALID_ARGUMENT, "cannot create %s", path);
+    bool ok = true;
+    for (auto& p : parts) ok = ok && fwrite(p.data(), 1, p.size(), f) == p.size();
+    ok = (fclose(f) == 0) && ok;
+    return ok ? VLR_OK : ifail(VLR_ERR_INVALID_ARGUMENT, "write failed on %s", path);
+}
+
+// write_observations (preprocessing/mod.rs:921-1038) for one sample of a host batch: the observation BCF that `call variants`
+// reads.  Used by bench.py --workload cli (synthetic pileups -> files) and by the round-trip tests; alleles are synthesised from
+// variant_type / ref_base / alt_base when `sites` is NULL (SNV: the bases; MNV: AC>GT; indel: A>AT; SV: N><DUP>; other: N><METH>).
+int vlr_obs_write(const char* path, const vlr_batch* in, int sample, const vlr_obs_sites* sites, const int32_t* third_allele_evidence, int n_threads) {
+    if (!path || !in || sample < 0 || sample >= in->n_samples) return ifail(VLR_ERR_INVALID_ARGUMENT, "bad argument");
+    n_threads = pick_threads(n_threads);
+    const int S = in->n_samples;
+    const int64_t L = in->n_loci;
+    static const char* kInfo[FD_N_VEC + 1] = {"FRAGMENT_ID", "PROB_MAPPING", "PROB_REF", "PROB_ALT", "PROB_MISSED_ALLELE", "PROB_SAMPLE_ALT", "PROB_DOUBLE_OVERLAP",
+                                              "STRAND", "READ_ORIENTATION", "SOFTCLIPPED", "PAIRED", "READ_POSITION", "PROB_HIT_BASE", "IS_MAX_MAPQ", "ALT_LOCUS",
+                                              "THIRD_ALLELE_EVIDENCE", "PROB_HOMOPOLYMER_ARTIFACT_OBSERVABLE", "PROB_HOMOPOLYMER_VARIANT_OBSERVABLE", "HOMOPOLYMER_INDEL_LEN"};
+    std::string text = "##fileformat=VCFv4.2\n##FILTER=<ID=PASS,Description=\"All filters passed\">\n";
+    std::vector<std::string> contigs;
+    if (sites) for (int i = 0; i < sites->n_contigs; ++i) contigs.push_back(sites->contig_names[i]);
+    else contigs.push_back("1");
+    for (auto& c : contigs) text += "##contig=<ID=" + c + ">\n";
+    text += "##varlociraptor_observation_format_version=15\n";
+    for (int k = 0; k < FD_N_VEC + 1; ++k) text += std::string("##INFO=<ID=") + kInfo[k] + ",Number=.,Type=Integer,Description=\"Varlociraptor observations (binary encoded, meant for internal use only).\">\n";
+    text += "##INFO=<ID=IMPRECISE,Number=0,Type=Flag,Description=\"Imprecise structural variation\">\n";
+    text += "##INFO=<ID=EVENT,Number=1,Type=String,Description=\"ID of event associated to breakend\">\n";
+    text += "##INFO=<ID=MATEID,Number=1,Type=String,Description=\"ID of mate breakend\">\n";
+    text += "##INFO=<ID=HETEROZYGOSITY,Number=A,Type=Float,Description=\"PHRED scaled expected heterozygosity\">\n";
+    text += "##INFO=<ID=SOMATIC_EFFECTIVE_MUTATION_RATE,Number=A,Type=Float,Description=\"PHRED scaled expected somatic effective mutation rate\">\n";
+    text += "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n";
+    const int key0 = 1;  // PASS = 0, then the INFO lines in order
+    const int key_imprecise = key0 + FD_N_VEC + 1, key_het = key_imprecise + 3, key_som = key_imprecise + 4;
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, (L + 63) / 64));
+    std::vector<std::vector<uint8_t>> parts((size_t)T + 1);
+    {
+        auto& p0 = parts[0];
+        p0.insert(p0.end(), {'B', 'C', 'F', 2, 2});
+        put_u32(p0, (uint32_t)text.size() + 1);
+        p0.insert(p0.end(), text.begin(), text.end());
+        p0.push_back(0);
+    }
+    parallel_ranges(L, T, [&](int64_t b, int64_t e, int w) {
+        std::vector<uint8_t>& out = parts[(size_t)w + 1];
+        std::vector<uint8_t> enc, shared;
+        std::vector<int32_t> words;
+        for (int64_t l = b; l < e; ++l) {
+            const uint32_t o0 = in->obs_offset[l * S + sample], o1 = in->obs_offset[l * S + sample + 1];
+            const uint32_t n = o1 - o0;
+            shared.clear();
+            std::string ref, alt, id = "";
+            int32_t contig = 0;
+            int64_t pos = l + 1;
+            if (sites) {
+                contig = sites->contig[l]; pos = sites->pos[l];
+                ref = sites->strings + sites->ref_offset[l]; alt = sites->strings + sites->alt_offset[l];
+                id = sites->strings + sites->id_offset[l];
+                if (id == ".") id.clear();
+            } else {
+                const int vt = in->variant_type ? in->variant_type[l] : VLR_VT_SNV;
+                if (vt == VLR_VT_SNV) { ref = std::string(1, (char)(in->ref_base && in->ref_base[l] ? in->ref_base[l] : 'A')); alt = std::string(1, (char)(in->alt_base && in->alt_base[l] ? in->alt_base[l] : 'C')); }
+                else if (vt == VLR_VT_MNV) { ref = "AC"; alt = "GT"; }
+                else if (vt == VLR_VT_INDEL) { ref = "A"; alt = "AT"; }
+                else if (vt == VLR_VT_SV) { ref = "N"; alt = "<DUP>"; }
+                else { ref = "N"; alt = "<METH>"; }
+            }
+            put_str(shared, id.data(), id.size());
+            put_str(shared, ref.data(), ref.size());
+            uint32_t n_allele = 1;
+            if (alt != ".") { put_str(shared, alt.data(), alt.size()); n_allele = 2; }
+            shared.push_back(0x00);
+            uint32_t n_info = 0;
+            auto push = [&](int field_index) {  // push_values: bytes -> LE u16 words as i32 (mod.rs:978-1000)
+                if (enc.size() & 1) enc.push_back(0);
+                words.resize(enc.size() / 2);
+                for (size_t i = 0; i < words.size(); ++i) words[i] = enc[2 * i] | (enc[2 * i + 1] << 8);
+                put_typed_int_scalar(shared, key0 + field_index);
+                put_int_vec(shared, words.data(), (uint32_t)words.size());
+                ++n_info;
+            };
+            auto u64le = [&](uint64_t v) { for (int i = 0; i < 8; ++i) enc.push_back((uint8_t)(v >> (8 * i))); };
+            auto u32le = [&](uint32_t v) { for (int i = 0; i < 4; ++i) enc.push_back((uint8_t)(v >> (8 * i))); };
+            auto mini = [&](float v) {  // MiniLogProb::new (utils/mod.rs:455-463)
+                const uint16_t hbits = float_to_half(v);
+                const double proj = half_to_float(hbits);
+                if ((double)v < -10.0 && std::floor(proj) == std::floor((double)v)) { u32le(0); enc.push_back((uint8_t)(hbits & 0xff)); enc.push_back((uint8_t)(hbits >> 8)); }
+                else { u32le(1); uint32_t bits; memcpy(&bits, &v, 4); u32le(bits); }
+            };
+            auto minicol = [&](const float* col, int field_index) { enc.clear(); u64le(n); for (uint32_t i = 0; i < n; ++i) mini(col[o0 + i]); push(field_index); };
+            auto enumcol = [&](int field_index, auto get) { enc.clear(); u64le(n); for (uint32_t i = 0; i < n; ++i) u32le(get(in->flags[o0 + i])); push(field_index); };
+            auto bitcol = [&](int field_index, uint32_t flag) {  // bv::BitVec<u8>
+                enc.clear();
+                if (n == 0) { enc.push_back(0); u64le(0); push(field_index); return; }
+                enc.push_back(1);
+                const uint64_t nblocks = ((uint64_t)n + 7) / 8;
+                u64le(nblocks);
+                const size_t at = enc.size();
+                enc.resize(at + nblocks, 0);
+                for (uint32_t i = 0; i < n; ++i)
+                    if (in->flags[o0 + i] & flag) enc[at + (i >> 3)] |= (uint8_t)(1u << (i & 7));
+                u64le(n);
+                push(field_index);
+            };
+            enc.clear(); u64le(n); for (uint32_t i = 0; i < n; ++i) enc.push_back(0); push(0);  // FRAGMENT_ID: None
+            minicol(in->prob_mapping, 1); minicol(in->prob_ref, 2); minicol(in->prob_alt, 3); minicol(in->prob_missed_allele, 4);
+            minicol(in->prob_sample_alt, 5); minicol(in->prob_double_overlap, 6);
+            enumcol(7, [](uint32_t f) { return (f >> VLR_F_STRAND_SHIFT) & 3u; });
+            enumcol(8, [](uint32_t f) { const uint32_t o = (f >> VLR_F_ORIENT_SHIFT) & 3u; return o == VLR_ORIENT_F1R2 ? 0u : o == VLR_ORIENT_F2R1 ? 1u : o == VLR_ORIENT_NONE ? 8u : 2u; });
+            bitcol(9, VLR_F_SOFTCLIPPED); bitcol(10, VLR_F_PAIRED);
+            enumcol(11, [](uint32_t f) { return (f & VLR_F_READPOS_MAJOR) ? 0u : 1u; });
+            minicol(in->prob_hit_base, 12);
+            bitcol(13, VLR_F_MAX_MAPQ);
+            enumcol(14, [](uint32_t f) { return (f >> VLR_F_ALTLOCUS_SHIFT) & 3u; });
+            enc.clear(); u64le(n);
+            for (uint32_t i = 0; i < n; ++i) {
+                const int32_t tv = third_allele_evidence ? third_allele_evidence[o0 + i] : -1;
+                if (tv >= 0) { enc.push_back(1); u32le((uint32_t)tv); } else enc.push_back(0);
+            }
+            push(15);
+            bool any_hp = false;
+            if (in->prob_hp_artifact)
+                for (uint32_t i = 0; i < n; ++i) any_hp = any_hp || in->prob_hp_artifact[o0 + i] == in->prob_hp_artifact[o0 + i];
+            if (any_hp) {  // mod.rs:1018-1034: only if any observation carries homopolymer information
+                for (int k = 0; k < 2; ++k) {
+                    const float* col = k == 0 ? in->prob_hp_artifact : in->prob_hp_variant;
+                    enc.clear(); u64le(n);
+                    for (uint32_t i = 0; i < n; ++i) { const float v = col ? col[o0 + i] : NAN; if (v == v) { enc.push_back(1); mini(v); } else enc.push_back(0); }
+                    push(16 + k);
+                }
+                enc.clear(); u64le(n);
+                for (uint32_t i = 0; i < n; ++i) {
+                    const uint32_t f = in->flags[o0 + i];
+                    if (f & VLR_F_HP_LEN_VALID) { enc.push_back(1); enc.push_back((uint8_t)((f >> VLR_F_HP_LEN_SHIFT) & 0xff)); } else enc.push_back(0);
+                }
+                push(18);
+            }
+            // without site data the precision of a record is what its bias mask says (check_strand_bias follows is_precise, calling.rs:559)
+            const bool imprecise = sites ? (sites->imprecise && sites->imprecise[l]) : (in->locus_flags && !(in->locus_flags[l] & VLR_BIAS_STRAND) && (in->locus_flags[l] & VLR_BIAS_ALTLOCUS));
+            if (imprecise) { put_typed_int_scalar(shared, key_imprecise); shared.push_back(0x11); shared.push_back(1); ++n_info; }
+            if (sites && sites->heterozygosity_ln && sites->heterozygosity_ln[l] == sites->heterozygosity_ln[l]) {
+                const float ph = (float)(-10.0 * sites->heterozygosity_ln[l] / std::log(10.0));
+                uint32_t bits; memcpy(&bits, &ph, 4);
+                put_typed_int_scalar(shared, key_het); shared.push_back(0x15); put_u32(shared, bits); ++n_info;
+            }
+            if (sites && sites->somatic_effective_mutation_rate_ln && sites->somatic_effective_mutation_rate_ln[l] == sites->somatic_effective_mutation_rate_ln[l]) {
+                const float ph = (float)(-10.0 * sites->somatic_effective_mutation_rate_ln[l] / std::log(10.0));
+                uint32_t bits; memcpy(&bits, &ph, 4);
+                put_typed_int_scalar(shared, key_som); shared.push_back(0x15); put_u32(shared, bits); ++n_info;
+            }
+            put_u32(out, 24 + (uint32_t)shared.size()); put_u32(out, 0);
+            put_u32(out, (uint32_t)contig); put_u32(out, (uint32_t)(pos - 1)); put_u32(out, (uint32_t)ref.size());
+            put_u32(out, 0x7F800001u);
+            put_u32(out, (n_allele << 16) | n_info);
+            put_u32(out, 0);
+            out.insert(out.end(), shared.begin(), shared.end());
+        }
+    });
+    std::vector<const std::vector<uint8_t>*> ps;
+    for (auto& p : parts) ps.push_back(&p);
+    std::string err;
+    const char* lv = getenv("VLR_BGZF_LEVEL");
+    if (!write_bgzf_file(path, ps, n_threads, lv ? atoi(lv) : 1, err)) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s", err.c_str());
+    return VLR_OK;
+}
+
+}  // extern "C"

@@ -132,7 +132,9 @@ __device__ __forceinline__ ObsRow load_obs_row(const DevBatch& batch, uint32_t i
 #ifdef VLR_NO_UNI  // diagnosis builds: leave uniformity to the compiler's own analysis
 #define UNI(x) (x)
 __device__ __forceinline__ double uni_d(double v) { return v; }
+#define UNI64(x) (x)
 #else
+#define UNI64(x) __double_as_longlong(uni_d(__longlong_as_double(x)))
 #define UNI(x) __builtin_amdgcn_readfirstlane(x)
 __device__ __forceinline__ double uni_d(double v) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
@@ -684,7 +686,7 @@ struct Ctx {
     int nframes, nrs;
     int cap;                         // capacity of one visited-point table
     double *rowX, *rowV;             // [kRows][cap] visited-point tables of the row-parallel innermost chains
-    double* afd_seen;                // replay: [S][kMaxSet] recorded discrete VAFs
+    double* afd_seen;                // replay: [S][kMaxSet] recorded discrete operands: (VAF, l2fc-list key) pairs
     double* mapv;                    // replay: [S] MAP VAF per sample
     int* afd_nseen;                  // replay: [S] discrete VAFs of sample s already recorded (overlapping roots/branches
                                      // visit the same operands; the reference's joint_probs map keeps one entry)
@@ -803,20 +805,35 @@ __device__ inline bool disc_before(int nd, int od) {
     const int diff = nd ^ od;
     return diff != 0 && (nd & diff & -diff) != 0;
 }
+// Two operand sets with the same hypothesis and the same VAF tuple have the same joint probability whatever their is_discrete
+// flags (prior and likelihood depend on the VAFs only; a failed l2fc predicate makes it -inf).  The engine evaluates a VAF reached
+// as a chain point and as a Set member along different code paths whose results may differ in the last bits, the reference (and
+// the oracle) take both from one cache: such a pair is an exact tie there, broken by the flags.  Joints within 1e-9 relative are
+// candidates for that test; for distinct VAF tuples the plain comparison stands.
+__device__ __forceinline__ bool same_joint(double a, double b) {
+    return a == b || (fabs(a - b) <= 1e-9 * fabs(b) && fabs(b) < 1.7e308);
+}
 __device__ inline void map_consider(Ctx& c, double joint, int inner, double x) {
     joint = uni_d(joint); x = uni_d(x); inner = UNI(inner);
     if (!(joint == joint)) return;
     bool better = joint > c.curJ;
-    if (!better && joint == c.curJ && c.curHyp >= 0) {
-        if (c.hyp != (c.curHyp & 15)) better = c.hyp < (c.curHyp & 15);
+    if (c.curHyp >= 0 && same_joint(joint, c.curJ)) {
+        if (c.hyp != (c.curHyp & 15)) { if (joint == c.curJ) better = c.hyp < (c.curHyp & 15); }
         else {
             bool same = true;
             for (int s = 0; s < c.S; ++s) {
                 double v = (s == inner) ? x : c.w->ops_vaf[s];
                 double o = c.w->curMapVaf[s];
-                if (v != o) { better = v < o; same = false; break; }
+                if (v != o) { if (joint == c.curJ) better = v < o; same = false; break; }
             }
-            if (same) better = disc_before((inner >= 0) ? (c.disc & ~(1 << inner)) : c.disc, c.curHyp >> 4);
+            if (same) {  // same operands up to the flags: the flags decide, whatever the last bits of the two evaluations say
+                const int nd = (inner >= 0) ? (c.disc & ~(1 << inner)) : c.disc, od = c.curHyp >> 4;
+                if (nd != od) {
+                    better = disc_before(nd, od);
+                    joint = fmax(joint, c.curJ);  // one value in the reference; the slot keeps the larger of the two evaluations
+                    c.curJ = joint;
+                }
+            }
         }
     }
     if (c.curHyp < 0) better = true;
@@ -936,16 +953,23 @@ __device__ inline void cross_consider(Ctx& c, int g, double joint, int inner, do
     double curJ = uni_d(c.mapJ[slot]);
     int curHyp = UNI(c.mapHyp[slot]);
     bool better = curHyp < 0 || joint > curJ;
-    if (!better && joint == curJ) {
-        if (c.hyp != (curHyp & 15)) better = c.hyp < (curHyp & 15);
+    if (curHyp >= 0 && same_joint(joint, curJ)) {
+        if (c.hyp != (curHyp & 15)) { if (joint == curJ) better = c.hyp < (curHyp & 15); }
         else {
             bool same = true;
             for (int s = 0; s < c.S; ++s) {
                 double v = (s == inner) ? x : c.w->ops_vaf[s];
                 double o = c.mapVaf[slot * c.S + s];
-                if (v != o) { better = v < o; same = false; break; }
+                if (v != o) { if (joint == curJ) better = v < o; same = false; break; }
             }
-            if (same) better = disc_before((inner >= 0) ? (c.disc & ~(1 << inner)) : c.disc, curHyp >> 4);
+            if (same) {
+                const int nd = (inner >= 0) ? (c.disc & ~(1 << inner)) : c.disc, od = curHyp >> 4;
+                if (nd != od) {
+                    better = disc_before(nd, od);
+                    joint = fmax(joint, curJ);
+                    if (!better && joint > curJ) { __syncthreads(); if (c.lane == 0) c.mapJ[slot] = joint; __syncthreads(); }
+                }
+            }
         }
     }
     if (better) {
@@ -1149,6 +1173,21 @@ __device__ inline double eval_discrete_root(Ctx& c, int l0, int l1) {
 // AFD replay (calling.rs:889-928): record (VAF of sample s, posterior density) of every clean operand set that
 // equals the MAP on all other samples (allele_freq, artifacts, is_discrete) and is contained in the best event
 // with sample s excluded.
+// The l2fc terms on the path are part of the reference's map key (LikelihoodOperands::lfcs, modes/generic.rs:116-121): two operand
+// sets with equal VAFs and flags but different l2fc lists are two entries of joint_probs and appear twice in an AFD list.  A 64-bit
+// hash of the ordered list stands for it (0 = no terms).
+__device__ inline long long lfc_ctx_key(const Ctx& c) {
+    unsigned long long h = 0;
+    for (int i = 0; i < c.nlfc; ++i) {
+        const unsigned long long t = (unsigned long long)(unsigned)c.w->lfc_a[i] | ((unsigned long long)(unsigned)c.w->lfc_b[i] << 8) |
+                                     ((unsigned long long)(unsigned)c.w->lfc_cmp[i] << 16) | ((unsigned long long)(i + 1) << 24);
+        h = (h ^ t) * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 29;
+        h = (h ^ (unsigned long long)__double_as_longlong(c.w->lfc_val[i])) * 0xBF58476D1CE4E5B9ull;
+        h ^= h >> 32;
+    }
+    return c.nlfc ? (long long)(h | 1ull) : 0ll;
+}
 __device__ inline void afd_consider(Ctx& c, double joint, int inner, double x, int skip_sample = -1) {
     if (c.hyp != 0 || c.afd_mute) return;
     int mism = 0, ms = -1;
@@ -1159,18 +1198,23 @@ __device__ inline void afd_consider(Ctx& c, double joint, int inner, double x, i
         if (!eq) { mism++; ms = s; }
     }
     if (mism >= 2) return;
+    const long long lkey = UNI64(lfc_ctx_key(c));
     for (int s = 0; s < c.S; ++s) {
         if (mism == 1 && s != ms) continue;
         if (s == skip_sample) continue;  // vlr_afd_kernel has written this sample's entries of the record in bulk
         if (!group_contains(c, c.mapGroup, inner, x, s)) continue;
         const double vs = (s == inner) ? x : c.w->ops_vaf[s];
-        if ((disc >> s) & 1) {  // discrete operand for s: the whole operand set is a repeat if this VAF was recorded before
+        if ((disc >> s) & 1) {  // discrete operand for s: the whole operand set is a repeat if this (VAF, l2fc list) was recorded before
             int ns = c.afd_nseen[s];
             bool seen = false;
-            for (int i = 0; i < ns; ++i) seen = seen || (c.afd_seen[s * kMaxSet + i] == vs);
+            for (int i = 0; i < ns; ++i)
+                seen = seen || (c.afd_seen[2 * (s * kMaxSet + i)] == vs && __double_as_longlong(c.afd_seen[2 * (s * kMaxSet + i) + 1]) == lkey);
             if (seen) continue;
             __syncthreads();
-            if (c.lane == 0 && ns < kMaxSet) { c.afd_seen[s * kMaxSet + ns] = vs; c.afd_nseen[s] = ns + 1; }
+            if (c.lane == 0 && ns < kMaxSet) {
+                c.afd_seen[2 * (s * kMaxSet + ns)] = vs; c.afd_seen[2 * (s * kMaxSet + ns) + 1] = __longlong_as_double(lkey);
+                c.afd_nseen[s] = ns + 1;
+            }
             __syncthreads();
         }
         if (c.lane == 0) {
@@ -1183,6 +1227,7 @@ __device__ inline void afd_consider(Ctx& c, double joint, int inner, double x, i
                 if ((disc >> s) & 1) v = __hiloint2double(__double2hiint(v) | (int)0x80000000, __double2loint(v));
                 o.afd_vaf[slot * o.afd_capacity + idx] = v;
                 o.afd_lnprob[slot * o.afd_capacity + idx] = joint - c.marginal;
+                o.afd_key[slot * o.afd_capacity + idx] = lkey;
             }
         }
     }
@@ -1190,7 +1235,7 @@ __device__ inline void afd_consider(Ctx& c, double joint, int inner, double x, i
 
 // End of the replay pass: the reference's joint_probs is ONE map per record keyed by the operands, so an operand set
 // visited from several events / roots (overlapping events, the same Range point reached along two branches) has a
-// single AFD entry.  Entries of sample s are keyed by (VAF, is_discrete) — the other samples equal the MAP by
+// single AFD entry.  Entries of sample s are keyed by (VAF, is_discrete, l2fc list) — the other samples equal the MAP by
 // construction; the first occurrence is kept.
 __device__ inline void afd_finish(Ctx& c) {
     const DevResults& o = *c.outp;
@@ -1203,23 +1248,24 @@ __device__ inline void afd_finish(Ctx& c) {
         if (cnt <= 0) continue;
         double* vv = o.afd_vaf + slot * o.afd_capacity;
         double* pp = o.afd_lnprob + slot * o.afd_capacity;
+        long long* kk = o.afd_key + slot * o.afd_capacity;
         if (cnt <= o.afd_capacity) {
             int kept = 0;
             for (int base = 0; base < cnt; base += 64) {
                 const int i = base + c.lane;
                 const bool on = i < cnt;
                 const double v = on ? vv[i] : 0.0, pr = on ? pp[i] : 0.0;
-                const long long key = __double_as_longlong(v);
+                const long long key = __double_as_longlong(v), lk = on ? kk[i] : 0ll;
                 bool dup = false;
-                for (int j = 0; j < kept; ++j) dup = dup | (__double_as_longlong(vv[j]) == key);  // compacted prefix (earlier chunks)
+                for (int j = 0; j < kept; ++j) dup = dup | ((__double_as_longlong(vv[j]) == key) & (kk[j] == lk));  // compacted prefix (earlier chunks)
                 for (int j = base; j < base + 64 && j < cnt; ++j) {                                  // earlier entries of this chunk
-                    const long long kj = __shfl(key, j - base);
-                    dup = dup | ((j < i) & (kj == key));
+                    const long long kj = __shfl(key, j - base), lj = __shfl(lk, j - base);
+                    dup = dup | ((j < i) & (kj == key) & (lj == lk));
                 }
                 const unsigned long long keep = __ballot(on & !dup);
                 const int pos = kept + __popcll(keep & ((1ull << c.lane) - 1ull));
                 VLR_WG_FENCE();
-                if (on & !dup) { vv[pos] = v; pp[pos] = pr; }
+                if (on & !dup) { vv[pos] = v; pp[pos] = pr; kk[pos] = lk; }
                 VLR_WG_FENCE();
                 kept += __popcll(keep);
             }
@@ -2485,7 +2531,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
         pc = PC_BO_POST;
     } else {
         c.present = 0; c.disc = 0; c.nlfc = 0; c.contained = 1; c.afd_mute = 0;
-        c.alive = ((1 << (p.n_named + 1)) - 1) & ~(1 << c.group);
+        c.alive = (int)((1u << (p.n_named + 1)) - 1u) & ~(1 << c.group);  // n_named <= kMaxNamedEvents = 30: no shift reaches the sign bit
     }
     for (;;) {
         if (pc == PC_DESCEND) {
@@ -2819,7 +2865,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
 //   3. discrete leaves: classified one per lane, matches through afd_consider.
 __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, DevBatch batch, DevResults out) {
     __shared__ WaveSt wst;
-    __shared__ double sh_seen[kMaxSamples * kMaxSet];
+    __shared__ double sh_seen[2 * kMaxSamples * kMaxSet];  // (VAF, l2fc key) pairs
     __shared__ double sh_mapv[kMaxSamples];
     __shared__ int sh_nseen[kMaxSamples];
     const DevPlan& p = plan_arg;
@@ -2931,6 +2977,7 @@ __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, Dev
         const double* V = X + n_r;
         const double mx = uni_d(sh_mapv[sin_r]);
         const bool bulk = m_r == 0 && group_contains(c, c.mapGroup, sin_r, 0.0, sin_r);  // the integrated sample is excluded: x does not matter
+        const long long lkey_r = UNI64(lfc_ctx_key(c));
         for (int q0 = 0; q0 < n_r; q0 += 64) {
             const int q = q0 + lane;
             const bool on = q < n_r;
@@ -2949,6 +2996,7 @@ __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, Dev
                 if (emit && idx < out.afd_capacity) {
                     out.afd_vaf[slot * out.afd_capacity + idx] = xq;  // continuous operand: no discrete marker
                     out.afd_lnprob[slot * out.afd_capacity + idx] = vq - c.marginal;
+                    out.afd_key[slot * out.afd_capacity + idx] = lkey_r;
                 }
             }
             // the other samples' lists: only operand sets that equal the MAP in the integrated sample as well
@@ -3005,9 +3053,9 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
     c.cacheA = c.setv + S * p.max_set;      // [S][kCacheWays] x 3   (setv: [S][max_set], the plan's largest Set spectrum)
     c.cacheB = c.cacheA + S * kCacheWays;
     c.cacheV = c.cacheB + S * kCacheWays;
-    c.afd_seen = c.cacheV + S * kCacheWays;  // [S][kMaxSet]
-    const int n_seen = out.replay ? S * kMaxSet + 2 * S : 0;  // only the AFD replay pass records discrete VAFs
-    c.mapv = c.afd_seen + S * kMaxSet;
+    c.afd_seen = c.cacheV + S * kCacheWays;  // [S][kMaxSet] x (VAF, l2fc key)
+    const int n_seen = out.replay ? 2 * S * kMaxSet + 2 * S : 0;  // only the AFD replay pass records discrete VAFs
+    c.mapv = c.afd_seen + 2 * S * kMaxSet;
     c.afd_nseen = (int*)(c.mapv + S);
     int* mapHyp = (int*)(c.afd_seen + n_seen);  // [n_slots]
     c.dkeyV = c.afd_seen + n_seen + (n_slots + 1) / 2 + 2;  // [n_dkey]
@@ -3716,7 +3764,7 @@ extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_host, const vlr::
     size_t n_slots = (size_t)n_univ + 1;
     size_t cap = (size_t)plan_host->table_cap;
     size_t dbl = (size_t)2 * max_obs + (size_t)2 * plan_host->max_tab_depth * cap + (size_t)2 * kRows * cap + (size_t)kRows * n_samples +
-                 (size_t)2 * n_univ + n_slots + n_slots * n_samples + (size_t)n_samples * plan_host->max_set + (size_t)(out->replay ? n_samples * kMaxSet + 2 * n_samples : 0) + (size_t)3 * n_samples * kCacheWays +
+                 (size_t)2 * n_univ + n_slots + n_slots * n_samples + (size_t)n_samples * plan_host->max_set + (size_t)(out->replay ? 2 * n_samples * kMaxSet + 2 * n_samples : 0) + (size_t)3 * n_samples * kCacheWays +
                  (n_slots + 1) / 2 + 2 + (size_t)plan_host->n_dkey +
                  ((size_t)plan_host->max_frames * sizeof(Frame) + (size_t)range_depth * sizeof(RangeSt) + 7) / 8;
     size_t bytes = dbl * sizeof(double);

@@ -12,7 +12,7 @@ constexpr int kTableCap = 128;        // upper limit of visited points of one ra
                                       // the per-plan capacity is derived from the finest resolution
 constexpr int kMaxRangeDepth = 4;     // nested Range levels on one path
 constexpr int kMaxSet = 16;           // members of one Set spectrum
-constexpr int kMaxNamedEvents = 31;   // scenario events (engine universe = 1 + 2*named)
+constexpr int kMaxNamedEvents = 30;   // scenario events (engine universe = 1 + 2*named); 1 + named event groups fit the 31 value bits of the int32 alive masks
 constexpr int kNHyp = 9;              // 0 = Artifacts::none(), 1..8 single-artifact combinations
 constexpr int kCacheWays = 4;         // per-sample pileup-likelihood cache entries
 constexpr int kMaxBatchPoints = 16;   // points evaluated by one eval_pileup call
@@ -120,6 +120,8 @@ struct DevResults {
     int32_t* afd_count;     // [n_loci * S]
     double* afd_vaf;        // [n_loci * S * afd_capacity]
     double* afd_lnprob;     // [n_loci * S * afd_capacity]
+    long long* afd_key;     // [n_loci * S * afd_capacity] l2fc-list key of every AFD entry (kernel scratch, plan-owned): part of the
+                            // reference's map key, so equal VAFs under different l2fc lists stay two entries
     int32_t afd_capacity;
     int32_t replay;         // 0: call pass, 1: AFD replay pass
     double* escratch;       // [n_loci * max_obs] third likelihood coefficient per kept observation (kernel scratch, plan-owned)

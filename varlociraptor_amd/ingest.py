@@ -1,0 +1,154 @@
+"""Native ingest / emission at the process boundary (csrc/vlr_ingest.cpp behind include/vlr.h): observation BCF/VCF files
+-> PileupBatch whose columns are views of the table's page-locked arrays; results -> calls BCF/VCF.
+
+Replaces, on the product path, the Python decoder (obsfmt.py), BCF reader/writer (bcfio.py) and record formatter
+(callsfmt.py), which stay as the independent restatement the tests compare against (reference: calling.rs:306-339,
+preprocessing/mod.rs:818-1038, calling/variants/mod.rs:178-600).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import abi, engine
+from .batch import CallResults, PileupBatch
+
+
+class ObsSites(C.Structure):
+    _fields_ = [
+        ("n_loci", C.c_int64), ("n_contigs", C.c_int32), ("_pad", C.c_int32),
+        ("contig_names", C.POINTER(C.c_char_p)), ("contig", C.c_void_p), ("pos", C.c_void_p), ("strings", C.c_void_p),
+        ("id_offset", C.c_void_p), ("ref_offset", C.c_void_p), ("alt_offset", C.c_void_p),
+        ("group_representative", C.c_void_p), ("heterozygosity_ln", C.c_void_p), ("somatic_effective_mutation_rate_ln", C.c_void_p),
+        ("third_allele_evidence", C.c_void_p), ("imprecise", C.c_void_p),
+    ]
+
+
+def _lib():
+    L = engine.lib()
+    if not getattr(L, "_ingest_typed", False):
+        L.vlr_obs_read.restype = C.c_int
+        L.vlr_obs_read.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
+        L.vlr_obs_table_free.restype = None
+        L.vlr_obs_table_free.argtypes = [C.c_void_p]
+        L.vlr_obs_table_batch.restype = C.c_int
+        L.vlr_obs_table_batch.argtypes = [C.c_void_p, C.POINTER(abi.Batch)]
+        L.vlr_obs_table_sites.restype = C.c_int
+        L.vlr_obs_table_sites.argtypes = [C.c_void_p, C.POINTER(ObsSites)]
+        L.vlr_obs_write.restype = C.c_int
+        L.vlr_obs_write.argtypes = [C.c_char_p, C.POINTER(abi.Batch), C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.vlr_calls_write.restype = C.c_int
+        L.vlr_calls_write.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.POINTER(abi.Results), C.POINTER(C.c_char_p), C.c_int]
+        L._ingest_typed = True
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise engine.EngineError(rc, (engine.lib().vlr_last_error() or b"").decode())
+
+
+def _view(ptr, n, dtype):
+    dt = np.dtype(dtype)
+    if n == 0 or not ptr:
+        return np.zeros(0, dt)
+    buf = (C.c_char * (n * dt.itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dt, count=n)
+
+
+class Sites:
+    """Per-locus site data of a table: arrays (contig index, position, group representative, prior overrides) and strings on
+    demand.  Indexing gives the (chrom, pos, ref, alt) tuple the Python formatter uses."""
+
+    def __init__(self, table: "ObsTable"):
+        s = ObsSites()
+        _check(_lib().vlr_obs_table_sites(table.handle, C.byref(s)))
+        self._table = table
+        n = int(s.n_loci)
+        self.n_loci = n
+        self.contig_names = [s.contig_names[i].decode() for i in range(s.n_contigs)]
+        self.contig = _view(s.contig, n, np.int32)
+        self.pos = _view(s.pos, n, np.int64)
+        self.group_representative = _view(s.group_representative, n, np.int64)
+        self.heterozygosity_ln = _view(s.heterozygosity_ln, n, np.float64)
+        self.somatic_effective_mutation_rate_ln = _view(s.somatic_effective_mutation_rate_ln, n, np.float64)
+        self.imprecise = _view(s.imprecise, n, np.uint8)
+        self._strings = s.strings
+        self._id, self._ref, self._alt = (_view(p, n, np.uint64) for p in (s.id_offset, s.ref_offset, s.alt_offset))
+        self.third_allele_evidence = _view(s.third_allele_evidence, table.n_obs, np.int32)
+
+    def _str(self, off) -> str:
+        return C.string_at(self._strings + int(off)).decode()
+
+    def chrom(self, l: int) -> str:
+        c = int(self.contig[l])
+        return self.contig_names[c] if 0 <= c < len(self.contig_names) else str(c)
+
+    def __len__(self):
+        return self.n_loci
+
+    def __getitem__(self, l: int) -> Tuple[str, int, str, str]:
+        return (self.chrom(l), int(self.pos[l]), self._str(self._ref[l]), self._str(self._alt[l]))
+
+    def record_id(self, l: int) -> str:
+        return self._str(self._id[l])
+
+
+class ObsTable:
+    def __init__(self, handle):
+        self.handle = handle
+        b = abi.Batch()
+        _check(_lib().vlr_obs_table_batch(handle, C.byref(b)))
+        self.n_loci, self.n_samples, self.n_obs = int(b.n_loci), int(b.n_samples), int(b.n_obs)
+        self._struct = b
+
+    def batch(self) -> PileupBatch:
+        b = self._struct
+        cols = {name: _view(getattr(b, name), self.n_obs, dt) for name, dt in abi.OBS_COLUMNS}
+        locus = {name: _view(getattr(b, name), self.n_loci, dt) for name, dt in abi.LOCUS_COLUMNS}
+        pb = PileupBatch(self.n_samples, _view(b.obs_offset, self.n_loci * self.n_samples + 1, np.uint32), cols, locus)
+        pb._table = self  # the views live as long as the table
+        return pb
+
+    def close(self):
+        if self.handle:
+            _lib().vlr_obs_table_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def read_observations(paths: Sequence[str], omit_bias_mask: int = 0, threads: int = 0):
+    """vlr_obs_read: one observation file per sample (sample-index order) -> (PileupBatch, Sites).  batch.extra carries what the
+    Python decoder's does (third_allele_evidence, haplotype groups as representatives, prior overrides as arrays)."""
+    arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+    h = C.c_void_p()
+    _check(_lib().vlr_obs_read(len(paths), arr, int(omit_bias_mask), int(threads), C.byref(h)))
+    table = ObsTable(h)
+    batch = table.batch()
+    sites = Sites(table)
+    batch.extra = {"third_allele_evidence": sites.third_allele_evidence, "group_representative": sites.group_representative,
+                   "prior_het_ln": sites.heterozygosity_ln, "prior_som_ln": sites.somatic_effective_mutation_rate_ln, "native_table": table}
+    return batch, sites
+
+
+def write_observations(path: str, batch: PileupBatch, sample: int, threads: int = 0, third_allele_evidence: Optional[np.ndarray] = None):
+    """vlr_obs_write: the observation BCF of one sample of a host batch (synthetic sites)."""
+    bs = batch.as_struct()
+    third = None
+    if third_allele_evidence is not None:
+        third = np.ascontiguousarray(third_allele_evidence, np.int32)
+    _check(_lib().vlr_obs_write(path.encode(), C.byref(bs), int(sample), None, third.ctypes.data if third is not None else None, int(threads)))
+
+
+def write_calls(path: str, header_text: str, table: ObsTable, results: CallResults, out_names: List[str], threads: int = 0):
+    """vlr_calls_write: calls BCF (path ends in .bcf) or text VCF for the loci of `table`."""
+    rs = results.as_struct()
+    names = (C.c_char_p * len(out_names))(*[n.encode() for n in out_names])
+    _check(_lib().vlr_calls_write(path.encode(), header_text.encode(), table.handle, C.byref(rs), names, int(threads)))
