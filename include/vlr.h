@@ -425,6 +425,10 @@ int  vlr_obs_write(const char* path, const vlr_batch* in, int sample, const vlr_
  * of ln_posterior ("absent", the scenario events, "artifact") — INFO PROB_<NAME>, PHRED, f32, sorted by descending probability. */
 int  vlr_calls_write(const char* path, const char* header_text, const vlr_obs_table* table, const vlr_results* results,
                      const char* const* out_names, int n_threads);
+/* Measurement aid: wall seconds of the stages of the last vlr_obs_read ([0] file reads, [1] BGZF inflate, [2] parse + decode — summed
+ * over the sample files, which run side by side — [3] all files, [4] merge into the table, [5] strings and groups, [6] total) and of
+ * the last vlr_calls_write ([8] record encoding, [9] BGZF deflate + file write, [10] total). */
+void vlr_ingest_last_timings(double* out16);
 
 #ifdef __cplusplus
 }

@@ -20,12 +20,32 @@ class Stats(C.Structure):
 
 def build(force=False):
     so = os.path.join(_HERE, "libvlr_oracle.so")
+    so2 = os.path.join(_HERE, "libvlr_oracle_tuned.so")
     src = os.path.join(_HERE, "vlr_oracle.cpp")
     src2 = os.path.join(_HERE, "vlr_realign_oracle.cpp")
     hdr = os.path.join(_HERE, "..", "include", "vlr.h")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(src2), os.path.getmtime(hdr)):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libvlr_oracle.so"], stdout=subprocess.DEVNULL)
+    newest = max(os.path.getmtime(src), os.path.getmtime(src2), os.path.getmtime(hdr))
+    if force or not os.path.exists(so) or not os.path.exists(so2) or min(os.path.getmtime(so), os.path.getmtime(so2)) < newest:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "all"], stdout=subprocess.DEVNULL)
     return so
+
+
+_LIB_TUNED = None
+
+
+def lib_tuned():
+    """The same source built for AVX2/FMA hosts (-O3 -march=x86-64-v3): only vlro_call_batch_tuned is used from it."""
+    global _LIB_TUNED
+    if _LIB_TUNED is None:
+        so = os.path.join(_HERE, "libvlr_oracle_tuned.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        L.vlro_call_batch_tuned.restype = C.c_int
+        L.vlro_call_batch_tuned.argtypes = [C.POINTER(abi.ScenarioDesc), C.POINTER(abi.Batch), C.POINTER(abi.Results),
+                                            C.c_int64, C.c_int64, C.c_void_p, C.POINTER(Stats)]
+        _LIB_TUNED = L
+    return _LIB_TUNED
 
 
 def lib():
@@ -82,6 +102,19 @@ def pairhmm_prob_related(allele: bytes, read: bytes, qual, gap, max_edit_dist: i
     return float(L.vlro_pairhmm_prob_related(x.ctypes.data, len(allele), y.ctypes.data, q.ctypes.data, len(read), g, int(max_edit_dist)))
 
 
+def pairhmm_prob_related_variant(allele: bytes, read: bytes, qual, gap, max_edit_dist: int = -1, crate_behaviours: int = 7) -> float:
+    """The recursion with the crate behaviours of the oracle's header switched on (bit 0 approximate 3-way sum, bit 1 stale gap
+    states of skipped band cells, bit 2 doubled start mass of the first column)."""
+    L = lib()
+    L.vlro_pairhmm_prob_related_variant.restype = C.c_double
+    L.vlro_pairhmm_prob_related_variant.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int]
+    x = np.frombuffer(bytes(allele) or b"\0", np.uint8)
+    y = np.frombuffer(bytes(read) or b"\0", np.uint8)
+    q = np.asarray(bytearray(qual) or b"\0", np.uint8)
+    g = (C.c_double * 4)(*gap)
+    return float(L.vlro_pairhmm_prob_related_variant(x.ctypes.data, len(allele), y.ctypes.data, q.ctypes.data, len(read), g, int(max_edit_dist), int(crate_behaviours)))
+
+
 def edit_distance(allele: bytes, read: bytes):
     """(dist, end, n_hits) of the semiglobal edit distance of `read` in `allele` (oracle/vlr_realign_oracle.cpp)."""
     L = lib()
@@ -110,8 +143,9 @@ def normalize_support(prob_ref: float, prob_alt: float):
     return r.value, a.value
 
 
-def call(scenario, batch: PileupBatch, afd_capacity: int = 0, begin: int = 0, end: int = None, want_events=False):
-    """Run the restated reference algorithm on loci [begin, end) of a host batch."""
+def call(scenario, batch: PileupBatch, afd_capacity: int = 0, begin: int = 0, end: int = None, want_events=False, tuned=False):
+    """Run the restated reference algorithm on loci [begin, end) of a host batch.  tuned=True: the tuned CPU baseline (affine
+    product form of the pileup likelihood, libvlr_oracle_tuned.so built with -march=x86-64-v3)."""
     L = lib()
     end = batch.n_loci if end is None else end
     desc = scenario.desc()
@@ -119,7 +153,8 @@ def call(scenario, batch: PileupBatch, afd_capacity: int = 0, begin: int = 0, en
     bs, rs = batch.as_struct(), res.as_struct()
     stats = Stats()
     ev = np.full((end - begin, 1 + 2 * len(scenario.event_names)), np.nan) if want_events else None
-    rc = L.vlro_call_batch(C.byref(desc), C.byref(bs), C.byref(rs), begin, end,
+    fn = lib_tuned().vlro_call_batch_tuned if tuned else L.vlro_call_batch
+    rc = fn(C.byref(desc), C.byref(bs), C.byref(rs), begin, end,
                            ev.ctypes.data if ev is not None else None, C.byref(stats))
     if rc != 0:
         raise RuntimeError("oracle failed: %d" % rc)

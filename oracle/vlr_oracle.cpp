@@ -868,6 +868,13 @@ struct Ctx {
     std::vector<JointEntry> joint;
     uint64_t n_lik_evals = 0, n_obs_terms = 0;
     bool nan_seen = false;
+    // "tuned" CPU baseline (vlro_call_batch_tuned): the pileup likelihood in the affine form of SURVEY App. B — per observation
+    // and hypothesis three linear-space coefficients, a pileup evaluation is a product of (c + q*alpha + e*beta) with the binary
+    // exponent taken out every few terms and ONE logarithm at the end; no allocation in the term loop.  Tree walk, prior,
+    // integrator and caches are the fidelity code above.  coef[s][h] is built on first use.
+    bool tuned = false;
+    struct Coef { bool built = false, slow = false, has_e = false; int group = 8; std::vector<double> c, q, e; };
+    std::vector<std::vector<Coef>> coef;
 };
 
 inline uint64_t dbits(double d) { uint64_t u; std::memcpy(&u, &d, 8); return u; }
@@ -920,6 +927,76 @@ inline double lik_obs_contaminated(double purity, double impurity, double ln_af_
                       o.prob_mismapping + o.prob_missed_allele + art_prob_any(ap, o));
 }
 
+// ---- tuned baseline: affine coefficients (the same algebra as the engine's coefficient pass)
+//   w = e^pm, u = e^(pmis + missed + b_any), A = e^(pa + b_alt), R = e^(pr + b_ref), s = e^prob_sample_alt
+//   L_i(alpha, beta) = c + q*alpha + e*beta,  c = w R + u,  q = w s (A - R),  e = w (1 - s) (A - R)
+//   single sample: alpha = a, beta = [a == 1];  contaminated: alpha = rho a + (1 - rho) a', beta = rho [a == 1] + (1 - rho) [a' == 1]
+void build_coef(Ctx& c, int s, int h) {
+    Ctx::Coef& k = c.coef[s][h];
+    const Pileup& pile = c.pileups[s];
+    const Artifacts& a = c.hyps[h];
+    const size_t n = pile.obs.size();
+    k.c.resize(n); k.q.resize(n); k.e.resize(n);
+    double tmin = 1.0;
+    bool bad = false;
+    for (size_t i = 0; i < n; ++i) {
+        const Obs& o = pile.obs[i];
+        const double w = std::exp(o.prob_mapping);
+        const double u = std::exp(o.prob_mismapping + o.prob_missed_allele + art_prob_any(a, o));
+        const double A = std::exp(o.p_alt() + art_prob_alt(a, o)), R = std::exp(o.p_ref() + art_prob_ref(a, o));
+        const double sa = std::exp(o.prob_sample_alt);
+        const double d = w * (A - R);
+        k.c[i] = w * R + u; k.q[i] = sa * d; k.e[i] = (1.0 - sa) * d;
+        if (k.e[i] != 0.0) k.has_e = true;
+        const double t0 = k.c[i], t1 = k.c[i] + k.q[i] + k.e[i], t2 = k.c[i] + k.q[i];
+        const double m = std::min(t0, std::min(t1, t2));
+        if (!(m > 0.0) || !std::isfinite(m) || !std::isfinite(t0 + t1 + t2)) bad = true;
+        tmin = std::min(tmin, m);
+    }
+    // a term that is zero or denormal in linear space is still a finite logarithm in the reference: such pileups keep the
+    // log-space code; terms above 2^-120 allow eight factors between two exponent extractions
+    k.slow = bad || tmin < 1e-290;
+    k.group = tmin >= 0x1p-120 ? 8 : 1;
+    k.built = true;
+}
+inline double pileup_affine(const Ctx::Coef& k, double alpha, double beta) {
+    const size_t n = k.c.size();
+    const double* cc = k.c.data();
+    const double* cq = k.q.data();
+    const double* ce = k.e.data();
+    const bool use_e = k.has_e && beta != 0.0;
+    double P = 1.0;
+    long E = 0;
+    size_t i = 0;
+    if (k.group == 8) {
+        for (; i + 8 <= n; i += 8) {
+            double p0 = 1.0, p1 = 1.0;
+            if (use_e) {
+                for (int j = 0; j < 8; j += 2) {
+                    p0 *= std::fma(ce[i + j], beta, std::fma(cq[i + j], alpha, cc[i + j]));
+                    p1 *= std::fma(ce[i + j + 1], beta, std::fma(cq[i + j + 1], alpha, cc[i + j + 1]));
+                }
+            } else {
+                for (int j = 0; j < 8; j += 2) {
+                    p0 *= std::fma(cq[i + j], alpha, cc[i + j]);
+                    p1 *= std::fma(cq[i + j + 1], alpha, cc[i + j + 1]);
+                }
+            }
+            int e0, e1;
+            const double m = std::frexp(P, &e0) * std::frexp(p0 * p1, &e1);
+            P = m;
+            E += e0 + e1;
+        }
+    }
+    for (; i < n; ++i) {
+        const double t = use_e ? std::fma(ce[i], beta, std::fma(cq[i], alpha, cc[i])) : std::fma(cq[i], alpha, cc[i]);
+        int e0, e1;
+        P = std::frexp(P, &e0) * std::frexp(t, &e1);
+        E += e0 + e1;
+    }
+    return std::log(P) + (double)E * 0.6931471805599453;
+}
+
 // modes/generic.rs:496-555 GenericLikelihood::compute
 double likelihood_compute(Ctx& c, const Operands& ops) {
     const Scenario& sc = *c.sc;
@@ -945,7 +1022,23 @@ double likelihood_compute(Ctx& c, const Operands& ops) {
             lh = 0.0;
             c.n_lik_evals++;
             c.n_obs_terms += pile.obs.size();
-            if (by >= 0) {  // likelihood.rs:122-157
+            bool done = false;
+            if (c.tuned && (by < 0 || ops.events[by].art == e.art)) {
+                if (!c.coef[s][e.art].built) build_coef(c, s, e.art);
+                const Ctx::Coef& k = c.coef[s][e.art];
+                if (!k.slow) {
+                    double alpha = e.af, beta = e.af == 1.0 ? 1.0 : 0.0;
+                    if (by >= 0) {
+                        const double rho = std::exp(sc.purity_ln[s]), af2 = ops.events[by].af;
+                        alpha = rho * e.af + (1.0 - rho) * af2;
+                        beta = rho * beta + (1.0 - rho) * (af2 == 1.0 ? 1.0 : 0.0);
+                    }
+                    lh = pileup_affine(k, alpha, beta);
+                    done = true;
+                }
+            }
+            if (done) {
+            } else if (by >= 0) {  // likelihood.rs:122-157
                 const SampleEvent& e2 = ops.events[by];
                 double la = std::log(e.af), lb = std::log(e2.af);
                 for (auto& o : pile.obs)
@@ -1328,8 +1421,21 @@ typedef struct {
 // (Caller::call_record, calling.rs:720-842 incl. preprocess_record's pileup edits 590-625).
 // `event_ln_posterior` (optional) receives [n * (1 + 2*n_events)] posteriors of the full event universe
 // (absent, then clean/artifact twin per scenario event; -inf-filled twin columns when no bias is enabled).
+static int call_batch_impl(const vlr_scenario_desc* desc, const vlr_batch* in, vlr_results* out, int64_t locus_begin,
+                           int64_t locus_end, double* event_ln_posterior, vlro_stats* stats, bool tuned);
 int vlro_call_batch(const vlr_scenario_desc* desc, const vlr_batch* in, vlr_results* out, int64_t locus_begin,
                     int64_t locus_end, double* event_ln_posterior, vlro_stats* stats) {
+    return call_batch_impl(desc, in, out, locus_begin, locus_end, event_ln_posterior, stats, false);
+}
+// The tuned CPU baseline of bench.py (cpu_baseline.kind = "tuned"): same tree walk, prior, integrator and result extraction, the
+// pileup likelihood in affine product form (Ctx::tuned).  Not bit-identical to the fidelity path (products instead of sums of
+// logarithms); bench.py reports its deviation.
+int vlro_call_batch_tuned(const vlr_scenario_desc* desc, const vlr_batch* in, vlr_results* out, int64_t locus_begin,
+                          int64_t locus_end, double* event_ln_posterior, vlro_stats* stats) {
+    return call_batch_impl(desc, in, out, locus_begin, locus_end, event_ln_posterior, stats, true);
+}
+static int call_batch_impl(const vlr_scenario_desc* desc, const vlr_batch* in, vlr_results* out, int64_t locus_begin,
+                           int64_t locus_end, double* event_ln_posterior, vlro_stats* stats, bool tuned) {
     Scenario sc;
     build_scenario(desc, sc);
     const int S = sc.S;
@@ -1407,6 +1513,8 @@ int vlro_call_batch(const vlr_scenario_desc* desc, const vlr_batch* in, vlr_resu
             }
         }
         c.lik_cache.assign(S, {});
+        c.tuned = tuned;
+        if (tuned) c.coef.assign(S, std::vector<Ctx::Coef>(c.hyps.size()));
 
         // ---- Model::compute (bio) with GenericPosterior::compute (modes/generic.rs:425-461)
         std::vector<double> value(universe.size());

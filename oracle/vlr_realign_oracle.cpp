@@ -69,8 +69,12 @@ extern "C" {
 //   x[0..len_x)  allele bases (reference coordinates of the shrunken window), y/qual[0..len_y) read window
 //   gap[4] = {ln prob_gap_x (insertion artifact), ln prob_gap_y (deletion artifact), ln x-extend, ln y-extend}
 //   max_edit_dist < 0: no band
-double vlro_pairhmm_prob_related(const uint8_t* x, int len_x, const uint8_t* y, const uint8_t* qual, int len_y, const double* gap,
-                                 int max_edit_dist) {
+// `crate_behaviours`: bit 0 = approximate three-way sum (addends more than e^-10 below the largest are dropped), bit 1 = skipped band
+// cells keep the gap states of the column two steps back (only the match state is reset), bit 2 = the first column starts with the
+// free-start mass ADDED to an initial mass of one (ln 2).  0 = the exact restatement the GPU kernel is compared with.
+static double prob_related_impl(const uint8_t* x, int len_x, const uint8_t* y, const uint8_t* qual, int len_y, const double* gap,
+                                int max_edit_dist, int crate_behaviours) {
+    const bool approx3 = crate_behaviours & 1, stale_skip = crate_behaviours & 2, start2 = crate_behaviours & 4;
     const double PROB_CONFUSION = std::log(0.3333);  // pairhmm.rs:22-24
     const double prob_gap_x = gap[0], prob_gap_y = gap[1], prob_gap_x_extend = gap[2], prob_gap_y_extend = gap[3];
     // GapParamCache (bio): P(no gap) = 1 - (P(gap x) + P(gap y)); leaving a gap: 1 - P(extend)
@@ -96,7 +100,7 @@ double vlro_pairhmm_prob_related(const uint8_t* x, int len_x, const uint8_t* y, 
     int prev = 0, curr = 1;
     for (int i = 0; i < len_x; ++i) {
         // semiglobal: an alignment may start at any column of x with mass one (StartEndGapParameters, pairhmm.rs:186-205)
-        fm[prev][0] = 0.0;
+        fm[prev][0] = (start2 && i == 0) ? std::log(2.0) : 0.0;
         med[prev][0] = 0;
         fx[prev][0] = NEG_INF; fy[prev][0] = NEG_INF;
         const double prob_emit_x = 0.0;  // pairhmm.rs:350-352
@@ -105,12 +109,19 @@ double vlro_pairhmm_prob_related(const uint8_t* x, int len_x, const uint8_t* y, 
             const int j_ = j + 1, jm = j;
             const unsigned e_tl = med[prev][jm], e_top = med[curr][jm], e_left = med[prev][j_];
             // a fresh column: everything outside the band is probability zero / unreachable
-            fm[curr][j_] = NEG_INF; fx[curr][j_] = NEG_INF; fy[curr][j_] = NEG_INF; med[curr][j_] = BIG;
-            if (max_edit_dist >= 0 && std::min(e_tl, std::min(e_top, e_left)) > (unsigned)max_edit_dist) continue;
+            const bool skip = max_edit_dist >= 0 && std::min(e_tl, std::min(e_top, e_left)) > (unsigned)max_edit_dist;
+            fm[curr][j_] = NEG_INF; med[curr][j_] = BIG;
+            if (!(stale_skip && skip)) { fx[curr][j_] = NEG_INF; fy[curr][j_] = NEG_INF; }
+            if (skip) continue;
             // match or mismatch (ReadEmission::prob_match_mismatch, pairhmm.rs:434-445)
             const bool is_match = upper(y[j]) == xb;
             const double emit_xy = is_match ? no_miscall[j] : any_miscall[j] + PROB_CONFUSION;
             std::vector<double> in3 = {prob_no_gap + fm[prev][jm], prob_no_gap_y_extend + fx[prev][jm], prob_no_gap_x_extend + fy[prev][jm]};
+            if (approx3) {
+                const double mx = std::max(in3[0], std::max(in3[1], in3[2]));
+                for (auto& v : in3)
+                    if (v - mx < -10.0) v = NEG_INF;
+            }
             fm[curr][j_] = emit_xy + ln_sum_exp(in3);
             // gap in y: x_i is emitted alone (a deletion in the read)
             double g = prob_gap_y + fm[prev][j_];
@@ -132,6 +143,17 @@ double vlro_pairhmm_prob_related(const uint8_t* x, int len_x, const uint8_t* y, 
     }
     const double p = ln_sum_exp(prob_cols);
     return p > 0.0 ? 0.0 : p;  // "sum of paths can exceed probability 1.0 especially in case of repeats"
+}
+
+double vlro_pairhmm_prob_related(const uint8_t* x, int len_x, const uint8_t* y, const uint8_t* qual, int len_y, const double* gap,
+                                 int max_edit_dist) {
+    return prob_related_impl(x, len_x, y, qual, len_y, gap, max_edit_dist, 0);
+}
+// The same recursion with the three crate behaviours of the header switched on individually (bits of `crate_behaviours`): used to
+// MEASURE how far the exact restatement can be from the real crate (tools/realign_crate_bound.py).
+double vlro_pairhmm_prob_related_variant(const uint8_t* x, int len_x, const uint8_t* y, const uint8_t* qual, int len_y, const double* gap,
+                                         int max_edit_dist, int crate_behaviours) {
+    return prob_related_impl(x, len_x, y, qual, len_y, gap, max_edit_dist, crate_behaviours);
 }
 
 // The ref/alt normalisation of Realigner::allele_support (realignment/mod.rs:359-385): both non-zero -> divide by the sum;

@@ -166,7 +166,7 @@ def test_cli_reads_variant_specific_priors_from_the_first_record_of_a_contig(gol
     with_info = cli.call_variants(cli.scenario_from_yaml(str(y)), {"normal": str(obs)}, out=io.StringIO())
     plain = cli.call_variants(cli.scenario_from_yaml(str(y)), {"normal": os.path.join(d, "normal.vcf")}, out=io.StringIO())
     sc = cli.scenario_from_yaml(str(y))
-    sc.variant_heterozygosity_ln = -13.0103 * np.log(10.0) / 10.0
+    sc.variant_heterozygosity_ln = -float(np.float32(13.0103)) * np.log(10.0) / 10.0  # an INFO float is f32 (calling.rs:470-494 reads it through htslib)
     forced = cli.call_variants(sc, {"normal": os.path.join(d, "normal.vcf")}, out=io.StringIO())
     assert np.array_equal(with_info.ln_posterior, forced.ln_posterior, equal_nan=True)
     assert not np.allclose(with_info.ln_posterior, plain.ln_posterior, equal_nan=True)
@@ -197,7 +197,7 @@ def test_cli_precise_and_imprecise_records_share_the_model_of_a_contig(golden_di
     y.write_text("species:\n  heterozygosity: 0.001\n  ploidy: 2\nsamples:\n  normal:\n    resolution: 0.1\nevents:\n  het: 'normal:0.5'\n  hom: 'normal:1.0'\n")
     mixed = cli.call_variants(cli.scenario_from_yaml(str(y)), {"normal": write("mixed.vcf", "HETEROZYGOSITY=13.0103;", "IMPRECISE;")}, out=io.StringIO())
     sc = cli.scenario_from_yaml(str(y))
-    sc.variant_heterozygosity_ln = -13.0103 * np.log(10.0) / 10.0
+    sc.variant_heterozygosity_ln = -float(np.float32(13.0103)) * np.log(10.0) / 10.0  # an INFO float is f32 (calling.rs:470-494 reads it through htslib)
     forced = cli.call_variants(sc, {"normal": write("imp.vcf", "", "IMPRECISE;")}, out=io.StringIO())
     assert np.array_equal(mixed.ln_posterior, forced.ln_posterior, equal_nan=True)
 

@@ -4,6 +4,7 @@ constructor defaults (src/variants/model/mod.rs:374-402), plus checks of the res
 arithmetic (bio LogProb, itertools_num::linspace, VAFRange::observable_min/max)."""
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import pytest
@@ -198,3 +199,26 @@ def test_clonal_inheritance_of_somatic_vaf_without_own_rate(oracle):
     assert prior(0.3, 0.3) == NEG_INF          # 0.3 is not a germline level of the relapse sample
     assert prior(0.3, 0.0) == NEG_INF          # parent carries a somatic VAF the child cannot have inherited unchanged
     assert prior(0.3, 0.5) == NEG_INF
+
+
+def test_tuned_cpu_baseline_agrees_with_the_fidelity_path(oracle):
+    """bench.py's cpu_baseline.tuned: the affine product form of the pileup likelihood against the log-space
+    restatement on every BASELINE workload shape, incl. loci whose terms leave the linear range (those keep the log-space code)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from parity import compare, describe
+    from varlociraptor_amd import synth
+    for name, n in (("config2", 300), ("config3", 60), ("config4", 40), ("config5", 120)):
+        cfg = synth.CONFIGS[name]()
+        b = synth.generate(cfg, n, seed=19)
+        ref = oracle.call(cfg.scenario, b, want_events=True)
+        got = oracle.call(cfg.scenario, b, want_events=True, tuned=True)
+        m = compare(got, ref, label="tuned " + name)
+        assert m["frac_within"] == 1.0 and m["bias_equal"] and m["status_equal"], describe(m)
+    cfg = synth.config3()
+    b = synth.generate(cfg, 30, seed=23)
+    b.columns["prob_alt"][::3] = -740.0   # supports below the f64 linear range
+    ref = oracle.call(cfg.scenario, b, want_events=True)
+    got = oracle.call(cfg.scenario, b, want_events=True, tuned=True)
+    m = compare(got, ref, label="tuned deep supports")
+    assert m["frac_within"] == 1.0, describe(m)

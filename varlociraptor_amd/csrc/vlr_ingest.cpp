@@ -13,6 +13,8 @@
 // No htslib: BGZF members are located through their BSIZE fields and inflated in parallel with zlib, BCF records are decoded in
 // place, every stage runs on a pool of std::threads over contiguous record ranges.  Pure host code; the only device-related call
 // is vlr_host_alloc (page-locked result arrays so that vlr_batch_run_host copies them by direct DMA).
+#include <dlfcn.h>
+#include <sched.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -37,7 +39,12 @@
 
 extern "C" void vlr_set_error(const char* msg);  // vlr_host.cpp: the text behind vlr_last_error()
 
+#include <chrono>
 namespace {
+
+// stage timings of the last vlr_obs_read / vlr_calls_write of this process (vlr_ingest_last_timings): measurement aid
+double g_ingest_t[16] = {0};
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int ifail(int code, const char* fmt, ...) {
     char buf[512];
@@ -50,10 +57,30 @@ int ifail(int code, const char* fmt, ...) {
 }
 
 // ------------------------------------------------------------------------------------------------ threads
+// CPUs this process may actually use: the affinity mask and the cgroup CPU quota (containers report the host's hardware threads)
+int effective_cpus() {
+    unsigned h = std::thread::hardware_concurrency();
+    int n = (int)(h ? h : 1u);
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min(n, std::max(1, CPU_COUNT(&set)));
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota> <period>" or "max <period>"
+        char q[64];
+        long period = 0;
+        if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) n = std::min(n, (int)std::max(1L, (atol(q) + period - 1) / period));
+        fclose(f);
+    } else {
+        long quota = -1, period = 0;
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%ld", &quota) != 1) quota = -1; fclose(g); }
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%ld", &period) != 1) period = 0; fclose(g); }
+        if (quota > 0 && period > 0) n = std::min(n, (int)std::max(1L, (quota + period - 1) / period));
+    }
+    return std::max(1, n);
+}
 int pick_threads(int n) {
     if (n > 0) return n;
-    unsigned h = std::thread::hardware_concurrency();
-    return (int)std::max(1u, std::min(h ? h : 1u, 128u));
+    if (const char* ev = getenv("VLR_INGEST_THREADS")) { const int v = atoi(ev); if (v > 0) return v; }
+    static const int eff = effective_cpus();
+    return std::max(1, std::min(eff, 256));
 }
 // fn(begin, end, worker) over [0, n) in contiguous ranges
 template <typename F>
@@ -89,14 +116,28 @@ void parallel_items(int64_t n, int n_threads, F&& fn) {
 }
 
 // ------------------------------------------------------------------------------------------------ files, BGZF
-bool read_whole_file(const char* path, std::vector<uint8_t>& out, std::string& err) {
+// an uninitialised byte buffer (std::vector would zero gigabytes on one thread before the workers overwrite them)
+struct Blob {
+    uint8_t* p = nullptr;
+    size_t n = 0;
+    Blob() = default;
+    Blob(const Blob&) = delete;
+    Blob& operator=(const Blob&) = delete;
+    ~Blob() { free(p); }
+    bool alloc(size_t bytes) { free(p); p = (uint8_t*)malloc(bytes ? bytes : 1); n = p ? bytes : 0; return p != nullptr; }
+    const uint8_t* data() const { return p; }
+    size_t size() const { return n; }
+    uint8_t operator[](size_t i) const { return p[i]; }
+};
+
+bool read_whole_file(const char* path, Blob& out, std::string& err) {
     FILE* f = fopen(path, "rb");
     if (!f) { err = std::string("cannot open ") + path; return false; }
     fseek(f, 0, SEEK_END);
     const long n = ftell(f);
     fseek(f, 0, SEEK_SET);
-    out.resize((size_t)std::max(0L, n));
-    const size_t got = n > 0 ? fread(out.data(), 1, (size_t)n, f) : 0;
+    if (!out.alloc((size_t)std::max(0L, n))) { fclose(f); err = "out of memory"; return false; }
+    const size_t got = n > 0 ? fread(out.p, 1, (size_t)n, f) : 0;
     fclose(f);
     if (got != (size_t)std::max(0L, n)) { err = std::string("short read on ") + path; return false; }
     return true;
@@ -105,7 +146,7 @@ bool read_whole_file(const char* path, std::vector<uint8_t>& out, std::string& e
 struct BgzfBlock { size_t off, clen; uint32_t isize; size_t out_off; };
 
 // all gzip members carry the BGZF extra field `BC` with their total size: index them without inflating
-bool bgzf_index(const std::vector<uint8_t>& raw, std::vector<BgzfBlock>& blocks) {
+bool bgzf_index(const Blob& raw, std::vector<BgzfBlock>& blocks) {
     size_t p = 0;
     size_t total = 0;
     while (p < raw.size()) {
@@ -130,7 +171,43 @@ bool bgzf_index(const std::vector<uint8_t>& raw, std::vector<BgzfBlock>& blocks)
     return true;
 }
 
+// libdeflate (a system library next to zlib, about twice zlib's inflate rate) is taken through dlopen when it is installed — the
+// image carries the runtime library without its header; its C API (v1.x) is declared here.  zlib is the fallback.
+struct LibDeflate {
+    void* (*alloc_d)() = nullptr;
+    int (*decompress)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
+    void (*free_d)(void*) = nullptr;
+    void* (*alloc_c)(int) = nullptr;
+    size_t (*compress)(void*, const void*, size_t, void*, size_t) = nullptr;
+    size_t (*bound)(void*, size_t) = nullptr;
+    void (*free_c)(void*) = nullptr;
+    uint32_t (*crc32)(uint32_t, const void*, size_t) = nullptr;
+    bool ok = false;
+    LibDeflate() {
+        if (getenv("VLR_NO_LIBDEFLATE")) return;
+        void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        alloc_d = (void* (*)())dlsym(h, "libdeflate_alloc_decompressor");
+        decompress = (int (*)(void*, const void*, size_t, void*, size_t, size_t*))dlsym(h, "libdeflate_deflate_decompress");
+        free_d = (void (*)(void*))dlsym(h, "libdeflate_free_decompressor");
+        alloc_c = (void* (*)(int))dlsym(h, "libdeflate_alloc_compressor");
+        compress = (size_t (*)(void*, const void*, size_t, void*, size_t))dlsym(h, "libdeflate_deflate_compress");
+        bound = (size_t (*)(void*, size_t))dlsym(h, "libdeflate_deflate_compress_bound");
+        free_c = (void (*)(void*))dlsym(h, "libdeflate_free_compressor");
+        crc32 = (uint32_t (*)(uint32_t, const void*, size_t))dlsym(h, "libdeflate_crc32");
+        ok = alloc_d && decompress && free_d && alloc_c && compress && bound && free_c && crc32;
+    }
+};
+const LibDeflate& libdeflate() { static LibDeflate L; return L; }
+
 bool inflate_raw(const uint8_t* src, size_t clen, uint8_t* dst, size_t dlen) {
+    const LibDeflate& ld = libdeflate();
+    if (ld.ok) {
+        thread_local void* d = ld.alloc_d();
+        size_t got = 0;
+        if (d && ld.decompress(d, src, clen, dst, dlen, &got) == 0 && got == dlen) return true;
+        // fall through to zlib on any doubt
+    }
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, -15) != Z_OK) return false;
@@ -143,21 +220,27 @@ bool inflate_raw(const uint8_t* src, size_t clen, uint8_t* dst, size_t dlen) {
 }
 
 // file contents, decompressed: BGZF (parallel), plain gzip (sequential), or as is
-bool load_inflated(const char* path, std::vector<uint8_t>& out, int n_threads, std::string& err) {
-    std::vector<uint8_t> raw;
+bool load_inflated(const char* path, Blob& out_blob, int n_threads, std::string& err) {
+    Blob raw;
+    const double t0 = now_s();
     if (!read_whole_file(path, raw, err)) return false;
-    if (raw.size() < 2 || raw[0] != 0x1f || raw[1] != 0x8b) { out.swap(raw); return true; }
+    g_ingest_t[0] += now_s() - t0;
+    std::vector<uint8_t> out;
+    auto finish = [&](std::vector<uint8_t>& v) { if (!out_blob.alloc(v.size())) { err = "out of memory"; return false; } memcpy(out_blob.p, v.data(), v.size()); return true; };
+    if (raw.size() < 2 || raw[0] != 0x1f || raw[1] != 0x8b) { std::swap(out_blob.p, raw.p); std::swap(out_blob.n, raw.n); return true; }
     std::vector<BgzfBlock> blocks;
     if (bgzf_index(raw, blocks)) {
         size_t total = 0;
         for (auto& b : blocks) total += b.isize;
-        out.resize(total);
+        if (!out_blob.alloc(total)) { err = "out of memory"; return false; }
         std::atomic<bool> bad{false};
+        const double t1 = now_s();
         parallel_items((int64_t)blocks.size(), n_threads, [&](int64_t i, int) {
             const BgzfBlock& b = blocks[(size_t)i];
             if (b.isize == 0) return;
-            if (!inflate_raw(raw.data() + b.off, b.clen, out.data() + b.out_off, b.isize)) bad = true;
+            if (!inflate_raw(raw.data() + b.off, b.clen, out_blob.p + b.out_off, b.isize)) bad = true;
         });
+        g_ingest_t[1] += now_s() - t1;
         if (bad) { err = std::string("corrupt BGZF block in ") + path; return false; }
         return true;
     }
@@ -165,7 +248,7 @@ bool load_inflated(const char* path, std::vector<uint8_t>& out, int n_threads, s
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, 15 + 32) != Z_OK) { err = "zlib init failed"; return false; }
-    zs.next_in = raw.data(); zs.avail_in = (uInt)std::min<size_t>(raw.size(), 0x7fffffff);
+    zs.next_in = raw.p; zs.avail_in = (uInt)std::min<size_t>(raw.size(), 0x7fffffff);
     out.resize(std::max<size_t>(raw.size() * 4, 1 << 16));
     size_t have = 0;
     for (;;) {
@@ -182,27 +265,42 @@ bool load_inflated(const char* path, std::vector<uint8_t>& out, int n_threads, s
     }
     inflateEnd(&zs);
     out.resize(have);
-    return true;
+    return finish(out);
 }
 
 // one BGZF member holding `n` bytes (n <= 0xff00)
 void bgzf_deflate_block(const uint8_t* data, size_t n, int level, std::vector<uint8_t>& out) {
     uLong bound = compressBound((uLong)n) + 64;
     const size_t at = out.size();
-    out.resize(at + 18 + bound + 8);
-    z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
-    zs.next_in = const_cast<Bytef*>(data); zs.avail_in = (uInt)n;
-    zs.next_out = out.data() + at + 18; zs.avail_out = (uInt)bound;
-    deflate(&zs, Z_FINISH);
-    const size_t clen = zs.total_out;
-    deflateEnd(&zs);
+    size_t clen = 0;
+    const LibDeflate& ld = libdeflate();
+    if (ld.ok) {
+        thread_local int c_level = -1;
+        thread_local void* c = nullptr;
+        if (c_level != level) { if (c) ld.free_c(c); c = ld.alloc_c(level); c_level = level; }
+        if (c) {
+            bound = (uLong)ld.bound(c, n) + 64;
+            out.resize(at + 18 + bound + 8);
+            clen = ld.compress(c, data, n, out.data() + at + 18, bound);
+        }
+    }
+    if (clen == 0 || clen + 26 > 0xffff) {
+        bound = compressBound((uLong)n) + 64;
+        out.resize(at + 18 + bound + 8);
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+        zs.next_in = const_cast<Bytef*>(data); zs.avail_in = (uInt)n;
+        zs.next_out = out.data() + at + 18; zs.avail_out = (uInt)bound;
+        deflate(&zs, Z_FINISH);
+        clen = zs.total_out;
+        deflateEnd(&zs);
+    }
     static const uint8_t head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
     memcpy(out.data() + at, head, 16);
     const unsigned bsize = (unsigned)(clen + 25);
     out[at + 16] = (uint8_t)(bsize & 0xff); out[at + 17] = (uint8_t)(bsize >> 8);
-    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), data, (uInt)n), isz = (uint32_t)n;
+    const uint32_t crc = ld.ok ? ld.crc32(0, data, n) : (uint32_t)crc32(crc32(0L, Z_NULL, 0), data, (uInt)n), isz = (uint32_t)n;
     uint8_t* t = out.data() + at + 18 + clen;
     for (int i = 0; i < 4; ++i) { t[i] = (uint8_t)(crc >> (8 * i)); t[4 + i] = (uint8_t)(isz >> (8 * i)); }
     out.resize(at + 18 + clen + 8);
@@ -670,8 +768,9 @@ struct SampleFile {
 };
 
 bool read_sample_file(const char* path, int n_threads, SampleFile& sf, std::string& err) {
-    std::vector<uint8_t> data;
+    Blob data;
     if (!load_inflated(path, data, n_threads, err)) return false;
+    const double t_parse0 = now_s();
     const bool is_bcf = data.size() >= 9 && memcmp(data.data(), "BCF\2\2", 5) == 0;
     Header h;
     std::vector<size_t> starts;  // record starts (+ end sentinel)
@@ -737,6 +836,7 @@ bool read_sample_file(const char* path, int n_threads, SampleFile& sf, std::stri
     });
     for (auto& c : sf.chunks)
         if (!c.error.empty()) { err = c.error; return false; }
+    g_ingest_t[2] += now_s() - t_parse0;
     return true;
 }
 
@@ -760,7 +860,9 @@ void variant_class(const char* ref, const char* alt, int& vt, bool& snv_or_mnv, 
 
 void* table_alloc(size_t bytes, bool& pinned) {
     if (bytes == 0) bytes = 8;
-    void* p = vlr_host_alloc(bytes);
+    // page-locking gigabytes costs more than the bounce copies it saves on a one-shot CLI run: opt-in (VLR_INGEST_PINNED=1)
+    static const bool want_pinned = getenv("VLR_INGEST_PINNED") && atoi(getenv("VLR_INGEST_PINNED")) != 0;
+    void* p = want_pinned ? vlr_host_alloc(bytes) : nullptr;
     pinned = p != nullptr;
     if (!p) p = aligned_alloc(64, (bytes + 63) & ~(size_t)63);
     return p;
@@ -804,9 +906,22 @@ int vlr_obs_read(int n_samples, const char* const* paths, uint32_t omit_bias_mas
     *out = nullptr;
     n_threads = pick_threads(n_threads);
     std::vector<SampleFile> files((size_t)n_samples);
+    for (int i = 0; i < 16; ++i) g_ingest_t[i] = 0.0;
+    const double t_all0 = now_s();
+    {   // the sample files side by side, each with its share of the threads
+        std::vector<std::string> errs((size_t)n_samples);
+        std::vector<char> oks((size_t)n_samples, 0);
+        std::vector<std::thread> th;
+        const int per = std::max(1, n_threads / n_samples);
+        for (int s = 0; s < n_samples; ++s)
+            th.emplace_back([&, s] { oks[(size_t)s] = read_sample_file(paths[s], per, files[(size_t)s], errs[(size_t)s]) ? 1 : 0; });
+        for (auto& x : th) x.join();
+        for (int s = 0; s < n_samples; ++s)
+            if (!oks[(size_t)s]) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s", errs[(size_t)s].c_str());
+    }
+    g_ingest_t[3] = now_s() - t_all0;
+    const double t_merge0 = now_s();
     for (int s = 0; s < n_samples; ++s) {
-        std::string err;
-        if (!read_sample_file(paths[s], n_threads, files[(size_t)s], err)) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s", err.c_str());
         if (files[(size_t)s].n_rec != files[0].n_rec) return ifail(VLR_ERR_INVALID_ARGUMENT, "inconsistent observations: %s holds %lld records, %s %lld (calling.rs:369-371)",
                                                                     paths[s], (long long)files[(size_t)s].n_rec, paths[0], (long long)files[0].n_rec);
     }
@@ -893,6 +1008,8 @@ int vlr_obs_read(int n_samples, const char* const* paths, uint32_t omit_bias_mas
         }
     });
     if (bad_rec >= 0) return ifail(VLR_ERR_INVALID_ARGUMENT, "inconsistent observations: record %lld differs between the sample files (calling.rs:379-390)", (long long)bad_rec + 1);
+    g_ingest_t[4] = now_s() - t_merge0;
+    const double t_str0 = now_s();
     // strings and breakend groups (sequential: first occurrence of a haplotype identifier is the representative)
     std::unordered_map<std::string, int64_t> first;
     {
@@ -914,9 +1031,16 @@ int vlr_obs_read(int n_samples, const char* const* paths, uint32_t omit_bias_mas
         t->hap_rep[(size_t)l] = rep;
     }
     for (auto& n : t->contig_names) t->contig_ptrs.push_back(n.c_str());
+    g_ingest_t[5] = now_s() - t_str0;
+    g_ingest_t[6] = now_s() - t_all0;
     *out = t.release();
     return VLR_OK;
 }
+
+// measurement aid: seconds of the stages of the last vlr_obs_read — [0] file reads, [1] BGZF inflate, [2] record parse + decode
+// (each summed over the sample files, which run side by side), [3] wall time of all files, [4] merge into the table, [5] strings and
+// breakend groups, [6] total — and of the last vlr_calls_write — [8] record encoding, [9] BGZF deflate + file write, [10] total.
+void vlr_ingest_last_timings(double* out16) { if (out16) for (int i = 0; i < 16; ++i) out16[i] = g_ingest_t[i]; }
 
 void vlr_obs_table_free(vlr_obs_table* t) { delete t; }
 
@@ -1040,12 +1164,12 @@ char kr_letter(double bf) {  // utils/mod.rs:158-167 over bio's Kass-Raftery sca
 // utils/mod.rs:122-156 generalized_cigar, keep_order = false: counts in first-appearance order, stable by count desc, stable by aux
 template <typename Aux>
 std::string generalized_cigar(const std::vector<std::string>& items, Aux aux) {
-    std::vector<std::pair<std::string, int>> cnt;
-    std::unordered_map<std::string, size_t> at;
+    std::vector<std::pair<std::string, int>> cnt;  // a handful of distinct items: a linear search beats hashing
     for (auto& it : items) {
-        auto f = at.find(it);
-        if (f == at.end()) { at.emplace(it, cnt.size()); cnt.emplace_back(it, 1); }
-        else cnt[f->second].second++;
+        size_t k = 0;
+        while (k < cnt.size() && cnt[k].first != it) ++k;
+        if (k == cnt.size()) cnt.emplace_back(it, 1);
+        else cnt[k].second++;
     }
     std::stable_sort(cnt.begin(), cnt.end(), [](const auto& a, const auto& b) { return a.second > b.second; });
     std::stable_sort(cnt.begin(), cnt.end(), [&](const auto& a, const auto& b) { return aux(a.first) < aux(b.first); });
@@ -1181,6 +1305,7 @@ int vlr_calls_write(const char* path, const char* header_text, const vlr_obs_tab
         parts[0].assign(ht.begin(), ht.end());
     }
     const double LN10 = std::log(10.0);
+    const double t_w0 = now_s();
     parallel_ranges(L, T, [&](int64_t b, int64_t e, int w) {
         std::vector<uint8_t>& out = parts[(size_t)w + 1];
         std::vector<SampleFields> sf((size_t)S);
@@ -1298,11 +1423,15 @@ int vlr_calls_write(const char* path, const char* header_text, const vlr_obs_tab
     });
     for (auto& e : errs)
         if (!e.empty()) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s", e.c_str());
+    g_ingest_t[8] = now_s() - t_w0;
     std::string err;
     if (bcf) {
         std::vector<const std::vector<uint8_t>*> ps;
         for (auto& p : parts) ps.push_back(&p);
-        if (!write_bgzf_file(path, ps, n_threads, 6, err)) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s", err.c_str());
+        const char* lv = getenv("VLR_BGZF_LEVEL");
+        if (!write_bgzf_file(path, ps, n_threads, lv ? atoi(lv) : 4, err)) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s", err.c_str());
+        g_ingest_t[9] = now_s() - t_w0 - g_ingest_t[8];
+        g_ingest_t[10] = now_s() - t_w0;
         return VLR_OK;
     }
     FILE* f = fopen(path, "wb");

@@ -26,7 +26,7 @@ EXPORTS = [
     "vlr_plan_n_samples", "vlr_plan_set_max_depth", "vlr_plan_set_max_obs", "vlr_plan_reserve", "vlr_batch_run", "vlr_batch_run_host",
     "vlr_plan_last_kernel_ms", "vlr_plan_work_counters", "vlr_host_alloc", "vlr_host_free",
     "vlr_realign_batch", "vlr_realign_batch_host", "vlr_edit_distance_batch", "vlr_edit_distance_batch_host", "vlr_fdr_threshold", "vlr_selftest_math", "vlr_selftest_stream",
-    "vlr_obs_read", "vlr_obs_table_free", "vlr_obs_table_batch", "vlr_obs_table_sites", "vlr_obs_write", "vlr_calls_write",
+    "vlr_obs_read", "vlr_obs_table_free", "vlr_obs_table_batch", "vlr_obs_table_sites", "vlr_obs_write", "vlr_calls_write", "vlr_ingest_last_timings",
 ]
 
 

@@ -152,3 +152,14 @@ def write_calls(path: str, header_text: str, table: ObsTable, results: CallResul
     rs = results.as_struct()
     names = (C.c_char_p * len(out_names))(*[n.encode() for n in out_names])
     _check(_lib().vlr_calls_write(path.encode(), header_text.encode(), table.handle, C.byref(rs), names, int(threads)))
+
+
+def last_timings() -> dict:
+    """Stage times of the last read_observations / write_calls (vlr_ingest_last_timings)."""
+    a = (C.c_double * 16)()
+    L = _lib()
+    L.vlr_ingest_last_timings.restype = None
+    L.vlr_ingest_last_timings.argtypes = [C.POINTER(C.c_double)]
+    L.vlr_ingest_last_timings(a)
+    k = ["file_read", "inflate", "parse_decode", "files_wall", "merge", "strings", "read_total", None, "encode", "deflate_write", "write_total"]
+    return {n: a[i] for i, n in enumerate(k) if n}

@@ -194,7 +194,7 @@ def _phred_info(info: Dict[str, str], key: str) -> Optional[float]:
     v = info.get(key)
     if v is None or v in ("", "."):
         return None
-    x = float(v.split(",")[0])
+    x = float(np.float32(float(v.split(",")[0])))  # INFO floats are f32 in the record (htslib), also when parsed from text
     if x != x:
         return None
     return -x * np.log(10.0) / 10.0
