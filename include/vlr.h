@@ -348,6 +348,15 @@ int vlr_realign_batch(int device, const vlr_realign_batch_desc* pairs, double* l
 /* Host pointers: stages the sequences, runs the kernel, returns when ln_prob is filled. */
 int vlr_realign_batch_host(int device, const vlr_realign_batch_desc* pairs, double* ln_prob);
 
+/* The `fast` realignment mode (--pairhmm-mode fast): replaces PathHMMRealigner::calculate_prob_allele
+ * (/root/reference/src/variants/evidence/realignment/mod.rs:547-678) — the path probability of an optimal edit-distance alignment
+ * (transition terms by the previous operation, emissions as above), best over the hit's alignments.  The reference takes the
+ * alignments from bio's Myers traceback, which does not specify the choice among co-optimal alignments; ln_prob[p] here is the
+ * best path probability over ALL alignments of minimal semiglobal edit distance (equal when unique, an upper bound otherwise).
+ * max_edit_dist is not read.  Same conventions as vlr_realign_batch. */
+int vlr_realign_fast_batch(int device, const vlr_realign_batch_desc* pairs, double* ln_prob, void* hip_stream);
+int vlr_realign_fast_batch_host(int device, const vlr_realign_batch_desc* pairs, double* ln_prob);
+
 /* Edit-distance pre-filter of the same pairs: replaces EditDistanceCalculation::calc_best_hit
  * (/root/reference/src/variants/evidence/realignment/edit_distance.rs:164-260, bio Myers find_all_lazy) as far as
  * Realigner::prob_allele and the band of the pair HMM use it.  dist[p] = smallest semiglobal edit distance of the read

@@ -115,6 +115,18 @@ def pairhmm_prob_related_variant(allele: bytes, read: bytes, qual, gap, max_edit
     return float(L.vlro_pairhmm_prob_related_variant(x.ctypes.data, len(allele), y.ctypes.data, q.ctypes.data, len(read), g, int(max_edit_dist), int(crate_behaviours)))
 
 
+def pathhmm_best(allele: bytes, read: bytes, qual, gap) -> float:
+    """`fast` realignment mode: best path probability over the minimal-edit-distance alignments (vlro_pathhmm_best)."""
+    L = lib()
+    L.vlro_pathhmm_best.restype = C.c_double
+    L.vlro_pathhmm_best.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+    x = np.frombuffer(bytes(allele) or b"\0", np.uint8)
+    y = np.frombuffer(bytes(read) or b"\0", np.uint8)
+    q = np.asarray(bytearray(qual) or b"\0", np.uint8)
+    g = (C.c_double * 4)(*gap)
+    return float(L.vlro_pathhmm_best(x.ctypes.data, len(allele), y.ctypes.data, q.ctypes.data, len(read), g))
+
+
 def edit_distance(allele: bytes, read: bytes):
     """(dist, end, n_hits) of the semiglobal edit distance of `read` in `allele` (oracle/vlr_realign_oracle.cpp)."""
     L = lib()

@@ -156,6 +156,51 @@ double vlro_pairhmm_prob_related_variant(const uint8_t* x, int len_x, const uint
     return prob_related_impl(x, len_x, y, qual, len_y, gap, max_edit_dist, crate_behaviours);
 }
 
+// `fast` realignment mode — PathHMMRealigner::calculate_prob_allele (realignment/mod.rs:547-678): the path probability of an
+// optimal edit-distance alignment of the read window in the allele window, transition terms chosen by the previous operation
+// (mod.rs:598-660, constants of PathHMMRealigner::new 560-584), emissions of ReadVsAlleleEmission; the best over the hit's
+// alignments.  The alignments come from bio's Myers traceback (edit_distance.rs:164-260), whose choice among co-optimal
+// alignments the reference does not specify: PARITY UNPINNED there.  This restatement (and the kernel) take the best path
+// probability over ALL alignments of minimal semiglobal edit distance — equal to the reference when the optimal alignment of
+// every best hit is unique, an upper bound otherwise.  Dynamic programme over (distance, ln p) pairs, lexicographic, per state.
+double vlro_pathhmm_best(const uint8_t* x, int len_x, const uint8_t* y, const uint8_t* qual, int len_y, const double* gap) {
+    if (len_x <= 0 || len_y <= 0) return NEG_INF;
+    const double gx = gap[0], gy = gap[1], gxe = gap[2], gye = gap[3];
+    const double no_gap = ln_one_minus_exp(ln_add_exp(gx, gy));
+    const double close_x = ln_one_minus_exp(gxe), close_y = ln_one_minus_exp(gye);
+    const double reopen_x = ln_add_exp(gxe, close_x + gx), reopen_y = ln_add_exp(gye, close_y + gy);
+    const double CONF = std::log(0.3333);
+    struct DP { unsigned d; double p; };
+    const unsigned BIG = 0x3fffffffu;
+    auto best = [](DP a, DP b) { return (a.d < b.d || (a.d == b.d && a.p > b.p)) ? a : b; };
+    auto step = [BIG](DP a, unsigned c, double lp) { return a.d >= BIG ? DP{BIG, NEG_INF} : DP{a.d + c, a.p + lp}; };
+    const DP dead{BIG, NEG_INF};
+    // column index c = i + 1 (c = 0: nothing of the allele consumed), rows j = 0..len_y-1; start row "above" row 0 handled inline
+    std::vector<DP> M((size_t)(len_x + 1), dead), D((size_t)(len_x + 1), dead), I((size_t)(len_x + 1), dead), pM, pD, pI;
+    DP result = dead;
+    for (int j = 0; j < len_y; ++j) {
+        pM = M; pD = D; pI = I;
+        const double lm = -(double)qual[j] * LN10 / 10.0, l_match = ln_one_minus_exp(lm), l_mis = lm + CONF, l_ins = lm;
+        for (int c = 0; c <= len_x; ++c) {
+            DP m = dead, dl = dead, in = dead;
+            // insertion: read base j alone, from (j-1, c)
+            if (j == 0) in = DP{1u, gx + l_ins};  // first operation: prev None (mod.rs:640-647)
+            else in = best(best(step(pM[(size_t)c], 1u, gx + l_ins), step(pI[(size_t)c], 1u, reopen_x + l_ins)), step(pD[(size_t)c], 1u, close_y + gx + l_ins));
+            if (c > 0) {
+                const bool is_match = upper(x[c - 1]) == upper(y[j]);
+                const unsigned mm = is_match ? 0u : 1u;
+                const double emit = is_match ? l_match : l_mis;
+                if (j == 0) m = DP{mm, emit};  // first operation: no transition term (mod.rs:598-612)
+                else m = best(best(step(pM[(size_t)c - 1], mm, no_gap + emit), step(pD[(size_t)c - 1], mm, close_y + emit)), step(pI[(size_t)c - 1], mm, close_x + emit));
+                dl = best(best(step(M[(size_t)c - 1], 1u, gy), step(D[(size_t)c - 1], 1u, reopen_y)), step(I[(size_t)c - 1], 1u, close_x + gy));
+            }
+            M[(size_t)c] = m; D[(size_t)c] = dl; I[(size_t)c] = in;
+        }
+    }
+    for (int c = 1; c <= len_x; ++c) result = best(result, best(M[(size_t)c], I[(size_t)c]));
+    return result.d >= BIG ? NEG_INF : result.p;
+}
+
 // The ref/alt normalisation of Realigner::allele_support (realignment/mod.rs:359-385): both non-zero -> divide by the sum;
 // both zero -> 0.5 / 0.5.
 void vlro_normalize_support(double* prob_ref, double* prob_alt) {

@@ -171,10 +171,22 @@ def test_lds_depth_budget(oracle):
     kept = b.depth()[:, 0] - removed
     deep = kept > 100
     assert deep.any() and (~deep).any()
-    # loci above the budget are flagged, not silently wrong
-    assert np.all((got.status[deep] & abi.LOCUS_TOO_DEEP) != 0)
-    assert np.all((got.status[~deep] & abi.LOCUS_TOO_DEEP) == 0)
+    # round 3: loci above the LDS budget are no longer flagged — the deep launch (coefficients in an HBM pool) evaluates them,
+    # with the results of the oracle; without the pool (VLR_DEEP_POOL_MB=0) they come back flagged, never silently wrong
+    assert np.all((got.status & abi.LOCUS_TOO_DEEP) == 0)
+    ref = oracle_mt(oracle, cfg.scenario, b)
+    m = compare(got, ref, label="over the LDS budget -> deep launch")
+    assert m["frac_within"] == 1.0 and m["bias_equal"] and m["status_equal"], describe(m)
     plan.close()
+    os.environ["VLR_DEEP_POOL_MB"] = "0"
+    try:
+        plan = engine.Plan(cfg.scenario, max_depth=100)
+        flagged = plan.call_host(b)
+        plan.close()
+    finally:
+        del os.environ["VLR_DEEP_POOL_MB"]
+    assert np.all((flagged.status[deep] & abi.LOCUS_TOO_DEEP) != 0)
+    assert np.all((flagged.status[~deep] & abi.LOCUS_TOO_DEEP) == 0)
     cfg = with_depth(synth.config2(), 190.0)
     b = synth.generate(cfg, 64, seed=19)
     check(oracle, cfg.scenario, b, "deep pileups, budget 200", max_depth=200)
@@ -400,3 +412,43 @@ def test_thirty_named_events_use_every_bit_of_the_alive_masks(oracle):
     too_many = Scenario({"s": Sample(resolution=0.01, universe="[0.0,1.0]")}, {("x%02d" % i): "s:{%r}" % (i / 40.0) for i in range(31)})
     with pytest.raises(Exception):
         engine.Plan(too_many)
+
+
+def test_whole_terms_below_the_f64_range_take_the_scaled_coefficient_pass(oracle):
+    """observations whose WHOLE likelihood term leaves the linear range (prob_alt, prob_ref and
+    prob_missed_allele all around -800: legal in the reference's log space, likelihood.rs:198-220) no longer come back flagged
+    VLR_LOCUS_UNDERFLOW: the coefficient pass scales each such observation by its own power of two and the exponents are added
+    back to every pileup log-likelihood.  Results equal the log-space oracle, status low bits are zero."""
+    for cfg, n, seed in ((with_depth(synth.config3(), 40.0), 160, 61), (with_depth(synth.config2(), 30.0), 300, 62), (synth.config5(), 120, 63)):
+        b = synth.generate(cfg, n, seed=seed)
+        rng = np.random.default_rng(seed)
+        hit = rng.random(b.n_obs) < 0.15
+        for col, v in (("prob_alt", -800.0), ("prob_ref", -805.0), ("prob_missed_allele", -802.0)):
+            a = b.columns[col]
+            a[hit] = np.float32(v) + rng.integers(-20, 20, int(hit.sum())).astype(np.float32)
+        got, ref = check(oracle, cfg.scenario, b, "whole terms below the f64 range (%s)" % cfg.name)
+        assert not (got.status & 0xF).any()
+
+
+def test_pileups_far_above_the_lds_budget(oracle):
+    """20 000 observations per locus (the reference has no depth limit; sample.rs:236 is a default of the
+    preprocessing step): tumor-normal and single-sample, with AFD lists, through the deep launch.  Equal to the oracle, status
+    low bits zero."""
+    for cfg, n in ((with_depth(synth.config2(), 20000.0, max_depth=40000), 6), (with_depth(synth.config3(), 9000.0, max_depth=20000), 4)):
+        b = synth.generate(cfg, n, seed=71)
+        assert b.depth().sum(axis=1).max() > engine.MAX_OBS_LDS
+        plan = engine.Plan(cfg.scenario)
+        plan.set_max_obs(engine.MAX_OBS_LDS)
+        got = plan.call_host(b, afd_capacity=160)
+        plan.close()
+        ref = oracle.call(cfg.scenario, b, afd_capacity=160, want_events=True)
+        m = compare(got, ref, label="depth %d" % int(cfg.depth))
+        print(describe(m))
+        assert m["frac_within"] == 1.0 and m["bias_equal"] and m["status_equal"], describe(m)
+        assert not (got.status & 0xF).any()
+        assert np.array_equal(got.afd_count, ref.afd_count)
+        for l in range(n):
+            for s_ in range(b.n_samples):
+                k = int(ref.afd_count[l, s_])
+                if k <= 160:
+                    assert np.array_equal(np.sort(got.afd_vaf[l, s_, :k]), np.sort(ref.afd_vaf[l, s_, :k]))

@@ -138,3 +138,35 @@ def test_resident_pairs_take_their_band_from_the_edit_distance_kernel(oracle):
     pb.band = [int(d) + realign.EDIT_BAND for d in want]
     ref = oracle.pairhmm_batch(pb, GapParams(), threads=8)
     assert np.all(np.abs(got - ref) <= TOL * np.maximum(1.0, np.abs(ref) * 1e-3))
+
+
+def test_fast_mode_matches_restatement(oracle):
+    """vlr_realign_fast_batch (PathHMMRealigner, realignment/mod.rs:547-678): best path probability over the alignments of
+    minimal edit distance, max-plus wavefront in log space, against the CPU restatement (itself checked against brute-force
+    enumeration in tests/test_realign_oracle.py).  Random windows of every variant kind, gap extension, edge shapes."""
+    for gap in (GapParams(), GapParams(math.log(1e-4), math.log(2e-4), math.log(0.2), math.log(0.3))):
+        pb, truth = realign_synth.generate(250, seed=13, banded=False)
+        g = [gap.prob_insertion_artifact, gap.prob_deletion_artifact, gap.prob_insertion_extend_artifact, gap.prob_deletion_extend_artifact]
+        got = realign.prob_best_path(pb, gap)
+        ref = np.array([oracle.pathhmm_best(pb.x[k], pb.y[k], pb.q[k], g) for k in range(len(pb))])
+        d = np.where(np.isneginf(got) & np.isneginf(ref), 0.0, np.abs(got - ref))
+        assert np.all(d <= 1e-9 * np.maximum(1.0, np.abs(ref))), (float(np.nanmax(d)), int(np.nanargmax(d)))
+        sup = np.array([got[2 * k + 1] > got[2 * k] for k in range(len(truth))])
+        assert (sup == truth).mean() > 0.9
+    rng = np.random.default_rng(6)
+    B = np.frombuffer(b"ACGT", np.uint8)
+    pb = PairBatch()
+    pb.add(b"A", b"A", [30]); pb.add(b"C", b"A", [30]); pb.add(b"ACGT", b"A", [40]); pb.add(b"AAAA", b"A", [40])
+    x = B[rng.integers(0, 4, 300)].tobytes()
+    pb.add(x, x[100:228], [37] * 128)
+    pb.add(x.lower(), x[100:228], [37] * 128)
+    pb.add(x[:3], x[:64], [20] * 64)                   # read much longer than the allele: leading / trailing insertions
+    pb.add(x, x[10:40] + x[45:90], [30] * 75)          # a deletion in the read
+    pb.add(x, x[10:40] + b"ACGTT" + x[40:90], [30] * 85)  # an insertion
+    for ly in (1, 2, 3, 63, 64, 65, 127, 128):
+        pb.add(x, x[50:50 + ly], [35] * ly)
+    g = GapParams()
+    gl = [g.prob_insertion_artifact, g.prob_deletion_artifact, g.prob_insertion_extend_artifact, g.prob_deletion_extend_artifact]
+    got = realign.prob_best_path(pb, g)
+    ref = np.array([oracle.pathhmm_best(pb.x[k], pb.y[k], pb.q[k], gl) for k in range(len(pb))])
+    assert np.allclose(got, ref, rtol=0, atol=1e-9), (got, ref)

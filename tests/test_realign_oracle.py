@@ -134,3 +134,52 @@ def test_edit_distance_restatement_against_the_textbook_definition(oracle):
         assert realign.best_hit(y, x) == (d, by_end.index(d) + 1)
     assert oracle.edit_distance(b"acgtACGT", b"CGTa")[0] == 0          # case-insensitive
     assert oracle.edit_distance(b"", b"A")[0] == -1 and oracle.edit_distance(b"A", b"")[0] == -1
+
+
+def _brute_best_path(x, y, q, gap):
+    """All semiglobal alignments of y in x by recursion: (edit distance, ln path probability) with the transition rules of
+    PathHMMRealigner (realignment/mod.rs:598-660); returns the best ln p among those of minimal distance."""
+    import math
+    gx, gy, gxe, gye = gap
+    lome = lambda p: math.log1p(-math.exp(p)) if p < -0.693 else (math.log(-math.expm1(p)) if p < 0 else -math.inf)
+    lae = lambda a, b: max(a, b) + math.log1p(math.exp(-abs(a - b))) if max(a, b) > -math.inf else -math.inf
+    no_gap = lome(lae(gx, gy))
+    close_x, close_y = lome(gxe), lome(gye)
+    reopen_x, reopen_y = lae(gxe, close_x + gx), lae(gye, close_y + gy)
+    best = [None]
+
+    def rec(i, j, prev, d, p):
+        if j == len(y):
+            if prev != "D" and (best[0] is None or (d, -p) < (best[0][0], -best[0][1])):
+                best[0] = (d, p)
+            return
+        lm = -q[j] * math.log(10) / 10
+        if i < len(x):  # match / substitution
+            t = {None: 0.0, "M": no_gap, "D": close_y, "I": close_x}[prev]
+            mm = x[i:i + 1].upper() != y[j:j + 1].upper()
+            rec(i + 1, j + 1, "M", d + mm, p + t + (lm + math.log(0.3333) if mm else lome(lm)))
+            if prev is not None:  # a leading deletion is never part of an optimal semiglobal alignment
+                t = {"M": gy, "D": reopen_y, "I": close_x + gy}[prev]
+                rec(i + 1, j, "D", d + 1, p + t)
+        t = {None: gx, "M": gx, "I": reopen_x, "D": close_y + gx}[prev]
+        rec(i, j + 1, "I", d + 1, p + t + lm)
+    for start in range(len(x) + 1):
+        rec(start, 0, None, 0, 0.0)
+    return best[0]
+
+
+def test_fast_mode_restatement_against_brute_force(oracle):
+    """vlro_pathhmm_best (PathHMMRealigner, realignment/mod.rs:547-678) on tiny sequences: equal to the enumeration of all
+    alignments — best path probability among those of minimal edit distance — with and without gap extension."""
+    import math
+    rng = np.random.default_rng(11)
+    for gap in ([math.log(2.8e-6), math.log(5.1e-6), -math.inf, -math.inf], [math.log(1e-3), math.log(2e-3), math.log(0.2), math.log(0.3)]):
+        for _ in range(60):
+            lx, ly = int(rng.integers(1, 7)), int(rng.integers(1, 5))
+            x = bytes(rng.choice(list(b"ACGT"), lx).tolist())
+            y = bytes(rng.choice(list(b"ACGT"), ly).tolist())
+            q = [int(v) for v in rng.choice([10, 20, 30, 40], ly)]
+            d, p = _brute_best_path(x, y, q, gap)
+            got = oracle.pathhmm_best(x, y, q, gap)
+            assert got == pytest.approx(p, abs=1e-9), (x, y, q, d, p, got)
+            assert oracle.edit_distance(x, y)[0] == d

@@ -22,6 +22,8 @@
 #include "vlr_plan.h"
 
 extern "C" int vlr_launch_afd_kernel(const vlr::DevPlan* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out, void* stream);
+extern "C" int vlr_launch_call_kernel_deep(const vlr::DevPlan* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out,
+                                           int n_univ, int n_samples, int range_depth, void* stream);
 extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_dev, const vlr::DevBatch* batch, const vlr::DevResults* out,
                                       int n_univ, int n_samples, int max_obs, int range_depth, void* stream);
 
@@ -270,6 +272,8 @@ struct vlr_plan {
     void* afd_log[2] = {nullptr, nullptr};
     size_t afd_log_bytes[2] = {0, 0};
     size_t afd_log_words = 0;
+    void* deep_pool[2] = {nullptr, nullptr};  // coefficient triples of the loci above the LDS budget (deep launch), one pool per slot;
+    size_t deep_pool_bytes[2] = {0, 0};       // its first 128 bytes hold the bump counters of the two AFD lanes
     void* afd_keys[2] = {nullptr, nullptr};   // l2fc-list keys of the AFD entries (DevResults::afd_key), one per slot
     size_t afd_keys_bytes[2] = {0, 0};
     int64_t afd_log_loci[2] = {0, 0};  // loci whose log regions fit afd_log[slot] (the budget of ensure_buffers)
@@ -798,6 +802,7 @@ void vlr_plan_destroy(vlr_plan* plan) {
         if (plan->escratch[k]) (void)hipFree(plan->escratch[k]);
         if (plan->afd_log[k]) (void)hipFree(plan->afd_log[k]);
         if (plan->afd_keys[k]) (void)hipFree(plan->afd_keys[k]);
+        if (plan->deep_pool[k]) (void)hipFree(plan->deep_pool[k]);
         if (plan->stage_stream[k]) (void)hipStreamDestroy(plan->stage_stream[k]);
     }
     if (plan->work_dev) (void)hipFree(plan->work_dev);
@@ -851,6 +856,12 @@ static int ensure_buffers(vlr_plan* plan, int64_t n_loci, int max_obs, bool want
     };
     int rc = grow(&plan->escratch[k], &plan->escratch_bytes[k], L * (size_t)max_obs * sizeof(double), false);
     if (rc != VLR_OK) return rc;
+    {   // pool of the deep launch: 24 B per kept observation of the loci above the LDS budget (default 512 MiB = 22 M observations
+        // per batch; VLR_DEEP_POOL_MB, 0 = no deep launch: such loci stay flagged VLR_LOCUS_TOO_DEEP).  Optional: no room, no fallback.
+        size_t pool = (size_t)512 << 20;
+        if (const char* ev = getenv("VLR_DEEP_POOL_MB")) pool = (size_t)std::max(0L, atol(ev)) << 20;
+        if (pool > 0) (void)grow(&plan->deep_pool[k], &plan->deep_pool_bytes[k], pool + 128, true);
+    }
     if (want_afd) {
         rc = grow(&plan->afd_scratch[k], &plan->afd_scratch_bytes[k], L + 8 * L + 4 * L + 64, false);
         if (rc != VLR_OK) return rc;
@@ -946,9 +957,27 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
     }
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipEventRecord(plan->ev_start, st));
+    // deep launch behind a call (or replay) launch: re-evaluates the loci that launch flagged VLR_LOCUS_TOO_DEEP with their
+    // coefficients in the plan's HBM pool; every other locus exits at once.  `lane`/`two`: the AFD sub-range lanes share the pool.
+    auto deep_launch = [&](const DevBatch& bs, DevResults rs, void* ss, int lane, bool two) -> int {
+        const int k = plan->slot & 1;
+        if (!plan->deep_pool[k] || plan->deep_pool_bytes[k] <= 128) return VLR_OK;
+        char* base = (char*)plan->deep_pool[k];
+        unsigned long long* ctr = (unsigned long long*)(base + 64 * lane);
+        size_t cap_d = (plan->deep_pool_bytes[k] - 128) / sizeof(double);
+        double* data = (double*)(base + 128);
+        if (two) { cap_d /= 2; data += (size_t)lane * cap_d; }
+        if (hipMemsetAsync(ctr, 0, sizeof(unsigned long long), (hipStream_t)ss) != hipSuccess) return fail(VLR_ERR_HIP, "deep pool reset failed");
+        rs.deep_pool = data; rs.deep_used = ctr; rs.deep_capacity = (long long)cap_d;
+        const int rc = vlr_launch_call_kernel_deep(&plan->host, &bs, &rs, plan->host.n_univ, plan->host.S, plan->host.max_range_depth, ss);
+        if (rc != 0) return fail(VLR_ERR_HIP, "deep kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        return VLR_OK;
+    };
     if (!want_afd) {
         int rc = vlr_launch_call_kernel(&plan->host, &b, &r, plan->host.n_univ, plan->host.S, max_obs, plan->host.max_range_depth, stream);
         if (rc != 0) return fail(VLR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        rc = deep_launch(b, r, stream, 0, false);
+        if (rc != VLR_OK) return rc;
         HIP_TRY(hipEventRecord(plan->ev_stop, st));
     } else {
         // FORMAT/AFD (calling.rs:889-928): from the log of the call pass; replay of the clean events where the log overflowed.
@@ -990,6 +1019,8 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
             rs.afd_key += (size_t)lane * (size_t)step * (size_t)S * (size_t)r.afd_capacity;
             int rc = vlr_launch_call_kernel(&plan->host, &bs, &rs, plan->host.n_univ, S, max_obs, plan->host.max_range_depth, ss);
             if (rc != 0) return fail(VLR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+            rc = deep_launch(bs, rs, ss, lane, two);
+            if (rc != VLR_OK) return rc;
             if (rs.afd_log) {
                 rc = vlr_launch_afd_kernel(&plan->host, &bs, &rs, ss);
                 if (rc != 0) return fail(VLR_ERR_HIP, "AFD kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -997,6 +1028,8 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
             rs.replay = 1;
             rc = vlr_launch_call_kernel(&plan->host, &bs, &rs, plan->host.n_univ, S, max_obs, plan->host.max_range_depth, ss);
             if (rc != 0) return fail(VLR_ERR_HIP, "AFD replay launch failed: %s", hipGetErrorString((hipError_t)rc));
+            rc = deep_launch(bs, rs, ss, lane, two);  // rs.replay == 1: the lists of the deep loci
+            if (rc != VLR_OK) return rc;
         }
         if (two) {
             HIP_TRY(hipEventRecord(plan->ev_join, plan->afd_aux_stream));
@@ -1232,17 +1265,32 @@ static int check_realign(const vlr_realign_batch_desc* b, const double* ln_prob)
     return VLR_OK;
 }
 
-int vlr_realign_batch(int device, const vlr_realign_batch_desc* b, double* ln_prob, void* hip_stream) {
+extern "C" int vlr_launch_pathhmm_kernel(const vlr_realign_batch_desc* b, double* ln_prob, void* stream);
+typedef int (*realign_launcher)(const vlr_realign_batch_desc*, double*, void*);
+
+static int realign_device(int device, const vlr_realign_batch_desc* b, double* ln_prob, void* hip_stream, realign_launcher launch) {
     int rc = check_realign(b, ln_prob);
     if (rc != VLR_OK) return rc;
     if (b->n_pairs == 0) return VLR_OK;
     HIP_TRY(hipSetDevice(device));
-    hipError_t e = (hipError_t)vlr_launch_realign_kernel(b, ln_prob, hip_stream);
+    hipError_t e = (hipError_t)launch(b, ln_prob, hip_stream);
     if (e != hipSuccess) return fail(VLR_ERR_HIP, "realign kernel launch: %s", hipGetErrorString(e));
     return VLR_OK;
 }
+static int realign_host(int device, const vlr_realign_batch_desc* b, double* ln_prob, realign_launcher launch);
 
-int vlr_realign_batch_host(int device, const vlr_realign_batch_desc* b, double* ln_prob) {
+int vlr_realign_batch(int device, const vlr_realign_batch_desc* b, double* ln_prob, void* hip_stream) {
+    return realign_device(device, b, ln_prob, hip_stream, vlr_launch_realign_kernel);
+}
+int vlr_realign_batch_host(int device, const vlr_realign_batch_desc* b, double* ln_prob) { return realign_host(device, b, ln_prob, vlr_launch_realign_kernel); }
+// `fast` realignment mode (PathHMMRealigner, realignment/mod.rs:547-678): best path probability over the alignments of minimal edit
+// distance; max_edit_dist of the batch is not read
+int vlr_realign_fast_batch(int device, const vlr_realign_batch_desc* b, double* ln_prob, void* hip_stream) {
+    return realign_device(device, b, ln_prob, hip_stream, vlr_launch_pathhmm_kernel);
+}
+int vlr_realign_fast_batch_host(int device, const vlr_realign_batch_desc* b, double* ln_prob) { return realign_host(device, b, ln_prob, vlr_launch_pathhmm_kernel); }
+
+static int realign_host(int device, const vlr_realign_batch_desc* b, double* ln_prob, realign_launcher launch) {
     int rc = check_realign(b, ln_prob);
     if (rc != VLR_OK) return rc;
     const int64_t n = b->n_pairs;
@@ -1271,7 +1319,7 @@ int vlr_realign_batch_host(int device, const vlr_realign_batch_desc* b, double* 
         db.x_offset = (const uint32_t*)(d + o_xoff); db.y_offset = (const uint32_t*)(d + o_yoff);
         db.x_bases = (const uint8_t*)(d + o_x); db.y_bases = (const uint8_t*)(d + o_y); db.y_quals = (const uint8_t*)(d + o_q);
         db.max_edit_dist = b->max_edit_dist ? (const int32_t*)(d + o_band) : nullptr;
-        hipError_t e = (hipError_t)vlr_launch_realign_kernel(&db, (double*)(d + o_out), st);
+        hipError_t e = (hipError_t)launch(&db, (double*)(d + o_out), st);
         if (e != hipSuccess) { rc = fail(VLR_ERR_HIP, "realign kernel launch: %s", hipGetErrorString(e)); break; }
         if (hipMemcpyAsync(ln_prob, d + o_out, n * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
             rc = fail(VLR_ERR_HIP, "result copy failed"); break;

@@ -14,6 +14,10 @@
 // place, every stage runs on a pool of std::threads over contiguous record ranges.  Pure host code; the only device-related call
 // is vlr_host_alloc (page-locked result arrays so that vlr_batch_run_host copies them by direct DMA).
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <sched.h>
 #include <zlib.h>
 
@@ -123,14 +127,31 @@ struct Blob {
     Blob() = default;
     Blob(const Blob&) = delete;
     Blob& operator=(const Blob&) = delete;
-    ~Blob() { free(p); }
-    bool alloc(size_t bytes) { free(p); p = (uint8_t*)malloc(bytes ? bytes : 1); n = p ? bytes : 0; return p != nullptr; }
+    bool mapped = false;
+    void release() { if (p) { if (mapped) munmap(p, n ? n : 1); else free(p); } p = nullptr; n = 0; mapped = false; }
+    ~Blob() { release(); }
+    bool alloc(size_t bytes) { release(); p = (uint8_t*)malloc(bytes ? bytes : 1); n = p ? bytes : 0; return p != nullptr; }
+    // the file's pages straight from the page cache (no copy; the inflate workers fault them in side by side)
+    bool map_file(const char* path) {
+        release();
+        const int fd = open(path, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || st.st_size <= 0) { close(fd); return false; }
+        void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) return false;
+        (void)madvise(m, (size_t)st.st_size, MADV_WILLNEED);
+        p = (uint8_t*)m; n = (size_t)st.st_size; mapped = true;
+        return true;
+    }
     const uint8_t* data() const { return p; }
     size_t size() const { return n; }
     uint8_t operator[](size_t i) const { return p[i]; }
 };
 
 bool read_whole_file(const char* path, Blob& out, std::string& err) {
+    if (out.map_file(path)) return true;
     FILE* f = fopen(path, "rb");
     if (!f) { err = std::string("cannot open ") + path; return false; }
     fseek(f, 0, SEEK_END);
@@ -227,7 +248,7 @@ bool load_inflated(const char* path, Blob& out_blob, int n_threads, std::string&
     g_ingest_t[0] += now_s() - t0;
     std::vector<uint8_t> out;
     auto finish = [&](std::vector<uint8_t>& v) { if (!out_blob.alloc(v.size())) { err = "out of memory"; return false; } memcpy(out_blob.p, v.data(), v.size()); return true; };
-    if (raw.size() < 2 || raw[0] != 0x1f || raw[1] != 0x8b) { std::swap(out_blob.p, raw.p); std::swap(out_blob.n, raw.n); return true; }
+    if (raw.size() < 2 || raw[0] != 0x1f || raw[1] != 0x8b) { std::swap(out_blob.p, raw.p); std::swap(out_blob.n, raw.n); std::swap(out_blob.mapped, raw.mapped); return true; }
     std::vector<BgzfBlock> blocks;
     if (bgzf_index(raw, blocks)) {
         size_t total = 0;
@@ -458,13 +479,52 @@ struct RecView {
     bool imprecise = false;
     double het_ln = NAN, som_ln = NAN;
     std::vector<uint8_t> vec[FD_N_VEC];  // bincode bytes of every vector field (LE u16 words of the INFO integers)
+    // the MiniLogProb and enum vectors of a BCF record (the bulk of it) are decoded straight from the typed integers:
+    // word k of the field = low 16 bits of element k; wstride = bytes per element (1: int8, sign-extended; 2; 4), 0 = use vec
+    const uint8_t* wsrc[FD_N_VEC] = {};
+    uint32_t wn[FD_N_VEC] = {};
+    int wstride[FD_N_VEC] = {};
     bool present[FD_N_VEC] = {};
     void reset() {
         id.clear(); ref.clear(); alt.clear(); event.clear(); mateid.clear();
         imprecise = false; het_ln = NAN; som_ln = NAN;
-        for (int i = 0; i < FD_N_VEC; ++i) { vec[i].clear(); present[i] = false; }
+        for (int i = 0; i < FD_N_VEC; ++i) { vec[i].clear(); present[i] = false; wsrc[i] = nullptr; wn[i] = 0; wstride[i] = 0; }
     }
 };
+inline bool hot_field(int f) { return f <= FD_PROB_HIT_BASE || (f >= FD_STRAND && f <= FD_ALTLOCUS); }
+template <int ST>
+inline uint32_t word16(const uint8_t* p, size_t k) {
+    if (ST == 4) return (uint32_t)p[4 * k] | ((uint32_t)p[4 * k + 1] << 8);
+    if (ST == 2) return (uint32_t)p[2 * k] | ((uint32_t)p[2 * k + 1] << 8);
+    return (uint32_t)(uint16_t)(int16_t)(int8_t)p[k];
+}
+// Vec<MiniLogProb>: u64 length (4 words), then per element a u32 tag (2 words) and an f16 (1 word) or an f32 (2 words)
+template <int ST>
+bool mini_words(const uint8_t* p, uint32_t nw, uint64_t n, float* dst) {
+    size_t k = 4;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (k + 3 > nw) return false;
+        const uint32_t tag = word16<ST>(p, k) | (word16<ST>(p, k + 1) << 16);
+        if (tag == 0) { dst[i] = half_to_float((uint16_t)word16<ST>(p, k + 2)); k += 3; }
+        else if (tag == 1) {
+            if (k + 4 > nw) return false;
+            const uint32_t bits = word16<ST>(p, k + 2) | (word16<ST>(p, k + 3) << 16);
+            float f; memcpy(&f, &bits, 4); dst[i] = f; k += 4;
+        } else return false;
+    }
+    return true;
+}
+template <int ST>
+uint64_t len_words(const uint8_t* p, uint32_t nw) {
+    if (nw < 4) return ~0ull;
+    return (uint64_t)word16<ST>(p, 0) | ((uint64_t)word16<ST>(p, 1) << 16) | ((uint64_t)word16<ST>(p, 2) << 32) | ((uint64_t)word16<ST>(p, 3) << 48);
+}
+template <int ST, typename Put>
+bool enum_words(const uint8_t* p, uint32_t nw, uint64_t n, Put&& put) {
+    if ((uint64_t)nw < 4 + 2 * n) return false;
+    for (uint64_t i = 0; i < n; ++i) put(i, word16<ST>(p, 4 + 2 * i) | (word16<ST>(p, 5 + 2 * i) << 16));
+    return true;
+}
 
 struct Cursor {  // bincode reader (little-endian, u64 lengths, u32 enum tags, u8 Option tags)
     const uint8_t* p; const uint8_t* e; bool bad = false;
@@ -512,21 +572,45 @@ bool decode_into(const RecView& r, Chunk& c, std::string& err) {
     uint64_t n = 0;
     const size_t base = c.flags.size();
     for (int k = 0; k < 7; ++k) {  // column order of vlr_batch: pm, pa, pr, miss, psa, pdo, phb
-        const auto& v = r.vec[kMini[k]];
+        const int f = kMini[k];
+        auto& col = c.col[k];
+        if (r.wstride[f]) {
+            const uint8_t* p = r.wsrc[f];
+            const uint32_t nw = r.wn[f];
+            const int st = r.wstride[f];
+            const uint64_t m = st == 4 ? len_words<4>(p, nw) : st == 2 ? len_words<2>(p, nw) : len_words<1>(p, nw);
+            if (k == 0) n = m;
+            if (m != n || m > (1u << 28)) { err = "inconsistent observation vector lengths"; return false; }
+            col.resize(base + n);
+            float* dst = col.data() + base;
+            const bool ok = st == 4 ? mini_words<4>(p, nw, n, dst) : st == 2 ? mini_words<2>(p, nw, n, dst) : mini_words<1>(p, nw, n, dst);
+            if (!ok) { err = std::string("truncated ") + kFieldName[f]; return false; }
+            continue;
+        }
+        const auto& v = r.vec[f];
         Cursor cu{v.data(), v.data() + v.size()};
         const uint64_t m = cu.u64();
         if (k == 0) n = m;
         if (m != n || m > (1u << 28)) { err = "inconsistent observation vector lengths"; return false; }
-        auto& col = c.col[k];
         col.resize(base + n);
         float* dst = col.data() + base;
         for (uint64_t i = 0; i < n; ++i) dst[i] = cu.mini();
-        if (cu.bad) { err = std::string("truncated ") + kFieldName[kMini[k]]; return false; }
+        if (cu.bad) { err = std::string("truncated ") + kFieldName[f]; return false; }
     }
     c.flags.resize(base + n);
     uint32_t* fl = c.flags.data() + base;
     for (uint64_t i = 0; i < n; ++i) fl[i] = 0;
     auto enums = [&](int field, auto&& put) -> bool {
+        if (r.wstride[field]) {
+            const uint8_t* p = r.wsrc[field];
+            const uint32_t nw = r.wn[field];
+            const int st = r.wstride[field];
+            const uint64_t m = st == 4 ? len_words<4>(p, nw) : st == 2 ? len_words<2>(p, nw) : len_words<1>(p, nw);
+            if (m != n) { err = std::string("length of ") + kFieldName[field]; return false; }
+            const bool ok = st == 4 ? enum_words<4>(p, nw, n, put) : st == 2 ? enum_words<2>(p, nw, n, put) : enum_words<1>(p, nw, n, put);
+            if (!ok) { err = std::string("truncated ") + kFieldName[field]; return false; }
+            return true;
+        }
         const auto& v = r.vec[field];
         Cursor cu{v.data(), v.data() + v.size()};
         if (cu.u64() != n) { err = std::string("length of ") + kFieldName[field]; return false; }
@@ -672,6 +756,7 @@ bool parse_bcf_record(const uint8_t* rec, const uint8_t* end, const std::vector<
         if (f < 0) continue;
         if (f < FD_N_VEC) {
             if (val.type < 1 || val.type > 3) continue;  // read_values: info(tag).integer()
+            if (hot_field(f)) { r.wsrc[f] = val.data; r.wn[f] = val.n; r.wstride[f] = val.type == 3 ? 4 : val.type; r.present[f] = true; continue; }
             auto& out = r.vec[f];
             out.resize((size_t)val.n * 2);
             // i32 -> u16 -> 2 bytes LE (mod.rs:836-842); vector-end padding cannot occur inside an INFO vector
@@ -817,6 +902,11 @@ bool read_sample_file(const char* path, int n_threads, SampleFile& sf, std::stri
     std::mutex contig_mu;
     parallel_ranges(n, T, [&](int64_t b, int64_t e, int t) {
         Chunk& c = sf.chunks[(size_t)t];
+        {   // one allocation per column instead of doubling (a v15 observation takes 100-160 bytes of an uncompressed BCF record)
+            const size_t est = is_bcf ? (starts[(size_t)e] - starts[(size_t)b]) / 100 + 1024 : 0;
+            if (est) { for (int k = 0; k < 9; ++k) c.col[k].reserve(est); c.flags.reserve(est); c.third.reserve(est); }
+            c.n_obs.reserve((size_t)(e - b));
+        }
         RecView r;
         for (int64_t i = b; i < e && c.error.empty(); ++i) {
             r.reset();
@@ -1163,6 +1253,14 @@ char kr_letter(double bf) {  // utils/mod.rs:158-167 over bio's Kass-Raftery sca
 }
 // utils/mod.rs:122-156 generalized_cigar, keep_order = false: counts in first-appearance order, stable by count desc, stable by aux
 template <typename Aux>
+std::string cigar_of_counts(std::vector<std::pair<std::string, int>>& cnt, Aux aux) {
+    std::stable_sort(cnt.begin(), cnt.end(), [](const auto& a, const auto& b) { return a.second > b.second; });
+    std::stable_sort(cnt.begin(), cnt.end(), [&](const auto& a, const auto& b) { return aux(a.first) < aux(b.first); });
+    std::string out;
+    for (auto& kv : cnt) { out += std::to_string(kv.second); out += kv.first; }
+    return out;
+}
+template <typename Aux>
 std::string generalized_cigar(const std::vector<std::string>& items, Aux aux) {
     std::vector<std::pair<std::string, int>> cnt;  // a handful of distinct items: a linear search beats hashing
     for (auto& it : items) {
@@ -1185,7 +1283,10 @@ void sample_fields(const vlr_obs_table* t, const vlr_results* r, int64_t l, int 
     const int S = t->n_samples;
     const uint32_t b = t->obs_offset[l * S + s], e = t->obs_offset[l * S + s + 1];
     const bool drop_nonstd = t->locus_flags[l] & VLR_LOCUS_REMOVE_NONSTANDARD;  // pileup.rs:26-43
-    std::vector<std::string> obs_items, alt_items, ref_items;
+    // observations are counted by a packed key (two score characters, the flag characters, third-allele evidence); the strings
+    // are only built for the distinct keys, in first-appearance order (what Counter::most_common sees)
+    std::vector<std::pair<uint64_t, int>> obs_cnt;
+    std::vector<std::string> alt_items, ref_items;
     double depth = 0.0;
     int kept = 0;
     for (uint32_t i = b; i < e; ++i) {
@@ -1197,29 +1298,45 @@ void sample_fields(const vlr_obs_table* t, const vlr_results* r, int64_t l, int 
         depth += std::exp(pm);
         const double bf_alt = std::exp(pa - pr), bf_ref = std::exp(pr - pa);
         const bool maxq = f & VLR_F_MAX_MAPQ;
-        std::string score;
-        if (bf_alt > bf_ref) { score = "A"; score.push_back(kr_letter(bf_alt)); }
-        else if (bf_ref > bf_alt) { score = "R"; score.push_back(kr_letter(bf_ref)); }
-        else score = "E";
-        for (auto& ch : score) ch = maxq ? (char)toupper(ch) : (char)tolower(ch);
+        char s0, s1 = 0;
+        if (bf_alt > bf_ref) { s0 = 'A'; s1 = kr_letter(bf_alt); }
+        else if (bf_ref > bf_alt) { s0 = 'R'; s1 = kr_letter(bf_ref); }
+        else s0 = 'E';
+        if (!maxq) { s0 = (char)tolower(s0); if (s1) s1 = (char)tolower(s1); }
         const unsigned strand = (f >> VLR_F_STRAND_SHIFT) & 3, altloc = (f >> VLR_F_ALTLOCUS_SHIFT) & 3;
         const bool hp_err = (f & VLR_F_HP_LEN_VALID) && ((f >> VLR_F_HP_LEN_SHIFT) & 0xff) != 0;
-        std::string item = score;
-        item += t->third[i] >= 0 ? std::to_string(t->third[i]) : std::string(".");
-        item.push_back((f & VLR_F_PAIRED) ? 'p' : 's');
-        item.push_back("#*."[altloc > 2 ? 2 : altloc]);
-        item.push_back("+-*."[strand]);
-        item.push_back("><*!"[orient]);
-        item.push_back((f & VLR_F_READPOS_MAJOR) ? '^' : '*');
-        item.push_back((f & VLR_F_SOFTCLIPPED) ? '$' : '.');
-        item.push_back(hp_err ? '*' : '.');
-        obs_items.push_back(item);
+        const uint64_t key = (uint64_t)(uint8_t)s0 | ((uint64_t)(uint8_t)s1 << 8) | ((uint64_t)((f & VLR_F_PAIRED) ? 1 : 0) << 16) |
+                             ((uint64_t)(altloc > 2 ? 2 : altloc) << 17) | ((uint64_t)strand << 19) | ((uint64_t)orient << 21) |
+                             ((uint64_t)((f & VLR_F_READPOS_MAJOR) ? 1 : 0) << 23) | ((uint64_t)((f & VLR_F_SOFTCLIPPED) ? 1 : 0) << 24) |
+                             ((uint64_t)(hp_err ? 1 : 0) << 25) | ((uint64_t)(uint32_t)(t->third[i] + 1) << 32);
+        size_t k = 0;
+        while (k < obs_cnt.size() && obs_cnt[k].first != key) ++k;
+        if (k == obs_cnt.size()) obs_cnt.emplace_back(key, 1);
+        else obs_cnt[k].second++;
         if (pa > pr) { const char c = kr_letter(bf_alt); alt_items.push_back(std::string(1, maxq ? (char)toupper(c) : (char)tolower(c))); }
         else { const char c = kr_letter(bf_ref); ref_items.push_back(std::string(1, maxq ? (char)toupper(c) : (char)tolower(c))); }
     }
+    std::vector<std::pair<std::string, int>> obs_pairs;
+    obs_pairs.reserve(obs_cnt.size());
+    for (auto& kc : obs_cnt) {
+        const uint64_t key = kc.first;
+        std::string item;
+        item.push_back((char)(key & 0xff));
+        if ((key >> 8) & 0xff) item.push_back((char)((key >> 8) & 0xff));
+        const uint32_t th = (uint32_t)(key >> 32);
+        item += th ? std::to_string((int64_t)th - 1) : std::string(".");
+        item.push_back(((key >> 16) & 1) ? 'p' : 's');
+        item.push_back("#*."[(key >> 17) & 3]);
+        item.push_back("+-*."[(key >> 19) & 3]);
+        item.push_back("><*!"[(key >> 21) & 3]);
+        item.push_back(((key >> 23) & 1) ? '^' : '*');
+        item.push_back(((key >> 24) & 1) ? '$' : '.');
+        item.push_back(((key >> 25) & 1) ? '*' : '.');
+        obs_pairs.emplace_back(item, kc.second);
+    }
     o.dp = kept ? (int32_t)std::floor(depth + 0.5) : 0;  // expected_depth (read_observation.rs:43-47)
     o.oobs = (int32_t)(e - b) - kept;
-    o.obs = generalized_cigar(obs_items, [](const std::string& k) { return k[0] == 'N' ? 2 : k[0] == 'E' ? 1 : 0; });
+    o.obs = cigar_of_counts(obs_pairs, [](const std::string& k) { return k[0] == 'N' ? 2 : k[0] == 'E' ? 1 : 0; });
     auto simple = [](const std::string& k) { return k[0] == 'R' ? 2 : (k.back() == 'E' ? 1 : 0); };
     o.saobs = generalized_cigar(alt_items, simple);
     o.srobs = generalized_cigar(ref_items, simple);

@@ -24,6 +24,15 @@
 
 #pragma clang fp contract(off)
 
+// Deep build (vlr_kernels_deep.hip includes this file with VLR_DEEP_BUILD and the namespace renamed): the same call kernel with the
+// coefficient triples of a locus in a plan-owned HBM pool instead of LDS, launched behind the normal kernel for the loci it
+// flagged VLR_LOCUS_TOO_DEEP (pileups above the LDS budget; the reference has no depth limit, sample.rs:236 is only a default).
+#ifdef VLR_DEEP_BUILD
+#define VLR_DEEP 1
+#else
+#define VLR_DEEP 0
+#endif
+
 namespace vlr {
 
 // optional per-phase cycle accounting (build with -DVLR_PROFILE): wall cycles of the wave spent per phase
@@ -681,6 +690,8 @@ struct Ctx {
     const double* ecoef;               // third coefficient of every kept observation of this locus (HBM scratch row)
     double *cacheA, *cacheB, *cacheV;  // [S][kCacheWays] per-sample likelihood cache (LDS)
     double* dkeyV;                     // [n_dkey] pileup likelihoods of the flattened discrete roots, per hypothesis (LDS)
+    int* kshift;                       // [S] binary exponent taken out of the coefficients of sample s under the current hypothesis
+                                       // (0 unless the pileup needed the scaled coefficient pass, see "underflow rescue")
     Frame* frames;                     // [nframes] explicit recursion stack of walk_root (LDS, sized by the plan's deepest path)
     RangeSt* rs;                       // [nrs] adaptive-integration state per nested Range level (LDS)
     int nframes, nrs;
@@ -758,6 +769,13 @@ __device__ inline void alpha_beta(const DevPlan& p, int s, double a, double b, d
 }
 
 // scratch row of the third coefficients of sample s, or nullptr when they are all zero (WaveSt::ehas)
+// ln 2 x (exponents taken out of the coefficients of the samples in `mask`): added to every pileup log-likelihood of those samples
+__device__ __forceinline__ double kshift_ln(const Ctx& c, int mask) {
+    int k = 0;
+    for (int s = 0; s < c.S; ++s)
+        if ((mask >> s) & 1) k += c.kshift[s];
+    return (double)UNI(k) * kLn2;
+}
 __device__ __forceinline__ const double* ecoef_of(const Ctx& c, int s, int off) {
     return ((c.ehas >> s) & 1) ? c.ecoef + off : nullptr;
 }
@@ -774,7 +792,7 @@ __device__ inline double sample_lik_point(Ctx& c, int s, double a, double b) {  
     accum_terms<1, 64>(c.coef + 2 * off, ecoef_of(c, s, off), D, c.lane, (w->fastok >> s) & 1, &al, &be, P1, E1);
     reduce_terms<1, 64>(P1, E1);
     if (c.lane == 0) { w->work[0] += 1; w->work[1] += (unsigned long long)D; }
-    return uni_d(log(P1[0]) + (double)E1[0] * kLn2);
+    return uni_d(log(P1[0]) + (double)(E1[0] + c.kshift[s]) * kLn2);
 }
 __device__ inline double sample_lik(Ctx& c, int s, double a, double b) {
     WaveSt* w = c.w;
@@ -1433,6 +1451,7 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
     }
     fixed = uni_d(fixed);
     pidx = UNI(pidx);
+    const double dep_shift = kshift_ln(c, dep);
     const double* ptab = p.prior_table + c.vt * p.table_size;
     const int istride = p.class_stride[inner];
     const int ncls = p.n_class[inner];
@@ -1498,7 +1517,7 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
                 accum_terms<1, 16>(c.coef + 2 * UNI(w->soff[s]), ecoef_of(c, s, UNI(w->soff[s])), UNI(w->nkeep[s]), rlane, (w->fastok >> s) & 1, &al, &be, P1, E1);
             }
             reduce_terms<1, 16>(P1, E1);
-            const double lik = fixed + (log(P1[0]) + (double)E1[0] * kLn2);
+            const double lik = fixed + (log(P1[0]) + (double)E1[0] * kLn2) + dep_shift;
             double jv;
             if (c.nlfc > 0 && !lfcs_ok(c, inner, xr)) jv = VLR_NEG_INF;
             else {
@@ -1879,7 +1898,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
     const int cap = c.cap;
     VLR_WAVE_FENCE();
     const ChainTask& T = w->task[rowon ? row : __builtin_ctz(rowmask)];
-    const double lo = T.lo, hi = T.hi, res = T.res, fixed = T.fixed;
+    const double lo = T.lo, hi = T.hi, res = T.res, fixed0 = T.fixed;
     const RangeV orig{T.ostart, T.oend, T.olex, T.orex};
     const int simpson_n = T.simpson_n, pidx = T.pidx, contained = T.contained;
     const double* tvr = c.tvaf + (rowon ? row : __builtin_ctz(rowmask)) * c.S;
@@ -1890,6 +1909,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
     int dep = 0;
     for (int s = 0; s < c.S; ++s)
         if (s == inner || p.by[s] == inner) dep |= 1 << s;
+    const double fixed = fixed0 + kshift_ln(c, dep);  // + the exponents the scaled coefficient pass took out (0 otherwise)
     unsigned dep_terms = 0;  // observation terms per point
     for (int s = 0; s < c.S; ++s)
         if ((dep >> s) & 1) dep_terms += (unsigned)w->nkeep[s];
@@ -2390,7 +2410,7 @@ __device__ __forceinline__ bool bo_setup(Ctx& c, const Frame& f, RangeSt& r) {
         int off = UNI(w->soff[s]), D = UNI(w->nkeep[s]);
         eval_pileup(c.coef + 2 * off, ecoef_of(c, s, off), D, (w->fastok >> s) & 1, nt, w->bpend[1], w->bpend[2], w->bpend[3], lane);
         __syncthreads();
-        if (lane < nt) w->task[lane].fixed += w->bpend[3][lane];
+        if (lane < nt) w->task[lane].fixed += w->bpend[3][lane] + (double)c.kshift[s] * kLn2;
         if (lane == 0) { w->work[0] += (unsigned long long)nt; w->work[1] += (unsigned long long)nt * (unsigned long long)D; }
         __syncthreads();
     }
@@ -3017,15 +3037,16 @@ __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, Dev
 // +33 %).  The launcher picks by LDS bytes.
 template <int WPE>
 __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_arg, DevBatch batch, DevResults out,
-                                                           int max_obs, int range_depth) {
+                                                           int max_obs, int range_depth, int dyn_doubles) {
     extern __shared__ double dyn[];
     __shared__ WaveSt wst;
     const DevPlan& p = plan_arg;
     const int lane = threadIdx.x;
     const int64_t locus = blockIdx.x;
     if (locus >= batch.n_loci) return;
+    if (VLR_DEEP && !(out.status[locus] & VLR_LOCUS_TOO_DEEP)) return;  // deep launch: only what the LDS-resident kernel could not hold
     // replay launch next to an AFD log: only the loci whose log region overflowed are re-evaluated
-    if (out.replay && out.afd_log && __double_as_longlong(out.afd_log[(size_t)locus * (size_t)out.afd_log_stride]) >= 0) return;
+    if (!VLR_DEEP && out.replay && out.afd_log && __double_as_longlong(out.afd_log[(size_t)locus * (size_t)out.afd_log_stride]) >= 0) return;
     const int S = p.S;
     WaveSt* w = &wst;
 
@@ -3062,12 +3083,13 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
     c.nframes = p.max_frames; c.nrs = range_depth;
     c.frames = (Frame*)(c.dkeyV + p.n_dkey);
     c.rs = (RangeSt*)(c.frames + c.nframes);
+    c.kshift = (int*)(dyn + dyn_doubles - (S + 1) / 2);  // last words of the dynamic area
     c.mapJ = mapJ; c.mapVaf = mapVaf; c.mapHyp = mapHyp; c.n_slots = n_slots;
     c.status = 0;
     if (lane == 0) { w->work[0] = 0; w->work[1] = 0; }
     c.need_batch = 0; c.bt_nt = 0; c.bt_inner = 0;
     c.replay = out.replay; c.locus = locus; c.outp = &out; c.mapGroup = 0; c.mapDisc = 0; c.marginal = 0.0;
-    c.lg = (out.afd_log && !out.replay) ? out.afd_log + (size_t)locus * (size_t)out.afd_log_stride : nullptr;
+    c.lg = (out.afd_log && !out.replay && !VLR_DEEP) ? out.afd_log + (size_t)locus * (size_t)out.afd_log_stride : nullptr;
     c.lg_pos = kLogFirst; c.lg_cap = (int)out.afd_log_stride; c.lg_nrec = 0; c.hyp = 0;
 #ifdef VLR_PROFILE
     for (int i = 0; i < 24; ++i) c.prof[i] = 0;
@@ -3209,7 +3231,21 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
         __syncthreads();
         if (lane == 0) { w->pos_all[s] = e_all; w->pos_major[s] = e_major; w->pos_rate[s] = e_rate; }
     }
-    if (offset_acc > max_obs) too_deep = true;
+    int obs_cap = max_obs;
+    double* ecoef_w = out.escratch + (size_t)blockIdx.x * (size_t)max_obs;
+    if (VLR_DEEP) {  // {c, q} pairs and e of every kept observation from the pool: 3 doubles per observation
+        const unsigned long long need = 3ull * (unsigned long long)offset_acc;
+        unsigned long long at = 0;
+        if (lane == 0) at = atomicAdd(out.deep_used, need);
+        at = (unsigned long long)UNI64((long long)at);
+        if (at + need > (unsigned long long)out.deep_capacity) too_deep = true;
+        else {
+            c.coef = out.deep_pool + at;
+            ecoef_w = out.deep_pool + at + 2ull * (unsigned long long)offset_acc;
+            c.ecoef = ecoef_w;
+            obs_cap = offset_acc;
+        }
+    } else if (offset_acc > max_obs) too_deep = true;
     if (lane == 0) w->ehas = ehas_mask;
     c.ehas = ehas_mask;
     __syncthreads();
@@ -3311,7 +3347,10 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
         for (int s = 0; s < S; ++s) { double v = out.map_vaf[locus * S + s]; if (v != v) have = false; }
         bool art = false;
         if (out.map_bias) for (int i = 0; i < VLR_N_BIAS; ++i) art = art || out.map_bias[locus * VLR_N_BIAS + i] != 0;
-        if (!have || art || too_deep) return;
+        if (!have || art || too_deep) {
+            if (VLR_DEEP && !too_deep && lane == 0) out.status[locus] &= ~VLR_LOCUS_TOO_DEEP;  // no lists to make: done
+            return;
+        }
         __syncthreads();
         if (lane < S) { c.mapv[lane] = out.map_vaf[locus * S + lane]; c.afd_nseen[lane] = 0; }
         __syncthreads();
@@ -3340,6 +3379,16 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
             int wr = w->soff[s];
             int fast_s = 1, vfast_s = 1;
             const bool ehas_s = (ehas_mask >> s) & 1;
+            // Underflow rescue: a term that is finite in the reference's log space but zero or subnormal in linear space
+            // (|log-prob| beyond ~708) makes the pass run a second time for this sample with every observation's coefficients
+            // scaled by its own power of two 2^-k_i; the exponents add up to kshift[s], which every pileup log-likelihood of the
+            // sample gets back (kshift_ln).  Never taken on pair-HMM output (supports are normalised, realignment/mod.rs:359-374).
+            bool need_rescue = false;
+            int kacc = 0;
+          for (int scaled = 0; scaled < 2; ++scaled) {
+            if (scaled && !need_rescue) break;
+            wr = w->soff[s]; fast_s = 1; vfast_s = 1;
+            bool fatal = false;
             // every column of a row in one round of loads (the few rows that are dropped below are loaded in vain), and the rows of
             // the NEXT 64 observations are requested before this iteration's arithmetic starts
             ObsRow nxt = load_obs_row(batch, o0 + lane, o1);
@@ -3408,13 +3457,28 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                     double A = exp(pa) * fa, R = exp(pr) * fr;
                     double uu = mis * exp(miss) * fany;
                     double sv = exp(psa);
-                    const bool uflow = (A == 0.0 && fa != 0.0 && pa > VLR_NEG_INF) || (R == 0.0 && fr != 0.0 && pr > VLR_NEG_INF);
+                    bool uflow = (A == 0.0 && fa != 0.0 && pa > VLR_NEG_INF) || (R == 0.0 && fr != 0.0 && pr > VLR_NEG_INF);
                     double d = A - R;
                     double cc_ = wv * R + uu, cq_ = wv * sv * d, ce_ = wv * (1.0 - sv) * d;
-                    if (pos < max_obs) {
+                    if (scaled) {
+                        // the three log-space addends of the observation's likelihood, their largest as the binary exponent k
+                        const double lA = (fa > 0.0 && pa > VLR_NEG_INF) ? pm + pa + log(fa) : VLR_NEG_INF;
+                        const double lR = (fr > 0.0 && pr > VLR_NEG_INF) ? pm + pr + log(fr) : VLR_NEG_INF;
+                        const double lU = (mis > 0.0 && fany > 0.0 && miss > VLR_NEG_INF) ? log(mis) + miss + log(fany) : VLR_NEG_INF;
+                        const double mx = fmax(lA, fmax(lR, lU));
+                        const int ki = (mx > VLR_NEG_INF) ? (int)floor(mx / kLn2) : 0;
+                        const double sh = (double)ki * kLn2;
+                        const double WA = (lA > VLR_NEG_INF) ? exp(lA - sh) : 0.0, WR = (lR > VLR_NEG_INF) ? exp(lR - sh) : 0.0;
+                        const double UU = (lU > VLR_NEG_INF) ? exp(lU - sh) : 0.0;
+                        d = WA - WR;
+                        cc_ = WR + UU; cq_ = sv * d; ce_ = (1.0 - sv) * d;
+                        kacc += ki;
+                        uflow = false;
+                    }
+                    if (pos < obs_cap) {
                         c.coef[2 * pos + 0] = cc_;
                         c.coef[2 * pos + 1] = cq_;
-                        if (ehas_s) __hip_atomic_store(out.escratch + (size_t)blockIdx.x * (size_t)max_obs + pos, ce_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (ehas_s) __hip_atomic_store(ecoef_w + pos, ce_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                     // smallest value the term can take over alpha in [0,1], beta in [0,1] (linear => at a corner)
                     double mn = fmin(fmin(cc_, cc_ + cq_), fmin(cc_ + ce_, cc_ + cq_ + ce_));
@@ -3422,12 +3486,20 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                     // e^x of a finite log-probability came out as zero: harmless while the term itself stays a normal number
                     // (whatever underflowed is below 5e-324, i.e. < 2.5e-16 of any normal term: the reference's ln_add_exp
                     // drops it too).  Only a term that is itself unrepresentable makes the locus unusable in linear space.
-                    if (uflow && !(mn >= 0x1p-1022)) c.status |= VLR_LOCUS_UNDERFLOW;
+                    if (uflow && !(mn >= 0x1p-1022)) fatal = true;
                     small = !(mn >= 0x1p-70 && fmax(fmax(cc_, cc_ + cq_), fmax(cc_ + ce_, cc_ + cq_ + ce_)) <= 2.0);
                 }
                 if (__ballot(tiny)) fast_s = 0;
                 if (__ballot(small)) vfast_s = 0;
                 wr += popc64(km);
+            }
+            const bool bad = __ballot(fatal) != 0ull;
+            if (!scaled) need_rescue = bad;
+            else if (bad) c.status |= VLR_LOCUS_UNDERFLOW;  // cannot happen: the largest addend of every term is in [1/2, 1)
+          }
+            {
+                const int ks = need_rescue ? (int)wave_sum((double)kacc) : 0;
+                if (lane == 0) c.kshift[s] = ks;
             }
             if (fast_s) fastmask |= 1 << s;
             if (vfast_s) vfastmask |= 1 << s;
@@ -3602,7 +3674,11 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
         PROF_ADD(c, 3);
     }
     PROF_ADD(c, 3);  // walk remainder (everything in the event loop not attributed below)
-    if (c.replay) { afd_finish(c); return; }
+    if (c.replay) {
+        afd_finish(c);
+        if (VLR_DEEP && lane == 0) out.status[locus] &= ~VLR_LOCUS_TOO_DEEP;  // evaluated by the deep call launch, lists done
+        return;
+    }
     // ============================ phase C: posteriors + MAP ============================
     // bio Model::compute: marginal = ln_sum_exp(event values); posterior = value - marginal
     const int n_out = p.n_named + 2;
@@ -3683,6 +3759,8 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
         c.lg[0] = __longlong_as_double((long long)c.lg_pos);
         c.lg[1] = __longlong_as_double((long long)c.lg_nrec);
     }
+    // deep launch with AFD lists: the deep replay launch still has to find this locus
+    if (VLR_DEEP && out.afd_count && !(c.status & VLR_LOCUS_TOO_DEEP)) c.status |= VLR_LOCUS_TOO_DEEP;
     if (lane == 0) {
         out.status[locus] = c.status;
         if (out.work) {
@@ -3736,6 +3814,7 @@ __global__ void __launch_bounds__(64) vlr_selftest_stream_kernel(const float* in
     }
 }
 }  // namespace vlr
+#if !VLR_DEEP
 extern "C" int vlr_launch_selftest_stream(const float* in, double* out, long long n, int mode, void* stream) {
     if (n <= 0) return 0;
     const long long per_wg = 64 * 256;
@@ -3749,6 +3828,28 @@ extern "C" int vlr_launch_selftest_math(int which, const double* a, const double
     return (int)hipGetLastError();
 }
 
+#endif  // !VLR_DEEP (selftest launchers)
+#if VLR_DEEP
+// deep launcher: the 2-waves-per-SIMD instance only (no coefficient area in LDS; max_obs = 0 for the layout)
+extern "C" int vlr_launch_call_kernel_deep(const vlr::DevPlan* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out,
+                                           int n_univ, int n_samples, int range_depth, void* stream) {
+    using namespace vlr;
+    if (batch->n_loci <= 0) return 0;
+    if (range_depth < 1) range_depth = 1;
+    size_t n_slots = (size_t)n_univ + 1;
+    size_t cap = (size_t)plan_host->table_cap;
+    size_t dbl = (size_t)2 * plan_host->max_tab_depth * cap + (size_t)2 * kRows * cap + (size_t)kRows * n_samples +
+                 (size_t)2 * n_univ + n_slots + n_slots * n_samples + (size_t)n_samples * plan_host->max_set + (size_t)(out->replay ? 2 * n_samples * kMaxSet + 2 * n_samples : 0) + (size_t)3 * n_samples * kCacheWays +
+                 (n_slots + 1) / 2 + 2 + (size_t)plan_host->n_dkey +
+                 ((size_t)plan_host->max_frames * sizeof(Frame) + (size_t)range_depth * sizeof(RangeSt) + 7) / 8 +
+                 (size_t)(n_samples + 1) / 2;
+    size_t bytes = dbl * sizeof(double);
+    hipError_t e = hipFuncSetAttribute((const void*)vlr_call_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(vlr_call_kernel<2>, dim3((unsigned)batch->n_loci), dim3(64), bytes, (hipStream_t)stream, *plan_host, *batch, *out, 0, range_depth, (int)dbl);
+    return (int)hipGetLastError();
+}
+#else
 extern "C" int vlr_launch_afd_kernel(const vlr::DevPlan* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out, void* stream) {
     if (batch->n_loci <= 0) return 0;
     hipLaunchKernelGGL(vlr::vlr_afd_kernel, dim3((unsigned)batch->n_loci), dim3(64), 0, (hipStream_t)stream, *plan_host, *batch, *out);
@@ -3766,7 +3867,8 @@ extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_host, const vlr::
     size_t dbl = (size_t)2 * max_obs + (size_t)2 * plan_host->max_tab_depth * cap + (size_t)2 * kRows * cap + (size_t)kRows * n_samples +
                  (size_t)2 * n_univ + n_slots + n_slots * n_samples + (size_t)n_samples * plan_host->max_set + (size_t)(out->replay ? 2 * n_samples * kMaxSet + 2 * n_samples : 0) + (size_t)3 * n_samples * kCacheWays +
                  (n_slots + 1) / 2 + 2 + (size_t)plan_host->n_dkey +
-                 ((size_t)plan_host->max_frames * sizeof(Frame) + (size_t)range_depth * sizeof(RangeSt) + 7) / 8;
+                 ((size_t)plan_host->max_frames * sizeof(Frame) + (size_t)range_depth * sizeof(RangeSt) + 7) / 8 +
+                 (size_t)(n_samples + 1) / 2;  // kshift[S] (ints)
     size_t bytes = dbl * sizeof(double);
     static size_t static_lds = 0;
     if (!static_lds) {
@@ -3785,7 +3887,7 @@ extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_host, const vlr::
     case W: {                                                                                                                \
         hipError_t e = hipFuncSetAttribute((const void*)vlr_call_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
         if (e != hipSuccess) return (int)e;                                                                                  \
-        hipLaunchKernelGGL(vlr_call_kernel<W>, grid, block, bytes, (hipStream_t)stream, *plan_host, *batch, *out, max_obs, range_depth); \
+        hipLaunchKernelGGL(vlr_call_kernel<W>, grid, block, bytes, (hipStream_t)stream, *plan_host, *batch, *out, max_obs, range_depth, (int)dbl); \
         break;                                                                                                               \
     }
     switch (wpe) {
@@ -3801,3 +3903,4 @@ extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_host, const vlr::
 #undef VLR_LAUNCH
     return (int)hipGetLastError();
 }
+#endif  // VLR_DEEP / !VLR_DEEP launchers

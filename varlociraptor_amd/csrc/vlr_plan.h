@@ -131,6 +131,11 @@ struct DevResults {
     // -1 when the region overflowed (that locus falls back to the replay launch).
     double* afd_log;
     long long afd_log_stride;
+    // deep launch (vlr_kernels_deep.hip): pool of coefficient triples for the loci the LDS-resident kernel flagged
+    // VLR_LOCUS_TOO_DEEP; deep_used is a bump counter (doubles) reset before every deep launch
+    double* deep_pool;
+    unsigned long long* deep_used;
+    long long deep_capacity;
 };
 
 }  // namespace vlr

@@ -272,7 +272,167 @@ __global__ void __launch_bounds__(64) vlr_edit_kernel(EditArgs a) {
     }
 }
 
+// ---- `fast` realignment mode -------------------------------------------------------------------------------------------
+// PathHMMRealigner::calculate_prob_allele (realignment/mod.rs:547-678): instead of summing over all alignments, the path
+// probability of the optimal edit-distance alignments of the best hits (bio Myers traceback, edit_distance.rs:164-260) — transition
+// terms by the previous operation (no_gap / close_gap / gap open / extend-or-reopen, mod.rs:560-584), emissions of the
+// ReadVsAlleleEmission model — and the best of them.  Which of several co-optimal alignments the crate's traceback returns is
+// not specified by the reference; this kernel takes the BEST path probability over ALL alignments of minimal semiglobal edit
+// distance (an upper bound of, and with a unique optimal alignment equal to, the reference's value).
+// Same wavefront as the pair HMM, in max-plus form over (edit distance, ln probability) pairs ordered lexicographically
+// (smaller distance first, then larger probability) per state {match, deletion, insertion}: adds and compares only, log space,
+// no scaling.  Cell (j, i) = read bases 0..j and allele bases ..i consumed; row -1 is the free start in every column.
+struct PathArgs {
+    int64_t n_pairs;
+    const uint32_t* x_offset;
+    const uint8_t* x_bases;
+    const uint32_t* y_offset;
+    const uint8_t* y_bases;
+    const uint8_t* y_quals;
+    double no_gap, close_x, close_y, gap_x, gap_y, reopen_x, reopen_y;  // ln; reopen_* = ln(extend + close * open) (mod.rs:576-584)
+    double* ln_prob;
+};
+struct DP { unsigned d; double p; };
+__device__ __forceinline__ DP dp_best(DP a, DP b) {
+    const bool ta = (a.d < b.d) | ((a.d == b.d) & (a.p > b.p));
+    DP r; r.d = ta ? a.d : b.d; r.p = ta ? a.p : b.p; return r;
+}
+__device__ __forceinline__ DP dp_step(DP a, unsigned cost, double lp) {  // unreachable stays unreachable
+    DP r; r.d = a.d >= kBig ? kBig : a.d + cost; r.p = a.d >= kBig ? -__builtin_huge_val() : a.p + lp; return r;
+}
+__device__ __forceinline__ double shr1d(double v, double edge) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(edge), lo, 0x138, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), hi, 0x138, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ DP dp_shr1(DP v) { DP r; r.d = shr1(v.d, kBig); r.p = shr1d(v.p, -__builtin_huge_val()); return r; }
+
+__global__ void __launch_bounds__(64) vlr_pathhmm_kernel(PathArgs a) {
+    const int64_t pair = blockIdx.x;
+    if (pair >= a.n_pairs) return;
+    const int lane = threadIdx.x;
+    const uint32_t x0 = a.x_offset[pair], y0 = a.y_offset[pair];
+    const int len_x = (int)(a.x_offset[pair + 1] - x0), len_y = (int)(a.y_offset[pair + 1] - y0);
+    const double NINF = -__builtin_huge_val();
+    if (len_y > 128 || len_y <= 0 || len_x <= 0) {
+        if (lane == 0) a.ln_prob[pair] = (len_x <= 0 || len_y <= 0) ? NINF : __builtin_nan("");
+        return;
+    }
+    int yb[2];
+    double l_match[2], l_mis[2], l_ins[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int j = 2 * lane + r;
+        const bool rowon = j < len_y;
+        const int q = rowon ? a.y_quals[y0 + j] : 0;
+        yb[r] = rowon ? up(a.y_bases[y0 + j]) : 0;
+        const double lm = -(double)q * 2.302585092994046 / 10.0;  // ln P(miscall)
+        l_ins[r] = lm;
+        l_mis[r] = lm + log(0.3333);                               // PROB_CONFUSION, pairhmm.rs:22-24
+        l_match[r] = (lm < -0.693) ? log1p(-exp(lm)) : log(-expm1(lm));
+    }
+    // column -1: read bases inserted before the first allele base — insertion chain from the start (prev None: gap_x, mod.rs:640-647)
+    // pre[j] = gap_x + ins_0 + sum_{k=1..j} (reopen_x + ins_k): inclusive prefix sums over the rows (two per lane)
+    double pre[2];
+    {
+        const double t0 = (lane == 0 ? a.gap_x : a.reopen_x) + l_ins[0], t1 = a.reopen_x + l_ins[1];
+        double s = t0 + t1;  // lane sum
+        double inc = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        const double excl = inc - s;
+        pre[0] = excl + t0; pre[1] = excl + t0 + t1;
+    }
+    DP M1[2], D1[2], I1[2], Mt[2], Dt[2], It[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int j = 2 * lane + r;
+        M1[r] = {kBig, NINF}; D1[r] = {kBig, NINF};
+        I1[r] = {(unsigned)(j + 1), pre[r]};                      // (j, -1)
+        Mt[r] = {kBig, NINF}; Dt[r] = {kBig, NINF};
+    }
+    It[1] = {(unsigned)(2 * lane + 1), pre[0]};                   // (j-1, -1) of the lane's second row = its first row
+    {
+        const double up1 = __shfl_up(pre[1], 1);
+        It[0] = {lane == 0 ? kBig : (unsigned)(2 * lane), lane == 0 ? NINF : up1};  // row 0: the start row, handled below
+    }
+    const int last_row = len_y - 1;
+    const int lr = last_row & 1;
+    const bool owner_lane = lane == (last_row >> 1);
+    DP best = {kBig, NINF};
+    const int nsteps = len_x + len_y - 1;
+    int xchunk = 0, xb0 = 0, xb1 = 0;
+    for (int d = 0; d < nsteps; ++d) {
+        if ((d & 63) == 0) {
+            const int i = d + lane;
+            xchunk = (i < len_x) ? up(a.x_bases[x0 + i]) : 0;
+        }
+        const int xnew = __builtin_amdgcn_readlane(xchunk, d & 63);
+        const int prev1 = xb1;
+        xb1 = xb0;
+        xb0 = (int)shr1((unsigned)prev1, (unsigned)xnew);
+        DP Mu[2], Du[2], Iu[2];
+        Mu[0] = dp_shr1(M1[1]); Du[0] = dp_shr1(D1[1]); Iu[0] = dp_shr1(I1[1]);
+        Mu[1] = M1[0]; Du[1] = D1[0]; Iu[1] = I1[0];
+        DP Mn[2], Dn[2], In[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int j = 2 * lane + r;
+            const int i = d - j;
+            const bool incol = (unsigned)i < (unsigned)len_x;
+            const int xb = r == 0 ? xb0 : xb1;
+            const bool is_match = xb == yb[r];
+            const unsigned mm = is_match ? 0u : 1u;
+            const double emit = is_match ? l_match[r] : l_mis[r];
+            // match / substitution from (j-1, i-1)
+            DP m = dp_best(dp_best(dp_step(Mt[r], mm, a.no_gap + emit), dp_step(Dt[r], mm, a.close_y + emit)), dp_step(It[r], mm, a.close_x + emit));
+            // deletion (allele base alone, prob_emit_x = 1) from (j, i-1)
+            DP dl = dp_best(dp_best(dp_step(M1[r], 1u, a.gap_y), dp_step(D1[r], 1u, a.reopen_y)), dp_step(I1[r], 1u, a.close_x + a.gap_y));
+            // insertion (read base alone) from (j-1, i)
+            DP in = dp_best(dp_best(dp_step(Mu[r], 1u, a.gap_x + l_ins[r]), dp_step(Iu[r], 1u, a.reopen_x + l_ins[r])), dp_step(Du[r], 1u, a.close_y + a.gap_x + l_ins[r]));
+            if (j == 0) {  // the start row above row 0: first operation, no transition term (prev None, mod.rs:598-647)
+                const DP sm = {mm, emit}, si = {1u, a.gap_x + l_ins[r]};
+                m = dp_best(m, sm);
+                in = dp_best(in, si);
+            }
+            const DP dead = {kBig, NINF};
+            Mn[r] = incol ? m : dead; Dn[r] = incol ? dl : dead;
+            In[r] = incol ? in : I1[r];  // before its first column a row keeps the insertion chain of column -1
+            if (!incol && i >= len_x) In[r] = dead;
+        }
+        {
+            const int i = d - last_row;
+            const bool hit = owner_lane && (unsigned)i < (unsigned)len_x;
+            const DP e = dp_best(Mn[lr], In[lr]);  // an optimal semiglobal alignment does not end in a deletion
+            if (hit) best = dp_best(best, e);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { Mt[r] = Mu[r]; Dt[r] = Du[r]; It[r] = Iu[r]; M1[r] = Mn[r]; D1[r] = Dn[r]; I1[r] = In[r]; }
+    }
+    if (owner_lane) a.ln_prob[pair] = best.d >= kBig ? NINF : best.p;
+}
+
 }  // namespace vlr
+
+extern "C" int vlr_launch_pathhmm_kernel(const vlr_realign_batch_desc* b, double* ln_prob, void* stream) {
+    using namespace vlr;
+    if (b->n_pairs <= 0) return 0;
+    PathArgs a;
+    a.n_pairs = b->n_pairs; a.x_offset = b->x_offset; a.x_bases = b->x_bases; a.y_offset = b->y_offset; a.y_bases = b->y_bases;
+    a.y_quals = b->y_quals; a.ln_prob = ln_prob;
+    // PathHMMRealigner::new (realignment/mod.rs:560-584)
+    const double gx = exp(b->gap[0]), gy = exp(b->gap[1]), gxe = exp(b->gap[2]), gye = exp(b->gap[3]);
+    a.gap_x = b->gap[0]; a.gap_y = b->gap[1];
+    a.no_gap = log(1.0 - (gx + gy));
+    a.close_x = log(1.0 - gxe); a.close_y = log(1.0 - gye);
+    a.reopen_x = log(gxe + (1.0 - gxe) * gx); a.reopen_y = log(gye + (1.0 - gye) * gy);
+    hipLaunchKernelGGL(vlr_pathhmm_kernel, dim3((unsigned)b->n_pairs), dim3(64), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
 
 extern "C" int vlr_launch_realign_kernel(const vlr_realign_batch_desc* b, double* ln_prob, void* stream) {
     using namespace vlr;

@@ -25,7 +25,7 @@ EXPORTS = [
     "vlr_abi_version", "vlr_build_id", "vlr_last_error", "vlr_plan_create", "vlr_plan_destroy", "vlr_plan_n_out",
     "vlr_plan_n_samples", "vlr_plan_set_max_depth", "vlr_plan_set_max_obs", "vlr_plan_reserve", "vlr_batch_run", "vlr_batch_run_host",
     "vlr_plan_last_kernel_ms", "vlr_plan_work_counters", "vlr_host_alloc", "vlr_host_free",
-    "vlr_realign_batch", "vlr_realign_batch_host", "vlr_edit_distance_batch", "vlr_edit_distance_batch_host", "vlr_fdr_threshold", "vlr_selftest_math", "vlr_selftest_stream",
+    "vlr_realign_batch", "vlr_realign_batch_host", "vlr_realign_fast_batch", "vlr_realign_fast_batch_host", "vlr_edit_distance_batch", "vlr_edit_distance_batch_host", "vlr_fdr_threshold", "vlr_selftest_math", "vlr_selftest_stream",
     "vlr_obs_read", "vlr_obs_table_free", "vlr_obs_table_batch", "vlr_obs_table_sites", "vlr_obs_write", "vlr_calls_write", "vlr_ingest_last_timings",
 ]
 
@@ -39,7 +39,7 @@ class EngineError(RuntimeError):
 def build(force: bool = False) -> str:
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in ("vlr_kernels.hip", "vlr_realign.hip", "vlr_fdr.hip", "vlr_host.cpp", "vlr_ingest.cpp", "vlr_plan.h")] + [os.path.join(_HERE, "..", "include", "vlr.h")]
+    srcs = [os.path.join(src_dir, f) for f in ("vlr_kernels.hip", "vlr_kernels_deep.hip", "vlr_realign.hip", "vlr_fdr.hip", "vlr_host.cpp", "vlr_ingest.cpp", "vlr_plan.h")] + [os.path.join(_HERE, "..", "include", "vlr.h")]
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", src_dir, "-B"], stdout=subprocess.DEVNULL)
     return LIB_PATH
@@ -54,7 +54,7 @@ def source_id() -> str:
     """The id a build of the current sources would carry (same recipe as csrc/Makefile)."""
     import hashlib
     h = hashlib.sha1()
-    for f in ("csrc/vlr_kernels.hip", "csrc/vlr_realign.hip", "csrc/vlr_fdr.hip", "csrc/vlr_host.cpp", "csrc/vlr_ingest.cpp", "csrc/vlr_plan.h", "../include/vlr.h", "../include/vlr_detmath.h"):
+    for f in ("csrc/vlr_kernels.hip", "csrc/vlr_kernels_deep.hip", "csrc/vlr_realign.hip", "csrc/vlr_fdr.hip", "csrc/vlr_host.cpp", "csrc/vlr_ingest.cpp", "csrc/vlr_plan.h", "../include/vlr.h", "../include/vlr_detmath.h"):
         with open(os.path.join(_HERE, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

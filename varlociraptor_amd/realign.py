@@ -98,6 +98,22 @@ def prob_related(batch: PairBatch, gap: Optional[GapParams] = None, device: int 
     return out
 
 
+def prob_best_path(batch: PairBatch, gap: Optional[GapParams] = None, device: int = 0) -> np.ndarray:
+    """`fast` mode (PathHMMRealigner, realignment/mod.rs:547-678): ln of the best path probability over the minimal-edit-distance
+    alignments of every pair (vlr_realign_fast_batch_host)."""
+    L = _bind()
+    L.vlr_realign_fast_batch_host.restype = C.c_int
+    L.vlr_realign_fast_batch_host.argtypes = [C.c_int, C.POINTER(RealignDesc), C.c_void_p]
+    gap = gap or GapParams()
+    xo, xb, yo, yb, qb, band = batch.arrays()
+    out = np.empty(len(batch), np.float64)
+    d = RealignDesc(len(batch), xo.ctypes.data, xb.ctypes.data, yo.ctypes.data, yb.ctypes.data, qb.ctypes.data, None, gap.as_array())
+    rc = L.vlr_realign_fast_batch_host(device, C.byref(d), out.ctypes.data)
+    if rc != 0:
+        raise engine.EngineError(rc, (L.vlr_last_error() or b"").decode())
+    return out
+
+
 class DevicePairs:
     """A PairBatch resident in HBM (torch owns the buffers) for vlr_realign_batch / vlr_edit_distance_batch."""
 

@@ -65,6 +65,7 @@ class SynthConfig:
     empty_fraction: float = 0.0      # loci with an empty pileup in one sample (edge case)
     strand_none_fraction: float = 0.0    # observations of SV/breakend loci without strand information (Strand::None:
                                          # realignment/mod.rs:237,387-396 keeps the strand of informative reads only)
+    max_depth: int = 200                 # clip of the Poisson depth; raised by the deep-pileup tests
     breakend_pair_fraction: float = 0.0  # SV loci followed by a mate record that shares their pileup (breakend groups,
                                          # calling.rs:569-580,726-741): truth["group"] gives the shared id
 
@@ -159,7 +160,7 @@ def generate(cfg: SynthConfig, n_loci: int, seed: Optional[int] = None, chunk: i
     has_hp = is_indel & (rng.random(L) < cfg.hp_fraction)
     artifact_kind = np.where(rng.random(L) < cfg.artifact_fraction, rng.integers(1, 5, size=L), 0)  # 1 strand 2 orient 3 softclip 4 position
     has_altloc = rng.random(L) < cfg.alt_locus_fraction
-    depth = np.clip(rng.poisson(cfg.depth, size=(L, S)), 1, 200)
+    depth = np.clip(rng.poisson(cfg.depth, size=(L, S)), 1, max(200, int(getattr(cfg, "max_depth", 200))))
     if cfg.empty_fraction > 0:
         empty = rng.random((L, S)) < cfg.empty_fraction
         depth = np.where(empty, 0, depth)
