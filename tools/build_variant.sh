@@ -8,5 +8,7 @@ name=$1; shift
 BASE=${BASEFLAGS:--O3 -std=c++17 -fPIC -Wno-unused-function -ffp-contract=off -mllvm -disable-machine-licm}
 mkdir -p $R/varlociraptor_amd/matrix
 cd $R/varlociraptor_amd/csrc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 $BASE "$@" -DVLR_SRC_ID="\"$(cat vlr_kernels.hip vlr_realign.hip vlr_fdr.hip vlr_host.cpp vlr_plan.h ../../include/vlr.h ../../include/vlr_detmath.h | sha1sum | cut -c1-16)\"" -shared vlr_kernels.hip vlr_realign.hip vlr_fdr.hip vlr_host.cpp -o ../matrix/libvlr_$name.so 2>&1 | grep -v "warning\|unused\|\^\|^ *[0-9]* |\|generated" || true
+SRC=$(grep '^SRC = ' Makefile | cut -d= -f2)
+LIBS=$(grep '^LIBS = ' Makefile | cut -d= -f2)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 $BASE "$@" -DVLR_SRC_ID="\"$(cat $SRC vlr_plan.h ../../include/vlr.h ../../include/vlr_detmath.h | sha1sum | cut -c1-16)\"" -shared $SRC -o ../matrix/libvlr_$name.so $LIBS 2>&1 | grep -v "warning\|unused\|\^\|^ *[0-9]* |\|generated" || true
 ls -la ../matrix/libvlr_$name.so

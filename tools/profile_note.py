@@ -24,7 +24,7 @@ md = ["# %s" % title, "",
       "pass is its own run (`--kernel-trace --stats` for durations; `--pmc` passes with `--kernel-trace` only).  Tables made by",
       "`tools/profile_note.py` from the rocpd databases and the bench lines (committed next to this note as `%s_bench_*.json`)." % tag, "",
       "## bench.py lines (HBM-resident inputs, 3 timed launches after 1 warm-up)", "",
-      "| workload | units per launch | value | ms per step | kernel ms (HIP events) | evaluations / unit | parity vs oracle | cpu_baseline (oracle, 256 threads) |", "|---|---|---|---|---|---|---|---|"]
+      "| workload | units per launch | value | ms per step | kernel ms (HIP events) | evaluations / unit | parity vs oracle | cpu_baseline port / tuned (threads = effective CPUs) |", "|---|---|---|---|---|---|---|---|"]
 for w in ("config3", "config2", "config4", "config5", "realign"):
     j = line("bench_%s.json" % w)
     if not j:
@@ -37,13 +37,21 @@ for w in ("config3", "config2", "config4", "config5", "realign"):
     pr = ("max |dposterior| %.1e, max |dMAP VAF| %.1e over %d loci" % (par.get("max_abs_dposterior", 0), par.get("max_abs_dmap_vaf", 0), par.get("n_checked", 0))) if "max_abs_dposterior" in par else ("max |dln p| %.1e over %d pairs" % (par.get("max_abs_dlnprob", 0), par.get("n_checked", 0)))
     cb = j.get("cpu_baseline") or {}
     md.append("| %s | %d | %.3f M %s | %.2f | %.2f | %s | %s | %.0f %s |" % (w, units, j["value"] / 1e6, j["unit"], j["ms_per_step"], rf["kernel_ms"],
-              ("%.0f" % (ev / units)) if ev else ("%.0f cells" % (v.get("cells_per_s", 0) * rf["kernel_ms"] / 1e3 / units)), pr, cb.get("value", 0), cb.get("unit", "")))
+              ("%.0f" % (ev / units)) if ev else ("%.0f cells" % (v.get("cells_per_s", 0) * rf["kernel_ms"] / 1e3 / units)), pr, cb.get("value", 0), (("/ %.0f " % cb["tuned"]["value"]) if cb.get("tuned") else "") + cb.get("unit", "") + (" (%d threads)" % cb.get("cores", 0))))
 j = line("bench_config3_afd.json")
 if j and j.get("with_afd"):
     shutil.copy(os.path.join(O, "bench_config3_afd.json"), os.path.join(P, "%s_bench_config3_afd.json" % tag))
     a = j["with_afd"]
     md += ["", "With AFD lists (`bench.py --afd`, capacity %d): %.3f M loci/s = %.0f %% of the plain rate (%.1f ms for call pass + log filter + replay of overflowed loci), mean %.1f points per sample list, %d truncated lists."
            % (a["afd_capacity"], a["value"] / 1e6, 100 * a["ratio_to_plain"], a["kernel_ms_both_launches"], a["mean_afd_points_per_sample"], a["truncated_lists"])]
+j = line("bench_cli.json")
+if j:
+    shutil.copy(os.path.join(O, "bench_cli.json"), os.path.join(P, "%s_bench_cli.json" % tag))
+    st, nt = j["stages_s"], j.get("native_stage_seconds_last_step", {})
+    md += ["", "End to end through the process boundary (`bench.py --workload cli`: %s; %d effective CPUs of %d visible): **%.1f k records/s** — read %.2f s (inflate %.2f + decode %.2f summed over the two files, merge %.2f), call %.2f s, write %.2f s (encode %.2f, deflate + file %.2f)."
+           % (j["config"]["workload"], j["config"].get("effective_cpus", 0), j["config"].get("host_threads", 0), j["value"] / 1e3, st["read_s"], nt.get("inflate", 0), nt.get("parse_decode", 0), nt.get("merge", 0), st["call_s"], st["write_s"], nt.get("encode", 0), nt.get("deflate_write", 0))]
+if os.path.exists(os.path.join(O, "cpu_probe.txt")):
+    shutil.copy(os.path.join(O, "cpu_probe.txt"), os.path.join(P, "%s_cpu_probe.txt" % tag))
 md += ["", "## rocprofv3 --kernel-trace --stats of `python bench.py --no-cpu-baseline` (config3, 1 M loci per launch)", "", rocpd("stats_config3"),
        "## … of `python bench.py --afd --no-cpu-baseline`", "", rocpd("stats_config3_afd"),
        "## … of `python bench.py --workload realign --no-cpu-baseline`", "", rocpd("stats_realign")]
