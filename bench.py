@@ -84,9 +84,9 @@ def generate(name, n_loci, rank, chunk_loci=50000, workers=None):
 
 
 def _gen_pairs(args):
-    n_reads, seed = args
+    n_reads, seed, window = args
     from varlociraptor_amd import realign_synth
-    pb, _ = realign_synth.generate(n_reads, seed=seed)
+    pb, _ = realign_synth.generate(n_reads, seed=seed, window=window)
     return pb.x, pb.y, pb.q, pb.band
 
 
@@ -107,7 +107,7 @@ def bench_realign(args, rank, world, local_rank, dev):
     import torch.distributed as dist
     from varlociraptor_amd import engine, realign
     n_reads = 4000 if args.loci is None else max(50, args.loci // 2)
-    jobs = [(250, 1000 * rank + k) for k in range(max(1, n_reads // 250))]
+    jobs = [(250, 1000 * rank + k, args.read_window) for k in range(max(1, n_reads // 250))]
     with ProcessPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 8)) as ex:
         parts = list(ex.map(_gen_pairs, jobs))
     base = realign.PairBatch()
@@ -178,7 +178,7 @@ def bench_realign(args, rank, world, local_rank, dev):
         "metric": "read-allele pairs/sec (pair HMM, whole node)", "value": n_pairs * world * args.steps / elapsed, "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "realign: %d read-allele pairs/GPU (%d distinct, SNV/MNV/insertion/deletion loci, read windows <= 128 bases, reference windows 192 bases, banded)" % (n_pairs, len(base)),
+        "config": {"workload": "realign: %d read-allele pairs/GPU (%d distinct, SNV/MNV/insertion/deletion loci, read windows %d..%d bases, reference windows %d bases, banded)" % (n_pairs, len(base), args.read_window, min(128, 2 * args.read_window), 3 * args.read_window),
                    "parallelism": "pairs sharded x%d, no collective" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic_for("realign", n_pairs, engine.build_id()), "algorithmic_bytes_per_launch": int(dp.bytes), "kernel_ms": kernel_ms,
@@ -311,6 +311,7 @@ def main():
     ap.add_argument("--afd-capacity", type=int, default=96)
     ap.add_argument("--cpu-loci", type=int, default=None, help="loci of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--read-window", type=int, default=64, help="realign workload: realignment window; read windows are window..2*window bases (32: short reads, two pairs per wave)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -327,7 +328,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # VLR_BENCH_FORCE_DIST=1: go through RCCL even with a single rank (tests/test_gpu_cli_end_to_end.py: the collective path on a
+    # one-GPU box) — the all-gather of the result records is then part of the timed step at world size 1 as well
+    force_dist = os.environ.get("VLR_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
@@ -360,25 +364,25 @@ def main():
 
     def step(o=out):
         plan.call_device(dbatch, o, stream)
-        if world > 1:
+        if world > 1 or force_dist:
             # the FULL fixed-size record travels: posteriors, marginal, MAP VAFs, bias codes, best event, status
             return all_gather_records(pack_full_records(o), n_total, world)
         return None
 
     def timed(fn):
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             fn()
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        if world > 1:
+        if world > 1 or force_dist:
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
@@ -496,10 +500,11 @@ def main():
             "with_afd": with_afd,
             "cpu_baseline": cpu, "parity": parity, "posterior_normalisation_max_err": norm_err,
             "status_counts": {str(k): int(v) for k, v in zip(*np.unique(res.status, return_counts=True))},
+            "collective": ("rccl all_gather_into_tensor, world size %d" % world) if (world > 1 or force_dist) else None,
             "build_id": engine.build_id(),
         }
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

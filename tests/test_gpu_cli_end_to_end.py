@@ -233,3 +233,21 @@ def test_cli_two_ranks_shard_and_reassemble(golden_dir, tmp_path):
                     "--master-port", "29541"] + base + ["--output", str(two)] + tail, check=True, cwd=root, env=env, timeout=900)
     a, b = one.read_text(), two.read_text()
     assert a == b and a.count("\n") > 11
+
+
+def test_bench_step_through_rccl_on_one_gpu(tmp_path):
+    """nothing in the repo had ever exercised RCCL itself (the two-rank tests use gloo: a one-GPU box cannot
+    host two NCCL ranks).  One rank under torch.distributed.run with backend nccl: process-group set-up on the device, the
+    all-gather of the packed result records through RCCL inside the timed step, barrier and max-reduction of the timing."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, VLR_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "1", "--loci", "20000", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-afd"], capture_output=True, text=True, cwd=root, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["collective"].startswith("rccl") and line["n_gpus"] == 1 and line["value"] > 0
+    assert line["posterior_normalisation_max_err"] < 1e-9

@@ -170,3 +170,20 @@ def test_fast_mode_matches_restatement(oracle):
     got = realign.prob_best_path(pb, g)
     ref = np.array([oracle.pathhmm_best(pb.x[k], pb.y[k], pb.q[k], gl) for k in range(len(pb))])
     assert np.allclose(got, ref, rtol=0, atol=1e-9), (got, ref)
+
+
+def test_two_pairs_per_wave_on_short_read_windows(oracle):
+    """vlr_realign_kernel2: read windows of at most 64 bases run two pairs per wave (lanes 0-31 / 32-63).  Short windows of
+    every variant kind, banded and not, odd pair counts, and batches that mix short and long windows pair by pair."""
+    for banded in (True, False):
+        pb, truth = realign_synth.generate(201, seed=17, window=24, banded=banded)   # read windows of 24..48 bases
+        assert max(len(y) for y in pb.y) <= 64
+        check(oracle, pb)
+    rng = np.random.default_rng(8)
+    B = np.frombuffer(b"ACGT", np.uint8)
+    x = B[rng.integers(0, 4, 260)].tobytes()
+    pb = PairBatch()
+    for ly in (1, 2, 31, 32, 33, 63, 64, 65, 100, 128, 64, 5, 64, 64, 3):   # neighbours (2w, 2w+1): short+short, short+long, long+long, odd tail
+        o = int(rng.integers(0, 100))
+        pb.add(x, x[o:o + ly], [int(q) for q in rng.choice([20, 30, 40], ly)], int(rng.choice([-1, 4, 9])))
+    check(oracle, pb, GapParams(math.log(1e-4), math.log(2e-4), math.log(0.2), math.log(0.3)))

@@ -11,7 +11,7 @@ def main():
     con = sqlite3.connect(sys.argv[1])
     div = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
     rows = list(con.execute("select kernel_name, counter_name, sum(value), count(distinct dispatch_id) from counters_collection "
-                            "where kernel_name like '%vlr_call_kernel%' group by kernel_name, counter_name order by counter_name"))
+                            "where kernel_name like '%vlr_call_kernel%' and kernel_name not like '%vlr_deep%' group by kernel_name, counter_name order by counter_name"))
     print("| counter | sum over dispatches | dispatches | per unit (/%g) |" % div)
     print("|---|---|---|---|")
     for _, name, val, nd in rows:

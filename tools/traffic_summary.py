@@ -8,7 +8,9 @@ O, W = sys.argv[1], sys.argv[2]
 def counter(name, ctr, like):
     db = glob.glob(os.path.join(O, name, "**", "*.db"), recursive=True)[0]
     con = sqlite3.connect(db)
-    rows = list(con.execute("select sum(value), count(distinct dispatch_id) from counters_collection where counter_name = ? and kernel_name like ?", (ctr, like)))
+    # (the deep launch behind every call launch — vlr_deep::vlr_call_kernel, exits at once for every locus of these workloads — is
+    # its own dispatch: not part of the per-launch average of the LDS-resident kernel)
+    rows = list(con.execute("select sum(value), count(distinct dispatch_id) from counters_collection where counter_name = ? and kernel_name like ? and kernel_name not like '%vlr_deep%'", (ctr, like)))
     return float(rows[0][0]), int(rows[0][1])
 
 

@@ -881,9 +881,8 @@ static int ensure_buffers(vlr_plan* plan, int64_t n_loci, int max_obs, bool want
         } else {
             plan->afd_log_loci[k] = 0;
         }
-        // one 8-byte key per AFD entry of a sub-range (vlr_batch_run walks the batch in steps of afd_log_loci loci)
-        const size_t step = plan->afd_log_loci[k] > 0 ? std::min<size_t>(L, (size_t)plan->afd_log_loci[k]) : L;  // both lanes
-        rc = grow(&plan->afd_keys[k], &plan->afd_keys_bytes[k], step * (size_t)plan->host.S * (size_t)std::max(afd_capacity, 1) * sizeof(long long), false);
+        // one 8-byte key per AFD entry of the batch (as large as the caller's own afd_vaf): the l2fc part of the reference's map key
+        rc = grow(&plan->afd_keys[k], &plan->afd_keys_bytes[k], L * (size_t)plan->host.S * (size_t)std::max(afd_capacity, 1) * sizeof(long long), false);
         if (rc != VLR_OK) return rc;
     }
     return VLR_OK;
@@ -957,6 +956,7 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
     }
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipEventRecord(plan->ev_start, st));
+    r.deep_used = (unsigned long long*)plan->deep_pool[plan->slot & 1];  // reset by workgroup 0 of every LDS-resident launch
     // deep launch behind a call (or replay) launch: re-evaluates the loci that launch flagged VLR_LOCUS_TOO_DEEP with their
     // coefficients in the plan's HBM pool; every other locus exits at once.  `lane`/`two`: the AFD sub-range lanes share the pool.
     auto deep_launch = [&](const DevBatch& bs, DevResults rs, void* ss, int lane, bool two) -> int {
@@ -967,8 +967,7 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
         size_t cap_d = (plan->deep_pool_bytes[k] - 128) / sizeof(double);
         double* data = (double*)(base + 128);
         if (two) { cap_d /= 2; data += (size_t)lane * cap_d; }
-        if (hipMemsetAsync(ctr, 0, sizeof(unsigned long long), (hipStream_t)ss) != hipSuccess) return fail(VLR_ERR_HIP, "deep pool reset failed");
-        rs.deep_pool = data; rs.deep_used = ctr; rs.deep_capacity = (long long)cap_d;
+        rs.deep_pool = data; rs.deep_used = ctr; rs.deep_capacity = (long long)cap_d;  // ctr was reset by the launch before (workgroup 0)
         const int rc = vlr_launch_call_kernel_deep(&plan->host, &bs, &rs, plan->host.n_univ, plan->host.S, plan->host.max_range_depth, ss);
         if (rc != 0) return fail(VLR_ERR_HIP, "deep kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         return VLR_OK;
@@ -1016,11 +1015,9 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
             rs.status += l0; rs.map_disc += l0; rs.escratch += (size_t)l0 * max_obs;
             rs.afd_count += l0 * S; rs.afd_vaf += (size_t)l0 * S * r.afd_capacity; rs.afd_lnprob += (size_t)l0 * S * r.afd_capacity;
             if (rs.afd_log) rs.afd_log += (size_t)lane * (size_t)step * (size_t)r.afd_log_stride;
-            rs.afd_key += (size_t)lane * (size_t)step * (size_t)S * (size_t)r.afd_capacity;
+            rs.afd_key += (size_t)l0 * (size_t)S * (size_t)r.afd_capacity;
             int rc = vlr_launch_call_kernel(&plan->host, &bs, &rs, plan->host.n_univ, S, max_obs, plan->host.max_range_depth, ss);
             if (rc != 0) return fail(VLR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-            rc = deep_launch(bs, rs, ss, lane, two);
-            if (rc != VLR_OK) return rc;
             if (rs.afd_log) {
                 rc = vlr_launch_afd_kernel(&plan->host, &bs, &rs, ss);
                 if (rc != 0) return fail(VLR_ERR_HIP, "AFD kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -1028,12 +1025,23 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
             rs.replay = 1;
             rc = vlr_launch_call_kernel(&plan->host, &bs, &rs, plan->host.n_univ, S, max_obs, plan->host.max_range_depth, ss);
             if (rc != 0) return fail(VLR_ERR_HIP, "AFD replay launch failed: %s", hipGetErrorString((hipError_t)rc));
-            rc = deep_launch(bs, rs, ss, lane, two);  // rs.replay == 1: the lists of the deep loci
-            if (rc != VLR_OK) return rc;
+
         }
         if (two) {
             HIP_TRY(hipEventRecord(plan->ev_join, plan->afd_aux_stream));
             HIP_TRY(hipStreamWaitEvent(st, plan->ev_join, 0));
+        }
+        // the loci above the LDS budget, once for the whole batch: call launch, then (counter reset in between) the lists
+        {
+            DevResults rd = r;
+            int rc = deep_launch(b, rd, stream, 0, false);
+            if (rc != VLR_OK) return rc;
+            if (plan->deep_pool[plan->slot & 1]) {
+                HIP_TRY(hipMemsetAsync(plan->deep_pool[plan->slot & 1], 0, sizeof(unsigned long long), st));
+                rd.replay = 1;
+                rc = deep_launch(b, rd, stream, 0, false);
+                if (rc != VLR_OK) return rc;
+            }
         }
         HIP_TRY(hipEventRecord(plan->ev_stop, st));
     }

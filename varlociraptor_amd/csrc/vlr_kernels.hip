@@ -690,8 +690,8 @@ struct Ctx {
     const double* ecoef;               // third coefficient of every kept observation of this locus (HBM scratch row)
     double *cacheA, *cacheB, *cacheV;  // [S][kCacheWays] per-sample likelihood cache (LDS)
     double* dkeyV;                     // [n_dkey] pileup likelihoods of the flattened discrete roots, per hypothesis (LDS)
-    int* kshift;                       // [S] binary exponent taken out of the coefficients of sample s under the current hypothesis
-                                       // (0 unless the pileup needed the scaled coefficient pass, see "underflow rescue")
+    // kshift(c)[s]: binary exponent taken out of the coefficients of sample s under the current hypothesis (0 unless the pileup
+    // needed the scaled coefficient pass, see "underflow rescue"); lives right behind the RangeSt array: no pointer of its own
     Frame* frames;                     // [nframes] explicit recursion stack of walk_root (LDS, sized by the plan's deepest path)
     RangeSt* rs;                       // [nrs] adaptive-integration state per nested Range level (LDS)
     int nframes, nrs;
@@ -769,11 +769,15 @@ __device__ inline void alpha_beta(const DevPlan& p, int s, double a, double b, d
 }
 
 // scratch row of the third coefficients of sample s, or nullptr when they are all zero (WaveSt::ehas)
+__device__ __forceinline__ int* kshift(const Ctx& c) { return (int*)(c.rs + c.nrs); }
 // ln 2 x (exponents taken out of the coefficients of the samples in `mask`): added to every pileup log-likelihood of those samples
 __device__ __forceinline__ double kshift_ln(const Ctx& c, int mask) {
+#ifdef VLR_NO_RESCUE
+    return 0.0;
+#endif
     int k = 0;
     for (int s = 0; s < c.S; ++s)
-        if ((mask >> s) & 1) k += c.kshift[s];
+        if ((mask >> s) & 1) k += kshift(c)[s];
     return (double)UNI(k) * kLn2;
 }
 __device__ __forceinline__ const double* ecoef_of(const Ctx& c, int s, int off) {
@@ -792,7 +796,11 @@ __device__ inline double sample_lik_point(Ctx& c, int s, double a, double b) {  
     accum_terms<1, 64>(c.coef + 2 * off, ecoef_of(c, s, off), D, c.lane, (w->fastok >> s) & 1, &al, &be, P1, E1);
     reduce_terms<1, 64>(P1, E1);
     if (c.lane == 0) { w->work[0] += 1; w->work[1] += (unsigned long long)D; }
-    return uni_d(log(P1[0]) + (double)(E1[0] + c.kshift[s]) * kLn2);
+#ifdef VLR_NO_RESCUE
+    return uni_d(log(P1[0]) + (double)E1[0] * kLn2);
+#else
+    return uni_d(log(P1[0]) + (double)(E1[0] + kshift(c)[s]) * kLn2);
+#endif
 }
 __device__ inline double sample_lik(Ctx& c, int s, double a, double b) {
     WaveSt* w = c.w;
@@ -2410,7 +2418,11 @@ __device__ __forceinline__ bool bo_setup(Ctx& c, const Frame& f, RangeSt& r) {
         int off = UNI(w->soff[s]), D = UNI(w->nkeep[s]);
         eval_pileup(c.coef + 2 * off, ecoef_of(c, s, off), D, (w->fastok >> s) & 1, nt, w->bpend[1], w->bpend[2], w->bpend[3], lane);
         __syncthreads();
-        if (lane < nt) w->task[lane].fixed += w->bpend[3][lane] + (double)c.kshift[s] * kLn2;
+#ifdef VLR_NO_RESCUE
+        if (lane < nt) w->task[lane].fixed += w->bpend[3][lane];
+#else
+        if (lane < nt) w->task[lane].fixed += w->bpend[3][lane] + (double)kshift(c)[s] * kLn2;
+#endif
         if (lane == 0) { w->work[0] += (unsigned long long)nt; w->work[1] += (unsigned long long)nt * (unsigned long long)D; }
         __syncthreads();
     }
@@ -3037,7 +3049,7 @@ __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, Dev
 // +33 %).  The launcher picks by LDS bytes.
 template <int WPE>
 __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_arg, DevBatch batch, DevResults out,
-                                                           int max_obs, int range_depth, int dyn_doubles) {
+                                                           int max_obs, int range_depth) {
     extern __shared__ double dyn[];
     __shared__ WaveSt wst;
     const DevPlan& p = plan_arg;
@@ -3083,7 +3095,6 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
     c.nframes = p.max_frames; c.nrs = range_depth;
     c.frames = (Frame*)(c.dkeyV + p.n_dkey);
     c.rs = (RangeSt*)(c.frames + c.nframes);
-    c.kshift = (int*)(dyn + dyn_doubles - (S + 1) / 2);  // last words of the dynamic area
     c.mapJ = mapJ; c.mapVaf = mapVaf; c.mapHyp = mapHyp; c.n_slots = n_slots;
     c.status = 0;
     if (lane == 0) { w->work[0] = 0; w->work[1] = 0; }
@@ -3231,9 +3242,9 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
         __syncthreads();
         if (lane == 0) { w->pos_all[s] = e_all; w->pos_major[s] = e_major; w->pos_rate[s] = e_rate; }
     }
-    int obs_cap = max_obs;
-    double* ecoef_w = out.escratch + (size_t)blockIdx.x * (size_t)max_obs;
-    if (VLR_DEEP) {  // {c, q} pairs and e of every kept observation from the pool: 3 doubles per observation
+#if VLR_DEEP
+    int obs_cap = 0;
+    {   // {c, q} pairs and e of every kept observation from the pool: 3 doubles per observation
         const unsigned long long need = 3ull * (unsigned long long)offset_acc;
         unsigned long long at = 0;
         if (lane == 0) at = atomicAdd(out.deep_used, need);
@@ -3241,11 +3252,15 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
         if (at + need > (unsigned long long)out.deep_capacity) too_deep = true;
         else {
             c.coef = out.deep_pool + at;
-            ecoef_w = out.deep_pool + at + 2ull * (unsigned long long)offset_acc;
-            c.ecoef = ecoef_w;
+            c.ecoef = out.deep_pool + at + 2ull * (unsigned long long)offset_acc;
             obs_cap = offset_acc;
         }
-    } else if (offset_acc > max_obs) too_deep = true;
+    }
+#else
+    if (offset_acc > max_obs) too_deep = true;
+    // the bump counter of the deep launch that follows this one in stream order (workgroup 0 resets it: no memset node per launch)
+    if (blockIdx.x == 0 && lane == 0 && out.deep_used) *out.deep_used = 0ull;
+#endif
     if (lane == 0) w->ehas = ehas_mask;
     c.ehas = ehas_mask;
     __syncthreads();
@@ -3475,10 +3490,14 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                         kacc += ki;
                         uflow = false;
                     }
+#if VLR_DEEP
                     if (pos < obs_cap) {
+#else
+                    if (pos < max_obs) {
+#endif
                         c.coef[2 * pos + 0] = cc_;
                         c.coef[2 * pos + 1] = cq_;
-                        if (ehas_s) __hip_atomic_store(ecoef_w + pos, ce_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (ehas_s) __hip_atomic_store(const_cast<double*>(c.ecoef) + pos, ce_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                     // smallest value the term can take over alpha in [0,1], beta in [0,1] (linear => at a corner)
                     double mn = fmin(fmin(cc_, cc_ + cq_), fmin(cc_ + ce_, cc_ + cq_ + ce_));
@@ -3499,7 +3518,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
           }
             {
                 const int ks = need_rescue ? (int)wave_sum((double)kacc) : 0;
-                if (lane == 0) c.kshift[s] = ks;
+                if (lane == 0) kshift(c)[s] = ks;
             }
             if (fast_s) fastmask |= 1 << s;
             if (vfast_s) vfastmask |= 1 << s;
@@ -3846,7 +3865,7 @@ extern "C" int vlr_launch_call_kernel_deep(const vlr::DevPlan* plan_host, const 
     size_t bytes = dbl * sizeof(double);
     hipError_t e = hipFuncSetAttribute((const void*)vlr_call_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(vlr_call_kernel<2>, dim3((unsigned)batch->n_loci), dim3(64), bytes, (hipStream_t)stream, *plan_host, *batch, *out, 0, range_depth, (int)dbl);
+    hipLaunchKernelGGL(vlr_call_kernel<2>, dim3((unsigned)batch->n_loci), dim3(64), bytes, (hipStream_t)stream, *plan_host, *batch, *out, 0, range_depth);
     return (int)hipGetLastError();
 }
 #else
@@ -3887,7 +3906,7 @@ extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_host, const vlr::
     case W: {                                                                                                                \
         hipError_t e = hipFuncSetAttribute((const void*)vlr_call_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
         if (e != hipSuccess) return (int)e;                                                                                  \
-        hipLaunchKernelGGL(vlr_call_kernel<W>, grid, block, bytes, (hipStream_t)stream, *plan_host, *batch, *out, max_obs, range_depth, (int)dbl); \
+        hipLaunchKernelGGL(vlr_call_kernel<W>, grid, block, bytes, (hipStream_t)stream, *plan_host, *batch, *out, max_obs, range_depth); \
         break;                                                                                                               \
     }
     switch (wpe) {

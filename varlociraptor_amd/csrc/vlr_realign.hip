@@ -18,6 +18,7 @@
 // No MFMA (a recurrence, not a contraction); HBM traffic is the two sequences and the qualities, a few hundred bytes per pair.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/vlr.h"
 
@@ -51,10 +52,7 @@ __device__ __forceinline__ unsigned shr1(unsigned v, unsigned edge) {
 
 constexpr unsigned kBig = 0x3fffffffu;  // "unreachable" edit distance (adding one cannot wrap)
 
-__global__ void __launch_bounds__(64) vlr_realign_kernel(RealignArgs a) {
-    const int64_t pair = blockIdx.x;
-    if (pair >= a.n_pairs) return;
-    const int lane = threadIdx.x;
+__device__ __forceinline__ void realign_one(const RealignArgs& a, const int64_t pair, const int lane) {
     const uint32_t x0 = a.x_offset[pair], y0 = a.y_offset[pair];
     const int len_x = (int)(a.x_offset[pair + 1] - x0), len_y = (int)(a.y_offset[pair + 1] - y0);
     const int med_max = a.max_edit_dist ? a.max_edit_dist[pair] : -1;
@@ -187,6 +185,156 @@ __global__ void __launch_bounds__(64) vlr_realign_kernel(RealignArgs a) {
     if (lane == 0) {
         double p = (total > 0.0) ? log(total) - (double)scale * 0.6931471805599453 : -__builtin_huge_val();
         a.ln_prob[pair] = p > 0.0 ? 0.0 : p;  // "sum of paths can exceed probability 1.0"
+    }
+}
+
+__global__ void __launch_bounds__(64) vlr_realign_kernel(RealignArgs a) {
+    const int64_t pair = blockIdx.x;
+    if (pair >= a.n_pairs) return;
+    realign_one(a, pair, threadIdx.x);
+}
+
+// ---- two pairs per wave ------------------------------------------------------------------------------------------------
+// A read window of at most 64 bases occupies 32 lanes of the wavefront above.  Workgroup w takes the pairs 2w and 2w + 1 — the
+// reference and the alt allele of one read are adjacent in a batch and share the read window — and, when both windows are
+// short, runs them side by side: lanes 0-31 pair 2w, lanes 32-63 pair 2w + 1.  Everything that was wave-uniform per pair
+// (lengths, band, owner lane, step count) is per half; the wave_shr:1 shifts cross the half boundary, so lane 32 takes the edge
+// value instead of lane 31's.  Same arithmetic per cell in the same order: results are bit-identical to the one-pair kernel.
+__global__ void __launch_bounds__(64) vlr_realign_kernel2(RealignArgs a) {
+    const int64_t pair0 = 2 * (int64_t)blockIdx.x;
+    if (pair0 >= a.n_pairs) return;
+    const int lane = threadIdx.x;
+    const bool have2 = pair0 + 1 < a.n_pairs;
+    const int ly0 = (int)(a.y_offset[pair0 + 1] - a.y_offset[pair0]);
+    const int ly1 = have2 ? (int)(a.y_offset[pair0 + 2] - a.y_offset[pair0 + 1]) : 0;
+    const int lx0 = (int)(a.x_offset[pair0 + 1] - a.x_offset[pair0]);
+    const int lx1 = have2 ? (int)(a.x_offset[pair0 + 2] - a.x_offset[pair0 + 1]) : 0;
+    if (!(have2 && ly0 > 0 && ly1 > 0 && ly0 <= 64 && ly1 <= 64 && lx0 > 0 && lx1 > 0)) {  // (uniform) one after the other
+        realign_one(a, pair0, lane);
+        if (have2) realign_one(a, pair0 + 1, lane);
+        return;
+    }
+    const int half = lane >> 5, hl = lane & 31;
+    const bool edge = hl == 0;  // lanes 0 and 32: row 0 of their pair
+    const int64_t pair = pair0 + half;
+    const uint32_t x0 = a.x_offset[pair], y0 = a.y_offset[pair];
+    const int len_x = half ? lx1 : lx0, len_y = half ? ly1 : ly0;
+    const int med_max = a.max_edit_dist ? a.max_edit_dist[pair] : -1;
+    const bool banded = med_max >= 0;
+    int yb[2];
+    double e_match[2], e_mis[2], e_ins[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int j = 2 * hl + r;
+        const bool rowon = j < len_y;
+        const int q = rowon ? a.y_quals[y0 + j] : 0;
+        yb[r] = rowon ? up(a.y_bases[y0 + j]) : 0;
+        const double mis = exp(-(double)q * 2.302585092994046 / 10.0);
+        e_match[r] = rowon ? 1.0 - mis : 0.0;
+        e_mis[r] = rowon ? mis * 0.3333 : 0.0;
+        e_ins[r] = rowon ? mis : 0.0;
+    }
+    double M1[2] = {0.0, 0.0}, X1[2] = {0.0, 0.0}, Y1[2] = {0.0, 0.0};
+    unsigned E1[2] = {kBig, kBig};
+    double Mt[2] = {0.0, 0.0}, Xt[2] = {0.0, 0.0}, Yt[2] = {0.0, 0.0};
+    unsigned Et[2] = {kBig, kBig};
+    double total = 0.0;
+    int scale = 0;
+    const int last_row = len_y - 1;
+    const int lr = last_row & 1;
+    const bool owner_lane = hl == (last_row >> 1);
+    const int nsteps = len_x + len_y - 1;
+    const int ns0 = __builtin_amdgcn_readlane(nsteps, 0), ns1 = __builtin_amdgcn_readlane(nsteps, 32);
+    const int nmax = ns0 > ns1 ? ns0 : ns1;
+    int xchunk = 0, xb0 = 0, xb1 = 0;
+    for (int d = 0; d < nmax; ++d) {
+        if ((d & 31) == 0) {
+            const int i = d + hl;
+            xchunk = (i < len_x) ? up(a.x_bases[x0 + i]) : 0;
+        }
+        const int xn0 = __builtin_amdgcn_readlane(xchunk, d & 31), xn1 = __builtin_amdgcn_readlane(xchunk, 32 + (d & 31));
+        const int xnew = half ? xn1 : xn0;
+        const int prev1 = xb1;
+        xb1 = xb0;
+        {
+            const int sh = (int)shr1((unsigned)prev1, (unsigned)xnew);
+            xb0 = edge ? xnew : sh;
+        }
+        double Mu[2], Xu[2], Yu[2];
+        unsigned Eu[2];
+        {
+            const double m = shr1z(M1[1]), x = shr1z(X1[1]), y = shr1z(Y1[1]);
+            const unsigned e = shr1(E1[1], kBig);
+            Mu[0] = edge ? 0.0 : m; Xu[0] = edge ? 0.0 : x; Yu[0] = edge ? 0.0 : y; Eu[0] = edge ? kBig : e;
+        }
+        {
+            const int nbs = (int)shr1((unsigned)scale, (unsigned)scale);
+            const int nb = edge ? scale : nbs;
+            if (__ballot(scale != nb)) {
+                const double mass = ((M1[0] + M1[1]) + (X1[0] + X1[1])) + ((Y1[0] + Y1[1]) + (Mt[0] + Mt[1])) + ((Xt[0] + Xt[1]) + (Yt[0] + Yt[1])) + total;
+                if (mass == 0.0) scale = nb;
+                int dsc = scale - nb;
+                dsc = dsc > 1000 ? 1000 : dsc < -1000 ? -1000 : dsc;
+                const double f = __builtin_ldexp(1.0, dsc);
+                Mu[0] *= f; Xu[0] *= f; Yu[0] *= f;
+            }
+        }
+        Mu[1] = M1[0]; Xu[1] = X1[0]; Yu[1] = Y1[0]; Eu[1] = E1[0];
+        if (edge) { Mt[0] = __builtin_ldexp(1.0, scale); Et[0] = 0u; }
+        double Mn[2], Xn[2], Yn[2];
+        unsigned En[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int i = d - (2 * hl + r);
+            const bool incol = (unsigned)i < (unsigned)len_x;
+            const int xb = r == 0 ? xb0 : xb1;
+            const bool is_match = xb == yb[r];
+            const double emit = is_match ? e_match[r] : e_mis[r];
+            const double m = emit * (a.pn * Mt[r] + a.pny * Xt[r] + a.pnx * Yt[r]);
+            const double x = a.pgy * M1[r] + a.pgye * X1[r];
+            const double y = e_ins[r] * (a.pgx * Mu[r] + a.pgxe * Yu[r]);
+            bool live = incol;
+            unsigned e = kBig;
+            {
+                const unsigned etl = Et[r], eu = Eu[r], el = E1[r];
+                const unsigned emin = min(etl, min(eu, el));
+                const bool in_band = !(emin > (unsigned)med_max);
+                live = incol && (!banded || in_band);
+                const unsigned eb = live ? min(min(is_match ? etl : etl + 1u, min(eu + 1u, el + 1u)), kBig) : kBig;
+                e = banded ? eb : kBig;
+            }
+            Mn[r] = live ? m : 0.0; Xn[r] = live ? x : 0.0; Yn[r] = live ? y : 0.0;
+            En[r] = e;
+        }
+        {
+            const double s = (Mn[lr] + Xn[lr]) + Yn[lr];
+            total += owner_lane ? s : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { Mt[r] = Mu[r]; Xt[r] = Xu[r]; Yt[r] = Yu[r]; Et[r] = Eu[r]; M1[r] = Mn[r]; X1[r] = Xn[r]; Y1[r] = Yn[r]; E1[r] = En[r]; }
+        if ((d & 7) == 7) {
+            double mx = fmax(fmax(fmax(M1[0], X1[0]), fmax(Y1[0], M1[1])), fmax(X1[1], Y1[1]));
+            mx = fmax(mx, fmax(fmax(Mt[0], Xt[0]), fmax(fmax(Yt[0], Mt[1]), fmax(Xt[1], Yt[1]))));
+            int ex = 0;
+            (void)__builtin_frexp(mx, &ex);
+            const bool resc = mx > 0.0 && (ex > 200 || (ex < -200 && !(total > mx * 0x1p60)));
+            if (__ballot(resc)) {
+                const int sh0 = -ex > 1000 ? 1000 : -ex < -1000 ? -1000 : -ex;
+                const int sh = resc ? sh0 : 0;
+                const double f1 = __builtin_ldexp(1.0, sh);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) { M1[r] *= f1; X1[r] *= f1; Y1[r] *= f1; Mt[r] *= f1; Xt[r] *= f1; Yt[r] *= f1; }
+                total *= f1;
+                scale += sh;
+            }
+        }
+    }
+    const int owner = 32 * half + (last_row >> 1);
+    total = __shfl(total, owner);
+    scale = __shfl(scale, owner);
+    if (edge) {
+        double p = (total > 0.0) ? log(total) - (double)scale * 0.6931471805599453 : -__builtin_huge_val();
+        a.ln_prob[pair] = p > 0.0 ? 0.0 : p;
     }
 }
 
@@ -444,7 +592,9 @@ extern "C" int vlr_launch_realign_kernel(const vlr_realign_batch_desc* b, double
     const double gx = exp(b->gap[0]), gy = exp(b->gap[1]), gxe = exp(b->gap[2]), gye = exp(b->gap[3]);
     a.pgx = gx; a.pgy = gy; a.pgxe = gxe; a.pgye = gye;
     a.pn = 1.0 - (gx + gy); a.pnx = 1.0 - gxe; a.pny = 1.0 - gye;
-    hipLaunchKernelGGL(vlr_realign_kernel, dim3((unsigned)b->n_pairs), dim3(64), 0, (hipStream_t)stream, a);
+    static const bool single = getenv("VLR_REALIGN_SINGLE") != nullptr;  // tuning / comparison knob
+    if (single) hipLaunchKernelGGL(vlr_realign_kernel, dim3((unsigned)b->n_pairs), dim3(64), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(vlr_realign_kernel2, dim3((unsigned)((b->n_pairs + 1) / 2)), dim3(64), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 
