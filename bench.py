@@ -423,7 +423,8 @@ def main():
             from oracle import oracle
             from parity import compare
             cores = effective_cpus()
-            per_core = {"config2": 2500, "config5": 400}.get(args.workload, 40)
+            # about 10 s of CPU work on the effective cores (863 / 97 k / 32 k loci/s for config3 / 2 / 5 on the box's 16 CPUs)
+            per_core = {"config2": 50000, "config5": 15000}.get(args.workload, 600)
             n_cpu = args.cpu_loci or min(batch.n_loci, per_core * cores)
             sub = batch.select(np.arange(n_cpu))
             bounds = np.linspace(0, n_cpu, cores + 1).astype(int)
@@ -452,7 +453,7 @@ def main():
                    "note": "fidelity oracle (reference operation order, log-space transcendentals, caches), not a tuned CPU implementation"}
             # the same algorithm with the pileup likelihood in affine product form, no allocation in the term
             # loop, AVX2/FMA build: the CPU path somebody tried to make fast (oracle/vlr_oracle.cpp, Ctx::tuned)
-            per_core_t = {"config2": 50000, "config5": 8000}.get(args.workload, 1500)
+            per_core_t = {"config2": 250000, "config5": 40000}.get(args.workload, 15000)
             n_t = min(batch.n_loci, per_core_t * cores)
             sub_t = batch.select(np.arange(n_t)) if n_t != n_cpu else sub
             bounds_t = np.linspace(0, n_t, cores + 1).astype(int)

@@ -168,3 +168,53 @@ def test_ingest_throughput_is_reported(tmp_path, capsys):
     rate = r.n_loci / dt
     print("native ingest: %.0f records/s (%d threads)" % (rate, os.cpu_count()))
     assert rate > 5000
+
+
+def test_container_variants_and_damaged_files(tmp_path, golden_dir):
+    """The reader accepts BGZF, plain (multi-member) gzip and uncompressed containers of BCF and text VCF, an empty record set,
+    and refuses damaged input with an error instead of decoding garbage."""
+    import gzip
+    cfg = synth.config3()
+    b = synth.generate(cfg, 60, seed=9)
+    p = str(tmp_path / "a.bcf")
+    ingest.write_observations(p, b, 0)
+    ref, _ = ingest.read_observations([p])
+    raw = gzip.open(p, "rb").read()
+    # uncompressed BCF, single-member gzip, two-member gzip
+    u = str(tmp_path / "u.bcf"); open(u, "wb").write(raw)
+    g1 = str(tmp_path / "g1.bcf"); open(g1, "wb").write(gzip.compress(raw))
+    g2 = str(tmp_path / "g2.bcf"); open(g2, "wb").write(gzip.compress(raw[:5000]) + gzip.compress(raw[5000:]))
+    for q in (u, g1, g2):
+        r, _ = ingest.read_observations([q])
+        _same_batch(r, ref)
+    # text VCF, gzipped
+    d = os.path.join(golden_dir, "flamegraph_profiling", "normal.vcf")
+    tz = str(tmp_path / "n.vcf.gz"); open(tz, "wb").write(gzip.compress(open(d, "rb").read()))
+    a, _ = ingest.read_observations([d]); c, _ = ingest.read_observations([tz])
+    _same_batch(a, c)
+    # no records at all
+    e = str(tmp_path / "e.bcf")
+    ingest.write_observations(e, b.select(np.arange(0)), 0)
+    z, sites = ingest.read_observations([e])
+    assert z.n_loci == 0 and z.n_obs == 0 and len(sites) == 0
+    # damaged: truncated file, flipped bytes inside a block, a record cut short, a vector cut short
+    blob = open(p, "rb").read()
+    t1 = str(tmp_path / "t1.bcf"); open(t1, "wb").write(blob[:len(blob) // 2])
+    t2 = str(tmp_path / "t2.bcf"); bad = bytearray(blob); bad[len(bad) // 3:len(bad) // 3 + 64] = bytes(64); open(t2, "wb").write(bytes(bad))
+    t3 = str(tmp_path / "t3.bcf"); open(t3, "wb").write(raw[:len(raw) - 37])
+    for q in (t1, t2, t3):
+        with pytest.raises(Exception):
+            ingest.read_observations([q])
+    lines = open(d).read().split("\n")
+    k = next(i for i, l in enumerate(lines) if l and not l.startswith("#"))
+    f = lines[k].split("\t")
+    info = f[7].split(";")
+    j = next(i for i, kv in enumerate(info) if kv.startswith("PROB_REF="))
+    info[j] = ",".join(info[j].split(",")[:-9])      # cut the PROB_REF vector short
+    f[7] = ";".join(info)
+    lines[k] = "\t".join(f)
+    t4 = str(tmp_path / "t4.vcf"); open(t4, "w").write("\n".join(lines))
+    with pytest.raises(Exception, match="truncated|inconsistent"):
+        ingest.read_observations([t4])
+    with pytest.raises(Exception, match="cannot open|No such"):
+        ingest.read_observations([str(tmp_path / "missing.bcf")])
