@@ -155,3 +155,30 @@ def test_breakend_mates_sharing_a_pileup_get_identical_results():
     for f in ("ln_posterior", "map_vaf", "map_bias", "best_event", "status"):
         a = getattr(got, f)
         assert np.array_equal(a[mates], a[g[mates]], equal_nan=True), f
+
+
+def test_afd_sub_ranges_on_two_lanes_equal_one_range(oracle, monkeypatch):
+    """The AFD log is budgeted (4 GiB): larger batches are walked in sub-ranges of loci on two stream lanes (the caller's stream and a
+    plan-owned one).  With a budget of a few MB a 3 000-locus batch takes a dozen sub-ranges: posteriors, MAP and lists must be
+    those of the single-range run, bit for bit, and the lists those of the oracle."""
+    from varlociraptor_amd import engine, synth
+    cfg = synth.config3()
+    b = synth.generate(cfg, 3000, seed=33)
+    plan = engine.Plan(cfg.scenario)
+    one = plan.call_host(b, afd_capacity=96)
+    plan.close()
+    monkeypatch.setenv("VLR_AFD_LOG_BUDGET_MB", "16")   # ~ 480 loci per log, 240 per lane
+    plan = engine.Plan(cfg.scenario)
+    many = plan.call_host(b, afd_capacity=96)
+    plan.close()
+    for f in ("ln_posterior", "map_vaf", "map_bias", "best_event", "status", "afd_count"):
+        assert np.array_equal(getattr(one, f), getattr(many, f), equal_nan=True), f
+    n = np.minimum(one.afd_count, 96)
+    for l in range(0, b.n_loci, 7):
+        for s in range(b.n_samples):
+            k = int(n[l, s])
+            a = sorted(zip(one.afd_vaf[l, s, :k], one.afd_lnprob[l, s, :k]))
+            c = sorted(zip(many.afd_vaf[l, s, :k], many.afd_lnprob[l, s, :k]))
+            assert a == c, (l, s)
+    ref = oracle.call(cfg.scenario, b, afd_capacity=96, begin=0, end=300)
+    assert np.array_equal(ref.afd_count[:300], many.afd_count[:300])

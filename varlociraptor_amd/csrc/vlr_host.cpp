@@ -873,7 +873,7 @@ static int ensure_buffers(vlr_plan* plan, int64_t n_loci, int max_obs, bool want
             // log; vlr_batch_run walks the batch in sub-ranges of afd_log_loci loci that share the buffer
             size_t budget = (size_t)4 << 30;
             if (const char* ev = getenv("VLR_AFD_LOG_BUDGET_MB")) budget = (size_t)std::max(1L, atol(ev)) << 20;
-            size_t loci = std::max<size_t>(std::min<size_t>(L, budget / (words * sizeof(double))), std::min<size_t>(L, 4096));
+            size_t loci = std::max<size_t>(std::min<size_t>(L, budget / (words * sizeof(double))), std::min<size_t>(L, getenv("VLR_AFD_LOG_BUDGET_MB") ? 64 : 4096));
             if (plan->afd_log_loci[k] > 0 && plan->afd_log[k] && (size_t)plan->afd_log_loci[k] * words * sizeof(double) <= plan->afd_log_bytes[k])
                 loci = std::max<size_t>(loci, std::min<size_t>(L, (size_t)plan->afd_log_loci[k]));
             (void)grow(&plan->afd_log[k], &plan->afd_log_bytes[k], loci * words * sizeof(double), true);  // no room: replay alone

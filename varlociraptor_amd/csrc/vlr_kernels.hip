@@ -699,6 +699,8 @@ struct Ctx {
     double *rowX, *rowV;             // [kRows][cap] visited-point tables of the row-parallel innermost chains
     double* afd_seen;                // replay: [S][kMaxSet] recorded discrete operands: (VAF, l2fc-list key) pairs
     double* mapv;                    // replay: [S] MAP VAF per sample
+    int* afd_cnt;                    // AFD filter kernel: [S] entries written so far, in LDS (one wave owns the locus: no global atomic per
+                                     // entry); nullptr in the replay launch, which counts in afd_count itself
     int* afd_nseen;                  // replay: [S] discrete VAFs of sample s already recorded (overlapping roots/branches
                                      // visit the same operands; the reference's joint_probs map keeps one entry)
     double* tvaf;                    // [kRows][S] outer operands of the chain tasks
@@ -1243,10 +1245,17 @@ __device__ inline void afd_consider(Ctx& c, double joint, int inner, double x, i
             }
             __syncthreads();
         }
+        int idx_l = 0;
+        if (c.afd_cnt) {
+            idx_l = UNI(c.afd_cnt[s]);
+            VLR_WAVE_FENCE();
+            if (c.lane == 0) c.afd_cnt[s] = idx_l + 1;
+            VLR_WAVE_FENCE();
+        }
         if (c.lane == 0) {
             const DevResults& o = *c.outp;
             int64_t slot = c.locus * c.S + s;
-            int idx = atomicAdd(&o.afd_count[slot], 1);
+            int idx = c.afd_cnt ? idx_l : atomicAdd(&o.afd_count[slot], 1);
             if (idx < o.afd_capacity) {
                 double v = (s == inner) ? x : c.w->ops_vaf[s];
                 // the sign bit marks a discrete operand until afd_finish() has removed repeated keys
@@ -1269,9 +1278,11 @@ __device__ inline void afd_finish(Ctx& c) {
     for (int s = 0; s < c.S; ++s) {
         const int64_t slot = c.locus * c.S + s;
         int cnt = 0;
-        if (c.lane == 0) cnt = atomicAdd(&o.afd_count[slot], 0);
+        if (c.afd_cnt) cnt = c.afd_cnt[s];
+        else if (c.lane == 0) cnt = atomicAdd(&o.afd_count[slot], 0);
         cnt = UNI(cnt);
         if (cnt <= 0) continue;
+        if (c.afd_cnt && c.lane == 0) o.afd_count[slot] = cnt;  // (replaced by the de-duplicated count below unless the list was truncated)
         double* vv = o.afd_vaf + slot * o.afd_capacity;
         double* pp = o.afd_lnprob + slot * o.afd_capacity;
         long long* kk = o.afd_key + slot * o.afd_capacity;
@@ -2900,6 +2911,7 @@ __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, Dev
     __shared__ double sh_seen[2 * kMaxSamples * kMaxSet];  // (VAF, l2fc key) pairs
     __shared__ double sh_mapv[kMaxSamples];
     __shared__ int sh_nseen[kMaxSamples];
+    __shared__ int sh_cnt[kMaxSamples];
     const DevPlan& p = plan_arg;
     const int lane = threadIdx.x;
     const int64_t locus = blockIdx.x;
@@ -2917,7 +2929,8 @@ __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, Dev
     c.afd_seen = sh_seen; c.mapv = sh_mapv; c.afd_nseen = sh_nseen;
     c.replay = 1; c.hyp = 0; c.afd_mute = 0; c.locus = locus; c.outp = &out; c.status = 0; c.lg = nullptr; c.lg_pos = -1; c.lg_cap = 0; c.lg_nrec = 0;
     c.vt = 0; c.has_snv = 0; c.refbase = 0; c.altbase = 0;
-    if (lane < S) { sh_mapv[lane] = out.map_vaf[locus * S + lane]; sh_nseen[lane] = 0; }
+    if (lane < S) { sh_mapv[lane] = out.map_vaf[locus * S + lane]; sh_nseen[lane] = 0; sh_cnt[lane] = 0; }
+    c.afd_cnt = sh_cnt;
     __syncthreads();
     const int be = UNI(out.best_event[locus]);
     c.mapGroup = (be == 0) ? 0 : ((be - 1) / 2 + 1);
@@ -2929,6 +2942,7 @@ __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, Dev
     __shared__ long long sh_hdr[kLogDir];
     __shared__ double sh_ops[kLogDir][kMaxSamples];
     __shared__ double sh_probe[kLogDir][3];
+    __shared__ double sh_x[kTableCap];
     int at = 0, n = 0, s_in = -1, disc = 0, nl = 0, kind = 0, grp = 0, mism = 99;
     long long h = 0;
     if (lane < nrec) {
@@ -3010,20 +3024,26 @@ __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, Dev
         const double mx = uni_d(sh_mapv[sin_r]);
         const bool bulk = m_r == 0 && group_contains(c, c.mapGroup, sin_r, 0.0, sin_r);  // the integrated sample is excluded: x does not matter
         const long long lkey_r = UNI64(lfc_ctx_key(c));
+        // the x values of the record go to LDS in one coalesced round (table capacity <= kTableCap = 128): the first-occurrence test
+        // below reads every earlier x once per entry — as uniform global loads that was one memory round trip per table entry
+        __syncthreads();
+        for (int i = lane; i < n_r && i < kTableCap; i += 64) sh_x[i] = X[i];
+        __syncthreads();
         for (int q0 = 0; q0 < n_r; q0 += 64) {
             const int q = q0 + lane;
             const bool on = q < n_r;
-            const double xq = on ? X[q] : __builtin_nan(""), vq = on ? V[q] : 0.0;
+            const double xq = on ? (q < kTableCap ? sh_x[q] : X[q]) : __builtin_nan(""), vq = on ? V[q] : 0.0;
             // one map key per revisited point of the chain: first occurrence only
             bool dup = false;
-            for (int j = 0; j < q0 + 64 && j < n_r; ++j) dup = dup || (j < q && X[j] == xq);
+            for (int j = 0; j < q0 + 64 && j < n_r; ++j) dup = dup || (j < q && (j < kTableCap ? sh_x[j] : X[j]) == xq);
             if (bulk) {
                 const bool emit = on && !dup;
                 const unsigned long long em = __ballot(emit);
                 const int64_t slot = locus * S + sin_r;
-                int base = 0;
-                if (lane == 0 && em) base = atomicAdd(&out.afd_count[slot], __popcll(em));
-                base = UNI(base);
+                int base = UNI(sh_cnt[sin_r]);
+                VLR_WAVE_FENCE();
+                if (lane == 0 && em) sh_cnt[sin_r] = base + __popcll(em);
+                VLR_WAVE_FENCE();
                 const int idx = base + __popcll(em & ((1ull << lane) - 1ull));
                 if (emit && idx < out.afd_capacity) {
                     out.afd_vaf[slot * out.afd_capacity + idx] = xq;  // continuous operand: no discrete marker
@@ -3099,7 +3119,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
     c.status = 0;
     if (lane == 0) { w->work[0] = 0; w->work[1] = 0; }
     c.need_batch = 0; c.bt_nt = 0; c.bt_inner = 0;
-    c.replay = out.replay; c.locus = locus; c.outp = &out; c.mapGroup = 0; c.mapDisc = 0; c.marginal = 0.0;
+    c.replay = out.replay; c.locus = locus; c.outp = &out; c.mapGroup = 0; c.mapDisc = 0; c.marginal = 0.0; c.afd_cnt = nullptr;
     c.lg = (out.afd_log && !out.replay && !VLR_DEEP) ? out.afd_log + (size_t)locus * (size_t)out.afd_log_stride : nullptr;
     c.lg_pos = kLogFirst; c.lg_cap = (int)out.afd_log_stride; c.lg_nrec = 0; c.hyp = 0;
 #ifdef VLR_PROFILE
