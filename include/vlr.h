@@ -434,6 +434,18 @@ int  vlr_obs_write(const char* path, const vlr_batch* in, int sample, const vlr_
  * of ln_posterior ("absent", the scenario events, "artifact") — INFO PROB_<NAME>, PHRED, f32, sorted by descending probability. */
 int  vlr_calls_write(const char* path, const char* header_text, const vlr_obs_table* table, const vlr_results* results,
                      const char* const* out_names, int n_threads);
+/* The same in pieces: a reader that delivers at most max_records records of every sample file per call (bounded memory; the
+ * caller may overlap the read of the next chunk with the evaluation and emission of the previous one), and a writer that appends
+ * one chunk per call.  vlr_obs_reader_next sets *out = NULL once the files are exhausted; every table is freed by the caller.
+ * Breakend groups (vlr_obs_sites.group_representative) are formed within a chunk. */
+typedef struct vlr_obs_reader vlr_obs_reader;
+int  vlr_obs_reader_open(int n_samples, const char* const* paths, uint32_t omit_bias_mask, int n_threads, vlr_obs_reader** out);
+int  vlr_obs_reader_next(vlr_obs_reader* reader, int64_t max_records, vlr_obs_table** out);
+void vlr_obs_reader_close(vlr_obs_reader* reader);
+typedef struct vlr_calls_writer vlr_calls_writer;
+int  vlr_calls_writer_open(const char* path, const char* header_text, vlr_calls_writer** out);
+int  vlr_calls_writer_append(vlr_calls_writer* writer, const vlr_obs_table* table, const vlr_results* results, const char* const* out_names, int n_threads);
+int  vlr_calls_writer_close(vlr_calls_writer* writer);   /* header (if nothing was appended), BGZF end-of-file member, close */
 /* Measurement aid: wall seconds of the stages of the last vlr_obs_read ([0] file reads, [1] BGZF inflate, [2] parse + decode — summed
  * over the sample files, which run side by side — [3] all files, [4] merge into the table, [5] strings and groups, [6] total) and of
  * the last vlr_calls_write ([8] record encoding, [9] BGZF deflate + file write, [10] total). */

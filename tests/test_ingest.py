@@ -218,3 +218,56 @@ def test_container_variants_and_damaged_files(tmp_path, golden_dir):
         ingest.read_observations([t4])
     with pytest.raises(Exception, match="cannot open|No such"):
         ingest.read_observations([str(tmp_path / "missing.bcf")])
+
+
+@pytest.mark.parametrize("chunk", [1, 7, 64, 1000])
+def test_streaming_reader_and_appending_writer_equal_the_whole_file_calls(oracle, tmp_path, chunk):
+    """vlr_obs_reader / vlr_calls_writer: chunks of `chunk` records concatenate to the table of vlr_obs_read (columns, sites, priors),
+    and the calls file written chunk by chunk holds the records of the one written at once.  Text VCF and BGZF BCF inputs."""
+    import gzip
+    cfg = synth.config3()
+    b = synth.generate(cfg, 150, seed=4)
+    paths = []
+    for s in range(2):
+        p = str(tmp_path / ("s%d.bcf" % s)); ingest.write_observations(p, b, s); paths.append(p)
+    whole, wsites = ingest.read_observations(paths)
+    parts = []
+    rd = ingest.ObsReader(paths, chunk_records=chunk)
+    for pb, sites in rd:
+        assert pb.n_loci <= chunk
+        parts.append((pb, sites))
+    rd.close()
+    assert sum(pb.n_loci for pb, _ in parts) == whole.n_loci and len(parts) == -(-whole.n_loci // chunk)
+    from varlociraptor_amd.batch import PileupBatch
+    cat = PileupBatch.concat([pb for pb, _ in parts])
+    _same_batch(cat, whole)
+    assert [s_[l] for _, s_ in parts for l in range(len(s_))] == [wsites[l] for l in range(len(wsites))]
+    # calls: whole vs appended
+    sc = cfg.scenario
+    names = sc.out_names()
+    header = callsfmt.header(names, sc.sample_names, ["1"])
+    res = oracle.call(sc, whole, afd_capacity=32)
+    one = str(tmp_path / "one.bcf"); ingest.write_calls(one, header, whole.extra["native_table"], res, names)
+    two = str(tmp_path / "two.bcf")
+    from varlociraptor_amd.batch import CallResults
+    with ingest.CallsWriter(two, header) as w:
+        l0 = 0
+        for pb, _ in parts:
+            sub = CallResults(pb.n_loci, res.n_out, res.n_samples, 32)
+            for f in ("ln_posterior", "ln_marginal", "map_vaf", "map_bias", "best_event", "status", "afd_count", "afd_vaf", "afd_lnprob"):
+                getattr(sub, f)[:] = getattr(res, f)[l0:l0 + pb.n_loci]
+            w.append(pb.extra["native_table"], sub, names)
+            l0 += pb.n_loci
+    assert gzip.open(one, "rb").read() == gzip.open(two, "rb").read()
+    assert len(list(BcfReader(two))) == whole.n_loci
+    if chunk == 7:   # text VCF through the streaming reader; an empty calls file
+        d = os.path.join(GOLDEN_FLAME, "normal.vcf")
+        a, _ = ingest.read_observations([d])
+        got = PileupBatch.concat([pb for pb, _ in ingest.ObsReader([d], chunk_records=4)])
+        _same_batch(got, a)
+        e = str(tmp_path / "empty.bcf")
+        ingest.CallsWriter(e, header).close()
+        assert len(list(BcfReader(e))) == 0
+
+
+GOLDEN_FLAME = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "flamegraph_profiling")

@@ -340,7 +340,17 @@ void bgzf_deflate_block(const uint8_t* data, size_t n, int level, std::vector<ui
 const uint8_t kBgzfEof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 // compress `data` into BGZF members of 0xff00 bytes in parallel and write the file
+bool write_bgzf_stream(FILE* f, const std::vector<const std::vector<uint8_t>*>& parts, int n_threads, int level, bool with_eof, std::string& err);
 bool write_bgzf_file(const char* path, const std::vector<const std::vector<uint8_t>*>& parts, int n_threads, int level, std::string& err) {
+    FILE* f = fopen(path, "wb");
+    if (!f) { err = std::string("cannot create ") + path; return false; }
+    bool ok = write_bgzf_stream(f, parts, n_threads, level, true, err);
+    ok = (fclose(f) == 0) && ok;
+    if (!ok && err.empty()) err = std::string("write failed on ") + path;
+    return ok;
+}
+// the parts, logically concatenated, as BGZF members appended to an open file (a short last member is legal BGZF)
+bool write_bgzf_stream(FILE* f, const std::vector<const std::vector<uint8_t>*>& parts, int n_threads, int level, bool with_eof, std::string& err) {
     // the parts are logically concatenated; cut into blocks without copying more than one block at a time
     size_t total = 0;
     std::vector<size_t> start;
@@ -363,13 +373,10 @@ bool write_bgzf_file(const char* path, const std::vector<const std::vector<uint8
         }
         bgzf_deflate_block(tmp.data(), tmp.size(), level, comp[(size_t)bi]);
     });
-    FILE* f = fopen(path, "wb");
-    if (!f) { err = std::string("cannot create ") + path; return false; }
     bool ok = true;
     for (auto& c : comp) ok = ok && fwrite(c.data(), 1, c.size(), f) == c.size();
-    ok = ok && fwrite(kBgzfEof, 1, 28, f) == 28;
-    ok = (fclose(f) == 0) && ok;
-    if (!ok) err = std::string("write failed on ") + path;
+    if (with_eof) ok = ok && fwrite(kBgzfEof, 1, 28, f) == 28;
+    if (!ok) err = "write failed";
     return ok;
 }
 
@@ -891,6 +898,10 @@ struct SampleFile {
     int64_t n_rec = 0;
 };
 
+bool decode_records(const uint8_t* base, size_t size, const std::vector<size_t>& starts, bool is_bcf, const std::vector<int8_t>& field_of_key,
+                    std::unordered_map<std::string, int>& contig_ids, std::mutex& contig_mu, const char* path, int64_t first_record_no, int n_threads,
+                    SampleFile& sf, std::string& err);
+
 bool read_sample_file(const char* path, int n_threads, SampleFile& sf, std::string& err) {
     Blob data;
     if (!load_inflated(path, data, n_threads, err)) return false;
@@ -933,12 +944,22 @@ bool read_sample_file(const char* path, int n_threads, SampleFile& sf, std::stri
     for (size_t i = 0; i < h.dict.size(); ++i)
         for (int f = 0; f < FD_N; ++f)
             if (h.dict[i] == kFieldName[f]) field_of_key[i] = (int8_t)f;
+    std::unordered_map<std::string, int> contig_ids;
+    std::mutex contig_mu;
+    if (!decode_records(data.data(), data.size(), starts, is_bcf, field_of_key, contig_ids, contig_mu, path, 0, n_threads, sf, err)) return false;
+    g_ingest_t[2] += now_s() - t_parse0;
+    return true;
+}
+
+// records [starts[i], starts[i+1]) of `base` -> the chunks of sf, on n_threads workers over contiguous record ranges
+bool decode_records(const uint8_t* base, size_t size, const std::vector<size_t>& starts, bool is_bcf, const std::vector<int8_t>& field_of_key,
+                    std::unordered_map<std::string, int>& contig_ids, std::mutex& contig_mu, const char* path, int64_t first_record_no, int n_threads,
+                    SampleFile& sf, std::string& err) {
+    struct View { const uint8_t* p; size_t n; const uint8_t* data() const { return p; } size_t size() const { return n; } } data{base, size};
     const int64_t n = (int64_t)starts.size() - 1;
     sf.n_rec = n;
     const int T = (int)std::max<int64_t>(1, std::min<int64_t>(pick_threads(n_threads), (n + 255) / 256));
     sf.chunks = std::vector<Chunk>((size_t)T);
-    std::unordered_map<std::string, int> contig_ids;
-    std::mutex contig_mu;
     parallel_ranges(n, T, [&](int64_t b, int64_t e, int t) {
         Chunk& c = sf.chunks[(size_t)t];
         {   // one allocation per column instead of doubling (a v15 observation takes 100-160 bytes of an uncompressed BCF record)
@@ -960,12 +981,11 @@ bool read_sample_file(const char* path, int n_threads, SampleFile& sf, std::stri
                 ok = parse_text_record(ls, le, contig_ids, contig_mu, sf.contig_names, r, er);
             }
             ok = ok && decode_into(r, c, er);
-            if (!ok) c.error = er + " (record " + std::to_string(i + 1) + " of " + path + ")";
+            if (!ok) c.error = er + " (record " + std::to_string(first_record_no + i + 1) + " of " + path + ")";
         }
     });
     for (auto& c : sf.chunks)
         if (!c.error.empty()) { err = c.error; return false; }
-    g_ingest_t[2] += now_s() - t_parse0;
     return true;
 }
 
@@ -1034,6 +1054,8 @@ struct vlr_obs_table {
     T* make(Arr& a, size_t n) { a.p = table_alloc(n * sizeof(T), a.pinned); return (T*)a.p; }
 };
 
+static int build_table(std::vector<SampleFile>& files, const char* const* paths, uint32_t omit_bias_mask, int n_threads, vlr_obs_table** out);
+
 extern "C" {
 
 int vlr_obs_read(int n_samples, const char* const* paths, uint32_t omit_bias_mask, int n_threads, vlr_obs_table** out) {
@@ -1055,6 +1077,16 @@ int vlr_obs_read(int n_samples, const char* const* paths, uint32_t omit_bias_mas
             if (!oks[(size_t)s]) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s", errs[(size_t)s].c_str());
     }
     g_ingest_t[3] = now_s() - t_all0;
+    const int rc = build_table(files, paths, omit_bias_mask, n_threads, out);
+    g_ingest_t[6] = now_s() - t_all0;
+    return rc;
+}
+}  // extern "C"
+
+// the decoded chunks of the sample files -> one table in the locus x sample order of vlr_batch
+static int build_table(std::vector<SampleFile>& files, const char* const* paths, uint32_t omit_bias_mask, int n_threads, vlr_obs_table** out) {
+    const int n_samples = (int)files.size();
+    const double t_all0 = now_s();
     const double t_merge0 = now_s();
     for (int s = 0; s < n_samples; ++s) {
         if (files[(size_t)s].n_rec != files[0].n_rec) return ifail(VLR_ERR_INVALID_ARGUMENT, "inconsistent observations: %s holds %lld records, %s %lld (calling.rs:369-371)",
@@ -1167,10 +1199,12 @@ int vlr_obs_read(int n_samples, const char* const* paths, uint32_t omit_bias_mas
     }
     for (auto& n : t->contig_names) t->contig_ptrs.push_back(n.c_str());
     g_ingest_t[5] = now_s() - t_str0;
-    g_ingest_t[6] = now_s() - t_all0;
+    (void)t_all0;
     *out = t.release();
     return VLR_OK;
 }
+
+extern "C" {
 
 // measurement aid: seconds of the stages of the last vlr_obs_read — [0] file reads, [1] BGZF inflate, [2] record parse + decode
 // (each summed over the sample files, which run side by side), [3] wall time of all files, [4] merge into the table, [5] strings and
@@ -1206,6 +1240,212 @@ int vlr_obs_table_sites(const vlr_obs_table* t, vlr_obs_sites* s) {
     s->imprecise = t->imprecise.data();
     return VLR_OK;
 }
+
+}  // extern "C"
+
+
+// ================================================================================================ streaming reader
+// The same files, a bounded number of records at a time (bounded memory, and the caller can overlap the read of the next chunk
+// with the evaluation and emission of the previous one).  Every sample file keeps its position: the BGZF block index, the next
+// block, and the inflated bytes behind the last record it delivered.  All files advance by the same number of records per call.
+namespace {
+struct FileStream {
+    std::string path;
+    Blob raw;                          // the mapped file
+    std::vector<BgzfBlock> blocks;     // BGZF members (empty: other containers — everything is inflated at open)
+    size_t next_block = 0;
+    std::vector<uint8_t> win;          // inflated, not yet delivered bytes (BGZF) ...
+    Blob whole;                        // ... or the whole inflated file
+    size_t pos = 0;                    // first undelivered byte of win / whole
+    bool use_whole = false, is_bcf = false, header_done = false;
+    Header h;
+    std::vector<int8_t> field_of_key;
+    std::vector<std::string> contig_names;
+    std::unordered_map<std::string, int> contig_ids;
+    std::mutex contig_mu;
+    int64_t delivered = 0;
+    const uint8_t* base() const { return use_whole ? whole.p : win.data(); }
+    size_t avail() const { return use_whole ? whole.n : win.size(); }
+    bool more_blocks() const { return !use_whole && next_block < blocks.size(); }
+};
+
+bool stream_open(FileStream& f, const char* path, int n_threads, std::string& err) {
+    f.path = path;
+    if (!read_whole_file(path, f.raw, err)) return false;
+    const bool gz = f.raw.size() >= 2 && f.raw[0] == 0x1f && f.raw[1] == 0x8b;
+    if (!(gz && bgzf_index(f.raw, f.blocks))) {
+        f.blocks.clear();
+        f.use_whole = true;
+        f.raw.release();
+        if (!load_inflated(path, f.whole, n_threads, err)) return false;
+    }
+    return true;
+}
+// inflate the next `count` blocks behind the undelivered bytes of the window
+bool stream_fill(FileStream& f, size_t count, int n_threads, std::string& err) {
+    if (f.pos > 0) { f.win.erase(f.win.begin(), f.win.begin() + (long)f.pos); f.pos = 0; }
+    const size_t b0 = f.next_block, b1 = std::min(f.blocks.size(), b0 + count);
+    size_t add = 0;
+    std::vector<size_t> off(b1 - b0);
+    for (size_t b = b0; b < b1; ++b) { off[b - b0] = add; add += f.blocks[b].isize; }
+    const size_t old = f.win.size();
+    f.win.resize(old + add);
+    std::atomic<bool> bad{false};
+    parallel_items((int64_t)(b1 - b0), n_threads, [&](int64_t i, int) {
+        const BgzfBlock& b = f.blocks[b0 + (size_t)i];
+        if (b.isize && !inflate_raw(f.raw.p + b.off, b.clen, f.win.data() + old + off[(size_t)i], b.isize)) bad = true;
+    });
+    f.next_block = b1;
+    if (bad) { err = std::string("corrupt BGZF block in ") + f.path; return false; }
+    return true;
+}
+// header of the stream (BCF: magic + text; text VCF: the leading '#' lines)
+bool stream_header(FileStream& f, int n_threads, std::string& err) {
+    for (;;) {
+        const uint8_t* d = f.base();
+        const size_t n = f.avail();
+        if (n >= 9 && memcmp(d, "BCF\2\2", 5) == 0) {
+            uint32_t l_text;
+            memcpy(&l_text, d + 5, 4);
+            if (9 + (size_t)l_text <= n) {
+                std::string text((const char*)d + 9, l_text);
+                while (!text.empty() && text.back() == '\0') text.pop_back();
+                parse_header(text, f.h);
+                f.is_bcf = true; f.pos = 9 + (size_t)l_text; f.contig_names = f.h.contigs;
+                break;
+            }
+        } else if (n > 0 && d[0] == '#') {
+            // all header lines must be in the window: the first line that does not start with '#' ends it
+            size_t p = 0;
+            std::string text;
+            bool complete = false;
+            while (p < n) {
+                const uint8_t* nl = (const uint8_t*)memchr(d + p, '\n', n - p);
+                if (!nl) break;
+                const size_t e = (size_t)(nl - d);
+                if (d[p] != '#') { complete = true; break; }
+                text.append((const char*)d + p, e - p + 1);
+                p = e + 1;
+            }
+            if (complete || !f.more_blocks()) { parse_header(text, f.h); f.is_bcf = false; f.pos = p; break; }
+        } else if (n > 0 && !f.more_blocks()) { err = std::string("not a BCF or VCF file: ") + f.path; return false; }
+        if (!f.more_blocks()) { if (n == 0) { parse_header("", f.h); break; } err = std::string("truncated header in ") + f.path; return false; }
+        if (!stream_fill(f, 64, n_threads, err)) return false;
+    }
+    if (!f.h.version_ok) { err = std::string("invalid observation format in ") + f.path + " (calling.rs:324-339: varlociraptor_observation_format_version=15 expected)"; return false; }
+    f.field_of_key.assign(f.h.dict.size(), -1);
+    for (size_t i = 0; i < f.h.dict.size(); ++i)
+        for (int k = 0; k < FD_N; ++k)
+            if (f.h.dict[i] == kFieldName[k]) f.field_of_key[i] = (int8_t)k;
+    f.header_done = true;
+    return true;
+}
+// up to max_records records of the stream into sf (fewer only at the end of the file)
+bool stream_next(FileStream& f, int64_t max_records, int n_threads, SampleFile& sf, std::string& err) {
+    if (!f.header_done && !stream_header(f, n_threads, err)) return false;
+    std::vector<size_t> starts;
+    size_t scan = f.pos;
+    for (;;) {
+        const uint8_t* d = f.base();
+        const size_t n = f.avail();
+        if (f.is_bcf) {
+            while ((int64_t)starts.size() < max_records && scan + 8 <= n) {
+                uint32_t ls, li;
+                memcpy(&ls, d + scan, 4); memcpy(&li, d + scan + 4, 4);
+                const size_t e = scan + 8 + (size_t)ls + li;
+                if (e > n) break;
+                starts.push_back(scan);
+                scan = e;
+            }
+        } else {
+            while ((int64_t)starts.size() < max_records && scan < n) {
+                const uint8_t* nl = (const uint8_t*)memchr(d + scan, '\n', n - scan);
+                if (!nl && f.more_blocks()) break;
+                const size_t e = nl ? (size_t)(nl - d) : n;
+                if (e > scan && d[scan] != '#') starts.push_back(scan);
+                scan = nl ? e + 1 : n;
+            }
+        }
+        if ((int64_t)starts.size() >= max_records || !f.more_blocks()) break;
+        // more input needed: the window is compacted by stream_fill, so the offsets collected so far move with it
+        const size_t shift = f.pos;
+        if (!stream_fill(f, 1024, n_threads, err)) return false;
+        for (auto& x : starts) x -= shift;
+        scan -= shift;
+    }
+    if (f.is_bcf && !f.more_blocks() && (int64_t)starts.size() < max_records && scan != f.avail()) { err = std::string("truncated BCF record in ") + f.path; return false; }
+    starts.push_back(scan);
+    sf = SampleFile();
+    sf.contig_names = f.contig_names;
+    const bool ok = decode_records(f.base(), f.avail(), starts, f.is_bcf, f.field_of_key, f.contig_ids, f.contig_mu, f.path.c_str(), f.delivered, n_threads, sf, err);
+    f.contig_names = sf.contig_names;
+    f.delivered += sf.n_rec;
+    f.pos = scan;
+    return ok;
+}
+}  // namespace
+
+struct vlr_obs_reader {
+    std::vector<std::unique_ptr<FileStream>> files;
+    std::vector<std::string> paths;
+    uint32_t omit = 0;
+    int n_threads = 0;
+    bool done = false;
+};
+
+extern "C" {
+
+int vlr_obs_reader_open(int n_samples, const char* const* paths, uint32_t omit_bias_mask, int n_threads, vlr_obs_reader** out) {
+    if (!out || !paths || n_samples < 1 || n_samples > VLR_MAX_SAMPLES) return ifail(VLR_ERR_INVALID_ARGUMENT, "vlr_obs_reader_open: bad argument");
+    *out = nullptr;
+    std::unique_ptr<vlr_obs_reader> r(new vlr_obs_reader());
+    r->omit = omit_bias_mask;
+    r->n_threads = pick_threads(n_threads);
+    for (int s = 0; s < n_samples; ++s) {
+        r->paths.push_back(paths[s]);
+        r->files.emplace_back(new FileStream());
+        std::string err;
+        if (!stream_open(*r->files.back(), paths[s], r->n_threads, err)) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s", err.c_str());
+    }
+    *out = r.release();
+    return VLR_OK;
+}
+
+// The next max_records records (fewer at the end) of every file as one table; *out = NULL once the files are exhausted.
+int vlr_obs_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out) {
+    if (!r || !out || max_records < 1) return ifail(VLR_ERR_INVALID_ARGUMENT, "vlr_obs_reader_next: bad argument");
+    *out = nullptr;
+    if (r->done) return VLR_OK;
+    const int S = (int)r->files.size();
+    for (int i = 0; i < 16; ++i) g_ingest_t[i] = 0.0;
+    const double t0 = now_s();
+    std::vector<SampleFile> files((size_t)S);
+    std::vector<std::string> errs((size_t)S);
+    std::vector<char> oks((size_t)S, 0);
+    {
+        std::vector<std::thread> th;
+        const int per = std::max(1, r->n_threads / S);
+        for (int s = 0; s < S; ++s)
+            th.emplace_back([&, s] { oks[(size_t)s] = stream_next(*r->files[(size_t)s], max_records, per, files[(size_t)s], errs[(size_t)s]) ? 1 : 0; });
+        for (auto& x : th) x.join();
+    }
+    for (int s = 0; s < S; ++s)
+        if (!oks[(size_t)s]) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s", errs[(size_t)s].c_str());
+    g_ingest_t[3] = now_s() - t0;
+    if (files[0].n_rec == 0) {
+        for (int s = 1; s < S; ++s)
+            if (files[(size_t)s].n_rec != 0) return ifail(VLR_ERR_INVALID_ARGUMENT, "inconsistent observations: %s holds more records than %s (calling.rs:369-371)", r->paths[(size_t)s].c_str(), r->paths[0].c_str());
+        r->done = true;
+        return VLR_OK;
+    }
+    std::vector<const char*> pp;
+    for (auto& p : r->paths) pp.push_back(p.c_str());
+    const int rc = build_table(files, pp.data(), r->omit, r->n_threads, out);
+    g_ingest_t[6] = now_s() - t0;
+    return rc;
+}
+
+void vlr_obs_reader_close(vlr_obs_reader* r) { delete r; }
 
 }  // extern "C"
 
@@ -1425,13 +1665,72 @@ extern "C" {
 // The calls file (calling.rs:296-304 bcf::Writer, mod.rs:178-600): one record per locus of the table.  `header_text`: the VCF
 // header (## lines and #CHROM line with the sample names); out_names[n_out]: names of the columns of ln_posterior
 // ("absent", events..., "artifact").  `path` ending in ".bcf" -> BCF2 in BGZF blocks, otherwise text VCF.
+static int calls_write_impl(FILE* out_file, bool bcf, bool with_header, bool with_eof, const char* header_text, const vlr_obs_table* t, const vlr_results* r,
+                            const char* const* out_names, int n_threads);
+
 int vlr_calls_write(const char* path, const char* header_text, const vlr_obs_table* t, const vlr_results* r, const char* const* out_names, int n_threads) {
     if (!path || !header_text || !t || !r || !out_names) return ifail(VLR_ERR_INVALID_ARGUMENT, "null argument");
+    const size_t plen = strlen(path);
+    const bool bcf = plen > 4 && strcmp(path + plen - 4, ".bcf") == 0;
+    FILE* f = fopen(path, "wb");
+    if (!f) return ifail(VLR_ERR_INVALID_ARGUMENT, "cannot create %s", path);
+    int rc = calls_write_impl(f, bcf, true, true, header_text, t, r, out_names, n_threads);
+    if (fclose(f) != 0 && rc == VLR_OK) rc = ifail(VLR_ERR_INVALID_ARGUMENT, "write failed on %s", path);
+    return rc;
+}
+
+// The same file written in pieces (the streaming CLI: one append per chunk of records): header with the first append (or at close
+// if nothing was appended), BGZF end-of-file marker at close.
+struct vlr_calls_writer { FILE* f = nullptr; bool bcf = false, first = true; std::string header; };
+
+int vlr_calls_writer_open(const char* path, const char* header_text, vlr_calls_writer** out) {
+    if (!path || !header_text || !out) return ifail(VLR_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    FILE* f = fopen(path, "wb");
+    if (!f) return ifail(VLR_ERR_INVALID_ARGUMENT, "cannot create %s", path);
+    vlr_calls_writer* w = new vlr_calls_writer();
+    const size_t plen = strlen(path);
+    w->f = f; w->bcf = plen > 4 && strcmp(path + plen - 4, ".bcf") == 0; w->header = header_text;
+    *out = w;
+    return VLR_OK;
+}
+int vlr_calls_writer_append(vlr_calls_writer* w, const vlr_obs_table* t, const vlr_results* r, const char* const* out_names, int n_threads) {
+    if (!w || !w->f || !t || !r || !out_names) return ifail(VLR_ERR_INVALID_ARGUMENT, "null argument");
+    const int rc = calls_write_impl(w->f, w->bcf, w->first, false, w->header.c_str(), t, r, out_names, n_threads);
+    w->first = false;
+    return rc;
+}
+int vlr_calls_writer_close(vlr_calls_writer* w) {
+    if (!w) return VLR_OK;
+    int rc = VLR_OK;
+    if (w->f) {
+        if (w->first || w->bcf) {  // header of an empty file and / or the end-of-file member
+            vlr_obs_table* empty = nullptr;
+            (void)empty;
+            OutHeader h;
+            build_out_header(w->header, h);
+            std::vector<uint8_t> p0;
+            if (w->first) {
+                if (w->bcf) { p0.insert(p0.end(), {'B', 'C', 'F', 2, 2}); put_u32(p0, (uint32_t)h.text.size() + 1); p0.insert(p0.end(), h.text.begin(), h.text.end()); p0.push_back(0); }
+                else { std::string ht = w->header; if (ht.empty() || ht.back() != '\n') ht.push_back('\n'); p0.assign(ht.begin(), ht.end()); }
+            }
+            std::string err;
+            bool ok = true;
+            if (w->bcf) { std::vector<const std::vector<uint8_t>*> ps{&p0}; ok = write_bgzf_stream(w->f, ps, 1, 4, true, err); }
+            else if (!p0.empty()) ok = fwrite(p0.data(), 1, p0.size(), w->f) == p0.size();
+            if (!ok) rc = ifail(VLR_ERR_INVALID_ARGUMENT, "write failed");
+        }
+        if (fclose(w->f) != 0 && rc == VLR_OK) rc = ifail(VLR_ERR_INVALID_ARGUMENT, "write failed");
+    }
+    delete w;
+    return rc;
+}
+
+static int calls_write_impl(FILE* out_file, bool bcf, bool with_header, bool with_eof, const char* header_text, const vlr_obs_table* t, const vlr_results* r,
+                            const char* const* out_names, int n_threads) {
     if (r->n_loci < t->n_loci || r->n_samples != t->n_samples || !r->ln_posterior || !r->map_vaf || !r->status)
         return ifail(VLR_ERR_INVALID_ARGUMENT, "results do not match the table");
     n_threads = pick_threads(n_threads);
-    const size_t plen = strlen(path);
-    const bool bcf = plen > 4 && strcmp(path + plen - 4, ".bcf") == 0;
     const int S = t->n_samples, n_out = r->n_out;
     const int64_t L = t->n_loci;
     OutHeader h;
@@ -1460,13 +1759,13 @@ int vlr_calls_write(const char* path, const char* header_text, const vlr_obs_tab
     const int T = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, (L + 63) / 64));
     std::vector<std::vector<uint8_t>> parts((size_t)T + 1);
     std::vector<std::string> errs((size_t)T);
-    if (bcf) {
+    if (with_header && bcf) {
         auto& p0 = parts[0];
         p0.insert(p0.end(), {'B', 'C', 'F', 2, 2});
         put_u32(p0, (uint32_t)h.text.size() + 1);
         p0.insert(p0.end(), h.text.begin(), h.text.end());
         p0.push_back(0);
-    } else {
+    } else if (with_header) {
         std::string ht;  // text output carries the caller's header verbatim (no PASS line added)
         ht = header_text;
         if (ht.empty() || ht.back() != '\n') ht.push_back('\n');
@@ -1598,17 +1897,14 @@ int vlr_calls_write(const char* path, const char* header_text, const vlr_obs_tab
         std::vector<const std::vector<uint8_t>*> ps;
         for (auto& p : parts) ps.push_back(&p);
         const char* lv = getenv("VLR_BGZF_LEVEL");
-        if (!write_bgzf_file(path, ps, n_threads, lv ? atoi(lv) : 4, err)) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s", err.c_str());
+        if (!write_bgzf_stream(out_file, ps, n_threads, lv ? atoi(lv) : 4, with_eof, err)) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s", err.c_str());
         g_ingest_t[9] = now_s() - t_w0 - g_ingest_t[8];
         g_ingest_t[10] = now_s() - t_w0;
         return VLR_OK;
     }
-    FILE* f = fopen(path, "wb");
-    if (!f) return ifail(VLR_ERR_INVALID_ARGUMENT, "cannot create %s", path);
     bool ok = true;
-    for (auto& p : parts) ok = ok && fwrite(p.data(), 1, p.size(), f) == p.size();
-    ok = (fclose(f) == 0) && ok;
-    return ok ? VLR_OK : ifail(VLR_ERR_INVALID_ARGUMENT, "write failed on %s", path);
+    for (auto& p : parts) ok = ok && fwrite(p.data(), 1, p.size(), out_file) == p.size();
+    return ok ? VLR_OK : ifail(VLR_ERR_INVALID_ARGUMENT, "write failed");
 }
 
 // write_observations (preprocessing/mod.rs:921-1038) for one sample of a host batch: the observation BCF that `call variants`

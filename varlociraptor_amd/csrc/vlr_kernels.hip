@@ -2979,6 +2979,37 @@ __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, Dev
             if (same) mism = 98;
         }
     }
+    // ---- 1b. chain records that differ from the MAP in exactly one other sample (the inner chains of all outer points but the
+    // MAP's: two dozen per tumor-normal locus) contribute ONE entry, at the table's first x equal to the MAP VAF of the integrated
+    // sample.  Found here for all of them with four coalesced table loads in flight and one gather of the values, instead of three
+    // dependent memory round trips per record in the loop below.  (Tables above 64 entries or with l2fc terms take that loop.)
+    int hitq = -2;          // lane r: -2 = record r is not handled here, -1 = no such x, else its index
+    double hitv = 0.0;
+    for (int r0 = 0; r0 < nrec; r0 += 4) {
+        double xs[4];
+        bool fastr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + u;
+            fastr[u] = false; xs[u] = __builtin_nan("");
+            if (r < nrec) {
+                const int k_r = __builtin_amdgcn_readlane(kind, r), m_r = __builtin_amdgcn_readlane(mism, r);
+                const int n_r = __builtin_amdgcn_readlane(n, r), nl_r = __builtin_amdgcn_readlane(nl, r);
+                fastr[u] = k_r == 1 && m_r == 1 && n_r <= 64 && nl_r == 0;
+                if (fastr[u] && lane < n_r) xs[u] = lg[__builtin_amdgcn_readlane(at, r) + 1 + S + lane];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + u;
+            if (r < nrec && fastr[u]) {
+                const double mxr = uni_d(sh_mapv[__builtin_amdgcn_readlane(s_in, r)]);
+                const unsigned long long hit = __ballot(xs[u] == mxr);
+                if (lane == r) hitq = hit ? (int)__builtin_ctzll(hit) : -1;
+            }
+        }
+    }
+    if (hitq >= 0) hitv = lg[at + 1 + S + n + hitq];
     // ---- 2./3. records in log order
     for (int r = 0; r < nrec; ++r) {
         const int k_r = __builtin_amdgcn_readlane(kind, r), m_r = __builtin_amdgcn_readlane(mism, r);
@@ -2988,6 +3019,18 @@ __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, Dev
         c.group = __builtin_amdgcn_readlane(grp, r);
         c.disc = __builtin_amdgcn_readlane(disc, r); c.nlfc = nl_r;
         const int pay = at_r + 1 + S + 2 * nl_r;
+        {
+            const int hq = __builtin_amdgcn_readlane(hitq, r);
+            if (hq != -2) {  // handled by 1b: operands from LDS, value from the gather
+                if (hq < 0) continue;
+                __syncthreads();
+                if (lane < S) wst.ops_vaf[lane] = sh_ops[r][lane];
+                __syncthreads();
+                const double hv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(hitv), r), __builtin_amdgcn_readlane(__double2loint(hitv), r));
+                afd_consider(c, hv, sin_r, uni_d(sh_mapv[sin_r]), -1);
+                continue;
+            }
+        }
         if (k_r == 3) {  // discrete leaves of one root: n_r x (S VAFs, joint)
             const double* L = lg + at_r + 1;
             for (int q0 = 0; q0 < n_r; q0 += 64) {

@@ -130,12 +130,88 @@ def read_observations(paths: Sequence[str], omit_bias_mask: int = 0, threads: in
     arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
     h = C.c_void_p()
     _check(_lib().vlr_obs_read(len(paths), arr, int(omit_bias_mask), int(threads), C.byref(h)))
+    return _wrap_table(h)
+
+
+def _wrap_table(h):
     table = ObsTable(h)
     batch = table.batch()
     sites = Sites(table)
     batch.extra = {"third_allele_evidence": sites.third_allele_evidence, "group_representative": sites.group_representative,
                    "prior_het_ln": sites.heterozygosity_ln, "prior_som_ln": sites.somatic_effective_mutation_rate_ln, "native_table": table}
     return batch, sites
+
+
+class ObsReader:
+    """vlr_obs_reader: the observation files a bounded number of records at a time.  Iterating yields (PileupBatch, Sites)."""
+
+    def __init__(self, paths: Sequence[str], omit_bias_mask: int = 0, threads: int = 0, chunk_records: int = 250_000):
+        L = _lib()
+        L.vlr_obs_reader_open.restype = C.c_int
+        L.vlr_obs_reader_open.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
+        L.vlr_obs_reader_next.restype = C.c_int
+        L.vlr_obs_reader_next.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
+        L.vlr_obs_reader_close.restype = None
+        L.vlr_obs_reader_close.argtypes = [C.c_void_p]
+        arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+        h = C.c_void_p()
+        _check(L.vlr_obs_reader_open(len(paths), arr, int(omit_bias_mask), int(threads), C.byref(h)))
+        self._h, self.chunk_records = h, int(chunk_records)
+
+    def next(self, max_records: Optional[int] = None):
+        h = C.c_void_p()
+        _check(_lib().vlr_obs_reader_next(self._h, int(max_records or self.chunk_records), C.byref(h)))
+        return _wrap_table(h) if h.value else None
+
+    def __iter__(self):
+        while True:
+            item = self.next()
+            if item is None:
+                return
+            yield item
+
+    def close(self):
+        if self._h:
+            _lib().vlr_obs_reader_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CallsWriter:
+    """vlr_calls_writer: the calls file written one chunk of records at a time."""
+
+    def __init__(self, path: str, header_text: str):
+        L = _lib()
+        L.vlr_calls_writer_open.restype = C.c_int
+        L.vlr_calls_writer_open.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+        L.vlr_calls_writer_append.restype = C.c_int
+        L.vlr_calls_writer_append.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.Results), C.POINTER(C.c_char_p), C.c_int]
+        L.vlr_calls_writer_close.restype = C.c_int
+        L.vlr_calls_writer_close.argtypes = [C.c_void_p]
+        h = C.c_void_p()
+        _check(L.vlr_calls_writer_open(path.encode(), header_text.encode(), C.byref(h)))
+        self._h = h
+
+    def append(self, table: ObsTable, results: CallResults, out_names: List[str], threads: int = 0):
+        rs = results.as_struct()
+        names = (C.c_char_p * len(out_names))(*[n.encode() for n in out_names])
+        _check(_lib().vlr_calls_writer_append(self._h, table.handle, C.byref(rs), names, int(threads)))
+
+    def close(self):
+        if self._h:
+            h, self._h = self._h, None
+            _check(_lib().vlr_calls_writer_close(h))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 def write_observations(path: str, batch: PileupBatch, sample: int, threads: int = 0, third_allele_evidence: Optional[np.ndarray] = None):
