@@ -290,7 +290,7 @@ def bench_cli(args, rank, world, local_rank, dev):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "cli: tumor-normal 100x (config3 pileups), %d records/GPU in two observation BCFs (format v15, BGZF), AFD lists of %d entries, calls written as BCF" % (n_loci, args.afd_capacity),
                    "parallelism": "records sharded x%d, one process per GPU" % world, "host_threads": os.cpu_count(), "effective_cpus": effective_cpus()},
-        "stages_s": per,
+        "stages_s": per, "stages_note": "seconds per step inside the reader / evaluation / writer threads of cli.call_variants; the three overlap across chunks of %s records (%d chunks per step), so their sum exceeds ms_per_step" % (os.environ.get("VLR_CLI_CHUNK", "16384"), tm.get("chunks", 1)),
         "stage_rates": {"read_records_per_s": n_loci / per["read_s"], "read_uncompressed_GBps": None, "call_loci_per_s": n_loci / per["call_s"], "write_records_per_s": n_loci / per["write_s"]},
         "native_stage_seconds_last_step": ingest.last_timings(),
         "files": {"observation_bcf_bytes": obs_bytes, "calls_bcf_bytes": calls_bytes, "observations": int(n_obs), "observation_write_s_untimed": t_write_obs},

@@ -139,36 +139,9 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
         scen.clear()
     import numpy as np
     import os
-    from .batch import CallResults
     import time
+    from .batch import CallResults
     native = (ingest or os.environ.get("VLR_INGEST", "native")) == "native"
-    t_begin = time.perf_counter()
-    if native:
-        # product path: BGZF inflate, BCF/VCF parse and the v15 decoder in native code (csrc/vlr_ingest.cpp)
-        from . import ingest as vingest
-        batch, sites = vingest.read_observations(paths, omit_bias_mask=omit_mask)
-        contig_names = list(sites.contig_names)
-        contig_of = np.asarray(sites.contig, np.int64)
-        het, som = batch.extra["prior_het_ln"], batch.extra["prior_som_ln"]
-        group_rep = np.asarray(batch.extra["group_representative"], np.int64)
-    else:
-        # the Python restatement of the same decoder (obsfmt.py / bcfio.py); the tests compare the two
-        batch, sites = obsfmt.read_observation_vcf(paths, omit_bias_mask=omit_mask)
-        contig_names = sorted(set(s_[0] for s_ in sites))
-        cidx = {c: i for i, c in enumerate(contig_names)}
-        contig_of = np.array([cidx[s_[0]] for s_ in sites], np.int64)
-        pri = batch.extra.get("prior_overrides") or []
-        het = np.array([np.nan if p_[0] is None else p_[0] for p_ in pri], np.float64)
-        som = np.array([np.nan if p_[1] is None else p_[1] for p_ in pri], np.float64)
-        reps_, source_ = obsfmt.haplotype_groups(batch.extra.get("haplotype") or [None] * batch.n_loci)
-        group_rep = np.asarray(reps_, np.int64)[np.asarray(source_, np.int64)] if batch.n_loci else np.zeros(0, np.int64)
-    L = batch.n_loci
-    t_read = time.perf_counter()
-    modes = model_modes(batch.locus["locus_flags"]) if L else np.zeros(0, np.int64)
-    key = contig_of * 256 + modes  # (contig, model mode): one model, one `last_rid`, one variant-specific prior (calling.rs:413-443)
-    for k_, first in zip(*np.unique(key, return_index=True)):
-        first_of_contig[(contig_names[int(k_) // 256] if contig_names else "all", int(k_) % 256)] = (
-            None if het[first] != het[first] else float(het[first]), None if som[first] != som[first] else float(som[first]))
     world, rank = 1, 0
     try:
         import torch.distributed as tdist
@@ -176,110 +149,254 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
             world, rank = tdist.get_world_size(), tdist.get_rank()
     except ImportError:
         pass
-    # breakends of one event share a pileup and a result: evaluate the first record of every event only and copy its
-    # event probabilities / sample info to the others (calling.rs:569-580, 726-741, 820-839)
-    reps = np.nonzero(group_rep == np.arange(L))[0]
-    groups: Dict[tuple, List] = {}
-    sig_scenario: Dict[tuple, Scenario] = {}
-    for k_ in np.unique(key[reps]) if len(reps) else []:
-        sc = resolve(contig_names[int(k_) // 256] if contig_names else "all", int(k_) % 256)
-        sig = _scenario_signature(sc)
-        sig_scenario.setdefault(sig, sc)
-        groups.setdefault(sig, []).append(reps[key[reps] == k_])
-    res = None
-    names = None
-    for sig, parts in groups.items():
-        loci = np.sort(np.concatenate(parts))
-        sc = sig_scenario[sig]
-        if world > 1:
-            # loci shard across the ranks (one process per GPU); the results are reassembled by one all-gather of
-            # fixed-size records (+ one for the AFD lists), every rank ends up with the full result
-            from . import dist as vdist
-            lo, hi = vdist.shard_range(len(loci), rank, world)
-            mine = loci[lo:hi]
-            n_out_, S_ = sc.n_out, len(sc.sample_names)
-            if len(mine):
-                plan = engine.Plan(sc, device=device)
-                sub = batch.select(mine)
-                plan.set_max_obs(min(max(int(sub.depth().sum(axis=1).max()), 1), engine.MAX_OBS_LDS))
-                rl = plan.call_host(sub, afd_capacity=afd_capacity)
-                plan.close()
-            else:
-                rl = CallResults(0, n_out_, S_, afd_capacity)
-            r = vdist.gather_call_results(rl, lo, hi, len(loci), n_out_, S_, afd_capacity)
-        else:
-            plan = engine.Plan(sc, device=device)
-            sub = batch if len(loci) == L else batch.select(loci)
-            # observation files are already capped by preprocess's --max-depth: size the LDS budget to the deepest record
-            deepest = int(sub.depth().sum(axis=1).max()) if sub.n_loci else 1
-            plan.set_max_obs(min(max(deepest, 1), engine.MAX_OBS_LDS))  # deeper records come back flagged VLR_LOCUS_TOO_DEEP
-            r = plan.call_host(sub, afd_capacity=afd_capacity)
-            plan.close()
-        if names is None:
-            names = sc.out_names()
-        if len(loci) == L:
-            res = r
-            break
-        if res is None:
-            res = CallResults(L, r.n_out, r.n_samples, afd_capacity)
-        for f in ("ln_posterior", "ln_marginal", "map_vaf", "map_bias", "best_event", "status", "afd_count", "afd_vaf", "afd_lnprob"):
-            a = getattr(res, f)
-            if a is not None:
-                a[loci] = getattr(r, f)
-    if res is not None and len(reps) < L:  # fan the group results out to every record of the group
-        for f in ("ln_posterior", "ln_marginal", "map_vaf", "map_bias", "best_event", "status", "afd_count", "afd_vaf", "afd_lnprob"):
-            a = getattr(res, f)
-            if a is not None:
-                a[:] = a[group_rep]
-    if res is not None and rank == 0:
-        # the reference panics on NaN (assert!(!p.is_nan())) and has no depth limit: say so instead of writing `.` silently
-        hard = res.status & (abi.LOCUS_NAN | abi.LOCUS_UNDERFLOW | abi.LOCUS_TABLE_FULL | abi.LOCUS_TOO_DEEP)
-        for bit, what in ((abi.LOCUS_NAN, "a likelihood became NaN"), (abi.LOCUS_UNDERFLOW, "an observation likelihood is outside the f64 range"),
-                          (abi.LOCUS_TABLE_FULL, "visited-point table overflow"), (abi.LOCUS_TOO_DEEP, "pileup above the LDS budget of %d observations" % engine.MAX_OBS_LDS)):
-            n_bad = int(((hard & bit) != 0).sum())
-            if n_bad:
-                print("warning: %d record(s) without a result: %s" % (n_bad, what), file=sys.stderr)
-    t_call = time.perf_counter()
+    plans: Dict[tuple, "engine.Plan"] = {}   # one plan per scenario signature, kept across the chunks of a run
+    FIELDS = ("ln_posterior", "ln_marginal", "map_vaf", "map_bias", "best_event", "status", "afd_count", "afd_vaf", "afd_lnprob")
 
-    def _done():
-        if timings is not None:
-            t_end = time.perf_counter()
-            timings.update({"read_s": t_read - t_begin, "call_s": t_call - t_read, "write_s": t_end - t_call, "n_loci": L, "n_obs": batch.n_obs})
-    scenario0 = resolve(contig_names[int(contig_of[0])] if L else "all")
-    header = callsfmt.header(names or scenario0.out_names(), scenario0.sample_names, sorted(set(contig_names[int(c_)] for c_ in np.unique(contig_of))) if L else [])
-    if rank != 0:
-        return res
-    names = names or scenario0.out_names()
-    if native and res is not None:
-        # the calls file from native code too (vlr_calls_write): BCF2 in BGZF blocks or text VCF
+    def evaluate(batch, contig_names, contig_of, het, som, group_rep):
+        """Results of one batch of records (the whole file, or one chunk of the streaming reader)."""
+        L = batch.n_loci
+        modes = model_modes(batch.locus["locus_flags"]) if L else np.zeros(0, np.int64)
+        key = contig_of * 256 + modes  # (contig, model mode): one model, one `last_rid`, one variant-specific prior (calling.rs:413-443)
+        for k_, first in zip(*np.unique(key, return_index=True)):
+            first_of_contig.setdefault((contig_names[int(k_) // 256] if contig_names else "all", int(k_) % 256), (
+                None if het[first] != het[first] else float(het[first]), None if som[first] != som[first] else float(som[first])))
+        # breakends of one event share a pileup and a result: evaluate the first record of every event only and copy its
+        # event probabilities / sample info to the others (calling.rs:569-580, 726-741, 820-839)
+        reps = np.nonzero(group_rep == np.arange(L))[0]
+        groups: Dict[tuple, List] = {}
+        sig_scenario: Dict[tuple, Scenario] = {}
+        for k_ in np.unique(key[reps]) if len(reps) else []:
+            sc = resolve(contig_names[int(k_) // 256] if contig_names else "all", int(k_) % 256)
+            sig = _scenario_signature(sc)
+            sig_scenario.setdefault(sig, sc)
+            groups.setdefault(sig, []).append(reps[key[reps] == k_])
+        res, names = None, None
+        for sig, parts in groups.items():
+            loci = np.sort(np.concatenate(parts))
+            sc = sig_scenario[sig]
+            n_out_, S_ = sc.n_out, len(sc.sample_names)
+            if world > 1:
+                # loci shard across the ranks (one process per GPU); the results are reassembled by one all-gather of
+                # fixed-size records (+ one for the AFD lists), every rank ends up with the full result
+                from . import dist as vdist
+                lo, hi = vdist.shard_range(len(loci), rank, world)
+                mine = loci[lo:hi]
+            else:
+                lo, hi, mine = 0, len(loci), loci
+            if len(mine):
+                if sig not in plans:
+                    plans[sig] = engine.Plan(sc, device=device)
+                plan = plans[sig]
+                sub = batch if len(mine) == L else batch.select(mine)
+                # observation files are already capped by preprocess's --max-depth: size the LDS budget to the deepest record
+                # (deeper records than the LDS holds take the deep launch)
+                plan.set_max_obs(min(max(int(sub.depth().sum(axis=1).max()), 1), engine.MAX_OBS_LDS))
+                r = plan.call_host(sub, afd_capacity=afd_capacity)
+            else:
+                r = CallResults(0, n_out_, S_, afd_capacity)
+            if world > 1:
+                from . import dist as vdist
+                r = vdist.gather_call_results(r, lo, hi, len(loci), n_out_, S_, afd_capacity)
+            if names is None:
+                names = sc.out_names()
+            if len(loci) == L:
+                res = r
+                break
+            if res is None:
+                res = CallResults(L, r.n_out, r.n_samples, afd_capacity)
+            for f in FIELDS:
+                a = getattr(res, f)
+                if a is not None:
+                    a[loci] = getattr(r, f)
+        if res is not None and len(reps) < L:  # fan the group results out to every record of the group
+            for f in FIELDS:
+                a = getattr(res, f)
+                if a is not None:
+                    a[:] = a[group_rep]
+        if res is not None and rank == 0:
+            # the reference panics on NaN (assert!(!p.is_nan())): say so instead of writing `.` silently
+            hard = res.status & (abi.LOCUS_NAN | abi.LOCUS_UNDERFLOW | abi.LOCUS_TABLE_FULL | abi.LOCUS_TOO_DEEP)
+            for bit, what in ((abi.LOCUS_NAN, "a likelihood became NaN"), (abi.LOCUS_UNDERFLOW, "an observation likelihood is outside the f64 range"),
+                              (abi.LOCUS_TABLE_FULL, "visited-point table overflow"), (abi.LOCUS_TOO_DEEP, "pileup above the LDS budget and the deep pool")):
+                n_bad = int(((hard & bit) != 0).sum())
+                if n_bad:
+                    print("warning: %d record(s) without a result: %s" % (n_bad, what), file=sys.stderr)
+        return res, names
+
+    def close_plans():
+        for p_ in plans.values():
+            p_.close()
+        plans.clear()
+
+    def header_for(names, contigs):
+        scenario0 = resolve(contigs[0] if contigs else "all")
+        return callsfmt.header(names or scenario0.out_names(), scenario0.sample_names, sorted(set(contigs))), scenario0
+
+    t_begin = time.perf_counter()
+    if native:
+        # product path: BGZF inflate, BCF/VCF parse, the v15 decoder and the calls writer in native code (csrc/vlr_ingest.cpp), a
+        # bounded number of records at a time; reader, evaluation and writer of consecutive chunks overlap (three threads: the
+        # native calls release the GIL)
+        import queue
+        import threading
         from . import ingest as vingest
-        table = batch.extra["native_table"]
-        if output:
-            vingest.write_calls(output, header, table, res, list(names))
-        else:
-            import tempfile
-            with tempfile.TemporaryDirectory() as td:
-                tmp = os.path.join(td, "calls.vcf")
-                vingest.write_calls(tmp, header, table, res, list(names))
-                with open(tmp) as fh:
-                    out.write(fh.read())
-        _done()
+        is_text = any(not (p_.endswith(".bcf") or p_.endswith(".bcf.gz")) for p_ in paths)
+        chunk = int(os.environ.get("VLR_CLI_CHUNK", "0")) or (1 << 62 if is_text else 16384)  # text VCF: contigs are only known at the end
+        reader = vingest.ObsReader(paths, omit_bias_mask=omit_mask, chunk_records=chunk)
+        q_in: "queue.Queue" = queue.Queue(maxsize=2)
+        q_out: "queue.Queue" = queue.Queue(maxsize=2)
+        stage = {"read_s": 0.0, "call_s": 0.0, "write_s": 0.0, "n_loci": 0, "n_obs": 0}
+        errors: List[BaseException] = []
+
+        stop = threading.Event()
+
+        def read_loop():
+            try:
+                while not stop.is_set():
+                    t0 = time.perf_counter()
+                    item = reader.next()
+                    stage["read_s"] += time.perf_counter() - t0
+                    while not stop.is_set():
+                        try:
+                            q_in.put(item, timeout=0.2)
+                            break
+                        except queue.Full:
+                            pass
+                    if item is None:
+                        return
+            except BaseException as ex:  # noqa: BLE001 (handed to the main thread)
+                errors.append(ex)
+                q_in.put(None)
+
+        writer_state = {"w": None, "tmp": None}
+
+        def write_loop():
+            try:
+                while True:
+                    item = q_out.get()
+                    if item is None:
+                        return
+                    table, res_, names_, contigs_ = item
+                    t0 = time.perf_counter()
+                    if writer_state["w"] is None:
+                        hdr, _ = header_for(names_, contigs_)
+                        target = output
+                        if not target:
+                            import tempfile
+                            writer_state["tmp"] = tempfile.TemporaryDirectory()
+                            target = os.path.join(writer_state["tmp"].name, "calls.vcf")
+                        writer_state["w"] = vingest.CallsWriter(target, hdr)
+                        writer_state["path"] = target
+                    writer_state["w"].append(table, res_, list(names_))
+                    stage["write_s"] += time.perf_counter() - t0
+            except BaseException as ex:  # noqa: BLE001
+                errors.append(ex)
+                while q_out.get() is not None:
+                    pass
+
+        tr = threading.Thread(target=read_loop, daemon=True)
+        tw = threading.Thread(target=write_loop, daemon=True) if rank == 0 else None
+        tr.start()
+        if tw:
+            tw.start()
+        collected = []
+        names = None
+        used_contigs: List[str] = []
+        try:
+            while True:
+                item = q_in.get()
+                if item is None or errors:
+                    break
+                batch, sites = item
+                t0 = time.perf_counter()
+                contig_names = list(sites.contig_names)
+                res, nm = evaluate(batch, contig_names, np.asarray(sites.contig, np.int64), batch.extra["prior_het_ln"], batch.extra["prior_som_ln"],
+                                   np.asarray(batch.extra["group_representative"], np.int64))
+                names = names or nm
+                stage["call_s"] += time.perf_counter() - t0
+                stage["n_loci"] += batch.n_loci
+                stage["n_obs"] += batch.n_obs
+                if not used_contigs:
+                    used_contigs = contig_names if not is_text else [contig_names[int(c_)] for c_ in np.unique(np.asarray(sites.contig))]
+                collected.append(res)
+                if tw and res is not None:
+                    q_out.put((batch.extra["native_table"], res, names, used_contigs))
+        finally:
+            if tw:
+                q_out.put(None)
+                tw.join()
+            stop.set()
+            tr.join()
+            reader.close()
+            close_plans()
+        if errors:
+            raise errors[0]
+        if rank == 0:
+            if writer_state["w"] is None:  # no records at all: the header alone
+                hdr, _ = header_for(names, used_contigs)
+                if output:
+                    vingest.CallsWriter(output, hdr).close()
+                else:
+                    print(hdr, file=out)
+            else:
+                writer_state["w"].close()
+                if not output:
+                    with open(writer_state["path"]) as fh:
+                        out.write(fh.read())
+                    writer_state["tmp"].cleanup()
+        if timings is not None:
+            timings.update(dict(stage, wall_s=time.perf_counter() - t_begin, chunks=len(collected)))
+        collected = [r_ for r_ in collected if r_ is not None]
+        if len(collected) == 1:
+            return collected[0]
+        if not collected:
+            return None
+        # several chunks: the fixed-size fields concatenated (the AFD lists went to the file chunk by chunk)
+        tot = CallResults(sum(r_.n_loci for r_ in collected), collected[0].n_out, collected[0].n_samples, 0)
+        o = 0
+        for r_ in collected:
+            for f in FIELDS[:6]:
+                getattr(tot, f)[o:o + r_.n_loci] = getattr(r_, f)
+            o += r_.n_loci
+        return tot
+
+    # the Python restatement of the same decoder and formatter (obsfmt.py / bcfio.py / callsfmt.py); the tests compare the two
+    batch, sites = obsfmt.read_observation_vcf(paths, omit_bias_mask=omit_mask)
+    contig_names = sorted(set(s_[0] for s_ in sites))
+    cidx = {c: i for i, c in enumerate(contig_names)}
+    contig_of = np.array([cidx[s_[0]] for s_ in sites], np.int64)
+    pri = batch.extra.get("prior_overrides") or []
+    het = np.array([np.nan if p_[0] is None else p_[0] for p_ in pri], np.float64)
+    som = np.array([np.nan if p_[1] is None else p_[1] for p_ in pri], np.float64)
+    reps_, source_ = obsfmt.haplotype_groups(batch.extra.get("haplotype") or [None] * batch.n_loci)
+    group_rep = np.asarray(reps_, np.int64)[np.asarray(source_, np.int64)] if batch.n_loci else np.zeros(0, np.int64)
+    L = batch.n_loci
+    t_read = time.perf_counter()
+    try:
+        res, names = evaluate(batch, contig_names, contig_of, het, som, group_rep)
+    finally:
+        close_plans()
+    t_call = time.perf_counter()
+    header, scenario0 = header_for(names, contig_names if L else [])
+    names = names or scenario0.out_names()
+    if rank != 0:
         return res
     if output and output.endswith(".bcf"):  # binary calls file (reference: bcf::Writer, calling.rs:296-304)
         from .bcfio import BcfWriter
         with BcfWriter(output, header) as wr:
             for l in range(L):
                 wr.write_line(callsfmt.format_record(sites[l], batch, res, l, names, scenario0.sample_names))
-        _done()
-        return res
-    if output:
-        out = open(output, "w")
-    print(header, file=out)
-    for l in range(L):
-        print(callsfmt.format_record(sites[l], batch, res, l, names, scenario0.sample_names), file=out)
-    if output:
-        out.close()
-    _done()
+    else:
+        if output:
+            out = open(output, "w")
+        print(header, file=out)
+        for l in range(L):
+            print(callsfmt.format_record(sites[l], batch, res, l, names, scenario0.sample_names), file=out)
+        if output:
+            out.close()
+    if timings is not None:
+        t_end = time.perf_counter()
+        timings.update({"read_s": t_read - t_begin, "call_s": t_call - t_read, "write_s": t_end - t_call, "n_loci": L, "n_obs": batch.n_obs, "wall_s": t_end - t_begin, "chunks": 1})
     return res
 
 

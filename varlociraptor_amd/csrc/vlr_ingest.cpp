@@ -1254,7 +1254,8 @@ struct FileStream {
     Blob raw;                          // the mapped file
     std::vector<BgzfBlock> blocks;     // BGZF members (empty: other containers — everything is inflated at open)
     size_t next_block = 0;
-    std::vector<uint8_t> win;          // inflated, not yet delivered bytes (BGZF) ...
+    RawVec<uint8_t> win;               // inflated, not yet delivered bytes (BGZF): uninitialised, 2 MB pages ...
+    double bytes_per_record = 32768.0; // running estimate: how many blocks a request for max_records needs
     Blob whole;                        // ... or the whole inflated file
     size_t pos = 0;                    // first undelivered byte of win / whole
     bool use_whole = false, is_bcf = false, header_done = false;
@@ -1264,8 +1265,8 @@ struct FileStream {
     std::unordered_map<std::string, int> contig_ids;
     std::mutex contig_mu;
     int64_t delivered = 0;
-    const uint8_t* base() const { return use_whole ? whole.p : win.data(); }
-    size_t avail() const { return use_whole ? whole.n : win.size(); }
+    const uint8_t* base() const { return use_whole ? whole.p : win.p; }
+    size_t avail() const { return use_whole ? whole.n : win.n; }
     bool more_blocks() const { return !use_whole && next_block < blocks.size(); }
 };
 
@@ -1283,17 +1284,21 @@ bool stream_open(FileStream& f, const char* path, int n_threads, std::string& er
 }
 // inflate the next `count` blocks behind the undelivered bytes of the window
 bool stream_fill(FileStream& f, size_t count, int n_threads, std::string& err) {
-    if (f.pos > 0) { f.win.erase(f.win.begin(), f.win.begin() + (long)f.pos); f.pos = 0; }
+    if (f.pos > 0) {  // drop what was delivered: the undelivered tail moves to the front
+        const size_t keep = f.win.n - f.pos;
+        if (keep) memmove(f.win.p, f.win.p + f.pos, keep);
+        f.win.n = keep; f.pos = 0;
+    }
     const size_t b0 = f.next_block, b1 = std::min(f.blocks.size(), b0 + count);
     size_t add = 0;
     std::vector<size_t> off(b1 - b0);
     for (size_t b = b0; b < b1; ++b) { off[b - b0] = add; add += f.blocks[b].isize; }
-    const size_t old = f.win.size();
+    const size_t old = f.win.n;
     f.win.resize(old + add);
     std::atomic<bool> bad{false};
     parallel_items((int64_t)(b1 - b0), n_threads, [&](int64_t i, int) {
         const BgzfBlock& b = f.blocks[b0 + (size_t)i];
-        if (b.isize && !inflate_raw(f.raw.p + b.off, b.clen, f.win.data() + old + off[(size_t)i], b.isize)) bad = true;
+        if (b.isize && !inflate_raw(f.raw.p + b.off, b.clen, f.win.p + old + off[(size_t)i], b.isize)) bad = true;
     });
     f.next_block = b1;
     if (bad) { err = std::string("corrupt BGZF block in ") + f.path; return false; }
@@ -1367,9 +1372,12 @@ bool stream_next(FileStream& f, int64_t max_records, int n_threads, SampleFile& 
             }
         }
         if ((int64_t)starts.size() >= max_records || !f.more_blocks()) break;
-        // more input needed: the window is compacted by stream_fill, so the offsets collected so far move with it
+        // more input needed: as many blocks as the missing records are expected to take (one round for a typical request); the
+        // window is compacted by stream_fill, so the offsets collected so far move with it
         const size_t shift = f.pos;
-        if (!stream_fill(f, 1024, n_threads, err)) return false;
+        const double missing = (double)(max_records - (int64_t)starts.size());
+        const size_t blocks_needed = (size_t)std::min(1e9, std::max(64.0, missing * f.bytes_per_record * 1.05 / 65280.0 + 8.0));
+        if (!stream_fill(f, blocks_needed, n_threads, err)) return false;
         for (auto& x : starts) x -= shift;
         scan -= shift;
     }
@@ -1380,6 +1388,7 @@ bool stream_next(FileStream& f, int64_t max_records, int n_threads, SampleFile& 
     const bool ok = decode_records(f.base(), f.avail(), starts, f.is_bcf, f.field_of_key, f.contig_ids, f.contig_mu, f.path.c_str(), f.delivered, n_threads, sf, err);
     f.contig_names = sf.contig_names;
     f.delivered += sf.n_rec;
+    if (sf.n_rec > 0) f.bytes_per_record = 0.5 * f.bytes_per_record + 0.5 * (double)(scan - f.pos) / (double)sf.n_rec;
     f.pos = scan;
     return ok;
 }

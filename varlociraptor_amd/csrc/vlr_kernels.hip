@@ -3200,16 +3200,23 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
         int sbias_alb_noloci = 0;
         double mx_all = VLR_NEG_INF, mx_major = VLR_NEG_INF, mx_rate = VLR_NEG_INF;
         for (int h = 0; h < kNHyp; ++h) sbias[h] = 0;
+        // all columns this pass needs in one round of loads (none waits for another), and the rows of the NEXT 64 observations are
+        // requested before this iteration's arithmetic starts
+        struct RowA { float pm, pa, pr, psa, phb; uint32_t f; };
+        auto load_a = [&](uint32_t i) {
+            RowA r{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0u};
+            if (i < o1) { r.pm = batch.pm[i]; r.pa = batch.pa[i]; r.pr = batch.pr[i]; r.f = batch.flags[i]; r.psa = batch.psa[i]; r.phb = batch.phb[i]; }
+            return r;
+        };
+        RowA nxa = load_a(o0 + lane);
         for (uint32_t base = o0; base < o1; base += 64) {
             uint32_t i = base + lane;
             bool valid = i < o1;
-            double pm = 0, pa = 0, pr = 0;
-            float psa_f = 0.0f, phb_f = 0.0f;
-            uint32_t f = 0;
-            if (valid) {  // all columns this pass needs in one round of loads (none waits for another)
-                pm = batch.pm[i]; pa = batch.pa[i]; pr = batch.pr[i];
-                f = batch.flags[i]; psa_f = batch.psa[i]; phb_f = batch.phb[i];
-            }
+            const RowA cua = nxa;
+            if (base + 64 < o1) nxa = load_a(i + 64);
+            double pm = cua.pm, pa = cua.pa, pr = cua.pr;
+            float psa_f = cua.psa, phb_f = cua.phb;
+            uint32_t f = cua.f;
             bool keep = valid && !(remove_nonstd && f_orient(f) == VLR_ORIENT_OTHER);  // pileup.rs:26-43
             filtered += popc64(__ballot(valid && !keep));
             if (__ballot(keep && psa_f != 0.0f)) ehas_mask |= 1 << s;  // s = e^psa != 1: third coefficient e != 0
@@ -3286,12 +3293,20 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
         const uint32_t o0 = batch.obs_offset[pidx], o1 = batch.obs_offset[pidx + 1];
         const double m_all = uni_d(w->pos_all[s]), m_major = uni_d(w->pos_major[s]), m_rate = uni_d(w->pos_rate[s]);
         DdAcc pa_all{{0.0, 0.0}}, pa_major{{0.0, 0.0}}, pa_rate{{0.0, 0.0}};
+        struct RowB { float pm, pa, pr, phb; uint32_t f; };
+        auto load_b = [&](uint32_t i) {
+            RowB r{0.0f, 0.0f, 0.0f, 0.0f, 0u};
+            if (i < o1) { r.pm = batch.pm[i]; r.pa = batch.pa[i]; r.pr = batch.pr[i]; r.phb = batch.phb[i]; r.f = batch.flags[i]; }
+            return r;
+        };
+        RowB nxb = load_b(o0 + lane);
         for (uint32_t base = o0; base < o1; base += 64) {
             uint32_t i = base + lane;
             bool valid = i < o1;
-            double pm = 0, pa = 0, pr = 0, phb = 0;
-            uint32_t f = 0;
-            if (valid) { pm = batch.pm[i]; pa = batch.pa[i]; pr = batch.pr[i]; phb = batch.phb[i]; f = batch.flags[i]; }
+            const RowB cub = nxb;
+            if (base + 64 < o1) nxb = load_b(i + 64);
+            double pm = cub.pm, pa = cub.pa, pr = cub.pr, phb = cub.phb;
+            uint32_t f = cub.f;
             bool keep = valid && !(remove_nonstd && f_orient(f) == VLR_ORIENT_OTHER);
             bool strong_ref = keep && exp(pr - pa) > 20.0;
             int strand = f_strand(f);
