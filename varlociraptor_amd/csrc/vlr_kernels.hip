@@ -1782,20 +1782,64 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
         const double c0 = a[0], q0 = a[1];
         cc[j] = i < D ? c0 : 1.0; cq[j] = i < D ? q0 : 0.0;
     }
-    const double sstep = simpson_n ? (hi - lo) / (double)(simpson_n - 1) : 0.0;
-    double px0 = lo, px1 = simpson_n ? lin_pt(lo, sstep, 1.0) : hi, px2 = simpson_n == 3 ? hi : simpson_n ? lin_pt(lo, sstep, 2.0) : hi;
-    int npp = simpson_n ? 3 : 2, k = 0, tn = 0;
-    int phase = simpson_n ? RP_SIMPSON : RP_INIT;
-    bool done = !q.rowon, failed = false, sawnan = false, have_first = false;
+    // The rows of a batch run the same PHASE at the same time (wave-uniform `up`, scalar branches): Simpson grids first (rare),
+    // then INIT, the ROUNDs while any row's bracket is still wider than its resolution (rows that are through wait: the tail has the
+    // same length for every row, so the slowest row sets the pass count either way), then the three TAIL passes.  Only the bracket
+    // update of a ROUND needs per-row selects.
+    enum { UP_SIMPSON = 0, UP_INIT = 1, UP_ROUND = 2, UP_TAIL = 3 };
+    bool live = q.rowon;                        // the row has not run out of table space
+    const bool simp = simpson_n != 0;           // per row
+    bool act = !simp;                           // the row's search goes on (ROUND)
+    const unsigned long long any_simp = __ballot(live && simp), any_norm = __ballot(live && !simp);
+    int up = any_simp ? UP_SIMPSON : UP_INIT;
+    const int kmax = any_simp ? max(max(__builtin_amdgcn_readlane(simpson_n, 0), __builtin_amdgcn_readlane(simpson_n, 16)),
+                                    max(__builtin_amdgcn_readlane(simpson_n, 32), __builtin_amdgcn_readlane(simpson_n, 48))) : 0;
+    const double sstep = simp ? (hi - lo) / (double)(simpson_n - 1) : 0.0;
+    int k = 0, tn = 0;
+    bool failed = false, sawnan = false, first = true;
     double L = lo, R = hi, vL = VLR_NEG_INF, vR = VLR_NEG_INF, mid = lo, first_mid = lo;
     PROF_ADD(c, 7);  // batch prologue (task fields, coefficient registers)
-    while (__ballot(!done)) {
+    for (;;) {
         PROF_ADD(c, 15);
-        const int rl = fresh_lane(rl0);  // lane masks (rl == 1, rl < npp, ...) are recomputed: one compare each instead of two lane reads of a spilled pair
-        const bool over = !done && (tn + npp > q.cap);
+        const int rl = fresh_lane(rl0);  // lane masks (rl == 1, rl < nn, ...) are recomputed: one compare each instead of two lane reads of a spilled pair
+        double px0, px1, px2;
+        int nn;
+        bool on;
+        if (up == UP_ROUND) {
+            on = live && act;
+            px0 = (R + L) / 2.0; px1 = (px0 + L) / 2.0; px2 = (R + px0) / 2.0; nn = 3;
+            mid = on ? px0 : mid;
+            if (first) first_mid = px0;
+            first = false;
+        } else if (up == UP_TAIL) {
+            // abandoned arm (95-106) + small interval around the optimum (107-131)
+            on = live && !simp;
+            const double arm = (mid < first_mid) ? (hi + first_mid) / 2.0 : (first_mid + lo) / 2.0;
+            const double lo3 = fmax(mid - res * 3.0, lo);
+            const double hi3 = fmin(mid + res * 3.0, hi);
+            const double sa = div3(mid - lo3), sb = div3(hi3 - mid);  // itertools_num::linspace step, n = 4
+            px0 = k == 0 ? arm : k == 3 ? lin_pt(lo3, sa, 2.0) : lin_pt(mid, sb, 3.0);
+            px1 = k == 0 ? lin_pt(lo3, sa, 0.0) : lin_pt(mid, sb, 1.0);
+            px2 = k == 0 ? lin_pt(lo3, sa, 1.0) : lin_pt(mid, sb, 2.0);
+            nn = k == 6 ? 1 : 3;
+            px1 = nn < 2 ? px0 : px1; px2 = nn < 2 ? px0 : px2;
+        } else if (up == UP_INIT) {
+            on = live && !simp;
+            px0 = lo; px1 = hi; px2 = hi; nn = 2;
+        } else {  // Simpson grid (modes/generic.rs:367-385): points k, k+1, k+2 of linspace(lo, hi, n) with exact end points
+            const int left = simpson_n - k;
+            on = live && simp && left > 0;
+            nn = left < 3 ? left : 3;
+            px0 = k == 0 ? lo : lin_pt(lo, sstep, (double)k);
+            px1 = (k + 1 == simpson_n - 1) ? hi : lin_pt(lo, sstep, (double)(k + 1));
+            px2 = (k + 2 == simpson_n - 1) ? hi : lin_pt(lo, sstep, (double)(k + 2));
+            px2 = nn < 3 ? px1 : px2;
+            px1 = nn < 2 ? px0 : px1; px2 = nn < 2 ? px0 : px2;
+        }
+        const bool over = on && (tn + nn > q.cap);
         failed = failed || over;
-        done = done || over;
-        const bool go = !done;
+        live = live && !over;
+        on = on && !over;
         double al[3], be[3], P[3];
         int E[3];
         {
@@ -1813,7 +1857,7 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
                 }
             }
         }
-        if (q.ecoef != nullptr && __ballot(go && (be[0] != 0.0 || be[1] != 0.0 || be[2] != 0.0)) != 0ull)
+        if (q.ecoef != nullptr && __ballot(on && (be[0] != 0.0 || be[1] != 0.0 || be[2] != 0.0)) != 0ull)
             lds_products_e(lcoef, q.ecoef, rl, D, al, be, P);
         else
             reg_products<NS>(cc, cq, lcoef, rl, D, al, P);
@@ -1833,71 +1877,41 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
             const double pv = cls == 0 ? q.pr0 : cls == 1 ? q.pr1 : cls == 2 ? q.pr2 : q.ptab[q.pidx + cls * q.istride];
             joint = pv + lik;
         }
-        const bool owner = go && rl < npp;
+        const bool owner = on && rl < nn;
         sawnan = sawnan || (owner && joint != joint);
         if (owner) { q.tx[tn + rl] = x; q.tv[tn + rl] = joint; }
+        tn = on ? tn + nn : tn;
         PROF_ADD(c, 14);  // pass: log + prior + store
-        const double j0 = row_bcast<0>(joint), j1 = row_bcast<1>(joint), j2 = row_bcast<2>(joint);
-        // ---- state update, select form
-        const bool isI = phase == RP_INIT, isR = phase == RP_ROUND, isTS = phase == RP_TAIL || phase == RP_SIMPSON;
-        const bool srch = go && (isI || isR);
-        tn = go ? tn + npp : tn;
-        // argmax over {left, middle1, middle2, right}, lowest index wins ties (adaptive_integration.rs:70-82): as three
-        // compare masks.  0: [L, m1]  1: [L, m2]  2: [m1, R]  3: [m2, R] — the new bracket keeps one end and takes one of the
-        // two middles, so the update is two selects for the middle and one per bracket field (INIT only sets the values)
-        const bool c1 = j1 > vL;
-        const double vb1 = c1 ? j1 : vL;
-        const bool c2 = j2 > vb1;
-        const double vb2 = c2 ? j2 : vb1;
-        const bool c3 = vR > vb2;
-        const bool keepR = c3 || c2;                 // kk >= 2: the left end moves
-        const bool useM2 = c3 || (!c2 && c1);        // kk odd: the moving end goes to middle2
-        const double mX = useM2 ? px2 : px1, mV = useM2 ? j2 : j1;
-        const bool rnd = go && isR, ini = go && isI;
-        const bool updL = rnd && keepR, updR = rnd && !keepR;
-        L = updL ? mX : L; R = updR ? mX : R;
-        vL = ini ? j0 : (updL ? mV : vL);
-        vR = ini ? j1 : (updR ? mV : vR);
-        const bool more = (((R - L) >= res) && L < R) || isI;  // the first round always happens (mid is None)
-        const bool toRound = srch && more, toTail = srch && !more;
-        const double nmid = (R + L) / 2.0;
-        first_mid = (toRound && !have_first) ? nmid : first_mid;
-        have_first = have_first || toRound;
-        mid = toRound ? nmid : mid;
-        px0 = toRound ? nmid : px0;
-        px1 = toRound ? (nmid + L) / 2.0 : px1;
-        px2 = toRound ? (R + nmid) / 2.0 : px2;
-        npp = toRound ? 3 : npp;
-        k = (go && isTS) ? k + 3 : toTail ? 0 : k;
-        phase = toRound ? RP_ROUND : toTail ? RP_TAIL : phase;
-        const bool nowTS = phase == RP_TAIL || phase == RP_SIMPSON;
-        done = done || (go && nowTS && k >= (phase == RP_TAIL ? 7 : simpson_n));
-        if (__ballot(!done && nowTS)) {  // next points of the rows in the tail / on a Simpson grid
-            // tail: abandoned arm (95-106) + small interval around the optimum (107-131)
-            const double arm = (mid < first_mid) ? (hi + first_mid) / 2.0 : (first_mid + lo) / 2.0;
-            const double lo3 = fmax(mid - res * 3.0, lo);
-            const double hi3 = fmin(mid + res * 3.0, hi);
-            const double sa = div3(mid - lo3), sb = div3(hi3 - mid);  // itertools_num::linspace step, n = 4
-            const double t0 = k == 0 ? arm : k == 3 ? lin_pt(lo3, sa, 2.0) : lin_pt(mid, sb, 3.0);
-            const double t1 = k == 0 ? lin_pt(lo3, sa, 0.0) : lin_pt(mid, sb, 1.0);
-            const double t2 = k == 0 ? lin_pt(lo3, sa, 1.0) : lin_pt(mid, sb, 2.0);
-            const bool isT = phase == RP_TAIL;
-            int nn = k == 6 ? 1 : 3;
-            double n0 = t0, n1 = t1, n2 = t2;
-            if (__ballot(!done && phase == RP_SIMPSON)) {  // rare (fewer than five observations, ranges below the resolution)
-                // Simpson grid (modes/generic.rs:367-385): points k, k+1, k+2 of linspace(lo, hi, n) with exact end points
-                const int left = simpson_n - k;
-                const double s0 = lin_pt(lo, sstep, (double)k);
-                const double s1 = (k + 1 == simpson_n - 1) ? hi : lin_pt(lo, sstep, (double)(k + 1));
-                const double s2 = (k + 2 == simpson_n - 1) ? hi : lin_pt(lo, sstep, (double)(k + 2));
-                nn = isT ? nn : (left < 3 ? left : 3);
-                n0 = isT ? t0 : s0; n1 = isT ? t1 : s1; n2 = isT ? t2 : s2;
+        if (up == UP_ROUND) {
+            const double j1 = row_bcast<1>(joint), j2 = row_bcast<2>(joint);
+            // argmax over {left, middle1, middle2, right}, lowest index wins ties (adaptive_integration.rs:70-82): as three
+            // compare masks.  0: [L, m1]  1: [L, m2]  2: [m1, R]  3: [m2, R] — the new bracket keeps one end and takes one of the
+            // two middles, so the update is two selects for the middle and one per bracket field
+            const bool c1 = j1 > vL;
+            const double vb1 = c1 ? j1 : vL;
+            const bool c2 = j2 > vb1;
+            const double vb2 = c2 ? j2 : vb1;
+            const bool c3 = vR > vb2;
+            const bool keepR = c3 || c2;                 // kk >= 2: the left end moves
+            const bool useM2 = c3 || (!c2 && c1);        // kk odd: the moving end goes to middle2
+            const double mX = useM2 ? px2 : px1, mV = useM2 ? j2 : j1;
+            const bool updL = on && keepR, updR = on && !keepR;
+            L = updL ? mX : L; R = updR ? mX : R;
+            vL = updL ? mV : vL; vR = updR ? mV : vR;
+            act = on && ((R - L) >= res) && L < R;
+            if (!__ballot(act)) { up = UP_TAIL; k = 0; }
+        } else if (up == UP_TAIL) {
+            k += 3;
+            if (k >= 7) break;
+        } else if (up == UP_INIT) {
+            vL = row_bcast<0>(joint); vR = row_bcast<1>(joint);  // rows that are not on never read them
+            up = UP_ROUND;                                        // the first round always happens (middle is None)
+        } else {
+            k += 3;
+            if (k >= kmax) {
+                if (!any_norm) break;
+                up = UP_INIT; k = 0;
             }
-            n2 = nn < 3 ? n1 : n2;
-            n1 = nn < 2 ? n0 : n1;
-            n2 = nn < 2 ? n0 : n2;
-            const bool upd = !done && nowTS;
-            px0 = upd ? n0 : px0; px1 = upd ? n1 : px1; px2 = upd ? n2 : px2; npp = upd ? nn : npp;
         }
     }
     PROF_ADD(c, 15);  // pass: state update (+ loop control)
