@@ -782,8 +782,8 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
     if (e == hipSuccess) e = hipMemcpy(plan->dev, &P, sizeof(DevPlan), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipEventCreate(&plan->ev_start);
     if (e == hipSuccess) e = hipEventCreate(&plan->ev_stop);
-    if (e == hipSuccess) e = hipMalloc((void**)&plan->work_dev, 32 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(plan->work_dev, 0, 32 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&plan->work_dev, 64 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(plan->work_dev, 0, 64 * sizeof(unsigned long long));
     if (e != hipSuccess) {
         vlr_plan_destroy(plan);
         return fail(VLR_ERR_HIP, "plan upload failed: %s", hipGetErrorString(e));
@@ -1063,7 +1063,7 @@ int vlr_plan_work_counters(vlr_plan* plan, unsigned long long* out2, int reset) 
     HIP_TRY(hipSetDevice(plan->device));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out2, plan->work_dev, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(hipMemset(plan->work_dev, 0, 32 * sizeof(unsigned long long)));
+    if (reset) HIP_TRY(hipMemset(plan->work_dev, 0, 64 * sizeof(unsigned long long)));
     return VLR_OK;
 }
 
@@ -1072,7 +1072,7 @@ extern "C" int vlr_plan_profile_counters(vlr_plan* plan, unsigned long long* out
     if (!plan || !out12) return fail(VLR_ERR_INVALID_ARGUMENT, "null argument");
     HIP_TRY(hipSetDevice(plan->device));
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out12, plan->work_dev + 2, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out12, plan->work_dev + 2, 40 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return VLR_OK;
 }
 

@@ -36,8 +36,15 @@
 namespace vlr {
 
 // optional per-phase cycle accounting (build with -DVLR_PROFILE): wall cycles of the wave spent per phase
-#ifdef VLR_PROFILE
-#define PROF_DECL unsigned long long prof[24]; unsigned long long prof_t;
+#if defined(VLR_PROFILE) && defined(VLR_PROFILE_VALU)
+// Per-region VALU INSTRUCTION counts instead of cycles: tools/valu_profile.sh rewrites the kernel's assembly so that every basic
+// block adds its number of VALU instructions to s100 (a register the compiler leaves alone: it stops at s99); the regions read it
+// where the cycle profile reads the clock.
+#define PROF_DECL unsigned long long prof[40]; unsigned long long prof_t;
+#define PROF_START(c) do { unsigned t_; asm volatile("s_mov_b32 s100, 0\n\ts_mov_b32 %0, 0" : "=s"(t_)); (c).prof_t = t_; } while (0)
+#define PROF_ADD(c, i) do { unsigned t_; asm volatile("s_mov_b32 %0, s100" : "=s"(t_)); (c).prof[i] += (unsigned)(t_ - (unsigned)(c).prof_t); (c).prof_t = t_; } while (0)
+#elif defined(VLR_PROFILE)
+#define PROF_DECL unsigned long long prof[40]; unsigned long long prof_t;
 #define PROF_START(c) (c).prof_t = __builtin_amdgcn_s_memtime()
 #define PROF_ADD(c, i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); (c).prof[i] += t_ - (c).prof_t; (c).prof_t = t_; } while (0)
 #else
@@ -1862,12 +1869,26 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
         else
             reg_products<NS>(cc, cq, lcoef, rl, D, al, P);
         PROF_ADD(c, 12);  // pass: term products
+        // reduction over the 16 lanes of the row: inside the quads for all three points, then lane t of every quad keeps point t
+        // and the four quads are combined for that point alone (rotations by 4 and 8 lanes): lane t of the row ends with point t
 #pragma unroll
-        for (int t = 0; t < 3; ++t) { int e; P[t] = __builtin_frexp(P[t], &e); E[t] = e; }
-        reduce_terms<3, 16>(P, E);
+        for (int t = 0; t < 3; ++t) {
+            int e;
+            P[t] = __builtin_frexp(P[t], &e); E[t] = e;
+            P[t] *= dpp_f64<0xB1>(P[t]); E[t] += dpp_i32<0xB1>(E[t]);      // quad_perm [1,0,3,2]
+            P[t] *= dpp_f64<0x4E>(P[t]); E[t] += dpp_i32<0x4E>(E[t]);      // quad_perm [2,3,0,1]
+        }
+        const int tq = rl & 3;
+        double Psel = tq == 1 ? P[1] : tq == 2 ? P[2] : P[0];
+        int Esel = tq == 1 ? E[1] : tq == 2 ? E[2] : E[0];
+        Psel *= dpp_f64<0x124>(Psel); Esel += dpp_i32<0x124>(Esel);        // row_ror:4
+        Psel *= dpp_f64<0x128>(Psel); Esel += dpp_i32<0x128>(Esel);        // row_ror:8
+        {
+            int e;
+            Psel = __builtin_frexp(Psel, &e);  // product of 16 mantissas >= 2^-16: one renormalisation suffices
+            Esel += e;
+        }
         PROF_ADD(c, 13);  // pass: reduction
-        const double Psel = rl == 1 ? P[1] : rl == 2 ? P[2] : P[0];
-        const int Esel = rl == 1 ? E[1] : rl == 2 ? E[2] : E[0];
         const double x = rl == 0 ? px0 : rl == 1 ? px1 : px2;
         const double lik = q.fixed + (ln_mantissa(Psel) + (double)Esel * kLn2);
         double joint;
@@ -2463,6 +2484,7 @@ __device__ __forceinline__ bool bo_deliver(Ctx& c, const Frame& f, RangeSt& r, d
     const int lane = fresh_lane(c.lane);
     const int np = UNI(B.np), c0 = UNI(B.c0), nt = UNI(B.nt), s_in = UNI(B.s_in), s_out = UNI(B.s_out);
     const bool dead = UNI(B.dead) != 0;
+    PROF_ADD(c, 24);  // walk: resume up to the delivery
     __syncthreads();
     // lane i < nt fetches the results of chain i and records its outer point in one go; the row loop below then reads lanes
     // instead of making an LDS round trip per field and row
@@ -2472,6 +2494,7 @@ __device__ __forceinline__ bool bo_deliver(Ctx& c, const Frame& f, RangeSt& r, d
     const int hbl = Tl.haveBest, alivel = Tl.alive, contl = Tl.contained, nl = Tl.n;
     const int tn0 = UNI(r.tn);
     if (lane < nt) { txo[tn0 + c0 + lane] = xl; tvo[tn0 + c0 + lane] = dead ? VLR_NEG_INF : resl; }
+    PROF_ADD(c, 25);  // delivery: fetch + outer table
     for (int i = 0; i < nt; ++i) {
         const double x = lane_d(xl, i);
         __syncthreads();
@@ -2494,6 +2517,7 @@ __device__ __forceinline__ bool bo_deliver(Ctx& c, const Frame& f, RangeSt& r, d
         }
     }
     const int c1 = c0 + nt;
+    PROF_ADD(c, 26);  // delivery: MAP candidates per chain
     __syncthreads();
     if (c1 < np) {
         if (lane == 0) w->bo.c0 = c1;
@@ -2791,7 +2815,8 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                 // the frame's constants (inner range, fixed likelihoods, ...) are set up in its first round only; later rounds
                 // just rewind the point counters (no other outer frame can run between the rounds of this one: its children
                 // are leaf chains)
-                if (UNI(r.tn) == 0) bo_begin(c, r, UNI(f.n), UNI(f.sv_alive));
+                PROF_ADD(c, 29);  // outer: round issue
+                if (UNI(r.tn) == 0) { bo_begin(c, r, UNI(f.n), UNI(f.sv_alive)); PROF_ADD(c, 30); }
                 else {
                     __syncthreads();
                     if (c.lane == 0) { BatchOuter& B = w->bo; B.np = r.npend; B.c0 = 0; B.nt = 0; }
@@ -2838,9 +2863,11 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                 // (what PC_RETURN does for a frame whose points come back one by one)
                 const bool done = range_advance(c, r, tx, tv);
                 __syncthreads();
+                PROF_ADD(c, 27);  // outer: range_advance
                 if (!done) pc = PC_RANGE_ISSUE;
                 else {
                     rv = range_finish(c, r, tx, tv);
+                    PROF_ADD(c, 28);  // outer: range_finish
                     c.present = UNI(f.sv_present); c.disc = UNI(f.sv_disc); c.nlfc = UNI(f.sv_nlfc); c.contained = UNI(f.sv_contained); c.alive = UNI(f.sv_alive); c.afd_mute = UNI(f.sv_mute);
                     sp--; nrange--;
                     pc = PC_RETURN;
@@ -3127,7 +3154,7 @@ __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, Dev
 template <int WPE>
 __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_arg, DevBatch batch, DevResults out,
                                                            int max_obs, int range_depth) {
-    extern __shared__ double dyn[];
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
     __shared__ WaveSt wst;
     const DevPlan& p = plan_arg;
     const int lane = threadIdx.x;
@@ -3180,7 +3207,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
     c.lg = (out.afd_log && !out.replay && !VLR_DEEP) ? out.afd_log + (size_t)locus * (size_t)out.afd_log_stride : nullptr;
     c.lg_pos = kLogFirst; c.lg_cap = (int)out.afd_log_stride; c.lg_nrec = 0; c.hyp = 0;
 #ifdef VLR_PROFILE
-    for (int i = 0; i < 24; ++i) c.prof[i] = 0;
+    for (int i = 0; i < 40; ++i) c.prof[i] = 0;
 #endif
     PROF_START(c);
 
@@ -3753,6 +3780,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                 }
                 PROF_ADD(c, 22);  // root exit (event accumulators, slot state)
                 if (run_kind) {
+                    PROF_ADD(c, 31);  // event loop: between the walk's return and the batch
                     if (run_kind != 1) c.nlfc = 0;  // deferred chains carry no l2fc terms; a later probe walk may have left some in the context
                     run_chain_batch(c, run_mask, run_inner);
                     __syncthreads();
@@ -3879,7 +3907,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
             atomicAdd(&out.work[1], w->work[1]);
 #ifdef VLR_PROFILE
             PROF_ADD(c, 9);  // phase C
-            for (int i = 0; i < 24; ++i) atomicAdd(&out.work[2 + i], c.prof[i]);
+            for (int i = 0; i < 40; ++i) atomicAdd(&out.work[2 + i], c.prof[i]);
 #endif
         }
     }
