@@ -1418,19 +1418,20 @@ __device__ inline bool range_advance(Ctx& c, RangeSt& r, const double* tx, const
         r.phase = RP_ROUND;
         return false;
     }
-    // tail: abandoned arm (95-106) + small interval around the optimum (107-131)
-    double arm = (r.mid < r.first_mid) ? (r.hi + r.first_mid) / 2.0 : (r.first_mid + r.lo) / 2.0;
+    // tail: small interval around the optimum (107-131)
+    // (the reference's "additional grid point in the initially abandoned arm", adaptive_integration.rs:95-106, is (max + first_middle)/2
+    // or (first_middle + min)/2: exactly middle2 or middle1 of the FIRST round, a key its HashMap already holds — re-evaluating it
+    // changes nothing, so it is not visited again)
     double lo3 = fmax(r.mid - r.res * 3.0, r.lo);
     double hi3 = fmin(r.mid + r.res * 3.0, r.hi);
     double sa = div3(r.mid - lo3), sb = div3(hi3 - r.mid);  // itertools_num::linspace step, n = 4
-    r.pend[0] = arm;
-    r.pend[1] = lin_pt(lo3, sa, 0.0);
-    r.pend[2] = lin_pt(lo3, sa, 1.0);
-    r.pend[3] = lin_pt(lo3, sa, 2.0);
-    r.pend[4] = lin_pt(r.mid, sb, 1.0);
-    r.pend[5] = lin_pt(r.mid, sb, 2.0);
-    r.pend[6] = lin_pt(r.mid, sb, 3.0);
-    r.npend = 7;
+    r.pend[0] = lin_pt(lo3, sa, 0.0);
+    r.pend[1] = lin_pt(lo3, sa, 1.0);
+    r.pend[2] = lin_pt(lo3, sa, 2.0);
+    r.pend[3] = lin_pt(r.mid, sb, 1.0);
+    r.pend[4] = lin_pt(r.mid, sb, 2.0);
+    r.pend[5] = lin_pt(r.mid, sb, 3.0);
+    r.npend = 6;
     r.phase = RP_TAIL;
     return false;
 }
@@ -1612,18 +1613,17 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
             np = 3;
             phase = RP_ROUND;
         } else {
-            double arm = (mid < first_mid) ? (hi + first_mid) / 2.0 : (first_mid + lo) / 2.0;
+            // (the abandoned-arm point of the reference is a first-round point again: see range_advance)
             double lo3 = fmax(mid - res * 3.0, lo);
             double hi3 = fmin(mid + res * 3.0, hi);
             double sa = div3(mid - lo3), sb = div3(hi3 - mid);  // itertools_num::linspace step, n = 4
-            if (lane < 7) {
+            if (lane < 6) {
                 double v;
-                if (lane == 0) v = arm;
-                else if (lane <= 3) v = lin_pt(lo3, sa, (double)(lane - 1));
-                else v = lin_pt(mid, sb, (double)(lane - 3));
+                if (lane <= 2) v = lin_pt(lo3, sa, (double)lane);
+                else v = lin_pt(mid, sb, (double)(lane - 2));
                 pend[lane] = v;
             }
-            np = 7;
+            np = 6;
             phase = RP_TAIL;
         }
         VLR_WAVE_FENCE();
@@ -1803,8 +1803,8 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
                                     max(__builtin_amdgcn_readlane(simpson_n, 32), __builtin_amdgcn_readlane(simpson_n, 48))) : 0;
     const double sstep = simp ? (hi - lo) / (double)(simpson_n - 1) : 0.0;
     int k = 0, tn = 0;
-    bool failed = false, sawnan = false, first = true;
-    double L = lo, R = hi, vL = VLR_NEG_INF, vR = VLR_NEG_INF, mid = lo, first_mid = lo;
+    bool failed = false, sawnan = false;
+    double L = lo, R = hi, vL = VLR_NEG_INF, vR = VLR_NEG_INF, mid = lo;
     PROF_ADD(c, 7);  // batch prologue (task fields, coefficient registers)
     for (;;) {
         PROF_ADD(c, 15);
@@ -1816,20 +1816,20 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
             on = live && act;
             px0 = (R + L) / 2.0; px1 = (px0 + L) / 2.0; px2 = (R + px0) / 2.0; nn = 3;
             mid = on ? px0 : mid;
-            if (first) first_mid = px0;
-            first = false;
         } else if (up == UP_TAIL) {
-            // abandoned arm (95-106) + small interval around the optimum (107-131)
+            // small interval around the optimum (107-131): three points below, three above (the abandoned-arm point of the
+            // reference is a first-round point again: see range_advance)
             on = live && !simp;
-            const double arm = (mid < first_mid) ? (hi + first_mid) / 2.0 : (first_mid + lo) / 2.0;
-            const double lo3 = fmax(mid - res * 3.0, lo);
-            const double hi3 = fmin(mid + res * 3.0, hi);
-            const double sa = div3(mid - lo3), sb = div3(hi3 - mid);  // itertools_num::linspace step, n = 4
-            px0 = k == 0 ? arm : k == 3 ? lin_pt(lo3, sa, 2.0) : lin_pt(mid, sb, 3.0);
-            px1 = k == 0 ? lin_pt(lo3, sa, 0.0) : lin_pt(mid, sb, 1.0);
-            px2 = k == 0 ? lin_pt(lo3, sa, 1.0) : lin_pt(mid, sb, 2.0);
-            nn = k == 6 ? 1 : 3;
-            px1 = nn < 2 ? px0 : px1; px2 = nn < 2 ? px0 : px2;
+            if (k == 0) {
+                const double lo3 = fmax(mid - res * 3.0, lo);
+                const double sa = div3(mid - lo3);  // itertools_num::linspace step, n = 4
+                px0 = lin_pt(lo3, sa, 0.0); px1 = lin_pt(lo3, sa, 1.0); px2 = lin_pt(lo3, sa, 2.0);
+            } else {
+                const double hi3 = fmin(mid + res * 3.0, hi);
+                const double sb = div3(hi3 - mid);
+                px0 = lin_pt(mid, sb, 1.0); px1 = lin_pt(mid, sb, 2.0); px2 = lin_pt(mid, sb, 3.0);
+            }
+            nn = 3;
         } else if (up == UP_INIT) {
             on = live && !simp;
             px0 = lo; px1 = hi; px2 = hi; nn = 2;
@@ -1923,7 +1923,7 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
             if (!__ballot(act)) { up = UP_TAIL; k = 0; }
         } else if (up == UP_TAIL) {
             k += 3;
-            if (k >= 7) break;
+            if (k >= 6) break;
         } else if (up == UP_INIT) {
             vL = row_bcast<0>(joint); vR = row_bcast<1>(joint);  // rows that are not on never read them
             up = UP_ROUND;                                        // the first round always happens (middle is None)
@@ -2116,18 +2116,17 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
                     np = 3;
                     phase = RP_ROUND;
                 } else {
-                    double arm = (mid < first_mid) ? (hi + first_mid) / 2.0 : (first_mid + lo) / 2.0;
+                    // (the abandoned-arm point of the reference is a first-round point again: see range_advance)
                     double lo3 = fmax(mid - res * 3.0, lo);
                     double hi3 = fmin(mid + res * 3.0, hi);
                     double sa = div3(mid - lo3), sb = div3(hi3 - mid);
-                    if (rl < 7) {
+                    if (rl < 6) {
                         double v;
-                        if (rl == 0) v = arm;
-                        else if (rl <= 3) v = lin_pt(lo3, sa, (double)(rl - 1));
-                        else v = lin_pt(mid, sb, (double)(rl - 3));
+                        if (rl <= 2) v = lin_pt(lo3, sa, (double)rl);
+                        else v = lin_pt(mid, sb, (double)(rl - 2));
                         pend[rl] = v;
                     }
-                    np = 7;
+                    np = 6;
                     phase = RP_TAIL;
                 }
             }
