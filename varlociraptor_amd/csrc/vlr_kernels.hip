@@ -165,13 +165,16 @@ __device__ __forceinline__ double uni_d(double v) {
 // the AFD pass as expensive as the likelihood evaluation itself.
 #define VLR_WG_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
 
+// VLR_SYNC(): the places that were written as workgroup barriers; the workgroup being one wave, they need no more than the
+// compiler-level ordering of VLR_WAVE_FENCE() (a hardware barrier also drains every outstanding load of the wave first)
 #if defined(VLR_WB_SYNC)
-#define VLR_WAVE_FENCE() __syncthreads()
+#define VLR_WAVE_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); } while (0)
 #elif defined(VLR_WB_PLAIN)
 #define VLR_WAVE_FENCE() __builtin_amdgcn_wave_barrier()
 #else
 #define VLR_WAVE_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #endif
+#define VLR_SYNC() VLR_WAVE_FENCE()
 
 // The lane id as a value the optimiser cannot hoist: without it every lane-derived constant of the chain runners
 // ((double)(lane - 1), row masks, ...) is computed once before the hypothesis loop and then SPILLED across it.
@@ -204,7 +207,7 @@ __device__ __forceinline__ double div3(double x) {
     return __builtin_fma(__builtin_fma(-3.0, q0, x), r, q0);
 }
 
-// wave helpers (wave64; one wave per workgroup so __syncthreads() is a wave-level LDS fence).
+// wave helpers (wave64; one wave per workgroup so VLR_SYNC() is a wave-level LDS fence).
 // Reductions over the wave: four DPP steps inside each 16-lane row (quad_perm, quad_perm, row_half_mirror, row_mirror: every
 // lane of a row ends with the row's total), then the four row totals are read into SGPRs and combined — the result is
 // wave-uniform.  (The __shfl_xor butterflies these replace go through ds_bpermute: six lane-address registers that the compiler
@@ -658,7 +661,7 @@ __device__ inline double integrate_table(const double* tx, const double* tv, int
         sx[rank] = x;
         sv[rank] = tv[i];
     }
-    __syncthreads();
+    VLR_SYNC();
     double M = VLR_NEG_INF;
     double t0 = VLR_NEG_INF, t1 = VLR_NEG_INF;
     {
@@ -684,7 +687,7 @@ __device__ inline double integrate_table(const double* tx, const double* tv, int
         s = wave_sum(s);
         r = M + log(s);
     }
-    __syncthreads();
+    VLR_SYNC();
     return r;
 }
 
@@ -823,14 +826,14 @@ __device__ inline double sample_lik(Ctx& c, int s, double a, double b) {
     }
     const double r = sample_lik_point(c, s, a, b);
     int slot = n % kCacheWays;
-    __syncthreads();
+    VLR_SYNC();
     if (c.lane == 0) {
         c.cacheA[s * kCacheWays + slot] = a;
         c.cacheB[s * kCacheWays + slot] = b;
         c.cacheV[s * kCacheWays + slot] = r;
         w->cacheN[s] = (unsigned char)(n + 1 == 252 ? 248 : n + 1);  // a byte: wraps within the same residue mod kCacheWays
     }
-    __syncthreads();
+    VLR_SYNC();
     return r;
 }
 
@@ -875,9 +878,9 @@ __device__ inline void map_consider(Ctx& c, double joint, int inner, double x) {
     if (better) {
         c.curJ = joint;
         c.curHyp = c.hyp | (((inner >= 0) ? (c.disc & ~(1 << inner)) : c.disc) << 4);  // hypothesis | is_discrete mask
-        __syncthreads();
+        VLR_SYNC();
         if (c.lane < c.S) c.w->curMapVaf[c.lane] = (c.lane == inner) ? x : c.w->ops_vaf[c.lane];
-        __syncthreads();
+        VLR_SYNC();
     }
 }
 
@@ -1002,16 +1005,16 @@ __device__ inline void cross_consider(Ctx& c, int g, double joint, int inner, do
                 if (nd != od) {
                     better = disc_before(nd, od);
                     joint = fmax(joint, curJ);
-                    if (!better && joint > curJ) { __syncthreads(); if (c.lane == 0) c.mapJ[slot] = joint; __syncthreads(); }
+                    if (!better && joint > curJ) { VLR_SYNC(); if (c.lane == 0) c.mapJ[slot] = joint; VLR_SYNC(); }
                 }
             }
         }
     }
     if (better) {
-        __syncthreads();
+        VLR_SYNC();
         if (c.lane == 0) { c.mapJ[slot] = joint; c.mapHyp[slot] = c.hyp | (((inner >= 0) ? (c.disc & ~(1 << inner)) : c.disc) << 4); }
         if (c.lane < c.S) c.mapVaf[slot * c.S + c.lane] = (c.lane == inner) ? x : c.w->ops_vaf[c.lane];
-        __syncthreads();
+        VLR_SYNC();
     }
 }
 // ---- AFD log (DevResults::afd_log): what FORMAT/AFD needs from the call pass (calling.rs:889-928) is the joint probability of
@@ -1172,9 +1175,9 @@ __device__ inline double eval_discrete_root(Ctx& c, int l0, int l1) {
         double J;
         const int best = dleaf_wave_best(leaves, bJ, bL, S, J);
         if (best >= 0) {
-            __syncthreads();
+            VLR_SYNC();
             if (lane < S) w->ops_vaf[lane] = leaves[best].vaf[lane];
-            __syncthreads();
+            VLR_SYNC();
             map_consider(c, J, -1, 0.0);
         }
     }
@@ -1195,9 +1198,9 @@ __device__ inline double eval_discrete_root(Ctx& c, int l0, int l1) {
         double J;
         const int best = dleaf_wave_best(leaves, gJ, gL, S, J);
         if (best >= 0) {
-            __syncthreads();
+            VLR_SYNC();
             if (lane < S) w->ops_vaf[lane] = leaves[best].vaf[lane];
-            __syncthreads();
+            VLR_SYNC();
             cross_consider(c, g, J, -1, 0.0);
         }
     }
@@ -1245,12 +1248,12 @@ __device__ inline void afd_consider(Ctx& c, double joint, int inner, double x, i
             for (int i = 0; i < ns; ++i)
                 seen = seen || (c.afd_seen[2 * (s * kMaxSet + i)] == vs && __double_as_longlong(c.afd_seen[2 * (s * kMaxSet + i) + 1]) == lkey);
             if (seen) continue;
-            __syncthreads();
+            VLR_SYNC();
             if (c.lane == 0 && ns < kMaxSet) {
                 c.afd_seen[2 * (s * kMaxSet + ns)] = vs; c.afd_seen[2 * (s * kMaxSet + ns) + 1] = __longlong_as_double(lkey);
                 c.afd_nseen[s] = ns + 1;
             }
-            __syncthreads();
+            VLR_SYNC();
         }
         int idx_l = 0;
         if (c.afd_cnt) {
@@ -1635,7 +1638,7 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
     if (haveBest) map_consider(c, bestJ, inner, bestX);
     if (failed) return __builtin_nan("");
     VLR_WAVE_FENCE();
-    __syncthreads();
+    VLR_SYNC();
     if (log_on(c)) log_table(c, inner, tx, tv, tn);
     if (phase == RP_SIMPSON) {  // bio LogProb::ln_simpsons_integrate_exp (modes/generic.rs:367-385)
         double M = VLR_NEG_INF, S = 0.0;
@@ -1804,6 +1807,7 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
     const double sstep = simp ? (hi - lo) / (double)(simpson_n - 1) : 0.0;
     int k = 0, tn = 0;
     bool failed = false, sawnan = false;
+    const bool all_fast = __ballot(q.rowon && !q.cls_fast) == 0ull;
     double L = lo, R = hi, vL = VLR_NEG_INF, vR = VLR_NEG_INF, mid = lo;
     PROF_ADD(c, 7);  // batch prologue (task fields, coefficient registers)
     for (;;) {
@@ -1893,6 +1897,7 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
         const double lik = q.fixed + (ln_mantissa(Psel) + (double)Esel * kLn2);
         double joint;
         if (c.nlfc > 0 && !lfcs_ok(c, q.inner, x)) joint = VLR_NEG_INF;
+        else if (all_fast) joint = (x == 0.0 ? q.pr0 : q.pr1) + lik;  // every row inside a uniform-prior universe: class 0 at exactly 0, else 1
         else {
             const int cls = q.cls_fast ? (x == 0.0 ? 0 : 1) : prior_class(p, q.inner, x);
             const double pv = cls == 0 ? q.pr0 : cls == 1 ? q.pr1 : cls == 2 ? q.pr2 : q.ptab[q.pidx + cls * q.istride];
@@ -2302,7 +2307,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
         To.result = r; To.bestJ = bJ; To.bestX = bX; To.haveBest = bHave | (rowout ? 2 : 0); To.n = n;
     }
     VLR_WAVE_FENCE();
-    __syncthreads();
+    VLR_SYNC();
     PROF_ADD(c, 8);  // batch epilogue (MAP scan + integrate)
 }
 
@@ -2400,7 +2405,7 @@ __device__ __forceinline__ void bo_begin(Ctx& c, RangeSt& r, int chn, int alive_
     fixed_const = uni_d(fixed_const);
     // cross-event MAP candidates: groups whose spectra for the outer sample miss the whole outer range need no per-point test
     const int alive0 = alive_restrict(c, alive_in, s_out, uni_d(r.lo), uni_d(r.hi));
-    __syncthreads();
+    VLR_SYNC();
     if (c.lane == 0) {
         BatchOuter& B = w->bo;
         B.alive0 = alive0;
@@ -2408,7 +2413,7 @@ __device__ __forceinline__ void bo_begin(Ctx& c, RangeSt& r, int chn, int alive_
         B.simpson = simpson; B.dead = dead ? 1 : 0; B.vary = vary; B.np = UNI(r.npend); B.c0 = 0; B.nt = 0;
         B.chn = chn; B.s_in = s_in; B.s_out = s_out;
     }
-    __syncthreads();
+    VLR_SYNC();
 }
 // tasks of the pending outer points [c0, c0 + kRows); returns false if the inner range is dead (no chains to run)
 __device__ __forceinline__ bool bo_setup(Ctx& c, const Frame& f, RangeSt& r) {
@@ -2421,7 +2426,7 @@ __device__ __forceinline__ bool bo_setup(Ctx& c, const Frame& f, RangeSt& r) {
     const int free_rows = kRows - c.nhold;  // held event-level chains keep the top rows (they ride along with this batch)
     const int nt = (np - c0) < free_rows ? (np - c0) : free_rows;
     PROF_ADD(c, 18);  // outer batch: entry (fixed samples) / delivery of the previous pass
-    __syncthreads();
+    VLR_SYNC();
     if (lane == 0) w->bo.nt = nt;
     if (lane < nt) {
         const DevNode ch = ld_node(p.nodes + chn);
@@ -2444,7 +2449,7 @@ __device__ __forceinline__ bool bo_setup(Ctx& c, const Frame& f, RangeSt& r) {
         T.group = c.group; T.disc = c.disc & ~(1 << s_in);  // for the AFD log
         T.result = VLR_NEG_INF; T.haveBest = 0; T.n = 0; T.bestJ = VLR_NEG_INF; T.bestX = 0.0;
     }
-    __syncthreads();
+    VLR_SYNC();
     PROF_ADD(c, 16);  // outer batch: task setup
     int vm = UNI(B.vary);
     while (vm && !dead) {
@@ -2459,17 +2464,17 @@ __device__ __forceinline__ bool bo_setup(Ctx& c, const Frame& f, RangeSt& r) {
             w->bpend[1][lane] = al;  // scratch: the row buffers are rewritten by the chain batch that follows
             w->bpend[2][lane] = be;
         }
-        __syncthreads();
+        VLR_SYNC();
         int off = UNI(w->soff[s]), D = UNI(w->nkeep[s]);
         eval_pileup(c.coef + 2 * off, ecoef_of(c, s, off), D, (w->fastok >> s) & 1, nt, w->bpend[1], w->bpend[2], w->bpend[3], lane);
-        __syncthreads();
+        VLR_SYNC();
 #ifdef VLR_NO_RESCUE
         if (lane < nt) w->task[lane].fixed += w->bpend[3][lane];
 #else
         if (lane < nt) w->task[lane].fixed += w->bpend[3][lane] + (double)kshift(c)[s] * kLn2;
 #endif
         if (lane == 0) { w->work[0] += (unsigned long long)nt; w->work[1] += (unsigned long long)nt * (unsigned long long)D; }
-        __syncthreads();
+        VLR_SYNC();
     }
     PROF_ADD(c, 17);  // outer batch: likelihoods of the samples that vary with the outer point
     c.bt_nt = nt;
@@ -2484,7 +2489,7 @@ __device__ __forceinline__ bool bo_deliver(Ctx& c, const Frame& f, RangeSt& r, d
     const int np = UNI(B.np), c0 = UNI(B.c0), nt = UNI(B.nt), s_in = UNI(B.s_in), s_out = UNI(B.s_out);
     const bool dead = UNI(B.dead) != 0;
     PROF_ADD(c, 24);  // walk: resume up to the delivery
-    __syncthreads();
+    VLR_SYNC();
     // lane i < nt fetches the results of chain i and records its outer point in one go; the row loop below then reads lanes
     // instead of making an LDS round trip per field and row
     const int li = lane < nt ? lane : 0;
@@ -2496,9 +2501,9 @@ __device__ __forceinline__ bool bo_deliver(Ctx& c, const Frame& f, RangeSt& r, d
     PROF_ADD(c, 25);  // delivery: fetch + outer table
     for (int i = 0; i < nt; ++i) {
         const double x = lane_d(xl, i);
-        __syncthreads();
+        VLR_SYNC();
         if (lane == 0) w->ops_vaf[s_out] = x;
-        __syncthreads();
+        VLR_SYNC();
         if (dead) continue;
         const int hb = __builtin_amdgcn_readlane(hbl, i), n_i = __builtin_amdgcn_readlane(nl, i);
         if (c.replay) {
@@ -2517,15 +2522,15 @@ __device__ __forceinline__ bool bo_deliver(Ctx& c, const Frame& f, RangeSt& r, d
     }
     const int c1 = c0 + nt;
     PROF_ADD(c, 26);  // delivery: MAP candidates per chain
-    __syncthreads();
+    VLR_SYNC();
     if (c1 < np) {
         if (lane == 0) w->bo.c0 = c1;
-        __syncthreads();
+        VLR_SYNC();
         return true;
     }
     PROF_ADD(c, 18);
     if (lane == 0) r.tn = r.tn + np;
-    __syncthreads();
+    VLR_SYNC();
     return false;
 }
 
@@ -2537,16 +2542,16 @@ __device__ __forceinline__ void flush_deliver(Ctx& c, int rowmask, double* evM, 
     // (the chains were run by the event loop's single run_chain_batch site; a lone deferred chain takes the same path)
     WaveSt* w = c.w;
     rowmask = UNI(rowmask);
-    __syncthreads();
+    VLR_SYNC();
     while (rowmask) {
         const int i = __builtin_ctz(rowmask);
         rowmask &= rowmask - 1;
         const ChainTask& T = w->task[i];
         const int u = UNI(T.u), s_in = UNI(T.inner);
         // restore the context of the deferred leaf: operands, event group, flags, and the slot's MAP candidate
-        __syncthreads();
+        VLR_SYNC();
         if (c.lane < c.S) { w->ops_vaf[c.lane] = c.tvaf[i * c.S + c.lane]; w->curMapVaf[c.lane] = c.mapVaf[u * c.S + c.lane]; }
-        __syncthreads();
+        VLR_SYNC();
         c.group = UNI(T.group); c.disc = UNI(T.disc); c.contained = UNI(T.contained); c.alive = UNI(T.alive); c.nlfc = 0;
         c.curJ = uni_d(c.mapJ[u]); c.curHyp = UNI(c.mapHyp[u]);
         const double dens = uni_d(T.result);
@@ -2562,10 +2567,10 @@ __device__ __forceinline__ void flush_deliver(Ctx& c, int rowmask, double* evM, 
         }
         double M = uni_d(evM[u]), Sx = uni_d(evS[u]);
         lse_add(M, Sx, bias_prior + dens);
-        __syncthreads();
+        VLR_SYNC();
         if (c.lane == 0) { evM[u] = M; evS[u] = Sx; c.mapJ[u] = c.curJ; c.mapHyp[u] = c.curHyp; }
         if (c.lane < c.S) c.mapVaf[u * c.S + c.lane] = w->curMapVaf[c.lane];
-        __syncthreads();
+        VLR_SYNC();
     }
 }
 // one chain task with its operands from row `from` (or the stash: from < 0) to row `to` (or the stash: to < 0)
@@ -2578,12 +2583,12 @@ __device__ __forceinline__ void move_task(Ctx& c, int from, int to) {
     double* dst = (double*)(to < 0 ? &w->stash : &w->task[to]);
     const double* vs = from < 0 ? w->stash_vaf : c.tvaf + from * c.S;
     double* vd = to < 0 ? w->stash_vaf : c.tvaf + to * c.S;
-    __syncthreads();
+    VLR_SYNC();
     const double a = src[lane < NW ? lane : 0], b = vs[lane < c.S ? lane : 0];
-    __syncthreads();
+    VLR_SYNC();
     if (lane < NW) dst[lane] = a;
     if (lane < c.S) vd[lane] = b;
-    __syncthreads();
+    VLR_SYNC();
 }
 
 // node id of the single child of `fnode` if that child is a leaf Sample node with a proper Range spectrum, else -1
@@ -2618,12 +2623,12 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
             const DevNode nd = ld_node(p.nodes + node);
             if (nd.kind == VLR_NODE_LFC) {  // 233-244
                 if (c.nlfc < kMaxLfc) {
-                    __syncthreads();
+                    VLR_SYNC();
                     if (c.lane == 0) {
                         w->lfc_a[c.nlfc] = nd.sample; w->lfc_b[c.nlfc] = nd.sample_b;
                         w->lfc_cmp[c.nlfc] = nd.cmp; w->lfc_val[c.nlfc] = nd.lfc_value;
                     }
-                    __syncthreads();
+                    VLR_SYNC();
                     c.nlfc++;
                 }
                 pc = PC_SUB;
@@ -2653,7 +2658,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                         for (int i = 0; i < nd.vafs.set_len; ++i) all_pos = all_pos && (ldc(p.vafs + nd.vafs.set_off + i) > 0.0);
                         if (clear_ref && all_pos) dead = true;
                         else {
-                            __syncthreads();
+                            VLR_SYNC();
                             for (int i = 0; i < nd.vafs.set_len && ncand < p.max_set; ++i) {
                                 double v = ldc(p.vafs + nd.vafs.set_off + i);
                                 if (!have_bounds || range_contains(bounds, v)) {
@@ -2661,7 +2666,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                                     ncand++;
                                 }
                             }
-                            __syncthreads();
+                            VLR_SYNC();
                             as_set = true;
                             if (ncand == 0) dead = true;  // ln_sum_exp of nothing
                         }
@@ -2670,9 +2675,9 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                         if (range_is_empty(vr)) dead = true;
                         else if (clear_ref && vr.start > 0.0) dead = true;
                         else if (range_is_singleton(vr)) {
-                            __syncthreads();
+                            VLR_SYNC();
                             if (c.lane == 0) c.setv[s * p.max_set] = vr.start;
-                            __syncthreads();
+                            VLR_SYNC();
                             ncand = 1;
                             as_set = true;
                         }
@@ -2681,7 +2686,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                 if (dead) { rv = VLR_NEG_INF; pc = PC_RETURN; }
                 else if (sp >= c.nframes) { c.status |= VLR_LOCUS_TABLE_FULL; rv = __builtin_nan(""); pc = PC_RETURN; }
                 else {
-                    __syncthreads();
+                    VLR_SYNC();
                     Frame& f = c.frames[sp];
                     if (c.lane == 0) {
                         f.node = node; f.iter = 0; f.accM = VLR_NEG_INF; f.accS = 0.0;
@@ -2696,7 +2701,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                     }
                     if (as_set) {
                         if (c.lane == 0) { f.kind = FK_SET; f.n = ncand; w->ops_vaf[s] = c.setv[s * p.max_set]; }
-                        __syncthreads();
+                        VLR_SYNC();
                         sp++;
                         c.present |= (1 << s);
                         c.disc |= (1 << s);
@@ -2729,7 +2734,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                                 r.pend[0] = min_vaf; r.pend[1] = max_vaf; r.npend = 2; r.phase = RP_INIT;
                             }
                         }
-                        __syncthreads();
+                        VLR_SYNC();
                         sp++;
                         nrange++;
                         c.present |= (1 << s);
@@ -2745,14 +2750,14 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
             else if (sp >= c.nframes) { c.status |= VLR_LOCUS_TABLE_FULL; rv = __builtin_nan(""); pc = PC_RETURN; }
             else if (c.defer_ok) { c.deferred = 2; return 0.0; }  // probe pass: branching root is not a single chain
             else {
-                __syncthreads();
+                VLR_SYNC();
                 Frame& f = c.frames[sp];
                 if (c.lane == 0) {
                     f.kind = FK_BRANCH; f.node = node; f.iter = 0; f.n = nd.n_children; f.accM = VLR_NEG_INF; f.accS = 0.0;
                     f.sv_present = c.present; f.sv_disc = c.disc; f.sv_nlfc = c.nlfc; f.sv_contained = c.contained;
                     f.sv_alive = c.alive; f.sv_mute = c.afd_mute;
                 }
-                __syncthreads();
+                VLR_SYNC();
                 sp++;
                 node = ldc(p.child_index + nd.child_off);
                 pc = PC_DESCEND;
@@ -2788,7 +2793,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                         if (!(s2 == inner || by == inner)) fixed += sample_lik(c, s2, w->ops_vaf[s2], by >= 0 ? w->ops_vaf[by] : 0.0);
                         if (s2 != inner) pidx += prior_class(p, s2, w->ops_vaf[s2]) * p.class_stride[s2];
                     }
-                    __syncthreads();
+                    VLR_SYNC();
                     if (c.lane == 0) {
                         ChainTask& T = w->task[row];
                         T.lo = r.lo; T.hi = r.hi; T.res = r.res; T.ostart = r.ostart; T.oend = r.oend; T.olex = r.olex; T.orex = r.orex;
@@ -2797,7 +2802,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                         T.group = c.group; T.disc = c.disc; T.inner = inner; T.u = c.defer_slot;
                     }
                     if (c.lane < S) c.tvaf[row * S + c.lane] = w->ops_vaf[c.lane];
-                    __syncthreads();
+                    VLR_SYNC();
                     c.ndef = row + 1;
                     c.deferred = 1;
                     return 0.0;
@@ -2817,9 +2822,9 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                 PROF_ADD(c, 29);  // outer: round issue
                 if (UNI(r.tn) == 0) { bo_begin(c, r, UNI(f.n), UNI(f.sv_alive)); PROF_ADD(c, 30); }
                 else {
-                    __syncthreads();
+                    VLR_SYNC();
                     if (c.lane == 0) { BatchOuter& B = w->bo; B.np = r.npend; B.c0 = 0; B.nt = 0; }
-                    __syncthreads();
+                    VLR_SYNC();
                 }
                 pc = PC_BO_PRE;
             } else {
@@ -2833,9 +2838,9 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                 c.contained = UNI(f.sv_contained) && range_contains(orig, x);
                 c.alive = alive_update(c, UNI(f.sv_alive), UNI(r.sample), x);
                 if (c.replay) c.afd_mute = UNI(f.sv_mute) || table_has(tx, UNI(r.tn), x, c.lane);
-                __syncthreads();
+                VLR_SYNC();
                 if (c.lane == 0) w->ops_vaf[UNI(r.sample)] = x;
-                __syncthreads();
+                VLR_SYNC();
                 node = fnode;
                 pc = PC_SUB;
             }
@@ -2843,9 +2848,9 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
             Frame& f = c.frames[sp - 1];
             RangeSt& r = c.rs[UNI(f.slot)];
             if (bo_setup(c, f, r)) {
-                __syncthreads();
+                VLR_SYNC();
                 if (c.lane == 0) { WalkSave& k = w->wk; k.sp = sp; k.node = node; k.nrange = nrange; k.skip_record = skip_record ? 1 : 0; k.rv = rv; }
-                __syncthreads();
+                VLR_SYNC();
                 c.need_batch = 1;
                 return 0.0;
             }
@@ -2861,7 +2866,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                 // all points of the round are recorded (f.iter stays 0 in batched rounds): advance the outer chain right here
                 // (what PC_RETURN does for a frame whose points come back one by one)
                 const bool done = range_advance(c, r, tx, tv);
-                __syncthreads();
+                VLR_SYNC();
                 PROF_ADD(c, 27);  // outer: range_advance
                 if (!done) pc = PC_RANGE_ISSUE;
                 else {
@@ -2881,16 +2886,16 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                 RangeSt& r = c.rs[fslot];
                 double* tx = c.tabX + fslot * c.cap;
                 double* tv = c.tabV + fslot * c.cap;
-                __syncthreads();
+                VLR_SYNC();
                 if (c.lane == 0 && !skip_record) { tx[r.tn] = r.pend[f.iter]; tv[r.tn] = rv; r.tn = r.tn + 1; f.iter = f.iter + 1; }
                 skip_record = false;
-                __syncthreads();
+                VLR_SYNC();
                 if (UNI(f.iter) < UNI(r.npend)) { pc = PC_RANGE_ISSUE; }
                 else {
                     bool done = range_advance(c, r, tx, tv);
-                    __syncthreads();
+                    VLR_SYNC();
                     if (c.lane == 0) f.iter = 0;
-                    __syncthreads();
+                    VLR_SYNC();
                     if (!done) { pc = PC_RANGE_ISSUE; }
                     else {
                         rv = range_finish(c, r, tx, tv);
@@ -2903,18 +2908,18 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                 double M = f.accM, S = f.accS;
                 lse_add(M, S, rv);
                 int it = UNI(f.iter) + 1;
-                __syncthreads();
+                VLR_SYNC();
                 if (c.lane == 0) { f.accM = M; f.accS = S; f.iter = it; }
-                __syncthreads();
+                VLR_SYNC();
                 c.present = UNI(f.sv_present); c.disc = UNI(f.sv_disc); c.nlfc = UNI(f.sv_nlfc); c.contained = UNI(f.sv_contained); c.alive = UNI(f.sv_alive); c.afd_mute = UNI(f.sv_mute);
                 if (it < UNI(f.n)) {
                     const int fnode = UNI(f.node);
                     const DevNode nd = ld_node(p.nodes + fnode);
                     if (UNI(f.kind) == FK_SET) {
                         int s = nd.sample;
-                        __syncthreads();
+                        VLR_SYNC();
                         if (c.lane == 0) w->ops_vaf[s] = c.setv[s * p.max_set + it];
-                        __syncthreads();
+                        VLR_SYNC();
                         c.present |= (1 << s);
                         c.disc |= (1 << s);
                         c.contained = UNI(f.sv_contained) && spectrum_contains(nd.vafs, p.vafs, w->ops_vaf[s]);
@@ -2971,7 +2976,7 @@ __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, Dev
     c.vt = 0; c.has_snv = 0; c.refbase = 0; c.altbase = 0;
     if (lane < S) { sh_mapv[lane] = out.map_vaf[locus * S + lane]; sh_nseen[lane] = 0; sh_cnt[lane] = 0; }
     c.afd_cnt = sh_cnt;
-    __syncthreads();
+    VLR_SYNC();
     const int be = UNI(out.best_event[locus]);
     c.mapGroup = (be == 0) ? 0 : ((be - 1) / 2 + 1);
     c.mapDisc = UNI((int)out.map_disc[locus]);
@@ -2998,7 +3003,7 @@ __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, Dev
             sh_probe[lane][0] = X[0]; sh_probe[lane][1] = (kind == 1 && n > 1) ? X[1] : 0.0; sh_probe[lane][2] = (kind == 1) ? X[n - 1] : 0.0;
         }
     }
-    __syncthreads();
+    VLR_SYNC();
     if (lane < nrec && kind != 3) {
         mism = 0;
         for (int s = 0; s < S; ++s) {
@@ -3063,9 +3068,9 @@ __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, Dev
             const int hq = __builtin_amdgcn_readlane(hitq, r);
             if (hq != -2) {  // handled by 1b: operands from LDS, value from the gather
                 if (hq < 0) continue;
-                __syncthreads();
+                VLR_SYNC();
                 if (lane < S) wst.ops_vaf[lane] = sh_ops[r][lane];
-                __syncthreads();
+                VLR_SYNC();
                 const double hv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(hitv), r), __builtin_amdgcn_readlane(__double2loint(hitv), r));
                 afd_consider(c, hv, sin_r, uni_d(sh_mapv[sin_r]), -1);
                 continue;
@@ -3085,22 +3090,22 @@ __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, Dev
                 while (todo) {
                     const int qq = q0 + __builtin_ctzll(todo);
                     todo &= todo - 1;
-                    __syncthreads();
+                    VLR_SYNC();
                     if (lane < S) wst.ops_vaf[lane] = L[qq * (S + 1) + lane];
-                    __syncthreads();
+                    VLR_SYNC();
                     afd_consider(c, uni_d(L[qq * (S + 1) + S]), -1, 0.0);
                 }
             }
             continue;
         }
-        __syncthreads();
+        VLR_SYNC();
         if (lane < S) wst.ops_vaf[lane] = lg[at_r + 1 + lane];
         if (lane < nl_r) {
             const long long t = __double_as_longlong(lg[at_r + 1 + S + 2 * lane]);
             wst.lfc_a[lane] = (int)(t & 0xff); wst.lfc_b[lane] = (int)((t >> 8) & 0xff); wst.lfc_cmp[lane] = (int)((t >> 16) & 0xff);
             wst.lfc_val[lane] = lg[at_r + 1 + S + 2 * lane + 1];
         }
-        __syncthreads();
+        VLR_SYNC();
         if (k_r == 2) { afd_consider(c, uni_d(lg[pay]), -1, 0.0); continue; }
         const double* X = lg + pay;
         const double* V = X + n_r;
@@ -3109,9 +3114,9 @@ __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, Dev
         const long long lkey_r = UNI64(lfc_ctx_key(c));
         // the x values of the record go to LDS in one coalesced round (table capacity <= kTableCap = 128): the first-occurrence test
         // below reads every earlier x once per entry — as uniform global loads that was one memory round trip per table entry
-        __syncthreads();
+        VLR_SYNC();
         for (int i = lane; i < n_r && i < kTableCap; i += 64) sh_x[i] = X[i];
-        __syncthreads();
+        VLR_SYNC();
         for (int q0 = 0; q0 < n_r; q0 += 64) {
             const int q = q0 + lane;
             const bool on = q < n_r;
@@ -3327,7 +3332,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
     // read_position_bias.rs:63-122, kept apart from the counters above to bound register pressure
     const double m_sb_all = uni_d(wave_max(mx_sb_all)), m_sb_fwd = uni_d(wave_max(mx_sb_fwd));
     DdAcc sb_all{{0.0, 0.0}}, sb_fwd{{0.0, 0.0}};
-    __syncthreads();
+    VLR_SYNC();
     for (int s = 0; s < S; ++s) {
         const int64_t pidx = locus * S + s;
         const uint32_t o0 = batch.obs_offset[pidx], o1 = batch.obs_offset[pidx + 1];
@@ -3357,7 +3362,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
             ddacc_add(pa_rate, pm + phb, m_rate, strong_ref);
         }
         const double e_all = ddacc_exp(pa_all, m_all), e_major = ddacc_exp(pa_major, m_major), e_rate = ddacc_exp(pa_rate, m_rate);
-        __syncthreads();
+        VLR_SYNC();
         if (lane == 0) { w->pos_all[s] = e_all; w->pos_major[s] = e_major; w->pos_rate[s] = e_rate; }
     }
 #if VLR_DEEP
@@ -3381,7 +3386,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
 #endif
     if (lane == 0) w->ehas = ehas_mask;
     c.ehas = ehas_mask;
-    __syncthreads();
+    VLR_SYNC();
     if (filtered > 0) c.status |= VLR_LOCUS_FILTERED_ALN;
     if (total_kept == 0) c.status |= VLR_LOCUS_MISSING_DATA;
     const bool singleton = (n_alt_like == 1);  // adjust_singleton_evidence (read_observation.rs:548-562)
@@ -3469,7 +3474,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
     // ============================ phase B: hypotheses x events ============================
     for (int u = lane; u < p.n_univ; u += 64) { evM[u] = VLR_NEG_INF; evS[u] = 0.0; }
     for (int u = lane; u < n_slots; u += 64) { mapJ[u] = VLR_NEG_INF; mapHyp[u] = -1; }
-    __syncthreads();
+    VLR_SYNC();
 
     if (too_deep) c.status |= VLR_LOCUS_TOO_DEEP;
     unsigned hyps = too_deep ? 0u : (1u | surviving);
@@ -3484,9 +3489,9 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
             if (VLR_DEEP && !too_deep && lane == 0) out.status[locus] &= ~VLR_LOCUS_TOO_DEEP;  // no lists to make: done
             return;
         }
-        __syncthreads();
+        VLR_SYNC();
         if (lane < S) { c.mapv[lane] = out.map_vaf[locus * S + lane]; c.afd_nseen[lane] = 0; }
-        __syncthreads();
+        VLR_SYNC();
         int be = UNI(out.best_event[locus]);
         c.mapGroup = (be == 0) ? 0 : ((be - 1) / 2 + 1);
         c.mapDisc = UNI((int)out.map_disc[locus]);
@@ -3643,14 +3648,14 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
         }
         if (lane == 0) { w->fastok = fastmask; w->vfast = vfastmask; }
         if (lane < S) w->cacheN[lane] = 0;
-        __syncthreads();  // also orders the e coefficients (HBM scratch row, written by other lanes than the ones that read them)
+        VLR_SYNC();  // also orders the e coefficients (HBM scratch row, written by other lanes than the ones that read them)
         if (__ballot((c.status & VLR_LOCUS_UNDERFLOW) != 0)) c.status |= VLR_LOCUS_UNDERFLOW;
         if (p.n_dkey > 0 && !c.replay) {  // pileup likelihoods of the flattened discrete roots under this hypothesis
             for (int k = 0; k < p.n_dkey; ++k) {
                 const double r = sample_lik_point(c, ldc(&p.dkey[k].sample), ldc(&p.dkey[k].a), ldc(&p.dkey[k].b));
                 if (lane == 0) c.dkeyV[k] = r;
             }
-            __syncthreads();
+            VLR_SYNC();
         }
 
         PROF_ADD(c, 2);  // coefficient pass
@@ -3730,11 +3735,11 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                     c.group = e + 1;
                     c.defer_ok = (1 - pass) & (int)((unsigned)(rc_ - 64) >> 31);  // pass == 0 && rc_ < 64, as integer arithmetic (stays a scalar)
                     c.defer_slot = u;
-                    __syncthreads();
+                    VLR_SYNC();
                     c.curJ = uni_d(mapJ[u]);
                     c.curHyp = UNI(mapHyp[u]);
                     if (lane < S) w->curMapVaf[lane] = mapVaf[u * S + lane];
-                    __syncthreads();
+                    VLR_SYNC();
                     root = (e < 0) ? p.absent_root : ldc(p.roots + ri);
                     const int di = (e < 0) ? 0 : 1 + ri;
                     const int dl0 = (c.replay || p.n_dkey == 0) ? -1 : ldc(p.droot + 2 * di);
@@ -3744,10 +3749,10 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                         if (dens != dens) c.status |= VLR_LOCUS_NAN;
                         double M = uni_d(evM[u]), Sx = uni_d(evS[u]);
                         lse_add(M, Sx, bias_prior + dens);
-                        __syncthreads();
+                        VLR_SYNC();
                         if (lane == 0) { evM[u] = M; evS[u] = Sx; mapJ[u] = c.curJ; mapHyp[u] = c.curHyp; }
                         if (lane < S) mapVaf[u * S + lane] = w->curMapVaf[lane];
-                        __syncthreads();
+                        VLR_SYNC();
                         st = IT_NEXT;
                     } else { resume = 0; st = IT_WALK; }
                     PROF_ADD(c, 20);  // root entry (slot state, discrete roots are counted apart)
@@ -3769,10 +3774,10 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                             if (dens != dens) c.status |= VLR_LOCUS_NAN;
                             double M = uni_d(evM[u]), Sx = uni_d(evS[u]);
                             lse_add(M, Sx, bias_prior + dens);
-                            __syncthreads();
+                            VLR_SYNC();
                             if (lane == 0) { evM[u] = M; evS[u] = Sx; mapJ[u] = c.curJ; mapHyp[u] = c.curHyp; }
                             if (lane < S) mapVaf[u * S + lane] = w->curMapVaf[lane];
-                            __syncthreads();
+                            VLR_SYNC();
                         }
                         st = IT_NEXT;
                     }
@@ -3782,21 +3787,21 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                     PROF_ADD(c, 31);  // event loop: between the walk's return and the batch
                     if (run_kind != 1) c.nlfc = 0;  // deferred chains carry no l2fc terms; a later probe walk may have left some in the context
                     run_chain_batch(c, run_mask, run_inner);
-                    __syncthreads();
+                    VLR_SYNC();
                     if (run_kind == 1) {
                         if (piggy) {
                             // the walk is suspended with the MAP candidate of ITS slot and its operands in the context: park them
                             // in the slot arrays, hand the held chains to their events, and take the context back
                             const int sg = c.group, sd = c.disc, sc = c.contained, sa = c.alive, sn = c.nlfc;
                             const double so = w->ops_vaf[lane < S ? lane : 0];
-                            __syncthreads();
+                            VLR_SYNC();
                             if (lane == 0) { mapJ[u] = c.curJ; mapHyp[u] = c.curHyp; }
                             if (lane < S) mapVaf[u * S + lane] = w->curMapVaf[lane];
-                            __syncthreads();
+                            VLR_SYNC();
                             flush_deliver(c, piggy, evM, evS, bias_prior);
                             c.curJ = uni_d(mapJ[u]); c.curHyp = UNI(mapHyp[u]);
                             if (lane < S) { w->curMapVaf[lane] = mapVaf[u * S + lane]; w->ops_vaf[lane] = so; }
-                            __syncthreads();
+                            VLR_SYNC();
                             c.group = sg; c.disc = sd; c.contained = sc; c.alive = sa; c.nlfc = sn;
                             c.nhold = 0;
                         }
@@ -3858,7 +3863,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
     }
     // sample_infos (calling.rs:844-937): MAP among operands of the best event's tree (clean + twin share it)
     {
-        __syncthreads();
+        VLR_SYNC();
         int uc = (best == 0) ? 0 : (((best - 1) / 2) * 2 + 1);
         int ua = (best == 0) ? p.n_univ : uc + 1;
         int pick = -1;
