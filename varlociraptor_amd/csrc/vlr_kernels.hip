@@ -2258,16 +2258,15 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
             }
             VLR_WAVE_FENCE();
         }
-        // ---- row arg-best of (bJ desc, bX asc) for the MAP candidate
-        for (int st = 0; st < 4; ++st) {
-            double oJ, oX;
-            int oH;
-            if (st == 0) { oJ = dpp_f64<0xB1>(bJ); oX = dpp_f64<0xB1>(bX); oH = dpp_i32<0xB1>(bHave); }
-            else if (st == 1) { oJ = dpp_f64<0x4E>(bJ); oX = dpp_f64<0x4E>(bX); oH = dpp_i32<0x4E>(bHave); }
-            else if (st == 2) { oJ = dpp_f64<0x141>(bJ); oX = dpp_f64<0x141>(bX); oH = dpp_i32<0x141>(bHave); }
-            else { oJ = dpp_f64<0x140>(bJ); oX = dpp_f64<0x140>(bX); oH = dpp_i32<0x140>(bHave); }
-            const bool take = (oH != 0) & ((bHave == 0) | (oJ > bJ) | ((oJ == bJ) & (oX < bX)));
-            bJ = take ? oJ : bJ; bX = take ? oX : bX; bHave = take ? 1 : bHave;
+        // ---- row arg-best of (bJ desc, bX asc) for the MAP candidate: the row maximum of the lanes' best joints (a lane
+        // without a candidate counts as -inf; whether the row has one at all travels apart: a candidate may be worth -inf itself),
+        // then the smallest x among the lanes that hold it
+        {
+            const int rowHave = row_or(bHave);
+            const double rowJ = row_max(bHave ? bJ : VLR_NEG_INF);
+            double xs_ = (bHave != 0 && bJ == rowJ) ? bX : __builtin_huge_val();
+            xs_ = fmin(xs_, dpp_f64<0xB1>(xs_)); xs_ = fmin(xs_, dpp_f64<0x4E>(xs_)); xs_ = fmin(xs_, dpp_f64<0x141>(xs_)); xs_ = fmin(xs_, dpp_f64<0x140>(xs_));
+            bJ = rowJ; bX = xs_; bHave = rowHave;
         }
         double m4 = VLR_NEG_INF;
 #pragma unroll
@@ -2295,7 +2294,12 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
             }
         }
         ssum = row_sum(ssum);
-        rint_ = (M == VLR_NEG_INF) ? VLR_NEG_INF : M + log(ssum);
+        {   // ln of the positive sum: exponent apart, the mantissa through the short logarithm of the passes (ssum == 0: -inf)
+            int es;
+            const double ms = __builtin_frexp(ssum, &es);
+            const double lns = ssum > 0.0 ? ln_mantissa(ms) + (double)es * kLn2 : VLR_NEG_INF;
+            rint_ = (M == VLR_NEG_INF) ? VLR_NEG_INF : M + lns;
+        }
     }
     int nanrow = row_or(anynan ? 1 : 0);
     const int rowout = row_or(anyout ? 1 : 0);
