@@ -57,6 +57,8 @@ namespace vlr {
 __device__ constexpr double kLn05 = -0.6931471805599453;    // ln 0.5   (utils/mod.rs:45 PROB_05)
 __device__ constexpr double kLn095 = -0.05129329438755058;  // ln 0.95  (utils/mod.rs:48 PROB_095)
 __device__ constexpr double kLn2 = 0.6931471805599453;
+__device__ constexpr double kLn20 = 2.995732273553991;   // ln 20: KassRaftery::Strong as a log Bayes factor
+__device__ constexpr double kLn3 = 1.0986122886681098;   // ln 3: KassRaftery::Positive
 __device__ constexpr double kEps = 2.220446049250313e-16;
 
 enum FrameKind { FK_BRANCH = 0, FK_SET = 1, FK_RANGE = 2 };
@@ -3269,10 +3271,13 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
             bool keep = valid && !(remove_nonstd && f_orient(f) == VLR_ORIENT_OTHER);  // pileup.rs:26-43
             filtered += popc64(__ballot(valid && !keep));
             if (__ballot(keep && psa_f != 0.0f)) ehas_mask |= 1 << s;  // s = e^psa != 1: third coefficient e != 0
-            double bf_ref = exp(pr - pa), bf_alt = exp(pa - pr);
-            bool strong_ref = keep && bf_ref > 20.0;       // read_observation.rs:434-437 (KassRaftery >= Strong)
-            bool strong_alt = keep && bf_alt > 20.0;       // 429-432
-            bool pos_ref = bf_ref > 3.0;                   // 443-446
+            // Bayes factors against their thresholds in log space: pr - pa is a difference of two f32 values, i.e. a multiple of
+            // 2^-22 or coarser near ln 20, so it never comes within an ulp of the threshold and exp(d) > 20 <=> d > ln 20 holds for
+            // every possible input (NaN and the infinities compare the same way) — no exponential needed
+            const double dra = pr - pa;
+            bool strong_ref = keep && dra > kLn20;         // read_observation.rs:434-437 (KassRaftery >= Strong)
+            bool strong_alt = keep && -dra > kLn20;        // 429-432
+            bool pos_ref = dra > kLn3;                     // 443-446
             bool ref_sup = pr > pa;                        // 439-441
             bool uniq = pm >= kLn095;                      // 425-427
             nk += popc64(__ballot(keep));
@@ -3357,7 +3362,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
             double pm = cub.pm, pa = cub.pa, pr = cub.pr, phb = cub.phb;
             uint32_t f = cub.f;
             bool keep = valid && !(remove_nonstd && f_orient(f) == VLR_ORIENT_OTHER);
-            bool strong_ref = keep && exp(pr - pa) > 20.0;
+            bool strong_ref = keep && (pr - pa) > kLn20;
             int strand = f_strand(f);
             ddacc_add(sb_all, pm, m_sb_all, strong_ref && strand != VLR_STRAND_BOTH);
             ddacc_add(sb_fwd, pm, m_sb_fwd, strong_ref && strand == VLR_STRAND_FORWARD);
