@@ -379,6 +379,18 @@ int vlr_edit_distance_batch_host(int device, const vlr_realign_batch_desc* pairs
 enum { VLR_FDR_EMPTY = 0, VLR_FDR_VALUE = 1, VLR_FDR_LN_ONE = 2, VLR_FDR_NONE = 3 };
 int vlr_fdr_threshold(int device, const double* ln_prob, int64_t n, int smart, double alpha_ln, double* threshold, int* status);
 
+/* The whole of `varlociraptor filter-calls control-fdr` (/root/reference/src/filtration/fdr.rs:36-158, record typing
+ * src/utils/collect_variants.rs:44-304, probability sums and the filtering pass src/utils/mod.rs:169-374): read the calls BCF
+ * `in_path`, collect the posterior of `events` (names as on the command line: PROB_<UPPER CASE> INFO tags; tags the header does
+ * not declare are dropped, none left = error "invalid FDR control events") per typed variant, find the threshold on `device`
+ * (vlr_fdr_threshold), and write the kept records, byte for byte as they came, with the input's header to the BCF `out_path`.
+ * mode: VLR_FDR_MODE_* (global = 0; LOCAL: threshold ln(1 - alpha); SMART: PROB_ABSENT [+ PROB_ARTIFACT] based, fdr.rs:96-114).
+ * vartype: NULL = all variants, else "SNV" "MNV" "INS" "DEL" "BND" "INV" "DUP" "REP"; minlen / maxlen: -1 = open (length range
+ * [minlen, maxlen) as Variant::is_type).  Records of one breakend EVENT share one decision.  n_kept / n_total may be NULL. */
+enum { VLR_FDR_MODE_LOCAL = 1, VLR_FDR_MODE_SMART = 2, VLR_FDR_MODE_RETAIN_ARTIFACTS = 4 };
+int vlr_calls_filter_fdr(const char* in_path, const char* out_path, int n_events, const char* const* events, double alpha, uint32_t mode,
+                         const char* vartype, int64_t minlen, int64_t maxlen, int device, int n_threads, int64_t* n_kept, int64_t* n_total);
+
 /* Diagnostics: the DEVICE build of the platform-independent decision arithmetic (include/vlr_detmath.h; which = 0 det_exp,
  * 1 det_log1p_pos, 2 det_log2_ratio(a, b), 3 det_exp2) and of the kernel's mantissa logarithm (4), element-wise on host
  * arrays.  tests/test_gpu_math.py requires 0-3 to be bit-identical to the host build of the same header. */

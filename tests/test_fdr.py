@@ -145,3 +145,57 @@ def test_filter_calls_writes_bcf_with_the_input_header(tmp_path):
     for rec in kept[:50]:
         orig = by_key[(rec["chrom"], rec["pos"], rec["ref"], rec["alt"])]
         assert rec["info"] == orig["info"] and rec["format"] == orig["format"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture,events,alpha,local,smart,retain,vartype,expected", CASES)
+def test_native_filter_matches_restatement(fixture, events, alpha, local, smart, retain, vartype, expected, tmp_path):
+    """vlr_calls_filter_fdr (the whole command behind the ABI: BCF in, kept records out, threshold search on the device) keeps
+    exactly the records the Python restatement keeps, byte for byte, on the reference's eight count cases."""
+    src = os.path.join(RES, fixture.replace("test_fdr_", "") + ".bcf")
+    out = str(tmp_path / "kept.bcf")
+    kept_n, total_n = fdr.filter_calls_native(src, out, events, alpha, vartype=vartype, local=local, smart=smart, smart_retain_artifacts=retain, device=0)
+    r = BcfReader(src)
+    recs = list(r)
+    tags = [l.split("ID=")[1].split(",")[0] for l in r.header_lines if "ID=PROB_" in l]
+    want = fdr.control_fdr(recs, events, alpha, vartype=vartype, local=local, smart=smart, smart_retain_artifacts=retain, header_tags=tags)
+    got = list(BcfReader(out))
+    assert total_n == len(recs) and kept_n == len(got) == len(want)
+    assert [g["raw"] for g in got] == [w["raw"] for w in want]
+    if expected > 50:
+        assert abs(kept_n - expected) <= 1
+    else:
+        assert kept_n == expected
+
+
+@pytest.mark.gpu
+def test_native_filter_rejects_unknown_events(tmp_path):
+    with pytest.raises(Exception, match="invalid FDR control events"):
+        fdr.filter_calls_native(os.path.join(RES, "local1.bcf"), str(tmp_path / "x.bcf"), ["NOSUCH"], 0.05, device=0)
+
+
+@pytest.mark.gpu
+def test_cli_filter_calls_native_path(tmp_path):
+    """`filter-calls control-fdr --device cuda --output x.bcf` runs through vlr_calls_filter_fdr; same records as the Python path."""
+    from varlociraptor_amd import cli
+    src = os.path.join(RES, "ev_2.bcf")
+    a, b = str(tmp_path / "native.bcf"), str(tmp_path / "python.bcf")
+    args = ["filter-calls", "control-fdr", src, "--events", "SOMATIC", "--fdr", "0.05", "--mode", "global-strict", "--var", "DEL", "--minlen", "1", "--maxlen", "30"]
+    cli.main(args + ["--device", "cuda", "--output", a])
+    cli.main(args + ["--output", b])
+    assert [r["raw"] for r in BcfReader(a)] == [r["raw"] for r in BcfReader(b)]
+
+
+@pytest.mark.parametrize("fixture,events,alpha,local,smart,retain,vartype,expected", [c for c in CASES if c[3]])
+def test_native_filter_local_modes(fixture, events, alpha, local, smart, retain, vartype, expected, tmp_path):
+    """The local modes of vlr_calls_filter_fdr need no threshold search (threshold = ln(1 - alpha)): host code only — reader, record
+    typing, probability sums, filtering pass and writer against the Python restatement and the reference's expected counts."""
+    src = os.path.join(RES, fixture.replace("test_fdr_", "") + ".bcf")
+    out = str(tmp_path / "kept.bcf")
+    kept_n, total_n = fdr.filter_calls_native(src, out, events, alpha, vartype=vartype, local=local, smart=smart, smart_retain_artifacts=retain, device=0)
+    r = BcfReader(src)
+    recs = list(r)
+    tags = [l.split("ID=")[1].split(",")[0] for l in r.header_lines if "ID=PROB_" in l]
+    want = fdr.control_fdr(recs, events, alpha, vartype=vartype, local=local, smart=smart, smart_retain_artifacts=retain, header_tags=tags)
+    assert total_n == len(recs) and kept_n == len(want) == expected
+    assert [g["raw"] for g in BcfReader(out)] == [w["raw"] for w in want]

@@ -445,14 +445,21 @@ def main(argv=None):
         tdist.init_process_group(backend, **({"device_id": torch.device("cuda", a.device)} if backend == "nccl" else {}))
     if a.cmd == "filter-calls":
         from . import fdr
-        from .bcfio import BcfReader
-        r = BcfReader(a.calls)
-        recs = list(r)
-        tags = [l.split("ID=")[1].split(",")[0] for l in r.header_lines if l.startswith("##INFO") and "ID=PROB_" in l]
         vartype = None
         if a.var:
             rng = (a.minlen or 0, a.maxlen if a.maxlen is not None else 1 << 62) if (a.minlen is not None or a.maxlen is not None) else None
             vartype = (a.var, rng)
+        if a.output and str(a.device).startswith("cuda") and os.environ.get("VLR_INGEST", "native") != "python":
+            # the whole command in the engine (vlr_calls_filter_fdr): BCF in, kept records out, threshold search on the device
+            dev = int(str(a.device).split(":")[1]) if ":" in str(a.device) else 0
+            kept_n, total_n = fdr.filter_calls_native(a.calls, a.output, a.events, a.fdr, vartype=vartype, local=a.mode.startswith("local"),
+                                                      smart=a.mode.endswith("smart"), smart_retain_artifacts=a.smart_retain_artifacts, device=dev)
+            print(f"{kept_n} of {total_n} records kept", file=sys.stderr)
+            return
+        from .bcfio import BcfReader
+        r = BcfReader(a.calls)
+        recs = list(r)
+        tags = [l.split("ID=")[1].split(",")[0] for l in r.header_lines if l.startswith("##INFO") and "ID=PROB_" in l]
         kept = fdr.control_fdr(recs, a.events, a.fdr, vartype=vartype, local=a.mode.startswith("local"), smart=a.mode.endswith("smart"),
                                smart_retain_artifacts=a.smart_retain_artifacts, header_tags=tags, device=a.device)
         # utils::filter_calls (filtration/fdr.rs:58-62, utils/mod.rs:288-374): the kept records go out as BCF with the input's

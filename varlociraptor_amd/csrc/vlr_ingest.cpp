@@ -37,6 +37,7 @@
 #include <string>
 #include <thread>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/vlr.h"
@@ -2075,3 +2076,292 @@ int vlr_obs_write(const char* path, const vlr_batch* in, int sample, const vlr_o
 }
 
 }  // extern "C"
+
+// ================================================================================================ filter-calls control-fdr
+// The whole of `varlociraptor filter-calls control-fdr` behind the ABI (reference src/filtration/fdr.rs:36-158,
+// src/utils/mod.rs:169-374, record typing src/utils/collect_variants.rs:44-304): calls BCF in -> kept records out, the threshold
+// search on the device (vlr_fdr_threshold).  The Python restatement the tests compare with: varlociraptor_amd/fdr.py.
+extern "C" int vlr_fdr_threshold(int device, const double* ln_prob, int64_t n, int smart, double alpha_ln, double* threshold, int* status);
+namespace {
+constexpr double kNumericalEpsilon = 1e-3;  // utils/mod.rs:40
+struct CallRec {
+    const uint8_t* raw = nullptr;
+    size_t raw_len = 0;
+    int64_t pos0 = 0;
+    std::string ref, event, svtype;
+    std::vector<std::string> alts;
+    bool has_event = false, has_svlen = false, has_end = false;
+    std::vector<int64_t> svlen;      // |SVLEN| per entry, -1 = missing
+    int64_t end0 = 0;                // END - 1
+    std::vector<std::vector<double>> prob;  // per wanted tag: PHRED values per ALT (NaN = missing), empty = tag absent
+};
+struct VarType { int kind = -1; int64_t len = 0; };  // kind < 0: skipped by collect_variants
+enum { VK_SNV, VK_MNV, VK_INS, VK_DEL, VK_BND, VK_INV, VK_DUP, VK_REP, VK_REF, VK_METH };
+int vk_of(const std::string& s) {
+    static const char* const n[] = {"SNV", "MNV", "INS", "DEL", "BND", "INV", "DUP", "REP", "REF", "METH"};
+    for (int i = 0; i < 10; ++i) if (s == n[i]) return i;
+    return -1;
+}
+bool valid_del(const std::string& r, const std::string& a) { return a == "<DEL>" || (r.size() > a.size() && r.compare(0, a.size(), a) == 0 && a.size() == 1); }
+bool valid_ins(const std::string& r, const std::string& a) { return a == "<INS>" || (r.size() < a.size() && a.compare(0, r.size(), r) == 0 && r.size() == 1); }
+// (type, length) per ALT allele as collect_variants types it (collect_variants.rs:44-304)
+bool variant_types(const CallRec& r, std::vector<VarType>& out, std::string& err) {
+    out.clear();
+    if (!r.svtype.empty()) {
+        const std::string& sv = r.svtype;
+        if (sv == "INV" || sv == "DUP") {
+            VarType v;
+            if (r.alts.size() == 1 && r.has_end) { v.kind = sv == "INV" ? VK_INV : VK_DUP; v.len = r.end0 + 1 - r.pos0; }
+            out.push_back(v);
+        } else if (sv == "BND") {
+            for (size_t i = 0; i < r.alts.size(); ++i) out.push_back(VarType{VK_BND, 0});
+        } else if (sv == "INS") {
+            VarType v;
+            if (!r.alts.empty() && r.alts[0] != "<INS>" && valid_ins(r.ref, r.alts[0])) { v.kind = VK_INS; v.len = (int64_t)r.alts[0].size() - (int64_t)r.ref.size(); }
+            out.push_back(v);
+        } else if (sv == "DEL") {
+            int64_t svlen;
+            if (r.has_svlen && !r.svlen.empty() && r.svlen[0] >= 0) svlen = r.svlen[0];
+            else if (!r.has_svlen && r.has_end) svlen = r.end0 - (r.pos0 + 1);  // collect_variants.rs:196-199
+            else { err = "missing SVLEN or END"; return false; }
+            VarType v;
+            if (!r.alts.empty() && valid_del(r.ref, r.alts[0])) { v.kind = VK_DEL; v.len = svlen; }
+            out.push_back(v);
+        }
+        return true;
+    }
+    for (size_t i = 0; i < r.alts.size(); ++i) {
+        const std::string& a = r.alts[i];
+        VarType v;
+        if (a == "<*>") v = VarType{VK_REF, 0};
+        else if (a == "<DEL>") { if (r.has_svlen && i < r.svlen.size() && r.svlen[i] >= 0) v = VarType{VK_DEL, r.svlen[i]}; }
+        else if (a == "<METH>") v = VarType{VK_METH, 0};
+        else if (!a.empty() && a[0] == '<') {}
+        else if (a.size() == 1 && r.ref.size() == 1) v = VarType{VK_SNV, 1};
+        else if (a.size() == r.ref.size()) v = VarType{VK_MNV, (int64_t)a.size()};
+        else if (valid_del(r.ref, a)) v = VarType{VK_DEL, (int64_t)r.ref.size() - (int64_t)a.size()};
+        else if (valid_ins(r.ref, a)) v = VarType{VK_INS, (int64_t)a.size() - (int64_t)r.ref.size()};
+        else v = VarType{VK_REP, 0};
+        out.push_back(v);
+    }
+    return true;
+}
+struct TypeFilter { int kind = -1; bool has_range = false; int64_t lo = 0, hi = 0; };
+bool is_type(const VarType& v, const TypeFilter& f) {  // Variant::is_type (variants/model/mod.rs)
+    if (v.kind < 0) return false;
+    if (f.kind < 0) return true;
+    if (v.kind != f.kind) return false;
+    return !f.has_range || (f.lo <= v.len && v.len < f.hi);
+}
+double lse(const std::vector<double>& v) {
+    double m = -INFINITY;
+    for (double x : v) m = std::max(m, x);
+    if (m == -INFINITY) return m;
+    double s = 0.0;
+    for (double x : v) s += std::exp(x - m);
+    return m + std::log(s);
+}
+// utils/mod.rs:177-212: ln-sum over the given PROB_* tags per (typed) variant; NaN = None
+void tags_prob_sum(const CallRec& r, const std::vector<VarType>& types, const std::vector<int>& tags, const TypeFilter& tf, std::vector<double>& out) {
+    std::vector<const VarType*> variants;
+    for (auto& v : types) if (v.kind >= 0) variants.push_back(&v);
+    std::vector<std::vector<double>> acc(variants.size());
+    for (int t : tags) {
+        const std::vector<double>& vals = r.prob[(size_t)t];
+        for (size_t i = 0; i < variants.size() && i < vals.size(); ++i) {
+            const double p = vals[i];
+            if (p != p || !is_type(*variants[i], tf)) continue;
+            acc[i].push_back(-p * std::log(10.0) / 10.0);
+        }
+    }
+    out.clear();
+    for (auto& probs : acc) {
+        if (probs.empty()) { out.push_back(NAN); continue; }
+        double s = lse(probs);
+        if (0.0 < s && s <= kNumericalEpsilon) s = 0.0;  // cap_numerical_overshoot
+        out.push_back(s);
+    }
+}
+double ln_one_minus_exp(double p) { return p < 0.0 ? (p < -0.693 ? std::log1p(-std::exp(p)) : std::log(-std::expm1(p))) : -INFINITY; }
+}  // namespace
+
+extern "C" int vlr_calls_filter_fdr(const char* in_path, const char* out_path, int n_events, const char* const* events, double alpha, uint32_t mode,
+                                    const char* vartype, int64_t minlen, int64_t maxlen, int device, int n_threads, int64_t* n_kept, int64_t* n_total) {
+    if (!in_path || !out_path || n_events <= 0 || !events) return ifail(VLR_ERR_INVALID_ARGUMENT, "null argument");
+    if (!(alpha > 0.0)) return ifail(VLR_ERR_INVALID_ARGUMENT, "alpha must be positive");
+    const bool local = (mode & VLR_FDR_MODE_LOCAL) != 0, smart = (mode & VLR_FDR_MODE_SMART) != 0, retain = (mode & VLR_FDR_MODE_RETAIN_ARTIFACTS) != 0;
+    n_threads = pick_threads(n_threads);
+    TypeFilter tf;
+    if (vartype && *vartype) {
+        tf.kind = vk_of(vartype);
+        if (tf.kind < 0) return ifail(VLR_ERR_INVALID_ARGUMENT, "unknown variant type %s", vartype);
+        if (minlen >= 0 || maxlen >= 0) { tf.has_range = true; tf.lo = minlen >= 0 ? minlen : 0; tf.hi = maxlen >= 0 ? maxlen : ((int64_t)1 << 62); }
+    }
+    std::string err;
+    Blob data;
+    if (!load_inflated(in_path, data, n_threads, err)) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s", err.c_str());
+    if (data.size() < 9 || memcmp(data.data(), "BCF\2\2", 5) != 0) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s is not a BCF file", in_path);
+    uint32_t l_text;
+    memcpy(&l_text, data.data() + 5, 4);
+    if (9 + (size_t)l_text > data.size()) return ifail(VLR_ERR_INVALID_ARGUMENT, "truncated BCF header in %s", in_path);
+    Header h;
+    {
+        std::string text((const char*)data.data() + 9, l_text);
+        while (!text.empty() && text.back() == '\0') text.pop_back();
+        parse_header(text, h);
+    }
+    // wanted INFO tags: the events' PROB_* (those the header declares, fdr.rs:46-60), PROB_ABSENT, PROB_ARTIFACT
+    std::vector<std::string> tag_names;
+    auto tag_id = [&](const std::string& name) {
+        for (size_t i = 0; i < tag_names.size(); ++i) if (tag_names[i] == name) return (int)i;
+        tag_names.push_back(name);
+        return (int)tag_names.size() - 1;
+    };
+    auto declared = [&](const std::string& name) { return std::find(h.dict.begin(), h.dict.end(), name) != h.dict.end() && h.text.find("##INFO=<ID=" + name + ",") != std::string::npos; };
+    std::vector<int> ev_tags;
+    for (int i = 0; i < n_events; ++i) {
+        std::string t = "PROB_";
+        for (const char* q = events[i]; *q; ++q) t.push_back((char)toupper((unsigned char)*q));
+        if (declared(t)) ev_tags.push_back(tag_id(t));
+    }
+    if (ev_tags.empty()) return ifail(VLR_ERR_INVALID_ARGUMENT, "invalid FDR control events");  // errors::Error::InvalidFDRControlEvents
+    const int t_absent = tag_id("PROB_ABSENT"), t_artifact = tag_id("PROB_ARTIFACT");
+    std::vector<int> key_tag(h.dict.size(), -1);  // dictionary index -> 0.. wanted tag, -2 EVENT, -3 SVTYPE, -4 SVLEN, -5 END
+    for (size_t k = 0; k < h.dict.size(); ++k) {
+        for (size_t t = 0; t < tag_names.size(); ++t) if (h.dict[k] == tag_names[t]) key_tag[k] = (int)t;
+        if (h.dict[k] == "EVENT") key_tag[k] = -2;
+        else if (h.dict[k] == "SVTYPE") key_tag[k] = -3;
+        else if (h.dict[k] == "SVLEN") key_tag[k] = -4;
+        else if (h.dict[k] == "END") key_tag[k] = -5;
+    }
+    // records
+    std::vector<CallRec> recs;
+    {
+        const uint8_t* p = data.data() + 9 + l_text;
+        const uint8_t* const e = data.data() + data.size();
+        while (p + 8 <= e) {
+            uint32_t ls, li;
+            memcpy(&ls, p, 4); memcpy(&li, p + 4, 4);
+            const size_t len = 8 + (size_t)ls + li;
+            if ((size_t)(e - p) < len || ls < 24) return ifail(VLR_ERR_INVALID_ARGUMENT, "truncated BCF record in %s", in_path);
+            CallRec r;
+            r.raw = p; r.raw_len = len;
+            r.prob.resize(tag_names.size());
+            const uint8_t* q = p + 8;
+            const uint8_t* se = q + ls;
+            int32_t pos;
+            uint32_t nai;
+            memcpy(&pos, q + 4, 4); memcpy(&nai, q + 16, 4);
+            q += 24;
+            r.pos0 = pos;
+            const uint32_t n_allele = nai >> 16, n_info = nai & 0xffff;
+            Typed t;
+            if (!bcf_typed(q, se, t)) return ifail(VLR_ERR_INVALID_ARGUMENT, "bad ID field in %s", in_path);
+            for (uint32_t a = 0; a < n_allele; ++a) {
+                if (!bcf_typed(q, se, t) || (t.type != 7 && t.n != 0)) return ifail(VLR_ERR_INVALID_ARGUMENT, "bad allele in %s", in_path);
+                std::string s((const char*)t.data, t.n);
+                if (a == 0) r.ref = s; else r.alts.push_back(s);
+            }
+            if (!bcf_typed(q, se, t)) return ifail(VLR_ERR_INVALID_ARGUMENT, "bad FILTER field in %s", in_path);
+            for (uint32_t k = 0; k < n_info; ++k) {
+                Typed key, val;
+                if (!bcf_typed(q, se, key) || key.n != 1 || !bcf_typed(q, se, val)) return ifail(VLR_ERR_INVALID_ARGUMENT, "bad INFO field in %s", in_path);
+                const int32_t ki = typed_int(key, 0);
+                const int kt = (ki >= 0 && (size_t)ki < key_tag.size()) ? key_tag[(size_t)ki] : -1;
+                if (kt >= 0 && val.type == 5) {
+                    auto& v = r.prob[(size_t)kt];
+                    for (uint32_t i = 0; i < val.n; ++i) {
+                        uint32_t bits;
+                        memcpy(&bits, val.data + 4 * (size_t)i, 4);
+                        if (bits == 0x7F800002u) break;  // end of vector
+                        float x;
+                        memcpy(&x, &bits, 4);
+                        v.push_back(bits == 0x7F800001u ? NAN : (double)x);
+                    }
+                    if (v.empty()) v.push_back(NAN);  // (a present tag is a list: keeps "tag absent" apart)
+                } else if (kt == -2 && val.type == 7) {
+                    r.event.assign((const char*)val.data, val.n);
+                    while (!r.event.empty() && r.event.back() == '\0') r.event.pop_back();
+                    r.has_event = true;
+                } else if (kt == -3 && val.type == 7) {
+                    r.svtype.assign((const char*)val.data, val.n);
+                    while (!r.svtype.empty() && r.svtype.back() == '\0') r.svtype.pop_back();
+                } else if ((kt == -4 || kt == -5) && val.type >= 1 && val.type <= 3) {
+                    static const int32_t miss[4] = {0, -128, -32768, (int32_t)0x80000000}, eov[4] = {0, -127, -32767, (int32_t)0x80000001};
+                    std::vector<int64_t> vals;
+                    for (uint32_t i = 0; i < val.n; ++i) {
+                        const int32_t x = typed_int(val, i);
+                        if (x == eov[val.type]) continue;
+                        vals.push_back(x == miss[val.type] ? -1 : (kt == -4 ? std::llabs((long long)x) : (int64_t)x));
+                    }
+                    if (kt == -4) { r.has_svlen = true; r.svlen = vals; }
+                    else if (!vals.empty()) { r.has_end = true; r.end0 = vals[0] - 1; }
+                }
+            }
+            recs.push_back(std::move(r));
+            p += len;
+        }
+    }
+    const int64_t N = (int64_t)recs.size();
+    std::vector<std::vector<VarType>> types((size_t)N);
+    for (int64_t i = 0; i < N; ++i)
+        if (!variant_types(recs[(size_t)i], types[(size_t)i], err)) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s (record %lld of %s)", err.c_str(), (long long)i, in_path);
+    // threshold (fdr.rs:62-141)
+    const double alpha_ln = std::log(alpha);
+    bool have_thr = false;
+    double thr = 0.0;
+    if (local) { have_thr = true; thr = alpha < 1.0 ? std::log1p(-alpha) : -INFINITY; }
+    else if (alpha != 1.0) {
+        std::vector<int> dist_tags;
+        if (smart) { dist_tags.push_back(t_absent); if (!retain) dist_tags.push_back(t_artifact); }
+        else dist_tags = ev_tags;
+        std::vector<double> dist, sums;
+        std::unordered_set<std::string> seen;
+        for (int64_t i = 0; i < N; ++i) {  // utils/mod.rs:236-270: one entry per breakend event
+            const CallRec& r = recs[(size_t)i];
+            if (r.has_event) { if (seen.count(r.event)) continue; seen.insert(r.event); }
+            tags_prob_sum(r, types[(size_t)i], dist_tags, tf, sums);
+            for (double s : sums) if (s == s) dist.push_back(s);
+        }
+        int status = 0;
+        const int rc = vlr_fdr_threshold(device, dist.data(), (int64_t)dist.size(), smart ? 1 : 0, alpha_ln, &thr, &status);
+        if (rc != 0) return rc;
+        if (status == VLR_FDR_VALUE) have_thr = true;
+        else if (status == VLR_FDR_LN_ONE) { have_thr = true; thr = 0.0; }
+    }
+    // filter_by_threshold (utils/mod.rs:288-374)
+    std::vector<int> ftags = ev_tags, absent_tags{t_absent};
+    if (smart && retain) ftags.push_back(t_artifact); else absent_tags.push_back(t_artifact);
+    std::unordered_map<std::string, bool> decisions;
+    std::vector<uint8_t> header_bytes(data.data(), data.data() + 9 + l_text);
+    std::vector<uint8_t> body;
+    int64_t kept = 0;
+    std::vector<double> pe, pa;
+    for (int64_t i = 0; i < N; ++i) {
+        const CallRec& r = recs[(size_t)i];
+        tags_prob_sum(r, types[(size_t)i], ftags, tf, pe);
+        if (smart) tags_prob_sum(r, types[(size_t)i], absent_tags, tf, pa);
+        bool keep_any = false;
+        for (size_t v = 0; v < pe.size(); ++v) {
+            bool keep;
+            auto it = r.has_event ? decisions.find(r.event) : decisions.end();
+            if (r.has_event && it != decisions.end()) keep = it->second;
+            else {
+                const double prob_events = pe[v];
+                double p = prob_events;
+                if (smart) { const double a = v < pa.size() ? pa[v] : NAN; p = (a == a) ? ln_one_minus_exp(a) : NAN; }
+                if (p == p && have_thr) keep = p > thr || relative_eq(p, thr);
+                else if (p == p) keep = true;
+                else keep = false;
+                if (smart) keep = keep && (prob_events == prob_events && prob_events > std::log(0.5));
+                if (r.has_event) decisions[r.event] = keep;
+            }
+            keep_any = keep_any || keep;
+        }
+        if (keep_any) { body.insert(body.end(), r.raw, r.raw + r.raw_len); ++kept; }
+    }
+    if (!write_bgzf_file(out_path, {&header_bytes, &body}, n_threads, 6, err)) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s", err.c_str());
+    if (n_kept) *n_kept = kept;
+    if (n_total) *n_total = N;
+    return VLR_OK;
+}

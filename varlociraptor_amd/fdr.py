@@ -240,3 +240,28 @@ def control_fdr(records: List[dict], events: Sequence[str], alpha: float, vartyp
         if keep_any:
             kept.append(rec)
     return kept
+
+
+def filter_calls_native(in_path: str, out_path: str, events: Sequence[str], alpha: float, vartype=None, local: bool = False, smart: bool = False,
+                        smart_retain_artifacts: bool = False, device: int = 0, threads: int = 0) -> Tuple[int, int]:
+    """vlr_calls_filter_fdr (include/vlr.h): the whole command in the engine — calls BCF in, kept records out, threshold search on
+    the device.  Returns (kept, total).  vartype = (kind, (lo, hi) | None) | None as control_fdr's."""
+    import ctypes as C
+    from . import engine
+    L = engine.lib()
+    L.vlr_calls_filter_fdr.restype = C.c_int
+    L.vlr_calls_filter_fdr.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.c_double, C.c_uint32, C.c_char_p, C.c_int64, C.c_int64,
+                                       C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    ev = (C.c_char_p * len(events))(*[e.encode() for e in events])
+    mode = (1 if local else 0) | (2 if smart else 0) | (4 if smart_retain_artifacts else 0)
+    kind, lo, hi = None, -1, -1
+    if vartype is not None:
+        kind, rng = vartype
+        if rng is not None:
+            lo, hi = int(rng[0]), int(min(rng[1], 1 << 62))
+    kept, total = C.c_int64(), C.c_int64()
+    rc = L.vlr_calls_filter_fdr(in_path.encode(), out_path.encode(), len(events), ev, float(alpha), mode, kind.encode() if kind else None, lo, hi,
+                                int(device), int(threads), C.byref(kept), C.byref(total))
+    if rc != 0:
+        raise engine.EngineError(rc, (L.vlr_last_error() or b"").decode())
+    return int(kept.value), int(total.value)
