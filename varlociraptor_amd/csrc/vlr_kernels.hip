@@ -462,6 +462,9 @@ struct DdAcc {
 __device__ __forceinline__ void ddacc_add(DdAcc& a, double v, double m, bool on) {
     if (on && v != VLR_NEG_INF) a.s = vlr_det::dd_add(a.s, vlr_det::det_exp(v - m));
 }
+__device__ __forceinline__ void ddacc_add_e(DdAcc& a, double e, bool on) {  // e = det_exp(v - m) of a finite v
+    if (on) a.s = vlr_det::dd_add(a.s, e);
+}
 __device__ inline double ddacc_exp(const DdAcc& a, double m) {
     vlr_det::dd t = a.s;
     { vlr_det::dd u{dpp_f64<0xB1>(t.hi), dpp_f64<0xB1>(t.lo)}; t = vlr_det::dd_add_dd(t, u); }
@@ -632,6 +635,7 @@ __device__ __forceinline__ void reduce_terms_n(int cnt, double* P, int* E) {
 }
 
 // ln pileup likelihood at np <= 4 points (alpha, beta) on all 64 lanes; lane j < np writes res[j]
+__device__ __forceinline__ double ln_mantissa(double m);
 __device__ inline void eval_pileup(const double* __restrict__ coef, const double* __restrict__ ecoef, int D, bool fast, int np, const double* ptA,
                                    const double* ptB, double* res, int lane) {
     double al[4], be[4], P[4];
@@ -645,7 +649,8 @@ __device__ inline void eval_pileup(const double* __restrict__ coef, const double
     reduce_terms_n<64>(np, P, E);
     const double Pm = lane == 1 ? P[1] : lane == 2 ? P[2] : lane == 3 ? P[3] : P[0];
     const int Em = lane == 1 ? E[1] : lane == 2 ? E[2] : lane == 3 ? E[3] : E[0];
-    if (lane < np) res[lane] = log(Pm) + (double)Em * kLn2;
+    // (Pm is a mantissa in [1/2, 1) after the reduction, or exactly zero: a term that is zero makes the likelihood zero)
+    if (lane < np) res[lane] = (Pm > 0.0 ? ln_mantissa(Pm) : (Pm == 0.0 ? VLR_NEG_INF : Pm)) + (double)Em * kLn2;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3364,10 +3369,15 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
             bool keep = valid && !(remove_nonstd && f_orient(f) == VLR_ORIENT_OTHER);
             bool strong_ref = keep && (pr - pa) > kLn20;
             int strand = f_strand(f);
-            ddacc_add(sb_all, pm, m_sb_all, strong_ref && strand != VLR_STRAND_BOTH);
-            ddacc_add(sb_fwd, pm, m_sb_fwd, strong_ref && strand == VLR_STRAND_FORWARD);
-            ddacc_add(pa_all, pm, m_all, strong_ref);
-            ddacc_add(pa_major, pm, m_major, strong_ref && (f & VLR_F_READPOS_MAJOR));
+            // exp(pm - maximum) once per distinct maximum: the four sums over prob_mapping differ in their subsets only, and their
+            // maxima coincide whenever the reads share the top mapping quality (same argument, same value: bit-identical sums)
+            const bool on_pm = strong_ref && pm != VLR_NEG_INF;
+            double e_all = 0.0;
+            if (__ballot(on_pm)) e_all = vlr_det::det_exp(pm - m_all);
+            ddacc_add_e(sb_all, (m_sb_all == m_all) ? e_all : vlr_det::det_exp(pm - m_sb_all), on_pm && strand != VLR_STRAND_BOTH);
+            ddacc_add_e(sb_fwd, (m_sb_fwd == m_all) ? e_all : vlr_det::det_exp(pm - m_sb_fwd), on_pm && strand == VLR_STRAND_FORWARD);
+            ddacc_add_e(pa_all, e_all, on_pm);
+            ddacc_add_e(pa_major, (m_major == m_all) ? e_all : vlr_det::det_exp(pm - m_major), on_pm && (f & VLR_F_READPOS_MAJOR));
             ddacc_add(pa_rate, pm + phb, m_rate, strong_ref);
         }
         const double e_all = ddacc_exp(pa_all, m_all), e_major = ddacc_exp(pa_major, m_major), e_rate = ddacc_exp(pa_rate, m_rate);
@@ -3583,7 +3593,8 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                     double sc_alt = (h == H_SCB) ? ((f & VLR_F_SOFTCLIPPED) ? 1.0 : 0.0) : 1.0;
                     // homopolymer (homopolymer_error.rs:23-44): prob_ref = prob_alt, prob_any = 1
                     double he_lp = (h == H_HE) ? hpa : hpv;
-                    double he_alt = (he_lp == he_lp) ? exp(he_lp) : 1.0;
+                    double he_alt = 1.0;
+                    if (__ballot(he_lp == he_lp)) he_alt = (he_lp == he_lp) ? exp(he_lp) : 1.0;  // (no homopolymer evidence in the whole row: no exponential)
                     // alt locus (alt_locus_bias.rs:63-113)
                     double al_alt = 0.5, al_ref = 0.5;
                     if (h == H_ALB) {
@@ -3603,7 +3614,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                     double mis = -expm1(pm);  // prob_mismapping = ln_one_minus_exp(pm) (read_observation.rs:283-286)
                     double A = exp(pa) * fa, R = exp(pr) * fr;
                     double uu = mis * exp(miss) * fany;
-                    double sv = exp(psa);
+                    const double sv = ehas_s ? exp(psa) : 1.0;  // (!ehas: prob_sample_alt == 0 on every kept observation of the sample, e^0 = 1)
                     bool uflow = (A == 0.0 && fa != 0.0 && pa > VLR_NEG_INF) || (R == 0.0 && fr != 0.0 && pr > VLR_NEG_INF);
                     double d = A - R;
                     double cc_ = wv * R + uu, cq_ = wv * sv * d, ce_ = wv * (1.0 - sv) * d;
