@@ -1536,6 +1536,7 @@ std::string fmt_g(float x) {
 }
 bool relative_eq(double a, double b) {
     if (a == b) return true;
+    if (std::isinf(a) || std::isinf(b)) return false;  // (approx::RelativeEq: infinities are equal only to themselves)
     const double d = std::fabs(a - b), eps = std::numeric_limits<double>::epsilon();
     return d <= eps || d <= std::max(std::fabs(a), std::fabs(b)) * eps;
 }
