@@ -1794,10 +1794,16 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
     double cc[NR], cq[NR];
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
+        // (slots every lane fills — 16 (j + 1) <= D, wave-uniform — need no masks; one slot at most is partial)
         const int i = rl0 + 16 * j;
-        const double* a = c.coef + 2 * (q.off + (i < D ? i : 0));
-        const double c0 = a[0], q0 = a[1];
-        cc[j] = i < D ? c0 : 1.0; cq[j] = i < D ? q0 : 0.0;
+        if (16 * (j + 1) <= D) {
+            const double* a = c.coef + 2 * (q.off + i);
+            cc[j] = a[0]; cq[j] = a[1];
+        } else if (16 * j < D) {
+            const double* a = c.coef + 2 * (q.off + (i < D ? i : 0));
+            const double c0 = a[0], q0 = a[1];
+            cc[j] = i < D ? c0 : 1.0; cq[j] = i < D ? q0 : 0.0;
+        } else { cc[j] = 1.0; cq[j] = 0.0; }
     }
     // The rows of a batch run the same PHASE at the same time (wave-uniform `up`, scalar branches): Simpson grids first (rare),
     // then INIT, the ROUNDs while any row's bracket is still wider than its resolution (rows that are through wait: the tail has the
@@ -1811,7 +1817,8 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
     int up = any_simp ? UP_SIMPSON : UP_INIT;
     const int kmax = any_simp ? max(max(__builtin_amdgcn_readlane(simpson_n, 0), __builtin_amdgcn_readlane(simpson_n, 16)),
                                     max(__builtin_amdgcn_readlane(simpson_n, 32), __builtin_amdgcn_readlane(simpson_n, 48))) : 0;
-    const double sstep = simp ? (hi - lo) / (double)(simpson_n - 1) : 0.0;
+    double sstep = 0.0;
+    if (any_simp) sstep = simp ? (hi - lo) / (double)(simpson_n - 1) : 0.0;  // (a division: only where a grid is walked)
     int k = 0, tn = 0;
     bool failed = false, sawnan = false;
     const bool all_fast = __ballot(q.rowon && !q.cls_fast) == 0ull;
