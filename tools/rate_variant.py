@@ -4,7 +4,7 @@ import numpy as np, torch
 from varlociraptor_amd import engine, synth
 from bench import generate
 n=200000
-for name in ["config3","config2"]:
+for name in os.environ.get("VLR_RATE_CONFIGS", "config3,config2").split(","):
     cfg = synth.CONFIGS[name]()
     batch = generate(name, n, 0)
     dbatch = engine.DeviceBatch(batch, "cuda:0")

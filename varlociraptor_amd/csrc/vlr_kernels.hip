@@ -266,8 +266,11 @@ __device__ inline void lse_add(double& M, double& S, double v) {
     if (v == VLR_NEG_INF) return;
     if (M != M) return;
     if (M == VLR_NEG_INF) { M = v; S = 1.0; return; }
-    if (v > M) { S = S * exp(M - v) + 1.0; M = v; }
-    else S += exp(v - M);
+    // one exponential for both orders: exp(M - v) for v > M and exp(v - M) otherwise are exp(-|v - M|) (the negation is exact)
+    const bool up = v > M;
+    const double e = exp(up ? M - v : v - M);
+    if (up) { S = S * e + 1.0; M = v; }
+    else S += e;
 }
 __device__ inline double lse_value(double M, double S) {
     if (M == VLR_NEG_INF) return VLR_NEG_INF;
@@ -336,7 +339,7 @@ __device__ inline double observable_max(const RangeV& r, int n) {  // 1198-1216
     double dn = (double)n;
     if (n < 10 || !(dn * (r.end - r.start) > 1.0)) return r.end;
     double c = dn * r.end;
-    if (r.rex && fmod(c, 1.0) == 0.0) c -= 1.0;
+    if (r.rex && c == floor(c)) c -= 1.0;  // (c % 1.0 == 0.0 of the reference: c is an integer; fmod is a loop on this target)
     c = floor(c);
     if (c == 0.0) return r.end;
     return floor(c) / dn;
@@ -348,7 +351,7 @@ __device__ inline double observable_min(const RangeV& r, int n) {  // 1170-1196
         min_vaf = r.start;
     } else {
         double c = dn * r.start;
-        if (r.lex && fmod(c, 1.0) == 0.0) {
+        if (r.lex && c == floor(c)) {
             double adjusted_end = observable_max(r, n);
             double s1 = ceil(c + 1.0) / dn;
             if (s1 <= 1.0 && s1 <= adjusted_end) return s1;
@@ -636,6 +639,9 @@ __device__ __forceinline__ void reduce_terms_n(int cnt, double* P, int* E) {
 
 // ln pileup likelihood at np <= 4 points (alpha, beta) on all 64 lanes; lane j < np writes res[j]
 __device__ __forceinline__ double ln_mantissa(double m);
+// ln of what reduce_terms leaves of a pileup product: a mantissa in [1/2, 1), exactly zero (a term that is zero makes the
+// likelihood zero) or NaN
+__device__ __forceinline__ double ln_product_mantissa(double Pm) { return Pm > 0.0 ? ln_mantissa(Pm) : (Pm == 0.0 ? VLR_NEG_INF : Pm); }
 __device__ inline void eval_pileup(const double* __restrict__ coef, const double* __restrict__ ecoef, int D, bool fast, int np, const double* ptA,
                                    const double* ptB, double* res, int lane) {
     double al[4], be[4], P[4];
@@ -650,7 +656,7 @@ __device__ inline void eval_pileup(const double* __restrict__ coef, const double
     const double Pm = lane == 1 ? P[1] : lane == 2 ? P[2] : lane == 3 ? P[3] : P[0];
     const int Em = lane == 1 ? E[1] : lane == 2 ? E[2] : lane == 3 ? E[3] : E[0];
     // (Pm is a mantissa in [1/2, 1) after the reduction, or exactly zero: a term that is zero makes the likelihood zero)
-    if (lane < np) res[lane] = (Pm > 0.0 ? ln_mantissa(Pm) : (Pm == 0.0 ? VLR_NEG_INF : Pm)) + (double)Em * kLn2;
+    if (lane < np) res[lane] = ln_product_mantissa(Pm) + (double)Em * kLn2;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -816,9 +822,9 @@ __device__ inline double sample_lik_point(Ctx& c, int s, double a, double b) {  
     reduce_terms<1, 64>(P1, E1);
     if (c.lane == 0) { w->work[0] += 1; w->work[1] += (unsigned long long)D; }
 #ifdef VLR_NO_RESCUE
-    return uni_d(log(P1[0]) + (double)E1[0] * kLn2);
+    return uni_d(ln_product_mantissa(P1[0]) + (double)E1[0] * kLn2);
 #else
-    return uni_d(log(P1[0]) + (double)(E1[0] + kshift(c)[s]) * kLn2);
+    return uni_d(ln_product_mantissa(P1[0]) + (double)(E1[0] + kshift(c)[s]) * kLn2);
 #endif
 }
 __device__ inline double sample_lik(Ctx& c, int s, double a, double b) {
@@ -3852,9 +3858,16 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
     // ============================ phase C: posteriors + MAP ============================
     // bio Model::compute: marginal = ln_sum_exp(event values); posterior = value - marginal
     const int n_out = p.n_named + 2;
+    // the value of event slot u (M + ln S of its streaming sum) once, on lane u (n_univ <= 2 kMaxNamedEvents + 1 = 61): the loops
+    // below used to take the same logarithm four times per slot on all lanes
+    VLR_SYNC();
+    const int u_l = lane < p.n_univ ? lane : 0;
+    const double evM_l = evM[u_l];
+    const double evV_l = lse_value(evM_l, evS[u_l]);
     double mM = VLR_NEG_INF, mS = 0.0;
     for (int u = 0; u < p.n_univ; ++u) {
-        double v = (evM[u] != evM[u]) ? evM[u] : lse_value(evM[u], evS[u]);
+        const double m_u = lane_d(evM_l, u);
+        double v = (m_u != m_u) ? m_u : lane_d(evV_l, u);
         lse_add(mM, mS, v);
     }
     double marginal = (mM != mM) ? mM : lse_value(mM, mS);
@@ -3867,7 +3880,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
     for (int u = 0; u < p.n_univ; ++u) {
         bool twin = (u > 0) && ((u & 1) == 0);
         if (twin && !have_twins) continue;
-        double v = lse_value(evM[u], evS[u]);
+        double v = lane_d(evV_l, u);
         double post = v - marginal;
         if (u == 0 || !(post < best_post)) { best = u; best_post = post; }  // last maximum wins (itertools minmax)
         if (twin) lse_add(aM, aS, post);
@@ -3877,13 +3890,13 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
     for (int u = 0; u < p.n_univ; ++u) {
         bool twin = (u > 0) && ((u & 1) == 0);
         if (twin) continue;
-        double post = lse_value(evM[u], evS[u]) - marginal;
+        double post = lane_d(evV_l, u) - marginal;
         if (!(post < prob_artifact)) is_artifact = false;
     }
     double* lp = out.ln_posterior + locus * n_out;
     if (lane == 0) {
-        lp[0] = lse_value(evM[0], evS[0]) - marginal;
-        for (int e = 0; e < p.n_named; ++e) lp[1 + e] = lse_value(evM[1 + 2 * e], evS[1 + 2 * e]) - marginal;
+        lp[0] = lane_d(evV_l, 0) - marginal;
+        for (int e = 0; e < p.n_named; ++e) lp[1 + e] = lane_d(evV_l, 1 + 2 * e) - marginal;
         lp[n_out - 1] = prob_artifact;
         if (out.ln_marginal) out.ln_marginal[locus] = marginal;
         if (out.best_event) out.best_event[locus] = best;
