@@ -675,28 +675,30 @@ __device__ inline double integrate_table(const double* tx, const double* tv, int
         sv[rank] = tv[i];
     }
     VLR_SYNC();
-    double M = VLR_NEG_INF;
-    double t0 = VLR_NEG_INF, t1 = VLR_NEG_INF;
-    {
-        int k = lane;
-        if (k + 1 < n) {
-            double w = (sx[k + 1] - sx[k]) / 2.0;
-            t0 = ln_add_exp(sv[k], sv[k + 1]) + log(w);
-        }
-        k = lane + 64;
-        if (k + 1 < n) {
-            double w = (sx[k + 1] - sx[k]) / 2.0;
-            t1 = ln_add_exp(sv[k], sv[k + 1]) + log(w);
+    // the trapezoid in the linear domain relative to the largest value, regrouped per grid point as in the row epilogue of
+    // run_chain_batch: sum_seg (e_k + e_{k+1}) (x_{k+1} - x_k)/2 = sum_k e_k (x_{k+1} - x_{k-1})/2, one-sided at the ends — one
+    // exponential per point and one logarithm instead of ln_add_exp + ln per segment
+    double vk[2], wk[2];
+    bool nan = false;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int k = lane + 64 * h;
+        vk[h] = VLR_NEG_INF; wk[h] = 0.0;
+        if (k < n) {
+            const double xl = sx[k > 0 ? k - 1 : 0], xr = sx[k + 1 < n ? k + 1 : k];
+            vk[h] = sv[k];
+            wk[h] = (xr - xl) / 2.0;
+            nan = nan || (vk[h] != vk[h]);
         }
     }
-    bool nan = (t0 != t0) || (t1 != t1);
-    unsigned long long anynan = __ballot(nan);
-    M = wave_max(fmax(t0 == t0 ? t0 : VLR_NEG_INF, t1 == t1 ? t1 : VLR_NEG_INF));
+    const unsigned long long anynan = __ballot(nan);
+    const double M = wave_max(fmax(vk[0] == vk[0] ? vk[0] : VLR_NEG_INF, vk[1] == vk[1] ? vk[1] : VLR_NEG_INF));
     double r;
     if (anynan) r = __builtin_nan("");
-    else if (M == VLR_NEG_INF) r = VLR_NEG_INF;
+    else if (M == VLR_NEG_INF || n < 2) r = VLR_NEG_INF;
     else {
-        double s = (t0 == VLR_NEG_INF ? 0.0 : exp(t0 - M)) + (t1 == VLR_NEG_INF ? 0.0 : exp(t1 - M));
+        double s = (vk[0] == VLR_NEG_INF ? 0.0 : exp(vk[0] - M) * wk[0]);
+        if (n > 64) s += (vk[1] == VLR_NEG_INF ? 0.0 : exp(vk[1] - M) * wk[1]);
         s = wave_sum(s);
         r = M + log(s);
     }
