@@ -13,7 +13,7 @@ L = engine.lib()
 out = (C.c_ulonglong * 40)()
 L.vlr_plan_profile_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 assert L.vlr_plan_profile_counters(plan._h, out) == 0
-names = ["A stats", "gating", "coefficients", "walk/other", "deliver held/deferred", "single integrate", "batch prep", "batch rounds", "batch epilogue", "phase C", "#batch runs", "#single chains", "round: products", "round: reduce", "round: log+prior", "round: advance", "outer: task setup", "outer: vary eval", "outer: entry/delivery", "iter: next root", "iter: root entry", "walk", "iter: root exit", "discrete roots", "walk: resume", "deliver: fetch", "deliver: MAP", "outer: advance", "outer: finish", "outer: issue", "outer: begin", "loop: pre-batch"] + ["-"] * 8
+names = ["A stats", "gating", "coefficients", "walk/other", "deliver held/deferred", "single integrate", "batch prep", "batch rounds", "batch epilogue", "phase C", "#batch runs", "#single chains", "round: products", "round: reduce", "round: log+prior", "round: advance", "outer: task setup", "outer: vary eval", "outer: entry/delivery", "iter: next root", "iter: root entry", "walk", "iter: root exit", "discrete roots", "walk: resume", "deliver: fetch", "deliver: MAP", "outer: advance", "outer: finish", "outer: issue", "outer: begin", "loop: pre-batch", "walk: sample node", "walk: range setup", "walk: deferred leaf", "walk: to leaf"] + ["-"] * 4
 cnt = {10, 11}
 tot = sum(v for i, v in enumerate(out) if i not in cnt)
 for nm, v in zip(names, out):

@@ -2709,6 +2709,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                         }
                     }
                 }
+                PROF_ADD(c, 32);  // walk: Sample node, bounds / candidates
                 if (dead) { rv = VLR_NEG_INF; pc = PC_RETURN; }
                 else if (sp >= c.nframes) { c.status |= VLR_LOCUS_TABLE_FULL; rv = __builtin_nan(""); pc = PC_RETURN; }
                 else {
@@ -2765,6 +2766,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                         nrange++;
                         c.present |= (1 << s);
                         c.disc &= ~(1 << s);
+                        PROF_ADD(c, 33);  // walk: Range frame set-up (observable bounds)
                         pc = PC_RANGE_ISSUE;
                     }
                 }
@@ -2809,6 +2811,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                     c.deferred = 2;
                     return 0.0;
                 }
+                PROF_ADD(c, 35);  // walk: up to the leaf Range
                 if (c.defer_ok) {
                     // defer: this root is exactly one innermost chain (all enclosing frames are single-valued)
                     const int inner = UNI(r.sample), S = c.S, row = c.ndef;
@@ -2831,6 +2834,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                     VLR_SYNC();
                     c.ndef = row + 1;
                     c.deferred = 1;
+                    PROF_ADD(c, 34);  // walk: deferred leaf chain (fixed likelihoods, prior index, task)
                     return 0.0;
                 }
                 rv = run_leaf_chain(c, r, c.rowX, c.rowV);
