@@ -652,9 +652,27 @@ __device__ inline void eval_pileup(const double* __restrict__ coef, const double
         al[j] = ptA[jj]; be[j] = ptB[jj]; P[j] = 1.0; E[j] = 0;
     }
     accum_terms_n<64>(np, coef, ecoef, D, lane, fast, al, be, P, E);
-    reduce_terms_n<64>(np, P, E);
-    const double Pm = lane == 1 ? P[1] : lane == 2 ? P[2] : lane == 3 ? P[3] : P[0];
-    const int Em = lane == 1 ? E[1] : lane == 2 ? E[2] : lane == 3 ? E[3] : E[0];
+    // reduction over the wave: inside the quads for every point, then lane t of every quad keeps point t and the quads of a row,
+    // then the four rows (through the LDS crossbar) are combined for that point alone: lane t < np ends with point t
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j < np) {
+            P[j] *= dpp_f64<0xB1>(P[j]); E[j] += dpp_i32<0xB1>(E[j]);      // quad_perm [1,0,3,2]
+            P[j] *= dpp_f64<0x4E>(P[j]); E[j] += dpp_i32<0x4E>(E[j]);      // quad_perm [2,3,0,1]
+        }
+    }
+    const int tq = lane & 3;
+    double Pm = tq == 1 ? P[1] : tq == 2 ? P[2] : tq == 3 ? P[3] : P[0];
+    int Em = tq == 1 ? E[1] : tq == 2 ? E[2] : tq == 3 ? E[3] : E[0];
+    Pm *= dpp_f64<0x124>(Pm); Em += dpp_i32<0x124>(Em);                    // row_ror:4
+    Pm *= dpp_f64<0x128>(Pm); Em += dpp_i32<0x128>(Em);                    // row_ror:8
+    Pm *= __shfl_xor(Pm, 16); Em += __shfl_xor(Em, 16);
+    Pm *= __shfl_xor(Pm, 32); Em += __shfl_xor(Em, 32);
+    {
+        int e2;
+        Pm = __builtin_frexp(Pm, &e2);  // product of <= 64 mantissas >= 2^-64: one renormalisation suffices
+        Em += e2;
+    }
     // (Pm is a mantissa in [1/2, 1) after the reduction, or exactly zero: a term that is zero makes the likelihood zero)
     if (lane < np) res[lane] = ln_product_mantissa(Pm) + (double)Em * kLn2;
 }
@@ -1830,6 +1848,7 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
     int k = 0, tn = 0;
     bool failed = false, sawnan = false;
     const bool all_fast = __ballot(q.rowon && !q.cls_fast) == 0ull;
+    const bool cap_safe = p.table_cap < kTableCap;  // the host's bound was not clamped (vlr_host.cpp: table capacity)
     double L = lo, R = hi, vL = VLR_NEG_INF, vR = VLR_NEG_INF, mid = lo;
     PROF_ADD(c, 7);  // batch prologue (task fields, coefficient registers)
     for (;;) {
@@ -1869,19 +1888,25 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
             px2 = nn < 3 ? px1 : px2;
             px1 = nn < 2 ? px0 : px1; px2 = nn < 2 ? px0 : px2;
         }
-        const bool over = on && (tn + nn > q.cap);
-        failed = failed || over;
-        live = live && !over;
-        on = on && !over;
+        if (!cap_safe) {  // (an unclamped capacity covers every chain: 2 + 3 rounds + 6 points, rounds <= log_{4/3}(1/resolution) + 1)
+            const bool over = on && (tn + nn > q.cap);
+            failed = failed || over;
+            live = live && !over;
+            on = on && !over;
+        }
         double al[3], be[3], P[3];
         int E[3];
         {
             const double xs[3] = {px0, px1, px2};
+            if (q.has_by) {  // (wave-uniform: the integrated sample has a contaminant)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                al[t] = q.has_by ? q.rho * xs[t] + q.al_fix : xs[t];
-                be[t] = 0.0;
+                for (int t = 0; t < 3; ++t) al[t] = q.rho * xs[t] + q.al_fix;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) al[t] = xs[t];
             }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) be[t] = 0.0;
             if (q.ecoef != nullptr) {  // beta only matters where the third coefficients are not all zero
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
@@ -2191,6 +2216,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
         unsigned long long key[4];
         int rank[4];
         const bool srt = phase != RP_SIMPSON;  // per row: trapezoid over the sorted visited points (Simpson grids are in order)
+        const bool any_simpson = __ballot(rowon && !srt) != 0ull;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             xi[t] = __builtin_huge_val(); vi[t] = VLR_NEG_INF;
@@ -2303,8 +2329,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
                 const bool zero = (vi[t] == VLR_NEG_INF) | (M == VLR_NEG_INF) | (vi[t] != vi[t]);
                 const double ev = zero ? 0.0 : exp(vi[t] - M);
                 double wgt;
-                if (!srt) wgt = (i == 0 || i == n - 1) ? 1.0 : (double)(2 + (i % 2) * 2);
-                else {
+                {
                     // sum_seg (e_k + e_{k+1}) (x_{k+1} - x_k)/2 = sum_k e_k (x_{k+1} - x_{k-1})/2, one-sided at the ends
                     const int rk = on ? rank[t] : 0;
                     const double pred = tx[rk > 0 ? rk - 1 : 0], succ = tx[(rk + 1 < n) ? rk + 1 : rk];
@@ -2312,6 +2337,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
                     const double hi2 = (rk + 1 < n) ? succ : xi[t];
                     wgt = (hi2 - lo2) / 2.0;
                 }
+                if (any_simpson) wgt = srt ? wgt : ((i == 0 || i == n - 1) ? 1.0 : (double)(2 + (i % 2) * 2));  // Simpson grids (rare)
                 ssum += on ? ev * wgt : 0.0;
             }
         }
