@@ -888,7 +888,7 @@ __device__ inline void map_consider(Ctx& c, double joint, int inner, double x) {
     joint = uni_d(joint); x = uni_d(x); inner = UNI(inner);
     if (!(joint == joint)) return;
     bool better = joint > c.curJ;
-    if (c.curHyp >= 0 && same_joint(joint, c.curJ)) {
+    if (__builtin_expect(c.curHyp >= 0 && same_joint(joint, c.curJ), 0)) {
         if (c.hyp != (c.curHyp & 15)) { if (joint == c.curJ) better = c.hyp < (c.curHyp & 15); }
         else {
             bool same = true;
@@ -1410,7 +1410,7 @@ __device__ inline double leaf_joint(Ctx& c) {
     joint = uni_d(joint);
     if (joint != joint) c.status |= VLR_LOCUS_NAN;
     if (log_on(c)) log_leaf(c, joint);
-    if (c.replay) afd_consider(c, joint, -1, 0.0);
+    if (__builtin_expect(c.replay != 0, 0)) afd_consider(c, joint, -1, 0.0);
     else map_all(c, joint, -1, 0.0, c.contained != 0, c.alive);
     PROF_ADD(c, 22);  // leaf: MAP candidates
     return joint;
@@ -1857,7 +1857,7 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
         double px0, px1, px2;
         int nn;
         bool on;
-        if (up == UP_ROUND) {
+        if (__builtin_expect(up == UP_ROUND, 1)) {
             on = live && act;
             px0 = (R + L) / 2.0; px1 = (px0 + L) / 2.0; px2 = (R + px0) / 2.0; nn = 3;
             mid = on ? px0 : mid;
@@ -1888,7 +1888,7 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
             px2 = nn < 3 ? px1 : px2;
             px1 = nn < 2 ? px0 : px1; px2 = nn < 2 ? px0 : px2;
         }
-        if (!cap_safe) {  // (an unclamped capacity covers every chain: 2 + 3 rounds + 6 points, rounds <= log_{4/3}(1/resolution) + 1)
+        if (__builtin_expect(!cap_safe, 0)) {  // (an unclamped capacity covers every chain: 2 + 3 rounds + 6 points, rounds <= log_{4/3}(1/resolution) + 1)
             const bool over = on && (tn + nn > q.cap);
             failed = failed || over;
             live = live && !over;
@@ -1943,8 +1943,8 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
         const double x = rl == 0 ? px0 : rl == 1 ? px1 : px2;
         const double lik = q.fixed + (ln_mantissa(Psel) + (double)Esel * kLn2);
         double joint;
-        if (c.nlfc > 0 && !lfcs_ok(c, q.inner, x)) joint = VLR_NEG_INF;
-        else if (all_fast) joint = (x == 0.0 ? q.pr0 : q.pr1) + lik;  // every row inside a uniform-prior universe: class 0 at exactly 0, else 1
+        if (__builtin_expect(c.nlfc > 0, 0) && !lfcs_ok(c, q.inner, x)) joint = VLR_NEG_INF;
+        else if (__builtin_expect(all_fast, 1)) joint = (x == 0.0 ? q.pr0 : q.pr1) + lik;  // every row inside a uniform-prior universe: class 0 at exactly 0, else 1
         else {
             const int cls = q.cls_fast ? (x == 0.0 ? 0 : 1) : prior_class(p, q.inner, x);
             const double pv = cls == 0 ? q.pr0 : cls == 1 ? q.pr1 : cls == 2 ? q.pr2 : q.ptab[q.pidx + cls * q.istride];
@@ -1955,7 +1955,7 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
         if (owner) { q.tx[tn + rl] = x; q.tv[tn + rl] = joint; }
         tn = on ? tn + nn : tn;
         PROF_ADD(c, 14);  // pass: log + prior + store
-        if (up == UP_ROUND) {
+        if (__builtin_expect(up == UP_ROUND, 1)) {
             const double j1 = row_bcast<1>(joint), j2 = row_bcast<2>(joint);
             // argmax over {left, middle1, middle2, right}, lowest index wins ties (adaptive_integration.rs:70-82): as three
             // compare masks.  0: [L, m1]  1: [L, m2]  2: [m1, R]  3: [m2, R] — the new bracket keeps one end and takes one of the
@@ -2045,7 +2045,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
     // register-resident runner: the integrated sample is the only one whose likelihood moves with the chain (no sample is
     // contaminated by it), its pileup fits the register slots and its terms need no renormalisation
     const bool regrun = dep == (1 << inner) && D_in <= 16 * kRegSlots && ((UNI(w->vfast) >> inner) & 1);
-    if (regrun) {
+    if (__builtin_expect(regrun, 1)) {
         RegChain rc;
         rc.lo = lo; rc.hi = hi; rc.res = res; rc.fixed = fixed; rc.pr0 = pr0; rc.pr1 = pr1; rc.pr2 = pr2;
         rc.tx = tx; rc.tv = tv; rc.ptab = ptab; rc.pidx = pidx; rc.istride = istride; rc.simpson_n = simpson_n;
@@ -2187,8 +2187,8 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
     }
     }  // !regrun
     PROF_ADD(c, 15);
-    if (__ballot(failed)) c.status |= VLR_LOCUS_TABLE_FULL;
-    if (__ballot(sawnan)) c.status |= VLR_LOCUS_NAN;
+    if (__builtin_expect(__ballot(failed) != 0ull, 0)) c.status |= VLR_LOCUS_TABLE_FULL;
+    if (__builtin_expect(__ballot(sawnan) != 0ull, 0)) c.status |= VLR_LOCUS_NAN;
     if (rowon && rl == 0) {  // work counters
         atomicAdd(&w->work[0], (unsigned long long)tn);
         atomicAdd(&w->work[1], (unsigned long long)tn * dep_terms);
@@ -2556,9 +2556,9 @@ __device__ __forceinline__ bool bo_deliver(Ctx& c, const Frame& f, RangeSt& r, d
         VLR_SYNC();
         if (lane == 0) w->ops_vaf[s_out] = x;
         VLR_SYNC();
-        if (dead) continue;
+        if (__builtin_expect(dead, 0)) continue;
         const int hb = __builtin_amdgcn_readlane(hbl, i), n_i = __builtin_amdgcn_readlane(nl, i);
-        if (c.replay) {
+        if (__builtin_expect(c.replay != 0, 0)) {
             if (UNI(f.sv_mute) || table_has(txo, tn0 + c0 + i, x, lane)) continue;  // repeated outer VAF: same map keys
             afd_emit_row(c, i, s_in, n_i);
             continue;
@@ -2566,7 +2566,7 @@ __device__ __forceinline__ bool bo_deliver(Ctx& c, const Frame& f, RangeSt& r, d
         if (hb & 1) map_consider(c, lane_d(bJl, i), s_in, lane_d(bXl, i));
         // rare: candidates for other groups / containment via another path (also of a visited excluded range end)
         const int al_i = __builtin_amdgcn_readlane(alivel, i), co_i = __builtin_amdgcn_readlane(contl, i);
-        if (al_i != 0 || !co_i || (hb & 2)) {
+        if (__builtin_expect(al_i != 0 || !co_i || (hb & 2), 0)) {
             const ChainTask& T = w->task[i];
             const RangeV io{uni_d(T.ostart), uni_d(T.oend), UNI(T.olex), UNI(T.orex)};
             scan_chain_candidates(c, c.rowX + i * c.cap, c.rowV + i * c.cap, n_i, io, co_i, al_i, s_in);
@@ -2609,10 +2609,10 @@ __device__ __forceinline__ void flush_deliver(Ctx& c, int rowmask, double* evM, 
         const double dens = uni_d(T.result);
         if (dens != dens) c.status |= VLR_LOCUS_NAN;
         const int nq = UNI(T.n);
-        if (c.replay) afd_emit_row(c, i, s_in, nq);
+        if (__builtin_expect(c.replay != 0, 0)) afd_emit_row(c, i, s_in, nq);
         else {
             if (UNI(T.haveBest) & 1) map_consider(c, uni_d(T.bestJ), s_in, uni_d(T.bestX));
-            if (c.alive != 0 || !c.contained || (UNI(T.haveBest) & 2)) {
+            if (__builtin_expect(c.alive != 0 || !c.contained || (UNI(T.haveBest) & 2), 0)) {
                 const RangeV io{uni_d(T.ostart), uni_d(T.oend), UNI(T.olex), UNI(T.orex)};
                 scan_chain_candidates(c, c.rowX + i * c.cap, c.rowV + i * c.cap, nq, io, c.contained, c.alive, s_in);
             }
@@ -3663,7 +3663,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                     bool uflow = (A == 0.0 && fa != 0.0 && pa > VLR_NEG_INF) || (R == 0.0 && fr != 0.0 && pr > VLR_NEG_INF);
                     double d = A - R;
                     double cc_ = wv * R + uu, cq_ = wv * sv * d, ce_ = wv * (1.0 - sv) * d;
-                    if (scaled) {
+                    if (__builtin_expect(scaled != 0, 0)) {
                         // the three log-space addends of the observation's likelihood, their largest as the binary exponent k
                         const double lA = (fa > 0.0 && pa > VLR_NEG_INF) ? pm + pa + log(fa) : VLR_NEG_INF;
                         const double lR = (fr > 0.0 && pr > VLR_NEG_INF) ? pm + pr + log(fr) : VLR_NEG_INF;
