@@ -99,6 +99,22 @@ def test_set_and_range_spectra_mixed(oracle):
     check(oracle, sc, synth.generate(cfg, 200, seed=14), "set+range")
 
 
+@pytest.mark.parametrize("depth", [4.0, 30.0])
+def test_four_single_chain_roots_beside_a_nested_root(oracle, depth):
+    """`!b:{0.5,1.0} & a:0.0` normalises to FOUR roots that are one innermost chain each (overlapping ranges of b under a = 0);
+    next to a nested root (`b:[0,1]`, a free) the probe pass of the event loop ends with exactly four deferred chains and a
+    root left for the second pass.  Four cannot be held for a ride in the nested root's batches (two rows and the stash take
+    three): they have to run as a batch of their own — the first of them used to be dropped (found by fuzz seed 41)."""
+    from varlociraptor_amd.scenario import Contamination
+    samples = {"a": Sample(resolution=0.1, universe="[0.0,1.0]", contamination=Contamination(by="b", fraction=0.5)),
+               "b": Sample(resolution=0.02, universe="[0.0,1.0]")}
+    sc = Scenario(samples, {"ev0": "b:[0.0,1.0]", "ev1": "b:]0.5,1.0[ & a:]0.2,0.8[", "ev2": "(!b:{0.5,1.0} & a:0.0) | (!a:[0.0,1.0] & b:]0.5,1.0[)"})
+    assert len(sc.vaftree("ev2")) == 4
+    cfg = synth.SynthConfig(name="four", config_id=51, scenario=sc, depth=depth, type_mix={abi.VT_SNV: 0.7, abi.VT_INDEL: 0.3},
+                            classes=[("c0", 0.5, ((0.0, 0.0), (0.0, 0.2))), ("c1", 0.5, ((0.1, 0.3), (0.5, 1.0)))], purity=None)
+    check(oracle, sc, synth.generate(cfg, 200, seed=41), "four deferred chains + nested root, depth %g" % depth)
+
+
 def test_map_via_another_branch_at_excluded_range_end(oracle):
     """With fewer than 10 observations the excluded end of `!b:1.0` (= b:[0,1[) is still visited (formula.rs:1170-1216);
     that operand set belongs to the same event through its other branch `b:1.0` and can be its MAP (calling.rs:851-864)."""

@@ -3771,7 +3771,9 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                             pass = 1; e = first_ev; rc_ = 0; fresh = true;
                             ri = (e < 0) ? 0 : ldc(p.root_off + e);
                             r1 = (e < 0) ? 1 : ldc(p.root_off + e + 1);
-                            if (c.ndef > 0 && (c.replay || todo == 0ull)) {  // nothing left that could give them a ride
+                            // (a FULL set of four cannot be held — two rows and the stash take three —: it runs as a batch of its own here,
+                            //  as it would have if a fifth deferrable root had followed)
+                            if (c.ndef > 0 && (c.replay || todo == 0ull || c.ndef == kRows)) {  // nothing left that could give them a ride
                                 run_kind = 3; run_mask = (1 << c.ndef) - 1; run_inner = UNI(w->task[0].inner); c.ndef = 0;
                             } else if (c.ndef > 0) {
                                 // Held chains: instead of a batch of their own (three of four rows busy in the tumor-normal
