@@ -17,6 +17,8 @@ shard of that size.  Prints ONE JSON line on rank 0.
   --dry-run                                   launcher / collective check without a GPU (gloo, synthetic result records)
 """
 import argparse
+import ctypes as C
+import math
 import json
 import os
 import sys
@@ -102,6 +104,58 @@ def traffic_for(workload, n_units, build_id):
     return tj.get("hbm_bytes_per_launch")
 
 
+def reference_binary_baseline(cfg, batch, n_loci, cores):
+    """BASELINE.md §2 / SURVEY §8(d): if a `varlociraptor` executable is on the box, time the REFERENCE's own `call variants` on
+    observation BCFs written from the first `n_loci` loci of the same synthetic batch, one process per effective CPU over
+    contiguous shards of the records.  Returns None when no binary is present (the only state this image has been seen in)."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("varlociraptor")
+    if exe is None:
+        return None
+    from varlociraptor_amd import ingest
+    names = cfg.scenario.sample_names
+    tumor_normal = cfg.purity is not None and sorted(names) == ["normal", "tumor"]
+    if not tumor_normal and len(names) != 1:
+        return {"value": None, "note": "binary found at %s, but only the tumor-normal and single-sample scenarios have a command line here" % exe}
+    tmp = tempfile.mkdtemp(prefix="vlr_refbin_")
+    try:
+        version = subprocess.run([exe, "--version"], capture_output=True, text=True, timeout=30).stdout.strip()
+        per = -(-n_loci // cores)
+        cmds = []
+        for k in range(cores):
+            lo, hi = min(n_loci, k * per), min(n_loci, (k + 1) * per)
+            if hi <= lo:
+                continue
+            sub = batch.select(np.arange(lo, hi))
+            paths = {}
+            for s, name in enumerate(names):
+                paths[name] = os.path.join(tmp, "%s_%d.bcf" % (name, k))
+                ingest.write_observations(paths[name], sub, s)
+            out = os.path.join(tmp, "calls_%d.bcf" % k)
+            if tumor_normal:
+                cmd = [exe, "call", "variants", "tumor-normal", "--tumor", paths["tumor"], "--normal", paths["normal"], "--purity", str(cfg.purity)]
+            else:
+                sc = os.path.join(tmp, "scenario.yaml")
+                if not os.path.exists(sc):
+                    with open(sc, "w") as f:
+                        f.write("samples:\n  %s:\n    resolution: 0.01\n    universe: \"[0.0,1.0]\"\nevents:\n  present: \"%s:]0.0,1.0]\"\n" % (names[0], names[0]))
+                cmd = [exe, "call", "variants", "generic", "--scenario", sc, "--obs", "%s=%s" % (names[0], paths[names[0]])]
+            cmds.append((cmd, out))
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen(c, stdout=open(o, "wb"), stderr=subprocess.PIPE) for c, o in cmds]
+        errs = [p.communicate()[1] for p in procs]
+        dt = time.perf_counter() - t0
+        bad = [e.decode(errors="replace")[-300:] for p, e in zip(procs, errs) if p.returncode != 0]
+        if bad:
+            return {"value": None, "binary": exe, "version": version, "note": "call variants failed: " + bad[0]}
+        return {"value": n_loci / dt, "unit": "loci/s", "cores": len(cmds), "kind": "reference", "binary": exe, "version": version,
+                "sample": "first %d loci of the same batch written as observation BCFs, %d processes x contiguous shards, %.1f s (process start-up and BCF I/O included)" % (n_loci, len(cmds), dt)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def bench_realign(args, rank, world, local_rank, dev):
     import torch
     import torch.distributed as dist
@@ -118,9 +172,28 @@ def bench_realign(args, rank, world, local_rank, dev):
     pb.x, pb.y, pb.q, pb.band = base.x * tile, base.y * tile, base.q * tile, base.band * tile
     dp = realign.DevicePairs(pb, dev)
     gap = realign.GapParams()
+    mode = args.mode
+    hop = None
+    if mode == "homopolymer":  # nanopore-like run-length error rates (HopParams, realignment/pairhmm.rs:207-295; the default is all zero)
+        hop = realign.HopParams([math.log(0.02)] * 4, [math.log(0.03)] * 4, [math.log(0.3)] * 4, [math.log(0.3)] * 4)
+    if mode == "fast":
+        L = realign._bind()
+        L.vlr_realign_fast_batch.restype = C.c_int
+        L.vlr_realign_fast_batch.argtypes = [C.c_int, C.POINTER(realign.RealignDesc), C.c_void_p, C.c_void_p]
+
+    def run_once():
+        if mode == "exact":
+            dp.run(gap, local_rank, stream)
+        elif mode == "homopolymer":
+            dp.run_homopolymer(gap, hop, local_rank, stream)
+        else:
+            p = [t.data_ptr() for t in dp.t]
+            d = realign.RealignDesc(dp.n, p[0], p[1], p[2], p[3], p[4], None, gap.as_array())
+            rc = L.vlr_realign_fast_batch(local_rank, C.byref(d), dp.out.data_ptr(), stream)
+            assert rc == 0, rc
     stream = torch.cuda.current_stream().cuda_stream
     for _ in range(args.warmup):
-        dp.run(gap, local_rank, stream)
+        run_once()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -129,7 +202,7 @@ def bench_realign(args, rank, world, local_rank, dev):
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(args.steps):
-        dp.run(gap, local_rank, stream)
+        run_once()
     ev1.record()
     torch.cuda.synchronize()
     if world > 1:
@@ -166,16 +239,22 @@ def bench_realign(args, rank, world, local_rank, dev):
         sub.x, sub.y, sub.q, sub.band = base.x[:n_cpu], base.y[:n_cpu], base.q[:n_cpu], base.band[:n_cpu]
         oracle.lib()
         tc = time.perf_counter()
-        ref = oracle.pairhmm_batch(sub, gap, threads=cores)
+        if mode == "exact":
+            ref = oracle.pairhmm_batch(sub, gap, threads=cores)
+        elif mode == "homopolymer":
+            ref = oracle.homopoly_batch(sub, gap, hop)
+        else:
+            g4 = [gap.prob_insertion_artifact, gap.prob_deletion_artifact, gap.prob_insertion_extend_artifact, gap.prob_deletion_extend_artifact]
+            ref = np.array([oracle.pathhmm_best(sub.x[k], sub.y[k], sub.q[k], g4) for k in range(n_cpu)])
         t_cpu = time.perf_counter() - tc
         d = np.abs(got[:n_cpu] - ref)
         parity = {"n_checked": int(n_cpu), "max_abs_dlnprob": float(np.nanmax(d)), "vs": "CPU restatement (oracle/vlr_realign_oracle.cpp), parity unpinned for the third-party recursion"}
-        cpu = {"value": n_cpu / t_cpu, "unit": "pairs/s", "cores": cores, "kind": "port",
-               "sample": "first %d pairs of the same batch, %d threads, %.1f s" % (n_cpu, cores, t_cpu)}
+        cpu = {"value": n_cpu / t_cpu, "unit": "pairs/s", "cores": cores if mode == "exact" else 1, "kind": "port",
+               "sample": "first %d pairs of the same batch, %d threads, %.1f s" % (n_cpu, cores if mode == "exact" else 1, t_cpu)}
     achieved = dp.bytes / (kernel_ms * 1e-3) / 1e9
     cells = dp.cells
     return {
-        "metric": "read-allele pairs/sec (pair HMM, whole node)", "value": n_pairs * world * args.steps / elapsed, "unit": "pairs/s",
+        "metric": "read-allele pairs/sec (pair HMM, whole node)" if mode == "exact" else "read-allele pairs/sec (pair HMM mode %s, whole node)" % mode, "value": n_pairs * world * args.steps / elapsed, "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "realign: %d read-allele pairs/GPU (%d distinct, SNV/MNV/insertion/deletion loci, read windows %d..%d bases, reference windows %d bases, banded)" % (n_pairs, len(base), args.read_window, min(128, 2 * args.read_window), 3 * args.read_window),
@@ -265,10 +344,12 @@ def bench_cli(args, rank, world, local_rank, dev):
         dist.barrier()
     t0 = time.perf_counter()
     stages = {"read_s": 0.0, "call_s": 0.0, "write_s": 0.0}
+    ingest.total_timings(reset=True)
     for _ in range(args.steps):
         step()
         for k in stages:
             stages[k] += tm[k]
+    native = {k: v / args.steps for k, v in ingest.total_timings().items()}
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -292,7 +373,8 @@ def bench_cli(args, rank, world, local_rank, dev):
                    "parallelism": "records sharded x%d, one process per GPU" % world, "host_threads": os.cpu_count(), "effective_cpus": effective_cpus()},
         "stages_s": per, "stages_note": "seconds per step inside the reader / evaluation / writer threads of cli.call_variants; the three overlap across chunks of %s records (%d chunks per step), so their sum exceeds ms_per_step" % (os.environ.get("VLR_CLI_CHUNK", "16384"), tm.get("chunks", 1)),
         "stage_rates": {"read_records_per_s": n_loci / per["read_s"], "read_uncompressed_GBps": None, "call_loci_per_s": n_loci / per["call_s"], "write_records_per_s": n_loci / per["write_s"]},
-        "native_stage_seconds_last_step": ingest.last_timings(),
+        "native_stage_seconds_per_step": native,
+        "native_stage_note": "inside read_s: inflate and parse_decode are summed over the sample files (which run side by side), files_wall is their wall time, merge + strings build the table; inside write_s: encode = record formatting, deflate_write = BGZF + file",
         "files": {"observation_bcf_bytes": obs_bytes, "calls_bcf_bytes": calls_bytes, "observations": int(n_obs), "observation_write_s_untimed": t_write_obs},
         "roofline": None, "cpu_baseline": None, "build_id": engine.build_id(),
     }
@@ -311,6 +393,7 @@ def main():
     ap.add_argument("--afd-capacity", type=int, default=96)
     ap.add_argument("--cpu-loci", type=int, default=None, help="loci of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="exact", choices=["exact", "fast", "homopolymer"], help="realign workload: --pairhmm-mode of the reference (cli.rs:912-947)")
     ap.add_argument("--read-window", type=int, default=64, help="realign workload: realignment window; read windows are window..2*window bases (32: short reads, two pairs per wave)")
     args = ap.parse_args()
 
@@ -473,6 +556,11 @@ def main():
                             "sample": "first %d loci of the same batch, %d threads x contiguous shards, %.1f s" % (n_t, cores, t_tuned),
                             "max_abs_dposterior_vs_port": dev_t,
                             "note": "affine product form of the pileup likelihood (one log per pileup evaluation), -O3 -march=x86-64-v3; tree walk, prior, integrator and caches shared with the port"}
+            # the reference itself, if somebody put its binary on the box (never seen so far: null)
+            try:
+                cpu["reference_binary"] = reference_binary_baseline(cfg, sub, n_cpu, cores)
+            except Exception as ex:  # a probe must not take the bench line down
+                cpu["reference_binary"] = {"value": None, "note": "probe failed: %r" % (ex,)}
         # posteriors must be normalised at full size (size-independent property)
         ps = np.exp(res.ln_posterior)
         ok = (res.status & 0xF) == 0

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define VLR_ABI_VERSION 2
+#define VLR_ABI_VERSION 3   /* 3: vlr_plan_reserve takes the AFD capacity, 30 named events, vlr_node_*, homopolymer realignment */
 #define VLR_MAX_SAMPLES 8      /* samples per scenario supported by the device path   */
 #define VLR_N_BIAS      6      /* strand, orientation, position, softclip, homopolymer, alt-locus */
 
@@ -292,6 +292,28 @@ int  vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* 
  * synchronises before returning.  Still requires the GPU (no CPU fallback).                             */
 int  vlr_batch_run_host(vlr_plan* plan, const vlr_batch* in, vlr_results* out);
 
+/* ------------------------------------------------------------------------------------------------
+ * One node, several devices (SURVEY.md 8 e): what the batching shim in Caller::call
+ * (/root/reference/src/calling/variants/calling.rs:320-455) binds when the host drives N GPUs from ONE process.
+ * vlr_node_create compiles the scenario once per device (devices = NULL, n_devices <= 0: every visible device; the same
+ * device may be listed twice — two plans, two streams); vlr_node_batch_run_host cuts the host batch into the contiguous
+ * blocks of vlr_node_shard_range (ceil(n / G) loci each, input order — the caller has already collapsed breakend groups
+ * to their representatives, calling.rs:569-580, so no group straddles a shard), runs vlr_batch_run_host on one thread and
+ * plan per device and returns when every record and AFD list sits at its input position in the caller's arrays.  No
+ * collective: inside one process the shards write disjoint ranges of host memory (the multi-process harness,
+ * varlociraptor_amd/dist.py, reassembles with one RCCL all-gather instead).  Errors: the first failing shard's code, its
+ * message prefixed with the device.                                                                   */
+typedef struct vlr_gpu_node vlr_gpu_node;
+int  vlr_node_create(const vlr_scenario_desc* desc, int n_devices, const int* devices, vlr_gpu_node** out);
+void vlr_node_destroy(vlr_gpu_node* node);
+int  vlr_node_n_devices(const vlr_gpu_node* node);
+int  vlr_node_device(const vlr_gpu_node* node, int shard);               /* HIP device of shard r */
+vlr_plan* vlr_node_plan(vlr_gpu_node* node, int shard);                  /* borrowed: per-device knobs, counters */
+int  vlr_node_set_max_depth(vlr_gpu_node* node, int per_sample_depth);   /* vlr_plan_set_max_depth on every plan */
+int  vlr_node_set_max_obs(vlr_gpu_node* node, int max_obs_per_locus);
+int  vlr_node_shard_range(int64_t n_loci, int n_shards, int shard, int64_t* l0, int64_t* l1);  /* pure arithmetic, no device */
+int  vlr_node_batch_run_host(vlr_gpu_node* node, const vlr_batch* in, vlr_results* out);
+
 /* Page-locked host memory for the arrays handed to vlr_batch_run_host (columns in, results out).  The staging
  * copies of vlr_batch_run_host are asynchronous; from pageable memory the runtime bounces them through its own
  * pinned buffer (about 14 GB/s here), from memory obtained here they are direct DMA and overlap the kernel of the
@@ -356,6 +378,16 @@ int vlr_realign_batch_host(int device, const vlr_realign_batch_desc* pairs, doub
  * max_edit_dist is not read.  Same conventions as vlr_realign_batch. */
 int vlr_realign_fast_batch(int device, const vlr_realign_batch_desc* pairs, double* ln_prob, void* hip_stream);
 int vlr_realign_fast_batch_host(int device, const vlr_realign_batch_desc* pairs, double* ln_prob);
+
+/* The `homopolymer` realignment mode (--pairhmm-mode homopolymer, /root/reference/src/cli.rs:912-947): replaces
+ * HomopolyPairHMMRealigner::calculate_prob_allele (/root/reference/src/variants/evidence/realignment/mod.rs:680-730) -> bio
+ * HomopolyPairHMM::prob_related — the pair HMM of vlr_realign_batch with per-base hop states for homopolymer run errors (the mode
+ * the reference's nanopore / PCR-homopolymer testcases run).  hop[16] = ln of HopParams (realignment/pairhmm.rs:207-295), each
+ * group in the order A, C, G, T: prob_seq_homopolymer (start a run error in the read), prob_ref_homopolymer (in the allele),
+ * prob_seq_extend_homopolymer, prob_ref_extend_homopolymer; -inf = impossible (the reference's default for all sixteen, which
+ * makes the mode equal to vlr_realign_batch).  Same batch layout, band and result conventions as vlr_realign_batch. */
+int vlr_realign_homopolymer_batch(int device, const vlr_realign_batch_desc* pairs, const double* hop, double* ln_prob, void* hip_stream);
+int vlr_realign_homopolymer_batch_host(int device, const vlr_realign_batch_desc* pairs, const double* hop, double* ln_prob);
 
 /* Edit-distance pre-filter of the same pairs: replaces EditDistanceCalculation::calc_best_hit
  * (/root/reference/src/variants/evidence/realignment/edit_distance.rs:164-260, bio Myers find_all_lazy) as far as
@@ -427,6 +459,10 @@ typedef struct {
     const double* somatic_effective_mutation_rate_ln;
     const int32_t* third_allele_evidence; /* [n_obs] output-only feature of the OBS string (mod.rs:283-287), -1 = None */
     const uint8_t* imprecise;            /* [n_loci] INFO IMPRECISE                                                  */
+    /* (ABI 3) 64-bit hash of the group's identifier, 0 for ungrouped records: group_representative only looks inside one
+     * table; a driver that streams a file in chunks (vlr_obs_reader_next) keeps key -> result of the first record and hands
+     * it to the later breakends of the event, as the reference does across the whole file (calling.rs:569-580, 726-741) */
+    const uint64_t* group_key;           /* [n_loci]                                                                 */
 } vlr_obs_sites;
 
 /* Read one observation file per sample (sample-index order; BCF2 in BGZF blocks, gzip or plain; text VCF accepted) into one
@@ -449,7 +485,7 @@ int  vlr_calls_write(const char* path, const char* header_text, const vlr_obs_ta
 /* The same in pieces: a reader that delivers at most max_records records of every sample file per call (bounded memory; the
  * caller may overlap the read of the next chunk with the evaluation and emission of the previous one), and a writer that appends
  * one chunk per call.  vlr_obs_reader_next sets *out = NULL once the files are exhausted; every table is freed by the caller.
- * Breakend groups (vlr_obs_sites.group_representative) are formed within a chunk. */
+ * Breakend groups (vlr_obs_sites.group_representative) are formed within a chunk; group_key identifies an event across chunks. */
 typedef struct vlr_obs_reader vlr_obs_reader;
 int  vlr_obs_reader_open(int n_samples, const char* const* paths, uint32_t omit_bias_mask, int n_threads, vlr_obs_reader** out);
 int  vlr_obs_reader_next(vlr_obs_reader* reader, int64_t max_records, vlr_obs_table** out);
@@ -462,6 +498,9 @@ int  vlr_calls_writer_close(vlr_calls_writer* writer);   /* header (if nothing w
  * over the sample files, which run side by side — [3] all files, [4] merge into the table, [5] strings and groups, [6] total) and of
  * the last vlr_calls_write ([8] record encoding, [9] BGZF deflate + file write, [10] total). */
 void vlr_ingest_last_timings(double* out16);
+/* The same indices summed over every vlr_obs_reader_next / vlr_calls_writer_append call since the last reset (reset != 0 clears
+ * them after reading): what the streaming front door spends per stage over a whole file. */
+void vlr_ingest_total_timings(double* out16, int reset);
 
 #ifdef __cplusplus
 }

@@ -127,6 +127,25 @@ def pathhmm_best(allele: bytes, read: bytes, qual, gap) -> float:
     return float(L.vlro_pathhmm_best(x.ctypes.data, len(allele), y.ctypes.data, q.ctypes.data, len(read), g))
 
 
+def homopoly_prob_related(allele: bytes, read: bytes, qual, gap, hop, max_edit_dist: int = -1) -> float:
+    """`homopolymer` realignment mode: restated bio HomopolyPairHMM::prob_related (vlro_homopoly_prob_related); hop = 16 ln values."""
+    L = lib()
+    L.vlro_homopoly_prob_related.restype = C.c_double
+    L.vlro_homopoly_prob_related.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
+    x = np.frombuffer(bytes(allele) or b"\0", np.uint8)
+    y = np.frombuffer(bytes(read) or b"\0", np.uint8)
+    q = np.asarray(bytearray(qual) or b"\0", np.uint8)
+    g = (C.c_double * 4)(*[float(v) for v in gap])
+    h = (C.c_double * 16)(*[float(v) for v in hop])
+    return float(L.vlro_homopoly_prob_related(x.ctypes.data, len(allele), y.ctypes.data, q.ctypes.data, len(read), g, h, int(max_edit_dist)))
+
+
+def homopoly_batch(batch, gap, hop):
+    g = [gap.prob_insertion_artifact, gap.prob_deletion_artifact, gap.prob_insertion_extend_artifact, gap.prob_deletion_extend_artifact]
+    h = hop.as_list()
+    return np.array([homopoly_prob_related(batch.x[k], batch.y[k], batch.q[k], g, h, batch.band[k]) for k in range(len(batch))])
+
+
 def edit_distance(allele: bytes, read: bytes):
     """(dist, end, n_hits) of the semiglobal edit distance of `read` in `allele` (oracle/vlr_realign_oracle.cpp)."""
     L = lib()

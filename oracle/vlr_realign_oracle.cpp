@@ -201,6 +201,114 @@ double vlro_pathhmm_best(const uint8_t* x, int len_x, const uint8_t* y, const ui
     return result.d >= BIG ? NEG_INF : result.p;
 }
 
+// `homopolymer` realignment mode — HomopolyPairHMMRealigner::calculate_prob_allele (realignment/mod.rs:680-730, selected at
+// cli.rs:912-947): bio::stats::pairhmm::HomopolyPairHMM::prob_related over the same ReadVsAlleleEmission (plus its
+// `Emission` impl that hands out the bases themselves, pairhmm.rs:370-384), GapParams, and the reference's HopParams
+// (pairhmm.rs:207-295: per base A, C, G, T the probabilities to START a homopolymer run error in the read — prob_seq_homopolymer
+// = prob_hop_x — or in the reference — prob_ref_homopolymer = prob_hop_y — and to EXTEND one; all zero by default).
+//
+// PARITY UNPINNED, like the two modes above: HomopolyPairHMM lives in the un-vendored crate bio (Cargo.toml:29) and the
+// reference tree holds no numeric vector for it.  Restated from the crate's published architecture (module documentation of
+// bio::stats::pairhmm::homopolypairhmm): fourteen states — MatchA/C/G/T, GapX, GapY, HopAX..HopTX, HopAY..HopTY —
+//   Match_b  emits the pair (x_i, y_j); here b is the base of x_i (non-ACGT bases use a fifth, hop-less match state);
+//            entered from any match state b' with 1 - (gap_x + gap_y + hop_x(b') + hop_y(b')), from a gap state with
+//            1 - extend, from a hop state of base b' with 1 - hop_extend(b'), from the free start with 1 - (gap_x + gap_y);
+//   GapX     emits y_j alone (gap in x, an insertion artifact): from any match with gap_x, from itself with gap_x_extend;
+//   GapY     emits x_i alone: from any match with gap_y, from itself with gap_y_extend;
+//   HopX_b   emits y_j alone and only if y_j == b (the read repeats the homopolymer base once more): from Match_b with
+//            hop_x(b), from itself with hop_x_extend(b);
+//   HopY_b   emits x_i alone and only if x_i == b: from Match_b with hop_y(b), from itself with hop_y_extend(b);
+// hops are entered from match states only and left to match states only; emissions, free start / end gaps in x, the column
+// sums, the cap at ln 1 and the edit-distance band are those of prob_related above.  With the default HopParams (all zero) the
+// model IS the three-state pair HMM: vlro_homopoly_prob_related == vlro_pairhmm_prob_related (tests/test_realign_oracle.py).
+// Which base labels a MISMATCH pair's match state (x_i here) is the one convention that cannot be checked against the crate.
+//   hop[16] = ln {hop_x[A,C,G,T], hop_y[A,C,G,T], hop_x_extend[A,C,G,T], hop_y_extend[A,C,G,T]}
+double vlro_homopoly_prob_related(const uint8_t* x, int len_x, const uint8_t* y, const uint8_t* qual, int len_y, const double* gap,
+                                  const double* hop, int max_edit_dist) {
+    if (len_x <= 0 || len_y <= 0) return NEG_INF;
+    const double PROB_CONFUSION = std::log(0.3333);
+    const double gx = gap[0], gy = gap[1], gxe = gap[2], gye = gap[3];
+    const double leave_gx = ln_one_minus_exp(gxe), leave_gy = ln_one_minus_exp(gye);
+    auto bidx = [](int b) { b = upper(b); return b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : b == 'T' ? 3 : 4; };
+    double hx[5], hy[5], hxe[5], hye[5], t_mm[5], leave_hx[5], leave_hy[5];
+    for (int b = 0; b < 5; ++b) {
+        hx[b] = b < 4 ? hop[b] : NEG_INF; hy[b] = b < 4 ? hop[4 + b] : NEG_INF;
+        hxe[b] = b < 4 ? hop[8 + b] : NEG_INF; hye[b] = b < 4 ? hop[12 + b] : NEG_INF;
+        t_mm[b] = ln_one_minus_exp(ln_sum_exp({gx, gy, hx[b], hy[b]}));
+        leave_hx[b] = ln_one_minus_exp(hxe[b]); leave_hy[b] = ln_one_minus_exp(hye[b]);
+    }
+    const double t_start = ln_one_minus_exp(ln_add_exp(gx, gy));
+    std::vector<double> any_miscall(len_y), no_miscall(len_y);
+    for (int j = 0; j < len_y; ++j) {
+        any_miscall[j] = -(double)qual[j] * LN10 / 10.0;
+        no_miscall[j] = ln_one_minus_exp(any_miscall[j]);
+    }
+    // states of one cell: M[5] (ACGT + other), HX[4], HY[4], GX, GY, and the free-start pseudo state of row 0 (index 15)
+    enum { S_M = 0, S_HX = 5, S_HY = 9, S_GX = 13, S_GY = 14, S_START = 15, NS = 16 };
+    const unsigned BIG = std::numeric_limits<unsigned>::max();
+    std::vector<std::vector<double>> v[2];
+    std::vector<unsigned> med[2];
+    for (int k = 0; k < 2; ++k) {
+        v[k].assign(len_y + 1, std::vector<double>(NS, NEG_INF));
+        med[k].assign(len_y + 1, BIG);
+    }
+    std::vector<double> prob_cols;
+    int prev = 0, curr = 1;
+    for (int i = 0; i < len_x; ++i) {
+        for (auto& s : v[prev][0]) s = NEG_INF;
+        v[prev][0][S_START] = 0.0;  // semiglobal: an alignment may start at any column of x with mass one
+        med[prev][0] = 0;
+        const int bx = bidx(x[i]);
+        for (int j = 0; j < len_y; ++j) {
+            const int j_ = j + 1, jm = j;
+            const unsigned e_tl = med[prev][jm], e_top = med[curr][jm], e_left = med[prev][j_];
+            const bool skip = max_edit_dist >= 0 && std::min(e_tl, std::min(e_top, e_left)) > (unsigned)max_edit_dist;
+            std::vector<double>& c = v[curr][j_];
+            for (auto& s : c) s = NEG_INF;
+            med[curr][j_] = BIG;
+            if (skip) continue;
+            const int by = bidx(y[j]);
+            const bool is_match = upper(y[j]) == upper(x[i]);
+            const double emit_xy = is_match ? no_miscall[j] : any_miscall[j] + PROB_CONFUSION;
+            const std::vector<double>& tl = v[prev][jm];   // (i-1, j-1)
+            const std::vector<double>& left = v[prev][j_]; // (i-1, j): x_i emitted alone
+            const std::vector<double>& top = v[curr][jm];  // (i, j-1): y_j emitted alone
+            {   // match state of base bx
+                std::vector<double> in;
+                for (int b = 0; b < 5; ++b) in.push_back(tl[S_M + b] + t_mm[b]);
+                for (int b = 0; b < 4; ++b) { in.push_back(tl[S_HX + b] + leave_hx[b]); in.push_back(tl[S_HY + b] + leave_hy[b]); }
+                in.push_back(tl[S_GX] + leave_gx); in.push_back(tl[S_GY] + leave_gy);
+                in.push_back(tl[S_START] + t_start);
+                c[S_M + bx] = emit_xy + ln_sum_exp(in);
+            }
+            {   // GapY: x_i alone (prob_emit_x = ln 1, pairhmm.rs:350-352)
+                std::vector<double> in;
+                for (int b = 0; b < 5; ++b) in.push_back(left[S_M + b] + gy);
+                in.push_back(left[S_GY] + gye);
+                c[S_GY] = ln_sum_exp(in);
+            }
+            {   // GapX: y_j alone (prob_emit_y = P(miscall), pairhmm.rs:354-357,447-449)
+                std::vector<double> in;
+                for (int b = 0; b < 5; ++b) in.push_back(top[S_M + b] + gx);
+                in.push_back(top[S_GX] + gxe);
+                c[S_GX] = any_miscall[j] + ln_sum_exp(in);
+            }
+            if (bx < 4) c[S_HY + bx] = ln_add_exp(left[S_M + bx] + hy[bx], left[S_HY + bx] + hye[bx]);                    // x_i == b alone
+            if (by < 4) c[S_HX + by] = any_miscall[j] + ln_add_exp(top[S_M + by] + hx[by], top[S_HX + by] + hxe[by]);     // y_j == b alone
+            if (max_edit_dist >= 0) {
+                auto inc = [BIG](unsigned e) { return e == BIG ? BIG : e + 1; };
+                med[curr][j_] = std::min(is_match ? e_tl : inc(e_tl), std::min(inc(e_top), inc(e_left)));
+            }
+        }
+        for (int s = 0; s < S_START; ++s) prob_cols.push_back(v[curr][len_y][s]);  // free end gap in x
+        std::swap(curr, prev);
+        for (auto& s : v[curr][0]) s = NEG_INF;
+        med[curr][0] = BIG;
+    }
+    const double p = ln_sum_exp(prob_cols);
+    return p > 0.0 ? 0.0 : p;
+}
+
 // The ref/alt normalisation of Realigner::allele_support (realignment/mod.rs:359-385): both non-zero -> divide by the sum;
 // both zero -> 0.5 / 0.5.
 void vlro_normalize_support(double* prob_ref, double* prob_alt) {

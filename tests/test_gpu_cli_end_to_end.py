@@ -147,6 +147,43 @@ def test_cli_breakend_groups_are_evaluated_once_and_fanned_out(golden_dir, tmp_p
         assert np.array_equal(grouped.map_vaf[l], plain.map_vaf[want], equal_nan=True)
 
 
+def test_cli_breakend_event_that_straddles_reader_chunks(golden_dir, tmp_path, monkeypatch):
+    """The streaming front door reads a bounded number of records at a time; an event whose breakends fall into different chunks
+    still gets ONE result, the first record's, as in the reference (calling.rs:569-580, 726-741 work on the whole file)."""
+    import numpy as np
+    from varlociraptor_amd.bcfio import BcfWriter
+    d = os.path.join(golden_dir, "flamegraph_profiling")
+    header, recs = [], []
+    k = 0
+    for l in open(os.path.join(d, "normal.vcf")).read().split("\n"):
+        if not l:
+            continue
+        if l.startswith("#"):
+            header.append(l)
+            continue
+        f = l.split("\t")
+        if k in (2, 5, 9):
+            f[7] = "EVENT=grp1;" + f[7]
+        k += 1
+        recs.append("\t".join(f))
+    obs = str(tmp_path / "grouped.bcf")
+    with BcfWriter(obs, "\n".join(header)) as wr:
+        for r in recs:
+            wr.write_line(r)
+    sc = cli.scenario_from_yaml(os.path.join(d, "scenario.yaml"))
+    whole = cli.call_variants(sc, {"normal": obs}, omit_mask=abi.BIAS_ALL, out=io.StringIO())
+    monkeypatch.setenv("VLR_CLI_CHUNK", "4")   # records 0-3 | 4-7 | 8-10: the event has one breakend in every chunk
+    tm = {}
+    pieces = cli.call_variants(sc, {"normal": obs}, omit_mask=abi.BIAS_ALL, out=io.StringIO(), timings=tm)
+    assert tm["chunks"] == 3
+    plain = cli.call_variants(sc, {"normal": os.path.join(d, "normal.vcf")}, omit_mask=abi.BIAS_ALL, out=io.StringIO())
+    for l in range(11):
+        want = 2 if l in (2, 5, 9) else l
+        for got in (whole, pieces):
+            assert np.array_equal(got.ln_posterior[l], plain.ln_posterior[want], equal_nan=True), l
+            assert np.array_equal(got.map_vaf[l], plain.map_vaf[want], equal_nan=True), l
+
+
 def test_cli_reads_variant_specific_priors_from_the_first_record_of_a_contig(golden_dir, tmp_path):
     import numpy as np
     d = os.path.join(golden_dir, "flamegraph_profiling")

@@ -1,0 +1,53 @@
+"""vlr_node_* (include/vlr.h): one C-ABI call shards a host batch over the devices of a node and reassembles the records and
+AFD lists in input order — what the batching shim of Caller::call (calling.rs:320-455) binds for N GPUs in one process.
+The box of the driver's GPU suite has one device; listing it twice builds two plans with their own streams and exercises the
+threads, the shard views and the reassembly (results must equal vlr_batch_run_host bit for bit)."""
+import numpy as np
+import pytest
+
+from varlociraptor_amd import engine, synth
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("ln_posterior", "ln_marginal", "map_vaf", "map_bias", "best_event", "status")
+
+
+def same(a, b, afd=False):
+    for f in FIELDS:
+        x, y = np.asarray(getattr(a, f)), np.asarray(getattr(b, f))
+        assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), f
+    if afd:
+        assert np.array_equal(a.afd_count, b.afd_count)
+        cap = a.afd_vaf.shape[-1]
+        m = np.arange(cap)[None, None, :] < np.minimum(a.afd_count, cap)[:, :, None]
+        assert np.array_equal(np.where(m, a.afd_vaf, 0.0), np.where(m, b.afd_vaf, 0.0))
+        assert np.array_equal(np.where(m, a.afd_lnprob, 0.0), np.where(m, b.afd_lnprob, 0.0))
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_node_run_equals_the_single_plan_run(devices):
+    cfg = synth.config3()
+    batch = synth.generate(cfg, 5003, seed=31)   # not a multiple of the shard count: the last shard is short
+    plan = engine.Plan(cfg.scenario)
+    want = plan.call_host(batch, afd_capacity=64)
+    plan.close()
+    node = engine.Node(cfg.scenario, devices=devices)
+    assert node.n_devices == len(devices) and node.devices == devices
+    got = node.call_host(batch, afd_capacity=64)
+    same(got, want, afd=True)
+    # fewer loci than devices: empty shards
+    small = synth.generate(cfg, 2, seed=32)
+    same(node.call_host(small), engine.Plan(cfg.scenario).call_host(small))
+    node.close()
+
+
+def test_node_defaults_to_every_visible_device_and_other_scenarios():
+    import torch
+    cfg = synth.config5()
+    batch = synth.generate(cfg, 1500, seed=33)
+    node = engine.Node(cfg.scenario)
+    assert node.n_devices == torch.cuda.device_count()
+    same(node.call_host(batch), engine.Plan(cfg.scenario).call_host(batch))
+    node.close()
+    with pytest.raises(engine.EngineError):
+        engine.Node(cfg.scenario, devices=[0, 99])

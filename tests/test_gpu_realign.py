@@ -187,3 +187,62 @@ def test_two_pairs_per_wave_on_short_read_windows(oracle):
         o = int(rng.integers(0, 100))
         pb.add(x, x[o:o + ly], [int(q) for q in rng.choice([20, 30, 40], ly)], int(rng.choice([-1, 4, 9])))
     check(oracle, pb, GapParams(math.log(1e-4), math.log(2e-4), math.log(0.2), math.log(0.3)))
+
+
+# ---- homopolymer mode (vlr_realign_homopolymer_batch; HomopolyPairHMMRealigner, realignment/mod.rs:680-730) ----------------
+
+def _hop(rng):
+    from varlociraptor_amd.realign import HopParams
+    return HopParams([math.log(v) for v in rng.uniform(0.001, 0.05, 4)], [math.log(v) for v in rng.uniform(0.001, 0.05, 4)],
+                     [math.log(v) for v in rng.uniform(0.05, 0.5, 4)], [math.log(v) for v in rng.uniform(0.05, 0.5, 4)])
+
+
+def _check_homopoly(oracle, pb, gap, hop, tol=TOL):
+    got = realign.prob_related_homopolymer(pb, gap, hop)
+    ref = oracle.homopoly_batch(pb, gap, hop)
+    both_inf = np.isneginf(got) & np.isneginf(ref)
+    d = np.where(both_inf, 0.0, np.abs(got - ref))
+    assert np.all(d <= tol * np.maximum(1.0, np.abs(ref) * 1e-3)), (float(np.nanmax(d)), int(np.nanargmax(d)))
+    return got, ref
+
+
+@pytest.mark.parametrize("banded", [True, False])
+def test_homopolymer_mode_matches_restatement(oracle, banded):
+    rng = np.random.default_rng(31)
+    pb, _ = realign_synth.generate(150, seed=13, banded=banded)
+    _check_homopoly(oracle, pb, GapParams(), _hop(rng))
+    _check_homopoly(oracle, pb, GapParams(math.log(1e-4), math.log(2e-4), math.log(0.2), math.log(0.3)), _hop(rng))
+    # homopolymer-rich windows (nanopore-like run length errors), lower case and N bases in the allele
+    B = np.frombuffer(b"AAAACCGTTTT", np.uint8)
+    pb2 = PairBatch()
+    for k in range(200):
+        x = bytearray(B[rng.integers(0, len(B), int(rng.integers(20, 160)))].tobytes())
+        s = int(rng.integers(0, max(1, len(x) - 10)))
+        y = bytearray(x[s:s + int(rng.integers(4, 100))])
+        for _ in range(int(rng.integers(0, 4))):                     # run-length errors: repeat or drop a base
+            p = int(rng.integers(0, len(y)))
+            if rng.random() < 0.5: y.insert(p, y[p])
+            elif len(y) > 2: del y[p]
+        y = y[:128]
+        if k % 17 == 0: x[len(x) // 2] = ord("N")
+        if k % 19 == 0: x = bytearray(bytes(x).lower())
+        pb2.add(bytes(x), bytes(y), [int(v) for v in rng.choice([7, 12, 20, 30], len(y))], -1 if not banded else int(rng.integers(2, 9)))
+    _check_homopoly(oracle, pb2, GapParams(), _hop(rng))
+
+
+def test_homopolymer_mode_with_default_hop_parameters_equals_the_pair_hmm_kernel():
+    pb, _ = realign_synth.generate(200, seed=14)
+    from varlociraptor_amd.realign import HopParams
+    a = realign.prob_related(pb)
+    b = realign.prob_related_homopolymer(pb, GapParams(), HopParams())
+    both_inf = np.isneginf(a) & np.isneginf(b)
+    assert np.all(np.where(both_inf, 0.0, np.abs(a - b)) <= 1e-12 * np.maximum(1.0, np.abs(a)))
+
+
+def test_homopolymer_mode_rejects_parameters_that_are_not_log_probabilities():
+    from varlociraptor_amd.realign import HopParams
+    from varlociraptor_amd import engine
+    pb = PairBatch()
+    pb.add(b"ACGT", b"CG", [30, 30])
+    with pytest.raises(engine.EngineError):
+        realign.prob_related_homopolymer(pb, GapParams(), HopParams([0.5, -1, -1, -1]))

@@ -125,6 +125,26 @@ def test_shard_range_covers_everything():
             assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
 
 
+def test_node_shard_range_of_the_c_abi_is_the_harness_rule():
+    """vlr_node_shard_range (pure arithmetic, no device) == dist.shard_range: the in-process node entry and the multi-process
+    harness cut a batch at the same loci."""
+    for n in (0, 1, 7, 8, 5003, 1000003):
+        for w in (1, 2, 3, 4, 8):
+            for k in range(w):
+                assert engine.shard_range(n, w, k) == shard_range(n, k, w)
+    with pytest.raises(engine.EngineError):
+        engine.shard_range(10, 0, 0)
+
+
+def test_node_create_without_a_device_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    with pytest.raises(engine.EngineError) as e:
+        engine.Node(single_sample(0.01))
+    assert e.value.code == abi.ERR_NO_DEVICE
+
+
 # ---- C ABI: library loads, exports every symbol include/vlr.h declares, fails loudly without a GPU
 def declared_functions():
     text = open(os.path.join(ROOT, "include", "vlr.h")).read()
@@ -349,3 +369,25 @@ def test_model_mode_has_only_the_four_reference_flags():
     m = cli.model_modes(np.array([precise_indel, imprecise_sv, snv, imprecise_sv & ~abi.BIAS_ALTLOCUS], dtype=np.uint8))
     assert m[0] == m[1] == m[3] and m[2] != m[0]
     assert cli.MODEL_MODE_MASK == 0x1E
+
+
+def test_bench_reference_binary_probe(tmp_path, monkeypatch):
+    """bench.py times the reference's own `call variants` when a varlociraptor binary is on the box: absent ->
+    None; present (here: a stand-in script that only checks its command line) -> one process per shard over observation BCFs
+    written from the same batch."""
+    import stat
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    cfg = synth.config3()
+    batch = synth.generate(cfg, 40, seed=3)
+    monkeypatch.setenv("PATH", str(tmp_path))
+    assert bench.reference_binary_baseline(cfg, batch, 40, 4) is None
+    exe = tmp_path / "varlociraptor"
+    exe.write_text("#!/bin/sh\nif [ \"$1\" = --version ]; then echo 'varlociraptor 8.9.3'; exit 0; fi\n"
+                   "[ \"$1 $2 $3\" = 'call variants tumor-normal' ] || exit 3\n"
+                   "for a in \"$@\"; do case $a in *.bcf) [ -s \"$a\" ] || exit 4;; esac; done\nprintf BCF\n")
+    exe.chmod(exe.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(tmp_path) + ":/usr/bin:/bin")
+    r = bench.reference_binary_baseline(cfg, batch, 40, 4)
+    assert r["kind"] == "reference" and r["value"] > 0 and r["cores"] == 4 and r["version"] == "varlociraptor 8.9.3"

@@ -183,3 +183,91 @@ def test_fast_mode_restatement_against_brute_force(oracle):
             got = oracle.pathhmm_best(x, y, q, gap)
             assert got == pytest.approx(p, abs=1e-9), (x, y, q, d, p, got)
             assert oracle.edit_distance(x, y)[0] == d
+
+
+# ---- homopolymer mode (HomopolyPairHMMRealigner, realignment/mod.rs:680-730; HopParams pairhmm.rs:207-295) -----------------
+
+HOP0 = [-math.inf] * 16
+
+
+def _brute_homopoly(x, y, q, gap, hop):
+    """Sum over ALL state paths of the fourteen-state model as oracle/vlr_realign_oracle.cpp documents it (linear domain, plain
+    recursion, no band): free start and end in x, Match_b labelled by the base of x_i, hops entered from / left to match states."""
+    ex = lambda v: math.exp(v) if v > -math.inf else 0.0
+    gx, gy, gxe, gye = [ex(v) for v in gap]
+    idx = lambda c: b"ACGT".find(bytes([c]).upper())
+    hx = [ex(v) for v in hop[0:4]]; hy = [ex(v) for v in hop[4:8]]; hxe = [ex(v) for v in hop[8:12]]; hye = [ex(v) for v in hop[12:16]]
+    mis = [10 ** (-v / 10) for v in q]
+    total = [0.0]
+
+    def rec(i, j, st, b, p):
+        if p == 0.0:
+            return
+        if j == len(y) and st != "S":
+            total[0] += p                      # free end gap in x: every column may end the alignment, in any state
+        # leave-to-match factor of the current state
+        if st == "S": tm = 1 - (gx + gy)
+        elif st == "M": tm = 1 - (gx + gy + (hx[b] + hy[b] if b >= 0 else 0.0))
+        elif st == "GX": tm = 1 - gxe
+        elif st == "GY": tm = 1 - gye
+        elif st == "HX": tm = 1 - hxe[b]
+        else: tm = 1 - hye[b]
+        if i < len(x) and j < len(y):
+            e = (1 - mis[j]) if bytes([x[i]]).upper() == bytes([y[j]]).upper() else mis[j] * 0.3333
+            rec(i + 1, j + 1, "M", idx(x[i]), p * tm * e)
+        if st in ("M", "GX") and j < len(y):   # y_j alone after a gap open / extension
+            rec(i, j + 1, "GX", -1, p * (gx if st == "M" else gxe) * mis[j])
+        if st in ("M", "GY") and i < len(x):   # x_i alone (prob_emit_x = 1)
+            rec(i + 1, j, "GY", -1, p * (gy if st == "M" else gye))
+        if st in ("M", "HX") and b >= 0 and j < len(y) and idx(y[j]) == b:
+            rec(i, j + 1, "HX", b, p * (hx[b] if st == "M" else hxe[b]) * mis[j])
+        if st in ("M", "HY") and b >= 0 and i < len(x) and idx(x[i]) == b:
+            rec(i + 1, j, "HY", b, p * (hy[b] if st == "M" else hye[b]))
+    for start in range(len(x)):
+        rec(start, 0, "S", -1, 1.0)
+    return math.log(min(total[0], 1.0)) if total[0] > 0 else -math.inf
+
+
+def test_homopolymer_mode_with_default_hop_parameters_is_the_pair_hmm(oracle):
+    """HopParams::default() is all zero (pairhmm.rs:223-256): no hop state can be entered and the model is PairHMM."""
+    rng = np.random.default_rng(21)
+    for gap in (GAP, [math.log(1e-3), math.log(2e-3), math.log(0.2), math.log(0.3)]):
+        for _ in range(40):
+            x = bytes(rng.choice(list(b"ACGTN"), int(rng.integers(1, 40))).tolist())
+            y = bytes(rng.choice(list(b"ACGT"), int(rng.integers(1, 20))).tolist())
+            q = [int(v) for v in rng.choice([10, 20, 30, 40], len(y))]
+            for band in (-1, 3):
+                a = oracle.pairhmm_prob_related(x, y, q, gap, band)
+                b = oracle.homopoly_prob_related(x, y, q, gap, HOP0, band)
+                assert (a == b) or abs(a - b) < 1e-12, (x, y, a, b)
+
+
+def test_homopolymer_restatement_against_enumeration_of_all_paths(oracle):
+    rng = np.random.default_rng(22)
+    gaps = ([math.log(1e-3), math.log(2e-3), math.log(0.2), math.log(0.3)], GAP)
+    for it in range(80):
+        gap = gaps[it % 2]
+        hop = [math.log(v) for v in rng.uniform(0.001, 0.05, 8)] + [math.log(v) for v in rng.uniform(0.05, 0.5, 8)]
+        lx, ly = int(rng.integers(1, 7)), int(rng.integers(1, 5))
+        alphabet = list(b"AAC") if it % 3 else list(b"ACGT")   # homopolymer-rich
+        x = bytes(rng.choice(alphabet, lx).tolist())
+        y = bytes(rng.choice(alphabet, ly).tolist())
+        q = [int(v) for v in rng.choice([5, 10, 20, 30], ly)]
+        want = _brute_homopoly(x, y, q, gap, hop)
+        got = oracle.homopoly_prob_related(x, y, q, gap, hop)
+        assert got == pytest.approx(want, abs=1e-10), (x, y, q, want, got)
+
+
+def test_hop_parameters_explain_a_homopolymer_length_error(oracle):
+    """A read with one T more than the allele's T run: with seq-homopolymer probabilities the insertion is explained by a hop,
+    and only by a hop of the RIGHT base."""
+    x, y, q = b"ACGTTTTGCA", b"CGTTTTTGC", [30] * 9
+    plain = oracle.homopoly_prob_related(x, y, q, GAP, HOP0)
+    hop_t = list(HOP0); hop_t[3] = math.log(0.05)            # prob_seq_homopolymer[T]
+    hop_a = list(HOP0); hop_a[0] = math.log(0.05)            # ... [A]: does not apply to a T run
+    assert oracle.homopoly_prob_related(x, y, q, GAP, hop_t) > plain + 5.0
+    assert abs(oracle.homopoly_prob_related(x, y, q, GAP, hop_a) - plain) < 1e-3
+    # one T less in the read: the reference-homopolymer (hop_y) parameters
+    y2 = b"CGTTTGC"
+    hop_ref = list(HOP0); hop_ref[4 + 3] = math.log(0.05)
+    assert oracle.homopoly_prob_related(x, y2, [30] * 7, GAP, hop_ref) > oracle.homopoly_prob_related(x, y2, [30] * 7, GAP, HOP0) + 5.0

@@ -14,4 +14,7 @@ for name in os.environ.get("VLR_RATE_CONFIGS", "config3,config2").split(","):
     ms=[]
     for i in range(4):
         plan.call_device(dbatch, out, st); torch.cuda.synchronize(); ms.append(plan.last_kernel_ms())
-    print(os.environ.get("VLR_LIB","default").split("/")[-1], name, "%.2f ms" % min(ms[1:]), flush=True)
+    plan.work_counters(reset=True)
+    plan.call_device(dbatch, out, st); torch.cuda.synchronize()
+    ev, terms = plan.work_counters()
+    print(os.environ.get("VLR_LIB","default").split("/")[-1], name, "%.2f ms" % min(ms[1:]), "evals/locus %.1f terms/locus %.0f" % (ev / n, terms / n), flush=True)

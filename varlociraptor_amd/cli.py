@@ -152,7 +152,12 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
     plans: Dict[tuple, "engine.Plan"] = {}   # one plan per scenario signature, kept across the chunks of a run
     FIELDS = ("ln_posterior", "ln_marginal", "map_vaf", "map_bias", "best_event", "status", "afd_count", "afd_vaf", "afd_lnprob")
 
-    def evaluate(batch, contig_names, contig_of, het, som, group_rep):
+    # Breakend events whose first record sat in an EARLIER chunk of the streaming reader: the reference hands the first breakend's
+    # event probabilities and sample infos to every later record of the event across the whole file (calling.rs:569-580,
+    # 726-741); key = vlr_obs_sites.group_key, value = that record's result row
+    carried: Dict[int, dict] = {}
+
+    def evaluate(batch, contig_names, contig_of, het, som, group_rep, group_key=None):
         """Results of one batch of records (the whole file, or one chunk of the streaming reader)."""
         L = batch.n_loci
         modes = model_modes(batch.locus["locus_flags"]) if L else np.zeros(0, np.int64)
@@ -185,6 +190,8 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                 lo, hi, mine = 0, len(loci), loci
             if len(mine):
                 if sig not in plans:
+                    while len(plans) >= 4:  # a plan owns device buffers (staging slots, scratch rows, AFD log): keep a handful
+                        plans.pop(next(iter(plans))).close()
                     plans[sig] = engine.Plan(sc, device=device)
                 plan = plans[sig]
                 sub = batch if len(mine) == L else batch.select(mine)
@@ -213,6 +220,17 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                 a = getattr(res, f)
                 if a is not None:
                     a[:] = a[group_rep]
+        if res is not None and group_key is not None and L:
+            grouped = np.nonzero(group_key != 0)[0]
+            if len(grouped):
+                for l in grouped:
+                    k_ = int(group_key[l])
+                    row = carried.get(k_)
+                    if row is None:   # first record of the event in the file (a representative of this chunk)
+                        carried[k_] = {f: np.array(getattr(res, f)[l]) for f in FIELDS if getattr(res, f) is not None}
+                    else:             # the event began in an earlier chunk: its first record's result
+                        for f, v in row.items():
+                            getattr(res, f)[l] = v
         if res is not None and rank == 0:
             # the reference panics on NaN (assert!(!p.is_nan())): say so instead of writing `.` silently
             hard = res.status & (abi.LOCUS_NAN | abi.LOCUS_UNDERFLOW | abi.LOCUS_TABLE_FULL | abi.LOCUS_TOO_DEEP)
@@ -311,7 +329,7 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                 t0 = time.perf_counter()
                 contig_names = list(sites.contig_names)
                 res, nm = evaluate(batch, contig_names, np.asarray(sites.contig, np.int64), batch.extra["prior_het_ln"], batch.extra["prior_som_ln"],
-                                   np.asarray(batch.extra["group_representative"], np.int64))
+                                   np.asarray(batch.extra["group_representative"], np.int64), np.asarray(batch.extra["group_key"], np.uint64))
                 names = names or nm
                 stage["call_s"] += time.perf_counter() - t0
                 stage["n_loci"] += batch.n_loci

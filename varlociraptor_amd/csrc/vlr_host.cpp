@@ -16,6 +16,7 @@
 #include <functional>
 #include <limits>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/vlr.h"
@@ -278,6 +279,10 @@ struct vlr_plan {
     size_t afd_keys_bytes[2] = {0, 0};
     int64_t afd_log_loci[2] = {0, 0};  // loci whose log regions fit afd_log[slot] (the budget of ensure_buffers)
     int slot = 0;  // slot used by the next vlr_batch_run (set by vlr_batch_run_host)
+    // does the next vlr_batch_run need the deep launch (a pileup above the LDS budget)?  -1: unknown (device pointers: the host
+    // cannot see the depths, pool and launch as a precaution), 0 / 1: vlr_batch_run_host has looked at the chunk's offsets — the
+    // 512 MiB pool is only allocated, and the second launch only enqueued, when a locus needs them
+    int deep_hint = -1;
 };
 
 namespace {
@@ -860,7 +865,7 @@ static int ensure_buffers(vlr_plan* plan, int64_t n_loci, int max_obs, bool want
         // per batch; VLR_DEEP_POOL_MB, 0 = no deep launch: such loci stay flagged VLR_LOCUS_TOO_DEEP).  Optional: no room, no fallback.
         size_t pool = (size_t)512 << 20;
         if (const char* ev = getenv("VLR_DEEP_POOL_MB")) pool = (size_t)std::max(0L, atol(ev)) << 20;
-        if (pool > 0) (void)grow(&plan->deep_pool[k], &plan->deep_pool_bytes[k], pool + 128, true);
+        if (pool > 0 && plan->deep_hint != 0) (void)grow(&plan->deep_pool[k], &plan->deep_pool_bytes[k], pool + 128, true);
     }
     if (want_afd) {
         rc = grow(&plan->afd_scratch[k], &plan->afd_scratch_bytes[k], L + 8 * L + 4 * L + 64, false);
@@ -961,7 +966,7 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
     // coefficients in the plan's HBM pool; every other locus exits at once.  `lane`/`two`: the AFD sub-range lanes share the pool.
     auto deep_launch = [&](const DevBatch& bs, DevResults rs, void* ss, int lane, bool two) -> int {
         const int k = plan->slot & 1;
-        if (!plan->deep_pool[k] || plan->deep_pool_bytes[k] <= 128) return VLR_OK;
+        if (!plan->deep_pool[k] || plan->deep_pool_bytes[k] <= 128 || plan->deep_hint == 0) return VLR_OK;
         char* base = (char*)plan->deep_pool[k];
         unsigned long long* ctr = (unsigned long long*)(base + 64 * lane);
         size_t cap_d = (plan->deep_pool_bytes[k] - 128) / sizeof(double);
@@ -1036,7 +1041,7 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
             DevResults rd = r;
             int rc = deep_launch(b, rd, stream, 0, false);
             if (rc != VLR_OK) return rc;
-            if (plan->deep_pool[plan->slot & 1]) {
+            if (plan->deep_pool[plan->slot & 1] && plan->deep_hint != 0) {
                 HIP_TRY(hipMemsetAsync(plan->deep_pool[plan->slot & 1], 0, sizeof(unsigned long long), st));
                 rd.replay = 1;
                 rc = deep_launch(b, rd, stream, 0, false);
@@ -1169,10 +1174,13 @@ static int host_chunk_start(vlr_plan* plan, const vlr_batch* in, vlr_results* ou
         uint32_t mx = 1;
         for (int64_t l = l0; l < l1; ++l) mx = std::max(mx, in->obs_offset[(l + 1) * S] - in->obs_offset[l * S]);
         plan->max_obs = std::min<int>(budget, (int)mx);
+        // the LDS-resident kernel holds at most 7 680 kept observations of a locus; the launcher's own limit is the budget
+        plan->deep_hint = ((int)mx > std::min(budget, 7680)) ? 1 : 0;
     }
     plan->slot = k;
     int rc = vlr_batch_run(plan, &db, &dr, (void*)st);
     plan->max_obs = saved_max_obs;
+    plan->deep_hint = -1;
     if (rc != VLR_OK) return rc;
     hc->l0 = l0; hc->l1 = l1; hc->k = k; hc->dr = dr; hc->want_afd = want_afd; hc->active = true;
     return VLR_OK;
@@ -1247,6 +1255,119 @@ int vlr_batch_run_host(vlr_plan* plan, const vlr_batch* in, vlr_results* out) {
     return rc;
 }
 
+// ---- one node, several devices (SURVEY 8 e): contiguous shards of one host batch, one thread + plan per device -------------
+// The per-record loop of Caller::call (calling.rs:320-455) has no cross-record state: given the plan every locus is independent,
+// so N devices take the blocks [n r / N, n (r + 1) / N) of the (breakend-group de-duplicated, calling.rs:569-580) batch and write
+// their fixed-size records and AFD lists straight into the caller's arrays at the shard's offset — input order is restored by
+// construction and no collective is needed inside one process (the multi-process harness uses one RCCL all-gather instead).
+struct vlr_gpu_node {
+    std::vector<vlr_plan*> plans;
+    std::vector<int> devices;
+};
+
+int vlr_node_shard_range(int64_t n_loci, int n_shards, int shard, int64_t* l0, int64_t* l1) {
+    if (n_loci < 0 || n_shards < 1 || shard < 0 || shard >= n_shards || !l0 || !l1) return fail(VLR_ERR_INVALID_ARGUMENT, "bad shard request");
+    const int64_t per = (n_loci + n_shards - 1) / n_shards;  // ceil(n / G) loci per shard, the last ones may be short or empty
+    *l0 = std::min<int64_t>(n_loci, per * shard);
+    *l1 = std::min<int64_t>(n_loci, per * (shard + 1));
+    return VLR_OK;
+}
+
+int vlr_node_create(const vlr_scenario_desc* d, int n_devices, const int* devices, vlr_gpu_node** out) {
+    if (!d || !out) return fail(VLR_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { (void)hipGetLastError(); return fail(VLR_ERR_NO_DEVICE, "no HIP device (the engine has no CPU path)"); }
+    if (n_devices <= 0) { n_devices = ndev; devices = nullptr; }
+    auto* node = new vlr_gpu_node();
+    for (int r = 0; r < n_devices; ++r) {
+        const int dev = devices ? devices[r] : r;
+        if (dev < 0 || dev >= ndev) { vlr_node_destroy(node); return fail(VLR_ERR_NO_DEVICE, "no HIP device %d (%d visible)", dev, ndev); }
+        vlr_plan* p = nullptr;
+        const int rc = vlr_plan_create(d, dev, &p);
+        if (rc != VLR_OK) { vlr_node_destroy(node); return rc; }
+        node->plans.push_back(p);
+        node->devices.push_back(dev);
+    }
+    *out = node;
+    return VLR_OK;
+}
+
+void vlr_node_destroy(vlr_gpu_node* node) {
+    if (!node) return;
+    for (vlr_plan* p : node->plans) vlr_plan_destroy(p);
+    delete node;
+}
+
+int vlr_node_n_devices(const vlr_gpu_node* node) { return node ? (int)node->plans.size() : VLR_ERR_INVALID_ARGUMENT; }
+int vlr_node_device(const vlr_gpu_node* node, int shard) {
+    return (node && shard >= 0 && shard < (int)node->devices.size()) ? node->devices[(size_t)shard] : VLR_ERR_INVALID_ARGUMENT;
+}
+vlr_plan* vlr_node_plan(vlr_gpu_node* node, int shard) {
+    return (node && shard >= 0 && shard < (int)node->plans.size()) ? node->plans[(size_t)shard] : nullptr;
+}
+int vlr_node_set_max_depth(vlr_gpu_node* node, int per_sample_depth) {
+    if (!node) return fail(VLR_ERR_INVALID_ARGUMENT, "null node");
+    for (vlr_plan* p : node->plans) { const int rc = vlr_plan_set_max_depth(p, per_sample_depth); if (rc != VLR_OK) return rc; }
+    return VLR_OK;
+}
+int vlr_node_set_max_obs(vlr_gpu_node* node, int max_obs_per_locus) {
+    if (!node) return fail(VLR_ERR_INVALID_ARGUMENT, "null node");
+    for (vlr_plan* p : node->plans) { const int rc = vlr_plan_set_max_obs(p, max_obs_per_locus); if (rc != VLR_OK) return rc; }
+    return VLR_OK;
+}
+
+int vlr_node_batch_run_host(vlr_gpu_node* node, const vlr_batch* in, vlr_results* out) {
+    if (!node || !in || !out) return fail(VLR_ERR_INVALID_ARGUMENT, "null argument");
+    const int G = (int)node->plans.size();
+    if (G < 1) return fail(VLR_ERR_INVALID_ARGUMENT, "node without devices");
+    const int64_t L = in->n_loci;
+    if (L == 0) return VLR_OK;
+    if (!in->obs_offset) return fail(VLR_ERR_INVALID_ARGUMENT, "missing required column");
+    const int S = in->n_samples;
+    const int n_out = vlr_plan_n_out(node->plans[0]);
+    const bool want_afd = out->afd_count || out->afd_vaf || out->afd_lnprob;
+    const size_t cap = want_afd ? (size_t)out->afd_capacity : 0;
+    std::vector<int> rcs((size_t)G, VLR_OK);
+    std::vector<std::string> errs((size_t)G);
+    auto work = [&](int r) {
+        int64_t l0 = 0, l1 = 0;
+        (void)vlr_node_shard_range(L, G, r, &l0, &l1);
+        if (l1 <= l0) return;
+        // a view of the shard: the locus columns advance by l0, the observation columns stay (obs_offset carries absolute rows)
+        vlr_batch b = *in;
+        b.n_loci = l1 - l0;
+        b.obs_offset = in->obs_offset + l0 * S;
+        b.n_obs = (int64_t)in->obs_offset[l1 * S] - (int64_t)in->obs_offset[l0 * S];
+        b.locus_flags = in->locus_flags ? in->locus_flags + l0 : nullptr;
+        b.variant_type = in->variant_type ? in->variant_type + l0 : nullptr;
+        b.ref_base = in->ref_base ? in->ref_base + l0 : nullptr;
+        b.alt_base = in->alt_base ? in->alt_base + l0 : nullptr;
+        vlr_results o = *out;
+        o.n_loci = l1 - l0;
+        o.ln_posterior = out->ln_posterior ? out->ln_posterior + l0 * n_out : nullptr;
+        o.ln_marginal = out->ln_marginal ? out->ln_marginal + l0 : nullptr;
+        o.map_vaf = out->map_vaf ? out->map_vaf + l0 * S : nullptr;
+        o.map_bias = out->map_bias ? out->map_bias + l0 * VLR_N_BIAS : nullptr;
+        o.best_event = out->best_event ? out->best_event + l0 : nullptr;
+        o.status = out->status ? out->status + l0 : nullptr;
+        o.afd_count = out->afd_count ? out->afd_count + l0 * S : nullptr;
+        o.afd_vaf = out->afd_vaf ? out->afd_vaf + (size_t)l0 * S * cap : nullptr;
+        o.afd_lnprob = out->afd_lnprob ? out->afd_lnprob + (size_t)l0 * S * cap : nullptr;
+        rcs[(size_t)r] = vlr_batch_run_host(node->plans[(size_t)r], &b, &o);
+        if (rcs[(size_t)r] != VLR_OK) errs[(size_t)r] = g_err;  // (thread-local: carried back to the caller's thread below)
+    };
+    if (G == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int r = 0; r < G; ++r) th.emplace_back(work, r);
+        for (auto& t : th) t.join();
+    }
+    for (int r = 0; r < G; ++r)
+        if (rcs[(size_t)r] != VLR_OK) { g_err = "device " + std::to_string(node->devices[(size_t)r]) + ": " + errs[(size_t)r]; return rcs[(size_t)r]; }
+    return VLR_OK;
+}
+
 void* vlr_host_alloc(size_t bytes) {
     void* p = nullptr;
     if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
@@ -1274,7 +1395,13 @@ static int check_realign(const vlr_realign_batch_desc* b, const double* ln_prob)
 }
 
 extern "C" int vlr_launch_pathhmm_kernel(const vlr_realign_batch_desc* b, double* ln_prob, void* stream);
-typedef int (*realign_launcher)(const vlr_realign_batch_desc*, double*, void*);
+extern "C" int vlr_launch_homopoly_kernel(const vlr_realign_batch_desc* b, const double* hop, double* ln_prob, void* stream);
+// the three modes behind one staging routine: `hop` is only read by the homopolymer launcher
+struct realign_launcher {
+    int (*plain)(const vlr_realign_batch_desc*, double*, void*);
+    const double* hop;
+    int operator()(const vlr_realign_batch_desc* b, double* out, void* st) const { return hop ? vlr_launch_homopoly_kernel(b, hop, out, st) : plain(b, out, st); }
+};
 
 static int realign_device(int device, const vlr_realign_batch_desc* b, double* ln_prob, void* hip_stream, realign_launcher launch) {
     int rc = check_realign(b, ln_prob);
@@ -1288,15 +1415,32 @@ static int realign_device(int device, const vlr_realign_batch_desc* b, double* l
 static int realign_host(int device, const vlr_realign_batch_desc* b, double* ln_prob, realign_launcher launch);
 
 int vlr_realign_batch(int device, const vlr_realign_batch_desc* b, double* ln_prob, void* hip_stream) {
-    return realign_device(device, b, ln_prob, hip_stream, vlr_launch_realign_kernel);
+    return realign_device(device, b, ln_prob, hip_stream, realign_launcher{vlr_launch_realign_kernel, nullptr});
 }
-int vlr_realign_batch_host(int device, const vlr_realign_batch_desc* b, double* ln_prob) { return realign_host(device, b, ln_prob, vlr_launch_realign_kernel); }
+int vlr_realign_batch_host(int device, const vlr_realign_batch_desc* b, double* ln_prob) { return realign_host(device, b, ln_prob, realign_launcher{vlr_launch_realign_kernel, nullptr}); }
 // `fast` realignment mode (PathHMMRealigner, realignment/mod.rs:547-678): best path probability over the alignments of minimal edit
 // distance; max_edit_dist of the batch is not read
 int vlr_realign_fast_batch(int device, const vlr_realign_batch_desc* b, double* ln_prob, void* hip_stream) {
-    return realign_device(device, b, ln_prob, hip_stream, vlr_launch_pathhmm_kernel);
+    return realign_device(device, b, ln_prob, hip_stream, realign_launcher{vlr_launch_pathhmm_kernel, nullptr});
 }
-int vlr_realign_fast_batch_host(int device, const vlr_realign_batch_desc* b, double* ln_prob) { return realign_host(device, b, ln_prob, vlr_launch_pathhmm_kernel); }
+int vlr_realign_fast_batch_host(int device, const vlr_realign_batch_desc* b, double* ln_prob) { return realign_host(device, b, ln_prob, realign_launcher{vlr_launch_pathhmm_kernel, nullptr}); }
+// `homopolymer` realignment mode (HomopolyPairHMMRealigner, realignment/mod.rs:680-730; HopParams pairhmm.rs:207-295)
+static int check_hop(const double* hop) {
+    if (!hop) return fail(VLR_ERR_INVALID_ARGUMENT, "null hop parameters");
+    for (int k = 0; k < 16; ++k)
+        if (!(hop[k] <= 0.0)) return fail(VLR_ERR_INVALID_ARGUMENT, "hop parameter %d is not a ln probability", k);
+    return VLR_OK;
+}
+int vlr_realign_homopolymer_batch(int device, const vlr_realign_batch_desc* b, const double* hop, double* ln_prob, void* hip_stream) {
+    int rc = check_hop(hop);
+    if (rc != VLR_OK) return rc;
+    return realign_device(device, b, ln_prob, hip_stream, realign_launcher{nullptr, hop});
+}
+int vlr_realign_homopolymer_batch_host(int device, const vlr_realign_batch_desc* b, const double* hop, double* ln_prob) {
+    int rc = check_hop(hop);
+    if (rc != VLR_OK) return rc;
+    return realign_host(device, b, ln_prob, realign_launcher{nullptr, hop});
+}
 
 static int realign_host(int device, const vlr_realign_batch_desc* b, double* ln_prob, realign_launcher launch) {
     int rc = check_realign(b, ln_prob);

@@ -49,6 +49,7 @@ namespace {
 
 // stage timings of the last vlr_obs_read / vlr_calls_write of this process (vlr_ingest_last_timings): measurement aid
 double g_ingest_t[16] = {0};
+double g_ingest_total[16] = {0};  // the same stages summed over every call since the last reset (streaming reader / writer)
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int ifail(int code, const char* fmt, ...) {
@@ -281,16 +282,19 @@ bool load_inflated(const char* path, Blob& out_blob, int n_threads, std::string&
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, 15 + 32) != Z_OK) { err = "zlib init failed"; return false; }
-    zs.next_in = raw.p; zs.avail_in = (uInt)std::min<size_t>(raw.size(), 0x7fffffff);
+    zs.next_in = raw.p; zs.avail_in = 0;
+    const uint8_t* const raw_end = raw.p + raw.size();
     out.resize(std::max<size_t>(raw.size() * 4, 1 << 16));
     size_t have = 0;
     for (;;) {
         if (have == out.size()) out.resize(out.size() * 2);
+        // zlib counts in 32 bits: hand the input over in pieces (a plain-gzip file above 2 GiB used to end at the first piece)
+        if (zs.avail_in == 0 && zs.next_in < raw_end) zs.avail_in = (uInt)std::min<size_t>((size_t)(raw_end - zs.next_in), 0x40000000);
         zs.next_out = out.data() + have; zs.avail_out = (uInt)std::min<size_t>(out.size() - have, 0x7fffffff);
         const int rc = inflate(&zs, Z_NO_FLUSH);
         have = (size_t)(zs.next_out - out.data());
         if (rc == Z_STREAM_END) {
-            if (zs.avail_in == 0) break;
+            if (zs.avail_in == 0 && zs.next_in >= raw_end) break;
             if (inflateReset(&zs) != Z_OK) { inflateEnd(&zs); err = "zlib reset failed"; return false; }
             continue;
         }
@@ -797,7 +801,7 @@ bool parse_bcf_record(const uint8_t* rec, const uint8_t* end, const std::vector<
     if (!bcf_typed(p, se, t)) { err = "bad FILTER"; return false; }
     for (uint32_t k = 0; k < n_info; ++k) {
         Typed key, val;
-        if (!bcf_typed(p, se, key) || key.n != 1 || !bcf_typed(p, se, val)) { err = "bad INFO"; return false; }
+        if (!bcf_typed(p, se, key) || key.n != 1 || key.type < 1 || key.type > 3 || !bcf_typed(p, se, val)) { err = "bad INFO"; return false; }
         const int32_t ki = typed_int(key, 0);
         const int f = (ki >= 0 && (size_t)ki < field_of_key.size()) ? field_of_key[(size_t)ki] : -1;
         if (f < 0) continue;
@@ -1039,6 +1043,8 @@ struct vlr_obs_table {
     uint8_t *locus_flags = nullptr, *variant_type = nullptr, *ref_base = nullptr, *alt_base = nullptr;
     std::vector<int32_t> contig;
     std::vector<int64_t> pos, hap_rep;
+    std::vector<uint64_t> hap_key;  // 64-bit hash of the haplotype identifier of a grouped record (0: ungrouped): lets a driver that reads
+                                    // the file in chunks recognise an event whose first record sat in an earlier chunk
     std::vector<double> het, som;
     std::vector<uint8_t> imprecise;
     std::vector<std::string> contig_names;
@@ -1121,7 +1127,7 @@ static int build_table(std::vector<SampleFile>& files, const char* const* paths,
     t->ref_base = t->make<uint8_t>(t->a_ref, (size_t)L);
     t->alt_base = t->make<uint8_t>(t->a_alt, (size_t)L);
     t->contig.resize((size_t)L); t->pos.resize((size_t)L); t->het.resize((size_t)L); t->som.resize((size_t)L); t->imprecise.resize((size_t)L);
-    t->id_off.resize((size_t)L); t->ref_off.resize((size_t)L); t->alt_off.resize((size_t)L); t->hap_rep.resize((size_t)L);
+    t->id_off.resize((size_t)L); t->ref_off.resize((size_t)L); t->alt_off.resize((size_t)L); t->hap_rep.resize((size_t)L); t->hap_key.resize((size_t)L);
     // contigs: names of sample 0's file; the other files must name the same contig at every record
     t->contig_names = files[0].contig_names;
     std::atomic<int64_t> bad_rec{-1};
@@ -1192,11 +1198,16 @@ static int build_table(std::vector<SampleFile>& files, const char* const* paths,
         t->ref_off[(size_t)l] = t->pool.size(); t->pool.append(base + a.c->ref[a.i]); t->pool.push_back('\0');
         t->alt_off[(size_t)l] = t->pool.size(); t->pool.append(base + a.c->alt[a.i]); t->pool.push_back('\0');
         int64_t rep = l;
+        uint64_t hk = 0;
         if (a.c->hap[a.i] != 0xffffffffu) {
             auto ins = first.emplace(std::string(base + a.c->hap[a.i]), l);
             rep = ins.first->second;
+            hk = 0xcbf29ce484222325ull;  // FNV-1a
+            for (const char* q = base + a.c->hap[a.i]; *q; ++q) { hk ^= (unsigned char)*q; hk *= 0x100000001b3ull; }
+            hk |= 1ull;
         }
         t->hap_rep[(size_t)l] = rep;
+        t->hap_key[(size_t)l] = hk;
     }
     for (auto& n : t->contig_names) t->contig_ptrs.push_back(n.c_str());
     g_ingest_t[5] = now_s() - t_str0;
@@ -1211,6 +1222,12 @@ extern "C" {
 // (each summed over the sample files, which run side by side), [3] wall time of all files, [4] merge into the table, [5] strings and
 // breakend groups, [6] total — and of the last vlr_calls_write — [8] record encoding, [9] BGZF deflate + file write, [10] total.
 void vlr_ingest_last_timings(double* out16) { if (out16) for (int i = 0; i < 16; ++i) out16[i] = g_ingest_t[i]; }
+// the same indices summed over all vlr_obs_reader_next / vlr_calls_writer_append calls since the last reset (the streaming front
+// door makes dozens of calls per file: the last one — the empty chunk at the end — says nothing)
+void vlr_ingest_total_timings(double* out16, int reset) {
+    if (out16) for (int i = 0; i < 16; ++i) out16[i] = g_ingest_total[i];
+    if (reset) for (int i = 0; i < 16; ++i) g_ingest_total[i] = 0.0;
+}
 
 void vlr_obs_table_free(vlr_obs_table* t) { delete t; }
 
@@ -1239,6 +1256,7 @@ int vlr_obs_table_sites(const vlr_obs_table* t, vlr_obs_sites* s) {
     s->heterozygosity_ln = t->het.data(); s->somatic_effective_mutation_rate_ln = t->som.data();
     s->third_allele_evidence = t->third;
     s->imprecise = t->imprecise.data();
+    s->group_key = t->hap_key.data();
     return VLR_OK;
 }
 
@@ -1297,10 +1315,12 @@ bool stream_fill(FileStream& f, size_t count, int n_threads, std::string& err) {
     const size_t old = f.win.n;
     f.win.resize(old + add);
     std::atomic<bool> bad{false};
+    const double t_inf0 = now_s();
     parallel_items((int64_t)(b1 - b0), n_threads, [&](int64_t i, int) {
         const BgzfBlock& b = f.blocks[b0 + (size_t)i];
         if (b.isize && !inflate_raw(f.raw.p + b.off, b.clen, f.win.p + old + off[(size_t)i], b.isize)) bad = true;
     });
+    g_ingest_t[1] += now_s() - t_inf0;  // (summed over the sample files, which run side by side)
     f.next_block = b1;
     if (bad) { err = std::string("corrupt BGZF block in ") + f.path; return false; }
     return true;
@@ -1452,6 +1472,7 @@ int vlr_obs_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** 
     for (auto& p : r->paths) pp.push_back(p.c_str());
     const int rc = build_table(files, pp.data(), r->omit, r->n_threads, out);
     g_ingest_t[6] = now_s() - t0;
+    for (int i = 0; i < 7; ++i) g_ingest_total[i] += g_ingest_t[i];
     return rc;
 }
 
@@ -1911,6 +1932,7 @@ static int calls_write_impl(FILE* out_file, bool bcf, bool with_header, bool wit
         if (!write_bgzf_stream(out_file, ps, n_threads, lv ? atoi(lv) : 4, with_eof, err)) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s", err.c_str());
         g_ingest_t[9] = now_s() - t_w0 - g_ingest_t[8];
         g_ingest_t[10] = now_s() - t_w0;
+        for (int i = 8; i <= 10; ++i) g_ingest_total[i] += g_ingest_t[i];
         return VLR_OK;
     }
     bool ok = true;
@@ -2154,13 +2176,17 @@ bool is_type(const VarType& v, const TypeFilter& f) {  // Variant::is_type (vari
     if (v.kind != f.kind) return false;
     return !f.has_range || (f.lo <= v.len && v.len < f.hi);
 }
-double lse(const std::vector<double>& v) {
-    double m = -INFINITY;
-    for (double x : v) m = std::max(m, x);
+double lse(const std::vector<double>& v) {  // bio LogProb::ln_sum_exp: the maximum apart, ln_1p of the others
+    if (v.empty()) return -INFINITY;
+    size_t im = 0;
+    for (size_t i = 1; i < v.size(); ++i)
+        if (v[i] > v[im]) im = i;
+    const double m = v[im];
     if (m == -INFINITY) return m;
     double s = 0.0;
-    for (double x : v) s += std::exp(x - m);
-    return m + std::log(s);
+    for (size_t i = 0; i < v.size(); ++i)
+        if (i != im && v[i] != -INFINITY) s += std::exp(v[i] - m);
+    return m + std::log1p(s);
 }
 // utils/mod.rs:177-212: ln-sum over the given PROB_* tags per (typed) variant; NaN = None
 void tags_prob_sum(const CallRec& r, const std::vector<VarType>& types, const std::vector<int>& tags, const TypeFilter& tf, std::vector<double>& out) {
@@ -2266,7 +2292,7 @@ extern "C" int vlr_calls_filter_fdr(const char* in_path, const char* out_path, i
             if (!bcf_typed(q, se, t)) return ifail(VLR_ERR_INVALID_ARGUMENT, "bad FILTER field in %s", in_path);
             for (uint32_t k = 0; k < n_info; ++k) {
                 Typed key, val;
-                if (!bcf_typed(q, se, key) || key.n != 1 || !bcf_typed(q, se, val)) return ifail(VLR_ERR_INVALID_ARGUMENT, "bad INFO field in %s", in_path);
+                if (!bcf_typed(q, se, key) || key.n != 1 || key.type < 1 || key.type > 3 || !bcf_typed(q, se, val)) return ifail(VLR_ERR_INVALID_ARGUMENT, "bad INFO field in %s", in_path);
                 const int32_t ki = typed_int(key, 0);
                 const int kt = (ki >= 0 && (size_t)ki < key_tag.size()) ? key_tag[(size_t)ki] : -1;
                 if (kt >= 0 && val.type == 5) {
@@ -2359,7 +2385,15 @@ extern "C" int vlr_calls_filter_fdr(const char* in_path, const char* out_path, i
             }
             keep_any = keep_any || keep;
         }
-        if (keep_any) { body.insert(body.end(), r.raw, r.raw + r.raw_len); ++kept; }
+        if (keep_any) {
+            // The reference removes the alleles that did not pass (filter_calls, utils/mod.rs:382-417: record.remove_alleles) and
+            // asserts one filter decision per ALT.  This entry writes kept records byte for byte, which is the same thing for the
+            // single-ALT records `call variants` emits; anything else is refused rather than emitted untrimmed.
+            if (r.alts.size() > 1 || pe.size() != r.alts.size())
+                return ifail(VLR_ERR_UNSUPPORTED, "record %lld of %s has %zu ALT alleles (%zu typed variants): multi-allelic calls files are not supported by control-fdr here",
+                             (long long)i, in_path, r.alts.size(), pe.size());
+            body.insert(body.end(), r.raw, r.raw + r.raw_len); ++kept;
+        }
     }
     if (!write_bgzf_file(out_path, {&header_bytes, &body}, n_threads, 6, err)) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s", err.c_str());
     if (n_kept) *n_kept = kept;

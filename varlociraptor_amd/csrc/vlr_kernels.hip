@@ -1747,28 +1747,38 @@ constexpr int kRegHeld = 8;    // slots whose coefficient pairs stay in register
 template <int NS>
 __device__ __forceinline__ void reg_products(const double* cc, const double* cq, const double* lcoef, int rl, int D, const double* al, double* P) {
     constexpr int NR = NS < kRegHeld ? NS : kRegHeld;
+    // smallest pileup this instantiation is chosen for (run_chain_batch): slots below it are filled on every lane's row
+    constexpr int DMIN = NS <= 4 ? 1 : (NS <= 8 ? 65 : 129);
     double xc[NS > NR ? NS - NR : 1], xq[NS > NR ? NS - NR : 1];
 #pragma unroll
     for (int j = NR; j < NS; ++j) {  // issued first: the LDS latency hides behind the register-held slots
-        const int i = rl + 16 * j;
-        const double* a = lcoef + 2 * (i < D ? i : 0);
-        const double c0 = a[0], q0 = a[1];
-        xc[j - NR] = i < D ? c0 : 1.0; xq[j - NR] = i < D ? q0 : 0.0;
+        xc[j - NR] = 1.0; xq[j - NR] = 0.0;
+        if (16 * j < DMIN || 16 * j < D) {  // (wave-uniform: slots no lane fills are not read)
+            const int i = rl + 16 * j;
+            const double* a = lcoef + 2 * (i < D ? i : 0);
+            const double c0 = a[0], q0 = a[1];
+            xc[j - NR] = i < D ? c0 : 1.0; xq[j - NR] = i < D ? q0 : 0.0;
+        }
     }
 #pragma unroll
     for (int t = 0; t < 3; ++t) P[t] = 1.0;
+    // Slot pairs in a fixed association (products of two terms, then of pairs).  A slot that no lane fills holds {1, 0}: its term
+    // is exactly 1 and L0 * 1 == L0, so leaving it (or the whole pair) out gives the same bits.  D is wave-uniform: scalar branches.
 #pragma unroll
     for (int j = 0; j < NS; j += 2) {
         const double c0 = j < NR ? cc[j < NR ? j : 0] : xc[j >= NR ? j - NR : 0], q0 = j < NR ? cq[j < NR ? j : 0] : xq[j >= NR ? j - NR : 0];
         const double c1 = (j + 1 < NR) ? cc[(j + 1 < NR) ? j + 1 : 0] : xc[(j + 1 >= NR && j + 1 < NS) ? j + 1 - NR : 0];
         const double q1 = (j + 1 < NR) ? cq[(j + 1 < NR) ? j + 1 : 0] : xq[(j + 1 >= NR && j + 1 < NS) ? j + 1 - NR : 0];
+        if (j + 1 < NS && (16 * (j + 1) < DMIN || 16 * (j + 1) < D)) {
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const double L0 = __builtin_fma(q0, al[t], c0);
-            if (j + 1 < NS) {
+            for (int t = 0; t < 3; ++t) {
+                const double L0 = __builtin_fma(q0, al[t], c0);
                 const double L1 = __builtin_fma(q1, al[t], c1);
                 P[t] *= L0 * L1;
-            } else P[t] *= L0;
+            }
+        } else if (16 * j < DMIN || 16 * j < D) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) P[t] *= __builtin_fma(q0, al[t], c0);
         }
     }
 }
@@ -1810,7 +1820,25 @@ struct RegChain {
     int tn;
     bool failed, sawnan;
 };
-template <int NS>
+// Keyed passes (KEYED): when every row of the batch has the same finite prior value at all of its points and a finite fixed part
+// (uniform-prior universes, no l2fc terms — the BASELINE scenarios), the joint values of one chain differ only by the pileup
+// product, so the argmax of a round (adaptive_integration.rs:61-94) can be taken on the products themselves: a pass keeps the
+// (exponent, mantissa) pair of every product as one ordered 64-bit key — exponent in the high 16 bits, the top 48 fraction bits of
+// the mantissa below — compares keys, and appends them to the visited-point table; the logarithms (ln_mantissa: a quarter of the
+// instructions of a pass, useful on 12 of 64 lanes there) are taken once per table entry in the batch epilogue, on all lanes.
+__device__ __forceinline__ long long product_key(double Pm, int E) {  // Pm in [1/2, 1)
+    const unsigned hi = (unsigned)__double2hiint(Pm), lo = (unsigned)__double2loint(Pm);
+    const unsigned khi = ((unsigned)E << 16) | ((hi >> 4) & 0xffffu);
+    const unsigned klo = (hi << 28) | (lo >> 4);
+    return (long long)(((unsigned long long)khi << 32) | klo);
+}
+__device__ __forceinline__ double key_ln(long long key) {  // ln of the product a key stands for
+    const unsigned khi = (unsigned)((unsigned long long)key >> 32), klo = (unsigned)key;
+    const int E = (int)khi >> 16;
+    const unsigned hi = 0x3fe00000u | ((khi & 0xffffu) << 4) | (klo >> 28), lo = klo << 4;
+    return ln_mantissa(__hiloint2double((int)hi, (int)lo)) + (double)E * kLn2;
+}
+template <int NS, bool KEYED>
 __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
     const DevPlan& p = *c.plan;
     const int rl0 = q.rl, D = q.D, simpson_n = q.simpson_n;
@@ -1850,6 +1878,7 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
     const bool all_fast = __ballot(q.rowon && !q.cls_fast) == 0ull;
     const bool cap_safe = p.table_cap < kTableCap;  // the host's bound was not clamped (vlr_host.cpp: table capacity)
     double L = lo, R = hi, vL = VLR_NEG_INF, vR = VLR_NEG_INF, mid = lo;
+    long long kL = 0, kR = 0;  // KEYED: the bracket ends' product keys
     PROF_ADD(c, 7);  // batch prologue (task fields, coefficient registers)
     for (;;) {
         PROF_ADD(c, 15);
@@ -1941,43 +1970,68 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
         }
         PROF_ADD(c, 13);  // pass: reduction
         const double x = rl == 0 ? px0 : rl == 1 ? px1 : px2;
-        const double lik = q.fixed + (ln_mantissa(Psel) + (double)Esel * kLn2);
-        double joint;
-        if (__builtin_expect(c.nlfc > 0, 0) && !lfcs_ok(c, q.inner, x)) joint = VLR_NEG_INF;
-        else if (__builtin_expect(all_fast, 1)) joint = (x == 0.0 ? q.pr0 : q.pr1) + lik;  // every row inside a uniform-prior universe: class 0 at exactly 0, else 1
-        else {
-            const int cls = q.cls_fast ? (x == 0.0 ? 0 : 1) : prior_class(p, q.inner, x);
-            const double pv = cls == 0 ? q.pr0 : cls == 1 ? q.pr1 : cls == 2 ? q.pr2 : q.ptab[q.pidx + cls * q.istride];
-            joint = pv + lik;
-        }
         const bool owner = on && rl < nn;
-        sawnan = sawnan || (owner && joint != joint);
-        if (owner) { q.tx[tn + rl] = x; q.tv[tn + rl] = joint; }
+        double joint = 0.0;
+        long long key = 0;
+        if (KEYED) {
+            key = product_key(Psel, Esel);
+            if (owner) { q.tx[tn + rl] = x; q.tv[tn + rl] = __longlong_as_double(key); }
+        } else {
+            const double lik = q.fixed + (ln_mantissa(Psel) + (double)Esel * kLn2);
+            if (__builtin_expect(c.nlfc > 0, 0) && !lfcs_ok(c, q.inner, x)) joint = VLR_NEG_INF;
+            else if (__builtin_expect(all_fast, 1)) joint = (x == 0.0 ? q.pr0 : q.pr1) + lik;  // every row inside a uniform-prior universe: class 0 at exactly 0, else 1
+            else {
+                const int cls = q.cls_fast ? (x == 0.0 ? 0 : 1) : prior_class(p, q.inner, x);
+                const double pv = cls == 0 ? q.pr0 : cls == 1 ? q.pr1 : cls == 2 ? q.pr2 : q.ptab[q.pidx + cls * q.istride];
+                joint = pv + lik;
+            }
+            sawnan = sawnan || (owner && joint != joint);
+            if (owner) { q.tx[tn + rl] = x; q.tv[tn + rl] = joint; }
+        }
         tn = on ? tn + nn : tn;
         PROF_ADD(c, 14);  // pass: log + prior + store
         if (__builtin_expect(up == UP_ROUND, 1)) {
-            const double j1 = row_bcast<1>(joint), j2 = row_bcast<2>(joint);
             // argmax over {left, middle1, middle2, right}, lowest index wins ties (adaptive_integration.rs:70-82): as three
             // compare masks.  0: [L, m1]  1: [L, m2]  2: [m1, R]  3: [m2, R] — the new bracket keeps one end and takes one of the
             // two middles, so the update is two selects for the middle and one per bracket field
-            const bool c1 = j1 > vL;
-            const double vb1 = c1 ? j1 : vL;
-            const bool c2 = j2 > vb1;
-            const double vb2 = c2 ? j2 : vb1;
-            const bool c3 = vR > vb2;
-            const bool keepR = c3 || c2;                 // kk >= 2: the left end moves
-            const bool useM2 = c3 || (!c2 && c1);        // kk odd: the moving end goes to middle2
-            const double mX = useM2 ? px2 : px1, mV = useM2 ? j2 : j1;
+            bool keepR, useM2;
+            if (KEYED) {
+                const long long j1 = __double_as_longlong(row_bcast<1>(__longlong_as_double(key))), j2 = __double_as_longlong(row_bcast<2>(__longlong_as_double(key)));
+                const bool c1 = j1 > kL;
+                const long long vb1 = c1 ? j1 : kL;
+                const bool c2 = j2 > vb1;
+                const long long vb2 = c2 ? j2 : vb1;
+                const bool c3 = kR > vb2;
+                keepR = c3 || c2;                 // kk >= 2: the left end moves
+                useM2 = c3 || (!c2 && c1);        // kk odd: the moving end goes to middle2
+                const long long mK = useM2 ? j2 : j1;
+                kL = (on && keepR) ? mK : kL; kR = (on && !keepR) ? mK : kR;
+            } else {
+                const double j1 = row_bcast<1>(joint), j2 = row_bcast<2>(joint);
+                const bool c1 = j1 > vL;
+                const double vb1 = c1 ? j1 : vL;
+                const bool c2 = j2 > vb1;
+                const double vb2 = c2 ? j2 : vb1;
+                const bool c3 = vR > vb2;
+                keepR = c3 || c2;
+                useM2 = c3 || (!c2 && c1);
+                const double mV = useM2 ? j2 : j1;
+                vL = (on && keepR) ? mV : vL; vR = (on && !keepR) ? mV : vR;
+            }
+            const double mX = useM2 ? px2 : px1;
             const bool updL = on && keepR, updR = on && !keepR;
             L = updL ? mX : L; R = updR ? mX : R;
-            vL = updL ? mV : vL; vR = updR ? mV : vR;
             act = on && ((R - L) >= res) && L < R;
             if (!__ballot(act)) { up = UP_TAIL; k = 0; }
         } else if (up == UP_TAIL) {
             k += 3;
             if (k >= 6) break;
         } else if (up == UP_INIT) {
-            vL = row_bcast<0>(joint); vR = row_bcast<1>(joint);  // rows that are not on never read them
+            if (KEYED) {
+                kL = __double_as_longlong(row_bcast<0>(__longlong_as_double(key))); kR = __double_as_longlong(row_bcast<1>(__longlong_as_double(key)));
+            } else {
+                vL = row_bcast<0>(joint); vR = row_bcast<1>(joint);  // rows that are not on never read them
+            }
             up = UP_ROUND;                                        // the first round always happens (middle is None)
         } else {
             k += 3;
@@ -2045,6 +2099,9 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
     // register-resident runner: the integrated sample is the only one whose likelihood moves with the chain (no sample is
     // contaminated by it), its pileup fits the register slots and its terms need no renormalisation
     const bool regrun = dep == (1 << inner) && D_in <= 16 * kRegSlots && ((UNI(w->vfast) >> inner) & 1);
+    // keyed passes (see reg_chain_loop): every point of every row has the same finite prior value and a finite fixed part
+    const bool keyed = regrun && c.nlfc == 0 &&
+                       __ballot(rowon && !(cls_fast && (pr0 == pr1 || lo != 0.0) && fabs(pr1) < __builtin_huge_val() && fabs(fixed) < __builtin_huge_val())) == 0ull;
     if (__builtin_expect(regrun, 1)) {
         RegChain rc;
         rc.lo = lo; rc.hi = hi; rc.res = res; rc.fixed = fixed; rc.pr0 = pr0; rc.pr1 = pr1; rc.pr2 = pr2;
@@ -2057,9 +2114,15 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
         const double bvaf = byi >= 0 ? tvr[byi] : 0.0;  // contaminant VAF: fixed along the chain
         rc.al_fix = p.irho[inner] * bvaf; rc.be_fix = p.irho[inner] * (bvaf == 1.0 ? 1.0 : 0.0);
         rc.ecoef = ecoef_of(c, inner, rc.off);
-        if (D_in <= 64) reg_chain_loop<4>(c, rc);
-        else if (D_in <= 128) reg_chain_loop<8>(c, rc);
-        else reg_chain_loop<kRegSlots>(c, rc);
+        if (keyed) {
+            if (D_in <= 64) reg_chain_loop<4, true>(c, rc);
+            else if (D_in <= 128) reg_chain_loop<8, true>(c, rc);
+            else reg_chain_loop<kRegSlots, true>(c, rc);
+        } else {
+            if (D_in <= 64) reg_chain_loop<4, false>(c, rc);
+            else if (D_in <= 128) reg_chain_loop<8, false>(c, rc);
+            else reg_chain_loop<kRegSlots, false>(c, rc);
+        }
         tn = rc.tn; failed = rc.failed; sawnan = rc.sawnan;
         phase = simpson_n ? RP_SIMPSON : RP_TAIL;
         np = 0;
@@ -2225,7 +2288,9 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
                 const int i = rl + 16 * t;
                 const bool on = i < n;
                 const int ic = on ? i : 0;
-                const double xr = tx[ic], vr = tv[ic];
+                const double xr = tx[ic];
+                double vr = tv[ic];
+                if (keyed) vr = (xr == 0.0 ? pr0 : pr1) + (fixed + key_ln(__double_as_longlong(vr)));  // the pass stored the product's key
                 xi[t] = on ? xr : __builtin_huge_val();
                 vi[t] = on ? vr : VLR_NEG_INF;
                 // sort key: the bit pattern of a non-negative double orders like the number; the low six bits carry the
@@ -2303,6 +2368,14 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
                         else tv[i] = vi[t];
                     }
                 }
+            }
+            VLR_WAVE_FENCE();
+        } else if (keyed) {  // no row is sorted (Simpson grids only): the tables still hold keys
+            VLR_WAVE_FENCE();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int i = rl + 16 * t;
+                if (t < TT && i < n) tv[i] = vi[t];
             }
             VLR_WAVE_FENCE();
         }

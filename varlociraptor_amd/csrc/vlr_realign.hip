@@ -338,6 +338,176 @@ __global__ void __launch_bounds__(64) vlr_realign_kernel2(RealignArgs a) {
     }
 }
 
+// ---- `homopolymer` realignment mode --------------------------------------------------------------------------------------
+// HomopolyPairHMMRealigner::calculate_prob_allele (realignment/mod.rs:680-730): bio's HomopolyPairHMM::prob_related with the
+// reference's HopParams (pairhmm.rs:207-295) — the pair HMM above plus, per base, hop states that emit one more copy of the
+// homopolymer base in the read (HopX_b: y_j == b alone) or in the allele (HopY_b: x_i == b alone), entered from the match state of
+// the same base and left to a match state only.  Restated in oracle/vlr_realign_oracle.cpp (vlro_homopoly_prob_related, PARITY
+// UNPINNED: the recursion lives in the un-vendored crate bio) with all fourteen states spelled out; here the model is folded:
+// the match state of a cell is the one of its allele base x_i, so of the four HopX_b / HopY_b / Match_b at most one each is
+// non-zero per cell — HopX needs y_j == x_i, HopY needs x_i == x_{i-1} — and a cell carries five values {M, X, Y, P, Q}
+// (X = x_i alone after a gap open, Y = y_j alone, P = HopY, Q = HopX).  The transition out of a match or hop state depends on the
+// base of the PREVIOUS column (1 - (gap_x + gap_y + hop_x(b') + hop_y(b')), 1 - hop_extend(b')): the per-base constants sit in a
+// 5 x 8 table in LDS (row 4: any other base, no hops), row 0 of a lane looks up the base entering its column, row 1 inherits
+// what row 0 held one step earlier.  Same wavefront, scaling and band as realign_one.
+struct HomopolyArgs {
+    RealignArgs r;
+    double hx[4], hy[4], hxe[4], hye[4];  // linear: start / extend a homopolymer run in the read (x gap) / in the allele (y gap)
+};
+__device__ __forceinline__ int base_index(int b) { return b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : b == 'T' ? 3 : 4; }
+
+__global__ void __launch_bounds__(64) vlr_homopoly_kernel(HomopolyArgs h) {
+    const RealignArgs& a = h.r;
+    const int64_t pair = blockIdx.x;
+    if (pair >= a.n_pairs) return;
+    const int lane = threadIdx.x;
+    __shared__ double tab[5][8];  // {hop_x, hop_y, hop_x_extend, hop_y_extend, match->match, leave hop x, leave hop y, -}
+    if (lane < 5) {
+        const bool acgt = lane < 4;
+        const int b = acgt ? lane : 0;
+        const double hx = acgt ? h.hx[b] : 0.0, hy = acgt ? h.hy[b] : 0.0, hxe = acgt ? h.hxe[b] : 0.0, hye = acgt ? h.hye[b] : 0.0;
+        tab[lane][0] = hx; tab[lane][1] = hy; tab[lane][2] = hxe; tab[lane][3] = hye;
+        tab[lane][4] = 1.0 - (((a.pgx + a.pgy) + hx) + hy);
+        tab[lane][5] = 1.0 - hxe; tab[lane][6] = 1.0 - hye; tab[lane][7] = 0.0;
+    }
+    __syncthreads();
+    const uint32_t x0 = a.x_offset[pair], y0 = a.y_offset[pair];
+    const int len_x = (int)(a.x_offset[pair + 1] - x0), len_y = (int)(a.y_offset[pair + 1] - y0);
+    const int med_max = a.max_edit_dist ? a.max_edit_dist[pair] : -1;
+    const bool banded = med_max >= 0;
+    if (len_y > 128 || len_y <= 0 || len_x <= 0) {
+        if (lane == 0) a.ln_prob[pair] = (len_x <= 0 || len_y <= 0) ? -__builtin_huge_val() : __builtin_nan("");
+        return;
+    }
+    int yb[2];
+    double e_match[2], e_mis[2], e_ins[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int j = 2 * lane + r;
+        const bool rowon = j < len_y;
+        const int q = rowon ? a.y_quals[y0 + j] : 0;
+        yb[r] = rowon ? up(a.y_bases[y0 + j]) : 0;
+        const double mis = exp(-(double)q * 2.302585092994046 / 10.0);
+        e_match[r] = rowon ? 1.0 - mis : 0.0;
+        e_mis[r] = rowon ? mis * 0.3333 : 0.0;
+        e_ins[r] = rowon ? mis : 0.0;
+    }
+    double M1[2] = {0.0, 0.0}, X1[2] = {0.0, 0.0}, Y1[2] = {0.0, 0.0}, P1[2] = {0.0, 0.0}, Q1[2] = {0.0, 0.0};
+    unsigned E1[2] = {kBig, kBig};
+    double Mt[2] = {0.0, 0.0}, Xt[2] = {0.0, 0.0}, Yt[2] = {0.0, 0.0}, Pt[2] = {0.0, 0.0}, Qt[2] = {0.0, 0.0};
+    unsigned Et[2] = {kBig, kBig};
+    // per-base constants of the column each row works on (c*) and of the column before it (p*: what the top-left cell leaves with)
+    double chx[2] = {0.0, 0.0}, chy[2] = {0.0, 0.0}, chxe[2] = {0.0, 0.0}, chye[2] = {0.0, 0.0};
+    double ctm[2] = {a.pn, a.pn}, clx[2] = {1.0, 1.0}, cly[2] = {1.0, 1.0};
+    double ptm[2] = {a.pn, a.pn}, plx[2] = {1.0, 1.0}, ply[2] = {1.0, 1.0};
+    double total = 0.0;
+    int scale = 0;
+    const int last_row = len_y - 1;
+    const int lr = last_row & 1;
+    const bool owner_lane = lane == (last_row >> 1);
+    const int nsteps = len_x + len_y - 1;
+    int xchunk = 0, xb0 = 0, xb1 = 0, xp0 = 0, xp1 = 0;
+    for (int d = 0; d < nsteps; ++d) {
+        if ((d & 63) == 0) {
+            const int i = d + lane;
+            xchunk = (i < len_x) ? up(a.x_bases[x0 + i]) : 0;
+        }
+        const int xnew = __builtin_amdgcn_readlane(xchunk, d & 63);
+        xp1 = xb1; xp0 = xb0;  // the bases of the previous column of each row
+        const int prev1 = xb1;
+        xb1 = xb0;
+        xb0 = (int)shr1((unsigned)prev1, (unsigned)xnew);
+        // constants: row 1 inherits row 0's of the previous step (same column), row 0 looks its new base up
+        ptm[1] = ctm[1]; plx[1] = clx[1]; ply[1] = cly[1];
+        chx[1] = chx[0]; chy[1] = chy[0]; chxe[1] = chxe[0]; chye[1] = chye[0]; ctm[1] = ctm[0]; clx[1] = clx[0]; cly[1] = cly[0];
+        ptm[0] = ctm[0]; plx[0] = clx[0]; ply[0] = cly[0];
+        {
+            const double* t = tab[base_index(xb0)];
+            chx[0] = t[0]; chy[0] = t[1]; chxe[0] = t[2]; chye[0] = t[3]; ctm[0] = t[4]; clx[0] = t[5]; cly[0] = t[6];
+        }
+        double Mu[2], Xu[2], Yu[2], Qu[2];
+        unsigned Eu[2];
+        Mu[0] = shr1z(M1[1]); Xu[0] = shr1z(X1[1]); Yu[0] = shr1z(Y1[1]); Eu[0] = shr1(E1[1], kBig);
+        double Pu0 = shr1z(P1[1]);
+        Qu[0] = shr1z(Q1[1]);
+        {
+            const int nb = (int)shr1((unsigned)scale, (unsigned)scale);
+            if (__ballot(scale != nb)) {
+                const double mass = ((M1[0] + M1[1]) + (X1[0] + X1[1])) + ((Y1[0] + Y1[1]) + (Mt[0] + Mt[1])) + ((Xt[0] + Xt[1]) + (Yt[0] + Yt[1])) +
+                                    ((P1[0] + P1[1]) + (Q1[0] + Q1[1])) + ((Pt[0] + Pt[1]) + (Qt[0] + Qt[1])) + total;
+                if (mass == 0.0) scale = nb;
+                int dsc = scale - nb;
+                dsc = dsc > 1000 ? 1000 : dsc < -1000 ? -1000 : dsc;
+                const double f = __builtin_ldexp(1.0, dsc);
+                Mu[0] *= f; Xu[0] *= f; Yu[0] *= f; Pu0 *= f; Qu[0] *= f;
+            }
+        }
+        Mu[1] = M1[0]; Xu[1] = X1[0]; Yu[1] = Y1[0]; Qu[1] = Q1[0]; Eu[1] = E1[0];
+        const double Pu1 = P1[0];
+        // virtual start row: the top-left neighbour of row 0 holds mass one in every column, left with 1 - (gap_x + gap_y)
+        double tm0 = ptm[0];
+        if (lane == 0) { Mt[0] = __builtin_ldexp(1.0, scale); Et[0] = 0u; tm0 = a.pn; }
+        double Mn[2], Xn[2], Yn[2], Pn[2], Qn[2];
+        unsigned En[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int i = d - (2 * lane + r);
+            const bool incol = (unsigned)i < (unsigned)len_x;
+            const int xb = r == 0 ? xb0 : xb1, xp = r == 0 ? xp0 : xp1;
+            const bool is_match = xb == yb[r];
+            const double emit = is_match ? e_match[r] : e_mis[r];
+            const double tm = r == 0 ? tm0 : ptm[1];
+            const double m = emit * ((tm * Mt[r] + a.pny * Xt[r] + a.pnx * Yt[r]) + (ply[r] * Pt[r] + plx[r] * Qt[r]));
+            const double x = a.pgy * M1[r] + a.pgye * X1[r];
+            const double y = e_ins[r] * (a.pgx * Mu[r] + a.pgxe * Yu[r]);
+            const double pp = (xb == xp && i > 0) ? chy[r] * M1[r] + chye[r] * P1[r] : 0.0;           // x_i == x_{i-1} alone
+            const double qq = is_match ? e_ins[r] * (chx[r] * Mu[r] + chxe[r] * Qu[r]) : 0.0;          // y_j == x_i alone
+            bool live = incol;
+            unsigned e = kBig;
+            if (banded) {
+                const unsigned etl = Et[r], eu = Eu[r], el = E1[r];
+                const unsigned emin = min(etl, min(eu, el));
+                live = incol && !(emin > (unsigned)med_max);
+                e = live ? min(min(is_match ? etl : etl + 1u, min(eu + 1u, el + 1u)), kBig) : kBig;
+            }
+            Mn[r] = live ? m : 0.0; Xn[r] = live ? x : 0.0; Yn[r] = live ? y : 0.0; Pn[r] = live ? pp : 0.0; Qn[r] = live ? qq : 0.0;
+            En[r] = e;
+        }
+        {
+            const double s = ((Mn[lr] + Xn[lr]) + Yn[lr]) + (Pn[lr] + Qn[lr]);
+            total += owner_lane ? s : 0.0;
+        }
+        Mt[0] = Mu[0]; Xt[0] = Xu[0]; Yt[0] = Yu[0]; Pt[0] = Pu0; Qt[0] = Qu[0]; Et[0] = Eu[0];
+        Mt[1] = Mu[1]; Xt[1] = Xu[1]; Yt[1] = Yu[1]; Pt[1] = Pu1; Qt[1] = Qu[1]; Et[1] = Eu[1];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { M1[r] = Mn[r]; X1[r] = Xn[r]; Y1[r] = Yn[r]; P1[r] = Pn[r]; Q1[r] = Qn[r]; E1[r] = En[r]; }
+        if ((d & 7) == 7) {
+            double mx = fmax(fmax(fmax(M1[0], X1[0]), fmax(Y1[0], M1[1])), fmax(X1[1], Y1[1]));
+            mx = fmax(mx, fmax(fmax(Mt[0], Xt[0]), fmax(fmax(Yt[0], Mt[1]), fmax(Xt[1], Yt[1]))));
+            mx = fmax(mx, fmax(fmax(fmax(P1[0], P1[1]), fmax(Q1[0], Q1[1])), fmax(fmax(Pt[0], Pt[1]), fmax(Qt[0], Qt[1]))));
+            int ex = 0;
+            (void)__builtin_frexp(mx, &ex);
+            const bool resc = mx > 0.0 && (ex > 200 || (ex < -200 && !(total > mx * 0x1p60)));
+            if (__ballot(resc)) {
+                const int sh0 = -ex > 1000 ? 1000 : -ex < -1000 ? -1000 : -ex;
+                const int sh = resc ? sh0 : 0;
+                const double f1 = __builtin_ldexp(1.0, sh);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) { M1[r] *= f1; X1[r] *= f1; Y1[r] *= f1; P1[r] *= f1; Q1[r] *= f1; Mt[r] *= f1; Xt[r] *= f1; Yt[r] *= f1; Pt[r] *= f1; Qt[r] *= f1; }
+                total *= f1;
+                scale += sh;
+            }
+        }
+    }
+    const int owner = last_row >> 1;
+    total = __shfl(total, owner);
+    scale = __shfl(scale, owner);
+    if (lane == 0) {
+        double p = (total > 0.0) ? log(total) - (double)scale * 0.6931471805599453 : -__builtin_huge_val();
+        a.ln_prob[pair] = p > 0.0 ? 0.0 : p;
+    }
+}
+
 // ---- edit-distance pre-filter ----------------------------------------------------------------------------------------
 // EditDistanceCalculation::calc_best_hit (edit_distance.rs:164-260; bio Myers `find_all_lazy`): the smallest semiglobal edit
 // distance of the read window against the allele window (free start and end in the allele), the first allele position at
@@ -579,6 +749,22 @@ extern "C" int vlr_launch_pathhmm_kernel(const vlr_realign_batch_desc* b, double
     a.close_x = log(1.0 - gxe); a.close_y = log(1.0 - gye);
     a.reopen_x = log(gxe + (1.0 - gxe) * gx); a.reopen_y = log(gye + (1.0 - gye) * gy);
     hipLaunchKernelGGL(vlr_pathhmm_kernel, dim3((unsigned)b->n_pairs), dim3(64), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+// hop[16] = ln {hop_x[A,C,G,T] (prob_seq_homopolymer), hop_y[..] (prob_ref_homopolymer), hop_x_extend[..], hop_y_extend[..]}
+extern "C" int vlr_launch_homopoly_kernel(const vlr_realign_batch_desc* b, const double* hop, double* ln_prob, void* stream) {
+    using namespace vlr;
+    if (b->n_pairs <= 0) return 0;
+    HomopolyArgs h;
+    RealignArgs& a = h.r;
+    a.n_pairs = b->n_pairs; a.x_offset = b->x_offset; a.x_bases = b->x_bases; a.y_offset = b->y_offset; a.y_bases = b->y_bases;
+    a.y_quals = b->y_quals; a.max_edit_dist = b->max_edit_dist; a.ln_prob = ln_prob;
+    const double gx = exp(b->gap[0]), gy = exp(b->gap[1]), gxe = exp(b->gap[2]), gye = exp(b->gap[3]);
+    a.pgx = gx; a.pgy = gy; a.pgxe = gxe; a.pgye = gye;
+    a.pn = 1.0 - (gx + gy); a.pnx = 1.0 - gxe; a.pny = 1.0 - gye;
+    for (int k = 0; k < 4; ++k) { h.hx[k] = exp(hop[k]); h.hy[k] = exp(hop[4 + k]); h.hxe[k] = exp(hop[8 + k]); h.hye[k] = exp(hop[12 + k]); }
+    hipLaunchKernelGGL(vlr_homopoly_kernel, dim3((unsigned)b->n_pairs), dim3(64), 0, (hipStream_t)stream, h);
     return (int)hipGetLastError();
 }
 

@@ -25,8 +25,9 @@ EXPORTS = [
     "vlr_abi_version", "vlr_build_id", "vlr_last_error", "vlr_plan_create", "vlr_plan_destroy", "vlr_plan_n_out",
     "vlr_plan_n_samples", "vlr_plan_set_max_depth", "vlr_plan_set_max_obs", "vlr_plan_reserve", "vlr_batch_run", "vlr_batch_run_host",
     "vlr_plan_last_kernel_ms", "vlr_plan_work_counters", "vlr_host_alloc", "vlr_host_free",
-    "vlr_realign_batch", "vlr_realign_batch_host", "vlr_realign_fast_batch", "vlr_realign_fast_batch_host", "vlr_edit_distance_batch", "vlr_edit_distance_batch_host", "vlr_fdr_threshold", "vlr_selftest_math", "vlr_selftest_stream",
-    "vlr_obs_read", "vlr_obs_table_free", "vlr_obs_table_batch", "vlr_obs_table_sites", "vlr_obs_write", "vlr_calls_write", "vlr_ingest_last_timings",
+    "vlr_node_create", "vlr_node_destroy", "vlr_node_n_devices", "vlr_node_device", "vlr_node_plan", "vlr_node_set_max_depth", "vlr_node_set_max_obs", "vlr_node_shard_range", "vlr_node_batch_run_host",
+    "vlr_realign_batch", "vlr_realign_batch_host", "vlr_realign_fast_batch", "vlr_realign_fast_batch_host", "vlr_realign_homopolymer_batch", "vlr_realign_homopolymer_batch_host", "vlr_edit_distance_batch", "vlr_edit_distance_batch_host", "vlr_fdr_threshold", "vlr_selftest_math", "vlr_selftest_stream",
+    "vlr_obs_read", "vlr_obs_table_free", "vlr_obs_table_batch", "vlr_obs_table_sites", "vlr_obs_write", "vlr_calls_write", "vlr_ingest_last_timings", "vlr_ingest_total_timings",
     "vlr_obs_reader_open", "vlr_obs_reader_next", "vlr_obs_reader_close", "vlr_calls_writer_open", "vlr_calls_writer_append", "vlr_calls_writer_close", "vlr_calls_filter_fdr",
 ]
 
@@ -228,6 +229,75 @@ class Plan:
         out = (C.c_ulonglong * 2)()
         _check(lib().vlr_plan_work_counters(self._h, out, int(reset)))
         return int(out[0]), int(out[1])
+
+
+def shard_range(n_loci: int, n_shards: int, shard: int):
+    """vlr_node_shard_range: the contiguous block of loci shard `shard` of `n_shards` evaluates (no device needed)."""
+    L = lib()
+    L.vlr_node_shard_range.restype = C.c_int
+    L.vlr_node_shard_range.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    l0, l1 = C.c_int64(), C.c_int64()
+    _check(L.vlr_node_shard_range(int(n_loci), int(n_shards), int(shard), C.byref(l0), C.byref(l1)))
+    return int(l0.value), int(l1.value)
+
+
+class Node:
+    """vlr_gpu_node: one scenario compiled for several devices of this node; call_host shards a host batch over them in one
+    C-ABI call (vlr_node_batch_run_host) and returns the records in input order."""
+
+    def __init__(self, scenario, devices=None, max_depth: Optional[int] = None):
+        L = lib()
+        L.vlr_node_create.restype = C.c_int
+        L.vlr_node_create.argtypes = [C.POINTER(abi.ScenarioDesc), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
+        L.vlr_node_destroy.restype = None
+        L.vlr_node_destroy.argtypes = [C.c_void_p]
+        L.vlr_node_n_devices.restype = C.c_int
+        L.vlr_node_n_devices.argtypes = [C.c_void_p]
+        L.vlr_node_device.restype = C.c_int
+        L.vlr_node_device.argtypes = [C.c_void_p, C.c_int]
+        L.vlr_node_plan.restype = C.c_void_p
+        L.vlr_node_plan.argtypes = [C.c_void_p, C.c_int]
+        L.vlr_node_set_max_depth.restype = C.c_int
+        L.vlr_node_set_max_depth.argtypes = [C.c_void_p, C.c_int]
+        L.vlr_node_set_max_obs.restype = C.c_int
+        L.vlr_node_set_max_obs.argtypes = [C.c_void_p, C.c_int]
+        L.vlr_node_batch_run_host.restype = C.c_int
+        L.vlr_node_batch_run_host.argtypes = [C.c_void_p, C.POINTER(abi.Batch), C.POINTER(abi.Results)]
+        self.scenario = scenario
+        self._h = C.c_void_p()
+        desc = scenario.desc()
+        if devices is None:
+            _check(L.vlr_node_create(C.byref(desc), 0, None, C.byref(self._h)))
+        else:
+            arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+            _check(L.vlr_node_create(C.byref(desc), len(devices), arr, C.byref(self._h)))
+        self.n_devices = L.vlr_node_n_devices(self._h)
+        self.devices = [L.vlr_node_device(self._h, r) for r in range(self.n_devices)]
+        p0 = L.vlr_node_plan(self._h, 0)
+        self.n_out = L.vlr_plan_n_out(p0)
+        self.n_samples = L.vlr_plan_n_samples(p0)
+        if max_depth is not None:
+            _check(L.vlr_node_set_max_depth(self._h, int(max_depth)))
+
+    def set_max_obs(self, n: int):
+        _check(lib().vlr_node_set_max_obs(self._h, int(n)))
+
+    def call_host(self, batch: PileupBatch, afd_capacity: int = 0) -> CallResults:
+        res = CallResults(batch.n_loci, self.n_out, self.n_samples, afd_capacity)
+        bs, rs = batch.as_struct(), res.as_struct()
+        _check(lib().vlr_node_batch_run_host(self._h, C.byref(bs), C.byref(rs)))
+        return res
+
+    def close(self):
+        if self._h:
+            lib().vlr_node_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class DeviceBatch:

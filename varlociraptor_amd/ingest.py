@@ -22,7 +22,7 @@ class ObsSites(C.Structure):
         ("contig_names", C.POINTER(C.c_char_p)), ("contig", C.c_void_p), ("pos", C.c_void_p), ("strings", C.c_void_p),
         ("id_offset", C.c_void_p), ("ref_offset", C.c_void_p), ("alt_offset", C.c_void_p),
         ("group_representative", C.c_void_p), ("heterozygosity_ln", C.c_void_p), ("somatic_effective_mutation_rate_ln", C.c_void_p),
-        ("third_allele_evidence", C.c_void_p), ("imprecise", C.c_void_p),
+        ("third_allele_evidence", C.c_void_p), ("imprecise", C.c_void_p), ("group_key", C.c_void_p),
     ]
 
 
@@ -75,6 +75,7 @@ class Sites:
         self.heterozygosity_ln = _view(s.heterozygosity_ln, n, np.float64)
         self.somatic_effective_mutation_rate_ln = _view(s.somatic_effective_mutation_rate_ln, n, np.float64)
         self.imprecise = _view(s.imprecise, n, np.uint8)
+        self.group_key = _view(s.group_key, n, np.uint64)
         self._strings = s.strings
         self._id, self._ref, self._alt = (_view(p, n, np.uint64) for p in (s.id_offset, s.ref_offset, s.alt_offset))
         self.third_allele_evidence = _view(s.third_allele_evidence, table.n_obs, np.int32)
@@ -137,9 +138,20 @@ def _wrap_table(h):
     table = ObsTable(h)
     batch = table.batch()
     sites = Sites(table)
-    batch.extra = {"third_allele_evidence": sites.third_allele_evidence, "group_representative": sites.group_representative,
+    batch.extra = {"third_allele_evidence": sites.third_allele_evidence, "group_representative": sites.group_representative, "group_key": sites.group_key,
                    "prior_het_ln": sites.heterozygosity_ln, "prior_som_ln": sites.somatic_effective_mutation_rate_ln, "native_table": table}
     return batch, sites
+
+
+def total_timings(reset: bool = False) -> dict:
+    """Stage times summed over all streaming reader / writer calls since the last reset (vlr_ingest_total_timings)."""
+    a = (C.c_double * 16)()
+    L = _lib()
+    L.vlr_ingest_total_timings.restype = None
+    L.vlr_ingest_total_timings.argtypes = [C.POINTER(C.c_double), C.c_int]
+    L.vlr_ingest_total_timings(a, int(reset))
+    k = ["file_read", "inflate", "parse_decode", "files_wall", "merge", "strings", "read_total", None, "encode", "deflate_write", "write_total"]
+    return {n: a[i] for i, n in enumerate(k) if n}
 
 
 class ObsReader:

@@ -13,7 +13,7 @@ In reference v8.9.3 `shrink_to_hit` (pairhmm.rs:66-72) only moves the `ref_offse
 `len_x` of every emission type use the unshrunken fields, so the HMM always sees the whole reference window
 (2 x 1.5 x realignment_window around the breakpoint, mod.rs:149-153) — the band is what bounds the work.
 Not mirrored (documented in DESIGN.md): candidate_region / CIGAR projection (needs BAM records), multiple loci per variant,
-the read-inferred "third allele" (mod.rs:311-349), homopolymer pair HMM mode.
+the read-inferred "third allele" (mod.rs:311-349).
 """
 from __future__ import annotations
 
@@ -41,6 +41,23 @@ class GapParams:
     def as_array(self):
         return (C.c_double * 4)(self.prob_insertion_artifact, self.prob_deletion_artifact,
                                 self.prob_insertion_extend_artifact, self.prob_deletion_extend_artifact)
+
+
+@dataclass
+class HopParams:
+    """ln probabilities per base A, C, G, T (pairhmm.rs:207-256; all zero probability by default)."""
+    prob_seq_homopolymer: Sequence[float] = (-math.inf,) * 4
+    prob_ref_homopolymer: Sequence[float] = (-math.inf,) * 4
+    prob_seq_extend_homopolymer: Sequence[float] = (-math.inf,) * 4
+    prob_ref_extend_homopolymer: Sequence[float] = (-math.inf,) * 4
+
+    def as_list(self):
+        v = [*self.prob_seq_homopolymer, *self.prob_ref_homopolymer, *self.prob_seq_extend_homopolymer, *self.prob_ref_extend_homopolymer]
+        assert len(v) == 16
+        return [float(t) for t in v]
+
+    def as_array(self):
+        return (C.c_double * 16)(*self.as_list())
 
 
 class RealignDesc(C.Structure):
@@ -114,6 +131,22 @@ def prob_best_path(batch: PairBatch, gap: Optional[GapParams] = None, device: in
     return out
 
 
+def prob_related_homopolymer(batch: PairBatch, gap: Optional[GapParams] = None, hop: Optional[HopParams] = None, device: int = 0) -> np.ndarray:
+    """`homopolymer` mode (HomopolyPairHMMRealigner, realignment/mod.rs:680-730): vlr_realign_homopolymer_batch_host."""
+    L = _bind()
+    L.vlr_realign_homopolymer_batch_host.restype = C.c_int
+    L.vlr_realign_homopolymer_batch_host.argtypes = [C.c_int, C.POINTER(RealignDesc), C.POINTER(C.c_double), C.c_void_p]
+    gap = gap or GapParams()
+    hop = hop or HopParams()
+    xo, xb, yo, yb, qb, band = batch.arrays()
+    out = np.empty(len(batch), np.float64)
+    d = RealignDesc(len(batch), xo.ctypes.data, xb.ctypes.data, yo.ctypes.data, yb.ctypes.data, qb.ctypes.data, band.ctypes.data, gap.as_array())
+    rc = L.vlr_realign_homopolymer_batch_host(device, C.byref(d), hop.as_array(), out.ctypes.data)
+    if rc != 0:
+        raise engine.EngineError(rc, (L.vlr_last_error() or b"").decode())
+    return out
+
+
 class DevicePairs:
     """A PairBatch resident in HBM (torch owns the buffers) for vlr_realign_batch / vlr_edit_distance_batch."""
 
@@ -132,6 +165,19 @@ class DevicePairs:
         p = [t.data_ptr() for t in self.t]
         d = RealignDesc(self.n, p[0], p[1], p[2], p[3], p[4], p[5], gap.as_array())
         rc = L.vlr_realign_batch(device, C.byref(d), self.out.data_ptr(), stream)
+        if rc != 0:
+            raise engine.EngineError(rc, (L.vlr_last_error() or b"").decode())
+        return self.out
+
+    def run_homopolymer(self, gap: Optional[GapParams] = None, hop: Optional[HopParams] = None, device: int = 0, stream: int = 0):
+        L = _bind()
+        L.vlr_realign_homopolymer_batch.restype = C.c_int
+        L.vlr_realign_homopolymer_batch.argtypes = [C.c_int, C.POINTER(RealignDesc), C.POINTER(C.c_double), C.c_void_p, C.c_void_p]
+        gap = gap or GapParams()
+        hop = hop or HopParams()
+        p = [t.data_ptr() for t in self.t]
+        d = RealignDesc(self.n, p[0], p[1], p[2], p[3], p[4], p[5], gap.as_array())
+        rc = L.vlr_realign_homopolymer_batch(device, C.byref(d), hop.as_array(), self.out.data_ptr(), stream)
         if rc != 0:
             raise engine.EngineError(rc, (L.vlr_last_error() or b"").decode())
         return self.out
