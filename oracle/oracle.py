@@ -127,6 +127,21 @@ def pathhmm_best(allele: bytes, read: bytes, qual, gap) -> float:
     return float(L.vlro_pathhmm_best(x.ctypes.data, len(allele), y.ctypes.data, q.ctypes.data, len(read), g))
 
 
+def pathhmm_fixed_traceback(allele: bytes, read: bytes, qual, gap):
+    """(ln path probability of the alignment a diagonal-first traceback picks, number of co-optimal alignments at its end position):
+    measurement aid for the `fast` mode (vlro_pathhmm_fixed_traceback)."""
+    L = lib()
+    L.vlro_pathhmm_fixed_traceback.restype = C.c_double
+    L.vlro_pathhmm_fixed_traceback.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    x = np.frombuffer(bytes(allele) or b"\0", np.uint8)
+    y = np.frombuffer(bytes(read) or b"\0", np.uint8)
+    q = np.asarray(bytearray(qual) or b"\0", np.uint8)
+    g = (C.c_double * 4)(*[float(v) for v in gap])
+    n = C.c_double()
+    p = float(L.vlro_pathhmm_fixed_traceback(x.ctypes.data, len(allele), y.ctypes.data, q.ctypes.data, len(read), g, C.byref(n)))
+    return p, float(n.value)
+
+
 def homopoly_prob_related(allele: bytes, read: bytes, qual, gap, hop, max_edit_dist: int = -1) -> float:
     """`homopolymer` realignment mode: restated bio HomopolyPairHMM::prob_related (vlro_homopoly_prob_related); hop = 16 ln values."""
     L = lib()

@@ -201,6 +201,72 @@ double vlro_pathhmm_best(const uint8_t* x, int len_x, const uint8_t* y, const ui
     return result.d >= BIG ? NEG_INF : result.p;
 }
 
+// Measurement aid for the `fast` mode: the path probability of ONE optimal alignment picked by a fixed
+// traceback rule — from the FIRST end position of minimal distance backwards, preferring the diagonal (match / substitution), then
+// a deletion (allele base alone), then an insertion: what a Myers traceback that prefers diagonals would return — next to
+// vlro_pathhmm_best's maximum over ALL co-optimal alignments, and the number of co-optimal alignments ending at that position
+// (capped at 1e9).  Same transition and emission terms as vlro_pathhmm_best.
+double vlro_pathhmm_fixed_traceback(const uint8_t* x, int len_x, const uint8_t* y, const uint8_t* qual, int len_y, const double* gap,
+                                    double* n_cooptimal) {
+    if (n_cooptimal) *n_cooptimal = 0.0;
+    if (len_x <= 0 || len_y <= 0) return NEG_INF;
+    const double gx = gap[0], gy = gap[1], gxe = gap[2], gye = gap[3];
+    const double no_gap = ln_one_minus_exp(ln_add_exp(gx, gy));
+    const double close_x = ln_one_minus_exp(gxe), close_y = ln_one_minus_exp(gye);
+    const double reopen_x = ln_add_exp(gxe, close_x + gx), reopen_y = ln_add_exp(gye, close_y + gy);
+    const double CONF = std::log(0.3333);
+    // D[j][c]: semiglobal edit distance of y[0..j) against a suffix of x[0..c) (free start in x); W: number of optimal alignments
+    std::vector<std::vector<int>> D((size_t)len_y + 1, std::vector<int>((size_t)len_x + 1, 0));
+    std::vector<std::vector<double>> W((size_t)len_y + 1, std::vector<double>((size_t)len_x + 1, 1.0));
+    for (int j = 1; j <= len_y; ++j) {
+        D[(size_t)j][0] = j; W[(size_t)j][0] = 1.0;
+        for (int c = 1; c <= len_x; ++c) {
+            const int sub = D[(size_t)j - 1][(size_t)c - 1] + (upper(x[c - 1]) == upper(y[j - 1]) ? 0 : 1);
+            const int del = D[(size_t)j][(size_t)c - 1] + 1, ins = D[(size_t)j - 1][(size_t)c] + 1;
+            const int d = std::min(sub, std::min(del, ins));
+            double w = 0.0;
+            if (sub == d) w += W[(size_t)j - 1][(size_t)c - 1];
+            if (del == d) w += W[(size_t)j][(size_t)c - 1];
+            if (ins == d) w += W[(size_t)j - 1][(size_t)c];
+            D[(size_t)j][(size_t)c] = d; W[(size_t)j][(size_t)c] = std::min(w, 1e9);
+        }
+    }
+    int best = D[(size_t)len_y][1], end = 1;
+    for (int c = 1; c <= len_x; ++c)
+        if (D[(size_t)len_y][(size_t)c] < best) { best = D[(size_t)len_y][(size_t)c]; end = c; }
+    if (n_cooptimal) *n_cooptimal = W[(size_t)len_y][(size_t)end];
+    // traceback (operations in reverse), then the path probability forwards
+    std::vector<char> ops;
+    int j = len_y, c = end;
+    while (j > 0) {
+        const int d = D[(size_t)j][(size_t)c];
+        if (c > 0 && D[(size_t)j - 1][(size_t)c - 1] + (upper(x[c - 1]) == upper(y[j - 1]) ? 0 : 1) == d) { ops.push_back('M'); --j; --c; }
+        else if (c > 0 && D[(size_t)j][(size_t)c - 1] + 1 == d) { ops.push_back('D'); --c; }
+        else { ops.push_back('I'); --j; }
+    }
+    std::reverse(ops.begin(), ops.end());
+    double p = 0.0;
+    char prev = 0;
+    int pr = c, pj = 0;
+    for (char op : ops) {
+        if (op == 'M') {
+            if (prev == 'D') p += close_y; else if (prev == 'I') p += close_x; else if (prev == 'M') p += no_gap;
+            const double lm = -(double)qual[pj] * LN10 / 10.0;
+            p += upper(x[pr]) == upper(y[pj]) ? ln_one_minus_exp(lm) : lm + CONF;
+            ++pr; ++pj;
+        } else if (op == 'D') {
+            if (prev == 'D') p += reopen_y; else if (prev == 'I') p += close_x + gy; else p += gy;
+            ++pr;
+        } else {
+            if (prev == 'I') p += reopen_x; else if (prev == 'D') p += close_y + gx; else p += gx;
+            p += -(double)qual[pj] * LN10 / 10.0;
+            ++pj;
+        }
+        prev = op;
+    }
+    return p;
+}
+
 // `homopolymer` realignment mode — HomopolyPairHMMRealigner::calculate_prob_allele (realignment/mod.rs:680-730, selected at
 // cli.rs:912-947): bio::stats::pairhmm::HomopolyPairHMM::prob_related over the same ReadVsAlleleEmission (plus its
 // `Emission` impl that hands out the bases themselves, pairhmm.rs:370-384), GapParams, and the reference's HopParams

@@ -184,6 +184,52 @@ def test_cli_breakend_event_that_straddles_reader_chunks(golden_dir, tmp_path, m
             assert np.array_equal(got.map_vaf[l], plain.map_vaf[want], equal_nan=True), l
 
 
+def test_cli_call_processor_and_candidate_filter_plug_points(tmp_path, monkeypatch):
+    """calling.rs:964-1020: the driver's two plug points, as `estimate contamination` uses them (contamination.rs:371-428): a
+    candidate filter that keeps SNVs with a clean contaminant pileup and strong alt evidence in the sample, and a processor that
+    collects the calls instead of writing a file.  The collected results are those of the unfiltered run at the kept records."""
+    import numpy as np
+    from varlociraptor_amd import ingest, synth
+    from varlociraptor_amd.scenario import Sample, Scenario
+    sc = Scenario({"sample": Sample(resolution=0.01, universe="[0.0,1.0]"), "contaminant": Sample(resolution=0.01, universe="[0.0,1.0]")},
+                  {"denovo": "sample:]0.0,1.0] & contaminant:0.0", "other": "sample:[0.0,1.0] & contaminant:]0.0,1.0]"})
+    cfg = synth.config3()
+    cfg.depth = 40.0
+    batch = synth.generate(cfg, 600, seed=41)    # two samples in name order: contaminant = index 0, sample = index 1
+    paths = {}
+    for s_, name in enumerate(sc.sample_names):
+        paths[name] = str(tmp_path / ("%s.bcf" % name))
+        ingest.write_observations(paths[name], batch, s_)
+    monkeypatch.setenv("VLR_CLI_CHUNK", "250")
+
+    class Collect(cli.CallProcessor):
+        def __init__(self):
+            self.rows, self.loci, self.setups, self.done = [], [], 0, 0
+
+        def setup(self, out_names, sample_names):
+            self.setups += 1
+            assert out_names[0] == "absent" and sample_names == ["contaminant", "sample"]
+
+        def process_calls(self, chunk):
+            assert chunk.results.n_loci == len(chunk.loci) == chunk.batch.n_loci
+            self.rows.append(np.array(chunk.results.ln_posterior))
+            self.loci.append(np.array(chunk.loci) + chunk.offset)
+
+        def finalize(self):
+            self.done += 1
+    col = Collect()
+    cli.call_variants(sc, paths, processor=col, candidate_filter=cli.ContaminationCandidateFilter())
+    assert col.setups == 1 and col.done == 1
+    kept = np.concatenate(col.loci)
+    want = cli.ContaminationCandidateFilter().filter(batch, None, sc.sample_names)
+    assert 0 < want.sum() < batch.n_loci
+    assert np.array_equal(np.nonzero(want)[0], kept)
+    full = cli.call_variants(sc, paths, out=io.StringIO())
+    assert np.array_equal(np.concatenate(col.rows), full.ln_posterior[kept])
+    with pytest.raises(ValueError):
+        cli.call_variants(sc, paths, candidate_filter=cli.CandidateFilter())
+
+
 def test_cli_reads_variant_specific_priors_from_the_first_record_of_a_contig(golden_dir, tmp_path):
     import numpy as np
     d = os.path.join(golden_dir, "flamegraph_profiling")

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 def big_batch(name, n):
     from bench import generate
-    return generate(name, n, 0, chunk_loci=25000, workers=8)
+    return generate(name, n, 0, chunk_loci=25000, workers=8 if n <= 200_000 else 14)
 
 
 @pytest.fixture(scope="module")
@@ -115,6 +115,67 @@ def test_random_sample_of_the_full_batch_matches_the_oracle(config3_full, oracle
     m = compare(got, ref, label="config3 sample of 200k")
     print(describe(m))
     assert m["frac_within"] == 1.0, describe(m)
+
+
+# ---- BASELINE configs[3] and configs[4] at their per-GPU FULL sizes (10 M / 8 and 5 M / 8 loci): the same size-independent
+# properties as config 3 above plus oracle parity on a random sample
+FULL_SIZES = {"config4": 1_250_000, "config5": 625_000}
+
+
+@pytest.fixture(scope="module", params=sorted(FULL_SIZES))
+def full_config(request):
+    name = request.param
+    cfg = synth.CONFIGS[name]()
+    b = big_batch(name, FULL_SIZES[name])
+    plan = engine.Plan(cfg.scenario)
+    plan.set_max_obs(min(int(b.depth().sum(axis=1).max()), engine.MAX_OBS_LDS))
+    res = plan.call_host(b)
+    yield name, cfg, b, plan, res
+    plan.close()
+
+
+def test_full_size_normalisation_determinism_and_shards(full_config):
+    name, cfg, b, plan, res = full_config
+    n = b.n_loci
+    assert n == FULL_SIZES[name]
+    assert not (res.status & 0xF).any()
+    ps = np.exp(res.ln_posterior)
+    assert np.all(np.isfinite(ps))
+    assert np.abs(ps.sum(axis=1) - 1.0).max() < 1e-9
+    ok = ~np.isnan(res.map_vaf)
+    assert np.all((res.map_vaf[ok] >= 0.0) & (res.map_vaf[ok] <= 1.0))
+    # the multi-GPU partition: contiguous shards of 8 ranks give bit-identical per-locus results (ranks 0 and 5 here)
+    for rank in (0, 5):
+        lo, hi = shard_range(n, rank, 8)
+        sub = plan.call_host(b.select(np.arange(lo, hi)))
+        assert np.array_equal(sub.ln_posterior, res.ln_posterior[lo:hi])
+        assert np.array_equal(sub.map_vaf, res.map_vaf[lo:hi], equal_nan=True)
+        assert np.array_equal(sub.status, res.status[lo:hi])
+    # permutation invariance and run-to-run determinism on a random 60 000-locus subset
+    rng = np.random.default_rng(11)
+    perm = rng.permutation(n)[:60_000]
+    pb = b.select(perm)
+    one, two = plan.call_host(pb), plan.call_host(pb)
+    for f in ("ln_posterior", "map_bias", "best_event", "status"):
+        assert np.array_equal(getattr(one, f), getattr(res, f)[perm]), f
+        assert np.array_equal(getattr(one, f), getattr(two, f)), f
+    assert np.array_equal(one.map_vaf, res.map_vaf[perm], equal_nan=True)
+
+
+def test_full_size_random_sample_matches_the_oracle(full_config, oracle):
+    from test_gpu_edge_cases import oracle_mt
+    from varlociraptor_amd.batch import CallResults
+    name, cfg, b, plan, res = full_config
+    rng = np.random.default_rng(13)
+    pick = np.sort(rng.choice(b.n_loci, size=3000, replace=False))
+    ref = oracle_mt(oracle, cfg.scenario, b.select(pick), threads=min(64, os.cpu_count() or 8))
+    got = CallResults(len(pick), plan.n_out, plan.n_samples)
+    for f in ("ln_posterior", "map_vaf", "map_bias", "best_event", "status"):
+        getattr(got, f)[:] = getattr(res, f)[pick]
+    m = compare(got, ref, label="%s sample of %d" % (name, b.n_loci))
+    print(describe(m))
+    assert m["frac_within"] == 1.0, describe(m)
+    assert m["status_equal"]
 
 
 def test_config2_full_size_parity(oracle):

@@ -98,10 +98,73 @@ def _scenario_signature(sc: Scenario):
     return tuple((n, s.universe, s.ploidy) for n, s in sc.samples.items()) + (sc.variant_heterozygosity_ln, sc.variant_somatic_effective_mutation_rate_ln)
 
 
+class CallChunk:
+    """What a CallProcessor sees of one chunk of records, in input order: the pileups (`batch`), the site columns (`sites`:
+    contig, pos, ref / alt through sites.ref(l) ...), the results (`results`: ln_posterior[l][k] for out_names[k], map_vaf,
+    map_bias, status, AFD lists) and `loci`, the indices of these records within the chunk the reader delivered."""
+
+    def __init__(self, batch, sites, results, out_names, sample_names, loci, offset=0):
+        self.batch, self.sites, self.results, self.out_names, self.sample_names, self.loci = batch, sites, results, out_names, sample_names, loci
+        self.offset = offset   # records of the file(s) delivered before this chunk: offset + loci = record numbers
+
+
+class CallProcessor:
+    """Plug point of the driver, calling.rs:964-975 (`CallProcessor{setup, process_call, finalize}`): what is done with the calls.
+    The default (processor=None) is the reference's CallWriter (calling.rs:977-1006): the calls file.  `estimate contamination`
+    (estimation/contamination.rs:371-399) plugs a collector in here.  process_calls is the batched form of process_call: one
+    invocation per chunk of the streaming reader, records in input order."""
+
+    def setup(self, out_names, sample_names):
+        return None
+
+    def process_calls(self, chunk: "CallChunk"):
+        raise NotImplementedError
+
+    def finalize(self):
+        return None
+
+
+class CandidateFilter:
+    """calling.rs:1008-1020 (`CandidateFilter::filter(work_item, sample_names) -> bool`), vectorised over a chunk: returns a boolean
+    array, True = the record is processed (evaluated and handed to the processor), False = skipped as in calling.rs:409."""
+
+    def filter(self, batch, sites, sample_names):
+        import numpy as np
+        return np.ones(batch.n_loci, bool)
+
+
+class ContaminationCandidateFilter(CandidateFilter):
+    """estimation/contamination.rs:404-428: SNVs whose contaminant pileup has >= 10 observations that are all ref support
+    (prob_ref > prob_alt, read_observation.rs:439-441) and whose sample pileup has >= 10 observations with at least one strong
+    alt support (Bayes factor alt:ref above 20, read_observation.rs:429-432)."""
+
+    def filter(self, batch, sites, sample_names):
+        import numpy as np
+        S = batch.n_samples
+        ci, si = list(sample_names).index("contaminant"), list(sample_names).index("sample")
+        off = batch.obs_offset.astype(np.int64)
+        pa, pr = batch.columns["prob_alt"].astype(np.float64), batch.columns["prob_ref"].astype(np.float64)
+        ref_support = pr > pa
+        with np.errstate(invalid="ignore"):   # (-inf) - (-inf)
+            strong_alt = (pa - pr) > np.log(20.0)
+        cs = np.concatenate([[0], np.cumsum(~ref_support)])
+        sa = np.concatenate([[0], np.cumsum(strong_alt)])
+        L = batch.n_loci
+        c0, c1 = off[np.arange(L) * S + ci], off[np.arange(L) * S + ci + 1]
+        s0, s1 = off[np.arange(L) * S + si], off[np.arange(L) * S + si + 1]
+        has_snv = (batch.locus["locus_flags"] & abi.LOCUS_HAS_SNV) != 0
+        return has_snv & (c1 - c0 >= 10) & (cs[c1] - cs[c0] == 0) & (s1 - s0 >= 10) & (sa[s1] - sa[s0] > 0)
+
+
 def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_capacity: int = 128, out=sys.stdout,
-                  device: int = 0, output: str = None, ingest: str = None, timings: dict = None):
+                  device: int = 0, output: str = None, ingest: str = None, timings: dict = None,
+                  processor: "CallProcessor" = None, candidate_filter: "CandidateFilter" = None):
     """`scenario`: a Scenario, or a callable contig -> Scenario (contig-specific universes / ploidies: one plan per
-    distinct resolution, as the reference re-configures its model on contig change, calling.rs:343-356)."""
+    distinct resolution, as the reference re-configures its model on contig change, calling.rs:343-356).
+    `processor` / `candidate_filter`: the driver's two plug points (calling.rs:964-1020); with a processor no calls file is
+    written (the processor IS the consumer, as CallWriter is in the reference); a candidate filter needs a processor."""
+    if candidate_filter is not None and processor is None:
+        raise ValueError("a candidate filter comes with its own call processor (calling.rs:1022-1040: call_generic takes both)")
     per_contig = scenario if callable(scenario) else (lambda contig: scenario)
     scen: Dict[str, Scenario] = {}
 
@@ -142,6 +205,8 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
     import time
     from .batch import CallResults
     native = (ingest or os.environ.get("VLR_INGEST", "native")) == "native"
+    if processor is not None and not native:
+        raise ValueError("call processors plug into the native streaming driver (VLR_INGEST=native)")
     world, rank = 1, 0
     try:
         import torch.distributed as tdist
@@ -312,8 +377,9 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                 while q_out.get() is not None:
                     pass
 
+        proc_state = {"setup": False}
         tr = threading.Thread(target=read_loop, daemon=True)
-        tw = threading.Thread(target=write_loop, daemon=True) if rank == 0 else None
+        tw = threading.Thread(target=write_loop, daemon=True) if (rank == 0 and processor is None) else None
         tr.start()
         if tw:
             tw.start()
@@ -328,8 +394,24 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                 batch, sites = item
                 t0 = time.perf_counter()
                 contig_names = list(sites.contig_names)
-                res, nm = evaluate(batch, contig_names, np.asarray(sites.contig, np.int64), batch.extra["prior_het_ln"], batch.extra["prior_som_ln"],
-                                   np.asarray(batch.extra["group_representative"], np.int64), np.asarray(batch.extra["group_key"], np.uint64))
+                contig_of = np.asarray(sites.contig, np.int64)
+                het_, som_ = batch.extra["prior_het_ln"], batch.extra["prior_som_ln"]
+                grep_, gkey_ = np.asarray(batch.extra["group_representative"], np.int64), np.asarray(batch.extra["group_key"], np.uint64)
+                loci_ = np.arange(batch.n_loci)
+                ebatch = batch
+                if candidate_filter is not None:   # calling.rs:409: work items the filter rejects are not processed at all
+                    keep = np.asarray(candidate_filter.filter(batch, sites, sample_order), bool)
+                    if not keep.all():
+                        loci_ = np.nonzero(keep)[0]
+                        ebatch = batch.select(loci_)
+                        contig_of, het_, som_, gkey_ = contig_of[loci_], np.asarray(het_)[loci_], np.asarray(som_)[loci_], gkey_[loci_]
+                        # representatives among the records that are left: the first kept record of every group
+                        grep_ = np.arange(len(loci_))
+                        first_of: Dict[int, int] = {}
+                        for j_, k_ in enumerate(gkey_):
+                            if k_:
+                                grep_[j_] = first_of.setdefault(int(k_), j_)
+                res, nm = (evaluate(ebatch, contig_names, contig_of, het_, som_, grep_, gkey_) if ebatch.n_loci else (None, None))
                 names = names or nm
                 stage["call_s"] += time.perf_counter() - t0
                 stage["n_loci"] += batch.n_loci
@@ -337,7 +419,13 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                 if not used_contigs:
                     used_contigs = contig_names if not is_text else [contig_names[int(c_)] for c_ in np.unique(np.asarray(sites.contig))]
                 collected.append(res)
-                if tw and res is not None:
+                if processor is not None:
+                    if res is not None and rank == 0:
+                        if not proc_state["setup"]:
+                            processor.setup(list(names), list(sample_order))
+                            proc_state["setup"] = True
+                        processor.process_calls(CallChunk(ebatch, sites, res, list(names), list(sample_order), loci_, stage["n_loci"] - batch.n_loci))
+                elif tw and res is not None:
                     q_out.put((batch.extra["native_table"], res, names, used_contigs))
         finally:
             if tw:
@@ -349,7 +437,12 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
             close_plans()
         if errors:
             raise errors[0]
-        if rank == 0:
+        if processor is not None:
+            if rank == 0:
+                if not proc_state["setup"]:
+                    processor.setup(list(names or resolve(used_contigs[0] if used_contigs else "all").out_names()), list(sample_order))
+                processor.finalize()
+        elif rank == 0:
             if writer_state["w"] is None:  # no records at all: the header alone
                 hdr, _ = header_for(names, used_contigs)
                 if output:

@@ -607,6 +607,9 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
     // ---- all-discrete roots, flattened for the lane-parallel leaf evaluation (vlr_kernels.hip eval_discrete_root)
     std::vector<DevDLeaf> dleaf;
     std::vector<DevDKey> dkey;
+    // ---- compiled roots (DevFastRoot): chains of single-valued Sample nodes ending in a leaf Range node
+    std::vector<DevFastRoot> froot(1 + roots.size());
+    for (auto& f : froot) { memset(&f, 0, sizeof f); }
     std::vector<int32_t> droot(2 * (1 + roots.size()), -1);
     {
         auto node_values = [&](const DevNode& n, std::vector<double>& vals) {
@@ -734,6 +737,63 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
         }
         P.n_dkey = (int32_t)dkey.size();
         P.n_dleaf = (int32_t)dleaf.size();
+        if (!getenv("VLR_NO_FAST_ROOTS")) {
+            auto may_contain = [&](int g, int s2, double v) {  // group_may_contain of the kernel: some spectrum of group g for sample s2 holds v
+                for (int k = gs_off[g * S + s2]; k < gs_off[g * S + s2 + 1]; ++k) {
+                    const DevSpectrum& sp = gs[k];
+                    if (sp.kind == VLR_SPECTRUM_SET) { for (int i = 0; i < sp.set_len; ++i) if (pool[sp.set_off + i] == v) return true; }
+                    else if ((sp.start < v || (!sp.lex && sp.start == v)) && (sp.end > v || (!sp.rex && sp.end == v))) return true;
+                }
+                return false;
+            };
+            for (size_t i = 0; i < froot.size(); ++i) {
+                int own = 0;
+                if (i > 0) for (int e = 0; e < d->n_events; ++e) if ((int)(i - 1) >= root_off[e] && (int)(i - 1) < root_off[e + 1]) own = e + 1;
+                DevFastRoot f{};
+                int node = i == 0 ? P.absent_root : roots[i - 1];
+                uint32_t have = 0;
+                int alive = (int)((1u << (d->n_events + 1)) - 1u) & ~(1 << own);
+                int pidx = 0;
+                bool ok = true;
+                for (;;) {
+                    const DevNode& n = nodes[node];
+                    if (n.kind != VLR_NODE_SAMPLE || (have & (1u << n.sample))) { ok = false; break; }
+                    have |= 1u << n.sample;
+                    const bool single = n.vafs.kind == VLR_SPECTRUM_SET ? n.vafs.set_len == 1 : (n.vafs.start == n.vafs.end && !n.vafs.lex && !n.vafs.rex);
+                    if (n.n_children == 0) {   // the leaf: a proper range
+                        if (n.vafs.kind != VLR_SPECTRUM_RANGE || n.vafs.start == n.vafs.end) { ok = false; break; }
+                        f.inner = n.sample; f.leaf_node = node;
+                        f.start = n.vafs.start; f.end = n.vafs.end; f.lex = n.vafs.lex; f.rex = n.vafs.rex;
+                        f.alive = alive & n.alive_mask;
+                        break;
+                    }
+                    if (n.n_children != 1 || !single || f.n_fixed >= kMaxSamples) { ok = false; break; }
+                    const double v = n.vafs.kind == VLR_SPECTRUM_SET ? pool[n.vafs.set_off] : n.vafs.start;
+                    f.fsample[f.n_fixed] = n.sample; f.fvaf[f.n_fixed] = v; f.n_fixed++;
+                    f.disc |= 1 << n.sample;
+                    pidx += prior_class(n.sample, v) * P.class_stride[n.sample];
+                    // walk_root: f.sv_alive = c.alive & nd.alive_mask; c.alive = alive_update(sv_alive & nd.alive_mask, s, v)
+                    int m = alive & n.alive_mask, res = m;
+                    for (int g = 0; g <= d->n_events; ++g)
+                        if (((m >> g) & 1) && !may_contain(g, n.sample, v)) res &= ~(1 << g);
+                    alive = res;
+                    node = child[n.child_off];
+                }
+                if (!ok || have != ((1u << S) - 1u)) {   // (a chain record needs every sample on the path: the operands of a leaf are complete)
+                    // Not a chain.  If the probe pass would hand the root to the general pass at its very first node anyway — a Sample
+                    // node with a proper Range above other nodes, or with a Set of several members (walk_root: deferred = 2) — say so:
+                    // the event loop then skips the probe walk (kind 2).
+                    const DevNode& r0 = nodes[i == 0 ? P.absent_root : roots[i - 1]];
+                    if (r0.kind == VLR_NODE_SAMPLE &&
+                        ((r0.vafs.kind == VLR_SPECTRUM_RANGE && r0.vafs.start != r0.vafs.end && r0.n_children != 0) ||
+                         (r0.vafs.kind == VLR_SPECTRUM_SET && r0.vafs.set_len > 1)))
+                        froot[i].kind = 2;
+                    continue;
+                }
+                f.kind = 1; f.pidx = pidx;
+                froot[i] = f;
+            }
+        }
     }
 
     rc = check_device(device);
@@ -749,7 +809,8 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
            o_dl = o_gs + al(std::max<size_t>(1, gs.size()) * sizeof(DevSpectrum)),
            o_dk = o_dl + al(std::max<size_t>(1, dleaf.size()) * sizeof(DevDLeaf)),
            o_dr = o_dk + al(std::max<size_t>(1, dkey.size()) * sizeof(DevDKey)),
-           total = o_dr + al(droot.size() * 4);
+           o_fr = o_dr + al(droot.size() * 4),
+           total = o_fr + al(froot.size() * sizeof(DevFastRoot));
     std::vector<char> hostblob(total, 0);
     memcpy(&hostblob[o_nodes], nodes.data(), nodes.size() * sizeof(DevNode));
     if (!child.empty()) memcpy(&hostblob[o_child], child.data(), child.size() * 4);
@@ -763,6 +824,7 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
     if (!dleaf.empty()) memcpy(&hostblob[o_dl], dleaf.data(), dleaf.size() * sizeof(DevDLeaf));
     if (!dkey.empty()) memcpy(&hostblob[o_dk], dkey.data(), dkey.size() * sizeof(DevDKey));
     memcpy(&hostblob[o_dr], droot.data(), droot.size() * 4);
+    memcpy(&hostblob[o_fr], froot.data(), froot.size() * sizeof(DevFastRoot));
 
     vlr_plan* plan = new vlr_plan();
     plan->device = device;
@@ -781,6 +843,7 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
     P.dleaf = (const DevDLeaf*)(base + o_dl);
     P.dkey = (const DevDKey*)(base + o_dk);
     P.droot = (const int32_t*)(base + o_dr);
+    P.froot = (const DevFastRoot*)(base + o_fr);
     plan->host = P;
     hipError_t e = hipMemcpy(plan->blob, hostblob.data(), total, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&plan->dev, sizeof(DevPlan));

@@ -740,7 +740,8 @@ struct Ctx {
     int nframes, nrs;
     int cap;                         // capacity of one visited-point table
     double *rowX, *rowV;             // [kRows][cap] visited-point tables of the row-parallel innermost chains
-    double* afd_seen;                // replay: [S][kMaxSet] recorded discrete operands: (VAF, l2fc-list key) pairs
+    double* afd_seen;                // replay: [S][seen_cap] recorded discrete operands: (VAF, l2fc-list key) pairs
+    int seen_cap;                    // = max(16, largest Set spectrum of the plan)
     double* mapv;                    // replay: [S] MAP VAF per sample
     int* afd_cnt;                    // AFD filter kernel: [S] entries written so far, in LDS (one wave owns the locus: no global atomic per
                                      // entry); nullptr in the replay launch, which counts in afd_count itself
@@ -1279,11 +1280,11 @@ __device__ inline void afd_consider(Ctx& c, double joint, int inner, double x, i
             int ns = c.afd_nseen[s];
             bool seen = false;
             for (int i = 0; i < ns; ++i)
-                seen = seen || (c.afd_seen[2 * (s * kMaxSet + i)] == vs && __double_as_longlong(c.afd_seen[2 * (s * kMaxSet + i) + 1]) == lkey);
+                seen = seen || (c.afd_seen[2 * (s * c.seen_cap + i)] == vs && __double_as_longlong(c.afd_seen[2 * (s * c.seen_cap + i) + 1]) == lkey);
             if (seen) continue;
             VLR_SYNC();
-            if (c.lane == 0 && ns < kMaxSet) {
-                c.afd_seen[2 * (s * kMaxSet + ns)] = vs; c.afd_seen[2 * (s * kMaxSet + ns) + 1] = __longlong_as_double(lkey);
+            if (c.lane == 0 && ns < c.seen_cap) {
+                c.afd_seen[2 * (s * c.seen_cap + ns)] = vs; c.afd_seen[2 * (s * c.seen_cap + ns) + 1] = __longlong_as_double(lkey);
                 c.afd_nseen[s] = ns + 1;
             }
             VLR_SYNC();
@@ -2716,6 +2717,54 @@ __device__ __forceinline__ void move_task(Ctx& c, int from, int to) {
     VLR_SYNC();
 }
 
+// Compiled chain root (DevFastRoot, vlr_plan.h): what walk_root does in the probe pass for a root that is a chain of single-valued
+// Sample nodes ending in a leaf Range node — clear-ref shortcuts of every node on the way (modes/generic.rs:270-347), operands,
+// the leaf's observable range, fixed-sample likelihoods, the deferred ChainTask — from the plan's record instead of the tree.
+// Returns 0: the density is ln 0 (a node is dead: nothing to add to the event), 1: deferred as task c.ndef - 1,
+// 2: leave the root to the general pass (another integrated sample than the chains collected so far / tables above 64 entries).
+__device__ __forceinline__ int fast_chain_root(Ctx& c, const DevFastRoot* fr) {
+    const DevPlan& p = *c.plan;
+    WaveSt* w = c.w;
+    const int lane = fresh_lane(c.lane), S = c.S;
+    const int n_fixed = ldc(&fr->n_fixed), inner = ldc(&fr->inner);
+    // the fixed values, one per lane (lane k < n_fixed: node k of the path)
+    const int kf = lane < n_fixed ? lane : 0;
+    const int fs = fr->fsample[kf];
+    const double fv = fr->fvaf[kf];
+    // clear_ref && every VAF of the node above zero: the node (and the root) is dead — Set 294-330, singleton Range 342-347
+    const bool dead_l = lane < n_fixed && w->nkeep[fs] > 10 && w->all_posref[fs] != 0 && fv > 0.0;
+    const int n_obs = UNI(w->nkeep[inner]);
+    const bool clear_in = n_obs > 10 && UNI((int)w->all_posref[inner]) != 0;
+    const RangeV vr{ldc(&fr->start), ldc(&fr->end), ldc(&fr->lex), ldc(&fr->rex)};
+    if (__ballot(dead_l) != 0ull || (clear_in && vr.start > 0.0)) return 0;
+    if (c.cap > 64 || (c.ndef > 0 && UNI(w->task[0].inner) != inner)) return 2;
+    VLR_SYNC();
+    if (lane < n_fixed) w->ops_vaf[fs] = fv;
+    VLR_SYNC();
+    const double res = p.resolution[inner];
+    const double lo = uni_d(observable_min(vr, n_obs)), hi = uni_d(observable_max(vr, n_obs));
+    const int simpson = ((hi - lo) < res) ? 3 : (n_obs < 5 ? 11 : 0);  // 367-394
+    double fixed = 0.0;
+    for (int s2 = 0; s2 < S; ++s2) {
+        const int by = p.by[s2];
+        if (!(s2 == inner || by == inner)) fixed += sample_lik(c, s2, w->ops_vaf[s2], by >= 0 ? w->ops_vaf[by] : 0.0);
+    }
+    const int row = c.ndef;
+    VLR_SYNC();
+    if (lane == 0) {
+        ChainTask& T = w->task[row];
+        T.lo = lo; T.hi = hi; T.res = res; T.ostart = vr.start; T.oend = vr.end; T.olex = vr.lex; T.orex = vr.rex;
+        T.simpson_n = simpson; T.fixed = fixed; T.pidx = ldc(&fr->pidx); T.contained = 1; T.alive = ldc(&fr->alive);
+        T.result = VLR_NEG_INF; T.haveBest = 0; T.n = 0; T.bestJ = VLR_NEG_INF; T.bestX = 0.0;
+        T.group = c.group; T.disc = ldc(&fr->disc); T.inner = inner; T.u = c.defer_slot;
+    }
+    if (lane < S) c.tvaf[row * S + lane] = w->ops_vaf[lane];
+    VLR_SYNC();
+    c.ndef = row + 1;
+    c.afd_mute = 0;
+    return 1;
+}
+
 // node id of the single child of `fnode` if that child is a leaf Sample node with a proper Range spectrum, else -1
 __device__ __forceinline__ int leaf_range_child(const DevPlan& p, int fnode) {
     const DevNode* f = p.nodes + fnode;
@@ -3082,7 +3131,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
 //   3. discrete leaves: classified one per lane, matches through afd_consider.
 __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, DevBatch batch, DevResults out) {
     __shared__ WaveSt wst;
-    __shared__ double sh_seen[2 * kMaxSamples * kMaxSet];  // (VAF, l2fc key) pairs
+    extern __shared__ double sh_seen[];  // [S][seen_cap] (VAF, l2fc key) pairs (dynamic: the plan's largest Set spectrum sets the size)
     __shared__ double sh_mapv[kMaxSamples];
     __shared__ int sh_nseen[kMaxSamples];
     __shared__ int sh_cnt[kMaxSamples];
@@ -3101,6 +3150,7 @@ __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, Dev
     Ctx c;
     c.plan = &plan_arg; c.w = &wst; c.lane = lane; c.S = S;
     c.afd_seen = sh_seen; c.mapv = sh_mapv; c.afd_nseen = sh_nseen;
+    c.seen_cap = p.max_set > 16 ? p.max_set : 16;
     c.replay = 1; c.hyp = 0; c.afd_mute = 0; c.locus = locus; c.outp = &out; c.status = 0; c.lg = nullptr; c.lg_pos = -1; c.lg_cap = 0; c.lg_nrec = 0;
     c.vt = 0; c.has_snv = 0; c.refbase = 0; c.altbase = 0;
     if (lane < S) { sh_mapv[lane] = out.map_vaf[locus * S + lane]; sh_nseen[lane] = 0; sh_cnt[lane] = 0; }
@@ -3323,9 +3373,10 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
     c.cacheA = c.setv + S * p.max_set;      // [S][kCacheWays] x 3   (setv: [S][max_set], the plan's largest Set spectrum)
     c.cacheB = c.cacheA + S * kCacheWays;
     c.cacheV = c.cacheB + S * kCacheWays;
-    c.afd_seen = c.cacheV + S * kCacheWays;  // [S][kMaxSet] x (VAF, l2fc key)
-    const int n_seen = out.replay ? 2 * S * kMaxSet + 2 * S : 0;  // only the AFD replay pass records discrete VAFs
-    c.mapv = c.afd_seen + 2 * S * kMaxSet;
+    c.afd_seen = c.cacheV + S * kCacheWays;  // [S][seen_cap] x (VAF, l2fc key)
+    c.seen_cap = p.max_set > 16 ? p.max_set : 16;
+    const int n_seen = out.replay ? 2 * S * c.seen_cap + 2 * S : 0;  // only the AFD replay pass records discrete VAFs
+    c.mapv = c.afd_seen + 2 * S * c.seen_cap;
     c.afd_nseen = (int*)(c.mapv + S);
     int* mapHyp = (int*)(c.afd_seen + n_seen);  // [n_slots]
     c.dkeyV = c.afd_seen + n_seen + (n_slots + 1) / 2 + 2;  // [n_dkey]
@@ -3875,6 +3926,16 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                     c.group = e + 1;
                     c.defer_ok = (1 - pass) & (int)((unsigned)(rc_ - 64) >> 31);  // pass == 0 && rc_ < 64, as integer arithmetic (stays a scalar)
                     c.defer_slot = u;
+                    const DevFastRoot* fr = p.froot + ((e < 0) ? 0 : 1 + ri);
+                    const bool is_droot = !(c.replay || p.n_dkey == 0) && ldc(p.droot + 2 * ((e < 0) ? 0 : 1 + ri)) >= 0;  // all-discrete roots: below
+                    const int fkind = (c.defer_ok && !is_droot) ? ldc(&fr->kind) : 0;
+                    if (fkind != 0) {  // compiled chain root: the task straight from the plan's record; 2: certainly a root for the general pass
+                        const int fk = fkind == 1 ? fast_chain_root(c, fr) : 2;
+                        if (fk == 2) todo |= 1ull << rc_;
+                        st = IT_NEXT;
+                        PROF_ADD(c, 34);
+                        continue;
+                    }
                     VLR_SYNC();
                     c.curJ = uni_d(mapJ[u]);
                     c.curHyp = UNI(mapHyp[u]);
@@ -4129,7 +4190,7 @@ extern "C" int vlr_launch_call_kernel_deep(const vlr::DevPlan* plan_host, const 
     size_t n_slots = (size_t)n_univ + 1;
     size_t cap = (size_t)plan_host->table_cap;
     size_t dbl = (size_t)2 * plan_host->max_tab_depth * cap + (size_t)2 * kRows * cap + (size_t)kRows * n_samples +
-                 (size_t)2 * n_univ + n_slots + n_slots * n_samples + (size_t)n_samples * plan_host->max_set + (size_t)(out->replay ? 2 * n_samples * kMaxSet + 2 * n_samples : 0) + (size_t)3 * n_samples * kCacheWays +
+                 (size_t)2 * n_univ + n_slots + n_slots * n_samples + (size_t)n_samples * plan_host->max_set + (size_t)(out->replay ? 2 * n_samples * (plan_host->max_set > 16 ? plan_host->max_set : 16) + 2 * n_samples : 0) + (size_t)3 * n_samples * kCacheWays +
                  (n_slots + 1) / 2 + 2 + (size_t)plan_host->n_dkey +
                  ((size_t)plan_host->max_frames * sizeof(Frame) + (size_t)range_depth * sizeof(RangeSt) + 7) / 8 +
                  (size_t)(n_samples + 1) / 2;
@@ -4142,7 +4203,8 @@ extern "C" int vlr_launch_call_kernel_deep(const vlr::DevPlan* plan_host, const 
 #else
 extern "C" int vlr_launch_afd_kernel(const vlr::DevPlan* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out, void* stream) {
     if (batch->n_loci <= 0) return 0;
-    hipLaunchKernelGGL(vlr::vlr_afd_kernel, dim3((unsigned)batch->n_loci), dim3(64), 0, (hipStream_t)stream, *plan_host, *batch, *out);
+    const size_t seen_bytes = (size_t)2 * plan_host->S * (plan_host->max_set > 16 ? plan_host->max_set : 16) * sizeof(double);
+    hipLaunchKernelGGL(vlr::vlr_afd_kernel, dim3((unsigned)batch->n_loci), dim3(64), seen_bytes, (hipStream_t)stream, *plan_host, *batch, *out);
     return (int)hipGetLastError();
 }
 
@@ -4155,7 +4217,7 @@ extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_host, const vlr::
     size_t n_slots = (size_t)n_univ + 1;
     size_t cap = (size_t)plan_host->table_cap;
     size_t dbl = (size_t)2 * max_obs + (size_t)2 * plan_host->max_tab_depth * cap + (size_t)2 * kRows * cap + (size_t)kRows * n_samples +
-                 (size_t)2 * n_univ + n_slots + n_slots * n_samples + (size_t)n_samples * plan_host->max_set + (size_t)(out->replay ? 2 * n_samples * kMaxSet + 2 * n_samples : 0) + (size_t)3 * n_samples * kCacheWays +
+                 (size_t)2 * n_univ + n_slots + n_slots * n_samples + (size_t)n_samples * plan_host->max_set + (size_t)(out->replay ? 2 * n_samples * (plan_host->max_set > 16 ? plan_host->max_set : 16) + 2 * n_samples : 0) + (size_t)3 * n_samples * kCacheWays +
                  (n_slots + 1) / 2 + 2 + (size_t)plan_host->n_dkey +
                  ((size_t)plan_host->max_frames * sizeof(Frame) + (size_t)range_depth * sizeof(RangeSt) + 7) / 8 +
                  (size_t)(n_samples + 1) / 2;  // kshift[S] (ints)

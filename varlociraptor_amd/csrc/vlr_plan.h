@@ -11,7 +11,7 @@ constexpr int kMaxFrames = 16;        // explicit recursion stack of the VAF-tre
 constexpr int kTableCap = 128;        // upper limit of visited points of one range chain (57 at resolution 0.01);
                                       // the per-plan capacity is derived from the finest resolution
 constexpr int kMaxRangeDepth = 4;     // nested Range levels on one path
-constexpr int kMaxSet = 16;           // members of one Set spectrum
+constexpr int kMaxSet = 1024;         // members of one Set spectrum (LDS: 8 B x samples x the plan's largest set; the reference has no limit)
 constexpr int kMaxNamedEvents = 30;   // scenario events (engine universe = 1 + 2*named); 1 + named event groups fit the 31 value bits of the int32 alive masks
 constexpr int kNHyp = 9;              // 0 = Artifacts::none(), 1..8 single-artifact combinations
 constexpr int kCacheWays = 4;         // per-sample pileup-likelihood cache entries
@@ -57,6 +57,27 @@ struct DevDLeaf {
 };
 struct DevDKey { int32_t sample, pad; double a, b; };
 
+// Roots whose walk is a constant of the plan (DESIGN.md §3 "compiled roots"): a chain of single-valued Sample nodes — one per sample
+// but one — ending in a leaf Sample node with a proper Range spectrum, no l2fc / Variant nodes (tumor-normal: somatic_tumor,
+// germline_het, germline_hom; single-sample scenarios: every Range event).  What GenericPosterior::density does on the way down
+// (modes/generic.rs:247-397: clear-ref shortcuts per node, operands, is_discrete flags) only depends on two per-sample flags of
+// the locus, so the plan compiler writes the root out as a record and the kernel's event loop builds the chain task from it
+// without walking the tree: no frames, no node loads, no per-node alive / prior-class loops.  The general walk remains for
+// everything else and is what the records are checked against (VLR_NO_FAST_ROOTS=1 switches them off).
+struct DevFastRoot {
+    int32_t kind;                  // 0: general walk, 1: chain record below, 2: general walk, known not to be deferrable in the probe pass
+    int32_t n_fixed;               // single-valued Sample nodes above the leaf, in path order
+    int32_t inner;                 // sample of the leaf Range node
+    int32_t leaf_node;
+    int32_t alive;                 // other event groups that can still contain the operands at the leaf (static: walk_root's c.alive)
+    int32_t disc;                  // is_discrete mask of the fixed samples
+    int32_t pidx;                  // prior-table index of the fixed samples' classes (the integrated sample adds its own)
+    int32_t lex, rex, pad;         // the leaf's range
+    double start, end;
+    int32_t fsample[kMaxSamples];
+    double fvaf[kMaxSamples];
+};
+
 // prior "class" per sample: the reference's Prior::compute
 // (src/variants/model/prior.rs:298-438,715-762) depends on a VAF only through equality tests with
 // k/ploidy and universe membership, so it is tabulated on the host over per-sample classes.
@@ -95,6 +116,7 @@ struct DevPlan {
     const DevDLeaf* dleaf;
     const DevDKey* dkey;
     const int32_t* droot;
+    const DevFastRoot* froot;   // [1 + n_roots] like droot (0 = absent, 1 + k = roots[k])
 };
 
 // SoA observation columns + per-locus columns (device pointers), mirrors vlr_batch
