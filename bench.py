@@ -393,6 +393,7 @@ def main():
     ap.add_argument("--afd-capacity", type=int, default=96)
     ap.add_argument("--cpu-loci", type=int, default=None, help="loci of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive and observation-BCF -> calls-BCF legs of the default line")
     ap.add_argument("--mode", default="exact", choices=["exact", "fast", "homopolymer"], help="realign workload: --pairhmm-mode of the reference (cli.rs:912-947)")
     ap.add_argument("--read-window", type=int, default=64, help="realign workload: realignment window; read windows are window..2*window bases (32: short reads, two pairs per wave)")
     args = ap.parse_args()
@@ -494,6 +495,29 @@ def main():
                     "ratio_to_plain": (n_total * args.steps / el_afd) / (n_total * args.steps / elapsed)}
         del out_afd
 
+    # like-for-like with the reference's per-record loop, which starts from host memory and always computes the AFD lists
+    # (calling.rs:889-928): host buffers in and out through vlr_batch_run_host (page-locked arrays, staging pipelined with the
+    # kernels), without and with AFD lists; and the whole process boundary (observation BCFs -> call variants -> calls BCF)
+    pcie = e2e = None
+    if world == 1 and not force_dist and args.workload == "config3" and not args.no_end_to_end:
+        import types
+        pb = engine.pin_batch(batch)
+        plan.call_host(pb)
+        t0 = time.perf_counter(); plan.call_host(pb); t_plain = time.perf_counter() - t0
+        t0 = time.perf_counter(); plan.call_host(pb, afd_capacity=args.afd_capacity); t_afd = time.perf_counter() - t0
+        del pb
+        pcie = {"value": batch.n_loci / t_plain, "with_afd": batch.n_loci / t_afd, "unit": "loci/s",
+                "note": "vlr_batch_run_host: host arrays (page-locked) in, results (and AFD lists of %d entries) out, one call each" % args.afd_capacity}
+        try:
+            a2 = types.SimpleNamespace(**vars(args))
+            a2.loci, a2.steps, a2.warmup = min(200_000, batch.n_loci), 1, 1
+            cl = bench_cli(a2, 0, 1, local_rank, dev)
+            e2e = {"value": cl["value"], "unit": "records/s", "records": a2.loci, "stages_s": cl["stages_s"], "native_stage_seconds": cl["native_stage_seconds_per_step"],
+                   "host_threads_effective": cl["config"]["effective_cpus"], "files": cl["files"],
+                   "note": "observation BCFs (format v15) -> cli.call_variants (native ingest, AFD lists, native calls writer) -> calls BCF; reader, evaluation and writer overlap; `python bench.py --workload cli` is the same with more steps"}
+        except Exception as ex:  # the front door must not take the kernel line down
+            e2e = {"value": None, "note": "end-to-end leg failed: %r" % (ex,)}
+
     res = out.to_host()
     line = None
     if rank == 0:
@@ -586,7 +610,7 @@ def main():
                          "valu": {"pileup_evals_per_launch": n_eval // max(1, args.steps), "obs_terms_per_launch": int(terms_per_launch),
                                   "terms_per_s": terms_per_launch / (last_ms * 1e-3), "flop_per_term": FLOP_PER_TERM,
                                   "achieved_tflops": tflops, "peak_tflops": F64_VALU_PEAK_TFLOPS, "frac": tflops / F64_VALU_PEAK_TFLOPS}},
-            "with_afd": with_afd,
+            "with_afd": with_afd, "pcie_inclusive": pcie, "end_to_end": e2e,
             "cpu_baseline": cpu, "parity": parity, "posterior_normalisation_max_err": norm_err,
             "status_counts": {str(k): int(v) for k, v in zip(*np.unique(res.status, return_counts=True))},
             "collective": ("rccl all_gather_into_tensor, world size %d" % world) if (world > 1 or force_dist) else None,

@@ -497,6 +497,8 @@ int  vlr_calls_writer_close(vlr_calls_writer* writer);   /* header (if nothing w
 /* Measurement aid: wall seconds of the stages of the last vlr_obs_read ([0] file reads, [1] BGZF inflate, [2] parse + decode — summed
  * over the sample files, which run side by side — [3] all files, [4] merge into the table, [5] strings and groups, [6] total) and of
  * the last vlr_calls_write ([8] record encoding, [9] BGZF deflate + file write, [10] total). */
+/* Diagnostics: the calls writer's own "%.<digits>f" (digits 0..3) of one value, for the tests to hold against printf. */
+int  vlr_selftest_format_fixed(double v, int digits, char* out, int cap);
 void vlr_ingest_last_timings(double* out16);
 /* The same indices summed over every vlr_obs_reader_next / vlr_calls_writer_append call since the last reset (reset != 0 clears
  * them after reading): what the streaming front door spends per stage over a whole file. */

@@ -271,3 +271,29 @@ def test_streaming_reader_and_appending_writer_equal_the_whole_file_calls(oracle
 
 
 GOLDEN_FLAME = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "flamegraph_profiling")
+
+
+def test_writer_fixed_point_formatting_equals_printf():
+    """The calls writer formats AFD entries (`%.3f=%.2f`, calling/variants/mod.rs:520-559) with its own routine; it must give what
+    printf gives — correctly rounded decimal expansion of the binary value, ties to even — on random values, exact ties, values
+    just beside a tie, zero, negative zero, large PHRED values and non-finite input."""
+    import ctypes as C
+    from varlociraptor_amd import engine
+    L = engine.lib()
+    L.vlr_selftest_format_fixed.restype = C.c_int
+    L.vlr_selftest_format_fixed.argtypes = [C.c_double, C.c_int, C.c_char_p, C.c_int]
+    buf = C.create_string_buffer(80)
+
+    def fmt(v, d):
+        assert L.vlr_selftest_format_fixed(v, d, buf, 80) == 0
+        return buf.value.decode()
+    rng = np.random.default_rng(4)
+    vals = list(rng.random(20000)) + list(rng.random(5000) * 3000) + list(-rng.random(2000) * 50) + [0.0, -0.0, 1.0, 0.9995, 0.0005, 0.0015, 0.0625, 0.1875,
+            0.5, 2.5, 0.125, 0.375, 1e-9, 999.995, 1234.565, 0.045, 2.675, 1e14 + 0.5, float("inf"), float("-inf"), float("nan")]
+    for k in range(2000):   # k/8000: exactly representable ties at three digits
+        vals.append(k / 8000.0)
+        vals.append(np.nextafter(k / 8000.0, 1.0))
+        vals.append(np.nextafter(k / 8000.0, -1.0))
+    for v in vals:
+        for d in (0, 2, 3):
+            assert fmt(float(v), d) == "%.*f" % (d, float(v)), (v, d)

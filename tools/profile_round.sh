@@ -14,8 +14,8 @@ done
 python bench.py --workload config3 --afd --no-cpu-baseline > $O/bench_config3_afd.json 2> $O/bench_config3_afd.err
 python bench.py --workload cli --steps 3 --warmup 1 > $O/bench_cli.json 2> $O/bench_cli.err
 python tools/cpu_probe.py > $O/cpu_probe.txt 2>&1
-(cd /tmp && rocprofv3 --kernel-trace --stats -d $O/stats_config3 -o s -- python $R/bench.py --no-cpu-baseline --no-afd > $O/stats_config3.json 2> $O/stats_config3.err)
-(cd /tmp && rocprofv3 --kernel-trace --stats -d $O/stats_config3_afd -o s -- python $R/bench.py --afd --no-cpu-baseline > $O/stats_config3_afd.json 2> $O/stats_config3_afd.err)
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $O/stats_config3 -o s -- python $R/bench.py --no-cpu-baseline --no-end-to-end --no-afd > $O/stats_config3.json 2> $O/stats_config3.err)
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $O/stats_config3_afd -o s -- python $R/bench.py --afd --no-cpu-baseline --no-end-to-end > $O/stats_config3_afd.json 2> $O/stats_config3_afd.err)
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $O/stats_realign -o s -- python $R/bench.py --workload realign --no-cpu-baseline > $O/stats_realign.json 2> $O/stats_realign.err)
 find $O -name "*.db" -size +20M -delete
 bash tools/pmc_pass.sh $T/pmc config3 50000 > $O/pmc.md 2>&1

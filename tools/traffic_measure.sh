@@ -11,6 +11,6 @@ O=$R/gpurun_out/traffic_$W; rm -rf $O; mkdir -p $O
 pmc() { name=$1; ctr=$2; shift 2; (cd /tmp && rocprofv3 --pmc $ctr --kernel-trace -d $O/$name -o p -- "$@" > $O/$name.out 2> $O/$name.err); }
 pmc cal_read FETCH_SIZE python $R/tools/traffic_calibrate.py read
 pmc cal_write WRITE_SIZE python $R/tools/traffic_calibrate.py write
-pmc fetch FETCH_SIZE python $R/bench.py --workload $W $LOCI --steps 1 --warmup 0 --no-cpu-baseline --no-afd
-pmc write WRITE_SIZE python $R/bench.py --workload $W $LOCI --steps 1 --warmup 0 --no-cpu-baseline --no-afd
+pmc fetch FETCH_SIZE python $R/bench.py --workload $W $LOCI --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end --no-afd
+pmc write WRITE_SIZE python $R/bench.py --workload $W $LOCI --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end --no-afd
 python $R/tools/traffic_summary.py $O $W

@@ -522,10 +522,36 @@ inline uint32_t word16(const uint8_t* p, size_t k) {
     return (uint32_t)(uint16_t)(int16_t)(int8_t)p[k];
 }
 // Vec<MiniLogProb>: u64 length (4 words), then per element a u32 tag (2 words) and an f16 (1 word) or an f32 (2 words)
+// f16 -> f32 bit patterns of all 65 536 halves (256 kB, built once): the decoder's inner loop selects between the table entry and
+// the f32 payload with a mask instead of branching on the element's tag — which of the two a MiniLogProb is (utils/mod.rs:449-474:
+// f16 below -10 when that loses nothing) varies from element to element and is not predictable
+const uint32_t* half_bits_table() {
+    static const std::vector<uint32_t> tab = [] {
+        std::vector<uint32_t> t(65536);
+        for (uint32_t h = 0; h < 65536; ++h) { const float f = half_to_float((uint16_t)h); memcpy(&t[h], &f, 4); }
+        return t;
+    }();
+    return tab.data();
+}
 template <int ST>
 bool mini_words(const uint8_t* p, uint32_t nw, uint64_t n, float* dst) {
     size_t k = 4;
-    for (uint64_t i = 0; i < n; ++i) {
+    uint64_t i = 0;
+    {
+        const uint32_t* hb = half_bits_table();
+        uint32_t bad = 0;
+        uint32_t* out = reinterpret_cast<uint32_t*>(dst);
+        for (; i < n && k + 4 <= nw; ++i) {  // all four words of the widest element are readable: no bounds test per variant
+            const uint32_t tag = word16<ST>(p, k) | (word16<ST>(p, k + 1) << 16);
+            const uint32_t lo = word16<ST>(p, k + 2), hi = word16<ST>(p, k + 3);
+            const uint32_t m32 = 0u - (tag & 1u);               // all ones for an f32 payload
+            out[i] = ((lo | (hi << 16)) & m32) | (hb[lo] & ~m32);
+            bad |= tag >> 1;
+            k += 3 + (tag & 1u);
+        }
+        if (bad) return false;
+    }
+    for (; i < n; ++i) {
         if (k + 3 > nw) return false;
         const uint32_t tag = word16<ST>(p, k) | (word16<ST>(p, k + 1) << 16);
         if (tag == 0) { dst[i] = half_to_float((uint16_t)word16<ST>(p, k + 2)); k += 3; }
@@ -1593,6 +1619,38 @@ std::string generalized_cigar(const std::vector<std::string>& items, Aux aux) {
     return out;
 }
 
+// "%.<digits>f" of a finite double below 1e12 in magnitude, correctly rounded like printf (exact decimal expansion of the binary
+// value, ties to even): x = v * 10^digits with its exact rounding error from an fma, so a product that lands on k + 1/2 is decided
+// by the side the true value lies on.  Appends to `out`; anything else (inf, nan, huge) goes through snprintf.
+inline void append_fixed(std::string& out, double v, int digits) {
+    static const double p10[4] = {1.0, 10.0, 100.0, 1000.0};
+    if (!(std::fabs(v) < 1e12) || digits < 0 || digits > 3) {   // (v * 10^digits stays below 2^53: floor and the tie test are exact)
+        char b[64];
+        snprintf(b, sizeof b, "%.*f", digits, v);
+        out += b;
+        return;
+    }
+    const bool neg = std::signbit(v);
+    const double a = std::fabs(v), sc = p10[digits];
+    const double x = a * sc, err = std::fma(a, sc, -x);   // a * sc = x + err exactly
+    double k = std::floor(x);
+    const double frac = x - k;                             // exact
+    bool up;
+    if (frac > 0.5) up = true;
+    else if (frac < 0.5) up = false;
+    else up = err > 0.0 || (err == 0.0 && std::fmod(k, 2.0) == 1.0);   // on the tie: the side of the exact value, then half to even
+    // (frac just below / above 1/2 by less than |err| cannot happen: |err| <= ulp(x)/2 and frac is a multiple of ulp(x))
+    if (up) k += 1.0;
+    uint64_t n = (uint64_t)k;
+    char buf[40];
+    int pos = 40;
+    for (int d = 0; d < digits; ++d) { buf[--pos] = (char)('0' + n % 10); n /= 10; }
+    if (digits) buf[--pos] = '.';
+    do { buf[--pos] = (char)('0' + n % 10); n /= 10; } while (n);
+    if (neg) buf[--pos] = '-';   // (printf prints -0.000 for a negative value that rounds to zero)
+    out.append(buf + pos, (size_t)(40 - pos));
+}
+
 struct SampleFields { int32_t dp = 0, oobs = 0; float af = NAN; std::string saobs, srobs, obs, sym[6], afd; bool has_afd = false; };
 
 // Call::write_final_record, per sample (calling/variants/mod.rs:233-360, 473-559); mirrors callsfmt.sample_fields
@@ -1612,18 +1670,35 @@ void sample_fields(const vlr_obs_table* t, const vlr_results* r, int64_t l, int 
     };
     double depth = 0.0;
     int kept = 0;
+    double last_pm = NAN, last_w = 0.0;
+    static const double kLn3 = std::log(3.0), kLn20 = std::log(20.0), kLn150 = std::log(150.0);
     for (uint32_t i = b; i < e; ++i) {
         const uint32_t f = t->flags[i];
         const unsigned orient = (f >> VLR_F_ORIENT_SHIFT) & 3;
         if (drop_nonstd && orient == VLR_ORIENT_OTHER) continue;
         ++kept;
         const double pa = t->col[1][i], pr = t->col[2][i], pm = t->col[0][i];
-        depth += std::exp(pm);
-        const double bf_alt = std::exp(pa - pr), bf_ref = std::exp(pr - pa);
+        if (pm != last_pm) { last_pm = pm; last_w = std::exp(pm); }   // (the MAPQ-adjusted mean: one value per pileup as a rule)
+        depth += last_w;
+        // Bayes factors exp(pa - pr) / exp(pr - pa) against the Kass-Raftery bounds 1, 3, 20, 150 in log space: d is a difference of
+        // two f32 values — a dyadic rational that cannot sit within rounding distance of ln 3, ln 20 or ln 150 — so the comparisons
+        // are those of the exponentials; only differences the exponential rounds to 1 (|d| < 1e-15) take the exponentials themselves
+        const double d = pa - pr;
+        double bf_alt, bf_ref;
+        char kl_alt, kl_ref;
+        if (std::fabs(d) >= 1e-15 && std::fabs(d) < 700.0) {
+            const double ad = std::fabs(d);
+            const char k = ad <= kLn3 ? 'B' : ad <= kLn20 ? 'P' : ad <= kLn150 ? 'S' : 'V';
+            bf_alt = d > 0 ? 2.0 : 0.5; bf_ref = d > 0 ? 0.5 : 2.0;   // (only their order is used below)
+            kl_alt = d > 0 ? k : 'N'; kl_ref = d > 0 ? 'N' : k;
+        } else {
+            bf_alt = std::exp(d); bf_ref = std::exp(-d);
+            kl_alt = kr_letter(bf_alt); kl_ref = kr_letter(bf_ref);
+        }
         const bool maxq = f & VLR_F_MAX_MAPQ;
         char s0, s1 = 0;
-        if (bf_alt > bf_ref) { s0 = 'A'; s1 = kr_letter(bf_alt); }
-        else if (bf_ref > bf_alt) { s0 = 'R'; s1 = kr_letter(bf_ref); }
+        if (bf_alt > bf_ref) { s0 = 'A'; s1 = kl_alt; }
+        else if (bf_ref > bf_alt) { s0 = 'R'; s1 = kl_ref; }
         else s0 = 'E';
         if (!maxq) { s0 = (char)tolower(s0); if (s1) s1 = (char)tolower(s1); }
         const unsigned strand = (f >> VLR_F_STRAND_SHIFT) & 3, altloc = (f >> VLR_F_ALTLOCUS_SHIFT) & 3;
@@ -1636,8 +1711,8 @@ void sample_fields(const vlr_obs_table* t, const vlr_results* r, int64_t l, int 
         while (k < obs_cnt.size() && obs_cnt[k].first != key) ++k;
         if (k == obs_cnt.size()) obs_cnt.emplace_back(key, 1);
         else obs_cnt[k].second++;
-        if (pa > pr) { const char c = kr_letter(bf_alt); count_letter(alt_cnt, maxq ? (char)toupper(c) : (char)tolower(c)); }
-        else { const char c = kr_letter(bf_ref); count_letter(ref_cnt, maxq ? (char)toupper(c) : (char)tolower(c)); }
+        if (pa > pr) { const char c = kl_alt; count_letter(alt_cnt, maxq ? (char)toupper(c) : (char)tolower(c)); }
+        else { const char c = kl_ref; count_letter(ref_cnt, maxq ? (char)toupper(c) : (char)tolower(c)); }
     }
     std::vector<std::pair<std::string, int>> obs_pairs;
     obs_pairs.reserve(obs_cnt.size());
@@ -1678,12 +1753,15 @@ void sample_fields(const vlr_obs_table* t, const vlr_results* r, int64_t l, int 
         for (int i = 0; i < n; ++i) order[(size_t)i] = i;
         std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return v[a] < v[c]; });
         std::string out;
-        char buf[64];
+        out.reserve((size_t)n * 12);
+        static const double kLn10 = std::log(10.0);
         for (int k = 0; k < n; ++k) {
             const int i = order[(size_t)k];
-            const double ph = -10.0 * p[i] / std::log(10.0) + 0.0;
-            snprintf(buf, sizeof buf, "%s%.3f=%.2f", k ? "," : "", v[i], ph);
-            out += buf;
+            const double ph = -10.0 * p[i] / kLn10 + 0.0;
+            if (k) out.push_back(',');
+            append_fixed(out, v[i], 3);
+            out.push_back('=');
+            append_fixed(out, ph, 2);
         }
         o.afd = out;
         o.has_afd = true;
@@ -1693,6 +1771,15 @@ void sample_fields(const vlr_obs_table* t, const vlr_results* r, int64_t l, int 
 }  // namespace
 
 extern "C" {
+
+// diagnostics: the writer's "%.<digits>f" (append_fixed) for one value, NUL-terminated into out[cap] — compared with printf by the tests
+int vlr_selftest_format_fixed(double v, int digits, char* out, int cap) {
+    std::string s;
+    append_fixed(s, v, digits);
+    if (!out || cap < (int)s.size() + 1) return VLR_ERR_INVALID_ARGUMENT;
+    memcpy(out, s.c_str(), s.size() + 1);
+    return VLR_OK;
+}
 
 // The calls file (calling.rs:296-304 bcf::Writer, mod.rs:178-600): one record per locus of the table.  `header_text`: the VCF
 // header (## lines and #CHROM line with the sample names); out_names[n_out]: names of the columns of ln_posterior
@@ -1929,7 +2016,9 @@ static int calls_write_impl(FILE* out_file, bool bcf, bool with_header, bool wit
         std::vector<const std::vector<uint8_t>*> ps;
         for (auto& p : parts) ps.push_back(&p);
         const char* lv = getenv("VLR_BGZF_LEVEL");
-        if (!write_bgzf_stream(out_file, ps, n_threads, lv ? atoi(lv) : 4, with_eof, err)) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s", err.c_str());
+        // level 1 by default: the calls file is written once and read once; deflate at level 4 was 60 % of the writer's time for 12 %
+        // smaller files (VLR_BGZF_LEVEL selects another level)
+        if (!write_bgzf_stream(out_file, ps, n_threads, lv ? atoi(lv) : 1, with_eof, err)) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s", err.c_str());
         g_ingest_t[9] = now_s() - t_w0 - g_ingest_t[8];
         g_ingest_t[10] = now_s() - t_w0;
         for (int i = 8; i <= 10; ++i) g_ingest_total[i] += g_ingest_t[i];
