@@ -502,10 +502,14 @@ def main():
     if world == 1 and not force_dist and args.workload == "config3" and not args.no_end_to_end:
         import types
         pb = engine.pin_batch(batch)
-        plan.call_host(pb)
-        t0 = time.perf_counter(); plan.call_host(pb); t_plain = time.perf_counter() - t0
-        t0 = time.perf_counter(); plan.call_host(pb, afd_capacity=args.afd_capacity); t_afd = time.perf_counter() - t0
-        del pb
+        from varlociraptor_amd.batch import CallResults
+        r_plain = CallResults(batch.n_loci, plan.n_out, plan.n_samples, 0, alloc=engine.host_array)
+        r_afd = CallResults(batch.n_loci, plan.n_out, plan.n_samples, args.afd_capacity, alloc=engine.host_array)
+        plan.call_host(pb, results=r_plain)
+        t0 = time.perf_counter(); plan.call_host(pb, results=r_plain); t_plain = time.perf_counter() - t0
+        plan.call_host(pb, afd_capacity=args.afd_capacity, results=r_afd)
+        t0 = time.perf_counter(); plan.call_host(pb, afd_capacity=args.afd_capacity, results=r_afd); t_afd = time.perf_counter() - t0
+        del pb, r_plain, r_afd
         pcie = {"value": batch.n_loci / t_plain, "with_afd": batch.n_loci / t_afd, "unit": "loci/s",
                 "note": "vlr_batch_run_host: host arrays (page-locked) in, results (and AFD lists of %d entries) out, one call each" % args.afd_capacity}
         try:
@@ -612,6 +616,7 @@ def main():
                                   "achieved_tflops": tflops, "peak_tflops": F64_VALU_PEAK_TFLOPS, "frac": tflops / F64_VALU_PEAK_TFLOPS}},
             "with_afd": with_afd, "pcie_inclusive": pcie, "end_to_end": e2e,
             "cpu_baseline": cpu, "parity": parity, "posterior_normalisation_max_err": norm_err,
+            "n1_only": None if world == 1 else "cpu_baseline, parity, pcie_inclusive and end_to_end are measured at N=1 only (rank 0, a bounded sample): null here by design; this line carries the whole-job rate, the per-rank kernel roofline and the collective",
             "status_counts": {str(k): int(v) for k, v in zip(*np.unique(res.status, return_counts=True))},
             "collective": ("rccl all_gather_into_tensor, world size %d" % world) if (world > 1 or force_dist) else None,
             "build_id": engine.build_id(),

@@ -114,20 +114,22 @@ def test_gather_call_results_including_afd_lists(n_loci, world):
     assert np.array_equal(full["afd_vaf"][m], ref.afd_vaf[m]) and np.array_equal(full["afd_lnprob"][m], ref.afd_lnprob[m])
 
 
-def test_bench_starts_its_own_ranks():
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_starts_its_own_ranks(n):
     """`python bench.py --gpus N` (the driver's command shape) must work outside torchrun.  Dry run over gloo:
     bench.py re-executes itself under torch.distributed.run with N ranks on 127.0.0.1, the ranks all-gather their record
     blocks in input order and rank 0 prints one JSON line."""
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--loci", "777", "--dry-run"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "0", "--loci", "777", "--dry-run"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["gathered_in_order"] is True and line["steps"] == 2
+    # (8 = the node the north star names: the launcher has been seen with eight ranks before an 8-GPU node ever appears)
+    assert line["n_gpus"] == n and line["gathered_in_order"] is True and line["steps"] == 2
 
 
 def test_bench_without_a_device_fails_loudly():

@@ -56,7 +56,7 @@ while i < len(src):
             op = ts.split()[0]
             if op.startswith(("s_cbranch_scc", "s_cselect", "s_addc", "s_subb", "s_cmov")): break
             if op.startswith(("s_cmp", "s_and", "s_or", "s_xor", "s_add_", "s_sub_", "s_lshl", "s_lshr", "s_ashr", "s_not", "s_bfe", "s_andn2", "s_orn2",
-                              "s_nand", "s_nor", "s_xnor", "s_min", "s_max", "s_abs", "s_bcnt", "s_wqm", "s_quadmask", "s_addk", "s_mulk", "s_cmpk", "s_bitcmp")) and "saveexec" not in op:
+                              "s_nand", "s_nor", "s_xnor", "s_min", "s_max", "s_abs", "s_bcnt", "s_wqm", "s_quadmask", "s_addk", "s_cmpk", "s_bitcmp")) and "saveexec" not in op:
                 live = False
                 break
             if "saveexec" in op:

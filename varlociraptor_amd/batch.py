@@ -102,18 +102,32 @@ class PileupBatch:
 class CallResults:
     """Host result buffers of include/vlr.h `vlr_results`."""
 
-    def __init__(self, n_loci: int, n_out: int, n_samples: int, afd_capacity: int = 0):
+    def __init__(self, n_loci: int, n_out: int, n_samples: int, afd_capacity: int = 0, alloc=None):
+        """`alloc(shape, dtype)`: allocator of the arrays (engine.host_array: page-locked memory, so that vlr_batch_run_host copies the
+        results back by direct DMA — the AFD lists are gigabytes for a million loci); default: ordinary initialised numpy arrays."""
         self.n_loci, self.n_out, self.n_samples, self.afd_capacity = n_loci, n_out, n_samples, afd_capacity
-        self.ln_posterior = np.full((n_loci, n_out), np.nan)
-        self.ln_marginal = np.full(n_loci, np.nan)
-        self.map_vaf = np.full((n_loci, n_samples), np.nan)
-        self.map_bias = np.zeros((n_loci, abi.N_BIAS), np.uint8)
-        self.best_event = np.full(n_loci, -1, np.int32)
-        self.status = np.zeros(n_loci, np.uint32)
+        custom = alloc is not None
+        if alloc is None:
+            def alloc(shape, dtype, fill=0):
+                return np.full(shape, fill, dtype)
+        else:
+            raw = alloc
+
+            def alloc(shape, dtype, fill=0):
+                a = raw(shape, dtype)
+                if fill is not None and np.prod(shape) < (1 << 24):   # (the large AFD arrays are overwritten up to afd_count: not touched here)
+                    a[...] = fill
+                return a
+        self.ln_posterior = alloc((n_loci, n_out), np.float64, np.nan)
+        self.ln_marginal = alloc((n_loci,), np.float64, np.nan)
+        self.map_vaf = alloc((n_loci, n_samples), np.float64, np.nan)
+        self.map_bias = alloc((n_loci, abi.N_BIAS), np.uint8)
+        self.best_event = alloc((n_loci,), np.int32, -1)
+        self.status = alloc((n_loci,), np.uint32)
         if afd_capacity > 0:
-            self.afd_count = np.zeros((n_loci, n_samples), np.int32)
-            self.afd_vaf = np.zeros((n_loci, n_samples, afd_capacity), np.float64)
-            self.afd_lnprob = np.zeros((n_loci, n_samples, afd_capacity), np.float64)
+            self.afd_count = alloc((n_loci, n_samples), np.int32)
+            self.afd_vaf = alloc((n_loci, n_samples, afd_capacity), np.float64, None if custom else 0)
+            self.afd_lnprob = alloc((n_loci, n_samples, afd_capacity), np.float64, None if custom else 0)
         else:
             self.afd_count = self.afd_vaf = self.afd_lnprob = None
 

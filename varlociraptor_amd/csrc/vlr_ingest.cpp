@@ -563,6 +563,49 @@ bool mini_words(const uint8_t* p, uint32_t nw, uint64_t n, float* dst) {
     }
     return true;
 }
+// The seven mandatory MiniLogProb vectors of a record side by side: where element i + 1 of a vector starts depends on the tag of its
+// element i, a chain of dependent loads per vector — seven vectors give the core seven independent chains to overlap.  Elements
+// [0, returned count) of every vector are decoded; the caller finishes the (short) remainders with mini_words' own loop.
+template <int ST>
+uint64_t mini_words_x7(const uint8_t* const* p, const uint32_t* nw, uint64_t n, float* const* dst, size_t* k_out, bool* bad_out) {
+    const uint32_t* hb = half_bits_table();
+    size_t k[7];
+    uint32_t bad = 0;
+    for (int c = 0; c < 7; ++c) k[c] = 4;
+    uint64_t i = 0;
+    for (; i < n; ++i) {
+        bool room = true;
+        for (int c = 0; c < 7; ++c) room = room && (k[c] + 4 <= nw[c]);
+        if (!room) break;
+        for (int c = 0; c < 7; ++c) {
+            const uint8_t* q = p[c];
+            const uint32_t tag = word16<ST>(q, k[c]) | (word16<ST>(q, k[c] + 1) << 16);
+            const uint32_t lo = word16<ST>(q, k[c] + 2), hi = word16<ST>(q, k[c] + 3);
+            const uint32_t m32 = 0u - (tag & 1u);
+            reinterpret_cast<uint32_t*>(dst[c])[i] = ((lo | (hi << 16)) & m32) | (hb[lo] & ~m32);
+            bad |= tag >> 1;
+            k[c] += 3 + (tag & 1u);
+        }
+    }
+    for (int c = 0; c < 7; ++c) k_out[c] = k[c];
+    *bad_out = bad != 0;
+    return i;
+}
+// the remainder of one vector from word k on (elements i0 .. n)
+template <int ST>
+bool mini_words_from(const uint8_t* p, uint32_t nw, uint64_t n, float* dst, size_t k, uint64_t i0) {
+    for (uint64_t i = i0; i < n; ++i) {
+        if (k + 3 > nw) return false;
+        const uint32_t tag = word16<ST>(p, k) | (word16<ST>(p, k + 1) << 16);
+        if (tag == 0) { dst[i] = half_to_float((uint16_t)word16<ST>(p, k + 2)); k += 3; }
+        else if (tag == 1) {
+            if (k + 4 > nw) return false;
+            const uint32_t bits = word16<ST>(p, k + 2) | (word16<ST>(p, k + 3) << 16);
+            float f; memcpy(&f, &bits, 4); dst[i] = f; k += 4;
+        } else return false;
+    }
+    return true;
+}
 template <int ST>
 uint64_t len_words(const uint8_t* p, uint32_t nw) {
     if (nw < 4) return ~0ull;
@@ -648,7 +691,28 @@ bool decode_into(const RecView& r, Chunk& c, std::string& err) {
         if (!r.present[f]) { err = std::string("No varlociraptor observations found in record (") + kFieldName[f] + ")"; return false; }
     uint64_t n = 0;
     const size_t base = c.flags.size();
-    for (int k = 0; k < 7; ++k) {  // column order of vlr_batch: pm, pa, pr, miss, psa, pdo, phb
+    bool all7 = false;   // the seven vectors decoded side by side (all int32-typed, the rule for values up to 65535)
+    {
+        bool same = true;
+        for (int k = 0; k < 7; ++k) same = same && r.wstride[kMini[k]] == 4;
+        if (same) {
+            const uint8_t* ps[7]; uint32_t nws[7]; float* ds[7];
+            for (int k = 0; k < 7; ++k) { ps[k] = r.wsrc[kMini[k]]; nws[k] = r.wn[kMini[k]]; }
+            n = len_words<4>(ps[0], nws[0]);
+            bool ok = n <= (1u << 28);
+            for (int k = 1; k < 7 && ok; ++k) ok = len_words<4>(ps[k], nws[k]) == n;
+            if (!ok) { err = "inconsistent observation vector lengths"; return false; }
+            for (int k = 0; k < 7; ++k) { c.col[k].resize(base + n); ds[k] = c.col[k].data() + base; }
+            size_t kk[7];
+            bool bad = false;
+            const uint64_t done = mini_words_x7<4>(ps, nws, n, ds, kk, &bad);
+            if (bad) { err = "truncated PROB vector"; return false; }
+            for (int k = 0; k < 7; ++k)
+                if (!mini_words_from<4>(ps[k], nws[k], n, ds[k], kk[k], done)) { err = std::string("truncated ") + kFieldName[kMini[k]]; return false; }
+            all7 = true;
+        }
+    }
+    for (int k = 0; k < 7 && !all7; ++k) {  // column order of vlr_batch: pm, pa, pr, miss, psa, pdo, phb
         const int f = kMini[k];
         auto& col = c.col[k];
         if (r.wstride[f]) {

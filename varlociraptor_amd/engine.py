@@ -201,8 +201,9 @@ class Plan:
             pass
 
     # ---- host buffers in, host buffers out (stages through the device; synchronous)
-    def call_host(self, batch: PileupBatch, afd_capacity: int = 0) -> CallResults:
-        res = CallResults(batch.n_loci, self.n_out, self.n_samples, afd_capacity)
+    def call_host(self, batch: PileupBatch, afd_capacity: int = 0, results: Optional[CallResults] = None) -> CallResults:
+        """`results`: caller-owned buffers to fill (e.g. CallResults(..., alloc=engine.host_array): page-locked, reusable)."""
+        res = results if results is not None else CallResults(batch.n_loci, self.n_out, self.n_samples, afd_capacity)
         bs, rs = batch.as_struct(), res.as_struct()
         _check(lib().vlr_batch_run_host(self._h, C.byref(bs), C.byref(rs)))
         return res
