@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define VLR_ABI_VERSION 3   /* 3: vlr_plan_reserve takes the AFD capacity, 30 named events, vlr_node_*, homopolymer realignment */
-#define VLR_MAX_SAMPLES 8      /* samples per scenario supported by the device path   */
+#define VLR_MAX_SAMPLES 16     /* samples per scenario supported by the device path   */
 #define VLR_N_BIAS      6      /* strand, orientation, position, softclip, homopolymer, alt-locus */
 
 /* ---------------------------------------------------------------- status codes */

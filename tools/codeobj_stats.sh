@@ -28,11 +28,11 @@ for f in $W/co*.elf; do
   $L/llvm-readelf --notes $f 2>/dev/null | python3 -c "
 import sys, re
 t = sys.stdin.read()
-for m in re.finditer(r'\.name:\s+(\S+).*?(?=\n\s+- \.a|\Z)', t, re.S):
-    blk = m.group(0)
-    if 'vlr_call_kernel' not in blk and 'afd_kernel' not in blk: continue
+for blk in re.split(r'\n\s+- (?=\.a)', t):   # one block per kernel (its keys are sorted: the block starts at .agpr_count / .args)
+    nm = re.search(r'\.name:\s+(\S+)', blk)
+    if not nm or ('vlr_call_kernel' not in nm.group(1) and 'afd_kernel' not in nm.group(1)): continue
     g = lambda k: (re.search(r'\.%s:\s+(\d+)' % k, blk) or [0, '?'])[1]
-    print(m.group(1)[:60], 'vgpr', g('vgpr_count'), 'vspill', g('vgpr_spill_count'), 'sgpr', g('sgpr_count'), 'sspill', g('sgpr_spill_count'), 'lds', g('group_segment_fixed_size'), 'scratch', g('private_segment_fixed_size'))
+    print(nm.group(1)[:60], 'vgpr', g('vgpr_count'), 'vspill', g('vgpr_spill_count'), 'sgpr', g('sgpr_count'), 'sspill', g('sgpr_spill_count'), 'lds', g('group_segment_fixed_size'), 'scratch', g('private_segment_fixed_size'))
 "
   ls -l $f | awk "{print \"code object bytes\", \$5}"
 done

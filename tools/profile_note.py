@@ -47,9 +47,9 @@ if j and j.get("with_afd"):
 j = line("bench_cli.json")
 if j:
     shutil.copy(os.path.join(O, "bench_cli.json"), os.path.join(P, "%s_bench_cli.json" % tag))
-    st, nt = j["stages_s"], j.get("native_stage_seconds_last_step", {})
-    md += ["", "End to end through the process boundary (`bench.py --workload cli`: %s; %d effective CPUs of %d visible): **%.1f k records/s** — read %.2f s (inflate %.2f + decode %.2f summed over the two files, merge %.2f), call %.2f s, write %.2f s (encode %.2f, deflate + file %.2f)."
-           % (j["config"]["workload"], j["config"].get("effective_cpus", 0), j["config"].get("host_threads", 0), j["value"] / 1e3, st["read_s"], nt.get("inflate", 0), nt.get("parse_decode", 0), nt.get("merge", 0), st["call_s"], st["write_s"], nt.get("encode", 0), nt.get("deflate_write", 0))]
+    st, nt = j["stages_s"], (j.get("native_stage_seconds_per_step") or j.get("native_stage_seconds_last_step") or {})
+    md += ["", "End to end through the process boundary (`bench.py --workload cli`: %s; %d effective CPUs of %d visible): **%.1f k records/s** — read %.2f s (inflate %.2f summed over the two files, both files in %.2f wall, merge %.2f), call %.2f s, write %.2f s (encode %.2f, deflate + file %.2f)."
+           % (j["config"]["workload"], j["config"].get("effective_cpus", 0), j["config"].get("host_threads", 0), j["value"] / 1e3, st["read_s"], nt.get("inflate", 0), nt.get("files_wall", 0), nt.get("merge", 0), st["call_s"], st["write_s"], nt.get("encode", 0), nt.get("deflate_write", 0))]
 if os.path.exists(os.path.join(O, "cpu_probe.txt")):
     shutil.copy(os.path.join(O, "cpu_probe.txt"), os.path.join(P, "%s_cpu_probe.txt" % tag))
 md += ["", "## rocprofv3 --kernel-trace --stats of `python bench.py --no-cpu-baseline` (config3, 1 M loci per launch)", "", rocpd("stats_config3"),

@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 ABI_VERSION = 3
-MAX_SAMPLES = 8
+MAX_SAMPLES = 16
 N_BIAS = 6
 
 # status codes

@@ -22,10 +22,13 @@
 #include "../../include/vlr.h"
 #include "vlr_plan.h"
 
-extern "C" int vlr_launch_afd_kernel(const vlr::DevPlan* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out, void* stream);
-extern "C" int vlr_launch_call_kernel_deep(const vlr::DevPlan* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out,
+extern "C" int vlr_launch_afd_kernel(const vlr::DevPlanT<8>* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out, void* stream);
+extern "C" int vlr_launch_call_kernel_deep(const vlr::DevPlanT<8>* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out,
                                            int n_univ, int n_samples, int range_depth, void* stream);
-extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_dev, const vlr::DevBatch* batch, const vlr::DevResults* out,
+extern "C" int vlr_launch_afd_kernel_wide(const vlr::DevPlanT<16>* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out, void* stream);
+extern "C" int vlr_launch_call_kernel_wide(const vlr::DevPlanT<16>* plan_dev, const vlr::DevBatch* batch, const vlr::DevResults* out,
+                                           int n_univ, int n_samples, int max_obs, int range_depth, void* stream);
+extern "C" int vlr_launch_call_kernel(const vlr::DevPlanT<8>* plan_dev, const vlr::DevBatch* batch, const vlr::DevResults* out,
                                       int n_univ, int n_samples, int max_obs, int range_depth, void* stream);
 
 namespace {
@@ -247,8 +250,9 @@ struct HostPrior {
 
 struct vlr_plan {
     int device = 0;
-    vlr::DevPlan host{};       // host copy (device pointers inside)
-    vlr::DevPlan* dev = nullptr;
+    vlr::DevPlanT<16> host{};  // host copy (device pointers inside): the layout for up to sixteen samples
+    vlr::DevPlanT<8> host8{};  // the same plan in the layout of the standard and deep builds (plans of at most eight samples)
+    vlr::DevPlanT<16>* dev = nullptr;
     void* blob = nullptr;      // device arrays
     int max_depth_per_sample = 200;  // reference default max_depth (src/variants/sample.rs:236)
     int max_obs = 0;                 // 0: max_depth_per_sample * S
@@ -298,7 +302,7 @@ HostSpectrum host_spectrum(const vlr_spectrum& s, const double* pool) {
 // Tabulate Prior::compute over per-sample VAF classes:
 //   uniform sample      : {in universe & 0, in universe & != 0, outside}
 //   ploidy-based sample : {k/ploidy for k = 0..ploidy, any other value}
-int build_prior_table(const vlr_scenario_desc* d, vlr::DevPlan& P, std::vector<double>& table) {
+int build_prior_table(const vlr_scenario_desc* d, vlr::DevPlanT<16>& P, std::vector<double>& table) {
     const int S = d->n_samples;
     HostPrior pr;
     pr.S = S;
@@ -432,7 +436,7 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
             if (!(purity > 0.0 && purity <= 1.0)) return fail(VLR_ERR_INVALID_ARGUMENT, "purity must be in (0,1] (likelihood.rs:78)");
         }
     }
-    DevPlan P{};
+    DevPlanT<16> P{};
     P.S = S;
     P.n_named = d->n_events;
     P.n_univ = 1 + 2 * d->n_events;
@@ -845,9 +849,10 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
     P.droot = (const int32_t*)(base + o_dr);
     P.froot = (const DevFastRoot*)(base + o_fr);
     plan->host = P;
+    if (S <= 8) plan->host8 = narrow_plan(P);
     hipError_t e = hipMemcpy(plan->blob, hostblob.data(), total, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc((void**)&plan->dev, sizeof(DevPlan));
-    if (e == hipSuccess) e = hipMemcpy(plan->dev, &P, sizeof(DevPlan), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&plan->dev, sizeof(DevPlanT<16>));
+    if (e == hipSuccess) e = hipMemcpy(plan->dev, &P, sizeof(DevPlanT<16>), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipEventCreate(&plan->ev_start);
     if (e == hipSuccess) e = hipEventCreate(&plan->ev_stop);
     if (e == hipSuccess) e = hipMalloc((void**)&plan->work_dev, 64 * sizeof(unsigned long long));
@@ -931,7 +936,7 @@ static int ensure_buffers(vlr_plan* plan, int64_t n_loci, int max_obs, bool want
         if (pool > 0 && plan->deep_hint != 0) (void)grow(&plan->deep_pool[k], &plan->deep_pool_bytes[k], pool + 128, true);
     }
     if (want_afd) {
-        rc = grow(&plan->afd_scratch[k], &plan->afd_scratch_bytes[k], L + 8 * L + 4 * L + 64, false);
+        rc = grow(&plan->afd_scratch[k], &plan->afd_scratch_bytes[k], 2 * L + 8 * L + 4 * L + 64, false);
         if (rc != VLR_OK) return rc;
         if (want_log) {
             size_t words = 1 + (size_t)36 * (1 + plan->host.S + 2 * (size_t)plan->host.table_cap);
@@ -1012,7 +1017,7 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
         char* sc = (char*)plan->afd_scratch[k];
         if (!r.ln_marginal) r.ln_marginal = (double*)sc;
         if (!r.best_event) r.best_event = (int32_t*)(sc + 8 * L);
-        r.map_disc = (uint8_t*)(sc + 12 * L);
+        r.map_disc = (uint16_t*)(sc + 12 * L);
         if (!r.map_bias) return fail(VLR_ERR_INVALID_ARGUMENT, "AFD needs map_bias");
         r.afd_count = out->afd_count; r.afd_vaf = out->afd_vaf; r.afd_lnprob = out->afd_lnprob; r.afd_capacity = out->afd_capacity;
         r.afd_key = (long long*)plan->afd_keys[k];
@@ -1024,24 +1029,33 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
     }
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipEventRecord(plan->ev_start, st));
+    // plans with more than eight samples run the wide build of the kernels (vlr_kernels_wide.hip: per-sample LDS arrays for sixteen)
+    const bool wide = plan->host.S > kLdsSamples;
+    auto call_launch = [&](const DevBatch* bb, const DevResults* rr, int mo, void* ss) {
+        return wide ? vlr_launch_call_kernel_wide(&plan->host, bb, rr, plan->host.n_univ, plan->host.S, mo, plan->host.max_range_depth, ss)
+                    : vlr_launch_call_kernel(&plan->host8, bb, rr, plan->host.n_univ, plan->host.S, mo, plan->host.max_range_depth, ss);
+    };
+    auto afd_launch = [&](const DevBatch* bb, const DevResults* rr, void* ss) {
+        return wide ? vlr_launch_afd_kernel_wide(&plan->host, bb, rr, ss) : vlr_launch_afd_kernel(&plan->host8, bb, rr, ss);
+    };
     r.deep_used = (unsigned long long*)plan->deep_pool[plan->slot & 1];  // reset by workgroup 0 of every LDS-resident launch
     // deep launch behind a call (or replay) launch: re-evaluates the loci that launch flagged VLR_LOCUS_TOO_DEEP with their
     // coefficients in the plan's HBM pool; every other locus exits at once.  `lane`/`two`: the AFD sub-range lanes share the pool.
     auto deep_launch = [&](const DevBatch& bs, DevResults rs, void* ss, int lane, bool two) -> int {
         const int k = plan->slot & 1;
-        if (!plan->deep_pool[k] || plan->deep_pool_bytes[k] <= 128 || plan->deep_hint == 0) return VLR_OK;
+        if (!plan->deep_pool[k] || plan->deep_pool_bytes[k] <= 128 || plan->deep_hint == 0 || plan->host.S > kLdsSamples) return VLR_OK;  // (no wide deep build)
         char* base = (char*)plan->deep_pool[k];
         unsigned long long* ctr = (unsigned long long*)(base + 64 * lane);
         size_t cap_d = (plan->deep_pool_bytes[k] - 128) / sizeof(double);
         double* data = (double*)(base + 128);
         if (two) { cap_d /= 2; data += (size_t)lane * cap_d; }
         rs.deep_pool = data; rs.deep_used = ctr; rs.deep_capacity = (long long)cap_d;  // ctr was reset by the launch before (workgroup 0)
-        const int rc = vlr_launch_call_kernel_deep(&plan->host, &bs, &rs, plan->host.n_univ, plan->host.S, plan->host.max_range_depth, ss);
+        const int rc = vlr_launch_call_kernel_deep(&plan->host8, &bs, &rs, plan->host.n_univ, plan->host.S, plan->host.max_range_depth, ss);
         if (rc != 0) return fail(VLR_ERR_HIP, "deep kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         return VLR_OK;
     };
     if (!want_afd) {
-        int rc = vlr_launch_call_kernel(&plan->host, &b, &r, plan->host.n_univ, plan->host.S, max_obs, plan->host.max_range_depth, stream);
+        int rc = call_launch(&b, &r, max_obs, stream);
         if (rc != 0) return fail(VLR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         rc = deep_launch(b, r, stream, 0, false);
         if (rc != VLR_OK) return rc;
@@ -1084,14 +1098,14 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
             rs.afd_count += l0 * S; rs.afd_vaf += (size_t)l0 * S * r.afd_capacity; rs.afd_lnprob += (size_t)l0 * S * r.afd_capacity;
             if (rs.afd_log) rs.afd_log += (size_t)lane * (size_t)step * (size_t)r.afd_log_stride;
             rs.afd_key += (size_t)l0 * (size_t)S * (size_t)r.afd_capacity;
-            int rc = vlr_launch_call_kernel(&plan->host, &bs, &rs, plan->host.n_univ, S, max_obs, plan->host.max_range_depth, ss);
+            int rc = call_launch(&bs, &rs, max_obs, ss);
             if (rc != 0) return fail(VLR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
             if (rs.afd_log) {
-                rc = vlr_launch_afd_kernel(&plan->host, &bs, &rs, ss);
+                rc = afd_launch(&bs, &rs, ss);
                 if (rc != 0) return fail(VLR_ERR_HIP, "AFD kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
             }
             rs.replay = 1;
-            rc = vlr_launch_call_kernel(&plan->host, &bs, &rs, plan->host.n_univ, S, max_obs, plan->host.max_range_depth, ss);
+            rc = call_launch(&bs, &rs, max_obs, ss);
             if (rc != 0) return fail(VLR_ERR_HIP, "AFD replay launch failed: %s", hipGetErrorString((hipError_t)rc));
 
         }

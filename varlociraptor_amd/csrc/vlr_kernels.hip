@@ -99,28 +99,28 @@ struct WalkSave {                // walk_root state while the kernel's event loo
 };
 
 struct WaveSt {
-    double ops_vaf[kMaxSamples];
+    double ops_vaf[kLdsSamples];
     double lfc_val[kMaxLfc];
     int lfc_a[kMaxLfc], lfc_b[kMaxLfc], lfc_cmp[kMaxLfc];
-    int nkeep[kMaxSamples], soff[kMaxSamples];
-    unsigned char all_posref[kMaxSamples];  // (bytes: the static LDS of the kernel sits 32 B under an occupancy step for 4 x 60x pileups)
+    int nkeep[kLdsSamples], soff[kLdsSamples];
+    unsigned char all_posref[kLdsSamples];  // (bytes: the static LDS of the kernel sits 32 B under an occupancy step for 4 x 60x pileups)
     union {
         struct {  // phase A statistics: dead once the hypotheses are gated (before phase B starts)
-            double pos_all[kMaxSamples], pos_major[kMaxSamples], pos_rate[kMaxSamples];
-            int all_ref[kMaxSamples], strong_all[kMaxSamples];
-            int strong_bias[kMaxSamples][kNHyp];
-            int any_strong_alt[kMaxSamples], has_ins[kMaxSamples], has_del[kMaxSamples];
+            double pos_all[kLdsSamples], pos_major[kLdsSamples], pos_rate[kLdsSamples];
+            int all_ref[kLdsSamples], strong_all[kLdsSamples];
+            int strong_bias[kLdsSamples][kNHyp];
+            int any_strong_alt[kLdsSamples], has_ins[kLdsSamples], has_del[kLdsSamples];
         };
         struct {  // phase B: pending points / values of the row-parallel chains
             double bpend[kRows][kRowPts], bvals[kRows][kRowPts];
         };
     };
-    unsigned char cacheN[kMaxSamples];
-    double curMapVaf[kMaxSamples];
+    unsigned char cacheN[kLdsSamples];
+    double curMapVaf[kLdsSamples];
     int cs_node[kContainStack], cs_mask[kContainStack];
     ChainTask task[kRows];
     ChainTask stash;                  // one held event-level chain that found no free row yet (see the event loop: "held chains")
-    double stash_vaf[kMaxSamples];
+    double stash_vaf[kLdsSamples];
     BatchOuter bo;
     WalkSave wk;
     unsigned long long work[2];  // [0] pileup evaluations, [1] observation terms (lane 0 adds; profiling aid)
@@ -1055,12 +1055,12 @@ __device__ inline void cross_consider(Ctx& c, int g, double joint, int inner, do
 // every visited operand set; which of them end up in the lists is only known once the MAP is.  Re-evaluating the clean events
 // in a second launch (the replay below) costs as much as the call itself, so the call pass writes the values it has anyway:
 //   record = header word | S outer operands | nlfc x 2 words (l2fc terms on the path) | payload
-//   header: n (16 bits) | integrated sample + 1 (4) | is_discrete mask (8) | event group (8) | nlfc (4) | kind (2)
+//   header: n (16 bits) | integrated sample + 1 (5) | is_discrete mask (16) | event group (8) | nlfc (4) | kind (2)
 //   kind 1: the visited-point table of a Range chain: n x values, then n joint values;  kind 2: one discrete leaf: its joint
 __device__ __forceinline__ bool log_on(const Ctx& c) { return c.lg != nullptr && c.hyp == 0 && !c.replay && c.lg_pos >= 0; }
 __device__ __forceinline__ long long log_header(int kind, int n, int s_in, int disc, int group, int nlfc) {
-    return (long long)n | ((long long)(s_in + 1) << 16) | ((long long)(disc & 0xff) << 20) | ((long long)(group & 0xff) << 28) |
-           ((long long)(nlfc & 0xf) << 36) | ((long long)kind << 40);
+    return (long long)n | ((long long)(s_in + 1) << 16) | ((long long)(disc & 0xffff) << 21) | ((long long)(group & 0xff) << 37) |
+           ((long long)(nlfc & 0xf) << 45) | ((long long)kind << 49);
 }
 // Region layout: word 0 = words used (-1: overflow), word 1 = number of records, words 2 .. 2 + kLogDir = start of every
 // record (so that vlr_afd_kernel can look at all headers at once), records from word kLogFirst on.
@@ -3132,9 +3132,9 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
 __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, DevBatch batch, DevResults out) {
     __shared__ WaveSt wst;
     extern __shared__ double sh_seen[];  // [S][seen_cap] (VAF, l2fc key) pairs (dynamic: the plan's largest Set spectrum sets the size)
-    __shared__ double sh_mapv[kMaxSamples];
-    __shared__ int sh_nseen[kMaxSamples];
-    __shared__ int sh_cnt[kMaxSamples];
+    __shared__ double sh_mapv[kLdsSamples];
+    __shared__ int sh_nseen[kLdsSamples];
+    __shared__ int sh_cnt[kLdsSamples];
     const DevPlan& p = plan_arg;
     const int lane = threadIdx.x;
     const int64_t locus = blockIdx.x;
@@ -3164,7 +3164,7 @@ __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, Dev
     // ---- 1. classify the records, one per lane (headers, operands and three probes of the table go through LDS so that the
     // comparison with the earlier records does not chase global memory)
     __shared__ long long sh_hdr[kLogDir];
-    __shared__ double sh_ops[kLogDir][kMaxSamples];
+    __shared__ double sh_ops[kLogDir][kLdsSamples];
     __shared__ double sh_probe[kLogDir][3];
     __shared__ double sh_x[kTableCap];
     int at = 0, n = 0, s_in = -1, disc = 0, nl = 0, kind = 0, grp = 0, mism = 99;
@@ -3172,8 +3172,8 @@ __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, Dev
     if (lane < nrec) {
         at = (int)__double_as_longlong(lg[2 + lane]);
         h = __double_as_longlong(lg[at]);
-        n = (int)(h & 0xffff); s_in = (int)((h >> 16) & 0xf) - 1; disc = (int)((h >> 20) & 0xff); grp = (int)((h >> 28) & 0xff);
-        nl = (int)((h >> 36) & 0xf); kind = (int)((h >> 40) & 3);
+        n = (int)(h & 0xffff); s_in = (int)((h >> 16) & 0x1f) - 1; disc = (int)((h >> 21) & 0xffff); grp = (int)((h >> 37) & 0xff);
+        nl = (int)((h >> 45) & 0xf); kind = (int)((h >> 49) & 3);
         sh_hdr[lane] = h;
         if (kind != 3) {
             for (int s = 0; s < S; ++s) sh_ops[lane][s] = lg[at + 1 + s];
@@ -3192,7 +3192,7 @@ __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, Dev
         // the same map keys as an earlier record? (an outer chain that evaluates a VAF twice runs the inner chain twice)
         for (int r = 0; r < lane && mism <= 1; ++r) {
             const long long h2 = sh_hdr[r];
-            if (((h ^ h2) & ~(0xffll << 28)) != 0) continue;  // sample, flags, l2fc count, kind, table length (event group aside)
+            if (((h ^ h2) & ~(0xffll << 37)) != 0) continue;  // sample, flags, l2fc count, kind, table length (event group aside)
             bool same = true;
             for (int s = 0; s < S; ++s) same = same && (s == s_in || sh_ops[lane][s] == sh_ops[r][s]);
             if (kind == 1) same = same && sh_probe[lane][0] == sh_probe[r][0] && sh_probe[lane][1] == sh_probe[r][1] && sh_probe[lane][2] == sh_probe[r][2];
@@ -3342,7 +3342,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
     const DevPlan& p = plan_arg;
     const int lane = threadIdx.x;
     const int64_t locus = blockIdx.x;
-    if (locus >= batch.n_loci) return;
+    if (locus >= batch.n_loci) return;   // (plans above kLdsSamples samples: the host launches the wide build)
     if (VLR_DEEP && !(out.status[locus] & VLR_LOCUS_TOO_DEEP)) return;  // deep launch: only what the LDS-resident kernel could not hold
     // replay launch next to an AFD log: only the loci whose log region overflowed are re-evaluated
     if (!VLR_DEEP && out.replay && out.afd_log && __double_as_longlong(out.afd_log[(size_t)locus * (size_t)out.afd_log_stride]) >= 0) return;
@@ -3928,7 +3928,11 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                     c.defer_slot = u;
                     const DevFastRoot* fr = p.froot + ((e < 0) ? 0 : 1 + ri);
                     const bool is_droot = !(c.replay || p.n_dkey == 0) && ldc(p.droot + 2 * ((e < 0) ? 0 : 1 + ri)) >= 0;  // all-discrete roots: below
+#ifdef VLR_NO_FAST_CODE
+                    const int fkind = 0;
+#else
                     const int fkind = (c.defer_ok && !is_droot) ? ldc(&fr->kind) : 0;
+#endif
                     if (fkind != 0) {  // compiled chain root: the task straight from the plan's record; 2: certainly a root for the general pass
                         const int fk = fkind == 1 ? fast_chain_root(c, fr) : 2;
                         if (fk == 2) todo |= 1ull << rc_;
@@ -4092,7 +4096,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
             uint8_t* mb = out.map_bias + locus * VLR_N_BIAS;
             for (int i = 0; i < VLR_N_BIAS; ++i) mb[i] = 0;
             int hh = pick >= 0 ? (mapHyp[pick] & 15) : 0;
-            if (out.map_disc) out.map_disc[locus] = (uint8_t)(pick >= 0 ? (mapHyp[pick] >> 4) : 0);
+            if (out.map_disc) out.map_disc[locus] = (uint16_t)(pick >= 0 ? (mapHyp[pick] >> 4) : 0);
             switch (hh) {
                 case H_SBF: mb[0] = 1; break;
                 case H_SBR: mb[0] = 2; break;
@@ -4165,7 +4169,16 @@ __global__ void __launch_bounds__(64) vlr_selftest_stream_kernel(const float* in
     }
 }
 }  // namespace vlr
-#if !VLR_DEEP
+// Wide build (vlr_kernels_wide.hip: VLR_WIDE_BUILD, VLR_LDS_SAMPLES 16, namespace renamed): the same kernels with per-sample LDS
+// arrays for sixteen samples; exports vlr_launch_call_kernel_wide and vlr_launch_afd_kernel_wide and nothing else.
+#ifdef VLR_WIDE_BUILD
+#define VLR_FN_CALL vlr_launch_call_kernel_wide
+#define VLR_FN_AFD vlr_launch_afd_kernel_wide
+#else
+#define VLR_FN_CALL vlr_launch_call_kernel
+#define VLR_FN_AFD vlr_launch_afd_kernel
+#endif
+#if !VLR_DEEP && !defined(VLR_WIDE_BUILD)
 extern "C" int vlr_launch_selftest_stream(const float* in, double* out, long long n, int mode, void* stream) {
     if (n <= 0) return 0;
     const long long per_wg = 64 * 256;
@@ -4179,13 +4192,14 @@ extern "C" int vlr_launch_selftest_math(int which, const double* a, const double
     return (int)hipGetLastError();
 }
 
-#endif  // !VLR_DEEP (selftest launchers)
+#endif  // !VLR_DEEP && !VLR_WIDE_BUILD (selftest launchers)
 #if VLR_DEEP
 // deep launcher: the 2-waves-per-SIMD instance only (no coefficient area in LDS; max_obs = 0 for the layout)
 extern "C" int vlr_launch_call_kernel_deep(const vlr::DevPlan* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out,
                                            int n_univ, int n_samples, int range_depth, void* stream) {
     using namespace vlr;
     if (batch->n_loci <= 0) return 0;
+    if (n_samples > kLdsSamples) return (int)hipErrorInvalidValue;  // (the per-sample LDS arrays of this build; the host picks the wide build)
     if (range_depth < 1) range_depth = 1;
     size_t n_slots = (size_t)n_univ + 1;
     size_t cap = (size_t)plan_host->table_cap;
@@ -4201,7 +4215,7 @@ extern "C" int vlr_launch_call_kernel_deep(const vlr::DevPlan* plan_host, const 
     return (int)hipGetLastError();
 }
 #else
-extern "C" int vlr_launch_afd_kernel(const vlr::DevPlan* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out, void* stream) {
+extern "C" int VLR_FN_AFD(const vlr::DevPlan* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out, void* stream) {
     if (batch->n_loci <= 0) return 0;
     const size_t seen_bytes = (size_t)2 * plan_host->S * (plan_host->max_set > 16 ? plan_host->max_set : 16) * sizeof(double);
     hipLaunchKernelGGL(vlr::vlr_afd_kernel, dim3((unsigned)batch->n_loci), dim3(64), seen_bytes, (hipStream_t)stream, *plan_host, *batch, *out);
@@ -4209,10 +4223,11 @@ extern "C" int vlr_launch_afd_kernel(const vlr::DevPlan* plan_host, const vlr::D
 }
 
 // host-callable launcher (used by vlr_host.cpp)
-extern "C" int vlr_launch_call_kernel(const vlr::DevPlan* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out,
+extern "C" int VLR_FN_CALL(const vlr::DevPlan* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out,
                                       int n_univ, int n_samples, int max_obs, int range_depth, void* stream) {
     using namespace vlr;
     if (batch->n_loci <= 0) return 0;
+    if (n_samples > kLdsSamples) return (int)hipErrorInvalidValue;  // (the per-sample LDS arrays of this build; the host picks the wide build)
     if (range_depth < 1) range_depth = 1;
     size_t n_slots = (size_t)n_univ + 1;
     size_t cap = (size_t)plan_host->table_cap;

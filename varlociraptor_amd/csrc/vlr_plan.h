@@ -5,7 +5,13 @@
 
 namespace vlr {
 
-constexpr int kMaxSamples = 8;        // == VLR_MAX_SAMPLES
+constexpr int kMaxSamples = 16;       // == VLR_MAX_SAMPLES: size of the per-sample arrays of the plan layout below
+#ifndef VLR_LDS_SAMPLES
+#define VLR_LDS_SAMPLES 8
+#endif
+constexpr int kLdsSamples = VLR_LDS_SAMPLES;  // per-sample arrays of the KERNEL's LDS state: 8 in the standard build (the static LDS of a
+                                      // workgroup decides the occupancy of the tumor-normal workloads), 16 in the wide build
+                                      // (vlr_kernels_wide.hip) the launcher takes for plans with 9..16 samples
 constexpr int kMaxLfc = 4;            // LFC terms on one root->leaf path
 constexpr int kMaxFrames = 16;        // explicit recursion stack of the VAF-tree walk
 constexpr int kTableCap = 128;        // upper limit of visited points of one range chain (57 at resolution 0.01);
@@ -83,18 +89,23 @@ struct DevFastRoot {
 // k/ploidy and universe membership, so it is tabulated on the host over per-sample classes.
 enum PriorKind { PK_UNIFORM = 0, PK_GERMLINE = 1, PK_SOMATIC = 2 };
 
-struct DevPlan {
+// The plan header travels BY VALUE in the kernarg segment and its per-sample arrays are read with scalar loads the compiler likes to
+// hoist whole: sized for sixteen samples they cost the standard build 60 more spilled SGPRs and 8 % of its speed.  So the header is a
+// template over the array size: the host compiles every plan into DevPlanT<16> and hands the standard and the deep build a
+// DevPlanT<8> copy (narrow_plan() below), the wide build the original.
+template <int NS>
+struct DevPlanT {
     int32_t S, n_named, n_univ, absent_root;
     int32_t n_nodes, max_range_depth, table_size, table_cap;
-    double resolution[kMaxSamples];
-    double rho[kMaxSamples];   // purity (1 - contamination fraction); 1 for uncontaminated samples
-    double irho[kMaxSamples];  // 1 - purity
-    int32_t by[kMaxSamples];   // contaminant sample or -1
-    int32_t uni_off[kMaxSamples + 1];
-    int32_t prior_kind[kMaxSamples];
-    int32_t ploidy[kMaxSamples];
-    int32_t n_class[kMaxSamples];
-    int32_t class_stride[kMaxSamples];
+    double resolution[NS];
+    double rho[NS];   // purity (1 - contamination fraction); 1 for uncontaminated samples
+    double irho[NS];  // 1 - purity
+    int32_t by[NS];   // contaminant sample or -1
+    int32_t uni_off[NS + 1];
+    int32_t prior_kind[NS];
+    int32_t ploidy[NS];
+    int32_t n_class[NS];
+    int32_t class_stride[NS];
     const DevNode* nodes;
     const int32_t* child_index;
     const double* vafs;
@@ -118,6 +129,23 @@ struct DevPlan {
     const int32_t* droot;
     const DevFastRoot* froot;   // [1 + n_roots] like droot (0 = absent, 1 + k = roots[k])
 };
+using DevPlan = DevPlanT<kLdsSamples>;
+inline DevPlanT<8> narrow_plan(const DevPlanT<16>& w) {   // valid for plans of at most eight samples
+    DevPlanT<8> n{};
+    n.S = w.S; n.n_named = w.n_named; n.n_univ = w.n_univ; n.absent_root = w.absent_root;
+    n.n_nodes = w.n_nodes; n.max_range_depth = w.max_range_depth; n.table_size = w.table_size; n.table_cap = w.table_cap;
+    for (int s = 0; s < 8; ++s) {
+        n.resolution[s] = w.resolution[s]; n.rho[s] = w.rho[s]; n.irho[s] = w.irho[s]; n.by[s] = w.by[s];
+        n.prior_kind[s] = w.prior_kind[s]; n.ploidy[s] = w.ploidy[s]; n.n_class[s] = w.n_class[s]; n.class_stride[s] = w.class_stride[s];
+    }
+    for (int s = 0; s <= 8; ++s) n.uni_off[s] = w.uni_off[s];
+    n.nodes = w.nodes; n.child_index = w.child_index; n.vafs = w.vafs; n.roots = w.roots; n.root_off = w.root_off;
+    n.universe = w.universe; n.prior_table = w.prior_table; n.grp_spec_off = w.grp_spec_off; n.grp_spec = w.grp_spec;
+    n.n_dkey = w.n_dkey; n.n_dleaf = w.n_dleaf; n.max_frames = w.max_frames; n.max_tab_depth = w.max_tab_depth;
+    n.max_set = w.max_set; n.pad1 = w.pad1; n.dleaf = w.dleaf; n.dkey = w.dkey; n.droot = w.droot; n.froot = w.froot;
+    return n;
+}
+
 
 // SoA observation columns + per-locus columns (device pointers), mirrors vlr_batch
 struct DevBatch {
@@ -138,7 +166,7 @@ struct DevResults {
     unsigned long long* work;  // nullable: [0] pileup evaluations, [1] observation terms (profiling aid)
     // AFD (optional second "replay" launch): is_discrete flags of the MAP operands (internal, written by the first
     // launch), and the caller's AFD buffers
-    uint8_t* map_disc;      // [n_loci]
+    uint16_t* map_disc;     // [n_loci]
     int32_t* afd_count;     // [n_loci * S]
     double* afd_vaf;        // [n_loci * S * afd_capacity]
     double* afd_lnprob;     // [n_loci * S * afd_capacity]

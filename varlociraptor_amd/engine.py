@@ -41,7 +41,7 @@ class EngineError(RuntimeError):
 def build(force: bool = False) -> str:
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in ("vlr_kernels.hip", "vlr_kernels_deep.hip", "vlr_realign.hip", "vlr_fdr.hip", "vlr_host.cpp", "vlr_ingest.cpp", "vlr_plan.h")] + [os.path.join(_HERE, "..", "include", "vlr.h")]
+    srcs = [os.path.join(src_dir, f) for f in ("vlr_kernels.hip", "vlr_kernels_deep.hip", "vlr_kernels_wide.hip", "vlr_realign.hip", "vlr_fdr.hip", "vlr_host.cpp", "vlr_ingest.cpp", "vlr_plan.h")] + [os.path.join(_HERE, "..", "include", "vlr.h")]
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", src_dir, "-B"], stdout=subprocess.DEVNULL)
     return LIB_PATH
@@ -56,7 +56,7 @@ def source_id() -> str:
     """The id a build of the current sources would carry (same recipe as csrc/Makefile)."""
     import hashlib
     h = hashlib.sha1()
-    for f in ("csrc/vlr_kernels.hip", "csrc/vlr_kernels_deep.hip", "csrc/vlr_realign.hip", "csrc/vlr_fdr.hip", "csrc/vlr_host.cpp", "csrc/vlr_ingest.cpp", "csrc/vlr_plan.h", "../include/vlr.h", "../include/vlr_detmath.h"):
+    for f in ("csrc/vlr_kernels.hip", "csrc/vlr_kernels_deep.hip", "csrc/vlr_kernels_wide.hip", "csrc/vlr_realign.hip", "csrc/vlr_fdr.hip", "csrc/vlr_host.cpp", "csrc/vlr_ingest.cpp", "csrc/vlr_plan.h", "../include/vlr.h", "../include/vlr_detmath.h"):
         with open(os.path.join(_HERE, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -71,7 +71,7 @@ def build_all(force: bool = False) -> None:
 MAX_OBS_LDS = 7680  # kept observations of one locus whose coefficient pairs fit the 120 kB LDS budget (vlr_plan_set_max_obs)
 
 MATRIX_DIR = os.path.join(_HERE, "matrix")
-MATRIX_LIBS = ("stress", "O1", "sync")
+MATRIX_LIBS = ("stress", "O1", "O2", "sync")
 
 
 def build_matrix(force: bool = False) -> str:
