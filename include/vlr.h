@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define VLR_ABI_VERSION 3   /* 3: vlr_plan_reserve takes the AFD capacity, 30 named events, vlr_node_*, homopolymer realignment */
+#define VLR_ABI_VERSION 4   /* 3: vlr_plan_reserve takes the AFD capacity, 30 named events, vlr_node_*, homopolymer realignment; 4: device front door */
 #define VLR_MAX_SAMPLES 16     /* samples per scenario supported by the device path   */
 #define VLR_N_BIAS      6      /* strand, orientation, position, softclip, homopolymer, alt-locus */
 
@@ -292,6 +292,11 @@ int  vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* 
  * synchronises before returning.  Still requires the GPU (no CPU fallback).                             */
 int  vlr_batch_run_host(vlr_plan* plan, const vlr_batch* in, vlr_results* out);
 
+/* (ABI 4) Device columns in, host results out: `in` holds DEVICE pointers (the batch of a device reader,
+ * vlr_obs_table_device_batch), obs_offset_host is the host copy of in->obs_offset (vlr_obs_table_batch), `out` holds HOST
+ * pointers.  Only the result buffers are staged; synchronises before returning.                              */
+int  vlr_batch_run_device_in(vlr_plan* plan, const vlr_batch* in, const uint32_t* obs_offset_host, vlr_results* out);
+
 /* ------------------------------------------------------------------------------------------------
  * One node, several devices (SURVEY.md 8 e): what the batching shim in Caller::call
  * (/root/reference/src/calling/variants/calling.rs:320-455) binds when the host drives N GPUs from ONE process.
@@ -503,6 +508,24 @@ void vlr_ingest_last_timings(double* out16);
 /* The same indices summed over every vlr_obs_reader_next / vlr_calls_writer_append call since the last reset (reset != 0 clears
  * them after reading): what the streaming front door spends per stage over a whole file. */
 void vlr_ingest_total_timings(double* out16, int reset);
+
+/* ---- Device front door (ABI 4).  The same streaming reader with the BGZF inflate, the record split and the v15 decode as kernels
+ * on `device` (csrc/vlr_inflate.hip, csrc/vlr_decode.hip): the compressed members cross PCIe, the inflated records and the SoA
+ * columns are born in device memory.  Replaces the same reference rows as vlr_obs_reader_open (bcf::Reader over the observation
+ * files, calling.rs:297-339; read_observations, preprocessing/mod.rs:818-919; MiniLogProb, utils/mod.rs:449-474).  BCF2 in BGZF
+ * members only (the files `varlociraptor preprocess` writes); anything else: VLR_ERR_UNSUPPORTED, use vlr_obs_reader_open.
+ * The tables of such a reader hold the batch twice: in device memory (vlr_obs_table_device_batch: the pointers vlr_batch_run takes,
+ * valid until vlr_obs_table_free) and in page-locked host memory (vlr_obs_table_batch: what the calls writer formats DP / SAOBS /
+ * SROBS / OBS from), both complete when vlr_obs_reader_next returns.  CRC32 of the members is not checked on this path. */
+int  vlr_obs_reader_open_device(int device, int n_samples, const char* const* paths, uint32_t omit_bias_mask, int n_threads, vlr_obs_reader** out);
+int  vlr_obs_table_device_batch(const vlr_obs_table* table, vlr_batch* out);  /* VLR_ERR_INVALID_ARGUMENT for a table of a host reader */
+/* The inflate stage alone, host buffers in and out (tests, tools): `bgzf` is a sequence of BGZF members (SAM spec 4.1), *out_bytes
+ * receives the sum of their ISIZE fields (also when out_capacity is too small: VLR_ERR_INVALID_ARGUMENT then). */
+int  vlr_bgzf_inflate(int device, const void* bgzf, int64_t n_bytes, void* out, int64_t out_capacity, int64_t* out_bytes);
+/* Measurement aid of the device reader: seconds per stage summed since the last reset — [0] file read + member index, [1] H2D of the
+ * compressed bytes, [2] inflate kernel, [3] record split, [4] INFO scan, [5] decode, [6] D2H of columns and cold records, [7] host
+ * side (cold records, table), [8] total; [9] inflated bytes, [10] compressed bytes, [11] records. */
+void vlr_ingest_device_timings(double* out16, int reset);
 
 #ifdef __cplusplus
 }

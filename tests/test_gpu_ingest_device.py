@@ -1,0 +1,235 @@
+"""Device front door (csrc/vlr_inflate.hip, csrc/vlr_decode.hip behind vlr_obs_reader_open_device / vlr_bgzf_inflate, include/vlr.h):
+the BGZF inflate kernel against zlib on every DEFLATE block type, and the device reader against the host reader (csrc/vlr_ingest.cpp,
+itself held against the Python restatement and the reference's files in tests/test_ingest.py) — column by column, flag by flag,
+string by string; the device-resident batch evaluated by vlr_batch_run against the host batch through vlr_batch_run_host."""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from varlociraptor_amd import engine, ingest, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _member(payload: bytes, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, flush_at=()) -> bytes:
+    """One BGZF member (SAM spec 4.1) around a raw DEFLATE stream of `payload`."""
+    assert len(payload) <= 65536
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+    out, last = b"", 0
+    for cut in list(flush_at) + [len(payload)]:
+        out += co.compress(payload[last:cut])
+        if cut != len(payload):
+            out += co.flush(zlib.Z_FULL_FLUSH)   # ends the block and emits an empty stored block
+        last = cut
+    out += co.flush()
+    bsize = 18 + len(out) + 8
+    assert bsize <= 65536, bsize
+    head = b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+    return head + out + struct.pack("<II", zlib.crc32(payload), len(payload))
+
+
+def _payloads(rng):
+    ints = (rng.integers(0, 70000, 12000).astype(np.int32)).tobytes()            # the typed INFO vectors of a record: X Y 0 0 patterns
+    text = (b"the quick brown fox jumps over the lazy dog " * 1400)[:60000]
+    return {
+        "empty": b"",
+        "one byte": b"A",
+        "zeros (distance 1, length 258)": bytes(65536),
+        "random (literals, long codes)": rng.integers(0, 256, 40000, dtype=np.uint8).tobytes(),
+        "int32 words": ints[:48000],
+        "text": text,
+        "period 3": (b"abc" * 22000)[:65000],
+        "period 200": (bytes(range(200)) * 400)[:64000],
+        "skewed alphabet": rng.choice(np.arange(256, dtype=np.uint8), 50000, p=np.r_[[0.7], np.full(255, 0.3 / 255)]).tobytes(),
+    }
+
+
+def test_inflate_kernel_equals_zlib_on_every_block_type():
+    rng = np.random.default_rng(5)
+    members, plain = [], []
+    for name, pl in _payloads(rng).items():
+        for level, strategy in [(0, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY),
+                                (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE)]:
+            body = pl if level or len(pl) <= 60000 else pl[:60000]   # (stored blocks do not shrink: keep the member under 64 KiB)
+            if level and name.startswith("random"):
+                body = pl[:30000]
+            try:
+                m = _member(body, level, strategy)
+            except AssertionError:
+                continue
+            members.append(m); plain.append(body)
+    # several DEFLATE blocks inside one member, with the empty stored blocks Z_FULL_FLUSH leaves between them
+    body = _payloads(rng)["text"][:40000] + bytes(3000) + rng.integers(0, 256, 5000, dtype=np.uint8).tobytes()
+    members.append(_member(body, 6, flush_at=(100, 101, 20000, 43000))); plain.append(body)
+    # each member alone (a failure names the case), then all of them as one stream (output offsets that are not multiples of 16)
+    for m, pl in zip(members, plain):
+        assert ingest.bgzf_inflate(m) == pl
+    assert ingest.bgzf_inflate(b"".join(members)) == b"".join(plain)
+    # the EOF member htslib appends
+    eof = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    assert ingest.bgzf_inflate(members[3] + eof) == plain[3]
+
+
+def test_inflate_kernel_refuses_damaged_members():
+    rng = np.random.default_rng(6)
+    pl = _payloads(rng)["text"]
+    m = bytearray(_member(pl, 6))
+    ok = bytes(m)
+    assert ingest.bgzf_inflate(ok) == pl
+    bad_isize = bytearray(ok); bad_isize[-4:] = struct.pack("<I", len(pl) - 1)
+    with pytest.raises(engine.EngineError):
+        ingest.bgzf_inflate(bytes(bad_isize))
+    n_bad = 0
+    for at in range(30, len(ok) - 12, 97):   # a flipped byte inside the DEFLATE stream: an error or (rarely) other bytes, never a crash
+        x = bytearray(ok); x[at] ^= 0x5a
+        try:
+            got = ingest.bgzf_inflate(bytes(x))
+            n_bad += got != pl
+        except engine.EngineError:
+            n_bad += 1
+    assert n_bad > 0
+    with pytest.raises(engine.EngineError):
+        ingest.bgzf_inflate(b"not a gzip member at all, not even close....")
+
+
+def _tables_equal(a, sa, b, sb):
+    assert a.n_samples == b.n_samples and a.n_loci == b.n_loci
+    assert np.array_equal(a.obs_offset, b.obs_offset)
+    for k in a.columns:
+        x, y = a.columns[k], b.columns[k]
+        assert x.dtype == y.dtype and np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y), k
+    for k in a.locus:
+        assert np.array_equal(a.locus[k], b.locus[k]), k
+    for k in ("third_allele_evidence", "group_representative", "group_key"):
+        assert np.array_equal(a.extra[k], b.extra[k]), k
+    for k in ("prior_het_ln", "prior_som_ln"):
+        assert np.array_equal(a.extra[k], b.extra[k], equal_nan=True), k
+    assert len(sa) == len(sb)
+    for i in range(len(sa)):
+        assert sa[i] == sb[i], i
+
+
+def _read_all(paths, device, chunk):
+    rd = ingest.ObsReader(paths, chunk_records=chunk, device=device)
+    out = list(rd)
+    rd.close()
+    return out
+
+
+def _rows(chunks):
+    rows = []
+    for b, sites in chunks:
+        S = b.n_samples
+        for l in range(b.n_loci):
+            lo, hi = int(b.obs_offset[l * S]), int(b.obs_offset[(l + 1) * S])
+            rows.append((tuple(int(x) for x in b.obs_offset[l * S:(l + 1) * S + 1] - lo),
+                         {k: v[lo:hi].tobytes() for k, v in b.columns.items()}, {k: v[l].tobytes() for k, v in b.locus.items()},
+                         b.extra["third_allele_evidence"][lo:hi].tobytes(), int(b.extra["group_key"][l]), sites[l]))
+    return rows
+
+
+def _concat_check(host_chunks, dev_chunks, first=None):
+    """Chunk boundaries differ between the readers (the device reader delivers what its buffers hold): compare record by record."""
+    h, d = _rows(host_chunks), _rows(dev_chunks)
+    if first is not None:
+        h = h[:first]
+    assert len(h) == len(d)
+    for i, (x, y) in enumerate(zip(h, d)):
+        assert x == y, "record %d differs" % i
+
+
+@pytest.mark.parametrize("name", ["config3", "config4", "config5"])
+def test_device_reader_equals_host_reader(name, tmp_path):
+    cfg = synth.CONFIGS[name]()
+    b = synth.generate(cfg, 2500, seed=31)
+    third = np.where(np.arange(b.n_obs) % 5 == 0, np.arange(b.n_obs) % 4, -1).astype(np.int32)
+    paths = []
+    for s in range(b.n_samples):
+        p = str(tmp_path / ("%s_%d.bcf" % (name, s)))
+        ingest.write_observations(p, b, s, third_allele_evidence=third)
+        paths.append(p)
+    host = _read_all(paths, None, 1 << 20)
+    dev = _read_all(paths, 0, 1 << 20)
+    assert len(host) == 1 and len(dev) == 1
+    _tables_equal(host[0][0], host[0][1], dev[0][0], dev[0][1])
+    # small requests: many chunks, records that straddle the buffered bytes, the carry between calls
+    for chunk in (1, 7, 333):
+        if chunk == 1:
+            d1 = ingest.ObsReader(paths, chunk_records=1, device=0)
+            first = [d1.next() for _ in range(40)]
+            d1.close()
+            assert all(x is not None and x[0].n_loci == 1 for x in first)
+            _concat_check(host, first, first=40)
+            continue
+        _concat_check(host, _read_all(paths, 0, chunk))
+    # the verified walk and the serial walk agree
+    os.environ["VLR_INGEST_SERIAL_WALK"] = "1"
+    try:
+        _concat_check(host, _read_all(paths, 0, 900))
+    finally:
+        del os.environ["VLR_INGEST_SERIAL_WALK"]
+    t = ingest.device_timings()
+    assert t["records"] > 0
+
+
+def test_device_reader_on_files_of_the_reference(golden_dir, tmp_path):
+    """normal.bcf of the reference's flamegraph_profiling fixture was written by varlociraptor preprocess through htslib (other member
+    sizes, int8 / int16 typed vectors, its own header); the fourteen format-v15 testcases are re-encoded as BCF by the Python writer."""
+    import glob
+    from varlociraptor_amd import bcfio
+    files = [os.path.join(golden_dir, "flamegraph_profiling", "normal.bcf")]
+    for i, v in enumerate(sorted(glob.glob(os.path.join(golden_dir, "testcases", "*", "observations.vcf")))):
+        out = str(tmp_path / ("t%d.bcf" % i))
+        if bcfio.vcf_to_bcf(v, out):
+            files.append(out)
+    for f in files:
+        h = _read_all([f], None, 1 << 20)
+        d = _read_all([f], 0, 1 << 20)
+        _concat_check(h, d)
+
+
+def test_device_batch_evaluates_like_the_host_batch(tmp_path):
+    import ctypes as C
+    from varlociraptor_amd import abi
+    cfg = synth.config3()
+    b = synth.generate(cfg, 3000, seed=33)
+    paths = []
+    for s in range(b.n_samples):
+        p = str(tmp_path / ("s%d.bcf" % s))
+        ingest.write_observations(p, b, s)
+        paths.append(p)
+    (hb, _), = _read_all(paths, None, 1 << 20)
+    (db, _), = _read_all(paths, 0, 1 << 20)
+    plan = engine.Plan(cfg.scenario, device=0)
+    ref = plan.call_host(hb, afd_capacity=32)
+    got = plan.call_table_device(db.extra["native_table"], afd_capacity=32)
+    for k in ("ln_posterior", "map_vaf", "status", "best_event"):
+        x, y = getattr(ref, k), getattr(got, k)
+        assert np.array_equal(x, y, equal_nan=True), k
+    assert np.array_equal(ref.afd_count, got.afd_count)
+    valid = np.arange(32)[None, None, :] < ref.afd_count[:, :, None]   # (entries beyond the count are not written)
+    assert np.array_equal(ref.afd_vaf[valid], got.afd_vaf[valid]) and np.array_equal(ref.afd_lnprob[valid], got.afd_lnprob[valid])
+    plan.close()
+
+
+def test_device_reader_refuses_what_it_does_not_read(tmp_path, golden_dir):
+    with pytest.raises(engine.EngineError) as e:
+        ingest.ObsReader([os.path.join(golden_dir, "flamegraph_profiling", "normal.vcf")], device=0)
+    assert e.value.code == -2   # VLR_ERR_UNSUPPORTED: the host reader takes text VCF / plain gzip
+    cfg = synth.config3()
+    b = synth.generate(cfg, 300, seed=3)
+    p = str(tmp_path / "a.bcf")
+    ingest.write_observations(p, b, 0)
+    raw = open(p, "rb").read()
+    cut = str(tmp_path / "cut.bcf")
+    # whole members only, the last ones missing: the stream ends inside a record
+    off, offs = 0, []
+    while off < len(raw):
+        offs.append(off)
+        off += struct.unpack_from("<H", raw, off + 16)[0] + 1
+    open(cut, "wb").write(raw[:offs[len(offs) // 2]])
+    with pytest.raises(engine.EngineError, match="truncated"):
+        _read_all([cut], 0, 1 << 20)

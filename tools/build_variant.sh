@@ -10,5 +10,5 @@ mkdir -p $R/varlociraptor_amd/matrix
 cd $R/varlociraptor_amd/csrc
 SRC=$(grep '^SRC = ' Makefile | cut -d= -f2)
 LIBS=$(grep '^LIBS = ' Makefile | cut -d= -f2)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 $BASE "$@" -DVLR_SRC_ID="\"$(cat $SRC vlr_plan.h ../../include/vlr.h ../../include/vlr_detmath.h | sha1sum | cut -c1-16)\"" -shared $SRC -o ../matrix/libvlr_$name.so $LIBS 2>&1 | grep -v "warning\|unused\|\^\|^ *[0-9]* |\|generated" || true
+/opt/rocm/bin/hipcc --offload-arch=gfx950 $BASE "$@" -DVLR_SRC_ID="\"$(cat $SRC vlr_plan.h vlr_gpuio.h ../../include/vlr.h ../../include/vlr_detmath.h | sha1sum | cut -c1-16)\"" -shared $SRC -o ../matrix/libvlr_$name.so $LIBS 2>&1 | grep -v "warning\|unused\|\^\|^ *[0-9]* |\|generated" || true
 ls -la ../matrix/libvlr_$name.so

@@ -1,10 +1,12 @@
-"""CPU-only rate of the native streaming reader (no GPU needed): synthetic config3 observation BCFs -> vlr_obs_reader chunks.
-   usage: python tools/ingest_rate.py [records] [chunk]"""
+"""Rate of the native streaming reader alone: synthetic config3 observation BCFs -> vlr_obs_reader chunks.  Host reader (no GPU
+   needed) or, with a third argument `device`, the device reader (inflate, record split and v15 decode as kernels).
+   usage: python tools/ingest_rate.py [records] [chunk] [device]"""
 import os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from varlociraptor_amd import ingest, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
+dev = 0 if len(sys.argv) > 3 and sys.argv[3] == "device" else None
 cfg = synth.config3()
 b = synth.generate(cfg, n, seed=1)
 tmp = tempfile.mkdtemp()
@@ -14,7 +16,8 @@ for s, name in enumerate(cfg.scenario.sample_names):
 for rep in range(3):
     ingest.total_timings(reset=True)
     t0 = time.perf_counter()
-    r = ingest.ObsReader(paths, chunk_records=chunk)
+    if dev is not None: ingest.device_timings(reset=True)
+    r = ingest.ObsReader(paths, chunk_records=chunk, device=dev)
     k = 0
     while True:
         it = r.next()
@@ -23,4 +26,9 @@ for rep in range(3):
     r.close()
     dt = time.perf_counter() - t0
     t = ingest.total_timings()
+    if dev is not None:
+        d = ingest.device_timings()
+        print("device reader: %d records in %.3f s = %.0f records/s; " % (k, dt, k / dt) + ", ".join("%s %.3f" % (a, d[a]) for a in ("feed_inflate", "split_scan", "decode", "copy_back", "host_table", "total")) +
+              "; %.2f GB inflated from %.2f GB, %d serial walks" % (d["inflated_bytes"] / 1e9, d["compressed_bytes"] / 1e9, d["serial_walks"]))
+        continue
     print("%d records in %.3f s = %.0f records/s; inflate %.3f (summed over files) files_wall %.3f merge %.3f" % (k, dt, k / dt, t["inflate"], t["files_wall"], t["merge"]))

@@ -8,7 +8,7 @@ W=/tmp/valuprof; rm -rf $W; mkdir -p $W $R/varlociraptor_amd/matrix
 cd $R/varlociraptor_amd/csrc
 F="-O3 -std=c++17 -fPIC -Wno-unused-function -ffp-contract=off -mllvm -disable-machine-licm -DVLR_PROFILE -DVLR_PROFILE_VALU"
 SRC=$(grep '^SRC = ' Makefile | cut -d= -f2)
-ID="-DVLR_SRC_ID=\"$(cat $SRC vlr_plan.h ../../include/vlr.h ../../include/vlr_detmath.h | sha1sum | cut -c1-16)\""
+ID="-DVLR_SRC_ID=\"$(cat $SRC vlr_plan.h vlr_gpuio.h ../../include/vlr.h ../../include/vlr_detmath.h | sha1sum | cut -c1-16)\""
 /opt/rocm/bin/hipcc --offload-arch=gfx950 $F "$ID" -S --cuda-device-only vlr_kernels.hip -o $W/dev.s 2>/dev/null
 python $R/tools/valu_instrument.py $W/dev.s $W/dev_i.s
 python $R/tools/asm_islands.py $W/dev_i.s $W/dev.gpuo

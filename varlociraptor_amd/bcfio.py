@@ -338,3 +338,17 @@ class BcfWriter:
 
     def __exit__(self, *a):
         self.close()
+
+
+def vcf_to_bcf(vcf_path: str, bcf_path: str) -> int:
+    """Re-encode a text VCF (plain or gzip) as BCF2 in BGZF members with BcfWriter; returns the record count."""
+    import gzip
+    op = gzip.open if open(vcf_path, "rb").read(2) == b"\x1f\x8b" else open
+    with op(vcf_path, "rt") as fh:
+        lines = fh.read().split("\n")
+    head = [l for l in lines if l.startswith("#")]
+    recs = [l for l in lines if l and not l.startswith("#")]
+    with BcfWriter(bcf_path, "\n".join(head) + "\n") as w:
+        for l in recs:
+            w.write_line(l)
+    return len(recs)

@@ -10,7 +10,10 @@ import argparse
 import sys
 from typing import Dict, List
 
+import numpy as np
+
 from . import abi, callsfmt, engine, obsfmt
+from .batch import CallResults
 from .scenario import Contamination, Inheritance, Sample, Scenario, Species, tumor_normal
 
 
@@ -156,6 +159,54 @@ class ContaminationCandidateFilter(CandidateFilter):
         return has_snv & (c1 - c0 >= 10) & (cs[c1] - cs[c0] == 0) & (s1 - s0 >= 10) & (sa[s1] - sa[s0] > 0)
 
 
+class _PinnedResults:
+    """Result buffers of one chunk carved out of recycled page-locked blocks (engine.host_array): the AFD lists of a chunk are hundreds of
+    megabytes — allocating and first-touching them per chunk costs more than the kernel, and from page-locked memory the device
+    copies them by direct DMA."""
+
+    def __init__(self):
+        import threading
+        self.free, self.lock = [], threading.Lock()
+
+    def results(self, n_loci, n_out, n_samples, afd_capacity):
+        need = n_loci * (8 * (n_out + 1 + n_samples) + abi.N_BIAS + 8) + (n_loci * n_samples * (4 + 16 * afd_capacity) if afd_capacity else 0) + 64 * 16
+        block = None
+        with self.lock:
+            for i, b in enumerate(self.free):
+                if b.size >= need:
+                    block = self.free.pop(i)
+                    break
+            if block is None and len(self.free) >= 4:
+                self.free.pop(0)
+        if block is None:
+            block = engine.host_array(int(need * 1.15) + 4096, np.uint8)
+        at = [0]
+
+        def alloc(shape, dtype):
+            n = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+            off = at[0]
+            at[0] = (off + n + 63) & ~63
+            return block[off:off + n].view(dtype).reshape(shape)
+        res = CallResults(n_loci, n_out, n_samples, afd_capacity, alloc=alloc)
+        res._pool_block = block
+        return res
+
+    def release(self, res):
+        block = getattr(res, "_pool_block", None)
+        if block is not None:
+            res._pool_block = None
+            with self.lock:
+                self.free.append(block)
+
+
+def _fixed_fields(res):
+    """Copy of the fixed-size result fields (the AFD lists stay with the chunk's own buffers)."""
+    out = CallResults(res.n_loci, res.n_out, res.n_samples, 0)
+    for f in ("ln_posterior", "ln_marginal", "map_vaf", "map_bias", "best_event", "status"):
+        getattr(out, f)[...] = getattr(res, f)
+    return out
+
+
 def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_capacity: int = 128, out=sys.stdout,
                   device: int = 0, output: str = None, ingest: str = None, timings: dict = None,
                   processor: "CallProcessor" = None, candidate_filter: "CandidateFilter" = None):
@@ -216,6 +267,7 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
         pass
     plans: Dict[tuple, "engine.Plan"] = {}   # one plan per scenario signature, kept across the chunks of a run
     FIELDS = ("ln_posterior", "ln_marginal", "map_vaf", "map_bias", "best_event", "status", "afd_count", "afd_vaf", "afd_lnprob")
+    result_pool = _PinnedResults() if (native and processor is None and rank == 0 and world == 1 and output) else None
 
     # Breakend events whose first record sat in an EARLIER chunk of the streaming reader: the reference hands the first breakend's
     # event probabilities and sample infos to every later record of the event across the whole file (calling.rs:569-580,
@@ -263,7 +315,14 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                 # observation files are already capped by preprocess's --max-depth: size the LDS budget to the deepest record
                 # (deeper records than the LDS holds take the deep launch)
                 plan.set_max_obs(min(max(int(sub.depth().sum(axis=1).max()), 1), engine.MAX_OBS_LDS))
-                r = plan.call_host(sub, afd_capacity=afd_capacity)
+                table = batch.extra.get("native_table") if getattr(batch, "extra", None) else None
+                if len(mine) == L and table is not None and getattr(table, "on_device", False):
+                    # the columns were decoded on the device (device reader): nothing to stage but the results, which land in recycled
+                    # page-locked memory when the calls writer is the only consumer (it hands the block back after the chunk is written)
+                    buf = result_pool.results(L, n_out_, S_, afd_capacity) if result_pool is not None else None
+                    r = plan.call_table_device(table, afd_capacity=afd_capacity, results=buf)
+                else:
+                    r = plan.call_host(sub, afd_capacity=afd_capacity)
             else:
                 r = CallResults(0, n_out_, S_, afd_capacity)
             if world > 1:
@@ -325,7 +384,18 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
         from . import ingest as vingest
         is_text = any(not (p_.endswith(".bcf") or p_.endswith(".bcf.gz")) for p_ in paths)
         chunk = int(os.environ.get("VLR_CLI_CHUNK", "0")) or (1 << 62 if is_text else 16384)  # text VCF: contigs are only known at the end
-        reader = vingest.ObsReader(paths, omit_bias_mask=omit_mask, chunk_records=chunk)
+        reader = None
+        if not is_text and world == 1 and os.environ.get("VLR_INGEST_HOST", "0") == "0":
+            # BGZF inflate, record split and v15 decode as kernels (csrc/vlr_inflate.hip, csrc/vlr_decode.hip): the compressed members
+            # cross PCIe, the columns are born in device memory and the evaluation reads them there.  Files it does not read (plain
+            # gzip, uncompressed BCF) go to the host reader.
+            try:
+                reader = vingest.ObsReader(paths, omit_bias_mask=omit_mask, chunk_records=int(os.environ.get("VLR_CLI_CHUNK", "0")) or 32768, device=device)
+            except engine.EngineError as ex:
+                if ex.code != abi.ERR_UNSUPPORTED:
+                    raise
+        if reader is None:
+            reader = vingest.ObsReader(paths, omit_bias_mask=omit_mask, chunk_records=chunk)
         q_in: "queue.Queue" = queue.Queue(maxsize=2)
         q_out: "queue.Queue" = queue.Queue(maxsize=2)
         stage = {"read_s": 0.0, "call_s": 0.0, "write_s": 0.0, "n_loci": 0, "n_obs": 0}
@@ -371,6 +441,8 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                         writer_state["w"] = vingest.CallsWriter(target, hdr)
                         writer_state["path"] = target
                     writer_state["w"].append(table, res_, list(names_))
+                    if result_pool is not None:
+                        result_pool.release(res_)
                     stage["write_s"] += time.perf_counter() - t0
             except BaseException as ex:  # noqa: BLE001
                 errors.append(ex)
@@ -418,7 +490,7 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                 stage["n_obs"] += batch.n_obs
                 if not used_contigs:
                     used_contigs = contig_names if not is_text else [contig_names[int(c_)] for c_ in np.unique(np.asarray(sites.contig))]
-                collected.append(res)
+                collected.append(_fixed_fields(res) if (result_pool is not None and getattr(res, "_pool_block", None) is not None) else res)
                 if processor is not None:
                     if res is not None and rank == 0:
                         if not proc_state["setup"]:

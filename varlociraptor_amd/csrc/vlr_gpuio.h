@@ -1,0 +1,87 @@
+// Device front door: what vlr_ingest.cpp (host side of the reader) and the kernels of vlr_inflate.hip /
+// vlr_decode.hip share.  Internal: the C ABI of the reader stays vlr_obs_reader_* (include/vlr.h).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace vlr {
+
+// one BGZF member (SAM spec 4.1): its raw DEFLATE payload inside the compressed bytes and where its inflated bytes go
+struct InflateBlock {
+    uint64_t src;    // byte offset of the DEFLATE stream (after the 18-byte member header) in the compressed buffer
+    uint64_t dst;    // byte offset of the member's first inflated byte in the output buffer
+    uint32_t clen;   // DEFLATE bytes (BSIZE + 1 - 18 - 8)
+    uint32_t isize;  // inflated bytes (ISIZE, <= 65536)
+};
+enum InflateStatus : int {
+    INFL_OK = 0, INFL_BAD_BLOCK_TYPE = 1, INFL_BAD_STORED = 2, INFL_BAD_CODE_LENGTHS = 3, INFL_OVERSUBSCRIBED = 4, INFL_BAD_SYMBOL = 5,
+    INFL_BAD_DISTANCE = 6, INFL_OUTPUT_OVERRUN = 7, INFL_INPUT_OVERRUN = 8, INFL_SIZE_MISMATCH = 9,
+};
+
+// what the INFO scan leaves per record for the decode and cold-copy kernels
+constexpr int kGpuVec = 18;    // the vector fields (FD_N_VEC of VlrObsField below)
+constexpr int kColdSegs = 6;   // [0] ID, alleles, FILTER; [1..5] the INFO entries IMPRECISE, EVENT, MATEID, HETEROZYGOSITY, SOMATIC_EFFECTIVE_MUTATION_RATE
+struct RecDesc {
+    uint64_t start;                 // offset of the record in the inflated stream
+    uint32_t l_shared;
+    uint32_t n_obs;                 // u64 length of PROB_MAPPING
+    uint32_t cold_bytes;            // size of the record's cold copy (8 + 24 + segments)
+    uint32_t n_cold_info;
+    uint32_t seg_off[kColdSegs], seg_len[kColdSegs];   // from the record start; length 0 = absent
+    uint32_t voff[kGpuVec], vn[kGpuVec];               // payload offset from the record start, element count
+    uint8_t vstride[kGpuVec];                          // bytes per element (1: int8, sign-extended to the u16 word; 2; 4); 0 = absent
+    uint8_t pad[6];
+};
+// what the host reads back per record
+struct RecHost { uint32_t n_obs, cold_bytes, status, flags; };  // flags bit 0: homopolymer fields present (is_homopolymer_indel)
+enum RecStatus : uint32_t {
+    REC_OK = 0, REC_TRUNCATED = 1u << 0, REC_BAD_ID = 1u << 1, REC_BAD_ALLELE = 1u << 2, REC_BAD_FILTER = 1u << 3, REC_BAD_INFO = 1u << 4,
+    REC_MISSING_FIELD = 1u << 5, REC_BAD_LENGTHS = 1u << 6, REC_BAD_VECTOR = 1u << 7,
+};
+struct DeviceCols { float* col[9]; uint32_t* flags; int32_t* third; };
+
+}  // namespace vlr
+
+// INFO fields of an observation record (format v15), in the order both decoders index them
+enum VlrObsField {
+    FD_PROB_MAPPING, FD_PROB_REF, FD_PROB_ALT, FD_PROB_MISSED, FD_PROB_SAMPLE_ALT, FD_PROB_DOUBLE_OVERLAP, FD_PROB_HIT_BASE,
+    FD_STRAND, FD_ORIENT, FD_READPOS, FD_ALTLOCUS, FD_SOFTCLIPPED, FD_PAIRED, FD_MAX_MAPQ, FD_HP_ART, FD_HP_VAR, FD_HP_LEN, FD_THIRD,
+    FD_N_VEC,
+    FD_IMPRECISE = FD_N_VEC, FD_EVENT, FD_MATEID, FD_HET, FD_SOM, FD_N
+};
+static_assert(FD_N_VEC == vlr::kGpuVec, "field table");
+
+extern "C" {
+// vlr_inflate.hip: n_blocks BGZF members, one wave each.  d_comp must be readable 1 KiB beyond the last member (prefetch window).
+int vlr_launch_inflate_kernel(const uint8_t* d_comp, const vlr::InflateBlock* d_blocks, int n_blocks, uint8_t* d_out, int* d_status, void* stream);
+
+// vlr_decode.hip: one sample file's side of the device reader (buffers and stream owned by the object; see the .hip for the stages)
+struct vlr_dev_file;
+int vlr_dev_file_create(int device, vlr_dev_file** out);
+void vlr_dev_file_destroy(vlr_dev_file* f);
+// bytes of complete-or-not record data currently buffered behind the read position
+uint64_t vlr_dev_file_buffered(const vlr_dev_file* f);
+// append the inflated bytes of n_blocks members (src offsets relative to comp) behind the buffered ones; asynchronous on the file's stream
+int vlr_dev_file_feed(vlr_dev_file* f, const uint8_t* comp, size_t comp_bytes, const vlr::InflateBlock* blocks, int n_blocks, uint64_t inflated_bytes);
+// skip `bytes` (the BCF header) at the read position
+int vlr_dev_file_skip(vlr_dev_file* f, uint64_t bytes);
+// split the buffered bytes into records (at most max_records), scan their INFO entries; *n_records complete records found,
+// rec_host[0..n) (array owned by the object, valid until the next split) their counts.  Synchronises the file's stream.
+int vlr_dev_file_split(vlr_dev_file* f, int64_t max_records, int n_contigs, int n_hdr_samples, const int8_t* field_of_key, int n_keys, int64_t* n_records,
+                       const vlr::RecHost** rec_host, int* used_serial_walk);
+// decode records [0, n) into the merged columns: record r of this file goes to observation offset d_obs_offset[r * n_samples + sample]
+int vlr_dev_file_decode(vlr_dev_file* f, int64_t n, const uint32_t* d_obs_offset, int n_samples, int sample, const vlr::DeviceCols* cols);
+// cold copies of records [0, n) -> host buffer (cold_off[r] = prefix sum of RecHost.cold_bytes, cold_off[n] bytes in all); asynchronous
+int vlr_dev_file_cold(vlr_dev_file* f, int64_t n, const uint64_t* cold_off, uint8_t* host_out);
+// consume records [0, n): the bytes behind them stay buffered for the next split.  Then wait for the stream.
+int vlr_dev_file_consume(vlr_dev_file* f, int64_t n);
+int vlr_dev_file_sync(vlr_dev_file* f);
+// record-level error bits of the last decode (REC_*), and the first record that has any
+int vlr_dev_file_errors(vlr_dev_file* f, int64_t n, uint32_t* status_or, int64_t* first_bad);
+void* vlr_dev_file_stream(vlr_dev_file* f);
+// asynchronous copy on the file's stream (to_device != 0: host -> device)
+int vlr_dev_file_copy(vlr_dev_file* f, void* dst, const void* src, size_t bytes, int to_device);
+// column storage of a table: `bytes` of device memory and as many page-locked host bytes
+int vlr_dev_slab_alloc(int device, size_t bytes, void** d, void** h);
+void vlr_dev_slab_free(int device, void* d, void* h);
+}

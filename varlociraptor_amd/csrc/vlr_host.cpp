@@ -1168,11 +1168,14 @@ struct HostChunk {
     bool active = false;
 };
 
-static int host_chunk_start(vlr_plan* plan, const vlr_batch* in, vlr_results* out, int64_t l0, int64_t l1, int k, HostChunk* hc) {
+// (dev_off != nullptr: the columns of `in` are DEVICE arrays already — the batch of a device reader — and dev_off is the host copy of
+// its obs_offset; nothing is staged but the result buffers)
+static int host_chunk_start(vlr_plan* plan, const vlr_batch* in, vlr_results* out, int64_t l0, int64_t l1, int k, HostChunk* hc, const uint32_t* dev_off = nullptr) {
     const int S = plan->host.S;
     const int64_t L = l1 - l0;
     const int n_out = plan->n_events + 2;
-    const uint32_t ob = in->obs_offset[l0 * S], oe = in->obs_offset[l1 * S];
+    const uint32_t* h_off = dev_off ? dev_off : in->obs_offset;
+    const uint32_t ob = h_off[l0 * S], oe = h_off[l1 * S];
     const size_t N = (size_t)(oe - ob);
     hipStream_t st = plan->stage_stream[k];
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -1180,6 +1183,7 @@ static int host_chunk_start(vlr_plan* plan, const vlr_batch* in, vlr_results* ou
     std::vector<Col> cols;
     size_t off = 0;
     auto add = [&](const void* p, size_t bytes) {
+        if (dev_off) return (size_t)0;
         cols.push_back({p, bytes, off});
         size_t o = off;
         off += al(std::max<size_t>(bytes, 1));
@@ -1233,6 +1237,15 @@ static int host_chunk_start(vlr_plan* plan, const vlr_batch* in, vlr_results* ou
     db.variant_type = in->variant_type ? (const uint8_t*)(base + o_vt) : nullptr;
     db.ref_base = in->ref_base ? (const uint8_t*)(base + o_rb) : nullptr;
     db.alt_base = in->alt_base ? (const uint8_t*)(base + o_ab) : nullptr;
+    if (dev_off) {   // the caller's device arrays: observation columns are indexed absolutely, the per-locus ones advance
+        db = *in;
+        db.n_loci = L; db.n_obs = (int64_t)N;
+        db.obs_offset = in->obs_offset + l0 * S;
+        db.locus_flags = in->locus_flags + l0;
+        db.variant_type = in->variant_type ? in->variant_type + l0 : nullptr;
+        db.ref_base = in->ref_base ? in->ref_base + l0 : nullptr;
+        db.alt_base = in->alt_base ? in->alt_base + l0 : nullptr;
+    }
     vlr_results dr = *out;
     dr.n_loci = L;
     dr.ln_posterior = (double*)(base + r_post);
@@ -1249,7 +1262,7 @@ static int host_chunk_start(vlr_plan* plan, const vlr_batch* in, vlr_results* ou
     {
         int budget = plan->max_obs > 0 ? plan->max_obs : plan->max_depth_per_sample * S;
         uint32_t mx = 1;
-        for (int64_t l = l0; l < l1; ++l) mx = std::max(mx, in->obs_offset[(l + 1) * S] - in->obs_offset[l * S]);
+        for (int64_t l = l0; l < l1; ++l) mx = std::max(mx, h_off[(l + 1) * S] - h_off[l * S]);
         plan->max_obs = std::min<int>(budget, (int)mx);
         // the LDS-resident kernel holds at most 7 680 kept observations of a locus; the launcher's own limit is the budget
         plan->deep_hint = ((int)mx > std::min(budget, 7680)) ? 1 : 0;
@@ -1323,6 +1336,42 @@ int vlr_batch_run_host(vlr_plan* plan, const vlr_batch* in, vlr_results* out) {
         const int64_t l0 = L * c / n_chunks, l1 = L * (c + 1) / n_chunks;
         rc = host_chunk_start(plan, in, out, l0, l1, k, &hc[k]);
         if (rc == VLR_OK) rc = host_chunk_finish(plan, out, &hc[k ^ 1]);  // previous chunk: overlaps the kernel just launched
+    }
+    for (int k = 0; k < 2; ++k) {
+        int r2 = host_chunk_finish(plan, out, &hc[k]);
+        if (rc == VLR_OK) rc = r2;
+    }
+    if (rc != VLR_OK) (void)hipDeviceSynchronize();
+    return rc;
+}
+
+// Device columns in (the batch of a device reader, vlr_obs_table_device_batch), host results out: the evaluation stage of the
+// front door when the observation columns were decoded on the device.  obs_offset_host: host copy of in->obs_offset.
+int vlr_batch_run_device_in(vlr_plan* plan, const vlr_batch* in, const uint32_t* obs_offset_host, vlr_results* out) {
+    if (!plan || !in || !out || !obs_offset_host) return fail(VLR_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(plan->device));
+    const int S = plan->host.S;
+    const int64_t L = in->n_loci;
+    if (L == 0) return VLR_OK;
+    if (in->n_samples != S) return fail(VLR_ERR_INVALID_ARGUMENT, "batch has %d samples, plan %d", in->n_samples, S);
+    if (!in->obs_offset || !in->flags || !in->locus_flags) return fail(VLR_ERR_INVALID_ARGUMENT, "missing required column");
+    const bool want_afd = out->afd_count || out->afd_vaf || out->afd_lnprob;
+    if (want_afd && (!out->afd_count || !out->afd_vaf || !out->afd_lnprob || out->afd_capacity < 1))
+        return fail(VLR_ERR_INVALID_ARGUMENT, "AFD needs afd_count, afd_vaf, afd_lnprob and afd_capacity >= 1");
+    for (int k = 0; k < 2; ++k)
+        if (!plan->stage_stream[k]) HIP_TRY(hipStreamCreateWithFlags(&plan->stage_stream[k], hipStreamNonBlocking));
+    // chunks only bound the result staging (the AFD lists are 1.5 kB per locus and sample at capacity 96) and let the copy of one
+    // chunk's results run behind the kernel of the next
+    const size_t per_locus = (size_t)(plan->n_events + 2 + S + 1) * 8 + 16 + (want_afd ? (size_t)S * (4 + 16 * (size_t)out->afd_capacity) : 0);
+    int64_t n_chunks = std::max<int64_t>(1, (int64_t)((double)per_locus * (double)L / 256.0e6));
+    n_chunks = std::min<int64_t>(n_chunks, std::max<int64_t>(1, L / 8192));
+    HostChunk hc[2];
+    int rc = VLR_OK;
+    for (int64_t c = 0; c < n_chunks && rc == VLR_OK; ++c) {
+        const int k = (int)(c & 1);
+        const int64_t l0 = L * c / n_chunks, l1 = L * (c + 1) / n_chunks;
+        rc = host_chunk_start(plan, in, out, l0, l1, k, &hc[k], obs_offset_host);
+        if (rc == VLR_OK) rc = host_chunk_finish(plan, out, &hc[k ^ 1]);
     }
     for (int k = 0; k < 2; ++k) {
         int r2 = host_chunk_finish(plan, out, &hc[k]);

@@ -1,0 +1,358 @@
+// BGZF members inflated on the device: one wave64 (= one workgroup) per member.
+//
+// What it replaces: htslib's bgzf_read / libdeflate behind rust-htslib's bcf::Reader, which the reference opens per sample in
+// `call variants` (reference src/calling/variants/calling.rs:297-316, ObservationBcfs; preprocessing/mod.rs:818-919 reads the
+// records).  On the 16-CPU box the host inflate of the observation files is 3.4 CPU-seconds per 200 000 tumor-normal records — the
+// whole budget of 1 M records/s — while the compressed bytes are 1/11 of the inflated ones: they cross PCIe, and the
+// inflated stream is born in HBM where the record decoder (vlr_decode.hip) reads it.
+//
+// DEFLATE (RFC 1951) is a serial bit stream: symbol k+1 starts where symbol k ends.  The wave runs it as ONE decoder whose state
+// (bit buffer, output position, current symbol) is wave-uniform, and uses the 64 lanes for everything that is parallel around it:
+//   * the compressed bytes reach the bit buffer through a 64-dword window held one dword per lane (one coalesced load per 256
+//     bytes, prefetched one window ahead); the decoder takes dword i with a lane read — no memory latency on the serial path;
+//   * the last 32 KiB of the inflated member (DEFLATE's window) live in an LDS ring, so a match is one LDS read and one LDS write
+//     of up to 64 bytes per instruction pair, with the period trick for overlapping matches (source index = i mod distance), and
+//     literals are single LDS byte stores of lane 0; 38 kB of LDS per wave = four members in flight per CU, one per SIMD (a single
+//     wave issues an instruction every 4-5 cycles at best: the ~150 instructions of a symbol, not the LDS latency, set its pace);
+//   * the table entry of the NEXT symbol is fetched before the bytes of the current match are copied (its position is known as soon as
+//     the distance's extra bits are), so the lookup latency hides behind the copy;
+//   * Huffman tables are built by all lanes (canonical codes from per-length ballots) into single-lookup tables whose entries
+//     already carry the length / distance base and extra-bit count; codes longer than the table index fall back to the canonical
+//     bit-serial walk;
+//   * finished 8 KiB pieces of the ring go to HBM in 16-byte lanes (ring positions are shifted by the low 4 bits of the destination
+//     so both sides of the copy are aligned).
+// CRC32 of the member is NOT checked on the device (ISIZE, end-of-block and every code are); VLR_INGEST_HOST_INFLATE=1 selects the
+// host path, which checks it.
+#include <hip/hip_runtime.h>
+
+#include "vlr_gpuio.h"
+
+namespace vlr {
+namespace {
+
+constexpr int kLitBits = 10, kDistBits = 9, kClBits = 7;
+constexpr uint32_t kRing = 32768, kRingMask = kRing - 1, kFlush = 8192;   // flushed to HBM in 8 KiB pieces, each before the ring wraps onto it
+
+struct InflLds {
+    uint8_t out[kRing];              // ring over the last 32 KiB of the inflated member (DEFLATE's window), position shifted by (HBM destination & 15)
+    uint32_t lit[1 << kLitBits];     // code length (4) | kind (2: literal, length, end of block, invalid) @4 | value or length base (9) @8 | extra bits (3) @20
+    uint32_t dist[1 << kDistBits];   // code length (4) | extra bits (4; 15 = invalid symbol) @4 | base (16) @8.  Also the code-length code's table.
+    uint16_t lsym[288], dsym[32];    // symbols in canonical order (bit-serial fallback)
+    uint16_t lcount[16], dcount[16];
+    uint8_t lens[328];
+};
+
+struct Bits {
+    const uint32_t* g;   // dword-aligned base of the stream
+    uint32_t cur, nxt;   // per lane: dwords 64 wi + lane and 64 (wi + 1) + lane
+    uint32_t w;          // next dword to take
+    uint64_t buf;
+    int cnt;
+};
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t take32(Bits& b, int lane) {
+    const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)b.cur, (int)uni(b.w & 63u));
+    b.w += 1;
+    if ((b.w & 63u) == 0) { b.cur = b.nxt; b.nxt = b.g[b.w + 64 + lane]; }
+    return v;
+}
+__device__ __forceinline__ void refill(Bits& b, int lane) {  // afterwards at least 33 bits are buffered
+    if (b.cnt <= 32) { b.buf |= (uint64_t)take32(b, lane) << b.cnt; b.cnt += 32; }
+}
+__device__ __forceinline__ uint32_t peek(const Bits& b, int n) { return (uint32_t)b.buf & ((1u << n) - 1u); }
+__device__ __forceinline__ void drop(Bits& b, int n) { b.buf >>= n; b.cnt -= n; }
+__device__ __forceinline__ void bits_open(Bits& b, const uint8_t* p, int lane) {
+    const uintptr_t a = (uintptr_t)p;
+    b.g = (const uint32_t*)(a & ~(uintptr_t)3);
+    b.w = 0; b.buf = 0; b.cnt = 0;
+    b.cur = b.g[lane]; b.nxt = b.g[64 + lane];
+    refill(b, lane);
+    drop(b, (int)(a & 3) * 8);
+}
+__device__ __forceinline__ const uint8_t* bits_byte_pos(const Bits& b) {  // (only at a byte boundary)
+    return (const uint8_t*)b.g + (((uint64_t)b.w * 32 - (uint64_t)b.cnt) >> 3);
+}
+__device__ __forceinline__ const uint8_t* bits_used_end(const Bits& b) {  // first byte no consumed bit lies in
+    return (const uint8_t*)b.g + (((uint64_t)b.w * 32 - (uint64_t)b.cnt + 7) >> 3);
+}
+
+template <int KIND>
+__device__ __forceinline__ uint32_t make_entry(uint32_t s) {
+    if (KIND == 0) {
+        if (s < 256) return s << 8;
+        if (s == 256) return 2u << 4;
+        if (s > 285) return 3u << 4;
+        const uint32_t k = s - 257;
+        uint32_t xb = 0, base = 3 + k;
+        if (k == 28) base = 258;
+        else if (k >= 8) { xb = (k >> 2) - 1; base = 3 + ((4 + (k & 3)) << xb); }
+        return (1u << 4) | (base << 8) | (xb << 20);
+    }
+    if (KIND == 1) {
+        if (s >= 30) return 15u << 4;
+        uint32_t xb = 0, base = 1 + s;
+        if (s >= 4) { xb = (s >> 1) - 1; base = 1 + ((2 + (s & 1)) << xb); }
+        return (xb << 4) | (base << 8);
+    }
+    return s << 8;
+}
+
+// canonical Huffman code of `n` symbols with lengths lens[0..n) -> single-lookup table of 2^TB entries (longer codes: entry 0),
+// symbols in canonical order and per-length counts for the bit-serial fallback.  false: over-subscribed set of lengths.
+template <int KIND, int TB>
+__device__ __forceinline__ bool build_table(const uint8_t* lens, int n, uint32_t* table, uint16_t* symorder, uint16_t* count, int lane) {
+    for (int i = lane; i < (1 << TB); i += 64) table[i] = 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t mycnt = 0;  // lane L: symbols of length L
+    const int nch = (n + 63) >> 6;
+    for (int c = 0; c < nch; ++c) {
+        const int s = c * 64 + lane;
+        const int l = s < n ? lens[s] : 0;
+        for (int L = 1; L <= 15; ++L) {
+            const unsigned long long m = __ballot(l == L);
+            if (lane == L) mycnt += (uint32_t)__popcll(m);
+        }
+    }
+    if (lane < 16) count[lane] = (uint16_t)mycnt;
+    uint32_t mybase = 0, myoff = 0;
+    {
+        uint32_t code = 0, off = 0, prev = 0;
+        int left = 1;
+        for (int L = 1; L <= 15; ++L) {
+            const uint32_t cL = (uint32_t)__builtin_amdgcn_readlane((int)mycnt, L);
+            left = (left << 1) - (int)cL;
+            if (left < 0) return false;
+            code = (code + prev) << 1;
+            if (lane == L) { mybase = code; myoff = off; }
+            off += cL; prev = cL;
+        }
+    }
+    for (int c = 0; c < nch; ++c) {
+        const int s = c * 64 + lane;
+        const int l = s < n ? lens[s] : 0;
+        uint32_t code_s = 0, idx_s = 0;
+        for (int L = 1; L <= 15; ++L) {
+            const unsigned long long m = __ballot(l == L);
+            if (m == 0) continue;
+            const uint32_t bL = (uint32_t)__builtin_amdgcn_readlane((int)mybase, L), oL = (uint32_t)__builtin_amdgcn_readlane((int)myoff, L);
+            const uint32_t rank = (uint32_t)__popcll(m & lt), pc = (uint32_t)__popcll(m);
+            if (l == L) { code_s = bL + rank; idx_s = oL + rank; }
+            if (lane == L) { mybase += pc; myoff += pc; }
+        }
+        if (l > 0) {
+            symorder[idx_s] = (uint16_t)s;
+            if (l <= TB) {
+                const uint32_t rev = __brev(code_s) >> (32 - l);
+                const uint32_t e = make_entry<KIND>((uint32_t)s) | (uint32_t)l;
+                for (uint32_t k = rev; k < (1u << TB); k += 1u << l) table[k] = e;
+            }
+        }
+    }
+    return true;
+}
+
+// bit-serial canonical decode (codes longer than the table index); needs 15 buffered bits.  -1: no such code
+__device__ __forceinline__ int slow_symbol(Bits& b, const uint16_t* count, const uint16_t* symorder) {
+    const uint32_t v = (uint32_t)b.buf;
+    int code = 0, first = 0, index = 0;
+    for (int len = 1; len <= 15; ++len) {
+        code |= (int)((v >> (len - 1)) & 1u);
+        const int c = (int)uni(count[len]);
+        if (code - c < first) {
+            const int sym = (int)uni(symorder[index + (code - first)]);
+            drop(b, len);
+            return sym;
+        }
+        index += c; first += c;
+        first <<= 1; code <<= 1;
+    }
+    return -1;
+}
+
+// ring position P (= shift + byte offset in the member) -> HBM: pieces [from, to) with from a multiple of 16 except at the member's start
+__device__ __forceinline__ void flush_ring(const InflLds& L, uint8_t* gbase, uint32_t from, uint32_t to, uint32_t sh, int lane) {
+    for (uint32_t k = (from & ~15u) + 16u * (uint32_t)lane; k < to; k += 1024u) {
+        if (k >= from && k + 16 <= to) *reinterpret_cast<uint4*>(gbase + k) = *reinterpret_cast<const uint4*>(&L.out[k & kRingMask]);
+        else
+            for (uint32_t j = k < from ? from : k; j < k + 16 && j < to; ++j) gbase[j] = L.out[j & kRingMask];
+    }
+    (void)sh;
+}
+
+__global__ __launch_bounds__(64) void vlr_inflate_kernel(const uint8_t* __restrict__ comp, const InflateBlock* __restrict__ blocks, int n_blocks,
+                                                        uint8_t* __restrict__ out, int* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) InflLds L;
+    const int lane = (int)threadIdx.x;
+    const int blk = (int)blockIdx.x;
+    if (blk >= n_blocks) return;
+    const uint64_t src = blocks[blk].src, dst = blocks[blk].dst;
+    const uint32_t clen = uni(blocks[blk].clen), isize = uni(blocks[blk].isize);
+    const uint32_t sh = uni((uint32_t)(((uintptr_t)out + dst) & 15));  // ring positions are shifted so that LDS and HBM addresses agree mod 16
+    const uint8_t* in_end = comp + src + clen;
+    uint8_t* gbase = out + dst - sh;  // 16-byte aligned: ring position P goes to gbase[P]
+    int err = INFL_OK;
+    uint32_t pos = sh;                // ring position of the next byte
+    uint32_t flushed = sh;            // ring positions below are in HBM
+    const uint32_t lim = sh + isize;
+    if (isize > 65536u) err = INFL_SIZE_MISMATCH;
+    Bits b;
+    bits_open(b, comp + src, lane);
+    bool last = (isize == 0 && clen == 0);
+    while (!last && err == INFL_OK) {
+        refill(b, lane);
+        last = (peek(b, 1) != 0);
+        const uint32_t type = (peek(b, 3) >> 1);
+        drop(b, 3);
+        if (type == 0) {  // stored
+            drop(b, b.cnt & 7);
+            refill(b, lane);
+            const uint32_t len = peek(b, 16);
+            drop(b, 16);
+            refill(b, lane);
+            const uint32_t nlen = peek(b, 16);
+            drop(b, 16);
+            const uint8_t* p = bits_byte_pos(b);
+            if ((len ^ 0xffffu) != nlen) { err = INFL_BAD_STORED; break; }
+            if (pos + len > lim) { err = INFL_OUTPUT_OVERRUN; break; }
+            if (p + len > in_end) { err = INFL_INPUT_OVERRUN; break; }
+            for (uint32_t done = 0; done < len;) {   // through the ring in pieces the flush keeps up with
+                const uint32_t piece = len - done < kFlush ? len - done : kFlush;
+                for (uint32_t k = (uint32_t)lane; k < piece; k += 64) L.out[(pos + k) & kRingMask] = p[done + k];
+                pos += piece; done += piece;
+                if (pos - flushed >= kFlush) { const uint32_t to = pos & ~(kFlush - 1); flush_ring(L, gbase, flushed, to, sh, lane); flushed = to; }
+            }
+            bits_open(b, p + len, lane);
+            continue;
+        }
+        if (type == 3) { err = INFL_BAD_BLOCK_TYPE; break; }
+        if (type == 1) {  // fixed code (RFC 1951 3.2.6)
+            for (int s = lane; s < 288; s += 64) L.lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
+            if (lane < 32) L.lens[288 + lane] = 5;
+            build_table<0, kLitBits>(L.lens, 288, L.lit, L.lsym, L.lcount, lane);
+            build_table<1, kDistBits>(L.lens + 288, 32, L.dist, L.dsym, L.dcount, lane);
+        } else {  // dynamic code
+            refill(b, lane);
+            const int hlit = (int)peek(b, 5) + 257;
+            drop(b, 5);
+            const int hdist = (int)peek(b, 5) + 1;
+            drop(b, 5);
+            const int hclen = (int)peek(b, 4) + 4;
+            drop(b, 4);
+            if (hlit > 286 || hdist > 30) { err = INFL_BAD_CODE_LENGTHS; break; }
+            if (lane < 19) L.lens[lane] = 0;
+            // order of the code-length code lengths (RFC 1951 3.2.7)
+            static constexpr unsigned char order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            for (int i = 0; i < hclen; ++i) {
+                refill(b, lane);
+                const uint32_t v = peek(b, 3);
+                drop(b, 3);
+                if (lane == 0) L.lens[order[i]] = (uint8_t)v;
+            }
+            if (!build_table<2, kClBits>(L.lens, 19, L.dist, L.dsym, L.dcount, lane)) { err = INFL_OVERSUBSCRIBED; break; }
+            const int total = hlit + hdist;
+            int i = 0;
+            uint32_t prev = 0;
+            while (i < total) {
+                refill(b, lane);
+                const uint32_t e = uni(L.dist[peek(b, kClBits)]);
+                int sym;
+                if ((e & 15u) == 0) {
+                    sym = slow_symbol(b, L.dcount, L.dsym);
+                    if (sym < 0) { err = INFL_BAD_CODE_LENGTHS; break; }
+                } else { sym = (int)(e >> 8); drop(b, (int)(e & 15u)); }
+                if (sym < 16) { if (lane == 0) L.lens[i] = (uint8_t)sym; prev = (uint32_t)sym; i += 1; continue; }
+                int rep;
+                uint32_t val = 0;
+                if (sym == 16) {
+                    if (i == 0) { err = INFL_BAD_CODE_LENGTHS; break; }
+                    rep = 3 + (int)peek(b, 2); drop(b, 2); val = prev;
+                } else if (sym == 17) { rep = 3 + (int)peek(b, 3); drop(b, 3); prev = 0; }
+                else { rep = 11 + (int)peek(b, 7); drop(b, 7); prev = 0; }
+                if (i + rep > total) { err = INFL_BAD_CODE_LENGTHS; break; }
+                for (int k = lane; k < rep; k += 64) L.lens[i + k] = (uint8_t)val;
+                i += rep;
+            }
+            if (err != INFL_OK) break;
+            if (uni(L.lens[256]) == 0) { err = INFL_BAD_CODE_LENGTHS; break; }
+            // (the distance lengths are copied behind the 288 literal/length slots before the tables are built: build_table reads them
+            // while it writes the tables, and L.dist still holds the code-length table until then)
+            const uint8_t dl = lane < hdist ? L.lens[hlit + lane] : (uint8_t)0;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 32) L.lens[288 + lane] = dl;
+            if (!build_table<0, kLitBits>(L.lens, hlit, L.lit, L.lsym, L.lcount, lane)) { err = INFL_OVERSUBSCRIBED; break; }
+            if (!build_table<1, kDistBits>(L.lens + 288, hdist, L.dist, L.dsym, L.dcount, lane)) { err = INFL_OVERSUBSCRIBED; break; }
+        }
+        // ---- symbols of the block.  `e` is the table entry at the current bit position, fetched one symbol ahead.  Checks that only
+        // guard against a corrupt stream (bad distance code, distance beyond the output) are collected in `bad` without a branch:
+        // the ring mask keeps every LDS access in range, and the output bound — the one check the HBM copy depends on — stays exact.
+        // (One loop exit: every early exit of a multi-exit loop costs the structurised control flow a flag test per iteration.)
+        refill(b, lane);
+        uint32_t e = uni(L.lit[peek(b, kLitBits)]);
+        uint32_t bad = 0;
+        bool done = false;
+        do {
+            if (__builtin_expect((e & 15u) == 0, 0)) {
+                const int sym = slow_symbol(b, L.lcount, L.lsym);
+                e = sym < 0 ? (3u << 4) : make_entry<0>((uint32_t)sym);
+            } else drop(b, (int)(e & 15u));
+            const uint32_t kind = (e >> 4) & 3u;
+            if (kind == 0) {
+                const uint32_t byte = e >> 8;
+                refill(b, lane);
+                const uint32_t ev = L.lit[peek(b, kLitBits)];   // (made uniform after the store: the read is in flight meanwhile)
+                L.out[pos & kRingMask] = (uint8_t)byte;         // (every lane stores the same byte to the same address)
+                bad |= (pos >= lim) ? (uint32_t)INFL_OUTPUT_OVERRUN << 8 : 0u;
+                pos += 1;
+                e = uni(ev);
+            } else if (kind == 1) {
+                const int xb = (int)((e >> 20) & 7u);
+                const uint32_t len = ((e >> 8) & 511u) + peek(b, xb);
+                drop(b, xb);
+                refill(b, lane);
+                uint32_t d = uni(L.dist[peek(b, kDistBits)]);
+                if (__builtin_expect((d & 15u) == 0, 0)) {
+                    const int sym = slow_symbol(b, L.dcount, L.dsym);
+                    d = sym < 0 ? (15u << 4) : make_entry<1>((uint32_t)sym);
+                } else drop(b, (int)(d & 15u));
+                const int dx = (int)((d >> 4) & 15u);
+                const uint32_t dist = (d >> 8) + peek(b, dx);
+                drop(b, dx);
+                bad |= ((dx == 15) | (dist > pos - sh)) ? (uint32_t)INFL_BAD_DISTANCE : 0u;
+                bad |= (pos + len > lim) ? (uint32_t)INFL_OUTPUT_OVERRUN << 8 : 0u;
+                refill(b, lane);
+                const uint32_t ev = L.lit[peek(b, kLitBits)];   // the next symbol's entry: in flight while the bytes are copied
+                const uint32_t from = pos - dist;
+                // byte k of the match repeats with period `dist` (k mod dist = k when dist >= len); every source byte lies before `pos`
+                // (approximate reciprocal: the two corrections below make the remainder exact for k < 512)
+                const float rd = __builtin_amdgcn_rcpf((float)(dist | (uint32_t)(dist == 0)));
+                for (uint32_t k = (uint32_t)lane; k < len; k += 64) {
+                    int r = (int)k - (int)((float)k * rd) * (int)dist;
+                    r = r < 0 ? r + (int)dist : r;
+                    r = r >= (int)dist ? r - (int)dist : r;
+                    L.out[(pos + k) & kRingMask] = L.out[(from + (uint32_t)r) & kRingMask];
+                }
+                pos += len;
+                e = uni(ev);
+            } else {
+                done = true;   // 2: end of block
+                bad |= kind == 3 ? (uint32_t)INFL_BAD_SYMBOL : 0u;
+            }
+            done = done || bad != 0;
+            if (__builtin_expect(!done && pos - flushed >= kFlush + 512, 0)) { const uint32_t to = pos & ~(kFlush - 1); flush_ring(L, gbase, flushed, to, sh, lane); flushed = to; }
+        } while (!done);
+        if (bad) err = (bad >> 8) ? (int)(bad >> 8) : (int)(bad & 0xffu);
+        if (err == INFL_OK && bits_used_end(b) > in_end) err = INFL_INPUT_OVERRUN;
+    }
+    if (err == INFL_OK && pos != lim) err = INFL_SIZE_MISMATCH;
+    if (err == INFL_OK && pos > flushed) flush_ring(L, gbase, flushed, pos, sh, lane);
+    if (lane == 0) status[blk] = err;
+}
+
+}  // namespace
+}  // namespace vlr
+
+extern "C" int vlr_launch_inflate_kernel(const uint8_t* d_comp, const vlr::InflateBlock* d_blocks, int n_blocks, uint8_t* d_out, int* d_status, void* stream) {
+    if (n_blocks <= 0) return 0;
+    hipLaunchKernelGGL(vlr::vlr_inflate_kernel, dim3((unsigned)n_blocks), dim3(64), 0, (hipStream_t)stream, d_comp, d_blocks, n_blocks, d_out, d_status);
+    return (int)hipGetLastError();
+}

@@ -41,6 +41,7 @@
 #include <vector>
 
 #include "../../include/vlr.h"
+#include "vlr_gpuio.h"
 
 extern "C" void vlr_set_error(const char* msg);  // vlr_host.cpp: the text behind vlr_last_error()
 
@@ -482,12 +483,7 @@ void parse_header(const std::string& text, Header& h) {
 }
 
 // ------------------------------------------------------------------------------------------------ observation records
-enum Field {
-    FD_PROB_MAPPING, FD_PROB_REF, FD_PROB_ALT, FD_PROB_MISSED, FD_PROB_SAMPLE_ALT, FD_PROB_DOUBLE_OVERLAP, FD_PROB_HIT_BASE,
-    FD_STRAND, FD_ORIENT, FD_READPOS, FD_ALTLOCUS, FD_SOFTCLIPPED, FD_PAIRED, FD_MAX_MAPQ, FD_HP_ART, FD_HP_VAR, FD_HP_LEN, FD_THIRD,
-    FD_N_VEC,
-    FD_IMPRECISE = FD_N_VEC, FD_EVENT, FD_MATEID, FD_HET, FD_SOM, FD_N
-};
+// (enum VlrObsField: vlr_gpuio.h — the device decoder indexes the same table)
 const char* const kFieldName[FD_N] = {
     "PROB_MAPPING", "PROB_REF", "PROB_ALT", "PROB_MISSED_ALLELE", "PROB_SAMPLE_ALT", "PROB_DOUBLE_OVERLAP", "PROB_HIT_BASE",
     "STRAND", "READ_ORIENTATION", "READ_POSITION", "ALT_LOCUS", "SOFTCLIPPED", "PAIRED", "IS_MAX_MAPQ",
@@ -682,6 +678,29 @@ uint32_t pool_add(std::string& pool, const std::string& s) {
     return at;
 }
 
+// the per-record (cold) fields of a decoded record: site, strings, haplotype identifier, priors
+bool push_cold(const RecView& r, Chunk& c, uint32_t n, bool is_hp, std::string& err) {
+    c.n_obs.push_back(n);
+    c.is_hp.push_back(is_hp ? 1 : 0);
+    c.imprecise.push_back(r.imprecise ? 1 : 0);
+    c.contig.push_back(r.contig);
+    c.pos.push_back(r.pos);
+    c.het.push_back(r.het_ln);
+    c.som.push_back(r.som_ln);
+    c.id.push_back(pool_add(c.pool, r.id.empty() ? std::string(".") : r.id));
+    c.ref.push_back(pool_add(c.pool, r.ref));
+    c.alt.push_back(pool_add(c.pool, r.alt));
+    // HaplotypeIdentifier::from (variants/model/mod.rs:87-133): EVENT, else the sorted pair (record id, MATEID)
+    if (!r.event.empty()) c.hap.push_back(pool_add(c.pool, r.event.substr(0, r.event.find(','))));
+    else if (!r.mateid.empty()) {
+        if (r.id.empty() || r.id == ".") { err = "breakend with MATEID but without record ID"; return false; }
+        std::string a = r.id, b = r.mateid.substr(0, r.mateid.find(','));
+        if (b < a) std::swap(a, b);
+        c.hap.push_back(pool_add(c.pool, a + "-" + b));
+    } else c.hap.push_back(0xffffffffu);
+    return true;
+}
+
 // read_observations (preprocessing/mod.rs:818-919) of one record into the chunk
 bool decode_into(const RecView& r, Chunk& c, std::string& err) {
     static const int kMini[7] = {FD_PROB_MAPPING, FD_PROB_ALT, FD_PROB_REF, FD_PROB_MISSED, FD_PROB_SAMPLE_ALT, FD_PROB_DOUBLE_OVERLAP, FD_PROB_HIT_BASE};
@@ -816,25 +835,7 @@ bool decode_into(const RecView& r, Chunk& c, std::string& err) {
         if (cu.bad) { err = "truncated THIRD_ALLELE_EVIDENCE"; return false; }
     } else
         for (uint64_t i = 0; i < n; ++i) th[i] = -1;
-    c.n_obs.push_back((uint32_t)n);
-    c.is_hp.push_back(is_hp ? 1 : 0);
-    c.imprecise.push_back(r.imprecise ? 1 : 0);
-    c.contig.push_back(r.contig);
-    c.pos.push_back(r.pos);
-    c.het.push_back(r.het_ln);
-    c.som.push_back(r.som_ln);
-    c.id.push_back(pool_add(c.pool, r.id.empty() ? std::string(".") : r.id));
-    c.ref.push_back(pool_add(c.pool, r.ref));
-    c.alt.push_back(pool_add(c.pool, r.alt));
-    // HaplotypeIdentifier::from (variants/model/mod.rs:87-133): EVENT, else the sorted pair (record id, MATEID)
-    if (!r.event.empty()) c.hap.push_back(pool_add(c.pool, r.event.substr(0, r.event.find(','))));
-    else if (!r.mateid.empty()) {
-        if (r.id.empty() || r.id == ".") { err = "breakend with MATEID but without record ID"; return false; }
-        std::string a = r.id, b = r.mateid.substr(0, r.mateid.find(','));
-        if (b < a) std::swap(a, b);
-        c.hap.push_back(pool_add(c.pool, a + "-" + b));
-    } else c.hap.push_back(0xffffffffu);
-    return true;
+    return push_cold(r, c, (uint32_t)n, is_hp, err);
 }
 
 // ---- BCF2 typed values
@@ -1118,6 +1119,64 @@ void* table_alloc(size_t bytes, bool& pinned) {
     return p;
 }
 
+// column storage of the tables of a device reader: one device allocation and one page-locked host allocation of the same layout,
+// recycled (hipMalloc / hipHostMalloc synchronise the device and take milliseconds per hundred megabytes)
+struct DevSlab { void* d = nullptr; void* h = nullptr; size_t cap = 0; };
+struct DevPool {
+    int device = 0;
+    std::mutex mu;
+    std::vector<DevSlab> free_list;
+    ~DevPool() { for (auto& s : free_list) vlr_dev_slab_free(device, s.d, s.h); }
+    int acquire(size_t bytes, DevSlab& out) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            int best = -1;
+            for (int i = 0; i < (int)free_list.size(); ++i)
+                if (free_list[(size_t)i].cap >= bytes && (best < 0 || free_list[(size_t)i].cap < free_list[(size_t)best].cap)) best = i;
+            if (best >= 0) { out = free_list[(size_t)best]; free_list.erase(free_list.begin() + best); return VLR_OK; }
+            if (free_list.size() >= 8) { vlr_dev_slab_free(device, free_list[0].d, free_list[0].h); free_list.erase(free_list.begin()); }  // (too small ones do not pile up)
+        }
+        const size_t cap = bytes + bytes / 8 + (1u << 20);
+        const int rc = vlr_dev_slab_alloc(device, cap, &out.d, &out.h);
+        if (rc != VLR_OK) return rc;
+        out.cap = cap;
+        return VLR_OK;
+    }
+    void release(DevSlab& s) {
+        if (!s.d && !s.h) return;
+        std::lock_guard<std::mutex> g(mu);
+        free_list.push_back(s);
+        s = DevSlab();
+    }
+};
+// one pool per device for the whole process: page-locking a slab costs tens of milliseconds, and a caller that opens one reader per
+// file (or per bench step) would pay it again for every table in flight
+std::shared_ptr<DevPool> shared_dev_pool(int device) {
+    static std::mutex mu;
+    static auto* pools = new std::map<int, std::shared_ptr<DevPool>>();   // (never destroyed: no HIP calls during static destruction)
+    std::lock_guard<std::mutex> g(mu);
+    auto& p = (*pools)[device];
+    if (!p) { p = std::make_shared<DevPool>(); p->device = device; }
+    return p;
+}
+// byte offsets of the arrays of a table inside its slab (same on both sides)
+struct DevLayout {
+    size_t off_obs, off_col[9], off_flags, off_third, off_lflags, off_vt, off_ref, off_alt, bytes;
+    static size_t up(size_t x) { return (x + 255) & ~(size_t)255; }
+    DevLayout(int64_t L, int S, uint64_t total) {
+        size_t at = 0;
+        off_obs = at; at = up(at + ((size_t)(L * S) + 1) * 4);
+        for (int k = 0; k < 9; ++k) { off_col[k] = at; at = up(at + (size_t)total * 4); }
+        off_flags = at; at = up(at + (size_t)total * 4);
+        off_third = at; at = up(at + (size_t)total * 4);
+        off_lflags = at; at = up(at + (size_t)L);
+        off_vt = at; at = up(at + (size_t)L);
+        off_ref = at; at = up(at + (size_t)L);
+        off_alt = at; at = up(at + (size_t)L);
+        bytes = at;
+    }
+};
+
 }  // namespace
 
 // ================================================================================================ the observation table
@@ -1141,7 +1200,14 @@ struct vlr_obs_table {
     std::vector<const char*> contig_ptrs;
     std::string pool;
     std::vector<uint64_t> id_off, ref_off, alt_off;
+    // a table of the device reader: every array above points into one page-locked slab, `dev` holds the same layout in device
+    // memory; both go back to the reader's pool when the table is freed
+    std::shared_ptr<DevPool> dev_pool;
+    DevSlab slab;
+    vlr_batch dev_batch;
+    bool has_dev = false;
     ~vlr_obs_table() {
+        if (dev_pool) dev_pool->release(slab);
         Arr* all[] = {&a_off, &a_col[0], &a_col[1], &a_col[2], &a_col[3], &a_col[4], &a_col[5], &a_col[6], &a_col[7], &a_col[8],
                       &a_flags, &a_lflags, &a_vt, &a_ref, &a_alt, &a_third};
         for (Arr* a : all)
@@ -1151,7 +1217,8 @@ struct vlr_obs_table {
     T* make(Arr& a, size_t n) { a.p = table_alloc(n * sizeof(T), a.pinned); return (T*)a.p; }
 };
 
-static int build_table(std::vector<SampleFile>& files, const char* const* paths, uint32_t omit_bias_mask, int n_threads, vlr_obs_table** out);
+static int build_table(std::vector<SampleFile>& files, const char* const* paths, uint32_t omit_bias_mask, int n_threads, vlr_obs_table** out,
+                       const DevLayout* dl = nullptr, std::shared_ptr<DevPool> pool = nullptr, DevSlab* slab = nullptr);
 
 extern "C" {
 
@@ -1181,7 +1248,10 @@ int vlr_obs_read(int n_samples, const char* const* paths, uint32_t omit_bias_mas
 }  // extern "C"
 
 // the decoded chunks of the sample files -> one table in the locus x sample order of vlr_batch
-static int build_table(std::vector<SampleFile>& files, const char* const* paths, uint32_t omit_bias_mask, int n_threads, vlr_obs_table** out) {
+// (dl != nullptr: a table of the device reader — the columns are already in `slab` (device side decoded them, host side copied), only
+// the per-locus arrays and the site data are filled here)
+static int build_table(std::vector<SampleFile>& files, const char* const* paths, uint32_t omit_bias_mask, int n_threads, vlr_obs_table** out,
+                       const DevLayout* dl, std::shared_ptr<DevPool> pool, DevSlab* slab) {
     const int n_samples = (int)files.size();
     const double t_all0 = now_s();
     const double t_merge0 = now_s();
@@ -1203,19 +1273,42 @@ static int build_table(std::vector<SampleFile>& files, const char* const* paths,
             for (uint32_t i = 0; i < c.n_obs.size(); ++i) { loc[(size_t)(l * S + s)] = {&c, i, base}; base += c.n_obs[i]; ++l; }
         }
     }
-    t->obs_offset = t->make<uint32_t>(t->a_off, (size_t)(L * S + 1));
+    if (dl) {
+        t->dev_pool = pool; t->slab = *slab; *slab = DevSlab(); t->has_dev = true;
+        uint8_t* h = (uint8_t*)t->slab.h;
+        t->obs_offset = (uint32_t*)(h + dl->off_obs);
+    } else t->obs_offset = t->make<uint32_t>(t->a_off, (size_t)(L * S + 1));
     uint64_t total = 0;
     for (int64_t p = 0; p < L * S; ++p) { t->obs_offset[p] = (uint32_t)total; total += loc[(size_t)p].c->n_obs[loc[(size_t)p].i]; }
     if (total > 0xffffffffull) return ifail(VLR_ERR_INVALID_ARGUMENT, "more than 2^32 observations in one table");
     t->obs_offset[L * S] = (uint32_t)total;
     t->n_obs = (int64_t)total;
-    for (int k = 0; k < 9; ++k) t->col[k] = t->make<float>(t->a_col[k], (size_t)total);
-    t->flags = t->make<uint32_t>(t->a_flags, (size_t)total);
-    t->third = t->make<int32_t>(t->a_third, (size_t)total);
-    t->locus_flags = t->make<uint8_t>(t->a_lflags, (size_t)L);
-    t->variant_type = t->make<uint8_t>(t->a_vt, (size_t)L);
-    t->ref_base = t->make<uint8_t>(t->a_ref, (size_t)L);
-    t->alt_base = t->make<uint8_t>(t->a_alt, (size_t)L);
+    if (dl) {
+        uint8_t* h = (uint8_t*)t->slab.h;
+        uint8_t* d = (uint8_t*)t->slab.d;
+        for (int k = 0; k < 9; ++k) t->col[k] = (float*)(h + dl->off_col[k]);
+        t->flags = (uint32_t*)(h + dl->off_flags);
+        t->third = (int32_t*)(h + dl->off_third);
+        t->locus_flags = h + dl->off_lflags; t->variant_type = h + dl->off_vt; t->ref_base = h + dl->off_ref; t->alt_base = h + dl->off_alt;
+        vlr_batch& b = t->dev_batch;
+        memset(&b, 0, sizeof b);
+        b.n_loci = L; b.n_samples = S; b.n_obs = (int64_t)total;
+        b.obs_offset = (const uint32_t*)(d + dl->off_obs);
+        b.prob_mapping = (const float*)(d + dl->off_col[0]); b.prob_alt = (const float*)(d + dl->off_col[1]); b.prob_ref = (const float*)(d + dl->off_col[2]);
+        b.prob_missed_allele = (const float*)(d + dl->off_col[3]); b.prob_sample_alt = (const float*)(d + dl->off_col[4]);
+        b.prob_double_overlap = (const float*)(d + dl->off_col[5]); b.prob_hit_base = (const float*)(d + dl->off_col[6]);
+        b.prob_hp_artifact = (const float*)(d + dl->off_col[7]); b.prob_hp_variant = (const float*)(d + dl->off_col[8]);
+        b.flags = (const uint32_t*)(d + dl->off_flags);
+        b.locus_flags = d + dl->off_lflags; b.variant_type = d + dl->off_vt; b.ref_base = d + dl->off_ref; b.alt_base = d + dl->off_alt;
+    } else {
+        for (int k = 0; k < 9; ++k) t->col[k] = t->make<float>(t->a_col[k], (size_t)total);
+        t->flags = t->make<uint32_t>(t->a_flags, (size_t)total);
+        t->third = t->make<int32_t>(t->a_third, (size_t)total);
+        t->locus_flags = t->make<uint8_t>(t->a_lflags, (size_t)L);
+        t->variant_type = t->make<uint8_t>(t->a_vt, (size_t)L);
+        t->ref_base = t->make<uint8_t>(t->a_ref, (size_t)L);
+        t->alt_base = t->make<uint8_t>(t->a_alt, (size_t)L);
+    }
     t->contig.resize((size_t)L); t->pos.resize((size_t)L); t->het.resize((size_t)L); t->som.resize((size_t)L); t->imprecise.resize((size_t)L);
     t->id_off.resize((size_t)L); t->ref_off.resize((size_t)L); t->alt_off.resize((size_t)L); t->hap_rep.resize((size_t)L); t->hap_key.resize((size_t)L);
     // contigs: names of sample 0's file; the other files must name the same contig at every record
@@ -1231,9 +1324,11 @@ static int build_table(std::vector<SampleFile>& files, const char* const* paths,
                 const Loc& x = loc[(size_t)(l * S + s)];
                 const uint32_t n = x.c->n_obs[x.i];
                 const uint32_t dst = t->obs_offset[l * S + s];
-                for (int k = 0; k < 9; ++k) memcpy(t->col[k] + dst, x.c->col[k].data() + x.base, (size_t)n * 4);
-                memcpy(t->flags + dst, x.c->flags.data() + x.base, (size_t)n * 4);
-                memcpy(t->third + dst, x.c->third.data() + x.base, (size_t)n * 4);
+                if (!dl) {
+                    for (int k = 0; k < 9; ++k) memcpy(t->col[k] + dst, x.c->col[k].data() + x.base, (size_t)n * 4);
+                    memcpy(t->flags + dst, x.c->flags.data() + x.base, (size_t)n * 4);
+                    memcpy(t->third + dst, x.c->third.data() + x.base, (size_t)n * 4);
+                }
                 any_hp = any_hp || x.c->is_hp[x.i];
                 if (s > 0) {  // calling.rs:379-390: same site in every sample
                     const std::string& n0 = files[0].contig_names.size() > (size_t)a.c->contig[a.i] && a.c->contig[a.i] >= 0 ? files[0].contig_names[(size_t)a.c->contig[a.i]] : std::string();
@@ -1358,6 +1453,22 @@ int vlr_obs_table_sites(const vlr_obs_table* t, vlr_obs_sites* s) {
 // with the evaluation and emission of the previous one).  Every sample file keeps its position: the BGZF block index, the next
 // block, and the inflated bytes behind the last record it delivered.  All files advance by the same number of records per call.
 namespace {
+// std::vector storage from vlr_host_alloc (page-locked when a device is present)
+template <typename T>
+struct PinnedAlloc {
+    using value_type = T;
+    PinnedAlloc() = default;
+    template <typename U> PinnedAlloc(const PinnedAlloc<U>&) {}
+    T* allocate(size_t n) { void* p = vlr_host_alloc(n * sizeof(T)); if (!p) p = malloc(n * sizeof(T)), tag(p, false); else tag(p, true); if (!p) throw std::bad_alloc(); return (T*)p; }
+    void deallocate(T* p, size_t) { if (was_pinned(p)) vlr_host_free(p); else free(p); }
+    template <typename U> bool operator==(const PinnedAlloc<U>&) const { return true; }
+    template <typename U> bool operator!=(const PinnedAlloc<U>&) const { return false; }
+    static std::mutex& mu() { static std::mutex m; return m; }
+    static std::unordered_set<void*>& set() { static std::unordered_set<void*> s; return s; }
+    static void tag(void* p, bool pinned) { if (p && pinned) { std::lock_guard<std::mutex> g(mu()); set().insert(p); } }
+    static bool was_pinned(void* p) { std::lock_guard<std::mutex> g(mu()); return set().erase(p) != 0; }
+};
+
 struct FileStream {
     std::string path;
     Blob raw;                          // the mapped file
@@ -1505,13 +1616,40 @@ bool stream_next(FileStream& f, int64_t max_records, int n_threads, SampleFile& 
 }
 }  // namespace
 
+// one sample file of the device reader: the compressed file on the host, its inflated records on the device (vlr_decode.hip)
+struct DevFileStream {
+    std::string path;
+    Blob raw;
+    std::vector<BgzfBlock> blocks;
+    size_t next_block = 0;
+    vlr_dev_file* dev = nullptr;
+    Header h;
+    std::vector<int8_t> field_of_key;
+    size_t header_bytes = 0;           // "BCF\2\2" + l_text + text: skipped behind the first members
+    bool header_skipped = false;
+    int n_hdr_samples = 0;
+    double bytes_per_record = 12288.0;
+    int64_t delivered = 0;
+    std::vector<uint8_t, PinnedAlloc<uint8_t>> cold;   // cold records of the current chunk (page-locked: asynchronous D2H)
+    std::vector<uint64_t> cold_off;
+    bool more_blocks() const { return next_block < blocks.size(); }
+    ~DevFileStream() { if (dev) vlr_dev_file_destroy(dev); }
+};
+
 struct vlr_obs_reader {
     std::vector<std::unique_ptr<FileStream>> files;
     std::vector<std::string> paths;
     uint32_t omit = 0;
     int n_threads = 0;
     bool done = false;
+    // device reader (vlr_obs_reader_open_device)
+    bool on_device = false;
+    int device = 0;
+    std::vector<std::unique_ptr<DevFileStream>> dfiles;
+    std::shared_ptr<DevPool> pool;
 };
+
+namespace { int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out); }
 
 extern "C" {
 
@@ -1536,6 +1674,7 @@ int vlr_obs_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** 
     if (!r || !out || max_records < 1) return ifail(VLR_ERR_INVALID_ARGUMENT, "vlr_obs_reader_next: bad argument");
     *out = nullptr;
     if (r->done) return VLR_OK;
+    if (r->on_device) return dev_reader_next(r, max_records, out);
     const int S = (int)r->files.size();
     for (int i = 0; i < 16; ++i) g_ingest_t[i] = 0.0;
     const double t0 = now_s();
@@ -1567,6 +1706,305 @@ int vlr_obs_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** 
 }
 
 void vlr_obs_reader_close(vlr_obs_reader* r) { delete r; }
+
+}  // extern "C"
+
+// ================================================================================================ device reader
+// The same reader with inflate, record split and v15 decode on the device (vlr_inflate.hip, vlr_decode.hip).  This file keeps what
+// is per-file and per-record bookkeeping: the BGZF member index, the BCF header (inflated here: kilobytes), the merge of the sample
+// files into one table, the strings.
+namespace {
+double g_dev_t[16] = {0};
+
+int count_header_samples(const std::string& text) {
+    const size_t p = text.rfind("#CHROM");
+    if (p == std::string::npos) return 0;
+    size_t e = text.find('\n', p);
+    if (e == std::string::npos) e = text.size();
+    int tabs = 0;
+    for (size_t i = p; i < e; ++i) tabs += text[i] == '\t';
+    return tabs >= 9 ? tabs - 8 : 0;  // CHROM POS ID REF ALT QUAL FILTER INFO [FORMAT sample...]
+}
+
+// the BCF header of a BGZF file, inflated on the host from the first members
+int dev_stream_open(DevFileStream& f, const char* path, int device) {
+    f.path = path;
+    std::string err;
+    if (!read_whole_file(path, f.raw, err)) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s", err.c_str());
+    const bool gz = f.raw.size() >= 2 && f.raw[0] == 0x1f && f.raw[1] == 0x8b;
+    if (!gz || !bgzf_index(f.raw, f.blocks)) return ifail(VLR_ERR_UNSUPPORTED, "device reader: %s is not a BGZF file (use vlr_obs_reader_open)", path);
+    std::vector<uint8_t> head;
+    size_t b = 0;
+    size_t need = 9;
+    while (head.size() < need && b < f.blocks.size()) {
+        const BgzfBlock& k = f.blocks[b++];
+        const size_t old = head.size();
+        head.resize(old + k.isize);
+        if (k.isize && !inflate_raw(f.raw.p + k.off, k.clen, head.data() + old, k.isize)) return ifail(VLR_ERR_INVALID_ARGUMENT, "corrupt BGZF block in %s", path);
+        if (head.size() >= 9 && need == 9) {
+            if (memcmp(head.data(), "BCF\2\2", 5) != 0) return ifail(VLR_ERR_UNSUPPORTED, "device reader: %s is not a BCF2 file (use vlr_obs_reader_open)", path);
+            uint32_t l_text;
+            memcpy(&l_text, head.data() + 5, 4);
+            need = 9 + (size_t)l_text;
+        }
+    }
+    if (head.size() < need || need == 9) return ifail(VLR_ERR_INVALID_ARGUMENT, "truncated header in %s", path);
+    std::string text((const char*)head.data() + 9, need - 9);
+    while (!text.empty() && text.back() == '\0') text.pop_back();
+    parse_header(text, f.h);
+    if (!f.h.version_ok) return ifail(VLR_ERR_INVALID_ARGUMENT, "invalid observation format in %s (calling.rs:324-339: varlociraptor_observation_format_version=15 expected)", path);
+    f.header_bytes = need;
+    f.n_hdr_samples = count_header_samples(text);
+    f.field_of_key.assign(f.h.dict.size(), -1);
+    for (size_t i = 0; i < f.h.dict.size(); ++i)
+        for (int k = 0; k < FD_N; ++k)
+            if (f.h.dict[i] == kFieldName[k]) f.field_of_key[i] = (int8_t)k;
+    return vlr_dev_file_create(device, &f.dev);
+}
+
+// members up to `want` buffered bytes onto the device
+int dev_stream_feed(DevFileStream& f, uint64_t want) {
+    while (f.more_blocks() && vlr_dev_file_buffered(f.dev) + (f.header_skipped ? 0 : 0) < want + (f.header_skipped ? 0 : f.header_bytes)) {
+        const uint64_t have = vlr_dev_file_buffered(f.dev);
+        const uint64_t goal = want + (f.header_skipped ? 0 : f.header_bytes);
+        const size_t b0 = f.next_block;
+        size_t b1 = b0;
+        uint64_t add = 0;
+        std::vector<vlr::InflateBlock> ib;
+        while (b1 < f.blocks.size() && (have + add < goal || b1 == b0) && b1 - b0 < (1u << 20)) {
+            const BgzfBlock& k = f.blocks[b1];
+            vlr::InflateBlock x;
+            x.src = k.off - f.blocks[b0].off; x.dst = add; x.clen = (uint32_t)k.clen; x.isize = k.isize;
+            ib.push_back(x);
+            add += k.isize;
+            ++b1;
+        }
+        const uint8_t* comp = f.raw.p + f.blocks[b0].off;
+        const size_t comp_bytes = (f.blocks[b1 - 1].off + f.blocks[b1 - 1].clen) - f.blocks[b0].off;
+        const double t0 = now_s();
+        const int rc = vlr_dev_file_feed(f.dev, comp, comp_bytes, ib.data(), (int)ib.size(), add);
+        g_dev_t[2] += now_s() - t0;
+        g_dev_t[9] += (double)add; g_dev_t[10] += (double)comp_bytes;
+        if (rc != VLR_OK) return rc;
+        f.next_block = b1;
+        if (!f.header_skipped && vlr_dev_file_buffered(f.dev) >= f.header_bytes) {
+            const int rs = vlr_dev_file_skip(f.dev, f.header_bytes);
+            if (rs != VLR_OK) return rs;
+            f.header_skipped = true;
+        }
+    }
+    if (!f.header_skipped) return ifail(VLR_ERR_INVALID_ARGUMENT, "truncated header in %s", f.path.c_str());
+    return VLR_OK;
+}
+
+const char* rec_status_text(uint32_t st) {
+    if (st & vlr::REC_TRUNCATED) return "truncated BCF record";
+    if (st & vlr::REC_BAD_ID) return "bad ID";
+    if (st & vlr::REC_BAD_ALLELE) return "bad allele";
+    if (st & vlr::REC_BAD_FILTER) return "bad FILTER";
+    if (st & vlr::REC_BAD_INFO) return "bad INFO";
+    if (st & vlr::REC_MISSING_FIELD) return "No varlociraptor observations found in record";
+    if (st & vlr::REC_BAD_LENGTHS) return "inconsistent observation vector lengths";
+    return "truncated observation vector";
+}
+
+int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out) {
+    const int S = (int)r->dfiles.size();
+    const double t_all0 = now_s();
+    std::vector<int64_t> n_rec((size_t)S, 0);
+    std::vector<const vlr::RecHost*> rh((size_t)S, nullptr);
+    int64_t n = 0;
+    double scale = 1.0;
+    for (int round = 0;; ++round) {
+        for (int s = 0; s < S; ++s) {
+            DevFileStream& f = *r->dfiles[(size_t)s];
+            const uint64_t want = (uint64_t)((double)max_records * f.bytes_per_record * 1.04 * scale) + 131072;
+            const int rc = dev_stream_feed(f, want);
+            if (rc != VLR_OK) return rc;
+        }
+        const double t0 = now_s();
+        n = max_records;
+        for (int s = 0; s < S; ++s) {
+            DevFileStream& f = *r->dfiles[(size_t)s];
+            int serial = 0;
+            const int rc = vlr_dev_file_split(f.dev, max_records, (int)f.h.contigs.size(), f.n_hdr_samples, f.field_of_key.data(), (int)f.field_of_key.size(), &n_rec[(size_t)s], &rh[(size_t)s], &serial);
+            if (rc != VLR_OK) return rc;
+            if (serial) g_dev_t[12] += 1.0;
+            n = std::min(n, n_rec[(size_t)s]);
+        }
+        g_dev_t[3] += now_s() - t0;
+        if (n > 0) break;
+        bool any_more = false, any_left = false;
+        for (int s = 0; s < S; ++s) { any_more = any_more || r->dfiles[(size_t)s]->more_blocks(); any_left = any_left || vlr_dev_file_buffered(r->dfiles[(size_t)s]->dev) > 0 || n_rec[(size_t)s] > 0; }
+        if (!any_more) {
+            for (int s = 0; s < S; ++s) {
+                if (n_rec[(size_t)s] > 0) return ifail(VLR_ERR_INVALID_ARGUMENT, "inconsistent observations: %s holds more records than the other files (calling.rs:369-371)", r->paths[(size_t)s].c_str());
+                if (vlr_dev_file_buffered(r->dfiles[(size_t)s]->dev) > 0) return ifail(VLR_ERR_INVALID_ARGUMENT, "truncated BCF record in %s", r->paths[(size_t)s].c_str());
+            }
+            (void)any_left;
+            r->done = true;
+            return VLR_OK;
+        }
+        scale *= 2.0;   // a record larger than the request's estimate: buffer more
+        if (round > 40) return ifail(VLR_ERR_INVALID_ARGUMENT, "device reader: record larger than the device buffer in %s", r->paths[0].c_str());
+    }
+    const int64_t L = n;
+    // records with scan errors
+    for (int s = 0; s < S; ++s)
+        for (int64_t i = 0; i < L; ++i)
+            if (rh[(size_t)s][i].status) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s (record %lld of %s)", rec_status_text(rh[(size_t)s][i].status), (long long)(r->dfiles[(size_t)s]->delivered + i + 1), r->paths[(size_t)s].c_str());
+    // merged observation offsets: pileup p = locus * S + sample
+    uint64_t total = 0;
+    std::vector<uint32_t> obs_offset((size_t)(L * S) + 1);
+    for (int64_t l = 0; l < L; ++l)
+        for (int s = 0; s < S; ++s) { obs_offset[(size_t)(l * S + s)] = (uint32_t)total; total += rh[(size_t)s][l].n_obs; }
+    if (total > 0xffffffffull) return ifail(VLR_ERR_INVALID_ARGUMENT, "more than 2^32 observations in one table");
+    obs_offset[(size_t)(L * S)] = (uint32_t)total;
+    const DevLayout dl(L, S, total);
+    DevSlab slab;
+    {
+        const int rc = r->pool->acquire(dl.bytes, slab);
+        if (rc != VLR_OK) return rc;
+    }
+    uint8_t* d = (uint8_t*)slab.d;
+    uint8_t* h = (uint8_t*)slab.h;
+    auto fail = [&](int rc) { r->pool->release(slab); return rc; };
+    const double t_dec0 = now_s();
+    {   // offsets up (every decode kernel reads them), then the files side by side on their own streams
+        DevFileStream& f0 = *r->dfiles[0];
+        int rc = vlr_dev_file_copy(f0.dev, d + dl.off_obs, obs_offset.data(), obs_offset.size() * 4, 1);
+        if (rc == VLR_OK) rc = vlr_dev_file_sync(f0.dev);
+        if (rc != VLR_OK) return fail(rc);
+    }
+    vlr::DeviceCols cols;
+    for (int k = 0; k < 9; ++k) cols.col[k] = (float*)(d + dl.off_col[k]);
+    cols.flags = (uint32_t*)(d + dl.off_flags);
+    cols.third = (int32_t*)(d + dl.off_third);
+    for (int s = 0; s < S; ++s) {
+        DevFileStream& f = *r->dfiles[(size_t)s];
+        int rc = vlr_dev_file_decode(f.dev, L, (const uint32_t*)(d + dl.off_obs), S, s, &cols);
+        if (rc != VLR_OK) return fail(rc);
+        f.cold_off.resize((size_t)L + 1);
+        uint64_t at = 0;
+        for (int64_t i = 0; i < L; ++i) { f.cold_off[(size_t)i] = at; at += rh[(size_t)s][i].cold_bytes; }
+        f.cold_off[(size_t)L] = at;
+        f.cold.resize((size_t)at + 64);
+        rc = vlr_dev_file_cold(f.dev, L, f.cold_off.data(), f.cold.data());
+        if (rc != VLR_OK) return fail(rc);
+    }
+    // the per-record flags the table needs from the scan (before the decode's error pass overwrites the host copy)
+    std::vector<std::vector<uint32_t>> n_obs_of((size_t)S), flags_of((size_t)S);
+    for (int s = 0; s < S; ++s) {
+        n_obs_of[(size_t)s].resize((size_t)L); flags_of[(size_t)s].resize((size_t)L);
+        for (int64_t i = 0; i < L; ++i) { n_obs_of[(size_t)s][(size_t)i] = rh[(size_t)s][i].n_obs; flags_of[(size_t)s][(size_t)i] = rh[(size_t)s][i].flags; }
+    }
+    for (int s = 0; s < S; ++s) {
+        uint32_t st = 0;
+        int64_t bad = -1;
+        const int rc = vlr_dev_file_errors(r->dfiles[(size_t)s]->dev, L, &st, &bad);   // (waits for the file's stream)
+        if (rc != VLR_OK) return fail(rc);
+        if (st) return fail(ifail(VLR_ERR_INVALID_ARGUMENT, "%s (record %lld of %s)", rec_status_text(st), (long long)(r->dfiles[(size_t)s]->delivered + bad + 1), r->paths[(size_t)s].c_str()));
+    }
+    g_dev_t[5] += now_s() - t_dec0;
+    const double t_d2h0 = now_s();
+    {   // columns down for the calls writer (one copy: the column arrays are contiguous in the slab)
+        DevFileStream& f0 = *r->dfiles[0];
+        const int rc = vlr_dev_file_copy(f0.dev, h + dl.off_col[0], d + dl.off_col[0], dl.off_lflags - dl.off_col[0], 0);
+        if (rc != VLR_OK) return fail(rc);
+    }
+    // ---- host side, while the columns come down: the cold records -> chunks -> table
+    const double t_host0 = now_s();
+    std::vector<SampleFile> files((size_t)S);
+    std::vector<std::string> errs((size_t)S);
+    for (int s = 0; s < S; ++s) {
+        DevFileStream& f = *r->dfiles[(size_t)s];
+        SampleFile& sf = files[(size_t)s];
+        sf.n_rec = L;
+        sf.contig_names = f.h.contigs;
+        const int T = (int)std::max<int64_t>(1, std::min<int64_t>(r->n_threads, (L + 1023) / 1024));
+        sf.chunks = std::vector<Chunk>((size_t)T);
+        parallel_ranges(L, T, [&](int64_t b, int64_t e, int t) {
+            Chunk& c = sf.chunks[(size_t)t];
+            RecView rv;
+            for (int64_t i = b; i < e && c.error.empty(); ++i) {
+                rv.reset();
+                std::string er;
+                const uint8_t* p = f.cold.data() + f.cold_off[(size_t)i];
+                const uint8_t* pe = f.cold.data() + f.cold_off[(size_t)i + 1];
+                bool ok = parse_bcf_record(p, pe, f.field_of_key, rv, er);
+                ok = ok && push_cold(rv, c, n_obs_of[(size_t)s][(size_t)i], (flags_of[(size_t)s][(size_t)i] & 1u) != 0, er);
+                if (!ok) c.error = er + " (record " + std::to_string(f.delivered + i + 1) + " of " + f.path + ")";
+            }
+        });
+        for (auto& c : sf.chunks)
+            if (!c.error.empty()) return fail(ifail(VLR_ERR_INVALID_ARGUMENT, "%s", c.error.c_str()));
+    }
+    std::vector<const char*> pp;
+    for (auto& p : r->paths) pp.push_back(p.c_str());
+    // (build_table writes obs_offset and the per-locus arrays into the host side of the slab)
+    int rc = build_table(files, pp.data(), r->omit, r->n_threads, out, &dl, r->pool, &slab);
+    if (rc != VLR_OK) { if (slab.d) r->pool->release(slab); return rc; }
+    g_dev_t[7] += now_s() - t_host0;
+    {
+        DevFileStream& f0 = *r->dfiles[0];
+        vlr_obs_table* t = *out;
+        rc = vlr_dev_file_copy(f0.dev, (uint8_t*)t->slab.d + dl.off_lflags, (uint8_t*)t->slab.h + dl.off_lflags, dl.bytes - dl.off_lflags, 1);
+        if (rc == VLR_OK) rc = vlr_dev_file_sync(f0.dev);
+        if (rc != VLR_OK) { vlr_obs_table_free(t); *out = nullptr; return rc; }
+    }
+    g_dev_t[6] += now_s() - t_d2h0;
+    for (int s = 0; s < S; ++s) {
+        DevFileStream& f = *r->dfiles[(size_t)s];
+        rc = vlr_dev_file_consume(f.dev, L);
+        if (rc != VLR_OK) { vlr_obs_table_free(*out); *out = nullptr; return rc; }
+        f.delivered += L;
+    }
+    // bytes per record of this chunk (the next request's feed size)
+    for (int s = 0; s < S; ++s) {
+        DevFileStream& f = *r->dfiles[(size_t)s];
+        uint64_t cb = 0;
+        for (int64_t i = 0; i < L; ++i) cb += n_obs_of[(size_t)s][(size_t)i];
+        const double est = 160.0 + 113.0 * (double)cb / (double)L;   // (a v15 observation takes ~113 bytes of an uncompressed record)
+        f.bytes_per_record = 0.5 * f.bytes_per_record + 0.5 * est;
+    }
+    g_dev_t[8] += now_s() - t_all0;
+    g_dev_t[11] += (double)L;
+    return VLR_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int vlr_obs_reader_open_device(int device, int n_samples, const char* const* paths, uint32_t omit_bias_mask, int n_threads, vlr_obs_reader** out) {
+    if (!out || !paths || n_samples < 1 || n_samples > VLR_MAX_SAMPLES) return ifail(VLR_ERR_INVALID_ARGUMENT, "vlr_obs_reader_open_device: bad argument");
+    *out = nullptr;
+    std::unique_ptr<vlr_obs_reader> r(new vlr_obs_reader());
+    r->omit = omit_bias_mask;
+    r->n_threads = pick_threads(n_threads);
+    r->on_device = true;
+    r->device = device;
+    r->pool = shared_dev_pool(device);
+    for (int s = 0; s < n_samples; ++s) {
+        r->paths.push_back(paths[s]);
+        r->dfiles.emplace_back(new DevFileStream());
+        const int rc = dev_stream_open(*r->dfiles.back(), paths[s], device);
+        if (rc != VLR_OK) return rc;
+    }
+    *out = r.release();
+    return VLR_OK;
+}
+
+int vlr_obs_table_device_batch(const vlr_obs_table* t, vlr_batch* b) {
+    if (!t || !b) return ifail(VLR_ERR_INVALID_ARGUMENT, "null argument");
+    if (!t->has_dev) return ifail(VLR_ERR_INVALID_ARGUMENT, "vlr_obs_table_device_batch: the table was not read by a device reader");
+    *b = t->dev_batch;
+    return VLR_OK;
+}
+
+void vlr_ingest_device_timings(double* out16, int reset) {
+    if (out16) for (int i = 0; i < 16; ++i) out16[i] = g_dev_t[i];
+    if (reset) for (int i = 0; i < 16; ++i) g_dev_t[i] = 0.0;
+}
 
 }  // extern "C"
 

@@ -104,6 +104,7 @@ class ObsTable:
         _check(_lib().vlr_obs_table_batch(handle, C.byref(b)))
         self.n_loci, self.n_samples, self.n_obs = int(b.n_loci), int(b.n_samples), int(b.n_obs)
         self._struct = b
+        self.on_device = False   # set by a device reader: device_batch() holds the same batch in device memory
 
     def batch(self) -> PileupBatch:
         b = self._struct
@@ -112,6 +113,15 @@ class ObsTable:
         pb = PileupBatch(self.n_samples, _view(b.obs_offset, self.n_loci * self.n_samples + 1, np.uint32), cols, locus)
         pb._table = self  # the views live as long as the table
         return pb
+
+    def device_batch(self) -> "abi.Batch":
+        """vlr_obs_table_device_batch: the same batch in device memory (tables of a device reader only) — what vlr_batch_run takes."""
+        b = abi.Batch()
+        L = _lib()
+        L.vlr_obs_table_device_batch.restype = C.c_int
+        L.vlr_obs_table_device_batch.argtypes = [C.c_void_p, C.POINTER(abi.Batch)]
+        _check(L.vlr_obs_table_device_batch(self.handle, C.byref(b)))
+        return b
 
     def close(self):
         if self.handle:
@@ -154,26 +164,65 @@ def total_timings(reset: bool = False) -> dict:
     return {n: a[i] for i, n in enumerate(k) if n}
 
 
+def bgzf_inflate(data: bytes, device: int = 0) -> bytes:
+    """vlr_bgzf_inflate: a sequence of BGZF members inflated by the device kernel (csrc/vlr_inflate.hip)."""
+    L = _lib()
+    L.vlr_bgzf_inflate.restype = C.c_int
+    L.vlr_bgzf_inflate.argtypes = [C.c_int, C.c_char_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    n = C.c_int64(0)
+    # first call sizes the output (ISIZE sum), second fills it
+    rc = L.vlr_bgzf_inflate(int(device), data, len(data), None, 0, C.byref(n))
+    if n.value == 0:
+        _check(rc)
+        return b""
+    out = np.empty(n.value, np.uint8)
+    _check(L.vlr_bgzf_inflate(int(device), data, len(data), out.ctypes.data, n.value, C.byref(n)))
+    return out.tobytes()
+
+
+def device_timings(reset: bool = False) -> dict:
+    """Stage times of the device reader summed since the last reset (vlr_ingest_device_timings)."""
+    a = (C.c_double * 16)()
+    L = _lib()
+    L.vlr_ingest_device_timings.restype = None
+    L.vlr_ingest_device_timings.argtypes = [C.POINTER(C.c_double), C.c_int]
+    L.vlr_ingest_device_timings(a, int(reset))
+    k = [None, None, "feed_inflate", "split_scan", None, "decode", "copy_back", "host_table", "total", "inflated_bytes", "compressed_bytes", "records", "serial_walks"]
+    return {n: a[i] for i, n in enumerate(k) if n}
+
+
 class ObsReader:
     """vlr_obs_reader: the observation files a bounded number of records at a time.  Iterating yields (PileupBatch, Sites)."""
 
-    def __init__(self, paths: Sequence[str], omit_bias_mask: int = 0, threads: int = 0, chunk_records: int = 250_000):
+    def __init__(self, paths: Sequence[str], omit_bias_mask: int = 0, threads: int = 0, chunk_records: int = 250_000, device: Optional[int] = None):
+        """device = None: the host reader.  device = k: vlr_obs_reader_open_device — BGZF inflate, record split and v15 decode as kernels on
+        device k; the tables then also hold the batch in device memory (ObsTable.device_batch)."""
         L = _lib()
         L.vlr_obs_reader_open.restype = C.c_int
         L.vlr_obs_reader_open.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
+        L.vlr_obs_reader_open_device.restype = C.c_int
+        L.vlr_obs_reader_open_device.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_char_p), C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
+        self.device = device
         L.vlr_obs_reader_next.restype = C.c_int
         L.vlr_obs_reader_next.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
         L.vlr_obs_reader_close.restype = None
         L.vlr_obs_reader_close.argtypes = [C.c_void_p]
         arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
         h = C.c_void_p()
-        _check(L.vlr_obs_reader_open(len(paths), arr, int(omit_bias_mask), int(threads), C.byref(h)))
+        if device is None:
+            _check(L.vlr_obs_reader_open(len(paths), arr, int(omit_bias_mask), int(threads), C.byref(h)))
+        else:
+            _check(L.vlr_obs_reader_open_device(int(device), len(paths), arr, int(omit_bias_mask), int(threads), C.byref(h)))
         self._h, self.chunk_records = h, int(chunk_records)
 
     def next(self, max_records: Optional[int] = None):
         h = C.c_void_p()
         _check(_lib().vlr_obs_reader_next(self._h, int(max_records or self.chunk_records), C.byref(h)))
-        return _wrap_table(h) if h.value else None
+        if not h.value:
+            return None
+        item = _wrap_table(h)
+        item[0].extra["native_table"].on_device = self.device is not None
+        return item
 
     def __iter__(self):
         while True:
