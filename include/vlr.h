@@ -519,6 +519,13 @@ void vlr_ingest_total_timings(double* out16, int reset);
  * SROBS / OBS from), both complete when vlr_obs_reader_next returns.  CRC32 of the members is not checked on this path. */
 int  vlr_obs_reader_open_device(int device, int n_samples, const char* const* paths, uint32_t omit_bias_mask, int n_threads, vlr_obs_reader** out);
 int  vlr_obs_table_device_batch(const vlr_obs_table* table, vlr_batch* out);  /* VLR_ERR_INVALID_ARGUMENT for a table of a host reader */
+/* keep == 0: the tables of this device reader do not bring the observation columns down to the host; instead a kernel counts per
+ * pileup what the calls writer formats from them (distinct observation keys, Kass-Raftery letters, prob_mapping runs: the OBS / SAOBS /
+ * SROBS / DP fields) and only those summaries cross PCIe.  The observation arrays of vlr_obs_table_batch and
+ * vlr_obs_sites.third_allele_evidence are then NOT filled until vlr_obs_table_fetch_columns copies them on demand (the writer does
+ * that itself where it has to).  Default: keep. */
+int  vlr_obs_reader_set_host_columns(vlr_obs_reader* reader, int keep);
+int  vlr_obs_table_fetch_columns(vlr_obs_table* table);
 /* The inflate stage alone, host buffers in and out (tests, tools): `bgzf` is a sequence of BGZF members (SAM spec 4.1), *out_bytes
  * receives the sum of their ISIZE fields (also when out_capacity is too small: VLR_ERR_INVALID_ARGUMENT then). */
 int  vlr_bgzf_inflate(int device, const void* bgzf, int64_t n_bytes, void* out, int64_t out_capacity, int64_t* out_bytes);

@@ -233,3 +233,70 @@ def test_device_reader_refuses_what_it_does_not_read(tmp_path, golden_dir):
     open(cut, "wb").write(raw[:offs[len(offs) // 2]])
     with pytest.raises(engine.EngineError, match="truncated"):
         _read_all([cut], 0, 1 << 20)
+
+
+@pytest.mark.parametrize("name", ["config3", "config5"])
+def test_writer_from_device_summaries_equals_writer_from_columns(name, tmp_path):
+    """host_columns=False: the observation columns stay in device memory, obs_summary_kernel counts per pileup what the calls writer
+    formats (OBS / SAOBS / SROBS / DP) and the writer works from those summaries.  The file must be the one written from the columns —
+    text VCF, so every character is compared — and fetch_columns must deliver the host reader's columns."""
+    from varlociraptor_amd import callsfmt
+    cfg = synth.CONFIGS[name]()
+    b = synth.generate(cfg, 3000, seed=37)
+    third = np.where(np.arange(b.n_obs) % 3 == 0, np.arange(b.n_obs) % 6, -1).astype(np.int32)
+    paths = []
+    for s in range(b.n_samples):
+        p = str(tmp_path / ("%s_%d.bcf" % (name, s)))
+        ingest.write_observations(p, b, s, third_allele_evidence=third)
+        paths.append(p)
+    (hb, hsites), = _read_all(paths, None, 1 << 20)
+    rd = ingest.ObsReader(paths, chunk_records=1 << 20, device=0, host_columns=False)
+    db, dsites = rd.next()
+    table = db.extra["native_table"]
+    plan = engine.Plan(cfg.scenario, device=0)
+    res = plan.call_table_device(table, afd_capacity=24)
+    names = cfg.scenario.out_names()
+    header = callsfmt.header(names, cfg.scenario.sample_names, list(dsites.contig_names))
+    a, c = str(tmp_path / "from_summaries.vcf"), str(tmp_path / "from_columns.vcf")
+    ingest.write_calls(a, header, table, res, names)
+    table.fetch_columns()
+    ingest.write_calls(c, header, table, res, names)
+    ta, tc = open(a).read(), open(c).read()
+    assert ta == tc
+    assert ta.count("\n") > b.n_loci
+    _tables_equal(hb, hsites, db, dsites)
+    # and the host reader's table gives the same file
+    ref = plan.call_host(hb, afd_capacity=24)
+    h = str(tmp_path / "host.vcf")
+    ingest.write_calls(h, header, hb.extra["native_table"], ref, names)
+    assert open(h).read() == ta
+    rd.close()
+    plan.close()
+
+
+def test_device_reader_records_larger_than_a_segment_and_tiny_files(tmp_path):
+    """Records of 0.2 to 2 MB (pileups of thousands of observations) span many 64 KiB segments of the inflated stream: segments
+    without any record start, anchors found far behind the boundary; plus the degenerate files (no record, one record)."""
+    base = synth.config3()
+    deep = synth.config3()
+    deep.depth, deep.max_depth = 6000.0, 20000
+    b = synth.generate(deep, 9, seed=5)
+    assert b.n_obs > 50000
+    for name, batch in (("deep", b), ("one", synth.generate(base, 1, seed=6)), ("none", synth.generate(base, 4, seed=7).select(np.arange(0)))):
+        paths = []
+        for s in range(batch.n_samples):
+            p = str(tmp_path / ("%s_%d.bcf" % (name, s)))
+            ingest.write_observations(p, batch, s)
+            paths.append(p)
+        host = _read_all(paths, None, 1 << 20)
+        for chunk in (1 << 20, 2):
+            dev = _read_all(paths, 0, chunk)
+            _concat_check(host, dev)
+    # mixed: deep records between ordinary ones, several requests
+    mix = synth.generate(base, 400, seed=8)
+    paths = []
+    for s in range(mix.n_samples):
+        p = str(tmp_path / ("mix_%d.bcf" % s))
+        ingest.write_observations(p, mix, s)
+        paths.append(p)
+    _concat_check(_read_all(paths, None, 1 << 20), _read_all(paths, 0, 37))

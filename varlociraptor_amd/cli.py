@@ -322,6 +322,9 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                     buf = result_pool.results(L, n_out_, S_, afd_capacity) if result_pool is not None else None
                     r = plan.call_table_device(table, afd_capacity=afd_capacity, results=buf)
                 else:
+                    if table is not None and getattr(table, "on_device", False):
+                        table.fetch_columns()   # (several models in one chunk: the sub-batches are cut from the host columns)
+                        sub = batch if len(mine) == L else batch.select(mine)
                     r = plan.call_host(sub, afd_capacity=afd_capacity)
             else:
                 r = CallResults(0, n_out_, S_, afd_capacity)
@@ -390,7 +393,12 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
             # cross PCIe, the columns are born in device memory and the evaluation reads them there.  Files it does not read (plain
             # gzip, uncompressed BCF) go to the host reader.
             try:
-                reader = vingest.ObsReader(paths, omit_bias_mask=omit_mask, chunk_records=int(os.environ.get("VLR_CLI_CHUNK", "0")) or 32768, device=device)
+                big = sum(os.path.getsize(p_) for p_ in paths) > (1 << 30)   # (chunks bound the pipeline's fill and drain: smaller for small files)
+                reader = vingest.ObsReader(paths, omit_bias_mask=omit_mask, chunk_records=int(os.environ.get("VLR_CLI_CHUNK", "0")) or (32768 if big else 16384), device=device,
+                                           # VLR_INGEST_SUMMARIES=1: the observation columns stay on the device and the calls writer formats from per-pileup
+                                           # summaries (vlr_obs_reader_set_host_columns; pays off when pileups have few distinct observation keys — the
+                                           # synthetic bench pileups have almost one per observation and fall back to the columns)
+                                           host_columns=(processor is not None or candidate_filter is not None or os.environ.get("VLR_INGEST_SUMMARIES", "0") != "1"))
             except engine.EngineError as ex:
                 if ex.code != abi.ERR_UNSUPPORTED:
                     raise

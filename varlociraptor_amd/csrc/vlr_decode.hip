@@ -464,6 +464,125 @@ __global__ __launch_bounds__(64) void rec_cold_kernel(const uint8_t* __restrict_
     }
 }
 
+// ---- observation summaries for the calls writer: one lane per pileup, the host's per-observation loop (sample_fields) as it stands
+__device__ __forceinline__ bool d_relative_eq(double a, double b, double eps) {
+    if (a == b) return true;
+    if (isinf(a) || isinf(b)) return false;
+    const double d = fabs(a - b);
+    return d <= eps || d <= fmax(fabs(a), fabs(b)) * eps;
+}
+__device__ __forceinline__ uint32_t d_kr_letter(double bf, double eps) {  // utils/mod.rs:158-167
+    if (bf <= 1.0) return d_relative_eq(bf, 1.0, eps) ? 'E' : 'N';
+    if (bf <= 3.0) return 'B';
+    if (bf <= 20.0) return 'P';
+    if (bf <= 150.0) return 'S';
+    return 'V';
+}
+__device__ __forceinline__ uint32_t d_lower(uint32_t c) { return (c >= 'A' && c <= 'Z') ? c + 32u : c; }
+
+__global__ void obs_summary_kernel(DeviceCols cols, const uint32_t* __restrict__ obs_offset, const uint8_t* __restrict__ locus_flags, int64_t n_pileups, int n_samples,
+                                   SumConsts K, PileSum* __restrict__ hdr, uint64_t* __restrict__ ent_key, uint32_t* __restrict__ ent_cnt,
+                                   float* __restrict__ run_pm, uint32_t* __restrict__ run_len, uint32_t* __restrict__ cursor) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pileups) return;
+    const uint32_t b = obs_offset[p], e = obs_offset[p + 1];
+    const bool drop_nonstd = (locus_flags[p / n_samples] & VLR_LOCUS_REMOVE_NONSTANDARD) != 0;   // pileup.rs:26-43
+    uint64_t keys[kSumMaxKeys];
+    uint32_t cnts[kSumMaxKeys];
+    uint32_t nk = 0, kept = 0, n_run = 0, overflow = 0;
+    PileSum h;
+    h.alt_n = 0; h.ref_n = 0; h.pad[0] = h.pad[1] = 0;
+    for (int i = 0; i < kSumLetters; ++i) { h.alt_letter[i] = 0; h.ref_letter[i] = 0; h.alt_cnt[i] = 0; h.ref_cnt[i] = 0; }
+    // the runs go straight to the bump array: reserve the worst case (one run per observation) only when a second run appears —
+    // first count them
+    {
+        float last = 0.0f;
+        bool have = false;
+        for (uint32_t i = b; i < e; ++i) {
+            const uint32_t f = cols.flags[i];
+            if (drop_nonstd && ((f >> VLR_F_ORIENT_SHIFT) & 3u) == VLR_ORIENT_OTHER) continue;
+            const float pm = cols.col[0][i];
+            const bool same = have && pm == last;   // (exactly the test of the second pass: the reservation must match what it writes)
+            if (!same) { n_run += 1; last = pm; have = true; }
+        }
+    }
+    const uint32_t run_off = n_run ? atomicAdd(&cursor[1], n_run) : 0u;
+    uint32_t r_at = 0, r_len = 0;
+    float r_pm = 0.0f;
+    bool r_have = false;
+    for (uint32_t i = b; i < e; ++i) {
+        const uint32_t f = cols.flags[i];
+        const uint32_t orient = (f >> VLR_F_ORIENT_SHIFT) & 3u;
+        if (drop_nonstd && orient == VLR_ORIENT_OTHER) continue;
+        kept += 1;
+        const float pmf = cols.col[0][i];
+        {   // (the host compares doubles converted from these floats: pm != last_pm — NaN starts a run every time there, and here)
+            const bool same = r_have && pmf == r_pm;
+            if (!same) {
+                if (r_have) { run_pm[run_off + r_at] = r_pm; run_len[run_off + r_at] = r_len; r_at += 1; }
+                r_pm = pmf; r_len = 0; r_have = true;
+            }
+            r_len += 1;
+        }
+        const double pa = (double)cols.col[1][i], pr = (double)cols.col[2][i];
+        const double d = pa - pr;
+        double bf_alt, bf_ref;
+        uint32_t kl_alt, kl_ref;
+        if (fabs(d) >= 1e-15 && fabs(d) < 700.0) {
+            const double ad = fabs(d);
+            const uint32_t k = ad <= K.ln3 ? 'B' : ad <= K.ln20 ? 'P' : ad <= K.ln150 ? 'S' : 'V';
+            bf_alt = d > 0 ? 2.0 : 0.5; bf_ref = d > 0 ? 0.5 : 2.0;
+            kl_alt = d > 0 ? k : 'N'; kl_ref = d > 0 ? 'N' : k;
+        } else if (fabs(d) >= 700.0) {
+            // exp(+-d) is 0 / inf or 1e-304 / 1e304: the order and the letters of the host's exponentials
+            bf_alt = d > 0 ? 2.0 : 0.5; bf_ref = d > 0 ? 0.5 : 2.0;
+            kl_alt = d > 0 ? 'V' : 'N'; kl_ref = d > 0 ? 'N' : 'V';
+        } else {
+            // |d| < 1e-15 (or NaN): exp(d) = 1 + d rounded to nearest (the next term is below 1e-30)
+            bf_alt = 1.0 + d; bf_ref = 1.0 - d;
+            kl_alt = d_kr_letter(bf_alt, K.eps); kl_ref = d_kr_letter(bf_ref, K.eps);
+        }
+        const bool maxq = (f & VLR_F_MAX_MAPQ) != 0;
+        uint32_t s0, s1 = 0;
+        if (bf_alt > bf_ref) { s0 = 'A'; s1 = kl_alt; }
+        else if (bf_ref > bf_alt) { s0 = 'R'; s1 = kl_ref; }
+        else s0 = 'E';
+        if (!maxq) { s0 = d_lower(s0); if (s1) s1 = d_lower(s1); }
+        const uint32_t strand = (f >> VLR_F_STRAND_SHIFT) & 3u, altloc = (f >> VLR_F_ALTLOCUS_SHIFT) & 3u;
+        const bool hp_err = (f & VLR_F_HP_LEN_VALID) && ((f >> VLR_F_HP_LEN_SHIFT) & 0xffu) != 0;
+        const uint64_t key = (uint64_t)s0 | ((uint64_t)s1 << 8) | ((uint64_t)((f & VLR_F_PAIRED) ? 1 : 0) << 16) |
+                             ((uint64_t)(altloc > 2 ? 2 : altloc) << 17) | ((uint64_t)strand << 19) | ((uint64_t)orient << 21) |
+                             ((uint64_t)((f & VLR_F_READPOS_MAJOR) ? 1 : 0) << 23) | ((uint64_t)((f & VLR_F_SOFTCLIPPED) ? 1 : 0) << 24) |
+                             ((uint64_t)(hp_err ? 1 : 0) << 25) | ((uint64_t)(uint32_t)(cols.third[i] + 1) << 32);
+        if (!overflow) {
+            uint32_t k = 0;
+            while (k < nk && keys[k] != key) ++k;
+            if (k == nk) {
+                if (nk == kSumMaxKeys) overflow = 1;
+                else { keys[nk] = key; cnts[nk] = 1; nk += 1; }
+            } else cnts[k] += 1;
+        }
+        {
+            const bool to_alt = pa > pr;
+            const uint32_t c0 = to_alt ? kl_alt : kl_ref;
+            const uint8_t c = (uint8_t)(maxq ? c0 : d_lower(c0));
+            uint8_t* letters = to_alt ? h.alt_letter : h.ref_letter;
+            uint32_t* lc = to_alt ? h.alt_cnt : h.ref_cnt;
+            uint8_t& n = to_alt ? h.alt_n : h.ref_n;
+            uint32_t q = 0;
+            while (q < n && letters[q] != c) ++q;
+            if (q == n) { if (n < kSumLetters) { letters[n] = c; lc[n] = 1; n += 1; } else overflow = 1; }
+            else lc[q] += 1;
+        }
+    }
+    if (r_have) { run_pm[run_off + r_at] = r_pm; run_len[run_off + r_at] = r_len; r_at += 1; }
+    const uint32_t ent_off = (nk && !overflow) ? atomicAdd(&cursor[0], nk) : 0u;
+    if (!overflow)
+        for (uint32_t k = 0; k < nk; ++k) { ent_key[ent_off + k] = keys[k]; ent_cnt[ent_off + k] = cnts[k]; }
+    h.ent_off = ent_off; h.n_ent = overflow ? 0u : nk; h.run_off = run_off; h.n_run = r_at; h.kept = kept; h.overflow = overflow;
+    hdr[p] = h;
+}
+
 }  // namespace
 }  // namespace vlr
 
@@ -471,6 +590,8 @@ __global__ __launch_bounds__(64) void rec_cold_kernel(const uint8_t* __restrict_
 struct vlr_dev_file {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t feed_stream = nullptr;   // H2D of compressed members + inflate kernel: runs beside the decode of the previous chunk
+    bool feed_pending = false;
     uint8_t* buf = nullptr;       // inflated stream: bytes [rd, wr) are buffered
     size_t cap = 0, rd = 0, wr = 0;
     uint8_t* spare = nullptr;     // the other half of the ping-pong (compaction never copies inside one allocation)
@@ -512,7 +633,7 @@ int vlr_dev_file_create(int device, vlr_dev_file** out) {
     VLR_HIP_OK(hipSetDevice(device));
     vlr_dev_file* f = new vlr_dev_file();
     f->device = device;
-    if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) { delete f; return dfail(VLR_ERR_HIP, "hipStreamCreate failed"); }
+    if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&f->feed_stream, hipStreamNonBlocking) != hipSuccess) { delete f; return dfail(VLR_ERR_HIP, "hipStreamCreate failed"); }
     if (hipMalloc(&f->d_nout, 8) != hipSuccess) { (void)hipStreamDestroy(f->stream); delete f; return dfail(VLR_ERR_OUT_OF_MEMORY, "device reader: out of device memory"); }
     *out = f;
     return VLR_OK;
@@ -521,6 +642,7 @@ int vlr_dev_file_create(int device, vlr_dev_file** out) {
 void vlr_dev_file_destroy(vlr_dev_file* f) {
     if (!f) return;
     (void)hipSetDevice(f->device);
+    if (f->feed_stream) { (void)hipStreamSynchronize(f->feed_stream); (void)hipStreamDestroy(f->feed_stream); }
     if (f->stream) { (void)hipStreamSynchronize(f->stream); (void)hipStreamDestroy(f->stream); }
     void* all[] = {f->buf, f->spare, f->d_comp, f->d_blocks, f->d_status, f->d_anchor, f->d_landing, f->d_segbase, f->d_count, f->d_landc, f->d_starts, f->d_nout,
                    f->d_desc, f->d_host, f->d_fok, f->d_cold_off, f->d_cold};
@@ -534,26 +656,30 @@ uint64_t vlr_dev_file_buffered(const vlr_dev_file* f) { return f ? (uint64_t)(f-
 void* vlr_dev_file_stream(vlr_dev_file* f) { return f ? (void*)f->stream : nullptr; }
 int vlr_dev_file_sync(vlr_dev_file* f) { VLR_HIP_OK(hipSetDevice(f->device)); VLR_HIP_OK(hipStreamSynchronize(f->stream)); return VLR_OK; }
 
+// Enqueue on the feed stream: compressed members up, inflate behind the buffered bytes.  `comp` and `blocks` must stay valid until
+// vlr_dev_file_feed_wait.  The buffered bytes [rd, wr) are only read by kernels already enqueued on the decode stream: compaction
+// copies them into the other allocation (never inside one), so the feed may run beside those kernels.
 int vlr_dev_file_feed(vlr_dev_file* f, const uint8_t* comp, size_t comp_bytes, const vlr::InflateBlock* blocks, int n_blocks, uint64_t inflated_bytes) {
     if (!f || n_blocks <= 0) return VLR_OK;
     VLR_HIP_OK(hipSetDevice(f->device));
+    if (f->feed_pending) { const int rc = vlr_dev_file_feed_wait(f); if (rc != VLR_OK) return rc; }
+    hipStream_t st = f->feed_stream;
     const size_t live = f->wr - f->rd;
     if (f->wr + inflated_bytes + 64 > f->cap) {   // compact into the other buffer (grown if needed)
         const size_t need = live + (size_t)inflated_bytes + 64;
         if (need > f->spare_cap) {
-            VLR_HIP_OK(hipStreamSynchronize(f->stream));
+            VLR_HIP_OK(hipStreamSynchronize(f->stream));   // (kernels of two chunks ago may still read the allocation that is replaced)
             if (f->spare) (void)hipFree(f->spare);
             f->spare = nullptr; f->spare_cap = 0;
             const size_t ncap = need + need / 4 + (1u << 20);
             if (hipMalloc(&f->spare, ncap) != hipSuccess) return dfail(VLR_ERR_OUT_OF_MEMORY, "device reader: out of device memory (%s%lld bytes)", "", (long long)ncap);
             f->spare_cap = ncap;
         }
-        if (live) VLR_HIP_OK(hipMemcpyAsync(f->spare, f->buf + f->rd, live, hipMemcpyDeviceToDevice, f->stream));
+        if (live) VLR_HIP_OK(hipMemcpyAsync(f->spare, f->buf + f->rd, live, hipMemcpyDeviceToDevice, st));
         std::swap(f->buf, f->spare); std::swap(f->cap, f->spare_cap);
         f->rd = 0; f->wr = live;
     }
     {   // compressed bytes and member list; the kernel reads up to 1 KiB beyond the last member
-        if (comp_bytes + 1024 > f->comp_cap || (size_t)n_blocks > f->blocks_cap) VLR_HIP_OK(hipStreamSynchronize(f->stream));
         int rc = dev_grow(f->d_comp, f->comp_cap, comp_bytes + 1024);
         if (rc) return rc;
         if ((size_t)n_blocks > f->blocks_cap) {
@@ -563,17 +689,24 @@ int vlr_dev_file_feed(vlr_dev_file* f, const uint8_t* comp, size_t comp_bytes, c
             f->blocks_cap = c1 < c2 ? c1 : c2;
         }
     }
-    VLR_HIP_OK(hipMemcpyAsync(f->d_comp, comp, comp_bytes, hipMemcpyHostToDevice, f->stream));
-    VLR_HIP_OK(hipMemsetAsync(f->d_comp + comp_bytes, 0, 1024, f->stream));
-    VLR_HIP_OK(hipMemcpyAsync(f->d_blocks, blocks, (size_t)n_blocks * sizeof(vlr::InflateBlock), hipMemcpyHostToDevice, f->stream));
-    const int lrc = vlr_launch_inflate_kernel(f->d_comp, f->d_blocks, n_blocks, f->buf + f->wr, f->d_status, f->stream);
+    VLR_HIP_OK(hipMemcpyAsync(f->d_comp, comp, comp_bytes, hipMemcpyHostToDevice, st));
+    VLR_HIP_OK(hipMemsetAsync(f->d_comp + comp_bytes, 0, 1024, st));
+    VLR_HIP_OK(hipMemcpyAsync(f->d_blocks, blocks, (size_t)n_blocks * sizeof(vlr::InflateBlock), hipMemcpyHostToDevice, st));
+    const int lrc = vlr_launch_inflate_kernel(f->d_comp, f->d_blocks, n_blocks, f->buf + f->wr, f->d_status, st);
     if (lrc != 0) return dfail(VLR_ERR_HIP, "inflate kernel launch failed (hip error %s%lld)", "", lrc);
     f->h_status.resize((size_t)n_blocks);
-    VLR_HIP_OK(hipMemcpyAsync(f->h_status.data(), f->d_status, (size_t)n_blocks * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    VLR_HIP_OK(hipMemcpyAsync(f->h_status.data(), f->d_status, (size_t)n_blocks * sizeof(int), hipMemcpyDeviceToHost, st));
     f->pending_blocks = (size_t)n_blocks;
     f->wr += (size_t)inflated_bytes;
-    // the host buffers (comp, blocks) may be reused by the caller: wait for the copies (the kernel itself is short)
-    VLR_HIP_OK(hipStreamSynchronize(f->stream));
+    f->feed_pending = true;
+    return VLR_OK;
+}
+
+int vlr_dev_file_feed_wait(vlr_dev_file* f) {
+    if (!f || !f->feed_pending) return VLR_OK;
+    VLR_HIP_OK(hipSetDevice(f->device));
+    VLR_HIP_OK(hipStreamSynchronize(f->feed_stream));
+    f->feed_pending = false;
     for (size_t i = 0; i < f->pending_blocks; ++i)
         if (f->h_status[i] != 0) return dfail(VLR_ERR_INVALID_ARGUMENT, "corrupt DEFLATE stream in a BGZF member (inflate status %s%lld)", "", (long long)f->h_status[i]);
     f->pending_blocks = 0;
@@ -589,6 +722,7 @@ int vlr_dev_file_skip(vlr_dev_file* f, uint64_t bytes) {
 int vlr_dev_file_split(vlr_dev_file* f, int64_t max_records, int n_contigs, int n_hdr_samples, const int8_t* field_of_key, int n_keys, int64_t* n_records,
                        const vlr::RecHost** rec_host, int* used_serial_walk) {
     VLR_HIP_OK(hipSetDevice(f->device));
+    { const int rcw = vlr_dev_file_feed_wait(f); if (rcw != VLR_OK) return rcw; }
     *n_records = 0; *rec_host = nullptr;
     if (used_serial_walk) *used_serial_walk = 0;
     f->n_split = 0;
@@ -720,10 +854,31 @@ int vlr_dev_file_copy(vlr_dev_file* f, void* dst, const void* src, size_t bytes,
     return VLR_OK;
 }
 
+int vlr_dev_file_summaries(vlr_dev_file* f, const vlr::DeviceCols* cols, const uint32_t* d_obs_offset, const uint8_t* d_locus_flags, int64_t n_loci, int n_samples,
+                           const vlr::SumConsts* k, vlr::PileSum* d_hdr, uint64_t* d_ent_key, uint32_t* d_ent_cnt, float* d_run_pm, uint32_t* d_run_len, uint32_t* d_cursor) {
+    const int64_t P = n_loci * n_samples;
+    if (P <= 0) return VLR_OK;
+    VLR_HIP_OK(hipSetDevice(f->device));
+    VLR_HIP_OK(hipMemsetAsync(d_cursor, 0, 8, f->stream));
+    hipLaunchKernelGGL(vlr::obs_summary_kernel, dim3((unsigned)((P + 63) / 64)), dim3(64), 0, f->stream, *cols, d_obs_offset, d_locus_flags, P, n_samples, *k,
+                       d_hdr, d_ent_key, d_ent_cnt, d_run_pm, d_run_len, d_cursor);
+    VLR_HIP_OK(hipGetLastError());
+    return VLR_OK;
+}
+
+int vlr_dev_copy_to_host(int device, void* dst, const void* src, size_t bytes) {
+    if (!bytes) return VLR_OK;
+    VLR_HIP_OK(hipSetDevice(device));
+    VLR_HIP_OK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return VLR_OK;
+}
+
 int vlr_dev_slab_alloc(int device, size_t bytes, void** d, void** h) {
-    *d = nullptr; *h = nullptr;
+    *d = nullptr;
+    if (h) *h = nullptr;
     VLR_HIP_OK(hipSetDevice(device));
     if (hipMalloc(d, bytes) != hipSuccess) return dfail(VLR_ERR_OUT_OF_MEMORY, "device reader: out of device memory (%s%lld bytes)", "", (long long)bytes);
+    if (h == nullptr) return VLR_OK;   // device side only
     if (hipHostMalloc(h, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipFree(*d); *d = nullptr; return dfail(VLR_ERR_OUT_OF_MEMORY, "device reader: out of page-locked memory (%s%lld bytes)", "", (long long)bytes); }
     return VLR_OK;
 }
@@ -735,8 +890,6 @@ void vlr_dev_slab_free(int device, void* d, void* h) {
 
 int vlr_dev_file_consume(vlr_dev_file* f, int64_t n) {
     if (n < 0 || n > f->n_split) return dfail(VLR_ERR_INVALID_ARGUMENT, "device reader: consume beyond the split records");
-    VLR_HIP_OK(hipSetDevice(f->device));
-    VLR_HIP_OK(hipStreamSynchronize(f->stream));
     if (n > 0) f->rd += (size_t)f->h_starts[(size_t)n];
     f->n_split = 0;
     return VLR_OK;

@@ -40,6 +40,23 @@ enum RecStatus : uint32_t {
 };
 struct DeviceCols { float* col[9]; uint32_t* flags; int32_t* third; };
 
+// Per-pileup summary of the observations for the calls writer (Call::write_final_record, calling/variants/mod.rs:233-360): what
+// sample_fields of vlr_ingest.cpp counts per observation — distinct packed observation keys with their counts in first-appearance
+// order (OBS), the Kass-Raftery letters of the alt- and ref-supporting observations (SAOBS, SROBS), the kept observations and the
+// run-lengths of prob_mapping over them (DP is a sum of exp(prob_mapping) in observation order) — so that the host formats text per
+// record without touching the columns.
+constexpr int kSumLetters = 12;   // N B P S V E in two cases
+constexpr int kSumMaxKeys = 64;   // distinct observation keys of one pileup the kernel keeps (more: `overflow`, the host counts from the columns)
+struct PileSum {
+    uint32_t ent_off, n_ent;      // entries [ent_off, ent_off + n_ent) of the key / count arrays
+    uint32_t run_off, n_run;      // runs of equal prob_mapping over the kept observations
+    uint32_t kept, overflow;
+    uint8_t alt_n, ref_n, pad[2];
+    uint8_t alt_letter[kSumLetters], ref_letter[kSumLetters];
+    uint32_t alt_cnt[kSumLetters], ref_cnt[kSumLetters];
+};
+struct SumConsts { double ln3, ln20, ln150, eps; };
+
 }  // namespace vlr
 
 // INFO fields of an observation record (format v15), in the order both decoders index them
@@ -61,9 +78,11 @@ int vlr_dev_file_create(int device, vlr_dev_file** out);
 void vlr_dev_file_destroy(vlr_dev_file* f);
 // bytes of complete-or-not record data currently buffered behind the read position
 uint64_t vlr_dev_file_buffered(const vlr_dev_file* f);
-// append the inflated bytes of n_blocks members (src offsets relative to comp) behind the buffered ones; asynchronous on the file's stream
+// append the inflated bytes of n_blocks members (src offsets relative to comp) behind the buffered ones: enqueued on the file's feed
+// stream, beside whatever the decode stream still runs; comp and blocks stay valid until vlr_dev_file_feed_wait (which split calls)
 int vlr_dev_file_feed(vlr_dev_file* f, const uint8_t* comp, size_t comp_bytes, const vlr::InflateBlock* blocks, int n_blocks, uint64_t inflated_bytes);
 // skip `bytes` (the BCF header) at the read position
+int vlr_dev_file_feed_wait(vlr_dev_file* f);
 int vlr_dev_file_skip(vlr_dev_file* f, uint64_t bytes);
 // split the buffered bytes into records (at most max_records), scan their INFO entries; *n_records complete records found,
 // rec_host[0..n) (array owned by the object, valid until the next split) their counts.  Synchronises the file's stream.
@@ -73,7 +92,7 @@ int vlr_dev_file_split(vlr_dev_file* f, int64_t max_records, int n_contigs, int 
 int vlr_dev_file_decode(vlr_dev_file* f, int64_t n, const uint32_t* d_obs_offset, int n_samples, int sample, const vlr::DeviceCols* cols);
 // cold copies of records [0, n) -> host buffer (cold_off[r] = prefix sum of RecHost.cold_bytes, cold_off[n] bytes in all); asynchronous
 int vlr_dev_file_cold(vlr_dev_file* f, int64_t n, const uint64_t* cold_off, uint8_t* host_out);
-// consume records [0, n): the bytes behind them stay buffered for the next split.  Then wait for the stream.
+// consume records [0, n): the bytes behind them stay buffered for the next split (kernels already enqueued keep their pointers)
 int vlr_dev_file_consume(vlr_dev_file* f, int64_t n);
 int vlr_dev_file_sync(vlr_dev_file* f);
 // record-level error bits of the last decode (REC_*), and the first record that has any
@@ -81,6 +100,12 @@ int vlr_dev_file_errors(vlr_dev_file* f, int64_t n, uint32_t* status_or, int64_t
 void* vlr_dev_file_stream(vlr_dev_file* f);
 // asynchronous copy on the file's stream (to_device != 0: host -> device)
 int vlr_dev_file_copy(vlr_dev_file* f, void* dst, const void* src, size_t bytes, int to_device);
+// observation summaries of n_pileups pileups (locus-major): hdr[n_pileups], entries and runs through bump cursors (cursor[0] entries,
+// cursor[1] runs; zeroed by the call).  Everything is enqueued on the file's stream; ent_* / run_* hold at least n_obs elements.
+int vlr_dev_file_summaries(vlr_dev_file* f, const vlr::DeviceCols* cols, const uint32_t* d_obs_offset, const uint8_t* d_locus_flags, int64_t n_loci, int n_samples,
+                           const vlr::SumConsts* k, vlr::PileSum* d_hdr, uint64_t* d_ent_key, uint32_t* d_ent_cnt, float* d_run_pm, uint32_t* d_run_len, uint32_t* d_cursor);
+// synchronous device -> host copy outside any stream (lazy fetch of a table's columns)
+int vlr_dev_copy_to_host(int device, void* dst, const void* src, size_t bytes);
 // column storage of a table: `bytes` of device memory and as many page-locked host bytes
 int vlr_dev_slab_alloc(int device, size_t bytes, void** d, void** h);
 void vlr_dev_slab_free(int device, void* d, void* h);

@@ -285,11 +285,14 @@ __global__ __launch_bounds__(64) void vlr_inflate_kernel(const uint8_t* __restri
         // ---- symbols of the block.  `e` is the table entry at the current bit position, fetched one symbol ahead.  Checks that only
         // guard against a corrupt stream (bad distance code, distance beyond the output) are collected in `bad` without a branch:
         // the ring mask keeps every LDS access in range, and the output bound — the one check the HBM copy depends on — stays exact.
-        // (One loop exit: every early exit of a multi-exit loop costs the structurised control flow a flag test per iteration.)
+        // (One loop exit — every early exit of a multi-exit loop costs the structurised control flow a flag test per iteration — and one
+        // rare branch: the position is compared with `next_stop`, the nearer of the next flush point and the member's end; a corrupt
+        // stream that runs past the end is caught there, before anything beyond the member's bytes could go to HBM.)
         refill(b, lane);
         uint32_t e = uni(L.lit[peek(b, kLitBits)]);
         uint32_t bad = 0;
         bool done = false;
+        uint32_t next_stop = flushed + kFlush + 512 < lim + 1 ? flushed + kFlush + 512 : lim + 1;
         do {
             if (__builtin_expect((e & 15u) == 0, 0)) {
                 const int sym = slow_symbol(b, L.lcount, L.lsym);
@@ -301,7 +304,6 @@ __global__ __launch_bounds__(64) void vlr_inflate_kernel(const uint8_t* __restri
                 refill(b, lane);
                 const uint32_t ev = L.lit[peek(b, kLitBits)];   // (made uniform after the store: the read is in flight meanwhile)
                 L.out[pos & kRingMask] = (uint8_t)byte;         // (every lane stores the same byte to the same address)
-                bad |= (pos >= lim) ? (uint32_t)INFL_OUTPUT_OVERRUN << 8 : 0u;
                 pos += 1;
                 e = uni(ev);
             } else if (kind == 1) {
@@ -318,18 +320,26 @@ __global__ __launch_bounds__(64) void vlr_inflate_kernel(const uint8_t* __restri
                 const uint32_t dist = (d >> 8) + peek(b, dx);
                 drop(b, dx);
                 bad |= ((dx == 15) | (dist > pos - sh)) ? (uint32_t)INFL_BAD_DISTANCE : 0u;
-                bad |= (pos + len > lim) ? (uint32_t)INFL_OUTPUT_OVERRUN << 8 : 0u;
                 refill(b, lane);
                 const uint32_t ev = L.lit[peek(b, kLitBits)];   // the next symbol's entry: in flight while the bytes are copied
                 const uint32_t from = pos - dist;
                 // byte k of the match repeats with period `dist` (k mod dist = k when dist >= len); every source byte lies before `pos`
                 // (approximate reciprocal: the two corrections below make the remainder exact for k < 512)
                 const float rd = __builtin_amdgcn_rcpf((float)(dist | (uint32_t)(dist == 0)));
-                for (uint32_t k = (uint32_t)lane; k < len; k += 64) {
+                if (len <= 64) {
+                    const uint32_t k = (uint32_t)lane;
                     int r = (int)k - (int)((float)k * rd) * (int)dist;
                     r = r < 0 ? r + (int)dist : r;
                     r = r >= (int)dist ? r - (int)dist : r;
-                    L.out[(pos + k) & kRingMask] = L.out[(from + (uint32_t)r) & kRingMask];
+                    const uint8_t v = L.out[(from + (uint32_t)r) & kRingMask];
+                    if (k < len) L.out[(pos + k) & kRingMask] = v;
+                } else {
+                    for (uint32_t k = (uint32_t)lane; k < len; k += 64) {
+                        int r = (int)k - (int)((float)k * rd) * (int)dist;
+                        r = r < 0 ? r + (int)dist : r;
+                        r = r >= (int)dist ? r - (int)dist : r;
+                        L.out[(pos + k) & kRingMask] = L.out[(from + (uint32_t)r) & kRingMask];
+                    }
                 }
                 pos += len;
                 e = uni(ev);
@@ -337,9 +347,14 @@ __global__ __launch_bounds__(64) void vlr_inflate_kernel(const uint8_t* __restri
                 done = true;   // 2: end of block
                 bad |= kind == 3 ? (uint32_t)INFL_BAD_SYMBOL : 0u;
             }
-            done = done || bad != 0;
-            if (__builtin_expect(!done && pos - flushed >= kFlush + 512, 0)) { const uint32_t to = pos & ~(kFlush - 1); flush_ring(L, gbase, flushed, to, sh, lane); flushed = to; }
+            if (__builtin_expect(pos >= next_stop, 0)) {
+                if (pos > lim) { bad |= (uint32_t)INFL_OUTPUT_OVERRUN << 8; done = true; }
+                else if (bad) done = true;
+                else if (pos - flushed >= kFlush + 512) { const uint32_t to = pos & ~(kFlush - 1); flush_ring(L, gbase, flushed, to, sh, lane); flushed = to; }
+                next_stop = flushed + kFlush + 512 < lim + 1 ? flushed + kFlush + 512 : lim + 1;
+            }
         } while (!done);
+        if (pos > lim) bad |= (uint32_t)INFL_OUTPUT_OVERRUN << 8;
         if (bad) err = (bad >> 8) ? (int)(bad >> 8) : (int)(bad & 0xffu);
         if (err == INFL_OK && bits_used_end(b) > in_end) err = INFL_INPUT_OVERRUN;
     }

@@ -1206,6 +1206,17 @@ struct vlr_obs_table {
     DevSlab slab;
     vlr_batch dev_batch;
     bool has_dev = false;
+    int device = 0;
+    bool cols_on_host = true;      // false: the observation columns were not copied down (vlr_obs_table_fetch_columns does it on demand)
+    size_t col_region_off = 0, col_region_bytes = 0;   // the column arrays inside the slab (both sides)
+    // observation summaries of the device reader (vlr::PileSum): what the calls writer needs per pileup instead of the columns.
+    // They live in the host side of the column region until the columns are fetched over them.
+    bool has_summary = false;
+    const vlr::PileSum* sum_hdr = nullptr;
+    const uint64_t* sum_key = nullptr;
+    const uint32_t* sum_cnt = nullptr;
+    const float* sum_run_pm = nullptr;
+    const uint32_t* sum_run_len = nullptr;
     ~vlr_obs_table() {
         if (dev_pool) dev_pool->release(slab);
         Arr* all[] = {&a_off, &a_col[0], &a_col[1], &a_col[2], &a_col[3], &a_col[4], &a_col[5], &a_col[6], &a_col[7], &a_col[8],
@@ -1290,6 +1301,7 @@ static int build_table(std::vector<SampleFile>& files, const char* const* paths,
         t->flags = (uint32_t*)(h + dl->off_flags);
         t->third = (int32_t*)(h + dl->off_third);
         t->locus_flags = h + dl->off_lflags; t->variant_type = h + dl->off_vt; t->ref_base = h + dl->off_ref; t->alt_base = h + dl->off_alt;
+        t->col_region_off = dl->off_col[0]; t->col_region_bytes = dl->off_lflags - dl->off_col[0];
         vlr_batch& b = t->dev_batch;
         memset(&b, 0, sizeof b);
         b.n_loci = L; b.n_samples = S; b.n_obs = (int64_t)total;
@@ -1632,6 +1644,7 @@ struct DevFileStream {
     int64_t delivered = 0;
     std::vector<uint8_t, PinnedAlloc<uint8_t>> cold;   // cold records of the current chunk (page-locked: asynchronous D2H)
     std::vector<uint64_t> cold_off;
+    std::vector<vlr::InflateBlock> ib;   // members of the feed in flight (read by the asynchronous copy)
     bool more_blocks() const { return next_block < blocks.size(); }
     ~DevFileStream() { if (dev) vlr_dev_file_destroy(dev); }
 };
@@ -1647,6 +1660,9 @@ struct vlr_obs_reader {
     int device = 0;
     std::vector<std::unique_ptr<DevFileStream>> dfiles;
     std::shared_ptr<DevPool> pool;
+    bool host_columns = true;       // vlr_obs_reader_set_host_columns
+    bool summaries_off = false;     // a chunk had pileups with more distinct observation keys than the summary kernel keeps: columns from then on
+    DevSlab sum_scratch;            // device side only in use: summary headers, entries, runs, cursors of the chunk being built
 };
 
 namespace { int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out); }
@@ -1705,7 +1721,10 @@ int vlr_obs_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** 
     return rc;
 }
 
-void vlr_obs_reader_close(vlr_obs_reader* r) { delete r; }
+void vlr_obs_reader_close(vlr_obs_reader* r) {
+    if (r && r->sum_scratch.d) vlr_dev_slab_free(r->device, r->sum_scratch.d, r->sum_scratch.h);
+    delete r;
+}
 
 }  // extern "C"
 
@@ -1770,7 +1789,9 @@ int dev_stream_feed(DevFileStream& f, uint64_t want) {
         const size_t b0 = f.next_block;
         size_t b1 = b0;
         uint64_t add = 0;
-        std::vector<vlr::InflateBlock> ib;
+        { const int rcw = vlr_dev_file_feed_wait(f.dev); if (rcw != VLR_OK) return rcw; }   // (f.ib is read by the copy in flight)
+        std::vector<vlr::InflateBlock>& ib = f.ib;
+        ib.clear();
         while (b1 < f.blocks.size() && (have + add < goal || b1 == b0) && b1 - b0 < (1u << 20)) {
             const BgzfBlock& k = f.blocks[b1];
             vlr::InflateBlock x;
@@ -1781,9 +1802,7 @@ int dev_stream_feed(DevFileStream& f, uint64_t want) {
         }
         const uint8_t* comp = f.raw.p + f.blocks[b0].off;
         const size_t comp_bytes = (f.blocks[b1 - 1].off + f.blocks[b1 - 1].clen) - f.blocks[b0].off;
-        const double t0 = now_s();
         const int rc = vlr_dev_file_feed(f.dev, comp, comp_bytes, ib.data(), (int)ib.size(), add);
-        g_dev_t[2] += now_s() - t0;
         g_dev_t[9] += (double)add; g_dev_t[10] += (double)comp_bytes;
         if (rc != VLR_OK) return rc;
         f.next_block = b1;
@@ -1821,6 +1840,11 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
             const uint64_t want = (uint64_t)((double)max_records * f.bytes_per_record * 1.04 * scale) + 131072;
             const int rc = dev_stream_feed(f, want);
             if (rc != VLR_OK) return rc;
+        }
+        {
+            const double tw = now_s();
+            for (int s = 0; s < S; ++s) { const int rc = vlr_dev_file_feed_wait(r->dfiles[(size_t)s]->dev); if (rc != VLR_OK) return rc; }
+            g_dev_t[2] += now_s() - tw;
         }
         const double t0 = now_s();
         n = max_records;
@@ -1898,6 +1922,26 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
         n_obs_of[(size_t)s].resize((size_t)L); flags_of[(size_t)s].resize((size_t)L);
         for (int64_t i = 0; i < L; ++i) { n_obs_of[(size_t)s][(size_t)i] = rh[(size_t)s][i].n_obs; flags_of[(size_t)s][(size_t)i] = rh[(size_t)s][i].flags; }
     }
+    // the records are consumed (the kernels above hold their own pointers) and the members of the NEXT request go up and inflate on
+    // the feed streams, beside the decode kernels, the copies and the host work below — and beside the caller's evaluation of this chunk
+    for (int s = 0; s < S; ++s) {
+        DevFileStream& f = *r->dfiles[(size_t)s];
+        const uint64_t before = vlr_dev_file_buffered(f.dev);
+        const int rc = vlr_dev_file_consume(f.dev, L);
+        if (rc != VLR_OK) return fail(rc);
+        const double used = (double)(before - vlr_dev_file_buffered(f.dev)) / (double)L;
+        f.bytes_per_record = 0.5 * f.bytes_per_record + 0.5 * used;
+    }
+    {
+        const double tf = now_s();
+        for (int s = 0; s < S; ++s) {
+            DevFileStream& f = *r->dfiles[(size_t)s];
+            const uint64_t want = (uint64_t)((double)max_records * f.bytes_per_record * 1.04) + 131072;
+            const int rc = dev_stream_feed(f, want);
+            if (rc != VLR_OK) return fail(rc);
+        }
+        g_dev_t[2] += now_s() - tf;
+    }
     for (int s = 0; s < S; ++s) {
         uint32_t st = 0;
         int64_t bad = -1;
@@ -1907,7 +1951,12 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
     }
     g_dev_t[5] += now_s() - t_dec0;
     const double t_d2h0 = now_s();
-    {   // columns down for the calls writer (one copy: the column arrays are contiguous in the slab)
+    // the per-pileup summaries need P headers and at most one entry and one run per observation: they are brought down INTO the host
+    // side of the column region, so they must fit there (they do unless most pileups are empty)
+    const int64_t P = L * S;
+    const size_t sum_need = (size_t)P * sizeof(vlr::PileSum) + 64 + (size_t)total * 12 + 64 + (size_t)total * 8 + 64;
+    const bool summaries = !r->host_columns && !r->summaries_off && sum_need <= dl.off_lflags - dl.off_col[0];
+    if (!summaries) {   // columns down for the calls writer (one copy: the column arrays are contiguous in the slab)
         DevFileStream& f0 = *r->dfiles[0];
         const int rc = vlr_dev_file_copy(f0.dev, h + dl.off_col[0], d + dl.off_col[0], dl.off_lflags - dl.off_col[0], 0);
         if (rc != VLR_OK) return fail(rc);
@@ -1952,21 +2001,60 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
         if (rc == VLR_OK) rc = vlr_dev_file_sync(f0.dev);
         if (rc != VLR_OK) { vlr_obs_table_free(t); *out = nullptr; return rc; }
     }
+    (*out)->device = r->device;
+    if (summaries) {
+        // ---- observation summaries (the locus flags they need are on the device now); the columns stay in device memory
+        vlr_obs_table* t = *out;
+        DevFileStream& f0 = *r->dfiles[0];
+        auto up = [](size_t x) { return (x + 63) & ~(size_t)63; };
+        const size_t o_hdr = 0, o_key = up((size_t)P * sizeof(vlr::PileSum)), o_cnt = o_key + up((size_t)total * 8), o_rpm = o_cnt + up((size_t)total * 4),
+                     o_rln = o_rpm + up((size_t)total * 4), o_cur = o_rln + up((size_t)total * 4), need = o_cur + 64;
+        if (r->sum_scratch.cap < need) {
+            if (r->sum_scratch.d) vlr_dev_slab_free(r->device, r->sum_scratch.d, r->sum_scratch.h);
+            r->sum_scratch = DevSlab();
+            rc = vlr_dev_slab_alloc(r->device, need + need / 4, &r->sum_scratch.d, nullptr);
+            if (rc != VLR_OK) { vlr_obs_table_free(t); *out = nullptr; return rc; }
+            r->sum_scratch.cap = need + need / 4;
+        }
+        uint8_t* sd = (uint8_t*)r->sum_scratch.d;
+        static const vlr::SumConsts kc = {std::log(3.0), std::log(20.0), std::log(150.0), std::numeric_limits<double>::epsilon()};
+        vlr::DeviceCols dc;
+        for (int k = 0; k < 9; ++k) dc.col[k] = (float*)((uint8_t*)t->slab.d + dl.off_col[k]);
+        dc.flags = (uint32_t*)((uint8_t*)t->slab.d + dl.off_flags);
+        dc.third = (int32_t*)((uint8_t*)t->slab.d + dl.off_third);
+        rc = vlr_dev_file_summaries(f0.dev, &dc, (const uint32_t*)((uint8_t*)t->slab.d + dl.off_obs), (const uint8_t*)t->slab.d + dl.off_lflags, L, S, &kc,
+                                    (vlr::PileSum*)(sd + o_hdr), (uint64_t*)(sd + o_key), (uint32_t*)(sd + o_cnt), (float*)(sd + o_rpm), (uint32_t*)(sd + o_rln), (uint32_t*)(sd + o_cur));
+        uint32_t cur[2] = {0, 0};
+        if (rc == VLR_OK) rc = vlr_dev_file_copy(f0.dev, cur, sd + o_cur, 8, 0);
+        if (rc == VLR_OK) rc = vlr_dev_file_sync(f0.dev);
+        // host layout inside the column region: headers, keys, counts, run values, run lengths
+        uint8_t* hb = (uint8_t*)t->slab.h + dl.off_col[0];
+        const size_t h_key = up((size_t)P * sizeof(vlr::PileSum)), h_cnt = h_key + up((size_t)cur[0] * 8), h_rpm = h_cnt + up((size_t)cur[0] * 4), h_rln = h_rpm + up((size_t)cur[1] * 4);
+        if (rc == VLR_OK) rc = vlr_dev_file_copy(f0.dev, hb, sd + o_hdr, (size_t)P * sizeof(vlr::PileSum), 0);
+        if (rc == VLR_OK) rc = vlr_dev_file_copy(f0.dev, hb + h_key, sd + o_key, (size_t)cur[0] * 8, 0);
+        if (rc == VLR_OK) rc = vlr_dev_file_copy(f0.dev, hb + h_cnt, sd + o_cnt, (size_t)cur[0] * 4, 0);
+        if (rc == VLR_OK) rc = vlr_dev_file_copy(f0.dev, hb + h_rpm, sd + o_rpm, (size_t)cur[1] * 4, 0);
+        if (rc == VLR_OK) rc = vlr_dev_file_copy(f0.dev, hb + h_rln, sd + o_rln, (size_t)cur[1] * 4, 0);
+        if (rc == VLR_OK) rc = vlr_dev_file_sync(f0.dev);
+        if (rc != VLR_OK) { vlr_obs_table_free(t); *out = nullptr; return rc; }
+        t->cols_on_host = false;
+        t->has_summary = true;
+        {   // pileups the kernel could not summarise (more than kSumMaxKeys distinct observation keys: diverse synthetic pileups, very
+            // deep real ones) need the columns after all: fetch them now and stop summarising this file
+            int64_t n_over = 0;
+            const vlr::PileSum* hh = (const vlr::PileSum*)hb;
+            for (int64_t q = 0; q < P; ++q) n_over += hh[q].overflow != 0;
+            if (n_over * 50 > P) {
+                r->summaries_off = true;
+                rc = vlr_obs_table_fetch_columns(t);
+                if (rc != VLR_OK) { vlr_obs_table_free(t); *out = nullptr; return rc; }
+            }
+        }
+        t->sum_hdr = (const vlr::PileSum*)hb; t->sum_key = (const uint64_t*)(hb + h_key); t->sum_cnt = (const uint32_t*)(hb + h_cnt);
+        t->sum_run_pm = (const float*)(hb + h_rpm); t->sum_run_len = (const uint32_t*)(hb + h_rln);
+    }
     g_dev_t[6] += now_s() - t_d2h0;
-    for (int s = 0; s < S; ++s) {
-        DevFileStream& f = *r->dfiles[(size_t)s];
-        rc = vlr_dev_file_consume(f.dev, L);
-        if (rc != VLR_OK) { vlr_obs_table_free(*out); *out = nullptr; return rc; }
-        f.delivered += L;
-    }
-    // bytes per record of this chunk (the next request's feed size)
-    for (int s = 0; s < S; ++s) {
-        DevFileStream& f = *r->dfiles[(size_t)s];
-        uint64_t cb = 0;
-        for (int64_t i = 0; i < L; ++i) cb += n_obs_of[(size_t)s][(size_t)i];
-        const double est = 160.0 + 113.0 * (double)cb / (double)L;   // (a v15 observation takes ~113 bytes of an uncompressed record)
-        f.bytes_per_record = 0.5 * f.bytes_per_record + 0.5 * est;
-    }
+    for (int s = 0; s < S; ++s) r->dfiles[(size_t)s]->delivered += L;
     g_dev_t[8] += now_s() - t_all0;
     g_dev_t[11] += (double)L;
     return VLR_OK;
@@ -1998,6 +2086,23 @@ int vlr_obs_table_device_batch(const vlr_obs_table* t, vlr_batch* b) {
     if (!t || !b) return ifail(VLR_ERR_INVALID_ARGUMENT, "null argument");
     if (!t->has_dev) return ifail(VLR_ERR_INVALID_ARGUMENT, "vlr_obs_table_device_batch: the table was not read by a device reader");
     *b = t->dev_batch;
+    return VLR_OK;
+}
+
+int vlr_obs_reader_set_host_columns(vlr_obs_reader* r, int keep) {
+    if (!r) return ifail(VLR_ERR_INVALID_ARGUMENT, "null reader");
+    r->host_columns = keep != 0;
+    return VLR_OK;
+}
+
+int vlr_obs_table_fetch_columns(vlr_obs_table* t) {
+    if (!t) return ifail(VLR_ERR_INVALID_ARGUMENT, "null table");
+    if (t->cols_on_host) return VLR_OK;
+    // (the summaries live where the columns go: they are gone afterwards, the writer then counts from the columns)
+    t->has_summary = false;
+    const int rc = vlr_dev_copy_to_host(t->device, (uint8_t*)t->slab.h + t->col_region_off, (const uint8_t*)t->slab.d + t->col_region_off, t->col_region_bytes);
+    if (rc != VLR_OK) return rc;
+    t->cols_on_host = true;
     return VLR_OK;
 }
 
@@ -2153,6 +2258,15 @@ inline void append_fixed(std::string& out, double v, int digits) {
     out.append(buf + pos, (size_t)(40 - pos));
 }
 
+#ifdef VLR_WRITER_PROF
+#include <x86intrin.h>
+static std::atomic<unsigned long long> g_wprof[8];
+struct WProf { int k; unsigned long long t0; WProf(int k_) : k(k_), t0(__rdtsc()) {} ~WProf() { g_wprof[k] += __rdtsc() - t0; } };
+#define WPROF(k) WProf wprof_##k(k)
+extern "C" void vlr_writer_prof(unsigned long long* out8, int reset) { for (int i = 0; i < 8; ++i) { out8[i] = g_wprof[i]; if (reset) g_wprof[i] = 0; } }
+#else
+#define WPROF(k)
+#endif
 struct SampleFields { int32_t dp = 0, oobs = 0; float af = NAN; std::string saobs, srobs, obs, sym[6], afd; bool has_afd = false; };
 
 // Call::write_final_record, per sample (calling/variants/mod.rs:233-360, 473-559); mirrors callsfmt.sample_fields
@@ -2162,8 +2276,9 @@ void sample_fields(const vlr_obs_table* t, const vlr_results* r, int64_t l, int 
     const bool drop_nonstd = t->locus_flags[l] & VLR_LOCUS_REMOVE_NONSTANDARD;  // pileup.rs:26-43
     // observations are counted by a packed key (two score characters, the flag characters, third-allele evidence); the strings
     // are only built for the distinct keys, in first-appearance order (what Counter::most_common sees)
-    std::vector<std::pair<uint64_t, int>> obs_cnt;
-    obs_cnt.reserve(32);
+    static thread_local std::vector<std::pair<uint64_t, int>> obs_cnt;
+    static thread_local std::vector<int> slots;
+    obs_cnt.clear(); slots.clear();
     std::vector<std::pair<std::string, int>> alt_cnt, ref_cnt;  // one-letter items: at most twelve distinct
     auto count_letter = [](std::vector<std::pair<std::string, int>>& v, char ch) {
         for (auto& kv : v)
@@ -2174,7 +2289,21 @@ void sample_fields(const vlr_obs_table* t, const vlr_results* r, int64_t l, int 
     int kept = 0;
     double last_pm = NAN, last_w = 0.0;
     static const double kLn3 = std::log(3.0), kLn20 = std::log(20.0), kLn150 = std::log(150.0);
-    for (uint32_t i = b; i < e; ++i) {
+    const bool from_summary = t->has_summary;
+    if (from_summary) {
+        // the device counted per observation (vlr_decode.hip obs_summary_kernel: this loop, lane per pileup); what is left is per pileup
+        const vlr::PileSum& h = t->sum_hdr[l * S + s];
+        kept = (int)h.kept;
+        for (uint32_t q = 0; q < h.n_ent; ++q) obs_cnt.emplace_back(t->sum_key[h.ent_off + q], (int)t->sum_cnt[h.ent_off + q]);
+        for (uint32_t q = 0; q < h.alt_n; ++q) alt_cnt.emplace_back(std::string(1, (char)h.alt_letter[q]), (int)h.alt_cnt[q]);
+        for (uint32_t q = 0; q < h.ref_n; ++q) ref_cnt.emplace_back(std::string(1, (char)h.ref_letter[q]), (int)h.ref_cnt[q]);
+        for (uint32_t q = 0; q < h.n_run; ++q) {   // the same sequence of additions as the loop below
+            const double w = std::exp((double)t->sum_run_pm[h.run_off + q]);
+            for (uint32_t j = 0; j < t->sum_run_len[h.run_off + q]; ++j) depth += w;
+        }
+    }
+    { WPROF(0);
+    for (uint32_t i = b; i < e && !from_summary; ++i) {
         const uint32_t f = t->flags[i];
         const unsigned orient = (f >> VLR_F_ORIENT_SHIFT) & 3;
         if (drop_nonstd && orient == VLR_ORIENT_OTHER) continue;
@@ -2209,34 +2338,63 @@ void sample_fields(const vlr_obs_table* t, const vlr_results* r, int64_t l, int 
                              ((uint64_t)(altloc > 2 ? 2 : altloc) << 17) | ((uint64_t)strand << 19) | ((uint64_t)orient << 21) |
                              ((uint64_t)((f & VLR_F_READPOS_MAJOR) ? 1 : 0) << 23) | ((uint64_t)((f & VLR_F_SOFTCLIPPED) ? 1 : 0) << 24) |
                              ((uint64_t)(hp_err ? 1 : 0) << 25) | ((uint64_t)(uint32_t)(t->third[i] + 1) << 32);
-        size_t k = 0;
-        while (k < obs_cnt.size() && obs_cnt[k].first != key) ++k;
-        if (k == obs_cnt.size()) obs_cnt.emplace_back(key, 1);
-        else obs_cnt[k].second++;
+        {   // first-appearance counting through a small open-addressing table (synthetic pileups have almost as many distinct keys
+            // as observations: the linear search was quadratic)
+            if (slots.empty() || obs_cnt.size() * 2 >= slots.size()) {
+                slots.assign(slots.empty() ? 64 : slots.size() * 2, -1);
+                for (size_t q = 0; q < obs_cnt.size(); ++q) {
+                    size_t hq = (size_t)((obs_cnt[q].first * 0x9E3779B97F4A7C15ull) >> 32) & (slots.size() - 1);
+                    while (slots[hq] >= 0) hq = (hq + 1) & (slots.size() - 1);
+                    slots[hq] = (int)q;
+                }
+            }
+            size_t hq = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 32) & (slots.size() - 1);
+            while (slots[hq] >= 0 && obs_cnt[(size_t)slots[hq]].first != key) hq = (hq + 1) & (slots.size() - 1);
+            if (slots[hq] < 0) { slots[hq] = (int)obs_cnt.size(); obs_cnt.emplace_back(key, 1); }
+            else obs_cnt[(size_t)slots[hq]].second++;
+        }
         if (pa > pr) { const char c = kl_alt; count_letter(alt_cnt, maxq ? (char)toupper(c) : (char)tolower(c)); }
         else { const char c = kl_ref; count_letter(ref_cnt, maxq ? (char)toupper(c) : (char)tolower(c)); }
     }
-    std::vector<std::pair<std::string, int>> obs_pairs;
-    obs_pairs.reserve(obs_cnt.size());
-    for (auto& kc : obs_cnt) {
+    }
+    WPROF(1);
+    // generalized_cigar(keep_order = false) of the items (utils/mod.rs:122-156): stable by count descending, then stable by the
+    // auxiliary class — one sort of (class, -count, first appearance) — and the item text is written once, in output order
+    static thread_local std::vector<uint64_t> ord;
+    ord.clear();
+    for (size_t q = 0; q < obs_cnt.size(); ++q) {
+        const char s0 = (char)(obs_cnt[q].first & 0xff);
+        const uint64_t aux = s0 == 'N' ? 2 : s0 == 'E' ? 1 : 0;
+        ord.push_back((aux << 56) | ((uint64_t)(0xffffffu - (uint32_t)std::min(obs_cnt[q].second, 0xffffff)) << 32) | (uint64_t)q);
+    }
+    std::sort(ord.begin(), ord.end());
+    o.obs.clear();
+    for (uint64_t v : ord) {
+        const auto& kc = obs_cnt[(size_t)(v & 0xffffffffu)];
         const uint64_t key = kc.first;
-        std::string item;
-        item.push_back((char)(key & 0xff));
-        if ((key >> 8) & 0xff) item.push_back((char)((key >> 8) & 0xff));
+        char item[40];
+        int n = 0;
+        {   // count
+            char d[12]; int m = 0; unsigned c = (unsigned)kc.second;
+            do { d[m++] = (char)('0' + c % 10); c /= 10; } while (c);
+            while (m) item[n++] = d[--m];
+        }
+        item[n++] = (char)(key & 0xff);
+        if ((key >> 8) & 0xff) item[n++] = (char)((key >> 8) & 0xff);
         const uint32_t th = (uint32_t)(key >> 32);
-        item += th ? std::to_string((int64_t)th - 1) : std::string(".");
-        item.push_back(((key >> 16) & 1) ? 'p' : 's');
-        item.push_back("#*."[(key >> 17) & 3]);
-        item.push_back("+-*."[(key >> 19) & 3]);
-        item.push_back("><*!"[(key >> 21) & 3]);
-        item.push_back(((key >> 23) & 1) ? '^' : '*');
-        item.push_back(((key >> 24) & 1) ? '$' : '.');
-        item.push_back(((key >> 25) & 1) ? '*' : '.');
-        obs_pairs.emplace_back(item, kc.second);
+        if (th) { char d[12]; int m = 0; uint32_t c = th - 1; do { d[m++] = (char)('0' + c % 10); c /= 10; } while (c); while (m) item[n++] = d[--m]; }
+        else item[n++] = '.';
+        item[n++] = ((key >> 16) & 1) ? 'p' : 's';
+        item[n++] = "#*."[(key >> 17) & 3];
+        item[n++] = "+-*."[(key >> 19) & 3];
+        item[n++] = "><*!"[(key >> 21) & 3];
+        item[n++] = ((key >> 23) & 1) ? '^' : '*';
+        item[n++] = ((key >> 24) & 1) ? '$' : '.';
+        item[n++] = ((key >> 25) & 1) ? '*' : '.';
+        o.obs.append(item, (size_t)n);
     }
     o.dp = kept ? (int32_t)std::floor(depth + 0.5) : 0;  // expected_depth (read_observation.rs:43-47)
     o.oobs = (int32_t)(e - b) - kept;
-    o.obs = cigar_of_counts(obs_pairs, [](const std::string& k) { return k[0] == 'N' ? 2 : k[0] == 'E' ? 1 : 0; });
     auto simple = [](const std::string& k) { return k[0] == 'R' ? 2 : (k.back() == 'E' ? 1 : 0); };
     o.saobs = cigar_of_counts(alt_cnt, simple);
     o.srobs = cigar_of_counts(ref_cnt, simple);
@@ -2248,6 +2406,7 @@ void sample_fields(const vlr_obs_table* t, const vlr_results* r, int64_t l, int 
     o.afd = ".";
     o.has_afd = false;
     if (r->afd_count && !any_bias) {
+        WPROF(2);
         const int n = std::min(r->afd_count[l * S + s], r->afd_capacity);
         const double* v = r->afd_vaf + (size_t)(l * S + s) * r->afd_capacity;
         const double* p = r->afd_lnprob + (size_t)(l * S + s) * r->afd_capacity;
@@ -2354,6 +2513,14 @@ static int calls_write_impl(FILE* out_file, bool bcf, bool with_header, bool wit
     n_threads = pick_threads(n_threads);
     const int S = t->n_samples, n_out = r->n_out;
     const int64_t L = t->n_loci;
+    if (t->has_summary) {   // a pileup with more distinct observation keys than the kernel keeps: count from the columns instead
+        bool over = false;
+        for (int64_t p = 0; p < L * S && !over; ++p) over = t->sum_hdr[p].overflow != 0;
+        if (over) { const int rc = vlr_obs_table_fetch_columns(const_cast<vlr_obs_table*>(t)); if (rc != VLR_OK) return rc; }
+    } else if (!t->cols_on_host) {
+        const int rc = vlr_obs_table_fetch_columns(const_cast<vlr_obs_table*>(t));
+        if (rc != VLR_OK) return rc;
+    }
     OutHeader h;
     build_out_header(header_text, h);
     static const char* kFmt[13] = {"DP", "AF", "SAOBS", "SROBS", "OBS", "OOBS", "SB", "ROB", "RPB", "SCB", "HE", "ALB", "AFD"};
@@ -2409,7 +2576,8 @@ static int calls_write_impl(FILE* out_file, bool bcf, bool with_header, bool wit
                 const double ka = lp[a] == lp[a] ? -lp[a] : INFINITY, kc = lp[c] == lp[c] ? -lp[c] : INFINITY;
                 return ka < kc;
             });
-            if (!missing) for (int s = 0; s < S; ++s) sample_fields(t, r, l, s, sf[(size_t)s]);
+            if (!missing) { WPROF(3); for (int s = 0; s < S; ++s) sample_fields(t, r, l, s, sf[(size_t)s]); }
+            WPROF(4);
             const char* cid = t->pool.c_str() + t->id_off[(size_t)l];
             const char* ref = t->pool.c_str() + t->ref_off[(size_t)l];
             const char* alt = t->pool.c_str() + t->alt_off[(size_t)l];

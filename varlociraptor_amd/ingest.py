@@ -123,6 +123,13 @@ class ObsTable:
         _check(L.vlr_obs_table_device_batch(self.handle, C.byref(b)))
         return b
 
+    def fetch_columns(self):
+        """vlr_obs_table_fetch_columns: bring the observation columns of a device reader's table down to the host (no-op when they are)."""
+        L = _lib()
+        L.vlr_obs_table_fetch_columns.restype = C.c_int
+        L.vlr_obs_table_fetch_columns.argtypes = [C.c_void_p]
+        _check(L.vlr_obs_table_fetch_columns(self.handle))
+
     def close(self):
         if self.handle:
             _lib().vlr_obs_table_free(self.handle)
@@ -194,7 +201,8 @@ def device_timings(reset: bool = False) -> dict:
 class ObsReader:
     """vlr_obs_reader: the observation files a bounded number of records at a time.  Iterating yields (PileupBatch, Sites)."""
 
-    def __init__(self, paths: Sequence[str], omit_bias_mask: int = 0, threads: int = 0, chunk_records: int = 250_000, device: Optional[int] = None):
+    def __init__(self, paths: Sequence[str], omit_bias_mask: int = 0, threads: int = 0, chunk_records: int = 250_000, device: Optional[int] = None,
+                 host_columns: bool = True):
         """device = None: the host reader.  device = k: vlr_obs_reader_open_device — BGZF inflate, record split and v15 decode as kernels on
         device k; the tables then also hold the batch in device memory (ObsTable.device_batch)."""
         L = _lib()
@@ -213,6 +221,12 @@ class ObsReader:
             _check(L.vlr_obs_reader_open(len(paths), arr, int(omit_bias_mask), int(threads), C.byref(h)))
         else:
             _check(L.vlr_obs_reader_open_device(int(device), len(paths), arr, int(omit_bias_mask), int(threads), C.byref(h)))
+            if not host_columns:
+                # the observation columns stay on the device; the calls writer gets per-pileup summaries (vlr_obs_reader_set_host_columns).
+                # ObsTable.fetch_columns() fills the numpy views of the columns on demand.
+                L.vlr_obs_reader_set_host_columns.restype = C.c_int
+                L.vlr_obs_reader_set_host_columns.argtypes = [C.c_void_p, C.c_int]
+                _check(L.vlr_obs_reader_set_host_columns(h, 0))
         self._h, self.chunk_records = h, int(chunk_records)
 
     def next(self, max_records: Optional[int] = None):
