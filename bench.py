@@ -380,12 +380,85 @@ def bench_cli(args, rank, world, local_rank, dev):
     }
 
 
+def bench_ingest(args, rank, world, local_rank, dev):
+    """The device reader alone: observation BCFs on disk -> the SoA columns of vlr_batch in device memory
+    (BGZF inflate, record split and v15 decode as kernels).  One step = one pass over the rank's files.  roofline: the inflate kernel,
+    the dominant one — algorithmic bytes = compressed bytes read + inflated bytes written, over its HIP-event time."""
+    import tempfile
+    import torch
+    import torch.distributed as dist
+    from varlociraptor_amd import engine, ingest, synth
+    n_loci = args.loci or 200_000
+    cfg = synth.CONFIGS["config3"]()
+    batch = generate("config3", n_loci, rank)
+    tmp = tempfile.mkdtemp(prefix="vlr_ingest_%d_" % rank, dir=os.environ.get("VLR_BENCH_TMP", None))
+    paths = []
+    for s, name in enumerate(cfg.scenario.sample_names):
+        paths.append(os.path.join(tmp, "%s.bcf" % name))
+        ingest.write_observations(paths[-1], batch, s)
+    obs_bytes = sum(os.path.getsize(p) for p in paths)
+    n_obs = int(batch.n_obs)
+    del batch
+    chunk = int(os.environ.get("VLR_CLI_CHUNK", "0")) or 32768
+
+    def one_pass(device):
+        rd = ingest.ObsReader(paths, chunk_records=chunk, device=device)
+        k = 0
+        for b, _ in rd:
+            k += b.n_loci
+        rd.close()
+        return k
+    for _ in range(max(1, args.warmup)):
+        assert one_pass(local_rank) == n_loci
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ingest.device_timings(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_pass(local_rank)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    tm = ingest.device_timings()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    host = None
+    if rank == 0 and not args.no_cpu_baseline:   # the host reader on the same files and cores (product code, not the oracle): one pass
+        th = time.perf_counter()
+        one_pass(None)
+        host = n_loci / (time.perf_counter() - th)
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    if rank != 0:
+        return None
+    algo = (tm["inflated_bytes"] + tm["compressed_bytes"]) / args.steps
+    k_s = tm["inflate_kernel"] / args.steps
+    return {
+        "metric": "observation records/sec through the device reader (BGZF inflate + record split + v15 decode, whole node)", "value": n_loci * world * args.steps / elapsed,
+        "unit": "records/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup), "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "ingest: tumor-normal 100x (config3 pileups), %d records/GPU in two observation BCFs (format v15, BGZF), requests of %d records" % (n_loci, chunk),
+                   "parallelism": "files sharded x%d, one process per GPU" % world, "effective_cpus": effective_cpus()},
+        "stages_s": {k: v / args.steps for k, v in tm.items() if k not in ("inflated_bytes", "compressed_bytes", "records", "serial_walks")},
+        "files": {"observation_bcf_bytes": obs_bytes, "inflated_bytes": tm["inflated_bytes"] / args.steps, "observations": n_obs, "serial_walks": tm["serial_walks"]},
+        "roofline": {"bound": "hbm", "achieved": algo / k_s / 1e9 if k_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (algo / k_s / 1e9 / HBM_PEAK_GBS) if k_s > 0 else None,
+                     "traffic": None, "algorithmic_bytes_per_step": algo, "kernel_ms": k_s * 1e3,
+                     "note": "vlr_inflate_kernel: one serial DEFLATE decoder per wave, four waves per CU (LDS window) — bound by the instruction issue of single waves, not by bandwidth (DESIGN 3e)"},
+        "cpu_baseline": {"value": host, "unit": "records/s", "cores": effective_cpus(), "kind": "host reader (csrc/vlr_ingest.cpp: libdeflate + v15 decode on all cores; product code, not the oracle)", "sample": "one pass over the same files"} if host else None,
+        "build_id": engine.build_id(),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="config3", choices=["config2", "config3", "config4", "config5", "realign", "cli"])
+    ap.add_argument("--workload", default="config3", choices=["config2", "config3", "config4", "config5", "realign", "cli", "ingest"])
     ap.add_argument("--loci", type=int, default=None, help="loci per GPU (default: the config's size); realign: pairs per GPU")
     ap.add_argument("--afd", dest="afd", action="store_true", default=True, help="(default) also time the step with the AFD lists")
     ap.add_argument("--no-afd", dest="afd", action="store_false", help="only the plain step")
@@ -424,8 +497,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
 
-    if args.workload in ("realign", "cli"):
-        line = (bench_realign if args.workload == "realign" else bench_cli)(args, rank, world, local_rank, dev)
+    if args.workload in ("realign", "cli", "ingest"):
+        line = {"realign": bench_realign, "cli": bench_cli, "ingest": bench_ingest}[args.workload](args, rank, world, local_rank, dev)
         if rank == 0:
             print(json.dumps(line))
         if world > 1:

@@ -531,7 +531,8 @@ int  vlr_obs_table_fetch_columns(vlr_obs_table* table);
 int  vlr_bgzf_inflate(int device, const void* bgzf, int64_t n_bytes, void* out, int64_t out_capacity, int64_t* out_bytes);
 /* Measurement aid of the device reader: seconds per stage summed since the last reset — [0] file read + member index, [1] H2D of the
  * compressed bytes, [2] inflate kernel, [3] record split, [4] INFO scan, [5] decode, [6] D2H of columns and cold records, [7] host
- * side (cold records, table), [8] total; [9] inflated bytes, [10] compressed bytes, [11] records. */
+ * side (cold records, table), [8] total; [9] inflated bytes, [10] compressed bytes, [11] records, [12] chunks whose record split fell
+ * back to the serial walk, [13] seconds of the inflate kernels alone (HIP events on their stream, summed over the files). */
 void vlr_ingest_device_timings(double* out16, int reset);
 
 #ifdef __cplusplus

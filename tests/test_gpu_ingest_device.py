@@ -47,7 +47,19 @@ def _payloads(rng):
     }
 
 
-def test_inflate_kernel_equals_zlib_on_every_block_type():
+@pytest.fixture(params=["0", "1"], ids=["symbol loop", "speculative batches"])
+def inflate_mode(request):
+    """Both symbol loops of vlr_inflate_kernel (VLR_INFLATE_BATCH is read at every launch)."""
+    old = os.environ.get("VLR_INFLATE_BATCH")
+    os.environ["VLR_INFLATE_BATCH"] = request.param
+    yield request.param
+    if old is None:
+        del os.environ["VLR_INFLATE_BATCH"]
+    else:
+        os.environ["VLR_INFLATE_BATCH"] = old
+
+
+def test_inflate_kernel_equals_zlib_on_every_block_type(inflate_mode):
     rng = np.random.default_rng(5)
     members, plain = [], []
     for name, pl in _payloads(rng).items():
@@ -73,7 +85,7 @@ def test_inflate_kernel_equals_zlib_on_every_block_type():
     assert ingest.bgzf_inflate(members[3] + eof) == plain[3]
 
 
-def test_inflate_kernel_refuses_damaged_members():
+def test_inflate_kernel_refuses_damaged_members(inflate_mode):
     rng = np.random.default_rng(6)
     pl = _payloads(rng)["text"]
     m = bytearray(_member(pl, 6))
@@ -142,7 +154,7 @@ def _concat_check(host_chunks, dev_chunks, first=None):
 
 
 @pytest.mark.parametrize("name", ["config3", "config4", "config5"])
-def test_device_reader_equals_host_reader(name, tmp_path):
+def test_device_reader_equals_host_reader(name, tmp_path, inflate_mode):
     cfg = synth.CONFIGS[name]()
     b = synth.generate(cfg, 2500, seed=31)
     third = np.where(np.arange(b.n_obs) % 5 == 0, np.arange(b.n_obs) % 4, -1).astype(np.int32)
@@ -175,7 +187,7 @@ def test_device_reader_equals_host_reader(name, tmp_path):
     assert t["records"] > 0
 
 
-def test_device_reader_on_files_of_the_reference(golden_dir, tmp_path):
+def test_device_reader_on_files_of_the_reference(golden_dir, tmp_path, inflate_mode):
     """normal.bcf of the reference's flamegraph_profiling fixture was written by varlociraptor preprocess through htslib (other member
     sizes, int8 / int16 typed vectors, its own header); the fourteen format-v15 testcases are re-encoded as BCF by the Python writer."""
     import glob

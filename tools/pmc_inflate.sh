@@ -11,4 +11,4 @@ run() { name=$1; shift; (cd /tmp && rocprofv3 --pmc "$@" --kernel-trace -d $O/$n
 run insts SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_ANY
 run util SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAVES SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS
 find $O/trace -name "*.db" -size +20M -delete
-cat $O/trace.md | head -30; cat $O/insts.md $O/util.md
+head -12 $O/trace.md; echo; cat $O/insts.md; echo; cat $O/util.md

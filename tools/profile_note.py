@@ -50,6 +50,22 @@ if j:
     st, nt = j["stages_s"], (j.get("native_stage_seconds_per_step") or j.get("native_stage_seconds_last_step") or {})
     md += ["", "End to end through the process boundary (`bench.py --workload cli`: %s; %d effective CPUs of %d visible): **%.1f k records/s** — read %.2f s (inflate %.2f summed over the two files, both files in %.2f wall, merge %.2f), call %.2f s, write %.2f s (encode %.2f, deflate + file %.2f)."
            % (j["config"]["workload"], j["config"].get("effective_cpus", 0), j["config"].get("host_threads", 0), j["value"] / 1e3, st["read_s"], nt.get("inflate", 0), nt.get("files_wall", 0), nt.get("merge", 0), st["call_s"], st["write_s"], nt.get("encode", 0), nt.get("deflate_write", 0))]
+for fn, what in (("bench_cli_1M.json", "the same with 1 000 000 records per step (the size of BASELINE configs[2])"), ("bench_cli_hostreader.json", "the same through the HOST reader (`VLR_INGEST_HOST=1`: libdeflate + v15 decode on the CPUs)")):
+    j = line(fn)
+    if j:
+        shutil.copy(os.path.join(O, fn), os.path.join(P, "%s_%s" % (tag, fn)))
+        st = j["stages_s"]
+        md += ["", "… %s: **%.1f k records/s** — read %.2f s, call %.2f s, write %.2f s per step." % (what, j["value"] / 1e3, st["read_s"], st["call_s"], st["write_s"])]
+j = line("bench_ingest.json")
+if j:
+    shutil.copy(os.path.join(O, "bench_ingest.json"), os.path.join(P, "%s_bench_ingest.json" % tag))
+    st, rf, fl = j["stages_s"], j["roofline"], j["files"]
+    md += ["", "Device reader alone (`bench.py --workload ingest`: %s): **%.1f k records/s** (host reader on the same files: %s records/s); per step: members up + inflate wait %.3f s, record split + INFO scan %.3f, decode %.3f, column copy %.3f, host side %.3f, all %.3f; %.2f GB inflated from %.2f GB; inflate kernels %.1f ms per step = **%.1f GB/s** of algorithmic bytes (compressed in + inflated out) = %.2f %% of the HBM roofline; %d chunks fell back to the serial record walk."
+           % (j["config"]["workload"], j["value"] / 1e3, ("%.0f k" % (j["cpu_baseline"]["value"] / 1e3)) if j.get("cpu_baseline") else "n/a", st.get("feed_inflate", 0), st.get("split_scan", 0), st.get("decode", 0),
+              st.get("copy_back", 0), st.get("host_table", 0), st.get("total", 0), fl["inflated_bytes"] / 1e9, fl["observation_bcf_bytes"] / 1e9, rf["kernel_ms"], rf["achieved"] or 0, 100 * (rf["frac"] or 0), fl["serial_walks"])]
+pi = os.path.join(O, "pmc_inflate.md")
+if os.path.exists(pi):
+    md += ["", "## Kernels of the device reader: rocprofv3 --kernel-trace --stats and PMC passes of `tools/ingest_rate.py 50000 32768 device` (3 passes over 2 x 50 000 records; `tools/pmc_inflate.sh`; counters of vlr_inflate_kernel, summed over dispatches)", "", open(pi).read().rstrip(), ""]
 if os.path.exists(os.path.join(O, "cpu_probe.txt")):
     shutil.copy(os.path.join(O, "cpu_probe.txt"), os.path.join(P, "%s_cpu_probe.txt" % tag))
 md += ["", "## rocprofv3 --kernel-trace --stats of `python bench.py --no-cpu-baseline` (config3, 1 M loci per launch)", "", rocpd("stats_config3"),

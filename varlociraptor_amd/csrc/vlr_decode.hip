@@ -592,6 +592,8 @@ struct vlr_dev_file {
     hipStream_t stream = nullptr;
     hipStream_t feed_stream = nullptr;   // H2D of compressed members + inflate kernel: runs beside the decode of the previous chunk
     bool feed_pending = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the inflate kernel of the feed in flight (measurement: vlr_dev_file_inflate_seconds)
+    double inflate_s = 0.0;
     uint8_t* buf = nullptr;       // inflated stream: bytes [rd, wr) are buffered
     size_t cap = 0, rd = 0, wr = 0;
     uint8_t* spare = nullptr;     // the other half of the ping-pong (compaction never copies inside one allocation)
@@ -643,6 +645,8 @@ void vlr_dev_file_destroy(vlr_dev_file* f) {
     if (!f) return;
     (void)hipSetDevice(f->device);
     if (f->feed_stream) { (void)hipStreamSynchronize(f->feed_stream); (void)hipStreamDestroy(f->feed_stream); }
+    if (f->ev0) (void)hipEventDestroy(f->ev0);
+    if (f->ev1) (void)hipEventDestroy(f->ev1);
     if (f->stream) { (void)hipStreamSynchronize(f->stream); (void)hipStreamDestroy(f->stream); }
     void* all[] = {f->buf, f->spare, f->d_comp, f->d_blocks, f->d_status, f->d_anchor, f->d_landing, f->d_segbase, f->d_count, f->d_landc, f->d_starts, f->d_nout,
                    f->d_desc, f->d_host, f->d_fok, f->d_cold_off, f->d_cold};
@@ -652,6 +656,7 @@ void vlr_dev_file_destroy(vlr_dev_file* f) {
     delete f;
 }
 
+double vlr_dev_file_inflate_seconds(vlr_dev_file* f, int reset) { if (!f) return 0.0; const double v = f->inflate_s; if (reset) f->inflate_s = 0.0; return v; }
 uint64_t vlr_dev_file_buffered(const vlr_dev_file* f) { return f ? (uint64_t)(f->wr - f->rd) : 0; }
 void* vlr_dev_file_stream(vlr_dev_file* f) { return f ? (void*)f->stream : nullptr; }
 int vlr_dev_file_sync(vlr_dev_file* f) { VLR_HIP_OK(hipSetDevice(f->device)); VLR_HIP_OK(hipStreamSynchronize(f->stream)); return VLR_OK; }
@@ -692,8 +697,11 @@ int vlr_dev_file_feed(vlr_dev_file* f, const uint8_t* comp, size_t comp_bytes, c
     VLR_HIP_OK(hipMemcpyAsync(f->d_comp, comp, comp_bytes, hipMemcpyHostToDevice, st));
     VLR_HIP_OK(hipMemsetAsync(f->d_comp + comp_bytes, 0, 1024, st));
     VLR_HIP_OK(hipMemcpyAsync(f->d_blocks, blocks, (size_t)n_blocks * sizeof(vlr::InflateBlock), hipMemcpyHostToDevice, st));
+    if (!f->ev0) { (void)hipEventCreate(&f->ev0); (void)hipEventCreate(&f->ev1); }
+    if (f->ev0) (void)hipEventRecord(f->ev0, st);
     const int lrc = vlr_launch_inflate_kernel(f->d_comp, f->d_blocks, n_blocks, f->buf + f->wr, f->d_status, st);
     if (lrc != 0) return dfail(VLR_ERR_HIP, "inflate kernel launch failed (hip error %s%lld)", "", lrc);
+    if (f->ev1) (void)hipEventRecord(f->ev1, st);
     f->h_status.resize((size_t)n_blocks);
     VLR_HIP_OK(hipMemcpyAsync(f->h_status.data(), f->d_status, (size_t)n_blocks * sizeof(int), hipMemcpyDeviceToHost, st));
     f->pending_blocks = (size_t)n_blocks;
@@ -707,6 +715,7 @@ int vlr_dev_file_feed_wait(vlr_dev_file* f) {
     VLR_HIP_OK(hipSetDevice(f->device));
     VLR_HIP_OK(hipStreamSynchronize(f->feed_stream));
     f->feed_pending = false;
+    if (f->ev0 && f->ev1) { float ms = 0.0f; if (hipEventElapsedTime(&ms, f->ev0, f->ev1) == hipSuccess) f->inflate_s += (double)ms * 1e-3; }
     for (size_t i = 0; i < f->pending_blocks; ++i)
         if (f->h_status[i] != 0) return dfail(VLR_ERR_INVALID_ARGUMENT, "corrupt DEFLATE stream in a BGZF member (inflate status %s%lld)", "", (long long)f->h_status[i]);
     f->pending_blocks = 0;

@@ -83,6 +83,8 @@ uint64_t vlr_dev_file_buffered(const vlr_dev_file* f);
 int vlr_dev_file_feed(vlr_dev_file* f, const uint8_t* comp, size_t comp_bytes, const vlr::InflateBlock* blocks, int n_blocks, uint64_t inflated_bytes);
 // skip `bytes` (the BCF header) at the read position
 int vlr_dev_file_feed_wait(vlr_dev_file* f);
+// seconds the inflate kernels of this file ran (HIP events on the feed stream), summed since the last reset
+double vlr_dev_file_inflate_seconds(vlr_dev_file* f, int reset);
 int vlr_dev_file_skip(vlr_dev_file* f, uint64_t bytes);
 // split the buffered bytes into records (at most max_records), scan their INFO entries; *n_records complete records found,
 // rec_host[0..n) (array owned by the object, valid until the next split) their counts.  Synchronises the file's stream.

@@ -14,8 +14,12 @@
 //     of up to 64 bytes per instruction pair, with the period trick for overlapping matches (source index = i mod distance), and
 //     literals are single LDS byte stores of lane 0; 38 kB of LDS per wave = four members in flight per CU, one per SIMD (a single
 //     wave issues an instruction every 4-5 cycles at best: the ~150 instructions of a symbol, not the LDS latency, set its pace);
-//   * the table entry of the NEXT symbol is fetched before the bytes of the current match are copied (its position is known as soon as
-//     the distance's extra bits are), so the lookup latency hides behind the copy;
+//   * symbols are decoded in speculative batches: lane i decodes the symbol that WOULD start at bit i of the next 64 stream bits
+//     (literal/length lookup, extra bits, distance lookup, extra bits — two LDS round trips for 64 candidates at once) and leaves a
+//     32-bit token with the bits it takes; the wave then follows the chain of real symbol starts through the tokens with lane reads
+//     and executes them in order (about six symbols per batch in the observation files).  Codes longer than the table index are
+//     decoded bit by bit where the chain reaches them.  The first version of the loop — one symbol at a time, the table entry of the
+//     next symbol fetched before the bytes of the current match are copied — is kept (VLR_INFLATE_BATCH=0): the tests run both;
 //   * Huffman tables are built by all lanes (canonical codes from per-length ballots) into single-lookup tables whose entries
 //     already carry the length / distance base and extra-bit count; codes longer than the table index fall back to the canonical
 //     bit-serial walk;
@@ -25,12 +29,15 @@
 // host path, which checks it.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "vlr_gpuio.h"
 
 namespace vlr {
 namespace {
 
 constexpr int kLitBits = 10, kDistBits = 9, kClBits = 7;
+constexpr bool kInflateBatchDefault = true;   // speculative batches (VLR_INFLATE_BATCH=0: one symbol at a time, the cross-check)
 constexpr uint32_t kRing = 32768, kRingMask = kRing - 1, kFlush = 8192;   // flushed to HBM in 8 KiB pieces, each before the ring wraps onto it
 
 struct InflLds {
@@ -169,16 +176,41 @@ __device__ __forceinline__ int slow_symbol(Bits& b, const uint16_t* count, const
     return -1;
 }
 
+// the same walk on a value (the low 15 bits of v are the next stream bits)
+// (returns symbol | code length << 16, or -1)
+__device__ __forceinline__ int slow_symbol_v(uint32_t v, const uint16_t* count, const uint16_t* symorder) {
+    int code = 0, first = 0, index = 0;
+    for (int len = 1; len <= 15; ++len) {
+        code |= (int)((v >> (len - 1)) & 1u);
+        const int c = (int)uni(count[len]);
+        if (code - c < first) return (int)uni(symorder[index + (code - first)]) | (len << 16);
+        index += c; first += c;
+        first <<= 1; code <<= 1;
+    }
+    return -1;
+}
+// 32 stream bits at bit offset q (< 128) of the five dwords S0..S4
+// (five values, not an array: a select chain over an array in memory turns into an indexed scratch load)
+__device__ __forceinline__ uint32_t window_bits(uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3, uint32_t s4, uint32_t q) {
+    const bool b0 = (q & 32u) != 0, b1 = (q & 64u) != 0;
+    const uint32_t lo = b1 ? (b0 ? s3 : s2) : (b0 ? s1 : s0);
+    const uint32_t hi = b1 ? (b0 ? s4 : s3) : (b0 ? s2 : s1);
+    return __builtin_amdgcn_alignbit(hi, lo, q & 31u);
+}
+// token of one symbol: kind (2: 0 literal, 1 match, 2 end of block, 3 invalid) | stream bits it takes (6; 0 = not decodable by table
+// lookups alone) @2 | literal byte or match length (9) @8 | distance - 1 (15) @17
+__device__ __forceinline__ uint32_t make_token(uint32_t kind, uint32_t adv, uint32_t val, uint32_t dist) { return kind | (adv << 2) | (val << 8) | ((dist - 1u) << 17); }
+
 // ring position P (= shift + byte offset in the member) -> HBM: pieces [from, to) with from a multiple of 16 except at the member's start
-__device__ __forceinline__ void flush_ring(const InflLds& L, uint8_t* gbase, uint32_t from, uint32_t to, uint32_t sh, int lane) {
+__device__ __forceinline__ void flush_ring(const InflLds& L, uint8_t* gbase, uint32_t from, uint32_t to, int lane) {
     for (uint32_t k = (from & ~15u) + 16u * (uint32_t)lane; k < to; k += 1024u) {
         if (k >= from && k + 16 <= to) *reinterpret_cast<uint4*>(gbase + k) = *reinterpret_cast<const uint4*>(&L.out[k & kRingMask]);
         else
             for (uint32_t j = k < from ? from : k; j < k + 16 && j < to; ++j) gbase[j] = L.out[j & kRingMask];
     }
-    (void)sh;
 }
 
+template <bool BATCH>
 __global__ __launch_bounds__(64) void vlr_inflate_kernel(const uint8_t* __restrict__ comp, const InflateBlock* __restrict__ blocks, int n_blocks,
                                                         uint8_t* __restrict__ out, int* __restrict__ status) {
     __shared__ __attribute__((aligned(16))) InflLds L;
@@ -219,7 +251,7 @@ __global__ __launch_bounds__(64) void vlr_inflate_kernel(const uint8_t* __restri
                 const uint32_t piece = len - done < kFlush ? len - done : kFlush;
                 for (uint32_t k = (uint32_t)lane; k < piece; k += 64) L.out[(pos + k) & kRingMask] = p[done + k];
                 pos += piece; done += piece;
-                if (pos - flushed >= kFlush) { const uint32_t to = pos & ~(kFlush - 1); flush_ring(L, gbase, flushed, to, sh, lane); flushed = to; }
+                if (pos - flushed >= kFlush) { const uint32_t to = pos & ~(kFlush - 1); flush_ring(L, gbase, flushed, to, lane); flushed = to; }
             }
             bits_open(b, p + len, lane);
             continue;
@@ -288,11 +320,129 @@ __global__ __launch_bounds__(64) void vlr_inflate_kernel(const uint8_t* __restri
         // (One loop exit — every early exit of a multi-exit loop costs the structurised control flow a flag test per iteration — and one
         // rare branch: the position is compared with `next_stop`, the nearer of the next flush point and the member's end; a corrupt
         // stream that runs past the end is caught there, before anything beyond the member's bytes could go to HBM.)
-        refill(b, lane);
-        uint32_t e = uni(L.lit[peek(b, kLitBits)]);
         uint32_t bad = 0;
         bool done = false;
         uint32_t next_stop = flushed + kFlush + 512 < lim + 1 ? flushed + kFlush + 512 : lim + 1;
+        if (BATCH) {
+            // ---- speculative batches: lane i decodes the symbol that WOULD start at bit i of the next 64 stream bits — literal/length
+            // lookup, extra bits, distance lookup, extra bits: two LDS round trips for 64 candidates at once — and leaves a token with the
+            // bits it takes; then the wave follows the chain of real symbol starts through the tokens with lane reads (no memory latency
+            // on the serial path) and executes them in order.  A batch covers ~6 symbols of these files.
+            uint32_t bp = b.w * 32u - (uint32_t)b.cnt;   // bit position of the next symbol from b.g
+            uint32_t gi = bp >> 11;                        // 64-dword group of the window registers
+            uint32_t wcur = b.g[64u * gi + (uint32_t)lane], wnxt = b.g[64u * (gi + 1) + (uint32_t)lane];
+            do {
+                const uint32_t base = bp >> 5;
+                while ((base >> 6) != gi) { wcur = wnxt; gi += 1; wnxt = b.g[64u * (gi + 1) + (uint32_t)lane]; }
+                const uint32_t j0 = base - 64u * gi;   // 0 .. 63; dwords j0 .. j0 + 4 of the two window registers
+                auto dw = [&](uint32_t j) {
+                    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)wcur, (int)uni(j & 63u)), c = (uint32_t)__builtin_amdgcn_readlane((int)wnxt, (int)uni(j & 63u));
+                    return j < 64 ? a : c;
+                };
+                const uint32_t s0 = dw(j0), s1 = dw(j0 + 1), s2 = dw(j0 + 2), s3 = dw(j0 + 3), s4 = dw(j0 + 4);
+                const uint32_t q0 = bp & 31u;
+                uint32_t tok;
+                {
+                    const uint32_t q = q0 + (uint32_t)lane;
+                    const uint32_t v = window_bits(s0, s1, s2, s3, s4, q);
+                    const uint32_t e = L.lit[v & ((1u << kLitBits) - 1u)];
+                    const uint32_t cl = e & 15u, kind = (e >> 4) & 3u;
+                    const uint32_t xb = (e >> 20) & 7u;
+                    const uint32_t len = ((e >> 8) & 511u) + ((v >> cl) & ((1u << xb) - 1u));
+                    const uint32_t v2 = window_bits(s0, s1, s2, s3, s4, q + cl + xb);
+                    const uint32_t d = L.dist[v2 & ((1u << kDistBits) - 1u)];
+                    const uint32_t dl = d & 15u, dx = (d >> 4) & 15u;
+                    const uint32_t dist = (d >> 8) + ((v2 >> dl) & ((1u << dx) - 1u));
+                    const bool m_ok = dl != 0 && dx != 15u && dist != 0;
+                    const uint32_t adv = cl == 0 || kind == 3 ? 0u : kind == 1 ? (m_ok ? cl + xb + dl + dx : 0u) : cl;
+                    tok = kind == 1 ? make_token(1, adv, len, m_ok ? dist : 1u) : make_token(kind, adv, kind == 0 ? (e >> 8) & 255u : 0u, 1u);
+                }
+                uint32_t off = 0;
+                for (;;) {
+                    uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tok, (int)uni(off));
+                    if (__builtin_expect(((t >> 2) & 63u) == 0, 0)) {
+                        // a code longer than the table index (or an invalid one) starts here: decode this symbol bit by bit
+                        const uint32_t qu = q0 + off;
+                        const unsigned long long v64 = (unsigned long long)uni(window_bits(s0, s1, s2, s3, s4, qu)) | ((unsigned long long)uni(window_bits(s0, s1, s2, s3, s4, qu + 32)) << 32);
+                        uint32_t e = uni(L.lit[(uint32_t)v64 & ((1u << kLitBits) - 1u)]);
+                        int n = (int)(e & 15u);
+                        if (n == 0) {
+                            const int sl = slow_symbol_v((uint32_t)v64, L.lcount, L.lsym);
+                            e = sl < 0 ? (3u << 4) : make_entry<0>((uint32_t)sl & 0xffffu);
+                            n = sl < 0 ? 1 : sl >> 16;
+                        }
+                        const uint32_t kind = (e >> 4) & 3u;
+                        if (kind == 1) {
+                            const int xb = (int)((e >> 20) & 7u);
+                            const uint32_t len = ((e >> 8) & 511u) + ((uint32_t)(v64 >> n) & ((1u << xb) - 1u));
+                            n += xb;
+                            uint32_t d = uni(L.dist[(uint32_t)(v64 >> n) & ((1u << kDistBits) - 1u)]);
+                            int dl = (int)(d & 15u);
+                            if (dl == 0) {
+                                const int sl = slow_symbol_v((uint32_t)(v64 >> n), L.dcount, L.dsym);
+                                d = sl < 0 ? (15u << 4) : make_entry<1>((uint32_t)sl & 0xffffu);
+                                dl = sl < 0 ? 1 : sl >> 16;
+                            }
+                            n += dl;
+                            const int dx = (int)((d >> 4) & 15u);
+                            if (dx == 15) { bad |= (uint32_t)INFL_BAD_DISTANCE; t = make_token(3, 1, 0, 1); }
+                            else {
+                                const uint32_t dist = (d >> 8) + ((uint32_t)(v64 >> n) & ((1u << dx) - 1u));
+                                n += dx;
+                                t = make_token(1, (uint32_t)n, len, dist ? dist : 1u);
+                                if (dist == 0) bad |= (uint32_t)INFL_BAD_DISTANCE;
+                            }
+                        } else t = make_token(kind, (uint32_t)n, kind == 0 ? (e >> 8) & 255u : 0u, 1u);
+                    }
+                    const uint32_t kind = t & 3u, adv = (t >> 2) & 63u;
+                    if (kind == 0) {
+                        L.out[pos & kRingMask] = (uint8_t)((t >> 8) & 255u);
+                        pos += 1;
+                    } else if (kind == 1) {
+                        const uint32_t len = (t >> 8) & 511u, dist = (t >> 17) + 1u;
+                        bad |= (dist > pos - sh) ? (uint32_t)INFL_BAD_DISTANCE : 0u;
+                        const uint32_t from = pos - dist;
+                        const float rd = __builtin_amdgcn_rcpf((float)dist);
+                        if (len <= 64) {
+                            const uint32_t k = (uint32_t)lane;
+                            int r = (int)k - (int)((float)k * rd) * (int)dist;
+                            r = r < 0 ? r + (int)dist : r;
+                            r = r >= (int)dist ? r - (int)dist : r;
+                            const uint8_t vv = L.out[(from + (uint32_t)r) & kRingMask];
+                            if (k < len) L.out[(pos + k) & kRingMask] = vv;
+                        } else {
+                            for (uint32_t k = (uint32_t)lane; k < len; k += 64) {
+                                int r = (int)k - (int)((float)k * rd) * (int)dist;
+                                r = r < 0 ? r + (int)dist : r;
+                                r = r >= (int)dist ? r - (int)dist : r;
+                                L.out[(pos + k) & kRingMask] = L.out[(from + (uint32_t)r) & kRingMask];
+                            }
+                        }
+                        pos += len;
+                    } else {
+                        done = true;   // 2: end of block
+                        bad |= kind == 3 ? (uint32_t)INFL_BAD_SYMBOL : 0u;
+                    }
+                    off += adv;
+                    if (__builtin_expect(pos >= next_stop, 0)) {
+                        if (pos > lim) { bad |= (uint32_t)INFL_OUTPUT_OVERRUN << 8; done = true; }
+                        else if (bad) done = true;
+                        else if (pos - flushed >= kFlush + 512) { const uint32_t to = pos & ~(kFlush - 1); flush_ring(L, gbase, flushed, to, lane); flushed = to; }
+                        next_stop = flushed + kFlush + 512 < lim + 1 ? flushed + kFlush + 512 : lim + 1;
+                    }
+                    if (done || off >= 64) break;
+                }
+                bp += off;
+            } while (!done);
+            // back to the bit reader at bp (the block header of the next block is read through it)
+            b.w = bp >> 5;
+            b.cur = b.g[64u * (b.w >> 6) + (uint32_t)lane]; b.nxt = b.g[64u * ((b.w >> 6) + 1) + (uint32_t)lane];
+            b.buf = 0; b.cnt = 0;
+            refill(b, lane);
+            drop(b, (int)(bp & 31u));
+        } else {
+        refill(b, lane);
+        uint32_t e = uni(L.lit[peek(b, kLitBits)]);
         do {
             if (__builtin_expect((e & 15u) == 0, 0)) {
                 const int sym = slow_symbol(b, L.lcount, L.lsym);
@@ -350,16 +500,17 @@ __global__ __launch_bounds__(64) void vlr_inflate_kernel(const uint8_t* __restri
             if (__builtin_expect(pos >= next_stop, 0)) {
                 if (pos > lim) { bad |= (uint32_t)INFL_OUTPUT_OVERRUN << 8; done = true; }
                 else if (bad) done = true;
-                else if (pos - flushed >= kFlush + 512) { const uint32_t to = pos & ~(kFlush - 1); flush_ring(L, gbase, flushed, to, sh, lane); flushed = to; }
+                else if (pos - flushed >= kFlush + 512) { const uint32_t to = pos & ~(kFlush - 1); flush_ring(L, gbase, flushed, to, lane); flushed = to; }
                 next_stop = flushed + kFlush + 512 < lim + 1 ? flushed + kFlush + 512 : lim + 1;
             }
         } while (!done);
+        }
         if (pos > lim) bad |= (uint32_t)INFL_OUTPUT_OVERRUN << 8;
         if (bad) err = (bad >> 8) ? (int)(bad >> 8) : (int)(bad & 0xffu);
         if (err == INFL_OK && bits_used_end(b) > in_end) err = INFL_INPUT_OVERRUN;
     }
     if (err == INFL_OK && pos != lim) err = INFL_SIZE_MISMATCH;
-    if (err == INFL_OK && pos > flushed) flush_ring(L, gbase, flushed, pos, sh, lane);
+    if (err == INFL_OK && pos > flushed) flush_ring(L, gbase, flushed, pos, lane);
     if (lane == 0) status[blk] = err;
 }
 
@@ -368,6 +519,10 @@ __global__ __launch_bounds__(64) void vlr_inflate_kernel(const uint8_t* __restri
 
 extern "C" int vlr_launch_inflate_kernel(const uint8_t* d_comp, const vlr::InflateBlock* d_blocks, int n_blocks, uint8_t* d_out, int* d_status, void* stream) {
     if (n_blocks <= 0) return 0;
-    hipLaunchKernelGGL(vlr::vlr_inflate_kernel, dim3((unsigned)n_blocks), dim3(64), 0, (hipStream_t)stream, d_comp, d_blocks, n_blocks, d_out, d_status);
+    // VLR_INFLATE_BATCH=1: speculative batches of 64 candidate symbol starts; 0: one symbol at a time (read per launch: the tests run both)
+    const char* env = getenv("VLR_INFLATE_BATCH");
+    const bool batch = env ? atoi(env) != 0 : vlr::kInflateBatchDefault;
+    if (batch) hipLaunchKernelGGL(vlr::vlr_inflate_kernel<true>, dim3((unsigned)n_blocks), dim3(64), 0, (hipStream_t)stream, d_comp, d_blocks, n_blocks, d_out, d_status);
+    else hipLaunchKernelGGL(vlr::vlr_inflate_kernel<false>, dim3((unsigned)n_blocks), dim3(64), 0, (hipStream_t)stream, d_comp, d_blocks, n_blocks, d_out, d_status);
     return (int)hipGetLastError();
 }

@@ -1783,26 +1783,27 @@ int dev_stream_open(DevFileStream& f, const char* path, int device) {
 
 // members up to `want` buffered bytes onto the device
 int dev_stream_feed(DevFileStream& f, uint64_t want) {
-    while (f.more_blocks() && vlr_dev_file_buffered(f.dev) + (f.header_skipped ? 0 : 0) < want + (f.header_skipped ? 0 : f.header_bytes)) {
+    // (the header bytes in front of the first record are buffered like record bytes until they are skipped)
+    const auto goal = [&] { return want + (f.header_skipped ? 0 : (uint64_t)f.header_bytes); };
+    while (f.more_blocks() && vlr_dev_file_buffered(f.dev) < goal()) {
+        { const int rcw = vlr_dev_file_feed_wait(f.dev); if (rcw != VLR_OK) return rcw; }   // (f.ib is read by the copy in flight)
         const uint64_t have = vlr_dev_file_buffered(f.dev);
-        const uint64_t goal = want + (f.header_skipped ? 0 : f.header_bytes);
         const size_t b0 = f.next_block;
         size_t b1 = b0;
         uint64_t add = 0;
-        { const int rcw = vlr_dev_file_feed_wait(f.dev); if (rcw != VLR_OK) return rcw; }   // (f.ib is read by the copy in flight)
-        std::vector<vlr::InflateBlock>& ib = f.ib;
-        ib.clear();
-        while (b1 < f.blocks.size() && (have + add < goal || b1 == b0) && b1 - b0 < (1u << 20)) {
+        f.ib.clear();
+        while (b1 < f.blocks.size() && (have + add < goal() || b1 == b0) && b1 - b0 < (1u << 20)) {
             const BgzfBlock& k = f.blocks[b1];
             vlr::InflateBlock x;
             x.src = k.off - f.blocks[b0].off; x.dst = add; x.clen = (uint32_t)k.clen; x.isize = k.isize;
-            ib.push_back(x);
+            f.ib.push_back(x);
             add += k.isize;
             ++b1;
         }
+        // one contiguous piece of the file: from the first member's DEFLATE payload to the end of the last one's
         const uint8_t* comp = f.raw.p + f.blocks[b0].off;
         const size_t comp_bytes = (f.blocks[b1 - 1].off + f.blocks[b1 - 1].clen) - f.blocks[b0].off;
-        const int rc = vlr_dev_file_feed(f.dev, comp, comp_bytes, ib.data(), (int)ib.size(), add);
+        const int rc = vlr_dev_file_feed(f.dev, comp, comp_bytes, f.ib.data(), (int)f.ib.size(), add);
         g_dev_t[9] += (double)add; g_dev_t[10] += (double)comp_bytes;
         if (rc != VLR_OK) return rc;
         f.next_block = b1;
@@ -1829,6 +1830,7 @@ const char* rec_status_text(uint32_t st) {
 
 int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out) {
     const int S = (int)r->dfiles.size();
+    max_records = std::min<int64_t>(max_records, (int64_t)1 << 22);   // (per-request device buffers are sized by it; the caller just asks again)
     const double t_all0 = now_s();
     std::vector<int64_t> n_rec((size_t)S, 0);
     std::vector<const vlr::RecHost*> rh((size_t)S, nullptr);
@@ -1858,14 +1860,13 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
         }
         g_dev_t[3] += now_s() - t0;
         if (n > 0) break;
-        bool any_more = false, any_left = false;
-        for (int s = 0; s < S; ++s) { any_more = any_more || r->dfiles[(size_t)s]->more_blocks(); any_left = any_left || vlr_dev_file_buffered(r->dfiles[(size_t)s]->dev) > 0 || n_rec[(size_t)s] > 0; }
+        bool any_more = false;
+        for (int s = 0; s < S; ++s) any_more = any_more || r->dfiles[(size_t)s]->more_blocks();
         if (!any_more) {
             for (int s = 0; s < S; ++s) {
                 if (n_rec[(size_t)s] > 0) return ifail(VLR_ERR_INVALID_ARGUMENT, "inconsistent observations: %s holds more records than the other files (calling.rs:369-371)", r->paths[(size_t)s].c_str());
                 if (vlr_dev_file_buffered(r->dfiles[(size_t)s]->dev) > 0) return ifail(VLR_ERR_INVALID_ARGUMENT, "truncated BCF record in %s", r->paths[(size_t)s].c_str());
             }
-            (void)any_left;
             r->done = true;
             return VLR_OK;
         }
@@ -1964,7 +1965,6 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
     // ---- host side, while the columns come down: the cold records -> chunks -> table
     const double t_host0 = now_s();
     std::vector<SampleFile> files((size_t)S);
-    std::vector<std::string> errs((size_t)S);
     for (int s = 0; s < S; ++s) {
         DevFileStream& f = *r->dfiles[(size_t)s];
         SampleFile& sf = files[(size_t)s];
@@ -2057,6 +2057,7 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
     for (int s = 0; s < S; ++s) r->dfiles[(size_t)s]->delivered += L;
     g_dev_t[8] += now_s() - t_all0;
     g_dev_t[11] += (double)L;
+    for (int s = 0; s < S; ++s) g_dev_t[13] += vlr_dev_file_inflate_seconds(r->dfiles[(size_t)s]->dev, 1);
     return VLR_OK;
 }
 }  // namespace
