@@ -312,3 +312,45 @@ def test_device_reader_records_larger_than_a_segment_and_tiny_files(tmp_path):
         ingest.write_observations(p, mix, s)
         paths.append(p)
     _concat_check(_read_all(paths, None, 1 << 20), _read_all(paths, 0, 37))
+
+
+def test_device_reader_on_damaged_records(tmp_path):
+    """Bytes flipped INSIDE the inflated records (length words, typed descriptors, vector payloads), re-packed as valid BGZF: the device
+    reader must behave like the host reader — the same table or an error, never a crash, a hang or a silently different table."""
+    import gzip
+    from varlociraptor_amd import bcfio
+    cfg = synth.config3()
+    b = synth.generate(cfg, 40, seed=11)
+    p = str(tmp_path / "a.bcf")
+    ingest.write_observations(p, b, 0)
+    raw = bytearray(gzip.open(p, "rb").read())
+    l_text = struct.unpack_from("<I", raw, 5)[0]
+    first = 9 + l_text
+    rng = np.random.default_rng(12)
+    n_err = n_same = 0
+    for trial in range(60):
+        x = bytearray(raw)
+        # a handful of positions: the start of a record (length words / fixed fields) or anywhere behind the header
+        for _ in range(int(rng.integers(1, 4))):
+            at = int(rng.integers(first, len(x))) if trial % 3 else first + int(rng.integers(0, 64))
+            x[at] ^= int(rng.integers(1, 256))
+        q = str(tmp_path / ("d%d.bcf" % trial))
+        with open(q, "wb") as fh:
+            for o in range(0, len(x), 0xff00):
+                fh.write(bcfio._bgzf_block(bytes(x[o:o + 0xff00])))
+            fh.write(bcfio._BGZF_EOF)
+        try:
+            h = _read_all([q], None, 1 << 20)
+        except engine.EngineError:
+            h = None
+        try:
+            d = _read_all([q], 0, 1 << 20)
+        except engine.EngineError:
+            d = None
+        if h is None or d is None:
+            assert h is None and d is None, "trial %d: one reader refused the file, the other did not" % trial
+            n_err += 1
+        else:
+            _concat_check(h, d)
+            n_same += 1
+    assert n_err > 0 and n_same > 0

@@ -88,7 +88,7 @@ extern "C" int vlr_bgzf_inflate(int device, const void* bgzf, int64_t n_bytes, v
     uint8_t *d_comp = nullptr, *d_out = nullptr;
     vlr::InflateBlock* d_blocks = nullptr;
     int* d_status = nullptr;
-    const size_t pad = 1024;
+    const size_t pad = vlr::kInflateInputSlack;
     int rc = VLR_OK;
     std::vector<int> status(blocks.size(), -1);
     auto run = [&]() -> int {
@@ -304,6 +304,8 @@ __global__ void rec_scan_kernel(const uint8_t* __restrict__ base, const uint64_t
         if (status) break;
         const uint64_t n = vlen(rec + d.voff[FD_PROB_MAPPING], d.vstride[FD_PROB_MAPPING], d.vn[FD_PROB_MAPPING]);
         if (n > (1ull << 28)) { status |= REC_BAD_LENGTHS; break; }
+        // (a count the vector cannot hold — three words per element at least — is refused here, before the table is sized by it)
+        if ((uint64_t)d.vn[FD_PROB_MAPPING] < 4ull + 3ull * n) { status |= REC_BAD_VECTOR; break; }
         d.n_obs = (uint32_t)n;
     } while (false);
     uint32_t cold = 8 + 24, nci = 0;
@@ -684,8 +686,8 @@ int vlr_dev_file_feed(vlr_dev_file* f, const uint8_t* comp, size_t comp_bytes, c
         std::swap(f->buf, f->spare); std::swap(f->cap, f->spare_cap);
         f->rd = 0; f->wr = live;
     }
-    {   // compressed bytes and member list; the kernel reads up to 1 KiB beyond the last member
-        int rc = dev_grow(f->d_comp, f->comp_cap, comp_bytes + 1024);
+    {   // compressed bytes and member list; the kernel may read kInflateInputSlack bytes beyond the last member
+        int rc = dev_grow(f->d_comp, f->comp_cap, comp_bytes + vlr::kInflateInputSlack);
         if (rc) return rc;
         if ((size_t)n_blocks > f->blocks_cap) {
             size_t c1 = f->blocks_cap, c2 = f->blocks_cap;
@@ -695,7 +697,7 @@ int vlr_dev_file_feed(vlr_dev_file* f, const uint8_t* comp, size_t comp_bytes, c
         }
     }
     VLR_HIP_OK(hipMemcpyAsync(f->d_comp, comp, comp_bytes, hipMemcpyHostToDevice, st));
-    VLR_HIP_OK(hipMemsetAsync(f->d_comp + comp_bytes, 0, 1024, st));
+    VLR_HIP_OK(hipMemsetAsync(f->d_comp + comp_bytes, 0, vlr::kInflateInputSlack, st));
     VLR_HIP_OK(hipMemcpyAsync(f->d_blocks, blocks, (size_t)n_blocks * sizeof(vlr::InflateBlock), hipMemcpyHostToDevice, st));
     if (!f->ev0) { (void)hipEventCreate(&f->ev0); (void)hipEventCreate(&f->ev1); }
     if (f->ev0) (void)hipEventRecord(f->ev0, st);

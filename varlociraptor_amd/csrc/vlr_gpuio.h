@@ -13,6 +13,7 @@ struct InflateBlock {
     uint32_t clen;   // DEFLATE bytes (BSIZE + 1 - 18 - 8)
     uint32_t isize;  // inflated bytes (ISIZE, <= 65536)
 };
+constexpr size_t kInflateInputSlack = 32768;
 enum InflateStatus : int {
     INFL_OK = 0, INFL_BAD_BLOCK_TYPE = 1, INFL_BAD_STORED = 2, INFL_BAD_CODE_LENGTHS = 3, INFL_OVERSUBSCRIBED = 4, INFL_BAD_SYMBOL = 5,
     INFL_BAD_DISTANCE = 6, INFL_OUTPUT_OVERRUN = 7, INFL_INPUT_OVERRUN = 8, INFL_SIZE_MISMATCH = 9,
@@ -69,7 +70,8 @@ enum VlrObsField {
 static_assert(FD_N_VEC == vlr::kGpuVec, "field table");
 
 extern "C" {
-// vlr_inflate.hip: n_blocks BGZF members, one wave each.  d_comp must be readable 1 KiB beyond the last member (prefetch window).
+// vlr_inflate.hip: n_blocks BGZF members, one wave each.  d_comp must be readable kInflateInputSlack bytes beyond the last member (the
+// prefetch window, and the distance a corrupt stream can run before the kernel's next position check stops it).
 int vlr_launch_inflate_kernel(const uint8_t* d_comp, const vlr::InflateBlock* d_blocks, int n_blocks, uint8_t* d_out, int* d_status, void* stream);
 
 // vlr_decode.hip: one sample file's side of the device reader (buffers and stream owned by the object; see the .hip for the stages)

@@ -38,6 +38,8 @@ namespace {
 
 constexpr int kLitBits = 10, kDistBits = 9, kClBits = 7;
 constexpr bool kInflateBatchDefault = true;   // speculative batches (VLR_INFLATE_BATCH=0: one symbol at a time, the cross-check)
+// a corrupt stream is noticed at the next position check (every 8.7 KiB of output at most = 16.3 KiB of input at 15 bits per symbol):
+// the compressed bytes handed to the kernel must be readable this far beyond the last member (vlr_gpuio.h kInflateInputSlack)
 constexpr uint32_t kRing = 32768, kRingMask = kRing - 1, kFlush = 8192;   // flushed to HBM in 8 KiB pieces, each before the ring wraps onto it
 
 struct InflLds {
@@ -427,6 +429,7 @@ __global__ __launch_bounds__(64) void vlr_inflate_kernel(const uint8_t* __restri
                     if (__builtin_expect(pos >= next_stop, 0)) {
                         if (pos > lim) { bad |= (uint32_t)INFL_OUTPUT_OVERRUN << 8; done = true; }
                         else if (bad) done = true;
+                        else if ((const uint8_t*)b.g + ((bp + off) >> 3) > in_end + 8) { bad |= (uint32_t)INFL_INPUT_OVERRUN << 8; done = true; }   // (a corrupt stream must not read far beyond its member: kInputSlack)
                         else if (pos - flushed >= kFlush + 512) { const uint32_t to = pos & ~(kFlush - 1); flush_ring(L, gbase, flushed, to, lane); flushed = to; }
                         next_stop = flushed + kFlush + 512 < lim + 1 ? flushed + kFlush + 512 : lim + 1;
                     }
@@ -500,6 +503,7 @@ __global__ __launch_bounds__(64) void vlr_inflate_kernel(const uint8_t* __restri
             if (__builtin_expect(pos >= next_stop, 0)) {
                 if (pos > lim) { bad |= (uint32_t)INFL_OUTPUT_OVERRUN << 8; done = true; }
                 else if (bad) done = true;
+                else if (bits_used_end(b) > in_end + 8) { bad |= (uint32_t)INFL_INPUT_OVERRUN << 8; done = true; }
                 else if (pos - flushed >= kFlush + 512) { const uint32_t to = pos & ~(kFlush - 1); flush_ring(L, gbase, flushed, to, lane); flushed = to; }
                 next_stop = flushed + kFlush + 512 < lim + 1 ? flushed + kFlush + 512 : lim + 1;
             }
