@@ -637,7 +637,14 @@ int vlr_dev_file_create(int device, vlr_dev_file** out) {
     VLR_HIP_OK(hipSetDevice(device));
     vlr_dev_file* f = new vlr_dev_file();
     f->device = device;
-    if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&f->feed_stream, hipStreamNonBlocking) != hipSuccess) { delete f; return dfail(VLR_ERR_HIP, "hipStreamCreate failed"); }
+    // the feed stream (upload + inflate of the NEXT request) yields to everything that works on the current chunk: the decode kernels
+    // of this reader and the caller's evaluation wait for nobody behind a prefetch
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // (numerically: lowest priority first)
+    if (hipStreamCreateWithPriority(&f->stream, hipStreamNonBlocking, prio_hi) != hipSuccess || hipStreamCreateWithPriority(&f->feed_stream, hipStreamNonBlocking, prio_lo) != hipSuccess) {
+        delete f;
+        return dfail(VLR_ERR_HIP, "hipStreamCreate failed");
+    }
     if (hipMalloc(&f->d_nout, 8) != hipSuccess) { (void)hipStreamDestroy(f->stream); delete f; return dfail(VLR_ERR_OUT_OF_MEMORY, "device reader: out of device memory"); }
     *out = f;
     return VLR_OK;
