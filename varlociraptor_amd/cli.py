@@ -199,6 +199,16 @@ class _PinnedResults:
                 self.free.append(block)
 
 
+_RESULT_POOL = None
+
+
+def _shared_result_pool():
+    global _RESULT_POOL
+    if _RESULT_POOL is None:
+        _RESULT_POOL = _PinnedResults()
+    return _RESULT_POOL
+
+
 def _fixed_fields(res):
     """Copy of the fixed-size result fields (the AFD lists stay with the chunk's own buffers)."""
     out = CallResults(res.n_loci, res.n_out, res.n_samples, 0)
@@ -267,7 +277,8 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
         pass
     plans: Dict[tuple, "engine.Plan"] = {}   # one plan per scenario signature, kept across the chunks of a run
     FIELDS = ("ln_posterior", "ln_marginal", "map_vaf", "map_bias", "best_event", "status", "afd_count", "afd_vaf", "afd_lnprob")
-    result_pool = _PinnedResults() if (native and processor is None and rank == 0 and world == 1 and output) else None
+    # (one pool per process: page-locking its blocks again for every run costs tens of milliseconds)
+    result_pool = _shared_result_pool() if (native and processor is None and rank == 0 and world == 1 and output) else None
 
     # Breakend events whose first record sat in an EARLIER chunk of the streaming reader: the reference hands the first breakend's
     # event probabilities and sample infos to every later record of the event across the whole file (calling.rs:569-580,

@@ -26,6 +26,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -614,6 +615,8 @@ struct vlr_dev_file {
 };
 
 namespace {
+std::mutex& park_mutex() { static std::mutex m; return m; }
+std::vector<vlr_dev_file*>& parked() { static auto* v = new std::vector<vlr_dev_file*>(); return *v; }   // (never destroyed: no HIP calls at exit)
 template <typename T>
 int dev_grow(T*& p, size_t& cap, size_t need, size_t slack_num = 5, size_t slack_den = 4) {
     if (need <= cap) return VLR_OK;
@@ -635,6 +638,19 @@ int vlr_dev_file_create(int device, vlr_dev_file** out) {
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return dfail(VLR_ERR_NO_DEVICE, "no HIP device (the device reader has no host fallback)");
     if (device < 0 || device >= n) return dfail(VLR_ERR_INVALID_ARGUMENT, "device index out of range");
     VLR_HIP_OK(hipSetDevice(device));
+    {   // a parked object of an earlier reader: its streams, events and (grown) buffers are taken over
+        std::lock_guard<std::mutex> g(park_mutex());
+        auto& park = parked();
+        for (size_t i = 0; i < park.size(); ++i)
+            if (park[i]->device == device) {
+                vlr_dev_file* f = park[i];
+                park.erase(park.begin() + (long)i);
+                f->rd = f->wr = 0; f->feed_pending = false; f->pending_blocks = 0; f->n_split = 0; f->inflate_s = 0.0;
+                f->fok_n = -1;   // (the key table of the new file is uploaded at its first split)
+                *out = f;
+                return VLR_OK;
+            }
+    }
     vlr_dev_file* f = new vlr_dev_file();
     f->device = device;
     // the feed stream (upload + inflate of the NEXT request) yields to everything that works on the current chunk: the decode kernels
@@ -653,7 +669,14 @@ int vlr_dev_file_create(int device, vlr_dev_file** out) {
 void vlr_dev_file_destroy(vlr_dev_file* f) {
     if (!f) return;
     (void)hipSetDevice(f->device);
-    if (f->feed_stream) { (void)hipStreamSynchronize(f->feed_stream); (void)hipStreamDestroy(f->feed_stream); }
+    if (f->feed_stream) (void)hipStreamSynchronize(f->feed_stream);
+    if (f->stream) (void)hipStreamSynchronize(f->stream);
+    {   // parked for the next reader of this process (a handful at most): allocating and freeing half a gigabyte of device buffers per
+        // file costs milliseconds and hipFree synchronises the device
+        std::lock_guard<std::mutex> g(park_mutex());
+        if (parked().size() < 8) { parked().push_back(f); return; }
+    }
+    if (f->feed_stream) (void)hipStreamDestroy(f->feed_stream);
     if (f->ev0) (void)hipEventDestroy(f->ev0);
     if (f->ev1) (void)hipEventDestroy(f->ev1);
     if (f->stream) { (void)hipStreamSynchronize(f->stream); (void)hipStreamDestroy(f->stream); }
