@@ -404,8 +404,7 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
             # cross PCIe, the columns are born in device memory and the evaluation reads them there.  Files it does not read (plain
             # gzip, uncompressed BCF) go to the host reader.
             try:
-                big = sum(os.path.getsize(p_) for p_ in paths) > (1 << 30)   # (chunks bound the pipeline's fill and drain: smaller for small files)
-                reader = vingest.ObsReader(paths, omit_bias_mask=omit_mask, chunk_records=int(os.environ.get("VLR_CLI_CHUNK", "0")) or (32768 if big else 16384), device=device,
+                reader = vingest.ObsReader(paths, omit_bias_mask=omit_mask, chunk_records=int(os.environ.get("VLR_CLI_CHUNK", "0")) or 32768, device=device,
                                            # VLR_INGEST_SUMMARIES=1: the observation columns stay on the device and the calls writer formats from per-pileup
                                            # summaries (vlr_obs_reader_set_host_columns; pays off when pileups have few distinct observation keys — the
                                            # synthetic bench pileups have almost one per observation and fall back to the columns)
