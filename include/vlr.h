@@ -526,6 +526,11 @@ int  vlr_obs_table_device_batch(const vlr_obs_table* table, vlr_batch* out);  /*
  * that itself where it has to).  Default: keep. */
 int  vlr_obs_reader_set_host_columns(vlr_obs_reader* reader, int keep);
 int  vlr_obs_table_fetch_columns(vlr_obs_table* table);
+/* on != 0: vlr_obs_reader_next of this device reader returns while the copy of the observation columns to the host side of the
+ * table is still in flight (the device side, what vlr_batch_run_device_in evaluates, is complete).  vlr_calls_writer_append and
+ * vlr_obs_table_fetch_columns wait for it; a caller that reads the observation arrays of vlr_obs_table_batch itself calls
+ * vlr_obs_table_fetch_columns first.  Default: off. */
+int  vlr_obs_reader_set_async_columns(vlr_obs_reader* reader, int on);
 /* The inflate stage alone, host buffers in and out (tests, tools): `bgzf` is a sequence of BGZF members (SAM spec 4.1), *out_bytes
  * receives the sum of their ISIZE fields (also when out_capacity is too small: VLR_ERR_INVALID_ARGUMENT then). */
 int  vlr_bgzf_inflate(int device, const void* bgzf, int64_t n_bytes, void* out, int64_t out_capacity, int64_t* out_bytes);

@@ -354,3 +354,37 @@ def test_device_reader_on_damaged_records(tmp_path):
             _concat_check(h, d)
             n_same += 1
     assert n_err > 0 and n_same > 0
+
+
+def test_async_columns_are_there_when_they_are_read(tmp_path):
+    """async_columns=True: next() returns while the column copy to the host is in flight; fetch_columns() and the calls writer wait."""
+    from varlociraptor_amd import callsfmt
+    cfg = synth.config3()
+    b = synth.generate(cfg, 6000, seed=41)
+    paths = []
+    for s in range(b.n_samples):
+        p = str(tmp_path / ("s%d.bcf" % s))
+        ingest.write_observations(p, b, s)
+        paths.append(p)
+    host = _read_all(paths, None, 1 << 20)
+    rd = ingest.ObsReader(paths, chunk_records=2000, device=0, async_columns=True)
+    chunks, tables = [], []
+    plan = engine.Plan(cfg.scenario, device=0)
+    names = cfg.scenario.out_names()
+    out = str(tmp_path / "calls.vcf")
+    w = None
+    for db, sites in rd:
+        t = db.extra["native_table"]
+        res = plan.call_table_device(t, afd_capacity=8)
+        if w is None:
+            w = ingest.CallsWriter(out, callsfmt.header(names, cfg.scenario.sample_names, list(sites.contig_names)))
+        w.append(t, res, names)          # (waits for the columns of this table)
+        t.fetch_columns()
+        chunks.append((db, sites))
+    w.close()
+    _concat_check(host, chunks)
+    ref = plan.call_host(host[0][0], afd_capacity=8)
+    h = str(tmp_path / "host.vcf")
+    ingest.write_calls(h, callsfmt.header(names, cfg.scenario.sample_names, list(host[0][1].contig_names)), host[0][0].extra["native_table"], ref, names)
+    assert open(h).read() == open(out).read()
+    rd.close(); plan.close()

@@ -408,7 +408,9 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                                            # VLR_INGEST_SUMMARIES=1: the observation columns stay on the device and the calls writer formats from per-pileup
                                            # summaries (vlr_obs_reader_set_host_columns; pays off when pileups have few distinct observation keys — the
                                            # synthetic bench pileups have almost one per observation and fall back to the columns)
-                                           host_columns=(processor is not None or candidate_filter is not None or os.environ.get("VLR_INGEST_SUMMARIES", "0") != "1"))
+                                           host_columns=(processor is not None or candidate_filter is not None or os.environ.get("VLR_INGEST_SUMMARIES", "0") != "1"),
+                                           # the evaluation reads the device side of a table; only the writer (which waits) needs the host copy of the columns
+                                           async_columns=(processor is None and candidate_filter is None))
             except engine.EngineError as ex:
                 if ex.code != abi.ERR_UNSUPPORTED:
                     raise

@@ -121,8 +121,11 @@ namespace {
 constexpr uint32_t kSeg = 65536;                       // bytes of the inflated stream per anchor / walk lane
 constexpr uint64_t kNone = ~0ull;
 
-__device__ __forceinline__ uint32_t ld16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
-__device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+// (records start at arbitrary byte offsets of the inflated stream; gfx950 global loads take unaligned addresses, and the compiler emits
+// one load for these copies — byte-wise loads made the decode kernel request-bound in L2)
+__device__ __forceinline__ uint32_t ld16(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
+__device__ __forceinline__ uint32_t ld32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ uint64_t ld64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 
 // the fixed part of a BCF2 record header at offset o of the stream looks like one (necessary conditions of every record this
 // reader accepts; NOT sufficient — the walk verifies every guess)
@@ -364,9 +367,33 @@ __global__ __launch_bounds__(64) void rec_decode_kernel(const uint8_t* __restric
         } else {
             uint32_t j = 8;
             for (uint32_t i = 0; i < n; ++i) {
+                // bytes j .. j + 8 of the little-endian word stream (zero beyond its end)
+                uint64_t lo;
+                uint32_t b8;
+                if (stride == 4) {          // u16 words in the low halves of five consecutive int32 elements: one 16-byte and one 4-byte load
+                    const uint8_t* q = v + 4 * (size_t)(j >> 1);
+                    const uint64_t a = ld64(q), c = ld64(q + 8);
+                    const uint32_t w4 = ld32(q + 16);
+                    const uint64_t W = (a & 0xffffull) | ((a >> 16) & 0xffff0000ull) | ((c & 0xffffull) << 32) | ((c >> 32 & 0xffffull) << 48);
+                    lo = (j & 1u) ? (W >> 8) | ((uint64_t)(w4 & 0xffu) << 56) : W;
+                    b8 = (j & 1u) ? (w4 >> 8) & 0xffu : w4 & 0xffu;
+                } else if (stride == 2) {   // the words are the bytes
+                    lo = ld64(v + j);
+                    b8 = v[j + 8];
+                } else {
+                    lo = 0;
+                    for (int t = 0; t < 8; ++t) lo |= (uint64_t)vbyte(v, stride, j + (uint32_t)t) << (8 * t);
+                    b8 = vbyte(v, stride, j + 8);
+                }
+                {
+                    const uint32_t left = nbytes - j;   // (j < nbytes here: the previous element ended inside the stream, or n would be 0)
+                    if (left < 8) lo &= (1ull << (8 * left)) - 1ull;
+                    if (left < 9) b8 = 0;
+                }
                 uint32_t b[9];
 #pragma unroll
-                for (int t = 0; t < 9; ++t) b[t] = (j + (uint32_t)t < nbytes) ? vbyte(v, stride, j + (uint32_t)t) : 0u;
+                for (int t = 0; t < 8; ++t) b[t] = (uint32_t)(lo >> (8 * t)) & 0xffu;
+                b[8] = b8;
                 const uint32_t o = kind == 0 ? 0u : 1u;
                 const bool some = kind == 0 ? true : b[0] != 0;
                 uint32_t size, val = none;
@@ -423,7 +450,12 @@ __global__ __launch_bounds__(64) void rec_decode_kernel(const uint8_t* __restric
         if (ok) {
             for (uint32_t i = (uint32_t)lane; i < n; i += 64) {
                 uint32_t e[4];
-                for (int k = 0; k < 4; ++k) e[k] = vword(ev[k], es[k], 4 + 2 * i) | (vword(ev[k], es[k], 5 + 2 * i) << 16);
+                for (int k = 0; k < 4; ++k) {
+                    if (es[k] == 4) {   // the two words of the u32 in one 8-byte load
+                        const uint64_t x = ld64(ev[k] + 4 * (size_t)(4 + 2 * i));
+                        e[k] = (uint32_t)(x & 0xffffull) | (uint32_t)((x >> 32) & 0xffffull) << 16;
+                    } else e[k] = vword(ev[k], es[k], 4 + 2 * i) | (vword(ev[k], es[k], 5 + 2 * i) << 16);
+                }
                 uint32_t fl = (e[0] & 3u) << VLR_F_STRAND_SHIFT;
                 const uint32_t orient = e[1] == 0 ? VLR_ORIENT_F1R2 : e[1] == 1 ? VLR_ORIENT_F2R1 : e[1] == 8 ? VLR_ORIENT_NONE : VLR_ORIENT_OTHER;
                 fl |= orient << VLR_F_ORIENT_SHIFT;
@@ -594,6 +626,7 @@ struct vlr_dev_file {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t feed_stream = nullptr;   // H2D of compressed members + inflate kernel: runs beside the decode of the previous chunk
+    hipStream_t copy_stream = nullptr;   // column copies the caller does not wait for (vlr_dev_file_copy_detached)
     bool feed_pending = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the inflate kernel of the feed in flight (measurement: vlr_dev_file_inflate_seconds)
     double inflate_s = 0.0;
@@ -671,12 +704,14 @@ void vlr_dev_file_destroy(vlr_dev_file* f) {
     (void)hipSetDevice(f->device);
     if (f->feed_stream) (void)hipStreamSynchronize(f->feed_stream);
     if (f->stream) (void)hipStreamSynchronize(f->stream);
+    if (f->copy_stream) (void)hipStreamSynchronize(f->copy_stream);
     {   // parked for the next reader of this process (a handful at most): allocating and freeing half a gigabyte of device buffers per
         // file costs milliseconds and hipFree synchronises the device
         std::lock_guard<std::mutex> g(park_mutex());
         if (parked().size() < 8) { parked().push_back(f); return; }
     }
     if (f->feed_stream) (void)hipStreamDestroy(f->feed_stream);
+    if (f->copy_stream) (void)hipStreamDestroy(f->copy_stream);
     if (f->ev0) (void)hipEventDestroy(f->ev0);
     if (f->ev1) (void)hipEventDestroy(f->ev1);
     if (f->stream) { (void)hipStreamSynchronize(f->stream); (void)hipStreamDestroy(f->stream); }
@@ -912,6 +947,33 @@ int vlr_dev_copy_to_host(int device, void* dst, const void* src, size_t bytes) {
     VLR_HIP_OK(hipSetDevice(device));
     VLR_HIP_OK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return VLR_OK;
+}
+
+// device -> host copy on the file's copy stream, NOT waited for by vlr_dev_file_sync: *event_out (owned by the caller:
+// vlr_dev_event_wait / vlr_dev_event_destroy) completes when the bytes are there.  The source must be final (the caller synchronised the
+// streams that wrote it).
+int vlr_dev_file_copy_detached(vlr_dev_file* f, void* dst, const void* src, size_t bytes, void** event_out) {
+    *event_out = nullptr;
+    VLR_HIP_OK(hipSetDevice(f->device));
+    if (!f->copy_stream) VLR_HIP_OK(hipStreamCreateWithFlags(&f->copy_stream, hipStreamNonBlocking));
+    hipEvent_t ev = nullptr;
+    VLR_HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    if (bytes) VLR_HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, f->copy_stream));
+    VLR_HIP_OK(hipEventRecord(ev, f->copy_stream));
+    *event_out = (void*)ev;
+    return VLR_OK;
+}
+int vlr_dev_event_wait(int device, void* event) {
+    if (!event) return VLR_OK;
+    VLR_HIP_OK(hipSetDevice(device));
+    VLR_HIP_OK(hipEventSynchronize((hipEvent_t)event));
+    return VLR_OK;
+}
+void vlr_dev_event_destroy(int device, void* event) {
+    if (!event) return;
+    (void)hipSetDevice(device);
+    (void)hipEventSynchronize((hipEvent_t)event);
+    (void)hipEventDestroy((hipEvent_t)event);
 }
 
 int vlr_dev_slab_alloc(int device, size_t bytes, void** d, void** h) {

@@ -110,6 +110,10 @@ int vlr_dev_file_summaries(vlr_dev_file* f, const vlr::DeviceCols* cols, const u
                            const vlr::SumConsts* k, vlr::PileSum* d_hdr, uint64_t* d_ent_key, uint32_t* d_ent_cnt, float* d_run_pm, uint32_t* d_run_len, uint32_t* d_cursor);
 // synchronous device -> host copy outside any stream (lazy fetch of a table's columns)
 int vlr_dev_copy_to_host(int device, void* dst, const void* src, size_t bytes);
+// device -> host copy nobody waits for until vlr_dev_event_wait(*event_out) (the caller owns the event)
+int vlr_dev_file_copy_detached(vlr_dev_file* f, void* dst, const void* src, size_t bytes, void** event_out);
+int vlr_dev_event_wait(int device, void* event);
+void vlr_dev_event_destroy(int device, void* event);
 // column storage of a table: `bytes` of device memory and as many page-locked host bytes
 int vlr_dev_slab_alloc(int device, size_t bytes, void** d, void** h);
 void vlr_dev_slab_free(int device, void* d, void* h);

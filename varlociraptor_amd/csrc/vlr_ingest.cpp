@@ -1208,6 +1208,8 @@ struct vlr_obs_table {
     bool has_dev = false;
     int device = 0;
     bool cols_on_host = true;      // false: the observation columns were not copied down (vlr_obs_table_fetch_columns does it on demand)
+    void* cols_event = nullptr;    // the copy of the columns is still in flight (reader option async columns): wait_columns() before reading them
+    std::mutex cols_mu;
     size_t col_region_off = 0, col_region_bytes = 0;   // the column arrays inside the slab (both sides)
     // observation summaries of the device reader (vlr::PileSum): what the calls writer needs per pileup instead of the columns.
     // They live in the host side of the column region until the columns are fetched over them.
@@ -1217,7 +1219,16 @@ struct vlr_obs_table {
     const uint32_t* sum_cnt = nullptr;
     const float* sum_run_pm = nullptr;
     const uint32_t* sum_run_len = nullptr;
+    int wait_columns() {
+        std::lock_guard<std::mutex> g(cols_mu);
+        if (!cols_event) return VLR_OK;
+        const int rc = vlr_dev_event_wait(device, cols_event);
+        vlr_dev_event_destroy(device, cols_event);
+        cols_event = nullptr;
+        return rc;
+    }
     ~vlr_obs_table() {
+        if (cols_event) vlr_dev_event_destroy(device, cols_event);   // (waits: the slab must not be recycled under a copy)
         if (dev_pool) dev_pool->release(slab);
         Arr* all[] = {&a_off, &a_col[0], &a_col[1], &a_col[2], &a_col[3], &a_col[4], &a_col[5], &a_col[6], &a_col[7], &a_col[8],
                       &a_flags, &a_lflags, &a_vt, &a_ref, &a_alt, &a_third};
@@ -1661,6 +1672,7 @@ struct vlr_obs_reader {
     std::vector<std::unique_ptr<DevFileStream>> dfiles;
     std::shared_ptr<DevPool> pool;
     bool host_columns = true;       // vlr_obs_reader_set_host_columns
+    bool async_columns = false;     // vlr_obs_reader_set_async_columns: next() returns while the column copy to the host is in flight
     bool summaries_off = false;     // a chunk had pileups with more distinct observation keys than the summary kernel keeps: columns from then on
     DevSlab sum_scratch;            // device side only in use: summary headers, entries, runs, cursors of the chunk being built
 };
@@ -1893,7 +1905,9 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
     }
     uint8_t* d = (uint8_t*)slab.d;
     uint8_t* h = (uint8_t*)slab.h;
-    auto fail = [&](int rc) { r->pool->release(slab); return rc; };
+    void* cols_event = nullptr;   // (detached copy of the columns, async_columns)
+    auto drop_event = [&] { if (cols_event) { vlr_dev_event_destroy(r->device, cols_event); cols_event = nullptr; } };
+    auto fail = [&](int rc) { drop_event(); r->pool->release(slab); return rc; };
     const double t_dec0 = now_s();
     {   // offsets up (every decode kernel reads them), then the files side by side on their own streams
         DevFileStream& f0 = *r->dfiles[0];
@@ -1959,7 +1973,8 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
     const bool summaries = !r->host_columns && !r->summaries_off && sum_need <= dl.off_lflags - dl.off_col[0];
     if (!summaries) {   // columns down for the calls writer (one copy: the column arrays are contiguous in the slab)
         DevFileStream& f0 = *r->dfiles[0];
-        const int rc = vlr_dev_file_copy(f0.dev, h + dl.off_col[0], d + dl.off_col[0], dl.off_lflags - dl.off_col[0], 0);
+        const int rc = r->async_columns ? vlr_dev_file_copy_detached(f0.dev, h + dl.off_col[0], d + dl.off_col[0], dl.off_lflags - dl.off_col[0], &cols_event)
+                                        : vlr_dev_file_copy(f0.dev, h + dl.off_col[0], d + dl.off_col[0], dl.off_lflags - dl.off_col[0], 0);
         if (rc != VLR_OK) return fail(rc);
     }
     // ---- host side, while the columns come down: the cold records -> chunks -> table
@@ -1992,7 +2007,10 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
     for (auto& p : r->paths) pp.push_back(p.c_str());
     // (build_table writes obs_offset and the per-locus arrays into the host side of the slab)
     int rc = build_table(files, pp.data(), r->omit, r->n_threads, out, &dl, r->pool, &slab);
-    if (rc != VLR_OK) { if (slab.d) r->pool->release(slab); return rc; }
+    if (rc != VLR_OK) { drop_event(); if (slab.d) r->pool->release(slab); return rc; }
+    (*out)->device = r->device;
+    (*out)->cols_event = cols_event;   // (the table waits for it where its columns are read, and before its slab goes back to the pool)
+    cols_event = nullptr;
     g_dev_t[7] += now_s() - t_host0;
     {
         DevFileStream& f0 = *r->dfiles[0];
@@ -2096,8 +2114,15 @@ int vlr_obs_reader_set_host_columns(vlr_obs_reader* r, int keep) {
     return VLR_OK;
 }
 
+int vlr_obs_reader_set_async_columns(vlr_obs_reader* r, int on) {
+    if (!r) return ifail(VLR_ERR_INVALID_ARGUMENT, "null reader");
+    r->async_columns = on != 0;
+    return VLR_OK;
+}
+
 int vlr_obs_table_fetch_columns(vlr_obs_table* t) {
     if (!t) return ifail(VLR_ERR_INVALID_ARGUMENT, "null table");
+    { const int rcw = t->wait_columns(); if (rcw != VLR_OK) return rcw; }
     if (t->cols_on_host) return VLR_OK;
     // (the summaries live where the columns go: they are gone afterwards, the writer then counts from the columns)
     t->has_summary = false;
@@ -2514,6 +2539,7 @@ static int calls_write_impl(FILE* out_file, bool bcf, bool with_header, bool wit
     n_threads = pick_threads(n_threads);
     const int S = t->n_samples, n_out = r->n_out;
     const int64_t L = t->n_loci;
+    { const int rcw = const_cast<vlr_obs_table*>(t)->wait_columns(); if (rcw != VLR_OK) return rcw; }   // (a device reader with async columns)
     if (t->has_summary) {   // a pileup with more distinct observation keys than the kernel keeps: count from the columns instead
         bool over = false;
         for (int64_t p = 0; p < L * S && !over; ++p) over = t->sum_hdr[p].overflow != 0;

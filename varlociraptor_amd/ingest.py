@@ -202,7 +202,7 @@ class ObsReader:
     """vlr_obs_reader: the observation files a bounded number of records at a time.  Iterating yields (PileupBatch, Sites)."""
 
     def __init__(self, paths: Sequence[str], omit_bias_mask: int = 0, threads: int = 0, chunk_records: int = 250_000, device: Optional[int] = None,
-                 host_columns: bool = True):
+                 host_columns: bool = True, async_columns: bool = False):
         """device = None: the host reader.  device = k: vlr_obs_reader_open_device — BGZF inflate, record split and v15 decode as kernels on
         device k; the tables then also hold the batch in device memory (ObsTable.device_batch)."""
         L = _lib()
@@ -221,6 +221,12 @@ class ObsReader:
             _check(L.vlr_obs_reader_open(len(paths), arr, int(omit_bias_mask), int(threads), C.byref(h)))
         else:
             _check(L.vlr_obs_reader_open_device(int(device), len(paths), arr, int(omit_bias_mask), int(threads), C.byref(h)))
+            if async_columns:
+                # next() returns while the columns are still on their way to the host (the device batch is complete): the calls writer and
+                # ObsTable.fetch_columns() wait for them; do not read the numpy views of the columns before fetch_columns()
+                L.vlr_obs_reader_set_async_columns.restype = C.c_int
+                L.vlr_obs_reader_set_async_columns.argtypes = [C.c_void_p, C.c_int]
+                _check(L.vlr_obs_reader_set_async_columns(h, 1))
             if not host_columns:
                 # the observation columns stay on the device; the calls writer gets per-pileup summaries (vlr_obs_reader_set_host_columns).
                 # ObsTable.fetch_columns() fills the numpy views of the columns on demand.
