@@ -188,6 +188,27 @@ def test_no_device_is_an_error_not_a_fallback():
     assert ei.value.code == abi.ERR_NO_DEVICE
 
 
+def test_device_front_door_without_a_device_is_an_error_not_a_fallback(golden_dir):
+    """vlr_obs_reader_open_device and vlr_bgzf_inflate have no host path behind them: without a GPU they fail (the host reader is a
+    separate entry point the caller chooses); a file the device reader does not take is refused before any device call."""
+    import torch
+    from varlociraptor_amd import ingest
+    d = os.path.join(golden_dir, "flamegraph_profiling")
+    with pytest.raises(engine.EngineError) as ei:   # text VCF: not BGZF-compressed BCF, whatever the machine
+        ingest.ObsReader([os.path.join(d, "normal.vcf")], device=0)
+    assert ei.value.code == abi.ERR_UNSUPPORTED
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(engine.EngineError) as ei:
+        ingest.ObsReader([os.path.join(d, "normal.bcf")], device=0)
+    assert ei.value.code in (abi.ERR_NO_DEVICE, abi.ERR_HIP)
+    with pytest.raises(engine.EngineError) as ei:
+        ingest.bgzf_inflate(open(os.path.join(d, "normal.bcf"), "rb").read())
+    assert ei.value.code in (abi.ERR_NO_DEVICE, abi.ERR_HIP)
+    # the host reader takes the same file
+    assert sum(b.n_loci for b, _ in ingest.ObsReader([os.path.join(d, "normal.bcf")])) > 0
+
+
 def test_bcf_reader_agrees_with_the_text_vcf(golden_dir):
     """The binary observation BCF of the reference's fixture decodes to exactly the batch of its text twin."""
     from varlociraptor_amd import obsfmt
