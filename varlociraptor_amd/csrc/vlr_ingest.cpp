@@ -29,6 +29,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
 #include <functional>
 #include <limits>
 #include <map>
@@ -346,7 +348,48 @@ void bgzf_deflate_block(const uint8_t* data, size_t n, int level, std::vector<ui
 const uint8_t kBgzfEof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 // compress `data` into BGZF members of 0xff00 bytes in parallel and write the file
-bool write_bgzf_stream(FILE* f, const std::vector<const std::vector<uint8_t>*>& parts, int n_threads, int level, bool with_eof, std::string& err);
+// File output behind the streaming calls writer: the compressed members of a chunk are handed to one I/O thread, so that copying
+// them into the page cache (tens of milliseconds per hundred megabytes, serial) runs beside the encoding of the next chunk.
+struct AsyncSink {
+    FILE* f = nullptr;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::vector<std::vector<uint8_t>>> q;
+    bool closing = false, failed = false;
+    explicit AsyncSink(FILE* file) : f(file) {
+        th = std::thread([this] {
+            for (;;) {
+                std::vector<std::vector<uint8_t>> job;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [this] { return closing || !q.empty(); });
+                    if (q.empty()) return;
+                    job = std::move(q.front());
+                    q.pop_front();
+                }
+                bool ok = true;
+                for (auto& c : job) ok = ok && fwrite(c.data(), 1, c.size(), f) == c.size();
+                if (!ok) { std::lock_guard<std::mutex> g(mu); failed = true; }
+                cv.notify_all();
+            }
+        });
+    }
+    void push(std::vector<std::vector<uint8_t>>&& job) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [this] { return q.size() < 3; });   // (bounded: at most three chunks of compressed members in memory)
+        q.push_back(std::move(job));
+        cv.notify_all();
+    }
+    bool finish() {   // everything handed over is in the file (or failed)
+        { std::lock_guard<std::mutex> g(mu); closing = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+        return !failed;
+    }
+    ~AsyncSink() { (void)finish(); }
+};
+bool write_bgzf_stream(FILE* f, const std::vector<const std::vector<uint8_t>*>& parts, int n_threads, int level, bool with_eof, std::string& err, AsyncSink* sink = nullptr);
 bool write_bgzf_file(const char* path, const std::vector<const std::vector<uint8_t>*>& parts, int n_threads, int level, std::string& err) {
     FILE* f = fopen(path, "wb");
     if (!f) { err = std::string("cannot create ") + path; return false; }
@@ -356,7 +399,7 @@ bool write_bgzf_file(const char* path, const std::vector<const std::vector<uint8
     return ok;
 }
 // the parts, logically concatenated, as BGZF members appended to an open file (a short last member is legal BGZF)
-bool write_bgzf_stream(FILE* f, const std::vector<const std::vector<uint8_t>*>& parts, int n_threads, int level, bool with_eof, std::string& err) {
+bool write_bgzf_stream(FILE* f, const std::vector<const std::vector<uint8_t>*>& parts, int n_threads, int level, bool with_eof, std::string& err, AsyncSink* sink) {
     // the parts are logically concatenated; cut into blocks without copying more than one block at a time
     size_t total = 0;
     std::vector<size_t> start;
@@ -379,6 +422,10 @@ bool write_bgzf_stream(FILE* f, const std::vector<const std::vector<uint8_t>*>& 
         }
         bgzf_deflate_block(tmp.data(), tmp.size(), level, comp[(size_t)bi]);
     });
+    if (sink) {   // (the streaming writer: the end-of-file member is written by its close, after the sink has drained)
+        sink->push(std::move(comp));
+        return true;
+    }
     bool ok = true;
     for (auto& c : comp) ok = ok && fwrite(c.data(), 1, c.size(), f) == c.size();
     if (with_eof) ok = ok && fwrite(kBgzfEof, 1, 28, f) == 28;
@@ -2472,7 +2519,7 @@ int vlr_selftest_format_fixed(double v, int digits, char* out, int cap) {
 // header (## lines and #CHROM line with the sample names); out_names[n_out]: names of the columns of ln_posterior
 // ("absent", events..., "artifact").  `path` ending in ".bcf" -> BCF2 in BGZF blocks, otherwise text VCF.
 static int calls_write_impl(FILE* out_file, bool bcf, bool with_header, bool with_eof, const char* header_text, const vlr_obs_table* t, const vlr_results* r,
-                            const char* const* out_names, int n_threads);
+                            const char* const* out_names, int n_threads, AsyncSink* sink = nullptr);
 
 int vlr_calls_write(const char* path, const char* header_text, const vlr_obs_table* t, const vlr_results* r, const char* const* out_names, int n_threads) {
     if (!path || !header_text || !t || !r || !out_names) return ifail(VLR_ERR_INVALID_ARGUMENT, "null argument");
@@ -2487,7 +2534,7 @@ int vlr_calls_write(const char* path, const char* header_text, const vlr_obs_tab
 
 // The same file written in pieces (the streaming CLI: one append per chunk of records): header with the first append (or at close
 // if nothing was appended), BGZF end-of-file marker at close.
-struct vlr_calls_writer { FILE* f = nullptr; bool bcf = false, first = true; std::string header; };
+struct vlr_calls_writer { FILE* f = nullptr; bool bcf = false, first = true; std::string header; std::unique_ptr<AsyncSink> sink; };
 
 int vlr_calls_writer_open(const char* path, const char* header_text, vlr_calls_writer** out) {
     if (!path || !header_text || !out) return ifail(VLR_ERR_INVALID_ARGUMENT, "null argument");
@@ -2497,19 +2544,23 @@ int vlr_calls_writer_open(const char* path, const char* header_text, vlr_calls_w
     vlr_calls_writer* w = new vlr_calls_writer();
     const size_t plen = strlen(path);
     w->f = f; w->bcf = plen > 4 && strcmp(path + plen - 4, ".bcf") == 0; w->header = header_text;
+    if (w->bcf) w->sink.reset(new AsyncSink(f));
     *out = w;
     return VLR_OK;
 }
 int vlr_calls_writer_append(vlr_calls_writer* w, const vlr_obs_table* t, const vlr_results* r, const char* const* out_names, int n_threads) {
     if (!w || !w->f || !t || !r || !out_names) return ifail(VLR_ERR_INVALID_ARGUMENT, "null argument");
-    const int rc = calls_write_impl(w->f, w->bcf, w->first, false, w->header.c_str(), t, r, out_names, n_threads);
+    const int rc = calls_write_impl(w->f, w->bcf, w->first, false, w->header.c_str(), t, r, out_names, n_threads, w->sink.get());
     w->first = false;
+    if (rc == VLR_OK && w->sink) { std::lock_guard<std::mutex> g(w->sink->mu); if (w->sink->failed) return ifail(VLR_ERR_INVALID_ARGUMENT, "write failed"); }
     return rc;
 }
 int vlr_calls_writer_close(vlr_calls_writer* w) {
     if (!w) return VLR_OK;
     int rc = VLR_OK;
     if (w->f) {
+        if (w->sink && !w->sink->finish()) rc = ifail(VLR_ERR_INVALID_ARGUMENT, "write failed");   // (every member handed over is in the file now)
+        w->sink.reset();
         if (w->first || w->bcf) {  // header of an empty file and / or the end-of-file member
             vlr_obs_table* empty = nullptr;
             (void)empty;
@@ -2533,7 +2584,7 @@ int vlr_calls_writer_close(vlr_calls_writer* w) {
 }
 
 static int calls_write_impl(FILE* out_file, bool bcf, bool with_header, bool with_eof, const char* header_text, const vlr_obs_table* t, const vlr_results* r,
-                            const char* const* out_names, int n_threads) {
+                            const char* const* out_names, int n_threads, AsyncSink* sink) {
     if (r->n_loci < t->n_loci || r->n_samples != t->n_samples || !r->ln_posterior || !r->map_vaf || !r->status)
         return ifail(VLR_ERR_INVALID_ARGUMENT, "results do not match the table");
     n_threads = pick_threads(n_threads);
@@ -2715,7 +2766,7 @@ static int calls_write_impl(FILE* out_file, bool bcf, bool with_header, bool wit
         const char* lv = getenv("VLR_BGZF_LEVEL");
         // level 1 by default: the calls file is written once and read once; deflate at level 4 was 60 % of the writer's time for 12 %
         // smaller files (VLR_BGZF_LEVEL selects another level)
-        if (!write_bgzf_stream(out_file, ps, n_threads, lv ? atoi(lv) : 1, with_eof, err)) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s", err.c_str());
+        if (!write_bgzf_stream(out_file, ps, n_threads, lv ? atoi(lv) : 1, with_eof, err, sink)) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s", err.c_str());
         g_ingest_t[9] = now_s() - t_w0 - g_ingest_t[8];
         g_ingest_t[10] = now_s() - t_w0;
         for (int i = 8; i <= 10; ++i) g_ingest_total[i] += g_ingest_t[i];
