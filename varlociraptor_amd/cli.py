@@ -276,6 +276,7 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
     except ImportError:
         pass
     plans: Dict[tuple, "engine.Plan"] = {}   # one plan per scenario signature, kept across the chunks of a run
+    reserve_loci = [0]
     FIELDS = ("ln_posterior", "ln_marginal", "map_vaf", "map_bias", "best_event", "status", "afd_count", "afd_vaf", "afd_lnprob")
     # (one pool per process: page-locking its blocks again for every run costs tens of milliseconds)
     result_pool = _shared_result_pool() if (native and processor is None and rank == 0 and world == 1 and output) else None
@@ -321,6 +322,8 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                     while len(plans) >= 4:  # a plan owns device buffers (staging slots, scratch rows, AFD log): keep a handful
                         plans.pop(next(iter(plans))).close()
                     plans[sig] = engine.Plan(sc, device=device)
+                    if native and reserve_loci[0]:   # size the plan's buffers once for the reader's request size: no growth (hipFree + hipMalloc) between chunks
+                        plans[sig].reserve(reserve_loci[0], afd_capacity)
                 plan = plans[sig]
                 sub = batch if len(mine) == L else batch.select(mine)
                 # observation files are already capped by preprocess's --max-depth: size the LDS budget to the deepest record
@@ -416,6 +419,8 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                     raise
         if reader is None:
             reader = vingest.ObsReader(paths, omit_bias_mask=omit_mask, chunk_records=chunk)
+        else:
+            reserve_loci[0] = reader.chunk_records
         q_in: "queue.Queue" = queue.Queue(maxsize=2)
         q_out: "queue.Queue" = queue.Queue(maxsize=2)
         stage = {"read_s": 0.0, "call_s": 0.0, "write_s": 0.0, "n_loci": 0, "n_obs": 0}
