@@ -298,9 +298,11 @@ def test_cli_reference_testcases_expected_allele_frequencies(golden_dir, name, s
     assert (res.status[0] & 0xF) == 0
 
 
-def test_cli_two_ranks_shard_and_reassemble(golden_dir, tmp_path):
+@pytest.mark.parametrize("obs_file", ["normal.vcf", "normal.bcf"], ids=["host reader (text VCF)", "device reader (BGZF BCF)"])
+def test_cli_two_ranks_shard_and_reassemble(golden_dir, tmp_path, obs_file):
     """`call variants` under torchrun with two ranks (both on the one GPU of the test box, gloo for the exchange): loci
-    are sharded, results all-gathered, rank 0 writes the same file as a single process."""
+    are sharded, results all-gathered, rank 0 writes the same file as a single process.  With the BCF every rank reads through the
+    device reader and cuts its shard from the host copy of the columns."""
     import subprocess
     import sys
     d = os.path.join(golden_dir, "flamegraph_profiling")
@@ -309,7 +311,7 @@ def test_cli_two_ranks_shard_and_reassemble(golden_dir, tmp_path):
     two = tmp_path / "two.vcf"
     base = ["-m", "varlociraptor_amd", "call", "variants", "--omit-strand-bias", "--omit-read-orientation-bias", "--omit-read-position-bias",
             "--omit-softclip-bias", "--omit-homopolymer-artifact-detection", "--omit-alt-locus-bias"]
-    tail = ["generic", "--scenario", os.path.join(d, "scenario.yaml"), "--obs", "normal=" + os.path.join(d, "normal.vcf")]
+    tail = ["generic", "--scenario", os.path.join(d, "scenario.yaml"), "--obs", "normal=" + os.path.join(d, obs_file)]
     env = dict(os.environ, PYTHONPATH=root, VLR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     subprocess.run([sys.executable] + base + ["--output", str(one)] + tail, check=True, cwd=root, env=env, timeout=600)
     subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

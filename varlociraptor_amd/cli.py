@@ -402,7 +402,7 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
         is_text = any(not (p_.endswith(".bcf") or p_.endswith(".bcf.gz")) for p_ in paths)
         chunk = int(os.environ.get("VLR_CLI_CHUNK", "0")) or (1 << 62 if is_text else 16384)  # text VCF: contigs are only known at the end
         reader = None
-        if not is_text and world == 1 and os.environ.get("VLR_INGEST_HOST", "0") == "0":
+        if not is_text and os.environ.get("VLR_INGEST_HOST", "0") == "0":
             # BGZF inflate, record split and v15 decode as kernels (csrc/vlr_inflate.hip, csrc/vlr_decode.hip): the compressed members
             # cross PCIe, the columns are born in device memory and the evaluation reads them there.  Files it does not read (plain
             # gzip, uncompressed BCF) go to the host reader.
@@ -413,7 +413,9 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                                            # synthetic bench pileups have almost one per observation and fall back to the columns)
                                            host_columns=(processor is not None or candidate_filter is not None or os.environ.get("VLR_INGEST_SUMMARIES", "0") != "1"),
                                            # the evaluation reads the device side of a table; only the writer (which waits) needs the host copy of the columns
-                                           async_columns=(processor is None and candidate_filter is None))
+                                           # (several ranks: every rank inflates and decodes the files on its own device instead of sharing the
+                                           # node's CPUs between N host readers; its shard is cut from the host copy of the columns)
+                                           async_columns=(processor is None and candidate_filter is None and world == 1))
             except engine.EngineError as ex:
                 if ex.code != abi.ERR_UNSUPPORTED:
                     raise
