@@ -388,3 +388,24 @@ def test_async_columns_are_there_when_they_are_read(tmp_path):
     ingest.write_calls(h, callsfmt.header(names, cfg.scenario.sample_names, list(host[0][1].contig_names)), host[0][0].extra["native_table"], ref, names)
     assert open(h).read() == open(out).read()
     rd.close(); plan.close()
+
+
+def test_device_reader_refuses_sample_files_that_do_not_match(tmp_path):
+    """calling.rs:369-390: the sample files must hold the same records in the same order — one file shorter, or a different site at
+    some record, is an error of the device reader as it is of the host reader."""
+    cfg = synth.config3()
+    b = synth.generate(cfg, 900, seed=17)
+    full = []
+    for s in range(b.n_samples):
+        p = str(tmp_path / ("s%d.bcf" % s))
+        ingest.write_observations(p, b, s)
+        full.append(p)
+    short = str(tmp_path / "short.bcf")
+    ingest.write_observations(short, b.select(np.arange(700)), 1)
+    other = str(tmp_path / "other.bcf")
+    ingest.write_observations(other, synth.generate(cfg, 900, seed=18), 1)
+    for device in (None, 0):
+        with pytest.raises(engine.EngineError, match="inconsistent observations"):
+            _read_all([full[0], short], device, 256)
+        with pytest.raises(engine.EngineError, match="inconsistent observations"):
+            _read_all([full[0], other], device, 256)
