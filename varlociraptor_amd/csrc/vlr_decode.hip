@@ -85,6 +85,10 @@ extern "C" int vlr_bgzf_inflate(int device, const void* bgzf, int64_t n_bytes, v
     *out_bytes = (int64_t)total;
     if ((int64_t)total > out_capacity) return dfail(VLR_ERR_INVALID_ARGUMENT, "vlr_bgzf_inflate: output buffer too small (%s%lld bytes needed)", "", (long long)total);
     if (blocks.empty()) return VLR_OK;
+    {
+        int n_dev = 0;
+        if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { (void)hipGetLastError(); return dfail(VLR_ERR_NO_DEVICE, "no HIP device (vlr_bgzf_inflate has no host path)"); }
+    }
     VLR_HIP_OK(hipSetDevice(device));
     uint8_t *d_comp = nullptr, *d_out = nullptr;
     vlr::InflateBlock* d_blocks = nullptr;

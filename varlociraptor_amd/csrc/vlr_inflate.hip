@@ -12,8 +12,8 @@
 //     bytes, prefetched one window ahead); the decoder takes dword i with a lane read — no memory latency on the serial path;
 //   * the last 32 KiB of the inflated member (DEFLATE's window) live in an LDS ring, so a match is one LDS read and one LDS write
 //     of up to 64 bytes per instruction pair, with the period trick for overlapping matches (source index = i mod distance), and
-//     literals are single LDS byte stores of lane 0; 38 kB of LDS per wave = four members in flight per CU, one per SIMD (a single
-//     wave issues an instruction every 4-5 cycles at best: the ~150 instructions of a symbol, not the LDS latency, set its pace);
+//     literals are single LDS byte stores; 39 kB of LDS per wave = four members in flight per CU, one per SIMD (a single wave
+//     issues an instruction every ~2 cycles at best: the ~70 instructions of a symbol, not the memory system, set its pace);
 //   * symbols are decoded in speculative batches: lane i decodes the symbol that WOULD start at bit i of the next 64 stream bits
 //     (literal/length lookup, extra bits, distance lookup, extra bits — two LDS round trips for 64 candidates at once) and leaves a
 //     32-bit token with the bits it takes; the wave then follows the chain of real symbol starts through the tokens with lane reads
@@ -25,8 +25,8 @@
 //     bit-serial walk;
 //   * finished 8 KiB pieces of the ring go to HBM in 16-byte lanes (ring positions are shifted by the low 4 bits of the destination
 //     so both sides of the copy are aligned).
-// CRC32 of the member is NOT checked on the device (ISIZE, end-of-block and every code are); VLR_INGEST_HOST_INFLATE=1 selects the
-// host path, which checks it.
+// CRC32 of the member is NOT checked on the device (ISIZE, end-of-block and every code are); the host reader (vlr_obs_reader_open,
+// VLR_INGEST_HOST=1 in the CLI) inflates with libdeflate / zlib, which check it.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(64) void vlr_inflate_kernel(const uint8_t* __restri
                     if (__builtin_expect(pos >= next_stop, 0)) {
                         if (pos > lim) { bad |= (uint32_t)INFL_OUTPUT_OVERRUN << 8; done = true; }
                         else if (bad) done = true;
-                        else if ((const uint8_t*)b.g + ((bp + off) >> 3) > in_end + 8) { bad |= (uint32_t)INFL_INPUT_OVERRUN << 8; done = true; }   // (a corrupt stream must not read far beyond its member: kInputSlack)
+                        else if ((const uint8_t*)b.g + ((bp + off) >> 3) > in_end + 8) { bad |= (uint32_t)INFL_INPUT_OVERRUN << 8; done = true; }   // (a corrupt stream must not read far beyond its member: kInflateInputSlack)
                         else if (pos - flushed >= kFlush + 512) { const uint32_t to = pos & ~(kFlush - 1); flush_ring(L, gbase, flushed, to, lane); flushed = to; }
                         next_stop = flushed + kFlush + 512 < lim + 1 ? flushed + kFlush + 512 : lim + 1;
                     }

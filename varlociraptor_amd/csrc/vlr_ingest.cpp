@@ -2483,14 +2483,22 @@ void sample_fields(const vlr_obs_table* t, const vlr_results* r, int64_t l, int 
         const int n = std::min(r->afd_count[l * S + s], r->afd_capacity);
         const double* v = r->afd_vaf + (size_t)(l * S + s) * r->afd_capacity;
         const double* p = r->afd_lnprob + (size_t)(l * S + s) * r->afd_capacity;
-        std::vector<int> order((size_t)std::max(n, 0));
-        for (int i = 0; i < n; ++i) order[(size_t)i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return v[a] < v[c]; });
+        // stable order by allele frequency: the lists are short (<= capacity) and mostly ascending already — an insertion sort on
+        // the stack instead of std::stable_sort's heap buffer per call
+        int order_buf[256];
+        std::vector<int> order_big;
+        int* order = order_buf;
+        if (n > 256) { order_big.resize((size_t)n); order = order_big.data(); }
+        for (int i = 0; i < n; ++i) {
+            int j = i;
+            while (j > 0 && v[i] < v[order[j - 1]]) { order[j] = order[j - 1]; --j; }
+            order[j] = i;
+        }
         std::string out;
         out.reserve((size_t)n * 12);
         static const double kLn10 = std::log(10.0);
         for (int k = 0; k < n; ++k) {
-            const int i = order[(size_t)k];
+            const int i = order[k];
             const double ph = -10.0 * p[i] / kLn10 + 0.0;
             if (k) out.push_back(',');
             append_fixed(out, v[i], 3);
