@@ -587,7 +587,7 @@ def main():
                 "note": "vlr_batch_run_host: host arrays (page-locked) in, results (and AFD lists of %d entries) out, one call each" % args.afd_capacity}
         try:
             a2 = types.SimpleNamespace(**vars(args))
-            a2.loci, a2.steps, a2.warmup = min(200_000, batch.n_loci), 1, 1
+            a2.loci, a2.steps, a2.warmup = min(200_000, batch.n_loci), 3, 1
             cl = bench_cli(a2, 0, 1, local_rank, dev)
             e2e = {"value": cl["value"], "unit": "records/s", "records": a2.loci, "stages_s": cl["stages_s"], "native_stage_seconds": cl["native_stage_seconds_per_step"],
                    "host_threads_effective": cl["config"]["effective_cpus"], "files": cl["files"],
