@@ -342,18 +342,22 @@ def bench_cli(args, rank, world, local_rank, dev):
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    import resource
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
-    stages = {"read_s": 0.0, "call_s": 0.0, "write_s": 0.0}
+    stages = {"read_s": 0.0, "call_s": 0.0, "write_s": 0.0, "setup_s": 0.0, "drain_s": 0.0}
     ingest.total_timings(reset=True)
     for _ in range(args.steps):
         step()
         for k in stages:
-            stages[k] += tm[k]
+            stages[k] += tm.get(k, 0.0)
     native = {k: v / args.steps for k, v in ingest.total_timings().items()}
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -374,6 +378,8 @@ def bench_cli(args, rank, world, local_rank, dev):
         "stages_s": per, "stages_note": "seconds per step inside the reader / evaluation / writer threads of cli.call_variants; the three overlap across chunks of %s records (%d chunks per step), so their sum exceeds ms_per_step" % (os.environ.get("VLR_CLI_CHUNK", "16384"), tm.get("chunks", 1)),
         "stage_rates": {"read_records_per_s": n_loci / per["read_s"], "read_uncompressed_GBps": None, "call_loci_per_s": n_loci / per["call_s"], "write_records_per_s": n_loci / per["write_s"]},
         "native_stage_seconds_per_step": native,
+        "process_cpu": {"cpu_seconds_per_step": cpu_s / args.steps, "busy_cpus": cpu_s / elapsed, "effective_cpus": effective_cpus(),
+                        "note": "user + system time of this process over the timed steps / wall time: how much of the CPU quota the pipeline uses"},
         "native_stage_note": "inside read_s: inflate and parse_decode are summed over the sample files (which run side by side), files_wall is their wall time, merge + strings build the table; inside write_s: encode = record formatting, deflate_write = BGZF + file",
         "files": {"observation_bcf_bytes": obs_bytes, "calls_bcf_bytes": calls_bytes, "observations": int(n_obs), "observation_write_s_untimed": t_write_obs},
         "roofline": None, "cpu_baseline": None, "build_id": engine.build_id(),

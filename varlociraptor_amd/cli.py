@@ -423,8 +423,8 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
             reader = vingest.ObsReader(paths, omit_bias_mask=omit_mask, chunk_records=chunk)
         else:
             reserve_loci[0] = reader.chunk_records
-        q_in: "queue.Queue" = queue.Queue(maxsize=2)
-        q_out: "queue.Queue" = queue.Queue(maxsize=2)
+        q_in: "queue.Queue" = queue.Queue(maxsize=int(os.environ.get("VLR_CLI_QUEUE", "2")))
+        q_out: "queue.Queue" = queue.Queue(maxsize=int(os.environ.get("VLR_CLI_QUEUE", "2")))
         stage = {"read_s": 0.0, "call_s": 0.0, "write_s": 0.0, "n_loci": 0, "n_obs": 0}
         errors: List[BaseException] = []
 
@@ -479,6 +479,7 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
         proc_state = {"setup": False}
         tr = threading.Thread(target=read_loop, daemon=True)
         tw = threading.Thread(target=write_loop, daemon=True) if (rank == 0 and processor is None) else None
+        stage["setup_s"] = time.perf_counter() - t_begin
         tr.start()
         if tw:
             tw.start()
@@ -527,6 +528,7 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                 elif tw and res is not None:
                     q_out.put((batch.extra["native_table"], res, names, used_contigs))
         finally:
+            t_loop_end = time.perf_counter()
             if tw:
                 q_out.put(None)
                 tw.join()
@@ -555,7 +557,7 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                         out.write(fh.read())
                     writer_state["tmp"].cleanup()
         if timings is not None:
-            timings.update(dict(stage, wall_s=time.perf_counter() - t_begin, chunks=len(collected)))
+            timings.update(dict(stage, wall_s=time.perf_counter() - t_begin, chunks=len(collected), drain_s=time.perf_counter() - t_loop_end))
         collected = [r_ for r_ in collected if r_ is not None]
         if len(collected) == 1:
             return collected[0]

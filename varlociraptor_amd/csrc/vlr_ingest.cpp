@@ -2630,9 +2630,12 @@ static int calls_write_impl(FILE* out_file, bool bcf, bool with_header, bool wit
         auto it = h.contigs.find(t->contig_names[i]);
         if (it != h.contigs.end()) contig_idx[i] = it->second;
     }
+    // records are encoded in blocks of 1 024 handed out dynamically (pileups differ in what they cost: contiguous shares per thread
+    // left the threads waiting for the slowest one); every block is its own part of the output, in order
     const int T = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, (L + 63) / 64));
-    std::vector<std::vector<uint8_t>> parts((size_t)T + 1);
-    std::vector<std::string> errs((size_t)T);
+    const int64_t kBlk = 1024, n_blk = (L + kBlk - 1) / kBlk;
+    std::vector<std::vector<uint8_t>> parts((size_t)n_blk + 1);
+    std::vector<std::string> errs((size_t)std::max<int64_t>(n_blk, 1));
     if (with_header && bcf) {
         auto& p0 = parts[0];
         p0.insert(p0.end(), {'B', 'C', 'F', 2, 2});
@@ -2647,7 +2650,8 @@ static int calls_write_impl(FILE* out_file, bool bcf, bool with_header, bool wit
     }
     const double LN10 = std::log(10.0);
     const double t_w0 = now_s();
-    parallel_ranges(L, T, [&](int64_t b, int64_t e, int w) {
+    parallel_items(n_blk, T, [&](int64_t w, int) {
+        const int64_t b = w * kBlk, e = std::min<int64_t>(L, b + kBlk);
         std::vector<uint8_t>& out = parts[(size_t)w + 1];
         out.reserve((size_t)(e - b) * (size_t)(200 + 260 * S));  // one allocation instead of doubling through tens of megabytes
         std::vector<SampleFields> sf((size_t)S);
