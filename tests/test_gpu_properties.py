@@ -25,7 +25,7 @@ def big_batch(name, n):
 @pytest.fixture(scope="module")
 def config3_full():
     cfg = synth.config3()
-    b = big_batch("config3", 200_000)
+    b = big_batch("config3", 1_000_000)  # the full size of BASELINE configs[2]
     plan = engine.Plan(cfg.scenario)
     plan.set_max_obs(int(b.depth().sum(axis=1).max()))
     res = plan.call_host(b)
@@ -112,7 +112,7 @@ def test_random_sample_of_the_full_batch_matches_the_oracle(config3_full, oracle
     got = CallResults(len(pick), plan.n_out, plan.n_samples)
     for f in ("ln_posterior", "map_vaf", "map_bias", "best_event", "status"):
         getattr(got, f)[:] = getattr(res, f)[pick]
-    m = compare(got, ref, label="config3 sample of 200k")
+    m = compare(got, ref, label="config3 sample of the full 1 M")
     print(describe(m))
     assert m["frac_within"] == 1.0, describe(m)
 
