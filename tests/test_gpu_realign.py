@@ -172,6 +172,32 @@ def test_fast_mode_matches_restatement(oracle):
     assert np.allclose(got, ref, rtol=0, atol=1e-9), (got, ref)
 
 
+def test_fast_mode_bound_vs_concrete_traceback_stays_below_the_recorded_gap(oracle):
+    """The `fast` kernel is an UPPER bound over all co-optimal alignments (include/vlr.h, vlr_realign_fast_batch); the reference
+    evaluates the one alignment bio's Myers traceback returns (realignment/mod.rs:547-678).  On the workload of
+    tools/fast_mode_gap.py (profiles/r04_fast_mode_gap.json: 600 reads, seed 7) the kernel must never fall below a concrete
+    diagonal-first traceback, and the NORMALISED ref/alt supports — what the observation records carry — must not move by more
+    than the recorded maximum (1.4e-13, asserted with a decade of slack and far inside BASELINE's 1e-6)."""
+    import json, os
+    rec = json.load(open(os.path.join(os.path.dirname(__file__), "..", "profiles", "r04_fast_mode_gap.json")))
+    pb, truth = realign_synth.generate(rec["reads"], seed=7)
+    assert len(pb) == rec["pairs"]
+    gap = GapParams()
+    g = [gap.prob_insertion_artifact, gap.prob_deletion_artifact, gap.prob_insertion_extend_artifact, gap.prob_deletion_extend_artifact]
+    best = realign.prob_best_path(pb, gap)
+    fixed = np.array([oracle.pathhmm_fixed_traceback(pb.x[k], pb.y[k], pb.q[k], g)[0] for k in range(len(pb))])
+    gap_ln = best - fixed
+    assert (gap_ln > -1e-9 * np.maximum(1.0, np.abs(fixed))).all(), "the maximum over all optimal alignments cannot be below one of them"
+    assert gap_ln.max() <= rec["max_gap_ln_p"] + 1e-6                      # ln P itself: up to 348 on unrelated windows
+    frac_open = float((gap_ln > 1e-9).mean())
+    assert abs(frac_open - rec["frac_pairs_where_the_bound_is_not_attained_by_the_fixed_traceback"]) < 0.01
+    moved = 0.0
+    for k in range(len(truth)):
+        b = realign.normalize_support(best[2 * k], best[2 * k + 1]); f = realign.normalize_support(fixed[2 * k], fixed[2 * k + 1])
+        moved = max(moved, abs(math.exp(b[0]) - math.exp(f[0])), abs(math.exp(b[1]) - math.exp(f[1])))
+    assert moved <= max(10.0 * rec["max_abs_d_normalised_support"], 1e-12), moved
+
+
 def test_two_pairs_per_wave_on_short_read_windows(oracle):
     """vlr_realign_kernel2: read windows of at most 64 bases run two pairs per wave (lanes 0-31 / 32-63).  Short windows of
     every variant kind, banded and not, odd pair counts, and batches that mix short and long windows pair by pair."""

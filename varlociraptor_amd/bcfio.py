@@ -1,9 +1,13 @@
-"""Minimal BCF2 (BGZF-compressed binary VCF) reader — enough for varlociraptor's observation and calls files.
+"""PYTHON CROSS-CHECK of the native BGZF / BCF2 code (csrc/vlr_ingest.cpp, csrc/vlr_inflate.hip), not the product path: used by
+the tests and by `VLR_INGEST=python`.
+
+Minimal BCF2 (BGZF-compressed binary VCF) reader and writer — enough for varlociraptor's observation and calls files.
 
 Spec: VCFv4.2 / BCF2.2 (samtools/hts-specs): BGZF = concatenated gzip members; magic `BCF\\2\\2`; header text;
 records = (l_shared, l_indiv, CHROM, POS, rlen, QUAL, n_allele<<16|n_info, n_fmt<<24|n_sample, ID, alleles,
 FILTER, INFO key/value pairs, FORMAT blocks) with typed values (descriptor byte len<<4|type; types 1/2/3 ints,
-5 float, 7 char).  Replaces rust-htslib's bcf::Reader for this path (reference calling.rs:306-318); no htslib here.
+5 float, 7 char).  Restates what rust-htslib's bcf::Reader / Writer do for this path (reference calling.rs:296-318); the product path is
+`vlr_obs_read` / `vlr_obs_reader_open(_device)` / `vlr_calls_write` behind the C ABI.
 """
 from __future__ import annotations
 

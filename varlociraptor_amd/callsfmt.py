@@ -1,9 +1,12 @@
-"""Calls record formatting: the text-VCF flavour of Call::write_final_record
+"""PYTHON CROSS-CHECK of the native calls writer (`vlr_calls_write` / `vlr_calls_writer_*`, csrc/vlr_ingest.cpp), not the product
+path: the end-to-end tests require the native writer's files to equal this formatter's byte for byte.
+
+Calls record formatting: the text-VCF flavour of Call::write_final_record
 (reference src/calling/variants/mod.rs:178-600) for records evaluated by the engine.
 
 Produces, per record, INFO `PROB_<EVENT>` (PHRED, f32, sorted by descending probability, mod.rs:223-231,
 447-466) and FORMAT `DP:AF:SAOBS:SROBS:OBS:OOBS:SB:ROB:RPB:SCB:HE:ALB:AFD` (mod.rs:233-559).
-The BCF container itself (htslib) is out of reach in this image; this is the "next" row §8(f)#2.
+BCF output of the same records goes through bcfio.BcfWriter (cross-check) or the native writer (product); SURVEY.md §8(f)#2.
 """
 from __future__ import annotations
 

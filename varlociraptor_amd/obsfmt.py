@@ -1,4 +1,7 @@
-"""Decoder for varlociraptor's observation format v15 (text VCF flavour) -> PileupBatch.
+"""PYTHON CROSS-CHECK of the native v15 decoder (csrc/vlr_ingest.cpp on the host, csrc/vlr_decode.hip on the device), not the
+product path: the tests compare the native readers with it record by record, and `VLR_INGEST=python` selects it in the CLI.
+
+Decoder for varlociraptor's observation format v15 (text VCF flavour) -> PileupBatch.
 
 Wire format (src/calling/variants/preprocessing/mod.rs:810-1038): every per-observation vector is
 `bincode(Vec<T>)` (little-endian, u64 length prefix, u32 enum variant index, u8 Option tag), split
@@ -6,8 +9,8 @@ into LE u16 words, each stored as one i32 of an INFO integer vector (odd byte co
 mod.rs:985-988).  T = MiniLogProb{F16(f16) | F32(f32)} (src/utils/mod.rs:449-474), Option<…>,
 C-like enums, bv::BitVec<u8> = {Option tag, u64 nblocks, blocks, u64 nbits}.
 
-Text `.vcf` and binary `.bcf` (via the htslib-free reader in bcfio.py) are accepted; the calls formatter is
-callsfmt.py ("next" row §8(f)#2 of SURVEY.md).
+Text `.vcf` and binary `.bcf` (via the pure-Python reader in bcfio.py) are accepted; the matching cross-check of the calls
+writer is callsfmt.py.
 """
 from __future__ import annotations
 
