@@ -1,7 +1,31 @@
 """Rewrite a gfx950 assembly file (hipcc -S --cuda-device-only of vlr_kernels.hip built with -DVLR_PROFILE -DVLR_PROFILE_VALU) so
 that every straight-line segment of the call kernels adds its number of VALU instructions to s100 (SCC is saved in s101 and
-restored: a segment may start with SCC live).  The PROF_ADD sites of the source read s100.  usage: valu_instrument.py in.s out.s"""
-import re, sys
+restored: a segment may start with SCC live).  The PROF_ADD sites of the source read s100.  usage: valu_instrument.py in.s out.s
+VALU_CLASS (environment) restricts what is counted to one class of instructions, so that a run per class gives the DYNAMIC mix per
+region: lane (v_readlane / v_writelane / v_readfirstlane: SGPR spill traffic and uniform reads), mov (v_mov / v_accvgpr, incl. DPP
+moves), dpp (anything with a dpp / row_ / quad_perm modifier), sel (v_cndmask), cmp (v_cmp*), f64 (arithmetic on doubles), salu
+(s_* instead of v_*), other (none of the above); default: every VALU instruction."""
+import os, re, sys
+CLASS = os.environ.get("VALU_CLASS", "all")
+def counted(tj):
+    op = tj.split()[0]
+    if CLASS == "salu": return op.startswith("s_") and not op.startswith(("s_waitcnt", "s_nop", "s_branch", "s_cbranch", "s_endpgm", "s_barrier", "s_sleep", "s_setprio"))
+    if not op.startswith("v_"): return False
+    lane = op.startswith(("v_readlane", "v_writelane", "v_readfirstlane"))
+    mov = op.startswith(("v_mov", "v_accvgpr"))
+    dpp = ("row_" in tj) or ("quad_perm" in tj) or ("wave_" in tj) or op.endswith("_dpp")
+    sel = op.startswith("v_cndmask")
+    cmp_ = op.startswith("v_cmp")
+    f64 = ("_f64" in op) and not cmp_
+    if CLASS == "all": return True
+    if CLASS == "lane": return lane
+    if CLASS == "mov": return mov
+    if CLASS == "dpp": return dpp
+    if CLASS == "sel": return sel
+    if CLASS == "cmp": return cmp_
+    if CLASS == "f64": return f64
+    if CLASS == "other": return not (lane or mov or sel or cmp_ or f64)
+    raise SystemExit("unknown VALU_CLASS " + CLASS)
 src = open(sys.argv[1]).read().splitlines()
 out = []
 in_kernel = False
@@ -42,7 +66,7 @@ while i < len(src):
         seg.append(src[j])
         if is_instr(tj):
             op = tj.split()[0]
-            if op.startswith("v_"): n += 1
+            if counted(tj): n += 1
             if is_branch(tj) or ("s100" in tj and op == "s_mov_b32"):
                 j += 1
                 break

@@ -927,7 +927,8 @@ static int ensure_buffers(vlr_plan* plan, int64_t n_loci, int max_obs, bool want
         *have = need;
         return VLR_OK;
     };
-    int rc = grow(&plan->escratch[k], &plan->escratch_bytes[k], L * (size_t)max_obs * sizeof(double), false);
+    // (+ 2 S doubles per locus in front of every row: the all-ones products, DevResults::escratch)
+    int rc = grow(&plan->escratch[k], &plan->escratch_bytes[k], L * ((size_t)max_obs + 2 * (size_t)plan->host.S) * sizeof(double), false);
     if (rc != VLR_OK) return rc;
     {   // pool of the deep launch: 24 B per kept observation of the loci above the LDS budget (default 512 MiB = 22 M observations
         // per batch; VLR_DEEP_POOL_MB, 0 = no deep launch: such loci stay flagged VLR_LOCUS_TOO_DEEP).  Optional: no room, no fallback.
@@ -1094,7 +1095,7 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
             if (bs.ref_base) bs.ref_base += l0;
             if (bs.alt_base) bs.alt_base += l0;
             rs.ln_posterior += l0 * n_out; rs.ln_marginal += l0; rs.map_vaf += l0 * S; rs.map_bias += l0 * 6; rs.best_event += l0;
-            rs.status += l0; rs.map_disc += l0; rs.escratch += (size_t)l0 * max_obs;
+            rs.status += l0; rs.map_disc += l0; rs.escratch += (size_t)l0 * ((size_t)max_obs + 2 * (size_t)S);
             rs.afd_count += l0 * S; rs.afd_vaf += (size_t)l0 * S * r.afd_capacity; rs.afd_lnprob += (size_t)l0 * S * r.afd_capacity;
             if (rs.afd_log) rs.afd_log += (size_t)lane * (size_t)step * (size_t)r.afd_log_stride;
             rs.afd_key += (size_t)l0 * (size_t)S * (size_t)r.afd_capacity;

@@ -766,7 +766,8 @@ struct Ctx {
     int need_batch, bt_nt, bt_inner;           // walk_root asks the event loop to run run_chain_batch (single inline site, few live registers)
     int nhold, nstash, hold_inner;             // held event-level chains: nhold of them parked in the TOP rows (tasks kRows-1, ...), one more in WaveSt::stash
     int afd_mute;  // replay: the current path repeats an outer VAF already visited by its chain (duplicate map key)
-    int ehas;      // bit s: sample s has non-zero third coefficients (constant per locus, see WaveSt::ehas)
+    int ehas;      // bit s: sample s has non-zero third coefficients (constant per locus, see WaveSt::ehas);
+                   // bit 16 + s: under the current hypothesis sample s takes its likelihood at alpha = beta = 1 from `ones` (ones_risk)
     double* lg;    // AFD log region of this locus (DevResults::afd_log) or nullptr
     int lg_pos, lg_cap;  // next free word / capacity; lg_pos < 0: overflowed
     int lg_nrec;         // records written so far (directory entries)
@@ -829,6 +830,28 @@ __device__ __forceinline__ double kshift_ln(const Ctx& c, int mask) {
 __device__ __forceinline__ const double* ecoef_of(const Ctx& c, int s, int off) {
     return ((c.ehas >> s) & 1) ? c.ecoef + off : nullptr;
 }
+// The all-ones point.  At a VAF of exactly 1 in the sample (and in its contaminant) the likelihood of an observation is w A + u
+// (likelihood.rs:43-53 with af == 1); the affine form evaluates it as (w R + u) + w (A - R), which cancels w R.  Harmless while
+// u = prob_mismapping * e^missed keeps the term above 2^-24 w R (every pair-HMM record: prob_missed_allele is ln((A + R) / 2));
+// where an observation has w R > 2^24 (w A + u) the coefficient pass leaves the product of the direct terms of the sample
+// (mantissa, exponent; the 2 S words in front of the locus' row of DevResults::escratch) and every evaluation at that point takes it instead of the affine product.
+__device__ __forceinline__ bool ones_any(const Ctx& c) { return ((unsigned)c.ehas >> 16) != 0u; }
+__device__ __forceinline__ bool ones_risk(const Ctx& c, int s) { return (((unsigned)c.ehas >> (16 + s)) & 1u) != 0u; }
+__device__ __forceinline__ bool is_all_ones(const DevPlan& p, int s, double a, double b) { return a == 1.0 && (p.by[s] < 0 || b == 1.0); }
+// (the 2 S words in front of the locus' scratch row: no pointer of their own in the context)
+__device__ __forceinline__ double* ones_ptr(const Ctx& c) { return const_cast<double*>(c.ecoef) - 2 * c.S; }
+__device__ __forceinline__ void ones_load(const Ctx& c, int s, double& Pm, int& E) {
+    const double* o = ones_ptr(c);
+    Pm = ld_e(o + 2 * s);
+    E = (int)ld_e(o + 2 * s + 1);
+}
+// the partial products of one point over a W-lane group replaced by the direct product: lane 0 of the group carries it
+__device__ __forceinline__ void ones_inject(const Ctx& c, int s, int k, double& P, int& E) {
+    double Pm; int Em;
+    ones_load(c, s, Pm, Em);
+    P *= (k == 0) ? Pm : 1.0;
+    E += (k == 0) ? Em : 0;
+}
 
 // cached single-point pileup likelihood of sample s (stands in for the per-sample LRU caches of
 // modes/generic.rs:38-53: the normal sample's likelihood is reused across all tumor VAFs)
@@ -839,8 +862,11 @@ __device__ inline double sample_lik_point(Ctx& c, int s, double a, double b) {  
     const int off = UNI(w->soff[s]), D = UNI(w->nkeep[s]);
     double P1[1] = {1.0};
     int E1[1] = {0};
+    if (__builtin_expect(ones_any(c), 0) && ones_risk(c, UNI(s)) && is_all_ones(*c.plan, UNI(s), uni_d(a), uni_d(b))) ones_load(c, s, P1[0], E1[0]);
+    else {
     accum_terms<1, 64>(c.coef + 2 * off, ecoef_of(c, s, off), D, c.lane, (w->fastok >> s) & 1, &al, &be, P1, E1);
     reduce_terms<1, 64>(P1, E1);
+    }
     if (c.lane == 0) { w->work[0] += 1; w->work[1] += (unsigned long long)D; }
 #ifdef VLR_NO_RESCUE
     return uni_d(ln_product_mantissa(P1[0]) + (double)E1[0] * kLn2);
@@ -1578,6 +1604,15 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
                 double b = by >= 0 ? ((by == inner) ? xr : w->ops_vaf[by]) : 0.0;
                 double al, be;
                 alpha_beta(p, s, a, b, al, be);
+                if (__builtin_expect(ones_any(c), 0) && ones_risk(c, s) && __ballot(is_all_ones(p, s, a, b))) {
+                    // (rows are at different points: the rows at the all-ones point take the direct product, the others their own)
+                    double Pt[1] = {1.0};
+                    int Et[1] = {0};
+                    accum_terms<1, 16>(c.coef + 2 * UNI(w->soff[s]), ecoef_of(c, s, UNI(w->soff[s])), UNI(w->nkeep[s]), rlane, (w->fastok >> s) & 1, &al, &be, Pt, Et);
+                    if (is_all_ones(p, s, a, b)) { Pt[0] = 1.0; Et[0] = 0; ones_inject(c, s, rlane, Pt[0], Et[0]); }
+                    P1[0] *= Pt[0]; E1[0] += Et[0];
+                    { int e2; P1[0] = __builtin_frexp(P1[0], &e2); E1[0] += e2; }
+                } else
                 accum_terms<1, 16>(c.coef + 2 * UNI(w->soff[s]), ecoef_of(c, s, UNI(w->soff[s])), UNI(w->nkeep[s]), rlane, (w->fastok >> s) & 1, &al, &be, P1, E1);
             }
             reduce_terms<1, 16>(P1, E1);
@@ -1877,6 +1912,7 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
     int k = 0, tn = 0;
     bool failed = false, sawnan = false;
     const bool all_fast = __ballot(q.rowon && !q.cls_fast) == 0ull;
+    const bool ones_on = ones_any(c) && ones_risk(c, q.inner);
     const bool cap_safe = p.table_cap < kTableCap;  // the host's bound was not clamped (vlr_host.cpp: table capacity)
     double L = lo, R = hi, vL = VLR_NEG_INF, vR = VLR_NEG_INF, mid = lo;
     long long kL = 0, kR = 0;  // KEYED: the bracket ends' product keys
@@ -1972,13 +2008,23 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
         PROF_ADD(c, 13);  // pass: reduction
         const double x = rl == 0 ? px0 : rl == 1 ? px1 : px2;
         const bool owner = on && rl < nn;
+        if (__builtin_expect(ones_on, 0) && up != UP_ROUND) {  // (a middle point of a round is never exactly the range end)
+            // this row's chain is at the all-ones point at x == 1 when its contaminant sits at 1 as well (al_fix = irho * contaminant VAF);
+            // nothing of this is kept in registers across the passes
+            double oP; int oE;
+            ones_load(c, q.inner, oP, oE);
+            const bool o1 = q.rowon && x == 1.0 && (!q.has_by || q.al_fix == p.irho[q.inner]);
+            Psel = o1 ? oP : Psel; Esel = o1 ? oE : Esel;
+        }
         double joint = 0.0;
         long long key = 0;
         if (KEYED) {
             key = product_key(Psel, Esel);
             if (owner) { q.tx[tn + rl] = x; q.tv[tn + rl] = __longlong_as_double(key); }
         } else {
-            const double lik = q.fixed + (ln_mantissa(Psel) + (double)Esel * kLn2);
+            double lm = ln_mantissa(Psel);
+            if (__builtin_expect(ones_on, 0)) lm = ln_product_mantissa(Psel);  // (a direct all-ones product may be exactly zero)
+            const double lik = q.fixed + (lm + (double)Esel * kLn2);
             if (__builtin_expect(c.nlfc > 0, 0) && !lfcs_ok(c, q.inner, x)) joint = VLR_NEG_INF;
             else if (__builtin_expect(all_fast, 1)) joint = (x == 0.0 ? q.pr0 : q.pr1) + lik;  // every row inside a uniform-prior universe: class 0 at exactly 0, else 1
             else {
@@ -2101,7 +2147,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
     // contaminated by it), its pileup fits the register slots and its terms need no renormalisation
     const bool regrun = dep == (1 << inner) && D_in <= 16 * kRegSlots && ((UNI(w->vfast) >> inner) & 1);
     // keyed passes (see reg_chain_loop): every point of every row has the same finite prior value and a finite fixed part
-    const bool keyed = regrun && c.nlfc == 0 &&
+    const bool keyed = regrun && c.nlfc == 0 && !(ones_any(c) && ones_risk(c, inner)) &&  // (the exponent of a direct all-ones product is not bounded by the key's 16 bits)
                        __ballot(rowon && !(cls_fast && (pr0 == pr1 || lo != 0.0) && fabs(pr1) < __builtin_huge_val() && fabs(fixed) < __builtin_huge_val())) == 0ull;
     if (__builtin_expect(regrun, 1)) {
         RegChain rc;
@@ -2177,6 +2223,31 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
                     const double b = by >= 0 ? ((by == inner) ? xs[j] : vb) : 0.0;
                     alpha_beta(p, s, a, b, al[j], be[j]);
                 }
+                bool one_j[kPass];
+                bool any_one = false;
+                if (__builtin_expect(ones_any(c), 0) && ones_risk(c, s)) {
+#pragma unroll
+                    for (int j = 0; j < kPass; ++j) {
+                        const double a = (s == inner) ? xs[j] : va;
+                        const double b = by >= 0 ? ((by == inner) ? xs[j] : vb) : 0.0;
+                        one_j[j] = is_all_ones(p, s, a, b);
+                        any_one = any_one || one_j[j];
+                    }
+                }
+                if (__builtin_expect(__ballot(any_one) != 0ull, 0)) {
+                    double Pt[kPass];
+                    int Et[kPass];
+#pragma unroll
+                    for (int j = 0; j < kPass; ++j) { Pt[j] = 1.0; Et[j] = 0; }
+                    accum_terms_n<16>(cnt, c.coef + 2 * UNI(w->soff[s]), ecoef_of(c, s, UNI(w->soff[s])), UNI(w->nkeep[s]), rl, (UNI(w->fastok) >> s) & 1, al, be, Pt, Et);
+#pragma unroll
+                    for (int j = 0; j < kPass; ++j) {
+                        if (one_j[j]) { Pt[j] = 1.0; Et[j] = 0; ones_inject(c, s, rl, Pt[j], Et[j]); }
+                        P[j] *= Pt[j]; E[j] += Et[j];
+                        int e2;
+                        P[j] = __builtin_frexp(P[j], &e2); E[j] += e2;
+                    }
+                } else
                 accum_terms_n<16>(cnt, c.coef + 2 * UNI(w->soff[s]), ecoef_of(c, s, UNI(w->soff[s])), UNI(w->nkeep[s]), rl, (UNI(w->fastok) >> s) & 1, al, be, P, E);
             }
             PROF_ADD(c, 12);  // round: term products
@@ -2594,6 +2665,14 @@ __device__ __forceinline__ bool bo_setup(Ctx& c, const Frame& f, RangeSt& r) {
         int off = UNI(w->soff[s]), D = UNI(w->nkeep[s]);
         eval_pileup(c.coef + 2 * off, ecoef_of(c, s, off), D, (w->fastok >> s) & 1, nt, w->bpend[1], w->bpend[2], w->bpend[3], lane);
         VLR_SYNC();
+        if (__builtin_expect(ones_any(c), 0) && ones_risk(c, s)) {
+            if (lane < nt && is_all_ones(p, s, c.tvaf[lane * S + s], by >= 0 ? c.tvaf[lane * S + by] : 0.0)) {
+                double Pm; int Em;
+                ones_load(c, s, Pm, Em);
+                w->bpend[3][lane] = ln_product_mantissa(Pm) + (double)Em * kLn2;
+            }
+            VLR_SYNC();
+        }
 #ifdef VLR_NO_RESCUE
         if (lane < nt) w->task[lane].fixed += w->bpend[3][lane];
 #else
@@ -3354,7 +3433,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
     const int cap = p.table_cap;
     c.cap = cap;
     c.coef = dyn;
-    c.ecoef = out.escratch + (size_t)blockIdx.x * (size_t)max_obs;
+    c.ecoef = out.escratch + (size_t)blockIdx.x * (size_t)(max_obs + 2 * p.S) + 2 * p.S;  // (the first 2 S words of the row: ones_ptr)
     c.tabX = dyn + 2 * max_obs;
     c.tabV = c.tabX + p.max_tab_depth * cap;
     c.rowX = c.tabV + p.max_tab_depth * cap;
@@ -3556,14 +3635,14 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
 #if VLR_DEEP
     int obs_cap = 0;
     {   // {c, q} pairs and e of every kept observation from the pool: 3 doubles per observation
-        const unsigned long long need = 3ull * (unsigned long long)offset_acc;
+        const unsigned long long need = 3ull * (unsigned long long)offset_acc + 2ull * (unsigned long long)S;  // (+ the all-ones words in front of e)
         unsigned long long at = 0;
         if (lane == 0) at = atomicAdd(out.deep_used, need);
         at = (unsigned long long)UNI64((long long)at);
         if (at + need > (unsigned long long)out.deep_capacity) too_deep = true;
         else {
             c.coef = out.deep_pool + at;
-            c.ecoef = out.deep_pool + at + 2ull * (unsigned long long)offset_acc;
+            c.ecoef = out.deep_pool + at + 2ull * (unsigned long long)offset_acc + 2ull * (unsigned long long)S;
             obs_cap = offset_acc;
         }
     }
@@ -3698,7 +3777,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
         //   w = e^pm, u = (1-w) * e^(missed + b_any), A = e^(pa + b_alt), R = e^(pr + b_ref), s = e^prob_sample_alt
         //   c = w*R + u, q = w*s*(A-R), e = w*(1-s)*(A-R)
         // (likelihood.rs:43-53,86-115,171-220; bias factors bias/mod.rs:259-284)
-        int fastmask = 0, vfastmask = 0;
+        int fastmask = 0, vfastmask = 0, onesmask = 0;
         for (int s = 0; s < S; ++s) {
             const int64_t pidx = locus * S + s;
             const uint32_t o0 = batch.obs_offset[pidx], o1 = batch.obs_offset[pidx + 1];
@@ -3715,6 +3794,9 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
             if (scaled && !need_rescue) break;
             wr = w->soff[s]; fast_s = 1; vfast_s = 1;
             bool fatal = false;
+            double P1 = 1.0;      // this lane's share of prod_i (w A_i + u_i): the sample's likelihood at alpha = beta = 1, without the cancellation
+            int E1 = 0;
+            bool risk = false;    // some term has w R > 2^24 (w A + u): c + q + e keeps fewer than 29 bits of it
             // every column of a row in one round of loads (the few rows that are dropped below are loaded in vain), and the rows of
             // the NEXT 64 observations are requested before this iteration's arithmetic starts
             ObsRow nxt = load_obs_row(batch, o0 + lane, o1);
@@ -3787,6 +3869,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                     bool uflow = (A == 0.0 && fa != 0.0 && pa > VLR_NEG_INF) || (R == 0.0 && fr != 0.0 && pr > VLR_NEG_INF);
                     double d = A - R;
                     double cc_ = wv * R + uu, cq_ = wv * sv * d, ce_ = wv * (1.0 - sv) * d;
+                    double one_t = wv * A + uu, ref_t = wv * R;  // the term at alpha = beta = 1 formed directly, and what c + q + e cancels
                     if (__builtin_expect(scaled != 0, 0)) {
                         // the three log-space addends of the observation's likelihood, their largest as the binary exponent k
                         const double lA = (fa > 0.0 && pa > VLR_NEG_INF) ? pm + pa + log(fa) : VLR_NEG_INF;
@@ -3799,8 +3882,17 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                         const double UU = (lU > VLR_NEG_INF) ? exp(lU - sh) : 0.0;
                         d = WA - WR;
                         cc_ = WR + UU; cq_ = sv * d; ce_ = (1.0 - sv) * d;
+                        one_t = WA + UU; ref_t = WR;
                         kacc += ki;
                         uflow = false;
+                    }
+                    {   // the all-ones term and its product over the lane's observations (mantissa, exponent)
+                        risk = risk || (ref_t > 0x1p24 * one_t);
+                        int e1;
+                        P1 *= __builtin_frexp(one_t, &e1);
+                        E1 += e1;
+                        P1 = __builtin_frexp(P1, &e1);
+                        E1 += e1;
                     }
 #if VLR_DEEP
                     if (pos < obs_cap) {
@@ -3827,6 +3919,18 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
             const bool bad = __ballot(fatal) != 0ull;
             if (!scaled) need_rescue = bad;
             else if (bad) c.status |= VLR_LOCUS_UNDERFLOW;  // cannot happen: the largest addend of every term is in [1/2, 1)
+            if (!(bad && !scaled)) {  // (the pass that stands)
+                if (__builtin_expect(__ballot(risk) != 0ull, 0)) {
+                    double Pw[1] = {P1};
+                    int Ew[1] = {E1};
+                    reduce_terms<1, 64>(Pw, Ew);
+                    if (lane == 0) {
+                        __hip_atomic_store(ones_ptr(c) + 2 * s, Pw[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(ones_ptr(c) + 2 * s + 1, (double)Ew[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    onesmask |= 1 << s;
+                }
+            }
           }
             {
                 const int ks = need_rescue ? (int)wave_sum((double)kacc) : 0;
@@ -3836,6 +3940,7 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
             if (vfast_s) vfastmask |= 1 << s;
         }
         if (lane == 0) { w->fastok = fastmask; w->vfast = vfastmask; }
+        c.ehas = ehas_mask | (onesmask << 16);
         if (lane < S) w->cacheN[lane] = 0;
         VLR_SYNC();  // also orders the e coefficients (HBM scratch row, written by other lanes than the ones that read them)
         if (__ballot((c.status & VLR_LOCUS_UNDERFLOW) != 0)) c.status |= VLR_LOCUS_UNDERFLOW;

@@ -174,7 +174,9 @@ struct DevResults {
                             // reference's map key, so equal VAFs under different l2fc lists stay two entries
     int32_t afd_capacity;
     int32_t replay;         // 0: call pass, 1: AFD replay pass
-    double* escratch;       // [n_loci * max_obs] third likelihood coefficient per kept observation (kernel scratch, plan-owned)
+    double* escratch;       // [n_loci * (2 S + max_obs)] kernel scratch, plan-owned; per locus: 2 S words = (mantissa, exponent) of
+                            // prod_i (w A_i + u_i), a sample's pileup likelihood at alpha = beta = 1 formed without the cancellation of c + q + e
+                            // (written per hypothesis for the samples that need it), then the third likelihood coefficient of every kept observation
     // AFD log (plan-owned, only when AFD lists are requested): the call pass appends every evaluated leaf operand set of the
     // clean events — whole visited-point tables of the Range chains, single discrete leaves — to a per-locus region of
     // afd_log_stride 8-byte words; vlr_afd_kernel filters it once the MAP is known.  Word 0 of a region = words used, or
