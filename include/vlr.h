@@ -539,6 +539,9 @@ int  vlr_bgzf_inflate(int device, const void* bgzf, int64_t n_bytes, void* out, 
  * side (cold records, table), [8] total; [9] inflated bytes, [10] compressed bytes, [11] records, [12] chunks whose record split fell
  * back to the serial walk, [13] seconds of the inflate kernels alone (HIP events on their stream, summed over the files). */
 void vlr_ingest_device_timings(double* out16, int reset);
+/* Closed device readers leave their device buffers (inflate windows, member lists; hundreds of MB per file) parked for the next reader
+ * of the process, bounded by VLR_INGEST_PARK_MB (default 2048).  A long-lived process calls this to hand all of it back to the device. */
+void vlr_ingest_device_trim(void);
 
 #ifdef __cplusplus
 }

@@ -10,3 +10,4 @@ for v in "$@"; do
   outs="$outs /tmp/p_${n}_$w.npz"
 done
 python tools/o1_probe.py /tmp/ref.npz $outs
+for f in $outs; do echo "#### $f"; python tools/o1_probe2.py /tmp/ref.npz $f; done

@@ -325,20 +325,22 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                     if native and reserve_loci[0]:   # size the plan's buffers once for the reader's request size: no growth (hipFree + hipMalloc) between chunks
                         plans[sig].reserve(reserve_loci[0], afd_capacity)
                 plan = plans[sig]
+                table = batch.extra.get("native_table") if getattr(batch, "extra", None) else None
+                on_dev = table is not None and getattr(table, "on_device", False)
+                if on_dev and len(mine) != L:
+                    # several models (or ranks) in one chunk: the sub-batches are cut from the HOST columns, which a device reader with
+                    # detached copies may still be filling — wait for them before the first select
+                    table.fetch_columns()
                 sub = batch if len(mine) == L else batch.select(mine)
                 # observation files are already capped by preprocess's --max-depth: size the LDS budget to the deepest record
-                # (deeper records than the LDS holds take the deep launch)
+                # (deeper records than the LDS holds take the deep launch); the depth comes from the offsets, never from the columns
                 plan.set_max_obs(min(max(int(sub.depth().sum(axis=1).max()), 1), engine.MAX_OBS_LDS))
-                table = batch.extra.get("native_table") if getattr(batch, "extra", None) else None
-                if len(mine) == L and table is not None and getattr(table, "on_device", False):
+                if len(mine) == L and on_dev:
                     # the columns were decoded on the device (device reader): nothing to stage but the results, which land in recycled
                     # page-locked memory when the calls writer is the only consumer (it hands the block back after the chunk is written)
                     buf = result_pool.results(L, n_out_, S_, afd_capacity) if result_pool is not None else None
                     r = plan.call_table_device(table, afd_capacity=afd_capacity, results=buf)
                 else:
-                    if table is not None and getattr(table, "on_device", False):
-                        table.fetch_columns()   # (several models in one chunk: the sub-batches are cut from the host columns)
-                        sub = batch if len(mine) == L else batch.select(mine)
                     r = plan.call_host(sub, afd_capacity=afd_capacity)
             else:
                 r = CallResults(0, n_out_, S_, afd_capacity)

@@ -68,6 +68,8 @@ bool bgzf_members(const uint8_t* p, size_t n, std::vector<vlr::InflateBlock>& ou
         b.src = off + 12 + xlen;
         b.clen = bsize - (12 + xlen) - 8;
         memcpy(&b.isize, p + off + bsize - 4, 4);
+        memcpy(&b.crc, p + off + bsize - 8, 4);
+        b.pad = 0;
         b.dst = total;
         total += b.isize;
         out.push_back(b);
@@ -654,6 +656,24 @@ struct vlr_dev_file {
 namespace {
 std::mutex& park_mutex() { static std::mutex m; return m; }
 std::vector<vlr_dev_file*>& parked() { static auto* v = new std::vector<vlr_dev_file*>(); return *v; }   // (never destroyed: no HIP calls at exit)
+// streams, events and every device buffer of a reader object back to the runtime (objects that are not parked, failed creations, trim)
+size_t dev_file_bytes(const vlr_dev_file* f) { return f->cap + f->spare_cap + f->comp_cap; }
+
+void dev_file_free(vlr_dev_file* f) {
+    (void)hipSetDevice(f->device);
+    if (f->feed_stream) (void)hipStreamDestroy(f->feed_stream);
+    if (f->copy_stream) (void)hipStreamDestroy(f->copy_stream);
+    if (f->ev0) (void)hipEventDestroy(f->ev0);
+    if (f->ev1) (void)hipEventDestroy(f->ev1);
+    if (f->stream) { (void)hipStreamSynchronize(f->stream); (void)hipStreamDestroy(f->stream); }
+    void* all[] = {f->buf, f->spare, f->d_comp, f->d_blocks, f->d_status, f->d_anchor, f->d_landing, f->d_segbase, f->d_count, f->d_landc, f->d_starts, f->d_nout,
+                   f->d_desc, f->d_host, f->d_fok, f->d_cold_off, f->d_cold};
+    for (void* p : all)
+        if (p) (void)hipFree(p);
+    if (f->h_host) (void)hipHostFree(f->h_host);
+    delete f;
+}
+
 template <typename T>
 int dev_grow(T*& p, size_t& cap, size_t need, size_t slack_num = 5, size_t slack_den = 4) {
     if (need <= cap) return VLR_OK;
@@ -695,10 +715,11 @@ int vlr_dev_file_create(int device, vlr_dev_file** out) {
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // (numerically: lowest priority first)
     if (hipStreamCreateWithPriority(&f->stream, hipStreamNonBlocking, prio_hi) != hipSuccess || hipStreamCreateWithPriority(&f->feed_stream, hipStreamNonBlocking, prio_lo) != hipSuccess) {
-        delete f;
+        (void)hipGetLastError();
+        dev_file_free(f);   // (whichever of the two streams exists is destroyed with it)
         return dfail(VLR_ERR_HIP, "hipStreamCreate failed");
     }
-    if (hipMalloc(&f->d_nout, 8) != hipSuccess) { (void)hipStreamDestroy(f->stream); delete f; return dfail(VLR_ERR_OUT_OF_MEMORY, "device reader: out of device memory"); }
+    if (hipMalloc(&f->d_nout, 8) != hipSuccess) { (void)hipGetLastError(); dev_file_free(f); return dfail(VLR_ERR_OUT_OF_MEMORY, "device reader: out of device memory"); }
     *out = f;
     return VLR_OK;
 }
@@ -709,22 +730,27 @@ void vlr_dev_file_destroy(vlr_dev_file* f) {
     if (f->feed_stream) (void)hipStreamSynchronize(f->feed_stream);
     if (f->stream) (void)hipStreamSynchronize(f->stream);
     if (f->copy_stream) (void)hipStreamSynchronize(f->copy_stream);
-    {   // parked for the next reader of this process (a handful at most): allocating and freeing half a gigabyte of device buffers per
-        // file costs milliseconds and hipFree synchronises the device
+    {   // parked for the next reader of this process: allocating and freeing half a gigabyte of device buffers per file costs
+        // milliseconds and hipFree synchronises the device.  Bounded in count AND in bytes (VLR_INGEST_PARK_MB, default 2048): a
+        // long-lived process does not sit on the inflate windows of every file it ever read; vlr_ingest_device_trim() returns the rest.
         std::lock_guard<std::mutex> g(park_mutex());
-        if (parked().size() < 8) { parked().push_back(f); return; }
+        size_t held = dev_file_bytes(f);
+        for (vlr_dev_file* q : parked()) held += dev_file_bytes(q);
+        size_t budget = (size_t)2048 << 20;
+        if (const char* ev = getenv("VLR_INGEST_PARK_MB")) budget = (size_t)std::max(0L, atol(ev)) << 20;
+        if (parked().size() < 8 && held <= budget) { parked().push_back(f); return; }
     }
-    if (f->feed_stream) (void)hipStreamDestroy(f->feed_stream);
-    if (f->copy_stream) (void)hipStreamDestroy(f->copy_stream);
-    if (f->ev0) (void)hipEventDestroy(f->ev0);
-    if (f->ev1) (void)hipEventDestroy(f->ev1);
-    if (f->stream) { (void)hipStreamSynchronize(f->stream); (void)hipStreamDestroy(f->stream); }
-    void* all[] = {f->buf, f->spare, f->d_comp, f->d_blocks, f->d_status, f->d_anchor, f->d_landing, f->d_segbase, f->d_count, f->d_landc, f->d_starts, f->d_nout,
-                   f->d_desc, f->d_host, f->d_fok, f->d_cold_off, f->d_cold};
-    for (void* p : all)
-        if (p) (void)hipFree(p);
-    if (f->h_host) (void)hipHostFree(f->h_host);
-    delete f;
+    dev_file_free(f);
+}
+
+// every reader object parked by vlr_dev_file_destroy goes back to the device (vlr_ingest_device_trim, include/vlr.h)
+void vlr_dev_file_trim() {
+    std::vector<vlr_dev_file*> all;
+    {
+        std::lock_guard<std::mutex> g(park_mutex());
+        all.swap(parked());
+    }
+    for (vlr_dev_file* f : all) dev_file_free(f);
 }
 
 double vlr_dev_file_inflate_seconds(vlr_dev_file* f, int reset) { if (!f) return 0.0; const double v = f->inflate_s; if (reset) f->inflate_s = 0.0; return v; }
@@ -788,7 +814,7 @@ int vlr_dev_file_feed_wait(vlr_dev_file* f) {
     f->feed_pending = false;
     if (f->ev0 && f->ev1) { float ms = 0.0f; if (hipEventElapsedTime(&ms, f->ev0, f->ev1) == hipSuccess) f->inflate_s += (double)ms * 1e-3; }
     for (size_t i = 0; i < f->pending_blocks; ++i)
-        if (f->h_status[i] != 0) return dfail(VLR_ERR_INVALID_ARGUMENT, "corrupt DEFLATE stream in a BGZF member (inflate status %s%lld)", "", (long long)f->h_status[i]);
+        if (f->h_status[i] != 0) return dfail(VLR_ERR_INVALID_ARGUMENT, "%s in a BGZF member (inflate status %lld)", f->h_status[i] == vlr::INFL_CRC_MISMATCH ? "CRC32 checksum mismatch" : "corrupt DEFLATE stream", (long long)f->h_status[i]);
     f->pending_blocks = 0;
     return VLR_OK;
 }

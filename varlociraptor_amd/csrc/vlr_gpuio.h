@@ -12,11 +12,13 @@ struct InflateBlock {
     uint64_t dst;    // byte offset of the member's first inflated byte in the output buffer
     uint32_t clen;   // DEFLATE bytes (BSIZE + 1 - 18 - 8)
     uint32_t isize;  // inflated bytes (ISIZE, <= 65536)
+    uint32_t crc;    // CRC32 of the inflated bytes (member trailer), checked on the device after the inflate (vlr_crc_kernel)
+    uint32_t pad;
 };
 constexpr size_t kInflateInputSlack = 32768;
 enum InflateStatus : int {
     INFL_OK = 0, INFL_BAD_BLOCK_TYPE = 1, INFL_BAD_STORED = 2, INFL_BAD_CODE_LENGTHS = 3, INFL_OVERSUBSCRIBED = 4, INFL_BAD_SYMBOL = 5,
-    INFL_BAD_DISTANCE = 6, INFL_OUTPUT_OVERRUN = 7, INFL_INPUT_OVERRUN = 8, INFL_SIZE_MISMATCH = 9,
+    INFL_BAD_DISTANCE = 6, INFL_OUTPUT_OVERRUN = 7, INFL_INPUT_OVERRUN = 8, INFL_SIZE_MISMATCH = 9, INFL_CRC_MISMATCH = 10,
 };
 
 // what the INFO scan leaves per record for the decode and cold-copy kernels
@@ -78,6 +80,8 @@ int vlr_launch_inflate_kernel(const uint8_t* d_comp, const vlr::InflateBlock* d_
 struct vlr_dev_file;
 int vlr_dev_file_create(int device, vlr_dev_file** out);
 void vlr_dev_file_destroy(vlr_dev_file* f);
+// destroyed reader objects are parked for the next reader (their device buffers stay allocated, bounded by VLR_INGEST_PARK_MB): free them all
+void vlr_dev_file_trim();
 // bytes of complete-or-not record data currently buffered behind the read position
 uint64_t vlr_dev_file_buffered(const vlr_dev_file* f);
 // append the inflated bytes of n_blocks members (src offsets relative to comp) behind the buffered ones: enqueued on the file's feed

@@ -30,6 +30,9 @@ extern "C" int vlr_launch_call_kernel_wide(const vlr::DevPlanT<16>* plan_dev, co
                                            int n_univ, int n_samples, int max_obs, int range_depth, void* stream);
 extern "C" int vlr_launch_call_kernel(const vlr::DevPlanT<8>* plan_dev, const vlr::DevBatch* batch, const vlr::DevResults* out,
                                       int n_univ, int n_samples, int max_obs, int range_depth, void* stream);
+// LDS a workgroup of the plan needs before any coefficient area (call pass, AFD replay, AFD log filter; vlr_kernels.hip)
+extern "C" long long vlr_plan_lds_floor(const vlr::DevPlanT<8>* plan_host, int n_univ, int n_samples, int range_depth);
+extern "C" long long vlr_plan_lds_floor_wide(const vlr::DevPlanT<16>* plan_host, int n_univ, int n_samples, int range_depth);
 
 namespace {
 
@@ -850,6 +853,16 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
     P.froot = (const DevFastRoot*)(base + o_fr);
     plan->host = P;
     if (S <= 8) plan->host8 = narrow_plan(P);
+    {   // The tables of the plan (Set candidates, the replay's lists of seen discrete operands: S x max_set doubles each) must leave room
+        // for at least a minimal pileup in the 160 KiB of LDS a CU has; otherwise the first batch would fail with a launch error.
+        const long long floor_b = S <= 8 ? vlr_plan_lds_floor(&plan->host8, P.n_univ, S, P.max_range_depth) : vlr_plan_lds_floor_wide(&plan->host, P.n_univ, S, P.max_range_depth);
+        const long long min_pileup = 16ll * 64;   // coefficient pairs of 64 observations
+        if (floor_b + min_pileup > 160ll * 1024) {
+            vlr_plan_destroy(plan);
+            return fail(VLR_ERR_UNSUPPORTED, "scenario needs %lld bytes of LDS per locus before any observation (largest Set spectrum %d members x %d samples): "
+                                             "above the 160 KiB of a CU", floor_b, P.max_set, S);
+        }
+    }
     hipError_t e = hipMemcpy(plan->blob, hostblob.data(), total, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&plan->dev, sizeof(DevPlanT<16>));
     if (e == hipSuccess) e = hipMemcpy(plan->dev, &P, sizeof(DevPlanT<16>), hipMemcpyHostToDevice);

@@ -10,10 +10,11 @@
 // (bit buffer, output position, current symbol) is wave-uniform, and uses the 64 lanes for everything that is parallel around it:
 //   * the compressed bytes reach the bit buffer through a 64-dword window held one dword per lane (one coalesced load per 256
 //     bytes, prefetched one window ahead); the decoder takes dword i with a lane read — no memory latency on the serial path;
-//   * the last 32 KiB of the inflated member (DEFLATE's window) live in an LDS ring, so a match is one LDS read and one LDS write
-//     of up to 64 bytes per instruction pair, with the period trick for overlapping matches (source index = i mod distance), and
-//     literals are single LDS byte stores; 39 kB of LDS per wave = four members in flight per CU, one per SIMD (a single wave
-//     issues an instruction every ~2 cycles at best: the ~70 instructions of a symbol, not the memory system, set its pace);
+//   * the last 4 KiB of the inflated member live in an LDS ring, so a match is one LDS read and one LDS write of up to 64 bytes per
+//     instruction pair, with the period trick for overlapping matches (source index = i mod distance), and literals are single LDS
+//     byte stores; the one match in ten that reaches further back than the ring (DEFLATE's window is 32 KiB) reads the member's own
+//     flushed output from HBM instead.  11 kB of LDS per wave = fourteen members in flight per CU (round 4: a 32 KiB ring, 39 kB,
+//     four members — one wave per SIMD, whose ~70 dependent instructions per symbol set the pace with nothing to hide them behind);
 //   * symbols are decoded in speculative batches: lane i decodes the symbol that WOULD start at bit i of the next 64 stream bits
 //     (literal/length lookup, extra bits, distance lookup, extra bits — two LDS round trips for 64 candidates at once) and leaves a
 //     32-bit token with the bits it takes; the wave then follows the chain of real symbol starts through the tokens with lane reads
@@ -25,8 +26,7 @@
 //     bit-serial walk;
 //   * finished 8 KiB pieces of the ring go to HBM in 16-byte lanes (ring positions are shifted by the low 4 bits of the destination
 //     so both sides of the copy are aligned).
-// CRC32 of the member is NOT checked on the device (ISIZE, end-of-block and every code are); the host reader (vlr_obs_reader_open,
-// VLR_INGEST_HOST=1 in the CLI) inflates with libdeflate / zlib, which check it.
+// The CRC32 of every member is checked against its trailer by vlr_crc_kernel, launched behind the inflate kernel (below).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -40,10 +40,17 @@ constexpr int kLitBits = 10, kDistBits = 9, kClBits = 7;
 constexpr bool kInflateBatchDefault = true;   // speculative batches (VLR_INFLATE_BATCH=0: one symbol at a time, the cross-check)
 // a corrupt stream is noticed at the next position check (every 8.7 KiB of output at most = 16.3 KiB of input at 15 bits per symbol):
 // the compressed bytes handed to the kernel must be readable this far beyond the last member (vlr_gpuio.h kInflateInputSlack)
-constexpr uint32_t kRing = 32768, kRingMask = kRing - 1, kFlush = 8192;   // flushed to HBM in 8 KiB pieces, each before the ring wraps onto it
+// The ring holds the last 4 KiB of the inflated member, not DEFLATE's whole 32 KiB window: 86 % of the matches of an observation file
+// reach back less than 1 KiB, 10 % between 8 and 16 KiB (the same INFO vector of the previous record) whatever the ring below 8 KiB — a
+// match that reaches beyond the ring (dist + len > kRing) takes its bytes from the member's flushed output in HBM (L2-resident: written
+// microseconds ago by this wave).  11 kB of LDS per wave instead of 39: fourteen members per CU instead of four, which is what a
+// decoder bound by the issue rate and latencies of ONE wave needs.  Everything below kRing - (kFlush + 512 + 2 x 258) behind the
+// position is in HBM when a far match asks for it: kRing >= kFlush + 1286.
+constexpr uint32_t kRing = 4096, kRingMask = kRing - 1, kFlush = 1024;   // flushed to HBM in 1 KiB pieces, each before the ring wraps onto it
+static_assert(kRing >= kFlush + 1286, "far matches read flushed bytes only");
 
 struct InflLds {
-    uint8_t out[kRing];              // ring over the last 32 KiB of the inflated member (DEFLATE's window), position shifted by (HBM destination & 15)
+    uint8_t out[kRing];              // ring over the last kRing bytes of the inflated member, position shifted by (HBM destination & 15)
     uint32_t lit[1 << kLitBits];     // code length (4) | kind (2: literal, length, end of block, invalid) @4 | value or length base (9) @8 | extra bits (3) @20
     uint32_t dist[1 << kDistBits];   // code length (4) | extra bits (4; 15 = invalid symbol) @4 | base (16) @8.  Also the code-length code's table.
     uint16_t lsym[288], dsym[32];    // symbols in canonical order (bit-serial fallback)
@@ -209,6 +216,42 @@ __device__ __forceinline__ void flush_ring(const InflLds& L, uint8_t* gbase, uin
         if (k >= from && k + 16 <= to) *reinterpret_cast<uint4*>(gbase + k) = *reinterpret_cast<const uint4*>(&L.out[k & kRingMask]);
         else
             for (uint32_t j = k < from ? from : k; j < k + 16 && j < to; ++j) gbase[j] = L.out[j & kRingMask];
+    }
+}
+
+// the len bytes of a match at distance dist, appended at ring position pos (all wave-uniform).  Near matches: one LDS read and one LDS
+// write of up to 64 bytes per instruction pair, byte k of the match repeats with period dist (k mod dist, = k when dist >= len; an
+// approximate reciprocal with two corrections is exact for k < 512).  Far matches (beyond the ring): the bytes come from the member's
+// own output in HBM, which the flushes have written (kRing >= kFlush + 1286: every byte that far back is flushed) — loads at agent
+// scope (past the vector L1, which may hold a line of the flush frontier from an earlier far match), after the flush stores of
+// this wave have completed.  `ok`: the distance lies inside the member (a corrupt stream's does not: nothing is read then).
+__device__ __forceinline__ void copy_match(InflLds& L, const uint8_t* gbase, uint32_t pos, uint32_t dist, uint32_t len, bool ok, int lane) {
+    const uint32_t from = pos - dist;
+    if (__builtin_expect(dist + len > kRing, 0)) {
+        if (!ok) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        for (uint32_t k = (uint32_t)lane; k < len; k += 64) {
+            const uintptr_t a = (uintptr_t)(gbase + from + k);
+            const uint32_t w = __hip_atomic_load((const uint32_t*)(a & ~(uintptr_t)3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            L.out[(pos + k) & kRingMask] = (uint8_t)(w >> (8u * (uint32_t)(a & 3)));
+        }
+        return;
+    }
+    const float rd = __builtin_amdgcn_rcpf((float)(dist | (uint32_t)(dist == 0)));
+    if (len <= 64) {
+        const uint32_t k = (uint32_t)lane;
+        int r = (int)k - (int)((float)k * rd) * (int)dist;
+        r = r < 0 ? r + (int)dist : r;
+        r = r >= (int)dist ? r - (int)dist : r;
+        const uint8_t v = L.out[(from + (uint32_t)r) & kRingMask];
+        if (k < len) L.out[(pos + k) & kRingMask] = v;
+    } else {
+        for (uint32_t k = (uint32_t)lane; k < len; k += 64) {
+            int r = (int)k - (int)((float)k * rd) * (int)dist;
+            r = r < 0 ? r + (int)dist : r;
+            r = r >= (int)dist ? r - (int)dist : r;
+            L.out[(pos + k) & kRingMask] = L.out[(from + (uint32_t)r) & kRingMask];
+        }
     }
 }
 
@@ -402,24 +445,9 @@ __global__ __launch_bounds__(64) void vlr_inflate_kernel(const uint8_t* __restri
                         pos += 1;
                     } else if (kind == 1) {
                         const uint32_t len = (t >> 8) & 511u, dist = (t >> 17) + 1u;
-                        bad |= (dist > pos - sh) ? (uint32_t)INFL_BAD_DISTANCE : 0u;
-                        const uint32_t from = pos - dist;
-                        const float rd = __builtin_amdgcn_rcpf((float)dist);
-                        if (len <= 64) {
-                            const uint32_t k = (uint32_t)lane;
-                            int r = (int)k - (int)((float)k * rd) * (int)dist;
-                            r = r < 0 ? r + (int)dist : r;
-                            r = r >= (int)dist ? r - (int)dist : r;
-                            const uint8_t vv = L.out[(from + (uint32_t)r) & kRingMask];
-                            if (k < len) L.out[(pos + k) & kRingMask] = vv;
-                        } else {
-                            for (uint32_t k = (uint32_t)lane; k < len; k += 64) {
-                                int r = (int)k - (int)((float)k * rd) * (int)dist;
-                                r = r < 0 ? r + (int)dist : r;
-                                r = r >= (int)dist ? r - (int)dist : r;
-                                L.out[(pos + k) & kRingMask] = L.out[(from + (uint32_t)r) & kRingMask];
-                            }
-                        }
+                        const bool inside = dist <= pos - sh;
+                        bad |= inside ? 0u : (uint32_t)INFL_BAD_DISTANCE;
+                        copy_match(L, gbase, pos, dist, len, inside, lane);
                         pos += len;
                     } else {
                         done = true;   // 2: end of block
@@ -472,28 +500,11 @@ __global__ __launch_bounds__(64) void vlr_inflate_kernel(const uint8_t* __restri
                 const int dx = (int)((d >> 4) & 15u);
                 const uint32_t dist = (d >> 8) + peek(b, dx);
                 drop(b, dx);
-                bad |= ((dx == 15) | (dist > pos - sh)) ? (uint32_t)INFL_BAD_DISTANCE : 0u;
+                const bool inside = (dx != 15) & (dist <= pos - sh) & (dist != 0);
+                bad |= inside ? 0u : (uint32_t)INFL_BAD_DISTANCE;
                 refill(b, lane);
                 const uint32_t ev = L.lit[peek(b, kLitBits)];   // the next symbol's entry: in flight while the bytes are copied
-                const uint32_t from = pos - dist;
-                // byte k of the match repeats with period `dist` (k mod dist = k when dist >= len); every source byte lies before `pos`
-                // (approximate reciprocal: the two corrections below make the remainder exact for k < 512)
-                const float rd = __builtin_amdgcn_rcpf((float)(dist | (uint32_t)(dist == 0)));
-                if (len <= 64) {
-                    const uint32_t k = (uint32_t)lane;
-                    int r = (int)k - (int)((float)k * rd) * (int)dist;
-                    r = r < 0 ? r + (int)dist : r;
-                    r = r >= (int)dist ? r - (int)dist : r;
-                    const uint8_t v = L.out[(from + (uint32_t)r) & kRingMask];
-                    if (k < len) L.out[(pos + k) & kRingMask] = v;
-                } else {
-                    for (uint32_t k = (uint32_t)lane; k < len; k += 64) {
-                        int r = (int)k - (int)((float)k * rd) * (int)dist;
-                        r = r < 0 ? r + (int)dist : r;
-                        r = r >= (int)dist ? r - (int)dist : r;
-                        L.out[(pos + k) & kRingMask] = L.out[(from + (uint32_t)r) & kRingMask];
-                    }
-                }
+                copy_match(L, gbase, pos, dist, len, inside, lane);
                 pos += len;
                 e = uni(ev);
             } else {
@@ -518,6 +529,89 @@ __global__ __launch_bounds__(64) void vlr_inflate_kernel(const uint8_t* __restri
     if (lane == 0) status[blk] = err;
 }
 
+// ---- CRC32 of every inflated member against its trailer (RFC 1952 2.3.1; htslib checks it per block: bgzf.c inflate_block /
+// bgzf_read_block "CRC32 checksum mismatch", the reader behind the reference's bcf::Reader, calling.rs:306-318).  A flipped bit in a
+// literal or a stored byte decodes to another valid stream of the same length: without this check it would end in wrong pileups.
+// One wave per member.  Lane 0 takes the first n - 63 C bytes, lanes 1..63 C bytes each (C: the multiple of four below n / 64), sixteen
+// bytes per load, slicing-by-4 through tables in LDS (4 KiB); the lane values are combined like zlib's crc32_combine:
+// crc(A || B) = crc(A) x^(8 |B|) mod P  xor  crc(B), along a binary tree whose right-hand lengths are C, 2 C, 4 C, ...
+constexpr uint32_t kCrcPoly = 0xedb88320u;   // reflected CRC-32 (IEEE 802.3)
+// a(x) b(x) mod P in the reflected representation (zlib crc32.c multmodp)
+__host__ __device__ constexpr uint32_t crc_multmodp(uint32_t a, uint32_t b) {
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1)) == 0) break;
+        }
+        m >>= 1;
+        b = (b & 1u) ? (b >> 1) ^ kCrcPoly : b >> 1;
+    }
+    return p;
+}
+struct CrcX2n { uint32_t v[32]; };   // x^(2^n) mod P
+constexpr CrcX2n crc_x2n_table() {
+    CrcX2n t{};
+    uint32_t p = 1u << 30;   // x^1
+    t.v[0] = p;
+    for (int n = 1; n < 32; ++n) { p = crc_multmodp(p, p); t.v[n] = p; }
+    return t;
+}
+__device__ constexpr CrcX2n kCrcX2n = crc_x2n_table();
+// x^(n 2^k) mod P (zlib x2nmodp)
+__device__ __forceinline__ uint32_t crc_x2nmodp(uint32_t n, unsigned k) {
+    uint32_t p = 1u << 31;   // x^0
+    while (n) {
+        if (n & 1u) p = crc_multmodp(kCrcX2n.v[k & 31u], p);
+        n >>= 1;
+        ++k;
+    }
+    return p;
+}
+struct __attribute__((packed, aligned(1))) CrcQuad { uint32_t w[4]; };
+__global__ void __launch_bounds__(64) vlr_crc_kernel(const uint8_t* __restrict__ out, const InflateBlock* __restrict__ blocks, int n_blocks, int* __restrict__ status) {
+    __shared__ uint32_t T[4][256];
+    const int lane = threadIdx.x;
+    const int blk = blockIdx.x;
+    if (blk >= n_blocks) return;
+    for (int i = lane; i < 256; i += 64) {
+        uint32_t c = (uint32_t)i;
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ kCrcPoly : c >> 1;
+        T[0][i] = c;
+    }
+    __syncthreads();
+    for (int i = lane; i < 256; i += 64) {
+        uint32_t c = T[0][i];
+        for (int t = 1; t < 4; ++t) { c = T[0][c & 0xffu] ^ (c >> 8); T[t][i] = c; }
+    }
+    __syncthreads();
+    const uint32_t n = blocks[blk].isize;
+    const uint32_t C = (n >> 6) & ~3u;
+    const uint32_t first = n - 63u * C;                      // lane 0's share (C .. C + 255 bytes)
+    const uint32_t len = lane == 0 ? first : C;
+    const uint8_t* g = out + blocks[blk].dst + (lane == 0 ? 0u : first + (uint32_t)(lane - 1) * C);
+    uint32_t c = 0xffffffffu;
+    uint32_t i = 0;
+    for (; i + 16 <= len; i += 16) {
+        const CrcQuad q = *(const CrcQuad*)(g + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            c ^= q.w[j];
+            c = T[3][c & 0xffu] ^ T[2][(c >> 8) & 0xffu] ^ T[1][(c >> 16) & 0xffu] ^ T[0][c >> 24];
+        }
+    }
+    for (; i < len; ++i) c = T[0][(c ^ g[i]) & 0xffu] ^ (c >> 8);
+    c = ~c;                                                  // the finished CRC of the lane's piece (of nothing: 0)
+    // tree: at level k the left neighbour's value moves over 2^k C bytes
+    uint32_t X = crc_x2nmodp(C, 3);                          // x^(8 C)
+    for (int k = 0; k < 6; ++k) {
+        const uint32_t right = (uint32_t)__shfl_down((int)c, 1 << k, 64);
+        if ((lane & ((2 << k) - 1)) == 0) c = crc_multmodp(X, c) ^ right;
+        X = crc_multmodp(X, X);
+    }
+    if (lane == 0 && status[blk] == INFL_OK && c != blocks[blk].crc) status[blk] = INFL_CRC_MISMATCH;
+}
+
 }  // namespace
 }  // namespace vlr
 
@@ -528,5 +622,8 @@ extern "C" int vlr_launch_inflate_kernel(const uint8_t* d_comp, const vlr::Infla
     const bool batch = env ? atoi(env) != 0 : vlr::kInflateBatchDefault;
     if (batch) hipLaunchKernelGGL(vlr::vlr_inflate_kernel<true>, dim3((unsigned)n_blocks), dim3(64), 0, (hipStream_t)stream, d_comp, d_blocks, n_blocks, d_out, d_status);
     else hipLaunchKernelGGL(vlr::vlr_inflate_kernel<false>, dim3((unsigned)n_blocks), dim3(64), 0, (hipStream_t)stream, d_comp, d_blocks, n_blocks, d_out, d_status);
+    // the members' CRC32 against their trailers, behind the inflate in stream order (VLR_INFLATE_CRC=0: measurement only)
+    const char* ce = getenv("VLR_INFLATE_CRC");
+    if (!ce || atoi(ce) != 0) hipLaunchKernelGGL(vlr::vlr_crc_kernel, dim3((unsigned)n_blocks), dim3(64), 0, (hipStream_t)stream, d_out, d_blocks, n_blocks, d_status);
     return (int)hipGetLastError();
 }

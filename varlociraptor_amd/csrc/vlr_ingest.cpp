@@ -180,7 +180,7 @@ bool read_whole_file(const char* path, Blob& out, std::string& err) {
     return true;
 }
 
-struct BgzfBlock { size_t off, clen; uint32_t isize; size_t out_off; };
+struct BgzfBlock { size_t off, clen; uint32_t isize; size_t out_off; uint32_t crc; };   // crc: CRC32 of the inflated bytes (member trailer)
 
 // all gzip members carry the BGZF extra field `BC` with their total size: index them without inflating
 bool bgzf_index(const Blob& raw, std::vector<BgzfBlock>& blocks) {
@@ -201,7 +201,8 @@ bool bgzf_index(const Blob& raw, std::vector<BgzfBlock>& blocks) {
         if (bsize < 0 || p + (size_t)bsize > raw.size() || (size_t)bsize < xlen + 20) return false;
         const size_t cdata = xend, cend = p + (size_t)bsize - 8;
         const uint32_t isize = raw[cend + 4] | (raw[cend + 5] << 8) | (raw[cend + 6] << 16) | ((uint32_t)raw[cend + 7] << 24);
-        blocks.push_back({cdata, cend - cdata, isize, total});
+        const uint32_t crc = raw[cend] | (raw[cend + 1] << 8) | (raw[cend + 2] << 16) | ((uint32_t)raw[cend + 3] << 24);
+        blocks.push_back({cdata, cend - cdata, isize, total, crc});
         total += isize;
         p += (size_t)bsize;
     }
@@ -237,12 +238,19 @@ struct LibDeflate {
 };
 const LibDeflate& libdeflate() { static LibDeflate L; return L; }
 
-bool inflate_raw(const uint8_t* src, size_t clen, uint8_t* dst, size_t dlen) {
+// CRC32 of an inflated member against the value in its trailer (RFC 1952; htslib's bgzf.c checks it for every block it reads)
+bool member_crc_ok(const uint8_t* data, size_t n, uint32_t want) {
+    const LibDeflate& ld = libdeflate();
+    const uint32_t got = ld.ok ? ld.crc32(0, data, n) : (uint32_t)crc32(crc32(0L, Z_NULL, 0), data, (uInt)n);
+    return got == want;
+}
+// one BGZF member: raw DEFLATE -> dlen bytes whose CRC32 is `crc`
+bool inflate_raw(const uint8_t* src, size_t clen, uint8_t* dst, size_t dlen, uint32_t crc) {
     const LibDeflate& ld = libdeflate();
     if (ld.ok) {
         thread_local void* d = ld.alloc_d();
         size_t got = 0;
-        if (d && ld.decompress(d, src, clen, dst, dlen, &got) == 0 && got == dlen) return true;
+        if (d && ld.decompress(d, src, clen, dst, dlen, &got) == 0 && got == dlen) return member_crc_ok(dst, dlen, crc);
         // fall through to zlib on any doubt
     }
     z_stream zs;
@@ -253,7 +261,7 @@ bool inflate_raw(const uint8_t* src, size_t clen, uint8_t* dst, size_t dlen) {
     const int rc = inflate(&zs, Z_FINISH);
     const bool ok = (rc == Z_STREAM_END) && zs.total_out == dlen;
     inflateEnd(&zs);
-    return ok;
+    return ok && member_crc_ok(dst, dlen, crc);
 }
 
 // file contents, decompressed: BGZF (parallel), plain gzip (sequential), or as is
@@ -275,7 +283,7 @@ bool load_inflated(const char* path, Blob& out_blob, int n_threads, std::string&
         parallel_items((int64_t)blocks.size(), n_threads, [&](int64_t i, int) {
             const BgzfBlock& b = blocks[(size_t)i];
             if (b.isize == 0) return;
-            if (!inflate_raw(raw.data() + b.off, b.clen, out_blob.p + b.out_off, b.isize)) bad = true;
+            if (!inflate_raw(raw.data() + b.off, b.clen, out_blob.p + b.out_off, b.isize, b.crc)) bad = true;
         });
         g_ingest_t[1] += now_s() - t1;
         if (bad) { err = std::string("corrupt BGZF block in ") + path; return false; }
@@ -1589,7 +1597,7 @@ bool stream_fill(FileStream& f, size_t count, int n_threads, std::string& err) {
     const double t_inf0 = now_s();
     parallel_items((int64_t)(b1 - b0), n_threads, [&](int64_t i, int) {
         const BgzfBlock& b = f.blocks[b0 + (size_t)i];
-        if (b.isize && !inflate_raw(f.raw.p + b.off, b.clen, f.win.p + old + off[(size_t)i], b.isize)) bad = true;
+        if (b.isize && !inflate_raw(f.raw.p + b.off, b.clen, f.win.p + old + off[(size_t)i], b.isize, b.crc)) bad = true;
     });
     g_ingest_t[1] += now_s() - t_inf0;  // (summed over the sample files, which run side by side)
     f.next_block = b1;
@@ -1818,7 +1826,7 @@ int dev_stream_open(DevFileStream& f, const char* path, int device) {
         const BgzfBlock& k = f.blocks[b++];
         const size_t old = head.size();
         head.resize(old + k.isize);
-        if (k.isize && !inflate_raw(f.raw.p + k.off, k.clen, head.data() + old, k.isize)) return ifail(VLR_ERR_INVALID_ARGUMENT, "corrupt BGZF block in %s", path);
+        if (k.isize && !inflate_raw(f.raw.p + k.off, k.clen, head.data() + old, k.isize, k.crc)) return ifail(VLR_ERR_INVALID_ARGUMENT, "corrupt BGZF block in %s", path);
         if (head.size() >= 9 && need == 9) {
             if (memcmp(head.data(), "BCF\2\2", 5) != 0) return ifail(VLR_ERR_UNSUPPORTED, "device reader: %s is not a BCF2 file (use vlr_obs_reader_open)", path);
             uint32_t l_text;
@@ -1854,7 +1862,7 @@ int dev_stream_feed(DevFileStream& f, uint64_t want) {
         while (b1 < f.blocks.size() && (have + add < goal() || b1 == b0) && b1 - b0 < (1u << 20)) {
             const BgzfBlock& k = f.blocks[b1];
             vlr::InflateBlock x;
-            x.src = k.off - f.blocks[b0].off; x.dst = add; x.clen = (uint32_t)k.clen; x.isize = k.isize;
+            x.src = k.off - f.blocks[b0].off; x.dst = add; x.clen = (uint32_t)k.clen; x.isize = k.isize; x.crc = k.crc; x.pad = 0;
             f.ib.push_back(x);
             add += k.isize;
             ++b1;
@@ -2016,7 +2024,10 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
     // the per-pileup summaries need P headers and at most one entry and one run per observation: they are brought down INTO the host
     // side of the column region, so they must fit there (they do unless most pileups are empty)
     const int64_t P = L * S;
-    const size_t sum_need = (size_t)P * sizeof(vlr::PileSum) + 64 + (size_t)total * 12 + 64 + (size_t)total * 8 + 64;
+    // (the same 64-byte roundings as the host layout below: headers, keys, counts, run values, run lengths — entries and runs are at most
+    //  one per observation)
+    const auto up64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
+    const size_t sum_need = up64((size_t)P * sizeof(vlr::PileSum)) + up64((size_t)total * 8) + 3 * up64((size_t)total * 4);
     const bool summaries = !r->host_columns && !r->summaries_off && sum_need <= dl.off_lflags - dl.off_col[0];
     if (!summaries) {   // columns down for the calls writer (one copy: the column arrays are contiguous in the slab)
         DevFileStream& f0 = *r->dfiles[0];
@@ -2183,6 +2194,8 @@ void vlr_ingest_device_timings(double* out16, int reset) {
     if (out16) for (int i = 0; i < 16; ++i) out16[i] = g_dev_t[i];
     if (reset) for (int i = 0; i < 16; ++i) g_dev_t[i] = 0.0;
 }
+
+void vlr_ingest_device_trim(void) { vlr_dev_file_trim(); }
 
 }  // extern "C"
 

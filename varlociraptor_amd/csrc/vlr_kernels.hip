@@ -181,6 +181,9 @@ __device__ __forceinline__ double uni_d(double v) {
 // The lane id as a value the optimiser cannot hoist: without it every lane-derived constant of the chain runners
 // ((double)(lane - 1), row masks, ...) is computed once before the hypothesis loop and then SPILLED across it.
 __device__ __forceinline__ int fresh_lane(int lane) {
+#ifdef VLR_DBG_NO_FRESH_LANE
+    return lane;
+#endif
     asm volatile("" : "+v"(lane));
     return lane;
 }
@@ -216,6 +219,12 @@ __device__ __forceinline__ double div3(double x) {
 // kept alive — and spilled — across the whole kernel, and six LDS round trips per reduction.)
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
+#ifdef VLR_DBG_DPP_SHFL  // diagnosis builds: the four permutations of the reductions through ds_bpermute instead of DPP moves of the halves
+    const int l_ = (int)__lane_id();
+    const int src_ = CTRL == 0xB1 ? (l_ ^ 1) : CTRL == 0x4E ? (l_ ^ 2) : CTRL == 0x141 ? ((l_ & ~7) | (7 - (l_ & 7))) : CTRL == 0x140 ? ((l_ & ~15) | (15 - (l_ & 15)))
+                   : CTRL == 0x124 ? ((l_ & ~15) | ((l_ + 4) & 15)) : CTRL == 0x128 ? ((l_ & ~15) | ((l_ + 8) & 15)) : l_;
+    if (CTRL == 0xB1 || CTRL == 0x4E || CTRL == 0x141 || CTRL == 0x140 || CTRL == 0x124 || CTRL == 0x128) return __shfl(v, src_, 64);
+#endif
     int lo = __double2loint(v), hi = __double2hiint(v);
     // every lane has a valid source under these permutations: bound_ctrl with an undefined `old` lets the compiler write the
     // destination directly instead of copying the source first (three instructions per f64 permute otherwise)
@@ -226,6 +235,9 @@ __device__ __forceinline__ double dpp_f64(double v) {
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
 __device__ __forceinline__ double lane_d(double v, int l) {
+#ifdef VLR_DBG_LANE_SHFL
+    return __shfl(v, l, 64);
+#endif
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 __device__ __forceinline__ double wave_sum(double v) {
@@ -489,6 +501,12 @@ __device__ inline double ddacc_exp(const DdAcc& a, double m) {
 // mantissa/exponent renormalisation of a POSITIVE NORMAL double with integer ops on the high word (the
 // fast path guarantees every partial product stays far above 2^-1022)
 __device__ __forceinline__ void renorm_pos(double& P, int& E) {
+#ifdef VLR_DBG_RENORM_FREXP  // diagnosis builds (tools/o1_variant.sh): the same renormalisation through the frexp instructions
+    int e_;
+    P = __builtin_frexp(P, &e_);
+    E += e_;
+    return;
+#endif
     const int hi = __double2hiint(P);
     E += (int)(((unsigned)hi >> 20) & 0x7ffu) - 1022;
     P = __hiloint2double((hi & 0x800fffff) | 0x3fe00000, __double2loint(P));
@@ -593,6 +611,9 @@ __device__ __forceinline__ void accum_terms_e(const double* __restrict__ coef, c
 template <int NP, int W>
 __device__ __forceinline__ void accum_terms(const double* __restrict__ coef, const double* __restrict__ ecoef, int D, int k, bool fast,
                                             const double* al, const double* be, double* P, int* E) {
+#ifdef VLR_DBG_ROBUST_TERMS  // diagnosis builds: every product through the per-term frexp path
+    fast = false;
+#endif
     bool nz = false;
 #pragma unroll
     for (int j = 0; j < NP; ++j) nz = nz || (be[j] != 0.0);
@@ -1744,6 +1765,9 @@ __device__ __forceinline__ int row_or(int v) {
 // fdlibm's e_log.c (< 1 ulp); no special cases (zero, negative, infinite, subnormal arguments cannot occur), about half the
 // instructions of the general log().  Returns ln(m) as hi part; the caller adds E * ln 2.
 __device__ __forceinline__ double ln_mantissa(double m) {
+#ifdef VLR_DBG_LIBM_LOG  // diagnosis builds: the library logarithm
+    return log(m);
+#endif
     const bool small = m < 0.70710678118654752440;
     const double mm = small ? m * 2.0 : m;       // [sqrt(1/2), sqrt(2))
     const double kk = small ? -1.0 : 0.0;
@@ -1766,6 +1790,9 @@ __device__ __forceinline__ double ln_mantissa(double m) {
 // value of row lane N on every lane of its 16-lane DPP row (row_newbcast: no LDS round trip)
 template <int N>
 __device__ __forceinline__ double row_bcast(double v) {
+#ifdef VLR_DBG_BCAST_SHFL
+    return __shfl(v, ((int)__lane_id() & ~15) | N, 64);
+#endif
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + N, 0xF, 0xF, true);
     hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + N, 0xF, 0xF, true);
@@ -1777,9 +1804,13 @@ __device__ __forceinline__ double row_bcast(double v) {
 // hold {c, q} = {1, 0}, so their term is exactly 1.  Same association as accum_terms_e's two-term groups (mantissas are
 // bit-identical); no renormalisation: every term is in [2^-70, 2] (WaveSt::vfast), 13 of them stay normal.
 constexpr int kRegSlots = 13;  // 16 * 13 = 208 observations of the integrated sample
+#ifdef VLR_DBG_REGHELD  // diagnosis builds: fewer (or no) coefficient pairs held in registers across a batch
+constexpr int kRegHeld = VLR_DBG_REGHELD;
+#else
 constexpr int kRegHeld = 8;    // slots whose coefficient pairs stay in registers for the whole batch; deeper slots of the 13-slot
                                // variant are re-read from LDS every pass (five b128 reads): holding all 13 pushed the
                                // 3-waves-per-SIMD build 20 VGPRs over its budget and the spills around the batch loop went to HBM
+#endif
 template <int NS>
 __device__ __forceinline__ void reg_products(const double* cc, const double* cq, const double* lcoef, int rl, int D, const double* al, double* P) {
     constexpr int NR = NS < kRegHeld ? NS : kRegHeld;
@@ -1912,7 +1943,11 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
     int k = 0, tn = 0;
     bool failed = false, sawnan = false;
     const bool all_fast = __ballot(q.rowon && !q.cls_fast) == 0ull;
+#ifdef VLR_DBG_NO_ONES_PASS
+    const bool ones_on = false;
+#else
     const bool ones_on = ones_any(c) && ones_risk(c, q.inner);
+#endif
     const bool cap_safe = p.table_cap < kTableCap;  // the host's bound was not clamped (vlr_host.cpp: table capacity)
     double L = lo, R = hi, vL = VLR_NEG_INF, vR = VLR_NEG_INF, mid = lo;
     long long kL = 0, kR = 0;  // KEYED: the bracket ends' product keys
@@ -2020,7 +2055,12 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
         long long key = 0;
         if (KEYED) {
             key = product_key(Psel, Esel);
+#ifdef VLR_DBG_UNIFORM_STORES  // diagnosis builds: the table append without a divergent region (lanes that own no point write to a scratch row)
+            { double* dx_ = owner ? q.tx + (tn + rl) : c.w->bpend[0] + (c.lane & 31); double* dv_ = owner ? q.tv + (tn + rl) : c.w->bvals[0] + (c.lane & 31);
+              *dx_ = x; *dv_ = __longlong_as_double(key); }
+#else
             if (owner) { q.tx[tn + rl] = x; q.tv[tn + rl] = __longlong_as_double(key); }
+#endif
         } else {
             double lm = ln_mantissa(Psel);
             if (__builtin_expect(ones_on, 0)) lm = ln_product_mantissa(Psel);  // (a direct all-ones product may be exactly zero)
@@ -2033,7 +2073,12 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
                 joint = pv + lik;
             }
             sawnan = sawnan || (owner && joint != joint);
+#ifdef VLR_DBG_UNIFORM_STORES
+            { double* dx_ = owner ? q.tx + (tn + rl) : c.w->bpend[0] + (c.lane & 31); double* dv_ = owner ? q.tv + (tn + rl) : c.w->bvals[0] + (c.lane & 31);
+              *dx_ = x; *dv_ = joint; }
+#else
             if (owner) { q.tx[tn + rl] = x; q.tv[tn + rl] = joint; }
+#endif
         }
         tn = on ? tn + nn : tn;
         PROF_ADD(c, 14);  // pass: log + prior + store
@@ -2092,6 +2137,93 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
     q.tn = tn; q.failed = failed; q.sawnan = sawnan;
 }
 
+
+// ---- ranks of a row's visited points by a bitonic network on 32-bit keys (batch epilogue).  The 16 lanes of a DPP row hold
+// N = 16 << NB keys, lane rl the sorted positions (rl << NB) .. (rl << NB) + (1 << NB) - 1.  A compare-exchange along a lane bit takes
+// the partner's key with ds_swizzle (the LDS crossbar: no VALU slot, no memory) and keeps the smaller or the larger key — one compare,
+// one scalar xor with the stage's lane mask, one select; along a register bit it is one compare and two selects.  146 VALU
+// instructions for 64 keys, where ranking every key against every other one is 2 x 4 x 57.
+template <int XOR>
+__device__ __forceinline__ unsigned swz_xor(unsigned v) { return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (XOR << 10) | 0x1f); }
+// lanes that keep the LARGER key in the cross-lane stage (k, j) / whose register pairs are sorted descending in a register stage of merge k
+template <int NB>
+__device__ constexpr unsigned long long bitonic_keepmax(int k, int j) {
+    unsigned long long m = 0;
+    for (int L = 0; L < 64; ++L) {
+        const int e = (L & 15) << NB;
+        const bool keep_min = ((e & j) == 0) == ((e & k) == 0);
+        if (!keep_min) m |= 1ull << L;
+    }
+    return m;
+}
+template <int NB>
+__device__ constexpr unsigned long long bitonic_desc(int k) {
+    unsigned long long m = 0;
+    for (int L = 0; L < 64; ++L)
+        if ((((L & 15) << NB) & k) != 0) m |= 1ull << L;
+    return m;
+}
+__device__ __forceinline__ unsigned bitonic_pick(unsigned a, unsigned b, unsigned long long keepmax) {
+    unsigned r;
+    asm("v_cmp_lt_u32_e32 vcc, %1, %2\n\ts_xor_b64 vcc, vcc, %3\n\tv_cndmask_b32_e32 %0, %2, %1, vcc" : "=v"(r) : "v"(a), "v"(b), "s"(keepmax) : "vcc");
+    return r;
+}
+__device__ __forceinline__ void bitonic_pair(unsigned& lo, unsigned& hi, unsigned long long desc) {
+    unsigned nl, nh;
+    asm("v_cmp_lt_u32_e32 vcc, %2, %3\n\ts_xor_b64 vcc, vcc, %4\n\tv_cndmask_b32_e32 %0, %3, %2, vcc\n\tv_cndmask_b32_e32 %1, %2, %3, vcc"
+        : "=&v"(nl), "=&v"(nh) : "v"(lo), "v"(hi), "s"(desc) : "vcc");
+    lo = nl; hi = nh;
+}
+template <int NB, int K, int J>
+__device__ __forceinline__ void bitonic_stage(unsigned* s) {
+    constexpr int R = 1 << NB;
+    if constexpr (J >= R) {
+        constexpr unsigned long long km = bitonic_keepmax<NB>(K, J);
+#pragma unroll
+        for (int t = 0; t < R; ++t) s[t] = bitonic_pick(s[t], swz_xor<(J >> NB)>(s[t]), km);
+    } else {
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            if ((t & J) == 0) {
+                // ascending where (e & K) == 0: a lane mask for K >= R, a property of the register pair below that
+                constexpr unsigned long long lane_desc = bitonic_desc<NB>(K);
+                const unsigned long long desc = (K >= R) ? lane_desc : ((t & K) != 0 ? ~0ull : 0ull);
+                bitonic_pair(s[t], s[t | J], desc);
+            }
+        }
+    }
+    if constexpr (J > 1) bitonic_stage<NB, K, (J >> 1)>(s);
+}
+template <int NB, int K>
+__device__ __forceinline__ void bitonic_merge_all(unsigned* s) {
+    bitonic_stage<NB, K, (K >> 1)>(s);
+    if constexpr (K < (16 << NB)) bitonic_merge_all<NB, (K << 1)>(s);
+}
+// rank[t] of the row's entry rl + 16 t (t < 1 << NB) among the row's n entries by (key of x, table index); rb: 64 bytes of the row's LDS
+template <int NB>
+__device__ __forceinline__ void bitonic_ranks(const double* xi, int n, int rl, double lo, double scale, unsigned char* rb, int* rank) {
+    constexpr int R = 1 << NB;
+    unsigned s[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        const int i = rl + 16 * t;
+        const unsigned q26 = (unsigned)((xi[t] - lo) * scale);   // (entries beyond n hold +inf: saturates; they get the key ~0 anyway)
+        s[t] = i < n ? ((q26 << 6) | (unsigned)i) : 0xffffffffu;
+    }
+    bitonic_merge_all<NB, 2>(s);
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        const int e = (rl << NB) | t;
+        if (e < n) rb[s[t] & 63u] = (unsigned char)e;
+    }
+    VLR_WAVE_FENCE();
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        const int i = rl + 16 * t;
+        rank[t] = i < n ? (int)rb[i] : 0;
+    }
+}
+
 __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) {
     rowmask = UNI(rowmask); inner = UNI(inner);
     PROF_ADD(c, 6);  // batch preparation (task setup, fixed-sample likelihoods)
@@ -2145,9 +2277,17 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
     const int D_in = UNI(w->nkeep[inner]);
     // register-resident runner: the integrated sample is the only one whose likelihood moves with the chain (no sample is
     // contaminated by it), its pileup fits the register slots and its terms need no renormalisation
+#ifdef VLR_DBG_NO_REGRUN  // diagnosis builds: every batch through the round-1 loop (coefficients from LDS, per-term renormalisation)
+    const bool regrun = false && dep == (1 << inner);
+#else
     const bool regrun = dep == (1 << inner) && D_in <= 16 * kRegSlots && ((UNI(w->vfast) >> inner) & 1);
+#endif
     // keyed passes (see reg_chain_loop): every point of every row has the same finite prior value and a finite fixed part
-    const bool keyed = regrun && c.nlfc == 0 && !(ones_any(c) && ones_risk(c, inner)) &&  // (the exponent of a direct all-ones product is not bounded by the key's 16 bits)
+#ifdef VLR_DBG_NO_KEYED  // diagnosis builds: every pass takes the logarithm itself
+    const bool keyed = false && c.nlfc == 0 &&
+#else
+    const bool keyed = regrun && c.nlfc == 0 && !(ones_any(c) && ones_risk(c, inner)) &&
+#endif  // (the exponent of a direct all-ones product is not bounded by the key's 16 bits)
                        __ballot(rowon && !(cls_fast && (pr0 == pr1 || lo != 0.0) && fabs(pr1) < __builtin_huge_val() && fabs(fixed) < __builtin_huge_val())) == 0ull;
     if (__builtin_expect(regrun, 1)) {
         RegChain rc;
@@ -2348,14 +2488,13 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
     double rint_ = VLR_NEG_INF;
     {
         double xi[4], vi[4];
-        unsigned long long key[4];
         int rank[4];
         const bool srt = phase != RP_SIMPSON;  // per row: trapezoid over the sorted visited points (Simpson grids are in order)
         const bool any_simpson = __ballot(rowon && !srt) != 0ull;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             xi[t] = __builtin_huge_val(); vi[t] = VLR_NEG_INF;
-            key[t] = ~0ull; rank[t] = 0;
+            rank[t] = 0;
             if (t < TT) {
                 const int i = rl + 16 * t;
                 const bool on = i < n;
@@ -2365,10 +2504,6 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
                 if (keyed) vr = (xr == 0.0 ? pr0 : pr1) + (fixed + key_ln(__double_as_longlong(vr)));  // the pass stored the product's key
                 xi[t] = on ? xr : __builtin_huge_val();
                 vi[t] = on ? vr : VLR_NEG_INF;
-                // sort key: the bit pattern of a non-negative double orders like the number; the low six bits carry the
-                // table index so that revisited points (equal x: HashMap key collisions in the reference) get distinct,
-                // adjacent ranks.  (Distinct points closer than 64 ulp may swap: a segment of width ~1e-16 changes sign.)
-                key[t] = on ? ((((unsigned long long)__double_as_longlong(xr)) & ~63ull) | (unsigned long long)i) : ~0ull;
                 const bool inlo = (orig.start < xi[t]) | ((orig.lex == 0) & (orig.start == xi[t]));
                 const bool inhi = (orig.end > xi[t]) | ((orig.rex == 0) & (orig.end == xi[t]));
                 const bool cand = on & (contained != 0) & inlo & inhi & (vi[t] == vi[t]);
@@ -2402,46 +2537,87 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
                 }
             }
         }
-        // rank of every entry among its row's entries: one compare + one add-with-carry per (entry, q).  The keys are parked in
-        // the value table meanwhile (x and value of every entry are in registers), so the loop reads finished keys
+        // rank of every entry among its row's entries, by (x, table index): revisited points (equal x: HashMap key collisions in the
+        // reference) get distinct, adjacent ranks.  First choice: a bitonic network on 32-bit keys — 26 bits of (x - lo) / (hi - lo) above
+        // the index — whose order is CHECKED against the x values once the table is rewritten; two distinct points closer than 2^-26 of
+        // the range fail the check and the exact ranking takes over: one 64-bit compare and one add-with-carry per (entry, q) against
+        // keys parked in the value table (x and value of every entry are in registers by now).
         if (__ballot(srt && n > 0)) {
-            unsigned long long* kv = (unsigned long long*)tv;
-            VLR_WAVE_FENCE();
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                if (t < TT) { const int i = rl + 16 * t; if (i < cap) kv[i] = key[t]; }  // ~0 beyond the row's entries
-            VLR_WAVE_FENCE();
-            int q0 = 0;
-            for (; q0 + 4 <= nmax; q0 += 4) {  // four table reads in flight
-                unsigned long long kq[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) kq[j] = kv[q0 + j];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        if (t < TT) rank[t] += (kq[j] < key[t]) ? 1 : 0;
+#ifdef VLR_NO_BITONIC
+            bool use32 = false;
+#else
+            bool use32 = true;
+            {
+                const double span = hi - lo;
+                const double scale = span > 0.0 ? 67108863.0 / span : 0.0;   // (2^26 - 1) / (hi - lo)
+                VLR_WAVE_FENCE();
+                if (nmax > 32) bitonic_ranks<2>(xi, n, rl, lo, scale, (unsigned char*)tv, rank);
+                else if (nmax > 16) bitonic_ranks<1>(xi, n, rl, lo, scale, (unsigned char*)tv, rank);
+                else bitonic_ranks<0>(xi, n, rl, lo, scale, (unsigned char*)tv, rank);
             }
-            for (; q0 < nmax; ++q0) {
-                const unsigned long long kq = kv[q0];
+#endif
+            for (;;) {
+                if (__builtin_expect(!use32, 0)) {
+                    // sort key: the bit pattern of a non-negative double orders like the number; the low six bits carry the table index.
+                    // (Distinct points closer than 64 ulp may swap: a segment of width ~1e-16 changes sign.)
+                    unsigned long long key[4];
+                    unsigned long long* kv = (unsigned long long*)tv;
+                    VLR_WAVE_FENCE();
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    if (t < TT) rank[t] += (kq < key[t]) ? 1 : 0;
-            }
-            VLR_WAVE_FENCE();
-            // scatter into sorted order, in place (every entry is in registers by now); rows that are not sorted (Simpson grids)
-            // get their values back
+                    for (int t = 0; t < 4; ++t) {
+                        const int i = rl + 16 * t;
+                        key[t] = i < n ? ((((unsigned long long)__double_as_longlong(xi[t])) & ~63ull) | (unsigned long long)i) : ~0ull;
+                        rank[t] = 0;
+                        if (t < TT && i < cap) kv[i] = key[t];  // ~0 beyond the row's entries
+                    }
+                    VLR_WAVE_FENCE();
+                    int q0 = 0;
+                    for (; q0 + 4 <= nmax; q0 += 4) {  // four table reads in flight
+                        unsigned long long kq[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (t < TT) {
-                    const int i = rl + 16 * t;
-                    if (i < n) {
-                        if (srt) { tx[rank[t]] = xi[t]; tv[rank[t]] = vi[t]; }
-                        else tv[i] = vi[t];
+                        for (int j = 0; j < 4; ++j) kq[j] = kv[q0 + j];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t)
+                                if (t < TT) rank[t] += (kq[j] < key[t]) ? 1 : 0;
+                    }
+                    for (; q0 < nmax; ++q0) {
+                        const unsigned long long kq = kv[q0];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if (t < TT) rank[t] += (kq < key[t]) ? 1 : 0;
                     }
                 }
+                VLR_WAVE_FENCE();
+                // scatter into sorted order, in place (every entry is in registers); rows that are not sorted (Simpson grids) get their
+                // values back
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (t < TT) {
+                        const int i = rl + 16 * t;
+                        if (i < n) {
+                            if (srt) { tx[rank[t]] = xi[t]; tv[rank[t]] = vi[t]; }
+                            else tv[i] = vi[t];
+                        }
+                    }
+                }
+                VLR_WAVE_FENCE();
+                if (!use32) break;
+                // the order the 32-bit keys gave, checked on the points themselves: no entry may lie below its predecessor
+                bool bad = false;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (t < TT) {
+                        const int i = rl + 16 * t;
+                        const int rk = rank[t];
+                        const double pred = tx[rk > 0 ? rk - 1 : 0];
+                        bad = bad || (srt && i < n && rk > 0 && pred > xi[t]);
+                    }
+                }
+                if (__builtin_expect(__ballot(bad) == 0ull, 1)) break;
+                use32 = false;
             }
-            VLR_WAVE_FENCE();
         } else if (keyed) {  // no row is sorted (Simpson grids only): the tables still hold keys
             VLR_WAVE_FENCE();
 #pragma unroll
@@ -3413,8 +3589,13 @@ __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, Dev
 // Two builds of the same kernel: WPE = 2 waves per SIMD (no spills) for workgroups whose LDS footprint allows only 8 of
 // them per CU anyway, WPE = 3 (168 VGPRs, 32 of them spilled) where 9 or more fit (single-sample 30x: 12 workgroups,
 // +33 %).  The launcher picks by LDS bytes.
+#ifdef VLR_DBG_NUM_VGPR  // diagnosis builds: a VGPR cap independent of the launch bounds (run at VLR_WAVES_PER_SIMD=2)
+#define VLR_DBG_VGPR_ATTR __attribute__((amdgpu_num_vgpr(VLR_DBG_NUM_VGPR)))
+#else
+#define VLR_DBG_VGPR_ATTR
+#endif
 template <int WPE>
-__global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_arg, DevBatch batch, DevResults out,
+__global__ void __launch_bounds__(64, WPE) VLR_DBG_VGPR_ATTR vlr_call_kernel(const DevPlan plan_arg, DevBatch batch, DevResults out,
                                                            int max_obs, int range_depth) {
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     __shared__ WaveSt wst;
@@ -3790,32 +3971,15 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
             // sample gets back (kshift_ln).  Never taken on pair-HMM output (supports are normalised, realignment/mod.rs:359-374).
             bool need_rescue = false;
             int kacc = 0;
-          for (int scaled = 0; scaled < 2; ++scaled) {
-            if (scaled && !need_rescue) break;
-            wr = w->soff[s]; fast_s = 1; vfast_s = 1;
-            bool fatal = false;
-            double P1 = 1.0;      // this lane's share of prod_i (w A_i + u_i): the sample's likelihood at alpha = beta = 1, without the cancellation
-            int E1 = 0;
-            bool risk = false;    // some term has w R > 2^24 (w A + u): c + q + e keeps fewer than 29 bits of it
-            // every column of a row in one round of loads (the few rows that are dropped below are loaded in vain), and the rows of
-            // the NEXT 64 observations are requested before this iteration's arithmetic starts
-            ObsRow nxt = load_obs_row(batch, o0 + lane, o1);
-            for (uint32_t base = o0; base < o1; base += 64) {
-                uint32_t i = base + lane;
-                bool valid = i < o1;
-                bool tiny = false, small = false;
-                const ObsRow cur = nxt;
-                if (base + 64 < o1) nxt = load_obs_row(batch, i + 64, o1);
+            // the terms of one kept observation under hypothesis h: the affine coefficients, the term at alpha = beta = 1 formed directly
+            // (one_t) and what c + q + e cancels there (ref_t); `scaled`: relative to the observation's own power of two 2^ki
+            auto obs_terms = [&](const ObsRow& cur, int scaled, double& cc_, double& cq_, double& ce_, double& one_t, double& ref_t, bool& uflow, int& ki) {
                 const uint32_t f = cur.f;
-                const float pm_f = cur.pm, pa_f = cur.pa, pr_f = cur.pr, miss_f = cur.miss, psa_f = cur.psa, pdo_f = cur.pdo, phb_f = cur.phb, hpa_f = cur.hpa, hpv_f = cur.hpv;
-                bool keep = valid && !(remove_nonstd && f_orient(f) == VLR_ORIENT_OTHER);
-                unsigned long long km = __ballot(keep);
-                int pos = wr + popc64(km & ((1ull << lane) - 1ull));
-                if (keep) {
-                    double pm = pm_f, pa = pa_f, pr = pr_f, miss = miss_f;
-                    double psa = psa_f, pdo = pdo_f, phb = phb_f;
-                    double hpa = hpa_f;
-                    double hpv = hpv_f;
+                ki = 0;
+                    double pm = cur.pm, pa = cur.pa, pr = cur.pr, miss = cur.miss;
+                    double psa = cur.psa, pdo = cur.pdo, phb = cur.phb;
+                    double hpa = cur.hpa;
+                    double hpv = cur.hpv;
                     if (singleton && pa > pr) { pa = kLn05; pr = kLn05; }  // prob_alt_adj / prob_ref_adj
                     int strand = f_strand(f), orient = f_orient(f);
                     bool major = (f & VLR_F_READPOS_MAJOR) != 0;
@@ -3866,34 +4030,51 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
                     double A = exp(pa) * fa, R = exp(pr) * fr;
                     double uu = mis * exp(miss) * fany;
                     const double sv = ehas_s ? exp(psa) : 1.0;  // (!ehas: prob_sample_alt == 0 on every kept observation of the sample, e^0 = 1)
-                    bool uflow = (A == 0.0 && fa != 0.0 && pa > VLR_NEG_INF) || (R == 0.0 && fr != 0.0 && pr > VLR_NEG_INF);
+                    uflow = (A == 0.0 && fa != 0.0 && pa > VLR_NEG_INF) || (R == 0.0 && fr != 0.0 && pr > VLR_NEG_INF);
                     double d = A - R;
-                    double cc_ = wv * R + uu, cq_ = wv * sv * d, ce_ = wv * (1.0 - sv) * d;
-                    double one_t = wv * A + uu, ref_t = wv * R;  // the term at alpha = beta = 1 formed directly, and what c + q + e cancels
+                    cc_ = wv * R + uu; cq_ = wv * sv * d; ce_ = wv * (1.0 - sv) * d;
+                    one_t = wv * A + uu; ref_t = wv * R;  // the term at alpha = beta = 1 formed directly, and what c + q + e cancels
                     if (__builtin_expect(scaled != 0, 0)) {
                         // the three log-space addends of the observation's likelihood, their largest as the binary exponent k
                         const double lA = (fa > 0.0 && pa > VLR_NEG_INF) ? pm + pa + log(fa) : VLR_NEG_INF;
                         const double lR = (fr > 0.0 && pr > VLR_NEG_INF) ? pm + pr + log(fr) : VLR_NEG_INF;
                         const double lU = (mis > 0.0 && fany > 0.0 && miss > VLR_NEG_INF) ? log(mis) + miss + log(fany) : VLR_NEG_INF;
                         const double mx = fmax(lA, fmax(lR, lU));
-                        const int ki = (mx > VLR_NEG_INF) ? (int)floor(mx / kLn2) : 0;
+                        ki = (mx > VLR_NEG_INF) ? (int)floor(mx / kLn2) : 0;
                         const double sh = (double)ki * kLn2;
                         const double WA = (lA > VLR_NEG_INF) ? exp(lA - sh) : 0.0, WR = (lR > VLR_NEG_INF) ? exp(lR - sh) : 0.0;
                         const double UU = (lU > VLR_NEG_INF) ? exp(lU - sh) : 0.0;
                         d = WA - WR;
                         cc_ = WR + UU; cq_ = sv * d; ce_ = (1.0 - sv) * d;
                         one_t = WA + UU; ref_t = WR;
-                        kacc += ki;
                         uflow = false;
                     }
-                    {   // the all-ones term and its product over the lane's observations (mantissa, exponent)
-                        risk = risk || (ref_t > 0x1p24 * one_t);
-                        int e1;
-                        P1 *= __builtin_frexp(one_t, &e1);
-                        E1 += e1;
-                        P1 = __builtin_frexp(P1, &e1);
-                        E1 += e1;
-                    }
+            };
+          for (int scaled = 0; scaled < 2; ++scaled) {
+            if (scaled && !need_rescue) break;
+            wr = w->soff[s]; fast_s = 1; vfast_s = 1;
+            bool fatal = false;
+            bool risk = false;    // some term has w R > 2^24 (w A + u): c + q + e keeps fewer than 29 bits of it at alpha = beta = 1
+            // every column of a row in one round of loads (the few rows that are dropped below are loaded in vain), and the rows of
+            // the NEXT 64 observations are requested before this iteration's arithmetic starts
+            ObsRow nxt = load_obs_row(batch, o0 + lane, o1);
+            for (uint32_t base = o0; base < o1; base += 64) {
+                uint32_t i = base + lane;
+                bool valid = i < o1;
+                bool tiny = false, small = false;
+                const ObsRow cur = nxt;
+                if (base + 64 < o1) nxt = load_obs_row(batch, i + 64, o1);
+                const uint32_t f = cur.f;
+                bool keep = valid && !(remove_nonstd && f_orient(f) == VLR_ORIENT_OTHER);
+                unsigned long long km = __ballot(keep);
+                int pos = wr + popc64(km & ((1ull << lane) - 1ull));
+                if (keep) {
+                    double cc_, cq_, ce_, one_t, ref_t;
+                    bool uflow;
+                    int ki;
+                    obs_terms(cur, scaled, cc_, cq_, ce_, one_t, ref_t, uflow, ki);
+                    kacc += ki;
+                    risk = risk || (ref_t > 0x1p24 * one_t);
 #if VLR_DEEP
                     if (pos < obs_cap) {
 #else
@@ -3921,8 +4102,23 @@ __global__ void __launch_bounds__(64, WPE) vlr_call_kernel(const DevPlan plan_ar
             else if (bad) c.status |= VLR_LOCUS_UNDERFLOW;  // cannot happen: the largest addend of every term is in [1/2, 1)
             if (!(bad && !scaled)) {  // (the pass that stands)
                 if (__builtin_expect(__ballot(risk) != 0ull, 0)) {
-                    double Pw[1] = {P1};
-                    int Ew[1] = {E1};
+                    // rare (never on pair-HMM records): one more pass over the sample's rows for prod_i (w A_i + u_i), the likelihood
+                    // at alpha = beta = 1 without the cancellation — mantissa and exponent, lane shares combined below
+                    double Pw[1] = {1.0};
+                    int Ew[1] = {0};
+                    for (uint32_t base = o0; base < o1; base += 64) {
+                        const ObsRow cur = load_obs_row(batch, base + lane, o1);
+                        if (base + lane < o1 && !(remove_nonstd && f_orient(cur.f) == VLR_ORIENT_OTHER)) {
+                            double cc_, cq_, ce_, one_t, ref_t;
+                            bool uflow;
+                            int ki, e1;
+                            obs_terms(cur, scaled, cc_, cq_, ce_, one_t, ref_t, uflow, ki);
+                            Pw[0] *= __builtin_frexp(one_t, &e1);
+                            Ew[0] += e1;
+                            Pw[0] = __builtin_frexp(Pw[0], &e1);
+                            Ew[0] += e1;
+                        }
+                    }
                     reduce_terms<1, 64>(Pw, Ew);
                     if (lane == 0) {
                         __hip_atomic_store(ones_ptr(c) + 2 * s, Pw[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -4279,9 +4475,11 @@ __global__ void __launch_bounds__(64) vlr_selftest_stream_kernel(const float* in
 #ifdef VLR_WIDE_BUILD
 #define VLR_FN_CALL vlr_launch_call_kernel_wide
 #define VLR_FN_AFD vlr_launch_afd_kernel_wide
+#define VLR_FN_LDS vlr_plan_lds_floor_wide
 #else
 #define VLR_FN_CALL vlr_launch_call_kernel
 #define VLR_FN_AFD vlr_launch_afd_kernel
+#define VLR_FN_LDS vlr_plan_lds_floor
 #endif
 #if !VLR_DEEP && !defined(VLR_WIDE_BUILD)
 extern "C" int vlr_launch_selftest_stream(const float* in, double* out, long long n, int mode, void* stream) {
@@ -4323,8 +4521,34 @@ extern "C" int vlr_launch_call_kernel_deep(const vlr::DevPlan* plan_host, const 
 extern "C" int VLR_FN_AFD(const vlr::DevPlan* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out, void* stream) {
     if (batch->n_loci <= 0) return 0;
     const size_t seen_bytes = (size_t)2 * plan_host->S * (plan_host->max_set > 16 ? plan_host->max_set : 16) * sizeof(double);
+    if (seen_bytes > 32768) {  // (large Set spectra: above the default dynamic LDS limit; vlr_plan_create has checked that it fits the CU)
+        const hipError_t e = hipFuncSetAttribute((const void*)vlr::vlr_afd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seen_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
     hipLaunchKernelGGL(vlr::vlr_afd_kernel, dim3((unsigned)batch->n_loci), dim3(64), seen_bytes, (hipStream_t)stream, *plan_host, *batch, *out);
     return (int)hipGetLastError();
+}
+
+// dynamic LDS of one workgroup of the call kernel (the layout at the top of vlr_call_kernel)
+static size_t call_kernel_dyn_lds(const vlr::DevPlan* plan_host, int n_univ, int n_samples, int max_obs, int range_depth, bool replay) {
+    using namespace vlr;
+    size_t n_slots = (size_t)n_univ + 1;
+    size_t cap = (size_t)plan_host->table_cap;
+    size_t dbl = (size_t)2 * max_obs + (size_t)2 * plan_host->max_tab_depth * cap + (size_t)2 * kRows * cap + (size_t)kRows * n_samples +
+                 (size_t)2 * n_univ + n_slots + n_slots * n_samples + (size_t)n_samples * plan_host->max_set + (size_t)(replay ? 2 * n_samples * (plan_host->max_set > 16 ? plan_host->max_set : 16) + 2 * n_samples : 0) + (size_t)3 * n_samples * kCacheWays +
+                 (n_slots + 1) / 2 + 2 + (size_t)plan_host->n_dkey +
+                 ((size_t)plan_host->max_frames * sizeof(Frame) + (size_t)range_depth * sizeof(RangeSt) + 7) / 8 +
+                 (size_t)(n_samples + 1) / 2;  // kshift[S] (ints)
+    return dbl * sizeof(double);
+}
+// Worst-case LDS of a plan's launches without any coefficient area (max_obs = 0): call pass, AFD replay and the AFD log filter.  A plan
+// whose tables alone do not fit the 160 KiB of a CU (Set spectra of hundreds of members in many samples) is refused by vlr_plan_create
+// with this number instead of failing at its first batch with a launch error.
+extern "C" long long VLR_FN_LDS(const vlr::DevPlan* plan_host, int n_univ, int n_samples, int range_depth) {
+    if (range_depth < 1) range_depth = 1;
+    const size_t call = call_kernel_dyn_lds(plan_host, n_univ, n_samples, 0, range_depth, true) + 4096;   // + the static part (WaveSt, < 4 KiB in every build)
+    const size_t afd = (size_t)2 * plan_host->S * (plan_host->max_set > 16 ? plan_host->max_set : 16) * sizeof(double) + 16384;  // + static part of vlr_afd_kernel
+    return (long long)(call > afd ? call : afd);
 }
 
 // host-callable launcher (used by vlr_host.cpp)
@@ -4334,14 +4558,7 @@ extern "C" int VLR_FN_CALL(const vlr::DevPlan* plan_host, const vlr::DevBatch* b
     if (batch->n_loci <= 0) return 0;
     if (n_samples > kLdsSamples) return (int)hipErrorInvalidValue;  // (the per-sample LDS arrays of this build; the host picks the wide build)
     if (range_depth < 1) range_depth = 1;
-    size_t n_slots = (size_t)n_univ + 1;
-    size_t cap = (size_t)plan_host->table_cap;
-    size_t dbl = (size_t)2 * max_obs + (size_t)2 * plan_host->max_tab_depth * cap + (size_t)2 * kRows * cap + (size_t)kRows * n_samples +
-                 (size_t)2 * n_univ + n_slots + n_slots * n_samples + (size_t)n_samples * plan_host->max_set + (size_t)(out->replay ? 2 * n_samples * (plan_host->max_set > 16 ? plan_host->max_set : 16) + 2 * n_samples : 0) + (size_t)3 * n_samples * kCacheWays +
-                 (n_slots + 1) / 2 + 2 + (size_t)plan_host->n_dkey +
-                 ((size_t)plan_host->max_frames * sizeof(Frame) + (size_t)range_depth * sizeof(RangeSt) + 7) / 8 +
-                 (size_t)(n_samples + 1) / 2;  // kshift[S] (ints)
-    size_t bytes = dbl * sizeof(double);
+    const size_t bytes = call_kernel_dyn_lds(plan_host, n_univ, n_samples, max_obs, range_depth, out->replay != 0);
     static size_t static_lds = 0;
     if (!static_lds) {
         hipFuncAttributes fa{};
