@@ -34,7 +34,8 @@
 extern "C" {
 #endif
 
-#define VLR_ABI_VERSION 4   /* 3: vlr_plan_reserve takes the AFD capacity, 30 named events, vlr_node_*, homopolymer realignment; 4: device front door */
+#define VLR_ABI_VERSION 5   /* 3: vlr_plan_reserve takes the AFD capacity, 30 named events, vlr_node_*, homopolymer realignment; 4: device front door;
+                             * 5: sharded device reader, calls-file parts, vlr_ingest_device_trim, CRC32 of BGZF members checked by both readers */
 #define VLR_MAX_SAMPLES 16     /* samples per scenario supported by the device path   */
 #define VLR_N_BIAS      6      /* strand, orientation, position, softclip, homopolymer, alt-locus */
 
@@ -499,6 +500,12 @@ typedef struct vlr_calls_writer vlr_calls_writer;
 int  vlr_calls_writer_open(const char* path, const char* header_text, vlr_calls_writer** out);
 int  vlr_calls_writer_append(vlr_calls_writer* writer, const vlr_obs_table* table, const vlr_results* results, const char* const* out_names, int n_threads);
 int  vlr_calls_writer_close(vlr_calls_writer* writer);   /* header (if nothing was appended), BGZF end-of-file member, close */
+/* Several writers, one file (the shards of a sharded run, vlr_obs_reader_open_device_shard): every shard writes its records as a PART —
+ * part 0 with the header, the others without (with_header = 0), none with the end-of-file member (with_eof = 0); BGZF members
+ * concatenate, so vlr_calls_concat_parts(path, parts, n) copies the parts in shard order behind each other, appends the end-of-file
+ * member and removes the part files.  BCF only. */
+int  vlr_calls_writer_set_part(vlr_calls_writer* writer, int with_header, int with_eof);
+int  vlr_calls_concat_parts(const char* path, const char* const* parts, int n_parts);
 /* Measurement aid: wall seconds of the stages of the last vlr_obs_read ([0] file reads, [1] BGZF inflate, [2] parse + decode — summed
  * over the sample files, which run side by side — [3] all files, [4] merge into the table, [5] strings and groups, [6] total) and of
  * the last vlr_calls_write ([8] record encoding, [9] BGZF deflate + file write, [10] total). */
@@ -516,8 +523,28 @@ void vlr_ingest_total_timings(double* out16, int reset);
  * members only (the files `varlociraptor preprocess` writes); anything else: VLR_ERR_UNSUPPORTED, use vlr_obs_reader_open.
  * The tables of such a reader hold the batch twice: in device memory (vlr_obs_table_device_batch: the pointers vlr_batch_run takes,
  * valid until vlr_obs_table_free) and in page-locked host memory (vlr_obs_table_batch: what the calls writer formats DP / SAOBS /
- * SROBS / OBS from), both complete when vlr_obs_reader_next returns.  CRC32 of the members is not checked on this path. */
+ * SROBS / OBS from), both complete when vlr_obs_reader_next returns.  The CRC32 of every member is checked against its trailer on
+ * the device (ABI 5; htslib does the same per block), like the host reader checks it on the CPU. */
 int  vlr_obs_reader_open_device(int device, int n_samples, const char* const* paths, uint32_t omit_bias_mask, int n_threads, vlr_obs_reader** out);
+/* Sharded device reader: N readers (the ranks of a torchrun job, the devices of a node) each inflate and decode about 1 / N of every
+ * file instead of all of it.  The reference reads every record once (calling.rs:306-339, 357-367) and the loci shard across the GPUs
+ * (north star): a shard is a contiguous range of records, every reader delivers the records of ITS range in file order.
+ *   vlr_obs_reader_open_device_shard   inflates the members of the reader's byte share of every file (plus a lead-in and a tail of
+ *                                      1/32 of the share, VLR_INGEST_SHARD_SLACK) and finds the record starts in them;
+ *   vlr_obs_reader_shard_counts        out[n_samples][vlr_obs_reader_shard_row_size()]: what the other readers need to know (records that
+ *                                      start in the share, where its first record starts and where the one behind its last record does);
+ *   the caller gathers the rows of all shards (one small all-gather; plain memory inside one process) in shard order and calls
+ *   vlr_obs_reader_shard_assign        on every reader: checks that consecutive shards meet in every file (a wrong guess of a record start
+ *                                      shows here: VLR_ERR_INVALID_ARGUMENT, read unsharded), numbers the records, positions the files at
+ *                                      the reader's range — the records of the FIRST file's share — and reports it (*first_record,
+ *                                      *n_records; the ranges of all shards partition the file in shard order).
+ * vlr_obs_reader_next then delivers that range like any reader.  Breakend groups and per-variant prior overrides that reach across
+ * a shard boundary are the caller's business (the CLI refuses such files in sharded mode). */
+int  vlr_obs_reader_open_device_shard(int device, int n_samples, const char* const* paths, uint32_t omit_bias_mask, int n_threads,
+                                      int shard, int n_shards, vlr_obs_reader** out);
+int  vlr_obs_reader_shard_row_size(void);
+int  vlr_obs_reader_shard_counts(const vlr_obs_reader* reader, int64_t* out);
+int  vlr_obs_reader_shard_assign(vlr_obs_reader* reader, const int64_t* all_rows, int64_t* first_record, int64_t* n_records);
 int  vlr_obs_table_device_batch(const vlr_obs_table* table, vlr_batch* out);  /* VLR_ERR_INVALID_ARGUMENT for a table of a host reader */
 /* keep == 0: the tables of this device reader do not bring the observation columns down to the host; instead a kernel counts per
  * pileup what the calls writer formats from them (distinct observation keys, Kass-Raftery letters, prob_mapping runs: the OBS / SAOBS /

@@ -320,6 +320,46 @@ def test_cli_two_ranks_shard_and_reassemble(golden_dir, tmp_path, obs_file):
     assert a == b and a.count("\n") > 11
 
 
+def test_cli_two_ranks_read_and_write_their_own_shards(tmp_path):
+    """VERDICT r04 missing #2 / next #3e: under torchrun with a BCF output every rank inflates and decodes only its share of the
+    members (ingest.ObsReader(shard=...)), evaluates it, writes its part of the calls file, and rank 0 concatenates the parts (BGZF
+    members concatenate).  Two ranks on the one GPU of the test box, gloo for the few counters that are exchanged: the records of
+    the assembled file are those of a single process, and each rank inflated about half of the bytes."""
+    import gzip
+    import json
+    import subprocess
+    import sys
+    from varlociraptor_amd import ingest, synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = synth.config3()
+    cfg.depth = 25.0
+    b = synth.generate(cfg, 5000, seed=17)
+    obs = {}
+    for s_, name in enumerate(cfg.scenario.sample_names):
+        obs[name] = str(tmp_path / (name + ".bcf"))
+        ingest.write_observations(obs[name], b, s_)
+    total_inflated = sum(len(gzip.decompress(open(p_, "rb").read())) for p_ in obs.values())
+    y = tmp_path / "scenario.yaml"
+    # the embedded tumor-normal scenario of the reference (src/cli.rs:1151-1172), purity 0.75: what synth.config3 evaluates
+    y.write_text("samples:\n  tumor:\n    resolution: 0.01\n    universe: '[0.0,1.0]'\n    contamination:\n      by: normal\n      fraction: 0.25\n"
+                 "  normal:\n    resolution: 0.1\n    universe: '[0.0,0.5[ | 0.5 | 1.0'\n"
+                 "events:\n  somatic_tumor: 'tumor:]0.0,1.0] & normal:0.0'\n  somatic_normal: 'tumor:]0.0,1.0] & normal:]0.0,0.5['\n"
+                 "  germline_het: 'tumor:]0.0,1.0] & normal:0.5'\n  germline_hom: 'tumor:]0.0,1.0] & normal:1.0'\n")
+    one, two = tmp_path / "one.bcf", tmp_path / "two.bcf"
+    base = ["-m", "varlociraptor_amd", "call", "variants"]
+    tail = ["generic", "--scenario", str(y), "--obs"] + ["%s=%s" % (n_, p_) for n_, p_ in obs.items()]
+    env = dict(os.environ, PYTHONPATH=root, VLR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", VLR_INGEST_SHARD_REPORT=str(tmp_path / "report"))
+    subprocess.run([sys.executable] + base + ["--output", str(one)] + tail, check=True, cwd=root, env=env, timeout=900)
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", "29543"] + base + ["--output", str(two)] + tail, check=True, cwd=root, env=env, timeout=900)
+    a, c = gzip.decompress(one.read_bytes()), gzip.decompress(two.read_bytes())
+    assert a == c and len(a) > 100000
+    reps = [json.load(open(str(tmp_path / "report") + ".%d" % k)) for k in range(2)]
+    assert reps[0]["first_record"] == 0 and reps[1]["first_record"] == reps[0]["n_records"] and reps[0]["n_records"] + reps[1]["n_records"] == 5000
+    for r_ in reps:
+        assert 0.3 * total_inflated < r_["device_reader"]["inflated_bytes"] < 0.62 * total_inflated, (r_["device_reader"]["inflated_bytes"], total_inflated)
+
+
 def test_bench_step_through_rccl_on_one_gpu(tmp_path):
     """nothing in the repo had ever exercised RCCL itself (the two-rank tests use gloo: a one-GPU box cannot
     host two NCCL ranks).  One rank under torch.distributed.run with backend nccl: process-group set-up on the device, the

@@ -216,16 +216,27 @@ def test_fine_resolution(oracle, res):
     check(oracle, sc, synth.generate(cfg, 80, seed=20), "resolution %g" % res)
 
 
-def test_resolution_too_fine_is_flagged():
-    sc = single_sample(0.000001)
-    cfg = with_depth(synth.config2(), 50.0)
+def test_resolutions_far_below_the_default_are_evaluated(oracle):
+    """VERDICT r04 missing #1: a visited-point table of more than 128 entries (resolutions below 2e-5 on a full-range chain; the
+    reference keeps the points in a HashMap, utils/adaptive_integration.rs:46) used to come back flagged VLR_LOCUS_TABLE_FULL.  The
+    capacity now follows the resolution up to 1 024 entries (single-chain runner, exact rank sort): equal to the oracle, no flag."""
+    for res, depth in ((0.000001, 50.0), (1e-12, 30.0)):
+        sc = single_sample(res)
+        cfg = with_depth(synth.config2(), depth)
+        cfg.scenario = sc
+        cfg.classes = [("het", 0.6, ((0.4, 0.6),)), ("absent", 0.2, ((0.0, 0.0),)), ("hom", 0.2, ((1.0, 1.0),))]
+        b = synth.generate(cfg, 24, seed=21)
+        got, ref = check(oracle, sc, b, "resolution %g" % res)
+        assert not (got.status & abi.LOCUS_TABLE_FULL).any()
+    # nested ranges at a fine resolution (outer tables and inner chains above 64 entries: the general walk)
+    sc = Scenario({"a": Sample(resolution=0.0001, universe="[0.0,1.0]"), "b": Sample(resolution=0.0001, universe="[0.0,1.0]")},
+                  {"both": "a:]0.0,0.5[ & b:]0.0,1.0]", "only_b": "a:0.0 & b:]0.0,1.0]"})
+    cfg = with_depth(synth.config3(), 12.0)
     cfg.scenario = sc
-    cfg.classes = [("het", 1.0, ((0.4, 0.6),))]
-    b = synth.generate(cfg, 16, seed=21)
-    plan = engine.Plan(sc)
-    got = plan.call_host(b)
-    plan.close()
-    assert np.all((got.status & abi.LOCUS_TABLE_FULL) != 0)
+    cfg.purity = None
+    b = synth.generate(cfg, 6, seed=22)
+    got, ref = check(oracle, sc, b, "nested ranges at resolution 1e-4")
+    assert not (got.status & abi.LOCUS_TABLE_FULL).any()
 
 
 def test_empty_batch():
@@ -496,6 +507,48 @@ def test_pooled_sample_with_a_ploidy_derived_universe_of_41_allele_frequencies(o
     finally:
         del os.environ["VLR_AFD_REPLAY"]
     assert np.array_equal(rep.afd_count, ref.afd_count)
+
+
+def test_plans_beyond_the_standard_limits_run_the_wide_build(oracle):
+    """VERDICT r04 missing #1: more than four l2fc terms or four nested ranges on a path used to end in VLR_ERR_UNSUPPORTED; the
+    reference builds arbitrary trees (grammar/vaftree.rs:168-305).  Such plans run the wide build of the kernels (eight of each,
+    vlr_plan.h) — also with few samples — and a deep pileup in them takes the wide deep launch (vlr_kernels_widedeep.hip)."""
+    # six l2fc terms on one path, three samples
+    smp = {n: Sample(resolution=0.1, universe="[0.0,1.0]") for n in ("a", "b", "c")}
+    events = {
+        "ordered": "l2fc(a,b) > 0.2 & l2fc(b,c) > 0.2 & l2fc(a,c) > 0.5 & l2fc(a,b) < 3.0 & l2fc(b,c) < 3.0 & l2fc(a,c) < 5.0 & a:]0.0,1.0] & b:]0.0,1.0] & c:]0.0,1.0]",
+        "only_a": "a:]0.0,1.0] & b:0.0 & c:0.0",
+    }
+    sc = Scenario(smp, events)
+    mk = lambda *v: tuple(v)
+    classes = [("absent", 0.3, mk((0.0, 0.0), (0.0, 0.0), (0.0, 0.0))), ("ord", 0.4, mk((0.6, 0.9), (0.3, 0.4), (0.1, 0.15))), ("a", 0.3, mk((0.2, 0.8), (0.0, 0.0), (0.0, 0.0)))]
+    cfg = synth.SynthConfig(name="l2fc6", config_id=61, scenario=sc, depth=14.0, type_mix={abi.VT_SNV: 0.8, abi.VT_INDEL: 0.2}, classes=classes, purity=None)
+    check(oracle, sc, synth.generate(cfg, 40, seed=71), "six l2fc terms on a path")
+    # five nested ranges (coarse resolution: every level is a three-point Simpson grid)
+    names = ["r%d" % i for i in range(5)]
+    smp = {n: Sample(resolution=0.999, universe="[0.0,1.0]") for n in names}
+    sc = Scenario(smp, {"all": " & ".join("%s:]0.0,1.0[" % n for n in names), "none_but_first": "r0:]0.0,1.0] & " + " & ".join("%s:0.0" % n for n in names[1:])})
+    classes = [("absent", 0.4, tuple((0.0, 0.0) for _ in names)), ("all", 0.6, tuple((0.2, 0.8) for _ in names))]
+    cfg = synth.SynthConfig(name="nest5", config_id=62, scenario=sc, depth=8.0, type_mix={abi.VT_SNV: 1.0}, classes=classes, purity=None)
+    check(oracle, sc, synth.generate(cfg, 8, seed=72), "five nested ranges")
+    # nine samples and a pileup budget far below the data: the flagged loci go through the wide deep launch
+    names = ["w%d" % i for i in range(9)]
+    smp = {n: Sample(resolution=0.1, universe="[0.0,1.0]") for n in names}
+    sc = Scenario(smp, {"first": "w0:]0.0,1.0] & " + " & ".join("%s:0.0" % n for n in names[1:]), "last": "w8:]0.0,1.0] & " + " & ".join("%s:0.0" % n for n in names[:-1])})
+    classes = [("absent", 0.4, tuple((0.0, 0.0) for _ in names)), ("first", 0.3, tuple((0.2, 0.7) if i == 0 else (0.0, 0.0) for i in range(9))),
+               ("last", 0.3, tuple((0.3, 0.9) if i == 8 else (0.0, 0.0) for i in range(9)))]
+    cfg = synth.SynthConfig(name="nine", config_id=63, scenario=sc, depth=20.0, type_mix={abi.VT_SNV: 0.8, abi.VT_INDEL: 0.2}, classes=classes, purity=None)
+    batch = synth.generate(cfg, 60, seed=73)
+    plan = engine.Plan(sc)
+    plan.set_max_obs(64)   # (about 180 observations per locus)
+    got = plan.call_host(batch, afd_capacity=32)
+    plan.close()
+    ref = oracle_mt(oracle, sc, batch)
+    m = compare(got, ref, label="nine samples above the pileup budget")
+    assert m["frac_within"] == 1.0 and m["status_equal"], describe(m)
+    assert not (got.status & abi.LOCUS_TOO_DEEP).any()
+    ref_afd = oracle.call(sc, batch, afd_capacity=32)
+    assert np.array_equal(got.afd_count, ref_afd.afd_count)
 
 
 def test_twelve_samples_run_the_wide_build(oracle):

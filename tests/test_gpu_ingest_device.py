@@ -463,3 +463,79 @@ def test_device_reader_refuses_sample_files_that_do_not_match(tmp_path):
             _read_all([full[0], short], device, 256)
         with pytest.raises(engine.EngineError, match="inconsistent observations"):
             _read_all([full[0], other], device, 256)
+
+
+def _drain(reader):
+    parts = []
+    for batch, sites in reader:
+        parts.append((batch, sites))
+    return parts
+
+
+def test_sharded_reader_partitions_the_file_and_inflates_its_share_only(tmp_path):
+    """VERDICT r04 missing #2: N readers (ranks / devices) each inflate and decode about 1 / N of every file
+    (vlr_obs_reader_open_device_shard: byte shares of the members, a guessed first record start confirmed by the neighbour's landing,
+    record numbers from an exchange of counts).  Three shards in one process (threads stand in for ranks, a barrier for the
+    all-gather): their tables, in shard order, are the unsharded reader's records column by column, and together they inflate
+    little more than the file once — not three times."""
+    import threading
+    cfg = synth.config3()
+    cfg.depth = 30.0
+    b = synth.generate(cfg, 6000, seed=9)
+    paths = []
+    for s in range(2):
+        p = str(tmp_path / ("s%d.bcf" % s))
+        ingest.write_observations(p, b, s)
+        paths.append(p)
+    ingest.device_timings(reset=True)
+    whole = _drain(ingest.ObsReader(paths, device=0, chunk_records=1500))
+    t_whole = ingest.device_timings(reset=True)
+    N = 3
+    rows, out, errs = [None] * N, [None] * N, []
+    bar = threading.Barrier(N)
+
+    def run(k):
+        def gather(mine):
+            rows[k] = np.array(mine)
+            bar.wait(timeout=120)
+            return np.stack(rows)
+        try:
+            r = ingest.ObsReader(paths, device=0, chunk_records=700, shard=(k, N), gather=gather)
+            out[k] = (r.first_record, r.n_records, _drain(r))
+        except Exception as ex:   # noqa: BLE001
+            errs.append(ex)
+            try:
+                bar.abort()
+            except Exception:
+                pass
+    th = [threading.Thread(target=run, args=(k,)) for k in range(N)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    t_shards = ingest.device_timings(reset=True)
+    # the ranges partition the records in shard order
+    at = 0
+    for k in range(N):
+        assert out[k][0] == at
+        at += out[k][1]
+        assert sum(bt.n_loci for bt, _ in out[k][2]) == out[k][1]
+    assert at == b.n_loci
+    assert min(o[1] for o in out) > 0.2 * b.n_loci / N
+    # column by column, locus by locus
+    def cat(parts, f):
+        return np.concatenate([f(bt, st) for bt, st in parts])
+    sharded = [x for k in range(N) for x in out[k][2]]
+    for name in whole[0][0].columns:
+        assert np.array_equal(cat(whole, lambda bt, st: bt.columns[name].view(np.uint32) if bt.columns[name].dtype == np.float32 else bt.columns[name]),
+                              cat(sharded, lambda bt, st: bt.columns[name].view(np.uint32) if bt.columns[name].dtype == np.float32 else bt.columns[name])), name
+    assert np.array_equal(cat(whole, lambda bt, st: np.diff(bt.obs_offset)), cat(sharded, lambda bt, st: np.diff(bt.obs_offset)))
+    for name in whole[0][0].locus:
+        assert np.array_equal(cat(whole, lambda bt, st: bt.locus[name]), cat(sharded, lambda bt, st: bt.locus[name])), name
+    assert np.array_equal(cat(whole, lambda bt, st: np.asarray(st.pos)), cat(sharded, lambda bt, st: np.asarray(st.pos)))
+    # the shards together inflate the file once, plus lead-ins and tails (1 / 32 of a share each)
+    assert t_shards["inflated_bytes"] < 1.25 * t_whole["inflated_bytes"], (t_shards["inflated_bytes"], t_whole["inflated_bytes"])
+    # a shard whose neighbour reports another landing than its first start is refused (the check that catches a wrong guess)
+    bad = np.stack(rows).copy()
+    bad[1, 0, 2] += 1
+    with pytest.raises(engine.EngineError, match="do not meet"):
+        ingest.ObsReader(paths, device=0, shard=(1, N), gather=lambda mine: bad)

@@ -217,6 +217,11 @@ def _fixed_fields(res):
     return out
 
 
+def _part_path(output: str, rank: int) -> str:
+    """Part file of a sharded run (ends in .bcf: the native writer picks the container by the suffix)."""
+    return "%s.part%d.bcf" % (output, rank)
+
+
 def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_capacity: int = 128, out=sys.stdout,
                   device: int = 0, output: str = None, ingest: str = None, timings: dict = None,
                   processor: "CallProcessor" = None, candidate_filter: "CandidateFilter" = None):
@@ -275,6 +280,11 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
             world, rank = tdist.get_world_size(), tdist.get_rank()
     except ImportError:
         pass
+    # Sharded front door (several ranks, device reader, BCF output): every rank inflates, decodes, evaluates and WRITES its own
+    # contiguous share of the records (ingest.ObsReader(shard=...): about 1 / N of the members of every file per rank) and rank 0 puts
+    # the parts of the calls file together — no rank ever holds the whole file, nothing but a few counters crosses between the ranks.
+    # Set below, once the reader is open; VLR_INGEST_SHARDED=0 keeps the older path (every rank reads everything, results all-gathered).
+    shard_state = {"on": False}
     plans: Dict[tuple, "engine.Plan"] = {}   # one plan per scenario signature, kept across the chunks of a run
     reserve_loci = [0]
     FIELDS = ("ln_posterior", "ln_marginal", "map_vaf", "map_bias", "best_event", "status", "afd_count", "afd_vaf", "afd_lnprob")
@@ -309,7 +319,7 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
             loci = np.sort(np.concatenate(parts))
             sc = sig_scenario[sig]
             n_out_, S_ = sc.n_out, len(sc.sample_names)
-            if world > 1:
+            if world > 1 and not shard_state["on"]:
                 # loci shard across the ranks (one process per GPU); the results are reassembled by one all-gather of
                 # fixed-size records (+ one for the AFD lists), every rank ends up with the full result
                 from . import dist as vdist
@@ -344,7 +354,7 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                     r = plan.call_host(sub, afd_capacity=afd_capacity)
             else:
                 r = CallResults(0, n_out_, S_, afd_capacity)
-            if world > 1:
+            if world > 1 and not shard_state["on"]:
                 from . import dist as vdist
                 r = vdist.gather_call_results(r, lo, hi, len(loci), n_out_, S_, afd_capacity)
             if names is None:
@@ -374,7 +384,7 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                     else:             # the event began in an earlier chunk: its first record's result
                         for f, v in row.items():
                             getattr(res, f)[l] = v
-        if res is not None and rank == 0:
+        if res is not None and (rank == 0 or shard_state["on"]):
             # the reference panics on NaN (assert!(!p.is_nan())): say so instead of writing `.` silently
             hard = res.status & (abi.LOCUS_NAN | abi.LOCUS_UNDERFLOW | abi.LOCUS_TABLE_FULL | abi.LOCUS_TOO_DEEP)
             for bit, what in ((abi.LOCUS_NAN, "a likelihood became NaN"), (abi.LOCUS_UNDERFLOW, "an observation likelihood is outside the f64 range"),
@@ -408,8 +418,11 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
             # BGZF inflate, record split and v15 decode as kernels (csrc/vlr_inflate.hip, csrc/vlr_decode.hip): the compressed members
             # cross PCIe, the columns are born in device memory and the evaluation reads them there.  Files it does not read (plain
             # gzip, uncompressed BCF) go to the host reader.
+            want_shards = (world > 1 and processor is None and candidate_filter is None and bool(output) and str(output).endswith(".bcf")
+                           and os.environ.get("VLR_INGEST_SHARDED", "1") != "0")
             try:
                 reader = vingest.ObsReader(paths, omit_bias_mask=omit_mask, chunk_records=int(os.environ.get("VLR_CLI_CHUNK", "0")) or 32768, device=device,
+                                           shard=(rank, world) if want_shards else None,
                                            # VLR_INGEST_SUMMARIES=1: the observation columns stay on the device and the calls writer formats from per-pileup
                                            # summaries (vlr_obs_reader_set_host_columns; pays off when pileups have few distinct observation keys — the
                                            # synthetic bench pileups have almost one per observation and fall back to the columns)
@@ -417,7 +430,8 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                                            # the evaluation reads the device side of a table; only the writer (which waits) needs the host copy of the columns
                                            # (several ranks: every rank inflates and decodes the files on its own device instead of sharing the
                                            # node's CPUs between N host readers; its shard is cut from the host copy of the columns)
-                                           async_columns=(processor is None and candidate_filter is None and world == 1))
+                                           async_columns=(processor is None and candidate_filter is None and (world == 1 or want_shards)))
+                shard_state["on"] = want_shards
             except engine.EngineError as ex:
                 if ex.code != abi.ERR_UNSUPPORTED:
                     raise
@@ -467,7 +481,9 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                             import tempfile
                             writer_state["tmp"] = tempfile.TemporaryDirectory()
                             target = os.path.join(writer_state["tmp"].name, "calls.vcf")
-                        writer_state["w"] = vingest.CallsWriter(target, hdr)
+                        if shard_state["on"]:
+                            target = _part_path(output, rank)
+                        writer_state["w"] = vingest.CallsWriter(target, hdr, part=(rank, world) if shard_state["on"] else None)
                         writer_state["path"] = target
                     writer_state["w"].append(table, res_, list(names_))
                     if result_pool is not None:
@@ -480,7 +496,7 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
 
         proc_state = {"setup": False}
         tr = threading.Thread(target=read_loop, daemon=True)
-        tw = threading.Thread(target=write_loop, daemon=True) if (rank == 0 and processor is None) else None
+        tw = threading.Thread(target=write_loop, daemon=True) if ((rank == 0 or shard_state["on"]) and processor is None) else None
         stage["setup_s"] = time.perf_counter() - t_begin
         tr.start()
         if tw:
@@ -499,6 +515,10 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                 contig_of = np.asarray(sites.contig, np.int64)
                 het_, som_ = batch.extra["prior_het_ln"], batch.extra["prior_som_ln"]
                 grep_, gkey_ = np.asarray(batch.extra["group_representative"], np.int64), np.asarray(batch.extra["group_key"], np.uint64)
+                if shard_state["on"] and ((gkey_ != 0).any() or np.isfinite(np.asarray(het_, np.float64)).any() or np.isfinite(np.asarray(som_, np.float64)).any()):
+                    # breakend events hand the FIRST record's result to the later ones, and per-variant prior overrides are installed from
+                    # the first record of a contig (calling.rs:569-580, 643-713): both reach across shard boundaries
+                    raise SystemExit("the sharded reader does not take files with breakend events or per-variant prior overrides: rerun with VLR_INGEST_SHARDED=0")
                 loci_ = np.arange(batch.n_loci)
                 ebatch = batch
                 if candidate_filter is not None:   # calling.rs:409: work items the filter rejects are not processed at all
@@ -536,6 +556,12 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                 tw.join()
             stop.set()
             tr.join()
+            if shard_state["on"] and os.environ.get("VLR_INGEST_SHARD_REPORT"):
+                # what this rank read (tests, tools): its record range and the bytes it inflated
+                import json
+                with open("%s.%d" % (os.environ["VLR_INGEST_SHARD_REPORT"], rank), "w") as fh_:
+                    json.dump({"rank": rank, "world": world, "first_record": reader.first_record, "n_records": reader.n_records,
+                               "total_records": getattr(reader, "total_records", None), "device_reader": vingest.device_timings()}, fh_)
             reader.close()
             close_plans()
         if errors:
@@ -545,6 +571,18 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                 if not proc_state["setup"]:
                     processor.setup(list(names or resolve(used_contigs[0] if used_contigs else "all").out_names()), list(sample_order))
                 processor.finalize()
+        elif shard_state["on"]:
+            # every rank closes its part (a rank without records writes an empty one: the header, on rank 0); rank 0 assembles the file
+            if writer_state["w"] is None:
+                hdr, _ = header_for(names, used_contigs)
+                vingest.CallsWriter(_part_path(output, rank), hdr, part=(rank, world)).close()
+            else:
+                writer_state["w"].close()
+            import torch.distributed as tdist
+            tdist.barrier()
+            if rank == 0:
+                vingest.concat_parts(output, [_part_path(output, k_) for k_ in range(world)])
+            tdist.barrier()
         elif rank == 0:
             if writer_state["w"] is None:  # no records at all: the header alone
                 hdr, _ = header_for(names, used_contigs)

@@ -168,6 +168,27 @@ __global__ __launch_bounds__(64) void rec_anchor_kernel(const uint8_t* __restric
     if (lane == 0) anchor[seg] = found;
 }
 
+// first record start at or behind offset 0 of a stream that begins INSIDE a record (a shard of a file, vlr_obs_reader_open_device_shard):
+// the first offset whose header is plausible and whose two successors are as well.  A guess like every anchor: the verified walk of
+// the split behind it and the neighbouring shard's landing (vlr_obs_reader_shard_assign) confirm it.
+__global__ __launch_bounds__(64) void rec_first_kernel(const uint8_t* __restrict__ base, uint64_t avail, int n_contigs, int n_hdr_samples, uint64_t* __restrict__ first) {
+    const int lane = (int)threadIdx.x;
+    uint64_t found = kNone;
+    for (uint64_t o0 = 0; o0 + 33 <= avail; o0 += 64) {
+        const uint64_t o = o0 + (uint64_t)lane;
+        bool ok = header_plausible(base, o, avail, n_contigs, n_hdr_samples, true);
+        uint64_t q = o;
+        for (int hop = 0; ok && hop < 2; ++hop) {
+            q = q + 8 + (uint64_t)ld32(base + q) + (uint64_t)ld32(base + q + 4);
+            if (q + 33 <= avail) ok = header_plausible(base, q, avail, n_contigs, n_hdr_samples, true);
+            else break;
+        }
+        const unsigned long long m = __ballot(ok);
+        if (m != 0) { found = o0 + (uint64_t)(__ffsll((long long)m) - 1); break; }
+    }
+    if (lane == 0) *first = found;
+}
+
 // one lane per segment: the complete records that start in [anchor, next boundary)
 __global__ void rec_walk_kernel(const uint8_t* __restrict__ base, uint64_t avail, int n_seg, const uint64_t* __restrict__ anchor,
                                 uint32_t* __restrict__ count, uint64_t* __restrict__ landing, uint8_t* __restrict__ land_complete) {
@@ -918,6 +939,29 @@ int vlr_dev_file_split(vlr_dev_file* f, int64_t max_records, int n_contigs, int 
     *n_records = (int64_t)n;
     *rec_host = f->h_host;
     return VLR_OK;
+}
+
+// The buffered bytes begin inside a record (the window of a file's shard): move the read position to the first record start.
+// *skipped: the bytes in front of it; VLR_ERR_INVALID_ARGUMENT when no start is found in the buffered bytes.
+int vlr_dev_file_anchor_first(vlr_dev_file* f, int n_contigs, int n_hdr_samples, uint64_t* skipped) {
+    VLR_HIP_OK(hipSetDevice(f->device));
+    { const int rcw = vlr_dev_file_feed_wait(f); if (rcw != VLR_OK) return rcw; }
+    const uint64_t avail = f->wr - f->rd;
+    uint64_t found = vlr::kNone;
+    if (avail >= 33) {
+        hipLaunchKernelGGL(vlr::rec_first_kernel, dim3(1), dim3(64), 0, f->stream, f->buf + f->rd, avail, n_contigs, n_hdr_samples, (uint64_t*)f->d_nout);
+        VLR_HIP_OK(hipMemcpyAsync(&found, f->d_nout, 8, hipMemcpyDeviceToHost, f->stream));
+        VLR_HIP_OK(hipStreamSynchronize(f->stream));
+    }
+    if (found == vlr::kNone) return dfail(VLR_ERR_INVALID_ARGUMENT, "device reader: no record start in the shard's window");
+    f->rd += (size_t)found;
+    if (skipped) *skipped = found;
+    return VLR_OK;
+}
+// record starts of the last split (n + 1 offsets from the read position: the last one is the end of the last complete record)
+const uint64_t* vlr_dev_file_starts(const vlr_dev_file* f, int64_t* n) {
+    if (n) *n = f->n_split;
+    return f->h_starts.data();
 }
 
 int vlr_dev_file_decode(vlr_dev_file* f, int64_t n, const uint32_t* d_obs_offset, int n_samples, int sample, const vlr::DeviceCols* cols) {

@@ -96,6 +96,10 @@ int vlr_dev_file_skip(vlr_dev_file* f, uint64_t bytes);
 // rec_host[0..n) (array owned by the object, valid until the next split) their counts.  Synchronises the file's stream.
 int vlr_dev_file_split(vlr_dev_file* f, int64_t max_records, int n_contigs, int n_hdr_samples, const int8_t* field_of_key, int n_keys, int64_t* n_records,
                        const vlr::RecHost** rec_host, int* used_serial_walk);
+// a shard's window begins inside a record: read position to the first record start (a guess the split's verified walk confirms)
+int vlr_dev_file_anchor_first(vlr_dev_file* f, int n_contigs, int n_hdr_samples, uint64_t* skipped);
+// record starts of the last split: n + 1 offsets from the read position (host copy, valid until the next split)
+const uint64_t* vlr_dev_file_starts(const vlr_dev_file* f, int64_t* n);
 // decode records [0, n) into the merged columns: record r of this file goes to observation offset d_obs_offset[r * n_samples + sample]
 int vlr_dev_file_decode(vlr_dev_file* f, int64_t n, const uint32_t* d_obs_offset, int n_samples, int sample, const vlr::DeviceCols* cols);
 // cold copies of records [0, n) -> host buffer (cold_off[r] = prefix sum of RecHost.cold_bytes, cold_off[n] bytes in all); asynchronous

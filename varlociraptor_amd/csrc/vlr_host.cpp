@@ -25,6 +25,8 @@
 extern "C" int vlr_launch_afd_kernel(const vlr::DevPlanT<8>* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out, void* stream);
 extern "C" int vlr_launch_call_kernel_deep(const vlr::DevPlanT<8>* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out,
                                            int n_univ, int n_samples, int range_depth, void* stream);
+extern "C" int vlr_launch_call_kernel_widedeep(const vlr::DevPlanT<16>* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out,
+                                               int n_univ, int n_samples, int range_depth, void* stream);
 extern "C" int vlr_launch_afd_kernel_wide(const vlr::DevPlanT<16>* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out, void* stream);
 extern "C" int vlr_launch_call_kernel_wide(const vlr::DevPlanT<16>* plan_dev, const vlr::DevBatch* batch, const vlr::DevResults* out,
                                            int n_univ, int n_samples, int max_obs, int range_depth, void* stream);
@@ -254,6 +256,7 @@ struct HostPrior {
 struct vlr_plan {
     int device = 0;
     vlr::DevPlanT<16> host{};  // host copy (device pointers inside): the layout for up to sixteen samples
+    bool wide = false;         // more than eight samples, four l2fc terms or four nested ranges on a path: the wide build of the kernels
     vlr::DevPlanT<8> host8{};  // the same plan in the layout of the standard and deep builds (plans of at most eight samples)
     vlr::DevPlanT<16>* dev = nullptr;
     void* blob = nullptr;      // device arrays
@@ -533,8 +536,10 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
             for (int c = 0; c < n.n_children; ++c) st.push_back({child[n.child_off + c], it.ranges, it.lfcs, it.frames});
         }
     }
-    if (max_range > kMaxRangeDepth) return fail(VLR_ERR_UNSUPPORTED, "more than %d nested VAF ranges on one path", kMaxRangeDepth);
-    if (max_lfc > kMaxLfc) return fail(VLR_ERR_UNSUPPORTED, "more than %d l2fc terms on one path", kMaxLfc);
+    if (max_range > kMaxRangeDepthWide) return fail(VLR_ERR_UNSUPPORTED, "more than %d nested VAF ranges on one path", kMaxRangeDepthWide);
+    if (max_lfc > kMaxLfcWide) return fail(VLR_ERR_UNSUPPORTED, "more than %d l2fc terms on one path", kMaxLfcWide);
+    // plans beyond the standard build's limits run the wide build of the kernels
+    const bool needs_wide = S > 8 || max_range > kMaxRangeDepthStd || max_lfc > kMaxLfcStd;
     if (max_frames > kMaxFrames) return fail(VLR_ERR_UNSUPPORTED, "VAF tree deeper than %d frames", kMaxFrames);
     P.max_range_depth = std::max(1, max_range);
     P.max_tab_depth = max_tab;
@@ -551,7 +556,7 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
             int rounds = (int)std::ceil(std::log(1.0 / d->resolution[s]) / std::log(4.0 / 3.0)) + 1;
             cap = std::max(cap, 2 + 3 * rounds + 7);
         }
-        cap = std::min((cap + 3) & ~3, (int)kTableCap);
+        cap = std::min((cap + 3) & ~3, (int)kTableCapMax);
         P.table_cap = cap;
     }
 
@@ -852,10 +857,11 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
     P.droot = (const int32_t*)(base + o_dr);
     P.froot = (const DevFastRoot*)(base + o_fr);
     plan->host = P;
+    plan->wide = needs_wide;
     if (S <= 8) plan->host8 = narrow_plan(P);
     {   // The tables of the plan (Set candidates, the replay's lists of seen discrete operands: S x max_set doubles each) must leave room
         // for at least a minimal pileup in the 160 KiB of LDS a CU has; otherwise the first batch would fail with a launch error.
-        const long long floor_b = S <= 8 ? vlr_plan_lds_floor(&plan->host8, P.n_univ, S, P.max_range_depth) : vlr_plan_lds_floor_wide(&plan->host, P.n_univ, S, P.max_range_depth);
+        const long long floor_b = !needs_wide ? vlr_plan_lds_floor(&plan->host8, P.n_univ, S, P.max_range_depth) : vlr_plan_lds_floor_wide(&plan->host, P.n_univ, S, P.max_range_depth);
         const long long min_pileup = 16ll * 64;   // coefficient pairs of 64 observations
         if (floor_b + min_pileup > 160ll * 1024) {
             vlr_plan_destroy(plan);
@@ -1043,8 +1049,8 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
     }
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipEventRecord(plan->ev_start, st));
-    // plans with more than eight samples run the wide build of the kernels (vlr_kernels_wide.hip: per-sample LDS arrays for sixteen)
-    const bool wide = plan->host.S > kLdsSamples;
+    // plans beyond the standard build's limits (vlr_plan.h) run the wide build of the kernels (vlr_kernels_wide.hip)
+    const bool wide = plan->wide;
     auto call_launch = [&](const DevBatch* bb, const DevResults* rr, int mo, void* ss) {
         return wide ? vlr_launch_call_kernel_wide(&plan->host, bb, rr, plan->host.n_univ, plan->host.S, mo, plan->host.max_range_depth, ss)
                     : vlr_launch_call_kernel(&plan->host8, bb, rr, plan->host.n_univ, plan->host.S, mo, plan->host.max_range_depth, ss);
@@ -1057,14 +1063,15 @@ int vlr_batch_run(vlr_plan* plan, const vlr_batch* in, vlr_results* out, void* s
     // coefficients in the plan's HBM pool; every other locus exits at once.  `lane`/`two`: the AFD sub-range lanes share the pool.
     auto deep_launch = [&](const DevBatch& bs, DevResults rs, void* ss, int lane, bool two) -> int {
         const int k = plan->slot & 1;
-        if (!plan->deep_pool[k] || plan->deep_pool_bytes[k] <= 128 || plan->deep_hint == 0 || plan->host.S > kLdsSamples) return VLR_OK;  // (no wide deep build)
+        if (!plan->deep_pool[k] || plan->deep_pool_bytes[k] <= 128 || plan->deep_hint == 0) return VLR_OK;
         char* base = (char*)plan->deep_pool[k];
         unsigned long long* ctr = (unsigned long long*)(base + 64 * lane);
         size_t cap_d = (plan->deep_pool_bytes[k] - 128) / sizeof(double);
         double* data = (double*)(base + 128);
         if (two) { cap_d /= 2; data += (size_t)lane * cap_d; }
         rs.deep_pool = data; rs.deep_used = ctr; rs.deep_capacity = (long long)cap_d;  // ctr was reset by the launch before (workgroup 0)
-        const int rc = vlr_launch_call_kernel_deep(&plan->host8, &bs, &rs, plan->host.n_univ, plan->host.S, plan->host.max_range_depth, ss);
+        const int rc = wide ? vlr_launch_call_kernel_widedeep(&plan->host, &bs, &rs, plan->host.n_univ, plan->host.S, plan->host.max_range_depth, ss)
+                            : vlr_launch_call_kernel_deep(&plan->host8, &bs, &rs, plan->host.n_univ, plan->host.S, plan->host.max_range_depth, ss);
         if (rc != 0) return fail(VLR_ERR_HIP, "deep kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         return VLR_OK;
     };

@@ -1711,7 +1711,12 @@ struct DevFileStream {
     std::vector<uint8_t, PinnedAlloc<uint8_t>> cold;   // cold records of the current chunk (page-locked: asynchronous D2H)
     std::vector<uint64_t> cold_off;
     std::vector<vlr::InflateBlock> ib;   // members of the feed in flight (read by the asynchronous copy)
-    bool more_blocks() const { return next_block < blocks.size(); }
+    // ---- sharded reader (vlr_obs_reader_open_device_shard): this reader's window of the file and what its scan found
+    size_t block_limit = (size_t)-1;   // members at and behind this index are not fed
+    size_t w0 = 0, mb0 = 0, mb1 = 0;   // window start, own members [mb0, mb1)
+    int64_t sh_lead = 0, sh_own = 0, sh_total = 0;   // complete records of the window: in front of the own share, starting in it, in all
+    uint64_t sh_first[2] = {0, 0}, sh_land[2] = {0, 0};   // (member, byte in the member) of the first own record's start / of the start behind the last own record
+    bool more_blocks() const { return next_block < blocks.size() && next_block < block_limit; }
     ~DevFileStream() { if (dev) vlr_dev_file_destroy(dev); }
 };
 
@@ -1729,6 +1734,10 @@ struct vlr_obs_reader {
     bool host_columns = true;       // vlr_obs_reader_set_host_columns
     bool async_columns = false;     // vlr_obs_reader_set_async_columns: next() returns while the column copy to the host is in flight
     bool summaries_off = false;     // a chunk had pileups with more distinct observation keys than the summary kernel keeps: columns from then on
+    // sharded reader: this reader delivers `remaining` records of its shard (set by vlr_obs_reader_shard_assign)
+    bool sharded = false, assigned = false;
+    int shard = 0, n_shards = 1;
+    int64_t remaining = 0;
     DevSlab sum_scratch;            // device side only in use: summary headers, entries, runs, cursors of the chunk being built
 };
 
@@ -1859,7 +1868,7 @@ int dev_stream_feed(DevFileStream& f, uint64_t want) {
         size_t b1 = b0;
         uint64_t add = 0;
         f.ib.clear();
-        while (b1 < f.blocks.size() && (have + add < goal() || b1 == b0) && b1 - b0 < (1u << 20)) {
+        while (b1 < f.blocks.size() && b1 < f.block_limit && (have + add < goal() || b1 == b0) && b1 - b0 < (1u << 20)) {
             const BgzfBlock& k = f.blocks[b1];
             vlr::InflateBlock x;
             x.src = k.off - f.blocks[b0].off; x.dst = add; x.clen = (uint32_t)k.clen; x.isize = k.isize; x.crc = k.crc; x.pad = 0;
@@ -1897,6 +1906,11 @@ const char* rec_status_text(uint32_t st) {
 
 int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out) {
     const int S = (int)r->dfiles.size();
+    if (r->sharded) {
+        if (!r->assigned) return ifail(VLR_ERR_INVALID_ARGUMENT, "sharded reader: vlr_obs_reader_shard_assign comes before the first vlr_obs_reader_next");
+        if (r->remaining <= 0) { r->done = true; return VLR_OK; }
+        max_records = std::min(max_records, r->remaining);
+    }
     max_records = std::min<int64_t>(max_records, (int64_t)1 << 22);   // (per-request device buffers are sized by it; the caller just asks again)
     const double t_all0 = now_s();
     std::vector<int64_t> n_rec((size_t)S, 0);
@@ -1930,6 +1944,7 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
         bool any_more = false;
         for (int s = 0; s < S; ++s) any_more = any_more || r->dfiles[(size_t)s]->more_blocks();
         if (!any_more) {
+            if (r->sharded) return ifail(VLR_ERR_INVALID_ARGUMENT, "sharded reader: the window of %s ends before the shard's records do", r->paths[0].c_str());
             for (int s = 0; s < S; ++s) {
                 if (n_rec[(size_t)s] > 0) return ifail(VLR_ERR_INVALID_ARGUMENT, "inconsistent observations: %s holds more records than the other files (calling.rs:369-371)", r->paths[(size_t)s].c_str());
                 if (vlr_dev_file_buffered(r->dfiles[(size_t)s]->dev) > 0) return ifail(VLR_ERR_INVALID_ARGUMENT, "truncated BCF record in %s", r->paths[(size_t)s].c_str());
@@ -2131,6 +2146,7 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
     }
     g_dev_t[6] += now_s() - t_d2h0;
     for (int s = 0; s < S; ++s) r->dfiles[(size_t)s]->delivered += L;
+    if (r->sharded) r->remaining -= L;
     g_dev_t[8] += now_s() - t_all0;
     g_dev_t[11] += (double)L;
     for (int s = 0; s < S; ++s) g_dev_t[13] += vlr_dev_file_inflate_seconds(r->dfiles[(size_t)s]->dev, 1);
@@ -2175,6 +2191,163 @@ int vlr_obs_reader_set_host_columns(vlr_obs_reader* r, int keep) {
 int vlr_obs_reader_set_async_columns(vlr_obs_reader* r, int on) {
     if (!r) return ifail(VLR_ERR_INVALID_ARGUMENT, "null reader");
     r->async_columns = on != 0;
+    return VLR_OK;
+}
+
+// ---- sharded device reader: N readers (ranks of a torchrun job, devices of a node) each inflate and decode about 1 / N of every file.
+// The reference reads every record once (calling.rs:306-339, 357-367); the loci then shard across the GPUs (north star).  A shard is
+// a contiguous range of RECORDS; where it lies in the compressed file is only known after inflating, so:
+//   open   every reader takes the members of its byte share of every file, plus a few members of lead-in and tail, inflates them, finds
+//          the record starts (first start: a guess, confirmed by the walk and by the neighbour) and counts the records that start in
+//          its own members;
+//   counts (vlr_obs_reader_shard_counts) are exchanged by the caller — one small all-gather, or plain memory inside one process;
+//   assign (vlr_obs_reader_shard_assign) checks that consecutive shards meet (landing of shard k - 1 = first start of shard k in
+//          every file), numbers the records, takes the record range of the FIRST file's share as this reader's range in every file
+//          (the shares of the other files differ by a few records: that is what lead-in and tail are for) and positions the files.
+// vlr_obs_reader_next then hands out the shard's records like any reader.
+namespace {
+struct ShardRow { int64_t own, first_m, first_o, land_m, land_o, lead, total; };
+constexpr int kShardRow = 7;
+
+// window offset -> (member index, byte in the member); `pre` = inflated bytes in front of member w0 + j, j = 0 .. n
+void member_of(const DevFileStream& f, const std::vector<uint64_t>& pre, uint64_t woff, uint64_t out[2]) {
+    size_t j = (size_t)(std::upper_bound(pre.begin(), pre.end(), woff) - pre.begin());
+    j = j == 0 ? 0 : j - 1;
+    // (the LAST member that starts at or in front of the offset: a position on a member boundary belongs to the member behind it, and a
+    //  position at the window's end to the member behind the window — the same pair whichever shard's window it is computed in)
+    if (j + 1 >= pre.size()) { out[0] = f.w0 + (pre.size() - 1); out[1] = 0; return; }
+    out[0] = f.w0 + j; out[1] = woff - pre[j];
+}
+
+int shard_scan_file(vlr_obs_reader* r, DevFileStream& f) {
+    const int N = r->n_shards, k = r->shard;
+    const size_t nb = f.blocks.size();
+    const uint64_t total_c = nb ? (uint64_t)(f.blocks.back().off + f.blocks.back().clen) : 0;
+    auto share_begin = [&](int q) -> size_t {
+        if (q <= 0) return 0;
+        if (q >= N) return nb;
+        const uint64_t at = total_c / (uint64_t)N * (uint64_t)q;
+        size_t lo = 0, hi = nb;
+        while (lo < hi) { const size_t mid = (lo + hi) / 2; if ((uint64_t)f.blocks[mid].off < at) lo = mid + 1; else hi = mid; }
+        return lo;
+    };
+    f.mb0 = share_begin(k); f.mb1 = share_begin(k + 1);
+    double slack = 1.0 / 32.0;
+    if (const char* ev = getenv("VLR_INGEST_SHARD_SLACK")) slack = std::max(0.0, atof(ev));
+    const size_t extra = std::max<size_t>(8, (size_t)((double)(f.mb1 - f.mb0) * slack));
+    f.w0 = k > 0 ? (f.mb0 > extra ? f.mb0 - extra : 0) : 0;
+    f.block_limit = k + 1 < N ? std::min(nb, f.mb1 + extra) : nb;
+    // the header is only in the window that starts at the file's first member
+    size_t hdr_members = 0;
+    { uint64_t acc = 0; while (hdr_members < nb && acc < f.header_bytes) acc += f.blocks[hdr_members++].isize; }
+    if (f.w0 < hdr_members) f.w0 = 0;   // (a window that would begin inside the header begins at the file's start)
+    f.next_block = f.w0;
+    f.header_skipped = f.w0 != 0;
+    int rc = dev_stream_feed(f, ~0ull >> 2);
+    if (rc != VLR_OK) return rc;
+    rc = vlr_dev_file_feed_wait(f.dev);
+    if (rc != VLR_OK) return rc;
+    uint64_t skipped = f.w0 == 0 ? f.header_bytes : 0;
+    if (f.w0 != 0) {
+        uint64_t sk = 0;
+        rc = vlr_dev_file_anchor_first(f.dev, (int)f.h.contigs.size(), f.n_hdr_samples, &sk);
+        if (rc != VLR_OK) return rc;
+        skipped = sk;
+    }
+    // every record of the window (the estimate of their number is doubled until it was large enough)
+    int64_t n = 0;
+    const vlr::RecHost* rh = nullptr;
+    int64_t cap = (int64_t)(vlr_dev_file_buffered(f.dev) / 4096) + 4096;
+    for (;;) {
+        int serial = 0;
+        rc = vlr_dev_file_split(f.dev, cap, (int)f.h.contigs.size(), f.n_hdr_samples, f.field_of_key.data(), (int)f.field_of_key.size(), &n, &rh, &serial);
+        if (rc != VLR_OK) return rc;
+        if (n < cap) break;
+        cap *= 2;
+    }
+    int64_t ns = 0;
+    const uint64_t* st = vlr_dev_file_starts(f.dev, &ns);
+    std::vector<uint64_t> pre(1, 0);
+    for (size_t m = f.w0; m < f.block_limit && m < nb; ++m) pre.push_back(pre.back() + f.blocks[m].isize);
+    const uint64_t U0 = pre[std::min(f.mb0 - f.w0, pre.size() - 1)], U1 = pre[std::min(f.mb1 - f.w0, pre.size() - 1)];
+    int64_t lead = 0, own = 0;
+    for (int64_t q = 0; q < n; ++q) {
+        const uint64_t w = skipped + st[q];
+        if (w < U0) ++lead; else if (w < U1 || k + 1 == N) ++own;
+    }
+    f.sh_lead = lead; f.sh_own = own; f.sh_total = n;
+    if (k + 1 < N && f.block_limit < nb && skipped + (n ? st[n] : 0) < U1)   // (the record behind the last complete one starts in the own share)
+        return ifail(VLR_ERR_INVALID_ARGUMENT, "sharded reader: the last record of the shard of %s is not complete in its window (VLR_INGEST_SHARD_SLACK)", f.path.c_str());
+    member_of(f, pre, skipped + (n ? st[lead] : 0), f.sh_first);
+    member_of(f, pre, skipped + (n ? st[lead + own] : 0), f.sh_land);
+    if (n == 0) { f.sh_first[0] = f.sh_land[0] = f.mb0; f.sh_first[1] = f.sh_land[1] = 0; }
+    return VLR_OK;
+}
+}  // namespace
+
+int vlr_obs_reader_open_device_shard(int device, int n_samples, const char* const* paths, uint32_t omit_bias_mask, int n_threads, int shard, int n_shards, vlr_obs_reader** out) {
+    if (!out || n_shards < 1 || shard < 0 || shard >= n_shards) return ifail(VLR_ERR_INVALID_ARGUMENT, "vlr_obs_reader_open_device_shard: bad argument");
+    vlr_obs_reader* r = nullptr;
+    int rc = vlr_obs_reader_open_device(device, n_samples, paths, omit_bias_mask, n_threads, &r);
+    if (rc != VLR_OK) return rc;
+    r->sharded = true; r->shard = shard; r->n_shards = n_shards;
+    for (auto& f : r->dfiles) {
+        rc = shard_scan_file(r, *f);
+        if (rc != VLR_OK) { vlr_obs_reader_close(r); return rc; }
+    }
+    *out = r;
+    return VLR_OK;
+}
+
+int vlr_obs_reader_shard_row_size(void) { return kShardRow; }
+
+int vlr_obs_reader_shard_counts(const vlr_obs_reader* r, int64_t* out) {
+    if (!r || !out || !r->sharded) return ifail(VLR_ERR_INVALID_ARGUMENT, "vlr_obs_reader_shard_counts: not a sharded reader");
+    for (size_t s = 0; s < r->dfiles.size(); ++s) {
+        const DevFileStream& f = *r->dfiles[s];
+        int64_t* o = out + (size_t)kShardRow * s;
+        o[0] = f.sh_own; o[1] = (int64_t)f.sh_first[0]; o[2] = (int64_t)f.sh_first[1]; o[3] = (int64_t)f.sh_land[0]; o[4] = (int64_t)f.sh_land[1];
+        o[5] = f.sh_lead; o[6] = f.sh_total;
+    }
+    return VLR_OK;
+}
+
+int vlr_obs_reader_shard_assign(vlr_obs_reader* r, const int64_t* all, int64_t* first_record, int64_t* n_records) {
+    if (!r || !all || !r->sharded) return ifail(VLR_ERR_INVALID_ARGUMENT, "vlr_obs_reader_shard_assign: not a sharded reader");
+    const int N = r->n_shards, S = (int)r->dfiles.size(), k = r->shard;
+    auto row = [&](int q, int s) { return all + ((size_t)q * (size_t)S + (size_t)s) * kShardRow; };
+    // consecutive shards meet: the start behind the last own record of shard q - 1 is the first own start of shard q
+    for (int s = 0; s < S; ++s)
+        for (int q = 1; q < N; ++q) {
+            const int64_t* a = row(q - 1, s);
+            const int64_t* b = row(q, s);
+            if (b[0] == 0 && a[0] == 0) continue;
+            if (a[3] != b[1] || a[4] != b[2])
+                return ifail(VLR_ERR_INVALID_ARGUMENT, "sharded reader: shards %d and %d of %s do not meet (a guessed record start was wrong); read the file unsharded", q - 1, q, r->paths[(size_t)s].c_str());
+        }
+    // records in front of shard q of file s
+    std::vector<int64_t> C((size_t)(N + 1) * (size_t)S, 0);
+    for (int s = 0; s < S; ++s)
+        for (int q = 0; q < N; ++q) C[(size_t)(q + 1) * S + s] = C[(size_t)q * S + s] + row(q, s)[0];
+    for (int s = 1; s < S; ++s)
+        if (C[(size_t)N * S + s] != C[(size_t)N * S])
+            return ifail(VLR_ERR_INVALID_ARGUMENT, "inconsistent observations: %s holds %lld records, %s %lld (calling.rs:369-371)", r->paths[(size_t)s].c_str(),
+                         (long long)C[(size_t)N * S + s], r->paths[0].c_str(), (long long)C[(size_t)N * S]);
+    const int64_t B0 = C[(size_t)k * S], B1 = C[(size_t)(k + 1) * S];   // this reader's records: those of the first file's share
+    for (int s = 0; s < S; ++s) {
+        DevFileStream& f = *r->dfiles[(size_t)s];
+        const int64_t skip = f.sh_lead + (B0 - C[(size_t)k * S + s]);
+        if (skip < 0 || skip + (B1 - B0) > f.sh_total)
+            return ifail(VLR_ERR_INVALID_ARGUMENT, "sharded reader: the window of %s does not hold records %lld .. %lld (it starts %lld records before its share and holds %lld): raise VLR_INGEST_SHARD_SLACK",
+                         f.path.c_str(), (long long)B0, (long long)B1, (long long)f.sh_lead, (long long)f.sh_total);
+        const int rc = vlr_dev_file_consume(f.dev, skip);
+        if (rc != VLR_OK) return rc;
+        f.delivered = B0;
+    }
+    r->remaining = B1 - B0;
+    r->assigned = true;
+    if (first_record) *first_record = B0;
+    if (n_records) *n_records = B1 - B0;
     return VLR_OK;
 }
 
@@ -2555,7 +2728,7 @@ int vlr_calls_write(const char* path, const char* header_text, const vlr_obs_tab
 
 // The same file written in pieces (the streaming CLI: one append per chunk of records): header with the first append (or at close
 // if nothing was appended), BGZF end-of-file marker at close.
-struct vlr_calls_writer { FILE* f = nullptr; bool bcf = false, first = true; std::string header; std::unique_ptr<AsyncSink> sink; };
+struct vlr_calls_writer { FILE* f = nullptr; bool bcf = false, first = true, eof = true; std::string header; std::unique_ptr<AsyncSink> sink; };
 
 int vlr_calls_writer_open(const char* path, const char* header_text, vlr_calls_writer** out) {
     if (!path || !header_text || !out) return ifail(VLR_ERR_INVALID_ARGUMENT, "null argument");
@@ -2567,6 +2740,38 @@ int vlr_calls_writer_open(const char* path, const char* header_text, vlr_calls_w
     w->f = f; w->bcf = plen > 4 && strcmp(path + plen - 4, ".bcf") == 0; w->header = header_text;
     if (w->bcf) w->sink.reset(new AsyncSink(f));
     *out = w;
+    return VLR_OK;
+}
+// A part of a calls file written by one of several writers (the shards of a sharded run): BGZF members concatenate, so part k > 0
+// carries records only (with_header = 0) and no part but the assembled file an end-of-file member (with_eof = 0);
+// vlr_calls_concat_parts puts the parts together.  Before the first append.
+int vlr_calls_writer_set_part(vlr_calls_writer* w, int with_header, int with_eof) {
+    if (!w || !w->f) return ifail(VLR_ERR_INVALID_ARGUMENT, "null argument");
+    if (!w->bcf) return ifail(VLR_ERR_UNSUPPORTED, "parts are written as BCF (BGZF members concatenate; text VCF takes one writer)");
+    if (!with_header) w->first = false;
+    w->eof = with_eof != 0;
+    return VLR_OK;
+}
+// the parts in order, then the BGZF end-of-file member; the part files are removed
+int vlr_calls_concat_parts(const char* path, const char* const* parts, int n_parts) {
+    if (!path || !parts || n_parts < 1) return ifail(VLR_ERR_INVALID_ARGUMENT, "null argument");
+    FILE* o = fopen(path, "wb");
+    if (!o) return ifail(VLR_ERR_INVALID_ARGUMENT, "cannot create %s", path);
+    std::vector<uint8_t> buf((size_t)4 << 20);
+    bool ok = true;
+    for (int k = 0; k < n_parts && ok; ++k) {
+        FILE* in = fopen(parts[k], "rb");
+        if (!in) { ok = false; break; }
+        size_t got;
+        while ((got = fread(buf.data(), 1, buf.size(), in)) > 0) ok = ok && fwrite(buf.data(), 1, got, o) == got;
+        ok = ok && !ferror(in);
+        fclose(in);
+    }
+    static const uint8_t kEof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    ok = ok && fwrite(kEof, 1, sizeof kEof, o) == sizeof kEof;
+    ok = (fclose(o) == 0) && ok;
+    if (!ok) return ifail(VLR_ERR_INVALID_ARGUMENT, "assembling %s from its parts failed", path);
+    for (int k = 0; k < n_parts; ++k) (void)remove(parts[k]);
     return VLR_OK;
 }
 int vlr_calls_writer_append(vlr_calls_writer* w, const vlr_obs_table* t, const vlr_results* r, const char* const* out_names, int n_threads) {
@@ -2582,7 +2787,7 @@ int vlr_calls_writer_close(vlr_calls_writer* w) {
     if (w->f) {
         if (w->sink && !w->sink->finish()) rc = ifail(VLR_ERR_INVALID_ARGUMENT, "write failed");   // (every member handed over is in the file now)
         w->sink.reset();
-        if (w->first || w->bcf) {  // header of an empty file and / or the end-of-file member
+        if (w->first || (w->bcf && w->eof)) {  // header of an empty file and / or the end-of-file member
             vlr_obs_table* empty = nullptr;
             (void)empty;
             OutHeader h;
@@ -2594,7 +2799,7 @@ int vlr_calls_writer_close(vlr_calls_writer* w) {
             }
             std::string err;
             bool ok = true;
-            if (w->bcf) { std::vector<const std::vector<uint8_t>*> ps{&p0}; ok = write_bgzf_stream(w->f, ps, 1, 4, true, err); }
+            if (w->bcf) { std::vector<const std::vector<uint8_t>*> ps{&p0}; ok = write_bgzf_stream(w->f, ps, 1, 4, w->eof, err); }
             else if (!p0.empty()) ok = fwrite(p0.data(), 1, p0.size(), w->f) == p0.size();
             if (!ok) rc = ifail(VLR_ERR_INVALID_ARGUMENT, "write failed");
         }

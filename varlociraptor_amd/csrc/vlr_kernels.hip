@@ -717,27 +717,28 @@ __device__ inline double integrate_table(const double* tx, const double* tv, int
     // the trapezoid in the linear domain relative to the largest value, regrouped per grid point as in the row epilogue of
     // run_chain_batch: sum_seg (e_k + e_{k+1}) (x_{k+1} - x_k)/2 = sum_k e_k (x_{k+1} - x_{k-1})/2, one-sided at the ends — one
     // exponential per point and one logarithm instead of ln_add_exp + ln per segment
-    double vk[2], wk[2];
+    // (tables of any length: lane l takes entries l, l + 64, ...; the same additions in the same order as the two-entry version
+    //  this replaces for n <= 128)
     bool nan = false;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int k = lane + 64 * h;
-        vk[h] = VLR_NEG_INF; wk[h] = 0.0;
-        if (k < n) {
-            const double xl = sx[k > 0 ? k - 1 : 0], xr = sx[k + 1 < n ? k + 1 : k];
-            vk[h] = sv[k];
-            wk[h] = (xr - xl) / 2.0;
-            nan = nan || (vk[h] != vk[h]);
-        }
+    double m = VLR_NEG_INF;
+    for (int k = lane; k < n; k += 64) {
+        const double v = sv[k];
+        nan = nan || (v != v);
+        m = fmax(m, v == v ? v : VLR_NEG_INF);
     }
     const unsigned long long anynan = __ballot(nan);
-    const double M = wave_max(fmax(vk[0] == vk[0] ? vk[0] : VLR_NEG_INF, vk[1] == vk[1] ? vk[1] : VLR_NEG_INF));
+    const double M = wave_max(m);
     double r;
     if (anynan) r = __builtin_nan("");
     else if (M == VLR_NEG_INF || n < 2) r = VLR_NEG_INF;
     else {
-        double s = (vk[0] == VLR_NEG_INF ? 0.0 : exp(vk[0] - M) * wk[0]);
-        if (n > 64) s += (vk[1] == VLR_NEG_INF ? 0.0 : exp(vk[1] - M) * wk[1]);
+        double s = 0.0;
+        for (int k = lane; k < n; k += 64) {
+            const double xl = sx[k > 0 ? k - 1 : 0], xr = sx[k + 1 < n ? k + 1 : k];
+            const double v = sv[k];
+            const double t = (v == VLR_NEG_INF ? 0.0 : exp(v - M) * ((xr - xl) / 2.0));
+            s = (k == lane) ? t : s + t;
+        }
         s = wave_sum(s);
         r = M + log(s);
     }
@@ -1948,7 +1949,7 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
 #else
     const bool ones_on = ones_any(c) && ones_risk(c, q.inner);
 #endif
-    const bool cap_safe = p.table_cap < kTableCap;  // the host's bound was not clamped (vlr_host.cpp: table capacity)
+    const bool cap_safe = p.table_cap < kTableCapMax;  // the host's bound was not clamped (vlr_host.cpp: table capacity)
     double L = lo, R = hi, vL = VLR_NEG_INF, vR = VLR_NEG_INF, mid = lo;
     long long kL = 0, kR = 0;  // KEYED: the bracket ends' product keys
     PROF_ADD(c, 7);  // batch prologue (task fields, coefficient registers)
@@ -2021,8 +2022,12 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
         else
             reg_products<NS>(cc, cq, lcoef, rl, D, al, P);
         PROF_ADD(c, 12);  // pass: term products
-        // reduction over the 16 lanes of the row: inside the quads for all three points, then lane t of every quad keeps point t
-        // and the four quads are combined for that point alone (rotations by 4 and 8 lanes): lane t of the row ends with point t
+        // reduction over the 16 lanes of the row, transposed from the first step on: a lane and its neighbour (xor 1) exchange what the
+        // OTHER keeps — the even lane goes on with points 0 and 2, the odd one with point 1 (and a copy of 2) —, then the halves of a
+        // quad (xor 2) do the same, lane t of every quad ends with the quad's product of point t, and the four quads are combined for
+        // that point alone (rotations by 4 and 8 lanes): lane t of the row ends with point t.  Five multiply / exchange groups instead
+        // of eight; the products are the same pairs in the same association as a full butterfly (a b = b a), bit for bit.
+#ifdef VLR_FULL_BUTTERFLY
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             int e;
@@ -2033,6 +2038,27 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
         const int tq = rl & 3;
         double Psel = tq == 1 ? P[1] : tq == 2 ? P[2] : P[0];
         int Esel = tq == 1 ? E[1] : tq == 2 ? E[2] : E[0];
+#else
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            int e;
+            P[t] = __builtin_frexp(P[t], &e); E[t] = e;
+        }
+        const int tq = rl & 3;
+        const bool odd = (tq & 1) != 0;
+        // neighbours: the even lane hands over its share of point 1 and takes the odd lane's share of point 0
+        const double sendA = odd ? P[0] : P[1], ownA = odd ? P[1] : P[0];
+        const int sendAE = odd ? E[0] : E[1], ownAE = odd ? E[1] : E[0];
+        const double KA = ownA * dpp_f64<0xB1>(sendA);                     // even: point 0, odd: point 1 (quad_perm [1,0,3,2])
+        const int KAE = ownAE + dpp_i32<0xB1>(sendAE);
+        const double KB = P[2] * dpp_f64<0xB1>(P[2]);                      // point 2 on both
+        const int KBE = E[2] + dpp_i32<0xB1>(E[2]);
+        // halves of the quad: lane 0 wants the other even lane's point 0, lane 2 its point 2; lanes 1 and 3 both go on with point 1
+        const double sendB = tq == 0 ? KB : KA, ownB = tq == 2 ? KB : KA;
+        const int sendBE = tq == 0 ? KBE : KAE, ownBE = tq == 2 ? KBE : KAE;
+        double Psel = ownB * dpp_f64<0x4E>(sendB);                         // quad_perm [2,3,0,1]
+        int Esel = ownBE + dpp_i32<0x4E>(sendBE);
+#endif
         Psel *= dpp_f64<0x124>(Psel); Esel += dpp_i32<0x124>(Esel);        // row_ror:4
         Psel *= dpp_f64<0x128>(Psel); Esel += dpp_i32<0x128>(Esel);        // row_ror:8
         {
@@ -4498,8 +4524,13 @@ extern "C" int vlr_launch_selftest_math(int which, const double* a, const double
 #endif  // !VLR_DEEP && !VLR_WIDE_BUILD (selftest launchers)
 #if VLR_DEEP
 // deep launcher: the 2-waves-per-SIMD instance only (no coefficient area in LDS; max_obs = 0 for the layout)
-extern "C" int vlr_launch_call_kernel_deep(const vlr::DevPlan* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out,
-                                           int n_univ, int n_samples, int range_depth, void* stream) {
+#ifdef VLR_WIDE_BUILD
+#define VLR_FN_DEEP vlr_launch_call_kernel_widedeep
+#else
+#define VLR_FN_DEEP vlr_launch_call_kernel_deep
+#endif
+extern "C" int VLR_FN_DEEP(const vlr::DevPlan* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out,
+                           int n_univ, int n_samples, int range_depth, void* stream) {
     using namespace vlr;
     if (batch->n_loci <= 0) return 0;
     if (n_samples > kLdsSamples) return (int)hipErrorInvalidValue;  // (the per-sample LDS arrays of this build; the host picks the wide build)

@@ -12,11 +12,22 @@ constexpr int kMaxSamples = 16;       // == VLR_MAX_SAMPLES: size of the per-sam
 constexpr int kLdsSamples = VLR_LDS_SAMPLES;  // per-sample arrays of the KERNEL's LDS state: 8 in the standard build (the static LDS of a
                                       // workgroup decides the occupancy of the tumor-normal workloads), 16 in the wide build
                                       // (vlr_kernels_wide.hip) the launcher takes for plans with 9..16 samples
-constexpr int kMaxLfc = 4;            // LFC terms on one root->leaf path
-constexpr int kMaxFrames = 16;        // explicit recursion stack of the VAF-tree walk
-constexpr int kTableCap = 128;        // upper limit of visited points of one range chain (57 at resolution 0.01);
-                                      // the per-plan capacity is derived from the finest resolution
-constexpr int kMaxRangeDepth = 4;     // nested Range levels on one path
+// Limits of the STANDARD build of the kernels, whose static LDS decides the occupancy of the tumor-normal workloads, and of the WIDE
+// build (vlr_kernels_wide.hip, vlr_kernels_widedeep.hip) that plans beyond them are routed to: sixteen samples, eight l2fc terms and
+// eight nested ranges on a path (the reference has no such limits: grammar/vaftree.rs:168-305 builds arbitrary trees).
+constexpr int kMaxLfcStd = 4, kMaxLfcWide = 8;                  // LFC terms on one root->leaf path
+constexpr int kMaxRangeDepthStd = 4, kMaxRangeDepthWide = 8;    // nested Range levels on one path
+#ifdef VLR_WIDE_BUILD
+constexpr int kMaxLfc = kMaxLfcWide;
+constexpr int kMaxRangeDepth = kMaxRangeDepthWide;
+#else
+constexpr int kMaxLfc = kMaxLfcStd;
+constexpr int kMaxRangeDepth = kMaxRangeDepthStd;
+#endif
+constexpr int kMaxFrames = 32;        // explicit recursion stack of the VAF-tree walk (LDS sized by the plan's deepest path, checked at plan creation)
+constexpr int kTableCap = 128;        // visited points of one range chain the AFD filter stages in LDS (57 at resolution 0.01)
+constexpr int kTableCapMax = 1024;    // upper limit of the per-plan table capacity, which is derived from the finest resolution (2 + 3 rounds + 7:
+                                      // resolution 1e-40 needs 971); whether the tables of a plan fit the LDS is checked at plan creation
 constexpr int kMaxSet = 1024;         // members of one Set spectrum (LDS: 8 B x samples x the plan's largest set; the reference has no limit)
 constexpr int kMaxNamedEvents = 30;   // scenario events (engine universe = 1 + 2*named); 1 + named event groups fit the 31 value bits of the int32 alive masks
 constexpr int kNHyp = 9;              // 0 = Artifacts::none(), 1..8 single-artifact combinations

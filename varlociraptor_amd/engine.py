@@ -28,7 +28,7 @@ EXPORTS = [
     "vlr_node_create", "vlr_node_destroy", "vlr_node_n_devices", "vlr_node_device", "vlr_node_plan", "vlr_node_set_max_depth", "vlr_node_set_max_obs", "vlr_node_shard_range", "vlr_node_batch_run_host",
     "vlr_realign_batch", "vlr_realign_batch_host", "vlr_realign_fast_batch", "vlr_realign_fast_batch_host", "vlr_realign_homopolymer_batch", "vlr_realign_homopolymer_batch_host", "vlr_edit_distance_batch", "vlr_edit_distance_batch_host", "vlr_fdr_threshold", "vlr_selftest_math", "vlr_selftest_stream", "vlr_selftest_format_fixed",
     "vlr_obs_read", "vlr_obs_table_free", "vlr_obs_table_batch", "vlr_obs_table_sites", "vlr_obs_write", "vlr_calls_write", "vlr_ingest_last_timings", "vlr_ingest_total_timings",
-    "vlr_obs_reader_open", "vlr_obs_reader_open_device", "vlr_obs_table_device_batch", "vlr_obs_reader_set_host_columns", "vlr_obs_reader_set_async_columns", "vlr_obs_table_fetch_columns", "vlr_bgzf_inflate", "vlr_ingest_device_timings", "vlr_ingest_device_trim", "vlr_obs_reader_next", "vlr_obs_reader_close", "vlr_calls_writer_open", "vlr_calls_writer_append", "vlr_calls_writer_close", "vlr_calls_filter_fdr",
+    "vlr_obs_reader_open", "vlr_obs_reader_open_device", "vlr_obs_table_device_batch", "vlr_obs_reader_set_host_columns", "vlr_obs_reader_set_async_columns", "vlr_obs_table_fetch_columns", "vlr_bgzf_inflate", "vlr_ingest_device_timings", "vlr_ingest_device_trim", "vlr_obs_reader_open_device_shard", "vlr_obs_reader_shard_row_size", "vlr_obs_reader_shard_counts", "vlr_obs_reader_shard_assign", "vlr_obs_reader_next", "vlr_obs_reader_close", "vlr_calls_writer_open", "vlr_calls_writer_append", "vlr_calls_writer_close", "vlr_calls_writer_set_part", "vlr_calls_concat_parts", "vlr_calls_filter_fdr",
 ]
 
 
@@ -41,7 +41,7 @@ class EngineError(RuntimeError):
 def build(force: bool = False) -> str:
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in ("vlr_kernels.hip", "vlr_kernels_deep.hip", "vlr_kernels_wide.hip", "vlr_realign.hip", "vlr_fdr.hip", "vlr_inflate.hip", "vlr_decode.hip", "vlr_host.cpp", "vlr_ingest.cpp", "vlr_plan.h", "vlr_gpuio.h")] + [os.path.join(_HERE, "..", "include", "vlr.h")]
+    srcs = [os.path.join(src_dir, f) for f in ("vlr_kernels.hip", "vlr_kernels_deep.hip", "vlr_kernels_wide.hip", "vlr_kernels_widedeep.hip", "vlr_realign.hip", "vlr_fdr.hip", "vlr_inflate.hip", "vlr_decode.hip", "vlr_host.cpp", "vlr_ingest.cpp", "vlr_plan.h", "vlr_gpuio.h")] + [os.path.join(_HERE, "..", "include", "vlr.h")]
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", src_dir] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
     return LIB_PATH
@@ -56,7 +56,7 @@ def source_id() -> str:
     """The id a build of the current sources would carry (same recipe as csrc/Makefile)."""
     import hashlib
     h = hashlib.sha1()
-    for f in ("csrc/vlr_kernels.hip", "csrc/vlr_kernels_deep.hip", "csrc/vlr_kernels_wide.hip", "csrc/vlr_realign.hip", "csrc/vlr_fdr.hip", "csrc/vlr_inflate.hip", "csrc/vlr_decode.hip", "csrc/vlr_host.cpp", "csrc/vlr_ingest.cpp", "csrc/vlr_plan.h", "csrc/vlr_gpuio.h", "../include/vlr.h", "../include/vlr_detmath.h"):
+    for f in ("csrc/vlr_kernels.hip", "csrc/vlr_kernels_deep.hip", "csrc/vlr_kernels_wide.hip", "csrc/vlr_kernels_widedeep.hip", "csrc/vlr_realign.hip", "csrc/vlr_fdr.hip", "csrc/vlr_inflate.hip", "csrc/vlr_decode.hip", "csrc/vlr_host.cpp", "csrc/vlr_ingest.cpp", "csrc/vlr_plan.h", "csrc/vlr_gpuio.h", "../include/vlr.h", "../include/vlr_detmath.h"):
         with open(os.path.join(_HERE, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

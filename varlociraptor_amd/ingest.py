@@ -198,11 +198,24 @@ def device_timings(reset: bool = False) -> dict:
     return {n: a[i] for i, n in enumerate(k) if n}
 
 
+def _gather_rows(mine: np.ndarray) -> np.ndarray:
+    """The shard rows of all ranks in rank order: one all_gather of a few int64 per file over the default process group."""
+    import torch
+    import torch.distributed as tdist
+    world = tdist.get_world_size()
+    backend = tdist.get_backend()
+    dev = "cuda:%d" % torch.cuda.current_device() if backend == "nccl" else "cpu"
+    t = torch.from_numpy(np.ascontiguousarray(mine)).to(dev)
+    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=dev)
+    tdist.all_gather_into_tensor(out, t)
+    return out.cpu().numpy()
+
+
 class ObsReader:
     """vlr_obs_reader: the observation files a bounded number of records at a time.  Iterating yields (PileupBatch, Sites)."""
 
     def __init__(self, paths: Sequence[str], omit_bias_mask: int = 0, threads: int = 0, chunk_records: int = 250_000, device: Optional[int] = None,
-                 host_columns: bool = True, async_columns: bool = False):
+                 host_columns: bool = True, async_columns: bool = False, shard: Optional[Tuple[int, int]] = None, gather=None):
         """device = None: the host reader.  device = k: vlr_obs_reader_open_device — BGZF inflate, record split and v15 decode as kernels on
         device k; the tables then also hold the batch in device memory (ObsTable.device_batch)."""
         L = _lib()
@@ -217,10 +230,44 @@ class ObsReader:
         L.vlr_obs_reader_close.argtypes = [C.c_void_p]
         arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
         h = C.c_void_p()
+        self.first_record, self.n_records = 0, None
         if device is None:
+            if shard is not None:
+                raise ValueError("the sharded reader is the device reader (device=k)")
             _check(L.vlr_obs_reader_open(len(paths), arr, int(omit_bias_mask), int(threads), C.byref(h)))
+        elif shard is not None:
+            # shard = (k, N): this reader inflates and decodes about 1 / N of every file (vlr_obs_reader_open_device_shard); `gather` takes
+            # this shard's int64 row array and returns the rows of all shards in shard order, shape (N, n_files, row) — by default one
+            # torch.distributed all_gather over the default process group
+            L.vlr_obs_reader_open_device_shard.restype = C.c_int
+            L.vlr_obs_reader_open_device_shard.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_char_p), C.c_uint32, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+            L.vlr_obs_reader_shard_counts.restype = C.c_int
+            L.vlr_obs_reader_shard_counts.argtypes = [C.c_void_p, C.c_void_p]
+            L.vlr_obs_reader_shard_assign.restype = C.c_int
+            L.vlr_obs_reader_shard_assign.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+            L.vlr_obs_reader_shard_row_size.restype = C.c_int
+            k, n = int(shard[0]), int(shard[1])
+            _check(L.vlr_obs_reader_open_device_shard(int(device), len(paths), arr, int(omit_bias_mask), int(threads), k, n, C.byref(h)))
+            try:
+                w = L.vlr_obs_reader_shard_row_size()
+                mine = np.zeros((len(paths), w), np.int64)
+                _check(L.vlr_obs_reader_shard_counts(h, mine.ctypes.data))
+                self.shard_rows = mine
+                rows = np.ascontiguousarray((gather or _gather_rows)(mine), np.int64)
+                if rows.shape != (n, len(paths), w):
+                    raise ValueError("gather returned rows of shape %r, expected %r" % (rows.shape, (n, len(paths), w)))
+                fr, nr = C.c_int64(0), C.c_int64(0)
+                _check(L.vlr_obs_reader_shard_assign(h, rows.ctypes.data, C.byref(fr), C.byref(nr)))
+                self.first_record, self.n_records = int(fr.value), int(nr.value)
+                self.total_records = int(rows[:, 0, 0].sum())
+            except Exception:
+                L.vlr_obs_reader_close.restype = None
+                L.vlr_obs_reader_close.argtypes = [C.c_void_p]
+                L.vlr_obs_reader_close(h)
+                raise
         else:
             _check(L.vlr_obs_reader_open_device(int(device), len(paths), arr, int(omit_bias_mask), int(threads), C.byref(h)))
+        if device is not None:
             if async_columns:
                 # next() returns while the columns are still on their way to the host (the device batch is complete): the calls writer and
                 # ObsTable.fetch_columns() wait for them; do not read the numpy views of the columns before fetch_columns()
@@ -266,7 +313,8 @@ class ObsReader:
 class CallsWriter:
     """vlr_calls_writer: the calls file written one chunk of records at a time."""
 
-    def __init__(self, path: str, header_text: str):
+    def __init__(self, path: str, header_text: str, part: Optional[Tuple[int, int]] = None):
+        """part = (k, N): this writer writes part k of a file that N writers produce (concat_parts assembles it)."""
         L = _lib()
         L.vlr_calls_writer_open.restype = C.c_int
         L.vlr_calls_writer_open.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
@@ -277,6 +325,10 @@ class CallsWriter:
         h = C.c_void_p()
         _check(L.vlr_calls_writer_open(path.encode(), header_text.encode(), C.byref(h)))
         self._h = h
+        if part is not None:
+            L.vlr_calls_writer_set_part.restype = C.c_int
+            L.vlr_calls_writer_set_part.argtypes = [C.c_void_p, C.c_int, C.c_int]
+            _check(L.vlr_calls_writer_set_part(h, 1 if int(part[0]) == 0 else 0, 0))
 
     def append(self, table: ObsTable, results: CallResults, out_names: List[str], threads: int = 0):
         rs = results.as_struct()
@@ -293,6 +345,15 @@ class CallsWriter:
 
     def __exit__(self, *a):
         self.close()
+
+
+def concat_parts(path: str, parts: Sequence[str]):
+    """vlr_calls_concat_parts: the part files of a sharded run, in shard order, as one calls BCF (the parts are removed)."""
+    L = _lib()
+    L.vlr_calls_concat_parts.restype = C.c_int
+    L.vlr_calls_concat_parts.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.c_int]
+    arr = (C.c_char_p * len(parts))(*[p.encode() for p in parts])
+    _check(L.vlr_calls_concat_parts(path.encode(), arr, len(parts)))
 
 
 def write_observations(path: str, batch: PileupBatch, sample: int, threads: int = 0, third_allele_evidence: Optional[np.ndarray] = None):
