@@ -205,10 +205,10 @@ def _gather_rows(mine: np.ndarray) -> np.ndarray:
     world = tdist.get_world_size()
     backend = tdist.get_backend()
     dev = "cuda:%d" % torch.cuda.current_device() if backend == "nccl" else "cpu"
-    t = torch.from_numpy(np.ascontiguousarray(mine)).to(dev)
-    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=dev)
+    t = torch.from_numpy(np.ascontiguousarray(mine)).reshape(-1).to(dev)
+    out = torch.empty(world * t.numel(), dtype=t.dtype, device=dev)
     tdist.all_gather_into_tensor(out, t)
-    return out.cpu().numpy()
+    return out.cpu().numpy().reshape((world,) + tuple(mine.shape))
 
 
 class ObsReader:
