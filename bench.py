@@ -459,7 +459,7 @@ def bench_ingest(args, rank, world, local_rank, dev):
         "files": {"observation_bcf_bytes": obs_bytes, "inflated_bytes": tm["inflated_bytes"] / args.steps, "observations": n_obs, "serial_walks": tm["serial_walks"]},
         "roofline": {"bound": "hbm", "achieved": algo / k_s / 1e9 if k_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (algo / k_s / 1e9 / HBM_PEAK_GBS) if k_s > 0 else None,
                      "traffic": None, "algorithmic_bytes_per_step": algo, "kernel_ms": k_s * 1e3,
-                     "note": "vlr_inflate_kernel: one serial DEFLATE decoder per wave, four waves per CU (LDS window) — bound by the instruction issue of single waves, not by bandwidth (DESIGN 3e)"},
+                     "note": "vlr_inflate_kernel: one serial DEFLATE decoder per wave, fourteen waves per CU (4 KiB ring + tables in LDS), followed by the CRC32 kernel — bound by the issue rate and latencies of single waves, not by bandwidth (DESIGN 3e)"},
         "cpu_baseline": {"value": host, "unit": "records/s", "cores": effective_cpus(), "kind": "host reader (csrc/vlr_ingest.cpp: libdeflate + v15 decode on all cores; product code, not the oracle)", "sample": "one pass over the same files"} if host else None,
         "build_id": engine.build_id(),
     }

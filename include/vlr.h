@@ -545,6 +545,11 @@ int  vlr_obs_reader_open_device_shard(int device, int n_samples, const char* con
 int  vlr_obs_reader_shard_row_size(void);
 int  vlr_obs_reader_shard_counts(const vlr_obs_reader* reader, int64_t* out);
 int  vlr_obs_reader_shard_assign(vlr_obs_reader* reader, const int64_t* all_rows, int64_t* first_record, int64_t* n_records);
+/* The same for a node driven from one process (vlr_node_*): one sharded reader per device of the node, opened side by side, the
+ * counts exchanged in memory; out[vlr_node_n_devices(node)].  Reader r delivers the records of shard r from device vlr_node_device(node, r):
+ * its tables go to vlr_batch_run_device_in on vlr_node_plan(node, r), its calls to a part writer (vlr_calls_writer_set_part). */
+int  vlr_node_obs_readers_open(vlr_gpu_node* node, int n_samples, const char* const* paths, uint32_t omit_bias_mask, int n_threads,
+                               vlr_obs_reader** out);
 int  vlr_obs_table_device_batch(const vlr_obs_table* table, vlr_batch* out);  /* VLR_ERR_INVALID_ARGUMENT for a table of a host reader */
 /* keep == 0: the tables of this device reader do not bring the observation columns down to the host; instead a kernel counts per
  * pileup what the calls writer formats from them (distinct observation keys, Kass-Raftery letters, prob_mapping runs: the OBS / SAOBS /

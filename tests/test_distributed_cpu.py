@@ -37,6 +37,34 @@ def _worker(rank, world, port, n_loci, q):
     dist.destroy_process_group()
 
 
+def _rows_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from varlociraptor_amd.ingest import _gather_rows
+    out = _gather_rows(np.arange(2 * 7, dtype=np.int64).reshape(2, 7) + 100 * rank)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_shard_rows_of_the_sharded_reader_are_gathered_in_rank_order(world):
+    """The one exchange of the sharded front door (ingest.ObsReader(shard=...)): every rank's [n_files][7] int64 rows, in rank order,
+    on every rank — over gloo as over RCCL (a flat tensor: gloo's all_gather_into_tensor takes no higher-rank output)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29620 + world
+    ps = [ctx.Process(target=_rows_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    got = dict(q.get(timeout=300) for _ in range(world))
+    [p.join(timeout=120) for p in ps]
+    want = np.stack([np.arange(14, dtype=np.int64).reshape(2, 7) + 100 * r for r in range(world)])
+    for r in range(world):
+        assert got[r].shape == (world, 2, 7) and np.array_equal(got[r], want)
+
+
 @pytest.mark.parametrize("n_loci", [37, 64])
 def test_two_rank_gather_matches_single_process(n_loci):
     sys.path.insert(0, ROOT)

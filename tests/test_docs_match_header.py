@@ -28,6 +28,7 @@ def _internal_ids():
                 src = _read(*d, name)
                 ids.update(re.findall(r"__global__[^\n{;]*?\b(vlr_[a-z0-9_]+)\s*\(", src))
                 ids.update(re.findall(r"\b(vlr_launch_[a-z0-9_]+)", src))
+                ids.update(re.findall(r"#define\s+VLR_FN_\w+\s+(vlr_[a-z0-9_]+)", src))   # launchers / helpers named per build variant
     return ids
 
 

@@ -51,3 +51,36 @@ def test_node_defaults_to_every_visible_device_and_other_scenarios():
     node.close()
     with pytest.raises(engine.EngineError):
         engine.Node(cfg.scenario, devices=[0, 99])
+
+
+def test_node_readers_partition_the_files_and_feed_the_node_plans(tmp_path):
+    """vlr_node_obs_readers_open: one sharded device reader per device of the node, counts exchanged in memory (the in-process form of
+    the sharded front door).  Three entries on the one device of the box: the readers' records, in shard order, evaluate through the
+    device-resident batches to what one plan gives on the whole file."""
+    from varlociraptor_amd import ingest
+    cfg = synth.config3()
+    cfg.depth = 30.0
+    b = synth.generate(cfg, 4000, seed=41)
+    paths = []
+    for s_ in range(2):
+        p = str(tmp_path / ("s%d.bcf" % s_))
+        ingest.write_observations(p, b, s_)
+        paths.append(p)
+    plan = engine.Plan(cfg.scenario)
+    want = plan.call_host(b)
+    node = engine.Node(cfg.scenario, devices=[0, 0, 0])
+    readers = ingest.node_readers(node, paths, chunk_records=900)
+    assert len(readers) == 3
+    at = 0
+    for r, rd in enumerate(readers):
+        for batch, sites in rd:
+            got = plan.call_table_device(batch.extra["native_table"])
+            n = batch.n_loci
+            for f in FIELDS:
+                x, y = np.asarray(getattr(got, f)), np.asarray(getattr(want, f))[at:at + n]
+                assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), (r, f)
+            at += n
+        rd.close()
+    assert at == b.n_loci
+    plan.close()
+    node.close()

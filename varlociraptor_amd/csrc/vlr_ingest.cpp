@@ -2351,6 +2351,42 @@ int vlr_obs_reader_shard_assign(vlr_obs_reader* r, const int64_t* all, int64_t* 
     return VLR_OK;
 }
 
+// The same for the devices of a node driven from ONE process (vlr_node_*): one sharded reader per device, opened side by side on threads
+// of their own, the counts exchanged in memory.  out[vlr_node_n_devices(node)]; reader r delivers the records of shard r on
+// vlr_node_device(node, r) — the tables of its vlr_obs_reader_next go to vlr_batch_run_device_in on vlr_node_plan(node, r).
+int vlr_node_obs_readers_open(vlr_gpu_node* node, int n_samples, const char* const* paths, uint32_t omit_bias_mask, int n_threads, vlr_obs_reader** out) {
+    if (!node || !out || !paths || n_samples < 1) return ifail(VLR_ERR_INVALID_ARGUMENT, "vlr_node_obs_readers_open: bad argument");
+    const int N = vlr_node_n_devices(node);
+    if (N < 1) return ifail(VLR_ERR_INVALID_ARGUMENT, "vlr_node_obs_readers_open: empty node");
+    std::vector<vlr_obs_reader*> rd((size_t)N, nullptr);
+    std::vector<int> rcs((size_t)N, VLR_OK);
+    std::vector<std::string> errs((size_t)N);
+    const int per = std::max(1, pick_threads(n_threads) / N);
+    {
+        std::vector<std::thread> th;
+        for (int r = 0; r < N; ++r)
+            th.emplace_back([&, r] {
+                rcs[(size_t)r] = vlr_obs_reader_open_device_shard(vlr_node_device(node, r), n_samples, paths, omit_bias_mask, per, r, N, &rd[(size_t)r]);
+                if (rcs[(size_t)r] != VLR_OK) errs[(size_t)r] = vlr_last_error();   // (the message is per thread)
+            });
+        for (auto& t : th) t.join();
+    }
+    auto close_all = [&] { for (auto* q : rd) if (q) vlr_obs_reader_close(q); };
+    for (int r = 0; r < N; ++r)
+        if (rcs[(size_t)r] != VLR_OK) { close_all(); return ifail(rcs[(size_t)r], "%s", errs[(size_t)r].c_str()); }
+    std::vector<int64_t> all((size_t)N * (size_t)n_samples * kShardRow);
+    for (int r = 0; r < N; ++r) {
+        const int rc = vlr_obs_reader_shard_counts(rd[(size_t)r], all.data() + (size_t)r * (size_t)n_samples * kShardRow);
+        if (rc != VLR_OK) { close_all(); return rc; }
+    }
+    for (int r = 0; r < N; ++r) {
+        const int rc = vlr_obs_reader_shard_assign(rd[(size_t)r], all.data(), nullptr, nullptr);
+        if (rc != VLR_OK) { close_all(); return rc; }
+    }
+    for (int r = 0; r < N; ++r) out[r] = rd[(size_t)r];
+    return VLR_OK;
+}
+
 int vlr_obs_table_fetch_columns(vlr_obs_table* t) {
     if (!t) return ifail(VLR_ERR_INVALID_ARGUMENT, "null table");
     { const int rcw = t->wait_columns(); if (rcw != VLR_OK) return rcw; }

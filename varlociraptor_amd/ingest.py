@@ -211,6 +211,27 @@ def _gather_rows(mine: np.ndarray) -> np.ndarray:
     return out.cpu().numpy().reshape((world,) + tuple(mine.shape))
 
 
+def node_readers(node, paths: Sequence[str], omit_bias_mask: int = 0, threads: int = 0, chunk_records: int = 32768) -> List["ObsReader"]:
+    """vlr_node_obs_readers_open: one sharded device reader per device of an engine.Node (one process, N devices); reader r delivers
+    the records of shard r in file order, its tables hold the batch on node.devices[r]."""
+    L = _lib()
+    L.vlr_node_obs_readers_open.restype = C.c_int
+    L.vlr_node_obs_readers_open.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
+    arr = (C.c_char_p * len(paths))(*[p_.encode() for p_ in paths])
+    hs = (C.c_void_p * node.n_devices)()
+    _check(L.vlr_node_obs_readers_open(node._h, len(paths), arr, int(omit_bias_mask), int(threads), hs))
+    out = []
+    for r in range(node.n_devices):
+        rd = ObsReader.__new__(ObsReader)
+        rd._h, rd.chunk_records, rd.device, rd.first_record, rd.n_records = C.c_void_p(hs[r]), int(chunk_records), node.devices[r], None, None
+        L.vlr_obs_reader_next.restype = C.c_int
+        L.vlr_obs_reader_next.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
+        L.vlr_obs_reader_close.restype = None
+        L.vlr_obs_reader_close.argtypes = [C.c_void_p]
+        out.append(rd)
+    return out
+
+
 class ObsReader:
     """vlr_obs_reader: the observation files a bounded number of records at a time.  Iterating yields (PileupBatch, Sites)."""
 
