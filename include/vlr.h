@@ -34,8 +34,10 @@
 extern "C" {
 #endif
 
-#define VLR_ABI_VERSION 5   /* 3: vlr_plan_reserve takes the AFD capacity, 30 named events, vlr_node_*, homopolymer realignment; 4: device front door;
-                             * 5: sharded device reader, calls-file parts, vlr_ingest_device_trim, CRC32 of BGZF members checked by both readers */
+#define VLR_ABI_VERSION 6   /* 3: vlr_plan_reserve takes the AFD capacity, 30 named events, vlr_node_*, homopolymer realignment; 4: device front door;
+                             * 5: sharded device reader, calls-file parts, vlr_ingest_device_trim, CRC32 of BGZF members checked by both readers;
+                             * 6: calls emission on the device — vlr_results.afd_text (FORMAT/AFD text), OBS text in the observation summaries,
+                             *    vlr_obs_table_summaries */
 #define VLR_MAX_SAMPLES 16     /* samples per scenario supported by the device path   */
 #define VLR_N_BIAS      6      /* strand, orientation, position, softclip, homopolymer, alt-locus */
 
@@ -252,6 +254,16 @@ typedef struct {
     int32_t* afd_count;     /* [n_loci * n_samples]                                                        */
     double*  afd_vaf;       /* [n_loci * n_samples * afd_capacity] (f64: the BCF prints it with 3 decimals)      */
     double*  afd_lnprob;    /* [n_loci * n_samples * afd_capacity]                                         */
+    /* (ABI 6) optional FORMAT/AFD TEXT, written on the device by vlr_batch_run_host / vlr_batch_run_device_in / vlr_node_batch_run_host
+     * (HOST pointers; needs the afd_* buffers above): the list of locus l and sample s in the order and format of
+     * Call::write_final_record (calling/variants/mod.rs:473-559) — entries by ascending allele frequency (stable), "%.3f=%.2f" of
+     * (vaf, -10 ln p / ln 10) joined by ',' — at afd_text[afd_text_span[2 p] .. + afd_text_span[2 p + 1]], p = l * n_samples + s.
+     * A length of 0xffffffff: not formatted (a value beyond 1e12, a NaN allele frequency, more than 1 024 entries, text buffer full) —
+     * the list is in afd_vaf / afd_lnprob then, which are only copied to the host when some list of the call needs them.
+     * vlr_calls_write / vlr_calls_writer_append take the text where it is given.  NULL: no text. */
+    uint8_t*  afd_text;
+    uint64_t  afd_text_capacity;
+    uint32_t* afd_text_span;   /* [n_loci * n_samples * 2] */
 } vlr_results;
 
 /* ---------------------------------------------------------------- entry points */
@@ -511,6 +523,10 @@ int  vlr_calls_concat_parts(const char* path, const char* const* parts, int n_pa
  * the last vlr_calls_write ([8] record encoding, [9] BGZF deflate + file write, [10] total). */
 /* Diagnostics: the calls writer's own "%.<digits>f" (digits 0..3) of one value, for the tests to hold against printf. */
 int  vlr_selftest_format_fixed(double v, int digits, char* out, int cap);
+/* the device formatter of vlr_results.afd_text on host arrays (tests): n_lists lists of `capacity` slots; text / span as in vlr_results;
+ * *n_unformatted = lists left to the arrays */
+int  vlr_selftest_afd_text(int device, int64_t n_lists, int capacity, const int32_t* count, const double* vaf, const double* lnprob,
+                           uint8_t* text, uint64_t text_capacity, uint32_t* span, uint32_t* n_unformatted);
 void vlr_ingest_last_timings(double* out16);
 /* The same indices summed over every vlr_obs_reader_next / vlr_calls_writer_append call since the last reset (reset != 0 clears
  * them after reading): what the streaming front door spends per stage over a whole file. */
@@ -551,12 +567,16 @@ int  vlr_obs_reader_shard_assign(vlr_obs_reader* reader, const int64_t* all_rows
 int  vlr_node_obs_readers_open(vlr_gpu_node* node, int n_samples, const char* const* paths, uint32_t omit_bias_mask, int n_threads,
                                vlr_obs_reader** out);
 int  vlr_obs_table_device_batch(const vlr_obs_table* table, vlr_batch* out);  /* VLR_ERR_INVALID_ARGUMENT for a table of a host reader */
-/* keep == 0: the tables of this device reader do not bring the observation columns down to the host; instead a kernel counts per
- * pileup what the calls writer formats from them (distinct observation keys, Kass-Raftery letters, prob_mapping runs: the OBS / SAOBS /
- * SROBS / DP fields) and only those summaries cross PCIe.  The observation arrays of vlr_obs_table_batch and
+/* keep == 0: the tables of this device reader do not bring the observation columns down to the host; instead a kernel (one wave per
+ * pileup) derives what the calls writer formats from them — the OBS text itself (distinct observation keys counted, ordered and written
+ * as in Call::write_final_record, calling/variants/mod.rs:233-360), the Kass-Raftery letters of SAOBS / SROBS, the prob_mapping runs
+ * of DP — and only those summaries cross PCIe.  The observation arrays of vlr_obs_table_batch and
  * vlr_obs_sites.third_allele_evidence are then NOT filled until vlr_obs_table_fetch_columns copies them on demand (the writer does
- * that itself where it has to).  Default: keep. */
+ * that itself where it has to: pileups of more than 1 024 observations).  Default: keep.
+ * vlr_obs_table_summaries: 1 when the calls writer will format this table from device summaries, 0 when from the columns;
+ * *n_overflow (may be NULL) = pileups the kernel left to the columns. */
 int  vlr_obs_reader_set_host_columns(vlr_obs_reader* reader, int keep);
+int  vlr_obs_table_summaries(const vlr_obs_table* table, int64_t* n_overflow);
 int  vlr_obs_table_fetch_columns(vlr_obs_table* table);
 /* on != 0: vlr_obs_reader_next of this device reader returns while the copy of the observation columns to the host side of the
  * table is still in flight (the device side, what vlr_batch_run_device_in evaluates, is complete).  vlr_calls_writer_append and

@@ -303,8 +303,9 @@ def test_device_reader_refuses_what_it_does_not_read(tmp_path, golden_dir):
 
 @pytest.mark.parametrize("name", ["config3", "config5"])
 def test_writer_from_device_summaries_equals_writer_from_columns(name, tmp_path):
-    """host_columns=False: the observation columns stay in device memory, obs_summary_kernel counts per pileup what the calls writer
-    formats (OBS / SAOBS / SROBS / DP) and the writer works from those summaries.  The file must be the one written from the columns —
+    """host_columns=False: the observation columns stay in device memory, obs_text_kernel (one wave per pileup) writes the OBS text and
+    counts what the calls writer formats (SAOBS / SROBS / DP) and the writer works from those summaries — also for the synthetic
+    pileups, which have almost one distinct observation key per observation.  The file must be the one written from the columns —
     text VCF, so every character is compared — and fetch_columns must deliver the host reader's columns."""
     from varlociraptor_amd import callsfmt
     cfg = synth.CONFIGS[name]()
@@ -324,8 +325,11 @@ def test_writer_from_device_summaries_equals_writer_from_columns(name, tmp_path)
     names = cfg.scenario.out_names()
     header = callsfmt.header(names, cfg.scenario.sample_names, list(dsites.contig_names))
     a, c = str(tmp_path / "from_summaries.vcf"), str(tmp_path / "from_columns.vcf")
+    assert table.summaries() == (True, 0)
     ingest.write_calls(a, header, table, res, names)
+    assert table.summaries() == (True, 0)   # (the writer did not have to fetch the columns)
     table.fetch_columns()
+    assert table.summaries() == (False, 0)
     ingest.write_calls(c, header, table, res, names)
     ta, tc = open(a).read(), open(c).read()
     assert ta == tc
@@ -539,3 +543,52 @@ def test_sharded_reader_partitions_the_file_and_inflates_its_share_only(tmp_path
     bad[1, 0, 2] += 1
     with pytest.raises(engine.EngineError, match="do not meet"):
         ingest.ObsReader(paths, device=0, shard=(1, N), gather=lambda mine: bad)
+
+
+def test_summaries_of_deep_and_filtered_pileups(tmp_path):
+    """Pileups of some hundred observations with repeated keys, runs of several prob_mapping values and loci that drop non-standard
+    alignments (pileup.rs:26-43) are written from the summaries; a table with a FEW pileups of more than 1 024 observations keeps its
+    summaries and the writer fetches the columns for it; a file of such pileups only turns the summaries off.  The calls text must be the
+    host reader's, character by character."""
+    from varlociraptor_amd import callsfmt
+    from varlociraptor_amd.batch import PileupBatch
+
+    def pileups(depth, n, seed):
+        cfg = synth.config3()
+        cfg.depth, cfg.max_depth = depth, 4000
+        return cfg, synth.generate(cfg, n, seed=seed)
+    cfg, mid = pileups(400.0, 40, 11)
+    _, deep = pileups(1500.0, 40, 12)
+    _, shallow = pileups(60.0, 300, 13)
+    mixed = PileupBatch.concat([shallow.select(np.arange(150)), deep.select(np.arange(2)), shallow.select(np.arange(150, 300))])
+    for tag, b, expect in (("mid", mid, (True, False, True)), ("mixed", mixed, (True, True, False)), ("deep", deep, (False, False, False))):
+        # few distinct keys and runs: quantise the evidence columns and repeat the flags
+        c = b.columns
+        c["prob_alt"][:] = np.round(c["prob_alt"] * 2) / 2
+        c["prob_ref"][:] = np.round(c["prob_ref"] * 2) / 2
+        c["flags"][:] = c["flags"][(np.arange(b.n_obs) // 7) * 7 % b.n_obs]
+        c["prob_mapping"][:] = np.where((np.arange(b.n_obs) // 5) % 2 == 0, np.float32(-0.001), np.float32(-0.25))
+        third = np.where(np.arange(b.n_obs) % 4 == 0, (np.arange(b.n_obs) % 3) * 1234567, -1).astype(np.int32)
+        paths = []
+        for s in range(b.n_samples):
+            p = str(tmp_path / ("%s_%d.bcf" % (tag, s)))
+            ingest.write_observations(p, b, s, third_allele_evidence=third)
+            paths.append(p)
+        (hb, hsites), = _read_all(paths, None, 1 << 20)
+        rd = ingest.ObsReader(paths, chunk_records=1 << 20, device=0, host_columns=False)
+        db, dsites = rd.next()
+        table = db.extra["native_table"]
+        on, n_over = table.summaries()
+        assert (on, n_over > 0) == expect[:2], (tag, on, n_over)
+        plan = engine.Plan(cfg.scenario, device=0)
+        res = plan.call_table_device(table, afd_capacity=16)
+        names = cfg.scenario.out_names()
+        header = callsfmt.header(names, cfg.scenario.sample_names, list(dsites.contig_names))
+        a, h = str(tmp_path / (tag + "_dev.vcf")), str(tmp_path / (tag + "_host.vcf"))
+        ingest.write_calls(a, header, table, res, names)
+        assert table.summaries()[0] == expect[2], tag   # (the writer took the columns where a pileup was left to them)
+        ref = plan.call_host(hb, afd_capacity=16)
+        ingest.write_calls(h, header, hb.extra["native_table"], ref, names)
+        assert open(a).read() == open(h).read()
+        rd.close()
+        plan.close()

@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_SAMPLES = 16
 N_BIAS = 6
 
@@ -109,6 +109,7 @@ class Results(C.Structure):
         ("map_bias", C.c_void_p), ("best_event", C.c_void_p), ("status", C.c_void_p),
         ("afd_capacity", C.c_int32), ("_pad", C.c_int32),
         ("afd_count", C.c_void_p), ("afd_vaf", C.c_void_p), ("afd_lnprob", C.c_void_p),
+        ("afd_text", C.c_void_p), ("afd_text_capacity", C.c_uint64), ("afd_text_span", C.c_void_p),
     ]
 
 

@@ -102,10 +102,13 @@ class PileupBatch:
 class CallResults:
     """Host result buffers of include/vlr.h `vlr_results`."""
 
-    def __init__(self, n_loci: int, n_out: int, n_samples: int, afd_capacity: int = 0, alloc=None):
+    def __init__(self, n_loci: int, n_out: int, n_samples: int, afd_capacity: int = 0, alloc=None, afd_text_capacity: int = 0):
         """`alloc(shape, dtype)`: allocator of the arrays (engine.host_array: page-locked memory, so that vlr_batch_run_host copies the
-        results back by direct DMA — the AFD lists are gigabytes for a million loci); default: ordinary initialised numpy arrays."""
+        results back by direct DMA — the AFD lists are gigabytes for a million loci); default: ordinary initialised numpy arrays.
+        `afd_text_capacity` > 0: the FORMAT/AFD text of every list is formatted on the device into `afd_text` / `afd_text_span`
+        (vlr_results.afd_text) and the lists themselves only come down when a list could not be formatted."""
         self.n_loci, self.n_out, self.n_samples, self.afd_capacity = n_loci, n_out, n_samples, afd_capacity
+        self.afd_text = self.afd_text_span = None
         custom = alloc is not None
         if alloc is None:
             def alloc(shape, dtype, fill=0):
@@ -128,8 +131,18 @@ class CallResults:
             self.afd_count = alloc((n_loci, n_samples), np.int32)
             self.afd_vaf = alloc((n_loci, n_samples, afd_capacity), np.float64, None if custom else 0)
             self.afd_lnprob = alloc((n_loci, n_samples, afd_capacity), np.float64, None if custom else 0)
+            if afd_text_capacity > 0:
+                self.afd_text = alloc((int(afd_text_capacity),), np.uint8, None if custom else 0)
+                self.afd_text_span = alloc((n_loci, n_samples, 2), np.uint32)
         else:
             self.afd_count = self.afd_vaf = self.afd_lnprob = None
+
+    def afd_strings(self, locus: int, sample: int):
+        """The device-formatted AFD text of one list, or None when the list was left to the arrays (or no text was requested)."""
+        if self.afd_text is None:
+            return None
+        off, n = (int(x) for x in self.afd_text_span[locus, sample])
+        return None if n == 0xffffffff else bytes(self.afd_text[off:off + n]).decode()
 
     def as_struct(self) -> abi.Results:
         r = abi.Results()
@@ -145,6 +158,10 @@ class CallResults:
             r.afd_count = self.afd_count.ctypes.data
             r.afd_vaf = self.afd_vaf.ctypes.data
             r.afd_lnprob = self.afd_lnprob.ctypes.data
+            if self.afd_text is not None:
+                r.afd_text = self.afd_text.ctypes.data
+                r.afd_text_capacity = int(self.afd_text.size)
+                r.afd_text_span = self.afd_text_span.ctypes.data
         return r
 
     def phred(self) -> np.ndarray:

@@ -168,8 +168,9 @@ class _PinnedResults:
         import threading
         self.free, self.lock = [], threading.Lock()
 
-    def results(self, n_loci, n_out, n_samples, afd_capacity):
-        need = n_loci * (8 * (n_out + 1 + n_samples) + abi.N_BIAS + 8) + (n_loci * n_samples * (4 + 16 * afd_capacity) if afd_capacity else 0) + 64 * 16
+    def results(self, n_loci, n_out, n_samples, afd_capacity, afd_text_capacity=0):
+        need = (n_loci * (8 * (n_out + 1 + n_samples) + abi.N_BIAS + 8) + (n_loci * n_samples * (4 + 16 * afd_capacity) if afd_capacity else 0)
+                + (afd_text_capacity + n_loci * n_samples * 8 if afd_capacity else 0) + 64 * 16)
         block = None
         with self.lock:
             for i, b in enumerate(self.free):
@@ -187,7 +188,7 @@ class _PinnedResults:
             off = at[0]
             at[0] = (off + n + 63) & ~63
             return block[off:off + n].view(dtype).reshape(shape)
-        res = CallResults(n_loci, n_out, n_samples, afd_capacity, alloc=alloc)
+        res = CallResults(n_loci, n_out, n_samples, afd_capacity, alloc=alloc, afd_text_capacity=afd_text_capacity)
         res._pool_block = block
         return res
 
@@ -348,7 +349,14 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                 if len(mine) == L and on_dev:
                     # the columns were decoded on the device (device reader): nothing to stage but the results, which land in recycled
                     # page-locked memory when the calls writer is the only consumer (it hands the block back after the chunk is written)
-                    buf = result_pool.results(L, n_out_, S_, afd_capacity) if result_pool is not None else None
+                    # the FORMAT/AFD text is written on the device (vlr_results.afd_text, 8 bytes per slot of the lists' capacity; a list
+                    # that does not fit comes down as numbers) unless results are copied between records afterwards — breakend events
+                    # (group fan-out, rows carried across chunks) index the arrays.  VLR_AFD_TEXT=0: numbers only.
+                    text_cap = 0
+                    if (afd_capacity and len(reps) == L and (group_key is None or not np.any(group_key)) and os.environ.get("VLR_AFD_TEXT", "1") != "0"):
+                        text_cap = min(L * S_ * 8 * afd_capacity, 0xffff0000)
+                    buf = (result_pool.results(L, n_out_, S_, afd_capacity, text_cap) if result_pool is not None
+                           else (CallResults(L, n_out_, S_, afd_capacity, afd_text_capacity=text_cap) if text_cap else None))
                     r = plan.call_table_device(table, afd_capacity=afd_capacity, results=buf)
                 else:
                     r = plan.call_host(sub, afd_capacity=afd_capacity)
@@ -423,10 +431,11 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
             try:
                 reader = vingest.ObsReader(paths, omit_bias_mask=omit_mask, chunk_records=int(os.environ.get("VLR_CLI_CHUNK", "0")) or 32768, device=device,
                                            shard=(rank, world) if want_shards else None,
-                                           # VLR_INGEST_SUMMARIES=1: the observation columns stay on the device and the calls writer formats from per-pileup
-                                           # summaries (vlr_obs_reader_set_host_columns; pays off when pileups have few distinct observation keys — the
-                                           # synthetic bench pileups have almost one per observation and fall back to the columns)
-                                           host_columns=(processor is not None or candidate_filter is not None or os.environ.get("VLR_INGEST_SUMMARIES", "0") != "1"),
+                                           # the observation columns stay on the device and the calls writer takes the OBS text, the SAOBS / SROBS letters
+                                           # and the DP runs of every pileup from obs_text_kernel (vlr_obs_reader_set_host_columns(0)); a processor, a
+                                           # candidate filter and the unsharded multi-rank path read the host columns.  VLR_INGEST_SUMMARIES=0: columns.
+                                           host_columns=(processor is not None or candidate_filter is not None or not (world == 1 or want_shards)
+                                                         or os.environ.get("VLR_INGEST_SUMMARIES", "1") == "0"),
                                            # the evaluation reads the device side of a table; only the writer (which waits) needs the host copy of the columns
                                            # (several ranks: every rank inflates and decodes the files on its own device instead of sharing the
                                            # node's CPUs between N host readers; its shard is cut from the host copy of the columns)

@@ -24,7 +24,10 @@
 //      "cold record" the host parses with the same code as a whole record (strings, EVENT / MATEID, IMPRECISE, priors).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -526,7 +529,12 @@ __global__ __launch_bounds__(64) void rec_cold_kernel(const uint8_t* __restrict_
     }
 }
 
-// ---- observation summaries for the calls writer: one lane per pileup, the host's per-observation loop (sample_fields) as it stands
+// ---- observation summaries for the calls writer: one WAVE per pileup (round 5; round 4 ran the host's loop with one lane per pileup and
+// kept 64 distinct keys in registers, which the synthetic pileups — almost one key per observation — overflowed).  The wave computes the
+// packed key of every kept observation (sample_fields of vlr_ingest.cpp, the same decisions), counts equal keys by comparing every
+// observation with every other one (keys in LDS, broadcast reads: 2 x 100 x 100 compares for a tumor-normal record), orders the distinct
+// keys like generalized_cigar(keep_order = false) (utils/mod.rs:122-156: stable by count descending, then stable by class — one rank
+// over (class, -count, first appearance)) and writes the OBS TEXT: the host copies it into the record.
 __device__ __forceinline__ bool d_relative_eq(double a, double b, double eps) {
     if (a == b) return true;
     if (isinf(a) || isinf(b)) return false;
@@ -542,107 +550,461 @@ __device__ __forceinline__ uint32_t d_kr_letter(double bf, double eps) {  // uti
 }
 __device__ __forceinline__ uint32_t d_lower(uint32_t c) { return (c >= 'A' && c <= 'Z') ? c + 32u : c; }
 
-__global__ void obs_summary_kernel(DeviceCols cols, const uint32_t* __restrict__ obs_offset, const uint8_t* __restrict__ locus_flags, int64_t n_pileups, int n_samples,
-                                   SumConsts K, PileSum* __restrict__ hdr, uint64_t* __restrict__ ent_key, uint32_t* __restrict__ ent_cnt,
-                                   float* __restrict__ run_pm, uint32_t* __restrict__ run_len, uint32_t* __restrict__ cursor) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_pileups) return;
-    const uint32_t b = obs_offset[p], e = obs_offset[p + 1];
+// the packed key of one kept observation and the letter it adds to SAOBS (to_alt) or SROBS
+struct ObsKey { uint64_t key; uint32_t letter; bool to_alt; };
+__device__ __forceinline__ ObsKey d_obs_key(float pa_f, float pr_f, uint32_t f, int32_t third, const SumConsts& K) {
+    const double pa = (double)pa_f, pr = (double)pr_f;
+    const double d = pa - pr;
+    double bf_alt, bf_ref;
+    uint32_t kl_alt, kl_ref;
+    if (fabs(d) >= 1e-15 && fabs(d) < 700.0) {
+        const double ad = fabs(d);
+        const uint32_t k = ad <= K.ln3 ? 'B' : ad <= K.ln20 ? 'P' : ad <= K.ln150 ? 'S' : 'V';
+        bf_alt = d > 0 ? 2.0 : 0.5; bf_ref = d > 0 ? 0.5 : 2.0;
+        kl_alt = d > 0 ? k : 'N'; kl_ref = d > 0 ? 'N' : k;
+    } else if (fabs(d) >= 700.0) {
+        // exp(+-d) is 0 / inf or 1e-304 / 1e304: the order and the letters of the host's exponentials
+        bf_alt = d > 0 ? 2.0 : 0.5; bf_ref = d > 0 ? 0.5 : 2.0;
+        kl_alt = d > 0 ? 'V' : 'N'; kl_ref = d > 0 ? 'N' : 'V';
+    } else {
+        // |d| < 1e-15 (or NaN): exp(d) = 1 + d rounded to nearest (the next term is below 1e-30)
+        bf_alt = 1.0 + d; bf_ref = 1.0 - d;
+        kl_alt = d_kr_letter(bf_alt, K.eps); kl_ref = d_kr_letter(bf_ref, K.eps);
+    }
+    const bool maxq = (f & VLR_F_MAX_MAPQ) != 0;
+    uint32_t s0, s1 = 0;
+    if (bf_alt > bf_ref) { s0 = 'A'; s1 = kl_alt; }
+    else if (bf_ref > bf_alt) { s0 = 'R'; s1 = kl_ref; }
+    else s0 = 'E';
+    if (!maxq) { s0 = d_lower(s0); if (s1) s1 = d_lower(s1); }
+    const uint32_t orient = (f >> VLR_F_ORIENT_SHIFT) & 3u, strand = (f >> VLR_F_STRAND_SHIFT) & 3u, altloc = (f >> VLR_F_ALTLOCUS_SHIFT) & 3u;
+    const bool hp_err = (f & VLR_F_HP_LEN_VALID) && ((f >> VLR_F_HP_LEN_SHIFT) & 0xffu) != 0;
+    ObsKey o;
+    o.key = (uint64_t)s0 | ((uint64_t)s1 << 8) | ((uint64_t)((f & VLR_F_PAIRED) ? 1 : 0) << 16) |
+            ((uint64_t)(altloc > 2 ? 2 : altloc) << 17) | ((uint64_t)strand << 19) | ((uint64_t)orient << 21) |
+            ((uint64_t)((f & VLR_F_READPOS_MAJOR) ? 1 : 0) << 23) | ((uint64_t)((f & VLR_F_SOFTCLIPPED) ? 1 : 0) << 24) |
+            ((uint64_t)(hp_err ? 1 : 0) << 25) | ((uint64_t)(uint32_t)(third + 1) << 32);
+    o.to_alt = pa > pr;
+    const uint32_t c0 = o.to_alt ? kl_alt : kl_ref;
+    o.letter = maxq ? c0 : d_lower(c0);
+    return o;
+}
+// N B P S V E, lower case + 6
+__device__ __forceinline__ uint32_t d_letter_index(uint32_t c) {
+    const uint32_t u = c & ~32u;
+    const uint32_t i = u == 'N' ? 0u : u == 'B' ? 1u : u == 'P' ? 2u : u == 'S' ? 3u : u == 'V' ? 4u : 5u;
+    return i + ((c & 32u) ? 6u : 0u);
+}
+__device__ __forceinline__ uint32_t d_letter_char(uint32_t i) {
+    const uint32_t j = i >= 6 ? i - 6 : i;
+    const uint32_t u = j == 0 ? 'N' : j == 1 ? 'B' : j == 2 ? 'P' : j == 3 ? 'S' : j == 4 ? 'V' : 'E';
+    return i >= 6 ? u + 32u : u;
+}
+__device__ __forceinline__ uint32_t d_digits(uint32_t v) {
+    return v < 10u ? 1u : v < 100u ? 2u : v < 1000u ? 3u : v < 10000u ? 4u : v < 100000u ? 5u : v < 1000000u ? 6u : v < 10000000u ? 7u : v < 100000000u ? 8u : v < 1000000000u ? 9u : 10u;
+}
+__device__ __forceinline__ uint8_t* d_put_dec(uint8_t* p, uint32_t v) {
+    const uint32_t n = d_digits(v);
+    for (uint32_t i = n; i-- > 0;) { p[i] = (uint8_t)('0' + v % 10u); v /= 10u; }
+    return p + n;
+}
+
+// bytes of one OBS item: count, one or two score letters, third-allele evidence or '.', seven flag characters
+__device__ __forceinline__ uint32_t d_item_len(uint64_t key, uint32_t cnt) {
+    const uint32_t th = (uint32_t)(key >> 32);
+    return d_digits(cnt) + 1u + (((key >> 8) & 0xffu) ? 1u : 0u) + (th ? d_digits(th - 1u) : 1u) + 7u;
+}
+
+// Three launches: obs_text_kernel counts, orders and leaves the distinct keys of pileup p in OUTPUT order in item_key / item_cnt
+// [obs_offset[p], + n_item) with the byte length of its text in text_len[p]; span_alloc_kernel places the texts (one atomic per 64
+// pileups: a bump cursor taken once per pileup made 131 000 same-address atomics per request the bound of the kernel);
+// obs_write_kernel writes the bytes.
+__global__ __launch_bounds__(64) void obs_text_kernel(DeviceCols cols, const uint32_t* __restrict__ obs_offset, const uint8_t* __restrict__ locus_flags, int n_samples,
+                                                      SumConsts K, PileSum* __restrict__ hdr, uint64_t* __restrict__ item_key, uint32_t* __restrict__ item_cnt,
+                                                      uint32_t* __restrict__ text_len, float* __restrict__ run_pm, uint32_t* __restrict__ run_len,
+                                                      uint32_t* __restrict__ cursor, uint32_t lds_obs) {
+    // dynamic LDS sized by the launcher for the largest pileup of the table (lds_obs = its observations, at most kSumMaxObs, + 8 for the
+    // sentinels of the unrolled loops, a multiple of 8): a 100x table takes 4 kB per wave instead of 25
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    uint64_t* s_key = (uint64_t*)s_dyn;                  // keys of the kept observations; then the order values of the distinct keys
+    uint64_t* s_hkey = s_key + lds_obs;                  // distinct keys in first-appearance order
+    uint32_t* s_a = (uint32_t*)(s_hkey + lds_obs);       // prob_mapping of the kept observations (bits); then the counts of the distinct keys
+    uint32_t* s_b = s_a + lds_obs;                       // run heads
+    uint32_t* s_lc = s_b + lds_obs;                      // SAOBS [0, 12) / SROBS [12, 24) letters: count, first appearance, order
+    uint32_t* s_lf = s_lc + 24;
+    uint32_t* s_perm = s_lf + 24;
+    const int64_t p = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t below = (1ull << lane) - 1ull;
+    const uint32_t b = obs_offset[p], e = obs_offset[p + 1], n = e - b;
+    if (n + 8u > lds_obs) {   // (wave-uniform; more than kSumMaxObs observations) the host counts this table from the columns
+        if (lane == 0) {
+            PileSum h;
+            memset(&h, 0, sizeof h);
+            h.overflow = 1;
+            hdr[p] = h;
+            text_len[p] = 0xffffffffu;
+        }
+        return;
+    }
     const bool drop_nonstd = (locus_flags[p / n_samples] & VLR_LOCUS_REMOVE_NONSTANDARD) != 0;   // pileup.rs:26-43
-    uint64_t keys[kSumMaxKeys];
-    uint32_t cnts[kSumMaxKeys];
-    uint32_t nk = 0, kept = 0, n_run = 0, overflow = 0;
-    PileSum h;
-    h.alt_n = 0; h.ref_n = 0; h.pad[0] = h.pad[1] = 0;
-    for (int i = 0; i < kSumLetters; ++i) { h.alt_letter[i] = 0; h.ref_letter[i] = 0; h.alt_cnt[i] = 0; h.ref_cnt[i] = 0; }
-    // the runs go straight to the bump array: reserve the worst case (one run per observation) only when a second run appears —
-    // first count them
-    {
-        float last = 0.0f;
-        bool have = false;
-        for (uint32_t i = b; i < e; ++i) {
-            const uint32_t f = cols.flags[i];
-            if (drop_nonstd && ((f >> VLR_F_ORIENT_SHIFT) & 3u) == VLR_ORIENT_OTHER) continue;
-            const float pm = cols.col[0][i];
-            const bool same = have && pm == last;   // (exactly the test of the second pass: the reservation must match what it writes)
-            if (!same) { n_run += 1; last = pm; have = true; }
-        }
-    }
-    const uint32_t run_off = n_run ? atomicAdd(&cursor[1], n_run) : 0u;
-    uint32_t r_at = 0, r_len = 0;
-    float r_pm = 0.0f;
-    bool r_have = false;
-    for (uint32_t i = b; i < e; ++i) {
-        const uint32_t f = cols.flags[i];
-        const uint32_t orient = (f >> VLR_F_ORIENT_SHIFT) & 3u;
-        if (drop_nonstd && orient == VLR_ORIENT_OTHER) continue;
-        kept += 1;
-        const float pmf = cols.col[0][i];
-        {   // (the host compares doubles converted from these floats: pm != last_pm — NaN starts a run every time there, and here)
-            const bool same = r_have && pmf == r_pm;
-            if (!same) {
-                if (r_have) { run_pm[run_off + r_at] = r_pm; run_len[run_off + r_at] = r_len; r_at += 1; }
-                r_pm = pmf; r_len = 0; r_have = true;
+    if (lane < 24) { s_lc[lane] = 0u; s_lf[lane] = 0xffffffffu; }
+    __syncthreads();
+    // ---- keys of the kept observations, in observation order
+    uint32_t kept = 0;
+    for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+        const uint32_t i = c0 + lane;
+        bool keep = false;
+        uint64_t key = 0;
+        uint32_t pmb = 0;
+        if (i < n) {
+            const uint32_t f = cols.flags[b + i];
+            keep = !(drop_nonstd && ((f >> VLR_F_ORIENT_SHIFT) & 3u) == VLR_ORIENT_OTHER);
+            if (keep) {
+                pmb = __float_as_uint(cols.col[0][b + i]);
+                const ObsKey k = d_obs_key(cols.col[1][b + i], cols.col[2][b + i], f, cols.third[b + i], K);
+                key = k.key;
+                const uint32_t code = (k.to_alt ? 0u : 12u) + d_letter_index(k.letter);
+                atomicAdd(&s_lc[code], 1u);
+                atomicMin(&s_lf[code], i);
             }
-            r_len += 1;
         }
-        const double pa = (double)cols.col[1][i], pr = (double)cols.col[2][i];
-        const double d = pa - pr;
-        double bf_alt, bf_ref;
-        uint32_t kl_alt, kl_ref;
-        if (fabs(d) >= 1e-15 && fabs(d) < 700.0) {
-            const double ad = fabs(d);
-            const uint32_t k = ad <= K.ln3 ? 'B' : ad <= K.ln20 ? 'P' : ad <= K.ln150 ? 'S' : 'V';
-            bf_alt = d > 0 ? 2.0 : 0.5; bf_ref = d > 0 ? 0.5 : 2.0;
-            kl_alt = d > 0 ? k : 'N'; kl_ref = d > 0 ? 'N' : k;
-        } else if (fabs(d) >= 700.0) {
-            // exp(+-d) is 0 / inf or 1e-304 / 1e304: the order and the letters of the host's exponentials
-            bf_alt = d > 0 ? 2.0 : 0.5; bf_ref = d > 0 ? 0.5 : 2.0;
-            kl_alt = d > 0 ? 'V' : 'N'; kl_ref = d > 0 ? 'N' : 'V';
-        } else {
-            // |d| < 1e-15 (or NaN): exp(d) = 1 + d rounded to nearest (the next term is below 1e-30)
-            bf_alt = 1.0 + d; bf_ref = 1.0 - d;
-            kl_alt = d_kr_letter(bf_alt, K.eps); kl_ref = d_kr_letter(bf_ref, K.eps);
+        const uint64_t m = __ballot(keep);
+        if (keep) { const uint32_t at = kept + (uint32_t)__popcll(m & below); s_key[at] = key; s_a[at] = pmb; }
+        kept += (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    // ---- runs of equal prob_mapping (the host compares the floats: NaN starts a run every time, there and here)
+    uint32_t R = 0;
+    for (uint32_t c0 = 0; c0 < kept; c0 += 64) {
+        const uint32_t k = c0 + lane;
+        bool head = false;
+        if (k < kept) head = k == 0 || !(__uint_as_float(s_a[k]) == __uint_as_float(s_a[k - 1]));
+        const uint64_t m = __ballot(head);
+        if (head) s_b[R + (uint32_t)__popcll(m & below)] = k;
+        R += (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    // (one run is the rule — prob_mapping is the MAPQ-adjusted mean of the pileup — and sits in the header; only further runs take
+    //  entries of the run arrays)
+    uint32_t run_off = 0;
+    if (R > 1) {
+        if (lane == 0) run_off = atomicAdd(&cursor[1], R - 1u);
+        run_off = (uint32_t)__shfl((int)run_off, 0);
+    }
+    for (uint32_t r = 1u + lane; r < R; r += 64) {
+        const uint32_t k0 = s_b[r], k1 = r + 1 < R ? s_b[r + 1] : kept;
+        run_pm[run_off + r - 1u] = __uint_as_float(s_a[k0]);
+        run_len[run_off + r - 1u] = k1 - k0;
+    }
+    const uint32_t run0_pm = R ? s_a[0] : 0u, run0_len = R ? (R > 1 ? s_b[1] : kept) : 0u;
+    __syncthreads();
+    // ---- distinct keys with their counts, in first-appearance order (what Counter::most_common sees).  Every observation is compared
+    // with every other one: the keys come from LDS as broadcast reads, eight per step (behind the last key stand eight sentinels no key
+    // equals), and a lane carries the observations of two chunks through one sweep.
+    if (lane < 8) s_key[kept + lane] = ~0ull;
+    __syncthreads();
+    const uint32_t kept8 = (kept + 7u) & ~7u;
+    uint32_t n_dist = 0;
+    for (uint32_t c0 = 0; c0 < kept; c0 += 128) {
+        const uint32_t k0 = c0 + lane, k1 = c0 + 64 + lane;
+        const bool valid0 = k0 < kept, valid1 = k1 < kept;
+        const uint64_t my0 = valid0 ? s_key[k0] : 0ull, my1 = valid1 ? s_key[k1] : 0ull;
+        uint32_t cnt0 = 0, before0 = 0, cnt1 = 0, before1 = 0;
+        for (uint32_t j = 0; j < kept8; j += 8) {
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                const uint64_t kj = s_key[j + u];
+                const bool eq0 = kj == my0, eq1 = kj == my1;
+                cnt0 += eq0 ? 1u : 0u; before0 += (eq0 && j + u < k0) ? 1u : 0u;
+                cnt1 += eq1 ? 1u : 0u; before1 += (eq1 && j + u < k1) ? 1u : 0u;
+            }
         }
-        const bool maxq = (f & VLR_F_MAX_MAPQ) != 0;
-        uint32_t s0, s1 = 0;
-        if (bf_alt > bf_ref) { s0 = 'A'; s1 = kl_alt; }
-        else if (bf_ref > bf_alt) { s0 = 'R'; s1 = kl_ref; }
-        else s0 = 'E';
-        if (!maxq) { s0 = d_lower(s0); if (s1) s1 = d_lower(s1); }
-        const uint32_t strand = (f >> VLR_F_STRAND_SHIFT) & 3u, altloc = (f >> VLR_F_ALTLOCUS_SHIFT) & 3u;
-        const bool hp_err = (f & VLR_F_HP_LEN_VALID) && ((f >> VLR_F_HP_LEN_SHIFT) & 0xffu) != 0;
-        const uint64_t key = (uint64_t)s0 | ((uint64_t)s1 << 8) | ((uint64_t)((f & VLR_F_PAIRED) ? 1 : 0) << 16) |
-                             ((uint64_t)(altloc > 2 ? 2 : altloc) << 17) | ((uint64_t)strand << 19) | ((uint64_t)orient << 21) |
-                             ((uint64_t)((f & VLR_F_READPOS_MAJOR) ? 1 : 0) << 23) | ((uint64_t)((f & VLR_F_SOFTCLIPPED) ? 1 : 0) << 24) |
-                             ((uint64_t)(hp_err ? 1 : 0) << 25) | ((uint64_t)(uint32_t)(cols.third[i] + 1) << 32);
-        if (!overflow) {
-            uint32_t k = 0;
-            while (k < nk && keys[k] != key) ++k;
-            if (k == nk) {
-                if (nk == kSumMaxKeys) overflow = 1;
-                else { keys[nk] = key; cnts[nk] = 1; nk += 1; }
-            } else cnts[k] += 1;
+        const bool head0 = valid0 && before0 == 0, head1 = valid1 && before1 == 0;
+        const uint64_t m0 = __ballot(head0), m1 = __ballot(head1);
+        // (q <= k: s_hkey / s_a are written behind what this sweep read; s_a is free since the runs)
+        if (head0) { const uint32_t q = n_dist + (uint32_t)__popcll(m0 & below); s_hkey[q] = my0; s_a[q] = cnt0; }
+        n_dist += (uint32_t)__popcll(m0);
+        if (head1) { const uint32_t q = n_dist + (uint32_t)__popcll(m1 & below); s_hkey[q] = my1; s_a[q] = cnt1; }
+        n_dist += (uint32_t)__popcll(m1);
+    }
+    __syncthreads();
+    // ---- output order: class (the writer's aux of the first score character), count descending, first appearance
+    for (uint32_t q = lane; q < n_dist + 8u; q += 64) {
+        uint64_t ord = ~0ull;   // (sentinels: never below a real order value)
+        if (q < n_dist) {
+            const uint32_t s0 = (uint32_t)(s_hkey[q] & 0xffu), cnt = s_a[q];
+            const uint64_t aux = s0 == 'N' ? 2u : s0 == 'E' ? 1u : 0u;
+            ord = (aux << 56) | ((uint64_t)(0xffffffu - (cnt < 0xffffffu ? cnt : 0xffffffu)) << 32) | (uint64_t)q;
         }
-        {
-            const bool to_alt = pa > pr;
-            const uint32_t c0 = to_alt ? kl_alt : kl_ref;
-            const uint8_t c = (uint8_t)(maxq ? c0 : d_lower(c0));
-            uint8_t* letters = to_alt ? h.alt_letter : h.ref_letter;
-            uint32_t* lc = to_alt ? h.alt_cnt : h.ref_cnt;
-            uint8_t& n = to_alt ? h.alt_n : h.ref_n;
-            uint32_t q = 0;
-            while (q < n && letters[q] != c) ++q;
-            if (q == n) { if (n < kSumLetters) { letters[n] = c; lc[n] = 1; n += 1; } else overflow = 1; }
-            else lc[q] += 1;
+        s_key[q] = ord;
+    }
+    __syncthreads();
+    const uint32_t dist8 = (n_dist + 7u) & ~7u;
+    uint32_t my_len = 0;
+    for (uint32_t c0 = 0; c0 < n_dist; c0 += 128) {
+        const uint32_t q0 = c0 + lane, q1 = c0 + 64 + lane;
+        const uint64_t my0 = q0 < n_dist ? s_key[q0] : 0ull, my1 = q1 < n_dist ? s_key[q1] : 0ull;
+        uint32_t rank0 = 0, rank1 = 0;
+        for (uint32_t j = 0; j < dist8; j += 8) {
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                const uint64_t oj = s_key[j + u];
+                rank0 += oj < my0 ? 1u : 0u;
+                rank1 += oj < my1 ? 1u : 0u;
+            }
+        }
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t q = h ? q1 : q0, rank = h ? rank1 : rank0;
+            if (q < n_dist) {
+                const uint64_t key = s_hkey[q];
+                item_key[b + rank] = key;
+                item_cnt[b + rank] = s_a[q];
+                my_len += d_item_len(key, s_a[q]);
+            }
         }
     }
-    if (r_have) { run_pm[run_off + r_at] = r_pm; run_len[run_off + r_at] = r_len; r_at += 1; }
-    const uint32_t ent_off = (nk && !overflow) ? atomicAdd(&cursor[0], nk) : 0u;
-    if (!overflow)
-        for (uint32_t k = 0; k < nk; ++k) { ent_key[ent_off + k] = keys[k]; ent_cnt[ent_off + k] = cnts[k]; }
-    h.ent_off = ent_off; h.n_ent = overflow ? 0u : nk; h.run_off = run_off; h.n_run = r_at; h.kept = kept; h.overflow = overflow;
-    hdr[p] = h;
+    for (int d = 32; d >= 1; d >>= 1) my_len += (uint32_t)__shfl_xor((int)my_len, d);
+    const uint32_t total = my_len;
+    // ---- header: SAOBS / SROBS letters in first-appearance order (the host sorts and formats the at most twelve items)
+    if (lane < 24) {
+        const uint32_t side = lane < 12 ? 0u : 12u;
+        const uint32_t myf = s_lf[lane];
+        uint32_t pos = 0;
+        for (uint32_t j = 0; j < 12; ++j) pos += (s_lc[side + j] > 0u && s_lf[side + j] < myf) ? 1u : 0u;
+        if (s_lc[lane]) s_perm[side + pos] = lane - side;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        PileSum h;
+        memset(&h, 0, sizeof h);
+        for (uint32_t j = 0; j < 12; ++j) { h.alt_n += s_lc[j] ? 1 : 0; h.ref_n += s_lc[12 + j] ? 1 : 0; }
+        for (uint32_t t = 0; t < h.alt_n; ++t) { const uint32_t j = s_perm[t]; h.alt_letter[t] = (uint8_t)d_letter_char(j); h.alt_cnt[t] = s_lc[j]; }
+        for (uint32_t t = 0; t < h.ref_n; ++t) { const uint32_t j = s_perm[12 + t]; h.ref_letter[t] = (uint8_t)d_letter_char(j); h.ref_cnt[t] = s_lc[12 + j]; }
+        h.n_item = n_dist;   // (obs_off / obs_len / overflow: obs_write_kernel, once the text has its place)
+        h.run_off = run_off; h.n_run = R; h.run0_pm = __uint_as_float(run0_pm); h.run0_len = run0_len; h.kept = kept;
+        hdr[p] = h;
+        text_len[p] = total;
+    }
+}
+
+// text lengths -> offsets: lane = pileup / list, one bump of the cursor per wave.  len 0xffffffff: not formatted (left alone); a text
+// that finds no room becomes 0xffffffff.  cursor[2] counts those.  Texts start on 16-byte steps.
+__global__ __launch_bounds__(64) void span_alloc_kernel(uint32_t* __restrict__ len, uint32_t* __restrict__ off, int stride, int64_t n, uint32_t cap, uint32_t* __restrict__ cursor) {
+    const int64_t p = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t l = p < n ? len[p * stride] : 0u;
+    const bool skip = l == 0xffffffffu;
+    const uint32_t need = (skip || l == 0u) ? 0u : (l + 15u) & ~15u;
+    uint32_t inc = need;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)inc, d);
+        if ((int)lane >= d) inc += t;
+    }
+    const uint32_t sum = (uint32_t)__shfl((int)inc, 63);
+    uint32_t base = 0;
+    if (sum) {
+        if (lane == 0) base = atomicAdd(&cursor[0], sum);
+        base = (uint32_t)__shfl((int)base, 0);
+    }
+    const uint32_t at = base + inc - need;
+    const bool full = !skip && need && (uint64_t)at + l > (uint64_t)cap;
+    const uint64_t lost = __ballot(skip || full);
+    if (lane == 0 && lost) atomicAdd(&cursor[2], (uint32_t)__popcll(lost));
+    if (p < n) { off[p * stride] = (skip || full) ? 0u : at; if (full) len[p * stride] = 0xffffffffu; }
+}
+
+__global__ __launch_bounds__(64) void obs_write_kernel(const uint32_t* __restrict__ obs_offset, PileSum* __restrict__ hdr, const uint64_t* __restrict__ item_key,
+                                                       const uint32_t* __restrict__ item_cnt, const uint32_t* __restrict__ text_len, const uint32_t* __restrict__ text_off,
+                                                       uint8_t* __restrict__ text) {
+    const int64_t p = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t len = text_len[p], off = text_off[p];
+    if (len == 0xffffffffu) {   // more observations than the kernel ranks, or no room for the text: the columns
+        if (lane == 0) { hdr[p].obs_off = 0u; hdr[p].obs_len = 0u; hdr[p].overflow = 1u; }
+        return;
+    }
+    const uint32_t b = obs_offset[p], n_item = hdr[p].n_item;
+    uint32_t done = 0;
+    for (uint32_t c0 = 0; c0 < n_item; c0 += 64) {
+        const uint32_t r = c0 + lane;
+        const bool valid = r < n_item;
+        const uint64_t key = valid ? item_key[b + r] : 0ull;
+        const uint32_t cnt = valid ? item_cnt[b + r] : 0u;
+        const uint32_t v = valid ? d_item_len(key, cnt) : 0u;
+        uint32_t inc = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)inc, d);
+            if ((int)lane >= d) inc += t;
+        }
+        if (valid) {
+            uint8_t* o = text + off + done + inc - v;
+            o = d_put_dec(o, cnt);
+            *o++ = (uint8_t)(key & 0xffu);
+            if ((key >> 8) & 0xffu) *o++ = (uint8_t)((key >> 8) & 0xffu);
+            const uint32_t th = (uint32_t)(key >> 32);
+            if (th) o = d_put_dec(o, th - 1u);
+            else *o++ = '.';
+            const uint32_t al = (uint32_t)(key >> 17) & 3u, st = (uint32_t)(key >> 19) & 3u, orr = (uint32_t)(key >> 21) & 3u;
+            *o++ = ((key >> 16) & 1u) ? 'p' : 's';
+            *o++ = al == 0 ? '#' : al == 1 ? '*' : '.';
+            *o++ = st == 0 ? '+' : st == 1 ? '-' : st == 2 ? '*' : '.';
+            *o++ = orr == 0 ? '>' : orr == 1 ? '<' : orr == 2 ? '*' : '!';
+            *o++ = ((key >> 23) & 1u) ? '^' : '*';
+            *o++ = ((key >> 24) & 1u) ? '$' : '.';
+            *o++ = ((key >> 25) & 1u) ? '*' : '.';
+        }
+        done += (uint32_t)__shfl((int)inc, 63);
+    }
+    if (lane == 0) { hdr[p].obs_off = off; hdr[p].obs_len = len; hdr[p].overflow = 0u; }
+}
+
+
+// ---- FORMAT/AFD text (Call::write_final_record, calling/variants/mod.rs:473-559; sample_fields of vlr_ingest.cpp): one wave per list —
+// entries ranked by allele frequency (stable: rank = entries that are smaller, or equal and earlier), "%.3f=%.2f" of (vaf, PHRED) with
+// append_fixed's arithmetic (x = v * 10^digits with its exact error from an fma: correctly rounded like printf, ties to even),
+// lengths scanned in output order, bytes written.  inf / nan are printf's words; a finite value of 1e12 or more, a NaN allele frequency,
+// more than kAfdMax entries or a full text buffer leave the list to the host (length 0xffffffff).
+constexpr int kAfdMax = 1024;
+struct FixedNum { uint64_t n; uint32_t kind; bool neg; };   // kind 0: digits of n; 1: inf; 2: nan; 3: not formatted here
+__device__ __forceinline__ FixedNum d_fixed(double v, int digits) {
+    FixedNum f;
+    f.neg = (__double_as_longlong(v) < 0);
+    f.n = 0;
+    if (v != v) { f.kind = 2; return f; }
+    const double a = fabs(v);
+    if (isinf(a)) { f.kind = 1; return f; }
+    if (!(a < 1e12)) { f.kind = 3; return f; }
+    const double sc = digits == 3 ? 1000.0 : digits == 2 ? 100.0 : digits == 1 ? 10.0 : 1.0;
+    const double x = a * sc, err = fma(a, sc, -x);   // a * sc = x + err exactly
+    double k = floor(x);
+    const double frac = x - k;
+    bool up;
+    if (frac > 0.5) up = true;
+    else if (frac < 0.5) up = false;
+    else up = err > 0.0 || (err == 0.0 && (((uint64_t)k) & 1ull));
+    if (up) k += 1.0;
+    f.n = (uint64_t)k;
+    f.kind = 0;
+    return f;
+}
+// (64-bit divisions are long instruction sequences on this target: the number of decimals is a template parameter — every division is
+//  by a constant — and values below 2^32, all that occur in practice, take 32-bit arithmetic)
+__device__ __forceinline__ uint32_t d_digits64(uint64_t v) {
+    if ((v >> 32) == 0) return d_digits((uint32_t)v);
+    uint32_t n = 10;   // (v >= 2^32 > 10^9)
+    v /= 1000000000ull;
+    while (v >= 10ull) { v /= 10ull; ++n; }
+    return n;
+}
+template <int DIGITS>
+__device__ __forceinline__ uint32_t d_fixed_len(const FixedNum& f) {
+    if (f.kind == 1 || f.kind == 2) return 3u + (f.neg ? 1u : 0u);
+    constexpr uint32_t P = DIGITS == 3 ? 1000u : DIGITS == 2 ? 100u : DIGITS == 1 ? 10u : 1u;
+    const uint32_t ipd = (f.n >> 32) == 0 ? d_digits((uint32_t)f.n / P) : d_digits64(f.n / (uint64_t)P);
+    return (f.neg ? 1u : 0u) + ipd + (DIGITS ? 1u + (uint32_t)DIGITS : 0u);
+}
+template <int DIGITS>
+__device__ __forceinline__ uint8_t* d_put_fixed(uint8_t* o, const FixedNum& f) {
+    if (f.neg) *o++ = '-';
+    if (f.kind == 1) { o[0] = 'i'; o[1] = 'n'; o[2] = 'f'; return o + 3; }
+    if (f.kind == 2) { o[0] = 'n'; o[1] = 'a'; o[2] = 'n'; return o + 3; }
+    constexpr uint32_t P = DIGITS == 3 ? 1000u : DIGITS == 2 ? 100u : DIGITS == 1 ? 10u : 1u;
+    uint32_t fr;
+    if ((f.n >> 32) == 0) {
+        const uint32_t n32 = (uint32_t)f.n;
+        fr = n32 % P;
+        o = d_put_dec(o, n32 / P);
+    } else {
+        uint64_t ip = f.n / (uint64_t)P;
+        fr = (uint32_t)(f.n % (uint64_t)P);
+        const uint32_t nd = d_digits64(ip);
+        for (uint32_t i = nd; i-- > 0;) { o[i] = (uint8_t)('0' + (uint32_t)(ip % 10ull)); ip /= 10ull; }
+        o += nd;
+    }
+    if (DIGITS) {
+        *o++ = '.';
+        for (int i = DIGITS; i-- > 0;) { o[i] = (uint8_t)('0' + fr % 10u); fr /= 10u; }
+        o += DIGITS;
+    }
+    return o;
+}
+
+// afd_rank_kernel: output position of every entry (rank16[p * capacity + i]) and the byte length of the list's text (span[2 p + 1];
+// 0xffffffff: left to the host); span_alloc_kernel places the texts; afd_write_kernel writes them.
+__global__ __launch_bounds__(64) void afd_rank_kernel(const int32_t* __restrict__ count, const double* __restrict__ vaf, const double* __restrict__ lnprob, int capacity,
+                                                      double ln10, uint16_t* __restrict__ rank16, uint32_t* __restrict__ span) {
+    // dynamic LDS for min(capacity, kAfdMax) entries (rounded up to an even number by the launcher)
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_afd[];
+    double* s_v = (double*)s_afd;
+    const int64_t p = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    int nn = count[p];
+    nn = nn < capacity ? nn : capacity;
+    const uint32_t n = nn > 0 ? (uint32_t)nn : 0u;
+    const double* v = vaf + (size_t)p * (size_t)capacity;
+    const double* lp = lnprob + (size_t)p * (size_t)capacity;
+    bool host = n > (uint32_t)kAfdMax;
+    uint32_t my_len = 0;
+    if (!host) {
+        for (uint32_t i = lane; i < n; i += 64) s_v[i] = v[i];
+        __syncthreads();
+        for (uint32_t i = lane; i < n; i += 64) {
+            const double my = s_v[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; ++j) { const double o = s_v[j]; rank += (o < my || (o == my && j < i)) ? 1u : 0u; }
+            const double ph = -10.0 * lp[i] / ln10 + 0.0;
+            const FixedNum a = d_fixed(my, 3), b = d_fixed(ph, 2);
+            if (my != my || a.kind == 3 || b.kind == 3) host = true;
+            rank16[(size_t)p * (size_t)capacity + i] = (uint16_t)rank;
+            my_len += (rank ? 1u : 0u) + d_fixed_len<3>(a) + 1u + d_fixed_len<2>(b);
+        }
+        host = __any(host) != 0;
+    }
+    for (int d = 32; d >= 1; d >>= 1) my_len += (uint32_t)__shfl_xor((int)my_len, d);
+    if (lane == 0) { span[2 * p] = 0u; span[2 * p + 1] = host ? 0xffffffffu : my_len; }
+}
+
+__global__ __launch_bounds__(64) void afd_write_kernel(const int32_t* __restrict__ count, const double* __restrict__ vaf, const double* __restrict__ lnprob, int capacity,
+                                                       double ln10, const uint16_t* __restrict__ rank16, const uint32_t* __restrict__ span, uint8_t* __restrict__ text) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_afd[];
+    uint32_t* s_len = (uint32_t*)s_afd;    // lengths in output order -> offsets
+    const int64_t p = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t off = span[2 * p], len = span[2 * p + 1];
+    if (len == 0xffffffffu || len == 0u) return;
+    int nn = count[p];
+    nn = nn < capacity ? nn : capacity;
+    const uint32_t n = (uint32_t)nn;
+    const double* v = vaf + (size_t)p * (size_t)capacity;
+    const double* lp = lnprob + (size_t)p * (size_t)capacity;
+    const uint16_t* rk = rank16 + (size_t)p * (size_t)capacity;
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint32_t rank = rk[i];
+        s_len[rank] = (rank ? 1u : 0u) + d_fixed_len<3>(d_fixed(v[i], 3)) + 1u + d_fixed_len<2>(d_fixed(-10.0 * lp[i] / ln10 + 0.0, 2));
+    }
+    __syncthreads();
+    uint32_t total = 0;
+    for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+        const uint32_t r = c0 + lane;
+        const uint32_t x = r < n ? s_len[r] : 0u;
+        uint32_t inc = x;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)inc, d);
+            if ((int)lane >= d) inc += t;
+        }
+        if (r < n) s_len[r] = total + inc - x;
+        total += (uint32_t)__shfl((int)inc, 63);
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint32_t rank = rk[i];
+        uint8_t* o = text + off + s_len[rank];
+        if (rank) *o++ = ',';
+        o = d_put_fixed<3>(o, d_fixed(v[i], 3));
+        *o++ = '=';
+        o = d_put_fixed<2>(o, d_fixed(-10.0 * lp[i] / ln10 + 0.0, 2));
+    }
 }
 
 }  // namespace
@@ -1005,13 +1367,35 @@ int vlr_dev_file_copy(vlr_dev_file* f, void* dst, const void* src, size_t bytes,
 }
 
 int vlr_dev_file_summaries(vlr_dev_file* f, const vlr::DeviceCols* cols, const uint32_t* d_obs_offset, const uint8_t* d_locus_flags, int64_t n_loci, int n_samples,
-                           const vlr::SumConsts* k, vlr::PileSum* d_hdr, uint64_t* d_ent_key, uint32_t* d_ent_cnt, float* d_run_pm, uint32_t* d_run_len, uint32_t* d_cursor) {
+                           uint32_t max_pileup_obs, const vlr::SumConsts* k, vlr::PileSum* d_hdr, uint8_t* d_text, uint32_t text_cap, float* d_run_pm,
+                           uint32_t* d_run_len, uint64_t* d_item_key, uint32_t* d_item_cnt, uint32_t* d_text_len, uint32_t* d_text_off, uint32_t* d_cursor) {
     const int64_t P = n_loci * n_samples;
     if (P <= 0) return VLR_OK;
+    if (P > 0x7fffffff) return VLR_ERR_INVALID_ARGUMENT;
     VLR_HIP_OK(hipSetDevice(f->device));
-    VLR_HIP_OK(hipMemsetAsync(d_cursor, 0, 8, f->stream));
-    hipLaunchKernelGGL(vlr::obs_summary_kernel, dim3((unsigned)((P + 63) / 64)), dim3(64), 0, f->stream, *cols, d_obs_offset, d_locus_flags, P, n_samples, *k,
-                       d_hdr, d_ent_key, d_ent_cnt, d_run_pm, d_run_len, d_cursor);
+    VLR_HIP_OK(hipMemsetAsync(d_cursor, 0, 16, f->stream));
+    // LDS per wave: 24 bytes per observation of the largest pileup (larger ones than kSumMaxObs are left to the columns) + the letter tables
+    const uint32_t lds_obs = (std::min<uint32_t>(std::max<uint32_t>(max_pileup_obs, 1u), (uint32_t)vlr::kSumMaxObs) + 8u + 7u) & ~7u;
+    const size_t lds = (size_t)lds_obs * 24 + 72 * 4;
+    hipLaunchKernelGGL(vlr::obs_text_kernel, dim3((unsigned)P), dim3(64), lds, f->stream, *cols, d_obs_offset, d_locus_flags, n_samples, *k,
+                       d_hdr, d_item_key, d_item_cnt, d_text_len, d_run_pm, d_run_len, d_cursor, lds_obs);
+    hipLaunchKernelGGL(vlr::span_alloc_kernel, dim3((unsigned)((P + 63) / 64)), dim3(64), 0, f->stream, d_text_len, d_text_off, 1, P, text_cap, d_cursor);
+    hipLaunchKernelGGL(vlr::obs_write_kernel, dim3((unsigned)P), dim3(64), 0, f->stream, d_obs_offset, d_hdr, d_item_key, d_item_cnt, d_text_len, d_text_off, d_text);
+    VLR_HIP_OK(hipGetLastError());
+    return VLR_OK;
+}
+
+int vlr_launch_afd_text(const int32_t* d_count, const double* d_vaf, const double* d_lnprob, int64_t n_lists, int capacity, uint8_t* d_text, uint32_t text_cap,
+                        uint32_t* d_span, uint16_t* d_rank, uint32_t* d_cursor, void* stream) {
+    if (n_lists <= 0) return VLR_OK;
+    if (n_lists > 0x7fffffff || capacity < 1) return VLR_ERR_INVALID_ARGUMENT;
+    hipStream_t st = (hipStream_t)stream;
+    VLR_HIP_OK(hipMemsetAsync(d_cursor, 0, 16, st));
+    const uint32_t lds_n = ((uint32_t)std::min(capacity, vlr::kAfdMax) + 1u) & ~1u;
+    const double ln10 = std::log(10.0);
+    hipLaunchKernelGGL(vlr::afd_rank_kernel, dim3((unsigned)n_lists), dim3(64), (size_t)lds_n * 8, st, d_count, d_vaf, d_lnprob, capacity, ln10, d_rank, d_span);
+    hipLaunchKernelGGL(vlr::span_alloc_kernel, dim3((unsigned)((n_lists + 63) / 64)), dim3(64), 0, st, d_span + 1, d_span, 2, n_lists, text_cap, d_cursor);
+    hipLaunchKernelGGL(vlr::afd_write_kernel, dim3((unsigned)n_lists), dim3(64), (size_t)lds_n * 4, st, d_count, d_vaf, d_lnprob, capacity, ln10, d_rank, d_span, d_text);
     VLR_HIP_OK(hipGetLastError());
     return VLR_OK;
 }

@@ -44,15 +44,20 @@ enum RecStatus : uint32_t {
 struct DeviceCols { float* col[9]; uint32_t* flags; int32_t* third; };
 
 // Per-pileup summary of the observations for the calls writer (Call::write_final_record, calling/variants/mod.rs:233-360): what
-// sample_fields of vlr_ingest.cpp counts per observation — distinct packed observation keys with their counts in first-appearance
-// order (OBS), the Kass-Raftery letters of the alt- and ref-supporting observations (SAOBS, SROBS), the kept observations and the
-// run-lengths of prob_mapping over them (DP is a sum of exp(prob_mapping) in observation order) — so that the host formats text per
-// record without touching the columns.
-constexpr int kSumLetters = 12;   // N B P S V E in two cases
-constexpr int kSumMaxKeys = 64;   // distinct observation keys of one pileup the kernel keeps (more: `overflow`, the host counts from the columns)
+// sample_fields of vlr_ingest.cpp derives per observation — the OBS text itself (generalized_cigar over the packed observation keys,
+// utils/mod.rs:122-156: distinct keys counted, ordered by class, count and first appearance, written as text by obs_text_kernel), the
+// Kass-Raftery letters of the alt- and ref-supporting observations (SAOBS, SROBS: at most twelve distinct items, formatted on the
+// host), the kept observations and the run-lengths of prob_mapping over them (DP is a sum of exp(prob_mapping) in observation order:
+// the host repeats the additions with its own exp) — so that the host writes records without touching the columns.
+constexpr int kSumLetters = 12;    // N B P S V E in two cases
+constexpr int kSumMaxObs = 1024;   // kept observations of one pileup the kernel ranks in LDS (more: `overflow`, the host counts from the columns)
+constexpr int kSumItemMax = 40;    // bytes of one OBS item at most (count, two score letters, third-allele evidence, seven flag characters)
 struct PileSum {
-    uint32_t ent_off, n_ent;      // entries [ent_off, ent_off + n_ent) of the key / count arrays
-    uint32_t run_off, n_run;      // runs of equal prob_mapping over the kept observations
+    uint32_t obs_off, obs_len;    // OBS text [obs_off, obs_off + obs_len) of the text buffer (empty pileup: length 0, the writer's ".")
+    uint32_t n_item;              // distinct observation keys (items of the text)
+    uint32_t run_off, n_run;      // runs of equal prob_mapping over the kept observations: the first one below, runs 1 .. n_run - 1 at
+    float run0_pm;                //   [run_off, run_off + n_run - 1) of the run arrays
+    uint32_t run0_len;
     uint32_t kept, overflow;
     uint8_t alt_n, ref_n, pad[2];
     uint8_t alt_letter[kSumLetters], ref_letter[kSumLetters];
@@ -112,10 +117,19 @@ int vlr_dev_file_errors(vlr_dev_file* f, int64_t n, uint32_t* status_or, int64_t
 void* vlr_dev_file_stream(vlr_dev_file* f);
 // asynchronous copy on the file's stream (to_device != 0: host -> device)
 int vlr_dev_file_copy(vlr_dev_file* f, void* dst, const void* src, size_t bytes, int to_device);
-// observation summaries of n_pileups pileups (locus-major): hdr[n_pileups], entries and runs through bump cursors (cursor[0] entries,
-// cursor[1] runs; zeroed by the call).  Everything is enqueued on the file's stream; ent_* / run_* hold at least n_obs elements.
+// observation summaries of n_pileups pileups (locus-major): hdr[n_pileups], the OBS text (placed by a cursor: cursor[0] = text bytes, in
+// 16-byte steps) and the prob_mapping runs behind the first one of a pileup (cursor[1]); cursor[2] = pileups left to the columns;
+// cursor[0..4) zeroed by the call.  Everything is enqueued on the file's stream; d_text holds text_cap bytes (a pileup whose text does
+// not fit is marked `overflow`), run_* / item_* at least n_obs elements, text_len / text_off n_pileups.  max_pileup_obs: observations of
+// the largest pileup (sizes the kernel's LDS).
 int vlr_dev_file_summaries(vlr_dev_file* f, const vlr::DeviceCols* cols, const uint32_t* d_obs_offset, const uint8_t* d_locus_flags, int64_t n_loci, int n_samples,
-                           const vlr::SumConsts* k, vlr::PileSum* d_hdr, uint64_t* d_ent_key, uint32_t* d_ent_cnt, float* d_run_pm, uint32_t* d_run_len, uint32_t* d_cursor);
+                           uint32_t max_pileup_obs, const vlr::SumConsts* k, vlr::PileSum* d_hdr, uint8_t* d_text, uint32_t text_cap, float* d_run_pm,
+                           uint32_t* d_run_len, uint64_t* d_item_key, uint32_t* d_item_cnt, uint32_t* d_text_len, uint32_t* d_text_off, uint32_t* d_cursor);
+// FORMAT/AFD text of n_lists lists (vlr_results.afd_text, include/vlr.h): one wave per list; span[2 p] = offset, span[2 p + 1] = length
+// (0xffffffff: left to the arrays); rank: n_lists * capacity entries of scratch; cursor[0] text bytes (16-byte steps), cursor[2] lists not
+// formatted — cursor[0..4) zeroed by the call.
+int vlr_launch_afd_text(const int32_t* d_count, const double* d_vaf, const double* d_lnprob, int64_t n_lists, int capacity, uint8_t* d_text, uint32_t text_cap,
+                        uint32_t* d_span, uint16_t* d_rank, uint32_t* d_cursor, void* stream);
 // synchronous device -> host copy outside any stream (lazy fetch of a table's columns)
 int vlr_dev_copy_to_host(int device, void* dst, const void* src, size_t bytes);
 // device -> host copy nobody waits for until vlr_dev_event_wait(*event_out) (the caller owns the event)

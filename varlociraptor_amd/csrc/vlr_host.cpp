@@ -21,6 +21,7 @@
 
 #include "../../include/vlr.h"
 #include "vlr_plan.h"
+#include "vlr_gpuio.h"
 
 extern "C" int vlr_launch_afd_kernel(const vlr::DevPlanT<8>* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out, void* stream);
 extern "C" int vlr_launch_call_kernel_deep(const vlr::DevPlanT<8>* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out,
@@ -1187,6 +1188,12 @@ struct HostChunk {
     vlr_results dr{};
     bool want_afd = false;
     bool active = false;
+    // FORMAT/AFD text of the chunk (vlr_results.afd_text): device staging and the chunk's share of the caller's text buffer
+    uint8_t* text_dev = nullptr;
+    uint32_t* span_dev = nullptr;
+    uint32_t* cur_dev = nullptr;
+    uint16_t* rank_dev = nullptr;
+    uint64_t text_cap = 0, text_base = 0;
 };
 
 // (dev_off != nullptr: the columns of `in` are DEVICE arrays already — the batch of a device reader — and dev_off is the host copy of
@@ -1230,6 +1237,19 @@ static int host_chunk_start(vlr_plan* plan, const vlr_batch* in, vlr_results* ou
     size_t r_ac = off; off += al(want_afd ? (size_t)L * S * 4 : 0);
     size_t r_av = off; off += al((size_t)L * S * cap * 8);
     size_t r_al = off; off += al((size_t)L * S * cap * 8);
+    // FORMAT/AFD text (vlr_results.afd_text): the chunk formats into its share [cap l0 / n, cap l1 / n) of the caller's buffer
+    const bool want_text = want_afd && out->afd_text && out->afd_text_span && out->afd_text_capacity >= 16;
+    uint64_t text_base = 0, text_cap = 0;
+    if (want_text) {
+        const uint64_t tot = std::min<uint64_t>(out->afd_text_capacity, 0xffffff00ull);
+        text_base = (uint64_t)((double)tot * (double)l0 / (double)in->n_loci) & ~15ull;
+        const uint64_t text_end = l1 >= in->n_loci ? tot : ((uint64_t)((double)tot * (double)l1 / (double)in->n_loci) & ~15ull);
+        text_cap = text_end > text_base ? text_end - text_base : 0;
+    }
+    size_t r_tx = off; off += al(want_text ? (size_t)text_cap : 0);
+    size_t r_sp = off; off += al(want_text ? (size_t)L * S * 8 : 0);
+    size_t r_cu = off; off += al(want_text ? 64 : 0);
+    size_t r_rk = off; off += al(want_text ? (size_t)L * S * cap * 2 : 0);
     if (off > plan->stage_bytes[k]) {
         if (plan->stage[k]) (void)hipFree(plan->stage[k]);
         plan->stage[k] = nullptr;
@@ -1293,6 +1313,14 @@ static int host_chunk_start(vlr_plan* plan, const vlr_batch* in, vlr_results* ou
     plan->max_obs = saved_max_obs;
     plan->deep_hint = -1;
     if (rc != VLR_OK) return rc;
+    hc->text_dev = nullptr;
+    if (want_text) {   // behind the AFD passes on the chunk's stream: the lists are final in the staging arrays
+        hc->text_dev = (uint8_t*)(base + r_tx); hc->span_dev = (uint32_t*)(base + r_sp); hc->cur_dev = (uint32_t*)(base + r_cu);
+        hc->rank_dev = (uint16_t*)(base + r_rk);
+        hc->text_cap = text_cap; hc->text_base = text_base;
+        rc = vlr_launch_afd_text(dr.afd_count, dr.afd_vaf, dr.afd_lnprob, L * S, (int)cap, hc->text_dev, (uint32_t)text_cap, hc->span_dev, hc->rank_dev, hc->cur_dev, (void*)st);
+        if (rc != VLR_OK) return fail(rc, "AFD text kernel launch failed");
+    }
     hc->l0 = l0; hc->l1 = l1; hc->k = k; hc->dr = dr; hc->want_afd = want_afd; hc->active = true;
     return VLR_OK;
 }
@@ -1313,8 +1341,26 @@ static int host_chunk_finish(vlr_plan* plan, vlr_results* out, HostChunk* hc) {
     HIP_TRY(hipMemcpyAsync(out->status + l0, dr.status, (size_t)L * 4, hipMemcpyDeviceToHost, st));
     if (hc->want_afd) {
         HIP_TRY(hipMemcpyAsync(out->afd_count + l0 * S, dr.afd_count, (size_t)L * S * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(out->afd_vaf + l0 * S * cap, dr.afd_vaf, (size_t)L * S * cap * 8, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(out->afd_lnprob + l0 * S * cap, dr.afd_lnprob, (size_t)L * S * cap * 8, hipMemcpyDeviceToHost, st));
+        bool lists = true;
+        if (hc->text_dev) {
+            // the text instead of the lists: 12 bytes per ENTRY against 16 per SLOT of the capacity; the lists only follow when the
+            // kernel left one of them to the host
+            uint32_t cur[4] = {0, 0, 0, 0};
+            uint32_t* sp = out->afd_text_span + (size_t)l0 * S * 2;
+            HIP_TRY(hipMemcpyAsync(cur, hc->cur_dev, 16, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(sp, hc->span_dev, (size_t)L * S * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            const size_t used = (size_t)std::min<uint64_t>(cur[0], hc->text_cap);
+            if (used) HIP_TRY(hipMemcpyAsync(out->afd_text + hc->text_base, hc->text_dev, used, hipMemcpyDeviceToHost, st));
+            lists = cur[2] != 0;
+            if (hc->text_base)
+                for (size_t q = 0; q < (size_t)L * S; ++q)
+                    if (sp[2 * q + 1] != 0xffffffffu) sp[2 * q] += (uint32_t)hc->text_base;
+        }
+        if (lists) {
+            HIP_TRY(hipMemcpyAsync(out->afd_vaf + l0 * S * cap, dr.afd_vaf, (size_t)L * S * cap * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(out->afd_lnprob + l0 * S * cap, dr.afd_lnprob, (size_t)L * S * cap * 8, hipMemcpyDeviceToHost, st));
+        }
     }
     HIP_TRY(hipStreamSynchronize(st));
     hc->active = false;
@@ -1501,7 +1547,19 @@ int vlr_node_batch_run_host(vlr_gpu_node* node, const vlr_batch* in, vlr_results
         o.afd_count = out->afd_count ? out->afd_count + l0 * S : nullptr;
         o.afd_vaf = out->afd_vaf ? out->afd_vaf + (size_t)l0 * S * cap : nullptr;
         o.afd_lnprob = out->afd_lnprob ? out->afd_lnprob + (size_t)l0 * S * cap : nullptr;
+        uint64_t text_base = 0;
+        if (out->afd_text && out->afd_text_span) {   // the shard's share of the text buffer; its spans are moved to the caller's offsets below
+            const uint64_t tot = std::min<uint64_t>(out->afd_text_capacity, 0xffffff00ull);
+            text_base = (uint64_t)((double)tot * (double)l0 / (double)L) & ~15ull;
+            const uint64_t text_end = l1 >= L ? tot : ((uint64_t)((double)tot * (double)l1 / (double)L) & ~15ull);
+            o.afd_text = out->afd_text + text_base;
+            o.afd_text_capacity = text_end - text_base;
+            o.afd_text_span = out->afd_text_span + (size_t)l0 * S * 2;
+        }
         rcs[(size_t)r] = vlr_batch_run_host(node->plans[(size_t)r], &b, &o);
+        if (rcs[(size_t)r] == VLR_OK && o.afd_text && text_base)
+            for (size_t q = 0; q < (size_t)(l1 - l0) * S; ++q)
+                if (o.afd_text_span[2 * q + 1] != 0xffffffffu) o.afd_text_span[2 * q] += (uint32_t)text_base;
         if (rcs[(size_t)r] != VLR_OK) errs[(size_t)r] = g_err;  // (thread-local: carried back to the caller's thread below)
     };
     if (G == 1) work(0);
@@ -1513,6 +1571,30 @@ int vlr_node_batch_run_host(vlr_gpu_node* node, const vlr_batch* in, vlr_results
     for (int r = 0; r < G; ++r)
         if (rcs[(size_t)r] != VLR_OK) { g_err = "device " + std::to_string(node->devices[(size_t)r]) + ": " + errs[(size_t)r]; return rcs[(size_t)r]; }
     return VLR_OK;
+}
+
+// the device formatter of vlr_results.afd_text on host arrays (tests)
+int vlr_selftest_afd_text(int device, int64_t n_lists, int capacity, const int32_t* count, const double* vaf, const double* lnprob, uint8_t* text,
+                          uint64_t text_capacity, uint32_t* span, uint32_t* n_unformatted) {
+    if (n_lists < 0 || capacity < 1 || !count || !vaf || !lnprob || !text || !span) return fail(VLR_ERR_INVALID_ARGUMENT, "bad argument");
+    if (n_lists == 0) return VLR_OK;
+    HIP_TRY(hipSetDevice(device));
+    const size_t slots = (size_t)n_lists * (size_t)capacity, tcap = (size_t)std::min<uint64_t>(text_capacity, 0xffffff00ull);
+    void *d_c = nullptr, *d_v = nullptr, *d_l = nullptr, *d_t = nullptr, *d_s = nullptr, *d_u = nullptr, *d_r = nullptr;
+    auto done = [&](int rc) { for (void* q : {d_c, d_v, d_l, d_t, d_s, d_u, d_r}) if (q) (void)hipFree(q); return rc; };
+    if (hipMalloc(&d_c, (size_t)n_lists * 4) != hipSuccess || hipMalloc(&d_v, slots * 8) != hipSuccess || hipMalloc(&d_l, slots * 8) != hipSuccess ||
+        hipMalloc(&d_t, tcap + 16) != hipSuccess || hipMalloc(&d_s, (size_t)n_lists * 8) != hipSuccess || hipMalloc(&d_u, 64) != hipSuccess ||
+        hipMalloc(&d_r, slots * 2 + 16) != hipSuccess)
+        return done(fail(VLR_ERR_OUT_OF_MEMORY, "hipMalloc failed"));
+    uint32_t cur[4] = {0, 0, 0, 0};
+    bool ok = hipMemcpy(d_c, count, (size_t)n_lists * 4, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d_v, vaf, slots * 8, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d_l, lnprob, slots * 8, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && vlr_launch_afd_text((const int32_t*)d_c, (const double*)d_v, (const double*)d_l, n_lists, capacity, (uint8_t*)d_t, (uint32_t)tcap, (uint32_t*)d_s, (uint16_t*)d_r, (uint32_t*)d_u, nullptr) == VLR_OK;
+    ok = ok && hipDeviceSynchronize() == hipSuccess && hipMemcpy(cur, d_u, 16, hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(span, d_s, (size_t)n_lists * 8, hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(text, d_t, std::min<size_t>(cur[0], tcap), hipMemcpyDeviceToHost) == hipSuccess;
+    if (n_unformatted) *n_unformatted = cur[2];
+    return done(ok ? VLR_OK : fail(VLR_ERR_HIP, "AFD text selftest: %s", hipGetErrorString(hipGetLastError())));
 }
 
 void* vlr_host_alloc(size_t bytes) {

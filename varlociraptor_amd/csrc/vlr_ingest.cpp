@@ -1270,8 +1270,7 @@ struct vlr_obs_table {
     // They live in the host side of the column region until the columns are fetched over them.
     bool has_summary = false;
     const vlr::PileSum* sum_hdr = nullptr;
-    const uint64_t* sum_key = nullptr;
-    const uint32_t* sum_cnt = nullptr;
+    const uint8_t* sum_text = nullptr;
     const float* sum_run_pm = nullptr;
     const uint32_t* sum_run_len = nullptr;
     int wait_columns() {
@@ -2036,14 +2035,16 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
     }
     g_dev_t[5] += now_s() - t_dec0;
     const double t_d2h0 = now_s();
-    // the per-pileup summaries need P headers and at most one entry and one run per observation: they are brought down INTO the host
-    // side of the column region, so they must fit there (they do unless most pileups are empty)
+    // the per-pileup summaries — P headers, the OBS text, at most one run per observation — are brought down INTO the host side of the
+    // column region (44 bytes per observation), so they must fit there: the text buffer of the kernel is what the region leaves behind
+    // the headers and the runs (an OBS item is 12 to 23 bytes per DISTINCT observation key; a pileup whose text does not fit any more is
+    // marked and the table takes the columns after all)
     const int64_t P = L * S;
-    // (the same 64-byte roundings as the host layout below: headers, keys, counts, run values, run lengths — entries and runs are at most
-    //  one per observation)
     const auto up64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
-    const size_t sum_need = up64((size_t)P * sizeof(vlr::PileSum)) + up64((size_t)total * 8) + 3 * up64((size_t)total * 4);
-    const bool summaries = !r->host_columns && !r->summaries_off && sum_need <= dl.off_lflags - dl.off_col[0];
+    const size_t sum_fixed = up64((size_t)P * sizeof(vlr::PileSum)) + 2 * up64((size_t)total * 4) + 64;
+    const size_t col_region = dl.off_lflags - dl.off_col[0];
+    const size_t text_cap = col_region > sum_fixed ? std::min<size_t>((col_region - sum_fixed) & ~(size_t)63, (size_t)0xffffff00u) : 0;
+    const bool summaries = !r->host_columns && !r->summaries_off && text_cap >= (size_t)total * 8;
     if (!summaries) {   // columns down for the calls writer (one copy: the column arrays are contiguous in the slab)
         DevFileStream& f0 = *r->dfiles[0];
         const int rc = r->async_columns ? vlr_dev_file_copy_detached(f0.dev, h + dl.off_col[0], d + dl.off_col[0], dl.off_lflags - dl.off_col[0], &cols_event)
@@ -2098,8 +2099,11 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
         vlr_obs_table* t = *out;
         DevFileStream& f0 = *r->dfiles[0];
         auto up = [](size_t x) { return (x + 63) & ~(size_t)63; };
-        const size_t o_hdr = 0, o_key = up((size_t)P * sizeof(vlr::PileSum)), o_cnt = o_key + up((size_t)total * 8), o_rpm = o_cnt + up((size_t)total * 4),
-                     o_rln = o_rpm + up((size_t)total * 4), o_cur = o_rln + up((size_t)total * 4), need = o_cur + 64;
+        // device scratch: headers, run arrays, the distinct keys of every pileup in output order (one slot per observation), text
+        // lengths and offsets, cursors, text
+        const size_t o_hdr = 0, o_rpm = up((size_t)P * sizeof(vlr::PileSum)), o_rln = o_rpm + up((size_t)total * 4), o_ik = o_rln + up((size_t)total * 4),
+                     o_ic = o_ik + up((size_t)total * 8), o_tl = o_ic + up((size_t)total * 4), o_to = o_tl + up((size_t)P * 4), o_cur = o_to + up((size_t)P * 4),
+                     o_txt = o_cur + 64, need = o_txt + text_cap;
         if (r->sum_scratch.cap < need) {
             if (r->sum_scratch.d) vlr_dev_slab_free(r->device, r->sum_scratch.d, r->sum_scratch.h);
             r->sum_scratch = DevSlab();
@@ -2113,25 +2117,29 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
         for (int k = 0; k < 9; ++k) dc.col[k] = (float*)((uint8_t*)t->slab.d + dl.off_col[k]);
         dc.flags = (uint32_t*)((uint8_t*)t->slab.d + dl.off_flags);
         dc.third = (int32_t*)((uint8_t*)t->slab.d + dl.off_third);
-        rc = vlr_dev_file_summaries(f0.dev, &dc, (const uint32_t*)((uint8_t*)t->slab.d + dl.off_obs), (const uint8_t*)t->slab.d + dl.off_lflags, L, S, &kc,
-                                    (vlr::PileSum*)(sd + o_hdr), (uint64_t*)(sd + o_key), (uint32_t*)(sd + o_cnt), (float*)(sd + o_rpm), (uint32_t*)(sd + o_rln), (uint32_t*)(sd + o_cur));
-        uint32_t cur[2] = {0, 0};
-        if (rc == VLR_OK) rc = vlr_dev_file_copy(f0.dev, cur, sd + o_cur, 8, 0);
+        uint32_t max_pile = 0;
+        for (int64_t q = 0; q < P; ++q) max_pile = std::max(max_pile, obs_offset[(size_t)q + 1] - obs_offset[(size_t)q]);
+        rc = vlr_dev_file_summaries(f0.dev, &dc, (const uint32_t*)((uint8_t*)t->slab.d + dl.off_obs), (const uint8_t*)t->slab.d + dl.off_lflags, L, S, max_pile, &kc,
+                                    (vlr::PileSum*)(sd + o_hdr), sd + o_txt, (uint32_t)text_cap, (float*)(sd + o_rpm), (uint32_t*)(sd + o_rln), (uint64_t*)(sd + o_ik),
+                                    (uint32_t*)(sd + o_ic), (uint32_t*)(sd + o_tl), (uint32_t*)(sd + o_to), (uint32_t*)(sd + o_cur));
+        uint32_t cur[4] = {0, 0, 0, 0};
+        if (rc == VLR_OK) rc = vlr_dev_file_copy(f0.dev, cur, sd + o_cur, 16, 0);
         if (rc == VLR_OK) rc = vlr_dev_file_sync(f0.dev);
-        // host layout inside the column region: headers, keys, counts, run values, run lengths
+        // host layout inside the column region: headers, run values, run lengths, text (pileups that found no room left their bytes
+        // out: the cursor may stand beyond the buffer)
         uint8_t* hb = (uint8_t*)t->slab.h + dl.off_col[0];
-        const size_t h_key = up((size_t)P * sizeof(vlr::PileSum)), h_cnt = h_key + up((size_t)cur[0] * 8), h_rpm = h_cnt + up((size_t)cur[0] * 4), h_rln = h_rpm + up((size_t)cur[1] * 4);
+        const size_t text_used = std::min<size_t>((size_t)cur[0], text_cap);
+        const size_t h_rpm = up((size_t)P * sizeof(vlr::PileSum)), h_rln = h_rpm + up((size_t)cur[1] * 4), h_txt = h_rln + up((size_t)cur[1] * 4);
         if (rc == VLR_OK) rc = vlr_dev_file_copy(f0.dev, hb, sd + o_hdr, (size_t)P * sizeof(vlr::PileSum), 0);
-        if (rc == VLR_OK) rc = vlr_dev_file_copy(f0.dev, hb + h_key, sd + o_key, (size_t)cur[0] * 8, 0);
-        if (rc == VLR_OK) rc = vlr_dev_file_copy(f0.dev, hb + h_cnt, sd + o_cnt, (size_t)cur[0] * 4, 0);
         if (rc == VLR_OK) rc = vlr_dev_file_copy(f0.dev, hb + h_rpm, sd + o_rpm, (size_t)cur[1] * 4, 0);
         if (rc == VLR_OK) rc = vlr_dev_file_copy(f0.dev, hb + h_rln, sd + o_rln, (size_t)cur[1] * 4, 0);
+        if (rc == VLR_OK) rc = vlr_dev_file_copy(f0.dev, hb + h_txt, sd + o_txt, text_used, 0);
         if (rc == VLR_OK) rc = vlr_dev_file_sync(f0.dev);
         if (rc != VLR_OK) { vlr_obs_table_free(t); *out = nullptr; return rc; }
         t->cols_on_host = false;
         t->has_summary = true;
-        {   // pileups the kernel could not summarise (more than kSumMaxKeys distinct observation keys: diverse synthetic pileups, very
-            // deep real ones) need the columns after all: fetch them now and stop summarising this file
+        {   // pileups the kernel could not summarise (more than kSumMaxObs observations, or no room left for their text) need the columns
+            // after all: when they are more than a few, fetch them now and stop summarising this file
             int64_t n_over = 0;
             const vlr::PileSum* hh = (const vlr::PileSum*)hb;
             for (int64_t q = 0; q < P; ++q) n_over += hh[q].overflow != 0;
@@ -2141,7 +2149,7 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
                 if (rc != VLR_OK) { vlr_obs_table_free(t); *out = nullptr; return rc; }
             }
         }
-        t->sum_hdr = (const vlr::PileSum*)hb; t->sum_key = (const uint64_t*)(hb + h_key); t->sum_cnt = (const uint32_t*)(hb + h_cnt);
+        t->sum_hdr = (const vlr::PileSum*)hb; t->sum_text = hb + h_txt;
         t->sum_run_pm = (const float*)(hb + h_rpm); t->sum_run_len = (const uint32_t*)(hb + h_rln);
     }
     g_dev_t[6] += now_s() - t_d2h0;
@@ -2387,6 +2395,14 @@ int vlr_node_obs_readers_open(vlr_gpu_node* node, int n_samples, const char* con
     return VLR_OK;
 }
 
+int vlr_obs_table_summaries(const vlr_obs_table* t, int64_t* n_overflow) {
+    if (n_overflow) *n_overflow = 0;
+    if (!t || !t->has_summary) return 0;
+    if (n_overflow)
+        for (int64_t p = 0; p < t->n_loci * t->n_samples; ++p) *n_overflow += t->sum_hdr[p].overflow != 0;
+    return 1;
+}
+
 int vlr_obs_table_fetch_columns(vlr_obs_table* t) {
     if (!t) return ifail(VLR_ERR_INVALID_ARGUMENT, "null table");
     { const int rcw = t->wait_columns(); if (rcw != VLR_OK) return rcw; }
@@ -2586,15 +2602,16 @@ void sample_fields(const vlr_obs_table* t, const vlr_results* r, int64_t l, int 
     static const double kLn3 = std::log(3.0), kLn20 = std::log(20.0), kLn150 = std::log(150.0);
     const bool from_summary = t->has_summary;
     if (from_summary) {
-        // the device counted per observation (vlr_decode.hip obs_summary_kernel: this loop, lane per pileup); what is left is per pileup
+        // the device counted per observation (vlr_decode.hip obs_text_kernel: this loop and the OBS text below, one wave per pileup); what is left is per pileup
         const vlr::PileSum& h = t->sum_hdr[l * S + s];
         kept = (int)h.kept;
-        for (uint32_t q = 0; q < h.n_ent; ++q) obs_cnt.emplace_back(t->sum_key[h.ent_off + q], (int)t->sum_cnt[h.ent_off + q]);
+        o.obs.assign((const char*)t->sum_text + h.obs_off, (size_t)h.obs_len);   // (counted, ordered and written by obs_text_kernel)
         for (uint32_t q = 0; q < h.alt_n; ++q) alt_cnt.emplace_back(std::string(1, (char)h.alt_letter[q]), (int)h.alt_cnt[q]);
         for (uint32_t q = 0; q < h.ref_n; ++q) ref_cnt.emplace_back(std::string(1, (char)h.ref_letter[q]), (int)h.ref_cnt[q]);
-        for (uint32_t q = 0; q < h.n_run; ++q) {   // the same sequence of additions as the loop below
-            const double w = std::exp((double)t->sum_run_pm[h.run_off + q]);
-            for (uint32_t j = 0; j < t->sum_run_len[h.run_off + q]; ++j) depth += w;
+        for (uint32_t q = 0; q < h.n_run; ++q) {   // the same sequence of additions as the loop below (run 0 sits in the header)
+            const double w = std::exp((double)(q ? t->sum_run_pm[h.run_off + q - 1] : h.run0_pm));
+            const uint32_t len = q ? t->sum_run_len[h.run_off + q - 1] : h.run0_len;
+            for (uint32_t j = 0; j < len; ++j) depth += w;
         }
     }
     { WPROF(0);
@@ -2657,13 +2674,13 @@ void sample_fields(const vlr_obs_table* t, const vlr_results* r, int64_t l, int 
     // auxiliary class — one sort of (class, -count, first appearance) — and the item text is written once, in output order
     static thread_local std::vector<uint64_t> ord;
     ord.clear();
-    for (size_t q = 0; q < obs_cnt.size(); ++q) {
+    for (size_t q = 0; q < obs_cnt.size() && !from_summary; ++q) {
         const char s0 = (char)(obs_cnt[q].first & 0xff);
         const uint64_t aux = s0 == 'N' ? 2 : s0 == 'E' ? 1 : 0;
         ord.push_back((aux << 56) | ((uint64_t)(0xffffffu - (uint32_t)std::min(obs_cnt[q].second, 0xffffff)) << 32) | (uint64_t)q);
     }
     std::sort(ord.begin(), ord.end());
-    o.obs.clear();
+    if (!from_summary) o.obs.clear();
     for (uint64_t v : ord) {
         const auto& kc = obs_cnt[(size_t)(v & 0xffffffffu)];
         const uint64_t key = kc.first;
@@ -2700,7 +2717,11 @@ void sample_fields(const vlr_obs_table* t, const vlr_results* r, int64_t l, int 
     o.af = (float)r->map_vaf[l * S + s];
     o.afd = ".";
     o.has_afd = false;
-    if (r->afd_count && !any_bias) {
+    const uint32_t* tspan = (r->afd_count && r->afd_text && r->afd_text_span) ? r->afd_text_span + 2 * (size_t)(l * S + s) : nullptr;
+    if (tspan && !any_bias && tspan[1] != 0xffffffffu) {   // formatted on the device (afd_text_kernel of vlr_decode.hip: the loop below)
+        o.afd.assign((const char*)r->afd_text + tspan[0], (size_t)tspan[1]);
+        o.has_afd = true;
+    } else if (r->afd_count && !any_bias) {
         WPROF(2);
         const int n = std::min(r->afd_count[l * S + s], r->afd_capacity);
         const double* v = r->afd_vaf + (size_t)(l * S + s) * r->afd_capacity;
@@ -2992,7 +3013,7 @@ static int calls_write_impl(FILE* out_file, bool bcf, bool with_header, bool wit
                 size_t n = 0;
                 for (int s = 0; s < S; ++s) n = std::max(n, get(s).size());
                 put_desc(indiv, (uint32_t)n, 7);
-                for (int s = 0; s < S; ++s) { const std::string v = get(s); indiv.insert(indiv.end(), v.begin(), v.end()); indiv.insert(indiv.end(), n - v.size(), (uint8_t)0); }
+                for (int s = 0; s < S; ++s) { const std::string& v = get(s); indiv.insert(indiv.end(), v.begin(), v.end()); indiv.insert(indiv.end(), n - v.size(), (uint8_t)0); }
             };
             const std::string dot(".");
             fmt_ints(0, [&](int s) { return missing ? 0 : sf[(size_t)s].dp; });
@@ -3003,13 +3024,14 @@ static int calls_write_impl(FILE* out_file, bool bcf, bool with_header, bool wit
                 if (!missing && sf[(size_t)s].af == sf[(size_t)s].af) memcpy(&bits, &sf[(size_t)s].af, 4);
                 put_u32(indiv, bits);
             }
-            fmt_strs(2, [&](int s) { return (missing || sf[(size_t)s].saobs.empty()) ? dot : sf[(size_t)s].saobs; });
-            fmt_strs(3, [&](int s) { return (missing || sf[(size_t)s].srobs.empty()) ? dot : sf[(size_t)s].srobs; });
-            fmt_strs(4, [&](int s) { return (missing || sf[(size_t)s].obs.empty()) ? dot : sf[(size_t)s].obs; });
-            if (missing) fmt_strs(5, [&](int) { return dot; });  // "." in an Integer field: callsfmt writes the missing value
+            // (the getters hand out references: an OBS or AFD string is a kilobyte, and every field asks twice)
+            fmt_strs(2, [&](int s) -> const std::string& { return (missing || sf[(size_t)s].saobs.empty()) ? dot : sf[(size_t)s].saobs; });
+            fmt_strs(3, [&](int s) -> const std::string& { return (missing || sf[(size_t)s].srobs.empty()) ? dot : sf[(size_t)s].srobs; });
+            fmt_strs(4, [&](int s) -> const std::string& { return (missing || sf[(size_t)s].obs.empty()) ? dot : sf[(size_t)s].obs; });
+            if (missing) fmt_strs(5, [&](int) -> const std::string& { return dot; });  // "." in an Integer field: callsfmt writes the missing value
             else fmt_ints(5, [&](int s) { return sf[(size_t)s].oobs; });
-            for (int k = 0; k < 6; ++k) fmt_strs(6 + k, [&](int s) { return missing ? dot : sf[(size_t)s].sym[k]; });
-            fmt_strs(12, [&](int s) { return missing ? dot : sf[(size_t)s].afd; });
+            for (int k = 0; k < 6; ++k) fmt_strs(6 + k, [&](int s) -> const std::string& { return missing ? dot : sf[(size_t)s].sym[k]; });
+            fmt_strs(12, [&](int s) -> const std::string& { return missing ? dot : sf[(size_t)s].afd; });
             const uint32_t l_shared = 24 + (uint32_t)shared.size(), l_indiv = (uint32_t)indiv.size();
             put_u32(out, l_shared); put_u32(out, l_indiv);
             put_u32(out, (uint32_t)contig_idx[(size_t)ci]);

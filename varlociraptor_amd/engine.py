@@ -26,9 +26,9 @@ EXPORTS = [
     "vlr_plan_n_samples", "vlr_plan_set_max_depth", "vlr_plan_set_max_obs", "vlr_plan_reserve", "vlr_batch_run", "vlr_batch_run_host", "vlr_batch_run_device_in",
     "vlr_plan_last_kernel_ms", "vlr_plan_work_counters", "vlr_host_alloc", "vlr_host_free",
     "vlr_node_create", "vlr_node_destroy", "vlr_node_n_devices", "vlr_node_device", "vlr_node_plan", "vlr_node_set_max_depth", "vlr_node_set_max_obs", "vlr_node_shard_range", "vlr_node_batch_run_host",
-    "vlr_realign_batch", "vlr_realign_batch_host", "vlr_realign_fast_batch", "vlr_realign_fast_batch_host", "vlr_realign_homopolymer_batch", "vlr_realign_homopolymer_batch_host", "vlr_edit_distance_batch", "vlr_edit_distance_batch_host", "vlr_fdr_threshold", "vlr_selftest_math", "vlr_selftest_stream", "vlr_selftest_format_fixed",
+    "vlr_realign_batch", "vlr_realign_batch_host", "vlr_realign_fast_batch", "vlr_realign_fast_batch_host", "vlr_realign_homopolymer_batch", "vlr_realign_homopolymer_batch_host", "vlr_edit_distance_batch", "vlr_edit_distance_batch_host", "vlr_fdr_threshold", "vlr_selftest_math", "vlr_selftest_stream", "vlr_selftest_format_fixed", "vlr_selftest_afd_text",
     "vlr_obs_read", "vlr_obs_table_free", "vlr_obs_table_batch", "vlr_obs_table_sites", "vlr_obs_write", "vlr_calls_write", "vlr_ingest_last_timings", "vlr_ingest_total_timings",
-    "vlr_obs_reader_open", "vlr_obs_reader_open_device", "vlr_obs_table_device_batch", "vlr_obs_reader_set_host_columns", "vlr_obs_reader_set_async_columns", "vlr_obs_table_fetch_columns", "vlr_bgzf_inflate", "vlr_ingest_device_timings", "vlr_ingest_device_trim", "vlr_obs_reader_open_device_shard", "vlr_obs_reader_shard_row_size", "vlr_obs_reader_shard_counts", "vlr_obs_reader_shard_assign", "vlr_node_obs_readers_open", "vlr_obs_reader_next", "vlr_obs_reader_close", "vlr_calls_writer_open", "vlr_calls_writer_append", "vlr_calls_writer_close", "vlr_calls_writer_set_part", "vlr_calls_concat_parts", "vlr_calls_filter_fdr",
+    "vlr_obs_reader_open", "vlr_obs_reader_open_device", "vlr_obs_table_device_batch", "vlr_obs_reader_set_host_columns", "vlr_obs_reader_set_async_columns", "vlr_obs_table_fetch_columns", "vlr_obs_table_summaries", "vlr_bgzf_inflate", "vlr_ingest_device_timings", "vlr_ingest_device_trim", "vlr_obs_reader_open_device_shard", "vlr_obs_reader_shard_row_size", "vlr_obs_reader_shard_counts", "vlr_obs_reader_shard_assign", "vlr_node_obs_readers_open", "vlr_obs_reader_next", "vlr_obs_reader_close", "vlr_calls_writer_open", "vlr_calls_writer_append", "vlr_calls_writer_close", "vlr_calls_writer_set_part", "vlr_calls_concat_parts", "vlr_calls_filter_fdr",
 ]
 
 

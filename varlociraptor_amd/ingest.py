@@ -123,6 +123,15 @@ class ObsTable:
         _check(L.vlr_obs_table_device_batch(self.handle, C.byref(b)))
         return b
 
+    def summaries(self):
+        """vlr_obs_table_summaries: (the calls writer formats this table from device summaries, pileups left to the columns)."""
+        L = engine.lib()
+        L.vlr_obs_table_summaries.restype = C.c_int
+        L.vlr_obs_table_summaries.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        n = C.c_int64(0)
+        on = L.vlr_obs_table_summaries(self.handle, C.byref(n))
+        return bool(on), int(n.value)
+
     def fetch_columns(self):
         """vlr_obs_table_fetch_columns: bring the observation columns of a device reader's table down to the host (no-op when they are)."""
         L = _lib()
