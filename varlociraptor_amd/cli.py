@@ -563,6 +563,7 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
             if tw:
                 q_out.put(None)
                 tw.join()
+            stage["drain_writer_s"] = time.perf_counter() - t_loop_end   # the writer's last chunk(s)
             stop.set()
             tr.join()
             if shard_state["on"] and os.environ.get("VLR_INGEST_SHARD_REPORT"):
@@ -571,8 +572,12 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                 with open("%s.%d" % (os.environ["VLR_INGEST_SHARD_REPORT"], rank), "w") as fh_:
                     json.dump({"rank": rank, "world": world, "first_record": reader.first_record, "n_records": reader.n_records,
                                "total_records": getattr(reader, "total_records", None), "device_reader": vingest.device_timings()}, fh_)
+            t_c0 = time.perf_counter()
             reader.close()
+            stage["drain_reader_close_s"] = time.perf_counter() - t_c0
+            t_c0 = time.perf_counter()
             close_plans()
+            stage["drain_plans_close_s"] = time.perf_counter() - t_c0
         if errors:
             raise errors[0]
         if processor is not None:

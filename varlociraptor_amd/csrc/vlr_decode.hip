@@ -379,72 +379,72 @@ __global__ __launch_bounds__(64) void rec_decode_kernel(const uint8_t* __restric
     const uint32_t n = d.n_obs;
     const size_t ob = (size_t)obs_offset[(size_t)r * (size_t)n_samples + (size_t)sample];
     uint32_t status = 0;
-    // ---- chains
+    // ---- chains, in lockstep (round 5).  Where element i + 1 starts depends on element i; round 4 let eleven lanes walk their vectors
+    // through one generic step with a branch per element kind and typed-integer width — the lanes diverge, the wave ran every path of
+    // every step (~1 000 static instructions, 40 % of them scalar control) and the kernel was bound by scalar issue: without the chains
+    // it takes 0.1 ms instead of 1.5 ms per 32 768 records, without their stores or with the vectors copied to LDS first just as long.
+    // Now the step is the same straight-line code for every lane: three unaligned loads at an address scaled by the lane's integer
+    // width, the three widths and the four element kinds told apart by selects.  (The same step on an LDS copy of the vectors was 1.8 x
+    // faster alone, but 12 kB of LDS per wave keep the kernel off the CUs the call kernel fills: end to end 0.64 M against 0.88 M.)
     // lane -> (field, kind): kind 0 MiniLogProb, 1 Option<MiniLogProb>, 2 Option<u8>, 3 Option<u32>
     if (lane < 11) {
         const int field = lane == 0 ? FD_PROB_MAPPING : lane == 1 ? FD_PROB_ALT : lane == 2 ? FD_PROB_REF : lane == 3 ? FD_PROB_MISSED : lane == 4 ? FD_PROB_SAMPLE_ALT
                         : lane == 5 ? FD_PROB_DOUBLE_OVERLAP : lane == 6 ? FD_PROB_HIT_BASE : lane == 7 ? FD_HP_ART : lane == 8 ? FD_HP_VAR : lane == 9 ? FD_HP_LEN : FD_THIRD;
-        const int kind = lane < 7 ? 0 : lane < 9 ? 1 : lane == 9 ? 2 : 3;
+        const uint32_t kind = lane < 7 ? 0u : lane < 9 ? 1u : lane == 9 ? 2u : 3u;
         const int stride = d.vstride[field];
+        const bool present = stride != 0;
         const uint8_t* v = rec + d.voff[field];
-        const uint32_t nbytes = stride ? 2u * d.vn[field] : 0u;
+        const uint32_t nbytes = present ? 2u * d.vn[field] : 0u;
         uint32_t* out = lane < 9 ? reinterpret_cast<uint32_t*>(cols.col[lane]) + ob : lane == 9 ? cols.flags + ob : reinterpret_cast<uint32_t*>(cols.third) + ob;
         const uint32_t none = kind <= 1 ? 0x7fc00000u : kind == 2 ? 0u : 0xffffffffu;
-        if (stride == 0) {   // absent optional field: None everywhere (the mandatory ones were checked by the scan)
-            for (uint32_t i = 0; i < n; ++i) out[i] = none;
-        } else if (vlen(v, stride, d.vn[field]) != (uint64_t)n) {
-            status |= REC_BAD_LENGTHS;
-        } else {
-            uint32_t j = 8;
-            for (uint32_t i = 0; i < n; ++i) {
-                // bytes j .. j + 8 of the little-endian word stream (zero beyond its end)
-                uint64_t lo;
-                uint32_t b8;
-                if (stride == 4) {          // u16 words in the low halves of five consecutive int32 elements: one 16-byte and one 4-byte load
-                    const uint8_t* q = v + 4 * (size_t)(j >> 1);
-                    const uint64_t a = ld64(q), c = ld64(q + 8);
-                    const uint32_t w4 = ld32(q + 16);
-                    const uint64_t W = (a & 0xffffull) | ((a >> 16) & 0xffff0000ull) | ((c & 0xffffull) << 32) | ((c >> 32 & 0xffffull) << 48);
-                    lo = (j & 1u) ? (W >> 8) | ((uint64_t)(w4 & 0xffu) << 56) : W;
-                    b8 = (j & 1u) ? (w4 >> 8) & 0xffu : w4 & 0xffu;
-                } else if (stride == 2) {   // the words are the bytes
-                    lo = ld64(v + j);
-                    b8 = v[j + 8];
-                } else {
-                    lo = 0;
-                    for (int t = 0; t < 8; ++t) lo |= (uint64_t)vbyte(v, stride, j + (uint32_t)t) << (8 * t);
-                    b8 = vbyte(v, stride, j + 8);
-                }
-                {
-                    const uint32_t left = nbytes - j;   // (j < nbytes here: the previous element ended inside the stream, or n would be 0)
-                    if (left < 8) lo &= (1ull << (8 * left)) - 1ull;
-                    if (left < 9) b8 = 0;
-                }
-                uint32_t b[9];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) b[t] = (uint32_t)(lo >> (8 * t)) & 0xffu;
-                b[8] = b8;
-                const uint32_t o = kind == 0 ? 0u : 1u;
-                const bool some = kind == 0 ? true : b[0] != 0;
-                uint32_t size, val = none;
-                if (kind <= 1) {
-                    const uint32_t tag = b[o] | (b[o + 1] << 8) | (b[o + 2] << 16) | (b[o + 3] << 24);
-                    size = o + (some ? 4u + (tag == 0 ? 2u : 4u) : 0u);
-                    if (some) {
-                        if (tag > 1) status |= REC_BAD_VECTOR;
-                        val = tag == 0 ? half_bits(b[o + 4] | (b[o + 5] << 8)) : (b[o + 4] | (b[o + 5] << 8) | (b[o + 6] << 16) | (b[o + 7] << 24));
-                    }
-                } else if (kind == 2) {
-                    size = 1u + (some ? 1u : 0u);
-                    if (some) val = VLR_F_HP_LEN_VALID | (b[1] << VLR_F_HP_LEN_SHIFT);
-                } else {
-                    size = 1u + (some ? 4u : 0u);
-                    if (some) val = b[1] | (b[2] << 8) | (b[3] << 16) | (b[4] << 24);
-                }
-                if (j + size > nbytes) { status |= REC_BAD_VECTOR; break; }
-                out[i] = val;
-                j += size;
+        // an absent optional field is None everywhere (the mandatory ones were checked by the scan); a vector whose length word differs
+        // from the record's observation count writes nothing: the record is an error
+        bool alive = present;
+        if (present && vlen(v, stride, d.vn[field]) != (uint64_t)n) { status |= REC_BAD_LENGTHS; alive = false; }
+        const bool writes = alive || !present;
+        uint32_t j = 8;
+        for (uint32_t i = 0; i < n; ++i) {
+            // bytes j .. j + 8 of the little-endian word stream: five words = five int32 / int16 / int8 elements of the file
+            const uint32_t jj = alive ? j : 0u;
+            const uint8_t* q = v + (stride == 4 ? 4 * (size_t)(jj >> 1) : stride == 2 ? (size_t)jj : (size_t)(jj >> 1));
+            const uint64_t A = ld64(q), C = ld64(q + 8);
+            const uint32_t W = ld32(q + 16);
+            const bool odd = (jj & 1u) != 0;
+            // int32: the words are the low halves
+            const uint64_t W4 = (A & 0xffffull) | ((A >> 16) & 0xffff0000ull) | ((C & 0xffffull) << 32) | (((C >> 32) & 0xffffull) << 48);
+            const uint64_t lo4 = odd ? (W4 >> 8) | ((uint64_t)(W & 0xffu) << 56) : W4;
+            const uint32_t b84 = odd ? (W >> 8) & 0xffu : W & 0xffu;
+            // int8: word k = byte k sign-extended
+            const uint64_t e0 = A & 0xffull, e1 = (A >> 8) & 0xffull, e2 = (A >> 16) & 0xffull, e3 = (A >> 24) & 0xffull, e4 = (A >> 32) & 0xffull;
+            const uint64_t W1 = (e0 | ((e0 & 0x80ull) ? 0xff00ull : 0ull)) | ((e1 | ((e1 & 0x80ull) ? 0xff00ull : 0ull)) << 16) | ((e2 | ((e2 & 0x80ull) ? 0xff00ull : 0ull)) << 32) |
+                                ((e3 | ((e3 & 0x80ull) ? 0xff00ull : 0ull)) << 48);
+            const uint32_t w41 = (uint32_t)(e4 | ((e4 & 0x80ull) ? 0xff00ull : 0ull));
+            const uint64_t lo1 = odd ? (W1 >> 8) | ((uint64_t)(w41 & 0xffu) << 56) : W1;
+            const uint32_t b81 = odd ? (w41 >> 8) & 0xffu : w41 & 0xffu;
+            uint64_t lo = stride == 4 ? lo4 : stride == 2 ? A : lo1;
+            uint32_t b8 = stride == 4 ? b84 : stride == 2 ? (uint32_t)C & 0xffu : b81;
+            {   // zero beyond the end of the stream (jj <= nbytes)
+                const uint32_t left = nbytes - jj;
+                lo = left < 8 ? lo & ((1ull << (8 * left)) - 1ull) : lo;
+                b8 = left < 9 ? 0u : b8;
             }
+            const bool some = kind == 0 || ((uint32_t)lo & 0xffu) != 0;
+            const uint64_t t = kind == 0 ? lo : (lo >> 8) | ((uint64_t)b8 << 56);   // the eight bytes behind the Option tag
+            const uint32_t tag = (uint32_t)t, pay = (uint32_t)(t >> 32);
+            // MiniLogProb: u32 tag, then f16 (tag 0, the host decoder's half_to_float: exact, NaN payloads kept) or f32 (tag 1)
+            const uint32_t h = pay & 0xffffu, hs = (h >> 15) << 31, he = (h >> 10) & 0x1fu, hm = h & 0x3ffu;
+            const int hk = __clz((int)(hm | 1u)) - 21;
+            const uint32_t sub = hm == 0 ? hs : hs | ((uint32_t)(127 - 15 - hk + 1) << 23) | (((hm << hk) & 0x3ffu) << 13);
+            const uint32_t half = he == 0 ? sub : he == 31 ? hs | 0x7f800000u | (hm << 13) : hs | ((he + 112u) << 23) | (hm << 13);
+            const uint32_t val_m = tag == 0 ? half : pay;
+            const uint32_t o = kind == 0 ? 0u : 1u;
+            const uint32_t size = kind <= 1 ? o + (some ? (tag == 0 ? 6u : 8u) : 0u) : kind == 2 ? 1u + (some ? 1u : 0u) : 1u + (some ? 4u : 0u);
+            const uint32_t val_s = kind <= 1 ? val_m : kind == 2 ? (VLR_F_HP_LEN_VALID | (((uint32_t)t & 0xffu) << VLR_F_HP_LEN_SHIFT)) : (uint32_t)t;
+            const uint32_t val = some ? val_s : none;
+            if (alive && kind <= 1 && some && tag > 1) status |= REC_BAD_VECTOR;
+            if (alive && j + size > nbytes) { status |= REC_BAD_VECTOR; alive = false; }
+            if (writes && (alive || !present)) out[i] = present ? val : none;
+            j = alive ? j + size : j;
         }
     }
     __syncthreads();   // the HOMOPOLYMER_INDEL_LEN bits of lane 9 are in cols.flags now
@@ -1016,16 +1016,27 @@ struct vlr_dev_file {
     hipStream_t stream = nullptr;
     hipStream_t feed_stream = nullptr;   // H2D of compressed members + inflate kernel: runs beside the decode of the previous chunk
     hipStream_t copy_stream = nullptr;   // column copies the caller does not wait for (vlr_dev_file_copy_detached)
-    bool feed_pending = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the inflate kernel of the feed in flight (measurement: vlr_dev_file_inflate_seconds)
+    // feeds in flight on the feed stream, oldest first (round 5: up to kFeedSlots, so that the inflate of request k + 2 is enqueued while
+    // request k + 1 is still inflating and the reader never waits for more than the oldest one)
+    static constexpr int kFeedSlots = 4;
+    struct Feed {
+        hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr;   // around the inflate kernel (vlr_dev_file_inflate_seconds); status copy complete
+        size_t wr_end = 0, n_blocks = 0;
+        // member list up, member status down: PAGE-LOCKED — a copy to or from pageable memory is synchronous, and the status copy behind
+        // the inflate kernel kept the enqueueing call waiting for the whole inflate (0.09 s of the reader's 0.14 s per 200 000 records)
+        int* h_status = nullptr;
+        vlr::InflateBlock* h_blocks = nullptr;
+        size_t h_cap = 0;
+    };
+    Feed feeds[kFeedSlots];
+    int feed_head = 0, feed_n = 0;   // ring: slots [feed_head, feed_head + feed_n) are pending
     double inflate_s = 0.0;
-    uint8_t* buf = nullptr;       // inflated stream: bytes [rd, wr) are buffered
-    size_t cap = 0, rd = 0, wr = 0;
+    uint8_t* buf = nullptr;       // inflated stream: bytes [rd, wr) are buffered, [rd, ready) inflated and checked
+    size_t cap = 0, rd = 0, wr = 0, ready = 0;
     uint8_t* spare = nullptr;     // the other half of the ping-pong (compaction never copies inside one allocation)
     size_t spare_cap = 0;
     uint8_t* d_comp = nullptr; size_t comp_cap = 0;
     vlr::InflateBlock* d_blocks = nullptr; int* d_status = nullptr; size_t blocks_cap = 0;
-    std::vector<int> h_status; size_t pending_blocks = 0;
     // split
     uint64_t *d_anchor = nullptr, *d_landing = nullptr, *d_segbase = nullptr; uint32_t* d_count = nullptr; uint8_t* d_landc = nullptr; size_t seg_cap = 0;
     uint64_t* d_starts = nullptr; uint64_t* d_nout = nullptr; vlr::RecDesc* d_desc = nullptr; vlr::RecHost* d_host = nullptr; size_t rec_cap = 0;
@@ -1046,8 +1057,12 @@ void dev_file_free(vlr_dev_file* f) {
     (void)hipSetDevice(f->device);
     if (f->feed_stream) (void)hipStreamDestroy(f->feed_stream);
     if (f->copy_stream) (void)hipStreamDestroy(f->copy_stream);
-    if (f->ev0) (void)hipEventDestroy(f->ev0);
-    if (f->ev1) (void)hipEventDestroy(f->ev1);
+    for (auto& fd : f->feeds) {
+        for (hipEvent_t e : {fd.ev0, fd.ev1, fd.done})
+            if (e) (void)hipEventDestroy(e);
+        if (fd.h_status) (void)hipHostFree(fd.h_status);
+        if (fd.h_blocks) (void)hipHostFree(fd.h_blocks);
+    }
     if (f->stream) { (void)hipStreamSynchronize(f->stream); (void)hipStreamDestroy(f->stream); }
     void* all[] = {f->buf, f->spare, f->d_comp, f->d_blocks, f->d_status, f->d_anchor, f->d_landing, f->d_segbase, f->d_count, f->d_landc, f->d_starts, f->d_nout,
                    f->d_desc, f->d_host, f->d_fok, f->d_cold_off, f->d_cold};
@@ -1085,7 +1100,7 @@ int vlr_dev_file_create(int device, vlr_dev_file** out) {
             if (park[i]->device == device) {
                 vlr_dev_file* f = park[i];
                 park.erase(park.begin() + (long)i);
-                f->rd = f->wr = 0; f->feed_pending = false; f->pending_blocks = 0; f->n_split = 0; f->inflate_s = 0.0;
+                f->rd = f->wr = f->ready = 0; f->feed_head = f->feed_n = 0; f->n_split = 0; f->inflate_s = 0.0;
                 f->fok_n = -1;   // (the key table of the new file is uploaded at its first split)
                 *out = f;
                 return VLR_OK;
@@ -1145,9 +1160,18 @@ int vlr_dev_file_sync(vlr_dev_file* f) { VLR_HIP_OK(hipSetDevice(f->device)); VL
 // vlr_dev_file_feed_wait.  The buffered bytes [rd, wr) are only read by kernels already enqueued on the decode stream: compaction
 // copies them into the other allocation (never inside one), so the feed may run beside those kernels.
 int vlr_dev_file_feed(vlr_dev_file* f, const uint8_t* comp, size_t comp_bytes, const vlr::InflateBlock* blocks, int n_blocks, uint64_t inflated_bytes) {
+    return vlr_dev_file_feed_pieces(f, &comp, &comp_bytes, 1, blocks, n_blocks, inflated_bytes);
+}
+
+// the same with the compressed bytes in n_pieces host pieces that are uploaded one behind the other (the segments of a page-locked
+// staging ring: the copies are DMA from there and the call returns at once; from pageable memory the calling thread stages them)
+int vlr_dev_file_feed_pieces(vlr_dev_file* f, const uint8_t* const* piece, const size_t* piece_bytes, int n_pieces, const vlr::InflateBlock* blocks, int n_blocks,
+                             uint64_t inflated_bytes) {
     if (!f || n_blocks <= 0) return VLR_OK;
+    size_t comp_bytes = 0;
+    for (int i = 0; i < n_pieces; ++i) comp_bytes += piece_bytes[i];
     VLR_HIP_OK(hipSetDevice(f->device));
-    if (f->feed_pending) { const int rc = vlr_dev_file_feed_wait(f); if (rc != VLR_OK) return rc; }
+    if (f->feed_n == vlr_dev_file::kFeedSlots) { const int rc = vlr_dev_file_feed_wait_oldest(f); if (rc != VLR_OK) return rc; }
     hipStream_t st = f->feed_stream;
     const size_t live = f->wr - f->rd;
     if (f->wr + inflated_bytes + 64 > f->cap) {   // compact into the other buffer (grown if needed)
@@ -1162,6 +1186,9 @@ int vlr_dev_file_feed(vlr_dev_file* f, const uint8_t* comp, size_t comp_bytes, c
         }
         if (live) VLR_HIP_OK(hipMemcpyAsync(f->spare, f->buf + f->rd, live, hipMemcpyDeviceToDevice, st));
         std::swap(f->buf, f->spare); std::swap(f->cap, f->spare_cap);
+        // (positions move with the bytes: the copy runs behind the pending inflates on the feed stream, which wrote the old positions)
+        for (int i = 0; i < f->feed_n; ++i) f->feeds[(f->feed_head + i) % vlr_dev_file::kFeedSlots].wr_end -= f->rd;
+        f->ready -= f->rd;
         f->rd = 0; f->wr = live;
     }
     {   // compressed bytes and member list; the kernel may read kInflateInputSlack bytes beyond the last member
@@ -1174,48 +1201,89 @@ int vlr_dev_file_feed(vlr_dev_file* f, const uint8_t* comp, size_t comp_bytes, c
             f->blocks_cap = c1 < c2 ? c1 : c2;
         }
     }
-    VLR_HIP_OK(hipMemcpyAsync(f->d_comp, comp, comp_bytes, hipMemcpyHostToDevice, st));
+    vlr_dev_file::Feed& fd = f->feeds[(f->feed_head + f->feed_n) % vlr_dev_file::kFeedSlots];
+    if ((size_t)n_blocks > fd.h_cap) {
+        if (fd.h_status) (void)hipHostFree(fd.h_status);
+        if (fd.h_blocks) (void)hipHostFree(fd.h_blocks);
+        fd.h_status = nullptr; fd.h_blocks = nullptr; fd.h_cap = 0;
+        const size_t ncap = (size_t)n_blocks + (size_t)n_blocks / 2 + 256;
+        if (hipHostMalloc(&fd.h_status, ncap * sizeof(int), hipHostMallocDefault) != hipSuccess || hipHostMalloc(&fd.h_blocks, ncap * sizeof(vlr::InflateBlock), hipHostMallocDefault) != hipSuccess)
+            return dfail(VLR_ERR_OUT_OF_MEMORY, "device reader: out of page-locked memory%s%lld", "", 0LL);
+        fd.h_cap = ncap;
+    }
+    memcpy(fd.h_blocks, blocks, (size_t)n_blocks * sizeof(vlr::InflateBlock));
+    {
+        size_t at = 0;
+        for (int i = 0; i < n_pieces; ++i) {
+            if (piece_bytes[i]) VLR_HIP_OK(hipMemcpyAsync(f->d_comp + at, piece[i], piece_bytes[i], hipMemcpyHostToDevice, st));
+            at += piece_bytes[i];
+        }
+    }
     VLR_HIP_OK(hipMemsetAsync(f->d_comp + comp_bytes, 0, vlr::kInflateInputSlack, st));
-    VLR_HIP_OK(hipMemcpyAsync(f->d_blocks, blocks, (size_t)n_blocks * sizeof(vlr::InflateBlock), hipMemcpyHostToDevice, st));
-    if (!f->ev0) { (void)hipEventCreate(&f->ev0); (void)hipEventCreate(&f->ev1); }
-    if (f->ev0) (void)hipEventRecord(f->ev0, st);
+    VLR_HIP_OK(hipMemcpyAsync(f->d_blocks, fd.h_blocks, (size_t)n_blocks * sizeof(vlr::InflateBlock), hipMemcpyHostToDevice, st));
+    if (!fd.ev0) { (void)hipEventCreate(&fd.ev0); (void)hipEventCreate(&fd.ev1); (void)hipEventCreateWithFlags(&fd.done, hipEventDisableTiming); }
+    if (!fd.done) return dfail(VLR_ERR_HIP, "device reader: hipEventCreate failed%s%lld", "", 0LL);
+    if (fd.ev0) (void)hipEventRecord(fd.ev0, st);
     const int lrc = vlr_launch_inflate_kernel(f->d_comp, f->d_blocks, n_blocks, f->buf + f->wr, f->d_status, st);
     if (lrc != 0) return dfail(VLR_ERR_HIP, "inflate kernel launch failed (hip error %s%lld)", "", lrc);
-    if (f->ev1) (void)hipEventRecord(f->ev1, st);
-    f->h_status.resize((size_t)n_blocks);
-    VLR_HIP_OK(hipMemcpyAsync(f->h_status.data(), f->d_status, (size_t)n_blocks * sizeof(int), hipMemcpyDeviceToHost, st));
-    f->pending_blocks = (size_t)n_blocks;
+    if (fd.ev1) (void)hipEventRecord(fd.ev1, st);
+    VLR_HIP_OK(hipMemcpyAsync(fd.h_status, f->d_status, (size_t)n_blocks * sizeof(int), hipMemcpyDeviceToHost, st));
+    VLR_HIP_OK(hipEventRecord(fd.done, st));
+    fd.n_blocks = (size_t)n_blocks;
     f->wr += (size_t)inflated_bytes;
-    f->feed_pending = true;
+    fd.wr_end = f->wr;
+    f->feed_n += 1;
     return VLR_OK;
 }
 
-int vlr_dev_file_feed_wait(vlr_dev_file* f) {
-    if (!f || !f->feed_pending) return VLR_OK;
+// the oldest feed in flight: its bytes are inflated and checked afterwards
+int vlr_dev_file_feed_wait_oldest(vlr_dev_file* f) {
+    if (!f || f->feed_n == 0) return VLR_OK;
     VLR_HIP_OK(hipSetDevice(f->device));
-    VLR_HIP_OK(hipStreamSynchronize(f->feed_stream));
-    f->feed_pending = false;
-    if (f->ev0 && f->ev1) { float ms = 0.0f; if (hipEventElapsedTime(&ms, f->ev0, f->ev1) == hipSuccess) f->inflate_s += (double)ms * 1e-3; }
-    for (size_t i = 0; i < f->pending_blocks; ++i)
-        if (f->h_status[i] != 0) return dfail(VLR_ERR_INVALID_ARGUMENT, "%s in a BGZF member (inflate status %lld)", f->h_status[i] == vlr::INFL_CRC_MISMATCH ? "CRC32 checksum mismatch" : "corrupt DEFLATE stream", (long long)f->h_status[i]);
-    f->pending_blocks = 0;
+    vlr_dev_file::Feed& fd = f->feeds[f->feed_head];
+    VLR_HIP_OK(hipEventSynchronize(fd.done));
+    f->feed_head = (f->feed_head + 1) % vlr_dev_file::kFeedSlots;
+    f->feed_n -= 1;
+    f->ready = fd.wr_end;
+    if (fd.ev0 && fd.ev1) { float ms = 0.0f; if (hipEventElapsedTime(&ms, fd.ev0, fd.ev1) == hipSuccess) f->inflate_s += (double)ms * 1e-3; }
+    for (size_t i = 0; i < fd.n_blocks; ++i)
+        if (fd.h_status[i] != 0) return dfail(VLR_ERR_INVALID_ARGUMENT, "%s in a BGZF member (inflate status %lld)", fd.h_status[i] == vlr::INFL_CRC_MISMATCH ? "CRC32 checksum mismatch" : "corrupt DEFLATE stream", (long long)fd.h_status[i]);
     return VLR_OK;
 }
+
+// every feed in flight
+int vlr_dev_file_feed_wait(vlr_dev_file* f) {
+    if (!f) return VLR_OK;
+    while (f->feed_n > 0) { const int rc = vlr_dev_file_feed_wait_oldest(f); if (rc != VLR_OK) return rc; }
+    return VLR_OK;
+}
+
+// feeds, oldest first, until `bytes` behind the read position are inflated (or nothing is in flight any more)
+int vlr_dev_file_wait_ready(vlr_dev_file* f, uint64_t bytes) {
+    if (!f) return VLR_OK;
+    while (f->feed_n > 0 && (uint64_t)(f->ready - f->rd) < bytes) { const int rc = vlr_dev_file_feed_wait_oldest(f); if (rc != VLR_OK) return rc; }
+    return VLR_OK;
+}
+int vlr_dev_file_feeds_in_flight(const vlr_dev_file* f) { return f ? f->feed_n : 0; }
+uint64_t vlr_dev_file_ready(const vlr_dev_file* f) { return f ? (uint64_t)(f->ready - f->rd) : 0; }
 
 int vlr_dev_file_skip(vlr_dev_file* f, uint64_t bytes) {
     if (f->rd + bytes > f->wr) return dfail(VLR_ERR_INVALID_ARGUMENT, "device reader: skip beyond the buffered bytes");
     f->rd += (size_t)bytes;
+    if (f->ready < f->rd) f->ready = f->rd;   // (skipped before its feed completed: nothing of it is read)
     return VLR_OK;
 }
 
 int vlr_dev_file_split(vlr_dev_file* f, int64_t max_records, int n_contigs, int n_hdr_samples, const int8_t* field_of_key, int n_keys, int64_t* n_records,
                        const vlr::RecHost** rec_host, int* used_serial_walk) {
     VLR_HIP_OK(hipSetDevice(f->device));
-    { const int rcw = vlr_dev_file_feed_wait(f); if (rcw != VLR_OK) return rcw; }
+    // (the inflated and checked bytes only: the caller waits for as many feeds as it wants — vlr_dev_file_wait_ready — and at least one
+    //  here when nothing is ready)
+    { const int rcw = vlr_dev_file_wait_ready(f, 8); if (rcw != VLR_OK) return rcw; }
     *n_records = 0; *rec_host = nullptr;
     if (used_serial_walk) *used_serial_walk = 0;
     f->n_split = 0;
-    const uint64_t avail = f->wr - f->rd;
+    const uint64_t avail = f->ready - f->rd;
     if (avail < 8 || max_records <= 0) return VLR_OK;
     const uint8_t* base = f->buf + f->rd;
     const int n_seg = (int)((avail + vlr::kSeg - 1) / vlr::kSeg);

@@ -90,10 +90,20 @@ void vlr_dev_file_trim();
 // bytes of complete-or-not record data currently buffered behind the read position
 uint64_t vlr_dev_file_buffered(const vlr_dev_file* f);
 // append the inflated bytes of n_blocks members (src offsets relative to comp) behind the buffered ones: enqueued on the file's feed
-// stream, beside whatever the decode stream still runs; comp and blocks stay valid until vlr_dev_file_feed_wait (which split calls)
+// stream, beside whatever the decode stream still runs and behind earlier feeds (up to four in flight); comp stays valid until the feed
+// has been waited for, blocks is copied
 int vlr_dev_file_feed(vlr_dev_file* f, const uint8_t* comp, size_t comp_bytes, const vlr::InflateBlock* blocks, int n_blocks, uint64_t inflated_bytes);
-// skip `bytes` (the BCF header) at the read position
+// (the compressed bytes in n_pieces host pieces, uploaded one behind the other: segments of a page-locked staging ring)
+int vlr_dev_file_feed_pieces(vlr_dev_file* f, const uint8_t* const* piece, const size_t* piece_bytes, int n_pieces, const vlr::InflateBlock* blocks, int n_blocks,
+                             uint64_t inflated_bytes);
+// wait for every feed in flight / for the oldest one / for feeds, oldest first, until `bytes` behind the read position are inflated and
+// checked (the split only looks at those); feeds still in flight; inflated bytes behind the read position
 int vlr_dev_file_feed_wait(vlr_dev_file* f);
+int vlr_dev_file_feed_wait_oldest(vlr_dev_file* f);
+int vlr_dev_file_wait_ready(vlr_dev_file* f, uint64_t bytes);
+int vlr_dev_file_feeds_in_flight(const vlr_dev_file* f);
+uint64_t vlr_dev_file_ready(const vlr_dev_file* f);
+// skip `bytes` (the BCF header) at the read position
 // seconds the inflate kernels of this file ran (HIP events on the feed stream), summed since the last reset
 double vlr_dev_file_inflate_seconds(vlr_dev_file* f, int reset);
 int vlr_dev_file_skip(vlr_dev_file* f, uint64_t bytes);

@@ -133,7 +133,15 @@ struct Blob {
     Blob(const Blob&) = delete;
     Blob& operator=(const Blob&) = delete;
     bool mapped = false;
-    void release() { if (p) { if (mapped) munmap(p, n ? n : 1); else free(p); } p = nullptr; n = 0; mapped = false; }
+    // (unmapping a file of gigabytes walks all its touched pages — 65 ms for the 2 GB of a million-record run: off the caller's thread)
+    void release() {
+        if (p) {
+            if (mapped && n >= ((size_t)64 << 20)) { uint8_t* q = p; const size_t m = n; std::thread([q, m] { munmap(q, m); }).detach(); }
+            else if (mapped) munmap(p, n ? n : 1);
+            else free(p);
+        }
+        p = nullptr; n = 0; mapped = false;
+    }
     ~Blob() { release(); }
     bool alloc(size_t bytes) {
         release();
@@ -1693,6 +1701,84 @@ bool stream_next(FileStream& f, int64_t max_records, int n_threads, SampleFile& 
 }
 }  // namespace
 
+// Page-locked staging of a mapped file for the uploads of the device reader (round 5).  hipMemcpyAsync from the mapping is staged by the
+// CALLING thread — 0.095 s of the reader's 0.14 s per 200 000 records went into that call —, so a helper thread copies the file, ahead of
+// the reader and in file order, into a ring of page-locked segments; a feed uploads its byte range from the ring as two or three DMA
+// copies and returns at once.  Segment k (file bytes [k, k + 1) * kSeg from `base`) lives in slot k mod kSlots; a slot is rewritten once
+// everything below the segment that comes to it has been released (the reader releases what its waited-for feeds covered).
+struct StageRing {
+    static constexpr size_t kSeg = (size_t)8 << 20;
+    static constexpr int kSlots = 20;
+    static constexpr size_t kMaxRange = 6 * kSeg - 2;   // the largest byte range of one feed the ring serves (three of them fit beside each other)
+    const uint8_t* src = nullptr;
+    size_t size = 0, base = 0;          // the file bytes, where staging starts
+    uint8_t* ring = nullptr;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t hi = 0, released = 0;        // [base, hi) staged so far; bytes below `released` are no longer read
+    bool stop = false;
+    static std::mutex& pool_mu() { static std::mutex m; return m; }
+    static std::vector<uint8_t*>& pool() { static auto* v = new std::vector<uint8_t*>(); return *v; }   // (page-locking 160 MB costs tens of milliseconds: rings outlive their reader)
+    bool start(const uint8_t* file, size_t file_size, size_t from) {
+        {
+            std::lock_guard<std::mutex> g(pool_mu());
+            if (!pool().empty()) { ring = pool().back(); pool().pop_back(); }
+        }
+        if (!ring) ring = (uint8_t*)vlr_host_alloc(kSeg * kSlots);
+        if (!ring) return false;
+        src = file; size = file_size; base = from - from % kSeg; hi = base; released = base;
+        th = std::thread([this] { run(); });
+        return true;
+    }
+    void run() {
+        for (;;) {
+            size_t at;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || (hi < size && hi + kSeg <= released - released % kSeg + kSeg * kSlots); });
+                if (stop || hi >= size) return;
+                at = hi;
+            }
+            const size_t n = std::min(kSeg, size - at);
+            memcpy(ring + ((at - base) / kSeg % kSlots) * kSeg, src + at, n);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                hi = at + n;
+            }
+            cv.notify_all();
+        }
+    }
+    // the pieces of file bytes [a, b) in the ring (at most 7: see fits); waits for the stager
+    int pieces(size_t a, size_t b, const uint8_t** ptr, size_t* len) {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return hi >= b || stop; });
+        }
+        int n = 0;
+        for (size_t p = a; p < b;) {
+            const size_t k = (p - base) / kSeg, in = (p - base) % kSeg, take = std::min(kSeg - in, b - p);
+            ptr[n] = ring + (k % kSlots) * kSeg + in; len[n] = take; ++n;
+            p += take;
+        }
+        return n;
+    }
+    bool fits(size_t a, size_t b) const { return ring && a >= base && b > a && b - a <= kMaxRange; }
+    void release(size_t upto) {
+        { std::lock_guard<std::mutex> lk(mu); if (upto > released) released = upto; }
+        cv.notify_all();
+    }
+    void shutdown() {
+        if (th.joinable()) {
+            { std::lock_guard<std::mutex> lk(mu); stop = true; }
+            cv.notify_all();
+            th.join();
+        }
+        if (ring) { std::lock_guard<std::mutex> g(pool_mu()); if (pool().size() < 8) pool().push_back(ring); else vlr_host_free(ring); ring = nullptr; }
+    }
+    ~StageRing() { shutdown(); }
+};
+
 // one sample file of the device reader: the compressed file on the host, its inflated records on the device (vlr_decode.hip)
 struct DevFileStream {
     std::string path;
@@ -1715,8 +1801,14 @@ struct DevFileStream {
     size_t w0 = 0, mb0 = 0, mb1 = 0;   // window start, own members [mb0, mb1)
     int64_t sh_lead = 0, sh_own = 0, sh_total = 0;   // complete records of the window: in front of the own share, starting in it, in all
     uint64_t sh_first[2] = {0, 0}, sh_land[2] = {0, 0};   // (member, byte in the member) of the first own record's start / of the start behind the last own record
+    // page-locked staging of the uploads (plain readers; a sharded reader's window is one large feed from the mapping)
+    std::unique_ptr<StageRing> stage;
+    std::deque<size_t> fed_begin;       // file offsets where the feeds still in flight begin (what the ring must keep)
     bool more_blocks() const { return next_block < blocks.size() && next_block < block_limit; }
-    ~DevFileStream() { if (dev) vlr_dev_file_destroy(dev); }
+    ~DevFileStream() {
+        if (dev) vlr_dev_file_destroy(dev);   // (waits for the uploads in flight: the ring goes after them)
+        stage.reset();
+    }
 };
 
 struct vlr_obs_reader {
@@ -1796,8 +1888,24 @@ int vlr_obs_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** 
     return rc;
 }
 
+// the summary scratch of a closed device reader waits for the next one (hipFree synchronises the device: milliseconds per run of the CLI);
+// vlr_ingest_device_trim returns it
+namespace {
+std::mutex g_scratch_mu;
+struct ParkedScratch { int device; DevSlab slab; };
+std::vector<ParkedScratch>& parked_scratch() { static auto* v = new std::vector<ParkedScratch>(); return *v; }
+}
 void vlr_obs_reader_close(vlr_obs_reader* r) {
-    if (r && r->sum_scratch.d) vlr_dev_slab_free(r->device, r->sum_scratch.d, r->sum_scratch.h);
+    if (r && r->sum_scratch.d) {
+        std::lock_guard<std::mutex> g(g_scratch_mu);
+        auto& pk = parked_scratch();
+        size_t k = 0;
+        while (k < pk.size() && pk[k].device != r->device) ++k;
+        if (k == pk.size()) pk.push_back({r->device, r->sum_scratch});
+        else if (pk[k].slab.cap < r->sum_scratch.cap) { vlr_dev_slab_free(pk[k].device, pk[k].slab.d, pk[k].slab.h); pk[k].slab = r->sum_scratch; }
+        else vlr_dev_slab_free(r->device, r->sum_scratch.d, r->sum_scratch.h);
+        r->sum_scratch = DevSlab();
+    }
     delete r;
 }
 
@@ -1856,18 +1964,18 @@ int dev_stream_open(DevFileStream& f, const char* path, int device) {
     return vlr_dev_file_create(device, &f.dev);
 }
 
-// members up to `want` buffered bytes onto the device
-int dev_stream_feed(DevFileStream& f, uint64_t want) {
+// members up to `want` buffered bytes onto the device, in feeds of at most `piece` inflated bytes each (a feed is what the reader waits
+// for: request-sized pieces let it take the oldest while the later ones still inflate)
+int dev_stream_feed(DevFileStream& f, uint64_t want, uint64_t piece = ~0ull) {
     // (the header bytes in front of the first record are buffered like record bytes until they are skipped)
     const auto goal = [&] { return want + (f.header_skipped ? 0 : (uint64_t)f.header_bytes); };
     while (f.more_blocks() && vlr_dev_file_buffered(f.dev) < goal()) {
-        { const int rcw = vlr_dev_file_feed_wait(f.dev); if (rcw != VLR_OK) return rcw; }   // (f.ib is read by the copy in flight)
         const uint64_t have = vlr_dev_file_buffered(f.dev);
         const size_t b0 = f.next_block;
         size_t b1 = b0;
         uint64_t add = 0;
         f.ib.clear();
-        while (b1 < f.blocks.size() && b1 < f.block_limit && (have + add < goal() || b1 == b0) && b1 - b0 < (1u << 20)) {
+        while (b1 < f.blocks.size() && b1 < f.block_limit && ((have + add < goal() && add < piece) || b1 == b0) && b1 - b0 < (1u << 20)) {
             const BgzfBlock& k = f.blocks[b1];
             vlr::InflateBlock x;
             x.src = k.off - f.blocks[b0].off; x.dst = add; x.clen = (uint32_t)k.clen; x.isize = k.isize; x.crc = k.crc; x.pad = 0;
@@ -1878,11 +1986,27 @@ int dev_stream_feed(DevFileStream& f, uint64_t want) {
         // one contiguous piece of the file: from the first member's DEFLATE payload to the end of the last one's
         const uint8_t* comp = f.raw.p + f.blocks[b0].off;
         const size_t comp_bytes = (f.blocks[b1 - 1].off + f.blocks[b1 - 1].clen) - f.blocks[b0].off;
-        const int rc = vlr_dev_file_feed(f.dev, comp, comp_bytes, f.ib.data(), (int)f.ib.size(), add);
+        const double t_up = now_s();
+        int rc;
+        const size_t fa = f.blocks[b0].off, fb = fa + comp_bytes;
+        if (f.stage && f.stage->fits(fa, fb)) {
+            // what the feeds that are no longer in flight covered may be overwritten in the ring
+            while ((int)f.fed_begin.size() > vlr_dev_file_feeds_in_flight(f.dev)) f.fed_begin.pop_front();
+            f.stage->release(f.fed_begin.empty() ? fa : f.fed_begin.front());
+            const uint8_t* pp[8]; size_t pl[8];
+            const int np = f.stage->pieces(fa, fb, pp, pl);
+            rc = vlr_dev_file_feed_pieces(f.dev, pp, pl, np, f.ib.data(), (int)f.ib.size(), add);
+            f.fed_begin.push_back(fa);
+        } else {
+            if (f.stage) { (void)vlr_dev_file_feed_wait(f.dev); f.stage.reset(); f.fed_begin.clear(); }   // (a range the ring does not hold: from the mapping from here on)
+            rc = vlr_dev_file_feed(f.dev, comp, comp_bytes, f.ib.data(), (int)f.ib.size(), add);
+        }
+        g_dev_t[14] += now_s() - t_up;   // (inside the enqueueing call: an upload from pageable memory is staged by the calling thread)
         g_dev_t[9] += (double)add; g_dev_t[10] += (double)comp_bytes;
         if (rc != VLR_OK) return rc;
         f.next_block = b1;
         if (!f.header_skipped && vlr_dev_file_buffered(f.dev) >= f.header_bytes) {
+            { const int rcw = vlr_dev_file_feed_wait(f.dev); if (rcw != VLR_OK) return rcw; }   // (once per file: the header's members are checked before they are skipped)
             const int rs = vlr_dev_file_skip(f.dev, f.header_bytes);
             if (rs != VLR_OK) return rs;
             f.header_skipped = true;
@@ -1916,27 +2040,49 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
     std::vector<const vlr::RecHost*> rh((size_t)S, nullptr);
     int64_t n = 0;
     double scale = 1.0;
-    for (int round = 0;; ++round) {
-        for (int s = 0; s < S; ++s) {
-            DevFileStream& f = *r->dfiles[(size_t)s];
-            const uint64_t want = (uint64_t)((double)max_records * f.bytes_per_record * 1.04 * scale) + 131072;
-            const int rc = dev_stream_feed(f, want);
-            if (rc != VLR_OK) return rc;
-        }
-        {
-            const double tw = now_s();
-            for (int s = 0; s < S; ++s) { const int rc = vlr_dev_file_feed_wait(r->dfiles[(size_t)s]->dev); if (rc != VLR_OK) return rc; }
-            g_dev_t[2] += now_s() - tw;
-        }
-        const double t0 = now_s();
-        n = max_records;
+    // requests ahead of the one being delivered whose members are uploaded and inflating (VLR_INGEST_PREFETCH; the reader waits for the
+    // OLDEST feed only).  Default 1: with two, the inflate waves of two requests sit on the CUs the decode and the evaluation of the current
+    // one want (stream priorities order dispatch, they do not preempt) — 838 k against 928 k records/s end to end, three: 452 k.
+    static const int depth = [] { const char* e = getenv("VLR_INGEST_PREFETCH"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v > 3 ? 3 : v; }();
+    auto split_all = [&](int64_t& n_min) -> int {
+        n_min = max_records;
         for (int s = 0; s < S; ++s) {
             DevFileStream& f = *r->dfiles[(size_t)s];
             int serial = 0;
             const int rc = vlr_dev_file_split(f.dev, max_records, (int)f.h.contigs.size(), f.n_hdr_samples, f.field_of_key.data(), (int)f.field_of_key.size(), &n_rec[(size_t)s], &rh[(size_t)s], &serial);
             if (rc != VLR_OK) return rc;
             if (serial) g_dev_t[12] += 1.0;
-            n = std::min(n, n_rec[(size_t)s]);
+            n_min = std::min(n_min, n_rec[(size_t)s]);
+        }
+        return VLR_OK;
+    };
+    for (int round = 0;; ++round) {
+        for (int s = 0; s < S; ++s) {
+            DevFileStream& f = *r->dfiles[(size_t)s];
+            const uint64_t want = (uint64_t)((double)max_records * f.bytes_per_record * 1.04 * scale) + 131072;
+            const int rc = dev_stream_feed(f, want * (uint64_t)depth, want);
+            if (rc != VLR_OK) return rc;
+        }
+        {
+            const double tw = now_s();
+            for (int s = 0; s < S; ++s) {
+                DevFileStream& f = *r->dfiles[(size_t)s];
+                const uint64_t want = (uint64_t)((double)max_records * f.bytes_per_record * 1.04 * scale) + 131072;
+                const int rc = round == 0 ? vlr_dev_file_wait_ready(f.dev, want) : vlr_dev_file_feed_wait(f.dev);
+                if (rc != VLR_OK) return rc;
+            }
+            g_dev_t[2] += now_s() - tw;
+        }
+        const double t0 = now_s();
+        { const int rc = split_all(n); if (rc != VLR_OK) return rc; }
+        if (n == 0) {   // nothing complete in the inflated bytes, but feeds are still in flight: all of them, then again
+            bool in_flight = false;
+            for (int s = 0; s < S; ++s) in_flight = in_flight || vlr_dev_file_feeds_in_flight(r->dfiles[(size_t)s]->dev) > 0;
+            if (in_flight) {
+                for (int s = 0; s < S; ++s) { const int rc = vlr_dev_file_feed_wait(r->dfiles[(size_t)s]->dev); if (rc != VLR_OK) return rc; }
+                const int rc = split_all(n);
+                if (rc != VLR_OK) return rc;
+            }
         }
         g_dev_t[3] += now_s() - t0;
         if (n > 0) break;
@@ -2021,7 +2167,7 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
         for (int s = 0; s < S; ++s) {
             DevFileStream& f = *r->dfiles[(size_t)s];
             const uint64_t want = (uint64_t)((double)max_records * f.bytes_per_record * 1.04) + 131072;
-            const int rc = dev_stream_feed(f, want);
+            const int rc = dev_stream_feed(f, want * (uint64_t)depth, want);
             if (rc != VLR_OK) return fail(rc);
         }
         g_dev_t[2] += now_s() - tf;
@@ -2104,6 +2250,12 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
         const size_t o_hdr = 0, o_rpm = up((size_t)P * sizeof(vlr::PileSum)), o_rln = o_rpm + up((size_t)total * 4), o_ik = o_rln + up((size_t)total * 4),
                      o_ic = o_ik + up((size_t)total * 8), o_tl = o_ic + up((size_t)total * 4), o_to = o_tl + up((size_t)P * 4), o_cur = o_to + up((size_t)P * 4),
                      o_txt = o_cur + 64, need = o_txt + text_cap;
+        if (r->sum_scratch.cap < need) {   // (the scratch a closed reader of this device left behind, if it is large enough)
+            std::lock_guard<std::mutex> g(g_scratch_mu);
+            auto& pk = parked_scratch();
+            for (size_t k = 0; k < pk.size(); ++k)
+                if (pk[k].device == r->device && pk[k].slab.cap >= need && !r->sum_scratch.d) { r->sum_scratch = pk[k].slab; pk.erase(pk.begin() + (long)k); break; }
+        }
         if (r->sum_scratch.cap < need) {
             if (r->sum_scratch.d) vlr_dev_slab_free(r->device, r->sum_scratch.d, r->sum_scratch.h);
             r->sum_scratch = DevSlab();
@@ -2176,8 +2328,30 @@ int vlr_obs_reader_open_device(int device, int n_samples, const char* const* pat
     for (int s = 0; s < n_samples; ++s) {
         r->paths.push_back(paths[s]);
         r->dfiles.emplace_back(new DevFileStream());
-        const int rc = dev_stream_open(*r->dfiles.back(), paths[s], device);
-        if (rc != VLR_OK) return rc;
+    }
+    // the files side by side: mapping one and walking its member chain (two page touches per member, 345 000 members in the file of a
+    // million tumor-normal records) is 45 ms of one thread
+    std::vector<int> rcs((size_t)n_samples, VLR_OK);
+    std::vector<std::string> errs((size_t)n_samples);
+    {
+        std::vector<std::thread> th;
+        for (int s = 1; s < n_samples; ++s)
+            th.emplace_back([&, s] { rcs[(size_t)s] = dev_stream_open(*r->dfiles[(size_t)s], paths[s], device); if (rcs[(size_t)s] != VLR_OK) errs[(size_t)s] = vlr_last_error(); });
+        rcs[0] = dev_stream_open(*r->dfiles[0], paths[0], device);
+        if (rcs[0] != VLR_OK) errs[0] = vlr_last_error();
+        for (auto& t : th) t.join();
+    }
+    for (int s = 0; s < n_samples; ++s)
+        if (rcs[(size_t)s] != VLR_OK) return ifail(rcs[(size_t)s], "%s", errs[(size_t)s].c_str());   // (the message is per thread)
+    {   // page-locked staging of the uploads (VLR_INGEST_STAGE=0: uploads from the mapping, staged by the reader's thread)
+        const char* e = getenv("VLR_INGEST_STAGE");
+        if (!(e && atoi(e) == 0))
+            for (int s = 0; s < n_samples; ++s) {
+                DevFileStream& f = *r->dfiles[(size_t)s];
+                if (f.blocks.empty() || f.raw.size() < ((size_t)32 << 20)) continue;   // (small files: nothing to gain)
+                f.stage.reset(new StageRing());
+                if (!f.stage->start(f.raw.p, f.raw.size(), f.blocks[0].off)) f.stage.reset();
+            }
     }
     *out = r.release();
     return VLR_OK;
@@ -2420,7 +2594,12 @@ void vlr_ingest_device_timings(double* out16, int reset) {
     if (reset) for (int i = 0; i < 16; ++i) g_dev_t[i] = 0.0;
 }
 
-void vlr_ingest_device_trim(void) { vlr_dev_file_trim(); }
+void vlr_ingest_device_trim(void) {
+    vlr_dev_file_trim();
+    std::lock_guard<std::mutex> g(g_scratch_mu);
+    for (auto& q : parked_scratch()) vlr_dev_slab_free(q.device, q.slab.d, q.slab.h);
+    parked_scratch().clear();
+}
 
 }  // extern "C"
 

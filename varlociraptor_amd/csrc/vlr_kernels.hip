@@ -52,6 +52,19 @@ namespace vlr {
 #define PROF_START(c)
 #define PROF_ADD(c, i)
 #endif
+// Issue priority of a wave (s_setprio): experiment of round 5 — the term products of a pass carry three independent chains per lane and
+// tolerate waiting for an issue slot, the control of the integrator around them is one dependent chain.  -DVLR_PRIO=1: products low, the
+// rest high; 2: the other way round; unset: no priority instructions.
+#if defined(VLR_PRIO) && VLR_PRIO == 1
+#define VLR_PRIO_PRODUCTS() __builtin_amdgcn_s_setprio(0)
+#define VLR_PRIO_CHAIN() __builtin_amdgcn_s_setprio(3)
+#elif defined(VLR_PRIO) && VLR_PRIO == 2
+#define VLR_PRIO_PRODUCTS() __builtin_amdgcn_s_setprio(3)
+#define VLR_PRIO_CHAIN() __builtin_amdgcn_s_setprio(0)
+#else
+#define VLR_PRIO_PRODUCTS()
+#define VLR_PRIO_CHAIN()
+#endif
 
 #define VLR_NEG_INF (-__builtin_huge_val())
 __device__ constexpr double kLn05 = -0.6931471805599453;    // ln 0.5   (utils/mod.rs:45 PROB_05)
@@ -2017,10 +2030,12 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
                 }
             }
         }
+        VLR_PRIO_PRODUCTS();
         if (q.ecoef != nullptr && __ballot(on && (be[0] != 0.0 || be[1] != 0.0 || be[2] != 0.0)) != 0ull)
             lds_products_e(lcoef, q.ecoef, rl, D, al, be, P);
         else
             reg_products<NS>(cc, cq, lcoef, rl, D, al, P);
+        VLR_PRIO_CHAIN();
         PROF_ADD(c, 12);  // pass: term products
         // reduction over the 16 lanes of the row, transposed from the first step on: a lane and its neighbour (xor 1) exchange what the
         // OTHER keeps — the even lane goes on with points 0 and 2, the odd one with point 1 (and a copy of 2) —, then the halves of a
