@@ -1710,9 +1710,16 @@ struct StageRing {
     static constexpr size_t kSeg = (size_t)8 << 20;
     static constexpr int kSlots = 20;
     static constexpr size_t kMaxRange = 6 * kSeg - 2;   // the largest byte range of one feed the ring serves (three of them fit beside each other)
-    const uint8_t* src = nullptr;
+    const uint8_t* src = nullptr;       // a mapped file ...
+    int fd = -1;                        // ... or a descriptor: pread straight into the ring, the file is never mapped (see index below)
     size_t size = 0, base = 0;          // the file bytes, where staging starts
     uint8_t* ring = nullptr;
+    // descriptor mode: the member chain (BSIZE fields) is walked in the ring as the bytes land, so that nobody touches the file's pages
+    // a second time — mapping a 2 GB file and walking its 345 000 members cost 0.07 s at open and the unmap 0.06 s at close
+    bool indexing = false, idx_done = false;
+    size_t idx_pos = 0, idx_out = 0;
+    std::vector<BgzfBlock> found;       // members indexed since the reader's last harvest (under mu)
+    std::string idx_err;
     std::thread th;
     std::mutex mu;
     std::condition_variable cv;
@@ -1731,6 +1738,56 @@ struct StageRing {
         th = std::thread([this] { run(); });
         return true;
     }
+    // descriptor mode: the whole file from offset 0, members indexed on the way (idx_from = offset of the first member to index)
+    bool start_fd(int file, size_t file_size) {
+        {
+            std::lock_guard<std::mutex> g(pool_mu());
+            if (!pool().empty()) { ring = pool().back(); pool().pop_back(); }
+        }
+        if (!ring) ring = (uint8_t*)vlr_host_alloc(kSeg * kSlots);
+        if (!ring) return false;
+        fd = file; size = file_size; base = 0; hi = 0; released = 0; indexing = true; idx_pos = 0; idx_out = 0;
+        th = std::thread([this] { run(); });
+        return true;
+    }
+    uint8_t byte_at(size_t off) const { return ring[((off - base) / kSeg % kSlots) * kSeg + (off - base) % kSeg]; }
+    // members whose bytes are all staged (stager thread; `upto` = hi)
+    void index_more(size_t upto) {
+        std::vector<BgzfBlock> add;
+        std::string err;
+        bool done = false;
+        size_t p = idx_pos, out = idx_out;
+        for (;;) {
+            if (p == size) { done = true; break; }
+            if (p + 18 > upto) { if (upto == size) err = "truncated BGZF member"; break; }
+            if (byte_at(p) != 0x1f || byte_at(p + 1) != 0x8b || byte_at(p + 2) != 8 || !(byte_at(p + 3) & 4)) { err = "not a BGZF member"; break; }
+            const size_t xlen = (size_t)byte_at(p + 10) | ((size_t)byte_at(p + 11) << 8);
+            size_t q = p + 12;
+            const size_t xend = q + xlen;
+            if (xend > upto) { if (upto == size) err = "truncated BGZF member"; break; }
+            long bsize = -1;
+            while (q + 4 <= xend) {
+                const size_t slen = (size_t)byte_at(q + 2) | ((size_t)byte_at(q + 3) << 8);
+                if (byte_at(q) == 'B' && byte_at(q + 1) == 'C' && slen == 2 && q + 6 <= xend) bsize = (long)((size_t)byte_at(q + 4) | ((size_t)byte_at(q + 5) << 8)) + 1;
+                q += 4 + slen;
+            }
+            if (bsize < 0 || (size_t)bsize < xlen + 20) { err = "not a BGZF member"; break; }
+            const size_t end = p + (size_t)bsize;
+            if (end > size) { err = "truncated BGZF member"; break; }
+            if (end > upto) break;
+            const size_t cend = end - 8;
+            const uint32_t crc = (uint32_t)byte_at(cend) | ((uint32_t)byte_at(cend + 1) << 8) | ((uint32_t)byte_at(cend + 2) << 16) | ((uint32_t)byte_at(cend + 3) << 24);
+            const uint32_t isize = (uint32_t)byte_at(cend + 4) | ((uint32_t)byte_at(cend + 5) << 8) | ((uint32_t)byte_at(cend + 6) << 16) | ((uint32_t)byte_at(cend + 7) << 24);
+            add.push_back({xend, cend - xend, isize, out, crc});
+            out += isize;
+            p = end;
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        found.insert(found.end(), add.begin(), add.end());
+        idx_pos = p; idx_out = out;
+        if (!err.empty()) { idx_err = err; idx_done = true; }
+        if (done) idx_done = true;
+    }
     void run() {
         for (;;) {
             size_t at;
@@ -1741,7 +1798,22 @@ struct StageRing {
                 at = hi;
             }
             const size_t n = std::min(kSeg, size - at);
-            memcpy(ring + ((at - base) / kSeg % kSlots) * kSeg, src + at, n);
+            uint8_t* dst = ring + ((at - base) / kSeg % kSlots) * kSeg;
+            if (fd >= 0) {
+                size_t got = 0;
+                while (got < n) {
+                    const ssize_t r = pread(fd, dst + got, n - got, (off_t)(at + got));
+                    if (r <= 0) break;
+                    got += (size_t)r;
+                }
+                if (got < n) {   // (the file shrank or cannot be read: what is there is zero-filled, the index reports it)
+                    memset(dst + got, 0, n - got);
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (idx_err.empty()) idx_err = "read error";
+                    idx_done = true;
+                }
+            } else memcpy(dst, src + at, n);
+            if (indexing && !idx_done) index_more(at + n);
             {
                 std::lock_guard<std::mutex> lk(mu);
                 hi = at + n;
@@ -1804,10 +1876,25 @@ struct DevFileStream {
     // page-locked staging of the uploads (plain readers; a sharded reader's window is one large feed from the mapping)
     std::unique_ptr<StageRing> stage;
     std::deque<size_t> fed_begin;       // file offsets where the feeds still in flight begin (what the ring must keep)
-    bool more_blocks() const { return next_block < blocks.size() && next_block < block_limit; }
+    // descriptor mode (plain readers of large files): the file is read through `fd` into the ring and never mapped; `blocks` grows as
+    // the stager indexes members (harvest)
+    int fd = -1;
+    bool streaming = false, index_done = false;
+    std::string index_err;
+    // members the stager has indexed since the last call -> blocks; wait: until there is at least one more (or the index is complete)
+    void harvest(bool wait) {
+        if (!streaming || index_done) return;
+        std::unique_lock<std::mutex> lk(stage->mu);
+        if (wait) stage->cv.wait(lk, [&] { return !stage->found.empty() || stage->idx_done; });
+        blocks.insert(blocks.end(), stage->found.begin(), stage->found.end());
+        stage->found.clear();
+        if (stage->idx_done) { index_done = true; index_err = stage->idx_err; }
+    }
+    bool more_blocks() const { return (next_block < blocks.size() && next_block < block_limit) || (streaming && !index_done); }
     ~DevFileStream() {
         if (dev) vlr_dev_file_destroy(dev);   // (waits for the uploads in flight: the ring goes after them)
         stage.reset();
+        if (fd >= 0) close(fd);
     }
 };
 
@@ -1928,6 +2015,66 @@ int count_header_samples(const std::string& text) {
     return tabs >= 9 ? tabs - 8 : 0;  // CHROM POS ID REF ALT QUAL FILTER INFO [FORMAT sample...]
 }
 
+int dev_stream_header(DevFileStream& f, const char* path, const std::vector<uint8_t>& head, size_t need, int device);
+
+// Descriptor mode (plain readers of files above 32 MB, VLR_INGEST_STAGE=0: off): the file is opened, its first megabyte read for the BCF
+// header, and everything else — bytes into the page-locked ring, member chain — is the stager's work beside the reader.  Returns
+// VLR_ERR_UNSUPPORTED for what it does not take (small files, a header beyond the first megabyte): the caller maps the file then.
+int dev_stream_open_fd(DevFileStream& f, const char* path, int device) {
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return VLR_ERR_UNSUPPORTED;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || (size_t)st.st_size < ((size_t)32 << 20)) { close(fd); return VLR_ERR_UNSUPPORTED; }
+    std::vector<uint8_t> first((size_t)1 << 20);
+    size_t got = 0;
+    while (got < first.size()) { const ssize_t r = pread(fd, first.data() + got, first.size() - got, (off_t)got); if (r <= 0) break; got += (size_t)r; }
+    if (got < first.size()) { close(fd); return VLR_ERR_UNSUPPORTED; }
+    // the members of the first megabyte, inflated until the header is complete
+    std::vector<uint8_t> head;
+    size_t need = 9, p = 0;
+    bool ok = true;
+    while (head.size() < need && ok) {
+        if (p + 18 > got || first[p] != 0x1f || first[p + 1] != 0x8b || first[p + 2] != 8 || !(first[p + 3] & 4)) { ok = false; break; }
+        const size_t xlen = first[p + 10] | ((size_t)first[p + 11] << 8);
+        size_t q = p + 12;
+        const size_t xend = q + xlen;
+        if (xend > got) { ok = false; break; }
+        long bsize = -1;
+        while (q + 4 <= xend) {
+            const size_t slen = first[q + 2] | ((size_t)first[q + 3] << 8);
+            if (first[q] == 'B' && first[q + 1] == 'C' && slen == 2 && q + 6 <= xend) bsize = (long)(first[q + 4] | ((size_t)first[q + 5] << 8)) + 1;
+            q += 4 + slen;
+        }
+        if (bsize < 0 || (size_t)bsize < xlen + 20 || p + (size_t)bsize > got) { ok = false; break; }
+        const size_t cend = p + (size_t)bsize - 8;
+        uint32_t crc, isize;
+        memcpy(&crc, first.data() + cend, 4); memcpy(&isize, first.data() + cend + 4, 4);
+        const size_t old = head.size();
+        head.resize(old + isize);
+        if (isize && !inflate_raw(first.data() + xend, cend - xend, head.data() + old, isize, crc)) { close(fd); return ifail(VLR_ERR_INVALID_ARGUMENT, "corrupt BGZF block in %s", path); }
+        if (head.size() >= 9 && need == 9) {
+            if (memcmp(head.data(), "BCF\2\2", 5) != 0) { close(fd); return ifail(VLR_ERR_UNSUPPORTED, "device reader: %s is not a BCF2 file (use vlr_obs_reader_open)", path); }
+            uint32_t l_text;
+            memcpy(&l_text, head.data() + 5, 4);
+            need = 9 + (size_t)l_text;
+        }
+        p += (size_t)bsize;
+    }
+    if (!ok || head.size() < need || need == 9) { close(fd); return VLR_ERR_UNSUPPORTED; }   // (not BGZF, or a header beyond the first megabyte: the mapped path decides)
+    f.path = path;
+    const int rc = dev_stream_header(f, path, head, need, device);
+    if (rc != VLR_OK) { close(fd); return rc; }
+    f.fd = fd;
+    f.stage.reset(new StageRing());
+    if (!f.stage->start_fd(fd, (size_t)st.st_size)) {
+        f.stage.reset(); f.fd = -1; close(fd);
+        vlr_dev_file_destroy(f.dev); f.dev = nullptr;
+        return VLR_ERR_UNSUPPORTED;
+    }
+    f.streaming = true;
+    return VLR_OK;
+}
+
 // the BCF header of a BGZF file, inflated on the host from the first members
 int dev_stream_open(DevFileStream& f, const char* path, int device) {
     f.path = path;
@@ -1951,6 +2098,11 @@ int dev_stream_open(DevFileStream& f, const char* path, int device) {
         }
     }
     if (head.size() < need || need == 9) return ifail(VLR_ERR_INVALID_ARGUMENT, "truncated header in %s", path);
+    return dev_stream_header(f, path, head, need, device);
+}
+
+// the parsed header, the field table and the device side of a file whose inflated header bytes are `head`
+int dev_stream_header(DevFileStream& f, const char* path, const std::vector<uint8_t>& head, size_t need, int device) {
     std::string text((const char*)head.data() + 9, need - 9);
     while (!text.empty() && text.back() == '\0') text.pop_back();
     parse_header(text, f.h);
@@ -1970,21 +2122,32 @@ int dev_stream_feed(DevFileStream& f, uint64_t want, uint64_t piece = ~0ull) {
     // (the header bytes in front of the first record are buffered like record bytes until they are skipped)
     const auto goal = [&] { return want + (f.header_skipped ? 0 : (uint64_t)f.header_bytes); };
     while (f.more_blocks() && vlr_dev_file_buffered(f.dev) < goal()) {
+        f.harvest(false);
         const uint64_t have = vlr_dev_file_buffered(f.dev);
         const size_t b0 = f.next_block;
         size_t b1 = b0;
         uint64_t add = 0;
         f.ib.clear();
-        while (b1 < f.blocks.size() && b1 < f.block_limit && ((have + add < goal() && add < piece) || b1 == b0) && b1 - b0 < (1u << 20)) {
-            const BgzfBlock& k = f.blocks[b1];
-            vlr::InflateBlock x;
-            x.src = k.off - f.blocks[b0].off; x.dst = add; x.clen = (uint32_t)k.clen; x.isize = k.isize; x.crc = k.crc; x.pad = 0;
-            f.ib.push_back(x);
-            add += k.isize;
-            ++b1;
+        for (;;) {
+            while (b1 < f.blocks.size() && b1 < f.block_limit && ((have + add < goal() && add < piece) || b1 == b0) && b1 - b0 < (1u << 20)) {
+                const BgzfBlock& k = f.blocks[b1];
+                // (a feed from the staging ring is one byte range the ring holds at once)
+                if (f.stage && b1 > b0 && (k.off + k.clen) - f.blocks[b0].off > StageRing::kMaxRange) break;
+                vlr::InflateBlock x;
+                x.src = k.off - f.blocks[b0].off; x.dst = add; x.clen = (uint32_t)k.clen; x.isize = k.isize; x.crc = k.crc; x.pad = 0;
+                f.ib.push_back(x);
+                add += k.isize;
+                ++b1;
+            }
+            // descriptor mode: the members behind the indexed ones, once the stager has walked them
+            if (f.streaming && !f.index_done && b1 == f.blocks.size() && ((have + add < goal() && add < piece) || b1 == b0)) { f.harvest(true); continue; }
+            break;
         }
+        if (f.streaming && f.index_done && !f.index_err.empty() && b1 == f.blocks.size())
+            return ifail(VLR_ERR_INVALID_ARGUMENT, "corrupt BGZF block in %s (%s)", f.path.c_str(), f.index_err.c_str());
+        if (b1 == b0) break;   // (the index ended: nothing left to feed)
         // one contiguous piece of the file: from the first member's DEFLATE payload to the end of the last one's
-        const uint8_t* comp = f.raw.p + f.blocks[b0].off;
+        const uint8_t* comp = f.raw.p ? f.raw.p + f.blocks[b0].off : nullptr;
         const size_t comp_bytes = (f.blocks[b1 - 1].off + f.blocks[b1 - 1].clen) - f.blocks[b0].off;
         const double t_up = now_s();
         int rc;
@@ -1997,6 +2160,8 @@ int dev_stream_feed(DevFileStream& f, uint64_t want, uint64_t piece = ~0ull) {
             const int np = f.stage->pieces(fa, fb, pp, pl);
             rc = vlr_dev_file_feed_pieces(f.dev, pp, pl, np, f.ib.data(), (int)f.ib.size(), add);
             f.fed_begin.push_back(fa);
+        } else if (f.streaming) {
+            return ifail(VLR_ERR_INVALID_ARGUMENT, "device reader: a member range of %s does not fit the staging ring", f.path.c_str());   // (cannot happen: feeds are cut to the ring)
         } else {
             if (f.stage) { (void)vlr_dev_file_feed_wait(f.dev); f.stage.reset(); f.fed_begin.clear(); }   // (a range the ring does not hold: from the mapping from here on)
             rc = vlr_dev_file_feed(f.dev, comp, comp_bytes, f.ib.data(), (int)f.ib.size(), add);
@@ -2316,7 +2481,13 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
 
 extern "C" {
 
+// allow_stage: page-locked staging of the uploads (descriptor mode for large files).  A sharded reader maps its files: its window is one
+// large feed anywhere in the file and it needs the whole member index up front.
+static int open_device_impl(int device, int n_samples, const char* const* paths, uint32_t omit_bias_mask, int n_threads, bool allow_stage, vlr_obs_reader** out);
 int vlr_obs_reader_open_device(int device, int n_samples, const char* const* paths, uint32_t omit_bias_mask, int n_threads, vlr_obs_reader** out) {
+    return open_device_impl(device, n_samples, paths, omit_bias_mask, n_threads, true, out);
+}
+static int open_device_impl(int device, int n_samples, const char* const* paths, uint32_t omit_bias_mask, int n_threads, bool allow_stage, vlr_obs_reader** out) {
     if (!out || !paths || n_samples < 1 || n_samples > VLR_MAX_SAMPLES) return ifail(VLR_ERR_INVALID_ARGUMENT, "vlr_obs_reader_open_device: bad argument");
     *out = nullptr;
     std::unique_ptr<vlr_obs_reader> r(new vlr_obs_reader());
@@ -2335,20 +2506,26 @@ int vlr_obs_reader_open_device(int device, int n_samples, const char* const* pat
     std::vector<std::string> errs((size_t)n_samples);
     {
         std::vector<std::thread> th;
-        for (int s = 1; s < n_samples; ++s)
-            th.emplace_back([&, s] { rcs[(size_t)s] = dev_stream_open(*r->dfiles[(size_t)s], paths[s], device); if (rcs[(size_t)s] != VLR_OK) errs[(size_t)s] = vlr_last_error(); });
-        rcs[0] = dev_stream_open(*r->dfiles[0], paths[0], device);
-        if (rcs[0] != VLR_OK) errs[0] = vlr_last_error();
+        const char* e = getenv("VLR_INGEST_STAGE");
+        const bool staged = allow_stage && !(e && atoi(e) == 0);
+        auto open_one = [&, staged](int s) {
+            int rc = staged ? dev_stream_open_fd(*r->dfiles[(size_t)s], paths[s], device) : VLR_ERR_UNSUPPORTED;
+            if (rc == VLR_ERR_UNSUPPORTED && !r->dfiles[(size_t)s]->streaming) rc = dev_stream_open(*r->dfiles[(size_t)s], paths[s], device);
+            rcs[(size_t)s] = rc;
+            if (rc != VLR_OK) errs[(size_t)s] = vlr_last_error();
+        };
+        for (int s = 1; s < n_samples; ++s) th.emplace_back(open_one, s);
+        open_one(0);
         for (auto& t : th) t.join();
     }
     for (int s = 0; s < n_samples; ++s)
         if (rcs[(size_t)s] != VLR_OK) return ifail(rcs[(size_t)s], "%s", errs[(size_t)s].c_str());   // (the message is per thread)
     {   // page-locked staging of the uploads (VLR_INGEST_STAGE=0: uploads from the mapping, staged by the reader's thread)
         const char* e = getenv("VLR_INGEST_STAGE");
-        if (!(e && atoi(e) == 0))
+        if (allow_stage && !(e && atoi(e) == 0))
             for (int s = 0; s < n_samples; ++s) {
                 DevFileStream& f = *r->dfiles[(size_t)s];
-                if (f.blocks.empty() || f.raw.size() < ((size_t)32 << 20)) continue;   // (small files: nothing to gain)
+                if (f.streaming || f.blocks.empty() || f.raw.size() < ((size_t)32 << 20)) continue;   // (descriptor mode has its ring; small files: nothing to gain)
                 f.stage.reset(new StageRing());
                 if (!f.stage->start(f.raw.p, f.raw.size(), f.blocks[0].off)) f.stage.reset();
             }
@@ -2470,7 +2647,7 @@ int shard_scan_file(vlr_obs_reader* r, DevFileStream& f) {
 int vlr_obs_reader_open_device_shard(int device, int n_samples, const char* const* paths, uint32_t omit_bias_mask, int n_threads, int shard, int n_shards, vlr_obs_reader** out) {
     if (!out || n_shards < 1 || shard < 0 || shard >= n_shards) return ifail(VLR_ERR_INVALID_ARGUMENT, "vlr_obs_reader_open_device_shard: bad argument");
     vlr_obs_reader* r = nullptr;
-    int rc = vlr_obs_reader_open_device(device, n_samples, paths, omit_bias_mask, n_threads, &r);
+    int rc = open_device_impl(device, n_samples, paths, omit_bias_mask, n_threads, false, &r);
     if (rc != VLR_OK) return rc;
     r->sharded = true; r->shard = shard; r->n_shards = n_shards;
     for (auto& f : r->dfiles) {
