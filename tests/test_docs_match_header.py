@@ -29,6 +29,8 @@ def _internal_ids():
                 ids.update(re.findall(r"__global__[^\n{;]*?\b(vlr_[a-z0-9_]+)\s*\(", src))
                 ids.update(re.findall(r"\b(vlr_launch_[a-z0-9_]+)", src))
                 ids.update(re.findall(r"#define\s+VLR_FN_\w+\s+(vlr_[a-z0-9_]+)", src))   # launchers / helpers named per build variant
+                if name == "vlr_gpuio.h":   # the interface between the host side of the device reader and its kernels' translation unit
+                    ids.update(re.findall(r"\b(vlr_[a-z0-9_]+)\s*\(", src))
     return ids
 
 

@@ -71,6 +71,9 @@ if os.path.exists(os.path.join(O, "cpu_probe.txt")):
 md += ["", "## rocprofv3 --kernel-trace --stats of `python bench.py --no-cpu-baseline` (config3, 1 M loci per launch)", "", rocpd("stats_config3"),
        "## … of `python bench.py --afd --no-cpu-baseline`", "", rocpd("stats_config3_afd"),
        "## … of `python bench.py --workload realign --no-cpu-baseline`", "", rocpd("stats_realign")]
+sc = os.path.join(O, "stats_cli.md")
+if os.path.exists(sc):
+    md += ["## … of `python bench.py --workload cli --steps 3 --warmup 1` (the whole pipeline: reader, evaluation, emission kernels on their streams; durations of kernels on the low-priority feed stream include the time they wait for CUs) and the union of the kernel intervals over the timed steps (`tools/timeline_busy.py`)", "", open(sc).read().rstrip(), ""]
 md += ["## PMC counters per locus (= per wave; config3, 50 000 loci, `tools/pmc_pass.sh`)", ""]
 for name in ("insts", "util", "f64", "icache"):
     f = os.path.join(O, "pmc", name + ".md")

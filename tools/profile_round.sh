@@ -20,6 +20,9 @@ python tools/cpu_probe.py > $O/cpu_probe.txt 2>&1
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $O/stats_config3 -o s -- python $R/bench.py --no-cpu-baseline --no-end-to-end --no-afd > $O/stats_config3.json 2> $O/stats_config3.err)
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $O/stats_config3_afd -o s -- python $R/bench.py --afd --no-cpu-baseline --no-end-to-end > $O/stats_config3_afd.json 2> $O/stats_config3_afd.err)
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $O/stats_realign -o s -- python $R/bench.py --workload realign --no-cpu-baseline > $O/stats_realign.json 2> $O/stats_realign.err)
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $O/stats_cli -o s -- python $R/bench.py --workload cli --steps 3 --warmup 1 > $O/stats_cli.json 2> $O/stats_cli.err)
+DBC=$(find $O/stats_cli -name "*.db" | head -1)
+if [ -n "$DBC" ]; then python tools/rocpd_summary.py $DBC | head -20 > $O/stats_cli.md; echo >> $O/stats_cli.md; python tools/timeline_busy.py $DBC 0.4 1.0 >> $O/stats_cli.md; fi
 find $O -name "*.db" -size +20M -delete
 bash tools/pmc_pass.sh $T/pmc config3 50000 > $O/pmc.md 2>&1
 bash tools/pmc_inflate.sh $T/pmc_inflate 50000 > $O/pmc_inflate.md 2>&1
