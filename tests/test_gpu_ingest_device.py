@@ -59,6 +59,23 @@ def inflate_mode(request):
         os.environ["VLR_INFLATE_BATCH"] = old
 
 
+@pytest.fixture(params=["mapped", "descriptor"])
+def reader_mode(request):
+    """The two ways the device reader takes a file: mapped (small files, sharded readers) and descriptor mode (pread into the page-locked
+    ring, member chain indexed there by the stager thread; files above 32 MB by default — VLR_INGEST_STAGE_MIN_MB=0 sends the tests'
+    small files through it)."""
+    old = os.environ.get("VLR_INGEST_STAGE_MIN_MB")
+    if request.param == "descriptor":
+        os.environ["VLR_INGEST_STAGE_MIN_MB"] = "0"
+    elif old is not None:
+        del os.environ["VLR_INGEST_STAGE_MIN_MB"]
+    yield request.param
+    if old is None:
+        os.environ.pop("VLR_INGEST_STAGE_MIN_MB", None)
+    else:
+        os.environ["VLR_INGEST_STAGE_MIN_MB"] = old
+
+
 def test_inflate_kernel_equals_zlib_on_every_block_type(inflate_mode):
     rng = np.random.default_rng(5)
     members, plain = [], []
@@ -135,7 +152,7 @@ def test_member_crc32_is_checked_on_the_device(inflate_mode):
             assert ingest.bgzf_inflate(_member(pl, level)) == pl
 
 
-def test_readers_refuse_a_member_with_a_wrong_crc(tmp_path):
+def test_readers_refuse_a_member_with_a_wrong_crc(tmp_path, reader_mode):
     """Both readers (device: vlr_crc_kernel; host: libdeflate / zlib CRC behind inflate_raw) fail on an observation file with one
     flipped payload bit that still inflates."""
     cfg = synth.config2()
@@ -208,7 +225,7 @@ def _concat_check(host_chunks, dev_chunks, first=None):
 
 
 @pytest.mark.parametrize("name", ["config3", "config4", "config5"])
-def test_device_reader_equals_host_reader(name, tmp_path, inflate_mode):
+def test_device_reader_equals_host_reader(name, tmp_path, inflate_mode, reader_mode):
     cfg = synth.CONFIGS[name]()
     b = synth.generate(cfg, 2500, seed=31)
     third = np.where(np.arange(b.n_obs) % 5 == 0, np.arange(b.n_obs) % 4, -1).astype(np.int32)
@@ -241,7 +258,7 @@ def test_device_reader_equals_host_reader(name, tmp_path, inflate_mode):
     assert t["records"] > 0
 
 
-def test_device_reader_on_files_of_the_reference(golden_dir, tmp_path, inflate_mode):
+def test_device_reader_on_files_of_the_reference(golden_dir, tmp_path, inflate_mode, reader_mode):
     """normal.bcf of the reference's flamegraph_profiling fixture was written by varlociraptor preprocess through htslib (other member
     sizes, int8 / int16 typed vectors, its own header); the fourteen format-v15 testcases are re-encoded as BCF by the Python writer."""
     import glob
@@ -281,7 +298,7 @@ def test_device_batch_evaluates_like_the_host_batch(tmp_path):
     plan.close()
 
 
-def test_device_reader_refuses_what_it_does_not_read(tmp_path, golden_dir):
+def test_device_reader_refuses_what_it_does_not_read(tmp_path, golden_dir, reader_mode):
     with pytest.raises(engine.EngineError) as e:
         ingest.ObsReader([os.path.join(golden_dir, "flamegraph_profiling", "normal.vcf")], device=0)
     assert e.value.code == -2   # VLR_ERR_UNSUPPORTED: the host reader takes text VCF / plain gzip
@@ -344,7 +361,7 @@ def test_writer_from_device_summaries_equals_writer_from_columns(name, tmp_path)
     plan.close()
 
 
-def test_device_reader_records_larger_than_a_segment_and_tiny_files(tmp_path):
+def test_device_reader_records_larger_than_a_segment_and_tiny_files(tmp_path, reader_mode):
     """Records of 0.2 to 2 MB (pileups of thousands of observations) span many 64 KiB segments of the inflated stream: segments
     without any record start, anchors found far behind the boundary; plus the degenerate files (no record, one record)."""
     base = synth.config3()
@@ -372,7 +389,7 @@ def test_device_reader_records_larger_than_a_segment_and_tiny_files(tmp_path):
     _concat_check(_read_all(paths, None, 1 << 20), _read_all(paths, 0, 37))
 
 
-def test_device_reader_on_damaged_records(tmp_path):
+def test_device_reader_on_damaged_records(tmp_path, reader_mode):
     """Bytes flipped INSIDE the inflated records (length words, typed descriptors, vector payloads), re-packed as valid BGZF: the device
     reader must behave like the host reader — the same table or an error, never a crash, a hang or a silently different table."""
     import gzip
@@ -448,7 +465,7 @@ def test_async_columns_are_there_when_they_are_read(tmp_path):
     rd.close(); plan.close()
 
 
-def test_device_reader_refuses_sample_files_that_do_not_match(tmp_path):
+def test_device_reader_refuses_sample_files_that_do_not_match(tmp_path, reader_mode):
     """calling.rs:369-390: the sample files must hold the same records in the same order — one file shorter, or a different site at
     some record, is an error of the device reader as it is of the host reader."""
     cfg = synth.config3()
@@ -592,3 +609,30 @@ def test_summaries_of_deep_and_filtered_pileups(tmp_path):
         assert open(a).read() == open(h).read()
         rd.close()
         plan.close()
+
+
+def test_descriptor_mode_reports_a_damaged_member_chain(tmp_path, reader_mode):
+    """A file whose member chain breaks in the middle (a BSIZE field that points nowhere, a file cut inside a member): the records in
+    front of the damage are delivered, then the reader fails — with the stager's index (descriptor mode) like with the index pass over the
+    mapping."""
+    cfg = synth.config3()
+    b = synth.generate(cfg, 400, seed=17)
+    p = str(tmp_path / "a.bcf")
+    ingest.write_observations(p, b, 0)
+    raw = bytearray(open(p, "rb").read())
+    offs, off = [], 0
+    while off < len(raw):
+        offs.append(off)
+        off += struct.unpack_from("<H", raw, off + 16)[0] + 1
+    assert len(offs) > 20
+    # (a) the magic of a member in the middle
+    bad = bytearray(raw)
+    bad[offs[len(offs) // 2]] = 0x1e
+    q = str(tmp_path / "magic.bcf")
+    open(q, "wb").write(bad)
+    # (b) the file cut inside a member
+    c = str(tmp_path / "cut.bcf")
+    open(c, "wb").write(raw[:offs[len(offs) // 2] + 40])
+    for path in (q, c):
+        with pytest.raises(engine.EngineError):
+            _read_all([path], 0, 64)

@@ -152,7 +152,8 @@ def test_native_calls_writer_reproduces_the_reference_calls_file(oracle, golden_
 
 
 def test_ingest_throughput_is_reported(tmp_path, capsys):
-    """Not a benchmark (8 cores here): the native reader must be far above the Python decoder's ~900 records/s."""
+    """Not a benchmark (8 cores here, shared with whatever else the suite left running: 4 700 to 8 300 records/s were seen for the same
+    build): the native reader must be well above the Python decoder's ~900 records/s."""
     import time
     cfg = synth.config3()
     b = synth.generate(cfg, 4000, seed=5)
@@ -167,7 +168,7 @@ def test_ingest_throughput_is_reported(tmp_path, capsys):
     assert r.n_loci == 4000
     rate = r.n_loci / dt
     print("native ingest: %.0f records/s (%d threads)" % (rate, os.cpu_count()))
-    assert rate > 5000
+    assert rate > 2500
 
 
 def test_container_variants_and_damaged_files(tmp_path, golden_dir):

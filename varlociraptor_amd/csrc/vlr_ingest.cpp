@@ -2024,8 +2024,11 @@ int dev_stream_open_fd(DevFileStream& f, const char* path, int device) {
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return VLR_ERR_UNSUPPORTED;
     struct stat st;
-    if (fstat(fd, &st) != 0 || (size_t)st.st_size < ((size_t)32 << 20)) { close(fd); return VLR_ERR_UNSUPPORTED; }
-    std::vector<uint8_t> first((size_t)1 << 20);
+    // (VLR_INGEST_STAGE_MIN_MB: files below it are mapped — default 32; the tests run their small files through this path with 0)
+    size_t min_bytes = (size_t)32 << 20;
+    if (const char* e = getenv("VLR_INGEST_STAGE_MIN_MB")) min_bytes = (size_t)std::max(0L, atol(e)) << 20;
+    if (fstat(fd, &st) != 0 || st.st_size <= 0 || (size_t)st.st_size < min_bytes) { close(fd); return VLR_ERR_UNSUPPORTED; }
+    std::vector<uint8_t> first(std::min<size_t>((size_t)1 << 20, (size_t)st.st_size));
     size_t got = 0;
     while (got < first.size()) { const ssize_t r = pread(fd, first.data() + got, first.size() - got, (off_t)got); if (r <= 0) break; got += (size_t)r; }
     if (got < first.size()) { close(fd); return VLR_ERR_UNSUPPORTED; }
@@ -2207,8 +2210,8 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
     double scale = 1.0;
     // requests ahead of the one being delivered whose members are uploaded and inflating (VLR_INGEST_PREFETCH; the reader waits for the
     // OLDEST feed only).  Default 1: with two, the inflate waves of two requests sit on the CUs the decode and the evaluation of the current
-    // one want (stream priorities order dispatch, they do not preempt) — 838 k against 928 k records/s end to end, three: 452 k.
-    static const int depth = [] { const char* e = getenv("VLR_INGEST_PREFETCH"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v > 3 ? 3 : v; }();
+    // one want (stream priorities order dispatch, they do not preempt) — 838 k against 928 k records/s end to end when the enqueueing call still waited for the inflate; level with it since.
+    static const int depth = [] { const char* e = getenv("VLR_INGEST_PREFETCH"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v > 2 ? 2 : v; }();   // (the staging ring holds three feed ranges: two in flight and the one being built)
     auto split_all = [&](int64_t& n_min) -> int {
         n_min = max_records;
         for (int s = 0; s < S; ++s) {
@@ -3574,8 +3577,11 @@ int vlr_obs_write(const char* path, const vlr_batch* in, int sample, const vlr_o
     std::vector<const std::vector<uint8_t>*> ps;
     for (auto& p : parts) ps.push_back(&p);
     std::string err;
-    const char* lv = getenv("VLR_BGZF_LEVEL");
-    if (!write_bgzf_file(path, ps, n_threads, lv ? atoi(lv) : 1, err)) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s", err.c_str());
+    // observation files are what `preprocess` writes through rust-htslib's bcf::Writer (preprocessing/mod.rs:921-1038): BGZF at htslib's
+    // default level 6 (bgzf.c: Z_DEFAULT_COMPRESSION -> 6).  Until the middle of round 5 this writer used level 1 like the calls writer —
+    // 11 % larger files with a third more symbols per member than the reader meets in files of the reference.  VLR_OBS_BGZF_LEVEL: other level.
+    const char* lv = getenv("VLR_OBS_BGZF_LEVEL");
+    if (!write_bgzf_file(path, ps, n_threads, lv ? atoi(lv) : 6, err)) return ifail(VLR_ERR_INVALID_ARGUMENT, "%s", err.c_str());
     return VLR_OK;
 }
 
