@@ -59,21 +59,26 @@ def inflate_mode(request):
         os.environ["VLR_INFLATE_BATCH"] = old
 
 
-@pytest.fixture(params=["mapped", "descriptor"])
+@pytest.fixture(params=["mapped", "descriptor", "descriptor, ring of 1.25 MB"])
 def reader_mode(request):
     """The two ways the device reader takes a file: mapped (small files, sharded readers) and descriptor mode (pread into the page-locked
     ring, member chain indexed there by the stager thread; files above 32 MB by default — VLR_INGEST_STAGE_MIN_MB=0 sends the tests'
     small files through it)."""
-    old = os.environ.get("VLR_INGEST_STAGE_MIN_MB")
-    if request.param == "descriptor":
+    keys = ("VLR_INGEST_STAGE_MIN_MB", "VLR_INGEST_STAGE_SEG_KB")
+    old = {k: os.environ.get(k) for k in keys}
+    for k in keys:
+        os.environ.pop(k, None)
+    if request.param != "mapped":
         os.environ["VLR_INGEST_STAGE_MIN_MB"] = "0"
-    elif old is not None:
-        del os.environ["VLR_INGEST_STAGE_MIN_MB"]
+    if "ring" in request.param:
+        # twenty segments of 64 KB: the files wrap around the ring many times, a request takes several feeds, the reader has to give
+        # ranges back before the stager can go on (a request of 131 072 records against the default ring hung before this was handled)
+        os.environ["VLR_INGEST_STAGE_SEG_KB"] = "64"
     yield request.param
-    if old is None:
-        os.environ.pop("VLR_INGEST_STAGE_MIN_MB", None)
-    else:
-        os.environ["VLR_INGEST_STAGE_MIN_MB"] = old
+    for k in keys:
+        os.environ.pop(k, None)
+        if old[k] is not None:
+            os.environ[k] = old[k]
 
 
 def test_inflate_kernel_equals_zlib_on_every_block_type(inflate_mode):

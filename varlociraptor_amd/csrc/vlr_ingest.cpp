@@ -1707,9 +1707,13 @@ bool stream_next(FileStream& f, int64_t max_records, int n_threads, SampleFile& 
 // copies and returns at once.  Segment k (file bytes [k, k + 1) * kSeg from `base`) lives in slot k mod kSlots; a slot is rewritten once
 // everything below the segment that comes to it has been released (the reader releases what its waited-for feeds covered).
 struct StageRing {
-    static constexpr size_t kSeg = (size_t)8 << 20;
+    // twenty segments of 8 MB (VLR_INGEST_STAGE_SEG_KB: other segment size — the tests run rings of 1.25 MB so that their small files
+    // wrap around them many times)
+    static size_t seg_bytes() { const char* e = getenv("VLR_INGEST_STAGE_SEG_KB"); const long k = e ? atol(e) : 0; return k >= 16 ? (size_t)k << 10 : (size_t)8 << 20; }
+    const size_t kSeg = seg_bytes();
     static constexpr int kSlots = 20;
-    static constexpr size_t kMaxRange = 6 * kSeg - 2;   // the largest byte range of one feed the ring serves (three of them fit beside each other)
+    const size_t kMaxRange = 6 * kSeg - 2;   // the largest byte range of one feed the ring serves (three of them fit beside each other)
+    static size_t max_range() { return 6 * seg_bytes() - 2; }
     const uint8_t* src = nullptr;       // a mapped file ...
     int fd = -1;                        // ... or a descriptor: pread straight into the ring, the file is never mapped (see index below)
     size_t size = 0, base = 0;          // the file bytes, where staging starts
@@ -1730,7 +1734,7 @@ struct StageRing {
     bool start(const uint8_t* file, size_t file_size, size_t from) {
         {
             std::lock_guard<std::mutex> g(pool_mu());
-            if (!pool().empty()) { ring = pool().back(); pool().pop_back(); }
+            if (!pool().empty() && kSeg == ((size_t)8 << 20)) { ring = pool().back(); pool().pop_back(); }
         }
         if (!ring) ring = (uint8_t*)vlr_host_alloc(kSeg * kSlots);
         if (!ring) return false;
@@ -1742,7 +1746,7 @@ struct StageRing {
     bool start_fd(int file, size_t file_size) {
         {
             std::lock_guard<std::mutex> g(pool_mu());
-            if (!pool().empty()) { ring = pool().back(); pool().pop_back(); }
+            if (!pool().empty() && kSeg == ((size_t)8 << 20)) { ring = pool().back(); pool().pop_back(); }
         }
         if (!ring) ring = (uint8_t*)vlr_host_alloc(kSeg * kSlots);
         if (!ring) return false;
@@ -1836,6 +1840,12 @@ struct StageRing {
         return n;
     }
     bool fits(size_t a, size_t b) const { return ring && a >= base && b > a && b - a <= kMaxRange; }
+    // staging up to file offset b overwrites nothing at or above `released`
+    bool can_stage(size_t b) {
+        std::lock_guard<std::mutex> lk(mu);
+        const size_t top = (b - base + kSeg - 1) / kSeg * kSeg + base;
+        return top <= released - released % kSeg + kSeg * kSlots;
+    }
     void release(size_t upto) {
         { std::lock_guard<std::mutex> lk(mu); if (upto > released) released = upto; }
         cv.notify_all();
@@ -1846,7 +1856,12 @@ struct StageRing {
             cv.notify_all();
             th.join();
         }
-        if (ring) { std::lock_guard<std::mutex> g(pool_mu()); if (pool().size() < 8) pool().push_back(ring); else vlr_host_free(ring); ring = nullptr; }
+        if (ring) {
+            std::lock_guard<std::mutex> g(pool_mu());
+            if (pool().size() < 8 && kSeg == ((size_t)8 << 20)) pool().push_back(ring);
+            else vlr_host_free(ring);
+            ring = nullptr;
+        }
     }
     ~StageRing() { shutdown(); }
 };
@@ -2135,15 +2150,24 @@ int dev_stream_feed(DevFileStream& f, uint64_t want, uint64_t piece = ~0ull) {
             while (b1 < f.blocks.size() && b1 < f.block_limit && ((have + add < goal() && add < piece) || b1 == b0) && b1 - b0 < (1u << 20)) {
                 const BgzfBlock& k = f.blocks[b1];
                 // (a feed from the staging ring is one byte range the ring holds at once)
-                if (f.stage && b1 > b0 && (k.off + k.clen) - f.blocks[b0].off > StageRing::kMaxRange) break;
+                if (f.stage && b1 > b0 && (k.off + k.clen) - f.blocks[b0].off > StageRing::max_range()) break;
                 vlr::InflateBlock x;
                 x.src = k.off - f.blocks[b0].off; x.dst = add; x.clen = (uint32_t)k.clen; x.isize = k.isize; x.crc = k.crc; x.pad = 0;
                 f.ib.push_back(x);
                 add += k.isize;
                 ++b1;
             }
-            // descriptor mode: the members behind the indexed ones, once the stager has walked them
-            if (f.streaming && !f.index_done && b1 == f.blocks.size() && ((have + add < goal() && add < piece) || b1 == b0)) { f.harvest(true); continue; }
+            // descriptor mode: the members behind the indexed ones.  With members in hand the feed goes with them (the next one takes the
+            // rest); with none the stager has to get on: it may be waiting for room in the ring, which only completed feeds give back
+            if (f.streaming && !f.index_done && b1 == f.blocks.size() && b1 == b0) {
+                f.harvest(false);
+                if (b1 < f.blocks.size() || f.index_done) continue;
+                if (vlr_dev_file_feeds_in_flight(f.dev) > 0) { const int rcw = vlr_dev_file_feed_wait_oldest(f.dev); if (rcw != VLR_OK) return rcw; }
+                while ((int)f.fed_begin.size() > vlr_dev_file_feeds_in_flight(f.dev)) f.fed_begin.pop_front();
+                f.stage->release(!f.fed_begin.empty() ? f.fed_begin.front() : f.blocks.empty() ? 0 : f.blocks.back().off + f.blocks.back().clen);
+                if (vlr_dev_file_feeds_in_flight(f.dev) == 0) f.harvest(true);
+                continue;
+            }
             break;
         }
         if (f.streaming && f.index_done && !f.index_err.empty() && b1 == f.blocks.size())
@@ -2159,6 +2183,14 @@ int dev_stream_feed(DevFileStream& f, uint64_t want, uint64_t piece = ~0ull) {
             // what the feeds that are no longer in flight covered may be overwritten in the ring
             while ((int)f.fed_begin.size() > vlr_dev_file_feeds_in_flight(f.dev)) f.fed_begin.pop_front();
             f.stage->release(f.fed_begin.empty() ? fa : f.fed_begin.front());
+            // the ring holds three ranges: with more feeds in flight (a request of several feeds) the oldest ones are waited for until the
+            // stager may write up to the end of this one — the reader would otherwise wait for bytes the stager has no room for
+            while (!f.stage->can_stage(fb) && vlr_dev_file_feeds_in_flight(f.dev) > 0) {
+                const int rcw = vlr_dev_file_feed_wait_oldest(f.dev);
+                if (rcw != VLR_OK) return rcw;
+                while ((int)f.fed_begin.size() > vlr_dev_file_feeds_in_flight(f.dev)) f.fed_begin.pop_front();
+                f.stage->release(f.fed_begin.empty() ? fa : f.fed_begin.front());
+            }
             const uint8_t* pp[8]; size_t pl[8];
             const int np = f.stage->pieces(fa, fb, pp, pl);
             rc = vlr_dev_file_feed_pieces(f.dev, pp, pl, np, f.ib.data(), (int)f.ib.size(), add);
@@ -2513,7 +2545,10 @@ static int open_device_impl(int device, int n_samples, const char* const* paths,
         const bool staged = allow_stage && !(e && atoi(e) == 0);
         auto open_one = [&, staged](int s) {
             int rc = staged ? dev_stream_open_fd(*r->dfiles[(size_t)s], paths[s], device) : VLR_ERR_UNSUPPORTED;
-            if (rc == VLR_ERR_UNSUPPORTED && !r->dfiles[(size_t)s]->streaming) rc = dev_stream_open(*r->dfiles[(size_t)s], paths[s], device);
+            if (rc == VLR_ERR_UNSUPPORTED && !r->dfiles[(size_t)s]->streaming) {
+                r->dfiles[(size_t)s].reset(new DevFileStream());   // (whatever the first attempt parsed is dropped with it)
+                rc = dev_stream_open(*r->dfiles[(size_t)s], paths[s], device);
+            }
             rcs[(size_t)s] = rc;
             if (rc != VLR_OK) errs[(size_t)s] = vlr_last_error();
         };
