@@ -1489,6 +1489,29 @@ int vlr_dev_file_copy_detached(vlr_dev_file* f, void* dst, const void* src, size
     *event_out = (void*)ev;
     return VLR_OK;
 }
+// more bytes of the same group: enqueued on the copy stream without an event of their own (a vlr_dev_file_copy_detached behind them marks
+// the end of the group)
+int vlr_dev_file_copy_more(vlr_dev_file* f, void* dst, const void* src, size_t bytes) {
+    VLR_HIP_OK(hipSetDevice(f->device));
+    if (!f->copy_stream) VLR_HIP_OK(hipStreamCreateWithFlags(&f->copy_stream, hipStreamNonBlocking));
+    if (bytes) VLR_HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, f->copy_stream));
+    return VLR_OK;
+}
+// what the copy stream has been given so far, as a mark the file's main stream can wait for before it overwrites the sources (*mark is
+// created on first use and owned by the caller: vlr_dev_event_destroy)
+int vlr_dev_file_copy_mark(vlr_dev_file* f, void** mark) {
+    VLR_HIP_OK(hipSetDevice(f->device));
+    if (!f->copy_stream) VLR_HIP_OK(hipStreamCreateWithFlags(&f->copy_stream, hipStreamNonBlocking));
+    if (!*mark) { hipEvent_t ev = nullptr; VLR_HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); *mark = (void*)ev; }
+    VLR_HIP_OK(hipEventRecord((hipEvent_t)*mark, f->copy_stream));
+    return VLR_OK;
+}
+int vlr_dev_file_wait_mark(vlr_dev_file* f, void* mark) {
+    if (!mark) return VLR_OK;
+    VLR_HIP_OK(hipSetDevice(f->device));
+    VLR_HIP_OK(hipStreamWaitEvent(f->stream, (hipEvent_t)mark, 0));
+    return VLR_OK;
+}
 int vlr_dev_event_wait(int device, void* event) {
     if (!event) return VLR_OK;
     VLR_HIP_OK(hipSetDevice(device));

@@ -144,6 +144,11 @@ int vlr_launch_afd_text(const int32_t* d_count, const double* d_vaf, const doubl
 int vlr_dev_copy_to_host(int device, void* dst, const void* src, size_t bytes);
 // device -> host copy nobody waits for until vlr_dev_event_wait(*event_out) (the caller owns the event)
 int vlr_dev_file_copy_detached(vlr_dev_file* f, void* dst, const void* src, size_t bytes, void** event_out);
+// more copies of one group on the copy stream (no event of their own); a mark of what the copy stream has been given so far (created on
+// first use, owned by the caller) and the main stream waiting for one before it overwrites the sources
+int vlr_dev_file_copy_more(vlr_dev_file* f, void* dst, const void* src, size_t bytes);
+int vlr_dev_file_copy_mark(vlr_dev_file* f, void** mark);
+int vlr_dev_file_wait_mark(vlr_dev_file* f, void* mark);
 int vlr_dev_event_wait(int device, void* event);
 void vlr_dev_event_destroy(int device, void* event);
 // column storage of a table: `bytes` of device memory and as many page-locked host bytes

@@ -1932,6 +1932,7 @@ struct vlr_obs_reader {
     int shard = 0, n_shards = 1;
     int64_t remaining = 0;
     DevSlab sum_scratch;            // device side only in use: summary headers, entries, runs, cursors of the chunk being built
+    void* sum_copy_mark = nullptr;  // the detached copies of the last table's summaries: the next summary kernels wait for them (they reuse the scratch)
 };
 
 namespace { int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out); }
@@ -1998,6 +1999,7 @@ struct ParkedScratch { int device; DevSlab slab; };
 std::vector<ParkedScratch>& parked_scratch() { static auto* v = new std::vector<ParkedScratch>(); return *v; }
 }
 void vlr_obs_reader_close(vlr_obs_reader* r) {
+    if (r && r->sum_copy_mark) { vlr_dev_event_destroy(r->device, r->sum_copy_mark); r->sum_copy_mark = nullptr; }   // (waits: the scratch is parked or freed below)
     if (r && r->sum_scratch.d) {
         std::lock_guard<std::mutex> g(g_scratch_mu);
         auto& pk = parked_scratch();
@@ -2471,7 +2473,8 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
         dc.third = (int32_t*)((uint8_t*)t->slab.d + dl.off_third);
         uint32_t max_pile = 0;
         for (int64_t q = 0; q < P; ++q) max_pile = std::max(max_pile, obs_offset[(size_t)q + 1] - obs_offset[(size_t)q]);
-        rc = vlr_dev_file_summaries(f0.dev, &dc, (const uint32_t*)((uint8_t*)t->slab.d + dl.off_obs), (const uint8_t*)t->slab.d + dl.off_lflags, L, S, max_pile, &kc,
+        if (r->sum_copy_mark) rc = vlr_dev_file_wait_mark(f0.dev, r->sum_copy_mark);   // (the previous table's summaries may still be on their way out of the scratch)
+        if (rc == VLR_OK) rc = vlr_dev_file_summaries(f0.dev, &dc, (const uint32_t*)((uint8_t*)t->slab.d + dl.off_obs), (const uint8_t*)t->slab.d + dl.off_lflags, L, S, max_pile, &kc,
                                     (vlr::PileSum*)(sd + o_hdr), sd + o_txt, (uint32_t)text_cap, (float*)(sd + o_rpm), (uint32_t*)(sd + o_rln), (uint64_t*)(sd + o_ik),
                                     (uint32_t*)(sd + o_ic), (uint32_t*)(sd + o_tl), (uint32_t*)(sd + o_to), (uint32_t*)(sd + o_cur));
         uint32_t cur[4] = {0, 0, 0, 0};
@@ -2482,19 +2485,30 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
         uint8_t* hb = (uint8_t*)t->slab.h + dl.off_col[0];
         const size_t text_used = std::min<size_t>((size_t)cur[0], text_cap);
         const size_t h_rpm = up((size_t)P * sizeof(vlr::PileSum)), h_rln = h_rpm + up((size_t)cur[1] * 4), h_txt = h_rln + up((size_t)cur[1] * 4);
-        if (rc == VLR_OK) rc = vlr_dev_file_copy(f0.dev, hb, sd + o_hdr, (size_t)P * sizeof(vlr::PileSum), 0);
-        if (rc == VLR_OK) rc = vlr_dev_file_copy(f0.dev, hb + h_rpm, sd + o_rpm, (size_t)cur[1] * 4, 0);
-        if (rc == VLR_OK) rc = vlr_dev_file_copy(f0.dev, hb + h_rln, sd + o_rln, (size_t)cur[1] * 4, 0);
-        if (rc == VLR_OK) rc = vlr_dev_file_copy(f0.dev, hb + h_txt, sd + o_txt, text_used, 0);
-        if (rc == VLR_OK) rc = vlr_dev_file_sync(f0.dev);
+        if (r->async_columns) {
+            // like the columns (vlr_obs_reader_set_async_columns): the summaries travel on the copy stream while the reader goes on — the
+            // writer and everything else that reads them waits for the table's event; the next summary kernels wait for the mark
+            if (rc == VLR_OK) rc = vlr_dev_file_copy_more(f0.dev, hb, sd + o_hdr, (size_t)P * sizeof(vlr::PileSum));
+            if (rc == VLR_OK) rc = vlr_dev_file_copy_more(f0.dev, hb + h_rpm, sd + o_rpm, (size_t)cur[1] * 4);
+            if (rc == VLR_OK) rc = vlr_dev_file_copy_more(f0.dev, hb + h_rln, sd + o_rln, (size_t)cur[1] * 4);
+            void* ev = nullptr;
+            if (rc == VLR_OK) rc = vlr_dev_file_copy_detached(f0.dev, hb + h_txt, sd + o_txt, text_used, &ev);
+            if (rc == VLR_OK) rc = vlr_dev_file_copy_mark(f0.dev, &r->sum_copy_mark);
+            if (rc == VLR_OK) { std::lock_guard<std::mutex> g(t->cols_mu); t->cols_event = ev; }
+            else if (ev) vlr_dev_event_destroy(r->device, ev);
+        } else {
+            if (rc == VLR_OK) rc = vlr_dev_file_copy(f0.dev, hb, sd + o_hdr, (size_t)P * sizeof(vlr::PileSum), 0);
+            if (rc == VLR_OK) rc = vlr_dev_file_copy(f0.dev, hb + h_rpm, sd + o_rpm, (size_t)cur[1] * 4, 0);
+            if (rc == VLR_OK) rc = vlr_dev_file_copy(f0.dev, hb + h_rln, sd + o_rln, (size_t)cur[1] * 4, 0);
+            if (rc == VLR_OK) rc = vlr_dev_file_copy(f0.dev, hb + h_txt, sd + o_txt, text_used, 0);
+            if (rc == VLR_OK) rc = vlr_dev_file_sync(f0.dev);
+        }
         if (rc != VLR_OK) { vlr_obs_table_free(t); *out = nullptr; return rc; }
         t->cols_on_host = false;
         t->has_summary = true;
         {   // pileups the kernel could not summarise (more than kSumMaxObs observations, or no room left for their text) need the columns
-            // after all: when they are more than a few, fetch them now and stop summarising this file
-            int64_t n_over = 0;
-            const vlr::PileSum* hh = (const vlr::PileSum*)hb;
-            for (int64_t q = 0; q < P; ++q) n_over += hh[q].overflow != 0;
+            // after all: when they are more than a few (the kernels count them: cursor[2]), fetch them now and stop summarising this file
+            const int64_t n_over = (int64_t)cur[2];
             if (n_over * 50 > P) {
                 r->summaries_off = true;
                 rc = vlr_obs_table_fetch_columns(t);
@@ -2787,6 +2801,7 @@ int vlr_node_obs_readers_open(vlr_gpu_node* node, int n_samples, const char* con
 int vlr_obs_table_summaries(const vlr_obs_table* t, int64_t* n_overflow) {
     if (n_overflow) *n_overflow = 0;
     if (!t || !t->has_summary) return 0;
+    if (n_overflow && const_cast<vlr_obs_table*>(t)->wait_columns() != VLR_OK) return 0;   // (the headers may still be on their way)
     if (n_overflow)
         for (int64_t p = 0; p < t->n_loci * t->n_samples; ++p) *n_overflow += t->sum_hdr[p].overflow != 0;
     return 1;
