@@ -2332,6 +2332,8 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
         if (rc == VLR_OK) rc = vlr_dev_file_sync(f0.dev);
         if (rc != VLR_OK) return fail(rc);
     }
+    g_dev_t[0] += now_s() - t_dec0;   // (decode_offsets_up)
+    const double t_launch0 = now_s();
     vlr::DeviceCols cols;
     for (int k = 0; k < 9; ++k) cols.col[k] = (float*)(d + dl.off_col[k]);
     cols.flags = (uint32_t*)(d + dl.off_flags);
@@ -2348,6 +2350,7 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
         rc = vlr_dev_file_cold(f.dev, L, f.cold_off.data(), f.cold.data());
         if (rc != VLR_OK) return fail(rc);
     }
+    g_dev_t[1] += now_s() - t_launch0;   // (decode_launch: decode + cold kernels and copies enqueued)
     // the per-record flags the table needs from the scan (before the decode's error pass overwrites the host copy)
     std::vector<std::vector<uint32_t>> n_obs_of((size_t)S), flags_of((size_t)S);
     for (int s = 0; s < S; ++s) {
@@ -2374,6 +2377,7 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
         }
         g_dev_t[2] += now_s() - tf;
     }
+    const double t_err0 = now_s();
     for (int s = 0; s < S; ++s) {
         uint32_t st = 0;
         int64_t bad = -1;
@@ -2381,6 +2385,7 @@ int dev_reader_next(vlr_obs_reader* r, int64_t max_records, vlr_obs_table** out)
         if (rc != VLR_OK) return fail(rc);
         if (st) return fail(ifail(VLR_ERR_INVALID_ARGUMENT, "%s (record %lld of %s)", rec_status_text(st), (long long)(r->dfiles[(size_t)s]->delivered + bad + 1), r->paths[(size_t)s].c_str()));
     }
+    g_dev_t[15] += now_s() - t_err0;   // (decode_wait: the decode and cold kernels of both files)
     g_dev_t[5] += now_s() - t_dec0;
     const double t_d2h0 = now_s();
     // the per-pileup summaries — P headers, the OBS text, at most one run per observation — are brought down INTO the host side of the

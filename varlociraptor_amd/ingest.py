@@ -203,7 +203,7 @@ def device_timings(reset: bool = False) -> dict:
     L.vlr_ingest_device_timings.restype = None
     L.vlr_ingest_device_timings.argtypes = [C.POINTER(C.c_double), C.c_int]
     L.vlr_ingest_device_timings(a, int(reset))
-    k = [None, None, "feed_inflate", "split_scan", None, "decode", "copy_back", "host_table", "total", "inflated_bytes", "compressed_bytes", "records", "serial_walks", "inflate_kernel", "feed_call"]
+    k = ["decode_offsets_up", "decode_launch", "feed_inflate", "split_scan", None, "decode", "copy_back", "host_table", "total", "inflated_bytes", "compressed_bytes", "records", "serial_walks", "inflate_kernel", "feed_call", "decode_wait"]
     return {n: a[i] for i, n in enumerate(k) if n}
 
 
