@@ -2831,6 +2831,11 @@ void vlr_ingest_device_timings(double* out16, int reset) {
 
 void vlr_ingest_device_trim(void) {
     vlr_dev_file_trim();
+    {   // the page-locked staging rings closed readers left behind
+        std::lock_guard<std::mutex> g(StageRing::pool_mu());
+        for (uint8_t* q : StageRing::pool()) vlr_host_free(q);
+        StageRing::pool().clear();
+    }
     std::lock_guard<std::mutex> g(g_scratch_mu);
     for (auto& q : parked_scratch()) vlr_dev_slab_free(q.device, q.slab.d, q.slab.h);
     parked_scratch().clear();
