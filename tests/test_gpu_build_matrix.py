@@ -1,7 +1,8 @@
 """Build matrix: the engine's results must not depend on the register allocator.
 
 The same kernel source is run under register budgets of 2, 3, 4, 6 and 8 waves per SIMD (256 ... 64 VGPRs; the last two
-spill hundreds of registers), under -O1 and -O2, and with workgroup barriers in place of the wave-level LDS fences
+spill hundreds of registers), under -O1 and -O2, under another machine-scheduler strategy, and with workgroup barriers in place of the
+wave-level LDS fences
 (varlociraptor_amd/csrc/Makefile `matrix`).  Every (build, budget) evaluates the same seeded workloads in its own process
 (tools/matrix_run.py: edge-case pileups, BASELINE configs 2-5 incl. AFD lists, 24 fuzzer scenarios) and every output
 array — ln posteriors, marginals, MAP VAFs, bias codes, best events, status words, AFD lists — must be bit-identical
@@ -21,6 +22,7 @@ MATRIX = [  # (library, waves per SIMD)
     ("stress", "6"), ("stress", "8"),
     ("O1", "2"), ("O1", "3"), ("O2", "4"),   # (-O1 under the 128-VGPR cap: see csrc/Makefile and DESIGN.md "Build matrix")
     ("sync", "3"),
+    ("ilp", "3"),   # (max-ILP scheduling strategy without the opaque lane id: see csrc/Makefile and DESIGN.md "Build matrix")
 ]
 
 

@@ -197,6 +197,9 @@ __device__ __forceinline__ int fresh_lane(int lane) {
 #ifdef VLR_DBG_NO_FRESH_LANE
     return lane;
 #endif
+#ifdef VLR_FRESH_BPERMUTE   // the lane's own id through the LDS crossbar: opaque to the optimiser without inline assembly
+    return __builtin_amdgcn_ds_bpermute(lane << 2, lane);
+#endif
     asm volatile("" : "+v"(lane));
     return lane;
 }
@@ -239,6 +242,9 @@ __device__ __forceinline__ double dpp_f64(double v) {
     if (CTRL == 0xB1 || CTRL == 0x4E || CTRL == 0x141 || CTRL == 0x140 || CTRL == 0x124 || CTRL == 0x128) return __shfl(v, src_, 64);
 #endif
     int lo = __double2loint(v), hi = __double2hiint(v);
+#ifdef VLR_DBG_DPP_NOP  // diagnosis builds: wait states between whatever wrote the halves and the DPP reads
+    asm volatile("s_nop 7" : "+v"(lo), "+v"(hi));
+#endif
     // every lane has a valid source under these permutations: bound_ctrl with an undefined `old` lets the compiler write the
     // destination directly instead of copying the source first (three instructions per f64 permute otherwise)
     lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
@@ -246,10 +252,18 @@ __device__ __forceinline__ double dpp_f64(double v) {
     return __hiloint2double(hi, lo);
 }
 template <int CTRL>
-__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+__device__ __forceinline__ int dpp_i32(int v) {
+#ifdef VLR_DBG_DPP_NOP
+    asm volatile("s_nop 7" : "+v"(v));
+#endif
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
 __device__ __forceinline__ double lane_d(double v, int l) {
 #ifdef VLR_DBG_LANE_SHFL
     return __shfl(v, l, 64);
+#endif
+#ifdef VLR_DBG_DPP_NOP
+    { int lo_ = __double2loint(v), hi_ = __double2hiint(v); asm volatile("s_nop 7" : "+v"(lo_), "+v"(hi_)); v = __hiloint2double(hi_, lo_); }
 #endif
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
