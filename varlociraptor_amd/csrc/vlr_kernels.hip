@@ -193,6 +193,10 @@ __device__ __forceinline__ double uni_d(double v) {
 
 // The lane id as a value the optimiser cannot hoist: without it every lane-derived constant of the chain runners
 // ((double)(lane - 1), row masks, ...) is computed once before the hypothesis loop and then SPILLED across it.
+// (VLR_FRESH_MASK: diagnosis builds keep the opaque id only at the call sites whose bit is set — the sites are numbered in source order)
+#ifndef VLR_FRESH_MASK
+#define VLR_FRESH_MASK 0xffffffffu
+#endif
 __device__ __forceinline__ int fresh_lane(int lane) {
 #ifdef VLR_DBG_NO_FRESH_LANE
     return lane;
@@ -1156,7 +1160,7 @@ __device__ inline int log_begin(Ctx& c, int kind, int n, int s_in, int disc, int
     const int at = log_reserve(c, 1 + S + 2 * nl + payload_words);
     if (at < 0) return -1;
     WaveSt* w = c.w;
-    const int lane = fresh_lane(c.lane);  // keeps the lane-derived offsets below out of registers that live across the kernel
+    const int lane = (((VLR_FRESH_MASK >> 0) & 1u) ? fresh_lane(c.lane) : (c.lane));  // keeps the lane-derived offsets below out of registers that live across the kernel
     if (lane == 0) c.lg[at] = __longlong_as_double(log_header(kind, n, s_in, disc, c.group, nl));
     if (lane < S) c.lg[at + 1 + lane] = w->ops_vaf[lane];
     if (lane < nl) {
@@ -1172,7 +1176,7 @@ __device__ inline void log_leaf(Ctx& c, double joint) {
 __device__ inline void log_table(Ctx& c, int s_in, const double* tx, const double* tv, int n) {  // a single chain, all 64 lanes
     const int at = log_begin(c, 1, n, s_in, c.disc & ~(1 << s_in), 2 * n);
     if (at < 0) return;
-    for (int i = fresh_lane(c.lane); i < n; i += 64) { c.lg[at + i] = tx[i]; c.lg[at + n + i] = tv[i]; }
+    for (int i = (((VLR_FRESH_MASK >> 1) & 1u) ? fresh_lane(c.lane) : (c.lane)); i < n; i += 64) { c.lg[at + i] = tx[i]; c.lg[at + n + i] = tv[i]; }
 }
 
 // ---- all-discrete roots (DevDLeaf): every leaf of the root on its own lane --------------------------------------
@@ -1204,7 +1208,7 @@ __device__ inline int dleaf_wave_best(const DevDLeaf* leaves, double bJ, int bL,
 __device__ inline double eval_discrete_root(Ctx& c, int l0, int l1) {
     const DevPlan& p = *c.plan;
     WaveSt* w = c.w;
-    const int lane = fresh_lane(c.lane), S = c.S;
+    const int lane = (((VLR_FRESH_MASK >> 2) & 1u) ? fresh_lane(c.lane) : (c.lane)), S = c.S;
     const DevDLeaf* leaves = p.dleaf;
     unsigned cr = 0;
     for (int s = 0; s < S; ++s)
@@ -1574,7 +1578,7 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
 #endif
     const DevPlan& p = *c.plan;
     WaveSt* w = c.w;
-    const int lane = fresh_lane(c.lane);
+    const int lane = (((VLR_FRESH_MASK >> 3) & 1u) ? fresh_lane(c.lane) : (c.lane));
     const int inner = UNI(rl.sample);
     const double lo = uni_d(rl.lo), hi = uni_d(rl.hi), res = uni_d(rl.res);
     const RangeV orig{uni_d(rl.ostart), uni_d(rl.oend), UNI(rl.olex), UNI(rl.orex)};
@@ -1982,7 +1986,7 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
     PROF_ADD(c, 7);  // batch prologue (task fields, coefficient registers)
     for (;;) {
         PROF_ADD(c, 15);
-        const int rl = fresh_lane(rl0);  // lane masks (rl == 1, rl < nn, ...) are recomputed: one compare each instead of two lane reads of a spilled pair
+        const int rl = (((VLR_FRESH_MASK >> 4) & 1u) ? fresh_lane(rl0) : (rl0));  // lane masks (rl == 1, rl < nn, ...) are recomputed: one compare each instead of two lane reads of a spilled pair
         double px0, px1, px2;
         int nn;
         bool on;
@@ -2287,7 +2291,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
 #endif
     const DevPlan& p = *c.plan;
     WaveSt* w = c.w;
-    const int lane = fresh_lane(c.lane), row = lane >> 4, rl = lane & 15;
+    const int lane = (((VLR_FRESH_MASK >> 5) & 1u) ? fresh_lane(c.lane) : (c.lane)), row = lane >> 4, rl = lane & 15;
     const bool rowon = (rowmask >> row) & 1;
     const int cap = c.cap;
     VLR_WAVE_FENCE();
@@ -2848,7 +2852,7 @@ __device__ __forceinline__ bool bo_setup(Ctx& c, const Frame& f, RangeSt& r) {
     const DevPlan& p = *c.plan;
     WaveSt* w = c.w;
     const BatchOuter& B = w->bo;
-    const int lane = fresh_lane(c.lane), S = c.S;
+    const int lane = (((VLR_FRESH_MASK >> 6) & 1u) ? fresh_lane(c.lane) : (c.lane)), S = c.S;
     const int np = UNI(B.np), c0 = UNI(B.c0), s_in = UNI(B.s_in), s_out = UNI(B.s_out), chn = UNI(B.chn);
     const bool dead = UNI(B.dead) != 0;
     const int free_rows = kRows - c.nhold;  // held event-level chains keep the top rows (they ride along with this batch)
@@ -2921,7 +2925,7 @@ __device__ __forceinline__ bool bo_setup(Ctx& c, const Frame& f, RangeSt& r) {
 __device__ __forceinline__ bool bo_deliver(Ctx& c, const Frame& f, RangeSt& r, double* txo, double* tvo) {
     WaveSt* w = c.w;
     const BatchOuter& B = w->bo;
-    const int lane = fresh_lane(c.lane);
+    const int lane = (((VLR_FRESH_MASK >> 7) & 1u) ? fresh_lane(c.lane) : (c.lane));
     const int np = UNI(B.np), c0 = UNI(B.c0), nt = UNI(B.nt), s_in = UNI(B.s_in), s_out = UNI(B.s_out);
     const bool dead = UNI(B.dead) != 0;
     PROF_ADD(c, 24);  // walk: resume up to the delivery
@@ -3012,7 +3016,7 @@ __device__ __forceinline__ void flush_deliver(Ctx& c, int rowmask, double* evM, 
 // one chain task with its operands from row `from` (or the stash: from < 0) to row `to` (or the stash: to < 0)
 __device__ __forceinline__ void move_task(Ctx& c, int from, int to) {
     WaveSt* w = c.w;
-    const int lane = fresh_lane(c.lane);
+    const int lane = (((VLR_FRESH_MASK >> 8) & 1u) ? fresh_lane(c.lane) : (c.lane));
     constexpr int NW = (int)(sizeof(ChainTask) / 8);
     static_assert(sizeof(ChainTask) % 8 == 0, "ChainTask is copied in 8-byte words");
     const double* src = (const double*)(from < 0 ? &w->stash : &w->task[from]);
@@ -3035,7 +3039,7 @@ __device__ __forceinline__ void move_task(Ctx& c, int from, int to) {
 __device__ __forceinline__ int fast_chain_root(Ctx& c, const DevFastRoot* fr) {
     const DevPlan& p = *c.plan;
     WaveSt* w = c.w;
-    const int lane = fresh_lane(c.lane), S = c.S;
+    const int lane = (((VLR_FRESH_MASK >> 9) & 1u) ? fresh_lane(c.lane) : (c.lane)), S = c.S;
     const int n_fixed = ldc(&fr->n_fixed), inner = ldc(&fr->inner);
     // the fixed values, one per lane (lane k < n_fixed: node k of the path)
     const int kf = lane < n_fixed ? lane : 0;
