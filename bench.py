@@ -104,6 +104,28 @@ def traffic_for(workload, n_units, build_id):
     return tj.get("hbm_bytes_per_launch")
 
 
+SIMDS = 256 * 4          # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
+SHADER_CLOCK_HZ = 2.4e9  # peak engine clock
+VALU_CYCLES_PER_INST = 4  # a wave64 VALU instruction occupies its SIMD's 16 lanes for four cycles (f64 FMA / MUL / ADD: full rate on this part)
+
+
+def valu_for(workload, build_id, n_loci, kernel_ms):
+    """The binding resource of the call kernel from the PMC stamp under profiles/ (tools/valu_stamp.py) — only if it was taken from
+    THIS build: VALU issue cycles of the launch over the SIMD cycles it had (valu_busy), the share of f64 FMA / MUL / ADD among the
+    VALU instructions (f64_share), and the instruction counts they come from.  None without a stamp of this build."""
+    vpath = os.path.join(ROOT, "profiles", "valu_%s.json" % workload)
+    if not os.path.exists(vpath):
+        return None
+    with open(vpath) as fh:
+        vj = json.load(fh)
+    if vj.get("build_id") != build_id:
+        return None
+    per = vj["per_locus"]
+    busy = per["valu_insts"] * VALU_CYCLES_PER_INST * n_loci / (SIMDS * SHADER_CLOCK_HZ * kernel_ms * 1e-3)
+    return {"valu_busy": busy, "f64_share": vj["f64_share"], "valu_insts_per_locus": per["valu_insts"], "salu_insts_per_locus": per["salu_insts"],
+            "lane_utilisation": vj.get("lane_utilisation"), "stamp": "profiles/valu_%s.json (%d loci)" % (workload, vj["n_units"])}
+
+
 def reference_binary_baseline(cfg, batch, n_loci, cores):
     """BASELINE.md §2 / SURVEY §8(d): if a `varlociraptor` executable is on the box, time the REFERENCE's own `call variants` on
     observation BCFs written from the first `n_loci` loci of the same synthetic batch, one process per effective CPU over
@@ -686,6 +708,7 @@ def main():
         norm_err = float(np.abs(ps[ok].sum(axis=1) - 1.0).max()) if ok.any() else None
         terms_per_launch = n_terms / max(1, args.steps)
         tflops = terms_per_launch * FLOP_PER_TERM / (last_ms * 1e-3) / 1e12
+        vstamp = valu_for(args.workload, engine.build_id(), n_loci, last_ms) or {}
         line = {
             "metric": "candidate loci/sec (whole node)", "value": n_total * args.steps / elapsed, "unit": "loci/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -701,7 +724,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic_for(args.workload, n_loci, engine.build_id()),
                          "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": last_ms,
-                         "note": "path is f64-VALU bound, not bandwidth bound (SURVEY §8d): see valu",
+                         "note": "path is f64-VALU bound, not bandwidth bound (SURVEY §8d): valu_busy = VALU issue cycles / SIMD cycles of the launch, f64_share = f64 FMA+MUL+ADD / VALU instructions (PMC stamp of this build under profiles/, null without one), f64_flops_frac = 3 flops per observation term / 78.6 TFLOP/s",
+                         "valu_busy": vstamp.get("valu_busy"), "f64_share": vstamp.get("f64_share"), "f64_flops_frac": tflops / F64_VALU_PEAK_TFLOPS,
+                         "valu_insts_per_locus": vstamp.get("valu_insts_per_locus"), "salu_insts_per_locus": vstamp.get("salu_insts_per_locus"),
+                         "lane_utilisation": vstamp.get("lane_utilisation"), "valu_stamp": vstamp.get("stamp"),
                          "valu": {"pileup_evals_per_launch": n_eval // max(1, args.steps), "obs_terms_per_launch": int(terms_per_launch),
                                   "terms_per_s": terms_per_launch / (last_ms * 1e-3), "flop_per_term": FLOP_PER_TERM,
                                   "achieved_tflops": tflops, "peak_tflops": F64_VALU_PEAK_TFLOPS, "frac": tflops / F64_VALU_PEAK_TFLOPS}},

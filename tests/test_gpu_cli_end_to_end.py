@@ -376,3 +376,45 @@ def test_bench_step_through_rccl_on_one_gpu(tmp_path):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["collective"].startswith("rccl") and line["n_gpus"] == 1 and line["value"] > 0
     assert line["posterior_normalisation_max_err"] < 1e-9
+
+
+def test_cli_two_ranks_fail_together_when_one_shard_holds_a_breakend_event(golden_dir, tmp_path):
+    """the sharded front door refuses files with breakend events (they reach across shard boundaries,
+    calling.rs:569-580) — and only the rank whose shard holds such a record notices.  Every rank must hear of it before anybody waits
+    at the barrier: both ranks end with an error within seconds (not after the collective's timeout), no part of the calls file and
+    no calls file is left behind."""
+    import glob
+    import subprocess
+    import sys
+    import time
+    from varlociraptor_amd.bcfio import BcfWriter
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(golden_dir, "flamegraph_profiling")
+    header, recs = [], []
+    k = 0
+    for l in open(os.path.join(d, "normal.vcf")).read().split("\n"):
+        if not l:
+            continue
+        if l.startswith("#"):
+            header.append(l)
+            continue
+        f = l.split("\t")
+        if k in (9, 10):   # the event lives in the LAST records: the second rank's shard alone
+            f[7] = "EVENT=grp1;" + f[7]
+        k += 1
+        recs.append("\t".join(f))
+    obs = str(tmp_path / "grouped.bcf")
+    with BcfWriter(obs, "\n".join(header)) as wr:
+        for r in recs:
+            wr.write_line(r)
+    out = tmp_path / "calls.bcf"
+    env = dict(os.environ, PYTHONPATH=root, VLR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29549", "-m", "varlociraptor_amd", "call", "variants", "--output", str(out), "generic",
+                        "--scenario", os.path.join(d, "scenario.yaml"), "--obs", "normal=" + obs],
+                       capture_output=True, text=True, cwd=root, env=env, timeout=600)
+    assert r.returncode != 0
+    assert "breakend events" in r.stderr
+    assert time.time() - t0 < 300, "the ranks waited for each other"
+    assert not out.exists() and not glob.glob(str(out) + "*"), glob.glob(str(tmp_path / "*"))

@@ -355,8 +355,11 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                     text_cap = 0
                     if (afd_capacity and len(reps) == L and (group_key is None or not np.any(group_key)) and os.environ.get("VLR_AFD_TEXT", "1") != "0"):
                         text_cap = min(L * S_ * 8 * afd_capacity, 0xffff0000)
+                    # (device text only where the native calls writer is the sole consumer of the lists — the pooled path and the sharded
+                    #  writer: a list that was formatted on the device is not copied down as numbers, and a caller of call_variants() that
+                    #  gets the CallResults of a single chunk back reads afd_vaf / afd_lnprob)
                     buf = (result_pool.results(L, n_out_, S_, afd_capacity, text_cap) if result_pool is not None
-                           else (CallResults(L, n_out_, S_, afd_capacity, afd_text_capacity=text_cap) if text_cap else None))
+                           else (CallResults(L, n_out_, S_, afd_capacity, afd_text_capacity=text_cap) if (text_cap and shard_state["on"]) else None))
                     r = plan.call_table_device(table, afd_capacity=afd_capacity, results=buf)
                 else:
                     r = plan.call_host(sub, afd_capacity=afd_capacity)
@@ -513,51 +516,57 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
         collected = []
         names = None
         used_contigs: List[str] = []
+        loop_exc: List[BaseException] = []   # sharded run: what went wrong on THIS rank (the others must hear of it before anybody waits)
         try:
-            while True:
-                item = q_in.get()
-                if item is None or errors:
-                    break
-                batch, sites = item
-                t0 = time.perf_counter()
-                contig_names = list(sites.contig_names)
-                contig_of = np.asarray(sites.contig, np.int64)
-                het_, som_ = batch.extra["prior_het_ln"], batch.extra["prior_som_ln"]
-                grep_, gkey_ = np.asarray(batch.extra["group_representative"], np.int64), np.asarray(batch.extra["group_key"], np.uint64)
-                if shard_state["on"] and ((gkey_ != 0).any() or np.isfinite(np.asarray(het_, np.float64)).any() or np.isfinite(np.asarray(som_, np.float64)).any()):
-                    # breakend events hand the FIRST record's result to the later ones, and per-variant prior overrides are installed from
-                    # the first record of a contig (calling.rs:569-580, 643-713): both reach across shard boundaries
-                    raise SystemExit("the sharded reader does not take files with breakend events or per-variant prior overrides: rerun with VLR_INGEST_SHARDED=0")
-                loci_ = np.arange(batch.n_loci)
-                ebatch = batch
-                if candidate_filter is not None:   # calling.rs:409: work items the filter rejects are not processed at all
-                    keep = np.asarray(candidate_filter.filter(batch, sites, sample_order), bool)
-                    if not keep.all():
-                        loci_ = np.nonzero(keep)[0]
-                        ebatch = batch.select(loci_)
-                        contig_of, het_, som_, gkey_ = contig_of[loci_], np.asarray(het_)[loci_], np.asarray(som_)[loci_], gkey_[loci_]
-                        # representatives among the records that are left: the first kept record of every group
-                        grep_ = np.arange(len(loci_))
-                        first_of: Dict[int, int] = {}
-                        for j_, k_ in enumerate(gkey_):
-                            if k_:
-                                grep_[j_] = first_of.setdefault(int(k_), j_)
-                res, nm = (evaluate(ebatch, contig_names, contig_of, het_, som_, grep_, gkey_) if ebatch.n_loci else (None, None))
-                names = names or nm
-                stage["call_s"] += time.perf_counter() - t0
-                stage["n_loci"] += batch.n_loci
-                stage["n_obs"] += batch.n_obs
-                if not used_contigs:
-                    used_contigs = contig_names if not is_text else [contig_names[int(c_)] for c_ in np.unique(np.asarray(sites.contig))]
-                collected.append(_fixed_fields(res) if (result_pool is not None and getattr(res, "_pool_block", None) is not None) else res)
-                if processor is not None:
-                    if res is not None and rank == 0:
-                        if not proc_state["setup"]:
-                            processor.setup(list(names), list(sample_order))
-                            proc_state["setup"] = True
-                        processor.process_calls(CallChunk(ebatch, sites, res, list(names), list(sample_order), loci_, stage["n_loci"] - batch.n_loci))
-                elif tw and res is not None:
-                    q_out.put((batch.extra["native_table"], res, names, used_contigs))
+          try:
+              while True:
+                  item = q_in.get()
+                  if item is None or errors:
+                      break
+                  batch, sites = item
+                  t0 = time.perf_counter()
+                  contig_names = list(sites.contig_names)
+                  contig_of = np.asarray(sites.contig, np.int64)
+                  het_, som_ = batch.extra["prior_het_ln"], batch.extra["prior_som_ln"]
+                  grep_, gkey_ = np.asarray(batch.extra["group_representative"], np.int64), np.asarray(batch.extra["group_key"], np.uint64)
+                  if shard_state["on"] and ((gkey_ != 0).any() or np.isfinite(np.asarray(het_, np.float64)).any() or np.isfinite(np.asarray(som_, np.float64)).any()):
+                      # breakend events hand the FIRST record's result to the later ones, and per-variant prior overrides are installed from
+                      # the first record of a contig (calling.rs:569-580, 643-713): both reach across shard boundaries
+                      raise SystemExit("the sharded reader does not take files with breakend events or per-variant prior overrides: rerun with VLR_INGEST_SHARDED=0")
+                  loci_ = np.arange(batch.n_loci)
+                  ebatch = batch
+                  if candidate_filter is not None:   # calling.rs:409: work items the filter rejects are not processed at all
+                      keep = np.asarray(candidate_filter.filter(batch, sites, sample_order), bool)
+                      if not keep.all():
+                          loci_ = np.nonzero(keep)[0]
+                          ebatch = batch.select(loci_)
+                          contig_of, het_, som_, gkey_ = contig_of[loci_], np.asarray(het_)[loci_], np.asarray(som_)[loci_], gkey_[loci_]
+                          # representatives among the records that are left: the first kept record of every group
+                          grep_ = np.arange(len(loci_))
+                          first_of: Dict[int, int] = {}
+                          for j_, k_ in enumerate(gkey_):
+                              if k_:
+                                  grep_[j_] = first_of.setdefault(int(k_), j_)
+                  res, nm = (evaluate(ebatch, contig_names, contig_of, het_, som_, grep_, gkey_) if ebatch.n_loci else (None, None))
+                  names = names or nm
+                  stage["call_s"] += time.perf_counter() - t0
+                  stage["n_loci"] += batch.n_loci
+                  stage["n_obs"] += batch.n_obs
+                  if not used_contigs:
+                      used_contigs = contig_names if not is_text else [contig_names[int(c_)] for c_ in np.unique(np.asarray(sites.contig))]
+                  collected.append(_fixed_fields(res) if (result_pool is not None and getattr(res, "_pool_block", None) is not None) else res)
+                  if processor is not None:
+                      if res is not None and rank == 0:
+                          if not proc_state["setup"]:
+                              processor.setup(list(names), list(sample_order))
+                              proc_state["setup"] = True
+                          processor.process_calls(CallChunk(ebatch, sites, res, list(names), list(sample_order), loci_, stage["n_loci"] - batch.n_loci))
+                  elif tw and res is not None:
+                      q_out.put((batch.extra["native_table"], res, names, used_contigs))
+          except BaseException as ex:  # noqa: BLE001
+            if not shard_state["on"]:
+                raise
+            loop_exc.append(ex)
         finally:
             t_loop_end = time.perf_counter()
             if tw:
@@ -578,6 +587,32 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
             t_c0 = time.perf_counter()
             close_plans()
             stage["drain_plans_close_s"] = time.perf_counter() - t_c0
+        if shard_state["on"]:
+            # One collective tells every rank whether ALL ranks came through and what the file's header holds (a rank that
+            # fails alone leaves the others at the barrier below until the RCCL timeout; a rank without records cannot know the contigs
+            # and output names the other parts index).  Nothing is written unless every rank succeeded; parts are removed otherwise.
+            import torch.distributed as tdist
+            mine_failed = bool(errors or loop_exc)
+            info: List = [None] * world
+            tdist.all_gather_object(info, (mine_failed, list(names) if names else None, list(used_contigs)))
+            if any(i_[0] for i_ in info):
+                if writer_state["w"] is not None:
+                    try:
+                        writer_state["w"].close()
+                    except Exception:  # noqa: BLE001 (already failing)
+                        pass
+                try:
+                    os.remove(_part_path(output, rank))
+                except OSError:
+                    pass
+                if loop_exc:
+                    raise loop_exc[0]
+                if errors:
+                    raise errors[0]
+                raise SystemExit("rank(s) %s of the sharded run failed: no calls file was written" % ", ".join(str(k_) for k_, i_ in enumerate(info) if i_[0]))
+            # the same header on every rank: names and contigs of the first rank that saw records
+            names = next((i_[1] for i_ in info if i_[1]), names)
+            used_contigs = next((i_[2] for i_ in info if i_[2]), used_contigs)
         if errors:
             raise errors[0]
         if processor is not None:
@@ -592,7 +627,6 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                 vingest.CallsWriter(_part_path(output, rank), hdr, part=(rank, world)).close()
             else:
                 writer_state["w"].close()
-            import torch.distributed as tdist
             tdist.barrier()
             if rank == 0:
                 vingest.concat_parts(output, [_part_path(output, k_) for k_ in range(world)])

@@ -143,6 +143,102 @@ struct WaveSt {
                  // (phase A); otherwise e == 0 exactly for the whole pileup and the HBM scratch row is neither written nor read
 };
 
+// ------------------------------------------------------------------------------------------------
+// Diagnosis builds of round 6 (VERDICT r05 "next" #1; tools/exec_assert.sh, tools/trace_diff.py).  Neither is part of a shipped library.
+//  -DVLR_DBG_EXEC_ASSERT: every cross-lane operation of the call kernel checks the EXEC mask it runs under against what the site
+//     assumes, and every UNI() / uni_d() / ldc() that its operand really is the same on all active lanes; what is seen goes to
+//     g_xsite[source line] = {site was executed, executions under partial EXEC, executions that break the site's rule, OR of the
+//     disabled lanes}.  Rules: DPP row operations and ds_swizzle inside a row need every 16-lane row all on or all off (a lane
+//     whose source is disabled reads 0 under bound_ctrl); whole-wave shuffles and row-leader reads need full EXEC; a lane read needs
+//     that lane on; a "uniform" value must be uniform.
+//  -DVLR_DBG_TRACE: the wave of ONE locus (vlr_debug_trace_arm) appends (id, source line, EXEC, 64 lane values) records to a device
+//     buffer at the TRC() points below; two builds of the same source are compared record by record on the host.
+#if (defined(VLR_DBG_EXEC_ASSERT) || defined(VLR_DBG_TRACE)) && !VLR_DEEP && !defined(VLR_WIDE_BUILD)
+#define VLR_DBG_OWNER 1   // this translation unit defines the device symbols and the host accessors
+#endif
+#ifdef VLR_DBG_EXEC_ASSERT
+constexpr int kXSites = 8192;
+#ifdef VLR_DBG_OWNER   // (the deep and wide builds are translation units of their own: their checks compile to nothing)
+__device__ unsigned long long g_xsite[kXSites * 4];
+#endif
+enum { XK_ROW = 0, XK_WAVE = 1, XK_ANY = 2 };
+__device__ __forceinline__ bool xrows_partial(unsigned long long e) {
+    bool bad = false;
+    for (int r = 0; r < 4; ++r) { const unsigned b = (unsigned)(e >> (16 * r)) & 0xffffu; bad = bad || (b != 0u && b != 0xffffu); }
+    return bad;
+}
+__device__ __forceinline__ void xnote(int line, unsigned long long e, bool viol) {
+#if VLR_DEEP || defined(VLR_WIDE_BUILD)
+    (void)line; (void)e; (void)viol;
+#else
+    if (__builtin_amdgcn_mbcnt_hi((unsigned)(e >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)e, 0u)) != 0u) return;  // first active lane
+    unsigned long long* g = g_xsite + 4 * (line & (kXSites - 1));
+    g[0] = 1ull;
+    if (e != ~0ull) { atomicAdd(g + 1, 1ull); atomicOr(g + 3, ~e); }
+    if (viol) atomicAdd(g + 2, 1ull);
+#endif
+}
+__device__ __forceinline__ void xchk(int kind, int line) {
+    const unsigned long long e = __builtin_amdgcn_read_exec();
+    xnote(line, e, kind == XK_ROW ? xrows_partial(e) : kind == XK_WAVE ? e != ~0ull : false);
+}
+__device__ __forceinline__ void xchk_lane(int l, int line) {
+    const unsigned long long e = __builtin_amdgcn_read_exec();
+    xnote(line, e, ((e >> (l & 63)) & 1ull) == 0ull);
+}
+__device__ __forceinline__ void xchk_uni(bool differs, int line) {
+    const unsigned long long e = __builtin_amdgcn_read_exec();
+    const bool viol = __builtin_amdgcn_ballot_w64(differs) != 0ull;
+    xnote(line, e, viol);
+}
+#define VLR_XCHK(kind, line) xchk(kind, line)
+#define VLR_XCHK_LANE(l, line) xchk_lane(l, line)
+#define VLR_XCHK_UNI(differs, line) xchk_uni(differs, line)
+#else
+#define VLR_XCHK(kind, line) ((void)0)
+#define VLR_XCHK_LANE(l, line) ((void)0)
+#define VLR_XCHK_UNI(differs, line) ((void)0)
+#endif
+#ifdef VLR_DBG_TRACE
+constexpr int kTraceCap = 1 << 16;
+#ifdef VLR_DBG_OWNER
+__device__ double g_trace_val[(size_t)kTraceCap * 64];
+__device__ unsigned long long g_trace_hdr[(size_t)kTraceCap * 2];  // (id << 32) | source line, EXEC
+__device__ int g_trace_n;
+__device__ long long g_trace_locus = -1;
+#endif
+__device__ __forceinline__ void trc_rec(long long locus, int id, double v, int line) {
+#if !VLR_DEEP && !defined(VLR_WIDE_BUILD)
+    if (locus != __hip_atomic_load(&g_trace_locus, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    const unsigned long long e = __builtin_amdgcn_read_exec();
+    int pos = 0;
+    const bool first = __builtin_amdgcn_mbcnt_hi((unsigned)(e >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)e, 0u)) == 0u;
+    if (first) pos = atomicAdd(&g_trace_n, 1);
+    pos = __builtin_amdgcn_readfirstlane(pos);
+    if (pos >= kTraceCap) return;
+    g_trace_val[(size_t)pos * 64 + (threadIdx.x & 63)] = v;
+    if (first) { g_trace_hdr[2 * (size_t)pos] = ((unsigned long long)(unsigned)id << 32) | (unsigned)line; g_trace_hdr[2 * (size_t)pos + 1] = e; }
+#endif
+}
+#define TRC(c, id, v) trc_rec((c).locus, (id), (double)(v), __LINE__)
+#define TRCB(c, id, v) trc_rec((c).locus, (id), __longlong_as_double((long long)(v)), __LINE__)   // raw 64-bit pattern
+#else
+#define TRC(c, id, v) ((void)0)
+#define TRCB(c, id, v) ((void)0)
+#endif
+#ifdef VLR_DBG_EXEC_ASSERT
+#define VLR_RDLANE(v, l) rdlane_i((v), (l), __LINE__)
+#define VLR_SHFL(v, l) shfl_chk((v), (l), __LINE__)
+#define VLR_SHFL_XOR(v, m) shfl_xor_chk((v), (m), __LINE__)
+__device__ __forceinline__ int rdlane_i(int v, int l, int line) { VLR_XCHK_LANE(l, line); return __builtin_amdgcn_readlane(v, l); }
+template <class T> __device__ __forceinline__ T shfl_chk(T v, int l, int line) { VLR_XCHK(XK_WAVE, line); return __shfl(v, l, 64); }
+template <class T> __device__ __forceinline__ T shfl_xor_chk(T v, int m, int line) { VLR_XCHK(XK_WAVE, line); return __shfl_xor(v, m); }
+#else  // (the plain builtins: the shipped code is the same instruction for instruction with and without these names)
+#define VLR_RDLANE(v, l) __builtin_amdgcn_readlane((v), (l))
+#define VLR_SHFL(v, l) __shfl((v), (l), 64)
+#define VLR_SHFL_XOR(v, m) __shfl_xor((v), (m))
+#endif
+
 // one observation row (all ten columns) of lane `i`; rows beyond `end` read as an empty observation
 struct ObsRow { uint32_t f; float pm, pa, pr, miss, psa, pdo, phb, hpa, hpv; };
 __device__ __forceinline__ ObsRow load_obs_row(const DevBatch& batch, uint32_t i, uint32_t end) {
@@ -166,9 +262,20 @@ __device__ __forceinline__ double uni_d(double v) { return v; }
 #define UNI64(x) (x)
 #else
 #define UNI64(x) __double_as_longlong(uni_d(__longlong_as_double(x)))
+#ifdef VLR_DBG_EXEC_ASSERT
+#define UNI(x) uni_i_chk((x), __LINE__)
+__device__ __forceinline__ int uni_i_chk(int v, int line) {
+    const int r = __builtin_amdgcn_readfirstlane(v);
+    VLR_XCHK_UNI(v != r, line);
+    return r;
+}
+#else
 #define UNI(x) __builtin_amdgcn_readfirstlane(x)
-__device__ __forceinline__ double uni_d(double v) {
-    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+#endif
+__device__ __forceinline__ double uni_d(double v, int site = __builtin_LINE()) {
+    const double r = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+    VLR_XCHK_UNI(__double_as_longlong(v) != __double_as_longlong(r), site);
+    return r;
 }
 #endif
 
@@ -211,15 +318,35 @@ __device__ __forceinline__ int fresh_lane(int lane) {
 // A wave-uniform double parked in SGPRs (park_sd, at its definition) and re-defined in SGPRs at the point of use (fresh_sd):
 // instruction selection otherwise copies an SGPR value that feeds a vector select into VGPRs where it is DEFINED (outside the
 // loops), and that copy then lives — spilled to scratch — across the kernel.
+// Both statements are EMPTY asm blocks since round 6: they only pin values in registers, every instruction around them is the
+// compiler's.  Until then they carried instructions, and both were wrong in ways no compiler check can see:
+//  * park_sd read the halves with `v_readfirstlane_b32` INSIDE the asm.  gfx950 needs one wait state between a VALU instruction that
+//    writes a VGPR and a lane read of that VGPR; the hazard recogniser inserts it for its own lane reads, not for asm text.  Wherever
+//    the scheduler put the `v_add_f64` of `1 - forward_rate` directly in front of the asm, the LOW word came back stale (the high
+//    word, read one instruction later, was right): the `-O1` / four-waves deviation of rounds 4-5 — every likelihood of a
+//    reverse-strand read off by ~2^-24.
+//  * fresh_sd moved the pair with two `s_mov_b32` and plain "=s" outputs.  The first move writes %0 before the second reads its
+//    input: without early-clobber outputs the compiler may give %0 the register of that input — which it did as soon as the parked
+//    pair had been spilled to a VGPR lane and was reloaded into temporaries in front of the statement — and the double came back
+//    as (lo, lo): a reverse rate of exactly 0 for 1 - 0.5.  That was the "max-ILP scheduler with fresh_lane" deviation of round 5.
+// Found with the per-wave trace of tools/exec_trace_run.py (first differing value: coefficient q of a reverse-strand read, in both
+// configurations); tests/test_build_hygiene.py now refuses lane reads and multi-instruction templates without early-clobber
+// outputs in this file's asm statements, and both configurations are back in the build matrix.
 struct SgprD { int lo, hi; };
 __device__ __forceinline__ SgprD park_sd(double v) {
+    // (the empty statement hides from the optimiser that the halves are wave-uniform: it folds a lane read of a value it knows to be
+    //  uniform, and the VGPR that is left cannot feed fresh_sd's "+s" operands.  The lane reads themselves are the compiler's: it puts
+    //  the `s_nop` between them and the VALU instruction that produced v.)
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    asm volatile("" : "+v"(lo), "+v"(hi));
     SgprD r;
-    asm volatile("v_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3" : "=s"(r.lo), "=s"(r.hi) : "v"(__double2loint(v)), "v"(__double2hiint(v)));
+    r.lo = __builtin_amdgcn_readfirstlane(lo);
+    r.hi = __builtin_amdgcn_readfirstlane(hi);
     return r;
 }
 __device__ __forceinline__ double fresh_sd(const SgprD& v) {
-    int lo, hi;
-    asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "s"(v.lo), "s"(v.hi));
+    int lo = v.lo, hi = v.hi;
+    asm volatile("" : "+s"(lo), "+s"(hi));
     return __hiloint2double(hi, lo);
 }
 
@@ -238,7 +365,8 @@ __device__ __forceinline__ double div3(double x) {
 // wave-uniform.  (The __shfl_xor butterflies these replace go through ds_bpermute: six lane-address registers that the compiler
 // kept alive — and spilled — across the whole kernel, and six LDS round trips per reduction.)
 template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
+__device__ __forceinline__ double dpp_f64(double v, int site = __builtin_LINE()) {
+    VLR_XCHK(XK_ROW, site);
 #ifdef VLR_DBG_DPP_SHFL  // diagnosis builds: the four permutations of the reductions through ds_bpermute instead of DPP moves of the halves
     const int l_ = (int)__lane_id();
     const int src_ = CTRL == 0xB1 ? (l_ ^ 1) : CTRL == 0x4E ? (l_ ^ 2) : CTRL == 0x141 ? ((l_ & ~7) | (7 - (l_ & 7))) : CTRL == 0x140 ? ((l_ & ~15) | (15 - (l_ & 15)))
@@ -256,13 +384,15 @@ __device__ __forceinline__ double dpp_f64(double v) {
     return __hiloint2double(hi, lo);
 }
 template <int CTRL>
-__device__ __forceinline__ int dpp_i32(int v) {
+__device__ __forceinline__ int dpp_i32(int v, int site = __builtin_LINE()) {
+    VLR_XCHK(XK_ROW, site);
 #ifdef VLR_DBG_DPP_NOP
     asm volatile("s_nop 7" : "+v"(v));
 #endif
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
-__device__ __forceinline__ double lane_d(double v, int l) {
+__device__ __forceinline__ double lane_d(double v, int l, int site = __builtin_LINE()) {
+    VLR_XCHK_LANE(l, site);
 #ifdef VLR_DBG_LANE_SHFL
     return __shfl(v, l, 64);
 #endif
@@ -271,16 +401,19 @@ __device__ __forceinline__ double lane_d(double v, int l) {
 #endif
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
-__device__ __forceinline__ double wave_sum(double v) {
-    v += dpp_f64<0xB1>(v); v += dpp_f64<0x4E>(v); v += dpp_f64<0x141>(v); v += dpp_f64<0x140>(v);
-    return (lane_d(v, 0) + lane_d(v, 16)) + (lane_d(v, 32) + lane_d(v, 48));
+__device__ __forceinline__ double wave_sum(double v, int site = __builtin_LINE()) {
+    VLR_XCHK(XK_WAVE, site);
+    v += dpp_f64<0xB1>(v, site); v += dpp_f64<0x4E>(v, site); v += dpp_f64<0x141>(v, site); v += dpp_f64<0x140>(v, site);
+    return (lane_d(v, 0, site) + lane_d(v, 16, site)) + (lane_d(v, 32, site) + lane_d(v, 48, site));
 }
-__device__ __forceinline__ double wave_max(double v) {
-    v = fmax(v, dpp_f64<0xB1>(v)); v = fmax(v, dpp_f64<0x4E>(v)); v = fmax(v, dpp_f64<0x141>(v)); v = fmax(v, dpp_f64<0x140>(v));
-    return fmax(fmax(lane_d(v, 0), lane_d(v, 16)), fmax(lane_d(v, 32), lane_d(v, 48)));
+__device__ __forceinline__ double wave_max(double v, int site = __builtin_LINE()) {
+    VLR_XCHK(XK_WAVE, site);
+    v = fmax(v, dpp_f64<0xB1>(v, site)); v = fmax(v, dpp_f64<0x4E>(v, site)); v = fmax(v, dpp_f64<0x141>(v, site)); v = fmax(v, dpp_f64<0x140>(v, site));
+    return fmax(fmax(lane_d(v, 0, site), lane_d(v, 16, site)), fmax(lane_d(v, 32, site), lane_d(v, 48, site)));
 }
-__device__ __forceinline__ int wave_or(int v) {
-    v |= dpp_i32<0xB1>(v); v |= dpp_i32<0x4E>(v); v |= dpp_i32<0x141>(v); v |= dpp_i32<0x140>(v);
+__device__ __forceinline__ int wave_or(int v, int site = __builtin_LINE()) {
+    VLR_XCHK(XK_WAVE, site);
+    v |= dpp_i32<0xB1>(v, site); v |= dpp_i32<0x4E>(v, site); v |= dpp_i32<0x141>(v, site); v |= dpp_i32<0x140>(v, site);
     return (__builtin_amdgcn_readlane(v, 0) | __builtin_amdgcn_readlane(v, 16)) | (__builtin_amdgcn_readlane(v, 32) | __builtin_amdgcn_readlane(v, 48));
 }
 __device__ inline int popc64(unsigned long long m) { return __popcll(m); }
@@ -327,14 +460,15 @@ __device__ inline double lse_value(double M, double S) {
 #define VLR_K4 __attribute__((address_space(4)))
 #ifdef VLR_NO_K4
 template <class T>
-__device__ __forceinline__ T ldc(const T* ptr) { return *ptr; }
+__device__ __forceinline__ T ldc(const T* ptr, int site = 0) { return *ptr; }
 #else
 template <class T>
-__device__ __forceinline__ T ldc(const T* ptr) {
+__device__ __forceinline__ T ldc(const T* ptr, int site = __builtin_LINE()) {
     // the address is wave-uniform by construction; say so even where the compiler's divergence analysis cannot see it
     const unsigned long long a = (unsigned long long)(uintptr_t)ptr;
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
     const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    VLR_XCHK_UNI(a != (((unsigned long long)hi << 32) | lo), site);
     return *(const VLR_K4 T*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
 }
 #endif
@@ -662,7 +796,7 @@ __device__ __forceinline__ void reduce_terms(double* P, int* E) {
         P[j] *= dpp_f64<0x140>(P[j]); E[j] += dpp_i32<0x140>(E[j]);    // row_mirror
         if (W == 64) {  // the four row products, combined from SGPRs (wave-uniform result)
             P[j] = (lane_d(P[j], 0) * lane_d(P[j], 16)) * (lane_d(P[j], 32) * lane_d(P[j], 48));
-            E[j] = (__builtin_amdgcn_readlane(E[j], 0) + __builtin_amdgcn_readlane(E[j], 16)) + (__builtin_amdgcn_readlane(E[j], 32) + __builtin_amdgcn_readlane(E[j], 48));
+            E[j] = (VLR_RDLANE(E[j], 0) + VLR_RDLANE(E[j], 16)) + (VLR_RDLANE(E[j], 32) + VLR_RDLANE(E[j], 48));
         }
         int e2;
         P[j] = __builtin_frexp(P[j], &e2);  // product of <= 64 mantissas >= 2^-64: one renormalisation suffices
@@ -718,8 +852,8 @@ __device__ inline void eval_pileup(const double* __restrict__ coef, const double
     int Em = tq == 1 ? E[1] : tq == 2 ? E[2] : tq == 3 ? E[3] : E[0];
     Pm *= dpp_f64<0x124>(Pm); Em += dpp_i32<0x124>(Em);                    // row_ror:4
     Pm *= dpp_f64<0x128>(Pm); Em += dpp_i32<0x128>(Em);                    // row_ror:8
-    Pm *= __shfl_xor(Pm, 16); Em += __shfl_xor(Em, 16);
-    Pm *= __shfl_xor(Pm, 32); Em += __shfl_xor(Em, 32);
+    Pm *= VLR_SHFL_XOR(Pm, 16); Em += VLR_SHFL_XOR(Em, 16);
+    Pm *= VLR_SHFL_XOR(Pm, 32); Em += VLR_SHFL_XOR(Em, 32);
     {
         int e2;
         Pm = __builtin_frexp(Pm, &e2);  // product of <= 64 mantissas >= 2^-64: one renormalisation suffices
@@ -920,6 +1054,7 @@ __device__ inline double sample_lik_point(Ctx& c, int s, double a, double b) {  
     accum_terms<1, 64>(c.coef + 2 * off, ecoef_of(c, s, off), D, c.lane, (w->fastok >> s) & 1, &al, &be, P1, E1);
     reduce_terms<1, 64>(P1, E1);
     }
+    TRC(c, 120, P1[0]); TRC(c, 121, E1[0]); TRC(c, 122, al); TRC(c, 123, be); TRC(c, 124, s);
     if (c.lane == 0) { w->work[0] += 1; w->work[1] += (unsigned long long)D; }
 #ifdef VLR_NO_RESCUE
     return uni_d(ln_product_mantissa(P1[0]) + (double)E1[0] * kLn2);
@@ -1199,7 +1334,7 @@ __device__ inline int dleaf_wave_best(const DevDLeaf* leaves, double bJ, int bL,
     while (tie) {
         const int ln = __builtin_ctzll(tie);
         tie &= tie - 1;
-        const int l = __builtin_amdgcn_readlane(bL, ln);
+        const int l = VLR_RDLANE(bL, ln);
         if (best < 0 || dleaf_tuple_before(leaves, l, best, S)) best = l;
     }
     Jout = Jm;
@@ -1419,7 +1554,7 @@ __device__ inline void afd_finish(Ctx& c) {
                 bool dup = false;
                 for (int j = 0; j < kept; ++j) dup = dup | ((__double_as_longlong(vv[j]) == key) & (kk[j] == lk));  // compacted prefix (earlier chunks)
                 for (int j = base; j < base + 64 && j < cnt; ++j) {                                  // earlier entries of this chunk
-                    const long long kj = __shfl(key, j - base), lj = __shfl(lk, j - base);
+                    const long long kj = VLR_SHFL(key, j - base), lj = VLR_SHFL(lk, j - base);
                     dup = dup | ((j < i) & (kj == key) & (lj == lk));
                 }
                 const unsigned long long keep = __ballot(on & !dup);
@@ -1488,6 +1623,7 @@ __device__ inline double leaf_joint(Ctx& c) {
         PROF_ADD(c, 21);  // leaf: prior
     }
     joint = uni_d(joint);
+    TRC(c, 125, joint);
     if (joint != joint) c.status |= VLR_LOCUS_NAN;
     if (log_on(c)) log_leaf(c, joint);
     if (__builtin_expect(c.replay != 0, 0)) afd_consider(c, joint, -1, 0.0);
@@ -1779,16 +1915,16 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
 // run concurrently, one per 16-lane DPP row.  Every "uniform" control instruction of the adaptive integrator now
 // serves four chains; the row's 16 lanes are split into (point, slice) groups for the pileup products and the
 // partial products are combined with in-row DPP permutes (a 16-lane row is exactly one DPP row).
-__device__ __forceinline__ double row_max(double v) {
-    v = fmax(v, dpp_f64<0xB1>(v)); v = fmax(v, dpp_f64<0x4E>(v)); v = fmax(v, dpp_f64<0x141>(v)); v = fmax(v, dpp_f64<0x140>(v));
+__device__ __forceinline__ double row_max(double v, int site = __builtin_LINE()) {
+    v = fmax(v, dpp_f64<0xB1>(v, site)); v = fmax(v, dpp_f64<0x4E>(v, site)); v = fmax(v, dpp_f64<0x141>(v, site)); v = fmax(v, dpp_f64<0x140>(v, site));
     return v;
 }
-__device__ __forceinline__ double row_sum(double v) {
-    v += dpp_f64<0xB1>(v); v += dpp_f64<0x4E>(v); v += dpp_f64<0x141>(v); v += dpp_f64<0x140>(v);
+__device__ __forceinline__ double row_sum(double v, int site = __builtin_LINE()) {
+    v += dpp_f64<0xB1>(v, site); v += dpp_f64<0x4E>(v, site); v += dpp_f64<0x141>(v, site); v += dpp_f64<0x140>(v, site);
     return v;
 }
-__device__ __forceinline__ int row_or(int v) {
-    v |= dpp_i32<0xB1>(v); v |= dpp_i32<0x4E>(v); v |= dpp_i32<0x141>(v); v |= dpp_i32<0x140>(v);
+__device__ __forceinline__ int row_or(int v, int site = __builtin_LINE()) {
+    v |= dpp_i32<0xB1>(v, site); v |= dpp_i32<0x4E>(v, site); v |= dpp_i32<0x141>(v, site); v |= dpp_i32<0x140>(v, site);
     return v;
 }
 
@@ -1821,7 +1957,8 @@ __device__ __forceinline__ double ln_mantissa(double m) {
 
 // value of row lane N on every lane of its 16-lane DPP row (row_newbcast: no LDS round trip)
 template <int N>
-__device__ __forceinline__ double row_bcast(double v) {
+__device__ __forceinline__ double row_bcast(double v, int site = __builtin_LINE()) {
+    VLR_XCHK(XK_ROW, site);
 #ifdef VLR_DBG_BCAST_SHFL
     return __shfl(v, ((int)__lane_id() & ~15) | N, 64);
 #endif
@@ -1968,8 +2105,8 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
     bool act = !simp;                           // the row's search goes on (ROUND)
     const unsigned long long any_simp = __ballot(live && simp), any_norm = __ballot(live && !simp);
     int up = any_simp ? UP_SIMPSON : UP_INIT;
-    const int kmax = any_simp ? max(max(__builtin_amdgcn_readlane(simpson_n, 0), __builtin_amdgcn_readlane(simpson_n, 16)),
-                                    max(__builtin_amdgcn_readlane(simpson_n, 32), __builtin_amdgcn_readlane(simpson_n, 48))) : 0;
+    const int kmax = any_simp ? max(max(VLR_RDLANE(simpson_n, 0), VLR_RDLANE(simpson_n, 16)),
+                                    max(VLR_RDLANE(simpson_n, 32), VLR_RDLANE(simpson_n, 48))) : 0;
     double sstep = 0.0;
     if (any_simp) sstep = simp ? (hi - lo) / (double)(simpson_n - 1) : 0.0;  // (a division: only where a grid is walked)
     int k = 0, tn = 0;
@@ -2027,6 +2164,7 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
             live = live && !over;
             on = on && !over;
         }
+        TRC(c, 50, up); TRC(c, 51, k); TRC(c, 52, px0); TRC(c, 53, px1); TRC(c, 54, px2); TRC(c, 55, nn); TRC(c, 56, on ? 1 : 0); TRC(c, 57, rl); TRC(c, 58, tn);
         double al[3], be[3], P[3];
         int E[3];
         {
@@ -2054,6 +2192,7 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
         else
             reg_products<NS>(cc, cq, lcoef, rl, D, al, P);
         VLR_PRIO_CHAIN();
+        TRC(c, 60, P[0]); TRC(c, 61, P[1]); TRC(c, 62, P[2]); TRC(c, 63, al[0]); TRC(c, 64, al[1]); TRC(c, 65, al[2]);
         PROF_ADD(c, 12);  // pass: term products
         // reduction over the 16 lanes of the row, transposed from the first step on: a lane and its neighbour (xor 1) exchange what the
         // OTHER keeps — the even lane goes on with points 0 and 2, the odd one with point 1 (and a copy of 2) —, then the halves of a
@@ -2099,6 +2238,7 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
             Psel = __builtin_frexp(Psel, &e);  // product of 16 mantissas >= 2^-16: one renormalisation suffices
             Esel += e;
         }
+        TRC(c, 66, Psel); TRC(c, 67, Esel);
         PROF_ADD(c, 13);  // pass: reduction
         const double x = rl == 0 ? px0 : rl == 1 ? px1 : px2;
         const bool owner = on && rl < nn;
@@ -2139,6 +2279,7 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
             if (owner) { q.tx[tn + rl] = x; q.tv[tn + rl] = joint; }
 #endif
         }
+        TRCB(c, 68, key); TRC(c, 69, joint); TRC(c, 70, owner ? 1 : 0); TRC(c, 71, x);
         tn = on ? tn + nn : tn;
         PROF_ADD(c, 14);  // pass: log + prior + store
         if (__builtin_expect(up == UP_ROUND, 1)) {
@@ -2172,6 +2313,7 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
             const double mX = useM2 ? px2 : px1;
             const bool updL = on && keepR, updR = on && !keepR;
             L = updL ? mX : L; R = updR ? mX : R;
+            TRC(c, 72, L); TRC(c, 73, R); TRCB(c, 74, kL); TRCB(c, 75, kR); TRC(c, 76, vL); TRC(c, 77, vR); TRC(c, 78, keepR ? 1 : 0); TRC(c, 79, useM2 ? 1 : 0);
             act = on && ((R - L) >= res) && L < R;
             if (!__ballot(act)) { up = UP_TAIL; k = 0; }
         } else if (up == UP_TAIL) {
@@ -2193,6 +2335,7 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
         }
     }
     PROF_ADD(c, 15);  // pass: state update (+ loop control)
+    TRC(c, 80, tn);
     q.tn = tn; q.failed = failed; q.sawnan = sawnan;
 }
 
@@ -2203,7 +2346,7 @@ __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
 // one scalar xor with the stage's lane mask, one select; along a register bit it is one compare and two selects.  146 VALU
 // instructions for 64 keys, where ranking every key against every other one is 2 x 4 x 57.
 template <int XOR>
-__device__ __forceinline__ unsigned swz_xor(unsigned v) { return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (XOR << 10) | 0x1f); }
+__device__ __forceinline__ unsigned swz_xor(unsigned v, int site = __builtin_LINE()) { VLR_XCHK(XK_ROW, site); return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (XOR << 10) | 0x1f); }
 // lanes that keep the LARGER key in the cross-lane stage (k, j) / whose register pairs are sorted descending in a register stage of merge k
 template <int NB>
 __device__ constexpr unsigned long long bitonic_keepmax(int k, int j) {
@@ -2341,6 +2484,8 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
 #else
     const bool regrun = dep == (1 << inner) && D_in <= 16 * kRegSlots && ((UNI(w->vfast) >> inner) & 1);
 #endif
+    TRC(c, 30, lo); TRC(c, 31, hi); TRC(c, 32, res); TRC(c, 33, fixed); TRC(c, 34, simpson_n); TRC(c, 35, pidx); TRC(c, 36, rowon ? 1 : 0);
+    TRC(c, 37, regrun ? 1 : 0); TRC(c, 38, D_in); TRC(c, 39, pr0); TRC(c, 40, pr1);
     // keyed passes (see reg_chain_loop): every point of every row has the same finite prior value and a finite fixed part
 #ifdef VLR_DBG_NO_KEYED  // diagnosis builds: every pass takes the logarithm itself
     const bool keyed = false && c.nlfc == 0 &&
@@ -2348,6 +2493,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
     const bool keyed = regrun && c.nlfc == 0 && !(ones_any(c) && ones_risk(c, inner)) &&
 #endif  // (the exponent of a direct all-ones product is not bounded by the key's 16 bits)
                        __ballot(rowon && !(cls_fast && (pr0 == pr1 || lo != 0.0) && fabs(pr1) < __builtin_huge_val() && fabs(fixed) < __builtin_huge_val())) == 0ull;
+    TRC(c, 41, keyed ? 1 : 0); TRC(c, 42, cls_fast ? 1 : 0);
     if (__builtin_expect(regrun, 1)) {
         RegChain rc;
         rc.lo = lo; rc.hi = hi; rc.res = res; rc.fixed = fixed; rc.pr0 = pr0; rc.pr1 = pr1; rc.pr2 = pr2;
@@ -2398,8 +2544,8 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
         // the largest, rows without points left compute on repeated points and discard the result.
         PROF_ADD(c, 15);  // round: advance + loop control (previous iteration)
         const int npg = go ? np : 0;
-        const int npmax = max(max(__builtin_amdgcn_readlane(npg, 0), __builtin_amdgcn_readlane(npg, 16)),
-                              max(__builtin_amdgcn_readlane(npg, 32), __builtin_amdgcn_readlane(npg, 48)));
+        const int npmax = max(max(VLR_RDLANE(npg, 0), VLR_RDLANE(npg, 16)),
+                              max(VLR_RDLANE(npg, 32), VLR_RDLANE(npg, 48)));
         const double x = pend[rl < np ? rl : np - 1];
         double Psel = 1.0;
         int Esel = 0;
@@ -2538,8 +2684,8 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
     // in rank order in place and the neighbours are read back.  Duplicate x (HashMap key collisions in the reference) are
     // neighbours at distance zero.
     const int n = (rowon && !failed) ? tn : 0;
-    const int nmax = max(max(__builtin_amdgcn_readlane(n, 0), __builtin_amdgcn_readlane(n, 16)),
-                         max(__builtin_amdgcn_readlane(n, 32), __builtin_amdgcn_readlane(n, 48)));
+    const int nmax = max(max(VLR_RDLANE(n, 0), VLR_RDLANE(n, 16)),
+                         max(VLR_RDLANE(n, 32), VLR_RDLANE(n, 48)));
     const int TT = (nmax + 15) >> 4;  // entries per lane (uniform), <= 4 because the row path requires cap <= 64
     double bJ = VLR_NEG_INF, bX = 0.0;
     int bHave = 0;
@@ -2572,13 +2718,14 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
                 anynan = anynan | (vi[t] != vi[t]);
             }
         }
+        TRC(c, 81, n); TRC(c, 82, nmax); TRC(c, 83, xi[0]); TRC(c, 84, vi[0]); TRC(c, 85, xi[1]); TRC(c, 86, vi[1]); TRC(c, 87, bJ); TRC(c, 88, bX);
         // AFD log: the four row tables as they stand (any order), one record per chain (no l2fc terms on batched chains)
         if (log_on(c)) {
             const int hsz = 1 + c.S;
             int at_row = -1;
 #pragma unroll
             for (int r4 = 0; r4 < kRows; ++r4) {
-                const int nr = __builtin_amdgcn_readlane(n, 16 * r4);
+                const int nr = VLR_RDLANE(n, 16 * r4);
                 if (nr > 0 && log_on(c)) {
                     const int a = log_reserve(c, hsz + 2 * nr);
                     at_row = (row == r4) ? a : at_row;
@@ -2721,6 +2868,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
                 ssum += on ? ev * wgt : 0.0;
             }
         }
+        TRC(c, 89, rank[0]); TRC(c, 90, rank[1]); TRC(c, 91, M); TRC(c, 92, ssum);
         ssum = row_sum(ssum);
         {   // ln of the positive sum: exponent apart, the mantissa through the short logarithm of the passes (ssum == 0: -inf)
             int es;
@@ -2729,6 +2877,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
             rint_ = (M == VLR_NEG_INF) ? VLR_NEG_INF : M + lns;
         }
     }
+    TRC(c, 93, rint_); TRC(c, 94, bJ); TRC(c, 95, bX); TRC(c, 96, bHave);
     int nanrow = row_or(anynan ? 1 : 0);
     const int rowout = row_or(anyout ? 1 : 0);
     double r = rint_;
@@ -2945,7 +3094,7 @@ __device__ __forceinline__ bool bo_deliver(Ctx& c, const Frame& f, RangeSt& r, d
         if (lane == 0) w->ops_vaf[s_out] = x;
         VLR_SYNC();
         if (__builtin_expect(dead, 0)) continue;
-        const int hb = __builtin_amdgcn_readlane(hbl, i), n_i = __builtin_amdgcn_readlane(nl, i);
+        const int hb = VLR_RDLANE(hbl, i), n_i = VLR_RDLANE(nl, i);
         if (__builtin_expect(c.replay != 0, 0)) {
             if (UNI(f.sv_mute) || table_has(txo, tn0 + c0 + i, x, lane)) continue;  // repeated outer VAF: same map keys
             afd_emit_row(c, i, s_in, n_i);
@@ -2953,7 +3102,7 @@ __device__ __forceinline__ bool bo_deliver(Ctx& c, const Frame& f, RangeSt& r, d
         }
         if (hb & 1) map_consider(c, lane_d(bJl, i), s_in, lane_d(bXl, i));
         // rare: candidates for other groups / containment via another path (also of a visited excluded range end)
-        const int al_i = __builtin_amdgcn_readlane(alivel, i), co_i = __builtin_amdgcn_readlane(contl, i);
+        const int al_i = VLR_RDLANE(alivel, i), co_i = VLR_RDLANE(contl, i);
         if (__builtin_expect(al_i != 0 || !co_i || (hb & 2), 0)) {
             const ChainTask& T = w->task[i];
             const RangeV io{uni_d(T.ostart), uni_d(T.oend), UNI(T.olex), UNI(T.orex)};
@@ -2995,6 +3144,7 @@ __device__ __forceinline__ void flush_deliver(Ctx& c, int rowmask, double* evM, 
         c.group = UNI(T.group); c.disc = UNI(T.disc); c.contained = UNI(T.contained); c.alive = UNI(T.alive); c.nlfc = 0;
         c.curJ = uni_d(c.mapJ[u]); c.curHyp = UNI(c.mapHyp[u]);
         const double dens = uni_d(T.result);
+        TRC(c, 100, dens); TRC(c, 101, u); TRC(c, 102, i);
         if (dens != dens) c.status |= VLR_LOCUS_NAN;
         const int nq = UNI(T.n);
         if (__builtin_expect(c.replay != 0, 0)) afd_emit_row(c, i, s_in, nq);
@@ -3531,17 +3681,18 @@ __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, Dev
             const int r = r0 + u;
             fastr[u] = false; xs[u] = __builtin_nan("");
             if (r < nrec) {
-                const int k_r = __builtin_amdgcn_readlane(kind, r), m_r = __builtin_amdgcn_readlane(mism, r);
-                const int n_r = __builtin_amdgcn_readlane(n, r), nl_r = __builtin_amdgcn_readlane(nl, r);
+                const int k_r = VLR_RDLANE(kind, r), m_r = VLR_RDLANE(mism, r);
+                const int n_r = VLR_RDLANE(n, r), nl_r = VLR_RDLANE(nl, r);
+                const int at_r = VLR_RDLANE(at, r);  // (read where every lane is on: lane r itself is off below when r >= n_r — round 6, EXEC assert build)
                 fastr[u] = k_r == 1 && m_r == 1 && n_r <= 64 && nl_r == 0;
-                if (fastr[u] && lane < n_r) xs[u] = lg[__builtin_amdgcn_readlane(at, r) + 1 + S + lane];
+                if (fastr[u] && lane < n_r) xs[u] = lg[at_r + 1 + S + lane];
             }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int r = r0 + u;
             if (r < nrec && fastr[u]) {
-                const double mxr = uni_d(sh_mapv[__builtin_amdgcn_readlane(s_in, r)]);
+                const double mxr = uni_d(sh_mapv[VLR_RDLANE(s_in, r)]);
                 const unsigned long long hit = __ballot(xs[u] == mxr);
                 if (lane == r) hitq = hit ? (int)__builtin_ctzll(hit) : -1;
             }
@@ -3550,15 +3701,15 @@ __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, Dev
     if (hitq >= 0) hitv = lg[at + 1 + S + n + hitq];
     // ---- 2./3. records in log order
     for (int r = 0; r < nrec; ++r) {
-        const int k_r = __builtin_amdgcn_readlane(kind, r), m_r = __builtin_amdgcn_readlane(mism, r);
+        const int k_r = VLR_RDLANE(kind, r), m_r = VLR_RDLANE(mism, r);
         if (k_r != 3 && m_r > 1) continue;
-        const int at_r = __builtin_amdgcn_readlane(at, r), n_r = __builtin_amdgcn_readlane(n, r), sin_r = __builtin_amdgcn_readlane(s_in, r);
-        const int nl_r = __builtin_amdgcn_readlane(nl, r);
-        c.group = __builtin_amdgcn_readlane(grp, r);
-        c.disc = __builtin_amdgcn_readlane(disc, r); c.nlfc = nl_r;
+        const int at_r = VLR_RDLANE(at, r), n_r = VLR_RDLANE(n, r), sin_r = VLR_RDLANE(s_in, r);
+        const int nl_r = VLR_RDLANE(nl, r);
+        c.group = VLR_RDLANE(grp, r);
+        c.disc = VLR_RDLANE(disc, r); c.nlfc = nl_r;
         const int pay = at_r + 1 + S + 2 * nl_r;
         {
-            const int hq = __builtin_amdgcn_readlane(hitq, r);
+            const int hq = VLR_RDLANE(hitq, r);
             if (hq != -2) {  // handled by 1b: operands from LDS, value from the gather
                 if (hq < 0) continue;
                 VLR_SYNC();
@@ -3977,6 +4128,7 @@ __global__ void __launch_bounds__(64, WPE) VLR_DBG_VGPR_ATTR vlr_call_kernel(con
         }
     }
 
+    TRC(c, 1, total_kept); TRC(c, 2, n_alt_like); TRC(c, 3, forward_rate); TRC(c, 4, (int)surviving); TRC(c, 5, (int)enabled); TRC(c, 6, offset_acc);
     PROF_ADD(c, 1);  // gating
     // ============================ phase B: hypotheses x events ============================
     for (int u = lane; u < p.n_univ; u += 64) { evM[u] = VLR_NEG_INF; evS[u] = 0.0; }
@@ -4012,6 +4164,7 @@ __global__ void __launch_bounds__(64, WPE) VLR_DBG_VGPR_ATTR vlr_call_kernel(con
     for (int h = 0; h < kNHyp; ++h) {
         if (!((hyps >> h) & 1u)) continue;
         c.hyp = h;
+        TRC(c, 10, h);
         // ---- per-observation affine coefficients for this hypothesis -> LDS
         // L_i(alpha, beta) = c_i + q_i*alpha + e_i*beta with
         //   w = e^pm, u = (1-w) * e^(missed + b_any), A = e^(pa + b_alt), R = e^(pr + b_ref), s = e^prob_sample_alt
@@ -4093,6 +4246,8 @@ __global__ void __launch_bounds__(64, WPE) VLR_DBG_VGPR_ATTR vlr_call_kernel(con
                     double d = A - R;
                     cc_ = wv * R + uu; cq_ = wv * sv * d; ce_ = wv * (1.0 - sv) * d;
                     one_t = wv * A + uu; ref_t = wv * R;  // the term at alpha = beta = 1 formed directly, and what c + q + e cancels
+                    TRC(c, 130, sb_alt); TRC(c, 131, fa); TRC(c, 132, fr); TRC(c, 133, A); TRC(c, 134, R); TRC(c, 135, wv); TRC(c, 136, uu); TRC(c, 137, sv); TRC(c, 138, d); TRC(c, 139, cq_);
+                    TRC(c, 140, exp(pa)); TRC(c, 141, rp_any); TRC(c, 142, he_alt); TRC(c, 143, ro_alt); TRC(c, 144, forward_rate); TRC(c, 145, fresh_sd(reverse_rate)); TRC(c, 146, pa); TRC(c, 147, strand);
                     if (__builtin_expect(scaled != 0, 0)) {
                         // the three log-space addends of the observation's likelihood, their largest as the binary exponent k
                         const double lA = (fa > 0.0 && pa > VLR_NEG_INF) ? pm + pa + log(fa) : VLR_NEG_INF;
@@ -4207,6 +4362,8 @@ __global__ void __launch_bounds__(64, WPE) VLR_DBG_VGPR_ATTR vlr_call_kernel(con
             VLR_SYNC();
         }
 
+        TRC(c, 11, c.coef[2 * (lane < offset_acc ? lane : 0)]); TRC(c, 12, c.coef[2 * (lane < offset_acc ? lane : 0) + 1]);
+        TRC(c, 13, w->fastok); TRC(c, 14, w->vfast); TRC(c, 15, c.ehas); TRC(c, 16, kshift(c)[lane < S ? lane : 0]);
         PROF_ADD(c, 2);  // coefficient pass
         // ---- events (calling.rs:654-687): absent + clean events under h = none, artifact twins otherwise
         const double bias_prior = (h == 0) ? kLn05 : ln_bias_share;  // modes/generic.rs:437-441
@@ -4324,6 +4481,7 @@ __global__ void __launch_bounds__(64, WPE) VLR_DBG_VGPR_ATTR vlr_call_kernel(con
                 }
                 if (st == IT_WALK) {
                     const double dens = uni_d(walk_root(c, root, resume));
+                    TRC(c, 24, dens); TRC(c, 25, u); TRC(c, 26, c.need_batch); TRC(c, 27, c.deferred);
                     PROF_ADD(c, 21);  // walk (descent, frames; the outer-batch steps are counted apart)
                     if (c.need_batch) {
                         c.need_batch = 0; run_kind = 1; run_mask = (1 << c.bt_nt) - 1; run_inner = c.bt_inner;
@@ -4351,6 +4509,7 @@ __global__ void __launch_bounds__(64, WPE) VLR_DBG_VGPR_ATTR vlr_call_kernel(con
                 if (run_kind) {
                     PROF_ADD(c, 31);  // event loop: between the walk's return and the batch
                     if (run_kind != 1) c.nlfc = 0;  // deferred chains carry no l2fc terms; a later probe walk may have left some in the context
+                    TRC(c, 20, run_mask); TRC(c, 21, run_inner); TRC(c, 22, run_kind); TRC(c, 23, piggy);
                     run_chain_batch(c, run_mask, run_inner);
                     VLR_SYNC();
                     if (run_kind == 1) {
@@ -4396,6 +4555,7 @@ __global__ void __launch_bounds__(64, WPE) VLR_DBG_VGPR_ATTR vlr_call_kernel(con
     const int u_l = lane < p.n_univ ? lane : 0;
     const double evM_l = evM[u_l];
     const double evV_l = lse_value(evM_l, evS[u_l]);
+    TRC(c, 110, evM_l); TRC(c, 111, evV_l); TRC(c, 112, evS[u_l]);
     double mM = VLR_NEG_INF, mS = 0.0;
     for (int u = 0; u < p.n_univ; ++u) {
         const double m_u = lane_d(evM_l, u);
@@ -4403,6 +4563,7 @@ __global__ void __launch_bounds__(64, WPE) VLR_DBG_VGPR_ATTR vlr_call_kernel(con
         lse_add(mM, mS, v);
     }
     double marginal = (mM != mM) ? mM : lse_value(mM, mS);
+    TRC(c, 113, marginal);
     if (marginal != marginal) c.status |= VLR_LOCUS_NAN;
     // call_record (calling.rs:762-803)
     int best = 0;
@@ -4426,9 +4587,12 @@ __global__ void __launch_bounds__(64, WPE) VLR_DBG_VGPR_ATTR vlr_call_kernel(con
         if (!(post < prob_artifact)) is_artifact = false;
     }
     double* lp = out.ln_posterior + locus * n_out;
+    {   // posterior of `absent` (slot 0) and of the clean named events (slots 1 + 2 e), each written by the lane that holds the slot's value:
+        // no lane read inside the `lane == 0` region below (a lane read of lanes that are off there — round 6, EXEC assert build)
+        const double post_l = evV_l - marginal;
+        if (lane < p.n_univ && (lane == 0 || (lane & 1))) lp[lane == 0 ? 0 : 1 + (lane >> 1)] = post_l;
+    }
     if (lane == 0) {
-        lp[0] = lane_d(evV_l, 0) - marginal;
-        for (int e = 0; e < p.n_named; ++e) lp[1 + e] = lane_d(evV_l, 1 + 2 * e) - marginal;
         lp[n_out - 1] = prob_artifact;
         if (out.ln_marginal) out.ln_marginal[locus] = marginal;
         if (out.best_event) out.best_event[locus] = best;
@@ -4539,6 +4703,43 @@ __global__ void __launch_bounds__(64) vlr_selftest_stream_kernel(const float* in
 #define VLR_FN_CALL vlr_launch_call_kernel
 #define VLR_FN_AFD vlr_launch_afd_kernel
 #define VLR_FN_LDS vlr_plan_lds_floor
+#endif
+#ifdef VLR_DBG_OWNER  // host side of the diagnosis builds (VLR_DBG_EXEC_ASSERT / VLR_DBG_TRACE above); not in a shipped library
+#ifdef VLR_DBG_EXEC_ASSERT
+// out[4 * line + {0: executed, 1: executions under partial EXEC, 2: executions breaking the site's rule, 3: OR of disabled lanes}]
+extern "C" int vlr_debug_exec_sites(unsigned long long* out, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(vlr::g_xsite), sizeof(unsigned long long) * vlr::kXSites * 4) != hipSuccess) return 2;
+    if (reset) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(vlr::g_xsite)) != hipSuccess) return 3;
+        if (hipMemset(p, 0, sizeof(unsigned long long) * vlr::kXSites * 4) != hipSuccess) return 4;
+    }
+    return 0;
+}
+#endif
+#ifdef VLR_DBG_TRACE
+extern "C" int vlr_debug_trace_arm(long long locus) {   // trace the wave of this locus of the following launches; -1: none
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    const int zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(vlr::g_trace_n), &zero, sizeof(int)) != hipSuccess) return 2;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(vlr::g_trace_locus), &locus, sizeof(long long)) != hipSuccess) return 3;
+    return 0;
+}
+// records written since vlr_debug_trace_arm (at most cap): hdr[2 r] = (id << 32) | source line, hdr[2 r + 1] = EXEC, val[64 r + lane]
+extern "C" long long vlr_debug_trace_read(unsigned long long* hdr, double* val, long long cap) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(vlr::g_trace_n), sizeof(int)) != hipSuccess) return -2;
+    long long k = n < vlr::kTraceCap ? n : vlr::kTraceCap;
+    if (k > cap) k = cap;
+    if (k > 0) {
+        if (hipMemcpyFromSymbol(hdr, HIP_SYMBOL(vlr::g_trace_hdr), sizeof(unsigned long long) * 2 * (size_t)k) != hipSuccess) return -3;
+        if (hipMemcpyFromSymbol(val, HIP_SYMBOL(vlr::g_trace_val), sizeof(double) * 64 * (size_t)k) != hipSuccess) return -4;
+    }
+    return (long long)n;
+}
+#endif
 #endif
 #if !VLR_DEEP && !defined(VLR_WIDE_BUILD)
 extern "C" int vlr_launch_selftest_stream(const float* in, double* out, long long n, int mode, void* stream) {

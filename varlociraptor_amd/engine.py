@@ -71,7 +71,7 @@ def build_all(force: bool = False) -> None:
 MAX_OBS_LDS = 7680  # kept observations of one locus whose coefficient pairs fit the 120 kB LDS budget (vlr_plan_set_max_obs)
 
 MATRIX_DIR = os.path.join(_HERE, "matrix")
-MATRIX_LIBS = ("stress", "O1", "O2", "sync")
+MATRIX_LIBS = ("stress", "O1", "O2", "sync", "ilp")
 
 
 def build_matrix(force: bool = False) -> str:

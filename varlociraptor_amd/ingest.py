@@ -277,23 +277,38 @@ class ObsReader:
             L.vlr_obs_reader_shard_assign.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
             L.vlr_obs_reader_shard_row_size.restype = C.c_int
             k, n = int(shard[0]), int(shard[1])
-            _check(L.vlr_obs_reader_open_device_shard(int(device), len(paths), arr, int(omit_bias_mask), int(threads), k, n, C.byref(h)))
+            # A rank that cannot open (or count) its shard still takes part in the exchange, with a row of -1, and every rank raises:
+            # leaving the collective to the others alone would hold them until the RCCL timeout.
+            w = L.vlr_obs_reader_shard_row_size()
+            mine = np.full((len(paths), w), -1, np.int64)
+            own_error = None
             try:
-                w = L.vlr_obs_reader_shard_row_size()
-                mine = np.zeros((len(paths), w), np.int64)
-                _check(L.vlr_obs_reader_shard_counts(h, mine.ctypes.data))
+                _check(L.vlr_obs_reader_open_device_shard(int(device), len(paths), arr, int(omit_bias_mask), int(threads), k, n, C.byref(h)))
+                counted = np.zeros((len(paths), w), np.int64)
+                _check(L.vlr_obs_reader_shard_counts(h, counted.ctypes.data))
+                mine = counted
+            except Exception as ex:  # noqa: BLE001 (raised below, after the exchange)
+                own_error = ex
+            try:
                 self.shard_rows = mine
                 rows = np.ascontiguousarray((gather or _gather_rows)(mine), np.int64)
+                if own_error is not None:
+                    raise own_error
                 if rows.shape != (n, len(paths), w):
                     raise ValueError("gather returned rows of shape %r, expected %r" % (rows.shape, (n, len(paths), w)))
+                if (rows < 0).any():
+                    bad = sorted(set(int(r_) for r_ in np.nonzero((rows < 0).reshape(n, -1).any(axis=1))[0]))
+                    raise engine.EngineError(abi.ERR_INVALID_ARGUMENT,
+                                             "shard(s) %s of the sharded reader could not be opened" % ", ".join(str(b_) for b_ in bad))
                 fr, nr = C.c_int64(0), C.c_int64(0)
                 _check(L.vlr_obs_reader_shard_assign(h, rows.ctypes.data, C.byref(fr), C.byref(nr)))
                 self.first_record, self.n_records = int(fr.value), int(nr.value)
                 self.total_records = int(rows[:, 0, 0].sum())
             except Exception:
-                L.vlr_obs_reader_close.restype = None
-                L.vlr_obs_reader_close.argtypes = [C.c_void_p]
-                L.vlr_obs_reader_close(h)
+                if h:
+                    L.vlr_obs_reader_close.restype = None
+                    L.vlr_obs_reader_close.argtypes = [C.c_void_p]
+                    L.vlr_obs_reader_close(h)
                 raise
         else:
             _check(L.vlr_obs_reader_open_device(int(device), len(paths), arr, int(omit_bias_mask), int(threads), C.byref(h)))
