@@ -1,0 +1,96 @@
+"""CPU checks of the test-side BAM front end (tests/bam_pairs.py) that feeds SURVEY §8 f1 with real (read window, allele window)
+pairs: the reader on the reference's own BAM fixtures, the projection of reference positions into reads, the candidate regions of
+realignment/mod.rs:58-153 — and, with the CPU restatement of the pair HMM in the kernels' place, the `expected:` block of
+`test_false_negative_indel_call` (the GPU twin is tests/test_gpu_realign_bam.py)."""
+import math
+import os
+
+import numpy as np
+
+import bam_pairs as bp
+from bam_pairs import BamRecord
+
+
+def _rec(pos, cigar, n=None):
+    n = n if n is not None else sum(l for op, l in cigar if op in "MIS=X")
+    return BamRecord("r", 0, 0, pos, 60, cigar, b"A" * n, bytes([30] * n), -1, -1, 0)
+
+
+def test_read_pos_follows_the_cigar():
+    r = _rec(100, [("S", 5), ("M", 10), ("D", 3), ("M", 10), ("I", 2), ("M", 5)])
+    assert bp.read_pos(r, 100, False, False) == 5            # first aligned base
+    assert bp.read_pos(r, 109, False, False) == 14
+    assert bp.read_pos(r, 110, False, False) is None         # inside the deletion
+    assert bp.read_pos(r, 110, False, True) == 15            # ... projects to where the deletion starts
+    assert bp.read_pos(r, 113, False, False) == 15
+    assert bp.read_pos(r, 123, False, False) == 27           # behind the insertion
+    assert bp.read_pos(r, 97, False, False) is None and bp.read_pos(r, 97, True, False) == 2   # inside the leading soft clip
+    assert bp.read_pos(r, 128, True, True) is None           # behind the read
+    assert r.end_pos() == 128
+
+
+def test_candidate_regions_of_enclosing_and_partial_reads():
+    ref_len = 2000
+    enclosing = _rec(400, [("M", 150)])
+    reg = bp.candidate_region(enclosing, 516, 519, ref_len)
+    assert reg.overlap and reg.ref_interval == (516 - 96, 516 + 96)
+    qs, qe = 116, 119
+    assert reg.read_interval == (qs - 63, min(qe + 63, 150))          # max_window shrinks by half the variant length
+    left = _rec(380, [("M", 138)])                                      # ends inside the variant: only the start projects
+    reg = bp.candidate_region(left, 516, 519, ref_len)
+    assert reg.overlap and reg.read_interval == (136 - 64, 138) and reg.ref_interval == (420, 612)
+    right = _rec(518, [("M", 150)])                                     # starts inside: only the end projects
+    reg = bp.candidate_region(right, 516, 519, ref_len)
+    assert reg.overlap and reg.read_interval == (0, 1 + 64) and reg.ref_interval == (519 - 96, 519 + 96)
+    far = _rec(900, [("M", 150)])
+    assert not bp.candidate_region(far, 516, 519, ref_len).overlap
+    long_read = _rec(300, [("M", 400)])                                 # window capped at the longest pattern (128 bases)
+    reg = bp.candidate_region(long_read, 516, 519, ref_len)
+    assert reg.read_interval[1] - reg.read_interval[0] == bp.MAX_PATTERN_LEN
+
+
+def test_reader_on_the_reference_fixtures(golden_dir):
+    contigs, recs = bp.read_bam(os.path.join(golden_dir, "bam", "test_false_negative_indel_call", "sample.bam"))
+    assert contigs == [("MN908947.3", 29903)] and len(recs) == 2870
+    assert all(len(r.seq) == 150 == len(r.qual) == sum(l for op, l in r.cigar if op in "MIS=X") for r in recs)
+    assert sum(1 for r in recs if not r.unmapped and bp.overlaps(r, 516, 519)) == 342
+    fa = bp.read_fasta(os.path.join(golden_dir, "bam", "test_false_negative_indel_call", "ref.fa"))
+    assert fa["MN908947.3"][516:520] == b"TATG"
+    contigs, recs = bp.read_bam(os.path.join(golden_dir, "bam", "test_uzuner_clonal_1", "sample.bam"))
+    assert len(recs) == 276 and contigs[5][0] == "chr6"
+
+
+def test_deletion_testcase_from_its_bam_with_the_restated_pair_hmm(oracle, golden_dir):
+    """The pipeline of tests/test_gpu_realign_bam.py with oracle/vlr_realign_oracle.cpp in the kernels' place: the pileup built from
+    the testcase's BAM satisfies its `expected:` block (`sample > 0.0`, `PROB_PRESENT <= 0.05`), which the observations recorded
+    before the fix do not (tests/test_oracle_fixture.py)."""
+    from varlociraptor_amd import abi, cli, realign
+    from varlociraptor_amd.batch import PileupBatch
+    from varlociraptor_amd.realign import GapParams, PairBatch
+    import test_gpu_realign_bam as T
+    name = "test_false_negative_indel_call"
+    reads, alt_allele, start, del_len = T._deletion_pairs(os.path.join(golden_dir, "bam", name))
+    assert len(reads) == 342
+    gap = GapParams(-12.785891140783116, -12.186270018233994, -math.inf, -math.inf)
+    pb = PairBatch()
+    for r, seq, qual, ref_allele in reads:
+        pb.add(ref_allele, seq, qual, -1)
+        pb.add(alt_allele, seq, qual, -1)
+    pb.band = [realign.best_hit(pb.y[k], pb.x[k])[0] + realign.EDIT_BAND for k in range(len(pb))]
+    lnp = oracle.pairhmm_batch(pb, gap, threads=8)
+    n = len(reads)
+    pa, pr = np.empty(n), np.empty(n)
+    for k in range(n):
+        pr[k], pa[k] = oracle.normalize_support(float(lnp[2 * k]), float(lnp[2 * k + 1]))
+    carried = np.array([any(op == "D" and l == del_len for op, l in r.cigar) for r, _, _, _ in reads])
+    assert carried.sum() == 40 and (pa[carried] > pr[carried]).all()
+    cols = {"prob_mapping": [bp.prob_mapping(r.mapq) for r, _, _, _ in reads], "prob_alt": pa, "prob_ref": pr,
+            "prob_missed_allele": np.logaddexp(pa, pr) - math.log(2.0), "prob_sample_alt": np.zeros(n),
+            "prob_double_overlap": np.full(n, -np.inf), "prob_hit_base": np.full(n, -math.log(150.0)),
+            "flags": abi.pack_flags(np.where([r.reverse for r, _, _, _ in reads], abi.STRAND_REVERSE, abi.STRAND_FORWARD), np.full(n, abi.ORIENT_NONE),
+                                    np.zeros(n, bool), np.zeros(n, bool), np.ones(n, bool), np.array([r.mapq == 60 for r, _, _, _ in reads]), np.full(n, abi.ALTLOCUS_NONE))}
+    batch = PileupBatch(1, np.array([0, n], np.uint32), {k: np.asarray(v, np.float32) if k != "flags" else v for k, v in cols.items()},
+                        {"locus_flags": np.array([0], np.uint8), "variant_type": np.array([abi.VT_INDEL], np.uint8)})
+    res = oracle.call(cli.scenario_from_yaml(os.path.join(golden_dir, "testcases", name, "scenario.yaml")), batch)
+    assert (res.status[0] & 0xF) == 0
+    assert float(res.map_vaf[0, 0]) > 0.0 and -10.0 * float(res.ln_posterior[0, 1]) / math.log(10.0) <= 0.05

@@ -1923,6 +1923,13 @@ __device__ __forceinline__ double row_sum(double v, int site = __builtin_LINE())
     v += dpp_f64<0xB1>(v, site); v += dpp_f64<0x4E>(v, site); v += dpp_f64<0x141>(v, site); v += dpp_f64<0x140>(v, site);
     return v;
 }
+// row maximum of signed 64-bit keys (every lane of the 16-lane row ends with it)
+__device__ __forceinline__ long long row_max_i64(long long k, int site = __builtin_LINE()) {
+#define VLR_STEP_(CTRL) { const long long o_ = (long long)(((unsigned long long)(unsigned)dpp_i32<CTRL>((int)((unsigned long long)k >> 32), site) << 32) | (unsigned)dpp_i32<CTRL>((int)k, site)); k = o_ > k ? o_ : k; }
+    VLR_STEP_(0xB1) VLR_STEP_(0x4E) VLR_STEP_(0x141) VLR_STEP_(0x140)
+#undef VLR_STEP_
+    return k;
+}
 __device__ __forceinline__ int row_or(int v, int site = __builtin_LINE()) {
     v |= dpp_i32<0xB1>(v, site); v |= dpp_i32<0x4E>(v, site); v |= dpp_i32<0x141>(v, site); v |= dpp_i32<0x140>(v, site);
     return v;
@@ -2073,6 +2080,12 @@ __device__ __forceinline__ double key_ln(long long key) {  // ln of the product 
     const int E = (int)khi >> 16;
     const unsigned hi = 0x3fe00000u | ((khi & 0xffffu) << 4) | (klo >> 28), lo = klo << 4;
     return ln_mantissa(__hiloint2double((int)hi, (int)lo)) + (double)E * kLn2;
+}
+// (mantissa in [1/2, 1), exponent) of the product a key stands for
+__device__ __forceinline__ void key_decode(long long key, double& Pm, int& E) {
+    const unsigned khi = (unsigned)((unsigned long long)key >> 32), klo = (unsigned)key;
+    E = (int)khi >> 16;
+    Pm = __hiloint2double((int)(0x3fe00000u | ((khi & 0xffffu) << 4) | (klo >> 28)), (int)(klo << 4));
 }
 template <int NS, bool KEYED>
 __device__ __forceinline__ void reg_chain_loop(Ctx& c, RegChain& q) {
@@ -2696,27 +2709,50 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
         int rank[4];
         const bool srt = phase != RP_SIMPSON;  // per row: trapezoid over the sorted visited points (Simpson grids are in order)
         const bool any_simpson = __ballot(rowon && !srt) != 0ull;
+        // Keyed batches (round 6): the table holds the product keys of the passes, and everything the epilogue computes is a function of
+        // the PRODUCTS — all entries of a row share prior and fixed part, so the arg-best is the largest key (ties: smallest x, as before:
+        // equal products are equal joints), the row maximum M is prior + fixed + ln(largest product), and e^(v - M) is the RATIO of two
+        // products, (P / P_max) 2^(E - E_max): one reciprocal per row instead of a logarithm and an exponential per entry.  The joint
+        // VALUES of the entries are only formed where somebody reads them: the AFD log, the replay pass, and chains whose points are
+        // candidates of other groups / lie outside their own range (scan_chain_candidates reads the row table).
+        constexpr long long kKeyNone = (long long)0x8000000000000000ull;
+        long long kk[4];
+        long long bK = kKeyNone;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             xi[t] = __builtin_huge_val(); vi[t] = VLR_NEG_INF;
+            kk[t] = kKeyNone;
             rank[t] = 0;
             if (t < TT) {
                 const int i = rl + 16 * t;
                 const bool on = i < n;
                 const int ic = on ? i : 0;
                 const double xr = tx[ic];
-                double vr = tv[ic];
-                if (keyed) vr = (xr == 0.0 ? pr0 : pr1) + (fixed + key_ln(__double_as_longlong(vr)));  // the pass stored the product's key
+                const double vr = tv[ic];
                 xi[t] = on ? xr : __builtin_huge_val();
-                vi[t] = on ? vr : VLR_NEG_INF;
                 const bool inlo = (orig.start < xi[t]) | ((orig.lex == 0) & (orig.start == xi[t]));
                 const bool inhi = (orig.end > xi[t]) | ((orig.rex == 0) & (orig.end == xi[t]));
-                const bool cand = on & (contained != 0) & inlo & inhi & (vi[t] == vi[t]);
-                const bool take = cand & ((bHave == 0) | (vi[t] > bJ) | ((vi[t] == bJ) & (xi[t] < bX)));
-                bJ = take ? vi[t] : bJ; bX = take ? xi[t] : bX; bHave = take ? 1 : bHave;
                 anyout = anyout | (on & !(inlo & inhi));
-                anynan = anynan | (vi[t] != vi[t]);
+                if (keyed) {  // (wave-uniform) the pass stored the product's key; products of keyed passes are finite and positive
+                    kk[t] = on ? __double_as_longlong(vr) : kKeyNone;
+                    const bool cand = on & (contained != 0) & inlo & inhi;
+                    const bool take = cand & ((bHave == 0) | (kk[t] > bK) | ((kk[t] == bK) & (xi[t] < bX)));
+                    bK = take ? kk[t] : bK; bX = take ? xi[t] : bX; bHave = take ? 1 : bHave;
+                } else {
+                    vi[t] = on ? vr : VLR_NEG_INF;
+                    const bool cand = on & (contained != 0) & inlo & inhi & (vi[t] == vi[t]);
+                    const bool take = cand & ((bHave == 0) | (vi[t] > bJ) | ((vi[t] == bJ) & (xi[t] < bX)));
+                    bJ = take ? vi[t] : bJ; bX = take ? xi[t] : bX; bHave = take ? 1 : bHave;
+                    anynan = anynan | (vi[t] != vi[t]);
+                }
             }
+        }
+        // who reads the joint values of this batch's entries (wave-uniform)
+        const bool need_vals = !keyed || log_on(c) || c.replay != 0 || __ballot(rowon && (T.alive != 0 || contained == 0 || anyout)) != 0ull;
+        if (keyed && need_vals) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (t < TT) vi[t] = (kk[t] != kKeyNone) ? (xi[t] == 0.0 ? pr0 : pr1) + (fixed + key_ln(kk[t])) : VLR_NEG_INF;
         }
         TRC(c, 81, n); TRC(c, 82, nmax); TRC(c, 83, xi[0]); TRC(c, 84, vi[0]); TRC(c, 85, xi[1]); TRC(c, 86, vi[1]); TRC(c, 87, bJ); TRC(c, 88, bX);
         // AFD log: the four row tables as they stand (any order), one record per chain (no l2fc terms on batched chains)
@@ -2803,8 +2839,8 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
                     if (t < TT) {
                         const int i = rl + 16 * t;
                         if (i < n) {
-                            if (srt) { tx[rank[t]] = xi[t]; tv[rank[t]] = vi[t]; }
-                            else tv[i] = vi[t];
+                            if (srt) { tx[rank[t]] = xi[t]; if (need_vals) tv[rank[t]] = vi[t]; }
+                            else if (need_vals) tv[i] = vi[t];
                         }
                     }
                 }
@@ -2824,7 +2860,7 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
                 if (__builtin_expect(__ballot(bad) == 0ull, 1)) break;
                 use32 = false;
             }
-        } else if (keyed) {  // no row is sorted (Simpson grids only): the tables still hold keys
+        } else if (keyed && need_vals) {  // no row is sorted (Simpson grids only): the tables still hold keys
             VLR_WAVE_FENCE();
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -2836,25 +2872,56 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
         // ---- row arg-best of (bJ desc, bX asc) for the MAP candidate: the row maximum of the lanes' best joints (a lane
         // without a candidate counts as -inf; whether the row has one at all travels apart: a candidate may be worth -inf itself),
         // then the smallest x among the lanes that hold it
-        {
+        double M;
+        double rP = 0.0;   // keyed: 1 / mantissa of the row's largest product, and its exponent
+        int mE = 0;
+        if (keyed) {
+            long long m4K = kk[0];
+#pragma unroll
+            for (int t = 1; t < 4; ++t) m4K = kk[t] > m4K ? kk[t] : m4K;
+            const long long rowKall = row_max_i64(m4K);
+            const long long candK = bHave ? bK : kKeyNone;
+            // (a lane whose best candidate is its largest entry — every lane of every row unless points lie outside their own range —
+            //  makes the second reduction the first)
+            const long long rowK = (__ballot(candK != m4K) == 0ull) ? rowKall : row_max_i64(candK);
+            const int rowHave = row_or(bHave);
+            double xs_ = (bHave != 0 && bK == rowK) ? bX : __builtin_huge_val();
+            xs_ = fmin(xs_, dpp_f64<0xB1>(xs_)); xs_ = fmin(xs_, dpp_f64<0x4E>(xs_)); xs_ = fmin(xs_, dpp_f64<0x141>(xs_)); xs_ = fmin(xs_, dpp_f64<0x140>(xs_));
+            double mP;
+            key_decode(rowKall, mP, mE);
+            M = (n > 0) ? pr1 + (fixed + (ln_mantissa(mP) + (double)mE * kLn2)) : VLR_NEG_INF;
+            bJ = M;
+            if (__ballot(rowHave != 0 && rowK != rowKall) != 0ull) bJ = (rowK == rowKall) ? M : pr1 + (fixed + key_ln(rowK));
+            bX = xs_; bHave = rowHave;
+            rP = __builtin_amdgcn_rcp(mP);
+            rP = __builtin_fma(__builtin_fma(-mP, rP, 1.0), rP, rP);
+            rP = __builtin_fma(__builtin_fma(-mP, rP, 1.0), rP, rP);
+        } else {
             const int rowHave = row_or(bHave);
             const double rowJ = row_max(bHave ? bJ : VLR_NEG_INF);
             double xs_ = (bHave != 0 && bJ == rowJ) ? bX : __builtin_huge_val();
             xs_ = fmin(xs_, dpp_f64<0xB1>(xs_)); xs_ = fmin(xs_, dpp_f64<0x4E>(xs_)); xs_ = fmin(xs_, dpp_f64<0x141>(xs_)); xs_ = fmin(xs_, dpp_f64<0x140>(xs_));
             bJ = rowJ; bX = xs_; bHave = rowHave;
-        }
-        double m4 = VLR_NEG_INF;
+            double m4 = VLR_NEG_INF;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) m4 = fmax(m4, (vi[t] == vi[t]) ? vi[t] : VLR_NEG_INF);
-        const double M = row_max(m4);
+            for (int t = 0; t < 4; ++t) m4 = fmax(m4, (vi[t] == vi[t]) ? vi[t] : VLR_NEG_INF);
+            M = row_max(m4);
+        }
         double ssum = 0.0;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             if (t < TT) {
                 const int i = rl + 16 * t;
                 const bool on = i < n;
-                const bool zero = (vi[t] == VLR_NEG_INF) | (M == VLR_NEG_INF) | (vi[t] != vi[t]);
-                const double ev = zero ? 0.0 : exp(vi[t] - M);
+                double ev;
+                if (keyed) {  // e^(v - M) as the ratio of the two products (entries beyond the row's table: far below the smallest double)
+                    double eP; int eE;
+                    key_decode(kk[t], eP, eE);
+                    ev = __builtin_ldexp(eP * rP, eE - mE);
+                } else {
+                    const bool zero = (vi[t] == VLR_NEG_INF) | (M == VLR_NEG_INF) | (vi[t] != vi[t]);
+                    ev = zero ? 0.0 : exp(vi[t] - M);
+                }
                 double wgt;
                 {
                     // sum_seg (e_k + e_{k+1}) (x_{k+1} - x_k)/2 = sum_k e_k (x_{k+1} - x_{k-1})/2, one-sided at the ends
@@ -4833,8 +4900,11 @@ extern "C" int VLR_FN_CALL(const vlr::DevPlan* plan_host, const vlr::DevBatch* b
     }
     // 160 kB of LDS per CU: the 2-wave build tops out at 8 workgroups per CU; from 9 on the 3-wave build wins although it
     // spills (tools/occupancy_probe.py: +5 % at 9-10 workgroups, +15..33 % at 10-12, -4 % at 8)
+    // Round 6 (tools/waves4_probe.py): where 16 workgroups fit, the 4-wave build (128 VGPRs, ~85 of them spilled) wins on the shallow
+    // multi-sample workloads — tumor-normal at 20x / 30x: +11 % / +12 % — and is level on config 2 (+1 %); at 15 it is +2 %, below that it
+    // only pays its spills (config 5, 13 workgroups: -3 %).
     const size_t lds_wg = (static_lds + bytes + 511) & ~(size_t)511;
-    int wpe = (163840 / lds_wg >= 9) ? 3 : 2;
+    int wpe = (163840 / lds_wg >= 16) ? 4 : (163840 / lds_wg >= 9) ? 3 : 2;
     if (const char* ev = getenv("VLR_WAVES_PER_SIMD")) wpe = atoi(ev);  // tuning / build-matrix knob (tests/test_gpu_build_matrix.py)
     dim3 grid((unsigned)batch->n_loci), block(64);
 #define VLR_LAUNCH(W)                                                                                                        \
