@@ -547,7 +547,7 @@ def main():
     dbatch = engine.DeviceBatch(batch, dev)
     plan = engine.Plan(cfg.scenario, device=local_rank)
     # the caller knows its pileups: size the kernel's LDS coefficient area to the deepest locus of the batch
-    plan.set_max_obs(int(batch.depth().sum(axis=1).max()))
+    plan.fit_max_obs(batch.obs_offset)   # LDS budget from the batch (vlr_plan_fit_max_obs: the deepest locus or the 16-workgroup budget)
     plan.reserve(batch.n_loci, with_afd=args.afd_capacity if args.afd else 0)  # vlr_batch_run then only enqueues work on the stream
     out = engine.DeviceResults(batch.n_loci, plan.n_out, plan.n_samples, dev)
     stream = torch.cuda.current_stream().cuda_stream

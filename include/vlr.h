@@ -296,6 +296,14 @@ int  vlr_plan_set_max_depth(vlr_plan* plan, int per_sample_depth);
  * workgroup = more resident waves.  vlr_batch_run_host does this automatically.                          */
 int  vlr_plan_set_max_obs(vlr_plan* plan, int max_obs_per_locus);
 
+/* The same knob set FROM the batch: `obs_offset_host` are the n_loci * n_samples + 1 pileup offsets of the batch in host memory.
+ * Picks the deepest locus — or, where a slightly smaller budget lets sixteen workgroups share a CU (the launcher then runs the
+ * kernel build with four waves per SIMD), that budget, provided no locus exceeds it or at most 0.5 % of a batch of 100 000 loci or
+ * more do; those take the deep launch (coefficients in the plan's HBM pool) like every locus above the LDS budget.  Returns the
+ * budget (>= 1) or an error (< 0).  vlr_batch_run_host applies the same rule per chunk; callers of vlr_batch_run with device
+ * batches call this.  (The reference has no such knob: its per-sample depth limit is preprocess's --max-depth, sample.rs:236.) */
+int  vlr_plan_fit_max_obs(vlr_plan* plan, const uint32_t* obs_offset_host, int64_t n_loci);
+
 /* Evaluate a batch of loci on the plan's device.  All pointers in `in` / `out` are device pointers.
  * `stream` is a hipStream_t (NULL = default stream); the call is stream-ordered and does not synchronise.
  * Replaces the per-record Caller::call_record (calling.rs:720-842) for n_loci records.                  */

@@ -8,7 +8,11 @@ for name in os.environ.get("VLR_RATE_CONFIGS", "config3,config2").split(","):
     cfg = synth.CONFIGS[name]()
     batch = generate(name, n, 0)
     dbatch = engine.DeviceBatch(batch, "cuda:0")
-    plan = engine.Plan(cfg.scenario); plan.set_max_obs(int(batch.depth().sum(axis=1).max()))
+    plan = engine.Plan(cfg.scenario)
+    try:
+        plan.fit_max_obs(batch.obs_offset)
+    except AttributeError:   # a library built before vlr_plan_fit_max_obs existed
+        plan.set_max_obs(int(batch.depth().sum(axis=1).max()))
     out = engine.DeviceResults(batch.n_loci, plan.n_out, plan.n_samples, "cuda:0")
     st = torch.cuda.current_stream().cuda_stream
     ms=[]

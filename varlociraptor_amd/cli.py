@@ -345,7 +345,7 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                 sub = batch if len(mine) == L else batch.select(mine)
                 # observation files are already capped by preprocess's --max-depth: size the LDS budget to the deepest record
                 # (deeper records than the LDS holds take the deep launch); the depth comes from the offsets, never from the columns
-                plan.set_max_obs(min(max(int(sub.depth().sum(axis=1).max()), 1), engine.MAX_OBS_LDS))
+                plan.fit_max_obs(sub.obs_offset)
                 if len(mine) == L and on_dev:
                     # the columns were decoded on the device (device reader): nothing to stage but the results, which land in recycled
                     # page-locked memory when the calls writer is the only consumer (it hands the block back after the chunk is written)

@@ -35,6 +35,7 @@ extern "C" int vlr_launch_call_kernel(const vlr::DevPlanT<8>* plan_dev, const vl
                                       int n_univ, int n_samples, int max_obs, int range_depth, void* stream);
 // LDS a workgroup of the plan needs before any coefficient area (call pass, AFD replay, AFD log filter; vlr_kernels.hip)
 extern "C" long long vlr_plan_lds_floor(const vlr::DevPlanT<8>* plan_host, int n_univ, int n_samples, int range_depth);
+extern "C" long long vlr_launch_call_lds_bytes(const vlr::DevPlanT<8>* plan_host, int n_univ, int n_samples, int max_obs, int range_depth);
 extern "C" long long vlr_plan_lds_floor_wide(const vlr::DevPlanT<16>* plan_host, int n_univ, int n_samples, int range_depth);
 
 namespace {
@@ -257,6 +258,7 @@ struct HostPrior {
 struct vlr_plan {
     int device = 0;
     vlr::DevPlanT<16> host{};  // host copy (device pointers inside): the layout for up to sixteen samples
+    long long lds_b0 = -2;     // LDS bytes of a call-kernel workgroup without coefficient area (fit_budget; -2: not asked yet)
     bool wide = false;         // more than eight samples, four l2fc terms or four nested ranges on a path: the wide build of the kernels
     vlr::DevPlanT<8> host8{};  // the same plan in the layout of the standard and deep builds (plans of at most eight samples)
     vlr::DevPlanT<16>* dev = nullptr;
@@ -929,6 +931,41 @@ int vlr_plan_set_max_obs(vlr_plan* plan, int max_obs_per_locus) {
     return VLR_OK;
 }
 
+// LDS budget for a batch whose pileups the caller knows (host offsets): the deepest locus — or, where a slightly smaller budget lets
+// SIXTEEN workgroups share a CU (the launcher then runs the 4-wave build: +11..13 % on shallow tumor-normal batches,
+// tools/waves4_lds_probe.py), at most 0.5 % of the loci exceed it and the batch is large enough to pay for the deep launch behind the
+// call launch (one locus' latency, ~1 ms: tools/budget_probe.py), that budget.
+static int fit_budget(vlr_plan* plan, const uint32_t* off, int64_t l0, int64_t l1, int S, int cap_budget) {
+    uint32_t mx = 1;
+    for (int64_t l = l0; l < l1; ++l) mx = std::max(mx, off[(l + 1) * S] - off[l * S]);
+    int best = std::min<int>(cap_budget, (int)mx);
+    if (plan->wide || getenv("VLR_NO_FIT_BUDGET")) return best;
+    if (plan->lds_b0 == -2) {
+        plan->lds_b0 = vlr_launch_call_lds_bytes(&plan->host8, plan->host.n_univ, S, 0, plan->host.max_range_depth);
+        if (plan->lds_b0 < 0) (void)hipGetLastError();
+    }
+    const long long b0 = plan->lds_b0;
+    if (b0 < 0) return best;
+    if (b0 + 16ll * ((best + 3) & ~3) <= vlr::kLdsWg16 || b0 + 64 > vlr::kLdsWg16) return best;
+    const int m16 = (int)((vlr::kLdsWg16 - b0) / 16) & ~3;   // largest budget with 16 workgroups per CU (the launch rounds budgets up to a multiple of four)
+    if (m16 < 1 || m16 >= best) return best;
+    int64_t over = 0;
+    for (int64_t l = l0; l < l1; ++l) over += (off[(l + 1) * S] - off[l * S]) > (uint32_t)m16;
+    return (over * 200 <= (l1 - l0) && (over == 0 || l1 - l0 >= 100000)) ? m16 : best;
+}
+
+int vlr_plan_fit_max_obs(vlr_plan* plan, const uint32_t* obs_offset_host, int64_t n_loci) {
+    if (!plan || !obs_offset_host || n_loci < 0) return fail(VLR_ERR_INVALID_ARGUMENT, "invalid argument");
+    int dev_before = 0;
+    (void)hipGetDevice(&dev_before);
+    (void)hipSetDevice(plan->device);
+    const int S = plan->host.S;
+    const int b = fit_budget(plan, obs_offset_host, 0, n_loci, S, 7680);
+    (void)hipSetDevice(dev_before);
+    const int rc = vlr_plan_set_max_obs(plan, std::max(1, b));
+    return rc != VLR_OK ? rc : std::max(1, b);
+}
+
 // Device buffers a batch of n_loci needs besides the caller's: kernel scratch (third coefficients), and with AFD the replay
 // scratch and the AFD log.  Grown here (hipMalloc/hipFree synchronise the device); vlr_batch_run calls this itself, callers that
 // need a strictly asynchronous vlr_batch_run size the plan once with vlr_plan_reserve.
@@ -1304,9 +1341,9 @@ static int host_chunk_start(vlr_plan* plan, const vlr_batch* in, vlr_results* ou
         int budget = plan->max_obs > 0 ? plan->max_obs : plan->max_depth_per_sample * S;
         uint32_t mx = 1;
         for (int64_t l = l0; l < l1; ++l) mx = std::max(mx, h_off[(l + 1) * S] - h_off[l * S]);
-        plan->max_obs = std::min<int>(budget, (int)mx);
+        plan->max_obs = fit_budget(plan, h_off, l0, l1, S, budget);   // (the deepest locus, or the 16-workgroup budget: see fit_budget)
         // the LDS-resident kernel holds at most 7 680 kept observations of a locus; the launcher's own limit is the budget
-        plan->deep_hint = ((int)mx > std::min(budget, 7680)) ? 1 : 0;
+        plan->deep_hint = ((int)mx > std::min(plan->max_obs, 7680)) ? 1 : 0;
     }
     plan->slot = k;
     int rc = vlr_batch_run(plan, &db, &dr, (void*)st);

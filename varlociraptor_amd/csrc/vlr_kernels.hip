@@ -17,6 +17,7 @@
 // No MFMA: this is f64 VALU + LDS work (north star); the HBM traffic is one pass over the columns.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "../../include/vlr.h"
 #include "../../include/vlr_detmath.h"
@@ -92,7 +93,7 @@ struct RangeSt {
     int have_first, phase, npend, simpson_n, tn, sample, olex, orex, leaf, have_mid;
 };
 
-constexpr int kRows = 4;        // concurrent chains per wave: one per 16-lane DPP row
+// (kRows = 4 concurrent chains per wave, one per 16-lane DPP row: vlr_plan.h)
 constexpr int kRowPts = 11;     // pending points of one chain round (Simpson fall-back: 11)
 constexpr int kPass = 3;        // points one lane carries through a pass over its observation slice
 
@@ -4883,6 +4884,16 @@ extern "C" long long VLR_FN_LDS(const vlr::DevPlan* plan_host, int n_univ, int n
     return (long long)(call > afd ? call : afd);
 }
 
+// LDS bytes of one workgroup of the call kernel (static + dynamic) at a pileup budget of max_obs: what the launcher's rule below sees
+// (vlr_plan_fit_max_obs in vlr_host.cpp sizes the budget of shallow batches with it)
+#ifndef VLR_WIDE_BUILD
+extern "C" long long vlr_launch_call_lds_bytes(const vlr::DevPlan* plan_host, int n_univ, int n_samples, int max_obs, int range_depth) {
+    hipFuncAttributes fa{};
+    if (hipFuncGetAttributes(&fa, (const void*)vlr::vlr_call_kernel<2>) != hipSuccess) return -1;
+    if (range_depth < 1) range_depth = 1;
+    return (long long)(fa.sharedSizeBytes + call_kernel_dyn_lds(plan_host, n_univ, n_samples, max_obs, range_depth, false));
+}
+#endif
 // host-callable launcher (used by vlr_host.cpp)
 extern "C" int VLR_FN_CALL(const vlr::DevPlan* plan_host, const vlr::DevBatch* batch, const vlr::DevResults* out,
                                       int n_univ, int n_samples, int max_obs, int range_depth, void* stream) {
@@ -4900,12 +4911,15 @@ extern "C" int VLR_FN_CALL(const vlr::DevPlan* plan_host, const vlr::DevBatch* b
     }
     // 160 kB of LDS per CU: the 2-wave build tops out at 8 workgroups per CU; from 9 on the 3-wave build wins although it
     // spills (tools/occupancy_probe.py: +5 % at 9-10 workgroups, +15..33 % at 10-12, -4 % at 8)
-    // Round 6 (tools/waves4_probe.py): where 16 workgroups fit, the 4-wave build (128 VGPRs, ~85 of them spilled) wins on the shallow
-    // multi-sample workloads — tumor-normal at 20x / 30x: +11 % / +12 % — and is level on config 2 (+1 %); at 15 it is +2 %, below that it
-    // only pays its spills (config 5, 13 workgroups: -3 %).
+    // Round 6 (tools/waves4_probe.py, waves4_lds_probe.py): where SIXTEEN workgroups fit a CU, the 4-wave build (128 VGPRs, ~85 of them
+    // spilled) wins on the shallow multi-sample workloads — tumor-normal at 20x / 30x: +11 % / +13 % — and is level on config 2 (+1 %); at
+    // 14-15 workgroups it is +2 %, below that it only pays its spills (-9 %).  (Getting config 3 there — 2 kB of row tables moved to the
+    // HBM scratch row plus a pileup budget at the 99.7 % quantile — was built and measured: +1.7 % on config 3, +2.3 % on config 4,
+    // -4 % on config 5; not kept.  profiles/r06c.md)
     const size_t lds_wg = (static_lds + bytes + 511) & ~(size_t)511;
-    int wpe = (163840 / lds_wg >= 16) ? 4 : (163840 / lds_wg >= 9) ? 3 : 2;
+    int wpe = (static_lds + bytes <= (size_t)kLdsWg16) ? 4 : (163840 / lds_wg >= 9) ? 3 : 2;
     if (const char* ev = getenv("VLR_WAVES_PER_SIMD")) wpe = atoi(ev);  // tuning / build-matrix knob (tests/test_gpu_build_matrix.py)
+    if (getenv("VLR_DEBUG_LAUNCH")) fprintf(stderr, "vlr launch: max_obs %d static %zu dynamic %zu -> %zu B, %d waves/SIMD\n", max_obs, static_lds, bytes, static_lds + bytes, wpe);
     dim3 grid((unsigned)batch->n_loci), block(64);
 #define VLR_LAUNCH(W)                                                                                                        \
     case W: {                                                                                                                \

@@ -31,6 +31,9 @@ constexpr int kTableCapMax = 1024;    // upper limit of the per-plan table capac
 constexpr int kMaxSet = 1024;         // members of one Set spectrum (LDS: 8 B x samples x the plan's largest set; the reference has no limit)
 constexpr int kMaxNamedEvents = 30;   // scenario events (engine universe = 1 + 2*named); 1 + named event groups fit the 31 value bits of the int32 alive masks
 constexpr int kNHyp = 9;              // 0 = Artifacts::none(), 1..8 single-artifact combinations
+constexpr int kRows = 4;             // concurrent innermost chains per wave of the call kernel: one per 16-lane DPP row
+constexpr int kLdsWg16 = 163840 / 16;  // LDS bytes of a workgroup (static + dynamic) up to which SIXTEEN workgroups share a CU (tools/budget_probe.py:
+                                       // 10 192 B fit, 10 256 B do not — the host rounds the pileup budget up to a multiple of four observations)
 constexpr int kCacheWays = 4;         // per-sample pileup-likelihood cache entries
 constexpr int kMaxBatchPoints = 16;   // points evaluated by one eval_pileup call
 constexpr int kContainStack = 24;     // explicit stack of the VAFTree::contains walk

@@ -23,7 +23,7 @@ _LIB = None
 
 EXPORTS = [
     "vlr_abi_version", "vlr_build_id", "vlr_last_error", "vlr_plan_create", "vlr_plan_destroy", "vlr_plan_n_out",
-    "vlr_plan_n_samples", "vlr_plan_set_max_depth", "vlr_plan_set_max_obs", "vlr_plan_reserve", "vlr_batch_run", "vlr_batch_run_host", "vlr_batch_run_device_in",
+    "vlr_plan_n_samples", "vlr_plan_set_max_depth", "vlr_plan_set_max_obs", "vlr_plan_fit_max_obs", "vlr_plan_reserve", "vlr_batch_run", "vlr_batch_run_host", "vlr_batch_run_device_in",
     "vlr_plan_last_kernel_ms", "vlr_plan_work_counters", "vlr_host_alloc", "vlr_host_free",
     "vlr_node_create", "vlr_node_destroy", "vlr_node_n_devices", "vlr_node_device", "vlr_node_plan", "vlr_node_set_max_depth", "vlr_node_set_max_obs", "vlr_node_shard_range", "vlr_node_batch_run_host",
     "vlr_realign_batch", "vlr_realign_batch_host", "vlr_realign_fast_batch", "vlr_realign_fast_batch_host", "vlr_realign_homopolymer_batch", "vlr_realign_homopolymer_batch_host", "vlr_edit_distance_batch", "vlr_edit_distance_batch_host", "vlr_fdr_threshold", "vlr_selftest_math", "vlr_selftest_stream", "vlr_selftest_format_fixed", "vlr_selftest_afd_text",
@@ -188,6 +188,18 @@ class Plan:
 
     def set_max_obs(self, n: int):
         _check(lib().vlr_plan_set_max_obs(self._h, int(n)))
+
+    def fit_max_obs(self, obs_offset) -> int:
+        """vlr_plan_fit_max_obs: LDS budget from the batch's pileup offsets (host array of n_loci * n_samples + 1 uint32) — the
+        deepest locus, or the budget that lets sixteen workgroups share a CU when at most 0.5 % of the loci exceed it."""
+        off = np.ascontiguousarray(obs_offset, np.uint32)
+        L = lib()
+        L.vlr_plan_fit_max_obs.restype = C.c_int
+        L.vlr_plan_fit_max_obs.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        rc = L.vlr_plan_fit_max_obs(self._h, off.ctypes.data, (len(off) - 1) // self.n_samples)
+        if rc < 0:
+            _check(rc)
+        return int(rc)
 
     def close(self):
         if self._h:
