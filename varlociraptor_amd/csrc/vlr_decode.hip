@@ -1042,6 +1042,10 @@ struct vlr_dev_file {
     size_t cap = 0, rd = 0, wr = 0, ready = 0;
     uint8_t* spare = nullptr;     // the other half of the ping-pong (compaction never copies inside one allocation)
     size_t spare_cap = 0;
+    // ordering of a compaction against the decode stream: the copy may only overwrite `spare` once the kernels that
+    // still read it (it was `buf` one compaction ago) are through, and the kernels enqueued after it must see the copied bytes
+    hipEvent_t ev_readers = nullptr, ev_compact = nullptr;
+    bool compact_pending = false;
     // split
     uint64_t *d_anchor = nullptr, *d_landing = nullptr, *d_segbase = nullptr; uint32_t* d_count = nullptr; uint8_t* d_landc = nullptr; size_t seg_cap = 0;
     uint64_t* d_starts = nullptr; uint64_t* d_nout = nullptr; vlr::RecDesc* d_desc = nullptr; vlr::RecHost* d_host = nullptr; size_t rec_cap = 0;
@@ -1063,6 +1067,8 @@ void dev_file_free(vlr_dev_file* f) {
     if (f->feed_stream) (void)hipStreamDestroy(f->feed_stream);
     if (f->up_stream) (void)hipStreamDestroy(f->up_stream);
     if (f->copy_stream) (void)hipStreamDestroy(f->copy_stream);
+    if (f->ev_readers) (void)hipEventDestroy(f->ev_readers);
+    if (f->ev_compact) (void)hipEventDestroy(f->ev_compact);
     for (auto& fd : f->feeds) {
         for (hipEvent_t e : {fd.ev0, fd.ev1, fd.done, fd.up})
             if (e) (void)hipEventDestroy(e);
@@ -1108,7 +1114,7 @@ int vlr_dev_file_create(int device, vlr_dev_file** out) {
             if (park[i]->device == device) {
                 vlr_dev_file* f = park[i];
                 park.erase(park.begin() + (long)i);
-                f->rd = f->wr = f->ready = 0; f->feed_head = f->feed_n = 0; f->n_split = 0; f->inflate_s = 0.0;
+                f->rd = f->wr = f->ready = 0; f->feed_head = f->feed_n = 0; f->n_split = 0; f->inflate_s = 0.0; f->compact_pending = false;
                 f->fok_n = -1;   // (the key table of the new file is uploaded at its first split)
                 *out = f;
                 return VLR_OK;
@@ -1194,7 +1200,15 @@ int vlr_dev_file_feed_pieces(vlr_dev_file* f, const uint8_t* const* piece, const
             if (hipMalloc(&f->spare, ncap) != hipSuccess) return dfail(VLR_ERR_OUT_OF_MEMORY, "device reader: out of device memory (%s%lld bytes)", "", (long long)ncap);
             f->spare_cap = ncap;
         }
+        if (!f->ev_readers) { (void)hipEventCreateWithFlags(&f->ev_readers, hipEventDisableTiming); (void)hipEventCreateWithFlags(&f->ev_compact, hipEventDisableTiming); }
+        if (!f->ev_readers || !f->ev_compact) return dfail(VLR_ERR_HIP, "device reader: hipEventCreate failed%s%lld", "", 0LL);
+        // (a second compaction within one call, or a feed cut into several pieces, reaches this point while split / decode kernels of
+        //  the chunk in front are still enqueued on the decode stream: they read what is about to become the copy's target)
+        VLR_HIP_OK(hipEventRecord(f->ev_readers, f->stream));
+        VLR_HIP_OK(hipStreamWaitEvent(st, f->ev_readers, 0));
         if (live) VLR_HIP_OK(hipMemcpyAsync(f->spare, f->buf + f->rd, live, hipMemcpyDeviceToDevice, st));
+        VLR_HIP_OK(hipEventRecord(f->ev_compact, st));
+        f->compact_pending = true;   // the next kernels on the decode stream wait for the copy (vlr_dev_file_split)
         std::swap(f->buf, f->spare); std::swap(f->cap, f->spare_cap);
         // (positions move with the bytes: the copy runs behind the pending inflates on the feed stream, which wrote the old positions)
         for (int i = 0; i < f->feed_n; ++i) f->feeds[(f->feed_head + i) % vlr_dev_file::kFeedSlots].wr_end -= f->rd;
@@ -1298,6 +1312,10 @@ int vlr_dev_file_split(vlr_dev_file* f, int64_t max_records, int n_contigs, int 
     f->n_split = 0;
     const uint64_t avail = f->ready - f->rd;
     if (avail < 8 || max_records <= 0) return VLR_OK;
+    if (f->compact_pending) {   // bytes that were buffered before a compaction reach this allocation by a copy on the feed stream
+        VLR_HIP_OK(hipStreamWaitEvent(f->stream, f->ev_compact, 0));
+        f->compact_pending = false;
+    }
     const uint8_t* base = f->buf + f->rd;
     const int n_seg = (int)((avail + vlr::kSeg - 1) / vlr::kSeg);
     int rc;

@@ -4918,6 +4918,10 @@ extern "C" int VLR_FN_CALL(const vlr::DevPlan* plan_host, const vlr::DevBatch* b
     // -4 % on config 5; not kept.  profiles/r06c.md)
     const size_t lds_wg = (static_lds + bytes + 511) & ~(size_t)511;
     int wpe = (static_lds + bytes <= (size_t)kLdsWg16) ? 4 : (163840 / lds_wg >= 9) ? 3 : 2;
+    // single-sample plans (one chain at a time, no nested frames: the walk's state is small) with room for 20 workgroups or more: the
+    // 6-wave build (80 VGPRs).  config 2: 5.71 -> 5.35 ms per 200 000 loci (+6.7 %); a two-sample plan at the same footprint loses half
+    // (tumor-normal at 15x: 26.8 -> 41.1 ms), 8 waves lose everywhere (tools/waves8_probe.py)
+    if (n_samples == 1 && 163840 / lds_wg >= 20) wpe = 6;
     if (const char* ev = getenv("VLR_WAVES_PER_SIMD")) wpe = atoi(ev);  // tuning / build-matrix knob (tests/test_gpu_build_matrix.py)
     if (getenv("VLR_DEBUG_LAUNCH")) fprintf(stderr, "vlr launch: max_obs %d static %zu dynamic %zu -> %zu B, %d waves/SIMD\n", max_obs, static_lds, bytes, static_lds + bytes, wpe);
     dim3 grid((unsigned)batch->n_loci), block(64);
@@ -4929,10 +4933,10 @@ extern "C" int VLR_FN_CALL(const vlr::DevPlan* plan_host, const vlr::DevBatch* b
         break;                                                                                                               \
     }
     switch (wpe) {
+        VLR_LAUNCH(6)
         VLR_LAUNCH(4)
         VLR_LAUNCH(3)
-#ifdef VLR_STRESS_BUDGETS  // register budgets far below anything shipped: 80 and 64 VGPRs, hundreds of spills
-        VLR_LAUNCH(6)
+#ifdef VLR_STRESS_BUDGETS  // a register budget far below anything shipped: 64 VGPRs, hundreds of spills
         VLR_LAUNCH(8)
 #endif
         default:
