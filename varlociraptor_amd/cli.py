@@ -432,7 +432,10 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
             want_shards = (world > 1 and processor is None and candidate_filter is None and bool(output) and str(output).endswith(".bcf")
                            and os.environ.get("VLR_INGEST_SHARDED", "1") != "0")
             try:
-                reader = vingest.ObsReader(paths, omit_bias_mask=omit_mask, chunk_records=int(os.environ.get("VLR_CLI_CHUNK", "0")) or 32768, device=device,
+                # records per request: 32 768, and 65 536 for inputs above a gigabyte (tools/cli_sweep.sh, 1 M records per step: 1.66 -> 1.75 M
+                # records/s; 131 072: 1.42 M — too few chunks for the three stages to overlap —, 16 384: 1.25 M)
+                big = sum(os.path.getsize(p_) for p_ in paths) >= (1 << 30)
+                reader = vingest.ObsReader(paths, omit_bias_mask=omit_mask, chunk_records=int(os.environ.get("VLR_CLI_CHUNK", "0")) or (65536 if big else 32768), device=device,
                                            shard=(rank, world) if want_shards else None,
                                            # the observation columns stay on the device and the calls writer takes the OBS text, the SAOBS / SROBS letters
                                            # and the DP runs of every pileup from obs_text_kernel (vlr_obs_reader_set_host_columns(0)); a processor, a
