@@ -40,8 +40,9 @@
 // (tests/test_bam_pairs.py) and the GPU kernels (tests/test_gpu_realign_bam.py, equal to 1e-9 in ln P on those 684 real pairs)
 // turn them into supports, and the call meets the testcase's `sample > 0.0`, `PROB_PRESENT <= 0.05`: every read whose alignment
 // carries the deletion supports the alt allele, 98.6 % of the reads aligned through the locus without it support the reference.
-// That pins the recursion at the level the reference's own test does (an inequality on the call); items (1)-(3) stay
-// unverifiable to the last digits without the crate.
+// Six GIAB testcases with a BAM (test_giab_04, _05, _06, _11, _12, _16: insertions and replacements, tests/bam_pairs.py:BAM_CASES)
+// go the same way and meet their `expected:` blocks.  That pins the recursion at the level the reference's own tests do (a
+// condition on the call, for three variant types); items (1)-(3) stay unverifiable to the last digits without the crate.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>

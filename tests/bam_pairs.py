@@ -11,6 +11,10 @@ positions into reads, and the candidate regions of one read against one variant 
   Realigner::ref_window / max_window          realignment/mod.rs:149-158 (ref window = 1.5 x realignment window)
   SingleLocus::overlap (enclosing / some)     variants/types/mod.rs (used by Deletion::is_valid_evidence, types/deletion.rs:167-175)
 
+`indel_pairs` classifies the candidate as utils/collect_variants.rs:274-300 does (deletion / insertion with a one-base anchor,
+anything else of unequal lengths a replacement) and builds the alt allele window of that type; `single_end_pileup` turns the
+per-read supports into the engine's pileup.
+
 What is NOT restated (and the tests say so where it matters): fragments (read pairs are two single-end observations here, without
 the insert-size support of deletion.rs:232-258), alternative variants at the locus, the read-inferred third allele
 (mod.rs:311-349), prob_sample_alt (taken as certain).
@@ -196,3 +200,126 @@ def prob_mapping(mapq: int) -> float:
     """ln(1 - 10^(-MAPQ/10)) (read_observation.rs:620-640; MAPQ 0 -> ln 0)"""
     p = 1.0 - 10.0 ** (-mapq / 10.0)
     return math.log(p) if p > 0.0 else -math.inf
+
+
+@dataclass
+class IndelCase:
+    kind: str                 # "deletion" | "insertion" | "replacement"
+    start: int                # locus start (0-based; the anchor base of a deletion / insertion)
+    end: int                  # locus end (exclusive)
+    len_diff: int             # alt length - ref length
+    alt_allele: bytes         # the alt allele window (independent of the read)
+    reads: list               # (record, read window, qualities, ref allele window) per read that is valid evidence
+
+
+def indel_pairs(d: str, window: int = 64) -> IndelCase:
+    """Reads of the testcase in directory `d` (one *.bam, ref.fa, variant.tsv) that are valid evidence for its variant, with their
+    read windows and allele windows."""
+    import glob
+    import os
+    from varlociraptor_amd import realign
+    bam, = glob.glob(os.path.join(d, "*.bam"))
+    _, recs = read_bam(bam)
+    var = open(os.path.join(d, "variant.tsv")).read().split("\n")[1].split("\t")
+    ref_seq = read_fasta(os.path.join(d, "ref.fa"))[var[0]].upper()
+    start = int(var[1]) - 1
+    ref, alt = var[3].encode(), var[4].encode()
+    assert ref_seq[start:start + len(ref)] == ref and len(ref) != len(alt)
+    ref_window = int(window * 1.5)
+    n = len(ref_seq)
+    if len(alt) == 1 and ref[:1] == alt:
+        # Deletion::new: locus = start..end, deleted bases start+1..end (deletion.rs:41-49); alt window deletion.rs:117-137
+        kind, dl = "deletion", len(ref) - 1
+        end = start + dl
+        allele = realign.deletion_allele(ref_seq, max(0, start - ref_window), min(start + ref_window, n - dl), start, dl)
+    elif len(ref) == 1 and alt[:1] == ref:
+        # Insertion::new: locus = start..start+1; alt window insertion.rs:92-113
+        kind, ins = "insertion", alt[1:]
+        end = start + 1
+        allele = realign.insertion_allele(ref_seq, max(0, start - ref_window), min(start + len(ins) + ref_window, n), start, ins)
+    else:
+        # Replacement::new: locus = the REF allele's interval; alt window replacement.rs:73-103
+        kind = "replacement"
+        end = start + len(ref)
+        allele = realign.replacement_allele(ref_seq, max(0, start - ref_window), min(start + len(ref) + ref_window, n), start, len(ref), alt)
+    reads = []
+    for r in recs:
+        if r.unmapped or r.flag & 0x900 or not overlaps(r, start, end):   # (secondary / supplementary records carry no evidence)
+            continue
+        reg = candidate_region(r, start, end, n, window)
+        if not reg.overlap:
+            continue
+        ro, re_ = reg.read_interval
+        if re_ - ro < 1:
+            continue
+        reads.append((r, r.seq[ro:re_].upper(), list(r.qual[ro:re_]), realign.ref_allele(ref_seq, *reg.ref_interval)))
+    return IndelCase(kind, start, end, len(alt) - len(ref), allele, reads)
+
+
+def pair_batch(case: IndelCase):
+    """(ref allele, read), (alt allele, read) per read, bands unset"""
+    from varlociraptor_amd.realign import PairBatch
+    pb = PairBatch()
+    for r, seq, qual, ref_allele in case.reads:
+        pb.add(ref_allele, seq, qual, -1)
+        pb.add(case.alt_allele, seq, qual, -1)
+    return pb
+
+
+def single_end_pileup(case: IndelCase, pa, pr):
+    """One observation per read from its normalised supports (ln P(read | alt), ln P(read | ref)): certain sampling, no
+    double-overlap term, uniform hit probability over the read, strand from the record — and a sample model without artifact
+    hypotheses (locus_flags 0), since strand / orientation / position features of a FRAGMENT need the mate logic this front end
+    does not have."""
+    import numpy as np
+    from varlociraptor_amd import abi
+    from varlociraptor_amd.batch import PileupBatch
+    recs = [r for r, _, _, _ in case.reads]
+    n = len(recs)
+    pa, pr = np.asarray(pa, float), np.asarray(pr, float)
+    strand = np.where(pa != pr, np.where([r.reverse for r in recs], abi.STRAND_REVERSE, abi.STRAND_FORWARD), abi.STRAND_NONE)
+    cols = {
+        "prob_mapping": [prob_mapping(r.mapq) for r in recs], "prob_alt": pa, "prob_ref": pr,
+        "prob_missed_allele": np.logaddexp(pa, pr) - math.log(2.0),                  # types/mod.rs:100-102
+        "prob_sample_alt": np.zeros(n), "prob_double_overlap": np.full(n, -np.inf),
+        "prob_hit_base": [-math.log(float(len(r.seq))) for r in recs],
+        "flags": abi.pack_flags(strand, np.full(n, abi.ORIENT_NONE), np.zeros(n, bool), np.zeros(n, bool), np.ones(n, bool),
+                                np.array([r.mapq == 60 for r in recs]), np.full(n, abi.ALTLOCUS_NONE)),
+    }
+    return PileupBatch(1, np.array([0, n], np.uint32), {k: np.asarray(v, np.float32) if k != "flags" else v for k, v in cols.items()},
+                       {"locus_flags": np.array([0], np.uint8), "variant_type": np.array([abi.VT_INDEL], np.uint8)})
+
+
+def phred_by_event(scenario, ln_posterior_row):
+    """{"PROB_<EVENT>": PHRED of the event's posterior} as the reference's testcase runner reads them from the INFO column"""
+    return {"PROB_" + name.upper(): -10.0 * float(ln_posterior_row[1 + k]) / math.log(10.0) for k, name in enumerate(scenario.event_names)}
+
+
+# the reference testcases held under tests/golden/bam/ (copied by tools/make_bam_fixtures.py): scenario file, contig of the ploidy
+# lookup, gap parameters of the sample (testcase.yaml: alignment properties where recorded, GapParams::default otherwise), the
+# variant type utils/collect_variants.rs gives the candidate, and the `expected:` block as a predicate over (MAP allele frequency,
+# PHRED posterior by event)
+BAM_CASES = {
+    "test_false_negative_indel_call": dict(        # tests/lib.rs:192; MN908947.3:517 TATG>T; `sample > 0.0`, `PROB_PRESENT <= 0.05`
+        scenario=("testcases", "test_false_negative_indel_call", "scenario.yaml"), contig=None,
+        gap=(-12.785891140783116, -12.186270018233994, -math.inf, -math.inf), kind="deletion", n_reads=342,
+        expected=lambda vaf, ph: vaf > 0.0 and ph["PROB_PRESENT"] <= 0.05 and 0.02 < vaf < 0.6),
+    "test_giab_04": dict(                           # lib.rs:105; 1:1201 GAAAAAAAAATACAG>GAAAAAAAATACAG; `NA12878 == 1.0`, `PROB_PRESENT <= 1.0`
+        scenario=("bam", "test_giab_04", "scenario.yaml"), contig="1", gap=None, kind="replacement", n_reads=40,
+        expected=lambda vaf, ph: vaf == 1.0 and ph["PROB_PRESENT"] <= 1.0),
+    "test_giab_05": dict(                           # lib.rs:107; 1:1001 CCA>CGCC; `NA12878 == 1.0`
+        scenario=("bam", "test_giab_05", "scenario.yaml"), contig="1", gap=None, kind="replacement", n_reads=129,
+        expected=lambda vaf, ph: vaf == 1.0),
+    "test_giab_06": dict(                           # lib.rs:109; 22:1200 G>GC; `index == 0.5`
+        scenario=("bam", "test_giab_06", "scenario.yaml"), contig="22", gap=None, kind="insertion", n_reads=117,
+        expected=lambda vaf, ph: vaf == 0.5),
+    "test_giab_11": dict(                           # lib.rs:114; 1:1198 CCCCTCCCTCCCTCCCA>CCCCTCCCTCCCTCCCTCCCA; `PROB_HET <= 0.05 || PROB_HOM <= 0.05`
+        scenario=("bam", "test_giab_11", "scenario.yaml"), contig="1", gap=None, kind="replacement", n_reads=232,
+        expected=lambda vaf, ph: ph["PROB_HET"] <= 0.05 or ph["PROB_HOM"] <= 0.05),
+    "test_giab_12": dict(                           # lib.rs:115; 1:1079 T>TCCT; `index == 0.5`
+        scenario=("bam", "test_giab_12", "scenario.yaml"), contig="1", gap=None, kind="insertion", n_reads=149,
+        expected=lambda vaf, ph: vaf == 0.5),
+    "test_giab_16": dict(                           # lib.rs:121; 1:1156 ATTTTTTTTTTATAGC>ATTTTTTTTTATAGC; `index != 0.0`
+        scenario=("bam", "test_giab_16", "scenario.yaml"), contig="1", gap=None, kind="replacement", n_reads=172,
+        expected=lambda vaf, ph: vaf != 0.0),
+}

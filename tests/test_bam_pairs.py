@@ -1,11 +1,12 @@
 """CPU checks of the test-side BAM front end (tests/bam_pairs.py) that feeds SURVEY §8 f1 with real (read window, allele window)
 pairs: the reader on the reference's own BAM fixtures, the projection of reference positions into reads, the candidate regions of
-realignment/mod.rs:58-153 — and, with the CPU restatement of the pair HMM in the kernels' place, the `expected:` block of
-`test_false_negative_indel_call` (the GPU twin is tests/test_gpu_realign_bam.py)."""
+realignment/mod.rs:58-153 — and, with the CPU restatement of the pair HMM in the kernels' place, the `expected:` blocks of
+the three testcases held under tests/golden/bam/ (the GPU twin is tests/test_gpu_realign_bam.py)."""
 import math
 import os
 
 import numpy as np
+import pytest
 
 import bam_pairs as bp
 from bam_pairs import BamRecord
@@ -60,37 +61,28 @@ def test_reader_on_the_reference_fixtures(golden_dir):
     assert len(recs) == 276 and contigs[5][0] == "chr6"
 
 
-def test_deletion_testcase_from_its_bam_with_the_restated_pair_hmm(oracle, golden_dir):
+@pytest.mark.parametrize("name", sorted(bp.BAM_CASES))
+def test_indel_testcase_from_its_bam_with_the_restated_pair_hmm(oracle, golden_dir, name):
     """The pipeline of tests/test_gpu_realign_bam.py with oracle/vlr_realign_oracle.cpp in the kernels' place: the pileup built from
-    the testcase's BAM satisfies its `expected:` block (`sample > 0.0`, `PROB_PRESENT <= 0.05`), which the observations recorded
-    before the fix do not (tests/test_oracle_fixture.py)."""
-    from varlociraptor_amd import abi, cli, realign
-    from varlociraptor_amd.batch import PileupBatch
-    from varlociraptor_amd.realign import GapParams, PairBatch
-    import test_gpu_realign_bam as T
-    name = "test_false_negative_indel_call"
-    reads, alt_allele, start, del_len = T._deletion_pairs(os.path.join(golden_dir, "bam", name))
-    assert len(reads) == 342
-    gap = GapParams(-12.785891140783116, -12.186270018233994, -math.inf, -math.inf)
-    pb = PairBatch()
-    for r, seq, qual, ref_allele in reads:
-        pb.add(ref_allele, seq, qual, -1)
-        pb.add(alt_allele, seq, qual, -1)
+    the testcase's BAM satisfies its `expected:` block — for `test_false_negative_indel_call` (`sample > 0.0`,
+    `PROB_PRESENT <= 0.05`) the observations recorded before the fix do not (tests/test_oracle_fixture.py)."""
+    from varlociraptor_amd import cli, realign
+    from varlociraptor_amd.realign import GapParams
+    spec = bp.BAM_CASES[name]
+    case = bp.indel_pairs(os.path.join(golden_dir, "bam", name))
+    assert case.kind == spec["kind"] and len(case.reads) == spec["n_reads"]
+    gap = GapParams(*spec["gap"]) if spec["gap"] else GapParams()
+    pb = bp.pair_batch(case)
     pb.band = [realign.best_hit(pb.y[k], pb.x[k])[0] + realign.EDIT_BAND for k in range(len(pb))]
     lnp = oracle.pairhmm_batch(pb, gap, threads=8)
-    n = len(reads)
+    n = len(case.reads)
     pa, pr = np.empty(n), np.empty(n)
     for k in range(n):
         pr[k], pa[k] = oracle.normalize_support(float(lnp[2 * k]), float(lnp[2 * k + 1]))
-    carried = np.array([any(op == "D" and l == del_len for op, l in r.cigar) for r, _, _, _ in reads])
-    assert carried.sum() == 40 and (pa[carried] > pr[carried]).all()
-    cols = {"prob_mapping": [bp.prob_mapping(r.mapq) for r, _, _, _ in reads], "prob_alt": pa, "prob_ref": pr,
-            "prob_missed_allele": np.logaddexp(pa, pr) - math.log(2.0), "prob_sample_alt": np.zeros(n),
-            "prob_double_overlap": np.full(n, -np.inf), "prob_hit_base": np.full(n, -math.log(150.0)),
-            "flags": abi.pack_flags(np.where([r.reverse for r, _, _, _ in reads], abi.STRAND_REVERSE, abi.STRAND_FORWARD), np.full(n, abi.ORIENT_NONE),
-                                    np.zeros(n, bool), np.zeros(n, bool), np.ones(n, bool), np.array([r.mapq == 60 for r, _, _, _ in reads]), np.full(n, abi.ALTLOCUS_NONE))}
-    batch = PileupBatch(1, np.array([0, n], np.uint32), {k: np.asarray(v, np.float32) if k != "flags" else v for k, v in cols.items()},
-                        {"locus_flags": np.array([0], np.uint8), "variant_type": np.array([abi.VT_INDEL], np.uint8)})
-    res = oracle.call(cli.scenario_from_yaml(os.path.join(golden_dir, "testcases", name, "scenario.yaml")), batch)
+    if name == "test_false_negative_indel_call":
+        carried = np.array([any(op == "D" and l == 3 for op, l in r.cigar) for r, _, _, _ in case.reads])
+        assert carried.sum() == 40 and (pa[carried] > pr[carried]).all()
+    sc = cli.scenario_from_yaml(os.path.join(golden_dir, *spec["scenario"]), **({"contig": spec["contig"]} if spec["contig"] else {}))
+    res = oracle.call(sc, bp.single_end_pileup(case, pa, pr))
     assert (res.status[0] & 0xF) == 0
-    assert float(res.map_vaf[0, 0]) > 0.0 and -10.0 * float(res.ln_posterior[0, 1]) / math.log(10.0) <= 0.05
+    assert spec["expected"](float(res.map_vaf[0, 0]), bp.phred_by_event(sc, res.ln_posterior[0]))

@@ -72,6 +72,11 @@ def test_allele_windows_follow_the_emission_types():
     assert realign.deletion_allele(ref, 2, 10, 3, 4) == b"AAGGGGTT"
     # insertion of TT after position 3 (types/insertion.rs:252-274): window grows by the insertion
     assert realign.insertion_allele(ref, 2, 10, 3, b"TT") == b"AATTCCCCGG"
+    # replacement of CCCC (4..8) by TG (types/replacement.rs:255-310): window shrinks by the length difference ...
+    assert realign.replacement_allele(ref, 2, 12, 4, 4, b"TG") == b"AATGGGGG"
+    # ... a replacement that shares its first base with the reference spells the deletion of the rest; one that is longer, the insertion
+    assert realign.replacement_allele(ref, 2, 12, 3, 5, b"A") == realign.deletion_allele(ref, 2, 8, 3, 4) == b"AAGGGG"
+    assert realign.replacement_allele(ref, 2, 10, 3, 1, b"ATT") == realign.insertion_allele(ref, 2, 10, 3, b"TT")
 
 
 def test_best_hit_is_the_semiglobal_edit_distance():

@@ -249,6 +249,25 @@ def insertion_allele(ref_seq: bytes, ref_offset: int, ref_end: int, ins_start: i
     return bytes(out)
 
 
+def replacement_allele(ref_seq: bytes, ref_offset: int, ref_end: int, repl_start: int, repl_ref_len: int, repl_seq: bytes) -> bytes:
+    """types/replacement.rs:255-310: the replacement sequence stands where the `repl_ref_len` reference bases from `repl_start` stood;
+    len_x = ref_end - ref_offset + alt_len - ref_len (the unaltered length when that comes out as zero)."""
+    alt_len = len(repl_seq)
+    alt_end = repl_start + alt_len
+    n = max(0, ref_end - ref_offset + alt_len - repl_ref_len) or (ref_end - ref_offset)
+    out = bytearray()
+    for i in range(n):
+        i_ = i + ref_offset
+        if i_ < repl_start:
+            out.append(ref_seq[i_])
+        elif i_ >= alt_end:
+            j = i_ - alt_len + repl_ref_len
+            out.append(ref_seq[j] if j < len(ref_seq) else ord("N"))
+        else:
+            out.append(repl_seq[i_ - repl_start])
+    return bytes(out)
+
+
 # ---- edit-distance pre-filter --------------------------------------------------------------------------------------
 
 def best_hit(read: bytes, allele: bytes) -> Optional[Tuple[int, int]]:
