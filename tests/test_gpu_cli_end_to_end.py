@@ -378,17 +378,9 @@ def test_bench_step_through_rccl_on_one_gpu(tmp_path):
     assert line["posterior_normalisation_max_err"] < 1e-9
 
 
-def test_cli_two_ranks_fail_together_when_one_shard_holds_a_breakend_event(golden_dir, tmp_path):
-    """the sharded front door refuses files with breakend events (they reach across shard boundaries,
-    calling.rs:569-580) — and only the rank whose shard holds such a record notices.  Every rank must hear of it before anybody waits
-    at the barrier: both ranks end with an error within seconds (not after the collective's timeout), no part of the calls file and
-    no calls file is left behind."""
-    import glob
-    import subprocess
-    import sys
-    import time
+def _flamegraph_with(tmp_path, golden_dir, edit):
+    """the observation file of the flamegraph testcase as BCF, `edit(k, fields)` applied to its k-th record"""
     from varlociraptor_amd.bcfio import BcfWriter
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     d = os.path.join(golden_dir, "flamegraph_profiling")
     header, recs = [], []
     k = 0
@@ -396,25 +388,76 @@ def test_cli_two_ranks_fail_together_when_one_shard_holds_a_breakend_event(golde
         if not l:
             continue
         if l.startswith("#"):
+            if l.startswith("#CHROM"):
+                header.append('##INFO=<ID=HETEROZYGOSITY,Number=A,Type=Float,Description="PHRED scaled expected heterozygosity">')
             header.append(l)
             continue
         f = l.split("\t")
-        if k in (9, 10):   # the event lives in the LAST records: the second rank's shard alone
-            f[7] = "EVENT=grp1;" + f[7]
+        edit(k, f)
         k += 1
         recs.append("\t".join(f))
-    obs = str(tmp_path / "grouped.bcf")
+    obs = str(tmp_path / "edited.bcf")
     with BcfWriter(obs, "\n".join(header)) as wr:
         for r in recs:
             wr.write_line(r)
+    return d, obs
+
+
+def _two_ranks(root, env, port, args, timeout=600):
+    import subprocess
+    import sys
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", str(port), "-m", "varlociraptor_amd"] + args, capture_output=True, text=True, cwd=root, env=env, timeout=timeout)
+
+
+@pytest.mark.parametrize("what", ["breakend event", "prior override"])
+def test_cli_two_ranks_take_records_that_reach_across_shards_on_the_unsharded_path(golden_dir, tmp_path, what):
+    """breakend events hand the FIRST record's result to the later ones and per-variant prior overrides are
+    installed from the first record of a contig (calling.rs:569-580, 643-713) — both reach across shard boundaries, and only the rank
+    whose shard holds such a record notices.  The ranks agree in the one collective before the barrier, drop their parts and take the
+    file again on the unsharded path: the calls file equals a single process's, no part file is left behind."""
+    import glob
+    import gzip
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def edit(k, f):
+        if what == "breakend event" and k in (9, 10):   # the event lives in the LAST records: the second rank's shard alone
+            f[7] = "EVENT=grp1;" + f[7]
+        if what == "prior override" and k == 0:          # the FIRST record of the contig: the first rank's shard alone
+            f[7] = "HETEROZYGOSITY=20.0;" + f[7]
+
+    d, obs = _flamegraph_with(tmp_path, golden_dir, edit)
+    one, two = tmp_path / "one.bcf", tmp_path / "two.bcf"
+    env = dict(os.environ, PYTHONPATH=root, VLR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    tail = ["generic", "--scenario", os.path.join(d, "scenario.yaml"), "--obs", "normal=" + obs]
+    subprocess.run([sys.executable, "-m", "varlociraptor_amd", "call", "variants", "--output", str(one)] + tail, check=True, cwd=root, env=env, timeout=600)
+    r = _two_ranks(root, env, 29549, ["call", "variants", "--output", str(two)] + tail)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "2 ranks read the whole file" in r.stderr
+    a, b = gzip.decompress(one.read_bytes()), gzip.decompress(two.read_bytes())
+    assert a == b and len(a) > 2000
+    assert sorted(glob.glob(str(two) + "*")) == [str(two)], glob.glob(str(tmp_path / "*"))
+
+
+def test_cli_two_ranks_fail_together_when_one_shard_is_corrupt(golden_dir, tmp_path):
+    """a rank that fails alone must not leave the others at the barrier until the collective's timeout.  A
+    flipped bit in the CRC32 trailer of the LAST data member of the observation file is seen by the second rank alone (its share of
+    the members); both ranks end with an error within seconds, no part of the calls file and no calls file is left behind."""
+    import glob
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d, obs = _flamegraph_with(tmp_path, golden_dir, lambda k, f: None)
+    raw = bytearray(open(obs, "rb").read())
+    assert raw[-28:-24] == bytes([0x1f, 0x8b, 8, 4])   # the empty end-of-file member (SAM spec 4.1.2)
+    raw[-28 - 8] ^= 0x10                                # CRC32 of the member before it
+    open(obs, "wb").write(bytes(raw))
     out = tmp_path / "calls.bcf"
     env = dict(os.environ, PYTHONPATH=root, VLR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     t0 = time.time()
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29549", "-m", "varlociraptor_amd", "call", "variants", "--output", str(out), "generic",
-                        "--scenario", os.path.join(d, "scenario.yaml"), "--obs", "normal=" + obs],
-                       capture_output=True, text=True, cwd=root, env=env, timeout=600)
+    r = _two_ranks(root, env, 29551, ["call", "variants", "--output", str(out), "generic", "--scenario", os.path.join(d, "scenario.yaml"), "--obs", "normal=" + obs])
     assert r.returncode != 0
-    assert "breakend events" in r.stderr
+    assert "CRC32 checksum mismatch" in r.stderr
     assert time.time() - t0 < 300, "the ranks waited for each other"
     assert not out.exists() and not glob.glob(str(out) + "*"), glob.glob(str(tmp_path / "*"))

@@ -223,9 +223,13 @@ def _part_path(output: str, rank: int) -> str:
     return "%s.part%d.bcf" % (output, rank)
 
 
+class _CrossesShards(Exception):
+    """a chunk of a sharded run holds records whose evaluation needs records of other shards"""
+
+
 def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_capacity: int = 128, out=sys.stdout,
                   device: int = 0, output: str = None, ingest: str = None, timings: dict = None,
-                  processor: "CallProcessor" = None, candidate_filter: "CandidateFilter" = None):
+                  processor: "CallProcessor" = None, candidate_filter: "CandidateFilter" = None, _allow_shards: bool = True):
     """`scenario`: a Scenario, or a callable contig -> Scenario (contig-specific universes / ploidies: one plan per
     distinct resolution, as the reference re-configures its model on contig change, calling.rs:343-356).
     `processor` / `candidate_filter`: the driver's two plug points (calling.rs:964-1020); with a processor no calls file is
@@ -430,7 +434,7 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
             # cross PCIe, the columns are born in device memory and the evaluation reads them there.  Files it does not read (plain
             # gzip, uncompressed BCF) go to the host reader.
             want_shards = (world > 1 and processor is None and candidate_filter is None and bool(output) and str(output).endswith(".bcf")
-                           and os.environ.get("VLR_INGEST_SHARDED", "1") != "0")
+                           and os.environ.get("VLR_INGEST_SHARDED", "1") != "0" and _allow_shards)
             try:
                 # records per request: 32 768, and 65 536 for inputs above a gigabyte (tools/cli_sweep.sh, 1 M records per step: 1.66 -> 1.75 M
                 # records/s; 131 072: 1.42 M — too few chunks for the three stages to overlap —, 16 384: 1.25 M)
@@ -534,8 +538,10 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                   grep_, gkey_ = np.asarray(batch.extra["group_representative"], np.int64), np.asarray(batch.extra["group_key"], np.uint64)
                   if shard_state["on"] and ((gkey_ != 0).any() or np.isfinite(np.asarray(het_, np.float64)).any() or np.isfinite(np.asarray(som_, np.float64)).any()):
                       # breakend events hand the FIRST record's result to the later ones, and per-variant prior overrides are installed from
-                      # the first record of a contig (calling.rs:569-580, 643-713): both reach across shard boundaries
-                      raise SystemExit("the sharded reader does not take files with breakend events or per-variant prior overrides: rerun with VLR_INGEST_SHARDED=0")
+                      # the first record of a contig (calling.rs:569-580, 643-713): both reach across shard boundaries.  This rank stops
+                      # here; after the collective below ALL ranks drop their parts and take the file again on the unsharded path
+                      # (every rank reads everything, results all-gathered), which carries both.
+                      raise _CrossesShards()
                   loci_ = np.arange(batch.n_loci)
                   ebatch = batch
                   if candidate_filter is not None:   # calling.rs:409: work items the filter rejects are not processed at all
@@ -595,9 +601,24 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
             # fails alone leaves the others at the barrier below until the RCCL timeout; a rank without records cannot know the contigs
             # and output names the other parts index).  Nothing is written unless every rank succeeded; parts are removed otherwise.
             import torch.distributed as tdist
-            mine_failed = bool(errors or loop_exc)
+            crosses = bool(loop_exc) and isinstance(loop_exc[0], _CrossesShards)
+            mine_failed = bool(errors or loop_exc) and not crosses
             info: List = [None] * world
-            tdist.all_gather_object(info, (mine_failed, list(names) if names else None, list(used_contigs)))
+            tdist.all_gather_object(info, (mine_failed, list(names) if names else None, list(used_contigs), crosses))
+            if any(i_[3] for i_ in info) and not any(i_[0] for i_ in info):
+                # records that reach across shard boundaries (seen by at least one rank): the whole file again, unsharded
+                if writer_state["w"] is not None:
+                    writer_state["w"].close()
+                try:
+                    os.remove(_part_path(output, rank))
+                except OSError:
+                    pass
+                if rank == 0:
+                    print("note: breakend events or per-variant prior overrides in the input: %d ranks read the whole file (results all-gathered) "
+                          "instead of a share each" % world, file=sys.stderr)
+                tdist.barrier()
+                return call_variants(scenario, obs_paths, omit_mask=omit_mask, afd_capacity=afd_capacity, out=out, device=device, output=output,
+                                     ingest=ingest, timings=timings, processor=processor, candidate_filter=candidate_filter, _allow_shards=False)
             if any(i_[0] for i_ in info):
                 if writer_state["w"] is not None:
                     try:
@@ -608,7 +629,7 @@ def call_variants(scenario, obs_paths: Dict[str, str], omit_mask: int = 0, afd_c
                     os.remove(_part_path(output, rank))
                 except OSError:
                     pass
-                if loop_exc:
+                if loop_exc and not crosses:
                     raise loop_exc[0]
                 if errors:
                     raise errors[0]
