@@ -435,7 +435,8 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
     *out = nullptr;
     const int S = d->n_samples;
     if (S < 1 || S > kMaxSamples) return fail(VLR_ERR_INVALID_ARGUMENT, "n_samples %d outside 1..%d", S, kMaxSamples);
-    if (d->n_events < 0 || d->n_events > kMaxNamedEvents) return fail(VLR_ERR_UNSUPPORTED, "n_events %d outside 0..%d", d->n_events, kMaxNamedEvents);
+    // (more than kMaxNamedEvents = 30 events: the wide build of the kernels, whose masks of event groups are 64 bits)
+    if (d->n_events < 0 || d->n_events > kMaxNamedEventsWide) return fail(VLR_ERR_UNSUPPORTED, "n_events %d outside 0..%d", d->n_events, kMaxNamedEventsWide);
     for (int s = 0; s < S; ++s) {
         if (!(d->resolution[s] > 0.0 && d->resolution[s] < 1.0)) return fail(VLR_ERR_INVALID_ARGUMENT, "resolution must be in (0,1) (grammar/mod.rs:477-481)");
         int by = d->contaminated_by[s];
@@ -542,7 +543,7 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
     if (max_range > kMaxRangeDepthWide) return fail(VLR_ERR_UNSUPPORTED, "more than %d nested VAF ranges on one path", kMaxRangeDepthWide);
     if (max_lfc > kMaxLfcWide) return fail(VLR_ERR_UNSUPPORTED, "more than %d l2fc terms on one path", kMaxLfcWide);
     // plans beyond the standard build's limits run the wide build of the kernels
-    const bool needs_wide = S > 8 || max_range > kMaxRangeDepthStd || max_lfc > kMaxLfcStd;
+    const bool needs_wide = S > 8 || max_range > kMaxRangeDepthStd || max_lfc > kMaxLfcStd || d->n_events > kMaxNamedEvents;
     if (max_frames > kMaxFrames) return fail(VLR_ERR_UNSUPPORTED, "VAF tree deeper than %d frames", kMaxFrames);
     P.max_range_depth = std::max(1, max_range);
     P.max_tab_depth = max_tab;
@@ -608,11 +609,13 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
             return false;
         };
         for (DevNode& n : nodes) {
-            n.alive_mask = 0;
+            n.alive_mask = 0; n.alive_mask_hi = 0;
             if (n.kind != VLR_NODE_SAMPLE) continue;
+            uint64_t am = 0;
             for (int g = 0; g <= d->n_events; ++g)
                 for (int k = gs_off[g * S + n.sample]; k < gs_off[g * S + n.sample + 1]; ++k)
-                    if (overlap(n.vafs, gs[k])) { n.alive_mask |= 1 << g; break; }
+                    if (overlap(n.vafs, gs[k])) { am |= 1ull << g; break; }
+            n.alive_mask = (int32_t)(uint32_t)am; n.alive_mask_hi = (int32_t)(uint32_t)(am >> 32);
         }
     }
     std::vector<double> table;
@@ -738,8 +741,10 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
                 if (!keys_ok) break;
                 L.prior_idx = idx;
                 L.posmask = q.posmask;
+                uint64_t cm = 0;
                 for (int g = 0; g <= d->n_events; ++g)
-                    if (g != own && group_contains(g, q.vaf)) L.cmask |= 1u << g;
+                    if (g != own && group_contains(g, q.vaf)) cm |= 1ull << g;
+                L.cmask = (uint32_t)cm; L.cmask_hi = (uint32_t)(cm >> 32);
                 dleaf.push_back(L);
             }
             if (!keys_ok) break;
@@ -767,7 +772,8 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
                 DevFastRoot f{};
                 int node = i == 0 ? P.absent_root : roots[i - 1];
                 uint32_t have = 0;
-                int alive = (int)((1u << (d->n_events + 1)) - 1u) & ~(1 << own);
+                uint64_t alive = ((1ull << (d->n_events + 1)) - 1ull) & ~(1ull << own);
+                auto node_alive = [](const DevNode& n) { return (uint64_t)(uint32_t)n.alive_mask | ((uint64_t)(uint32_t)n.alive_mask_hi << 32); };
                 int pidx = 0;
                 bool ok = true;
                 for (;;) {
@@ -779,7 +785,7 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
                         if (n.vafs.kind != VLR_SPECTRUM_RANGE || n.vafs.start == n.vafs.end) { ok = false; break; }
                         f.inner = n.sample; f.leaf_node = node;
                         f.start = n.vafs.start; f.end = n.vafs.end; f.lex = n.vafs.lex; f.rex = n.vafs.rex;
-                        f.alive = alive & n.alive_mask;
+                        f.alive = (int32_t)(uint32_t)(alive & node_alive(n)); f.alive_hi = (int32_t)(uint32_t)((alive & node_alive(n)) >> 32);
                         break;
                     }
                     if (n.n_children != 1 || !single || f.n_fixed >= kMaxSamples) { ok = false; break; }
@@ -788,9 +794,9 @@ int vlr_plan_create(const vlr_scenario_desc* d, int device, vlr_plan** out) {
                     f.disc |= 1 << n.sample;
                     pidx += prior_class(n.sample, v) * P.class_stride[n.sample];
                     // walk_root: f.sv_alive = c.alive & nd.alive_mask; c.alive = alive_update(sv_alive & nd.alive_mask, s, v)
-                    int m = alive & n.alive_mask, res = m;
+                    uint64_t m = alive & node_alive(n), res = m;
                     for (int g = 0; g <= d->n_events; ++g)
-                        if (((m >> g) & 1) && !may_contain(g, n.sample, v)) res &= ~(1 << g);
+                        if (((m >> g) & 1) && !may_contain(g, n.sample, v)) res &= ~(1ull << g);
                     alive = res;
                     node = child[n.child_off];
                 }

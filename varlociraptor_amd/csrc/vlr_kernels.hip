@@ -75,6 +75,26 @@ __device__ constexpr double kLn20 = 2.995732273553991;   // ln 20: KassRaftery::
 __device__ constexpr double kLn3 = 1.0986122886681098;   // ln 3: KassRaftery::Positive
 __device__ constexpr double kEps = 2.220446049250313e-16;
 
+// Masks of event groups (bit 0 = `absent`, bit 1 + e = named event e): one int in the standard build (kMaxNamedEvents = 30), 64 bits in
+// the wide build (kMaxNamedEventsWide = 62; the plan records carry the high word in their *_hi fields, vlr_plan.h).
+#ifdef VLR_WIDE_BUILD
+typedef long long alive_t;
+#define UNI_A(x) UNI64(x)
+#define ALIVE_BIT(g) ((long long)(1ull << (g)))
+#define ALIVE_FULL(n) ((long long)((1ull << (n)) - 1ull))
+#define ALIVE_OF(lo, hi) ((alive_t)(unsigned long long)(unsigned)(lo) | (alive_t)((unsigned long long)(unsigned)(hi) << 32))
+__device__ __forceinline__ int alive_ctz(alive_t m) { return __builtin_ctzll((unsigned long long)m); }
+#define NODE_ALIVE(nd) ALIVE_OF((nd).alive_mask, (nd).alive_mask_hi)
+#else
+typedef int alive_t;
+#define UNI_A(x) UNI(x)
+#define ALIVE_BIT(g) ((int)(1u << (g)))
+#define ALIVE_FULL(n) ((int)((1u << (n)) - 1u))
+#define ALIVE_OF(lo, hi) (lo)
+__device__ __forceinline__ int alive_ctz(alive_t m) { return __builtin_ctz(m); }
+#define NODE_ALIVE(nd) ((nd).alive_mask)
+#endif
+
 enum FrameKind { FK_BRANCH = 0, FK_SET = 1, FK_RANGE = 2 };
 enum RangePhase { RP_INIT = 0, RP_ROUND = 1, RP_TAIL = 2, RP_SIMPSON = 3 };
 
@@ -82,8 +102,15 @@ struct Frame {
     int kind, node, iter, n;
     double accM, accS;  // streaming ln-sum-exp
     int sv_present, sv_disc, sv_nlfc, sv_contained;
-    int slot, sv_alive;  // RANGE: index into rs[] / the visited-point tables; saved cross-event candidate mask
+    // slot: RANGE: index into rs[] / the visited-point tables; sv_alive: saved cross-event candidate mask
+#ifdef VLR_WIDE_BUILD
+    int slot, sv_mute;
+    alive_t sv_alive;
+#else
+    int slot;
+    alive_t sv_alive;
     int sv_mute, pad2;
+#endif
 };
 
 struct RangeSt {
@@ -99,13 +126,21 @@ constexpr int kPass = 3;        // points one lane carries through a pass over i
 
 struct ChainTask {              // one innermost Range chain (see run_chain_batch)
     double lo, hi, res, ostart, oend, fixed, result, bestJ, bestX;
-    int olex, orex, simpson_n, pidx, contained, alive, haveBest, n;
+#ifdef VLR_WIDE_BUILD
+    int olex, orex, simpson_n, pidx, contained, haveBest, n;
+    alive_t alive;
+#else
+    int olex, orex, simpson_n, pidx, contained;
+    alive_t alive;
+    int haveBest, n;
+#endif
     int u, group, disc, inner;  // deferred event-level chains: destination slot, event group, is_discrete mask, sample
 };
 
 struct BatchOuter {              // outer Range frame whose pending points are evaluated as row-parallel inner chains
     double lo, hi, res, fixed_const;
-    int simpson, dead, vary, np, c0, nt, chn, s_in, s_out, alive0;  // alive0: other groups that can contain ANY point of the outer range
+    int simpson, dead, vary, np, c0, nt, chn, s_in, s_out;
+    alive_t alive0;  // alive0: other groups that can contain ANY point of the outer range
 };
 struct WalkSave {                // walk_root state while the kernel's event loop runs a chain batch on its behalf
     double rv;
@@ -487,6 +522,12 @@ __device__ __forceinline__ DevNode ld_node(const DevNode* g) {
     n.vafs = ld_spec(&g->vafs);
     n.positive = ldc(&g->positive); n.refbase = ldc(&g->refbase); n.altbase = ldc(&g->altbase);
     n.child_off = ldc(&g->child_off); n.n_children = ldc(&g->n_children); n.alive_mask = ldc(&g->alive_mask);
+#ifdef VLR_WIDE_BUILD
+    n.alive_mask_hi = ldc(&g->alive_mask_hi);
+#else
+    n.alive_mask_hi = 0;
+#endif
+    n.pad = 0;
     return n;
 }
 
@@ -943,7 +984,7 @@ struct Ctx {
     int has_snv, refbase, altbase;
     // operands state (modes/generic.rs:116-121), wave-uniform
     int present, disc, nlfc, contained;
-    int alive;   // event groups (other than the current one) whose tree may still contain the current operands
+    alive_t alive;   // event groups (other than the current one) whose tree may still contain the current operands
     int group;   // group of the event being evaluated (0 absent, 1 + e)
     int n_slots;
     double* mapJ; double* mapVaf; int* mapHyp;  // best MAP candidate per slot (LDS)
@@ -1149,29 +1190,29 @@ __device__ inline bool group_may_contain(const DevPlan& p, int g, int s, double 
     return false;
 }
 // `alive` and s are wave-uniform (scalar loop over groups, scalar loads of the group spectra); v may differ per lane
-__device__ inline int alive_update(const Ctx& c, int alive, int s, double v) {
-    int m = UNI(alive);
+__device__ inline alive_t alive_update(const Ctx& c, alive_t alive, int s, double v) {
+    alive_t m = UNI_A(alive);
     s = UNI(s);
-    int res = m;
+    alive_t res = m;
     while (m) {
-        int g = __builtin_ctz(m);
+        int g = alive_ctz(m);
         m &= m - 1;
         const bool may = group_may_contain(*c.plan, g, s, v);
-        res = may ? res : (res & ~(1 << g));
+        res = may ? res : (res & ~ALIVE_BIT(g));
     }
     return res;
 }
 // groups among `alive` whose spectra for sample s can contain ANY point of [lo, hi] (closed, slightly widened: a tail
 // point of a chain may exceed the bracket by an ulp): a chain whose interval misses all spectra of the other groups
 // needs no per-point alive_update
-__device__ inline int alive_restrict(const Ctx& c, int alive, int s, double lo, double hi) {
+__device__ inline alive_t alive_restrict(const Ctx& c, alive_t alive, int s, double lo, double hi) {
     const DevPlan& p = *c.plan;
-    int m = UNI(alive);
+    alive_t m = UNI_A(alive);
     s = UNI(s);
     const double a = lo - 1e-9, b = hi + 1e-9;
-    int res = 0;
+    alive_t res = 0;
     while (m) {
-        const int g = __builtin_ctz(m);
+        const int g = alive_ctz(m);
         m &= m - 1;
         const int o0 = ldc(p.grp_spec_off + g * p.S + s), o1 = ldc(p.grp_spec_off + g * p.S + s + 1);
         bool hit = false;
@@ -1184,7 +1225,7 @@ __device__ inline int alive_restrict(const Ctx& c, int alive, int s, double lo, 
                 }
             } else hit = sp.start <= b && sp.end >= a;
         }
-        if (hit) res |= 1 << g;
+        if (hit) res |= ALIVE_BIT(g);
     }
     return res;
 }
@@ -1354,6 +1395,10 @@ __device__ inline double eval_discrete_root(Ctx& c, int l0, int l1) {
     const int TT = (l1 - l0 + 63) >> 6;  // leaves per lane (uniform)
     double jv[T];
     unsigned cm[T];
+#ifdef VLR_WIDE_BUILD
+    unsigned cmh[T];
+    unsigned gmh = 0;
+#endif
     bool ok[T];
     bool sawnan = false;
     unsigned gm = 0;
@@ -1363,6 +1408,9 @@ __device__ inline double eval_discrete_root(Ctx& c, int l0, int l1) {
     for (int t = 0; t < T; ++t) {
         const int l = l0 + lane + 64 * t;
         jv[t] = VLR_NEG_INF; cm[t] = 0; ok[t] = false;
+#ifdef VLR_WIDE_BUILD
+        cmh[t] = 0;
+#endif
         if (t < TT && l < l1) {
             const DevDLeaf& L = leaves[l];
             if ((L.posmask & cr) == 0) {
@@ -1373,6 +1421,9 @@ __device__ inline double eval_discrete_root(Ctx& c, int l0, int l1) {
                 else {
                     jv[t] = joint; cm[t] = L.cmask; ok[t] = true;
                     gm |= L.cmask;
+#ifdef VLR_WIDE_BUILD
+                    cmh[t] = L.cmask_hi; gmh |= L.cmask_hi;
+#endif
                     if (bL < 0 || joint > bJ || (joint == bJ && dleaf_tuple_before(leaves, l, bL, S))) { bJ = joint; bL = l; }
                 }
             }
@@ -1432,15 +1483,25 @@ __device__ inline double eval_discrete_root(Ctx& c, int l0, int l1) {
     }
     // other groups
     gm = (unsigned)wave_or((int)gm);
-    while (gm) {
-        const int g = __builtin_ctz(gm);
-        gm &= gm - 1;
+#ifdef VLR_WIDE_BUILD
+    alive_t gmm = ALIVE_OF(gm, wave_or((int)gmh));
+#else
+    alive_t gmm = (alive_t)gm;
+#endif
+    while (gmm) {
+        const int g = alive_ctz(gmm);
+        gmm &= gmm - 1;
         double gJ = VLR_NEG_INF;
         int gL = -1;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int l = l0 + lane + 64 * t;
-            if (t < TT && ok[t] && ((cm[t] >> g) & 1u)) {
+#ifdef VLR_WIDE_BUILD
+            const bool in_g = g < 32 ? ((cm[t] >> g) & 1u) != 0u : ((cmh[t] >> (g - 32)) & 1u) != 0u;
+#else
+            const bool in_g = ((cm[t] >> g) & 1u) != 0u;
+#endif
+            if (t < TT && ok[t] && in_g) {
                 if (gL < 0 || jv[t] > gJ || (jv[t] == gJ && dleaf_tuple_before(leaves, l, gL, S))) { gJ = jv[t]; gL = l; }
             }
         }
@@ -1582,12 +1643,12 @@ __device__ inline bool table_has(const double* tx, int n, double x, int lane) {
 }
 
 // all MAP bookkeeping for one evaluated operand set
-__device__ inline void map_all(Ctx& c, double joint, int inner, double x, bool own_path_contained, int alive) {
-    alive = UNI(alive);
+__device__ inline void map_all(Ctx& c, double joint, int inner, double x, bool own_path_contained, alive_t alive) {
+    alive = UNI_A(alive);
     if (own_path_contained) map_consider(c, joint, inner, x);
     else if (group_contains(c, c.group, inner, x)) map_consider(c, joint, inner, x);  // contained via another path
     while (alive) {
-        int g = __builtin_ctz(alive);
+        int g = alive_ctz(alive);
         alive &= alive - 1;
         if (group_contains(c, g, inner, x)) cross_consider(c, g, joint, inner, x);
     }
@@ -1737,7 +1798,7 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
     const int ncls = p.n_class[inner];
     const double pr0 = uni_d(ptab[pidx]), pr1 = ncls > 1 ? uni_d(ptab[pidx + istride]) : VLR_NEG_INF, pr2 = ncls > 2 ? uni_d(ptab[pidx + 2 * istride]) : VLR_NEG_INF;
 
-    const int alive_c = c.alive ? alive_restrict(c, c.alive, inner, lo, hi) : 0;  // other groups that can contain a point of this chain
+    const alive_t alive_c = c.alive ? alive_restrict(c, c.alive, inner, lo, hi) : 0;  // other groups that can contain a point of this chain
     // prior class of the integrated sample: if one Range spectrum of a uniform-prior universe covers [lo, hi], every
     // point of the chain is inside the universe (class 1, or 0 at exactly 0) — no per-point spectrum walk
     bool cls_fast = false;
@@ -1826,7 +1887,7 @@ __device__ __forceinline__ double run_leaf_chain(Ctx& c, RangeSt& rl, double* tx
 
         // MAP candidates (calling.rs:851-864)
         const bool own_in = c.contained && range_contains(orig, x);
-        const int al2 = alive_c ? alive_update(c, alive_c, inner, x) : 0;
+        const alive_t al2 = alive_c ? alive_update(c, alive_c, inner, x) : 0;
         const bool slow = __ballot(owner && (!own_in || al2 != 0)) != 0ull;
         (void)joint;
         if (c.replay) {
@@ -2962,20 +3023,20 @@ __device__ __forceinline__ void run_chain_batch(Ctx& c, int rowmask, int inner) 
 
 // MAP candidates of one finished row-parallel chain for OTHER groups / containment via another path (rare): the lanes
 // test all visited points at once; only points that need the full contains walk are visited one by one, in table order
-__device__ inline void scan_chain_candidates(Ctx& c, const double* rx, const double* rvv, int nq, const RangeV& io, int contained, int alive,
+__device__ inline void scan_chain_candidates(Ctx& c, const double* rx, const double* rvv, int nq, const RangeV& io, int contained, alive_t alive,
                                              int s_in) {
     for (int q0 = 0; q0 < nq; q0 += 64) {
         const int q = q0 + c.lane;
         const bool on = q < nq;
         const double xq = rx[on ? q : 0];
         const bool own = (contained != 0) & range_contains(io, xq);
-        const int al = alive ? alive_update(c, alive, s_in, xq) : 0;
+        const alive_t al = alive ? alive_update(c, alive, s_in, xq) : 0;
         unsigned long long need = __ballot(on & (!own | (al != 0)));
         while (need) {
             const int qq = q0 + __builtin_ctzll(need);
             need &= need - 1;
             const double xqq = uni_d(rx[qq]);
-            const int alq = alive ? UNI(alive_update(c, alive, s_in, xqq)) : 0;
+            const alive_t alq = alive ? UNI_A(alive_update(c, alive, s_in, xqq)) : 0;
             map_all(c, uni_d(rvv[qq]), s_in, xqq, false, alq);
         }
     }
@@ -3029,7 +3090,7 @@ __device__ inline void afd_emit_row(Ctx& c, int i, int s_in, int nq) {
 // The work is split in three steps around run_chain_batch, which the kernel's event loop runs on behalf of the
 // walk (bo_begin -> [bo_setup -> run_chain_batch -> bo_deliver]*): inlining the batch runner inside the walk kept
 // ~100 more VGPRs alive across it and made the compiler spill in its rounds.
-__device__ __forceinline__ void bo_begin(Ctx& c, RangeSt& r, int chn, int alive_in) {
+__device__ __forceinline__ void bo_begin(Ctx& c, RangeSt& r, int chn, alive_t alive_in) {
     PROF_ADD(c, 3);
     const DevPlan& p = *c.plan;
     WaveSt* w = c.w;
@@ -3053,7 +3114,7 @@ __device__ __forceinline__ void bo_begin(Ctx& c, RangeSt& r, int chn, int alive_
     }
     fixed_const = uni_d(fixed_const);
     // cross-event MAP candidates: groups whose spectra for the outer sample miss the whole outer range need no per-point test
-    const int alive0 = alive_restrict(c, alive_in, s_out, uni_d(r.lo), uni_d(r.hi));
+    const alive_t alive0 = alive_restrict(c, alive_in, s_out, uni_d(r.lo), uni_d(r.hi));
     VLR_SYNC();
     if (c.lane == 0) {
         BatchOuter& B = w->bo;
@@ -3086,7 +3147,7 @@ __device__ __forceinline__ bool bo_setup(Ctx& c, const Frame& f, RangeSt& r) {
         T.ostart = ch.vafs.start; T.oend = ch.vafs.end; T.olex = ch.vafs.lex; T.orex = ch.vafs.rex;
         T.simpson_n = B.simpson;
         T.contained = UNI(f.sv_contained) && range_contains(oorig, x);
-        T.alive = alive_update(c, UNI(B.alive0), s_out, x) & ch.alive_mask;  // (& the groups that can contain a VAF of the inner node)
+        T.alive = alive_update(c, UNI_A(B.alive0), s_out, x) & NODE_ALIVE(ch);  // (& the groups that can contain a VAF of the inner node)
         int pidx = 0;
         for (int s = 0; s < S; ++s) {
             double v = (s == s_out) ? x : w->ops_vaf[s];
@@ -3152,7 +3213,8 @@ __device__ __forceinline__ bool bo_deliver(Ctx& c, const Frame& f, RangeSt& r, d
     const int li = lane < nt ? lane : 0;
     const ChainTask& Tl = w->task[li];
     const double xl = r.pend[c0 + li], resl = Tl.result, bJl = Tl.bestJ, bXl = Tl.bestX;
-    const int hbl = Tl.haveBest, alivel = Tl.alive, contl = Tl.contained, nl = Tl.n;
+    const int hbl = Tl.haveBest, contl = Tl.contained, nl = Tl.n;
+    const alive_t alivel = Tl.alive;
     const int tn0 = UNI(r.tn);
     if (lane < nt) { txo[tn0 + c0 + lane] = xl; tvo[tn0 + c0 + lane] = dead ? VLR_NEG_INF : resl; }
     PROF_ADD(c, 25);  // delivery: fetch + outer table
@@ -3170,7 +3232,12 @@ __device__ __forceinline__ bool bo_deliver(Ctx& c, const Frame& f, RangeSt& r, d
         }
         if (hb & 1) map_consider(c, lane_d(bJl, i), s_in, lane_d(bXl, i));
         // rare: candidates for other groups / containment via another path (also of a visited excluded range end)
-        const int al_i = VLR_RDLANE(alivel, i), co_i = VLR_RDLANE(contl, i);
+#ifdef VLR_WIDE_BUILD
+        const alive_t al_i = ALIVE_OF(VLR_RDLANE((int)alivel, i), VLR_RDLANE((int)(alivel >> 32), i));
+#else
+        const alive_t al_i = VLR_RDLANE(alivel, i);
+#endif
+        const int co_i = VLR_RDLANE(contl, i);
         if (__builtin_expect(al_i != 0 || !co_i || (hb & 2), 0)) {
             const ChainTask& T = w->task[i];
             const RangeV io{uni_d(T.ostart), uni_d(T.oend), UNI(T.olex), UNI(T.orex)};
@@ -3209,7 +3276,7 @@ __device__ __forceinline__ void flush_deliver(Ctx& c, int rowmask, double* evM, 
         VLR_SYNC();
         if (c.lane < c.S) { w->ops_vaf[c.lane] = c.tvaf[i * c.S + c.lane]; w->curMapVaf[c.lane] = c.mapVaf[u * c.S + c.lane]; }
         VLR_SYNC();
-        c.group = UNI(T.group); c.disc = UNI(T.disc); c.contained = UNI(T.contained); c.alive = UNI(T.alive); c.nlfc = 0;
+        c.group = UNI(T.group); c.disc = UNI(T.disc); c.contained = UNI(T.contained); c.alive = UNI_A(T.alive); c.nlfc = 0;
         c.curJ = uni_d(c.mapJ[u]); c.curHyp = UNI(c.mapHyp[u]);
         const double dens = uni_d(T.result);
         TRC(c, 100, dens); TRC(c, 101, u); TRC(c, 102, i);
@@ -3286,7 +3353,7 @@ __device__ __forceinline__ int fast_chain_root(Ctx& c, const DevFastRoot* fr) {
     if (lane == 0) {
         ChainTask& T = w->task[row];
         T.lo = lo; T.hi = hi; T.res = res; T.ostart = vr.start; T.oend = vr.end; T.olex = vr.lex; T.orex = vr.rex;
-        T.simpson_n = simpson; T.fixed = fixed; T.pidx = ldc(&fr->pidx); T.contained = 1; T.alive = ldc(&fr->alive);
+        T.simpson_n = simpson; T.fixed = fixed; T.pidx = ldc(&fr->pidx); T.contained = 1; T.alive = ALIVE_OF(ldc(&fr->alive), ldc(&fr->alive_hi));
         T.result = VLR_NEG_INF; T.haveBest = 0; T.n = 0; T.bestJ = VLR_NEG_INF; T.bestX = 0.0;
         T.group = c.group; T.disc = ldc(&fr->disc); T.inner = inner; T.u = c.defer_slot;
     }
@@ -3322,7 +3389,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
         pc = PC_BO_POST;
     } else {
         c.present = 0; c.disc = 0; c.nlfc = 0; c.contained = 1; c.afd_mute = 0;
-        c.alive = (int)((1u << (p.n_named + 1)) - 1u) & ~(1 << c.group);  // n_named <= kMaxNamedEvents = 30: no shift reaches the sign bit
+        c.alive = ALIVE_FULL(p.n_named + 1) & ~ALIVE_BIT(c.group);  // n_named <= 30 (wide build: 62): no shift reaches the sign bit
     }
     for (;;) {
         if (pc == PC_DESCEND) {
@@ -3400,7 +3467,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                         f.sv_present = c.present; f.sv_disc = c.disc; f.sv_nlfc = c.nlfc; f.sv_contained = c.contained;
                         // every operand set below this frame takes sample s from this node: groups whose spectra for s miss the
                         // node's spectrum altogether (static, DevNode::alive_mask) cannot contain any of them
-                        f.sv_alive = c.alive & nd.alive_mask; f.sv_mute = c.afd_mute;
+                        f.sv_alive = c.alive & NODE_ALIVE(nd); f.sv_mute = c.afd_mute;
                     }
                     if (c.defer_ok && (as_set ? (ncand > 1) : (nd.n_children != 0))) {
                         c.deferred = 2;  // probe pass: not a single-chain root, evaluate in the second pass
@@ -3413,7 +3480,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                         c.present |= (1 << s);
                         c.disc |= (1 << s);
                         c.contained = UNI(f.sv_contained) && spectrum_contains(nd.vafs, p.vafs, w->ops_vaf[s]);
-                        c.alive = alive_update(c, UNI(f.sv_alive) & nd.alive_mask, s, w->ops_vaf[s]);
+                        c.alive = alive_update(c, UNI_A(f.sv_alive) & NODE_ALIVE(nd), s, w->ops_vaf[s]);
                         pc = PC_SUB;
                     } else if (nrange >= p.max_range_depth || nrange >= kMaxRangeDepth) {
                         c.status |= VLR_LOCUS_TABLE_FULL; rv = __builtin_nan(""); pc = PC_RETURN;
@@ -3478,7 +3545,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
             if (UNI(r.tn) + (UNI(r.npend) - UNI(f.iter)) > c.cap) {  // room for the points of this round still to be recorded
                 c.status |= VLR_LOCUS_TABLE_FULL;
                 rv = __builtin_nan("");
-                c.present = UNI(f.sv_present); c.disc = UNI(f.sv_disc); c.nlfc = UNI(f.sv_nlfc); c.contained = UNI(f.sv_contained); c.alive = UNI(f.sv_alive); c.afd_mute = UNI(f.sv_mute);
+                c.present = UNI(f.sv_present); c.disc = UNI(f.sv_disc); c.nlfc = UNI(f.sv_nlfc); c.contained = UNI(f.sv_contained); c.alive = UNI_A(f.sv_alive); c.afd_mute = UNI(f.sv_mute);
                 sp--; nrange--;
                 pc = PC_RETURN;
             } else if (UNI(r.leaf)) {
@@ -3486,7 +3553,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                 c.present = UNI(f.sv_present) | (1 << UNI(r.sample));
                 c.nlfc = UNI(f.sv_nlfc);
                 c.contained = UNI(f.sv_contained);
-                c.alive = UNI(f.sv_alive);
+                c.alive = UNI_A(f.sv_alive);
                 if (c.defer_ok && (c.cap > 64 || c.nlfc != 0 || (c.ndef > 0 && UNI(w->task[0].inner) != UNI(r.sample)))) {
                     c.deferred = 2;
                     return 0.0;
@@ -3518,7 +3585,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                     return 0.0;
                 }
                 rv = run_leaf_chain(c, r, c.rowX, c.rowV);
-                c.present = UNI(f.sv_present); c.disc = UNI(f.sv_disc); c.nlfc = UNI(f.sv_nlfc); c.contained = UNI(f.sv_contained); c.alive = UNI(f.sv_alive); c.afd_mute = UNI(f.sv_mute);
+                c.present = UNI(f.sv_present); c.disc = UNI(f.sv_disc); c.nlfc = UNI(f.sv_nlfc); c.contained = UNI(f.sv_contained); c.alive = UNI_A(f.sv_alive); c.afd_mute = UNI(f.sv_mute);
                 sp--; nrange--;
                 pc = PC_RETURN;
             } else if (c.cap <= 64 && UNI(f.iter) == 0 && UNI(f.sv_nlfc) == 0 && UNI(f.n) >= 0) {
@@ -3530,7 +3597,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                 // just rewind the point counters (no other outer frame can run between the rounds of this one: its children
                 // are leaf chains)
                 PROF_ADD(c, 29);  // outer: round issue
-                if (UNI(r.tn) == 0) { bo_begin(c, r, UNI(f.n), UNI(f.sv_alive)); PROF_ADD(c, 30); }
+                if (UNI(r.tn) == 0) { bo_begin(c, r, UNI(f.n), UNI_A(f.sv_alive)); PROF_ADD(c, 30); }
                 else {
                     VLR_SYNC();
                     if (c.lane == 0) { BatchOuter& B = w->bo; B.np = r.npend; B.c0 = 0; B.nt = 0; }
@@ -3546,7 +3613,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                 c.nlfc = UNI(f.sv_nlfc);
                 RangeV orig{r.ostart, r.oend, r.olex, r.orex};
                 c.contained = UNI(f.sv_contained) && range_contains(orig, x);
-                c.alive = alive_update(c, UNI(f.sv_alive), UNI(r.sample), x);
+                c.alive = alive_update(c, UNI_A(f.sv_alive), UNI(r.sample), x);
                 if (c.replay) c.afd_mute = UNI(f.sv_mute) || table_has(tx, UNI(r.tn), x, c.lane);
                 VLR_SYNC();
                 if (c.lane == 0) w->ops_vaf[UNI(r.sample)] = x;
@@ -3582,7 +3649,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                 else {
                     rv = range_finish(c, r, tx, tv);
                     PROF_ADD(c, 28);  // outer: range_finish
-                    c.present = UNI(f.sv_present); c.disc = UNI(f.sv_disc); c.nlfc = UNI(f.sv_nlfc); c.contained = UNI(f.sv_contained); c.alive = UNI(f.sv_alive); c.afd_mute = UNI(f.sv_mute);
+                    c.present = UNI(f.sv_present); c.disc = UNI(f.sv_disc); c.nlfc = UNI(f.sv_nlfc); c.contained = UNI(f.sv_contained); c.alive = UNI_A(f.sv_alive); c.afd_mute = UNI(f.sv_mute);
                     sp--; nrange--;
                     pc = PC_RETURN;
                 }
@@ -3609,7 +3676,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                     if (!done) { pc = PC_RANGE_ISSUE; }
                     else {
                         rv = range_finish(c, r, tx, tv);
-                        c.present = UNI(f.sv_present); c.disc = UNI(f.sv_disc); c.nlfc = UNI(f.sv_nlfc); c.contained = UNI(f.sv_contained); c.alive = UNI(f.sv_alive); c.afd_mute = UNI(f.sv_mute);
+                        c.present = UNI(f.sv_present); c.disc = UNI(f.sv_disc); c.nlfc = UNI(f.sv_nlfc); c.contained = UNI(f.sv_contained); c.alive = UNI_A(f.sv_alive); c.afd_mute = UNI(f.sv_mute);
                         sp--; nrange--;
                         pc = PC_RETURN;
                     }
@@ -3621,7 +3688,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                 VLR_SYNC();
                 if (c.lane == 0) { f.accM = M; f.accS = S; f.iter = it; }
                 VLR_SYNC();
-                c.present = UNI(f.sv_present); c.disc = UNI(f.sv_disc); c.nlfc = UNI(f.sv_nlfc); c.contained = UNI(f.sv_contained); c.alive = UNI(f.sv_alive); c.afd_mute = UNI(f.sv_mute);
+                c.present = UNI(f.sv_present); c.disc = UNI(f.sv_disc); c.nlfc = UNI(f.sv_nlfc); c.contained = UNI(f.sv_contained); c.alive = UNI_A(f.sv_alive); c.afd_mute = UNI(f.sv_mute);
                 if (it < UNI(f.n)) {
                     const int fnode = UNI(f.node);
                     const DevNode nd = ld_node(p.nodes + fnode);
@@ -3633,7 +3700,7 @@ __device__ __forceinline__ double walk_root(Ctx& c, int root, int resume) {
                         c.present |= (1 << s);
                         c.disc |= (1 << s);
                         c.contained = UNI(f.sv_contained) && spectrum_contains(nd.vafs, p.vafs, w->ops_vaf[s]);
-                        c.alive = alive_update(c, UNI(f.sv_alive), s, w->ops_vaf[s]);
+                        c.alive = alive_update(c, UNI_A(f.sv_alive), s, w->ops_vaf[s]);
                         node = fnode;
                         pc = PC_SUB;
                     } else {
@@ -4584,7 +4651,8 @@ __global__ void __launch_bounds__(64, WPE) VLR_DBG_VGPR_ATTR vlr_call_kernel(con
                         if (piggy) {
                             // the walk is suspended with the MAP candidate of ITS slot and its operands in the context: park them
                             // in the slot arrays, hand the held chains to their events, and take the context back
-                            const int sg = c.group, sd = c.disc, sc = c.contained, sa = c.alive, sn = c.nlfc;
+                            const int sg = c.group, sd = c.disc, sc = c.contained, sn = c.nlfc;
+                            const alive_t sa = c.alive;
                             const double so = w->ops_vaf[lane < S ? lane : 0];
                             VLR_SYNC();
                             if (lane == 0) { mapJ[u] = c.curJ; mapHyp[u] = c.curHyp; }
@@ -4620,14 +4688,24 @@ __global__ void __launch_bounds__(64, WPE) VLR_DBG_VGPR_ATTR vlr_call_kernel(con
     // the value of event slot u (M + ln S of its streaming sum) once, on lane u (n_univ <= 2 kMaxNamedEvents + 1 = 61): the loops
     // below used to take the same logarithm four times per slot on all lanes
     VLR_SYNC();
+#ifdef VLR_WIDE_BUILD
+    // wide build: up to 2 x 62 + 1 = 125 slots, more than one per lane: the values go through the LDS (evS[u] becomes the slot's value)
+    for (int u = lane; u < p.n_univ; u += 64) evS[u] = lse_value(evM[u], evS[u]);
+    VLR_SYNC();
+#define EV_M(u) evM[u]
+#define EV_V(u) evS[u]
+#else
     const int u_l = lane < p.n_univ ? lane : 0;
     const double evM_l = evM[u_l];
     const double evV_l = lse_value(evM_l, evS[u_l]);
     TRC(c, 110, evM_l); TRC(c, 111, evV_l); TRC(c, 112, evS[u_l]);
+#define EV_M(u) lane_d(evM_l, u)
+#define EV_V(u) lane_d(evV_l, u)
+#endif
     double mM = VLR_NEG_INF, mS = 0.0;
     for (int u = 0; u < p.n_univ; ++u) {
-        const double m_u = lane_d(evM_l, u);
-        double v = (m_u != m_u) ? m_u : lane_d(evV_l, u);
+        const double m_u = EV_M(u);
+        double v = (m_u != m_u) ? m_u : EV_V(u);
         lse_add(mM, mS, v);
     }
     double marginal = (mM != mM) ? mM : lse_value(mM, mS);
@@ -4641,7 +4719,7 @@ __global__ void __launch_bounds__(64, WPE) VLR_DBG_VGPR_ATTR vlr_call_kernel(con
     for (int u = 0; u < p.n_univ; ++u) {
         bool twin = (u > 0) && ((u & 1) == 0);
         if (twin && !have_twins) continue;
-        double v = lane_d(evV_l, u);
+        double v = EV_V(u);
         double post = v - marginal;
         if (u == 0 || !(post < best_post)) { best = u; best_post = post; }  // last maximum wins (itertools minmax)
         if (twin) lse_add(aM, aS, post);
@@ -4651,15 +4729,22 @@ __global__ void __launch_bounds__(64, WPE) VLR_DBG_VGPR_ATTR vlr_call_kernel(con
     for (int u = 0; u < p.n_univ; ++u) {
         bool twin = (u > 0) && ((u & 1) == 0);
         if (twin) continue;
-        double post = lane_d(evV_l, u) - marginal;
+        double post = EV_V(u) - marginal;
         if (!(post < prob_artifact)) is_artifact = false;
     }
     double* lp = out.ln_posterior + locus * n_out;
     {   // posterior of `absent` (slot 0) and of the clean named events (slots 1 + 2 e), each written by the lane that holds the slot's value:
         // no lane read inside the `lane == 0` region below (a lane read of lanes that are off there — round 6, EXEC assert build)
+#ifdef VLR_WIDE_BUILD
+        for (int u = lane; u < p.n_univ; u += 64)
+            if (u == 0 || (u & 1)) lp[u == 0 ? 0 : 1 + (u >> 1)] = evS[u] - marginal;
+#else
         const double post_l = evV_l - marginal;
         if (lane < p.n_univ && (lane == 0 || (lane & 1))) lp[lane == 0 ? 0 : 1 + (lane >> 1)] = post_l;
+#endif
     }
+#undef EV_M
+#undef EV_V
     if (lane == 0) {
         lp[n_out - 1] = prob_artifact;
         if (out.ln_marginal) out.ln_marginal[locus] = marginal;

@@ -30,6 +30,8 @@ constexpr int kTableCapMax = 1024;    // upper limit of the per-plan table capac
                                       // resolution 1e-40 needs 971); whether the tables of a plan fit the LDS is checked at plan creation
 constexpr int kMaxSet = 1024;         // members of one Set spectrum (LDS: 8 B x samples x the plan's largest set; the reference has no limit)
 constexpr int kMaxNamedEvents = 30;   // scenario events (engine universe = 1 + 2*named); 1 + named event groups fit the 31 value bits of the int32 alive masks
+constexpr int kMaxNamedEventsWide = 62;  // ... of the wide build, whose masks of event groups are 64 bits (low word | the *_hi word of the plan records);
+                                         // the reference has no limit (grammar/mod.rs:129-190)
 constexpr int kNHyp = 9;              // 0 = Artifacts::none(), 1..8 single-artifact combinations
 constexpr int kRows = 4;             // concurrent innermost chains per wave of the call kernel: one per 16-lane DPP row
 constexpr int kLdsWg16 = 163840 / 16;  // LDS bytes of a workgroup (static + dynamic) up to which SIXTEEN workgroups share a CU (tools/budget_probe.py:
@@ -63,6 +65,8 @@ struct DevNode {
     int32_t alive_mask;  // Sample nodes: event groups (bit 0 = absent, 1 + e = event e) with a spectrum for this sample that overlaps
                          // this node's spectrum at all (closed intervals, 1e-9 slack) — no other group can `contain` an operand set
                          // that takes this sample's VAF from here; lets the walk drop cross-event MAP candidates early
+    int32_t alive_mask_hi;  // groups 32..62 (read by the wide build only)
+    int32_t pad;
 };
 
 // All-discrete roots (every node a Sample node with a Set or single-valued spectrum, e.g. the pedigree scenarios and
@@ -73,7 +77,7 @@ struct DevDLeaf {
     uint32_t posmask;           // samples whose node on this path holds only VAFs > 0 (dead under clear_ref, generic.rs:270-291)
     uint32_t cmask;             // other event groups whose VAF tree contains these operands (vaftree.rs:42-51)
     uint8_t key[kMaxSamples];   // per sample: index of its (VAF, contaminant VAF) pair in DevPlan::dkey
-    int32_t pad;
+    uint32_t cmask_hi;          // groups 32..62 (read by the wide build only)
 };
 struct DevDKey { int32_t sample, pad; double a, b; };
 
@@ -92,7 +96,8 @@ struct DevFastRoot {
     int32_t alive;                 // other event groups that can still contain the operands at the leaf (static: walk_root's c.alive)
     int32_t disc;                  // is_discrete mask of the fixed samples
     int32_t pidx;                  // prior-table index of the fixed samples' classes (the integrated sample adds its own)
-    int32_t lex, rex, pad;         // the leaf's range
+    int32_t lex, rex;              // the leaf's range
+    int32_t alive_hi;              // groups 32..62 of `alive` (read by the wide build only)
     double start, end;
     int32_t fsample[kMaxSamples];
     double fvaf[kMaxSamples];
