@@ -145,7 +145,8 @@ typedef struct {
     int32_t is_absent_only;                /* !--full-prior (calling.rs:1086)                          */
     /* event universe of the scenario, WITHOUT `absent` and without artifact twins
      * (both are added by the engine exactly like calling.rs:654-687); events must be given
-     * in ascending name order (BTreeMap order of grammar/mod.rs:137).                                 */
+     * in ascending name order (BTreeMap order of grammar/mod.rs:137).  At most 62 (more than 30: the
+     * wide build of the kernels; VLR_ERR_UNSUPPORTED above).                                          */
     int32_t n_events;
     const char* const* event_names;
     const int32_t* event_root_offset;      /* [n_events+1] into root_index[]                           */

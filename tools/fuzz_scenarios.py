@@ -47,11 +47,12 @@ def random_scenario(rng):
         return " & ".join(parts)
 
     events = {}
-    for e in range(int(rng.integers(2, 5))):
+    # FUZZ_MANY_EVENTS=1: 33..48 events (masks of event groups beyond one word: the wide build of the kernels)
+    for e in range(int(rng.integers(33, 49)) if os.environ.get("FUZZ_MANY_EVENTS") == "1" else int(rng.integers(2, 5))):
         f = conj()
         if rng.random() < 0.3:
             f = "(%s) | (%s)" % (f, conj())
-        events["ev%d" % e] = f
+        events[("ev%02d" if os.environ.get("FUZZ_MANY_EVENTS") == "1" else "ev%d") % e] = f
     return Scenario(samples, events), names
 
 
@@ -142,7 +143,7 @@ def main(argv=None):
             print("plan rejected:", ex, sc.events)
             LAST_STATS["plans_rejected"] += 1
             continue
-        afd_cap = 256 if os.environ.get("FUZZ_AFD") == "1" else 0
+        afd_cap = int(os.environ.get("FUZZ_AFD_CAP") or 256) if os.environ.get("FUZZ_AFD") == "1" else 0
         got = plan.call_host(b, afd_capacity=afd_cap)
         plan.close()
         ref = oracle.call(sc, b, afd_capacity=afd_cap, want_events=True)
