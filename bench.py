@@ -409,7 +409,10 @@ def bench_cli(args, rank, world, local_rank, dev):
         "process_cpu": {"cpu_seconds_per_step": cpu_s / args.steps, "busy_cpus": cpu_s / elapsed, "effective_cpus": effective_cpus(),
                         "note": "user + system time of this process over the timed steps / wall time: how much of the CPU quota the pipeline uses"},
         "native_stage_note": "inside read_s: inflate and parse_decode are summed over the sample files (which run side by side), files_wall is their wall time, merge + strings build the table; inside write_s: encode = record formatting, deflate_write = BGZF + file",
-        "files": {"observation_bcf_bytes": obs_bytes, "calls_bcf_bytes": calls_bytes, "observations": int(n_obs), "observation_write_s_untimed": t_write_obs},
+        "files": {"observation_bcf_bytes": obs_bytes, "calls_bcf_bytes": calls_bytes, "observations": int(n_obs), "observation_write_s_untimed": t_write_obs,
+                  # the asymmetry between what is read and what is written: inputs deflated like htslib's default,
+                  # calls at level 1 (written once, read once; VLR_BGZF_LEVEL selects another level)
+                  "observation_bgzf_level": 6, "calls_bgzf_level": int(os.environ.get("VLR_BGZF_LEVEL") or 1)},
         "roofline": None, "cpu_baseline": None, "build_id": engine.build_id(),
     }
 

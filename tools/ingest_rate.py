@@ -28,7 +28,7 @@ for rep in range(3):
     t = ingest.total_timings()
     if dev is not None:
         d = ingest.device_timings()
-        print("device reader: %d records in %.3f s = %.0f records/s; " % (k, dt, k / dt) + ", ".join("%s %.3f" % (a, d[a]) for a in ("feed_inflate", "split_scan", "decode", "copy_back", "host_table", "total")) +
+        print("device reader: %d records in %.3f s = %.0f records/s; " % (k, dt, k / dt) + ", ".join("%s %.3f" % (a, d[a]) for a in ("feed_inflate", "split_scan", "decode", "copy_back", "host_table", "inflate_kernel", "decode_wait", "total")) +
               "; %.2f GB inflated from %.2f GB, %d serial walks" % (d["inflated_bytes"] / 1e9, d["compressed_bytes"] / 1e9, d["serial_walks"]))
         continue
     print("%d records in %.3f s = %.0f records/s; inflate %.3f (summed over files) files_wall %.3f merge %.3f" % (k, dt, k / dt, t["inflate"], t["files_wall"], t["merge"]))

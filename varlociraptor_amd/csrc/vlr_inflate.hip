@@ -36,7 +36,16 @@
 namespace vlr {
 namespace {
 
-constexpr int kLitBits = 10, kDistBits = 9, kClBits = 7;
+#ifndef VLR_INFL_LIT_BITS   // (sweep builds: tools/inflate_sweep.sh)
+#define VLR_INFL_LIT_BITS 10
+#endif
+#ifndef VLR_INFL_DIST_BITS
+#define VLR_INFL_DIST_BITS 9
+#endif
+#ifndef VLR_INFL_RING
+#define VLR_INFL_RING 4096
+#endif
+constexpr int kLitBits = VLR_INFL_LIT_BITS, kDistBits = VLR_INFL_DIST_BITS, kClBits = 7;
 constexpr bool kInflateBatchDefault = true;   // speculative batches (VLR_INFLATE_BATCH=0: one symbol at a time, the cross-check)
 // a corrupt stream is noticed at the next position check (every 8.7 KiB of output at most = 16.3 KiB of input at 15 bits per symbol):
 // the compressed bytes handed to the kernel must be readable this far beyond the last member (vlr_gpuio.h kInflateInputSlack)
@@ -46,7 +55,7 @@ constexpr bool kInflateBatchDefault = true;   // speculative batches (VLR_INFLAT
 // microseconds ago by this wave).  11 kB of LDS per wave instead of 39: fourteen members per CU instead of four, which is what a
 // decoder bound by the issue rate and latencies of ONE wave needs.  Everything below kRing - (kFlush + 512 + 2 x 258) behind the
 // position is in HBM when a far match asks for it: kRing >= kFlush + 1286.
-constexpr uint32_t kRing = 4096, kRingMask = kRing - 1, kFlush = 1024;   // flushed to HBM in 1 KiB pieces, each before the ring wraps onto it
+constexpr uint32_t kRing = VLR_INFL_RING, kRingMask = kRing - 1, kFlush = 1024;   // flushed to HBM in 1 KiB pieces, each before the ring wraps onto it
 static_assert(kRing >= kFlush + 1286, "far matches read flushed bytes only");
 
 struct InflLds {

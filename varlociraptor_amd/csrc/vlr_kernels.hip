@@ -3939,6 +3939,7 @@ __global__ void __launch_bounds__(64) vlr_afd_kernel(const DevPlan plan_arg, Dev
 #else
 #define VLR_DBG_VGPR_ATTR
 #endif
+constexpr int kGridQuantum = kXcds;   // the launchers round the grid up to a multiple of this (XCD-aware locus mapping below)
 template <int WPE>
 __global__ void __launch_bounds__(64, WPE) VLR_DBG_VGPR_ATTR vlr_call_kernel(const DevPlan plan_arg, DevBatch batch, DevResults out,
                                                            int max_obs, int range_depth) {
@@ -3946,7 +3947,21 @@ __global__ void __launch_bounds__(64, WPE) VLR_DBG_VGPR_ATTR vlr_call_kernel(con
     __shared__ WaveSt wst;
     const DevPlan& p = plan_arg;
     const int lane = threadIdx.x;
+    // XCD-aware mapping: consecutive workgroup ids go round the eight XCDs (each with its own L2), so workgroup w takes locus
+    // (w mod 8) * ceil(n / 8) + w / 8 — every XCD works through ONE contiguous eighth of the batch, and the loci whose column
+    // slices share cache lines at their ends (4 B x ~100 observations per column and pileup: three to four 128 B lines, two of them
+    // shared with the neighbours) meet in the same L2 at about the same time instead of being filled into two L2s.  Measured on
+    // config 3 (profiles/r06g.md): L2 fills + write-backs 12.49 -> 10.00 GB per million loci (1.55 -> 1.24 x the algorithmic bytes) for
+    // + 0.4 % kernel time; plans with more than two samples lose 1.6 - 2.8 % (configs 4, 5) and keep w -> w.  Tiled variants (8 to
+    // 1024 consecutive loci per XCD in turn) were slower than both.  VLR_NO_XCD_MAP: the A/B build.
+    // (The grid is rounded up to a multiple of eight: kXcds * ceil(n / 8) ids cover 0 .. n - 1 exactly once.)
+#ifdef VLR_NO_XCD_MAP
     const int64_t locus = blockIdx.x;
+#else
+    const int64_t locus = plan_arg.S <= kXcdMapMaxSamples
+                              ? (int64_t)(blockIdx.x % kXcds) * ((batch.n_loci + kXcds - 1) / kXcds) + (int64_t)(blockIdx.x / kXcds)
+                              : (int64_t)blockIdx.x;
+#endif
     if (locus >= batch.n_loci) return;   // (plans above kLdsSamples samples: the host launches the wide build)
     if (VLR_DEEP && !(out.status[locus] & VLR_LOCUS_TOO_DEEP)) return;  // deep launch: only what the LDS-resident kernel could not hold
     // replay launch next to an AFD log: only the loci whose log region overflowed are re-evaluated
@@ -3959,7 +3974,7 @@ __global__ void __launch_bounds__(64, WPE) VLR_DBG_VGPR_ATTR vlr_call_kernel(con
     const int cap = p.table_cap;
     c.cap = cap;
     c.coef = dyn;
-    c.ecoef = out.escratch + (size_t)blockIdx.x * (size_t)(max_obs + 2 * p.S) + 2 * p.S;  // (the first 2 S words of the row: ones_ptr)
+    c.ecoef = out.escratch + (size_t)locus * (size_t)(max_obs + 2 * p.S) + 2 * p.S;  // (the first 2 S words of the row: ones_ptr)
     c.tabX = dyn + 2 * max_obs;
     c.tabV = c.tabX + p.max_tab_depth * cap;
     c.rowX = c.tabV + p.max_tab_depth * cap;
@@ -4932,7 +4947,7 @@ extern "C" int VLR_FN_DEEP(const vlr::DevPlan* plan_host, const vlr::DevBatch* b
     size_t bytes = dbl * sizeof(double);
     hipError_t e = hipFuncSetAttribute((const void*)vlr_call_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(vlr_call_kernel<2>, dim3((unsigned)batch->n_loci), dim3(64), bytes, (hipStream_t)stream, *plan_host, *batch, *out, 0, range_depth);
+    hipLaunchKernelGGL(vlr_call_kernel<2>, dim3((unsigned)(((batch->n_loci + kGridQuantum - 1) / kGridQuantum) * kGridQuantum)), dim3(64), bytes, (hipStream_t)stream, *plan_host, *batch, *out, 0, range_depth);
     return (int)hipGetLastError();
 }
 #else
@@ -5009,7 +5024,7 @@ extern "C" int VLR_FN_CALL(const vlr::DevPlan* plan_host, const vlr::DevBatch* b
     if (n_samples == 1 && 163840 / lds_wg >= 20) wpe = 6;
     if (const char* ev = getenv("VLR_WAVES_PER_SIMD")) wpe = atoi(ev);  // tuning / build-matrix knob (tests/test_gpu_build_matrix.py)
     if (getenv("VLR_DEBUG_LAUNCH")) fprintf(stderr, "vlr launch: max_obs %d static %zu dynamic %zu -> %zu B, %d waves/SIMD\n", max_obs, static_lds, bytes, static_lds + bytes, wpe);
-    dim3 grid((unsigned)batch->n_loci), block(64);
+    dim3 grid((unsigned)(((batch->n_loci + kGridQuantum - 1) / kGridQuantum) * kGridQuantum)), block(64);   // (a multiple of eight: the kernel's XCD-aware mapping)
 #define VLR_LAUNCH(W)                                                                                                        \
     case W: {                                                                                                                \
         hipError_t e = hipFuncSetAttribute((const void*)vlr_call_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \

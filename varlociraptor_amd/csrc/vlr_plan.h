@@ -33,6 +33,8 @@ constexpr int kMaxNamedEvents = 30;   // scenario events (engine universe = 1 + 
 constexpr int kMaxNamedEventsWide = 62;  // ... of the wide build, whose masks of event groups are 64 bits (low word | the *_hi word of the plan records);
                                          // the reference has no limit (grammar/mod.rs:129-190)
 constexpr int kNHyp = 9;              // 0 = Artifacts::none(), 1..8 single-artifact combinations
+constexpr int kXcds = 8;             // XCDs of the MI355X, each with its own L2: consecutive workgroup ids go round them (call kernel: XCD-aware locus mapping)
+constexpr int kXcdMapMaxSamples = 2;  // ... for plans of up to this many samples (measured: profiles/r06g.md)
 constexpr int kRows = 4;             // concurrent innermost chains per wave of the call kernel: one per 16-lane DPP row
 constexpr int kLdsWg16 = 163840 / 16;  // LDS bytes of a workgroup (static + dynamic) up to which SIXTEEN workgroups share a CU (tools/budget_probe.py:
                                        // 10 192 B fit, 10 256 B do not — the host rounds the pileup budget up to a multiple of four observations)
