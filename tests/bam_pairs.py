@@ -319,6 +319,17 @@ BAM_CASES = {
     "test_giab_12": dict(                           # lib.rs:115; 1:1079 T>TCCT; `index == 0.5`
         scenario=("bam", "test_giab_12", "scenario.yaml"), contig="1", gap=None, kind="insertion", n_reads=149,
         expected=lambda vaf, ph: vaf == 0.5),
+    "test_nanopore_05": dict(                       # lib.rs:169 testcase!(test_nanopore_05, homopolymer); chr1:111 T>TT in a T run, 26 reads of
+        # ~224 bases; `PROB_GERMLINE_HET < 1.0 || PROB_GERMLINE_HOM < 1.0`; gap and homopolymer-run parameters of the sample's alignment properties
+        scenario=("bam", "test_nanopore_05", "scenario.yaml"), contig="chr1", kind="insertion", n_reads=26,
+        gap=(-4.320603998501797, -3.4073426177904595, -0.4111023053215838, -0.3729407271973288),
+        hop=([-2.4241876197016907, -2.0631363999353076, -2.075720902621972, -2.4607220391071825],
+             [-1.1525743935495203, -0.7538486971814485, -0.7904797474537245, -1.1450692553725095],
+             [-4.74532040606337, -4.029387645256212, -3.963866371464708, -5.121149314030805],
+             [-2.524995685227039, -3.137290211542217, -3.0427733560338037, -2.6016763482417575]),
+        # in this mode the reads that spell the shorter run are explained by a homopolymer-run error of the read: the call is homozygous
+        # (with the exact pair HMM on the same windows: heterozygous — tests/test_bam_pairs.py holds both)
+        expected=lambda vaf, ph: (ph["PROB_GERMLINE_HET"] < 1.0 or ph["PROB_GERMLINE_HOM"] < 1.0) and vaf == 1.0),
     "test_giab_16": dict(                           # lib.rs:121; 1:1156 ATTTTTTTTTTATAGC>ATTTTTTTTTATAGC; `index != 0.0`
         scenario=("bam", "test_giab_16", "scenario.yaml"), contig="1", gap=None, kind="replacement", n_reads=172,
         expected=lambda vaf, ph: vaf != 0.0),
