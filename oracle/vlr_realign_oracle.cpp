@@ -295,13 +295,22 @@ double vlro_pathhmm_fixed_traceback(const uint8_t* x, int len_x, const uint8_t* 
 //            1 - extend, from a hop state of base b' with 1 - hop_extend(b'), from the free start with 1 - (gap_x + gap_y);
 //   GapX     emits y_j alone (gap in x, an insertion artifact): from any match with gap_x, from itself with gap_x_extend;
 //   GapY     emits x_i alone: from any match with gap_y, from itself with gap_y_extend;
-//   HopX_b   emits y_j alone and only if y_j == b (the read repeats the homopolymer base once more): from Match_b with
+//   HopX_b   emits y_j alone, like a matching base, and only if y_j == b (the read repeats the homopolymer base once more): from Match_b with
 //            hop_x(b), from itself with hop_x_extend(b);
 //   HopY_b   emits x_i alone and only if x_i == b: from Match_b with hop_y(b), from itself with hop_y_extend(b);
 // hops are entered from match states only and left to match states only; emissions, free start / end gaps in x, the column
 // sums, the cap at ln 1 and the edit-distance band are those of prob_related above.  With the default HopParams (all zero) the
 // model IS the three-state pair HMM: vlro_homopoly_prob_related == vlro_pairhmm_prob_related (tests/test_realign_oracle.py).
 // Which base labels a MISMATCH pair's match state (x_i here) is the one convention that cannot be checked against the crate.
+// The emission of the hop states is a second one.  Until round 6 HopX emitted its read base like an inserted base (prob_emit_y =
+// P(miscall)); the per-read observations RECORDED in the reference's test_nanopore_05 (single-end, every base quality 255 =
+// P(miscall) 10^-25.5) refute that: a read with one T more than the allele's run is recorded at ln P(ref) - ln P(alt) = -1.149 —
+// exactly one hop probability (-1.145) and no miscall factor, where that emission costs 58 nats.  HopX now emits the repeated
+// base like a MATCHING base (1 - P(miscall), what prob_emit_xy gives for equal bases), HopY nothing (prob_emit_x = 1).  The same
+// file also shows that it was written by an earlier version (format 13; the hop probability it charges for a longer read run
+// is prob_ref_homopolymer where estimation/alignment_properties.rs:937-952 of this tree makes it prob_seq_homopolymer, and reads
+// without a run-length change are not reproduced under either reading): it cannot pin the recursion, it only decides this one
+// convention (tools/recorded_hop_compare.py, profiles/r06g_experiments.md section 5).
 //   hop[16] = ln {hop_x[A,C,G,T], hop_y[A,C,G,T], hop_x_extend[A,C,G,T], hop_y_extend[A,C,G,T]}
 double vlro_homopoly_prob_related(const uint8_t* x, int len_x, const uint8_t* y, const uint8_t* qual, int len_y, const double* gap,
                                   const double* hop, int max_edit_dist) {
@@ -374,7 +383,7 @@ double vlro_homopoly_prob_related(const uint8_t* x, int len_x, const uint8_t* y,
                 c[S_GX] = any_miscall[j] + ln_sum_exp(in);
             }
             if (bx < 4) c[S_HY + bx] = ln_add_exp(left[S_M + bx] + hy[bx], left[S_HY + bx] + hye[bx]);                    // x_i == b alone
-            if (by < 4) c[S_HX + by] = any_miscall[j] + ln_add_exp(top[S_M + by] + hx[by], top[S_HX + by] + hxe[by]);     // y_j == b alone
+            if (by < 4) c[S_HX + by] = no_miscall[j] + ln_add_exp(top[S_M + by] + hx[by], top[S_HX + by] + hxe[by]);      // y_j == b alone, emitted like a matching base
             if (max_edit_dist >= 0) {
                 auto inc = [BIG](unsigned e) { return e == BIG ? BIG : e + 1; };
                 med[curr][j_] = std::min(is_match ? e_tl : inc(e_tl), std::min(inc(e_top), inc(e_left)));

@@ -225,7 +225,7 @@ def _brute_homopoly(x, y, q, gap, hop):
         if st in ("M", "GY") and i < len(x):   # x_i alone (prob_emit_x = 1)
             rec(i + 1, j, "GY", -1, p * (gy if st == "M" else gye))
         if st in ("M", "HX") and b >= 0 and j < len(y) and idx(y[j]) == b:
-            rec(i, j + 1, "HX", b, p * (hx[b] if st == "M" else hxe[b]) * mis[j])
+            rec(i, j + 1, "HX", b, p * (hx[b] if st == "M" else hxe[b]) * (1 - mis[j]))   # the repeated base is emitted like a matching base
         if st in ("M", "HY") and b >= 0 and i < len(x) and idx(x[i]) == b:
             rec(i + 1, j, "HY", b, p * (hy[b] if st == "M" else hye[b]))
     for start in range(len(x)):

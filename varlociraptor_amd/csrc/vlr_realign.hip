@@ -341,7 +341,8 @@ __global__ void __launch_bounds__(64) vlr_realign_kernel2(RealignArgs a) {
 // ---- `homopolymer` realignment mode --------------------------------------------------------------------------------------
 // HomopolyPairHMMRealigner::calculate_prob_allele (realignment/mod.rs:680-730): bio's HomopolyPairHMM::prob_related with the
 // reference's HopParams (pairhmm.rs:207-295) — the pair HMM above plus, per base, hop states that emit one more copy of the
-// homopolymer base in the read (HopX_b: y_j == b alone) or in the allele (HopY_b: x_i == b alone), entered from the match state of
+// homopolymer base in the read (HopX_b: y_j == b alone, emitted like a matching base — oracle/vlr_realign_oracle.cpp says on which
+// evidence) or in the allele (HopY_b: x_i == b alone), entered from the match state of
 // the same base and left to a match state only.  Restated in oracle/vlr_realign_oracle.cpp (vlro_homopoly_prob_related, PARITY
 // UNPINNED: the recursion lives in the un-vendored crate bio) with all fourteen states spelled out; here the model is folded:
 // the match state of a cell is the one of its allele base x_i, so of the four HopX_b / HopY_b / Match_b at most one each is
@@ -461,7 +462,7 @@ __global__ void __launch_bounds__(64) vlr_homopoly_kernel(HomopolyArgs h) {
             const double x = a.pgy * M1[r] + a.pgye * X1[r];
             const double y = e_ins[r] * (a.pgx * Mu[r] + a.pgxe * Yu[r]);
             const double pp = (xb == xp && i > 0) ? chy[r] * M1[r] + chye[r] * P1[r] : 0.0;           // x_i == x_{i-1} alone
-            const double qq = is_match ? e_ins[r] * (chx[r] * Mu[r] + chxe[r] * Qu[r]) : 0.0;          // y_j == x_i alone
+            const double qq = is_match ? e_match[r] * (chx[r] * Mu[r] + chxe[r] * Qu[r]) : 0.0;        // y_j == x_i alone, emitted like a matching base
             bool live = incol;
             unsigned e = kBig;
             if (banded) {
