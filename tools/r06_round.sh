@@ -1,7 +1,7 @@
 # one GPU-box call for the round's profile note (round 6): kernel rates, the GPU suite, tools/profile_round.sh (bench lines of every
 # workload incl. the front door, kernel traces, PMC passes, calibrated HBM traffic) and the VALU stamp of the call kernel
 # (tools/valu_stamp.py -> gpurun_out/valu_config3.json: valu_busy / f64_share of bench.py's roofline object)
-T=${1:-r06d}
+T=${1:-r06h}
 mkdir -p gpurun_out/$T
 python tools/rate_variant.py 2>&1 | grep config | tee gpurun_out/$T/rates.txt
 python -m pytest tests -m gpu -q > gpurun_out/$T/pytest.txt 2>&1; tail -3 gpurun_out/$T/pytest.txt
