@@ -3,7 +3,7 @@
 # lists, prior scenarios, many events (wide build).  One summary line per (mode, seed) -> gpurun_out/fuzz_soak.txt
 cd "$(dirname "$0")/.."
 O=gpurun_out/fuzz_soak.txt; : > $O
-run() { tag=$1; shift; env "$@" python tools/fuzz_scenarios.py fuzz $N $SEED 2>&1 | tail -1 | sed "s/^/$tag seed $SEED: /" | tee -a $O; }
+run() { tag=$1; shift; env "$@" python tools/fuzz_scenarios.py $N $SEED 2>&1 | tail -1 | sed "s/^/$tag seed $SEED: /" | tee -a $O; }
 for SEED in 11 12 13 14 15 16; do N=60 run plain FUZZ_X=0; done
 for SEED in 21 22 23 24; do N=60 run afd FUZZ_AFD=1; done
 for SEED in 31 32 33; do N=40 run prior FUZZ_PRIOR=1; done
