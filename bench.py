@@ -616,12 +616,17 @@ def main():
         r_plain = CallResults(batch.n_loci, plan.n_out, plan.n_samples, 0, alloc=engine.host_array)
         r_afd = CallResults(batch.n_loci, plan.n_out, plan.n_samples, args.afd_capacity, alloc=engine.host_array)
         plan.call_host(pb, results=r_plain)
-        t0 = time.perf_counter(); plan.call_host(pb, results=r_plain); t_plain = time.perf_counter() - t0
+        t0 = time.perf_counter(); plan.call_host(pb, results=r_plain); t_plain_locked = time.perf_counter() - t0
+        # ... and into ordinary arrays: a third faster on the boxes of round 6 (tools/pcie_probe.py: the result copies into page-locked
+        # memory are DMA transfers that queue up with the uploads of the next chunk; into pageable memory the runtime stages them)
+        plan.call_host(pb)
+        t0 = time.perf_counter(); plan.call_host(pb); t_plain = time.perf_counter() - t0
         plan.call_host(pb, afd_capacity=args.afd_capacity, results=r_afd)
         t0 = time.perf_counter(); plan.call_host(pb, afd_capacity=args.afd_capacity, results=r_afd); t_afd = time.perf_counter() - t0
         del pb, r_plain, r_afd
-        pcie = {"value": batch.n_loci / t_plain, "with_afd": batch.n_loci / t_afd, "unit": "loci/s",
-                "note": "vlr_batch_run_host: host arrays (page-locked) in, results (and AFD lists of %d entries) out, one call each" % args.afd_capacity}
+        pcie = {"value": batch.n_loci / t_plain, "page_locked_results": batch.n_loci / t_plain_locked, "with_afd": batch.n_loci / t_afd, "unit": "loci/s",
+                "note": "vlr_batch_run_host: host arrays (page-locked) in, results out, one call each; value: results into ordinary arrays, "
+                        "page_locked_results / with_afd (AFD lists of %d entries): results into page-locked arrays" % args.afd_capacity}
         try:
             a2 = types.SimpleNamespace(**vars(args))
             # the whole of BASELINE configs[2] (1 M records) per step since round 5: a run of the CLI has 0.07 s of fixed costs (opening and
