@@ -35,7 +35,7 @@
 // operations reach the realigner.  (b) The candidates.vcf of test_uzuner_clonal_1..3, test_uzuner_fp_snv_on_ins and
 // test_false_negative_indel_call hold the observations recorded at the reporter's site BEFORE the fix each testcase documents —
 // the testcase's own `expected:` block is false on them (tests/test_oracle_fixture.py pins that) and the reference's test
-// recomputes them from sample.bam.  What those testcases DO hold for f1 is the BAM and the expectation: tests/bam_pairs.py cuts the
+// recomputes them from sample.bam.  What those testcases DO hold for f1 is the BAM and the expectation: varlociraptor_amd/readwindows.py (through tests/bam_pairs.py) cuts the
 // reference's candidate regions (realignment/mod.rs:58-153) from the records of test_false_negative_indel_call, this restatement
 // (tests/test_bam_pairs.py) and the GPU kernels (tests/test_gpu_realign_bam.py, equal to 1e-9 in ln P on those 684 real pairs)
 // turn them into supports, and the call meets the testcase's `sample > 0.0`, `PROB_PRESENT <= 0.05`: every read whose alignment

@@ -97,3 +97,25 @@ def test_indel_testcase_from_its_bam_with_the_restated_pair_hmm(oracle, golden_d
             pr[k], pa[k] = oracle.normalize_support(float(lnp[2 * k]), float(lnp[2 * k + 1]))
         res = oracle.call(sc, bp.single_end_pileup(case, pa, pr))
         assert float(res.map_vaf[0, 0]) == 0.5
+
+
+def test_product_front_end_classifies_candidates_and_refuses_what_is_not_realigned():
+    """varlociraptor_amd/readwindows.py (the package's own BAM front end, which tests/bam_pairs.py wraps): candidate classes of
+    utils/collect_variants.rs:274-300, loci of the three types, and SNVs / MNVs refused (they are scored base by base)."""
+    from varlociraptor_amd import readwindows as rw
+    ref = b"ACGTACGTTTTTACGATCGATCGGCTAGCTAGGATCGATTACA" * 8
+    p = 100
+    d = rw.indel_locus(ref, p, ref[p:p + 4], ref[p:p + 1])
+    assert (d.kind, d.start, d.end, d.len_diff) == ("deletion", p, p + 3, -3) and len(d.alt_allele) == 192
+    i = rw.indel_locus(ref, p, ref[p:p + 1], ref[p:p + 1] + b"GG")
+    assert (i.kind, i.start, i.end, i.len_diff) == ("insertion", p, p + 1, 2) and len(i.alt_allele) == 196   # (insertion.rs:92-113: the window grows by the insertion on both counts)
+    r = rw.indel_locus(ref, p, ref[p:p + 5], ref[p:p + 1] + b"TT" + ref[p + 4:p + 5])
+    assert (r.kind, r.start, r.end, r.len_diff) == ("replacement", p, p + 5, -1)
+    with pytest.raises(ValueError):
+        rw.indel_locus(ref, p, ref[p:p + 1], b"N" if ref[p:p + 1] != b"N" else b"A")
+    with pytest.raises(ValueError):
+        rw.indel_locus(ref, p, b"NNNN", b"N")
+    rec = _rec(p - 60, [("M", 150)])
+    (got,) = rw.evidence_windows([rec], ref, d)
+    assert got[0] is rec and len(got[1]) == len(got[2]) <= rw.MAX_PATTERN_LEN and len(got[3]) == 192
+    assert rw.evidence_windows([_rec(p + 40, [("M", 50)])], ref, d) == []

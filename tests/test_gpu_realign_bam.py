@@ -8,7 +8,7 @@ RECORDED in its candidates.vcf predate the fix the testcase documents (tests/tes
 P(present) 0.465 — the reported false negative); the reference's test recomputes them from sample.bam with the fixed code.  So does
 this test, with the engine's kernels in the place of `bio::stats::pairhmm`:
 
-  BAM records -> candidate regions (tests/bam_pairs.py: realignment/mod.rs:58-153) -> (allele window, read window) pairs
+  BAM records -> candidate regions (varlociraptor_amd/readwindows.py: realignment/mod.rs:58-153) -> (allele window, read window) pairs
   -> vlr_edit_distance_batch (band) + vlr_realign_batch (pair HMM, gap parameters of the testcase's alignment properties)
   -> normalisation (mod.rs:359-385) -> one observation per read -> vlr_batch_run -> MAP allele frequency and PROB_PRESENT.
 
@@ -45,27 +45,22 @@ def test_indel_testcase_from_its_bam_meets_the_reference_expectation(oracle, gol
     case = bp.indel_pairs(os.path.join(golden_dir, "bam", name), WINDOW)
     assert case.kind == spec["kind"] and len(case.reads) == spec["n_reads"]
     gap = GapParams(*spec["gap"]) if spec["gap"] else GapParams()
-    # ---- pairs: (ref allele, read), (alt allele, read) per read; band = best hit's edit distance + EDIT_BAND (pairhmm.rs:20)
-    pb = bp.pair_batch(case)
-    dist, _, _ = realign.best_hits(pb)
+    # ---- the product path: readwindows.allele_supports = edit-distance kernel (band = best hit + EDIT_BAND, pairhmm.rs:20) -> pair-HMM
+    # kernel (homopolymer mode where the testcase has run parameters) -> normalisation (mod.rs:359-385), one observation per read
+    from varlociraptor_amd import readwindows
+    hop = realign.HopParams(*spec["hop"]) if spec.get("hop") else None
+    pa, pr, pb = readwindows.allele_supports(case.reads, case.alt_allele, gap, hop)
     host_dist = [realign.best_hit(pb.y[k], pb.x[k])[0] for k in range(0, len(pb), 7)]
-    assert [int(dist[k]) for k in range(0, len(pb), 7)] == host_dist          # the edit-distance kernel on real windows
-    pb.band = [int(x) + realign.EDIT_BAND if x >= 0 else -1 for x in dist]
-    if spec.get("hop"):   # `homopolymer` mode: vlr_realign_homopolymer_batch against the restated HomopolyPairHMM
-        hop = realign.HopParams(*spec["hop"])
-        lnp = realign.prob_related_homopolymer(pb, gap, hop)
-        ref_lnp = oracle.homopoly_batch(pb, gap, hop)
-    else:
-        lnp = realign.prob_related(pb, gap)
-        ref_lnp = oracle.pairhmm_batch(pb, gap, threads=8)
+    assert [pb.band[k] - realign.EDIT_BAND for k in range(0, len(pb), 7)] == host_dist          # the edit-distance kernel on real windows
+    # ---- and the same pairs through the CPU restatement: parity of the kernels on REAL windows
+    lnp = realign.prob_related_homopolymer(pb, gap, hop) if hop is not None else realign.prob_related(pb, gap)
+    ref_lnp = oracle.homopoly_batch(pb, gap, hop) if hop is not None else oracle.pairhmm_batch(pb, gap, threads=8)
     both_inf = np.isneginf(lnp) & np.isneginf(ref_lnp)
     dev = np.where(both_inf, 0.0, np.abs(lnp - ref_lnp))
     assert np.all(dev <= 1e-9 * np.maximum(1.0, np.abs(ref_lnp) * 1e-3)), float(np.nanmax(dev))   # pair HMM: kernel == restatement
-    # ---- one observation per read (single-end evidence)
     n = len(case.reads)
-    pa, pr = np.empty(n), np.empty(n)
-    for k in range(n):
-        pr[k], pa[k] = realign.normalize_support(float(lnp[2 * k]), float(lnp[2 * k + 1]))
+    for k in range(0, n, 5):
+        assert (pr[k], pa[k]) == realign.normalize_support(float(lnp[2 * k]), float(lnp[2 * k + 1]))
     # reads whose alignment carries an indel of the variant's length at the locus support the alt allele, reads aligned through the
     # locus without any indel the reference
     op, ln = ("D", -case.len_diff) if case.len_diff < 0 else ("I", case.len_diff)
