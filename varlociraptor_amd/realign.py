@@ -12,8 +12,8 @@
 In reference v8.9.3 `shrink_to_hit` (pairhmm.rs:66-72) only moves the `ref_offset()/ref_end()` accessors; `ref_base` and
 `len_x` of every emission type use the unshrunken fields, so the HMM always sees the whole reference window
 (2 x 1.5 x realignment_window around the breakpoint, mod.rs:149-153) — the band is what bounds the work.
-Not mirrored (documented in DESIGN.md): candidate_region / CIGAR projection (needs BAM records), multiple loci per variant,
-the read-inferred "third allele" (mod.rs:311-349).
+candidate_region / CIGAR projection and the per-read supports from BAM records: varlociraptor_amd/readwindows.py.
+Not mirrored (documented in DESIGN.md): multiple loci per variant, the read-inferred "third allele" (mod.rs:311-349).
 """
 from __future__ import annotations
 
